@@ -1,0 +1,144 @@
+"""Deterministic synthetic bags and weights (SURVEY.md §8(d) "Synthetic inputs").
+
+A counter-based generator (splitmix64 -> uniform / Box-Muller normal) written in
+numpy, so this container, the oracle, the tests and the GPU box all regenerate
+bit-identical tensors from (seed, shape) without depending on torch's RNG
+streams (which differ between CPU and GPU and between torch versions).
+
+Nothing here is on the hot path: bench.py uses it once to fill HBM before the
+timed region.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """One splitmix64 output per 64-bit counter value (vectorised, wraps mod 2^64)."""
+    with np.errstate(over="ignore"):
+        z = (x + _GOLDEN).astype(np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _stream(seed: int, n: int, lane: int = 0) -> np.ndarray:
+    """n 64-bit words of stream (seed, lane)."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64) * _GOLDEN
+                           + np.uint64(lane))[0]
+        ctr = np.arange(n, dtype=np.uint64) * _GOLDEN + base
+    return _splitmix64(ctr)
+
+
+def uniform(seed: int, shape, lo: float = 0.0, hi: float = 1.0, lane: int = 0) -> np.ndarray:
+    """float64 uniform in [lo, hi) from the top 53 bits of each word."""
+    n = int(np.prod(shape)) if len(tuple(shape)) else 1
+    u = (_stream(seed, n, lane) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return (lo + (hi - lo) * u).reshape(shape)
+
+
+def normal(seed: int, shape, std: float = 1.0, lane: int = 0) -> np.ndarray:
+    """float64 N(0, std^2) by Box-Muller on two independent lanes."""
+    n = int(np.prod(shape)) if len(tuple(shape)) else 1
+    u1 = uniform(seed, (n,), lane=2 * lane + 101)
+    u2 = uniform(seed, (n,), lane=2 * lane + 102)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))          # 1-u1 in (0,1]
+    z = r * np.cos(2.0 * math.pi * u2)
+    return (std * z).reshape(shape)
+
+
+def permutation(seed: int, n: int, lane: int = 0) -> np.ndarray:
+    """A permutation of range(n) (stable argsort of 64-bit words: no ties in practice)."""
+    return np.argsort(_stream(seed, n, lane + 7777), kind="stable").astype(np.int64)
+
+
+def bag(seed: int, n: int, d: int) -> np.ndarray:
+    """One synthetic bag X[n, d] fp32: |N(0,1)|, i.e. non-negative post-ReLU-like patch features."""
+    return np.abs(normal(seed, (n, d))).astype(np.float32)
+
+
+def _xavier_normal(seed: int, out_f: int, in_f: int, lane: int) -> np.ndarray:
+    std = math.sqrt(2.0 / float(in_f + out_f))
+    return normal(seed, (out_f, in_f), std=std, lane=lane).astype(np.float32)
+
+
+def mhim_state(seed: int, input_dim: int = 1024, mlp_dim: int = 512, n_classes: int = 2,
+               baseline: str = "attn", merge_enable: bool = True, merge_k: int = 5,
+               gated: bool = False, scorer_dim: int = 128) -> dict:
+    """A state dict (numpy fp32) with the reference's parameter names and init law.
+
+    Key names: SURVEY.md §8(b) (measured from the reference's state_dict()).
+    Init law: xavier-normal Linear weights, zero Linear biases, LayerNorm 1/0
+    (reference modules/mhim_modules/utils.py:8-22), global_q_mm ~ U(+-sqrt(6/(768+E)))
+    (merge.py:108-111), cls_token ~ N(0,1) (baseline.py:228), depthwise convs get
+    a small normal init here (torch's default kaiming-uniform is not reproduced;
+    the reference never re-initialises them so any value is a valid state).
+    """
+    E = mlp_dim
+    sd = {}
+    lane = [0]
+
+    def nxt():
+        lane[0] += 1
+        return lane[0]
+
+    def lin(name, o, i, bias=True):
+        sd[name + ".weight"] = _xavier_normal(seed, o, i, nxt())
+        if bias:
+            sd[name + ".bias"] = np.zeros((o,), np.float32)
+
+    if merge_enable:
+        val = math.sqrt(6.0 / float(3 * 16 * 16 + E))
+        sd["merge.global_q_mm"] = uniform(seed, (1, merge_k, E), -val, val, lane=nxt()).astype(np.float32)
+        sd["merge.norm.weight"] = np.ones((E,), np.float32)
+        sd["merge.norm.bias"] = np.zeros((E,), np.float32)
+        lin("merge.attn.to_kv", 2 * 512, E, bias=False)
+        lin("merge.attn.to_q", 512, E, bias=False)
+        lin("merge.attn.to_out.0", E, 512)
+    lin("feature.0", E, input_dim)
+    if baseline == "attn":
+        if gated:
+            lin("online_encoder.attention.attention_a.0", scorer_dim, E, bias=False)
+            lin("online_encoder.attention.attention_b.0", scorer_dim, E, bias=False)
+            lin("online_encoder.attention.attention_c", 1, scorer_dim, bias=False)
+        else:
+            lin("online_encoder.attention.attention.0", scorer_dim, E, bias=False)
+            lin("online_encoder.attention.attention.2", 1, scorer_dim, bias=False)
+    elif baseline == "selfattn":
+        sd["online_encoder.cls_token"] = normal(seed, (1, 1, E), lane=nxt()).astype(np.float32)
+        sd["online_encoder.norm.weight"] = np.ones((E,), np.float32)
+        sd["online_encoder.norm.bias"] = np.zeros((E,), np.float32)
+        for l in ("layer1", "layer2"):
+            p = f"online_encoder.{l}."
+            sd[p + "norm.weight"] = np.ones((E,), np.float32)
+            sd[p + "norm.bias"] = np.zeros((E,), np.float32)
+            lin(p + "attn.to_qkv", 3 * E, E, bias=False)
+            lin(p + "attn.to_out.0", E, E)
+            sd[p + "attn.res_conv.weight"] = normal(seed, (8, 1, 33, 1), std=0.1, lane=nxt()).astype(np.float32)
+        for nm, k in (("proj", 7), ("proj1", 5), ("proj2", 3)):
+            p = f"online_encoder.pos_embedding.{nm}."
+            sd[p + "weight"] = normal(seed, (E, 1, k, k), std=1.0 / k, lane=nxt()).astype(np.float32)
+            sd[p + "bias"] = normal(seed, (E,), std=0.02, lane=nxt()).astype(np.float32)
+    else:
+        raise ValueError(f"baseline {baseline!r} not on the hot path (SURVEY.md §8(f) N1)")
+    lin("predictor", n_classes, E)
+    return sd
+
+
+def spread_teacher(sd: dict, pred_scale: float = 50.0, w2_scale: float = 20.0) -> dict:
+    """Teacher state for the tie-free family: predictor.weight x50, scorer w2 x20."""
+    out = {k: v.copy() for k, v in sd.items()}
+    out["predictor.weight"] = out["predictor.weight"] * np.float32(pred_scale)
+    for k in ("online_encoder.attention.attention.2.weight",
+              "online_encoder.attention.attention_c.weight"):
+        if k in out:
+            out[k] = out[k] * np.float32(w2_scale)
+    return out
