@@ -1,0 +1,226 @@
+/* mhimx.h — C-ABI of libmhimx.so: the MI355X-native (gfx950) MHIM aggregation path.
+ *
+ * The reference (DearCaat/MHIM-MIL) is pure Python/PyTorch: it has no FFI seam for
+ * this path.  The boundary is therefore NEW; each entry point
+ * below cites the reference function(s) it replaces (file:line into the reference
+ * tree).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 data unless the name says otherwise
+ *    (ids/rows/perm are int64 like torch index tensors; all must be 16-byte aligned
+ *    where they are matrices);
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *  - every function only ENQUEUES work on `stream` (no host sync, no allocation): the
+ *    caller owns all buffers including the workspace;
+ *  - return value: 0 ok; <0 argument/shape error; >0 a hipError_t.  The message is
+ *    retrievable with mhimx_last_error() (thread-local);
+ *  - nothing throws across this boundary.
+ */
+#ifndef MHIMX_H
+#define MHIMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHIMX_VERSION 100
+
+/* activations (feature act: mhim.py:71-74 relu|gelu|none; scorer act: baseline.py:17-22 gelu|relu|tanh|none) */
+enum { MHIMX_ACT_NONE = 0, MHIMX_ACT_RELU = 1, MHIMX_ACT_GELU = 2, MHIMX_ACT_TANH = 3 };
+
+/* matrix-core precision of a GEMM:
+ *  F32   : v_mfma_f32_32x32x2_f32, exact fp32 (bitwise an fmaf chain), 1/16 of the 16-bit rate
+ *  F16S  : A rounded to one fp16 term, B (the weight) split into fp16 hi+lo: 2 MFMAs / tile-step
+ *  BF16X3: A and B both split into bf16 hi+lo, 3 MFMAs (hi*hi + hi*lo + lo*hi): fp32 range, ~2^-16 */
+enum { MHIMX_PREC_F32 = 0, MHIMX_PREC_F16S = 1, MHIMX_PREC_BF16X3 = 2 };
+
+const char* mhimx_last_error(void);
+int mhimx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Building blocks (exposed so each kernel is parity-tested on its own)
+ * ---------------------------------------------------------------------------------------- */
+
+/* C[m,n] = epilogue( sum_k A[rows?rows[m]:m, k] * B[n,k] )      (torch nn.Linear: x @ W^T)
+ * epilogue: v = acc; if bias v += bias[n]; if rowv v += rowv[m]*colv[n]; if pre pre[m,n] = v;
+ *           v = act(v); if drop_p>0 v = keep(seed, row_id, n) ? v/(1-drop_p) : 0  (or drop_mask u8 [M,N]);
+ *           if accumulate v += C[m,n]; C[m,n] = v.
+ * K % 4 == 0; A,B,C 16-byte aligned with lda/ldb/ldc % 4 == 0.
+ * replaces: every nn.Linear on the path, e.g. mhim.py:69 (feature), baseline.py:14 (scorer), merge.py:35-39. */
+typedef struct {
+  const float* A; int64_t lda; const int64_t* rows;      /* optional gather of A rows             */
+  const float* B; int64_t ldb;                           /* [N,K] row-major (a Linear weight)     */
+  float* C; int64_t ldc;
+  int64_t M, N, K;
+  const float* bias;                                     /* [N] or NULL                           */
+  const float* rowv; const float* colv;                  /* optional rank-1 term                  */
+  float* pre; int64_t ldpre;                             /* optional pre-activation copy          */
+  int32_t act;                                           /* MHIMX_ACT_*                           */
+  float drop_p; uint64_t drop_seed; const uint8_t* drop_mask;   /* dropout: hashed RNG or injected keep-mask */
+  int32_t accumulate;                                    /* C += ...                              */
+  int32_t prec;                                          /* MHIMX_PREC_*                          */
+} mhimx_gemm_nt_args;
+int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
+
+/* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over
+ * `splits` slabs: ws must hold splits*K1*K2 floats when splits>1 (deterministic two-stage reduction).
+ * accumulate: C += result.   replaces: autograd of every nn.Linear weight on the path. */
+typedef struct {
+  const float* A; int64_t lda;                           /* [M,K1]                                */
+  const float* B; int64_t ldb; const int64_t* rows;      /* [*,K2], optional row gather           */
+  float* C; int64_t ldc;                                 /* [K1,K2]                               */
+  int64_t M, K1, K2;
+  int32_t splits; float* ws;
+  int32_t accumulate;
+  int32_t prec;
+} mhimx_gemm_tn_args;
+int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a);
+
+/* out[c,r] = in[r,c]  (weights are transposed once per step so that dX = dY W is also an NT GEMM) */
+int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C);
+
+/* ------------------------------------------------------------------------------------------
+ * ABMIL scorer + softmax pool on a token matrix T[M,E]          
+ * replaces: mhim_modules/baseline.py:31-41 (Attention.forward), :72-86 (AttentionGated.forward),
+ *           :97-110 (DAttention.forward);  modules/abmil.py:111-143, :203-251 (standalone, with biases)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t E;              /* token width (mlp_dim, 512)                                            */
+  int64_t A;              /* scorer hidden width (128; 384 for modules/abmil.AttentionGated)       */
+  int32_t act;            /* scorer activation                                                      */
+  int32_t gated;
+  int32_t prec;
+  const float* wa; const float* ba;     /* [A,E], [A]|NULL   attention.0 / attention_a.0            */
+  const float* wb; const float* bb;     /* gated: [A,E], [A]|NULL   attention_b.0                   */
+  const float* wc; const float* bc;     /* [A], [1]|NULL     attention.2 / attention_c              */
+} mhimx_scorer;
+
+/* Forward over up to two token segments (segment 1 = feature rows, segment 2 = merged tokens).
+ *  s[M]      raw scores (baseline.py:32 before softmax; what no_norm=True returns)
+ *  stats[2]  = {max_n s, sum_n exp(s-max)}
+ *  z[E]      = sum_n softmax(s)_n T[n,:]
+ *  u_pre     [M, A*(1+gated)] scorer pre-activations (kept for backward), may be NULL only if ws holds it
+ *  cproj     optional [M,C] = T Wp^T (class projections for the pseudo score), needs wp [C,E]
+ *  ws        workspace, mhimx_abmil_pool_ws_bytes(M, E, A, gated) bytes                           */
+typedef struct {
+  const float* T1; int64_t M1; const float* T2; int64_t M2;
+  float* s; float* stats; float* z;
+  float* u_pre;
+  const float* wp; int64_t C; float* cproj;
+  void* ws; int64_t ws_bytes;
+} mhimx_pool_io;
+int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
+int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io);
+
+/* Backward of the pool given g_z[E] (= dLoss/dz).  Produces dT1,dT2 (overwritten), and the scorer
+ * weight gradients (overwritten unless accumulate).  wa_t = transpose(wa) [E,A] (and wb_t). */
+typedef struct {
+  const float* g_z;
+  float* dT1; float* dT2;
+  float* d_wa; float* d_ba; float* d_wb; float* d_bb; float* d_wc; float* d_bc;
+  const float* wa_t; const float* wb_t;
+  int32_t accumulate;
+  int32_t splits;
+} mhimx_pool_grad;
+int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* g);
+
+/* attn[n] = exp(s[n]-stats[0])/stats[1]   (baseline.py:35, what return_attn gives) */
+int mhimx_softmax_from_stats(void* stream, const float* s, const float* stats, float* attn, int64_t M);
+
+/* score[n] = max_c softmax_c( attn_n * cproj[n,c] + bp0 )
+ * replaces: mhim_modules/scoring.py:37-58 (get_pseudo_score), incl. the class-0 bias quirk (:54). */
+int mhimx_pseudo_score(void* stream, const float* s, const float* stats, const float* cproj, const float* bp,
+                       float* score, float* attn_out, int64_t M, int64_t C);
+
+/* ------------------------------------------------------------------------------------------
+ * Hard-instance select                                          
+ * replaces: mhim_modules/masking.py:9-88 (select_mask_fn, 2-D scores) incl. the Python set()
+ *           round trip (:77-80), and its composition in modules/mhim.py:109-179 (get_mask).
+ * Tie contract (the reference's torch.topk order is implementation-defined): candidates are ordered by
+ * (value desc [asc if !largest], index asc).  Kept ids are emitted ascending.
+ *  score[N]; k = ceil(ps*ratio) candidates; the first n_sel entries of perm[k] (int64, a permutation of
+ *  0..k-1; NULL = identity) index the sorted candidate list (masking.py:66-71);
+ *  other[n_other] (int64, may be NULL) = ids masked by an earlier call: result is the sorted union (:74-75);
+ *  mask_ids[N] int64 = kept ascending ++ masked;  len_keep is returned through *len_keep_dev (device int64)
+ *  and equals N - |masked| (host-computable when other == NULL: N - n_sel).
+ *  N <= 2^24, k <= 16384 (LDS-resident sort).  ws: mhimx_select_ws_bytes(N) bytes. */
+int64_t mhimx_select_ws_bytes(int64_t N);
+int mhimx_select_mask(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
+                      const int64_t* perm, const int64_t* other, int64_t n_other,
+                      int64_t* mask_ids, int64_t* len_keep_dev, int64_t* topk_sorted /* [k] optional */,
+                      void* ws, int64_t ws_bytes);
+
+/* vote[n] = number of heads whose top-k contains n (masking.py:49-57, msa_fusion='vote'); attn [H,N] */
+int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,
+                      float* vote, void* ws, int64_t ws_bytes);
+
+/* out[i] = a[b[i]]  (index composition: ids_keep[ids_shuffle]) */
+int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Merge / MCA                                                   
+ * replaces: mhim_modules/merge.py:43-65 (MCA.forward), :131-144 (Merge.merge), :127-129 (EMA).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t E; int64_t k;               /* token width, number of global queries                       */
+  int64_t heads; int64_t dim_head;    /* 8 x 64                                                      */
+  const float* q_param;               /* merge.global_q_mm [k,E]                                     */
+  const float* ln_w; const float* ln_b;
+  const float* wkv; const float* wq; const float* wo; const float* bo;
+  const float* wkv_t; const float* wq_t; const float* wo_t;   /* transposes, backward only           */
+  float mm;                           /* EMA momentum g_q_mm                                         */
+  float drop_p; uint64_t drop_seed;   /* MCA dropout (merge.py:33,40), hashed RNG; 0 = off           */
+  int32_t prec;
+} mhimx_merge;
+int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
+/* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */
+int mhimx_merge_fwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new,
+                    int32_t update_q, void* ws, int64_t ws_bytes);
+typedef struct {
+  float* d_ln_w; float* d_ln_b; float* d_wkv; float* d_wq; float* d_wo; float* d_bo;
+  int32_t accumulate; int32_t splits;
+} mhimx_merge_grad;
+/* dz[k,E] -> dX[R,E] (overwritten) and parameter gradients. */
+int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX,
+                    const mhimx_merge_grad* g, void* ws, int64_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Feature projection backward pieces                            
+ * ---------------------------------------------------------------------------------------- */
+/* dPre = dH * act'(pre or H) * keep/(1-p), in place on dH.  For relu `pre` may be NULL (uses H>0). */
+int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int64_t M, int64_t E, int32_t act,
+                  float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows);
+/* out[e] (+)= sum_m X[m,e] */
+int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
+                 void* ws, int64_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Head: predictor + CE + SoftTargetCE, forward and backward in one launch
+ * replaces: mhim.py:97,371 (predictor), losses.py:26-45, mhim.py:300-316, base_engine.py:99-102.
+ *  logits[C] = Wp z + bp;  ce = -log softmax(logits)[label];  cl = -sum softmax(t/temp_t) log_softmax(z)
+ *  loss = (main_alpha*ce + aux_alpha*cl)/accum;  out: losses[3] = {loss*accum, ce, cl};
+ *  g_z[E], d_wp[C,E], d_bp[C] (of `loss`).  t may be NULL (aux term skipped, common_mil.py:24).
+ * ---------------------------------------------------------------------------------------- */
+int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float* wp, const float* bp,
+                       const int64_t* label_dev, int64_t E, int64_t C, float temp_t, float main_alpha,
+                       float aux_alpha, float inv_accum, float* logits, float* losses, float* g_z, float* d_wp,
+                       float* d_bp, int32_t accumulate);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser + EMA teacher                                       
+ * replaces: torch.optim.Adam as built in train_utils.py:58-65 (L2 weight decay added to the gradient)
+ *           and the per-parameter EMA loop base_engine.py:166-167.
+ *  p,g,m,v [n_train]; teacher[n_all] (n_all >= n_train: the tail holds non-trainable parameters such as
+ *  merge.global_q_mm which only take part in the EMA); step >= 1 is the Adam step AFTER this update.
+ *  grad_scale multiplies g first (1/world_size after a SUM all-reduce). teacher may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
+                   int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale, float ema_mm, int32_t zero_grad /* also clears g (cast away const) */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHIMX_H */

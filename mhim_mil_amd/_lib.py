@@ -1,0 +1,137 @@
+"""ctypes binding of libmhimx.so (include/mhimx.h).  No fallback: if the HIP library is missing or a
+symbol is absent this raises — the product never routes around the native path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmhimx.so")
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u8p = C.c_void_p
+
+ACT = {None: 0, "none": 0, "identity": 0, "relu": 1, "gelu": 2, "tanh": 3}
+PREC = {"f32": 0, "f16s": 1, "bf16x3": 2}
+
+
+def act_code(name, allowed):
+    """Reference semantics: an activation name outside ``allowed`` silently means "no activation"
+    (mhim.py:71-74 for the feature; baseline.py:17-22 for the scorer)."""
+    n = name.lower() if isinstance(name, str) else None
+    return ACT[n] if n in allowed else 0
+
+
+class GemmNT(C.Structure):
+    _fields_ = [("A", c_f32p), ("lda", C.c_int64), ("rows", c_i64p),
+                ("B", c_f32p), ("ldb", C.c_int64),
+                ("C", c_f32p), ("ldc", C.c_int64),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("bias", c_f32p), ("rowv", c_f32p), ("colv", c_f32p),
+                ("pre", c_f32p), ("ldpre", C.c_int64),
+                ("act", C.c_int32),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p),
+                ("accumulate", C.c_int32), ("prec", C.c_int32)]
+
+
+class GemmTN(C.Structure):
+    _fields_ = [("A", c_f32p), ("lda", C.c_int64),
+                ("B", c_f32p), ("ldb", C.c_int64), ("rows", c_i64p),
+                ("C", c_f32p), ("ldc", C.c_int64),
+                ("M", C.c_int64), ("K1", C.c_int64), ("K2", C.c_int64),
+                ("splits", C.c_int32), ("ws", c_f32p),
+                ("accumulate", C.c_int32), ("prec", C.c_int32)]
+
+
+class Scorer(C.Structure):
+    _fields_ = [("E", C.c_int64), ("A", C.c_int64), ("act", C.c_int32), ("gated", C.c_int32), ("prec", C.c_int32),
+                ("wa", c_f32p), ("ba", c_f32p), ("wb", c_f32p), ("bb", c_f32p), ("wc", c_f32p), ("bc", c_f32p)]
+
+
+class PoolIO(C.Structure):
+    _fields_ = [("T1", c_f32p), ("M1", C.c_int64), ("T2", c_f32p), ("M2", C.c_int64),
+                ("s", c_f32p), ("stats", c_f32p), ("z", c_f32p), ("u_pre", c_f32p),
+                ("wp", c_f32p), ("C", C.c_int64), ("cproj", c_f32p),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+
+
+class PoolGrad(C.Structure):
+    _fields_ = [("g_z", c_f32p), ("dT1", c_f32p), ("dT2", c_f32p),
+                ("d_wa", c_f32p), ("d_ba", c_f32p), ("d_wb", c_f32p), ("d_bb", c_f32p), ("d_wc", c_f32p),
+                ("d_bc", c_f32p), ("wa_t", c_f32p), ("wb_t", c_f32p),
+                ("accumulate", C.c_int32), ("splits", C.c_int32)]
+
+
+class Merge(C.Structure):
+    _fields_ = [("E", C.c_int64), ("k", C.c_int64), ("heads", C.c_int64), ("dim_head", C.c_int64),
+                ("q_param", c_f32p), ("ln_w", c_f32p), ("ln_b", c_f32p),
+                ("wkv", c_f32p), ("wq", c_f32p), ("wo", c_f32p), ("bo", c_f32p),
+                ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
+                ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32)]
+
+
+class MergeGrad(C.Structure):
+    _fields_ = [("d_ln_w", c_f32p), ("d_ln_b", c_f32p), ("d_wkv", c_f32p), ("d_wq", c_f32p), ("d_wo", c_f32p),
+                ("d_bo", c_f32p), ("accumulate", C.c_int32), ("splits", C.c_int32)]
+
+
+# symbol -> (restype, argtypes); every symbol include/mhimx.h declares must be listed here
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_F = C.c_float
+_U64 = C.c_uint64
+SYMBOLS = {
+    "mhimx_last_error": (C.c_char_p, []),
+    "mhimx_version": (C.c_int, []),
+    "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
+    "mhimx_gemm_tn": (C.c_int, [_P, C.POINTER(GemmTN)]),
+    "mhimx_transpose": (C.c_int, [_P, _P, _P, _I64, _I64]),
+    "mhimx_abmil_pool_ws_bytes": (_I64, [_I64, _I64, _I64, _I32]),
+    "mhimx_abmil_pool_fwd": (C.c_int, [_P, C.POINTER(Scorer), C.POINTER(PoolIO)]),
+    "mhimx_abmil_pool_bwd": (C.c_int, [_P, C.POINTER(Scorer), C.POINTER(PoolIO), C.POINTER(PoolGrad)]),
+    "mhimx_softmax_from_stats": (C.c_int, [_P, _P, _P, _P, _I64]),
+    "mhimx_pseudo_score": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64]),
+    "mhimx_select_ws_bytes": (_I64, [_I64]),
+    "mhimx_select_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64, _P, _P, _P, _P, _I64]),
+    "mhimx_vote_scores": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64]),
+    "mhimx_compose_ids": (C.c_int, [_P, _P, _P, _P, _I64]),
+    "mhimx_merge_ws_bytes": (_I64, [_I64, _I64, _I64, _I64, _I64]),
+    "mhimx_merge_fwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I32, _P, _I64]),
+    "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
+    "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P]),
+    "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
+    "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32]),
+    "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X HIP library has not been built "
+            f"(run `python -m mhim_mil_amd.build` or __graft_entry__.build()); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class MhimxError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib().mhimx_last_error()
+        raise MhimxError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

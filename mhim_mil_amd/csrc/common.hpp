@@ -1,0 +1,103 @@
+// common.hpp — shared host/device helpers for libmhimx (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <type_traits>
+
+#include "../../include/mhimx.h"
+
+namespace mhimx {
+
+// ---------------------------------------------------------------- host: errors
+void set_error(const std::string& s);
+int fail(int code, const char* fmt, ...);
+const std::string& last_error();
+
+#define MHIMX_CHECK_ARG(cond, ...)                      \
+  do {                                                  \
+    if (!(cond)) return ::mhimx::fail(-1, __VA_ARGS__); \
+  } while (0)
+
+#define MHIMX_HIP(expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return ::mhimx::fail((int)_e, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define MHIMX_LAUNCH_CHECK()                                                                  \
+  do {                                                                                        \
+    hipError_t _e = hipGetLastError();                                                        \
+    if (_e != hipSuccess) return ::mhimx::fail((int)_e, "kernel launch: %s", hipGetErrorString(_e)); \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// bump allocator over a caller-provided workspace (256-byte granules)
+struct Arena {
+  char* base;
+  int64_t cap, off;
+  Arena(void* p, int64_t bytes) : base((char*)p), cap(bytes), off(0) {}
+  template <typename T>
+  T* take(int64_t n) {
+    int64_t b = align_up(n * (int64_t)sizeof(T), 256);
+    T* r = (T*)(base + off);
+    off += b;
+    return r;
+  }
+  bool ok() const { return off <= cap && (base != nullptr || off == 0); }
+};
+
+// ---------------------------------------------------------------- device helpers
+#define MHIMX_DEV __device__ __forceinline__
+
+MHIMX_DEV float act_fwd(float x, int act) {
+  switch (act) {
+    case MHIMX_ACT_RELU: return x > 0.f ? x : 0.f;
+    case MHIMX_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));   // exact-erf GELU
+    case MHIMX_ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+
+// derivative w.r.t. the pre-activation x (y = act(x) is passed for the cheap forms)
+MHIMX_DEV float act_grad(float x, float y, int act) {
+  switch (act) {
+    case MHIMX_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case MHIMX_ACT_GELU: {
+      const float phi = 0.39894228040143267794f * __expf(-0.5f * x * x);
+      return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * phi;
+    }
+    case MHIMX_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// Counter-based keep/drop decision: one 32-bit mix of (seed, row, col) per element.  The same
+// (seed,row,col) gives the same bit in forward and backward, so no mask is ever stored.
+MHIMX_DEV uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+MHIMX_DEV bool drop_keep(uint64_t seed, uint64_t row, uint32_t col, float p) {
+  uint32_t h = mix32((uint32_t)seed ^ mix32((uint32_t)(row * 0x9E3779B1u) + col * 0x85EBCA77u + (uint32_t)(seed >> 32)));
+  h = mix32(h + (uint32_t)(row >> 16));
+  // keep with probability 1-p
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+MHIMX_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+MHIMX_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace mhimx

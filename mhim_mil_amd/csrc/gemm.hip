@@ -1,0 +1,410 @@
+// gemm.hip — LDS-tiled MFMA GEMMs for gfx950 (wave64, v_mfma_f32_32x32x{2_f32,16_f16,16_bf16}).
+//
+// Two kernels share one 128x128 tile / 4-wave (2x2) compute core:
+//   gemm_nt : C[M,N] = epi(A[M,K] (optionally row-gathered) . B[N,K]^T)      -- every Linear forward and dX
+//   gemm_tn : C[K1,K2] = A[M,K1]^T . B[M,K2] (B optionally row-gathered)     -- every Linear weight gradient
+// Operands live in HBM as fp32; they are converted on the way into LDS:
+//   F32    : kept fp32, exact v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit rate)
+//   F16S   : A -> one fp16 term, B -> fp16 hi + lo   (2 MFMAs per tile step; the weight is the systematic error
+//            source, the activation error averages out over rows: SURVEY.md §7 H1)
+//   BF16X3 : A,B -> bf16 hi + lo, hi*hi + hi*lo + lo*hi (3 MFMAs; fp32 range, used for gradients)
+// LDS rows are K-contiguous with a pad that makes the 16-byte fragment reads (ds_read_b128) conflict free:
+// row pitch 80 B => the 16 rows of a lane group land on 16 distinct 16-B slots of the 256-B bank row.
+#include "common.hpp"
+
+namespace mhimx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+
+template <int PREC> struct Prec;
+template <> struct Prec<MHIMX_PREC_F32> {
+  using T = float;
+  static constexpr int NA = 1, NB = 1, BK = 16, PITCH = 17;      // pitch in elements
+};
+template <> struct Prec<MHIMX_PREC_F16S> {
+  using T = _Float16;
+  static constexpr int NA = 1, NB = 2, BK = 32, PITCH = 40;
+};
+template <> struct Prec<MHIMX_PREC_BF16X3> {
+  using T = __bf16;
+  static constexpr int NA = 2, NB = 2, BK = 32, PITCH = 40;
+};
+
+// ---- fp32 -> (hi, lo) conversion -------------------------------------------------------------
+template <typename T> MHIMX_DEV T cvt(float x);
+template <> MHIMX_DEV float cvt<float>(float x) { return x; }
+template <> MHIMX_DEV _Float16 cvt<_Float16>(float x) { return (_Float16)x; }
+template <> MHIMX_DEV __bf16 cvt<__bf16>(float x) { return (__bf16)x; }
+
+template <typename T, int NTERM>
+MHIMX_DEV void split(float x, T& hi, T& lo) {
+  hi = cvt<T>(x);
+  if constexpr (NTERM == 2) lo = cvt<T>(x - (float)hi);
+}
+
+// ---- one k-step of MFMAs on the wave's 64x64 sub-tile ------------------------------------------
+// As/Bs: [term][128][PITCH]; wave covers rows wm*64.. of As and rows wn*64.. of Bs.
+template <int PREC>
+MHIMX_DEV void mma_step(const typename Prec<PREC>::T* As, const typename Prec<PREC>::T* Bs, int wm, int wn, int lane,
+                        f32x16 (&acc)[2][2]) {
+  using PP = Prec<PREC>;
+  using T = typename PP::T;
+  constexpr int PITCH = PP::PITCH;
+  constexpr int TSZ = 128 * PITCH;
+  const int r = lane & 31, kh = lane >> 5;
+  if constexpr (PREC == MHIMX_PREC_F32) {
+#pragma unroll
+    for (int ks = 0; ks < PP::BK / 2; ++ks) {
+      float a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[(wm * 64 + t * 32 + r) * PITCH + ks * 2 + kh];
+        b[t] = Bs[(wn * 64 + t * 32 + r) * PITCH + ks * 2 + kh];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  } else {
+    using V8 = typename std::conditional<PREC == MHIMX_PREC_F16S, h8, b8>::type;
+#pragma unroll
+    for (int ks = 0; ks < PP::BK / 16; ++ks) {
+      V8 a[PP::NA][2], b[PP::NB][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int q = 0; q < PP::NA; ++q)
+          a[q][t] = *reinterpret_cast<const V8*>(As + q * TSZ + (wm * 64 + t * 32 + r) * PITCH + ks * 16 + kh * 8);
+#pragma unroll
+        for (int q = 0; q < PP::NB; ++q)
+          b[q][t] = *reinterpret_cast<const V8*>(Bs + q * TSZ + (wn * 64 + t * 32 + r) * PITCH + ks * 16 + kh * 8);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if constexpr (PREC == MHIMX_PREC_F16S) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], b[1][nt], acc[mt][nt], 0, 0, 0);   // lo first
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+          } else {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[1][nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+          }
+        }
+    }
+  }
+}
+
+// ---- write 4 consecutive-k fp32 values of one tile row into LDS (K-contiguous rows) --------------
+template <int PREC, int NTERM>
+MHIMX_DEV void lds_put4(typename Prec<PREC>::T* S, int row, int k, float4 v) {
+  using PP = Prec<PREC>;
+  using T = typename PP::T;
+  constexpr int PITCH = PP::PITCH;
+  constexpr int TSZ = 128 * PITCH;
+  if constexpr (PREC == MHIMX_PREC_F32) {
+    float* p = S + row * PITCH + k;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+  } else {
+    using V4 = typename std::conditional<PREC == MHIMX_PREC_F16S, h4, b4>::type;
+    T hi[4], lo[4];
+    split<T, NTERM>(v.x, hi[0], lo[0]); split<T, NTERM>(v.y, hi[1], lo[1]);
+    split<T, NTERM>(v.z, hi[2], lo[2]); split<T, NTERM>(v.w, hi[3], lo[3]);
+    V4 h = {hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<V4*>(S + row * PITCH + k) = h;
+    if constexpr (NTERM == 2) {
+      V4 l = {lo[0], lo[1], lo[2], lo[3]};
+      *reinterpret_cast<V4*>(S + TSZ + row * PITCH + k) = l;
+    }
+  }
+}
+
+// =================================================================================================
+// gemm_nt
+// =================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g) {
+  using PP = Prec<PREC>;
+  using T = typename PP::T;
+  constexpr int BK = PP::BK, PITCH = PP::PITCH, TSZ = 128 * PITCH;
+  constexpr int F4R = BK / 4;                      // float4 per tile row
+  constexpr int ITEMS = BM * F4R / NTHREADS;       // float4 per thread per operand
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Bs = As + PP::NA * TSZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+  const float* ap[ITEMS];
+  const float* bp[ITEMS];
+  int rr[ITEMS], kk[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int idx = tid + j * NTHREADS;
+    rr[j] = idx / F4R;
+    kk[j] = (idx % F4R) * 4;
+    const int64_t m = m0 + rr[j], n = n0 + rr[j];
+    ap[j] = nullptr;
+    bp[j] = nullptr;
+    if (m < g.M) ap[j] = g.A + (g.rows ? g.rows[m] : m) * g.lda + kk[j];
+    if (n < g.N) bp[j] = g.B + n * g.ldb + kk[j];
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[ITEMS], rb[ITEMS];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const bool kin = (k0 + kk[j]) < g.K;
+      ra[j] = (ap[j] && kin) ? *reinterpret_cast<const float4*>(ap[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[j] = (bp[j] && kin) ? *reinterpret_cast<const float4*>(bp[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  fetch(0);
+  for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      lds_put4<PREC, PP::NA>(As, rr[j], kk[j], ra[j]);
+      lds_put4<PREC, PP::NB>(Bs, rr[j], kk[j], rb[j]);
+    }
+    __syncthreads();
+    if (k0 + BK < g.K) fetch(k0 + BK);
+    mma_step<PREC>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const int cl = lane & 31, rh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t n = n0 + wn * 64 + nt * 32 + cl;
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+      const float colv = g.rowv ? g.colv[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+        if (m >= g.M) continue;
+        float v = acc[mt][nt][e] + bias;
+        if (g.rowv) v += g.rowv[m] * colv;
+        if (g.pre) g.pre[m * g.ldpre + n] = v;
+        v = act_fwd(v, g.act);
+        if (g.drop_mask) {
+          v = g.drop_mask[m * g.N + n] ? v / (1.f - g.drop_p) : 0.f;
+        } else if (g.drop_p > 0.f) {
+          const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
+          v = drop_keep(g.drop_seed, rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
+        }
+        float* c = g.C + m * g.ldc + n;
+        if (g.accumulate) v += *c;
+        *c = v;
+      }
+    }
+}
+
+template <int PREC>
+static int launch_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
+  using PP = Prec<PREC>;
+  const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
+  dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
+  hipLaunchKernelGGL(gemm_nt_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
+  MHIMX_CHECK_ARG(g.M >= 0 && g.N > 0 && g.K > 0, "gemm_nt: bad dims M=%lld N=%lld K=%lld", (long long)g.M, (long long)g.N, (long long)g.K);
+  if (g.M == 0) return 0;
+  MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm_nt: K, lda, ldb must be multiples of 4");
+  MHIMX_CHECK_ARG(aligned16(g.A) && aligned16(g.B), "gemm_nt: A and B must be 16-byte aligned");
+  MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_nt: null operand");
+  MHIMX_CHECK_ARG(!g.rowv || g.colv, "gemm_nt: rowv needs colv");
+  MHIMX_CHECK_ARG(g.drop_p >= 0.f && g.drop_p < 1.f, "gemm_nt: drop_p out of range");
+  switch (g.prec) {
+    case MHIMX_PREC_F32: return launch_nt<MHIMX_PREC_F32>(st, g);
+    case MHIMX_PREC_F16S: return launch_nt<MHIMX_PREC_F16S>(st, g);
+    case MHIMX_PREC_BF16X3: return launch_nt<MHIMX_PREC_BF16X3>(st, g);
+    default: return fail(-1, "gemm_nt: unknown prec %d", g.prec);
+  }
+}
+
+// =================================================================================================
+// gemm_tn : C[i,j] = sum_m A[m,i] * B[rows[m], j]
+// =================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mhimx_gemm_tn_args g, int64_t mchunk) {
+  using PP = Prec<PREC>;
+  using T = typename PP::T;
+  constexpr int BK = PP::BK, PITCH = PP::PITCH, TSZ = 128 * PITCH;
+  constexpr int HK = BK / 2;                         // m-values per thread per operand
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Bs = As + PP::NA * TSZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
+  const int64_t mbeg = (int64_t)blockIdx.z * mchunk;
+  const int64_t mend = mbeg + mchunk < g.M ? mbeg + mchunk : g.M;
+
+  const int c = tid & 127, half = tid >> 7;          // this thread stages column c, m-range half
+  const bool ain = (i0 + c) < g.K1, bin = (j0 + c) < g.K2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float ra[HK], rb[HK];
+  auto fetch = [&](int64_t m0) {
+#pragma unroll
+    for (int q = 0; q < HK; ++q) {
+      const int64_t m = m0 + half * HK + q;
+      const bool in = m < mend;
+      ra[q] = (in && ain) ? g.A[m * g.lda + i0 + c] : 0.f;
+      rb[q] = (in && bin) ? g.B[(g.rows ? g.rows[m] : m) * g.ldb + j0 + c] : 0.f;
+    }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int q = 0; q < HK; q += 4) {
+      lds_put4<PREC, PP::NA>(As, c, half * HK + q, make_float4(ra[q], ra[q + 1], ra[q + 2], ra[q + 3]));
+      lds_put4<PREC, PP::NB>(Bs, c, half * HK + q, make_float4(rb[q], rb[q + 1], rb[q + 2], rb[q + 3]));
+    }
+  };
+
+  if (mbeg < mend) {
+    fetch(mbeg);
+    for (int64_t m0 = mbeg; m0 < mend; m0 += BK) {
+      put();
+      __syncthreads();
+      if (m0 + BK < mend) fetch(m0 + BK);
+      mma_step<PREC>(As, Bs, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  }
+
+  float* out = g.splits > 1 ? g.ws + (int64_t)blockIdx.z * g.K1 * g.K2 : g.C;
+  const int64_t ldo = g.splits > 1 ? g.K2 : g.ldc;
+  const bool accum = g.splits > 1 ? false : (g.accumulate != 0);
+  const int cl = lane & 31, rh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t j = j0 + wn * 64 + nt * 32 + cl;
+      if (j >= g.K2) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t i = i0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+        if (i >= g.K1) continue;
+        float v = acc[mt][nt][e];
+        float* p = out + i * ldo + j;
+        if (accum) v += *p;
+        *p = v;
+      }
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2,
+                                    int64_t ldc, int splits, int accumulate) {
+  const int64_t n = K1 * K2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * n + idx];       // fixed order: deterministic
+    float* p = C + (idx / K2) * ldc + (idx % K2);
+    *p = accumulate ? *p + s : s;
+  }
+}
+
+template <int PREC>
+static int launch_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
+  using PP = Prec<PREC>;
+  const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
+  const int splits = g.splits > 1 ? g.splits : 1;
+  const int64_t mchunk = align_up(cdiv(g.M, splits), PP::BK);
+  dim3 grid((unsigned)cdiv(g.K2, BN), (unsigned)cdiv(g.K1, BM), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_tn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, mchunk);
+  MHIMX_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t n = g.K1 * g.K2;
+    const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, splits, g.accumulate);
+    MHIMX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
+  MHIMX_CHECK_ARG(g.M >= 0 && g.K1 > 0 && g.K2 > 0, "gemm_tn: bad dims");
+  MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_tn: null operand");
+  MHIMX_CHECK_ARG(g.splits <= 1 || g.ws, "gemm_tn: splits>1 needs ws");
+  switch (g.prec) {
+    case MHIMX_PREC_F32: return launch_tn<MHIMX_PREC_F32>(st, g);
+    case MHIMX_PREC_F16S:      // fp16 has no headroom for gradients: use the bf16 3-term form
+    case MHIMX_PREC_BF16X3: return launch_tn<MHIMX_PREC_BF16X3>(st, g);
+    default: return fail(-1, "gemm_tn: unknown prec %d", g.prec);
+  }
+}
+
+// =================================================================================================
+// transpose (32x32 LDS tile, +1 pad)
+// =================================================================================================
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t R, int64_t C) {
+  __shared__ float tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int64_t r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? in[r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int64_t c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) out[c * R + r] = tile[threadIdx.x][i];
+  }
+}
+
+int transpose(hipStream_t st, const float* in, float* out, int64_t R, int64_t C) {
+  MHIMX_CHECK_ARG(in && out && R > 0 && C > 0, "transpose: bad args");
+  dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, st, in, out, R, C);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mhimx
+
+extern "C" int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a) {
+  if (!a) return mhimx::fail(-1, "gemm_nt: null args");
+  return mhimx::gemm_nt((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a) {
+  if (!a) return mhimx::fail(-1, "gemm_tn: null args");
+  return mhimx::gemm_tn((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C) {
+  return mhimx::transpose((hipStream_t)stream, in, out, R, C);
+}

@@ -1,0 +1,149 @@
+// optim.hip — the bag-level tail of a train step: predictor + losses (+ their gradients) in one launch,
+// and the fused Adam + EMA-teacher update over flat parameter buffers.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mhimx {
+
+constexpr int HEAD_THREADS = 256;
+
+MHIMX_DEV float blk_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+MHIMX_DEV float blk_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// One block.  C <= 16 classes.
+__global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                            const float* __restrict__ wp, const float* __restrict__ bp,
+                                                            const int64_t* __restrict__ label, int E, int C, float temp_t,
+                                                            float main_alpha, float aux_alpha, float inv_accum,
+                                                            float* __restrict__ logits, float* __restrict__ losses,
+                                                            float* __restrict__ g_z, float* __restrict__ d_wp,
+                                                            float* __restrict__ d_bp, int accumulate) {
+  __shared__ float red[4];
+  __shared__ float lg[16], gl[16];
+  const int tid = threadIdx.x;
+  // logits
+  for (int c = 0; c < C; ++c) {
+    float p = 0.f;
+    for (int e = tid; e < E; e += HEAD_THREADS) p += wp[c * E + e] * z[e];
+    p = blk_sum(p, red);
+    if (tid == 0) lg[c] = p + (bp ? bp[c] : 0.f);
+  }
+  __syncthreads();
+  // cross entropy on the logits (criterion = nn.CrossEntropyLoss, base_engine.py:99)
+  float ce = 0.f;
+  if (label) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lg[c]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(lg[c] - mx);
+    const int y = (int)label[0];
+    ce = -(lg[y] - mx - logf(den));
+    if (tid < C) gl[tid] = main_alpha * inv_accum * (expf(lg[tid] - mx) / den - (tid == y ? 1.f : 0.f));
+  } else if (tid < C) {
+    gl[tid] = 0.f;
+  }
+  __syncthreads();
+  // soft-target CE over the E feature dims: cl = -sum softmax(t/temp_t) * log_softmax(z)   (losses.py:40-43)
+  float cl = 0.f;
+  float zmx = 0.f, zden = 1.f, tmx = 0.f, tden = 1.f;
+  const bool aux = (t != nullptr);
+  if (aux) {
+    float a = -INFINITY, b = -INFINITY;
+    for (int e = tid; e < E; e += HEAD_THREADS) { a = fmaxf(a, z[e]); b = fmaxf(b, t[e] / temp_t); }
+    zmx = blk_max(a, red);
+    tmx = blk_max(b, red);
+    float sa = 0.f, sb = 0.f;
+    for (int e = tid; e < E; e += HEAD_THREADS) { sa += expf(z[e] - zmx); sb += expf(t[e] / temp_t - tmx); }
+    zden = blk_sum(sa, red);
+    tden = blk_sum(sb, red);
+    const float lz = logf(zden);
+    float acc = 0.f;
+    for (int e = tid; e < E; e += HEAD_THREADS) acc += (expf(t[e] / temp_t - tmx) / tden) * (z[e] - zmx - lz);
+    cl = -blk_sum(acc, red);
+  }
+  if (tid == 0) {
+    for (int c = 0; c < C; ++c) logits[c] = lg[c];
+    losses[0] = main_alpha * ce + aux_alpha * cl;
+    losses[1] = ce;
+    losses[2] = cl;
+  }
+  // gradients
+  for (int e = tid; e < E; e += HEAD_THREADS) {
+    float g = 0.f;
+    for (int c = 0; c < C; ++c) g += wp[c * E + e] * gl[c];
+    if (aux) g += aux_alpha * inv_accum * (expf(z[e] - zmx) / zden - expf(t[e] / temp_t - tmx) / tden);
+    g_z[e] = g;
+    if (d_wp)
+      for (int c = 0; c < C; ++c) {
+        const float v = gl[c] * z[e];
+        d_wp[c * E + e] = accumulate ? d_wp[c * E + e] + v : v;
+      }
+  }
+  if (d_bp && tid < C) d_bp[tid] = accumulate ? d_bp[tid] + gl[tid] : gl[tid];
+}
+
+// torch.optim.Adam semantics (weight decay folded into the gradient, bias-corrected, eps outside the sqrt of
+// the corrected second moment) + EMA teacher.  bc1 = 1-beta1^t, bc2s = sqrt(1-beta2^t) come from the host in fp64.
+__global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                float* __restrict__ teacher, int64_t n_train, int64_t n_all, float lr_over_bc1, float bc2s,
+                                float beta1, float beta2, float eps, float wd, float gscale, float mm, int zero_grad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
+    float w = p[i];
+    if (i < n_train) {
+      float gi = g[i] * gscale + wd * w;
+      const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+      const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+      m[i] = mi;
+      v[i] = vi;
+      const float denom = sqrtf(vi) / bc2s + eps;
+      w = w - lr_over_bc1 * (mi / denom);
+      p[i] = w;
+      if (zero_grad) g[i] = 0.f;
+    }
+    if (teacher) teacher[i] = teacher[i] * mm + w * (1.f - mm);
+  }
+}
+
+}  // namespace mhimx
+
+using namespace mhimx;
+
+extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float* wp, const float* bp,
+                                  const int64_t* label_dev, int64_t E, int64_t C, float temp_t, float main_alpha,
+                                  float aux_alpha, float inv_accum, float* logits, float* losses, float* g_z, float* d_wp,
+                                  float* d_bp, int32_t accumulate) {
+  MHIMX_CHECK_ARG(z && wp && logits && losses && g_z, "head: null args");
+  MHIMX_CHECK_ARG(C > 0 && C <= 16 && E > 0, "head: bad dims");
+  hipLaunchKernelGGL(head_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
+                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
+                              int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              float grad_scale, float ema_mm, int32_t zero_grad) {
+  MHIMX_CHECK_ARG(p && g && m && v && n_train >= 0 && n_all >= n_train && step >= 1, "adam_ema: bad args");
+  if (n_all == 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int64_t blocks = cdiv(n_all, 256) < 2048 ? cdiv(n_all, 256) : 2048;
+  hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v,
+                     teacher, n_train, n_all, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, weight_decay,
+                     grad_scale, ema_mm, zero_grad);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}

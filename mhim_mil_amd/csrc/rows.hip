@@ -1,0 +1,623 @@
+// rows.hip — row-streaming kernels of the ABMIL path: scorer tail + online-softmax pool (forward and
+// backward), pseudo score, LayerNorm, activation backward, column sums.  All HBM-bound: one wave owns
+// one token row at a time, lanes stride the row (coalesced 256-B segments), wave reductions by DPP
+// shuffles, cross-wave/-block merging by log-sum-exp partials (deterministic fixed-order finalize).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mhimx {
+
+int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g);
+int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
+
+constexpr int ROWS_THREADS = 256;
+constexpr int MAX_PART = 512;          // partial blocks per segment
+
+MHIMX_DEV float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// forward: s[n] = wc . (act(a_n) [* sigmoid(b_n)]) + bc ; per-block LSE partial of sum_n e^{s_n} T[n,:]
+// ------------------------------------------------------------------------------------------------
+template <int EPL>   // E = 64*EPL
+__global__ __launch_bounds__(ROWS_THREADS) void score_rows_fwd_kernel(
+    const float* __restrict__ T, int64_t M, int E, int A, int act, int gated, const float* __restrict__ u_pre,
+    const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ wp, int C,
+    float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl,
+    float* __restrict__ pz) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  // sm: [4][E] wave z-accumulators, then [4] m, [4] l
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ldu = A * (1 + gated);
+  const float bias_c = bc ? bc[0] : 0.f;
+
+  float mw = -INFINITY, lw = 0.f, zacc[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; ++q) zacc[q] = 0.f;
+
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+    const float* up = u_pre + n * ldu;
+    float part = 0.f;
+    for (int j = lane; j < A; j += 64) {
+      float u = act_fwd(up[j], act);
+      if (gated) u *= sigmoidf_(up[A + j]);
+      part += wc[j] * u;
+    }
+    const float s = wave_sum(part) + bias_c;
+    const float* h = T + n * (int64_t)E;
+    float hv[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) hv[q] = h[lane + 64 * q];
+    if (wp) {
+      for (int c = 0; c < C; ++c) {
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) d += hv[q] * wp[c * E + lane + 64 * q];
+        d = wave_sum(d);
+        if (lane == 0) cproj[n * C + c] = d;
+      }
+    }
+    if (lane == 0) s_out[n] = s;
+    if (s > mw) {
+      const float sc = (mw == -INFINITY) ? 0.f : __expf(mw - s);
+      lw = lw * sc + 1.f;
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) zacc[q] = zacc[q] * sc + hv[q];
+      mw = s;
+    } else {
+      const float p = __expf(s - mw);
+      lw += p;
+#pragma unroll
+      for (int q = 0; q < EPL; ++q) zacc[q] += p * hv[q];
+    }
+  }
+  float* zs = sm;
+  float* ms = sm + 4 * E;
+  float* ls = ms + 4;
+#pragma unroll
+  for (int q = 0; q < EPL; ++q) zs[wave * E + lane + 64 * q] = zacc[q];
+  if (lane == 0) { ms[wave] = mw; ls[wave] = lw; }
+  __syncthreads();
+  const float mb = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
+  float w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (ms[i] == -INFINITY) ? 0.f : __expf(ms[i] - mb);
+  for (int e = threadIdx.x; e < E; e += ROWS_THREADS)
+    pz[(int64_t)blockIdx.x * E + e] = zs[e] * w[0] + zs[E + e] * w[1] + zs[2 * E + e] * w[2] + zs[3 * E + e] * w[3];
+  if (threadIdx.x == 0) {
+    pm[blockIdx.x] = mb;
+    pl[blockIdx.x] = ls[0] * w[0] + ls[1] * w[1] + ls[2] * w[2] + ls[3] * w[3];
+  }
+}
+
+// merge G partials: stats = {max, sumexp}, z[e] = sum_b pz[b][e] e^{pm[b]-max} / sumexp
+__global__ void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                     const float* __restrict__ pz, int G, int E, float* __restrict__ stats,
+                                     float* __restrict__ z) {
+  __shared__ float red[ROWS_THREADS];
+  __shared__ float wgt[2 * MAX_PART];
+  float m = -INFINITY;
+  for (int b = threadIdx.x; b < G; b += blockDim.x) m = fmaxf(m, pm[b]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float mx = red[0];
+  __syncthreads();
+  for (int b = threadIdx.x; b < G; b += blockDim.x) wgt[b] = (pm[b] == -INFINITY) ? 0.f : __expf(pm[b] - mx);
+  __syncthreads();
+  // fixed-order sum of l (thread 0) keeps the result bit-reproducible run to run
+  __shared__ float Ls;
+  if (threadIdx.x == 0) {
+    float L = 0.f;
+    for (int b = 0; b < G; ++b) L += pl[b] * wgt[b];
+    Ls = L;
+    stats[0] = mx;
+    stats[1] = L;
+  }
+  __syncthreads();
+  const float inv = 1.f / Ls;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < G; ++b) acc += pz[(int64_t)b * E + e] * wgt[b];
+    z[e] = acc * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward rows: ds_n = A_n (g_z.h_n - g_z.z); du = ds * wc * act'(a) [gated forms]; attn_n = A_n
+// ------------------------------------------------------------------------------------------------
+template <int EPL>
+__global__ __launch_bounds__(ROWS_THREADS) void score_rows_bwd_kernel(
+    const float* __restrict__ T, int64_t M, int E, int A, int act, int gated, const float* __restrict__ u_pre,
+    const float* __restrict__ wc, const float* __restrict__ s_in, const float* __restrict__ stats,
+    const float* __restrict__ g_z, const float* __restrict__ z, float* __restrict__ du, float* __restrict__ attn,
+    float* __restrict__ dwc_part, float* __restrict__ dbc_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][A] dwc, [4] dbc
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ldu = A * (1 + gated);
+  float gz[EPL];
+  float c0 = 0.f;
+#pragma unroll
+  for (int q = 0; q < EPL; ++q) {
+    gz[q] = g_z[lane + 64 * q];
+    c0 += gz[q] * z[lane + 64 * q];
+  }
+  c0 = wave_sum(c0);
+  const float mx = stats[0], invL = 1.f / stats[1];
+  constexpr int MAXJ = 8;                      // A <= 512
+  float dwc[MAXJ];
+#pragma unroll
+  for (int i = 0; i < MAXJ; ++i) dwc[i] = 0.f;
+  float dbc = 0.f;
+
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+    const float* h = T + n * (int64_t)E;
+    float gh = 0.f;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) gh += gz[q] * h[lane + 64 * q];
+    gh = wave_sum(gh);
+    const float an = __expf(s_in[n] - mx) * invL;
+    const float ds = an * (gh - c0);
+    if (lane == 0) attn[n] = an;
+    dbc += ds;
+    const float* up = u_pre + n * ldu;
+    float* dp = du + n * ldu;
+#pragma unroll
+    for (int i = 0; i < MAXJ; ++i) {
+      const int j = lane + 64 * i;
+      if (j < A) {
+        const float a = up[j];
+        const float ya = act_fwd(a, act);
+        const float ga = act_grad(a, ya, act);
+        if (gated) {
+          const float sg = sigmoidf_(up[A + j]);
+          dp[j] = ds * wc[j] * sg * ga;
+          dp[A + j] = ds * wc[j] * ya * sg * (1.f - sg);
+          dwc[i] += ds * ya * sg;
+        } else {
+          dp[j] = ds * wc[j] * ga;
+          dwc[i] += ds * ya;
+        }
+      }
+    }
+  }
+  float* ws = sm;
+  float* bs = sm + 4 * A;
+#pragma unroll
+  for (int i = 0; i < MAXJ; ++i) {
+    const int j = lane + 64 * i;
+    if (j < A) ws[wave * A + j] = dwc[i];
+  }
+  if (lane == 0) bs[wave] = dbc;       // every lane holds the same dbc
+  __syncthreads();
+  for (int j = threadIdx.x; j < A; j += ROWS_THREADS)
+    dwc_part[(int64_t)blockIdx.x * A + j] = ws[j] + ws[A + j] + ws[2 * A + j] + ws[3 * A + j];
+  if (threadIdx.x == 0) dbc_part[blockIdx.x] = bs[0] + bs[1] + bs[2] + bs[3];
+}
+
+// out[j] (+)= sum_b part[b][j]   (fixed order)
+__global__ void reduce_parts_kernel(const float* __restrict__ part, int G, int W, int ld, float* __restrict__ out, int accumulate) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W; j += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < G; ++b) acc += part[(int64_t)b * ld + j];
+    out[j] = accumulate ? out[j] + acc : acc;
+  }
+}
+
+__global__ void softmax_from_stats_kernel(const float* __restrict__ s, const float* __restrict__ stats,
+                                          float* __restrict__ attn, int64_t M) {
+  const float mx = stats[0], invL = 1.f / stats[1];
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < M; n += (int64_t)gridDim.x * blockDim.x)
+    attn[n] = __expf(s[n] - mx) * invL;
+}
+
+// score_n = max_c softmax_c(attn_n * cproj[n,c] + bp[0]) = 1 / sum_c exp(cam_c - max_c cam)
+__global__ void pseudo_score_kernel(const float* __restrict__ s, const float* __restrict__ stats,
+                                    const float* __restrict__ cproj, const float* __restrict__ bp,
+                                    float* __restrict__ score, float* __restrict__ attn_out, int64_t M, int C) {
+  const float mx = stats[0], invL = 1.f / stats[1];
+  const float b0 = bp ? bp[0] : 0.f;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < M; n += (int64_t)gridDim.x * blockDim.x) {
+    const float an = __expf(s[n] - mx) * invL;
+    if (attn_out) attn_out[n] = an;
+    float cm = -INFINITY;
+    for (int c = 0; c < C; ++c) cm = fmaxf(cm, an * cproj[n * C + c] + b0);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf((an * cproj[n * C + c] + b0) - cm);
+    score[n] = 1.f / den;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-5, biased variance), one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ROWS_THREADS) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t M, int E,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+    const float* xr = x + n * (int64_t)E;
+    float sum = 0.f;
+    for (int e = lane; e < E; e += 64) sum += xr[e];
+    const float mu = wave_sum(sum) / (float)E;
+    float var = 0.f;
+    for (int e = lane; e < E; e += 64) { const float d = xr[e] - mu; var += d * d; }
+    const float rs = rsqrtf(wave_sum(var) / (float)E + 1e-5f);
+    for (int e = lane; e < E; e += 64) y[n * (int64_t)E + e] = (xr[e] - mu) * rs * w[e] + b[e];
+    if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
+  }
+}
+
+// dx = rstd*(dy*w - mean(dy*w) - xhat*mean(dy*w*xhat)); per-block partial dw = sum dy*xhat, db = sum dy
+__global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int E, const float* __restrict__ w,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+    float* __restrict__ dw_part, float* __restrict__ db_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dw, [4][E] db
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int MAXQ = 16;                    // E <= 1024
+  float dwa[MAXQ], dba[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) dwa[q] = dba[q] = 0.f;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+    const float mu = mean[n], rs = rstd[n];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int e = lane + 64 * q;
+      if (e < E) {
+        const float g = dy[n * (int64_t)E + e];
+        const float xh = (x[n * (int64_t)E + e] - mu) * rs;
+        const float gw = g * w[e];
+        s1 += gw; s2 += gw * xh;
+        dwa[q] += g * xh; dba[q] += g;
+      }
+    }
+    s1 = wave_sum(s1) / (float)E;
+    s2 = wave_sum(s2) / (float)E;
+    if (dx) {
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        const int e = lane + 64 * q;
+        if (e < E) {
+          const float xh = (x[n * (int64_t)E + e] - mu) * rs;
+          dx[n * (int64_t)E + e] = rs * (dy[n * (int64_t)E + e] * w[e] - s1 - xh * s2);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int e = lane + 64 * q;
+    if (e < E) { sm[wave * E + e] = dwa[q]; sm[(4 + wave) * E + e] = dba[q]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += ROWS_THREADS) {
+    dw_part[(int64_t)blockIdx.x * E + e] = sm[e] + sm[E + e] + sm[2 * E + e] + sm[3 * E + e];
+    db_part[(int64_t)blockIdx.x * E + e] = sm[4 * E + e] + sm[5 * E + e] + sm[6 * E + e] + sm[7 * E + e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// feature activation backward (in place on dH) and column sums
+// ------------------------------------------------------------------------------------------------
+__global__ void act_bwd_kernel(float* __restrict__ dH, const float* __restrict__ H, const float* __restrict__ pre,
+                               int64_t M, int E, int act, float drop_p, uint64_t seed,
+                               const uint8_t* __restrict__ drop_mask, const int64_t* __restrict__ rows) {
+  const int64_t total = M * (int64_t)E;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / E;
+    const int e = (int)(i - m * E);
+    float g = dH[i];
+    bool keep = true;
+    if (drop_mask) keep = drop_mask[i] != 0;
+    else if (drop_p > 0.f) keep = drop_keep(seed, rows ? (uint64_t)rows[m] : (uint64_t)m, (uint32_t)e, drop_p);
+    if (!keep) { dH[i] = 0.f; continue; }
+    g *= inv_keep;
+    if (act == MHIMX_ACT_RELU) {
+      // H = relu(pre) * keep/(1-p): positive exactly where pre > 0
+      g = (pre ? pre[i] > 0.f : H[i] > 0.f) ? g : 0.f;
+    } else if (act != MHIMX_ACT_NONE) {
+      const float x = pre[i];
+      g *= act_grad(x, act == MHIMX_ACT_TANH ? tanhf(x) : 0.f, act);
+    }
+    dH[i] = g;
+  }
+}
+
+__global__ void colsum_part_kernel(const float* __restrict__ X, int64_t M, int E, int64_t chunk, float* __restrict__ part) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t mb = (int64_t)blockIdx.y * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+  float acc = 0.f;
+  for (int64_t m = mb; m < me; ++m) acc += X[m * (int64_t)E + e];
+  part[(int64_t)blockIdx.y * E + e] = acc;
+}
+
+__global__ void compose_ids_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[b[i]];
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+static int grid_for_rows(int64_t M) {
+  int64_t g = cdiv(M, 32);
+  if (g < 1) g = 1;
+  if (g > MAX_PART) g = MAX_PART;
+  return (int)g;
+}
+
+struct PoolWs {
+  float *pm, *pl, *pz, *attn, *du, *dwc_part, *dbc_part, *u_pre;
+};
+
+static int64_t pool_ws_layout(Arena& ar, int64_t M, int64_t E, int64_t A, int gated, PoolWs* w) {
+  const int64_t G = 2 * MAX_PART;
+  PoolWs t;
+  t.pm = ar.take<float>(G);
+  t.pl = ar.take<float>(G);
+  t.pz = ar.take<float>(G * E);
+  t.attn = ar.take<float>(M);
+  t.du = ar.take<float>(M * A * (1 + gated));
+  t.dwc_part = ar.take<float>(G * A);
+  t.dbc_part = ar.take<float>(G);
+  t.u_pre = ar.take<float>(M * A * (1 + gated));
+  if (w) *w = t;
+  return ar.off;
+}
+
+template <typename F>
+static int dispatch_epl(int64_t E, F&& f) {
+  switch (E) {
+    case 256: return f(std::integral_constant<int, 4>());
+    case 512: return f(std::integral_constant<int, 8>());
+    case 1024: return f(std::integral_constant<int, 16>());
+    default: return fail(-1, "token width E=%lld unsupported (256, 512 or 1024)", (long long)E);
+  }
+}
+
+static int check_scorer(const mhimx_scorer* sc) {
+  MHIMX_CHECK_ARG(sc && sc->wa && sc->wc, "scorer: null weights");
+  MHIMX_CHECK_ARG(sc->A > 0 && sc->A <= 512 && sc->A % 4 == 0, "scorer: A must be a multiple of 4, <= 512");
+  MHIMX_CHECK_ARG(!sc->gated || sc->wb, "scorer: gated needs wb");
+  return 0;
+}
+
+int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* io) {
+  if (int r = check_scorer(sc)) return r;
+  MHIMX_CHECK_ARG(io && io->T1 && io->M1 > 0 && io->s && io->stats && io->z, "pool_fwd: null io");
+  MHIMX_CHECK_ARG(io->M2 == 0 || io->T2, "pool_fwd: M2>0 needs T2");
+  MHIMX_CHECK_ARG(!io->cproj || (io->wp && io->C > 0), "pool_fwd: cproj needs wp, C");
+  const int64_t M = io->M1 + io->M2, E = sc->E, A = sc->A;
+  const int gated = sc->gated ? 1 : 0;
+  Arena ar(io->ws, io->ws_bytes);
+  PoolWs w;
+  pool_ws_layout(ar, M, E, A, gated, &w);
+  MHIMX_CHECK_ARG(ar.ok(), "pool_fwd: workspace too small (%lld < %lld)", (long long)io->ws_bytes, (long long)ar.off);
+  float* u_pre = io->u_pre ? io->u_pre : w.u_pre;
+  const int64_t ldu = A * (1 + gated);
+
+  const float* Ts[2] = {io->T1, io->T2};
+  const int64_t Ms[2] = {io->M1, io->M2};
+  int64_t off = 0;
+  int G = 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    if (Ms[seg] == 0) continue;
+    mhimx_gemm_nt_args g = {};
+    g.A = Ts[seg]; g.lda = E; g.B = sc->wa; g.ldb = E; g.C = u_pre + off * ldu; g.ldc = ldu;
+    g.M = Ms[seg]; g.N = A; g.K = E; g.bias = sc->ba; g.prec = sc->prec;
+    if (int r = gemm_nt(st, g)) return r;
+    if (gated) {
+      g.B = sc->wb; g.bias = sc->bb; g.C = u_pre + off * ldu + A;
+      if (int r = gemm_nt(st, g)) return r;
+    }
+    const int grid = grid_for_rows(Ms[seg]);
+    const float* Tseg = Ts[seg];
+    const int64_t Mseg = Ms[seg];
+    int r = dispatch_epl(E, [&](auto epl) {
+      constexpr int EPL = decltype(epl)::value;
+      const size_t smem = (size_t)(4 * E + 8) * sizeof(float);
+      hipLaunchKernelGGL(score_rows_fwd_kernel<EPL>, dim3(grid), dim3(ROWS_THREADS), smem, st, Tseg, Mseg, (int)E, (int)A,
+                         sc->act, gated, u_pre + off * ldu, sc->wc, sc->bc, io->cproj ? io->wp : nullptr, (int)io->C,
+                         io->s + off, io->cproj ? io->cproj + off * io->C : nullptr, w.pm + G, w.pl + G,
+                         w.pz + (int64_t)G * E);
+      MHIMX_LAUNCH_CHECK();
+      return 0;
+    });
+    if (r) return r;
+    G += grid;
+    off += Ms[seg];
+  }
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3(1), dim3(ROWS_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* gr) {
+  if (int r = check_scorer(sc)) return r;
+  MHIMX_CHECK_ARG(io && gr && gr->g_z && gr->dT1 && gr->d_wa && gr->d_wc && gr->wa_t, "pool_bwd: null args");
+  MHIMX_CHECK_ARG(io->M2 == 0 || gr->dT2, "pool_bwd: M2>0 needs dT2");
+  const int64_t M = io->M1 + io->M2, E = sc->E, A = sc->A;
+  const int gated = sc->gated ? 1 : 0;
+  MHIMX_CHECK_ARG(!gated || (gr->d_wb && gr->wb_t), "pool_bwd: gated needs d_wb, wb_t");
+  Arena ar(io->ws, io->ws_bytes);
+  PoolWs w;
+  pool_ws_layout(ar, M, E, A, gated, &w);
+  MHIMX_CHECK_ARG(ar.ok(), "pool_bwd: workspace too small");
+  const float* u_pre = io->u_pre ? io->u_pre : w.u_pre;
+  const int64_t ldu = A * (1 + gated);
+  const float* Ts[2] = {io->T1, io->T2};
+  float* dTs[2] = {gr->dT1, gr->dT2};
+  const int64_t Ms[2] = {io->M1, io->M2};
+
+  int64_t off = 0;
+  int G = 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    if (Ms[seg] == 0) continue;
+    const int grid = grid_for_rows(Ms[seg]);
+    const float* Tseg = Ts[seg];
+    const int64_t Mseg = Ms[seg];
+    int r = dispatch_epl(E, [&](auto epl) {
+      constexpr int EPL = decltype(epl)::value;
+      const size_t smem = (size_t)(4 * A + 8) * sizeof(float);
+      hipLaunchKernelGGL(score_rows_bwd_kernel<EPL>, dim3(grid), dim3(ROWS_THREADS), smem, st, Tseg, Mseg, (int)E, (int)A,
+                         sc->act, gated, u_pre + off * ldu, sc->wc, io->s + off, io->stats, gr->g_z, io->z,
+                         w.du + off * ldu, w.attn + off, w.dwc_part + (int64_t)G * A, w.dbc_part + G);
+      MHIMX_LAUNCH_CHECK();
+      return 0;
+    });
+    if (r) return r;
+    G += grid;
+    off += Ms[seg];
+  }
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
+  MHIMX_LAUNCH_CHECK();
+  if (gr->d_bc) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(64), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
+    MHIMX_LAUNCH_CHECK();
+  }
+  off = 0;
+  for (int seg = 0; seg < 2; ++seg) {
+    if (Ms[seg] == 0) continue;
+    // dT = du_a . Wa + attn (x) g_z  [+ du_b . Wb]
+    mhimx_gemm_nt_args g = {};
+    g.A = w.du + off * ldu; g.lda = ldu; g.B = gr->wa_t; g.ldb = A; g.C = dTs[seg]; g.ldc = E;
+    g.M = Ms[seg]; g.N = E; g.K = A; g.rowv = w.attn + off; g.colv = gr->g_z; g.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
+    if (int r = gemm_nt(st, g)) return r;
+    if (gated) {
+      g.A = w.du + off * ldu + A; g.B = gr->wb_t; g.rowv = nullptr; g.colv = nullptr; g.accumulate = 1;
+      if (int r = gemm_nt(st, g)) return r;
+    }
+    // d_wa (+)= du_a^T T ; d_wb likewise
+    mhimx_gemm_tn_args t = {};
+    t.A = w.du + off * ldu; t.lda = ldu; t.B = Ts[seg]; t.ldb = E; t.C = gr->d_wa; t.ldc = E;
+    t.M = Ms[seg]; t.K1 = A; t.K2 = E; t.splits = 1; t.accumulate = (gr->accumulate || seg > 0) ? 1 : 0;
+    t.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
+    // split the long reduction over the pz scratch (free at this point): needs splits*A*E floats
+    int splits = gr->splits > 1 ? gr->splits : 1;
+    while (splits > 1 && (int64_t)splits * A * E > (int64_t)2 * MAX_PART * E) splits >>= 1;
+    if (Ms[seg] < 2048) splits = 1;
+    t.splits = splits; t.ws = w.pz;
+    if (int r = gemm_tn(st, t)) return r;
+    if (gated) {
+      t.A = w.du + off * ldu + A; t.C = gr->d_wb;
+      if (int r = gemm_tn(st, t)) return r;
+    }
+    off += Ms[seg];
+  }
+  // bias gradients of the standalone (biased) scorers: column sums of du
+  if (gr->d_ba || gr->d_bb) {
+    const int64_t W = ldu;
+    const int64_t chunk = cdiv(M, 64);
+    const int gy = (int)cdiv(M, chunk);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(W, 128), gy), dim3(128), 0, st, w.du, M, (int)W, chunk, w.pz);
+    MHIMX_LAUNCH_CHECK();
+    if (gr->d_ba) {
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, w.pz, gy, (int)A, (int)W, gr->d_ba, gr->accumulate);
+      MHIMX_LAUNCH_CHECK();
+    }
+    if (gr->d_bb && gated) {
+      // columns [A, 2A): strided view handled by offsetting the partial pointer (row pitch W)
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, w.pz + A, gy, (int)A, (int)W, gr->d_bb, gr->accumulate);
+      MHIMX_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y,
+                  float* mean, float* rstd) {
+  MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for_rows(M)), dim3(ROWS_THREADS), 0, st, x, M, (int)E, w, b, y, mean, rstd);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+// partials: dw_part/db_part [grid][E] scratch; d_w/d_b (+)= reduced
+int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
+                  const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate) {
+  MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
+  if (M == 0) return 0;
+  const int grid = grid_for_rows(M);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
+                     w, mean, rstd, dx, dw_part, db_part);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 128)), dim3(128), 0, st, dw_part, grid, (int)E, (int)E, d_w, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 128)), dim3(128), 0, st, db_part, grid, (int)E, (int)E, d_b, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(X && out && E > 0 && M >= 0, "colsum: bad args");
+  const int64_t chunk = cdiv(M > 0 ? M : 1, 128);
+  const int gy = (int)cdiv(M > 0 ? M : 1, chunk);
+  MHIMX_CHECK_ARG(ws && ws_bytes >= (int64_t)gy * E * 4, "colsum: workspace too small (need %lld bytes)", (long long)(gy * E * 4));
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(E, 128), gy), dim3(128), 0, st, X, M, (int)E, chunk, (float*)ws);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 128)), dim3(128), 0, st, (const float*)ws, gy, (int)E, (int)E, out, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mhimx
+
+using namespace mhimx;
+
+extern "C" int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated) {
+  Arena ar(nullptr, 0);
+  return pool_ws_layout(ar, M, E, A, gated ? 1 : 0, nullptr);
+}
+extern "C" int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io) {
+  return abmil_pool_fwd((hipStream_t)stream, sc, io);
+}
+extern "C" int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* g) {
+  return abmil_pool_bwd((hipStream_t)stream, sc, io, g);
+}
+extern "C" int mhimx_softmax_from_stats(void* stream, const float* s, const float* stats, float* attn, int64_t M) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(softmax_from_stats_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, s, stats, attn, M);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_pseudo_score(void* stream, const float* s, const float* stats, const float* cproj, const float* bp,
+                                  float* score, float* attn_out, int64_t M, int64_t C) {
+  MHIMX_CHECK_ARG(s && stats && cproj && score && C > 0, "pseudo_score: null args");
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(pseudo_score_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, s, stats, cproj, bp, score, attn_out, M, (int)C);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int64_t M, int64_t E, int32_t act,
+                             float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows) {
+  MHIMX_CHECK_ARG(dH && (H || pre), "act_bwd: null args");
+  MHIMX_CHECK_ARG(act == MHIMX_ACT_NONE || act == MHIMX_ACT_RELU || pre, "act_bwd: gelu/tanh need the pre-activation");
+  if (M <= 0) return 0;
+  const int64_t total = M * E;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, dH, H, pre, M, (int)E, act, drop_p, drop_seed, drop_mask, rows);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate, void* ws,
+                            int64_t ws_bytes) {
+  return colsum((hipStream_t)stream, X, M, E, out, accumulate, ws, ws_bytes);
+}
+extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(compose_ids_kernel, dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, out, n);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}

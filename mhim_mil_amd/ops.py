@@ -1,0 +1,297 @@
+"""Thin tensor-level wrappers over the C-ABI (one Python function per entry point of include/mhimx.h).
+
+PyTorch is only plumbing here: it owns the device memory and the stream.  Every function enqueues on
+torch's current HIP stream and returns immediately (no host sync).  Tensors must be fp32 (indices int64),
+contiguous and on the GPU; nothing falls back to torch math.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise L.MhimxError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise L.MhimxError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.MhimxError(f"{name}: expected a contiguous tensor")
+
+
+def prec_code(prec) -> int:
+    return L.PREC[prec] if isinstance(prec, str) else int(prec)
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, colv=None, drop_p=0.0, drop_seed=0,
+            drop_mask=None, accumulate=False, prec="f16s", M=None):
+    """out[m,n] = epi(sum_k a[rows[m] or m, k] * b[n,k]) — see mhimx_gemm_nt."""
+    for t, nm in ((a, "a"), (b, "b"), (bias, "bias"), (pre, "pre"), (rowv, "rowv"), (colv, "colv"), (out, "out")):
+        _chk(t, name=nm)
+    _chk(rows, torch.int64, "rows")
+    _chk(drop_mask, torch.uint8, "drop_mask")
+    K = a.shape[-1]
+    N = b.shape[0]
+    if M is None:
+        M = rows.shape[0] if rows is not None else a.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    g = L.GemmNT(A=_p(a), lda=a.stride(0) if a.dim() == 2 else K, rows=_p(rows), B=_p(b), ldb=b.stride(0), C=_p(out),
+                 ldc=out.stride(0), M=M, N=N, K=K, bias=_p(bias), rowv=_p(rowv), colv=_p(colv), pre=_p(pre),
+                 ldpre=pre.stride(0) if pre is not None else 0, act=int(act), drop_p=float(drop_p),
+                 drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(drop_mask), accumulate=int(bool(accumulate)),
+                 prec=prec_code(prec))
+    L.check(L.lib().mhimx_gemm_nt(_stream(), C.byref(g)), "mhimx_gemm_nt")
+    return out
+
+
+def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3", M=None):
+    """out[i,j] = sum_m a[m,i] * b[rows[m] or m, j] — see mhimx_gemm_tn."""
+    _chk(a, name="a"); _chk(b, name="b"); _chk(out, name="out"); _chk(rows, torch.int64, "rows")
+    if M is None:
+        M = a.shape[0]
+    K1, K2 = a.shape[1], b.shape[1]
+    if out is None:
+        out = torch.empty((K1, K2), device=a.device, dtype=torch.float32)
+    ws = torch.empty((splits, K1, K2), device=a.device, dtype=torch.float32) if splits > 1 else None
+    g = L.GemmTN(A=_p(a), lda=a.stride(0), B=_p(b), ldb=b.stride(0), rows=_p(rows), C=_p(out), ldc=out.stride(0), M=M,
+                 K1=K1, K2=K2, splits=int(splits), ws=_p(ws), accumulate=int(bool(accumulate)), prec=prec_code(prec))
+    L.check(L.lib().mhimx_gemm_tn(_stream(), C.byref(g)), "mhimx_gemm_tn")
+    return out
+
+
+def transpose(x, out=None):
+    _chk(x, name="x")
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty((Cc, R), device=x.device, dtype=torch.float32)
+    L.check(L.lib().mhimx_transpose(_stream(), _p(x), _p(out), R, Cc), "mhimx_transpose")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ pool
+class ScorerW:
+    """Scorer weights in the C layout (keeps the tensors alive)."""
+
+    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="f16s"):
+        self.t = (wa, wc, ba, wb, bb, bc)
+        for t in self.t:
+            _chk(t, name="scorer weight")
+        self.A, self.E = wa.shape
+        self.gated = wb is not None
+        self.c = L.Scorer(E=self.E, A=self.A, act=int(act), gated=int(self.gated), prec=prec_code(prec), wa=_p(wa),
+                          ba=_p(ba), wb=_p(wb), bb=_p(bb), wc=_p(wc), bc=_p(bc))
+
+
+class PoolState:
+    """Buffers of one pool forward (kept for the backward)."""
+
+    def __init__(self, T1, T2, C_classes=0, wp=None, device=None):
+        dev = T1.device
+        M1 = T1.shape[0]
+        M2 = 0 if T2 is None else T2.shape[0]
+        self.T1, self.T2, self.M1, self.M2 = T1, T2, M1, M2
+        M = M1 + M2
+        self.s = torch.empty(M, device=dev)
+        self.stats = torch.empty(2, device=dev)
+        self.z = torch.empty(T1.shape[1], device=dev)
+        self.cproj = torch.empty((M, C_classes), device=dev) if wp is not None else None
+        self.wp = wp
+        self.ws = None
+
+    def io(self, sc: ScorerW):
+        M = self.M1 + self.M2
+        nbytes = L.lib().mhimx_abmil_pool_ws_bytes(M, sc.E, sc.A, int(sc.gated))
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = torch.empty(nbytes, device=self.T1.device, dtype=torch.uint8)
+        return L.PoolIO(T1=_p(self.T1), M1=self.M1, T2=_p(self.T2), M2=self.M2, s=_p(self.s), stats=_p(self.stats),
+                        z=_p(self.z), u_pre=None, wp=_p(self.wp), C=0 if self.cproj is None else self.cproj.shape[1],
+                        cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel())
+
+
+def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None):
+    """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj)."""
+    _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp")
+    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp)
+    io = st.io(sc)
+    L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd")
+    return st
+
+
+def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=False, splits=8, grads=None,
+                   accumulate=False):
+    """Backward of the pool.  Returns dict(dT1, dT2, d_wa, d_wc, [d_wb, d_ba, d_bb, d_bc])."""
+    dev = g_z.device
+    E, A = sc.E, sc.A
+    out = grads or {}
+    out.setdefault("dT1", torch.empty((st.M1, E), device=dev))
+    if st.M2:
+        out.setdefault("dT2", torch.empty((st.M2, E), device=dev))
+    out.setdefault("d_wa", torch.empty((A, E), device=dev))
+    out.setdefault("d_wc", torch.empty((1, A), device=dev))
+    if sc.gated:
+        out.setdefault("d_wb", torch.empty((A, E), device=dev))
+    if need_bias:
+        out.setdefault("d_ba", torch.empty(A, device=dev))
+        out.setdefault("d_bc", torch.empty(1, device=dev))
+        if sc.gated:
+            out.setdefault("d_bb", torch.empty(A, device=dev))
+    io = st.io(sc)
+    g = L.PoolGrad(g_z=_p(g_z), dT1=_p(out["dT1"]), dT2=_p(out.get("dT2")), d_wa=_p(out["d_wa"]), d_ba=_p(out.get("d_ba")),
+                   d_wb=_p(out.get("d_wb")), d_bb=_p(out.get("d_bb")), d_wc=_p(out["d_wc"]), d_bc=_p(out.get("d_bc")),
+                   wa_t=_p(wa_t), wb_t=_p(wb_t), accumulate=int(bool(accumulate)), splits=int(splits))
+    L.check(L.lib().mhimx_abmil_pool_bwd(_stream(), C.byref(sc.c), C.byref(io), C.byref(g)), "mhimx_abmil_pool_bwd")
+    return out
+
+
+def softmax_from_stats(s, stats):
+    out = torch.empty_like(s)
+    L.check(L.lib().mhimx_softmax_from_stats(_stream(), _p(s), _p(stats), _p(out), s.numel()), "mhimx_softmax_from_stats")
+    return out
+
+
+def pseudo_score(s, stats, cproj, bp, want_attn=False):
+    score = torch.empty_like(s)
+    attn = torch.empty_like(s) if want_attn else None
+    L.check(L.lib().mhimx_pseudo_score(_stream(), _p(s), _p(stats), _p(cproj), _p(bp), _p(score), _p(attn), s.numel(),
+                                       cproj.shape[1]), "mhimx_pseudo_score")
+    return (score, attn) if want_attn else score
+
+
+# ------------------------------------------------------------------------------------------------ select
+def select_mask(score, k, n_sel, largest=True, perm=None, other=None, want_topk=False):
+    """Device-side select_mask_fn (2-D scores).  Returns (mask_ids int64 [N], len_keep_dev int64 [1], topk|None)."""
+    _chk(score, name="score"); _chk(perm, torch.int64, "perm"); _chk(other, torch.int64, "other")
+    N = score.numel()
+    dev = score.device
+    mask_ids = torch.empty(N, device=dev, dtype=torch.int64)
+    len_keep = torch.empty(1, device=dev, dtype=torch.int64)
+    topk = torch.empty(k, device=dev, dtype=torch.int64) if want_topk else None
+    ws = torch.empty(L.lib().mhimx_select_ws_bytes(N), device=dev, dtype=torch.uint8)
+    L.check(L.lib().mhimx_select_mask(_stream(), _p(score), N, int(k), int(n_sel), int(bool(largest)), _p(perm), _p(other),
+                                      0 if other is None else other.numel(), _p(mask_ids), _p(len_keep), _p(topk), _p(ws),
+                                      ws.numel()), "mhimx_select_mask")
+    return mask_ids, len_keep, topk
+
+
+def vote_scores(attn, k, largest=True):
+    _chk(attn, name="attn")
+    H, N = attn.shape
+    vote = torch.empty(N, device=attn.device)
+    L.check(L.lib().mhimx_vote_scores(_stream(), _p(attn), H, N, int(k), int(bool(largest)), _p(vote), None, 0),
+            "mhimx_vote_scores")
+    return vote
+
+
+def compose_ids(a, b):
+    _chk(a, torch.int64, "a"); _chk(b, torch.int64, "b")
+    out = torch.empty_like(b)
+    L.check(L.lib().mhimx_compose_ids(_stream(), _p(a), _p(b), _p(out), b.numel()), "mhimx_compose_ids")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ merge
+class MergeW:
+    def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
+                 prec="f16s", transposes=None):
+        self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo]
+        for t in self.t:
+            _chk(t, name="merge weight")
+        self.k, self.E = q_param.shape[-2], q_param.shape[-1]
+        self.heads, self.dim_head = heads, dim_head
+        self.tr = transposes or (None, None, None)
+        self.c = L.Merge(E=self.E, k=self.k, heads=heads, dim_head=dim_head, q_param=_p(q_param), ln_w=_p(ln_w),
+                         ln_b=_p(ln_b), wkv=_p(wkv), wq=_p(wq), wo=_p(wo), bo=_p(bo), wkv_t=_p(self.tr[0]),
+                         wq_t=_p(self.tr[1]), wo_t=_p(self.tr[2]), mm=float(mm), drop_p=float(drop_p),
+                         drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec))
+
+    def ws_for(self, R, device):
+        n = L.lib().mhimx_merge_ws_bytes(R, self.E, self.k, self.heads, self.dim_head)
+        return torch.empty(n, device=device, dtype=torch.uint8)
+
+
+def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None):
+    _chk(X, name="X")
+    R = X.shape[0]
+    dev = X.device
+    z = z_out if z_out is not None else torch.empty((mw.k, mw.E), device=dev)
+    q_new = torch.empty((mw.k, mw.E), device=dev) if update_q else None
+    ws = ws if ws is not None else mw.ws_for(R, dev)
+    L.check(L.lib().mhimx_merge_fwd(_stream(), C.byref(mw.c), _p(X), R, _p(z), _p(q_new), int(bool(update_q)), _p(ws),
+                                    ws.numel()), "mhimx_merge_fwd")
+    return z, q_new, ws
+
+
+def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False):
+    dev = X.device
+    R, E = X.shape
+    I = mw.heads * mw.dim_head
+    out = grads or {}
+    out.setdefault("dX", torch.empty((R, E), device=dev))
+    out.setdefault("d_ln_w", torch.empty(E, device=dev))
+    out.setdefault("d_ln_b", torch.empty(E, device=dev))
+    out.setdefault("d_wkv", torch.empty((2 * I, E), device=dev))
+    out.setdefault("d_wq", torch.empty((I, E), device=dev))
+    out.setdefault("d_wo", torch.empty((E, I), device=dev))
+    out.setdefault("d_bo", torch.empty(E, device=dev))
+    g = L.MergeGrad(d_ln_w=_p(out["d_ln_w"]), d_ln_b=_p(out["d_ln_b"]), d_wkv=_p(out["d_wkv"]), d_wq=_p(out["d_wq"]),
+                    d_wo=_p(out["d_wo"]), d_bo=_p(out["d_bo"]), accumulate=int(bool(accumulate)), splits=int(splits))
+    L.check(L.lib().mhimx_merge_bwd(_stream(), C.byref(mw.c), _p(X), R, _p(dz), _p(out["dX"]), C.byref(g), _p(ws),
+                                    ws.numel()), "mhimx_merge_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ misc
+def act_bwd(dH, H, pre, act, drop_p=0.0, drop_seed=0, drop_mask=None, rows=None):
+    M, E = dH.shape
+    L.check(L.lib().mhimx_act_bwd(_stream(), _p(dH), _p(H), _p(pre), M, E, int(act), float(drop_p),
+                                  int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(drop_mask), _p(rows)), "mhimx_act_bwd")
+    return dH
+
+
+def colsum(X, out=None, accumulate=False):
+    M, E = X.shape
+    if out is None:
+        out = torch.empty(E, device=X.device)
+    ws = torch.empty(128 * E, device=X.device)
+    L.check(L.lib().mhimx_colsum(_stream(), _p(X), M, E, _p(out), int(bool(accumulate)), _p(ws), ws.numel() * 4), "mhimx_colsum")
+    return out
+
+
+def head_fwd_bwd(z, t, wp, bp, label, temp_t=1.0, main_alpha=1.0, aux_alpha=0.0, inv_accum=1.0, d_wp=None, d_bp=None,
+                 accumulate=False):
+    """logits, losses[3] = {main*ce + aux*cl, ce, cl}, g_z, d_wp, d_bp."""
+    dev = z.device
+    Cc, E = wp.shape
+    logits = torch.empty(Cc, device=dev)
+    losses = torch.empty(3, device=dev)
+    g_z = torch.empty(E, device=dev)
+    d_wp = d_wp if d_wp is not None else torch.empty_like(wp)
+    d_bp = d_bp if d_bp is not None else torch.empty(Cc, device=dev)
+    L.check(L.lib().mhimx_head_fwd_bwd(_stream(), _p(z), _p(t), _p(wp), _p(bp), _p(label), E, Cc, float(temp_t),
+                                       float(main_alpha), float(aux_alpha), float(inv_accum), _p(logits), _p(losses),
+                                       _p(g_z), _p(d_wp), _p(d_bp), int(bool(accumulate))), "mhimx_head_fwd_bwd")
+    return logits, losses, g_z, d_wp, d_bp
+
+
+def adam_ema(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5,
+             grad_scale=1.0, ema_mm=0.9997, zero_grad=True):
+    n_all = p.numel()
+    L.check(L.lib().mhimx_adam_ema(_stream(), _p(p), _p(g), _p(m), _p(v), _p(teacher), int(n_train), int(n_all), int(step),
+                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                   float(grad_scale), float(ema_mm), int(bool(zero_grad))), "mhimx_adam_ema")

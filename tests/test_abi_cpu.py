@@ -1,0 +1,34 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/mhimx.h declares."""
+import os
+import re
+
+from mhim_mil_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mhimx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mhimx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.lib()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libmhimx.so lacks {n}"
+        assert n in L.SYMBOLS, f"ctypes binding lacks {n}"
+    assert set(L.SYMBOLS) == set(names)
+    assert lib.mhimx_version() == 100
+
+
+def test_argument_errors_are_reported_not_thrown():
+    lib = L.lib()
+    # no GPU needed: argument validation happens before any launch
+    assert lib.mhimx_gemm_nt(None, None) < 0
+    assert b"null" in lib.mhimx_last_error()
+    assert lib.mhimx_abmil_pool_ws_bytes(1000, 512, 128, 0) > 0
+    assert lib.mhimx_merge_ws_bytes(970, 512, 5, 8, 64) > 0
+    assert lib.mhimx_select_ws_bytes(10000) >= 10000
