@@ -202,11 +202,13 @@ int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out,
  *  logits[C] = Wp z + bp;  ce = -log softmax(logits)[label];  cl = -sum softmax(t/temp_t) log_softmax(z)
  *  loss = (main_alpha*ce + aux_alpha*cl)/accum;  out: losses[3] = {loss*accum, ce, cl};
  *  g_z[E], d_wp[C,E], d_bp[C] (of `loss`).  t may be NULL (aux term skipped, common_mil.py:24).
+ *  Autograd form: label_dev == NULL and g_logits_in[C] / g_cl_in[1] (device) carry the upstream gradients
+ *  of an externally computed criterion (the reference's trainer applies nn.CrossEntropyLoss itself).
  * ---------------------------------------------------------------------------------------- */
 int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float* wp, const float* bp,
                        const int64_t* label_dev, int64_t E, int64_t C, float temp_t, float main_alpha,
                        float aux_alpha, float inv_accum, float* logits, float* losses, float* g_z, float* d_wp,
-                       float* d_bp, int32_t accumulate);
+                       float* d_bp, int32_t accumulate, const float* g_logits_in, const float* g_cl_in);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser + EMA teacher                                       

@@ -205,20 +205,21 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   MergeWs w;
   merge_ws_layout(ar, R, E, k, H, m->dim_head, &w);
   MHIMX_CHECK_ARG(ar.ok(), "merge_fwd: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ar.off);
+  const int fprec = m->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;   // small GEMMs: ~fp32 accuracy
   if (int r = layernorm_fwd(st, X, R, E, m->ln_w, m->ln_b, w.xn, w.mean, w.rstd)) return r;
   if (int r = layernorm_fwd(st, m->q_param, k, E, m->ln_w, m->ln_b, w.gq, w.gmean, w.grstd)) return r;
   mhimx_gemm_nt_args g = {};
-  g.A = w.xn; g.lda = E; g.B = m->wkv; g.ldb = E; g.C = w.KV; g.ldc = 2 * I; g.M = R; g.N = 2 * I; g.K = E; g.prec = m->prec;
+  g.A = w.xn; g.lda = E; g.B = m->wkv; g.ldb = E; g.C = w.KV; g.ldc = 2 * I; g.M = R; g.N = 2 * I; g.K = E; g.prec = fprec;
   if (int r = gemm_nt(st, g)) return r;
   g = {};
-  g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = m->prec;
+  g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
   if (int r = gemm_nt(st, g)) return r;
   const float scale = 1.0f / sqrtf((float)m->dim_head);
   hipLaunchKernelGGL(mca_attend_fwd_kernel, dim3((unsigned)H, (unsigned)k), dim3(MCA_THREADS), 0, st, w.KV, w.Q, R, (int)H, (int)k,
                      scale, m->drop_p, m->drop_seed, w.P, w.O);
   MHIMX_LAUNCH_CHECK();
   g = {};
-  g.A = w.O; g.lda = I; g.B = m->wo; g.ldb = I; g.C = z; g.ldc = E; g.M = k; g.N = E; g.K = I; g.bias = m->bo; g.prec = m->prec;
+  g.A = w.O; g.lda = I; g.B = m->wo; g.ldb = I; g.C = z; g.ldc = E; g.M = k; g.N = E; g.K = I; g.bias = m->bo; g.prec = fprec;
   g.drop_p = m->drop_p; g.drop_seed = m->drop_seed + 0x9E3779B97F4A7C15ull;
   if (int r = gemm_nt(st, g)) return r;
   if (update_q) {

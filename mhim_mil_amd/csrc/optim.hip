@@ -30,7 +30,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restr
                                                             float main_alpha, float aux_alpha, float inv_accum,
                                                             float* __restrict__ logits, float* __restrict__ losses,
                                                             float* __restrict__ g_z, float* __restrict__ d_wp,
-                                                            float* __restrict__ d_bp, int accumulate) {
+                                                            float* __restrict__ d_bp, int accumulate,
+                                                            const float* __restrict__ g_logits_in,
+                                                            const float* __restrict__ g_cl_in) {
   __shared__ float red[4];
   __shared__ float lg[16], gl[16];
   const int tid = threadIdx.x;
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restr
     ce = -(lg[y] - mx - logf(den));
     if (tid < C) gl[tid] = main_alpha * inv_accum * (expf(lg[tid] - mx) / den - (tid == y ? 1.f : 0.f));
   } else if (tid < C) {
-    gl[tid] = 0.f;
+    gl[tid] = g_logits_in ? g_logits_in[tid] : 0.f;      // upstream dLoss/dlogits supplied by the caller (autograd path)
   }
+  if (g_cl_in) aux_alpha = g_cl_in[0];                  // upstream dLoss/dcl
   __syncthreads();
   // soft-target CE over the E feature dims: cl = -sum softmax(t/temp_t) * log_softmax(z)   (losses.py:40-43)
   float cl = 0.f;
@@ -124,11 +127,11 @@ using namespace mhimx;
 extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float* wp, const float* bp,
                                   const int64_t* label_dev, int64_t E, int64_t C, float temp_t, float main_alpha,
                                   float aux_alpha, float inv_accum, float* logits, float* losses, float* g_z, float* d_wp,
-                                  float* d_bp, int32_t accumulate) {
+                                  float* d_bp, int32_t accumulate, const float* g_logits_in, const float* g_cl_in) {
   MHIMX_CHECK_ARG(z && wp && logits && losses && g_z, "head: null args");
   MHIMX_CHECK_ARG(C > 0 && C <= 16 && E > 0, "head: bad dims");
   hipLaunchKernelGGL(head_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
-                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate);
+                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -412,7 +412,9 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     if (Ms[seg] == 0) continue;
     mhimx_gemm_nt_args g = {};
     g.A = Ts[seg]; g.lda = E; g.B = sc->wa; g.ldb = E; g.C = u_pre + off * ldu; g.ldc = ldu;
-    g.M = Ms[seg]; g.N = A; g.K = E; g.bias = sc->ba; g.prec = sc->prec;
+    g.M = Ms[seg]; g.N = A; g.K = E; g.bias = sc->ba;
+    // instance-level scores feed the top-k: keep them at ~fp32 accuracy (3-term bf16) unless exact f32 was asked for
+    g.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
     if (int r = gemm_nt(st, g)) return r;
     if (gated) {
       g.B = sc->wb; g.bias = sc->bb; g.C = u_pre + off * ldu + A;

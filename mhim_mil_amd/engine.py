@@ -1,0 +1,197 @@
+"""Train-step API for the MHIM path.
+
+``CommonMIL`` mirrors the hook object the reference trainer calls (engines/common_mil.py:1-68): same
+method names, keyword arguments and return tuples, so ``BaseTrainer.train/validate`` can drive the HIP
+model unchanged.
+
+``FusedTrainer`` is the MI355X-native step the benchmark times: teacher forward -> select -> student
+forward -> head (CE + distillation) -> hand-derived backward -> [RCCL all-reduce of ONE flat gradient
+buffer] -> fused Adam + EMA-teacher kernel.  It bypasses autograd and the per-parameter Python loops of
+base_engine.py:155-167 (one flat fp32 buffer each for student, teacher, gradient, Adam m and v), which is
+what makes a tens-of-microseconds bag step reachable at all.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .mhim import MHIM, BagPlan
+
+
+class CommonMIL:
+    """Hook object of the reference trainer (engines/common_mil.py)."""
+
+    def __init__(self, args=None) -> None:
+        self.training = True
+
+    def init_func_train(self, args, **kwargs):
+        self.training = True
+
+    def init_func_val(self, args, **kwargs):
+        self.training = False
+
+    def after_get_data_func(self, args, **kwargs):
+        pass
+
+    def after_backward_func(self, args, **kwargs):
+        pass
+
+    def final_train_func(self, args, **kwargs):
+        pass
+
+    def forward_func(self, args, model, model_ema, bag, label, criterion, batch_size, i, epoch, n_iter, pos, **kwargs):
+        """-> (logits, label, aux_loss, patch_num, keep_num, pad_ratio, kn_std)   (common_mil.py:14-48)"""
+        if getattr(args, "baseline", "attn") == "dsmil":
+            raise NotImplementedError("dsmil baseline: scope row N1 (SURVEY.md §8(f))")
+        if args.model == "mhim":
+            teacher_feat, score = (None, None)
+            if model_ema is not None:
+                teacher_feat, score = model_ema.forward_teacher(bag)
+            if args.aux_alpha == 0.:
+                teacher_feat = None                                        # common_mil.py:24
+            logits, aux_loss, patch_num, keep_num = model(bag, score, teacher_feat, i=n_iter, **kwargs)
+        elif args.model == "mhim_pure":
+            logits, aux_loss, patch_num, keep_num = model.pure(bag)
+        else:
+            raise NotImplementedError(f"model {args.model!r} is outside the MHIM hot path")
+        return logits, label, aux_loss, patch_num, keep_num, 0., 0.
+
+    def validate_func(self, args, model, bag, label, criterion, batch_size, i, pos, epoch=None, **kwargs):
+        """-> (logits, label)   (common_mil.py:56-68)"""
+        if args.model not in ("mhim", "mhim_pure"):
+            raise NotImplementedError(f"model {args.model!r} is outside the MHIM hot path")
+        return model.forward_test(bag), label
+
+
+class FlatState:
+    """Flat fp32 buffers behind a student/teacher pair.
+
+    Layout: [trainable parameters in named_parameters() order | non-trainable parameters (merge.global_q_mm)].
+    Every nn.Parameter of both models becomes a view into its flat buffer, so state_dict()/load_state_dict()
+    keep working and the fused optimiser touches each byte once.
+    """
+
+    def __init__(self, student: MHIM, teacher: Optional[MHIM]):
+        named = list(student.named_parameters())          # de-duplicated (global_q alias appears once)
+        self.train_names = [n for n, p in named if p.requires_grad]
+        self.fixed_names = [n for n, p in named if not p.requires_grad]
+        self.names = self.train_names + self.fixed_names
+        dev = named[0][1].device
+        sizes = {n: p.numel() for n, p in named}
+        self.offsets, off = {}, 0
+        for n in self.names:
+            self.offsets[n] = off
+            off += (sizes[n] + 3) // 4 * 4                  # keep every tensor 16-byte aligned
+            if n == self.train_names[-1]:
+                self.n_train = off
+        self.n_all = off
+        self.student = self._adopt(student, dev)
+        self.teacher = self._adopt(teacher, dev) if teacher is not None else None
+        self.grad = torch.zeros(self.n_all, device=dev)
+        self.m = torch.zeros(self.n_train, device=dev)
+        self.v = torch.zeros(self.n_train, device=dev)
+        self.grad_views = {}
+        pd = dict(student.named_parameters())
+        for n in self.train_names:
+            self.grad_views[n] = self.grad[self.offsets[n]:self.offsets[n] + sizes[n]].view_as(pd[n])
+        self.step = 0
+
+    def _adopt(self, model, dev):
+        flat = torch.zeros(self.n_all, device=dev)
+        pd = dict(model.named_parameters())
+        for n in self.names:
+            p = pd[n]
+            view = flat[self.offsets[n]:self.offsets[n] + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        return flat
+
+
+class FusedTrainer:
+    """One-call MHIM(ABMIL) train step on flat buffers (the benchmarked path)."""
+
+    def __init__(self, student: MHIM, teacher: Optional[MHIM], lr=2e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
+                 mm=0.9997, main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, process_group=None, model="mhim"):
+        self.s, self.t = student, teacher
+        self.flat = FlatState(student, teacher)
+        self.lr, self.wd, self.betas, self.eps, self.mm = lr, weight_decay, betas, eps, mm
+        self.main_alpha, self.aux_alpha = main_alpha, aux_alpha
+        self.accum = max(1, int(accumulation_steps))
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if self._dist() else 1
+        self.model_kind = model
+        self._micro = 0
+        self.last = {}
+
+    def _dist(self):
+        return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    # -------------------------------------------------------------------------------------------------
+    def forward_backward(self, bag, label, perm=None, ids_shuffle=None, i=None):
+        """Teacher fwd + select + student fwd + head + backward into the flat gradient buffer (accumulating)."""
+        s, t, fl = self.s, self.t, self.flat
+        x = s._check_x(bag)
+        ps = x.shape[0]
+        first = self._micro == 0
+        gv = fl.grad_views
+        if self.model_kind == "mhim":
+            teacher_feat, score = t.forward_teacher(x)
+            len_keep, mask_ids = s.get_mask(ps, i, score, perm=perm)
+            Lk = int(len_keep * s.merge.merge_ratio)
+            R = len_keep - Lk
+            if ids_shuffle is None:
+                ids_shuffle = torch.randperm(len_keep, device=x.device)
+            rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle)
+            plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True)
+            keep_num = Lk + s.merge.k
+        else:
+            teacher_feat = None
+            plan = s._plan_all_rows(ps)
+            plan.training = True
+            keep_num = ps
+        merge_on = s.merge_enable
+        if self.model_kind != "mhim":
+            s.merge_enable = False
+        try:
+            z, saved = s._bag_forward(x, plan)
+            t_in = teacher_feat.view(-1) if (teacher_feat is not None and self.aux_alpha != 0.) else None
+            logits, losses, g_z, _, _ = ops.head_fwd_bwd(
+                z, t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),
+                main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
+                d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
+            if first:
+                s._bag_backward(x, plan, saved, g_z, out=gv)
+            else:                                   # gradient accumulation: fresh buffers, then add (rare path)
+                g = s._bag_backward(x, plan, saved, g_z)
+                for n, v in g.items():
+                    gv[n].add_(v)
+        finally:
+            s.merge_enable = merge_on
+        self._micro += 1
+        self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num}
+        return logits, losses
+
+    def update(self):
+        """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
+        fl = self.flat
+        scale = 1.0
+        if self.world > 1:
+            # one collective for everything that must agree across ranks: the gradient AND the in-forward EMA of
+            # the global merge queries ride in the same flat buffer (tail = fixed parameters)
+            fl.grad[fl.n_train:].copy_(fl.student[fl.n_train:])
+            torch.distributed.all_reduce(fl.grad, group=self.pg)
+            scale = 1.0 / self.world
+            fl.student[fl.n_train:].copy_(fl.grad[fl.n_train:] * scale)
+        fl.step += 1
+        ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
+                     fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
+                     grad_scale=scale, ema_mm=self.mm, zero_grad=True)
+        self._micro = 0
+
+    def train_step(self, bag, label, **kw):
+        out = self.forward_backward(bag, label, **kw)
+        if self._micro >= self.accum:
+            self.update()
+        return out

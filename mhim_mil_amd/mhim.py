@@ -1,0 +1,480 @@
+"""MHIM — host-side mirror of the reference's ``modules/mhim.MHIM`` over the HIP kernels.
+
+Same constructor arguments, same methods and return conventions, same state_dict keys
+(SURVEY.md §8(b)), so a reference training script can import this class instead:
+
+    reference                               this class
+    ---------                               ----------
+    MHIM.forward_teacher  (mhim.py:181-227) forward_teacher  -> (feat [1,E], score [1,N])
+    MHIM.forward          (mhim.py:318-378) forward          -> (logit [1,C], cls_loss, ps, len_keep)
+    MHIM.forward_test     (mhim.py:229-272) forward_test     -> logits | (logits, attn)
+    MHIM.pure             (mhim.py:274-298) pure             -> (logits, 0, ps, ps) | logits
+
+All math runs in libmhimx.so (hand-written gfx950 kernels behind the C-ABI); torch only owns
+parameters, device memory, the stream and autograd's graph bookkeeping.  There is no eager/CPU
+fallback: inputs must be CUDA tensors and the library must be built.
+
+Only ``baseline='attn'`` (ABMIL) is wired in this round; 'selfattn' raises NotImplementedError
+(SURVEY.md §8 rows A9/A10 are the next kernels), 'dsmil' is scope row N1.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+_FEATURE_ACTS = ("relu", "gelu")
+_SCORER_ACTS = ("relu", "gelu", "tanh")
+
+
+# ----------------------------------------------------------------------------------------------- holders
+class _Lin(nn.Module):
+    """Parameter holder with nn.Linear's names/shapes/init law (no math: kernels read .weight/.bias)."""
+
+    def __init__(self, i, o, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.zeros(o)) if bias else None
+        nn.init.xavier_normal_(self.weight)          # mhim_modules/utils.py:16-19
+
+
+class _Norm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _Slot(nn.Module):
+    """Occupies a Sequential index that holds a parameter-free module in the reference (activation/dropout)."""
+
+
+class _Attention(nn.Module):
+    def __init__(self, E, gated):
+        super().__init__()
+        if gated:
+            self.attention_a = nn.Sequential(_Lin(E, 128, bias=False), _Slot())
+            self.attention_b = nn.Sequential(_Lin(E, 128, bias=False), _Slot())
+            self.attention_c = _Lin(128, 1, bias=False)
+        else:
+            self.attention = nn.Sequential(_Lin(E, 128, bias=False), _Slot(), _Lin(128, 1, bias=False))
+
+
+class _DAttention(nn.Module):
+    def __init__(self, E, gated=False):
+        super().__init__()
+        self.gated = gated
+        self.attention = _Attention(E, gated)
+
+
+class _MCA(nn.Module):
+    def __init__(self, E, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.to_kv = _Lin(E, 2 * inner, bias=False)
+        self.to_q = _Lin(E, inner, bias=False)
+        self.to_out = nn.Sequential(_Lin(inner, E), _Slot())
+
+
+class _Merge(nn.Module):
+    def __init__(self, E, k, mm, merge_ratio):
+        super().__init__()
+        self.norm = _Norm(E)
+        self.attn = _MCA(E)
+        val = math.sqrt(6.0 / float(3 * 16 * 16 + E))                      # merge.py:109-111
+        self.global_q_mm = nn.Parameter(torch.empty(1, k, E).uniform_(-val, val), requires_grad=False)
+        self.global_q = self.global_q_mm                                   # same Parameter, second name (merge.py:118)
+        self.k, self.g_q_mm, self.merge_ratio = k, mm, merge_ratio
+        self.dropout = 0.1                                                 # Merge(dropout=0.1) default, merge.py:72
+
+
+# ----------------------------------------------------------------------------------------------- autograd
+class _BagFn(torch.autograd.Function):
+    """Student bag forward: X rows -> feature -> (merge) -> scorer + pool -> bag feature z [E].
+
+    Saves only device buffers produced by the kernels; backward is hand-derived and
+    produces every parameter gradient in one pass of kernel launches.  X gets no gradient.
+    """
+
+    @staticmethod
+    def forward(ctx, model, x, plan, *params):
+        ctx.model, ctx.plan = model, plan
+        ctx.names = list(model._bag_param_names)
+        ctx.merge_on = model.merge_enable
+        z, saved = model._bag_forward(x, plan)
+        ctx.saved = saved
+        ctx.x = x
+        return z.view(1, -1)
+
+    @staticmethod
+    def backward(ctx, g_z):
+        model = ctx.model
+        keep, model.merge_enable = model.merge_enable, ctx.merge_on
+        try:
+            grads = model._bag_backward(ctx.x, ctx.plan, ctx.saved, g_z.contiguous().view(-1))
+        finally:
+            model.merge_enable = keep
+        out = [grads.get(name) for name in ctx.names]
+        return (None, None, None, *out)
+
+
+class _HeadFn(torch.autograd.Function):
+    """(z, teacher feat) -> (logits [1,C], cls_loss scalar): predictor + SoftTargetCrossEntropy in one kernel."""
+
+    @staticmethod
+    def forward(ctx, z, t, wp, bp, temp_t):
+        logits, losses, _, _, _ = ops.head_fwd_bwd(z.view(-1), None if t is None else t.contiguous().view(-1), wp, bp, None,
+                                                   temp_t=temp_t)
+        ctx.save_for_backward(z, t, wp, bp)
+        ctx.temp_t = temp_t
+        return logits.view(1, -1), losses[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_logits, g_cl):
+        z, t, wp, bp = ctx.saved_tensors
+        g_logits = g_logits.contiguous().view(-1)
+        g_cl = g_cl.contiguous().view(1) if g_cl is not None else torch.zeros(1, device=z.device)
+        _, _, g_z, d_wp, d_bp = ops.head_fwd_bwd(z.view(-1), None if t is None else t.contiguous().view(-1), wp, bp, None,
+                                                 temp_t=ctx.temp_t, g_logits_in=g_logits, g_cl_in=g_cl)
+        return g_z.view_as(z), None, d_wp, d_bp, None
+
+
+class BagPlan:
+    """Row bookkeeping of one student forward (all device tensors; no host sync)."""
+
+    def __init__(self, rows=None, L=0, Lk=0, R=0, drop_seed=0, drop_mask=None, mca_seed=0, training=True):
+        self.rows, self.L, self.Lk, self.R = rows, L, Lk, R
+        self.drop_seed, self.drop_mask, self.mca_seed, self.training = drop_seed, drop_mask, mca_seed, training
+
+
+# ----------------------------------------------------------------------------------------------- model
+class MHIM(nn.Module):
+    def __init__(self, input_dim=1024, mlp_dim=512, mask_ratio=0, n_classes=2, temp_t=1., dropout=0.25, act='relu',
+                 mask_ratio_h=0., mrh_sche=None, mask_ratio_hr=0., mask_ratio_l=0., da_act='gelu', baseline='selfattn',
+                 head=8, attn2score=True, merge_enable=True, merge_k=1, merge_mm=0.9998, merge_ratio=0.,
+                 merge_test=False, attn_layer=None, select_mask=None, prec="auto", gated=False, **_ignored):
+        # attn_layer / select_mask: accepted and ignored — the reference's own factory passes them although its
+        # constructor rejects them (modules/__init__.py:91,102).
+        super().__init__()
+        self.mask_ratio, self.mask_ratio_h, self.mask_ratio_hr, self.mask_ratio_l = mask_ratio, mask_ratio_h, mask_ratio_hr, mask_ratio_l
+        self.select_inv = False
+        self.msa_fusion = "vote"
+        self.mrh_sche = mrh_sche
+        self.attn_layer = 0
+        self.baseline = baseline
+        self.merge_test = merge_test
+        self.attn2score = attn2score
+        self.head = head
+        self.temp_t, self.temp_s = temp_t, 1.0
+        self.input_dim, self.mlp_dim, self.n_classes = input_dim, mlp_dim, n_classes
+        self.act, self.da_act = act, da_act
+        self.dropout_p = float(dropout)
+        self.prec = prec
+        self.merge_enable = bool(merge_enable)
+        if baseline != "attn":
+            raise NotImplementedError(
+                f"baseline={baseline!r}: only the ABMIL encoder ('attn') has HIP kernels in this round "
+                "(Nystrom 'selfattn' = SURVEY.md §8 A9/A10, next; 'dsmil' = scope row N1)")
+        self.merge = _Merge(mlp_dim, merge_k, merge_mm, merge_ratio) if merge_enable else nn.Identity()
+        self.feature = nn.Sequential(_Lin(input_dim, mlp_dim), _Slot())
+        self.online_encoder = _DAttention(mlp_dim, gated=gated)
+        self.predictor = _Lin(mlp_dim, n_classes)
+        self._step = 0
+        self._inject = {}
+        self._cache = {}
+
+    # ------------------------------------------------------------------ weights in kernel layout
+    @property
+    def _bag_param_names(self):
+        names = ["feature.0.weight", "feature.0.bias"]
+        if self.online_encoder.gated:
+            names += ["online_encoder.attention.attention_a.0.weight", "online_encoder.attention.attention_b.0.weight",
+                      "online_encoder.attention.attention_c.weight"]
+        else:
+            names += ["online_encoder.attention.attention.0.weight", "online_encoder.attention.attention.2.weight"]
+        if self.merge_enable:
+            names += ["merge.norm.weight", "merge.norm.bias", "merge.attn.to_kv.weight", "merge.attn.to_q.weight",
+                      "merge.attn.to_out.0.weight", "merge.attn.to_out.0.bias"]
+        return names
+
+    def _param(self, name):
+        obj = self
+        for part in name.split("."):
+            obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+        return obj
+
+    def _scorer(self):
+        att = self.online_encoder.attention
+        act = L.act_code(self.da_act, _SCORER_ACTS)
+        if self.online_encoder.gated:
+            return ops.ScorerW(att.attention_a[0].weight.data, att.attention_c.weight.data, act,
+                               wb=att.attention_b[0].weight.data, prec=self._op_prec)
+        return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec)
+
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False):
+        m = self.merge
+        tr = None
+        if need_t:
+            tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
+                  ops.transpose(m.attn.to_out[0].weight.data))
+        drop = m.dropout if (plan is not None and plan.training) else 0.0
+        return ops.MergeW(m.global_q_mm.data.view(m.k, -1), m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
+                          m.attn.to_q.weight.data, m.attn.to_out[0].weight.data, m.attn.to_out[0].bias.data, m.g_q_mm,
+                          drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr)
+
+    # ------------------------------------------------------------------ kernels: feature rows
+    def _check_x(self, x):
+        if not x.is_cuda:
+            raise L.MhimxError("MHIM (mhimx): input bag must be a CUDA tensor; there is no CPU path")
+        if x.dim() == 3:
+            if x.shape[0] != 1:
+                raise L.MhimxError("MHIM processes one bag per call (batch_size=1, as the reference trainer does)")
+            x = x[0]
+        return x.contiguous().float()
+
+    def _feature(self, x, rows=None, drop_p=0.0, drop_seed=0, drop_mask=None, want_pre=False, out=None, pre_out=None, M=None):
+        f = self.feature[0]
+        act = L.act_code(self.act, _FEATURE_ACTS)
+        nrows = M if M is not None else (rows.shape[0] if rows is not None else x.shape[0])
+        return ops.gemm_nt(x, f.weight.data, out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out, drop_p=drop_p,
+                           drop_seed=drop_seed, drop_mask=drop_mask, prec=self._feature_prec(nrows), M=M)
+
+    def _feature_prec(self, nrows):
+        """'auto' = 'bf16x3' (3 MFMAs per tile step, ~2^-16 relative, fp32 range): the only 16-bit form that keeps
+        INSTANCE-level quantities (scores, attention, hence the top-k) at fp32-parity when attention is peaked.
+        'f16s' (2 MFMAs: activation in one fp16 term, weight hi+lo) is the opt-in fast mode: bag logits stay
+        within 1e-4 when attention is diffuse (errors average over instances) but per-instance scores carry
+        ~1e-4 relative error, 2.7e-3 on the bag feature with a x20-sharpened scorer (measured)."""
+        if self.prec != "auto":
+            return self.prec
+        return "bf16x3"
+
+    @property
+    def _op_prec(self):
+        return "f16s" if self.prec == "auto" else self.prec
+
+    def _next_seed(self):
+        self._step += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------ student bag forward / backward
+    def _bag_forward(self, x, plan: BagPlan):
+        E = self.mlp_dim
+        Lrows = plan.L
+        dev = x.device
+        need_pre = L.act_code(self.act, _FEATURE_ACTS) == L.ACT["gelu"] and plan.training
+        H = torch.empty((Lrows, E), device=dev)
+        PRE = torch.empty((Lrows, E), device=dev) if need_pre else None
+        p = self.dropout_p if plan.training else 0.0
+        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows)
+        saved = {"H": H, "PRE": PRE}
+        sc = self._scorer()
+        if self.merge_enable and plan.R > 0:
+            mw = self._merge_w(plan, need_t=False)
+            z_tok, q_new, mws = ops.merge_fwd(mw, H[plan.Lk:], update_q=plan.training)
+            st = ops.abmil_pool_fwd(sc, H[:plan.Lk], z_tok)
+            saved.update(z_tok=z_tok, mws=mws, q_old=self.merge.global_q_mm.data.clone() if plan.training else None)
+            if plan.training:                       # in-forward EMA of the global queries (merge.py:142-143)
+                self.merge.global_q_mm.data.copy_(q_new.view_as(self.merge.global_q_mm))
+        else:
+            st = ops.abmil_pool_fwd(sc, H, None)
+        saved["pool"] = st
+        return st.z, saved
+
+    def _bag_backward(self, x, plan: BagPlan, saved, g_z, out=None):
+        """Returns {param name: gradient}.  ``out`` may map names to preallocated (flat-buffer) views to fill."""
+        out = out or {}
+        E = self.mlp_dim
+        dev = x.device
+        H, PRE, st = saved["H"], saved["PRE"], saved["pool"]
+        sc = self._scorer()
+        att = self.online_encoder.attention
+        dH = torch.empty_like(H)
+        grads = {}
+        pool_g = {"dT1": dH[:plan.Lk] if (self.merge_enable and plan.R > 0) else dH}
+        pre = "online_encoder.attention."
+        for key, nm in (("d_wa", "attention_a.0.weight" if self.online_encoder.gated else "attention.0.weight"),
+                        ("d_wb", "attention_b.0.weight"),
+                        ("d_wc", "attention_c.weight" if self.online_encoder.gated else "attention.2.weight")):
+            if pre + nm in out:
+                pool_g[key] = out[pre + nm]
+        if self.online_encoder.gated:
+            g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(att.attention_a[0].weight.data),
+                                   ops.transpose(att.attention_b[0].weight.data), grads=pool_g)
+            grads["online_encoder.attention.attention_a.0.weight"] = g["d_wa"]
+            grads["online_encoder.attention.attention_b.0.weight"] = g["d_wb"]
+            grads["online_encoder.attention.attention_c.weight"] = g["d_wc"]
+        else:
+            g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(att.attention[0].weight.data), grads=pool_g)
+            grads["online_encoder.attention.attention.0.weight"] = g["d_wa"]
+            grads["online_encoder.attention.attention.2.weight"] = g["d_wc"]
+        if self.merge_enable and plan.R > 0:
+            # LayerNorm(global_q) backward uses the PRE-update queries (the reference sees post-update values through
+            # an in-place .data write, a 1e-4-relative quirk: SURVEY.md §7 H7)
+            q_now = self.merge.global_q_mm.data.clone()
+            self.merge.global_q_mm.data.copy_(saved["q_old"])
+            mw = self._merge_w(plan, need_t=True)
+            mgr = {"dX": dH[plan.Lk:]}
+            for key, nm in (("d_ln_w", "merge.norm.weight"), ("d_ln_b", "merge.norm.bias"), ("d_wkv", "merge.attn.to_kv.weight"),
+                            ("d_wq", "merge.attn.to_q.weight"), ("d_wo", "merge.attn.to_out.0.weight"),
+                            ("d_bo", "merge.attn.to_out.0.bias")):
+                if nm in out:
+                    mgr[key] = out[nm]
+            mg = ops.merge_bwd(mw, H[plan.Lk:], g["dT2"], saved["mws"], grads=mgr)
+            self.merge.global_q_mm.data.copy_(q_now)
+            grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
+            grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
+            grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
+        p = self.dropout_p if plan.training else 0.0
+        ops.act_bwd(dH, H, PRE, L.act_code(self.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows)
+        splits = 8 if plan.L >= 2048 else 1
+        grads["feature.0.weight"] = ops.gemm_tn(dH, x, out=out.get("feature.0.weight"), rows=plan.rows, splits=splits,
+                                                prec="f32" if self.prec == "f32" else "bf16x3", M=plan.L)
+        grads["feature.0.bias"] = ops.colsum(dH, out=out.get("feature.0.bias"))
+        return grads
+
+    # ------------------------------------------------------------------ masking (mhim.py:109-179)
+    def get_mask(self, ps, i, attn, mrh=None, perm=None, perms=None):
+        """Device-side get_mask.  Returns (len_keep:int, mask_ids [1,ps] int64).  ``perm``/``perms`` inject the
+        randperm draws of masking.py:67 (parity tests); otherwise they are drawn on the device."""
+        if attn is None:
+            return ps, None
+        if attn.dim() == 3 or (attn.dim() == 2 and attn.shape[0] != 1):
+            raise NotImplementedError("per-head (3-D) attention comes from the selfattn baseline (next round)")
+        score = attn.reshape(-1).contiguous().float()
+        perms = list(perms) if perms is not None else [None, None, perm]
+        masked, n_masked, len_keep, mask_ids = None, 0, ps, None
+
+        def run(largest, ratio, rratio, pm):
+            nonlocal masked, n_masked, len_keep, mask_ids
+            eff = ratio / rratio
+            if eff > 1:
+                rratio, eff = ratio, 1.0
+            k = int(np.ceil(ps * eff))
+            n_sel = int(np.ceil(k * rratio)) if rratio < 1.0 else k
+            if rratio < 1.0 and pm is None:
+                pm = torch.randperm(k, device=score.device)
+            elif pm is not None and not torch.is_tensor(pm):
+                pm = torch.as_tensor(np.asarray(pm), dtype=torch.int64, device=score.device)
+            ids, lk_dev, _ = ops.select_mask(score, k, n_sel, largest, pm if rratio < 1.0 else None, other=masked)
+            if masked is None:
+                len_keep = ps - n_sel
+            else:
+                len_keep = int(lk_dev.item())      # union size is data dependent (v1 recipes only): one host sync
+            mask_ids = ids
+            masked = ids[len_keep:].contiguous()
+
+        if self.mask_ratio > 0.:
+            run(False, self.mask_ratio, 0.001, perms[0])
+        if self.mask_ratio_l > 0.:
+            run(False, self.mask_ratio_l, 1.0, None)
+        mask_ratio_h = self.mask_ratio_h
+        if self.mrh_sche is not None:
+            mask_ratio_h = self.mrh_sche[i]
+        if mrh is not None:
+            mask_ratio_h = mrh
+        if mask_ratio_h > 0.:
+            run(True, mask_ratio_h, self.mask_ratio_hr, perms[2])
+        return len_keep, (None if mask_ids is None else mask_ids.view(1, -1))
+
+    # ------------------------------------------------------------------ reference entry points
+    @torch.no_grad()
+    def forward_teacher(self, x, drop_mask=None):
+        x = self._check_x(x)
+        p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
+        H = self._feature(x, None, p, self._next_seed(), drop_mask)
+        p0 = H.shape[0]
+        T2 = None
+        if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)
+            mw = self._merge_w(None)
+            T2, _, _ = ops.merge_fwd(mw, H, update_q=False)
+        wp = self.predictor.weight.data if self.attn2score else None
+        st = ops.abmil_pool_fwd(self._scorer(), H, T2, wp=wp)
+        if self.attn2score:
+            score = ops.pseudo_score(st.s[:p0], st.stats, st.cproj[:p0], self.predictor.bias.data)
+        else:
+            score = ops.softmax_from_stats(st.s, st.stats)[:p0]
+        return st.z.view(1, -1), score.view(1, -1)
+
+    @torch.no_grad()
+    def forward_test(self, x, return_attn=False, no_norm=False, return_act=False, **kwargs):
+        x = self._check_x(x)
+        p = self.dropout_p if self.training else 0.0
+        H = self._feature(x, None, p, self._next_seed())
+        T2 = None
+        if self.merge_test:
+            T2, _, _ = ops.merge_fwd(self._merge_w(None), H, update_q=False)
+        st = ops.abmil_pool_fwd(self._scorer(), H, T2)
+        logits = ops.gemm_nt(st.z.view(1, -1), self.predictor.weight.data, bias=self.predictor.bias.data, prec="f32")
+        if not return_attn:
+            return logits
+        a = st.s.clone() if no_norm else ops.softmax_from_stats(st.s, st.stats)
+        a = a.view(1, -1)
+        if return_act:
+            act = H if T2 is None else torch.cat([H, T2], 0)
+            return logits, [a, act]
+        return logits, a
+
+    def _plan_all_rows(self, n):
+        return BagPlan(rows=None, L=n, Lk=n, R=0, drop_seed=self._next_seed(), mca_seed=0, training=self.training)
+
+    def _head(self, z, teacher_feat):
+        t = None if teacher_feat is None else teacher_feat.detach()
+        return _HeadFn.apply(z, t, self.predictor.weight, self.predictor.bias, float(self.temp_t))
+
+    def pure(self, x):
+        x = self._check_x(x)
+        ps = x.shape[0]
+        if not self.training:
+            return self.forward_test(x)
+        merge_enable, self.merge_enable = self.merge_enable, False     # pure(): no masking, no merging (mhim.py:274-298)
+        try:
+            plan = self._plan_all_rows(ps)
+            z = _BagFn.apply(self, x, plan, *[self._param(n) for n in self._bag_param_names])
+        finally:
+            self.merge_enable = merge_enable
+        logits, _ = self._head(z, None)
+        return logits, 0, ps, ps
+
+    def forward_loss(self, student_cls_feat, teacher_cls_feat):
+        if teacher_cls_feat is None:
+            return 0.
+        return self._head(student_cls_feat, teacher_cls_feat)[1]
+
+    def forward(self, x, attn=None, teacher_cls_feat=None, i=None, pos=None, perm=None, ids_shuffle=None, drop_mask=None):
+        x = self._check_x(x)
+        ps = x.shape[0]
+        len_keep, mask_ids = self.get_mask(ps, i, attn, perm=perm)
+        if mask_ids is None:
+            raise AssertionError("MHIM.forward needs a mask (mask_ratio_h > 0 or a v1 ratio), as the reference does "
+                                 "(masking.py:104)")
+        if not self.merge_enable:
+            raise TypeError("MHIM.forward requires merge_enable=True (the reference's Identity merge rejects the "
+                            "second argument, mhim.py:82,351)")
+        Lk = int(len_keep * self.merge.merge_ratio)                         # merge.py:163
+        R = len_keep - Lk
+        if self.training:
+            if ids_shuffle is None:
+                ids_shuffle = torch.randperm(len_keep, device=x.device)    # == argsort(rand(L)) in distribution
+            elif not torch.is_tensor(ids_shuffle):
+                ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=x.device)
+            rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
+        else:                                                               # eval: cat(x, merge(x)) (merge.py:197-198)
+            rows, Lk, R = mask_ids.view(-1)[:len_keep].contiguous(), len_keep, 0
+        if self.training and R == 0:
+            raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
+        plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=self._next_seed(), drop_mask=drop_mask,
+                       mca_seed=self._next_seed(), training=self.training)
+        if not self.training:
+            raise NotImplementedError("MHIM.forward in eval mode is not used by the reference trainer; use forward_test")
+        z = _BagFn.apply(self, x, plan, *[self._param(n) for n in self._bag_param_names])
+        logits, cls_loss = self._head(z, teacher_cls_feat)
+        if teacher_cls_feat is None:
+            cls_loss = 0.
+        return logits, cls_loss, ps, Lk + self.merge.k

@@ -14,6 +14,11 @@ import torch
 from . import _lib as L
 
 
+# bench.py installs a callable (tag, M, N, K) -> (start_event, end_event) | None to bracket one kernel with HIP
+# events on the launch stream (torch's current stream IS the stream the kernels are enqueued on).
+KERNEL_EVENT_HOOK = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -56,7 +61,12 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
                  ldpre=pre.stride(0) if pre is not None else 0, act=int(act), drop_p=float(drop_p),
                  drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(drop_mask), accumulate=int(bool(accumulate)),
                  prec=prec_code(prec))
+    evs = KERNEL_EVENT_HOOK("gemm_nt", M, N, K) if KERNEL_EVENT_HOOK is not None else None
+    if evs:
+        evs[0].record()
     L.check(L.lib().mhimx_gemm_nt(_stream(), C.byref(g)), "mhimx_gemm_nt")
+    if evs:
+        evs[1].record()
     return out
 
 
@@ -274,18 +284,19 @@ def colsum(X, out=None, accumulate=False):
 
 
 def head_fwd_bwd(z, t, wp, bp, label, temp_t=1.0, main_alpha=1.0, aux_alpha=0.0, inv_accum=1.0, d_wp=None, d_bp=None,
-                 accumulate=False):
+                 accumulate=False, g_logits_in=None, g_cl_in=None, g_z=None):
     """logits, losses[3] = {main*ce + aux*cl, ce, cl}, g_z, d_wp, d_bp."""
     dev = z.device
     Cc, E = wp.shape
     logits = torch.empty(Cc, device=dev)
     losses = torch.empty(3, device=dev)
-    g_z = torch.empty(E, device=dev)
+    g_z = g_z if g_z is not None else torch.empty(E, device=dev)
     d_wp = d_wp if d_wp is not None else torch.empty_like(wp)
     d_bp = d_bp if d_bp is not None else torch.empty(Cc, device=dev)
     L.check(L.lib().mhimx_head_fwd_bwd(_stream(), _p(z), _p(t), _p(wp), _p(bp), _p(label), E, Cc, float(temp_t),
                                        float(main_alpha), float(aux_alpha), float(inv_accum), _p(logits), _p(losses),
-                                       _p(g_z), _p(d_wp), _p(d_bp), int(bool(accumulate))), "mhimx_head_fwd_bwd")
+                                       _p(g_z), _p(d_wp), _p(d_bp), int(bool(accumulate)), _p(g_logits_in), _p(g_cl_in)),
+            "mhimx_head_fwd_bwd")
     return logits, losses, g_z, d_wp, d_bp
 
 

@@ -145,7 +145,7 @@ def test_pool_fwd_bwd(act, gated, bias, A, prec):
     d = lambda t: None if t is None else t.to(DEV)
     sc = ops.ScorerW(d(wa), d(wc), {"relu": 1, "gelu": 2, "tanh": 3}[act], ba=d(ba), wb=d(wb), bb=d(bb), bc=d(bc), prec=prec)
     st = ops.abmil_pool_fwd(sc, d(T1), d(T2), wp=d(wp))
-    f = 1.0 if prec == "f32" else 30.0
+    f = 1.0 if prec == "f32" else 4.0
     np.testing.assert_allclose(st.s.cpu().numpy(), s.detach().float().numpy(), atol=2e-5 * f, rtol=1e-5 * f)
     np.testing.assert_allclose(st.z.cpu().numpy(), z.detach().float().numpy(), atol=3e-6 * f, rtol=1e-5 * f)
     np.testing.assert_allclose(ops.softmax_from_stats(st.s, st.stats).cpu().numpy(), attn.detach().float().numpy(),
@@ -169,7 +169,8 @@ def test_pool_fwd_bwd(act, gated, bias, A, prec):
         close("d_wb", g["d_wb"], leaves["wb"].grad)
     if bias:
         close("d_ba", g["d_ba"], leaves["ba"].grad)
-        close("d_bc", g["d_bc"], leaves["bc"].grad)
+        # d_bc = sum_n ds_n is identically 0 (softmax is shift invariant): absolute check only
+        assert abs(float(g["d_bc"].cpu())) < 1e-6 and abs(float(leaves["bc"].grad)) < 1e-12
         if gated:
             close("d_bb", g["d_bb"], leaves["bb"].grad)
 
@@ -282,7 +283,7 @@ def test_merge_fwd_bwd(prec, R, k):
                     f32(p["merge.attn.to_out.0.bias"]), 0.9999, prec=prec, transposes=tr)
     Xd = f32(X)
     zd, qn, ws = ops.merge_fwd(mw, Xd)
-    f = 1.0 if prec == "f32" else 30.0
+    f = 1.0 if prec == "f32" else 4.0
     np.testing.assert_allclose(zd.cpu().numpy(), z.detach().float().numpy(), atol=5e-6 * f, rtol=1e-5 * f)
     np.testing.assert_allclose(qn.cpu().numpy(), g_new.detach().float().numpy(), atol=1e-7, rtol=1e-6)
     g = ops.merge_bwd(mw, Xd, dz.to(DEV), ws, splits=4)
