@@ -109,6 +109,25 @@ class FlatState:
         return flat
 
 
+def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, world: int, group=None) -> float:
+    """The ONE collective of a data-parallel update (RCCL on GPUs; any backend works, gloo in the CPU tests).
+
+    Everything that must agree across ranks rides in the same flat buffer: the gradient (first n_train floats) and,
+    in the tail, the non-trainable parameters that each rank mutated in its own forward (merge.global_q_mm's EMA,
+    merge.py:142-143).  After the SUM all-reduce the tail is averaged back into ``student``; the
+    returned scale (1/world) is applied to the gradient inside the fused Adam kernel.  No data-path collective exists:
+    bags are independent units.
+    """
+    if world <= 1:
+        return 1.0
+    grad[n_train:].copy_(student[n_train:])
+    torch.distributed.all_reduce(grad, group=group)
+    scale = 1.0 / world
+    student[n_train:].copy_(grad[n_train:] * scale)
+    grad[n_train:].zero_()
+    return scale
+
+
 class FusedTrainer:
     """One-call MHIM(ABMIL) train step on flat buffers (the benchmarked path)."""
 
@@ -176,14 +195,7 @@ class FusedTrainer:
     def update(self):
         """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
         fl = self.flat
-        scale = 1.0
-        if self.world > 1:
-            # one collective for everything that must agree across ranks: the gradient AND the in-forward EMA of
-            # the global merge queries (SURVEY.md §7 H5) ride in the same flat buffer (tail = fixed parameters)
-            fl.grad[fl.n_train:].copy_(fl.student[fl.n_train:])
-            torch.distributed.all_reduce(fl.grad, group=self.pg)
-            scale = 1.0 / self.world
-            fl.student[fl.n_train:].copy_(fl.grad[fl.n_train:] * scale)
+        scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
         fl.step += 1
         ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                      fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
