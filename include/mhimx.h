@@ -75,6 +75,7 @@ typedef struct {
   int32_t splits; float* ws;
   int32_t accumulate;
   int32_t prec;
+  int64_t ws_floats;                                     /* capacity of ws; the library may raise `splits` up to it   */
 } mhimx_gemm_tn_args;
 int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a);
 

@@ -41,7 +41,7 @@ class GemmTN(C.Structure):
                 ("C", c_f32p), ("ldc", C.c_int64),
                 ("M", C.c_int64), ("K1", C.c_int64), ("K2", C.c_int64),
                 ("splits", C.c_int32), ("ws", c_f32p),
-                ("accumulate", C.c_int32), ("prec", C.c_int32)]
+                ("accumulate", C.c_int32), ("prec", C.c_int32), ("ws_floats", C.c_int64)]
 
 
 class Scorer(C.Structure):

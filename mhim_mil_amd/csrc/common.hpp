@@ -89,15 +89,31 @@ MHIMX_DEV bool drop_keep(uint64_t seed, uint64_t row, uint32_t col, float p) {
   return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
+// Wave64 all-reduce on the VALU's DPP network (no LDS round trips: __shfl_xor lowers to ds_bpermute, ~6 dependent
+// LDS-crossbar hops per reduction; this is 6 DPP moves + one v_readlane).  DPP controls: quad_perm [1,0,3,2] = 0xB1,
+// [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+MHIMX_DEV float dpp_mov(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 MHIMX_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1, 0xf>(0.f, v);
+  v += dpp_mov<0x4E, 0xf>(0.f, v);
+  v += dpp_mov<0x141, 0xf>(0.f, v);
+  v += dpp_mov<0x140, 0xf>(0.f, v);          // every lane of a 16-lane row now holds its row sum
+  v += dpp_mov<0x142, 0xa>(0.f, v);          // rows 1,3 += row 0,2
+  v += dpp_mov<0x143, 0xc>(0.f, v);          // rows 2,3 += row 1 (= rows 0+1): lane 63 = total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 MHIMX_DEV float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = -__builtin_inff();
+  v = fmaxf(v, dpp_mov<0xB1, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_mov<0x4E, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_mov<0x141, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_mov<0x140, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_mov<0x142, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_mov<0x143, 0xc>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 }  // namespace mhimx

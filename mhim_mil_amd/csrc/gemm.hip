@@ -22,6 +22,12 @@ typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 
+// the DMA-staged fast core (gemm_dma.hip)
+bool nt_dma_ok(const mhimx_gemm_nt_args& g);
+int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g);
+bool tn_dma_ok(const mhimx_gemm_tn_args& g);
+int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_avail);
+
 template <int PREC> struct Prec;
 template <> struct Prec<MHIMX_PREC_F32> {
   using T = float;
@@ -222,6 +228,61 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g)
     }
 }
 
+
+// =================================================================================================
+// skinny forms (M <= 16 rows: the k global-query tokens of Merge): exact fp32 FMA, wave per output column
+// =================================================================================================
+constexpr int SKINNY_M = 16;
+
+__global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  if (n >= g.N) return;
+  float acc[SKINNY_M];
+#pragma unroll
+  for (int m = 0; m < SKINNY_M; ++m) acc[m] = 0.f;
+  const float* brow = g.B + n * g.ldb;
+  for (int64_t k = lane * 4; k < g.K; k += 256) {
+    const float4 w = *reinterpret_cast<const float4*>(brow + k);
+#pragma unroll
+    for (int m = 0; m < SKINNY_M; ++m) {
+      if (m < g.M) {
+        const float4 a = *reinterpret_cast<const float4*>(g.A + (g.rows ? g.rows[m] : (int64_t)m) * g.lda + k);
+        acc[m] += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < SKINNY_M; ++m) acc[m] = wave_sum(acc[m]);
+  if (lane != 0) return;
+  const float bias = g.bias ? g.bias[n] : 0.f;
+  for (int m = 0; m < g.M; ++m) {
+    float v = acc[m] + bias;
+    if (g.rowv) v += g.rowv[m] * g.colv[n];
+    if (g.pre) g.pre[m * g.ldpre + n] = v;
+    v = act_fwd(v, g.act);
+    if (g.drop_mask) {
+      v = g.drop_mask[m * g.N + n] ? v / (1.f - g.drop_p) : 0.f;
+    } else if (g.drop_p > 0.f) {
+      const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
+      v = drop_keep(g.drop_seed, rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
+    }
+    float* c = g.C + m * g.ldc + n;
+    if (g.accumulate) v += *c;
+    *c = v;
+  }
+}
+
+__global__ void skinny_tn_kernel(mhimx_gemm_tn_args g) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j >= g.K2) return;
+  float acc = 0.f;
+  for (int64_t m = 0; m < g.M; ++m) acc += g.A[m * g.lda + i] * g.B[(g.rows ? g.rows[m] : m) * g.ldb + j];
+  float* p = g.C + i * g.ldc + j;
+  *p = g.accumulate ? *p + acc : acc;
+}
+
 template <int PREC>
 static int launch_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
   using PP = Prec<PREC>;
@@ -240,6 +301,12 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
   MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_nt: null operand");
   MHIMX_CHECK_ARG(!g.rowv || g.colv, "gemm_nt: rowv needs colv");
   MHIMX_CHECK_ARG(g.drop_p >= 0.f && g.drop_p < 1.f, "gemm_nt: drop_p out of range");
+  if (g.M <= SKINNY_M) {
+    hipLaunchKernelGGL(skinny_nt_kernel, dim3((unsigned)cdiv(g.N, 4)), dim3(256), 0, st, g);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (nt_dma_ok(g)) return gemm_nt_dma(st, g);
   switch (g.prec) {
     case MHIMX_PREC_F32: return launch_nt<MHIMX_PREC_F32>(st, g);
     case MHIMX_PREC_F16S: return launch_nt<MHIMX_PREC_F16S>(st, g);
@@ -362,6 +429,23 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
   MHIMX_CHECK_ARG(g.M >= 0 && g.K1 > 0 && g.K2 > 0, "gemm_tn: bad dims");
   MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_tn: null operand");
   MHIMX_CHECK_ARG(g.splits <= 1 || g.ws, "gemm_tn: splits>1 needs ws");
+  if (g.M <= SKINNY_M) {
+    hipLaunchKernelGGL(skinny_tn_kernel, dim3((unsigned)cdiv(g.K2, 256), (unsigned)g.K1), dim3(256), 0, st, g);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (tn_dma_ok(g)) {
+    int64_t avail = g.ws ? (g.ws_floats > 0 ? g.ws_floats : (int64_t)(g.splits > 1 ? g.splits : 0) * g.K1 * g.K2) : 0;
+    const int used = gemm_tn_dma(st, g, avail);
+    if (used < 0) return used;
+    if (used > 1) {
+      const int64_t n = g.K1 * g.K2;
+      const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, used, g.accumulate);
+      MHIMX_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   switch (g.prec) {
     case MHIMX_PREC_F32: return launch_tn<MHIMX_PREC_F32>(st, g);
     case MHIMX_PREC_F16S:      // fp16 has no headroom for gradients: use the bf16 3-term form

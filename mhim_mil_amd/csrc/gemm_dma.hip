@@ -1,0 +1,463 @@
+// gemm_dma.hip — the fast GEMM core: fp32 operand tiles go HBM/L2 -> LDS by direct DMA
+// (global_load_lds_dwordx4: no VGPR staging, 16 B per lane, 1 KiB per wave instruction), two LDS stages,
+// two workgroups per CU; the fp32 -> (hi, lo) 16-bit split happens when the MFMA fragments are built.
+//
+//   gemm_nt_dma : C[M,N] = epi(A[rows?][M,K] . B[N,K]^T)     LDS image [row][32 k] fp32, 128-B rows.
+//       The DMA writes LDS lane-linearly, so the bank-conflict swizzle is applied to the per-lane SOURCE
+//       address and again on the fragment read (same involution: 16-B slot ^= (row>>1)&7): a 16-lane
+//       ds_read_b128 group then covers 16 distinct 16-B slots of the 256-B bank row.
+//   gemm_tn_dma : C[K1,K2] = A[M,K1]^T . B[rows?][M,K2]       LDS image [32 m][128 cols] fp32 exactly as in HBM
+//       (coalesced 512-B row segments); the k-contiguous fragment a lane needs is a strided column of that
+//       image: 8 x ds_read_b32 with consecutive lanes on consecutive banks.  No transposing stores.
+// Requirements (else the register-staged kernels in gemm.hip run): K % 32 == 0 (nt); K1,K2 % 128 == 0 (tn);
+// 16-byte aligned rows.
+#include "common.hpp"
+
+namespace mhimx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int DBM = 128, DBN = 128, DBK = 32, DTHREADS = 256;
+constexpr int TILE_BYTES = 128 * DBK * 4;          // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+#ifndef MHIMX_NT_STAGES
+#define MHIMX_NT_STAGES 2
+#endif
+constexpr int NSTAGE = MHIMX_NT_STAGES;           // LDS ring depth of the NT kernel (x 32 KiB); 2 => two workgroups per CU
+// 8 x ds_read_b128 from per-lane LDS byte addresses a[0..7] + off (issue only; pair with LDS_WAIT8 before use)
+#define LDS_READ8(x, a, off)                                                                                         \
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"       \
+               "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"          \
+               : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])    \
+               : "v"(a[0] + (off)), "v"(a[1] + (off)), "v"(a[2] + (off)), "v"(a[3] + (off)), "v"(a[4] + (off)),            \
+                 "v"(a[5] + (off)), "v"(a[6] + (off)), "v"(a[7] + (off))                                                   \
+               : "memory")
+#define LDS_WAIT8(x)                                                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])            \
+               :                                                                                                      \
+               : "memory")
+
+constexpr int MAX_TN_CHUNK = 4096;                 // rows of the reduction one workgroup may own (row-id table in LDS)
+
+__device__ float g_zero_row[256];                  // 1 KiB of zeros: source for out-of-range reduction rows
+
+template <int PREC> struct Frag;
+template <> struct Frag<MHIMX_PREC_BF16X3> {
+  using V8 = b8;
+  static constexpr int NA = 2, NB = 2;
+  static MHIMX_DEV void split2(const f4& a, const f4& b, V8& hi, V8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    split(x, hi, lo);
+  }
+  static MHIMX_DEV void split(const float (&x)[8], V8& hi, V8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const __bf16 h = (__bf16)x[i];
+      hi[i] = h;
+      lo[i] = (__bf16)(x[i] - (float)h);
+    }
+  }
+};
+template <> struct Frag<MHIMX_PREC_F16S> {
+  using V8 = h8;
+  static constexpr int NA = 1, NB = 2;
+  static MHIMX_DEV void split2(const f4& a, const f4& b, V8& hi, V8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    split(x, hi, lo);
+  }
+  static MHIMX_DEV void split(const float (&x)[8], V8& hi, V8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const _Float16 h = (_Float16)x[i];
+      hi[i] = h;
+      lo[i] = (_Float16)(x[i] - (float)h);
+    }
+  }
+};
+
+template <int PREC>
+MHIMX_DEV void mma12(const typename Frag<PREC>::V8 (&ah)[2], const typename Frag<PREC>::V8 (&al)[2],
+                     const typename Frag<PREC>::V8 (&bh)[2], const typename Frag<PREC>::V8 (&bl)[2], f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      if constexpr (PREC == MHIMX_PREC_BF16X3) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      } else {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+}
+
+// N x ds_read_b128 from per-lane LDS byte addresses a[i] + off (issue only; pair with lds_wait<N> before use).
+// Written as asm so the compiler does not tie them to the in-flight LDS-DMA (which would cost a vmcnt(0) drain).
+template <int N>
+MHIMX_DEV void lds_read(f4 (&x)[N], const unsigned (&a)[N], unsigned off, unsigned flip) {
+  static_assert(N == 6 || N == 8, "6 or 8 reads");
+  if constexpr (N == 8) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                 "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+                 : "v"((a[0] + off) ^ flip), "v"((a[1] + off) ^ flip), "v"((a[2] + off) ^ flip), "v"((a[3] + off) ^ flip), "v"((a[4] + off) ^ flip), "v"((a[5] + off) ^ flip),
+                   "v"((a[6] + off) ^ flip), "v"((a[7] + off) ^ flip)
+                 : "memory");
+  } else {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\t"
+                 "ds_read_b128 %4, %10\n\tds_read_b128 %5, %11"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5])
+                 : "v"((a[0] + off) ^ flip), "v"((a[1] + off) ^ flip), "v"((a[2] + off) ^ flip), "v"((a[3] + off) ^ flip), "v"((a[4] + off) ^ flip), "v"((a[5] + off) ^ flip)
+                 : "memory");
+  }
+}
+template <int N>
+MHIMX_DEV void lds_wait(f4 (&x)[N]) {
+  if constexpr (N == 8) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+                 :
+                 : "memory");
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]) : : "memory");
+  }
+}
+
+template <int PREC, int NT>
+MHIMX_DEV void mma_tile(const typename Frag<PREC>::V8 (&ah)[2], const typename Frag<PREC>::V8 (&al)[2],
+                        const typename Frag<PREC>::V8 (&bh)[NT], const typename Frag<PREC>::V8 (&bl)[NT], f32x16 (&acc)[2][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (PREC == MHIMX_PREC_BF16X3) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      } else {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+}
+
+MHIMX_DEV void dma16(const float* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// =================================================================================================
+// NT
+// =================================================================================================
+// NW = 4: 2x2 waves, 64x64 per wave (12 MFMAs per 16-deep k slice);  NW = 8: 2x4 waves, 64x32 per wave (6 MFMAs).
+// Eight waves put two waves on every SIMD even when a CU holds a single workgroup: one wave's DMA issue (~100
+// cycles per LDS-DMA instruction), fragment reads and fp32->bf16 splitting then overlap the other wave's MFMAs.
+template <int PREC, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args g) {
+  using FR = Frag<PREC>;
+  using V8 = typename FR::V8;
+  constexpr int NT = NW == 4 ? 2 : 1;               // 32-column tiles per wave
+  constexpr int NTHR = 64 * NW;
+  constexpr int NDMA = 1024 / NTHR;                 // DMA instructions per thread per operand per k-step
+  constexpr int NRD = 4 + 2 * NT;                   // ds_read_b128 per 16-deep k slice
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = NW == 4 ? (wave >> 1) : (wave >> 2), wn = NW == 4 ? (wave & 1) : (wave & 3);
+  // XCD-aware tile order: the dispatcher places linear block b on XCD b % 8 (speed only, never correctness).
+  // All N-tiles of one M-tile are given to the SAME XCD back to back, so the A (patch-feature) rows are fetched
+  // from HBM once and re-served by that XCD's L2.
+  const int nN = (int)((g.N + DBN - 1) / DBN), nM = (int)((g.M + DBM - 1) / DBM);
+  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int m_tile = (sidx / nN) * 8 + xcd, n_tile = sidx % nN;
+  if (m_tile >= nM) return;
+  const int64_t m0 = (int64_t)m_tile * DBM, n0 = (int64_t)n_tile * DBN;
+
+  // slot p = tid + NTHR*j of a [128 rows][8 slots] tile; LDS position is linear in p, the SOURCE is swizzled
+  const float* asrc[NDMA];
+  const float* bsrc[NDMA];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int p = tid + NTHR * j;
+    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
+    int64_t m = m0 + row, n = n0 + row;
+    if (m >= g.M) m = g.M - 1;                      // clamped rows feed accumulators that are never stored
+    if (n >= g.N) n = g.N - 1;
+    asrc[j] = g.A + (g.rows ? g.rows[m] : m) * g.lda + slot * 4;
+    bsrc[j] = g.B + n * g.ldb + slot * 4;
+  }
+  auto issue = [&](int64_t k0, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + wave * 1024;
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      dma16(asrc[j] + k0, sa + j * (NTHR * 16));
+      dma16(bsrc[j] + k0, sb + j * (NTHR * 16));
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // Fragment addresses (LDS byte offsets, stage 0, ks = 0): 16-B slots s0, s0+1 with s0 = kh*2, swizzled by
+  // (row>>1)&7.  ks = 1 flips slot bit 2 (address ^ 64).  fa[0..3]: A rows wm*64 + q*32 + r; fa[4..]: B rows.
+  const int r = lane & 31, kh = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  unsigned fa[NRD];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ra = wm * 64 + q * 32 + r;
+    fa[q * 2 + 0] = lds0 + ra * 128 + (((kh * 2) ^ ((ra >> 1) & 7)) << 4);
+    fa[q * 2 + 1] = lds0 + ra * 128 + (((kh * 2 + 1) ^ ((ra >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int rb = wn * (32 * NT) + q * 32 + r;
+    fa[4 + q * 2 + 0] = lds0 + TILE_BYTES + rb * 128 + (((kh * 2) ^ ((rb >> 1) & 7)) << 4);
+    fa[4 + q * 2 + 1] = lds0 + TILE_BYTES + rb * 128 + (((kh * 2 + 1) ^ ((rb >> 1) & 7)) << 4);
+  }
+
+  // NSTAGE-deep LDS ring, ONE barrier per k-step, counted vmcnt so younger tiles stay in flight across it.
+  // LDS reads are inline asm: a compiler-visible ds_read after an LDS-DMA makes hipcc drain the queue (vmcnt(0)).
+  const int nk = (int)(g.K / DBK);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue((int64_t)s * DBK, s);
+  for (int t = 0; t < nk; ++t) {
+    const int ahead = (nk - 1 - t) < (NSTAGE - 2) ? (nk - 1 - t) : (NSTAGE - 2);     // tiles issued after tile t
+    if (ahead >= 2) {
+      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (ahead == 1 && NSTAGE > 2) {
+      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                      // tile t landed for every wave; everyone left tile t-1
+    if (t + NSTAGE - 1 < nk) issue((int64_t)(t + NSTAGE - 1) * DBK, (t + NSTAGE - 1) % NSTAGE);
+    const unsigned so = (unsigned)((t % NSTAGE) * STAGE_BYTES);
+    f4 x[NRD], y[NRD];
+    lds_read<NRD>(x, fa, so, 0u);                         // ks = 0
+    lds_wait<NRD>(x);
+    lds_read<NRD>(y, fa, so, 64u);                     // ks = 1 in flight under the first MFMA batch
+    {
+      V8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) FR::split2(x[q * 2], x[q * 2 + 1], ah[q], al[q]);
+#pragma unroll
+      for (int q = 0; q < NT; ++q) FR::split2(x[4 + q * 2], x[4 + q * 2 + 1], bh[q], bl[q]);
+      mma_tile<PREC, NT>(ah, al, bh, bl, acc);
+    }
+    lds_wait<NRD>(y);
+    {
+      V8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) FR::split2(y[q * 2], y[q * 2 + 1], ah[q], al[q]);
+#pragma unroll
+      for (int q = 0; q < NT; ++q) FR::split2(y[4 + q * 2], y[4 + q * 2 + 1], bh[q], bl[q]);
+      mma_tile<PREC, NT>(ah, al, bh, bl, acc);
+    }
+  }
+
+  // ---- epilogue (same contract as gemm.hip)
+  const int cl = lane & 31, rh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int64_t n = n0 + wn * (32 * NT) + nt * 32 + cl;
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+      const float colv = g.rowv ? g.colv[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+        if (m >= g.M) continue;
+        float v = acc[mt][nt][e] + bias;
+        if (g.rowv) v += g.rowv[m] * colv;
+        if (g.pre) g.pre[m * g.ldpre + n] = v;
+        v = act_fwd(v, g.act);
+        if (g.drop_mask) {
+          v = g.drop_mask[m * g.N + n] ? v / (1.f - g.drop_p) : 0.f;
+        } else if (g.drop_p > 0.f) {
+          const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
+          v = drop_keep(g.drop_seed, rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
+        }
+        float* c = g.C + m * g.ldc + n;
+        if (g.accumulate) v += *c;
+        *c = v;
+      }
+    }
+}
+
+// =================================================================================================
+// TN
+// =================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk) {
+  using FR = Frag<PREC>;
+  using V8 = typename FR::V8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t* rowtab = reinterpret_cast<int64_t*>(smem + 2 * STAGE_BYTES);       // [mchunk] B-row element offsets
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware order: all output tiles of one reduction slab run on one XCD (its rows of A and B are shared via L2)
+  const int nJ = (int)(g.K2 / DBN), nT = (int)(g.K1 / DBM) * nJ;
+  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int zslab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
+  if (zslab >= g.splits && !(g.splits <= 1 && zslab == 0)) return;
+  const int64_t i0 = (int64_t)(tile / nJ) * DBM, j0 = (int64_t)(tile % nJ) * DBN;
+  const int64_t mbeg = (int64_t)zslab * mchunk;
+  const int64_t mend = mbeg + mchunk < g.M ? mbeg + mchunk : g.M;
+  const int nrows = (int)(mend > mbeg ? mend - mbeg : 0);
+
+  for (int q = tid; q < nrows; q += DTHREADS) rowtab[q] = (g.rows ? g.rows[mbeg + q] : (mbeg + q)) * g.ldb;
+  __syncthreads();
+
+  // slot p = tid + 256 j of a [32 m][32 slots] tile
+  auto issue = [&](int t, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + wave * 1024;
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = tid + 256 * j;
+      const int mm = t * DBK + (p >> 5), slot = p & 31;
+      const bool in = mm < nrows;
+      const float* a = in ? g.A + (mbeg + mm) * g.lda + i0 + slot * 4 : g_zero_row + slot * 4;
+      const float* b = in ? g.B + rowtab[mm] + j0 + slot * 4 : g_zero_row + slot * 4;
+      dma16(a, sa + j * 4096);
+      dma16(b, sb + j * 4096);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int r = lane & 31, kh = lane >> 5;
+  const int nk = (nrows + DBK - 1) / DBK;
+  if (nk > 0) issue(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float* sa = reinterpret_cast<const float*>(smem + (t & 1) * STAGE_BYTES);
+    const float* sb = sa + TILE_BYTES / 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      V8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ca = wm * 64 + q * 32 + r, cb = wn * 64 + q * 32 + r;
+        const int mrow = ks * 16 + kh * 8;
+        float xa[8], xb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xa[u] = sa[(mrow + u) * 128 + ca];
+          xb[u] = sb[(mrow + u) * 128 + cb];
+        }
+        FR::split(xa, ah[q], al[q]);
+        FR::split(xb, bh[q], bl[q]);
+      }
+      mma12<PREC>(ah, al, bh, bl, acc);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* out = g.splits > 1 ? g.ws + (int64_t)zslab * g.K1 * g.K2 : g.C;
+  const int64_t ldo = g.splits > 1 ? g.K2 : g.ldc;
+  const bool accum = g.splits > 1 ? false : (g.accumulate != 0);
+  const int cl = lane & 31, rh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t j = j0 + wn * 64 + nt * 32 + cl;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t i = i0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+        float v = acc[mt][nt][e];
+        float* p = out + i * ldo + j;
+        if (accum) v += *p;
+        *p = v;
+      }
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+bool nt_dma_ok(const mhimx_gemm_nt_args& g) {
+  return (g.prec == MHIMX_PREC_BF16X3 || g.prec == MHIMX_PREC_F16S) && g.K % DBK == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+         aligned16(g.A) && aligned16(g.B) && g.M > 16;
+}
+
+#ifndef MHIMX_NT_WAVES
+#define MHIMX_NT_WAVES 8
+#endif
+int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
+  constexpr int NW = MHIMX_NT_WAVES;
+  dim3 grid((unsigned)(8 * cdiv(g.N, DBN) * cdiv(cdiv(g.M, DBM), 8)));
+  static bool attr = false;
+  if (!attr) {
+    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
+    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
+    attr = true;
+  }
+  if (g.prec == MHIMX_PREC_BF16X3)
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
+  else
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+bool tn_dma_ok(const mhimx_gemm_tn_args& g) {
+  return g.prec != MHIMX_PREC_F32 && g.K1 % DBM == 0 && g.K2 % DBN == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && aligned16(g.A) &&
+         aligned16(g.B) && g.M > 16;
+}
+
+// picks the split count itself when the caller passes splits <= 0; returns the splits used through *splits_out
+int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_avail) {
+  mhimx_gemm_tn_args g = g0;
+  const int64_t tiles = (g.K1 / DBM) * (g.K2 / DBN);
+  int splits = g.splits > 1 ? g.splits : 1;
+  // enough workgroups to fill 256 CUs twice, at least 4 k-steps each, and a row table that fits LDS
+  int64_t want = cdiv(512, tiles);
+  if (want > cdiv(g.M, 4 * DBK)) want = cdiv(g.M, 4 * DBK);
+  if (want < 1) want = 1;
+  if (g.ws && want > splits) splits = (int)want;
+  while (splits > 1 && (int64_t)splits * g.K1 * g.K2 > ws_floats_avail) --splits;
+  while (cdiv(g.M, splits) > MAX_TN_CHUNK) {
+    ++splits;
+    if ((int64_t)splits * g.K1 * g.K2 > ws_floats_avail) return fail(-1, "gemm_tn: workspace too small for M=%lld", (long long)g.M);
+  }
+  g.splits = splits;
+  const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);
+  const size_t smem = 2 * STAGE_BYTES + (size_t)mchunk * 8;
+  static bool attr = false;
+  if (!attr) {
+    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8));
+    attr = true;
+  }
+  dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8)));
+  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk);
+  MHIMX_LAUNCH_CHECK();
+  return splits;
+}
+
+}  // namespace mhimx

@@ -33,111 +33,234 @@ MHIMX_DEV float block_reduce_max(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// grid (heads, k).  dim_head must be 64 (lane = column).  P[h,i,:] = softmax_r(scale * q_i . k_r)
-__global__ __launch_bounds__(MCA_THREADS) void mca_attend_fwd_kernel(const float* __restrict__ KV, const float* __restrict__ Q,
-                                                                     int64_t R, int heads, int kq, float scale,
-                                                                     float drop_p, uint64_t seed, float* __restrict__ P,
-                                                                     float* __restrict__ O) {
-  __shared__ float red[4];
-  __shared__ float osum[4][64];
-  const int h = blockIdx.x, i = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int inner = heads * 64;
-  const float q = Q[(int64_t)i * inner + h * 64 + lane];
-  float* Prow = P + ((int64_t)h * kq + i) * R;
-  float mx = -INFINITY;
-  for (int64_t r = wave; r < R; r += 4) {
-    const float d = wave_sum(q * KV[r * 2 * inner + h * 64 + lane]) * scale;
-    if (lane == 0) Prow[r] = d;
-    mx = fmaxf(mx, d);
-  }
-  mx = block_reduce_max(mx, red);          // includes the barrier that publishes Prow within the block
-  __threadfence_block();
-  float sum = 0.f;
-  for (int64_t r = threadIdx.x; r < R; r += MCA_THREADS) {
-    const float e = __expf(Prow[r] - mx);
-    Prow[r] = e;
-    sum += e;
-  }
-  sum = block_reduce_sum(sum, red);
-  const float inv = 1.f / sum;
-  for (int64_t r = threadIdx.x; r < R; r += MCA_THREADS) Prow[r] *= inv;
-  __threadfence_block();
-  __syncthreads();
-  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float acc = 0.f;
-  for (int64_t r = wave; r < R; r += 4) {
-    float p = Prow[r];
-    if (drop_p > 0.f) p = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? p * keep_scale : 0.f;
-    acc += p * KV[r * 2 * inner + inner + h * 64 + lane];
-  }
-  osum[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0) O[(int64_t)i * inner + h * 64 + lane] = osum[0][lane] + osum[1][lane] + osum[2][lane] + osum[3][lane];
-}
+// ---------------------------------------------------------------------------------------------------
+// Row-parallel cross attention.  A block owns MCA_ROWS consecutive key rows; its 4 waves split the heads
+// (wave w: heads w, w+4, ...), lane = head-dim column, so every K/V row is read once, in 256-B segments.
+// Forward is flash-style: per (head, query) running max / sum / weighted V sum, one partial per block,
+// merged by a tiny finalize kernel; the n x k probability matrix is never stored, only the raw scores.
+// ---------------------------------------------------------------------------------------------------
+constexpr int MCA_ROWS = 16;
+constexpr int MCA_HPW = 2;            // heads per wave (heads <= 8)
 
-// grid (heads, k): dP_r = dO_i . v_r (dropout-scaled); dd[h,i,r] = P_r (dP_r - sum_r P_r dP_r)
-__global__ __launch_bounds__(MCA_THREADS) void mca_dp_kernel(const float* __restrict__ KV, const float* __restrict__ dO,
-                                                             const float* __restrict__ P, int64_t R, int heads, int kq,
-                                                             float drop_p, uint64_t seed, float* __restrict__ dd) {
-  __shared__ float red[4];
-  const int h = blockIdx.x, i = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int inner = heads * 64;
-  const float go = dO[(int64_t)i * inner + h * 64 + lane];
-  const float* Prow = P + ((int64_t)h * kq + i) * R;
-  float* drow = dd + ((int64_t)h * kq + i) * R;
-  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float dot = 0.f;
-  for (int64_t r = wave; r < R; r += 4) {
-    float dp = wave_sum(go * KV[r * 2 * inner + inner + h * 64 + lane]);
-    if (drop_p > 0.f) dp = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? dp * keep_scale : 0.f;
-    if (lane == 0) drow[r] = dp;
-    dot += (lane == 0) ? Prow[r] * dp : 0.f;
-  }
-  dot = block_reduce_sum(dot, red);
-  __threadfence_block();
-  __syncthreads();
-  for (int64_t r = threadIdx.x; r < R; r += MCA_THREADS) drow[r] = Prow[r] * (drow[r] - dot);
-}
-
-// grid (heads, row blocks): dK[r] = scale sum_i dd[h,i,r] q_i ; dV[r] = sum_i Pd[h,i,r] dO_i
-__global__ __launch_bounds__(MCA_THREADS) void mca_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ dO,
-                                                              const float* __restrict__ P, const float* __restrict__ dd,
-                                                              int64_t R, int heads, int kq, float scale, float drop_p,
-                                                              uint64_t seed, float* __restrict__ dKV) {
-  const int h = blockIdx.x;
+template <int KQ>
+__global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* __restrict__ KV, const float* __restrict__ Q,
+                                                                   int64_t R, int heads, int kq, float scale, float drop_p,
+                                                                   uint64_t seed, float* __restrict__ dots,
+                                                                   float* __restrict__ pm, float* __restrict__ pl,
+                                                                   float* __restrict__ po) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inner = heads * 64;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < R; r += (int64_t)gridDim.y * 4) {
-    float dk = 0.f, dv = 0.f;
-    for (int i = 0; i < kq; ++i) {
-      const int64_t o = ((int64_t)h * kq + i) * R + r;
-      float p = P[o];
-      if (drop_p > 0.f) p = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? p * keep_scale : 0.f;
-      dk += dd[o] * Q[(int64_t)i * inner + h * 64 + lane];
-      dv += p * dO[(int64_t)i * inner + h * 64 + lane];
+  float q[MCA_HPW][KQ], m[MCA_HPW][KQ], l[MCA_HPW][KQ], o[MCA_HPW][KQ];
+#pragma unroll
+  for (int hh = 0; hh < MCA_HPW; ++hh)
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int h = wave + 4 * hh;
+      q[hh][i] = (h < heads && i < kq) ? Q[(int64_t)i * inner + h * 64 + lane] * scale : 0.f;
+      m[hh][i] = -INFINITY; l[hh][i] = 0.f; o[hh][i] = 0.f;
     }
-    dKV[r * 2 * inner + h * 64 + lane] = dk * scale;
-    dKV[r * 2 * inner + inner + h * 64 + lane] = dv;
+  const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
+  const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
+  for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h >= heads) continue;
+      const float kv = KV[r * 2 * inner + h * 64 + lane];
+      const float vv = KV[r * 2 * inner + inner + h * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        if (i >= kq) continue;
+        const float d = wave_sum(q[hh][i] * kv);
+        if (lane == 0) dots[((int64_t)h * kq + i) * R + r] = d;
+        float ks = 1.f;
+        if (drop_p > 0.f) ks = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? keep_scale : 0.f;
+        if (d > m[hh][i]) {
+          const float sc = (m[hh][i] == -INFINITY) ? 0.f : __expf(m[hh][i] - d);
+          l[hh][i] = l[hh][i] * sc + 1.f;
+          o[hh][i] = o[hh][i] * sc + ks * vv;
+          m[hh][i] = d;
+        } else {
+          const float p = __expf(d - m[hh][i]);
+          l[hh][i] += p;
+          o[hh][i] += p * ks * vv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int hh = 0; hh < MCA_HPW; ++hh) {
+    const int h = wave + 4 * hh;
+    if (h >= heads) continue;
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (i >= kq) continue;
+      const int64_t slot = (int64_t)blockIdx.x * heads * kq + h * kq + i;
+      if (lane == 0) { pm[slot] = m[hh][i]; pl[slot] = l[hh][i]; }
+      po[slot * 64 + lane] = o[hh][i];
+    }
   }
 }
 
-// grid (heads, k): dQ[i,h,:] = scale sum_r dd[h,i,r] k_r
-__global__ __launch_bounds__(MCA_THREADS) void mca_dq_kernel(const float* __restrict__ KV, const float* __restrict__ dd,
-                                                             int64_t R, int heads, int kq, float scale,
-                                                             float* __restrict__ dQ) {
-  __shared__ float osum[4][64];
-  const int h = blockIdx.x, i = blockIdx.y;
+// grid (heads*k), 64 threads: merge the per-block partials -> stats[h,i] = {max, sum}, O[i, h*64+c]
+__global__ void mca_fwd_final_kernel(const float* __restrict__ pm, const float* __restrict__ pl, const float* __restrict__ po,
+                                     int nb, int heads, int kq, float* __restrict__ stats, float* __restrict__ O) {
+  const int hi = blockIdx.x, lane = threadIdx.x;
+  const int h = hi / kq, i = hi % kq;
+  const int HK = heads * kq;
+  float mx = -INFINITY;
+  for (int b = lane; b < nb; b += 64) mx = fmaxf(mx, pm[(int64_t)b * HK + hi]);
+  mx = wave_max(mx);
+  float L = 0.f;
+  for (int b = lane; b < nb; b += 64) {
+    const float pmb = pm[(int64_t)b * HK + hi];
+    L += (pmb == -INFINITY) ? 0.f : pl[(int64_t)b * HK + hi] * __expf(pmb - mx);
+  }
+  L = wave_sum(L);
+  float acc = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const float pmb = pm[(int64_t)b * HK + hi];
+    if (pmb != -INFINITY) acc += po[((int64_t)b * HK + hi) * 64 + lane] * __expf(pmb - mx);
+  }
+  O[(int64_t)i * heads * 64 + h * 64 + lane] = acc / L;
+  if (lane == 0) { stats[2 * hi] = mx; stats[2 * hi + 1] = L; }
+}
+
+// backward pass 1: dP[h,i,r] = (dO_i . v_r) * keep/(1-p) ; per-block partial of sum_r P dP
+template <int KQ>
+__global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dp_kernel(const float* __restrict__ KV, const float* __restrict__ dO,
+                                                                 const float* __restrict__ dots, const float* __restrict__ stats,
+                                                                 int64_t R, int heads, int kq, float drop_p, uint64_t seed,
+                                                                 float* __restrict__ dP, float* __restrict__ prd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inner = heads * 64;
-  const float* drow = dd + ((int64_t)h * kq + i) * R;
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float go[MCA_HPW][KQ], rd[MCA_HPW][KQ], mx[MCA_HPW][KQ], il[MCA_HPW][KQ];
+#pragma unroll
+  for (int hh = 0; hh < MCA_HPW; ++hh)
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int h = wave + 4 * hh;
+      const bool ok = h < heads && i < kq;
+      go[hh][i] = ok ? dO[(int64_t)i * inner + h * 64 + lane] : 0.f;
+      mx[hh][i] = ok ? stats[2 * (h * kq + i)] : 0.f;
+      il[hh][i] = ok ? 1.f / stats[2 * (h * kq + i) + 1] : 0.f;
+      rd[hh][i] = 0.f;
+    }
+  const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
+  const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
+  for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h >= heads) continue;
+      const float vv = KV[r * 2 * inner + inner + h * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        if (i >= kq) continue;
+        float dp = wave_sum(go[hh][i] * vv);
+        if (drop_p > 0.f) dp = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? dp * keep_scale : 0.f;
+        const int64_t o = ((int64_t)h * kq + i) * R + r;
+        if (lane == 0) dP[o] = dp;
+        rd[hh][i] += __expf(dots[o] - mx[hh][i]) * il[hh][i] * dp;
+      }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h >= heads) continue;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i)
+        if (i < kq) prd[(int64_t)blockIdx.x * heads * kq + h * kq + i] = rd[hh][i];
+    }
+  }
+}
+
+// backward pass 2: dd = scale * P (dP - rowdot); dK_r = sum_i dd q_i; dV_r = sum_i Pd dO_i; per-block partial dQ_i += dd k_r
+template <int KQ>
+__global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* __restrict__ KV, const float* __restrict__ Q,
+                                                                  const float* __restrict__ dO, const float* __restrict__ dots,
+                                                                  const float* __restrict__ stats, const float* __restrict__ dP,
+                                                                  const float* __restrict__ prd, int nb, int64_t R, int heads,
+                                                                  int kq, float scale, float drop_p, uint64_t seed,
+                                                                  float* __restrict__ dKV, float* __restrict__ pdq) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int inner = heads * 64;
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float q[MCA_HPW][KQ], go[MCA_HPW][KQ], rd[MCA_HPW][KQ], mx[MCA_HPW][KQ], il[MCA_HPW][KQ], dq[MCA_HPW][KQ];
+#pragma unroll
+  for (int hh = 0; hh < MCA_HPW; ++hh)
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int h = wave + 4 * hh;
+      const bool ok = h < heads && i < kq;
+      q[hh][i] = ok ? Q[(int64_t)i * inner + h * 64 + lane] : 0.f;
+      go[hh][i] = ok ? dO[(int64_t)i * inner + h * 64 + lane] : 0.f;
+      mx[hh][i] = ok ? stats[2 * (h * kq + i)] : 0.f;
+      il[hh][i] = ok ? 1.f / stats[2 * (h * kq + i) + 1] : 0.f;
+      float s = 0.f;
+      if (ok)
+        for (int b = lane; b < nb; b += 64) s += prd[(int64_t)b * heads * kq + h * kq + i];
+      rd[hh][i] = wave_sum(s);
+      dq[hh][i] = 0.f;
+    }
+  const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
+  const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
+  for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      if (h >= heads) continue;
+      const float kv = KV[r * 2 * inner + h * 64 + lane];
+      float dk = 0.f, dv = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        if (i >= kq) continue;
+        const int64_t o = ((int64_t)h * kq + i) * R + r;
+        const float p = __expf(dots[o] - mx[hh][i]) * il[hh][i];
+        const float dd = scale * p * (dP[o] - rd[hh][i]);
+        float pd = p;
+        if (drop_p > 0.f) pd = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? p * keep_scale : 0.f;
+        dk += dd * q[hh][i];
+        dv += pd * go[hh][i];
+        dq[hh][i] += dd * kv;
+      }
+      dKV[r * 2 * inner + h * 64 + lane] = dk;
+      dKV[r * 2 * inner + inner + h * 64 + lane] = dv;
+    }
+  }
+#pragma unroll
+  for (int hh = 0; hh < MCA_HPW; ++hh) {
+    const int h = wave + 4 * hh;
+    if (h >= heads) continue;
+#pragma unroll
+    for (int i = 0; i < KQ; ++i)
+      if (i < kq) pdq[((int64_t)blockIdx.x * kq + i) * inner + h * 64 + lane] = dq[hh][i];
+  }
+}
+
+// out[j] = sum_b part[b][j]  (fixed order), 2-D parallel: blockDim (64, 4)
+__global__ void mca_reduce_kernel(const float* __restrict__ part, int nb, int W, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int j = blockIdx.x * 64 + threadIdx.x;
   float acc = 0.f;
-  for (int64_t r = wave; r < R; r += 4) acc += drow[r] * KV[r * 2 * inner + h * 64 + lane];
-  osum[wave][lane] = acc;
+  if (j < W)
+    for (int b = threadIdx.y; b < nb; b += 4) acc += part[(int64_t)b * W + j];
+  red[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
-  if (wave == 0) dQ[(int64_t)i * inner + h * 64 + lane] = scale * (osum[0][lane] + osum[1][lane] + osum[2][lane] + osum[3][lane]);
+  if (threadIdx.y == 0 && j < W) out[j] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <typename F>
+static int dispatch_kq(int64_t k, F&& f) {
+  if (k <= 1) return f(std::integral_constant<int, 1>());
+  if (k <= 5) return f(std::integral_constant<int, 5>());
+  if (k <= 10) return f(std::integral_constant<int, 10>());
+  if (k <= 16) return f(std::integral_constant<int, 16>());
+  return fail(-1, "merge: k=%lld global queries unsupported (max 16)", (long long)k);
 }
 
 __global__ void ema_kernel(const float* __restrict__ q, const float* __restrict__ z, float* __restrict__ out, int64_t n, float mm) {
@@ -158,6 +281,8 @@ __global__ void drop_bwd_kernel(const float* __restrict__ dz, float* __restrict_
 
 struct MergeWs {
   float *xn, *mean, *rstd, *gq, *gmean, *grstd, *KV, *Q, *P, *O, *dd, *dKV, *dQ, *dO, *dxn, *dgq, *dz0, *lnp_w, *lnp_b, *scratch;
+  float *stats, *pm, *pl, *po, *prd, *pdq;
+  int nb;
   int64_t scratch_bytes;
 };
 
@@ -183,6 +308,13 @@ static int64_t merge_ws_layout(Arena& ar, int64_t R, int64_t E, int64_t k, int64
   w.dz0 = ar.take<float>(k * E);
   w.lnp_w = ar.take<float>(512 * E);
   w.lnp_b = ar.take<float>(512 * E);
+  w.nb = (int)cdiv(R, MCA_ROWS);
+  w.stats = ar.take<float>(2 * heads * k);
+  w.pm = ar.take<float>((int64_t)w.nb * heads * k);
+  w.pl = ar.take<float>((int64_t)w.nb * heads * k);
+  w.po = ar.take<float>((int64_t)w.nb * heads * k * 64);
+  w.prd = ar.take<float>((int64_t)w.nb * heads * k);
+  w.pdq = ar.take<float>((int64_t)w.nb * k * I);
   w.scratch_bytes = 8 * 2 * I * E * 4;         // split-K slabs for dWkv (8 x [2I,E]) / colsum partials
   w.scratch = (float*)ar.take<char>(w.scratch_bytes);
   if (out) *out = w;
@@ -192,7 +324,7 @@ static int64_t merge_ws_layout(Arena& ar, int64_t R, int64_t E, int64_t k, int64
 static int check_merge(const mhimx_merge* m) {
   MHIMX_CHECK_ARG(m && m->q_param && m->ln_w && m->ln_b && m->wkv && m->wq && m->wo && m->bo, "merge: null weights");
   MHIMX_CHECK_ARG(m->dim_head == 64, "merge: dim_head must be 64");
-  MHIMX_CHECK_ARG(m->heads > 0 && m->k > 0 && m->E % 64 == 0, "merge: bad dims");
+  MHIMX_CHECK_ARG(m->heads > 0 && m->heads <= 8 && m->k > 0 && m->k <= 16 && m->E % 64 == 0, "merge: bad dims (heads <= 8, k <= 16)");
   return 0;
 }
 
@@ -215,8 +347,14 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
   if (int r = gemm_nt(st, g)) return r;
   const float scale = 1.0f / sqrtf((float)m->dim_head);
-  hipLaunchKernelGGL(mca_attend_fwd_kernel, dim3((unsigned)H, (unsigned)k), dim3(MCA_THREADS), 0, st, w.KV, w.Q, R, (int)H, (int)k,
-                     scale, m->drop_p, m->drop_seed, w.P, w.O);
+  if (int r = dispatch_kq(k, [&](auto kqc) {
+        constexpr int KQ = decltype(kqc)::value;
+        hipLaunchKernelGGL(mca_fwd_part_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, R, (int)H, (int)k, scale,
+                           m->drop_p, m->drop_seed, w.P, w.pm, w.pl, w.po);
+        MHIMX_LAUNCH_CHECK();
+        return 0;
+      })) return r;
+  hipLaunchKernelGGL(mca_fwd_final_kernel, dim3((unsigned)(H * k)), dim3(64), 0, st, w.pm, w.pl, w.po, w.nb, (int)H, (int)k, w.stats, w.O);
   MHIMX_LAUNCH_CHECK();
   g = {};
   g.A = w.O; g.lda = I; g.B = m->wo; g.ldb = I; g.C = z; g.ldc = E; g.M = k; g.N = E; g.K = I; g.bias = m->bo; g.prec = fprec;
@@ -257,14 +395,17 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   if (int r = gemm_nt(st, g)) return r;
   // attention
   const float scale = 1.0f / sqrtf((float)m->dim_head);
-  hipLaunchKernelGGL(mca_dp_kernel, dim3((unsigned)H, (unsigned)k), dim3(MCA_THREADS), 0, st, w.KV, w.dO, w.P, R, (int)H, (int)k,
-                     m->drop_p, m->drop_seed, w.dd);
-  MHIMX_LAUNCH_CHECK();
-  const unsigned rb = (unsigned)(cdiv(R, 16) < 64 ? cdiv(R, 16) : 64);
-  hipLaunchKernelGGL(mca_dkv_kernel, dim3((unsigned)H, rb), dim3(MCA_THREADS), 0, st, w.Q, w.dO, w.P, w.dd, R, (int)H, (int)k, scale,
-                     m->drop_p, m->drop_seed, w.dKV);
-  MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mca_dq_kernel, dim3((unsigned)H, (unsigned)k), dim3(MCA_THREADS), 0, st, w.KV, w.dd, R, (int)H, (int)k, scale, w.dQ);
+  if (int r = dispatch_kq(k, [&](auto kqc) {
+        constexpr int KQ = decltype(kqc)::value;
+        hipLaunchKernelGGL(mca_bwd_dp_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.dO, w.P, w.stats, R, (int)H,
+                           (int)k, m->drop_p, m->drop_seed, w.dd, w.prd);
+        MHIMX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mca_bwd_dkv_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, w.dO, w.P, w.stats, w.dd,
+                           w.prd, w.nb, R, (int)H, (int)k, scale, m->drop_p, m->drop_seed, w.dKV, w.pdq);
+        MHIMX_LAUNCH_CHECK();
+        return 0;
+      })) return r;
+  hipLaunchKernelGGL(mca_reduce_kernel, dim3((unsigned)cdiv(k * I, 64)), dim3(64, 4), 0, st, w.pdq, w.nb, (int)(k * I), w.dQ);
   MHIMX_LAUNCH_CHECK();
   // projections
   g = {};
@@ -272,7 +413,7 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   if (int r = gemm_nt(st, g)) return r;
   t = {};
   t.A = w.dKV; t.lda = 2 * I; t.B = w.xn; t.ldb = E; t.C = gr->d_wkv; t.ldc = E; t.M = R; t.K1 = 2 * I; t.K2 = E;
-  t.splits = (R >= 2048 && gr->splits > 1) ? (gr->splits > 8 ? 8 : gr->splits) : 1; t.ws = w.scratch; t.accumulate = acc; t.prec = gprec;
+  t.splits = 1; t.ws = w.scratch; t.ws_floats = w.scratch_bytes / 4; t.accumulate = acc; t.prec = gprec;
   if (int r = gemm_tn(st, t)) return r;
   t = {};
   t.A = w.dQ; t.lda = I; t.B = w.gq; t.ldb = E; t.C = gr->d_wq; t.ldc = E; t.M = k; t.K1 = I; t.K2 = E; t.splits = 1;

@@ -90,40 +90,40 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_fwd_kernel(
   }
 }
 
-// merge G partials: stats = {max, sumexp}, z[e] = sum_b pz[b][e] e^{pm[b]-max} / sumexp
-__global__ void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
-                                     const float* __restrict__ pz, int G, int E, float* __restrict__ stats,
-                                     float* __restrict__ z) {
-  __shared__ float red[ROWS_THREADS];
+// merge G partials: stats = {max, sumexp}, z[e] = sum_b pz[b][e] e^{pm[b]-max} / sumexp.
+// grid = E/64 blocks of 256 threads (64 columns x 4 partial groups); every block re-derives the G weights.
+__global__ __launch_bounds__(ROWS_THREADS) void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                      const float* __restrict__ pz, int G, int E,
+                                                                      float* __restrict__ stats, float* __restrict__ z) {
+  __shared__ float red[4];
   __shared__ float wgt[2 * MAX_PART];
+  __shared__ float acc4[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float m = -INFINITY;
-  for (int b = threadIdx.x; b < G; b += blockDim.x) m = fmaxf(m, pm[b]);
-  red[threadIdx.x] = m;
+  for (int b = threadIdx.x; b < G; b += ROWS_THREADS) m = fmaxf(m, pm[b]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
   __syncthreads();
-  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-    __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float lp = 0.f;
+  for (int b = threadIdx.x; b < G; b += ROWS_THREADS) {
+    const float w = (pm[b] == -INFINITY) ? 0.f : __expf(pm[b] - mx);
+    wgt[b] = w;
+    lp += pl[b] * w;
   }
-  const float mx = red[0];
+  lp = wave_sum(lp);
+  if (lane == 0) red[wave] = lp;
   __syncthreads();
-  for (int b = threadIdx.x; b < G; b += blockDim.x) wgt[b] = (pm[b] == -INFINITY) ? 0.f : __expf(pm[b] - mx);
+  const float L = (red[0] + red[1]) + (red[2] + red[3]);      // fixed order: deterministic
+  const int e = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (e < E)
+    for (int b = wave; b < G; b += 4) acc += pz[(int64_t)b * E + e] * wgt[b];
+  acc4[wave][lane] = acc;
   __syncthreads();
-  // fixed-order sum of l (thread 0) keeps the result bit-reproducible run to run
-  __shared__ float Ls;
-  if (threadIdx.x == 0) {
-    float L = 0.f;
-    for (int b = 0; b < G; ++b) L += pl[b] * wgt[b];
-    Ls = L;
-    stats[0] = mx;
-    stats[1] = L;
-  }
-  __syncthreads();
-  const float inv = 1.f / Ls;
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    float acc = 0.f;
-    for (int b = 0; b < G; ++b) acc += pz[(int64_t)b * E + e] * wgt[b];
-    z[e] = acc * inv;
-  }
+  if (wave == 0 && e < E) z[e] = ((acc4[0][lane] + acc4[1][lane]) + (acc4[2][lane] + acc4[3][lane])) / L;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = mx; stats[1] = L; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -199,11 +199,22 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_bwd_kernel(
 }
 
 // out[j] (+)= sum_b part[b][j]   (fixed order)
+// launched with 128 threads = 32 columns x 4 row groups per block (fixed summation order -> deterministic)
 __global__ void reduce_parts_kernel(const float* __restrict__ part, int G, int W, int ld, float* __restrict__ out, int accumulate) {
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W; j += gridDim.x * blockDim.x) {
+  __shared__ float red[4][32];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  for (int j0 = blockIdx.x * 32; j0 < W; j0 += gridDim.x * 32) {
+    const int j = j0 + c;
     float acc = 0.f;
-    for (int b = 0; b < G; ++b) acc += part[(int64_t)b * ld + j];
-    out[j] = accumulate ? out[j] + acc : acc;
+    if (j < W)
+      for (int b = rg; b < G; b += 4) acc += part[(int64_t)b * ld + j];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (rg == 0 && j < W) {
+      const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      out[j] = accumulate ? out[j] + v : v;
+    }
+    __syncthreads();
   }
 }
 
@@ -347,6 +358,13 @@ __global__ void compose_ids_kernel(const int64_t* __restrict__ a, const int64_t*
 // =================================================================================================
 // host side
 // =================================================================================================
+static int grid_for_ln(int64_t M) {       // LayerNorm: one row per wave, no partial-count limit issues (<= 512 blocks)
+  int64_t g = cdiv(M, 4);
+  if (g < 1) g = 1;
+  if (g > MAX_PART) g = MAX_PART;
+  return (int)g;
+}
+
 static int grid_for_rows(int64_t M) {
   int64_t g = cdiv(M, 32);
   if (g < 1) g = 1;
@@ -437,7 +455,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
-  hipLaunchKernelGGL(pool_finalize_kernel, dim3(1), dim3(ROWS_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z);
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(E, 64)), dim3(ROWS_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -479,10 +497,10 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(128), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
   MHIMX_LAUNCH_CHECK();
   if (gr->d_bc) {
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(64), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(128), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
     MHIMX_LAUNCH_CHECK();
   }
   off = 0;
@@ -506,7 +524,7 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     int splits = gr->splits > 1 ? gr->splits : 1;
     while (splits > 1 && (int64_t)splits * A * E > (int64_t)2 * MAX_PART * E) splits >>= 1;
     if (Ms[seg] < 2048) splits = 1;
-    t.splits = splits; t.ws = w.pz;
+    t.splits = splits; t.ws = w.pz; t.ws_floats = (int64_t)2 * MAX_PART * E;
     if (int r = gemm_tn(st, t)) return r;
     if (gated) {
       t.A = w.du + off * ldu + A; t.C = gr->d_wb;
@@ -522,12 +540,12 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(W, 128), gy), dim3(128), 0, st, w.du, M, (int)W, chunk, w.pz);
     MHIMX_LAUNCH_CHECK();
     if (gr->d_ba) {
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, w.pz, gy, (int)A, (int)W, gr->d_ba, gr->accumulate);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(128), 0, st, w.pz, gy, (int)A, (int)W, gr->d_ba, gr->accumulate);
       MHIMX_LAUNCH_CHECK();
     }
     if (gr->d_bb && gated) {
       // columns [A, 2A): strided view handled by offsetting the partial pointer (row pitch W)
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 128)), dim3(128), 0, st, w.pz + A, gy, (int)A, (int)W, gr->d_bb, gr->accumulate);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(128), 0, st, w.pz + A, gy, (int)A, (int)W, gr->d_bb, gr->accumulate);
       MHIMX_LAUNCH_CHECK();
     }
   }
@@ -538,7 +556,7 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
                   float* mean, float* rstd) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for_rows(M)), dim3(ROWS_THREADS), 0, st, x, M, (int)E, w, b, y, mean, rstd);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for_ln(M)), dim3(ROWS_THREADS), 0, st, x, M, (int)E, w, b, y, mean, rstd);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -548,13 +566,13 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
-  const int grid = grid_for_rows(M);
+  const int grid = grid_for_ln(M);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
                      w, mean, rstd, dx, dw_part, db_part);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 128)), dim3(128), 0, st, dw_part, grid, (int)E, (int)E, d_w, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(128), 0, st, dw_part, grid, (int)E, (int)E, d_w, accumulate);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 128)), dim3(128), 0, st, db_part, grid, (int)E, (int)E, d_b, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(128), 0, st, db_part, grid, (int)E, (int)E, d_b, accumulate);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -566,7 +584,7 @@ int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int
   MHIMX_CHECK_ARG(ws && ws_bytes >= (int64_t)gy * E * 4, "colsum: workspace too small (need %lld bytes)", (long long)(gy * E * 4));
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(E, 128), gy), dim3(128), 0, st, X, M, (int)E, chunk, (float*)ws);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 128)), dim3(128), 0, st, (const float*)ws, gy, (int)E, (int)E, out, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(128), 0, st, (const float*)ws, gy, (int)E, (int)E, out, accumulate);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

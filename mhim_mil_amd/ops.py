@@ -78,9 +78,13 @@ def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3"
     K1, K2 = a.shape[1], b.shape[1]
     if out is None:
         out = torch.empty((K1, K2), device=a.device, dtype=torch.float32)
-    ws = torch.empty((splits, K1, K2), device=a.device, dtype=torch.float32) if splits > 1 else None
+    nslab = max(int(splits), 1)
+    if splits > 1:                       # room for the library to split the reduction further (fills the chip)
+        nslab = max(nslab, min(64, -(-512 // max(1, (K1 // 128) * (K2 // 128)))), -(-M // 4096))
+    ws = torch.empty((nslab, K1, K2), device=a.device, dtype=torch.float32) if nslab > 1 else None
     g = L.GemmTN(A=_p(a), lda=a.stride(0), B=_p(b), ldb=b.stride(0), rows=_p(rows), C=_p(out), ldc=out.stride(0), M=M,
-                 K1=K1, K2=K2, splits=int(splits), ws=_p(ws), accumulate=int(bool(accumulate)), prec=prec_code(prec))
+                 K1=K1, K2=K2, splits=int(splits), ws=_p(ws), accumulate=int(bool(accumulate)), prec=prec_code(prec),
+                 ws_floats=0 if ws is None else ws.numel())
     L.check(L.lib().mhimx_gemm_tn(_stream(), C.byref(g)), "mhimx_gemm_tn")
     return out
 
