@@ -61,6 +61,8 @@ typedef struct {
   float drop_p; uint64_t drop_seed; const uint8_t* drop_mask;   /* dropout: hashed RNG or injected keep-mask */
   int32_t accumulate;                                    /* C += ...                              */
   int32_t prec;                                          /* MHIMX_PREC_*                          */
+  const uint64_t* drop_tick;                             /* optional device step counter mixed into drop_seed (graph replay) */
+  const uint16_t* B_hi; const uint16_t* B_lo;            /* optional pre-split 16-bit planes of B [N,K] (mhimx_split_planes) */
 } mhimx_gemm_nt_args;
 int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
 
@@ -78,6 +80,10 @@ typedef struct {
   int64_t ws_floats;                                     /* capacity of ws; the library may raise `splits` up to it   */
 } mhimx_gemm_tn_args;
 int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a);
+
+/* hi[i], lo[i] = 16-bit split of w[i] (bf16 planes for MHIMX_PREC_BF16X3, fp16 for F16S): lets a weight operand go
+ * LDS -> MFMA with no per-tile conversion.  Done once per step per weight (weights change every step). */
+int mhimx_split_planes(void* stream, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int32_t prec);
 
 /* out[c,r] = in[r,c]  (weights are transposed once per step so that dX = dY W is also an NT GEMM) */
 int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C);
@@ -153,6 +159,17 @@ int mhimx_select_mask(void* stream, const float* score, int64_t N, int64_t k, in
                       int64_t* mask_ids, int64_t* len_keep_dev, int64_t* topk_sorted /* [k] optional */,
                       void* ws, int64_t ws_bytes);
 
+/* Production form of the HAM mask + Merge split, all on the device and without host-drawn permutations:
+ *  candidates = top-k of score (tie contract above); a uniformly random n_sel-subset of them is masked (masking.py:66-71);
+ *  of the L = N - n_sel kept rows a uniformly random merge_R-subset is set aside for merging (merge.py:158-176).
+ *  rows_out[L] int64 = [kept rows that stay, ascending (L - merge_R) | rows to merge, ascending (merge_R)];
+ *  mask_ids[N] optional (kept ascending ++ masked).  Random keys: counter hash of (rand_seed + *tick, row).
+ *  Same distribution of SETS as the reference; the reference's random ORDER of kept rows is irrelevant to the pool.
+ *  N <= 16384, k <= 4096. */
+int mhimx_select_rows(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
+                      uint64_t rand_seed, const uint64_t* tick, int64_t merge_R, int64_t* rows_out, int64_t* mask_ids,
+                      void* ws, int64_t ws_bytes);
+
 /* vote[n] = number of heads whose top-k contains n (masking.py:49-57, msa_fusion='vote'); attn [H,N] */
 int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,
                       float* vote, void* ws, int64_t ws_bytes);
@@ -174,6 +191,7 @@ typedef struct {
   float mm;                           /* EMA momentum g_q_mm                                         */
   float drop_p; uint64_t drop_seed;   /* MCA dropout (merge.py:33,40), hashed RNG; 0 = off           */
   int32_t prec;
+  const uint64_t* drop_tick;          /* optional device step counter mixed into drop_seed           */
 } mhimx_merge;
 int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
 /* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */
@@ -190,9 +208,12 @@ int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t 
 /* ------------------------------------------------------------------------------------------
  * Feature projection backward pieces                            
  * ---------------------------------------------------------------------------------------- */
-/* dPre = dH * act'(pre or H) * keep/(1-p), in place on dH.  For relu `pre` may be NULL (uses H>0). */
+/* dPre = dH * act'(pre or H) * keep/(1-p), in place on dH.  For relu `pre` may be NULL (uses H>0).
+ * colsum_out[E] (optional, (+)= if accumulate): column sums of dPre = the feature-bias gradient, produced in the same pass
+ * (ws: 1024*E floats). */
 int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int64_t M, int64_t E, int32_t act,
-                  float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows);
+                  float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows, float* colsum_out,
+                  int32_t accumulate, void* ws, int64_t ws_bytes, const uint64_t* drop_tick);
 /* out[e] (+)= sum_m X[m,e] */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);
@@ -221,7 +242,11 @@ int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float
  * ---------------------------------------------------------------------------------------- */
 int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
                    int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                   float grad_scale, float ema_mm, int32_t zero_grad /* also clears g (cast away const) */);
+                   float grad_scale, float ema_mm, int32_t zero_grad /* also clears g (cast away const) */,
+                   const uint64_t* step_dev /* optional: Adam step read from device memory (graph replay) */);
+
+/* *counter += 1 (device-resident step counters for dropout streams / Adam under hipGraph replay) */
+int mhimx_tick(void* stream, uint64_t* counter);
 
 #ifdef __cplusplus
 }

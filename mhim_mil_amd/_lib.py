@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmhimx.so")
+LIB_PATH = os.path.join(HERE, os.environ.get("MHIMX_LIB_NAME", "libmhimx.so"))
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p
@@ -32,7 +32,7 @@ class GemmNT(C.Structure):
                 ("pre", c_f32p), ("ldpre", C.c_int64),
                 ("act", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p),
-                ("accumulate", C.c_int32), ("prec", C.c_int32)]
+                ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p), ("B_hi", C.c_void_p), ("B_lo", C.c_void_p)]
 
 
 class GemmTN(C.Structure):
@@ -68,7 +68,7 @@ class Merge(C.Structure):
                 ("q_param", c_f32p), ("ln_w", c_f32p), ("ln_b", c_f32p),
                 ("wkv", c_f32p), ("wq", c_f32p), ("wo", c_f32p), ("bo", c_f32p),
                 ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
-                ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32)]
+                ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p)]
 
 
 class MergeGrad(C.Structure):
@@ -87,6 +87,7 @@ SYMBOLS = {
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
     "mhimx_gemm_tn": (C.c_int, [_P, C.POINTER(GemmTN)]),
+    "mhimx_split_planes": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
     "mhimx_transpose": (C.c_int, [_P, _P, _P, _I64, _I64]),
     "mhimx_abmil_pool_ws_bytes": (_I64, [_I64, _I64, _I64, _I32]),
     "mhimx_abmil_pool_fwd": (C.c_int, [_P, C.POINTER(Scorer), C.POINTER(PoolIO)]),
@@ -95,15 +96,17 @@ SYMBOLS = {
     "mhimx_pseudo_score": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64]),
     "mhimx_select_ws_bytes": (_I64, [_I64]),
     "mhimx_select_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64, _P, _P, _P, _P, _I64]),
+    "mhimx_select_rows": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _U64, _P, _I64, _P, _P, _P, _I64]),
     "mhimx_vote_scores": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64]),
     "mhimx_compose_ids": (C.c_int, [_P, _P, _P, _P, _I64]),
     "mhimx_merge_ws_bytes": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "mhimx_merge_fwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I32, _P, _I64]),
     "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
-    "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P]),
+    "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
-    "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32]),
+    "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P]),
+    "mhimx_tick": (C.c_int, [_P, _P]),
 }
 
 _lib = None

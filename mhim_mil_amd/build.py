@@ -20,6 +20,10 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmhimx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS += os.environ.get("MHIMX_EXTRA_FLAGS", "").split()          # experiments only (e.g. -DMHIMX_DBG_NOCOMPUTE)
+if os.environ.get("MHIMX_LIB_NAME"):
+    LIB = os.path.join(HERE, os.environ["MHIMX_LIB_NAME"])
+    OBJ = os.path.join(HERE, "build_" + os.environ["MHIMX_LIB_NAME"].replace(".", "_"))
 
 
 def sources():

@@ -96,6 +96,12 @@ template <int CTRL, int ROW_MASK>
 MHIMX_DEV float dpp_mov(float old, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+// dropout seed of this launch: the by-value seed plus an optional device-resident step counter, so a captured
+// hipGraph (kernel arguments frozen at capture) still draws a fresh mask on every replay
+MHIMX_DEV uint64_t eff_seed(uint64_t seed, const uint64_t* tick) {
+  return tick ? seed + tick[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
 MHIMX_DEV float wave_sum(float v) {
   v += dpp_mov<0xB1, 0xf>(0.f, v);
   v += dpp_mov<0x4E, 0xf>(0.f, v);

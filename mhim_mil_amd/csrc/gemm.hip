@@ -27,6 +27,9 @@ bool nt_dma_ok(const mhimx_gemm_nt_args& g);
 int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g);
 bool tn_dma_ok(const mhimx_gemm_tn_args& g);
 int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_avail);
+bool nt_planes_ok(const mhimx_gemm_nt_args& g);
+int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g);
+int split_planes(hipStream_t st, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int prec);
 
 template <int PREC> struct Prec;
 template <> struct Prec<MHIMX_PREC_F32> {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g)
           v = g.drop_mask[m * g.N + n] ? v / (1.f - g.drop_p) : 0.f;
         } else if (g.drop_p > 0.f) {
           const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
-          v = drop_keep(g.drop_seed, rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
+          v = drop_keep(eff_seed(g.drop_seed, g.drop_tick), rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
         }
         float* c = g.C + m * g.ldc + n;
         if (g.accumulate) v += *c;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) {
       v = g.drop_mask[m * g.N + n] ? v / (1.f - g.drop_p) : 0.f;
     } else if (g.drop_p > 0.f) {
       const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
-      v = drop_keep(g.drop_seed, rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
+      v = drop_keep(eff_seed(g.drop_seed, g.drop_tick), rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
     }
     float* c = g.C + m * g.ldc + n;
     if (g.accumulate) v += *c;
@@ -306,6 +309,7 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
+  if (nt_planes_ok(g)) return gemm_nt_planes(st, g);
   if (nt_dma_ok(g)) return gemm_nt_dma(st, g);
   switch (g.prec) {
     case MHIMX_PREC_F32: return launch_nt<MHIMX_PREC_F32>(st, g);
@@ -488,6 +492,9 @@ extern "C" int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a) {
 extern "C" int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_tn: null args");
   return mhimx::gemm_tn((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_split_planes(void* stream, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int32_t prec) {
+  return mhimx::split_planes((hipStream_t)stream, w, hi, lo, n, prec);
 }
 extern "C" int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C) {
   return mhimx::transpose((hipStream_t)stream, in, out, R, C);

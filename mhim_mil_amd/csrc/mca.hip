@@ -39,15 +39,16 @@ MHIMX_DEV float block_reduce_max(float v, float* red) {
 // Forward is flash-style: per (head, query) running max / sum / weighted V sum, one partial per block,
 // merged by a tiny finalize kernel; the n x k probability matrix is never stored, only the raw scores.
 // ---------------------------------------------------------------------------------------------------
-constexpr int MCA_ROWS = 16;
+constexpr int MCA_ROWS = 4;             // key rows per block: small => many blocks, the row loop is latency bound
 constexpr int MCA_HPW = 2;            // heads per wave (heads <= 8)
 
 template <int KQ>
 __global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* __restrict__ KV, const float* __restrict__ Q,
                                                                    int64_t R, int heads, int kq, float scale, float drop_p,
-                                                                   uint64_t seed, float* __restrict__ dots,
+                                                                   uint64_t seed0, const uint64_t* __restrict__ tick, float* __restrict__ dots,
                                                                    float* __restrict__ pm, float* __restrict__ pl,
                                                                    float* __restrict__ po) {
+  const uint64_t seed = eff_seed(seed0, tick);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inner = heads * 64;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -62,13 +63,27 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* 
     }
   const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
   const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
-  for (int64_t r = r0; r < r1; ++r) {
+  float kbuf[MCA_ROWS][MCA_HPW], vbuf[MCA_ROWS][MCA_HPW];
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr)
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      const int64_t r = r0 + rr;
+      const bool ok = h < heads && r < r1;
+      kbuf[rr][hh] = ok ? KV[r * 2 * inner + h * 64 + lane] : 0.f;
+      vbuf[rr][hh] = ok ? KV[r * 2 * inner + inner + h * 64 + lane] : 0.f;
+    }
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr) {
+    const int64_t r = r0 + rr;
+    if (r >= r1) break;
 #pragma unroll
     for (int hh = 0; hh < MCA_HPW; ++hh) {
       const int h = wave + 4 * hh;
       if (h >= heads) continue;
-      const float kv = KV[r * 2 * inner + h * 64 + lane];
-      const float vv = KV[r * 2 * inner + inner + h * 64 + lane];
+      const float kv = kbuf[rr][hh];
+      const float vv = vbuf[rr][hh];
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
         if (i >= kq) continue;
@@ -103,36 +118,55 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* 
   }
 }
 
-// grid (heads*k), 64 threads: merge the per-block partials -> stats[h,i] = {max, sum}, O[i, h*64+c]
-__global__ void mca_fwd_final_kernel(const float* __restrict__ pm, const float* __restrict__ pl, const float* __restrict__ po,
-                                     int nb, int heads, int kq, float* __restrict__ stats, float* __restrict__ O) {
-  const int hi = blockIdx.x, lane = threadIdx.x;
+// grid (heads*k), 1024 threads (16 waves split the partial blocks): merge the per-block partials ->
+// stats[h,i] = {max, sum}, O[i, h*64+c]
+__global__ __launch_bounds__(1024) void mca_fwd_final_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                             const float* __restrict__ po, int nb, int heads, int kq,
+                                                             float* __restrict__ stats, float* __restrict__ O) {
+  __shared__ float red[16];
+  __shared__ float osum[16][64];
+  const int hi = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = hi / kq, i = hi % kq;
   const int HK = heads * kq;
   float mx = -INFINITY;
-  for (int b = lane; b < nb; b += 64) mx = fmaxf(mx, pm[(int64_t)b * HK + hi]);
+  for (int b = threadIdx.x; b < nb; b += 1024) mx = fmaxf(mx, pm[(int64_t)b * HK + hi]);
   mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  __syncthreads();
   float L = 0.f;
-  for (int b = lane; b < nb; b += 64) {
+  for (int b = threadIdx.x; b < nb; b += 1024) {
     const float pmb = pm[(int64_t)b * HK + hi];
     L += (pmb == -INFINITY) ? 0.f : pl[(int64_t)b * HK + hi] * __expf(pmb - mx);
   }
   L = wave_sum(L);
+  if (lane == 0) red[wave] = L;
   float acc = 0.f;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = wave; b < nb; b += 16) {
     const float pmb = pm[(int64_t)b * HK + hi];
     if (pmb != -INFINITY) acc += po[((int64_t)b * HK + hi) * 64 + lane] * __expf(pmb - mx);
   }
-  O[(int64_t)i * heads * 64 + h * 64 + lane] = acc / L;
-  if (lane == 0) { stats[2 * hi] = mx; stats[2 * hi + 1] = L; }
+  osum[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    float Lt = 0.f, a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { Lt += red[w]; a += osum[w][lane]; }     // fixed order
+    O[(int64_t)i * heads * 64 + h * 64 + lane] = a / Lt;
+    if (lane == 0) { stats[2 * hi] = mx; stats[2 * hi + 1] = Lt; }
+  }
 }
 
 // backward pass 1: dP[h,i,r] = (dO_i . v_r) * keep/(1-p) ; per-block partial of sum_r P dP
 template <int KQ>
 __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dp_kernel(const float* __restrict__ KV, const float* __restrict__ dO,
                                                                  const float* __restrict__ dots, const float* __restrict__ stats,
-                                                                 int64_t R, int heads, int kq, float drop_p, uint64_t seed,
-                                                                 float* __restrict__ dP, float* __restrict__ prd) {
+                                                                 int64_t R, int heads, int kq, float drop_p, uint64_t seed0,
+                                                                 const uint64_t* __restrict__ tick, float* __restrict__ dP, float* __restrict__ prd) {
+  const uint64_t seed = eff_seed(seed0, tick);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inner = heads * 64;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -185,8 +219,9 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
                                                                   const float* __restrict__ dO, const float* __restrict__ dots,
                                                                   const float* __restrict__ stats, const float* __restrict__ dP,
                                                                   const float* __restrict__ prd, int nb, int64_t R, int heads,
-                                                                  int kq, float scale, float drop_p, uint64_t seed,
-                                                                  float* __restrict__ dKV, float* __restrict__ pdq) {
+                                                                  int kq, float scale, float drop_p, uint64_t seed0,
+                                                                  const uint64_t* __restrict__ tick, float* __restrict__ dKV, float* __restrict__ pdq) {
+  const uint64_t seed = eff_seed(seed0, tick);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inner = heads * 64;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -269,7 +304,9 @@ __global__ void ema_kernel(const float* __restrict__ q, const float* __restrict_
 }
 
 // dz0 = dz * keep/(1-p) with the same (seed,row,col) stream as the forward epilogue
-__global__ void drop_bwd_kernel(const float* __restrict__ dz, float* __restrict__ out, int64_t M, int E, float p, uint64_t seed) {
+__global__ void drop_bwd_kernel(const float* __restrict__ dz, float* __restrict__ out, int64_t M, int E, float p, uint64_t seed0,
+                                const uint64_t* __restrict__ tick) {
+  const uint64_t seed = eff_seed(seed0, tick);
   const int64_t n = M * E;
   const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -350,15 +387,15 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   if (int r = dispatch_kq(k, [&](auto kqc) {
         constexpr int KQ = decltype(kqc)::value;
         hipLaunchKernelGGL(mca_fwd_part_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, R, (int)H, (int)k, scale,
-                           m->drop_p, m->drop_seed, w.P, w.pm, w.pl, w.po);
+                           m->drop_p, m->drop_seed, m->drop_tick, w.P, w.pm, w.pl, w.po);
         MHIMX_LAUNCH_CHECK();
         return 0;
       })) return r;
-  hipLaunchKernelGGL(mca_fwd_final_kernel, dim3((unsigned)(H * k)), dim3(64), 0, st, w.pm, w.pl, w.po, w.nb, (int)H, (int)k, w.stats, w.O);
+  hipLaunchKernelGGL(mca_fwd_final_kernel, dim3((unsigned)(H * k)), dim3(1024), 0, st, w.pm, w.pl, w.po, w.nb, (int)H, (int)k, w.stats, w.O);
   MHIMX_LAUNCH_CHECK();
   g = {};
   g.A = w.O; g.lda = I; g.B = m->wo; g.ldb = I; g.C = z; g.ldc = E; g.M = k; g.N = E; g.K = I; g.bias = m->bo; g.prec = fprec;
-  g.drop_p = m->drop_p; g.drop_seed = m->drop_seed + 0x9E3779B97F4A7C15ull;
+  g.drop_p = m->drop_p; g.drop_seed = m->drop_seed + 0x9E3779B97F4A7C15ull; g.drop_tick = m->drop_tick;
   if (int r = gemm_nt(st, g)) return r;
   if (update_q) {
     MHIMX_CHECK_ARG(q_new, "merge_fwd: update_q needs q_new");
@@ -383,7 +420,7 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   const int acc = gr->accumulate;
   // through the output dropout and projection
   hipLaunchKernelGGL(drop_bwd_kernel, dim3((unsigned)cdiv(k * E, 256)), dim3(256), 0, st, dz, w.dz0, k, (int)E, m->drop_p,
-                     m->drop_seed + 0x9E3779B97F4A7C15ull);
+                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick);
   MHIMX_LAUNCH_CHECK();
   if (int r = colsum(st, w.dz0, k, E, gr->d_bo, acc, w.scratch, w.scratch_bytes)) return r;
   mhimx_gemm_tn_args t = {};
@@ -398,10 +435,10 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   if (int r = dispatch_kq(k, [&](auto kqc) {
         constexpr int KQ = decltype(kqc)::value;
         hipLaunchKernelGGL(mca_bwd_dp_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.dO, w.P, w.stats, R, (int)H,
-                           (int)k, m->drop_p, m->drop_seed, w.dd, w.prd);
+                           (int)k, m->drop_p, m->drop_seed, m->drop_tick, w.dd, w.prd);
         MHIMX_LAUNCH_CHECK();
         hipLaunchKernelGGL(mca_bwd_dkv_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, w.dO, w.P, w.stats, w.dd,
-                           w.prd, w.nb, R, (int)H, (int)k, scale, m->drop_p, m->drop_seed, w.dKV, w.pdq);
+                           w.prd, w.nb, R, (int)H, (int)k, scale, m->drop_p, m->drop_seed, m->drop_tick, w.dKV, w.pdq);
         MHIMX_LAUNCH_CHECK();
         return 0;
       })) return r;

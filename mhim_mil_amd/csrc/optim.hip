@@ -102,7 +102,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restr
 // the corrected second moment) + EMA teacher.  bc1 = 1-beta1^t, bc2s = sqrt(1-beta2^t) come from the host in fp64.
 __global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                 float* __restrict__ teacher, int64_t n_train, int64_t n_all, float lr_over_bc1, float bc2s,
-                                float beta1, float beta2, float eps, float wd, float gscale, float mm, int zero_grad) {
+                                float beta1, float beta2, float eps, float wd, float gscale, float mm, int zero_grad,
+                                const uint64_t* __restrict__ step_dev, float lr) {
+  if (step_dev) {                       // graph replay: the step count lives on the device
+    const double t = (double)step_dev[0];
+    lr_over_bc1 = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+    bc2s = (float)sqrt(1.0 - pow((double)beta2, t));
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
     float w = p[i];
     if (i < n_train) {
@@ -138,15 +144,24 @@ extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, 
 
 extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
                               int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                              float grad_scale, float ema_mm, int32_t zero_grad) {
-  MHIMX_CHECK_ARG(p && g && m && v && n_train >= 0 && n_all >= n_train && step >= 1, "adam_ema: bad args");
+                              float grad_scale, float ema_mm, int32_t zero_grad, const uint64_t* step_dev) {
+  MHIMX_CHECK_ARG(p && g && m && v && n_train >= 0 && n_all >= n_train && (step >= 1 || step_dev), "adam_ema: bad args");
+  if (step < 1) step = 1;
   if (n_all == 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const int64_t blocks = cdiv(n_all, 256) < 2048 ? cdiv(n_all, 256) : 2048;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v,
                      teacher, n_train, n_all, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, weight_decay,
-                     grad_scale, ema_mm, zero_grad);
+                     grad_scale, ema_mm, zero_grad, step_dev, lr);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void tick_kernel(uint64_t* c) { c[0] += 1; }
+extern "C" int mhimx_tick(void* stream, uint64_t* counter) {
+  MHIMX_CHECK_ARG(counter, "tick: null counter");
+  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

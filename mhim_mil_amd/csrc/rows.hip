@@ -91,23 +91,26 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_fwd_kernel(
 }
 
 // merge G partials: stats = {max, sumexp}, z[e] = sum_b pz[b][e] e^{pm[b]-max} / sumexp.
-// grid = E/64 blocks of 256 threads (64 columns x 4 partial groups); every block re-derives the G weights.
-__global__ __launch_bounds__(ROWS_THREADS) void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
-                                                                      const float* __restrict__ pz, int G, int E,
-                                                                      float* __restrict__ stats, float* __restrict__ z) {
-  __shared__ float red[4];
+// grid = E/64 blocks of 1024 threads (64 columns x 16 partial groups); every block re-derives the G weights.
+constexpr int FIN_THREADS = 1024;
+__global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                     const float* __restrict__ pz, int G, int E,
+                                                                     float* __restrict__ stats, float* __restrict__ z) {
+  __shared__ float red[16];
   __shared__ float wgt[2 * MAX_PART];
-  __shared__ float acc4[4][64];
+  __shared__ float acc16[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float m = -INFINITY;
-  for (int b = threadIdx.x; b < G; b += ROWS_THREADS) m = fmaxf(m, pm[b]);
+  for (int b = threadIdx.x; b < G; b += FIN_THREADS) m = fmaxf(m, pm[b]);
   m = wave_max(m);
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float mx = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
   __syncthreads();
   float lp = 0.f;
-  for (int b = threadIdx.x; b < G; b += ROWS_THREADS) {
+  for (int b = threadIdx.x; b < G; b += FIN_THREADS) {
     const float w = (pm[b] == -INFINITY) ? 0.f : __expf(pm[b] - mx);
     wgt[b] = w;
     lp += pl[b] * w;
@@ -115,14 +118,21 @@ __global__ __launch_bounds__(ROWS_THREADS) void pool_finalize_kernel(const float
   lp = wave_sum(lp);
   if (lane == 0) red[wave] = lp;
   __syncthreads();
-  const float L = (red[0] + red[1]) + (red[2] + red[3]);      // fixed order: deterministic
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) L += red[w];                   // fixed order: deterministic
   const int e = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (e < E)
-    for (int b = wave; b < G; b += 4) acc += pz[(int64_t)b * E + e] * wgt[b];
-  acc4[wave][lane] = acc;
+    for (int b = wave; b < G; b += 16) acc += pz[(int64_t)b * E + e] * wgt[b];
+  acc16[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0 && e < E) z[e] = ((acc4[0][lane] + acc4[1][lane]) + (acc4[2][lane] + acc4[3][lane])) / L;
+  if (wave == 0 && e < E) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a += acc16[w][lane];
+    z[e] = a / L;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = mx; stats[1] = L; }
 }
 
@@ -199,19 +209,24 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_bwd_kernel(
 }
 
 // out[j] (+)= sum_b part[b][j]   (fixed order)
-// launched with 128 threads = 32 columns x 4 row groups per block (fixed summation order -> deterministic)
-__global__ void reduce_parts_kernel(const float* __restrict__ part, int G, int W, int ld, float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][32];
+// out[j] (+)= sum_b part[b*ld + j].  Launched with RP_THREADS = 32 columns x 32 row groups per block: the G partial rows
+// are read 32 at a time (fixed summation order -> deterministic), instead of one serial G-long chain per column.
+constexpr int RP_THREADS = 1024;
+__global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* __restrict__ part, int G, int W, int ld,
+                                                                   float* __restrict__ out, int accumulate) {
+  __shared__ float red[32][33];
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   for (int j0 = blockIdx.x * 32; j0 < W; j0 += gridDim.x * 32) {
     const int j = j0 + c;
     float acc = 0.f;
     if (j < W)
-      for (int b = rg; b < G; b += 4) acc += part[(int64_t)b * ld + j];
+      for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * ld + j];
     red[rg][c] = acc;
     __syncthreads();
     if (rg == 0 && j < W) {
-      const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v += red[q][c];
       out[j] = accumulate ? out[j] + v : v;
     }
     __syncthreads();
@@ -316,28 +331,40 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // feature activation backward (in place on dH) and column sums
 // ------------------------------------------------------------------------------------------------
-__global__ void act_bwd_kernel(float* __restrict__ dH, const float* __restrict__ H, const float* __restrict__ pre,
-                               int64_t M, int E, int act, float drop_p, uint64_t seed,
-                               const uint8_t* __restrict__ drop_mask, const int64_t* __restrict__ rows) {
-  const int64_t total = M * (int64_t)E;
+// one block = a chunk of rows, thread = a pair of columns: the backward through act+dropout and the bias gradient
+// (column sums of dPre) share one pass over dH.
+__global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dH, const float* __restrict__ H,
+                                                     const float* __restrict__ pre, int64_t M, int E, int act, float drop_p,
+                                                     uint64_t seed0, const uint8_t* __restrict__ drop_mask,
+                                                     const int64_t* __restrict__ rows, int64_t chunk, float* __restrict__ part,
+                                                     const uint64_t* __restrict__ tick) {
+  const uint64_t seed = eff_seed(seed0, tick);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / E;
-    const int e = (int)(i - m * E);
-    float g = dH[i];
-    bool keep = true;
-    if (drop_mask) keep = drop_mask[i] != 0;
-    else if (drop_p > 0.f) keep = drop_keep(seed, rows ? (uint64_t)rows[m] : (uint64_t)m, (uint32_t)e, drop_p);
-    if (!keep) { dH[i] = 0.f; continue; }
-    g *= inv_keep;
-    if (act == MHIMX_ACT_RELU) {
-      // H = relu(pre) * keep/(1-p): positive exactly where pre > 0
-      g = (pre ? pre[i] > 0.f : H[i] > 0.f) ? g : 0.f;
-    } else if (act != MHIMX_ACT_NONE) {
-      const float x = pre[i];
-      g *= act_grad(x, act == MHIMX_ACT_TANH ? tanhf(x) : 0.f, act);
+  const int64_t mb = (int64_t)blockIdx.x * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float colsum = 0.f;
+    for (int64_t m = mb; m < me; ++m) {
+      const int64_t i = m * E + e;
+      float g = dH[i];
+      bool keep = true;
+      if (drop_mask) keep = drop_mask[i] != 0;
+      else if (drop_p > 0.f) keep = drop_keep(seed, rows ? (uint64_t)rows[m] : (uint64_t)m, (uint32_t)e, drop_p);
+      if (!keep) {
+        g = 0.f;
+      } else {
+        g *= inv_keep;
+        if (act == MHIMX_ACT_RELU) {
+          g = (pre ? pre[i] > 0.f : H[i] > 0.f) ? g : 0.f;        // H = relu(pre)*keep/(1-p) > 0 exactly where pre > 0
+        } else if (act != MHIMX_ACT_NONE) {
+          const float x = pre[i];
+          g *= act_grad(x, act == MHIMX_ACT_TANH ? tanhf(x) : 0.f, act);
+        }
+      }
+      dH[i] = g;
+      colsum += g;
     }
-    dH[i] = g;
+    if (part) part[(int64_t)blockIdx.x * E + e] = colsum;
   }
 }
 
@@ -455,7 +482,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
-  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(E, 64)), dim3(ROWS_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z);
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -497,10 +524,10 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(128), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(RP_THREADS), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
   MHIMX_LAUNCH_CHECK();
   if (gr->d_bc) {
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(128), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(RP_THREADS), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
     MHIMX_LAUNCH_CHECK();
   }
   off = 0;
@@ -540,12 +567,12 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(W, 128), gy), dim3(128), 0, st, w.du, M, (int)W, chunk, w.pz);
     MHIMX_LAUNCH_CHECK();
     if (gr->d_ba) {
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(128), 0, st, w.pz, gy, (int)A, (int)W, gr->d_ba, gr->accumulate);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(RP_THREADS), 0, st, w.pz, gy, (int)A, (int)W, gr->d_ba, gr->accumulate);
       MHIMX_LAUNCH_CHECK();
     }
     if (gr->d_bb && gated) {
       // columns [A, 2A): strided view handled by offsetting the partial pointer (row pitch W)
-      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(128), 0, st, w.pz + A, gy, (int)A, (int)W, gr->d_bb, gr->accumulate);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(RP_THREADS), 0, st, w.pz + A, gy, (int)A, (int)W, gr->d_bb, gr->accumulate);
       MHIMX_LAUNCH_CHECK();
     }
   }
@@ -566,13 +593,15 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
-  const int grid = grid_for_ln(M);
+  int grid = (int)cdiv(M, 16);            // few partial rows: the weight-gradient reduce that follows is serial in them
+  if (grid < 1) grid = 1;
+  if (grid > 96) grid = 96;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
                      w, mean, rstd, dx, dw_part, db_part);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(128), 0, st, dw_part, grid, (int)E, (int)E, d_w, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, st, dw_part, grid, (int)E, (int)E, d_w, accumulate);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(128), 0, st, db_part, grid, (int)E, (int)E, d_b, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, st, db_part, grid, (int)E, (int)E, d_b, accumulate);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -584,7 +613,7 @@ int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int
   MHIMX_CHECK_ARG(ws && ws_bytes >= (int64_t)gy * E * 4, "colsum: workspace too small (need %lld bytes)", (long long)(gy * E * 4));
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(E, 128), gy), dim3(128), 0, st, X, M, (int)E, chunk, (float*)ws);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(128), 0, st, (const float*)ws, gy, (int)E, (int)E, out, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, st, (const float*)ws, gy, (int)E, (int)E, out, accumulate);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -620,14 +649,25 @@ extern "C" int mhimx_pseudo_score(void* stream, const float* s, const float* sta
   return 0;
 }
 extern "C" int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int64_t M, int64_t E, int32_t act,
-                             float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows) {
+                             float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows, float* colsum_out,
+                             int32_t accumulate, void* ws, int64_t ws_bytes, const uint64_t* drop_tick) {
   MHIMX_CHECK_ARG(dH && (H || pre), "act_bwd: null args");
   MHIMX_CHECK_ARG(act == MHIMX_ACT_NONE || act == MHIMX_ACT_RELU || pre, "act_bwd: gelu/tanh need the pre-activation");
   if (M <= 0) return 0;
-  const int64_t total = M * E;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096)), dim3(256), 0,
-                     (hipStream_t)stream, dH, H, pre, M, (int)E, act, drop_p, drop_seed, drop_mask, rows);
+  int64_t nblk = cdiv(M, 16);
+  if (nblk > 1024) nblk = 1024;
+  const int64_t chunk = cdiv(M, nblk);
+  nblk = cdiv(M, chunk);
+  MHIMX_CHECK_ARG(!colsum_out || (ws && ws_bytes >= nblk * E * 4), "act_bwd: workspace too small for the column sums (%lld bytes)",
+                  (long long)(nblk * E * 4));
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dH, H, pre, M, (int)E, act, drop_p,
+                     drop_seed, drop_mask, rows, chunk, colsum_out ? (float*)ws : nullptr, drop_tick);
   MHIMX_LAUNCH_CHECK();
+  if (colsum_out) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, (hipStream_t)stream, (const float*)ws, (int)nblk,
+                       (int)E, (int)E, colsum_out, accumulate);
+    MHIMX_LAUNCH_CHECK();
+  }
   return 0;
 }
 extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate, void* ws,

@@ -185,6 +185,262 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(
   if (tid == 0 && len_keep_dev) *len_keep_dev = (int64_t)kept_base;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path for N <= 16384 (a bag of one slide at 20x is ~1e4 patches): every thread keeps its <= 16 keys
+// in registers (scores are read from HBM exactly once), flags are an LDS bitmap, the k candidates are ordered
+// by rank counting (k^2/1024 LDS compares per thread, no barriers) when k <= 2048.
+// ------------------------------------------------------------------------------------------------
+// exclusive prefix sum of one integer per thread over the 1024 threads (thread order); *total = block sum
+MHIMX_DEV uint32_t block_scan_excl(uint32_t v, uint32_t* wave_tot /*[16] LDS*/, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SEL_WAVES; ++w) {
+    const uint32_t c = wave_tot[w];
+    if (w < wave) base += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// radix select over register-resident keys: returns the k-th largest key T among the valid ones and, in *remaining,
+// how many T-valued keys belong to the top-k.  hist: [16][256] LDS, misc: [>=2] LDS.
+template <int KPT>
+MHIMX_DEV uint32_t radix_select_regs(const uint32_t (&key)[KPT], const bool (&valid)[KPT], uint32_t k, uint32_t* hist,
+                                     uint32_t* misc, uint32_t* remaining_out) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  uint32_t prefix = 0, remaining = k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int i = tid; i < SEL_WAVES * 256; i += SEL_THREADS) hist[i] = 0;
+    __syncthreads();
+    const uint32_t hmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (valid[j] && (key[j] & hmask) == prefix) atomicAdd(&hist[wave * 256 + ((key[j] >> shift) & 255u)], 1u);
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int w = 0; w < SEL_WAVES; ++w) c += hist[w * 256 + tid];
+      hist[tid] = c;
+    }
+    __syncthreads();
+    if (tid < 256) {                       // every bin computes the population above it: no serial scan
+      uint32_t above = 0;
+      for (int d = tid + 1; d < 256; ++d) above += hist[d];
+      const uint32_t mine = hist[tid];
+      if (above < remaining && remaining <= above + mine) { misc[0] = (uint32_t)tid; misc[1] = remaining - above; }
+    }
+    __syncthreads();
+    prefix |= misc[0] << shift;
+    remaining = misc[1];
+    __syncthreads();
+  }
+  *remaining_out = remaining;
+  return prefix;
+}
+
+// Thread t owns the CONTIGUOUS instances [t*KPT, (t+1)*KPT): every order-dependent step (ties lowest index first,
+// ascending compaction) then costs ONE block scan of per-thread counts instead of one per 1024-instance chunk.
+template <int KPT>
+__global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
+    const float* __restrict__ score, int N, int k, int n_sel, int largest, const int64_t* __restrict__ perm,
+    const int64_t* __restrict__ other, int64_t n_other, int64_t* __restrict__ mask_ids, int64_t* __restrict__ len_keep_dev,
+    int64_t* __restrict__ topk_out, int P, int use_rand, uint64_t rand_seed0, const uint64_t* __restrict__ tick, int merge_R,
+    int64_t* __restrict__ rows_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint64_t rand_seed = eff_seed(rand_seed0, tick);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);               // [P] gathered, [P] sorted
+  uint64_t* sorted = keys + P;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(sorted + P);             // [16][256]
+  uint32_t* wave_tot = hist + SEL_WAVES * 256;                          // [16]
+  uint32_t* misc = wave_tot + SEL_WAVES;                                // [8]
+  uint32_t* bitmap = misc + 8;                                          // [512] = 16384 bits
+  const int tid = threadIdx.x;
+  const bool lg = largest != 0;
+  const int i0 = tid * KPT;
+
+  uint32_t key[KPT];
+  bool valid[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    valid[j] = (i0 + j) < N;
+    key[j] = valid[j] ? mono32(score[i0 + j], lg) : 0u;
+  }
+  for (int i = tid; i < 512; i += SEL_THREADS) bitmap[i] = 0;
+  if (tid == 0) misc[2] = 0;
+
+  // ---- 1. threshold
+  uint32_t remaining;
+  const uint32_t T = radix_select_regs<KPT>(key, valid, (uint32_t)k, hist, misc, &remaining);
+
+  // ---- 2. gather exactly k keys (ties: lowest index first)
+  uint32_t neq = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) neq += (valid[j] && key[j] == T) ? 1u : 0u;
+  uint32_t tot;
+  uint32_t eq_rank = block_scan_excl(neq, wave_tot, &tot);
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    if (!valid[j]) continue;
+    bool take = key[j] > T;
+    if (key[j] == T) { take = eq_rank < remaining; ++eq_rank; }
+    if (take) {
+      const uint32_t pos = atomicAdd(&misc[2], 1u);
+      keys[pos] = ((uint64_t)key[j] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(i0 + j));
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. order the candidates: (value desc, index asc) == key desc
+  if (k <= 2048) {
+    for (int j = tid; j < k; j += SEL_THREADS) {
+      const uint64_t mine = keys[j];
+      int rank = 0;
+      for (int q = 0; q < k; ++q) rank += keys[q] > mine ? 1 : 0;
+      sorted[rank] = mine;
+    }
+    __syncthreads();
+  } else {
+    for (int j = tid; j < P; j += SEL_THREADS) sorted[j] = j < k ? keys[j] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (P >> 1); t += SEL_THREADS) {
+          const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const uint64_t a = sorted[lo], b = sorted[hi];
+          if ((a < b) == desc) { sorted[lo] = b; sorted[hi] = a; }
+        }
+        __syncthreads();
+      }
+  }
+  if (topk_out)
+    for (int j = tid; j < k; j += SEL_THREADS) topk_out[j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(sorted[j] & 0xFFFFFFFFull));
+
+  // ---- 4. flags (LDS bitmap)
+  const bool has_other = other != nullptr && n_other > 0;
+  const int len_keep_simple = N - n_sel;
+  if (use_rand && !perm && n_sel < k) {
+    // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host
+    // permutation: every candidate gets a counter-based random key; the n_sel smallest keys win (rank counting).
+    for (int j = tid; j < k; j += SEL_THREADS) {
+      const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(sorted[j] & 0xFFFFFFFFull);
+      keys[j] = ((uint64_t)mix32(mix32(idx ^ (uint32_t)rand_seed) + (uint32_t)(rand_seed >> 32)) << 32) | idx;
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += SEL_THREADS) {
+      const uint64_t mine = keys[j];
+      int rank = 0;
+      for (int q = 0; q < k; ++q) rank += keys[q] < mine ? 1 : 0;
+      if (rank < n_sel) {
+        const uint32_t idx = (uint32_t)(mine & 0xFFFFFFFFull);
+        atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
+        if (!has_other && mask_ids) mask_ids[len_keep_simple + rank] = (int64_t)idx;
+      }
+    }
+  } else {
+    for (int j = tid; j < n_sel; j += SEL_THREADS) {
+      const int64_t src = perm ? perm[j] : (int64_t)j;
+      const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(sorted[src] & 0xFFFFFFFFull);
+      atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
+      if (!has_other && mask_ids) mask_ids[len_keep_simple + j] = (int64_t)idx;
+    }
+  }
+  if (has_other)
+    for (int64_t j = tid; j < n_other; j += SEL_THREADS) {
+      const uint32_t idx = (uint32_t)other[j];
+      atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
+    }
+  __syncthreads();
+
+  // ---- 5. ordered compaction: kept ids ascending (and, for a union with an earlier mask, masked ids ascending)
+  bool kv[KPT];
+  uint32_t nkeep = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int i = i0 + j;
+    kv[j] = valid[j] && !((bitmap[i >> 5] >> (i & 31)) & 1u);
+    nkeep += kv[j] ? 1u : 0u;
+  }
+  uint32_t kept_total;
+  uint32_t kpos = block_scan_excl(nkeep, wave_tot, &kept_total);
+  if (mask_ids) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (kv[j]) mask_ids[kpos++] = i0 + j;
+    if (has_other) {
+      uint32_t nm = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) nm += (valid[j] && !kv[j]) ? 1u : 0u;
+      uint32_t mt;
+      uint32_t mpos = kept_total + block_scan_excl(nm, wave_tot, &mt);
+#pragma unroll
+      for (int j = 0; j < KPT; ++j)
+        if (valid[j] && !kv[j]) mask_ids[mpos++] = i0 + j;
+    }
+  }
+  if (tid == 0 && len_keep_dev) *len_keep_dev = (int64_t)kept_total;
+  if (!rows_out) return;
+
+  // ---- 6. Merge.masking (merge.py:158-176): a uniformly random R-subset of the kept rows is merged away.  Same device:
+  // random 32-bit key per kept row, radix-select the R largest (ties by index), then ordered compactions ->
+  // rows_out = [kept rows that stay (ascending) | rows to merge (ascending)].  The pool is order independent, so the
+  // reference's random ORDER of the kept rows is not reproduced (only fp summation order differs).
+  const int Lrows = (int)kept_total;
+  const int Lk = Lrows - merge_R;
+  uint32_t rk[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j)
+    rk[j] = mix32(mix32((uint32_t)(i0 + j) ^ (uint32_t)(rand_seed >> 17)) + (uint32_t)rand_seed * 0x9E3779B1u);
+  uint32_t T2 = 0, remaining2 = 0;
+  const bool partial = merge_R > 0 && merge_R < Lrows;
+  if (partial) T2 = radix_select_regs<KPT>(rk, kv, (uint32_t)merge_R, hist, misc, &remaining2);
+  uint32_t neq2 = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) neq2 += (partial && kv[j] && rk[j] == T2) ? 1u : 0u;
+  uint32_t t2;
+  uint32_t eq2 = block_scan_excl(neq2, wave_tot, &t2);
+  bool mrg[KPT];
+  uint32_t nstay = 0, nmrg = 0;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    bool m = false;
+    if (kv[j]) {
+      if (merge_R >= Lrows) m = true;
+      else if (partial) {
+        m = rk[j] > T2;
+        if (rk[j] == T2) { m = eq2 < remaining2; ++eq2; }
+      }
+    }
+    mrg[j] = m;
+    nmrg += m ? 1u : 0u;
+    nstay += (kv[j] && !m) ? 1u : 0u;
+  }
+  uint32_t spos = block_scan_excl(nstay, wave_tot, &t2);
+  uint32_t mpos2 = (uint32_t)Lk + block_scan_excl(nmrg, wave_tot, &t2);
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    if (!kv[j]) continue;
+    if (mrg[j]) rows_out[mpos2++] = i0 + j;
+    else rows_out[spos++] = i0 + j;
+  }
+}
+
+static size_t select_small_smem(int P) { return (size_t)2 * P * 8 + (SEL_WAVES * 256 + SEL_WAVES + 8 + 512) * 4; }
+
 static int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -199,15 +455,37 @@ using namespace mhimx;
 
 extern "C" int64_t mhimx_select_ws_bytes(int64_t N) { return align_up(N, 256); }
 
-extern "C" int mhimx_select_mask(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
-                                 const int64_t* perm, const int64_t* other, int64_t n_other, int64_t* mask_ids,
-                                 int64_t* len_keep_dev, int64_t* topk_sorted, void* ws, int64_t ws_bytes) {
-  MHIMX_CHECK_ARG(score && mask_ids && ws, "select_mask: null args");
+static int select_impl(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
+                       const int64_t* perm, const int64_t* other, int64_t n_other, int64_t* mask_ids,
+                       int64_t* len_keep_dev, int64_t* topk_sorted, void* ws, int64_t ws_bytes, int g_use_rand,
+                       uint64_t g_rand_seed, const uint64_t* g_tick, int g_merge_R, int64_t* g_rows_out) {
+  MHIMX_CHECK_ARG(score && (mask_ids || g_rows_out) && ws, "select_mask: null args");
+  MHIMX_CHECK_ARG(!g_rows_out || N <= 16384, "select_rows: fused row list needs N <= 16384 (use select_mask + compose_ids)");
   MHIMX_CHECK_ARG(N > 0 && N <= (1ll << 24), "select_mask: N out of range");
   MHIMX_CHECK_ARG(k >= 1 && k <= N && k <= 16384, "select_mask: k=%lld out of range (1..min(N,16384))", (long long)k);
   MHIMX_CHECK_ARG(n_sel >= 0 && n_sel <= k, "select_mask: n_sel out of range");
   MHIMX_CHECK_ARG(ws_bytes >= N, "select_mask: workspace too small");
   const int P = next_pow2((int)k < 2 ? 2 : (int)k);
+  if (N <= 16384 && P <= 4096) {                       // registers + LDS fast path
+    const size_t sm = select_small_smem(P);
+#define MHIMX_SEL_SMALL(KPT)                                                                                                   \
+    hipLaunchKernelGGL(select_small_kernel<KPT>, dim3(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
+                       (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,          \
+                       g_rand_seed, g_tick, g_merge_R, g_rows_out)
+    static bool small_attr = false;
+    if (!small_attr) {
+      MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+      MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+      MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+      small_attr = true;
+    }
+    if (N <= 4096) MHIMX_SEL_SMALL(4);
+    else if (N <= 10240) MHIMX_SEL_SMALL(10);
+    else MHIMX_SEL_SMALL(16);          // thread t owns instances [t*KPT, (t+1)*KPT)
+#undef MHIMX_SEL_SMALL
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = select_smem(P);
   static bool attr_set = false;
   if (!attr_set) {
@@ -215,10 +493,26 @@ extern "C" int mhimx_select_mask(void* stream, const float* score, int64_t N, in
     MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384)));
     attr_set = true;
   }
+  MHIMX_CHECK_ARG(!g_use_rand && !g_rows_out, "select: the random-subset forms need N <= 16384 and k <= 4096");
   hipLaunchKernelGGL(select_kernel<false>, dim3(1), dim3(SEL_THREADS), smem, (hipStream_t)stream, score, N, (int)k, (int)n_sel,
                      largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, (uint8_t*)ws, (float*)nullptr, P);
   MHIMX_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mhimx_select_mask(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
+                                 const int64_t* perm, const int64_t* other, int64_t n_other, int64_t* mask_ids,
+                                 int64_t* len_keep_dev, int64_t* topk_sorted, void* ws, int64_t ws_bytes) {
+  return select_impl(stream, score, N, k, n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, ws, ws_bytes,
+                     0, 0, nullptr, 0, nullptr);
+}
+
+extern "C" int mhimx_select_rows(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
+                                 uint64_t rand_seed, const uint64_t* tick, int64_t merge_R, int64_t* rows_out, int64_t* mask_ids,
+                                 void* ws, int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(rows_out && merge_R >= 0 && merge_R <= N - n_sel, "select_rows: bad args");
+  return select_impl(stream, score, N, k, n_sel, largest, nullptr, nullptr, 0, mask_ids, nullptr, nullptr, ws, ws_bytes, 1, rand_seed,
+                     tick, (int)merge_R, rows_out);
 }
 
 extern "C" int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,

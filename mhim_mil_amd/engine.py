@@ -143,6 +143,15 @@ class FusedTrainer:
         self.model_kind = model
         self._micro = 0
         self.last = {}
+        dev = self.flat.student.device
+        # device-resident counters: hipGraph replays freeze kernel arguments, so the dropout stream position and the
+        # Adam step count live in HBM and are advanced by one-thread kernels that are part of the captured step
+        self.tick = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        student._tick = self.tick
+        if teacher is not None:
+            teacher._tick = self.tick
+        self._graph_pool = None
 
     def _dist(self):
         return torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -151,18 +160,14 @@ class FusedTrainer:
     def forward_backward(self, bag, label, perm=None, ids_shuffle=None, i=None):
         """Teacher fwd + select + student fwd + head + backward into the flat gradient buffer (accumulating)."""
         s, t, fl = self.s, self.t, self.flat
+        ops.tick(self.tick)
         x = s._check_x(bag)
         ps = x.shape[0]
         first = self._micro == 0
         gv = fl.grad_views
         if self.model_kind == "mhim":
             teacher_feat, score = t.forward_teacher(x)
-            len_keep, mask_ids = s.get_mask(ps, i, score, perm=perm)
-            Lk = int(len_keep * s.merge.merge_ratio)
-            R = len_keep - Lk
-            if ids_shuffle is None:
-                ids_shuffle = torch.randperm(len_keep, device=x.device)
-            rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle)
+            rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle)
             plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True)
             keep_num = Lk + s.merge.k
         else:
@@ -197,10 +202,26 @@ class FusedTrainer:
         fl = self.flat
         scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
         fl.step += 1
+        ops.tick(self.opt_step)
         ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                      fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
-                     grad_scale=scale, ema_mm=self.mm, zero_grad=True)
+                     grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step)
         self._micro = 0
+
+    def capture(self, bag, label, warmup=2, **kw):
+        """Capture one whole train step on (bag, label) into a hipGraph and return it; ``graph.replay()`` then costs one
+        launch instead of ~80.  The step must already have run eagerly (lazy one-time setup such as
+        hipFuncSetAttribute cannot happen under capture), hence the warm-up calls."""
+        assert self.accum == 1, "graph capture covers a full step (accumulation_steps == 1)"
+        for _ in range(warmup):
+            self.train_step(bag, label, **kw)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            self.train_step(bag, label, **kw)
+        return g
 
     def train_step(self, bag, label, **kw):
         out = self.forward_backward(bag, label, **kw)

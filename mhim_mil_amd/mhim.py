@@ -186,8 +186,8 @@ class MHIM(nn.Module):
         self.online_encoder = _DAttention(mlp_dim, gated=gated)
         self.predictor = _Lin(mlp_dim, n_classes)
         self._step = 0
-        self._inject = {}
-        self._cache = {}
+        self._tick = None          # optional device step counter (uint64 [1]) mixed into every dropout seed: set by
+                                   # FusedTrainer so that a captured hipGraph draws fresh masks on each replay
 
     # ------------------------------------------------------------------ weights in kernel layout
     @property
@@ -217,16 +217,18 @@ class MHIM(nn.Module):
                                wb=att.attention_b[0].weight.data, prec=self._op_prec)
         return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec)
 
-    def _merge_w(self, plan: Optional[BagPlan], need_t=False):
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None):
         m = self.merge
         tr = None
         if need_t:
             tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
                   ops.transpose(m.attn.to_out[0].weight.data))
         drop = m.dropout if (plan is not None and plan.training) else 0.0
-        return ops.MergeW(m.global_q_mm.data.view(m.k, -1), m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
+        q = m.global_q_mm.data.view(m.k, -1) if q is None else q.view(m.k, -1)
+        return ops.MergeW(q, m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
                           m.attn.to_q.weight.data, m.attn.to_out[0].weight.data, m.attn.to_out[0].bias.data, m.g_q_mm,
-                          drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr)
+                          drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr,
+                          drop_tick=self._tick)
 
     # ------------------------------------------------------------------ kernels: feature rows
     def _check_x(self, x):
@@ -243,7 +245,7 @@ class MHIM(nn.Module):
         act = L.act_code(self.act, _FEATURE_ACTS)
         nrows = M if M is not None else (rows.shape[0] if rows is not None else x.shape[0])
         return ops.gemm_nt(x, f.weight.data, out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out, drop_p=drop_p,
-                           drop_seed=drop_seed, drop_mask=drop_mask, prec=self._feature_prec(nrows), M=M)
+                           drop_seed=drop_seed, drop_mask=drop_mask, prec=self._feature_prec(nrows), M=M, drop_tick=self._tick)
 
     def _feature_prec(self, nrows):
         """'auto' = 'bf16x3' (3 MFMAs per tile step, ~2^-16 relative, fp32 range): the only 16-bit form that keeps
@@ -317,9 +319,7 @@ class MHIM(nn.Module):
         if self.merge_enable and plan.R > 0:
             # LayerNorm(global_q) backward uses the PRE-update queries (the reference sees post-update values through
             # an in-place .data write, a 1e-4-relative quirk: SURVEY.md §7 H7)
-            q_now = self.merge.global_q_mm.data.clone()
-            self.merge.global_q_mm.data.copy_(saved["q_old"])
-            mw = self._merge_w(plan, need_t=True)
+            mw = self._merge_w(plan, need_t=True, q=saved["q_old"])
             mgr = {"dX": dH[plan.Lk:]}
             for key, nm in (("d_ln_w", "merge.norm.weight"), ("d_ln_b", "merge.norm.bias"), ("d_wkv", "merge.attn.to_kv.weight"),
                             ("d_wq", "merge.attn.to_q.weight"), ("d_wo", "merge.attn.to_out.0.weight"),
@@ -327,16 +327,16 @@ class MHIM(nn.Module):
                 if nm in out:
                     mgr[key] = out[nm]
             mg = ops.merge_bwd(mw, H[plan.Lk:], g["dT2"], saved["mws"], grads=mgr)
-            self.merge.global_q_mm.data.copy_(q_now)
             grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
             grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
         p = self.dropout_p if plan.training else 0.0
-        ops.act_bwd(dH, H, PRE, L.act_code(self.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows)
+        _, db1 = ops.act_bwd(dH, H, PRE, L.act_code(self.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
+                             colsum_out=out.get("feature.0.bias"), want_colsum=True, drop_tick=self._tick)
         splits = 8 if plan.L >= 2048 else 1
         grads["feature.0.weight"] = ops.gemm_tn(dH, x, out=out.get("feature.0.weight"), rows=plan.rows, splits=splits,
                                                 prec="f32" if self.prec == "f32" else "bf16x3", M=plan.L)
-        grads["feature.0.bias"] = ops.colsum(dH, out=out.get("feature.0.bias"))
+        grads["feature.0.bias"] = db1
         return grads
 
     # ------------------------------------------------------------------ masking (mhim.py:109-179)
@@ -382,6 +382,50 @@ class MHIM(nn.Module):
         if mask_ratio_h > 0.:
             run(True, mask_ratio_h, self.mask_ratio_hr, perms[2])
         return len_keep, (None if mask_ids is None else mask_ids.view(1, -1))
+
+    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None):
+        """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
+
+        Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R).
+        Production (no injected draws, v2 recipe, N <= 16384): ONE kernel draws both random subsets on the device
+        (mhimx_select_rows).  With injected ``perm`` / ``ids_shuffle`` (parity tests) or v1 masks the reference's
+        two-stage form is followed literally: select_mask -> mask_ids, then ids_keep[ids_shuffle].
+        """
+        mask_ratio_h = self.mask_ratio_h
+        if self.mrh_sche is not None:
+            mask_ratio_h = self.mrh_sche[i]
+        if mrh is not None:
+            mask_ratio_h = mrh
+        v2 = self.mask_ratio == 0 and self.mask_ratio_l == 0 and mask_ratio_h > 0
+        if (v2 and perm is None and ids_shuffle is None and attn is not None and attn.numel() == ps and ps <= 16384):
+            eff, rr = mask_ratio_h / self.mask_ratio_hr, self.mask_ratio_hr
+            if eff > 1:
+                rr, eff = mask_ratio_h, 1.0
+            k = int(np.ceil(ps * eff))
+            n_sel = int(np.ceil(k * rr)) if rr < 1.0 else k
+            if k <= 4096:
+                len_keep = ps - n_sel
+                Lk = int(len_keep * self.merge.merge_ratio)
+                R = len_keep - Lk
+                if R == 0:
+                    raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
+                rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed(), tick=self._tick)
+                return rows, len_keep, Lk, R
+        len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm)
+        if mask_ids is None:
+            raise AssertionError("MHIM.forward needs a mask (mask_ratio_h > 0 or a v1 ratio), as the reference does "
+                                 "(masking.py:104)")
+        Lk = int(len_keep * self.merge.merge_ratio)                         # merge.py:163
+        R = len_keep - Lk
+        if R == 0:
+            raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
+        dev = mask_ids.device
+        if ids_shuffle is None:
+            ids_shuffle = torch.randperm(len_keep, device=dev)             # == argsort(rand(L)) in distribution
+        elif not torch.is_tensor(ids_shuffle):
+            ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=dev)
+        rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
+        return rows, len_keep, Lk, R
 
     # ------------------------------------------------------------------ reference entry points
     @torch.no_grad()
@@ -450,29 +494,14 @@ class MHIM(nn.Module):
     def forward(self, x, attn=None, teacher_cls_feat=None, i=None, pos=None, perm=None, ids_shuffle=None, drop_mask=None):
         x = self._check_x(x)
         ps = x.shape[0]
-        len_keep, mask_ids = self.get_mask(ps, i, attn, perm=perm)
-        if mask_ids is None:
-            raise AssertionError("MHIM.forward needs a mask (mask_ratio_h > 0 or a v1 ratio), as the reference does "
-                                 "(masking.py:104)")
         if not self.merge_enable:
             raise TypeError("MHIM.forward requires merge_enable=True (the reference's Identity merge rejects the "
                             "second argument, mhim.py:82,351)")
-        Lk = int(len_keep * self.merge.merge_ratio)                         # merge.py:163
-        R = len_keep - Lk
-        if self.training:
-            if ids_shuffle is None:
-                ids_shuffle = torch.randperm(len_keep, device=x.device)    # == argsort(rand(L)) in distribution
-            elif not torch.is_tensor(ids_shuffle):
-                ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=x.device)
-            rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
-        else:                                                               # eval: cat(x, merge(x)) (merge.py:197-198)
-            rows, Lk, R = mask_ids.view(-1)[:len_keep].contiguous(), len_keep, 0
-        if self.training and R == 0:
-            raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
-        plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=self._next_seed(), drop_mask=drop_mask,
-                       mca_seed=self._next_seed(), training=self.training)
         if not self.training:
             raise NotImplementedError("MHIM.forward in eval mode is not used by the reference trainer; use forward_test")
+        rows, len_keep, Lk, R = self.student_rows(ps, i, attn, perm=perm, ids_shuffle=ids_shuffle)
+        plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=self._next_seed(), drop_mask=drop_mask,
+                       mca_seed=self._next_seed(), training=self.training)
         z = _BagFn.apply(self, x, plan, *[self._param(n) for n in self._bag_param_names])
         logits, cls_loss = self._head(z, teacher_cls_feat)
         if teacher_cls_feat is None:

@@ -44,7 +44,7 @@ def prec_code(prec) -> int:
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, colv=None, drop_p=0.0, drop_seed=0,
-            drop_mask=None, accumulate=False, prec="f16s", M=None):
+            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, b_planes=None):
     """out[m,n] = epi(sum_k a[rows[m] or m, k] * b[n,k]) — see mhimx_gemm_nt."""
     for t, nm in ((a, "a"), (b, "b"), (bias, "bias"), (pre, "pre"), (rowv, "rowv"), (colv, "colv"), (out, "out")):
         _chk(t, name=nm)
@@ -60,7 +60,8 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
                  ldc=out.stride(0), M=M, N=N, K=K, bias=_p(bias), rowv=_p(rowv), colv=_p(colv), pre=_p(pre),
                  ldpre=pre.stride(0) if pre is not None else 0, act=int(act), drop_p=float(drop_p),
                  drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(drop_mask), accumulate=int(bool(accumulate)),
-                 prec=prec_code(prec))
+                 prec=prec_code(prec), drop_tick=_p(drop_tick), B_hi=_p(b_planes[0]) if b_planes is not None else None,
+                 B_lo=_p(b_planes[1]) if b_planes is not None else None)
     evs = KERNEL_EVENT_HOOK("gemm_nt", M, N, K) if KERNEL_EVENT_HOOK is not None else None
     if evs:
         evs[0].record()
@@ -87,6 +88,15 @@ def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3"
                  ws_floats=0 if ws is None else ws.numel())
     L.check(L.lib().mhimx_gemm_tn(_stream(), C.byref(g)), "mhimx_gemm_tn")
     return out
+
+
+def split_planes(w, prec="bf16x3", out=None):
+    """(hi, lo) 16-bit planes of an fp32 weight (int16 tensors holding bf16/fp16 bits) — see mhimx_split_planes."""
+    _chk(w, name="w")
+    hi, lo = out if out is not None else (torch.empty(w.shape, device=w.device, dtype=torch.int16),
+                                          torch.empty(w.shape, device=w.device, dtype=torch.int16))
+    L.check(L.lib().mhimx_split_planes(_stream(), _p(w), _p(hi), _p(lo), w.numel(), prec_code(prec)), "mhimx_split_planes")
+    return hi, lo
 
 
 def transpose(x, out=None):
@@ -203,6 +213,20 @@ def select_mask(score, k, n_sel, largest=True, perm=None, other=None, want_topk=
     return mask_ids, len_keep, topk
 
 
+def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, want_mask_ids=False):
+    """Fused HAM mask + Merge split with device-side random subsets -> rows int64 [N - n_sel] (stay | merge)."""
+    _chk(score, name="score")
+    N = score.numel()
+    dev = score.device
+    rows = torch.empty(N - n_sel, device=dev, dtype=torch.int64)
+    mask_ids = torch.empty(N, device=dev, dtype=torch.int64) if want_mask_ids else None
+    ws = torch.empty(L.lib().mhimx_select_ws_bytes(N), device=dev, dtype=torch.uint8)
+    L.check(L.lib().mhimx_select_rows(_stream(), _p(score), N, int(k), int(n_sel), int(bool(largest)),
+                                      int(rand_seed) & 0xFFFFFFFFFFFFFFFF, _p(tick), int(merge_R), _p(rows), _p(mask_ids), _p(ws),
+                                      ws.numel()), "mhimx_select_rows")
+    return (rows, mask_ids) if want_mask_ids else rows
+
+
 def vote_scores(attn, k, largest=True):
     _chk(attn, name="attn")
     H, N = attn.shape
@@ -222,7 +246,7 @@ def compose_ids(a, b):
 # ------------------------------------------------------------------------------------------------ merge
 class MergeW:
     def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
-                 prec="f16s", transposes=None):
+                 prec="f16s", transposes=None, drop_tick=None):
         self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo]
         for t in self.t:
             _chk(t, name="merge weight")
@@ -232,7 +256,7 @@ class MergeW:
         self.c = L.Merge(E=self.E, k=self.k, heads=heads, dim_head=dim_head, q_param=_p(q_param), ln_w=_p(ln_w),
                          ln_b=_p(ln_b), wkv=_p(wkv), wq=_p(wq), wo=_p(wo), bo=_p(bo), wkv_t=_p(self.tr[0]),
                          wq_t=_p(self.tr[1]), wo_t=_p(self.tr[2]), mm=float(mm), drop_p=float(drop_p),
-                         drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec))
+                         drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec), drop_tick=_p(drop_tick))
 
     def ws_for(self, R, device):
         n = L.lib().mhimx_merge_ws_bytes(R, self.E, self.k, self.heads, self.dim_head)
@@ -271,11 +295,17 @@ def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ misc
-def act_bwd(dH, H, pre, act, drop_p=0.0, drop_seed=0, drop_mask=None, rows=None):
+def act_bwd(dH, H, pre, act, drop_p=0.0, drop_seed=0, drop_mask=None, rows=None, colsum_out=None, want_colsum=False,
+            accumulate=False, drop_tick=None):
+    """In-place backward through activation+dropout; optionally the column sums (bias gradient) in the same pass."""
     M, E = dH.shape
+    if want_colsum and colsum_out is None:
+        colsum_out = torch.empty(E, device=dH.device)
+    ws = torch.empty(1024 * E, device=dH.device) if colsum_out is not None else None
     L.check(L.lib().mhimx_act_bwd(_stream(), _p(dH), _p(H), _p(pre), M, E, int(act), float(drop_p),
-                                  int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(drop_mask), _p(rows)), "mhimx_act_bwd")
-    return dH
+                                  int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(drop_mask), _p(rows), _p(colsum_out),
+                                  int(bool(accumulate)), _p(ws), 0 if ws is None else ws.numel() * 4, _p(drop_tick)), "mhimx_act_bwd")
+    return (dH, colsum_out) if colsum_out is not None else dH
 
 
 def colsum(X, out=None, accumulate=False):
@@ -305,8 +335,13 @@ def head_fwd_bwd(z, t, wp, bp, label, temp_t=1.0, main_alpha=1.0, aux_alpha=0.0,
 
 
 def adam_ema(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5,
-             grad_scale=1.0, ema_mm=0.9997, zero_grad=True):
+             grad_scale=1.0, ema_mm=0.9997, zero_grad=True, step_dev=None):
     n_all = p.numel()
     L.check(L.lib().mhimx_adam_ema(_stream(), _p(p), _p(g), _p(m), _p(v), _p(teacher), int(n_train), int(n_all), int(step),
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                   float(grad_scale), float(ema_mm), int(bool(zero_grad))), "mhimx_adam_ema")
+                                   float(grad_scale), float(ema_mm), int(bool(zero_grad)), _p(step_dev)), "mhimx_adam_ema")
+
+
+def tick(counter):
+    """counter (uint64/int64 [1], device) += 1 on the current stream."""
+    L.check(L.lib().mhimx_tick(_stream(), _p(counter)), "mhimx_tick")

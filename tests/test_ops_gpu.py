@@ -359,3 +359,67 @@ def test_adam_ema_matches_torch_adam():
         assert float(gd.abs().max()) == 0.0                              # zero_grad
     np.testing.assert_allclose(p.cpu().numpy(), torch.cat([ref_p.detach(), p0[n_train:]]).numpy(), atol=1e-7, rtol=1e-5)
     np.testing.assert_allclose(tea.cpu().numpy(), ref_t.numpy(), atol=1e-7, rtol=1e-5)
+
+
+def test_select_rows_fused_random_subsets():
+    """mhimx_select_rows: HAM mask + Merge split with device-drawn random subsets (production path).
+
+    Structure is checked exactly (sets, sizes, ordering, candidates = oracle top-k); the random draws are checked for
+    determinism in (seed, tick) and for uniformity over 200 seeds (every candidate masked ~ n_sel/k of the time,
+    every kept row merged ~ R/L of the time)."""
+    ops = _ops()
+    n = 10000
+    s = ((synth.permutation(5, n) + 0.25 * synth.uniform(6, (n,))) / n).astype(np.float32)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    L_ = n - n_sel
+    Lk = int(L_ * 0.9)
+    R = L_ - Lk
+    top = set(O.topk_indices(s, k, True).tolist())
+    sd = torch.from_numpy(s).to(DEV)
+    tick = torch.zeros(1, dtype=torch.int64, device=DEV)
+    rows, mask_ids = ops.select_rows(sd, k, n_sel, R, 1234, tick=tick, want_mask_ids=True)
+    rows2 = ops.select_rows(sd, k, n_sel, R, 1234, tick=tick)
+    assert torch.equal(rows, rows2)
+    rows, mask_ids = rows.cpu().numpy(), mask_ids.cpu().numpy()
+    assert rows.shape == (L_,) and len(set(rows.tolist())) == L_
+    assert np.all(np.diff(rows[:Lk]) > 0) and np.all(np.diff(rows[Lk:]) > 0)
+    masked = set(range(n)) - set(rows.tolist())
+    assert len(masked) == n_sel and masked <= top
+    assert np.array_equal(np.sort(mask_ids[:L_]), np.sort(rows)) and set(mask_ids[L_:].tolist()) == masked
+    assert np.all(np.diff(mask_ids[:L_]) > 0)
+    ops.tick(tick)
+    rows3 = ops.select_rows(sd, k, n_sel, R, 1234, tick=tick).cpu().numpy()
+    assert not np.array_equal(rows3, rows)                     # the device counter advances the stream
+    cnt_mask = np.zeros(n)
+    cnt_merge = np.zeros(n)
+    T = 200
+    for seed in range(T):
+        r = ops.select_rows(sd, k, n_sel, R, 99991 * seed + 7).cpu().numpy()
+        m = np.ones(n, bool); m[r] = False
+        cnt_mask[m] += 1
+        cnt_merge[r[Lk:]] += 1
+    cand = np.array(sorted(top))
+    f = cnt_mask[cand] / T
+    assert abs(f.mean() - n_sel / k) < 1e-9 and f.min() > 0.3 and f.max() < 0.7          # p = 0.5, sigma = 0.035
+    never = np.setdiff1d(np.arange(n), cand)
+    g = cnt_merge[never] / T
+    assert abs(g.mean() - R / L_) < 0.002 and g.max() < 0.25                            # p = 0.1, sigma = 0.021
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f16s"])
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 1024, 512), (257, 300, 64), (10000, 512, 128)])
+def test_gemm_nt_presplit_weight_planes(prec, M, N, K):
+    """The 128x256 kernel that takes the weight as pre-split 16-bit planes == the fp32-operand kernels == fp64 math."""
+    ops = _ops()
+    R = M + 37
+    x, w, bias = rnd(3, (R, K)).abs(), rnd(4, (N, K), std=0.05), rnd(5, (N,), std=0.1)
+    rows = torch.from_numpy(synth.permutation(9, R)[:M].copy())
+    ref = O._act(x[rows].double() @ w.double().t() + bias.double(), "gelu").float()
+    wd = w.to(DEV)
+    planes = ops.split_planes(wd, prec)
+    pre = torch.empty(M, N, device=DEV)
+    out = ops.gemm_nt(x.to(DEV), wd, rows=rows.to(DEV), bias=bias.to(DEV), act=2, pre=pre, prec=prec, b_planes=planes).cpu()
+    atol, rtol = TOL[prec]
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=atol * ref.abs().max().item(), rtol=rtol)
+    plain = ops.gemm_nt(x.to(DEV), wd, rows=rows.to(DEV), bias=bias.to(DEV), act=2, prec=prec).cpu()
+    np.testing.assert_allclose(out.numpy(), plain.numpy(), atol=2e-6 * ref.abs().max().item(), rtol=2e-5)
