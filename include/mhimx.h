@@ -66,6 +66,11 @@ typedef struct {
 } mhimx_gemm_nt_args;
 int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
 
+/* C[m,n] (+)= alpha * sum_k A[m,k] * B[k,n]   with B row-major [K,N] (ldb = its row pitch).  Only A, lda, rows, B, ldb,
+ * C, ldc, M, N, K, accumulate and prec of the argument block are read.  Both operands may be activations (attention
+ * products, the Nystrom pseudo-inverse iterations, dX = dY . W).   replaces: torch.matmul / `@` on the path. */
+int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float alpha, int32_t splits, float* ws /* splits*M*N floats when splits > 1 */);
+
 /* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over
  * `splits` slabs: ws must hold splits*K1*K2 floats when splits>1 (deterministic two-stage reduction).
  * accumulate: C += result.   replaces: autograd of every nn.Linear weight on the path. */
@@ -140,6 +145,52 @@ int mhimx_softmax_from_stats(void* stream, const float* s, const float* stats, f
  * replaces: mhim_modules/scoring.py:37-58 (get_pseudo_score), incl. the class-0 bias quirk (:54). */
 int mhimx_pseudo_score(void* stream, const float* s, const float* stats, const float* cproj, const float* bp,
                        float* score, float* attn_out, int64_t M, int64_t C);
+
+/* ------------------------------------------------------------------------------------------
+ * Nystrom / TransMIL encoder primitives (forward and backward)          
+ * The encoder is composed from the GEMMs above plus these streaming kernels; q,k,v stay packed as the
+ * [n_pad, 3*inner] output of to_qkv and every per-head matrix is addressed by (pointer offset, row pitch).
+ * ---------------------------------------------------------------------------------------- */
+/* LayerNorm over the last dim (eps 1e-5, biased variance) and its backward (dx may be NULL; d_w, d_b (+)= if accumulate).
+ * ws (bwd): 2*96*E floats.   replaces: nn.LayerNorm at baseline.py:199,222 / merge.py:96 and its autograd. */
+int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y, float* mean,
+                        float* rstd);
+int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
+                        const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws);
+/* out = x * keep/(1-p) with the counter-based mask of (seed + *tick, row, col): re-applies a forward dropout to a gradient */
+int mhimx_dropout_apply(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed, const uint64_t* tick);
+/* y[r,:] = softmax(alpha * x[r,:]) over the last dim of x[R,L]; bwd: dx = alpha*y*(dy - sum(y*dy)).
+ * replaces: `.softmax(dim=-1)` nystrom_attention.py:130 and its autograd. */
+int mhimx_softmax_rows(void* stream, const float* x, float* y, int64_t R, int64_t L, float alpha);
+int mhimx_softmax_rows_bwd(void* stream, const float* y, const float* dy, float* dx, int64_t R, int64_t L, float alpha);
+/* out[j,c] = mean over the l consecutive rows j*l..(j+1)*l-1 of x[T, C] (row pitch ldx).  nystrom_attention.py:93-109 */
+int mhimx_landmark_mean(void* stream, const float* x, int64_t ldx, int64_t T, int64_t l, int64_t C, float* out);
+int mhimx_landmark_mean_bwd(void* stream, const float* dout, int64_t T, int64_t l, int64_t C, float* dx, int64_t ldx, int32_t accumulate);
+/* y = a*I + b*x on [B,n,n] (the 7I-, 15I-, 13I- terms of nystrom_attention.py:25);  y = alpha*x + beta*y element-wise */
+int mhimx_affine_ident(void* stream, const float* x, float* y, int64_t B, int64_t n, float a, float b);
+int mhimx_axpby(void* stream, const float* x, float* y, int64_t n, float alpha, float beta);
+/* z0 = a^T / (max row-abs-sum * max col-abs-sum) with GLOBAL maxima over the B matrices (nystrom_attention.py:15-18).
+ * stats[4] = {c, r, argmax row, argmax col}; ws: 2*B*n floats (fwd), 256 floats (bwd).  bwd includes the gradient that
+ * flows through the two maxima (torch autograd differentiates them). */
+int mhimx_pinv_init(void* stream, const float* a, int64_t B, int64_t n, float* z, float* stats, float* ws);
+int mhimx_pinv_init_bwd(void* stream, const float* dz, const float* z0, const float* stats, int64_t B, int64_t n, float* da, float* ws);
+/* out[t,c] (+)= sum_tau w[c/dh, tau] * v[t+tau-KS/2, c] (zero outside [0,T)); flip=1 applies the transposed stencil
+ * (the gradient w.r.t. v).  nystrom_attention.py:59-63,135-136 (Conv2d(heads,heads,(33,1),groups=heads)). */
+int mhimx_resconv(void* stream, const float* v, int64_t ldv, const float* w, int64_t KS, int64_t dh, int64_t T, int64_t C, float* out,
+                  int64_t ldo, int32_t accumulate, int32_t flip);
+int64_t mhimx_resconv_dw_ws_floats(int64_t T, int64_t C, int64_t dh, int64_t KS);
+int mhimx_resconv_dw(void* stream, const float* dout, int64_t ldo, const float* v, int64_t ldv, int64_t KS, int64_t dh, int64_t T,
+                     int64_t C, float* dw, float* ws);
+/* PPEG (emb_position.py:85-120).  combine: wc[C,49] = w7 + pad(w5) + pad(w3) + identity, bc = b7+b5+b3;
+ * fwd: y[N,C] = depth-wise 7x7 stencil of the wrap-padded H x H token grid; bwd: dx, dwc [C,49], dbc [C]. */
+int mhimx_ppeg_combine(void* stream, const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,
+                       const float* b3, int64_t C, float* wc, float* bc);
+int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const float* wc, const float* bc, float* y);
+int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C);
+int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc, float* dbc,
+                   float* ws);
+/* out[t,c] = v[t,c] * a[c/dh, t]   (scoring.py:25: per-head value x attention, heads interleaved as (h d)) */
+int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, const float* a, int64_t lda, int64_t dh, int64_t T, int64_t C, float* out);
 
 /* ------------------------------------------------------------------------------------------
  * Hard-instance select                                          

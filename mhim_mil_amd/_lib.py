@@ -86,6 +86,7 @@ SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
+    "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),
     "mhimx_gemm_tn": (C.c_int, [_P, C.POINTER(GemmTN)]),
     "mhimx_split_planes": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
     "mhimx_transpose": (C.c_int, [_P, _P, _P, _I64, _I64]),
@@ -107,6 +108,25 @@ SYMBOLS = {
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P]),
     "mhimx_tick": (C.c_int, [_P, _P]),
+    "mhimx_layernorm_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mhimx_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "mhimx_dropout_apply": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _U64, _P]),
+    "mhimx_softmax_rows": (C.c_int, [_P, _P, _P, _I64, _I64, _F]),
+    "mhimx_softmax_rows_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F]),
+    "mhimx_landmark_mean": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),
+    "mhimx_landmark_mean_bwd": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _I64, _I32]),
+    "mhimx_affine_ident": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _F]),
+    "mhimx_axpby": (C.c_int, [_P, _P, _P, _I64, _F, _F]),
+    "mhimx_pinv_init": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
+    "mhimx_pinv_init_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "mhimx_resconv": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I32, _I32]),
+    "mhimx_resconv_dw_ws_floats": (_I64, [_I64, _I64, _I64, _I64]),
+    "mhimx_resconv_dw": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P, _P]),
+    "mhimx_ppeg_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "mhimx_ppeg_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
+    "mhimx_ppeg_bwd_ws_floats": (_I64, [_I64, _I64]),
+    "mhimx_ppeg_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mhimx_scale_heads": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
 }
 
 _lib = None

@@ -1,0 +1,554 @@
+// attn_ops.hip — non-GEMM pieces of the Nystrom / TransMIL encoder, forward and
+// backward: row softmax, landmark means, pseudo-inverse initialisation, a*I + b*X, the depth-wise residual
+// convolution along tokens, PPEG's 7x7+5x5+3x3 depth-wise grid convolution, and small element-wise helpers.
+// All are streaming (HBM-bound) kernels: coalesced along the 512-wide channel axis, wave/block reductions by DPP.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mhimx {
+
+constexpr int AT = 256;
+
+MHIMX_DEV float blk_sum4(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+MHIMX_DEV float blk_max4(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax over the last dimension of x[R, L] (scaled: y = softmax(alpha * x)), block per row
+// replaces: `.softmax(dim=-1)` at nystrom_attention.py:130
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AT) void softmax_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t R,
+                                                              int64_t L, float alpha) {
+  __shared__ float red[4];
+  for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    const float* xr = x + r * L;
+    float* yr = y + r * L;
+    float m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < L; i += AT) m = fmaxf(m, xr[i] * alpha);
+    m = blk_max4(m, red);
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < L; i += AT) s += __expf(xr[i] * alpha - m);
+    s = blk_sum4(s, red);
+    const float inv = 1.f / s;
+    for (int64_t i = threadIdx.x; i < L; i += AT) yr[i] = __expf(xr[i] * alpha - m) * inv;
+    __syncthreads();
+  }
+}
+// wave-per-row variant for short rows (L <= 1024): 4 rows per block
+__global__ __launch_bounds__(AT) void softmax_rows_fwd_short_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t R,
+                                                                    int L, float alpha) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < R; r += (int64_t)gridDim.x * 4) {
+    const float* xr = x + r * L;
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = lane + 64 * q;
+      v[q] = i < L ? xr[i] * alpha : -INFINITY;
+      m = fmaxf(m, v[q]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      v[q] = (lane + 64 * q) < L ? __expf(v[q] - m) : 0.f;
+      s += v[q];
+    }
+    const float inv = 1.f / wave_sum(s);
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if ((lane + 64 * q) < L) y[r * L + lane + 64 * q] = v[q] * inv;
+  }
+}
+// dx = alpha * y * (dy - sum(y*dy))
+__global__ __launch_bounds__(AT) void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, int64_t R, int64_t L, float alpha) {
+  __shared__ float red[4];
+  for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    const float* yr = y + r * L;
+    const float* gr = dy + r * L;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < L; i += AT) s += yr[i] * gr[i];
+    s = blk_sum4(s, red);
+    for (int64_t i = threadIdx.x; i < L; i += AT) dx[r * L + i] = alpha * yr[i] * (gr[i] - s);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// landmark means: out[j, c] = mean_{t in [j*l, (j+1)*l)} x[t*ldx + c]   (nystrom_attention.py:93-109)
+// bwd: dx[t, c] (+)= dout[t / l, c] / l
+// ------------------------------------------------------------------------------------------------
+__global__ void landmark_fwd_kernel(const float* __restrict__ x, int64_t ldx, int l, int C, float* __restrict__ out) {
+  const int j = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int t = 0; t < l; ++t) acc += x[((int64_t)j * l + t) * ldx + c];
+    out[(int64_t)j * C + c] = acc / (float)l;
+  }
+}
+__global__ void landmark_bwd_kernel(const float* __restrict__ dout, int l, int C, float* __restrict__ dx, int64_t ldx, int64_t T,
+                                    int accumulate) {
+  const float inv = 1.f / (float)l;
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float v = dout[(t / l) * C + c] * inv;
+      float* p = dx + t * ldx + c;
+      *p = accumulate ? *p + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = a*I + b*x on a batch of square matrices [B, n, n]   (the 13I - ..., 15I - ..., 7I - ... of nystrom:25)
+// ------------------------------------------------------------------------------------------------
+__global__ void affine_ident_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t total, int n, float a, float b) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i % ((int64_t)n * n);
+    const int r = (int)(e / n), c = (int)(e % n);
+    y[i] = b * x[i] + (r == c ? a : 0.f);
+  }
+}
+
+// y = alpha*x + beta*y  (residual adds, gradient accumulation of same-shaped tensors)
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float alpha, float beta) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = alpha * x[i] + (beta == 0.f ? 0.f : beta * y[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pseudo-inverse initialisation (nystrom_attention.py:15-18): z0 = a^T / (max_{b,i} sum_j |a_ij| * max_{b,j} sum_i |a_ij|)
+// with GLOBAL maxima over the batch of heads.  stats: [0]=c (max row sum), [1]=r (max col sum), [2]=argmax row (b*n+i),
+// [3]=argmax col (b*n+j), stored as floats.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AT) void pinv_sums_kernel(const float* __restrict__ a, int B, int n, float* __restrict__ rowsum,
+                                                       float* __restrict__ colsum) {
+  // one block per (b, i): row sum; and per (b, j): col sum (second half of the grid)
+  __shared__ float red[4];
+  const int idx = blockIdx.x;
+  const int total = B * n;
+  const bool is_col = idx >= total;
+  const int q = is_col ? idx - total : idx;
+  const int b = q / n, i = q % n;
+  float s = 0.f;
+  for (int t = threadIdx.x; t < n; t += AT) s += fabsf(is_col ? a[((int64_t)b * n + t) * n + i] : a[((int64_t)b * n + i) * n + t]);
+  s = blk_sum4(s, red);
+  if (threadIdx.x == 0) (is_col ? colsum : rowsum)[q] = s;
+}
+__global__ __launch_bounds__(AT) void pinv_argmax_kernel(const float* __restrict__ rowsum, const float* __restrict__ colsum, int total,
+                                                         float* __restrict__ stats) {
+  __shared__ float bv[AT];
+  __shared__ int bi[AT];
+  for (int which = 0; which < 2; ++which) {
+    const float* v = which ? colsum : rowsum;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int i = threadIdx.x; i < total; i += AT)
+      if (v[i] > best) { best = v[i]; arg = i; }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = arg;
+    __syncthreads();
+    for (int o = AT / 2; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        const float ov = bv[threadIdx.x + o];
+        const int oi = bi[threadIdx.x + o];
+        if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { stats[which] = bv[0]; stats[2 + which] = (float)bi[0]; }
+    __syncthreads();
+  }
+}
+// z0[b,j,i] = a[b,i,j] / (c*r)
+__global__ void pinv_init_kernel(const float* __restrict__ a, const float* __restrict__ stats, int B, int n, float* __restrict__ z) {
+  __shared__ float tile[32][33];
+  const float s = 1.f / (stats[0] * stats[1]);
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) tile[i][threadIdx.x] = a[((int64_t)b * n + r0 + i) * n + c0 + threadIdx.x];
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) z[((int64_t)b * n + c0 + i) * n + r0 + threadIdx.x] = tile[threadIdx.x][i] * s;
+}
+// backward: da = dz^T * s  - g * s * (1/c on the argmax row, 1/r on the argmax column),  g = sum(dz * z0)/s ... see host
+__global__ __launch_bounds__(AT) void dot_total_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
+                                                       float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * AT + threadIdx.x; i < n; i += (int64_t)gridDim.x * AT) s += x[i] * y[i];
+  s = blk_sum4(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void pinv_init_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ stats, const float* __restrict__ part,
+                                     int npart, int B, int n, float* __restrict__ da) {
+  // g = <dz, z0> = sum over partials; d(1/(c r)) terms land on the arg-max row / column of |a| (a >= 0 after softmax)
+  __shared__ float gs;
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    float g = 0.f;
+    for (int i = 0; i < npart; ++i) g += part[i];
+    gs = g;
+  }
+  __shared__ float tile[32][33];
+  __syncthreads();
+  const float c = stats[0], r = stats[1], s = 1.f / (c * r);
+  const int arow = (int)stats[2], acol = (int)stats[3];
+  const float g = gs;                          // = sum(dz * z0);  dL/ds = g / s ; ds/dc = -s/c ; ds/dr = -s/r
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) tile[i][threadIdx.x] = dz[((int64_t)b * n + r0 + i) * n + c0 + threadIdx.x];
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int ai = c0 + i, aj = r0 + threadIdx.x;      // element a[b, ai, aj] <- dz[b, aj, ai]
+    float v = tile[threadIdx.x][i] * s;
+    if (b * n + ai == arow) v -= g / c;
+    if (b * n + aj == acol) v -= g / r;
+    da[((int64_t)b * n + ai) * n + aj] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual depth-wise convolution along tokens (nystrom_attention.py:59-63,135-136): Conv2d(h,h,(33,1),groups=h), zero pad 16
+//   out[t, c] (+)= sum_tau w[c / dh, tau] * v[t + tau - P, c]          v, out: [T, C] with row pitches ldv, ldo
+// bwd: dv[t, c] (+)= sum_tau w[h, tau] * dout[t - tau + P, c] ;  dw[h, tau] = sum_{t,c in h} dout[t,c] * v[t+tau-P, c]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AT) void resconv_fwd_kernel(const float* __restrict__ v, int64_t ldv, const float* __restrict__ w, int KS,
+                                                         int dh, int64_t T, int C, float* __restrict__ out, int64_t ldo,
+                                                         int accumulate, int flip) {
+  const int P = KS / 2;
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x)
+    for (int c = threadIdx.x; c < C; c += AT) {
+      const float* wh = w + (c / dh) * KS;
+      float acc = 0.f;
+      for (int tau = 0; tau < KS; ++tau) {
+        const int64_t tt = flip ? t - tau + P : t + tau - P;
+        if (tt >= 0 && tt < T) acc += wh[tau] * v[tt * ldv + c];
+      }
+      float* p = out + t * ldo + c;
+      *p = accumulate ? *p + acc : acc;
+    }
+}
+// partial dw per block of tokens: part[blk][h*KS + tau]
+__global__ __launch_bounds__(AT) void resconv_dw_kernel(const float* __restrict__ dout, int64_t ldo, const float* __restrict__ v,
+                                                        int64_t ldv, int KS, int dh, int64_t T, int C, int64_t chunk,
+                                                        float* __restrict__ part) {
+  extern __shared__ float sm[];              // [heads*KS]
+  const int heads = C / dh, P = KS / 2;
+  for (int i = threadIdx.x; i < heads * KS; i += AT) sm[i] = 0.f;
+  __syncthreads();
+  const int64_t t0 = (int64_t)blockIdx.x * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave w handles heads w, w+4, ...; lane = channel inside the head (dh == 64)
+  for (int h = wave; h < heads; h += 4) {
+    const int c = h * dh + lane;
+    for (int tau = 0; tau < KS; ++tau) {
+      float acc = 0.f;
+      for (int64_t t = t0; t < t1; ++t) {
+        const int64_t tt = t + tau - P;
+        if (tt >= 0 && tt < T) acc += dout[t * ldo + c] * v[tt * ldv + c];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) sm[h * KS + tau] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < heads * KS; i += AT) part[(int64_t)blockIdx.x * heads * KS + i] = sm[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// PPEG (emb_position.py:85-120): tokens [N, C] laid on an H x H grid (first H*H-N tokens appended again: wrap;
+// if H < 7 zero-padded to 7x7), y = x + dw7(x) + dw5(x) + dw3(x) (+ biases), first N grid cells returned.
+// One combined 7x7 kernel per channel: wc = w7 + pad(w5) + pad(w3) (+1 at the centre for the identity); bias = b7+b5+b3.
+// ------------------------------------------------------------------------------------------------
+MHIMX_DEV int64_t ppeg_src(int64_t cell, int64_t N, int64_t wrapN) {       // grid cell -> source token or -1 (zero cell)
+  if (cell < N) return cell;
+  if (cell < wrapN) return cell - N;
+  return -1;
+}
+__global__ __launch_bounds__(AT) void ppeg_fwd_kernel(const float* __restrict__ x, int64_t N, int C, int H, int64_t wrapN,
+                                                      const float* __restrict__ wc /*[C,49]*/, const float* __restrict__ bc,
+                                                      float* __restrict__ y, int flip) {
+  for (int64_t cell = blockIdx.x; cell < N; cell += gridDim.x) {
+    const int gy = (int)(cell / H), gx = (int)(cell % H);
+    for (int c = threadIdx.x; c < C; c += AT) {
+      float acc = flip ? 0.f : bc[c];
+      for (int dy = -3; dy <= 3; ++dy) {
+        const int yy = gy + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -3; dx <= 3; ++dx) {
+          const int xx = gx + dx;
+          if (xx < 0 || xx >= H) continue;
+          const int64_t src = ppeg_src((int64_t)yy * H + xx, N, wrapN);
+          if (src < 0) continue;
+          const int tap = flip ? (3 - dy) * 7 + (3 - dx) : (dy + 3) * 7 + (dx + 3);
+          acc += wc[c * 49 + tap] * x[src * C + c];
+        }
+      }
+      y[cell * C + c] = acc;
+    }
+  }
+}
+// The wrapped cells (N <= cell < wrapN) also receive inputs/gradients: handled by a second pass over those cells that
+// ACCUMULATES into the first tokens (backward: dx[cell-N] += sum over the cell's neighbourhood of dy * w flipped).
+__global__ __launch_bounds__(AT) void ppeg_bwd_dx_kernel(const float* __restrict__ dy, int64_t N, int C, int H, int64_t wrapN,
+                                                         const float* __restrict__ wc, float* __restrict__ dx, int64_t cell0,
+                                                         int64_t cell1, int accumulate) {
+  // dx for the source token of grid cell `cell`: sum over output cells o (< N: only those are returned) in the 7x7
+  // neighbourhood of dy[o] * wc[tap(o -> cell)]
+  for (int64_t cell = cell0 + blockIdx.x; cell < cell1; cell += gridDim.x) {
+    const int64_t src = ppeg_src(cell, N, wrapN);
+    if (src < 0) continue;
+    const int gy = (int)(cell / H), gx = (int)(cell % H);
+    for (int c = threadIdx.x; c < C; c += AT) {
+      float acc = 0.f;
+      for (int dyy = -3; dyy <= 3; ++dyy) {
+        const int oy = gy - dyy;
+        if (oy < 0 || oy >= H) continue;
+        for (int dxx = -3; dxx <= 3; ++dxx) {
+          const int ox = gx - dxx;
+          if (ox < 0 || ox >= H) continue;
+          const int64_t o = (int64_t)oy * H + ox;
+          if (o >= N) continue;
+          acc += wc[c * 49 + (dyy + 3) * 7 + (dxx + 3)] * dy[o * C + c];
+        }
+      }
+      float* p = dx + src * C + c;
+      *p = accumulate ? *p + acc : acc;
+    }
+  }
+}
+// dwc partials: part[blk][c*49 + tap] = sum over the block's output cells of dy[o,c] * x[src(o + tap)]
+__global__ __launch_bounds__(AT) void ppeg_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t N, int C, int H,
+                                                     int64_t wrapN, int64_t chunk, float* __restrict__ part,
+                                                     float* __restrict__ part_b) {
+  const int64_t o0 = (int64_t)blockIdx.x * chunk, o1 = o0 + chunk < N ? o0 + chunk : N;
+  for (int c = threadIdx.x; c < C; c += AT) {
+    float acc[49];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) acc[i] = 0.f;
+    float ab = 0.f;
+    for (int64_t o = o0; o < o1; ++o) {
+      const float g = dy[o * C + c];
+      ab += g;
+      const int gy = (int)(o / H), gx = (int)(o % H);
+#pragma unroll
+      for (int dyy = -3; dyy <= 3; ++dyy)
+#pragma unroll
+        for (int dxx = -3; dxx <= 3; ++dxx) {
+          const int yy = gy + dyy, xx = gx + dxx;
+          if (yy < 0 || yy >= H || xx < 0 || xx >= H) continue;
+          const int64_t src = ppeg_src((int64_t)yy * H + xx, N, wrapN);
+          if (src < 0) continue;
+          acc[(dyy + 3) * 7 + (dxx + 3)] += g * x[src * C + c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 49; ++i) part[((int64_t)blockIdx.x * C + c) * 49 + i] = acc[i];
+    part_b[(int64_t)blockIdx.x * C + c] = ab;
+  }
+}
+
+// out[t, c] = v[t*ldv + c] * a[(c / dh) * lda + t]    (scoring.py:25: v * attn per head, heads interleaved as (h d))
+__global__ void scale_heads_kernel(const float* __restrict__ v, int64_t ldv, const float* __restrict__ a, int64_t lda, int dh,
+                                   int64_t T, int C, float* __restrict__ out) {
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[t * C + c] = v[t * ldv + c] * a[(int64_t)(c / dh) * lda + t];
+}
+
+}  // namespace mhimx
+
+using namespace mhimx;
+
+static inline unsigned grid1d(int64_t n, int per, int cap) {
+  int64_t g = cdiv(n, per);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+extern "C" int mhimx_softmax_rows(void* stream, const float* x, float* y, int64_t R, int64_t L, float alpha) {
+  MHIMX_CHECK_ARG(x && y && R > 0 && L > 0, "softmax_rows: bad args");
+  if (L <= 1024)
+    hipLaunchKernelGGL(softmax_rows_fwd_short_kernel, dim3(grid1d(R, 4, 65535)), dim3(AT), 0, (hipStream_t)stream, x, y, R, (int)L, alpha);
+  else
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(grid1d(R, 1, 65535)), dim3(AT), 0, (hipStream_t)stream, x, y, R, L, alpha);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_softmax_rows_bwd(void* stream, const float* y, const float* dy, float* dx, int64_t R, int64_t L, float alpha) {
+  MHIMX_CHECK_ARG(y && dy && dx && R > 0 && L > 0, "softmax_rows_bwd: bad args");
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(grid1d(R, 1, 65535)), dim3(AT), 0, (hipStream_t)stream, y, dy, dx, R, L, alpha);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_landmark_mean(void* stream, const float* x, int64_t ldx, int64_t T, int64_t l, int64_t C, float* out) {
+  MHIMX_CHECK_ARG(x && out && l > 0 && T % l == 0 && C > 0, "landmark_mean: T must be a multiple of l");
+  hipLaunchKernelGGL(landmark_fwd_kernel, dim3((unsigned)(T / l)), dim3(AT), 0, (hipStream_t)stream, x, ldx, (int)l, (int)C, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_landmark_mean_bwd(void* stream, const float* dout, int64_t T, int64_t l, int64_t C, float* dx, int64_t ldx,
+                                       int32_t accumulate) {
+  MHIMX_CHECK_ARG(dout && dx && l > 0 && T % l == 0, "landmark_mean_bwd: bad args");
+  hipLaunchKernelGGL(landmark_bwd_kernel, dim3(grid1d(T, 1, 8192)), dim3(AT), 0, (hipStream_t)stream, dout, (int)l, (int)C, dx, ldx, T, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_affine_ident(void* stream, const float* x, float* y, int64_t B, int64_t n, float a, float b) {
+  MHIMX_CHECK_ARG(x && y && B > 0 && n > 0, "affine_ident: bad args");
+  hipLaunchKernelGGL(affine_ident_kernel, dim3(grid1d(B * n * n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, B * n * n, (int)n, a, b);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_axpby(void* stream, const float* x, float* y, int64_t n, float alpha, float beta) {
+  MHIMX_CHECK_ARG(x && y && n >= 0, "axpby: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid1d(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, n, alpha, beta);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+// ws: (2*B*n + 4 + 1024) floats.  stats (4 floats) is kept by the caller for the backward.
+extern "C" int mhimx_pinv_init(void* stream, const float* a, int64_t B, int64_t n, float* z, float* stats, float* ws) {
+  MHIMX_CHECK_ARG(a && z && stats && ws && n % 32 == 0, "pinv_init: n must be a multiple of 32");
+  float* rowsum = ws;
+  float* colsum = ws + B * n;
+  hipLaunchKernelGGL(pinv_sums_kernel, dim3((unsigned)(2 * B * n)), dim3(AT), 0, (hipStream_t)stream, a, (int)B, (int)n, rowsum, colsum);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pinv_argmax_kernel, dim3(1), dim3(AT), 0, (hipStream_t)stream, rowsum, colsum, (int)(B * n), stats);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pinv_init_kernel, dim3((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream, a, stats, (int)B, (int)n, z);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_pinv_init_bwd(void* stream, const float* dz, const float* z0, const float* stats, int64_t B, int64_t n, float* da,
+                                   float* ws) {
+  MHIMX_CHECK_ARG(dz && z0 && stats && da && ws && n % 32 == 0, "pinv_init_bwd: bad args");
+  const int npart = 256;
+  hipLaunchKernelGGL(dot_total_kernel, dim3(npart), dim3(AT), 0, (hipStream_t)stream, dz, z0, B * n * n, ws);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pinv_init_bwd_kernel, dim3((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream, dz, stats,
+                     ws, npart, (int)B, (int)n, da);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_resconv(void* stream, const float* v, int64_t ldv, const float* w, int64_t KS, int64_t dh, int64_t T, int64_t C,
+                             float* out, int64_t ldo, int32_t accumulate, int32_t flip) {
+  MHIMX_CHECK_ARG(v && w && out && KS % 2 == 1 && C % dh == 0, "resconv: bad args");
+  hipLaunchKernelGGL(resconv_fwd_kernel, dim3(grid1d(T, 1, 16384)), dim3(AT), 0, (hipStream_t)stream, v, ldv, w, (int)KS, (int)dh, T, (int)C, out,
+                     ldo, accumulate, flip);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+// fixed-order reduction of partial rows: out[j] = sum_b part[b*W + j]
+__global__ __launch_bounds__(1024) void attn_reduce_kernel(const float* __restrict__ part, int G, int64_t W, float* __restrict__ out) {
+  __shared__ float red[32][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  for (int64_t j0 = (int64_t)blockIdx.x * 32; j0 < W; j0 += (int64_t)gridDim.x * 32) {
+    const int64_t j = j0 + c;
+    float acc = 0.f;
+    if (j < W)
+      for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * W + j];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (rg == 0 && j < W) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v += red[q][c];
+      out[j] = v;
+    }
+    __syncthreads();
+  }
+}
+static int attn_reduce(hipStream_t st, const float* part, int G, int64_t W, float* out) {
+  hipLaunchKernelGGL(attn_reduce_kernel, dim3(grid1d(W, 32, 4096)), dim3(1024), 0, st, part, G, W, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+// dw[h, tau] of the residual convolution.  ws: mhimx_resconv_dw_ws_floats(...) floats.
+extern "C" int64_t mhimx_resconv_dw_ws_floats(int64_t T, int64_t C, int64_t dh, int64_t KS) { return cdiv(T, 256) * (C / dh) * KS; }
+extern "C" int mhimx_resconv_dw(void* stream, const float* dout, int64_t ldo, const float* v, int64_t ldv, int64_t KS, int64_t dh,
+                                int64_t T, int64_t C, float* dw, float* ws) {
+  MHIMX_CHECK_ARG(dout && v && dw && ws && dh == 64 && C % dh == 0, "resconv_dw: dim_head must be 64");
+  const int nblk = (int)cdiv(T, 256);
+  const int W = (int)((C / dh) * KS);
+  hipLaunchKernelGGL(resconv_dw_kernel, dim3(nblk), dim3(AT), (size_t)W * 4, (hipStream_t)stream, dout, ldo, v, ldv, (int)KS, (int)dh, T, (int)C,
+                     (int64_t)256, ws);
+  MHIMX_LAUNCH_CHECK();
+  return attn_reduce((hipStream_t)stream, ws, nblk, W, dw);
+}
+
+// wc[c, 7x7] = w7 + centre-padded w5 + centre-padded w3 + identity ; bc = b7 + b5 + b3   (emb_position.py:115)
+__global__ void ppeg_combine_kernel(const float* __restrict__ w7, const float* __restrict__ w5, const float* __restrict__ w3,
+                                    const float* __restrict__ b7, const float* __restrict__ b5, const float* __restrict__ b3, int C,
+                                    float* __restrict__ wc, float* __restrict__ bc) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * 49; i += gridDim.x * blockDim.x) {
+    const int c = i / 49, t = i % 49, y = t / 7, x = t % 7;
+    float v = w7[i];
+    if (y >= 1 && y <= 5 && x >= 1 && x <= 5) v += w5[c * 25 + (y - 1) * 5 + (x - 1)];
+    if (y >= 2 && y <= 4 && x >= 2 && x <= 4) v += w3[c * 9 + (y - 2) * 3 + (x - 2)];
+    if (t == 24) v += 1.f;
+    wc[i] = v;
+    if (t == 0) bc[c] = b7[c] + b5[c] + b3[c];
+  }
+}
+extern "C" int mhimx_ppeg_combine(void* stream, const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,
+                                  const float* b3, int64_t C, float* wc, float* bc) {
+  MHIMX_CHECK_ARG(w7 && w5 && w3 && b7 && b5 && b3 && wc && bc, "ppeg_combine: null args");
+  hipLaunchKernelGGL(ppeg_combine_kernel, dim3(grid1d(C * 49, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w7, w5, w3, b7, b5, b3, (int)C, wc, bc);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+static void ppeg_geom(int64_t N, int* H, int64_t* wrapN) {
+  int h0 = (int)ceil(sqrt((double)N));
+  while ((int64_t)h0 * h0 < N) ++h0;
+  while (h0 > 1 && (int64_t)(h0 - 1) * (h0 - 1) >= N) --h0;
+  *wrapN = (int64_t)h0 * h0;
+  *H = h0 < 7 ? 7 : h0;
+}
+extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const float* wc, const float* bc, float* y) {
+  MHIMX_CHECK_ARG(x && wc && bc && y && N > 0, "ppeg_fwd: bad args");
+  int H; int64_t wrapN;
+  ppeg_geom(N, &H, &wrapN);
+  hipLaunchKernelGGL(ppeg_fwd_kernel, dim3(grid1d(N, 1, 32768)), dim3(AT), 0, (hipStream_t)stream, x, N, (int)C, H, wrapN, wc, bc, y, 0);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C) { return cdiv(N, 256) * C * 50; }
+extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc,
+                              float* dbc, float* ws) {
+  MHIMX_CHECK_ARG(dy && x && wc && dx && dwc && dbc && ws, "ppeg_bwd: null args");
+  int H; int64_t wrapN;
+  ppeg_geom(N, &H, &wrapN);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ppeg_bwd_dx_kernel, dim3(grid1d(N, 1, 32768)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc, dx, (int64_t)0, N, 0);
+  MHIMX_LAUNCH_CHECK();
+  if (wrapN > N) {
+    hipLaunchKernelGGL(ppeg_bwd_dx_kernel, dim3(grid1d(wrapN - N, 1, 32768)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc, dx, N, wrapN, 1);
+    MHIMX_LAUNCH_CHECK();
+  }
+  const int nblk = (int)cdiv(N, 256);
+  float* part = ws;
+  float* part_b = ws + (int64_t)nblk * C * 49;
+  hipLaunchKernelGGL(ppeg_dw_kernel, dim3(nblk), dim3(AT), 0, st, dy, x, N, (int)C, H, wrapN, (int64_t)256, part, part_b);
+  MHIMX_LAUNCH_CHECK();
+  if (int r = attn_reduce(st, part, nblk, C * 49, dwc)) return r;
+  return attn_reduce(st, part_b, nblk, C, dbc);
+}
+extern "C" int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, const float* a, int64_t lda, int64_t dh, int64_t T, int64_t C,
+                                 float* out) {
+  MHIMX_CHECK_ARG(v && a && out && C % dh == 0, "scale_heads: bad args");
+  hipLaunchKernelGGL(scale_heads_kernel, dim3(grid1d(T, 1, 16384)), dim3(AT), 0, (hipStream_t)stream, v, ldv, a, lda, (int)dh, T, (int)C, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}

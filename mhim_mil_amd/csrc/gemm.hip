@@ -458,6 +458,122 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
   }
 }
 
+__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2, int64_t ldc,
+                                    int splits, int accumulate);
+
+// =================================================================================================
+// gemm_nn : C[M,N] = A[M,K] . B[K,N]   (B row-major [K,N]: the k-strided operand is staged like gemm_tn's)
+// Used where both operands are activations (attention products, pseudo-inverse iterations, dX = dY . W).
+// alpha scales the product; accumulate adds into C.  K % 4 == 0, lda % 4 == 0.
+// =================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(mhimx_gemm_nt_args g, float alpha, int64_t kchunk, float* slabs) {
+  using PP = Prec<PREC>;
+  using T = typename PP::T;
+  constexpr int BK = PP::BK, PITCH = PP::PITCH, TSZ = 128 * PITCH;
+  constexpr int F4R = BK / 4, ITEMS = BM * F4R / NTHREADS, HK = BK / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Bs = As + PP::NA * TSZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const float* ap[ITEMS];
+  int rr[ITEMS], kk[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int idx = tid + j * NTHREADS;
+    rr[j] = idx / F4R;
+    kk[j] = (idx % F4R) * 4;
+    const int64_t m = m0 + rr[j];
+    ap[j] = m < g.M ? g.A + (g.rows ? g.rows[m] : m) * g.lda + kk[j] : nullptr;
+  }
+  const int c = tid & 127, half = tid >> 7;
+  const bool bin = (n0 + c) < g.N;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float4 ra[ITEMS];
+  float rb[HK];
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+      ra[j] = (ap[j] && (k0 + kk[j]) < kend) ? *reinterpret_cast<const float4*>(ap[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < HK; ++q) {
+      const int64_t k = k0 + half * HK + q;
+      rb[q] = (bin && k < kend) ? g.B[k * g.ldb + n0 + c] : 0.f;
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) lds_put4<PREC, PP::NA>(As, rr[j], kk[j], ra[j]);
+#pragma unroll
+    for (int q = 0; q < HK; q += 4)
+      lds_put4<PREC, PP::NB>(Bs, c, half * HK + q, make_float4(rb[q], rb[q + 1], rb[q + 2], rb[q + 3]));
+    __syncthreads();
+    if (k0 + BK < kend) fetch(k0 + BK);
+    mma_step<PREC>(As, Bs, wm, wn, lane, acc);
+    __syncthreads();
+  }
+  float* outp = slabs ? slabs + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const int64_t ldo = slabs ? g.N : g.ldc;
+  const int cl = lane & 31, rh = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t n = n0 + wn * 64 + nt * 32 + cl;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+        if (m >= g.M) continue;
+        float v = acc[mt][nt][e] * alpha;
+        float* cp = outp + m * ldo + n;
+        if (g.accumulate && !slabs) v += *cp;
+        *cp = v;
+      }
+    }
+}
+
+template <int PREC>
+static int launch_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits, float* ws) {
+  using PP = Prec<PREC>;
+  const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
+  if (splits < 1 || !ws) splits = 1;
+  const int64_t kchunk = align_up(cdiv(g.K, splits), PP::BK);
+  dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_nn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, alpha, kchunk, splits > 1 ? ws : (float*)nullptr);
+  MHIMX_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t n = g.M * g.N;
+    const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, g.C, g.M, g.N, g.ldc, splits, g.accumulate);
+    MHIMX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int gemm_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits, float* ws) {
+  MHIMX_CHECK_ARG(g.M >= 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_nn: bad args");
+  if (g.M == 0) return 0;
+  MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && aligned16(g.A), "gemm_nn: K, lda multiples of 4 and A 16-byte aligned");
+  switch (g.prec) {
+    case MHIMX_PREC_F32: return launch_nn<MHIMX_PREC_F32>(st, g, alpha, splits, ws);
+    case MHIMX_PREC_F16S:
+    case MHIMX_PREC_BF16X3: return launch_nn<MHIMX_PREC_BF16X3>(st, g, alpha, splits, ws);
+    default: return fail(-1, "gemm_nn: unknown prec %d", g.prec);
+  }
+}
+
 // =================================================================================================
 // transpose (32x32 LDS tile, +1 pad)
 // =================================================================================================
@@ -488,6 +604,10 @@ int transpose(hipStream_t st, const float* in, float* out, int64_t R, int64_t C)
 extern "C" int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_nt: null args");
   return mhimx::gemm_nt((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float alpha, int32_t splits, float* ws) {
+  if (!a) return mhimx::fail(-1, "gemm_nn: null args");
+  return mhimx::gemm_nn((hipStream_t)stream, *a, alpha, splits, ws);
 }
 extern "C" int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_tn: null args");

@@ -469,6 +469,18 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
 
 using namespace mhimx;
 
+// out = x * keep(seed + tick, row, col) / (1-p): the same counter-based mask the GEMM epilogue applies (forward) so a
+// backward can re-apply it to the incoming gradient without any stored mask.
+extern "C" int mhimx_dropout_apply(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed,
+                                   const uint64_t* tick) {
+  MHIMX_CHECK_ARG(x && out && M >= 0 && E > 0 && p >= 0.f && p < 1.f, "dropout_apply: bad args");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(drop_bwd_kernel, dim3((unsigned)(cdiv(M * E, 256) < 4096 ? cdiv(M * E, 256) : 4096)), dim3(256), 0, (hipStream_t)stream, x,
+                     out, M, (int)E, p, seed, tick);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head) {
   Arena ar(nullptr, 0);
   return merge_ws_layout(ar, R, E, k, heads, dim_head, nullptr);

@@ -674,6 +674,17 @@ extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, 
                             int64_t ws_bytes) {
   return colsum((hipStream_t)stream, X, M, E, out, accumulate, ws, ws_bytes);
 }
+// ws: 2*96*E floats (partial rows of the weight/bias gradients)
+extern "C" int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y,
+                                   float* mean, float* rstd) {
+  MHIMX_CHECK_ARG(x && w && b && y && mean && rstd, "layernorm_fwd: null args");
+  return layernorm_fwd((hipStream_t)stream, x, M, E, w, b, y, mean, rstd);
+}
+extern "C" int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
+                                   const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws) {
+  MHIMX_CHECK_ARG(dy && x && w && mean && rstd && d_w && d_b && ws, "layernorm_bwd: null args");
+  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate);
+}
 extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(compose_ids_kernel, dim3((unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024)), dim3(256), 0,

@@ -1,0 +1,510 @@
+"""Nystrom / TransMIL encoder over the HIP primitives.
+
+Mirrors the reference's ``SAttention`` (mhim_modules/baseline.py:222-288), ``TransLayer`` (:196-220),
+``NystromAttention`` (nystrom_attention.py:30-152) and ``PPEG`` (emb_position.py:85-120): same parameter
+names/shapes, same math incl. the quirks (front zero-padding whose pad tokens stay unmasked keys, global-max
+pseudo-inverse scaling, dim_head = 64, 256 landmarks).
+
+Every arithmetic step is a kernel of libmhimx.so.  The encoder is *composed* from primitives — GEMMs (nt / nn / tn),
+row softmax, landmark means, a*I+b*X, pseudo-inverse init, depth-wise residual conv, PPEG stencil, LayerNorm — each
+wrapped in a ``torch.autograd.Function`` whose backward is again kernels, so torch contributes only the graph
+bookkeeping, views and copies (cat / slice / zero-fill).  q, k, v stay packed in the [n_pad, 1536] to_qkv output; a
+per-head matrix is (pointer offset, row pitch), never a permuted copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+HEADS, DH, INNER, LANDMARKS, PINV_ITERS, CONV_K = 8, 64, 512, 256, 6, 33
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, off=0):
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+_PREC = "bf16x3"
+
+
+def set_precision(p):
+    global _PREC
+    _PREC = p
+
+
+# --------------------------------------------------------------------------------------------------- raw GEMMs
+def _gemm(mode, a, a_off, lda, b, b_off, ldb, c, c_off, ldc, M, N, K, accumulate=False, alpha=1.0, bias=None):
+    """One strided GEMM on raw (tensor, element offset, row pitch) operands.
+    nt: C[M,N] = A[M,K] B[N,K]^T ; nn: C[M,N] = A[M,K] B[K,N] ; tn: C[M,N] = A[K,M]^T B[K,N]."""
+    lib = L.lib()
+    prec = L.PREC[_PREC]
+    if mode == "tn":
+        splits = 1
+        ws = None
+        if K >= 4096:
+            splits = min(32, max(1, K // 2048))
+            ws = torch.empty(splits * M * N, device=c.device)
+        g = L.GemmTN(A=_ptr(a, a_off), lda=lda, B=_ptr(b, b_off), ldb=ldb, rows=None, C=_ptr(c, c_off), ldc=ldc, M=K, K1=M, K2=N,
+                     splits=splits, ws=None if ws is None else _ptr(ws), accumulate=int(accumulate), prec=prec,
+                     ws_floats=0 if ws is None else ws.numel())
+        L.check(lib.mhimx_gemm_tn(_st(), C.byref(g)), "mhimx_gemm_tn")
+        return
+    g = L.GemmNT(A=_ptr(a, a_off), lda=lda, rows=None, B=_ptr(b, b_off), ldb=ldb, C=_ptr(c, c_off), ldc=ldc, M=M, N=N, K=K,
+                 bias=None if bias is None else _ptr(bias), accumulate=int(accumulate), prec=prec)
+    if mode == "nt":
+        assert alpha == 1.0
+        L.check(lib.mhimx_gemm_nt(_st(), C.byref(g)), "mhimx_gemm_nt")
+    else:
+        splits, ws = 1, None
+        if K >= 4096 and M * N <= 256 * 256:
+            splits = min(64, max(1, K // 1024))
+            ws = torch.empty(splits * M * N, device=c.device)
+        L.check(lib.mhimx_gemm_nn(_st(), C.byref(g), float(alpha), splits, None if ws is None else _ptr(ws)), "mhimx_gemm_nn")
+
+
+class Op:
+    """Per-head operand descriptor: head h is the (rows x cols) matrix at t.data + base + h*head_off with row pitch ld."""
+
+    def __init__(self, t, base, head_off, ld, rows, cols):
+        self.t, self.base, self.head_off, self.ld, self.rows, self.cols = t, base, head_off, ld, rows, cols
+
+    def like(self, t):
+        return Op(t, self.base, self.head_off, self.ld, self.rows, self.cols)
+
+    def off(self, h):
+        return self.base + h * self.head_off
+
+
+def batched(t):
+    """[B, R, Cc] contiguous batch of matrices."""
+    B, R, Cc = t.shape
+    return Op(t, 0, R * Cc, Cc, R, Cc)
+
+
+def _heads_mm(mode, A: Op, Bo: Op, Co: Op, heads, accumulate=False):
+    for h in range(heads):
+        if mode == "nt":
+            M, N, K = A.rows, Bo.rows, A.cols
+        elif mode == "nn":
+            M, N, K = A.rows, Bo.cols, A.cols
+        else:
+            M, N, K = A.cols, Bo.cols, A.rows
+        _gemm(mode, A.t, A.off(h), A.ld, Bo.t, Bo.off(h), Bo.ld, Co.t, Co.off(h), Co.ld, M, N, K, accumulate=accumulate)
+
+
+class HeadsMatmul(torch.autograd.Function):
+    """C_h = op(A_h, B_h) for every head, operands addressed in place inside larger tensors (no permute copies).
+    Backward writes dA / dB straight into zero-filled tensors shaped like the parents."""
+
+    @staticmethod
+    def forward(ctx, a_t, b_t, mode, a_desc, b_desc, c_shape, c_desc, heads):
+        A, Bo = Op(a_t, *a_desc), Op(b_t, *b_desc)
+        c_t = torch.empty(c_shape, device=a_t.device)
+        Co = Op(c_t, *c_desc)
+        _heads_mm(mode, A, Bo, Co, heads)
+        ctx.save_for_backward(a_t, b_t)
+        ctx.cfg = (mode, a_desc, b_desc, c_desc, heads)
+        return c_t
+
+    @staticmethod
+    def backward(ctx, dc):
+        a_t, b_t = ctx.saved_tensors
+        mode, a_desc, b_desc, c_desc, heads = ctx.cfg
+        dc = dc.contiguous()
+        A, Bo, dC = Op(a_t, *a_desc), Op(b_t, *b_desc), Op(dc, *c_desc)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.zeros_like(a_t)
+            dA = A.like(da)
+            if mode == "nt":
+                _heads_mm("nn", dC, Bo, dA, heads)          # dA = dC B
+            elif mode == "nn":
+                _heads_mm("nt", dC, Bo, dA, heads)          # dA = dC B^T
+            else:
+                _heads_mm("nt", Bo, dC, dA, heads)          # dA = B dC^T
+        if ctx.needs_input_grad[1]:
+            db = torch.zeros_like(b_t)
+            dB = Bo.like(db)
+            if mode == "nt":
+                _heads_mm("tn", dC, A, dB, heads)           # dB = dC^T A
+            elif mode == "nn":
+                _heads_mm("tn", A, dC, dB, heads)           # dB = A^T dC
+            else:
+                _heads_mm("nn", A, dC, dB, heads)           # dB = A dC
+        return da, db, None, None, None, None, None, None
+
+
+def heads_mm(a_t, b_t, mode, a_desc, b_desc, c_shape, c_desc, heads=HEADS):
+    return HeadsMatmul.apply(a_t, b_t, mode, a_desc, b_desc, c_shape, c_desc, heads)
+
+
+# --------------------------------------------------------------------------------------------------- primitives
+class Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        Lr = x.shape[-1]
+        L.check(L.lib().mhimx_softmax_rows(_st(), _ptr(x), _ptr(y), x.numel() // Lr, Lr, float(alpha)), "softmax_rows")
+        ctx.save_for_backward(y)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        Lr = y.shape[-1]
+        L.check(L.lib().mhimx_softmax_rows_bwd(_st(), _ptr(y), _ptr(dy), _ptr(dx), y.numel() // Lr, Lr, float(ctx.alpha)),
+                "softmax_rows_bwd")
+        return dx, None
+
+
+class LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        M, E = x.shape
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(M, device=x.device), torch.empty(M, device=x.device)
+        L.check(L.lib().mhimx_layernorm_fwd(_st(), _ptr(x), M, E, _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd)), "layernorm_fwd")
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, E = x.shape
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        ws = torch.empty(2 * 96 * E, device=x.device)
+        L.check(L.lib().mhimx_layernorm_bwd(_st(), _ptr(dy), _ptr(x), M, E, _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
+                                            _ptr(db), 0, _ptr(ws)), "layernorm_bwd")
+        return dx, dw, db
+
+
+class Linear(torch.autograd.Function):
+    """y = dropout(x W^T + b) with the counter-based dropout stream (p = 0: none)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, drop_p, seed, tick):
+        x = x.contiguous()
+        y = ops.gemm_nt(x, w, bias=b, drop_p=drop_p, drop_seed=seed, drop_tick=tick, prec=_PREC)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (drop_p, seed, tick, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        drop_p, seed, tick, has_b = ctx.cfg
+        dy = dy.contiguous()
+        M, N = dy.shape
+        if drop_p > 0:
+            g = torch.empty_like(dy)
+            L.check(L.lib().mhimx_dropout_apply(_st(), _ptr(dy), _ptr(g), M, N, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                None if tick is None else _ptr(tick)), "dropout_apply")
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _gemm("nn", dy, 0, N, w, 0, w.shape[1], dx, 0, x.shape[1], M, x.shape[1], N)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_tn(dy, x, splits=8 if M >= 4096 else 1, prec=_PREC)
+        if has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)
+        return dx, dw, db, None, None, None
+
+
+class Landmarks(torch.autograd.Function):
+    """Means of l consecutive tokens of the q and k columns of qkv [n_pad, 1536] -> [256, 1024]."""
+
+    @staticmethod
+    def forward(ctx, qkv, l):
+        T = qkv.shape[0]
+        out = torch.empty((T // l, 2 * INNER), device=qkv.device)
+        L.check(L.lib().mhimx_landmark_mean(_st(), _ptr(qkv), qkv.shape[1], T, l, 2 * INNER, _ptr(out)), "landmark_mean")
+        ctx.cfg = (T, l, qkv.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, l, ld = ctx.cfg
+        dq = torch.zeros((T, ld), device=dout.device)
+        L.check(L.lib().mhimx_landmark_mean_bwd(_st(), _ptr(dout.contiguous()), T, l, 2 * INNER, _ptr(dq), ld, 0), "landmark_mean_bwd")
+        return dq, None
+
+
+class AffineIdent(torch.autograd.Function):
+    """a*I + b*x on [B, n, n]."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.lib().mhimx_affine_ident(_st(), _ptr(x), _ptr(y), x.shape[0], x.shape[1], float(a), float(b)), "affine_ident")
+        ctx.b = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(L.lib().mhimx_affine_ident(_st(), _ptr(dy), _ptr(dx), dy.shape[0], dy.shape[1], 0.0, float(ctx.b)), "affine_ident")
+        return dx, None, None
+
+
+class PinvInit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous()
+        B, n, _ = a.shape
+        z = torch.empty_like(a)
+        stats = torch.empty(4, device=a.device)
+        ws = torch.empty(2 * B * n, device=a.device)
+        L.check(L.lib().mhimx_pinv_init(_st(), _ptr(a), B, n, _ptr(z), _ptr(stats), _ptr(ws)), "pinv_init")
+        ctx.save_for_backward(z, stats)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        z, stats = ctx.saved_tensors
+        dz = dz.contiguous()
+        B, n, _ = z.shape
+        da = torch.empty_like(z)
+        ws = torch.empty(256, device=z.device)
+        L.check(L.lib().mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z), _ptr(stats), B, n, _ptr(da), _ptr(ws)), "pinv_init_bwd")
+        return da
+
+
+class ResConv(torch.autograd.Function):
+    """Depth-wise 33-tap convolution along tokens of the v columns of qkv -> [n_pad, 512]."""
+
+    @staticmethod
+    def forward(ctx, qkv, w):
+        T, ld = qkv.shape
+        out = torch.empty((T, INNER), device=qkv.device)
+        w2 = w.reshape(HEADS, -1).contiguous()
+        L.check(L.lib().mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(w2), w2.shape[1], DH, T, INNER, _ptr(out), INNER, 0, 0),
+                "resconv")
+        ctx.save_for_backward(qkv, w2)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, w2 = ctx.saved_tensors
+        dout = dout.contiguous()
+        T, ld = qkv.shape
+        KS = w2.shape[1]
+        dq = dw = None
+        if ctx.needs_input_grad[0]:
+            dq = torch.zeros_like(qkv)
+            L.check(L.lib().mhimx_resconv(_st(), _ptr(dout), INNER, _ptr(w2), KS, DH, T, INNER, _ptr(dq, 2 * INNER), ld, 0, 1), "resconv")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w2)
+            ws = torch.empty(L.lib().mhimx_resconv_dw_ws_floats(T, INNER, DH, KS), device=qkv.device)
+            L.check(L.lib().mhimx_resconv_dw(_st(), _ptr(dout), INNER, _ptr(qkv, 2 * INNER), ld, KS, DH, T, INNER, _ptr(dw), _ptr(ws)),
+                    "resconv_dw")
+            dw = dw.reshape(ctx.wshape)
+        return dq, dw
+
+
+class PPEG(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w7, w5, w3, b7, b5, b3):
+        x = x.contiguous()
+        N, Cc = x.shape
+        wc, bc = torch.empty((Cc, 49), device=x.device), torch.empty(Cc, device=x.device)
+        lib = L.lib()
+        L.check(lib.mhimx_ppeg_combine(_st(), _ptr(w7.contiguous()), _ptr(w5.contiguous()), _ptr(w3.contiguous()), _ptr(b7), _ptr(b5),
+                                       _ptr(b3), Cc, _ptr(wc), _ptr(bc)), "ppeg_combine")
+        y = torch.empty_like(x)
+        L.check(lib.mhimx_ppeg_fwd(_st(), _ptr(x), N, Cc, _ptr(wc), _ptr(bc), _ptr(y)), "ppeg_fwd")
+        ctx.save_for_backward(x, wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Cc = x.shape
+        dx, dwc, dbc = torch.empty_like(x), torch.empty_like(wc), torch.empty(Cc, device=x.device)
+        ws = torch.empty(L.lib().mhimx_ppeg_bwd_ws_floats(N, Cc), device=x.device)
+        L.check(L.lib().mhimx_ppeg_bwd(_st(), _ptr(dy), _ptr(x), N, Cc, _ptr(wc), _ptr(dx), _ptr(dwc), _ptr(dbc), _ptr(ws)), "ppeg_bwd")
+        g = dwc.view(Cc, 1, 7, 7)
+        # the three kernels were summed centre-aligned into one 7x7 stencil: their gradients are its centred windows
+        return (dx, g.contiguous(), g[:, :, 1:6, 1:6].contiguous(), g[:, :, 2:5, 2:5].contiguous(), dbc, dbc.clone(), dbc.clone())
+
+
+class Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = a.contiguous().clone()
+        L.check(L.lib().mhimx_axpby(_st(), _ptr(b.contiguous()), _ptr(y), y.numel(), 1.0, 1.0), "axpby")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+# --------------------------------------------------------------------------------------------------- modules
+class _P(nn.Module):
+    def __init__(self, **tensors):
+        super().__init__()
+        for k, v in tensors.items():
+            setattr(self, k, nn.Parameter(v) if v is not None else None)
+
+
+def _lin(i, o, bias=True):
+    w = torch.empty(o, i)
+    nn.init.xavier_normal_(w)
+    return _P(weight=w, bias=torch.zeros(o) if bias else None)
+
+
+class _Slot(nn.Module):
+    pass
+
+
+class NystromAttention(nn.Module):
+    """Parameters + forward of modules/nystrom_attention.NystromAttention (dim 512, 8 x 64, 256 landmarks, 6 pinv iters)."""
+
+    def __init__(self, dim=512, dropout=0.1):
+        super().__init__()
+        self.to_qkv = _lin(dim, 3 * INNER, bias=False)
+        self.to_out = nn.Sequential(_lin(INNER, dim), _Slot())
+        w = torch.empty(HEADS, 1, CONV_K, 1)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.res_conv = _P(weight=w)
+        self.dropout = dropout
+        self.scale = DH ** -0.5
+
+    def forward(self, x, return_attn=False, no_norm=False, seed=0, tick=None, training=False):
+        """x [n, dim] -> out [n, dim] (+ cls-row attention [8, n-1] and v [8, n-1, 64] views when return_attn)."""
+        n, dim = x.shape
+        m = LANDMARKS
+        pad = (m - n % m) % m
+        if pad:
+            x = torch.cat([x.new_zeros(pad, dim), x], 0)                      # nystrom_attention.py:70-73 (front padding)
+        T = x.shape[0]
+        l = math.ceil(n / m)
+        qkv = Linear.apply(x, self.to_qkv.weight, None, 0.0, 0, None)          # [T, 1536]: q | k | v, heads = 64-column groups
+        ld = 3 * INNER
+        lm = Landmarks.apply(qkv, l)                                          # [256, 1024]: q~ | k~
+        q_d, k_d, v_d = (0, DH, ld, T, DH), (INNER, DH, ld, T, DH), (2 * INNER, DH, ld, T, DH)
+        ql_d, kl_d = (0, DH, 2 * INNER, m, DH), (INNER, DH, 2 * INNER, m, DH)
+        bat = lambda r, c: (0, r * c, c, r, c)
+        s1 = heads_mm(qkv, lm, "nt", q_d, kl_d, (HEADS, T, m), bat(T, m))     # q k~^T        nystrom:114
+        s2 = heads_mm(lm, lm, "nt", ql_d, kl_d, (HEADS, m, m), bat(m, m))     # q~ k~^T       nystrom:115
+        s3 = heads_mm(lm, qkv, "nt", ql_d, k_d, (HEADS, m, T), bat(m, T))     # q~ k^T        nystrom:116
+        a1, a2, a3 = Softmax.apply(s1, self.scale), Softmax.apply(s2, self.scale), Softmax.apply(s3, self.scale)
+        z = _pinv(a2)
+        a3v = heads_mm(a3, qkv, "nn", bat(m, T), v_d, (HEADS, m, DH), bat(m, DH))         # a3 v          [8,256,64]
+        w2 = heads_mm(z, a3v, "nn", bat(m, m), bat(m, DH), (HEADS, m, DH), bat(m, DH))    # pinv (a3 v)
+        out = heads_mm(a1, w2, "nn", bat(T, m), bat(m, DH), (T, INNER), (0, DH, INNER, T, DH))   # a1 (pinv a3 v) -> [T, (h d)]
+        out = Add.apply(out, ResConv.apply(qkv, self.res_conv.weight))         # nystrom:135-136
+        p = self.dropout if training else 0.0
+        y = Linear.apply(out[pad:], self.to_out[0].weight, self.to_out[0].bias, p, seed, tick)   # last n rows (nystrom:142)
+        if not return_attn:
+            return y
+        with torch.no_grad():                                                  # nystrom:143-150: the cls token's attention row
+            if no_norm:
+                b1, b2, b3 = s1 * self.scale, _pinv(s2 * self.scale), s3 * self.scale
+            else:
+                b1, b2, b3 = a1, z, a3
+            u = heads_mm(b1[:, pad:pad + 1].contiguous(), b2, "nn", bat(1, m), bat(m, m), (HEADS, 1, m), bat(1, m))
+            r = heads_mm(u, b3, "nn", bat(1, m), bat(m, T), (HEADS, 1, T), bat(1, T))
+            attn = r[:, 0, pad + 1:]
+            v = qkv[pad + 1:, 2 * INNER:].reshape(n - 1, HEADS, DH).permute(1, 0, 2)
+        return y, attn, v
+
+
+def _pinv(a):
+    """moore_penrose_iter_pinv (nystrom_attention.py:12-27) on [8, 256, 256]."""
+    B, n, _ = a.shape
+    bat = (0, n * n, n, n, n)
+    mm = lambda p, q: heads_mm(p, q, "nn", bat, bat, (B, n, n), bat, B)
+    z = PinvInit.apply(a)
+    for _ in range(PINV_ITERS):
+        az = mm(a, z)
+        t = AffineIdent.apply(az, 7.0, -1.0)
+        t = AffineIdent.apply(mm(az, t), 15.0, -1.0)
+        t = AffineIdent.apply(mm(az, t), 13.0, -1.0)
+        z = AffineIdent.apply(mm(z, t), 0.0, 0.25)
+    return z
+
+
+class TransLayer(nn.Module):
+    def __init__(self, dim=512):
+        super().__init__()
+        self.norm = _P(weight=torch.ones(dim), bias=torch.zeros(dim))
+        self.attn = NystromAttention(dim)
+
+    def forward(self, x, need_attn=False, no_norm=False, seed=0, tick=None, training=False):
+        xn = LayerNorm.apply(x, self.norm.weight, self.norm.bias)
+        if need_attn:
+            z, attn, v = self.attn(xn, True, no_norm, seed, tick, training)
+            return Add.apply(x, z), attn, v
+        return Add.apply(x, self.attn(xn, False, no_norm, seed, tick, training))
+
+
+class _Conv(nn.Module):
+    def __init__(self, dim, k):
+        super().__init__()
+        w = torch.empty(dim, 1, k, k)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(k * k)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(dim).uniform_(-bound, bound))
+
+
+class _PPEG(nn.Module):
+    def __init__(self, dim=512):
+        super().__init__()
+        self.proj, self.proj1, self.proj2 = _Conv(dim, 7), _Conv(dim, 5), _Conv(dim, 3)
+
+    def forward(self, x):
+        return PPEG.apply(x, self.proj.weight, self.proj1.weight, self.proj2.weight, self.proj.bias, self.proj1.bias, self.proj2.bias)
+
+
+class SAttention(nn.Module):
+    """mhim_modules/baseline.SAttention (pos='ppeg', pos_pos=0)."""
+
+    def __init__(self, mlp_dim=512, head=8):
+        super().__init__()
+        if mlp_dim != 512:
+            raise L.MhimxError("the Nystrom encoder kernels are built for mlp_dim = 512 (8 heads x 64, 256 landmarks)")
+        self.norm = _P(weight=torch.ones(mlp_dim), bias=torch.zeros(mlp_dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, mlp_dim))
+        self.layer1 = TransLayer(mlp_dim)
+        self.layer2 = TransLayer(mlp_dim)
+        self.pos_embedding = _PPEG(mlp_dim)
+
+    def forward(self, h, return_attn=False, no_norm=False, seeds=(0, 0), tick=None, training=False):
+        """h [N, 512] tokens -> cls feature [512] (+ [attn_l1, attn_l2] each [8, N], v of layer 1 [8, N, 64])."""
+        x = torch.cat([self.cls_token.view(1, -1), h], 0)
+        attn = []
+        if return_attn:
+            x, a, v = self.layer1(x, True, no_norm, seeds[0], tick, training)
+            attn.append(a)
+        else:
+            x = self.layer1(x, False, no_norm, seeds[0], tick, training)
+        x = torch.cat([x[:1], self.pos_embedding(x[1:])], 0)                    # baseline.py:265-266
+        if return_attn:
+            x, a, _ = self.layer2(x, True, no_norm, seeds[1], tick, training)
+            attn.append(a)
+        else:
+            x = self.layer2(x, False, no_norm, seeds[1], tick, training)
+        x = LayerNorm.apply(x[:1].contiguous(), self.norm.weight, self.norm.bias)   # only the cls row is used (baseline.py:276-278)
+        return (x[0], attn, v) if return_attn else x[0]
