@@ -142,7 +142,8 @@ int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_
 int mhimx_softmax_from_stats(void* stream, const float* s, const float* stats, float* attn, int64_t M);
 
 /* score[n] = max_c softmax_c( attn_n * cproj[n,c] + bp0 )
- * replaces: mhim_modules/scoring.py:37-58 (get_pseudo_score), incl. the class-0 bias quirk (:54). */
+ * replaces: mhim_modules/scoring.py:37-58 (get_pseudo_score), incl. the class-0 bias quirk (:54).
+ * s == NULL: attn_n = 1, i.e. score[n] = max_c softmax_c(cproj[n,c] + bp0), the tail of get_pseudo_score_trans (scoring.py:27-33). */
 int mhimx_pseudo_score(void* stream, const float* s, const float* stats, const float* cproj, const float* bp,
                        float* score, float* attn_out, int64_t M, int64_t C);
 

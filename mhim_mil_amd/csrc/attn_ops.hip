@@ -190,29 +190,36 @@ __global__ __launch_bounds__(AT) void dot_total_kernel(const float* __restrict__
   s = blk_sum4(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ void pinv_init_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ stats, const float* __restrict__ part,
-                                     int npart, int B, int n, float* __restrict__ da) {
-  // g = <dz, z0> = sum over partials; d(1/(c r)) terms land on the arg-max row / column of |a| (a >= 0 after softmax)
+__global__ void pinv_init_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z0, const float* __restrict__ stats,
+                                     const float* __restrict__ part, int npart, int B, int n, float* __restrict__ da) {
+  // g = <dz, z0> = sum over partials; d(1/(c r)) terms land on the arg-max row / column of |a| with sign(a) = sign(z0^T).
+  // (After a softmax all row sums tie at 1 and the arg-max row is rounding noise — harmless: a constant added to a whole
+  //  row of d a is annihilated by the softmax backward.)
   __shared__ float gs;
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     float g = 0.f;
     for (int i = 0; i < npart; ++i) g += part[i];
     gs = g;
   }
-  __shared__ float tile[32][33];
+  __shared__ float tile[32][33], ztile[32][33];
   __syncthreads();
   const float c = stats[0], r = stats[1], s = 1.f / (c * r);
   const int arow = (int)stats[2], acol = (int)stats[3];
   const float g = gs;                          // = sum(dz * z0);  dL/ds = g / s ; ds/dc = -s/c ; ds/dr = -s/r
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  for (int i = threadIdx.y; i < 32; i += blockDim.y) tile[i][threadIdx.x] = dz[((int64_t)b * n + r0 + i) * n + c0 + threadIdx.x];
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    tile[i][threadIdx.x] = dz[((int64_t)b * n + r0 + i) * n + c0 + threadIdx.x];
+    ztile[i][threadIdx.x] = z0[((int64_t)b * n + r0 + i) * n + c0 + threadIdx.x];
+  }
   __syncthreads();
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
     const int ai = c0 + i, aj = r0 + threadIdx.x;      // element a[b, ai, aj] <- dz[b, aj, ai]
     float v = tile[threadIdx.x][i] * s;
-    if (b * n + ai == arow) v -= g / c;
-    if (b * n + aj == acol) v -= g / r;
+    const float zz = ztile[threadIdx.x][i];
+    const float sg = zz > 0.f ? 1.f : (zz < 0.f ? -1.f : 0.f);
+    if (b * n + ai == arow) v -= sg * g / c;
+    if (b * n + aj == acol) v -= sg * g / r;
     da[((int64_t)b * n + ai) * n + aj] = v;
   }
 }
@@ -436,7 +443,7 @@ extern "C" int mhimx_pinv_init_bwd(void* stream, const float* dz, const float* z
   const int npart = 256;
   hipLaunchKernelGGL(dot_total_kernel, dim3(npart), dim3(AT), 0, (hipStream_t)stream, dz, z0, B * n * n, ws);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pinv_init_bwd_kernel, dim3((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream, dz, stats,
+  hipLaunchKernelGGL(pinv_init_bwd_kernel, dim3((unsigned)(n / 32), (unsigned)(n / 32), (unsigned)B), dim3(32, 8), 0, (hipStream_t)stream, dz, z0, stats,
                      ws, npart, (int)B, (int)n, da);
   MHIMX_LAUNCH_CHECK();
   return 0;

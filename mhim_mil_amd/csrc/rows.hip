@@ -244,10 +244,10 @@ __global__ void softmax_from_stats_kernel(const float* __restrict__ s, const flo
 __global__ void pseudo_score_kernel(const float* __restrict__ s, const float* __restrict__ stats,
                                     const float* __restrict__ cproj, const float* __restrict__ bp,
                                     float* __restrict__ score, float* __restrict__ attn_out, int64_t M, int C) {
-  const float mx = stats[0], invL = 1.f / stats[1];
+  const float mx = s ? stats[0] : 0.f, invL = s ? 1.f / stats[1] : 1.f;
   const float b0 = bp ? bp[0] : 0.f;
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < M; n += (int64_t)gridDim.x * blockDim.x) {
-    const float an = __expf(s[n] - mx) * invL;
+    const float an = s ? __expf(s[n] - mx) * invL : 1.f;      // s == NULL: the TransMIL form, cam = cproj + b0 (scoring.py:9-34)
     if (attn_out) attn_out[n] = an;
     float cm = -INFINITY;
     for (int c = 0; c < C; ++c) cm = fmaxf(cm, an * cproj[n * C + c] + b0);
@@ -641,7 +641,7 @@ extern "C" int mhimx_softmax_from_stats(void* stream, const float* s, const floa
 }
 extern "C" int mhimx_pseudo_score(void* stream, const float* s, const float* stats, const float* cproj, const float* bp,
                                   float* score, float* attn_out, int64_t M, int64_t C) {
-  MHIMX_CHECK_ARG(s && stats && cproj && score && C > 0, "pseudo_score: null args");
+  MHIMX_CHECK_ARG((!s || stats) && cproj && score && C > 0, "pseudo_score: null args");
   if (M <= 0) return 0;
   hipLaunchKernelGGL(pseudo_score_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0,
                      (hipStream_t)stream, s, stats, cproj, bp, score, attn_out, M, (int)C);

@@ -14,8 +14,9 @@ All math runs in libmhimx.so (hand-written gfx950 kernels behind the C-ABI); tor
 parameters, device memory, the stream and autograd's graph bookkeeping.  There is no eager/CPU
 fallback: inputs must be CUDA tensors and the library must be built.
 
-Only ``baseline='attn'`` (ABMIL) is wired in this round; 'selfattn' raises NotImplementedError
-(SURVEY.md §8 rows A9/A10 are the next kernels), 'dsmil' is scope row N1.
+``baseline='attn'`` (ABMIL) runs the fused hand-derived forward/backward; ``baseline='selfattn'`` (TransMIL /
+Nystrom, SURVEY.md §8 rows A9/A10) composes the encoder from kernel-backed autograd primitives (nystrom.py);
+'dsmil' is scope row N1 and raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -27,6 +28,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
+from . import nystrom as NY
 from . import ops
 
 _FEATURE_ACTS = ("relu", "gelu")
@@ -145,6 +147,55 @@ class _HeadFn(torch.autograd.Function):
         return g_z.view_as(z), None, d_wp, d_bp, None
 
 
+class _FeatureFn(torch.autograd.Function):
+    """Token rows of the student: H = dropout(act(X[rows] W^T + b))  (mhim.py:68-76,337; masking.py:107 gathers the rows)."""
+
+    @staticmethod
+    def forward(ctx, model, x, plan, w, b):
+        need_pre = L.act_code(model.act, _FEATURE_ACTS) == L.ACT["gelu"]
+        H = torch.empty((plan.L, model.mlp_dim), device=x.device)
+        PRE = torch.empty_like(H) if need_pre else None
+        p = model.dropout_p if plan.training else 0.0
+        model._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=plan.L)
+        ctx.model, ctx.plan, ctx.x, ctx.H, ctx.PRE = model, plan, x, H, PRE
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        model, plan = ctx.model, ctx.plan
+        dH = dH.contiguous().clone()
+        p = model.dropout_p if plan.training else 0.0
+        _, db = ops.act_bwd(dH, ctx.H, ctx.PRE, L.act_code(model.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
+                            want_colsum=True, drop_tick=model._tick)
+        dW = ops.gemm_tn(dH, ctx.x, rows=plan.rows, splits=8 if plan.L >= 2048 else 1,
+                         prec="f32" if model.prec == "f32" else "bf16x3", M=plan.L)
+        return None, None, None, dW, db
+
+
+class _MergeFn(torch.autograd.Function):
+    """Merge.merge (merge.py:131-144): rows to merge -> k merged tokens, EMA of the global queries in the forward."""
+
+    NAMES = ("merge.norm.weight", "merge.norm.bias", "merge.attn.to_kv.weight", "merge.attn.to_q.weight",
+             "merge.attn.to_out.0.weight", "merge.attn.to_out.0.bias")
+
+    @staticmethod
+    def forward(ctx, model, plan, X, *params):
+        X = X.contiguous()
+        z_tok, q_new, mws = ops.merge_fwd(model._merge_w(plan), X, update_q=plan.training)
+        ctx.model, ctx.plan, ctx.X, ctx.mws = model, plan, X, mws
+        ctx.q_old = model.merge.global_q_mm.data.clone()
+        if plan.training:
+            model.merge.global_q_mm.data.copy_(q_new.view_as(model.merge.global_q_mm))
+        return z_tok
+
+    @staticmethod
+    def backward(ctx, dz):
+        model = ctx.model
+        mw = model._merge_w(ctx.plan, need_t=True, q=ctx.q_old)
+        mg = ops.merge_bwd(mw, ctx.X, dz.contiguous(), ctx.mws, grads={})
+        return (None, None, mg["dX"], mg["d_ln_w"], mg["d_ln_b"], mg["d_wkv"], mg["d_wq"], mg["d_wo"], mg["d_bo"])
+
+
 class BagPlan:
     """Row bookkeeping of one student forward (all device tensors; no host sync)."""
 
@@ -177,13 +228,12 @@ class MHIM(nn.Module):
         self.dropout_p = float(dropout)
         self.prec = prec
         self.merge_enable = bool(merge_enable)
-        if baseline != "attn":
-            raise NotImplementedError(
-                f"baseline={baseline!r}: only the ABMIL encoder ('attn') has HIP kernels in this round "
-                "(Nystrom 'selfattn' = SURVEY.md §8 A9/A10, next; 'dsmil' = scope row N1)")
+        if baseline not in ("attn", "selfattn"):
+            raise NotImplementedError(f"baseline={baseline!r}: 'attn' (ABMIL) and 'selfattn' (TransMIL/Nystrom) have HIP "
+                                      "kernels; 'dsmil' is scope row N1 (SURVEY.md §8(f))")
         self.merge = _Merge(mlp_dim, merge_k, merge_mm, merge_ratio) if merge_enable else nn.Identity()
         self.feature = nn.Sequential(_Lin(input_dim, mlp_dim), _Slot())
-        self.online_encoder = _DAttention(mlp_dim, gated=gated)
+        self.online_encoder = _DAttention(mlp_dim, gated=gated) if baseline == "attn" else NY.SAttention(mlp_dim, head)
         self.predictor = _Lin(mlp_dim, n_classes)
         self._step = 0
         self._tick = None          # optional device step counter (uint64 [1]) mixed into every dropout seed: set by
@@ -345,9 +395,15 @@ class MHIM(nn.Module):
         randperm draws of masking.py:67 (parity tests); otherwise they are drawn on the device."""
         if attn is None:
             return ps, None
+        heads = None
         if attn.dim() == 3 or (attn.dim() == 2 and attn.shape[0] != 1):
-            raise NotImplementedError("per-head (3-D) attention comes from the selfattn baseline (next round)")
-        score = attn.reshape(-1).contiguous().float()
+            # per-head attention of the TransMIL teacher ([1,h,N] or [h,N]): msa_fusion='vote' (masking.py:49-59) — every
+            # select call first turns the h rows into per-instance vote counts, then takes the top-k of the votes
+            heads = attn.reshape(-1, attn.shape[-1]).contiguous().float()
+            score = None
+        else:
+            score = attn.reshape(-1).contiguous().float()
+        dev = attn.device
         perms = list(perms) if perms is not None else [None, None, perm]
         masked, n_masked, len_keep, mask_ids = None, 0, ps, None
 
@@ -359,10 +415,13 @@ class MHIM(nn.Module):
             k = int(np.ceil(ps * eff))
             n_sel = int(np.ceil(k * rratio)) if rratio < 1.0 else k
             if rratio < 1.0 and pm is None:
-                pm = torch.randperm(k, device=score.device)
+                pm = torch.randperm(k, device=dev)
             elif pm is not None and not torch.is_tensor(pm):
-                pm = torch.as_tensor(np.asarray(pm), dtype=torch.int64, device=score.device)
-            ids, lk_dev, _ = ops.select_mask(score, k, n_sel, largest, pm if rratio < 1.0 else None, other=masked)
+                pm = torch.as_tensor(np.asarray(pm), dtype=torch.int64, device=dev)
+            sc, lg = score, largest
+            if heads is not None:
+                sc, lg = ops.vote_scores(heads, k, largest), True
+            ids, lk_dev, _ = ops.select_mask(sc, k, n_sel, lg, pm if rratio < 1.0 else None, other=masked)
             if masked is None:
                 len_keep = ps - n_sel
             else:
@@ -387,8 +446,9 @@ class MHIM(nn.Module):
         """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
 
         Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R).
-        Production (no injected draws, v2 recipe, N <= 16384): ONE kernel draws both random subsets on the device
-        (mhimx_select_rows).  With injected ``perm`` / ``ids_shuffle`` (parity tests) or v1 masks the reference's
+        Production (no injected draws, v2 recipe, N <= 16384, ABMIL whose pool is order-free): ONE kernel draws both
+        random subsets on the device (mhimx_select_rows).  The TransMIL encoder sees the token ORDER (landmark means,
+        PPEG grid), so it always takes the literal two-stage form with a device-drawn shuffle.  With injected ``perm`` / ``ids_shuffle`` (parity tests) or v1 masks the reference's
         two-stage form is followed literally: select_mask -> mask_ids, then ids_keep[ids_shuffle].
         """
         mask_ratio_h = self.mask_ratio_h
@@ -397,7 +457,8 @@ class MHIM(nn.Module):
         if mrh is not None:
             mask_ratio_h = mrh
         v2 = self.mask_ratio == 0 and self.mask_ratio_l == 0 and mask_ratio_h > 0
-        if (v2 and perm is None and ids_shuffle is None and attn is not None and attn.numel() == ps and ps <= 16384):
+        if (v2 and self.baseline == "attn" and perm is None and ids_shuffle is None and attn is not None and attn.numel() == ps
+                and ps <= 16384):
             eff, rr = mask_ratio_h / self.mask_ratio_hr, self.mask_ratio_hr
             if eff > 1:
                 rr, eff = mask_ratio_h, 1.0
@@ -438,6 +499,14 @@ class MHIM(nn.Module):
         if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)
             mw = self._merge_w(None)
             T2, _, _ = ops.merge_fwd(mw, H, update_q=False)
+        if self.baseline == "selfattn":
+            tok = H if T2 is None else torch.cat([H, T2], 0)
+            z, attn, v = self._encode(tok, return_attn=True)
+            if self.attn2score:
+                score = self._trans_score(v[:p0], attn[0][:, :p0]).view(1, -1)
+            else:
+                score = attn[self.attn_layer][:, :p0].contiguous().unsqueeze(0)          # [1,h,N] (mhim.py:224-225)
+            return z.view(1, -1), score
         wp = self.predictor.weight.data if self.attn2score else None
         st = ops.abmil_pool_fwd(self._scorer(), H, T2, wp=wp)
         if self.attn2score:
@@ -454,6 +523,17 @@ class MHIM(nn.Module):
         T2 = None
         if self.merge_test:
             T2, _, _ = ops.merge_fwd(self._merge_w(None), H, update_q=False)
+        if self.baseline == "selfattn":
+            tok = H if T2 is None else torch.cat([H, T2], 0)
+            pw, pb = self.predictor.weight.data, self.predictor.bias.data
+            if not return_attn:
+                return ops.gemm_nt(self._encode(tok).view(1, -1), pw, bias=pb, prec="f32")
+            z, attn, v = self._encode(tok, return_attn=True, no_norm=no_norm)
+            logits = ops.gemm_nt(z.view(1, -1), pw, bias=pb, prec="f32")
+            attn = [a.contiguous().unsqueeze(0) for a in attn]
+            if return_act:
+                return logits, [attn, v.reshape(v.shape[0], NY.HEADS, NY.DH).permute(1, 0, 2).unsqueeze(0)]
+            return logits, attn
         st = ops.abmil_pool_fwd(self._scorer(), H, T2)
         logits = ops.gemm_nt(st.z.view(1, -1), self.predictor.weight.data, bias=self.predictor.bias.data, prec="f32")
         if not return_attn:
@@ -464,6 +544,33 @@ class MHIM(nn.Module):
             act = H if T2 is None else torch.cat([H, T2], 0)
             return logits, [a, act]
         return logits, a
+
+    # ------------------------------------------------------------------ TransMIL (selfattn) pieces
+    def _encode(self, tok, return_attn=False, no_norm=False):
+        """SAttention over the token rows [n, E]; train-mode to_out dropouts use the counter-based stream."""
+        return self.online_encoder(tok, return_attn, no_norm, seeds=(self._next_seed(), self._next_seed()), tick=self._tick,
+                                   training=self.training)
+
+    def _trans_score(self, v, attn0):
+        """get_pseudo_score_trans (scoring.py:9-34): v [n, (h d)] (a strided view into the packed qkv rows), attn0 [h, n]
+        -> score [n] = max_c softmax_c(Wp to_out(v * attn) + bp[0])."""
+        n = v.shape[0]
+        f = torch.empty((n, NY.INNER), device=v.device)
+        L.check(L.lib().mhimx_scale_heads(ops._stream(), ops._p(v), v.stride(0), ops._p(attn0), attn0.stride(0), NY.DH, n, NY.INNER,
+                                          ops._p(f)), "mhimx_scale_heads")
+        to_out = self.online_encoder.layer1.attn.to_out[0]
+        p = self.online_encoder.layer1.attn.dropout if self.training else 0.0
+        f = ops.gemm_nt(f, to_out.weight.data, bias=to_out.bias.data, drop_p=p, drop_seed=self._next_seed(), drop_tick=self._tick,
+                        prec="bf16x3")
+        cam = ops.gemm_nt(f, self.predictor.weight.data, prec="bf16x3")
+        return ops.pseudo_score(None, None, cam, self.predictor.bias.data)
+
+    def _selfattn_student(self, x, plan):
+        H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
+        if self.merge_enable and plan.R > 0:
+            z_tok = _MergeFn.apply(self, plan, H[plan.Lk:], *[self._param(n) for n in _MergeFn.NAMES])
+            H = torch.cat([H[:plan.Lk], z_tok], 0)                  # merge.py:190-194: kept tokens ++ k merged tokens
+        return self._encode(H)
 
     def _plan_all_rows(self, n):
         return BagPlan(rows=None, L=n, Lk=n, R=0, drop_seed=self._next_seed(), mca_seed=0, training=self.training)
@@ -477,6 +584,11 @@ class MHIM(nn.Module):
         ps = x.shape[0]
         if not self.training:
             return self.forward_test(x)
+        if self.baseline == "selfattn":
+            plan = self._plan_all_rows(ps)
+            H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
+            logits, _ = self._head(self._encode(H).view(1, -1), None)
+            return logits, 0, ps, ps
         merge_enable, self.merge_enable = self.merge_enable, False     # pure(): no masking, no merging (mhim.py:274-298)
         try:
             plan = self._plan_all_rows(ps)
@@ -502,7 +614,10 @@ class MHIM(nn.Module):
         rows, len_keep, Lk, R = self.student_rows(ps, i, attn, perm=perm, ids_shuffle=ids_shuffle)
         plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=self._next_seed(), drop_mask=drop_mask,
                        mca_seed=self._next_seed(), training=self.training)
-        z = _BagFn.apply(self, x, plan, *[self._param(n) for n in self._bag_param_names])
+        if self.baseline == "selfattn":
+            z = self._selfattn_student(x, plan).view(1, -1)
+        else:
+            z = _BagFn.apply(self, x, plan, *[self._param(n) for n in self._bag_param_names])
         logits, cls_loss = self._head(z, teacher_cls_feat)
         if teacher_cls_feat is None:
             cls_loss = 0.

@@ -391,7 +391,7 @@ class NystromAttention(nn.Module):
         self.scale = DH ** -0.5
 
     def forward(self, x, return_attn=False, no_norm=False, seed=0, tick=None, training=False):
-        """x [n, dim] -> out [n, dim] (+ cls-row attention [8, n-1] and v [8, n-1, 64] views when return_attn)."""
+        """x [n, dim] -> out [n, dim] (+ views: cls-row attention [8, n-1] and v [n-1, (8 64)] when return_attn)."""
         n, dim = x.shape
         m = LANDMARKS
         pad = (m - n % m) % m
@@ -426,7 +426,7 @@ class NystromAttention(nn.Module):
             u = heads_mm(b1[:, pad:pad + 1].contiguous(), b2, "nn", bat(1, m), bat(m, m), (HEADS, 1, m), bat(1, m))
             r = heads_mm(u, b3, "nn", bat(1, m), bat(m, T), (HEADS, 1, T), bat(1, T))
             attn = r[:, 0, pad + 1:]
-            v = qkv[pad + 1:, 2 * INNER:].reshape(n - 1, HEADS, DH).permute(1, 0, 2)
+            v = qkv[pad + 1:, 2 * INNER:]                                     # [n-1, (h d)] strided view of the packed rows
         return y, attn, v
 
 
@@ -492,7 +492,7 @@ class SAttention(nn.Module):
         self.pos_embedding = _PPEG(mlp_dim)
 
     def forward(self, h, return_attn=False, no_norm=False, seeds=(0, 0), tick=None, training=False):
-        """h [N, 512] tokens -> cls feature [512] (+ [attn_l1, attn_l2] each [8, N], v of layer 1 [8, N, 64])."""
+        """h [N, 512] tokens -> cls feature [512] (+ [attn_l1, attn_l2] each [8, N], v of layer 1 [N, (8 64)])."""
         x = torch.cat([self.cls_token.view(1, -1), h], 0)
         attn = []
         if return_attn:

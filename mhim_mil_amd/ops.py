@@ -190,9 +190,10 @@ def softmax_from_stats(s, stats):
 
 
 def pseudo_score(s, stats, cproj, bp, want_attn=False):
-    score = torch.empty_like(s)
+    M = cproj.shape[0] if s is None else s.numel()
+    score = torch.empty(M, device=cproj.device)
     attn = torch.empty_like(s) if want_attn else None
-    L.check(L.lib().mhimx_pseudo_score(_stream(), _p(s), _p(stats), _p(cproj), _p(bp), _p(score), _p(attn), s.numel(),
+    L.check(L.lib().mhimx_pseudo_score(_stream(), _p(s), _p(stats), _p(cproj), _p(bp), _p(score), _p(attn), M,
                                        cproj.shape[1]), "mhimx_pseudo_score")
     return (score, attn) if want_attn else score
 

@@ -1,0 +1,311 @@
+"""Parity of the TransMIL / Nystrom path (BASELINE config c3) — GPU box only.
+
+Three layers: (1) every streaming primitive and the nn-GEMM against a plain torch fp32 statement of the same op,
+forward and backward; (2) the encoder against the fixtures generated from the reference import (g7/g8/g9);
+(3) the student's gradients element-wise against the CPU oracle's autograd.
+Tolerances: logits 1e-4 abs (north_star); attention rows 1e-3 rel; gradients 2e-3 of the tensor's scale.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mhim_mil_amd import synth
+from oracle import mhim_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+V2 = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True,
+          merge_k=5, merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.0)
+
+
+def NY():
+    from mhim_mil_amd import nystrom
+    return nystrom
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def close(got, ref, rtol=2e-3, what=""):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("shape", [(300, 256, 64), (1, 256, 256), (256, 64, 1280), (130, 72, 36)])
+def test_heads_matmul_modes(mode, shape):
+    ny = NY()
+    M, N, K = shape
+    a = rnd(3, *((M, K) if mode != "tn" else (K, M)), seed=1).requires_grad_()
+    b = rnd(3, *((N, K) if mode == "nt" else (K, N)), seed=2).requires_grad_()
+    ref = {"nt": lambda: a @ b.transpose(1, 2), "nn": lambda: a @ b, "tn": lambda: a.transpose(1, 2) @ b}[mode]()
+    bat = lambda t: (0, t.shape[1] * t.shape[2], t.shape[2], t.shape[1], t.shape[2])
+    got = ny.heads_mm(a, b, mode, bat(a), bat(b), (3, M, N), (0, M * N, N, M, N), 3)
+    close(got, ref, 1e-4, "fwd")
+    w = rnd(3, M, N, seed=3)
+    ga, gb = torch.autograd.grad((got * w).sum(), (a, b))
+    ra, rb = torch.autograd.grad((ref * w).sum(), (a, b))
+    close(ga, ra, 1e-4, "dA")
+    close(gb, rb, 1e-4, "dB")
+
+
+def test_heads_matmul_packed_operands():
+    """Heads addressed in place inside a packed [T, 3*512] buffer (64-column groups), output into [T, (h d)]."""
+    ny = NY()
+    T, m = 512, 256
+    qkv = rnd(T, 1536, seed=4).requires_grad_()
+    a1 = rnd(8, T, m, seed=5).requires_grad_()
+    w2 = rnd(8, m, 64, seed=6).requires_grad_()
+    out = ny.heads_mm(a1, w2, "nn", (0, T * m, m, T, m), (0, m * 64, 64, m, 64), (T, 512), (0, 64, 512, T, 64))
+    ref = torch.einsum("htm,hmd->thd", a1, w2).reshape(T, 512)
+    close(out, ref, 1e-4)
+    s1 = ny.heads_mm(qkv, qkv, "nt", (0, 64, 1536, T, 64), (512, 64, 1536, T, 64), (8, T, T), (0, T * T, T, T, T))
+    q = qkv[:, :512].reshape(T, 8, 64).permute(1, 0, 2)
+    k = qkv[:, 512:1024].reshape(T, 8, 64).permute(1, 0, 2)
+    close(s1, q @ k.transpose(1, 2), 1e-4)
+    w = rnd(8, T, T, seed=7)
+    g, = torch.autograd.grad((s1 * w).sum(), qkv)
+    r, = torch.autograd.grad(((q @ k.transpose(1, 2)) * w).sum(), qkv)
+    close(g, r, 1e-4, "d qkv")
+
+
+@pytest.mark.parametrize("R,Lr,alpha", [(50, 256, 0.125), (7, 1280, 1.0), (2048, 256, 0.125), (3, 50176, 0.125)])
+def test_softmax_rows(R, Lr, alpha):
+    ny = NY()
+    x = rnd(R, Lr, seed=8, scale=3.0).requires_grad_()
+    y = ny.Softmax.apply(x, alpha)
+    ref = torch.softmax(x * alpha, -1)
+    close(y, ref, 1e-5)
+    w = rnd(R, Lr, seed=9)
+    g, = torch.autograd.grad((y * w).sum(), x)
+    r, = torch.autograd.grad((ref * w).sum(), x)
+    close(g, r, 1e-4)
+
+
+@pytest.mark.parametrize("T,l", [(512, 2), (1280, 5), (256, 1)])
+def test_landmarks(T, l):
+    ny = NY()
+    x = rnd(T, 1536, seed=10).requires_grad_()
+    y = ny.Landmarks.apply(x, l)
+    ref = x[:, :1024].reshape(T // l, l, 1024).mean(1)
+    close(y, ref, 1e-5)
+    w = rnd(T // l, 1024, seed=11)
+    g, = torch.autograd.grad((y * w).sum(), x)
+    r, = torch.autograd.grad((ref * w).sum(), x)
+    close(g, r, 1e-5)
+
+
+def test_pinv_matches_oracle_and_autograd():
+    ny = NY()
+    # softmax rows all sum to 1: the arg-max ROW of the init scaling is rounding noise, but a constant added to a whole
+    # row of d a vanishes in the softmax backward — so the gradient is compared where it is well defined, at the logits
+    x0 = rnd(8, 256, 256, seed=12, scale=2.0)
+    x = x0.clone().requires_grad_()
+    z = ny._pinv(ny.Softmax.apply(x, 1.0))
+    xc = x0.cpu().clone().requires_grad_()
+    zr = O.pinv_iter(torch.softmax(xc, -1))
+    close(z, zr, 2e-4, "pinv")
+    w = rnd(8, 256, 256, seed=13)
+    g, = torch.autograd.grad((z * w).sum(), x)
+    r, = torch.autograd.grad((zr * w.cpu()).sum(), xc)
+    close(g, r, 2e-3, "d pinv")
+
+
+def test_pinv_init_bwd_through_maxima():
+    ny = NY()
+    a0 = rnd(8, 256, 256, seed=14)          # signed entries, distinct row / column abs-sums (no arg-max ties)
+    a = a0.clone().requires_grad_()
+    z = ny.PinvInit.apply(a)
+    ac = a0.cpu().double().requires_grad_()
+    ab = ac.abs()
+    zr = ac.transpose(1, 2) / (ab.sum(-1).max() * ab.sum(-2).max())
+    close(z, zr, 1e-5)
+    w = rnd(8, 256, 256, seed=15)
+    g, = torch.autograd.grad((z * w).sum(), a)
+    r, = torch.autograd.grad((zr * w.cpu().double()).sum(), ac)
+    close(g, r, 1e-4)
+
+
+@pytest.mark.parametrize("T", [256, 1280])
+def test_resconv(T):
+    ny = NY()
+    qkv = rnd(T, 1536, seed=16).requires_grad_()
+    w = rnd(8, 1, 33, 1, seed=17, scale=0.2).requires_grad_()
+    y = ny.ResConv.apply(qkv, w)
+    v = qkv[:, 1024:].reshape(T, 8, 64).permute(1, 0, 2).unsqueeze(0)          # [1,h,T,d]
+    ref = F.conv2d(v, w, padding=(16, 0), groups=8)[0].permute(1, 0, 2).reshape(T, 512)
+    close(y, ref, 1e-5)
+    ww = rnd(T, 512, seed=18)
+    g = torch.autograd.grad((y * ww).sum(), (qkv, w))
+    r = torch.autograd.grad((ref * ww).sum(), (qkv, w))
+    close(g[0], r[0], 1e-5, "d v")
+    close(g[1], r[1], 1e-4, "d w")
+
+
+@pytest.mark.parametrize("N", [47, 600, 1500])
+def test_ppeg(N):
+    ny = NY()
+    sd = synth.mhim_state(5, input_dim=64, baseline="selfattn", merge_enable=False)
+    pre = "online_encoder.pos_embedding."
+    names = ["proj.weight", "proj1.weight", "proj2.weight", "proj.bias", "proj1.bias", "proj2.bias"]
+    x0 = rnd(N, 512, seed=19)
+    x = x0.clone().requires_grad_()
+    ps = [torch.as_tensor(sd[pre + n]).to(DEV).requires_grad_() for n in names]
+    y = ny.PPEG.apply(x, *ps)
+    pc = {pre + n: torch.as_tensor(sd[pre + n]).clone().requires_grad_() for n in names}
+    xc = x0.cpu().clone().requires_grad_()
+    ref = O.ppeg(xc, pc, pre)
+    close(y, ref, 1e-5)
+    w = rnd(N, 512, seed=20)
+    g = torch.autograd.grad((y * w).sum(), [x] + ps)
+    r = torch.autograd.grad((ref * w.cpu()).sum(), [xc] + [pc[pre + n] for n in names])
+    for gi, ri, nm in zip(g, r, ["x"] + names):
+        close(gi, ri, 1e-4, nm)
+
+
+def test_layernorm_and_linear_fn():
+    ny = NY()
+    x = rnd(300, 512, seed=21).requires_grad_()
+    w, b = rnd(512, seed=22).requires_grad_(), rnd(512, seed=23).requires_grad_()
+    y = ny.LayerNorm.apply(x, w, b)
+    ref = F.layer_norm(x, (512,), w, b)
+    close(y, ref, 1e-5)
+    ww = rnd(300, 512, seed=24)
+    for gi, ri in zip(torch.autograd.grad((y * ww).sum(), (x, w, b)), torch.autograd.grad((ref * ww).sum(), (x, w, b))):
+        close(gi, ri, 1e-4)
+    W, bb = rnd(384, 512, seed=25, scale=0.05).requires_grad_(), rnd(384, seed=26).requires_grad_()
+    y = ny.Linear.apply(x, W, bb, 0.0, 0, None)
+    ref = F.linear(x, W, bb)
+    close(y, ref, 1e-4)
+    ww = rnd(300, 384, seed=27)
+    for gi, ri in zip(torch.autograd.grad((y * ww).sum(), (x, W, bb)), torch.autograd.grad((ref * ww).sum(), (x, W, bb))):
+        close(gi, ri, 1e-4)
+    # dropout: the backward re-applies exactly the forward's mask
+    y = ny.Linear.apply(x, W, bb, 0.3, 99, None)
+    keep = (y != 0).float()
+    assert 0.6 < keep.mean().item() < 0.8
+    g, = torch.autograd.grad((y * ww).sum(), x)
+    r, = torch.autograd.grad((F.linear(x, W, bb) * keep / 0.7 * ww).sum(), x)
+    close(g, r, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ golden fixtures
+def build(sd, prec="auto", **kw):
+    from mhim_mil_amd.mhim import MHIM
+    m = MHIM(baseline="selfattn", n_classes=2, prec=prec, **kw)
+    sd = dict(sd)
+    if "merge.global_q_mm" in sd:
+        sd["merge.global_q"] = sd["merge.global_q_mm"]
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV)
+    if kw.get("merge_enable", True):
+        m.merge.dropout = 0.0
+    m.online_encoder.layer1.attn.dropout = 0.0           # parity runs: the fixtures were made with the aux dropouts zeroed
+    m.online_encoder.layer2.attn.dropout = 0.0
+    return m
+
+
+def X(seed, n, d):
+    return torch.from_numpy(synth.bag(seed, n, d)).to(DEV).unsqueeze(0)
+
+
+@pytest.mark.parametrize("name", G.names("g7_nystrom"))
+def test_g7_nystrom(name):
+    meta, a = G.load(name)
+    m = build(synth.mhim_state(meta["seed"], input_dim=64, baseline="selfattn", merge_enable=False), input_dim=64, merge_enable=False).eval()
+    att = m.online_encoder.layer1.attn
+    x = torch.from_numpy((synth.normal(meta["xseed"], (meta["n"], meta["dim"])) * 0.5).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        out, attn, v = att(x, return_attn=True)
+        _, attn_raw, _ = att(x, return_attn=True, no_norm=True)
+    out = out.cpu().numpy()
+    np.testing.assert_allclose(out[:8], a["out_head"], atol=2e-5, rtol=2e-4)
+    np.testing.assert_allclose(out[-8:], a["out_tail"], atol=2e-5, rtol=2e-4)
+    np.testing.assert_allclose(out.sum(0), a["out_sum"], atol=2e-3, rtol=2e-4)
+    np.testing.assert_allclose(attn.cpu().numpy(), a["attn"], atol=1e-6, rtol=2e-3)
+    np.testing.assert_allclose(attn_raw.cpu().numpy(), a["attn_raw"], atol=2e-3, rtol=5e-3)
+    vt = v.reshape(v.shape[0], 8, 64).permute(1, 0, 2)[:, -4:].cpu().numpy()
+    np.testing.assert_allclose(vt, a["v_tail"], atol=2e-5, rtol=1e-4)     # bf16x3 GEMM: ~2^-16 of the row scale
+
+
+@pytest.mark.parametrize("name", G.names("g8_sattention"))
+def test_g8_sattention(name):
+    meta, a = G.load(name)
+    m = build(synth.mhim_state(meta["seed"], input_dim=meta["d"], baseline="selfattn", merge_enable=False),
+              input_dim=meta["d"], act=meta["act"], merge_enable=False).eval()
+    x = X(meta["xseed"], meta["n"], meta["d"])
+    logits, attn = m.forward_test(x, return_attn=True)
+    assert logits.shape == (1, 2) and attn[0].shape == (1, 8, meta["n"])
+    np.testing.assert_allclose(logits[0].cpu().numpy(), a["logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(attn[0][0].cpu().numpy(), a["attn1"], atol=1e-6, rtol=2e-3)
+    np.testing.assert_allclose(attn[1][0].cpu().numpy(), a["attn2"], atol=1e-6, rtol=2e-3)
+    np.testing.assert_allclose(m.forward_test(x)[0].cpu().numpy(), a["logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(m.pure(x)[0].cpu().numpy(), a["logits"], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", G.names("g9_transmil_teacher"))
+def test_g9_transmil_teacher(name):
+    meta, a = G.load(name)
+    base = synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_k=meta["merge_k"], baseline="selfattn")
+    m = build(synth.spread_teacher(base), input_dim=meta["d"], **{**V2, "attn2score": meta["attn2score"]}).train()
+    feat, score = m.forward_teacher(X(meta["xseed"], meta["n"], meta["d"]))
+    np.testing.assert_allclose(feat[0].cpu().numpy(), a["feat"], atol=1e-4, rtol=1e-4)
+    s = score[0].cpu().numpy()
+    np.testing.assert_allclose(s, a["score"], atol=5e-6, rtol=2e-3)
+
+
+def test_g9_transmil_student_golden_and_oracle_grads():
+    meta, a = G.load("g9_transmil_student")
+    sd = synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_k=meta["merge_k"], baseline="selfattn")
+    cfgd = {k: meta[k] for k in V2 if k in meta}
+    m = build(sd, input_dim=meta["d"], **cfgd).train()
+    x = X(meta["xseed"], meta["n"], meta["d"])
+    score = torch.from_numpy(a["teacher_score"]).to(DEV)
+    tfeat = torch.from_numpy(a["teacher_feat"]).to(DEV).view(1, -1)
+    logits, cl, ps, keep = m(x, score, tfeat, perm=a["perm"], ids_shuffle=a["ids_shuffle"])
+    assert keep == int(a["keep"]) and ps == meta["n"]
+    np.testing.assert_allclose(logits[0].detach().cpu().numpy(), a["logits"], atol=1e-4, rtol=0)
+    assert abs(cl.item() - float(a["cls_loss"])) < 1e-4
+    loss = F.cross_entropy(logits.view(1, -1), torch.tensor([meta["label"]], device=DEV)) + meta["aux_alpha"] * cl
+    loss.backward()
+    pd = dict(m.named_parameters())
+    keys = json.loads(str(a["grad_keys"]))
+    for k, n in zip(keys, a["grad_norms"]):
+        got = float(pd[k].grad.norm())
+        assert abs(got - n) <= 5e-3 * n + 1e-7, (k, got, n)
+    # element-wise against the oracle's autograd on the same inputs
+    p = O.as_torch(sd)
+    for k, v in p.items():
+        v.requires_grad_(k not in O.TRAINABLE_EXCLUDE)
+    cfg = O.Cfg(**{**cfgd, "baseline": "selfattn"})
+    lo, clo, _, _, _ = O.forward_student(x[0].cpu(), p, cfg, a["teacher_score"], torch.from_numpy(a["teacher_feat"]),
+                                         perm=a["perm"], ids_shuffle=a["ids_shuffle"])
+    (O.cross_entropy(lo, meta["label"]) + meta["aux_alpha"] * clo).backward()
+    for k in keys:
+        close(pd[k].grad, p[k].grad.view_as(pd[k].grad), 5e-3, k)
+
+
+def test_teacher_vote_mask_matches_oracle():
+    """attn2score=False: per-head attention [1,h,N] -> vote fusion (masking.py:49-59) -> same index set as the oracle."""
+    sd = synth.mhim_state(11, input_dim=64, merge_k=3, baseline="selfattn")
+    kw = {**V2, "attn2score": False, "merge_k": 3}
+    m = build(synth.spread_teacher(sd), input_dim=64, **kw).train()
+    x = X(77, 700, 64)
+    _, attn = m.forward_teacher(x)
+    assert attn.shape == (1, 8, 700)
+    k = int(np.ceil(700 * 0.03 / 0.5))
+    perm = synth.permutation(5, k)
+    lk, ids = m.get_mask(700, 0, attn, perm=perm)
+    lko, idso = O.get_mask(700, attn[0].cpu().numpy(), mask_ratio_h=0.03, mask_ratio_hr=0.5, perms=(None, None, perm))
+    assert lk == lko
+    np.testing.assert_array_equal(ids[0].cpu().numpy(), idso)
