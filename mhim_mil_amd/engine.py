@@ -175,6 +175,8 @@ class FusedTrainer:
             plan = s._plan_all_rows(ps)
             plan.training = True
             keep_num = ps
+        if s.baseline == "selfattn":
+            return self._selfattn_forward_backward(x, label, plan, teacher_feat, keep_num, first)
         merge_on = s.merge_enable
         if self.model_kind != "mhim":
             s.merge_enable = False
@@ -195,6 +197,33 @@ class FusedTrainer:
             s.merge_enable = merge_on
         self._micro += 1
         self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num}
+        return logits, losses
+
+    def _selfattn_forward_backward(self, x, label, plan, teacher_feat, keep_num, first):
+        """TransMIL student: the encoder is a graph of kernel-backed autograd primitives (nystrom.py); every parameter's
+        .grad IS its view of the flat gradient buffer, so autograd accumulates straight into the buffer the single
+        all-reduce and the fused Adam read."""
+        s, fl = self.s, self.flat
+        gv = fl.grad_views
+        if not getattr(self, "_grads_bound", False):
+            pd = dict(s.named_parameters())
+            for n in fl.train_names:
+                pd[n].grad = gv[n]
+            self._grads_bound = True
+        if self.model_kind == "mhim":
+            z = s._selfattn_student(x, plan)
+        else:
+            from .mhim import _FeatureFn
+            z = s._encode(_FeatureFn.apply(s, x, plan, s.feature[0].weight, s.feature[0].bias))
+        t_in = teacher_feat.view(-1) if (teacher_feat is not None and self.aux_alpha != 0.) else None
+        # predictor + CE + distillation and their gradients in one kernel; accumulate: the buffer is zero after each update
+        logits, losses, g_z, _, _ = ops.head_fwd_bwd(
+            z.detach(), t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),
+            main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
+            d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=True)
+        z.backward(g_z)
+        self._micro += 1
+        self.last = {"logits": logits, "losses": losses, "patch_num": x.shape[0], "keep_num": keep_num}
         return logits, losses
 
     def update(self):

@@ -309,3 +309,75 @@ def test_teacher_vote_mask_matches_oracle():
     lko, idso = O.get_mask(700, attn[0].cpu().numpy(), mask_ratio_h=0.03, mask_ratio_hr=0.5, perms=(None, None, perm))
     assert lk == lko
     np.testing.assert_array_equal(ids[0].cpu().numpy(), idso)
+
+
+# ------------------------------------------------------------------------------------------------ trainer + full size
+def test_fused_trainer_selfattn_two_steps_vs_oracle():
+    """FusedTrainer on the TransMIL student (autograd into the flat gradient buffer, head kernel, fused Adam + EMA)
+    against the oracle's train_step; Adam's first steps move weights by ~lr, so parameters are compared on that scale."""
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d, lr = 900, 64, 2e-4
+    base = synth.mhim_state(21, input_dim=d, merge_k=5, baseline="selfattn")
+    cfg = O.Cfg(**{**V2, "baseline": "selfattn"})
+    s = build(base, input_dim=d, **V2).train()
+    t = build(synth.spread_teacher(base), input_dim=d, **V2).train()
+    tr = FusedTrainer(s, t, lr=lr, aux_alpha=0.5, mm=0.999)
+    stu, tea, opt = O.as_torch(base), O.as_torch(synth.spread_teacher(base)), {}
+    k, n_sel, _ = O.mask_count(n, V2["mask_ratio_h"], V2["mask_ratio_hr"])
+    for step in range(2):
+        xn = synth.bag(500 + step, n, d)
+        perm, shuf = synth.permutation(30 + step, k), synth.permutation(40 + step, n - n_sel)
+        stu, tea, opt, info = O.train_step(torch.from_numpy(xn), step % 2, stu, tea, opt, cfg, step + 1, perm=perm, ids_shuffle=shuf,
+                                           aux_alpha=0.5, mm=0.999, lr=lr)
+        logits, losses = tr.forward_backward(torch.from_numpy(xn).to(DEV), torch.tensor([step % 2], device=DEV),
+                                             perm=torch.from_numpy(perm).to(DEV), ids_shuffle=torch.from_numpy(shuf).to(DEV))
+        assert abs(float(losses[0]) - info["loss"]) < 3e-4, (step, float(losses[0]), info["loss"])
+        np.testing.assert_allclose(logits.cpu().numpy(), info["logits"].numpy(), atol=1e-4, rtol=0)
+        for key, g in info["grads"].items():                 # the flat gradient buffer before the update
+            close(tr.flat.grad_views[key], g.view_as(tr.flat.grad_views[key]), 5e-3, f"step {step} grad {key}")
+        tr.update()
+    # Adam normalises every element to a ~lr move, so elements whose gradient is rounding noise (|g| ~ 1e-8 of the tensor's
+    # scale) may legitimately move the other way: bound the mean error tightly and the count of such outliers
+    for tag, mdl, ref in (("stu", s, stu), ("tea", t, tea)):
+        sd = mdl.state_dict()
+        for key, exp in ref.items():
+            err = (sd[key].detach().cpu().double() - exp.double().view_as(sd[key])).abs()
+            tol = 0.1 * 2 * lr if tag == "stu" else 1e-6          # EMA teacher: (1 - mm) of the student's moves + fp32 ulps
+            assert err.mean().item() <= 0.1 * tol + 1e-7, (tag, key, err.mean().item())
+            assert (err > tol + 1e-7).double().mean().item() < 2e-3, (tag, key, err.max().item())
+
+
+def test_c3_size_teacher_and_student_forward_vs_oracle():
+    """BASELINE config c3: MHIM(TransMIL) on one N=50 000, D=1024 bag — teacher score / feature and student logits
+    against the CPU oracle (forward only: the oracle's autograd at this size needs minutes)."""
+    n, d = 50000, 1024
+    base = synth.mhim_state(7, input_dim=d, merge_k=5, baseline="selfattn")
+    tsd = synth.spread_teacher(base)
+    cfg = O.Cfg(**{**V2, "baseline": "selfattn"})
+    xn = synth.bag(9, n, d)
+    k, n_sel, _ = O.mask_count(n, V2["mask_ratio_h"], V2["mask_ratio_hr"])
+    perm, shuf = synth.permutation(3, k), synth.permutation(4, n - n_sel)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        o_feat, o_score = O.forward_teacher(torch.from_numpy(xn), O.as_torch(tsd), cfg)
+    t = build(tsd, input_dim=d, **V2).train()
+    s = build(base, input_dim=d, **V2).train()
+    x = torch.from_numpy(xn).to(DEV)
+    feat, score = t.forward_teacher(x)
+    np.testing.assert_allclose(feat[0].cpu().numpy(), o_feat.numpy(), atol=2e-4, rtol=1e-3)
+    np.testing.assert_allclose(score[0].cpu().numpy(), o_score.numpy(), atol=1e-5, rtol=5e-3)
+    # student on the ORACLE's teacher outputs (identical inputs => identical index sets)
+    with torch.no_grad():
+        o_logits, o_cl, _, o_keep, ex = O.forward_student(torch.from_numpy(xn), O.as_torch(base), cfg, o_score, o_feat, perm=perm,
+                                                          ids_shuffle=shuf)
+    lk, ids = s.get_mask(n, 0, o_score.to(DEV).view(1, -1), perm=perm)
+    assert lk == ex["len_keep_mask"]
+    np.testing.assert_array_equal(ids[0].cpu().numpy(), ex["mask_ids"])
+    logits, cl, ps, keep = s(x, o_score.to(DEV).view(1, -1), o_feat.to(DEV).view(1, -1), perm=perm, ids_shuffle=shuf)
+    assert keep == o_keep
+    np.testing.assert_allclose(logits[0].detach().cpu().numpy(), o_logits.numpy(), atol=1e-4, rtol=0)
+    assert abs(float(cl) - float(o_cl)) < 2e-4
+    (logits.sum() + cl).backward()
+    for nme, p in s.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), nme
