@@ -70,6 +70,12 @@ int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
  * C, ldc, M, N, K, accumulate and prec of the argument block are read.  Both operands may be activations (attention
  * products, the Nystrom pseudo-inverse iterations, dX = dY . W).   replaces: torch.matmul / `@` on the path. */
 int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float alpha, int32_t splits, float* ws /* splits*M*N floats when splits > 1 */);
+/* `batch` GEMMs of one shape in ONE launch (attention heads, the Nystrom pseudo-inverse iterations): operand b of
+ * A / B / C lives at base + b*stride (floats).  mode 0: C_b = A_b B_b^T;  1: C_b = alpha A_b B_b;
+ * 2: C_b = A_b^T B_b with A_b [K,M], B_b [K,N].  No gather / epilogue fields.  splits > 1 (modes 1, 2) splits the
+ * reduction; ws >= batch*splits*M*N floats.   replaces: batched torch.matmul / einsum on [b h n d] tensors. */
+int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* args, int32_t batch, int64_t strideA,
+                       int64_t strideB, int64_t strideC, float alpha, int32_t splits, float* ws);
 
 /* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over
  * `splits` slabs: ws must hold splits*K1*K2 floats when splits>1 (deterministic two-stage reduction).

@@ -31,6 +31,10 @@ bool nt_planes_ok(const mhimx_gemm_nt_args& g);
 int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g);
 int split_planes(hipStream_t st, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int prec);
 
+// A launch may cover `batch` independent GEMMs (the heads of an attention product): blockIdx.z = b * splits + split,
+// operand b lives at base + b * stride.  {0,0,0,splits} = a single GEMM.
+struct Batch { int64_t sA, sB, sC; int splits; };
+
 template <int PREC> struct Prec;
 template <> struct Prec<MHIMX_PREC_F32> {
   using T = float;
@@ -140,8 +144,9 @@ MHIMX_DEV void lds_put4(typename Prec<PREC>::T* S, int row, int k, float4 v) {
 // gemm_nt
 // =================================================================================================
 template <int PREC>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g) {
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g, Batch bt) {
   using PP = Prec<PREC>;
+  g.A += blockIdx.z * bt.sA; g.B += blockIdx.z * bt.sB; g.C += blockIdx.z * bt.sC;
   using T = typename PP::T;
   constexpr int BK = PP::BK, PITCH = PP::PITCH, TSZ = 128 * PITCH;
   constexpr int F4R = BK / 4;                      // float4 per tile row
@@ -287,11 +292,11 @@ __global__ void skinny_tn_kernel(mhimx_gemm_tn_args g) {
 }
 
 template <int PREC>
-static int launch_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
+static int launch_nt(hipStream_t st, const mhimx_gemm_nt_args& g, int batch = 1, Batch bt = Batch{0, 0, 0, 1}) {
   using PP = Prec<PREC>;
   const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
-  dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM));
-  hipLaunchKernelGGL(gemm_nt_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g);
+  dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)batch);
+  hipLaunchKernelGGL(gemm_nt_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, bt);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -323,8 +328,10 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
 // gemm_tn : C[i,j] = sum_m A[m,i] * B[rows[m], j]
 // =================================================================================================
 template <int PREC>
-__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mhimx_gemm_tn_args g, int64_t mchunk) {
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mhimx_gemm_tn_args g, int64_t mchunk, Batch bt) {
   using PP = Prec<PREC>;
+  const int zb = blockIdx.z / bt.splits, zs = blockIdx.z % bt.splits;
+  g.A += zb * bt.sA; g.B += zb * bt.sB; g.C += zb * bt.sC;
   using T = typename PP::T;
   constexpr int BK = PP::BK, PITCH = PP::PITCH, TSZ = 128 * PITCH;
   constexpr int HK = BK / 2;                         // m-values per thread per operand
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mhimx_gemm_tn_args g,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
-  const int64_t mbeg = (int64_t)blockIdx.z * mchunk;
+  const int64_t mbeg = (int64_t)zs * mchunk;
   const int64_t mend = mbeg + mchunk < g.M ? mbeg + mchunk : g.M;
 
   const int c = tid & 127, half = tid >> 7;          // this thread stages column c, m-range half
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mhimx_gemm_tn_args g,
     }
   }
 
-  float* out = g.splits > 1 ? g.ws + (int64_t)blockIdx.z * g.K1 * g.K2 : g.C;
+  float* out = g.splits > 1 ? g.ws + (int64_t)blockIdx.z * g.K1 * g.K2 : g.C;      // slab index = b * splits + split
   const int64_t ldo = g.splits > 1 ? g.K2 : g.ldc;
   const bool accum = g.splits > 1 ? false : (g.accumulate != 0);
   const int cl = lane & 31, rh = lane >> 5;
@@ -401,8 +408,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(mhimx_gemm_tn_args g,
 }
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2,
-                                    int64_t ldc, int splits, int accumulate) {
+                                    int64_t ldc, int splits, int accumulate, int64_t sC = 0) {
   const int64_t n = K1 * K2;
+  ws += (int64_t)blockIdx.y * splits * n;          // batch element blockIdx.y
+  C += (int64_t)blockIdx.y * sC;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * n + idx];       // fixed order: deterministic
@@ -412,18 +421,20 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 }
 
 template <int PREC>
-static int launch_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
+static int launch_tn(hipStream_t st, const mhimx_gemm_tn_args& g, int batch = 1, Batch bt = Batch{0, 0, 0, 1}) {
   using PP = Prec<PREC>;
   const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
   const int splits = g.splits > 1 ? g.splits : 1;
+  bt.splits = splits;
   const int64_t mchunk = align_up(cdiv(g.M, splits), PP::BK);
-  dim3 grid((unsigned)cdiv(g.K2, BN), (unsigned)cdiv(g.K1, BM), (unsigned)splits);
-  hipLaunchKernelGGL(gemm_tn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, mchunk);
+  dim3 grid((unsigned)cdiv(g.K2, BN), (unsigned)cdiv(g.K1, BM), (unsigned)(splits * batch));
+  hipLaunchKernelGGL(gemm_tn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, mchunk, bt);
   MHIMX_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t n = g.K1 * g.K2;
     const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, splits, g.accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, splits, g.accumulate,
+                       bt.sC);
     MHIMX_LAUNCH_CHECK();
   }
   return 0;
@@ -459,7 +470,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
 }
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2, int64_t ldc,
-                                    int splits, int accumulate);
+                                    int splits, int accumulate, int64_t sC);
 
 // =================================================================================================
 // gemm_nn : C[M,N] = A[M,K] . B[K,N]   (B row-major [K,N]: the k-strided operand is staged like gemm_tn's)
@@ -467,8 +478,10 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 // alpha scales the product; accumulate adds into C.  K % 4 == 0, lda % 4 == 0.
 // =================================================================================================
 template <int PREC>
-__global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(mhimx_gemm_nt_args g, float alpha, int64_t kchunk, float* slabs) {
+__global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(mhimx_gemm_nt_args g, float alpha, int64_t kchunk, float* slabs, Batch bt) {
   using PP = Prec<PREC>;
+  const int zb = blockIdx.z / bt.splits, zs = blockIdx.z % bt.splits;
+  g.A += zb * bt.sA; g.B += zb * bt.sB; g.C += zb * bt.sC;
   using T = typename PP::T;
   constexpr int BK = PP::BK, PITCH = PP::PITCH, TSZ = 128 * PITCH;
   constexpr int F4R = BK / 4, ITEMS = BM * F4R / NTHREADS, HK = BK / 2;
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(mhimx_gemm_nt_args g,
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   float4 ra[ITEMS];
   float rb[HK];
-  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kbeg = (int64_t)zs * kchunk;
   const int64_t kend = kbeg + kchunk < g.K ? kbeg + kchunk : g.K;
   auto fetch = [&](int64_t k0) {
 #pragma unroll
@@ -545,18 +558,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nn_kernel(mhimx_gemm_nt_args g,
 }
 
 template <int PREC>
-static int launch_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits, float* ws) {
+static int launch_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits, float* ws, int batch = 1,
+                     Batch bt = Batch{0, 0, 0, 1}) {
   using PP = Prec<PREC>;
   const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
   if (splits < 1 || !ws) splits = 1;
+  bt.splits = splits;
   const int64_t kchunk = align_up(cdiv(g.K, splits), PP::BK);
-  dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)splits);
-  hipLaunchKernelGGL(gemm_nn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, alpha, kchunk, splits > 1 ? ws : (float*)nullptr);
+  dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)(splits * batch));
+  hipLaunchKernelGGL(gemm_nn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, alpha, kchunk, splits > 1 ? ws : (float*)nullptr, bt);
   MHIMX_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t n = g.M * g.N;
     const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, g.C, g.M, g.N, g.ldc, splits, g.accumulate);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, ws, g.C, g.M, g.N, g.ldc, splits, g.accumulate, bt.sC);
     MHIMX_LAUNCH_CHECK();
   }
   return 0;
@@ -590,6 +605,40 @@ int gemm_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits
 }
 
 // =================================================================================================
+// batched form: `batch` GEMMs of one shape in ONE launch (attention heads, pseudo-inverse iterations).
+// mode 0: C_b = A_b B_b^T (nt)   1: C_b = alpha A_b B_b (nn)   2: C_b = A_b^T B_b (tn; A_b is [K,M], B_b is [K,N])
+// splits > 1 (nn / tn): split the reduction dimension, ws >= batch*splits*M*N floats.
+// =================================================================================================
+int gemm_batched(hipStream_t st, int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
+                 int splits, float* ws) {
+  MHIMX_CHECK_ARG(batch >= 1 && batch <= 4096 && g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0, "gemm_batched: bad args");
+  MHIMX_CHECK_ARG(!g.rows && !g.bias && !g.rowv && !g.pre && g.act == 0 && g.drop_p == 0.f && !g.drop_mask,
+                  "gemm_batched: no epilogue / gather in the batched form");
+  if (splits < 1 || !ws) splits = 1;
+  MHIMX_CHECK_ARG((int64_t)batch * splits <= 65535, "gemm_batched: batch*splits > 65535");
+  const Batch bt{sA, sB, sC, splits};
+  const bool f32 = g.prec == MHIMX_PREC_F32;
+  if (mode == 0) {
+    MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 && aligned16(g.A) && aligned16(g.B),
+                    "gemm_batched(nt): K, lda, ldb, strides must be multiples of 4 and A, B 16-byte aligned");
+    return f32 ? launch_nt<MHIMX_PREC_F32>(st, g, batch, bt) : launch_nt<MHIMX_PREC_BF16X3>(st, g, batch, bt);
+  }
+  if (mode == 1) {
+    MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && sA % 4 == 0 && aligned16(g.A),
+                    "gemm_batched(nn): K, lda, A stride multiples of 4 and A 16-byte aligned");
+    return f32 ? launch_nn<MHIMX_PREC_F32>(st, g, alpha, splits, ws, batch, bt)
+               : launch_nn<MHIMX_PREC_BF16X3>(st, g, alpha, splits, ws, batch, bt);
+  }
+  if (mode == 2) {
+    mhimx_gemm_tn_args t{};
+    t.A = g.A; t.lda = g.lda; t.B = g.B; t.ldb = g.ldb; t.rows = nullptr; t.C = g.C; t.ldc = g.ldc;
+    t.M = g.K; t.K1 = g.M; t.K2 = g.N; t.splits = splits; t.ws = ws; t.accumulate = g.accumulate; t.prec = g.prec;
+    return f32 ? launch_tn<MHIMX_PREC_F32>(st, t, batch, bt) : launch_tn<MHIMX_PREC_BF16X3>(st, t, batch, bt);
+  }
+  return fail(-1, "gemm_batched: unknown mode %d", mode);
+}
+
+// =================================================================================================
 // transpose (32x32 LDS tile, +1 pad)
 // =================================================================================================
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t R, int64_t C) {
@@ -619,6 +668,11 @@ int transpose(hipStream_t st, const float* in, float* out, int64_t R, int64_t C)
 extern "C" int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_nt: null args");
   return mhimx::gemm_nt((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA,
+                                  int64_t strideB, int64_t strideC, float alpha, int32_t splits, float* ws) {
+  MHIMX_CHECK_ARG(a, "gemm_batched: null args");
+  return mhimx::gemm_batched((hipStream_t)stream, mode, *a, batch, strideA, strideB, strideC, alpha, splits, ws);
 }
 extern "C" int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float alpha, int32_t splits, float* ws) {
   if (!a) return mhimx::fail(-1, "gemm_nn: null args");

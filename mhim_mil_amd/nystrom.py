@@ -90,15 +90,33 @@ def batched(t):
     return Op(t, 0, R * Cc, Cc, R, Cc)
 
 
+_MODE = {"nt": 0, "nn": 1, "tn": 2}
+BATCHED = True
+
+
 def _heads_mm(mode, A: Op, Bo: Op, Co: Op, heads, accumulate=False):
-    for h in range(heads):
-        if mode == "nt":
-            M, N, K = A.rows, Bo.rows, A.cols
-        elif mode == "nn":
-            M, N, K = A.rows, Bo.cols, A.cols
-        else:
-            M, N, K = A.cols, Bo.cols, A.rows
-        _gemm(mode, A.t, A.off(h), A.ld, Bo.t, Bo.off(h), Bo.ld, Co.t, Co.off(h), Co.ld, M, N, K, accumulate=accumulate)
+    if mode == "nt":
+        M, N, K = A.rows, Bo.rows, A.cols
+    elif mode == "nn":
+        M, N, K = A.rows, Bo.cols, A.cols
+    else:
+        M, N, K = A.cols, Bo.cols, A.rows
+    aligned = K % 4 == 0 and A.ld % 4 == 0 and A.head_off % 4 == 0 and (mode != "nt" or (Bo.ld % 4 == 0 and Bo.head_off % 4 == 0))
+    if not BATCHED or (mode != "tn" and not aligned):
+        for h in range(heads):
+            _gemm(mode, A.t, A.off(h), A.ld, Bo.t, Bo.off(h), Bo.ld, Co.t, Co.off(h), Co.ld, M, N, K, accumulate=accumulate)
+        return
+    # all heads in ONE launch; a long reduction (K = tokens) is split so that the launch still fills the 256 CUs
+    splits, ws = 1, None
+    if mode != "nt" and K >= 2048:
+        tiles = heads * ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min((1024 + tiles - 1) // tiles, K // 256, 65535 // heads))
+        if splits > 1:
+            ws = torch.empty(heads * splits * M * N, device=Co.t.device)
+    g = L.GemmNT(A=_ptr(A.t, A.base), lda=A.ld, rows=None, B=_ptr(Bo.t, Bo.base), ldb=Bo.ld, C=_ptr(Co.t, Co.base), ldc=Co.ld, M=M, N=N,
+                 K=K, accumulate=int(accumulate), prec=L.PREC[_PREC])
+    L.check(L.lib().mhimx_gemm_batched(_st(), _MODE[mode], C.byref(g), heads, A.head_off, Bo.head_off, Co.head_off, 1.0, splits,
+                                       None if ws is None else _ptr(ws)), "mhimx_gemm_batched")
 
 
 class HeadsMatmul(torch.autograd.Function):
