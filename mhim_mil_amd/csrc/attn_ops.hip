@@ -7,6 +7,7 @@
 #include "common.hpp"
 
 namespace mhimx {
+int transpose(hipStream_t st, const float* in, float* out, int64_t R, int64_t C);   // gemm.hip
 
 constexpr int AT = 256;
 
@@ -365,6 +366,168 @@ __global__ __launch_bounds__(AT) void ppeg_dw_kernel(const float* __restrict__ d
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strip forms of the stencils (the production path).  A thread owns ONE channel and a strip of consecutive output
+// positions; the input window slides through registers so that every input value is loaded once per strip instead of
+// once per tap, all tap indices are compile-time constants and the lanes of a wave read consecutive channels (coalesced).
+// ------------------------------------------------------------------------------------------------
+constexpr int RS = 16;                  // residual conv: outputs per thread along the token axis
+template <int KS>
+__global__ __launch_bounds__(AT) void resconv_strip_kernel(const float* __restrict__ v, int64_t ldv, const float* __restrict__ w, int dh,
+                                                           int64_t T, int C, float* __restrict__ out, int64_t ldo, int accumulate,
+                                                           int flip) {
+  constexpr int P = KS / 2;
+  const int c = blockIdx.y * AT + threadIdx.x;
+  if (c >= C) return;
+  const int64_t t0 = (int64_t)blockIdx.x * RS;
+  const float* wh = w + (c / dh) * KS;
+  float wr[KS];
+#pragma unroll
+  for (int tau = 0; tau < KS; ++tau) wr[tau] = flip ? wh[KS - 1 - tau] : wh[tau];      // flip: the transposed stencil
+  float acc[RS];
+#pragma unroll
+  for (int j = 0; j < RS; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int r = 0; r < RS + KS - 1; ++r) {
+    const int64_t tt = t0 - P + r;
+    const float x = (tt >= 0 && tt < T) ? v[tt * ldv + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < RS; ++j)
+      if (r - j >= 0 && r - j < KS) acc[j] = fmaf(wr[r - j], x, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < RS; ++j)
+    if (t0 + j < T) {
+      float* p = out + (t0 + j) * ldo + c;
+      *p = accumulate ? *p + acc[j] : acc[j];
+    }
+}
+// dw partials: block (x = token chunk, y = 256-channel group = 4 heads of 64); part[x][h*KS + tau]
+template <int KS>
+__global__ __launch_bounds__(AT) void resconv_dw_strip_kernel(const float* __restrict__ dout, int64_t ldo, const float* __restrict__ v,
+                                                              int64_t ldv, int dh, int64_t T, int C, int64_t chunk,
+                                                              float* __restrict__ part) {
+  constexpr int P = KS / 2;
+  const int c = blockIdx.y * AT + threadIdx.x;          // C % 256 == 0 and dh == 64 (checked by the host): wave = one head
+  const int64_t c0 = (int64_t)blockIdx.x * chunk, c1 = c0 + chunk < T ? c0 + chunk : T;
+  float acc[KS];
+#pragma unroll
+  for (int tau = 0; tau < KS; ++tau) acc[tau] = 0.f;
+  for (int64_t t0 = c0; t0 < c1; t0 += RS) {
+    float g[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) g[j] = (t0 + j < c1) ? dout[(t0 + j) * ldo + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RS + KS - 1; ++r) {
+      const int64_t tt = t0 - P + r;
+      const float x = (tt >= 0 && tt < T) ? v[tt * ldv + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < RS; ++j)
+        if (r - j >= 0 && r - j < KS) acc[r - j] = fmaf(g[j], x, acc[r - j]);
+    }
+  }
+  const int heads = C / dh, h = c / dh, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int tau = 0; tau < KS; ++tau) {
+    const float a = wave_sum(acc[tau]);
+    if (lane == 0) part[((int64_t)blockIdx.x * heads + h) * KS + tau] = a;
+  }
+}
+
+constexpr int PS = 8;                   // PPEG: outputs per thread along a grid row
+// FLIP = 0: y[cell] = bc + sum_tap wc[tap] * x[src(cell + tap)]            (forward)
+// FLIP = 1: dx[cell] = sum_tap wc[flipped tap] * dy[cell + tap] (dy = 0 beyond N)   (backward w.r.t. x for cell < N)
+template <int FLIP>
+__global__ __launch_bounds__(AT) void ppeg_strip_kernel(const float* __restrict__ in, int64_t N, int C, int H, int64_t wrapN,
+                                                        const float* __restrict__ wc, const float* __restrict__ bc,
+                                                        float* __restrict__ out, int nsx) {
+  const int c = blockIdx.y * AT + threadIdx.x;
+  if (c >= C) return;
+  const int gy = blockIdx.x / nsx, gx0 = (blockIdx.x % nsx) * PS;
+  float w[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) w[i] = wc[c * 49 + i];
+  float acc[PS];
+  const float b0 = FLIP ? 0.f : bc[c];
+#pragma unroll
+  for (int j = 0; j < PS; ++j) acc[j] = b0;
+#pragma unroll
+  for (int dy = -3; dy <= 3; ++dy) {
+    const int yy = gy + dy;
+    if (yy < 0 || yy >= H) continue;
+    float xin[PS + 6];
+#pragma unroll
+    for (int i = 0; i < PS + 6; ++i) {
+      const int xx = gx0 - 3 + i;
+      float val = 0.f;
+      if (xx >= 0 && xx < H) {
+        const int64_t cell = (int64_t)yy * H + xx;
+        const int64_t src = FLIP ? (cell < N ? cell : -1) : ppeg_src(cell, N, wrapN);
+        if (src >= 0) val = in[src * C + c];
+      }
+      xin[i] = val;
+    }
+#pragma unroll
+    for (int j = 0; j < PS; ++j)
+#pragma unroll
+      for (int dx = -3; dx <= 3; ++dx) {
+        const int tap = FLIP ? (3 - dy) * 7 + (3 - dx) : (dy + 3) * 7 + (dx + 3);
+        acc[j] = fmaf(w[tap], xin[j + dx + 3], acc[j]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < PS; ++j) {
+    const int64_t cell = (int64_t)gy * H + gx0 + j;
+    if (gx0 + j < H && cell < N) out[cell * C + c] = acc[j];
+  }
+}
+// dwc / dbc partials, coalesced layout: part[blk][tap*C + c], part_b[blk][c]
+__global__ __launch_bounds__(AT) void ppeg_dw_strip_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t N, int C,
+                                                           int H, int64_t wrapN, int nsx, int spb, float* __restrict__ part,
+                                                           float* __restrict__ part_b) {
+  const int c = blockIdx.y * AT + threadIdx.x;
+  if (c >= C) return;
+  float acc[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) acc[i] = 0.f;
+  float ab = 0.f;
+  const int nstrips = H * nsx;
+  for (int s = blockIdx.x * spb; s < (int)(blockIdx.x + 1) * spb && s < nstrips; ++s) {
+    const int gy = s / nsx, gx0 = (s % nsx) * PS;
+    if ((int64_t)gy * H + gx0 >= N) break;
+    float g[PS];
+#pragma unroll
+    for (int j = 0; j < PS; ++j) {
+      const int64_t cell = (int64_t)gy * H + gx0 + j;
+      g[j] = (gx0 + j < H && cell < N) ? dy[cell * C + c] : 0.f;
+      ab += g[j];
+    }
+#pragma unroll
+    for (int ddy = -3; ddy <= 3; ++ddy) {
+      const int yy = gy + ddy;
+      if (yy < 0 || yy >= H) continue;
+      float xin[PS + 6];
+#pragma unroll
+      for (int i = 0; i < PS + 6; ++i) {
+        const int xx = gx0 - 3 + i;
+        float val = 0.f;
+        if (xx >= 0 && xx < H) {
+          const int64_t src = ppeg_src((int64_t)yy * H + xx, N, wrapN);
+          if (src >= 0) val = x[src * C + c];
+        }
+        xin[i] = val;
+      }
+#pragma unroll
+      for (int j = 0; j < PS; ++j)
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) acc[(ddy + 3) * 7 + dx + 3] = fmaf(g[j], xin[j + dx + 3], acc[(ddy + 3) * 7 + dx + 3]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 49; ++i) part[((int64_t)blockIdx.x * 49 + i) * C + c] = acc[i];
+  part_b[(int64_t)blockIdx.x * C + c] = ab;
+}
+
 // out[t, c] = v[t*ldv + c] * a[(c / dh) * lda + t]    (scoring.py:25: v * attn per head, heads interleaved as (h d))
 __global__ void scale_heads_kernel(const float* __restrict__ v, int64_t ldv, const float* __restrict__ a, int64_t lda, int dh,
                                    int64_t T, int C, float* __restrict__ out) {
@@ -451,6 +614,12 @@ extern "C" int mhimx_pinv_init_bwd(void* stream, const float* dz, const float* z
 extern "C" int mhimx_resconv(void* stream, const float* v, int64_t ldv, const float* w, int64_t KS, int64_t dh, int64_t T, int64_t C,
                              float* out, int64_t ldo, int32_t accumulate, int32_t flip) {
   MHIMX_CHECK_ARG(v && w && out && KS % 2 == 1 && C % dh == 0, "resconv: bad args");
+  if (KS == 33) {        // the reference's residual_conv_kernel (nystrom_attention.py:43): register-sliding strips
+    hipLaunchKernelGGL(resconv_strip_kernel<33>, dim3((unsigned)cdiv(T, RS), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, v, ldv,
+                       w, (int)dh, T, (int)C, out, ldo, accumulate, flip);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(resconv_fwd_kernel, dim3(grid1d(T, 1, 16384)), dim3(AT), 0, (hipStream_t)stream, v, ldv, w, (int)KS, (int)dh, T, (int)C, out,
                      ldo, accumulate, flip);
   MHIMX_LAUNCH_CHECK();
@@ -489,6 +658,12 @@ extern "C" int mhimx_resconv_dw(void* stream, const float* dout, int64_t ldo, co
   MHIMX_CHECK_ARG(dout && v && dw && ws && dh == 64 && C % dh == 0, "resconv_dw: dim_head must be 64");
   const int nblk = (int)cdiv(T, 256);
   const int W = (int)((C / dh) * KS);
+  if (KS == 33 && C % AT == 0) {
+    hipLaunchKernelGGL(resconv_dw_strip_kernel<33>, dim3((unsigned)nblk, (unsigned)(C / AT)), dim3(AT), 0, (hipStream_t)stream, dout, ldo, v,
+                       ldv, (int)dh, T, (int)C, (int64_t)256, ws);
+    MHIMX_LAUNCH_CHECK();
+    return attn_reduce((hipStream_t)stream, ws, nblk, W, dw);
+  }
   hipLaunchKernelGGL(resconv_dw_kernel, dim3(nblk), dim3(AT), (size_t)W * 4, (hipStream_t)stream, dout, ldo, v, ldv, (int)KS, (int)dh, T, (int)C,
                      (int64_t)256, ws);
   MHIMX_LAUNCH_CHECK();
@@ -527,18 +702,22 @@ extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C
   MHIMX_CHECK_ARG(x && wc && bc && y && N > 0, "ppeg_fwd: bad args");
   int H; int64_t wrapN;
   ppeg_geom(N, &H, &wrapN);
-  hipLaunchKernelGGL(ppeg_fwd_kernel, dim3(grid1d(N, 1, 32768)), dim3(AT), 0, (hipStream_t)stream, x, N, (int)C, H, wrapN, wc, bc, y, 0);
+  const int nsx = (int)cdiv(H, PS);
+  hipLaunchKernelGGL(ppeg_strip_kernel<0>, dim3((unsigned)(nsx * H), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, x, N, (int)C, H,
+                     wrapN, wc, bc, y, nsx);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C) { return cdiv(N, 256) * C * 50; }
+extern "C" int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C) { return cdiv(N, 256) * C * 50 + 49 * C; }
 extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc,
                               float* dbc, float* ws) {
   MHIMX_CHECK_ARG(dy && x && wc && dx && dwc && dbc && ws, "ppeg_bwd: null args");
   int H; int64_t wrapN;
   ppeg_geom(N, &H, &wrapN);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ppeg_bwd_dx_kernel, dim3(grid1d(N, 1, 32768)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc, dx, (int64_t)0, N, 0);
+  const int nsx = (int)cdiv(H, PS);
+  hipLaunchKernelGGL(ppeg_strip_kernel<1>, dim3((unsigned)(nsx * H), (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc,
+                     (const float*)nullptr, dx, nsx);
   MHIMX_LAUNCH_CHECK();
   if (wrapN > N) {
     hipLaunchKernelGGL(ppeg_bwd_dx_kernel, dim3(grid1d(wrapN - N, 1, 32768)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc, dx, N, wrapN, 1);
@@ -547,9 +726,13 @@ extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int
   const int nblk = (int)cdiv(N, 256);
   float* part = ws;
   float* part_b = ws + (int64_t)nblk * C * 49;
-  hipLaunchKernelGGL(ppeg_dw_kernel, dim3(nblk), dim3(AT), 0, st, dy, x, N, (int)C, H, wrapN, (int64_t)256, part, part_b);
+  float* dwc_t = part_b + (int64_t)nblk * C;                    // [49, C], transposed into dwc [C, 49] at the end
+  const int spb = (int)cdiv((int64_t)H * nsx, nblk);
+  hipLaunchKernelGGL(ppeg_dw_strip_kernel, dim3((unsigned)nblk, (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dy, x, N, (int)C, H, wrapN, nsx, spb,
+                     part, part_b);
   MHIMX_LAUNCH_CHECK();
-  if (int r = attn_reduce(st, part, nblk, C * 49, dwc)) return r;
+  if (int r = attn_reduce(st, part, nblk, C * 49, dwc_t)) return r;
+  if (int r = transpose(st, dwc_t, dwc, 49, C)) return r;
   return attn_reduce(st, part_b, nblk, C, dbc);
 }
 extern "C" int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, const float* a, int64_t lda, int64_t dh, int64_t T, int64_t C,

@@ -21,12 +21,18 @@ tr = FusedTrainer(s, t, aux_alpha=0.5)
 g = torch.Generator(device=dev); g.manual_seed(5)
 bags = [torch.randn(N, D, device=dev, generator=g).abs_() for _ in range(2)]
 lab = torch.tensor([1], device=dev)
+GRAPH = int(os.environ.get("GRAPH", 0))
+if GRAPH:
+    graphs = [tr.capture(bags[i], lab, warmup=2) for i in range(2)]
+    step = lambda i: graphs[i % 2].replay()
+else:
+    step = lambda i: tr.train_step(bags[i % 2], lab)
 for i in range(3):
-    tr.train_step(bags[i % 2], lab)
+    step(i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(STEPS):
-    tr.train_step(bags[i % 2], lab)
+    step(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / STEPS
-print(f"c3 N={N}: {dt*1e3:.2f} ms/step  {N/dt/1e6:.2f} M inst/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
+print(f"c3 N={N} graph={GRAPH}: {dt*1e3:.2f} ms/step  {N/dt/1e6:.2f} M inst/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB", flush=True)
