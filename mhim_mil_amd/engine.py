@@ -152,6 +152,7 @@ class FusedTrainer:
         if teacher is not None:
             teacher._tick = self.tick
         self._graph_pool = None
+        self._cap_stream = None
 
     def _dist(self):
         return torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -242,13 +243,21 @@ class FusedTrainer:
         launch instead of ~80.  The step must already have run eagerly (lazy one-time setup such as
         hipFuncSetAttribute cannot happen under capture), hence the warm-up calls."""
         assert self.accum == 1, "graph capture covers a full step (accumulation_steps == 1)"
-        for _ in range(warmup):
-            self.train_step(bag, label, **kw)
+        # warm up ON the capture stream: autograd's gradient-accumulation nodes (TransMIL student) remember the stream they
+        # were created on, and a node living on another stream would need a cross-stream event inside the capture
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
+        cs = self._cap_stream
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            for _ in range(warmup):
+                self.train_step(bag, label, **kw)
+        torch.cuda.current_stream().wait_stream(cs)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self._graph_pool):
+        with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):
             self.train_step(bag, label, **kw)
         return g
 

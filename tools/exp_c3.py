@@ -1,5 +1,6 @@
 """Time one MHIM(TransMIL) train step at BASELINE config c3 (N=50 000, D=1024) — eager launches."""
-import os, sys, time
+import os, sys, time, faulthandler
+faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mhim_mil_amd import synth
