@@ -147,6 +147,11 @@ int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_
 /* attn[n] = exp(s[n]-stats[0])/stats[1]   (baseline.py:35, what return_attn gives) */
 int mhimx_softmax_from_stats(void* stream, const float* s, const float* stats, float* attn, int64_t M);
 
+/* Instance-sharded bag (BASELINE config c5): merge W partial pools parts[W][2+E] = (max_w, L_w, z_w[E]) — one per rank,
+ * all-gathered — into the bag's (stats[2] = {max, L}, z[E]).  Fixed summation order; an empty shard sends L_w = 0.
+ * replaces: the single softmax over all N instances of baseline.py:35-41 when the rows live on several GPUs. */
+int mhimx_lse_merge(void* stream, const float* parts, int64_t W, int64_t E, float* stats, float* z);
+
 /* score[n] = max_c softmax_c( attn_n * cproj[n,c] + bp0 )
  * replaces: mhim_modules/scoring.py:37-58 (get_pseudo_score), incl. the class-0 bias quirk (:54).
  * s == NULL: attn_n = 1, i.e. score[n] = max_c softmax_c(cproj[n,c] + bp0), the tail of get_pseudo_score_trans (scoring.py:27-33). */

@@ -87,6 +87,7 @@ SYMBOLS = {
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
     "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),
+    "mhimx_lse_merge": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "mhimx_gemm_batched": (C.c_int, [_P, _I32, C.POINTER(GemmNT), _I32, _I64, _I64, _I64, _F, _I32, _P]),
     "mhimx_gemm_tn": (C.c_int, [_P, C.POINTER(GemmTN)]),
     "mhimx_split_planes": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),

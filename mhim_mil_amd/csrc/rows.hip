@@ -240,6 +240,29 @@ __global__ void softmax_from_stats_kernel(const float* __restrict__ s, const flo
     attn[n] = __expf(s[n] - mx) * invL;
 }
 
+// Merge of W partial softmax pools (one per shard of an instance-sharded bag), fixed order => deterministic:
+//   parts[w] = (max_w, L_w = sum_n exp(s_n - max_w), z_w[E] = sum_n exp(s_n - max_w) h_n / L_w)
+//   M = max_w max_w ; L = sum_w L_w e^{max_w - M} ; z = sum_w z_w L_w e^{max_w - M} / L.   An empty shard sends L_w = 0.
+__global__ void lse_merge_kernel(const float* __restrict__ parts, int W, int E, float* __restrict__ stats, float* __restrict__ z) {
+  const int ld = E + 2;
+  float M = -INFINITY;
+  for (int w = 0; w < W; ++w)
+    if (parts[w * ld + 1] > 0.f) M = fmaxf(M, parts[w * ld]);
+  float Lsum = 0.f;
+  for (int w = 0; w < W; ++w)
+    if (parts[w * ld + 1] > 0.f) Lsum += parts[w * ld + 1] * __expf(parts[w * ld] - M);
+  const float inv = 1.f / Lsum;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float Lw = parts[w * ld + 1];
+      if (Lw > 0.f) acc += parts[w * ld + 2 + e] * (Lw * __expf(parts[w * ld] - M));
+    }
+    z[e] = acc * inv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = M; stats[1] = Lsum; }
+}
+
 // score_n = max_c softmax_c(attn_n * cproj[n,c] + bp[0]) = 1 / sum_c exp(cam_c - max_c cam)
 __global__ void pseudo_score_kernel(const float* __restrict__ s, const float* __restrict__ stats,
                                     const float* __restrict__ cproj, const float* __restrict__ bp,
@@ -636,6 +659,12 @@ extern "C" int mhimx_softmax_from_stats(void* stream, const float* s, const floa
   if (M <= 0) return 0;
   hipLaunchKernelGGL(softmax_from_stats_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0,
                      (hipStream_t)stream, s, stats, attn, M);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_lse_merge(void* stream, const float* parts, int64_t W, int64_t E, float* stats, float* z) {
+  MHIMX_CHECK_ARG(parts && stats && z && W >= 1 && E >= 1, "lse_merge: bad args");
+  hipLaunchKernelGGL(lse_merge_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, (hipStream_t)stream, parts, (int)W, (int)E, stats, z);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -390,7 +390,7 @@ class MHIM(nn.Module):
         return grads
 
     # ------------------------------------------------------------------ masking (mhim.py:109-179)
-    def get_mask(self, ps, i, attn, mrh=None, perm=None, perms=None):
+    def get_mask(self, ps, i, attn, mrh=None, perm=None, perms=None, generator=None):
         """Device-side get_mask.  Returns (len_keep:int, mask_ids [1,ps] int64).  ``perm``/``perms`` inject the
         randperm draws of masking.py:67 (parity tests); otherwise they are drawn on the device."""
         if attn is None:
@@ -415,7 +415,7 @@ class MHIM(nn.Module):
             k = int(np.ceil(ps * eff))
             n_sel = int(np.ceil(k * rratio)) if rratio < 1.0 else k
             if rratio < 1.0 and pm is None:
-                pm = torch.randperm(k, device=dev)
+                pm = torch.randperm(k, device=dev, generator=generator)
             elif pm is not None and not torch.is_tensor(pm):
                 pm = torch.as_tensor(np.asarray(pm), dtype=torch.int64, device=dev)
             sc, lg = score, largest
@@ -442,7 +442,7 @@ class MHIM(nn.Module):
             run(True, mask_ratio_h, self.mask_ratio_hr, perms[2])
         return len_keep, (None if mask_ids is None else mask_ids.view(1, -1))
 
-    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None):
+    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None):
         """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
 
         Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R).
@@ -457,8 +457,8 @@ class MHIM(nn.Module):
         if mrh is not None:
             mask_ratio_h = mrh
         v2 = self.mask_ratio == 0 and self.mask_ratio_l == 0 and mask_ratio_h > 0
-        if (v2 and self.baseline == "attn" and perm is None and ids_shuffle is None and attn is not None and attn.numel() == ps
-                and ps <= 16384):
+        if (v2 and self.baseline == "attn" and perm is None and ids_shuffle is None and generator is None and attn is not None
+                and attn.numel() == ps and ps <= 16384):
             eff, rr = mask_ratio_h / self.mask_ratio_hr, self.mask_ratio_hr
             if eff > 1:
                 rr, eff = mask_ratio_h, 1.0
@@ -472,7 +472,7 @@ class MHIM(nn.Module):
                     raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
                 rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed(), tick=self._tick)
                 return rows, len_keep, Lk, R
-        len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm)
+        len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm, generator=generator)
         if mask_ids is None:
             raise AssertionError("MHIM.forward needs a mask (mask_ratio_h > 0 or a v1 ratio), as the reference does "
                                  "(masking.py:104)")
@@ -482,7 +482,7 @@ class MHIM(nn.Module):
             raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
         dev = mask_ids.device
         if ids_shuffle is None:
-            ids_shuffle = torch.randperm(len_keep, device=dev)             # == argsort(rand(L)) in distribution
+            ids_shuffle = torch.randperm(len_keep, device=dev, generator=generator)   # == argsort(rand(L)) in distribution
         elif not torch.is_tensor(ids_shuffle):
             ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=dev)
         rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())

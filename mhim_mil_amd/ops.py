@@ -198,6 +198,15 @@ def pseudo_score(s, stats, cproj, bp, want_attn=False):
     return (score, attn) if want_attn else score
 
 
+def lse_merge(parts):
+    """parts [W, 2+E] (max, L, z) of W shard-local pools -> (stats [2], z [E]) of the whole bag."""
+    _chk(parts, name="parts")
+    W, E = parts.shape[0], parts.shape[1] - 2
+    stats, z = torch.empty(2, device=parts.device), torch.empty(E, device=parts.device)
+    L.check(L.lib().mhimx_lse_merge(_stream(), _p(parts), W, E, _p(stats), _p(z)), "mhimx_lse_merge")
+    return stats, z
+
+
 # ------------------------------------------------------------------------------------------------ select
 def select_mask(score, k, n_sel, largest=True, perm=None, other=None, want_topk=False):
     """Device-side select_mask_fn (2-D scores).  Returns (mask_ids int64 [N], len_keep_dev int64 [1], topk|None)."""

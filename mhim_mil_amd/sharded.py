@@ -1,0 +1,219 @@
+"""One giant bag, instance-sharded across GPUs (BASELINE config c5: N=200 000, D=1536 on 8 x MI355X).
+
+Rank r holds a contiguous block of the bag's rows.  Rows are independent until a reduction over instances, so the
+MHIM(ABMIL) train step needs exactly these exchanges (RCCL on GPUs; every one is small next to the N x D stream):
+
+  teacher   all-gather of the shard-local softmax-pool partial (max, L, z[E])            (E+2 floats per rank)
+            all-gather of the per-instance scores                                         (N floats in total)
+  select    none — every rank runs the same top-k / random subsample on the full score vector with a shared-seed
+            generator, so the index sets are identical on all ranks and identical to the single-GPU result
+  student   all-reduce of the [R, E] block of rows-to-merge (each row is non-zero on exactly one rank => exact)
+            all-gather of the pool partial                                                (E+2 floats per rank)
+  backward  all-reduce (= broadcast from rank 0) of d(merged tokens) [k, E]
+            all-reduce(SUM) of the flat gradient buffer (replicated terms are kept on rank 0 only)
+
+The Merge cross-attention (R = 10 % of the kept rows), the head and the optimiser run replicated: they are O(R*E) / O(E)
+and keeping them replicated keeps ``merge.global_q_mm`` and the Adam state bit-identical on every rank with no extra traffic.
+
+Everything numeric is a kernel of libmhimx.so; torch.distributed only moves buffers.  With a ``gloo`` group (the CPU-side
+test harness on a 1-GPU box) buffers are staged through host memory; with ``nccl`` (= RCCL) they stay in HBM.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+from .engine import FlatState
+from .mhim import MHIM, BagPlan, _FEATURE_ACTS
+
+_RANK_SALT = 0x9E3779B97F4A7C15
+
+
+class _Comm:
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.stage = self.on and dist.get_backend(group) == "gloo"
+
+    def all_reduce_sum(self, t):
+        if self.world == 1:
+            return t
+        if self.stage:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        """[W, *t.shape]; every rank contributes the same shape."""
+        if self.world == 1:
+            return t.unsqueeze(0)
+        src = t.cpu() if self.stage else t.contiguous()
+        out = torch.empty(self.world * src.numel(), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src.reshape(-1), group=self.group)
+        return out.view((self.world,) + tuple(src.shape)).to(t.device)
+
+    def all_gather_rows(self, t, counts):
+        """Concatenate per-rank vectors of (known) different lengths."""
+        if self.world == 1:
+            return t
+        m = max(counts)
+        pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+        pad[:t.numel()] = t
+        g = self.all_gather(pad)
+        return torch.cat([g[r, :counts[r]] for r in range(self.world)])
+
+
+def partition_rows(rows, Lk, lo, n):
+    """Split the replicated row list ``rows`` = [rows that stay (Lk) | rows to merge] for the shard holding bag rows
+    [lo, lo+n).  Returns (rows_local [n_loc] shard-local ids, stay rows first; n_stay; merge_pos [n_loc - n_stay] =
+    positions of this shard's merge rows inside the merge list).  One host sync (the local counts are data dependent)."""
+    inshard = (rows >= lo) & (rows < lo + n)
+    pos = torch.nonzero(inshard).view(-1)
+    n_stay = int((pos < Lk).sum())
+    return (rows[pos] - lo).contiguous(), n_stay, (pos[n_stay:] - Lk).contiguous()
+
+
+class ShardedBagTrainer:
+    """Train step of MHIM(ABMIL) on ONE bag whose rows are split across the ranks of ``group``."""
+
+    def __init__(self, student: MHIM, teacher: MHIM, counts=None, group=None, seed=0, lr=2e-4, weight_decay=1e-5,
+                 betas=(0.9, 0.999), eps=1e-8, mm=0.9997, main_alpha=1.0, aux_alpha=0.5):
+        if student.baseline != "attn":
+            raise NotImplementedError("instance sharding is built for the ABMIL encoder; Nystrom bags are replicas only "
+                                      "(SURVEY.md §8(e))")
+        self.s, self.t = student, teacher
+        self.comm = _Comm(group)
+        self.flat = FlatState(student, teacher)
+        self.lr, self.wd, self.betas, self.eps, self.mm = lr, weight_decay, betas, eps, mm
+        self.main_alpha, self.aux_alpha = main_alpha, aux_alpha
+        dev = self.flat.student.device
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(int(seed))              # SAME seed on every rank: identical randperm draws
+        self.seed, self._n = int(seed), 0
+        self.counts = counts                         # rows per rank (list); None = equal shards
+        self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.step_count = 0
+        self.last = {}
+
+    def _seeds(self):
+        self._n += 1
+        shared = (self.seed * 0xD1B54A32D192ED03 + self._n * 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+        local = (shared + (self.comm.rank + 1) * _RANK_SALT) & 0xFFFFFFFFFFFFFFFF
+        return shared, local
+
+    def _pool_merge(self, st, E, dev):
+        """all-gather the shard's (max, L, z) and merge -> the bag's (stats, z)."""
+        part = torch.zeros(E + 2, device=dev)
+        if st is not None:
+            part[:2].copy_(st.stats)
+            part[2:].copy_(st.z)
+        else:
+            part[0] = float("-inf")
+        return ops.lse_merge(self.comm.all_gather(part).contiguous())
+
+    # -------------------------------------------------------------------------------------------------
+    def train_step(self, x_local, label, perm=None, ids_shuffle=None, i=None):
+        """x_local [n_r, D]: this rank's rows (rank order = row order of the bag).  Returns (logits [C], losses [3])."""
+        s, t, fl, cm = self.s, self.t, self.flat, self.comm
+        gv = fl.grad_views
+        x = s._check_x(x_local)
+        n, dev, E = x.shape[0], x.device, s.mlp_dim
+        counts = self.counts if self.counts is not None else [n] * cm.world
+        N, lo = sum(counts), sum(counts[:cm.rank])
+        assert counts[cm.rank] == n, "counts[rank] must equal the local row count"
+        shared_seed, local_seed = self._seeds()
+
+        # ---- teacher: local rows -> partial pool -> global (stats, z); scores need the global denominators
+        with torch.no_grad():
+            p = t.dropout_p if t.training else 0.0
+            Ht = t._feature(x, None, p, local_seed ^ 0x5bd1e995)
+            wp = t.predictor.weight.data if t.attn2score else None
+            st_t = ops.abmil_pool_fwd(t._scorer(), Ht, None, wp=wp)
+            gstats, t_feat = self._pool_merge(st_t, E, dev)
+            if t.attn2score:
+                sc_loc = ops.pseudo_score(st_t.s, gstats, st_t.cproj, t.predictor.bias.data)
+            else:
+                sc_loc = ops.softmax_from_stats(st_t.s, gstats)
+            score = cm.all_gather_rows(sc_loc, counts)
+            del Ht, st_t
+
+        # ---- select: replicated, identical on every rank (shared generator / injected draws)
+        rows, len_keep, Lk, R = s.student_rows(N, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle,
+                                               generator=None if (perm is not None and ids_shuffle is not None) else self.gen)
+        rows_local, n_stay, merge_pos = partition_rows(rows, Lk, lo, n)
+        n_loc = rows_local.numel()
+        n_merge = n_loc - n_stay
+        if n_stay == 0:
+            raise L.MhimxError("a shard without kept rows is not supported (bag too small for this many ranks)")
+        plan = BagPlan(rows=rows_local, L=n_loc, Lk=n_stay, R=R, drop_seed=local_seed, mca_seed=shared_seed, training=True)
+
+        # ---- student forward
+        need_pre = L.act_code(s.act, _FEATURE_ACTS) == L.ACT["gelu"]
+        H = torch.empty((n_loc, E), device=dev)
+        PRE = torch.empty_like(H) if need_pre else None
+        s._feature(x, rows_local, s.dropout_p, local_seed, None, out=H, pre_out=PRE, M=n_loc)
+        Hm = torch.zeros((R, E), device=dev)
+        if n_merge:
+            Hm.index_copy_(0, merge_pos, H[n_stay:])
+        cm.all_reduce_sum(Hm)                                      # every row has exactly one non-zero contributor: exact
+        z_tok, q_new, mws = ops.merge_fwd(s._merge_w(plan), Hm, update_q=True)
+        q_old = s.merge.global_q_mm.data.clone()
+        s.merge.global_q_mm.data.copy_(q_new.view_as(s.merge.global_q_mm))
+        sc = s._scorer()
+        st = ops.abmil_pool_fwd(sc, H[:n_stay], z_tok if cm.rank == 0 else None)    # merged tokens counted once
+        gstats, z = self._pool_merge(st, E, dev)
+
+        # ---- head (replicated): predictor + CE + distillation and their gradients
+        t_in = t_feat if self.aux_alpha != 0. else None
+        logits, losses, g_z, _, _ = ops.head_fwd_bwd(z, t_in, s.predictor.weight.data, s.predictor.bias.data, label,
+                                                     temp_t=float(s.temp_t), main_alpha=self.main_alpha, aux_alpha=self.aux_alpha,
+                                                     d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"])
+
+        # ---- backward: the pool backward sees the BAG's softmax statistics and pooled feature
+        st.stats.copy_(gstats)
+        st.z.copy_(z)
+        dH = torch.empty_like(H)
+        att = s.online_encoder.attention
+        pre = "online_encoder.attention."
+        pool_g = {"dT1": dH[:n_stay]}
+        if s.online_encoder.gated:
+            pool_g.update(d_wa=gv[pre + "attention_a.0.weight"], d_wb=gv[pre + "attention_b.0.weight"],
+                          d_wc=gv[pre + "attention_c.weight"])
+            g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(att.attention_a[0].weight.data),
+                                   ops.transpose(att.attention_b[0].weight.data), grads=pool_g)
+        else:
+            pool_g.update(d_wa=gv[pre + "attention.0.weight"], d_wc=gv[pre + "attention.2.weight"])
+            g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(att.attention[0].weight.data), grads=pool_g)
+        dT2 = g["dT2"] if cm.rank == 0 else torch.zeros_like(z_tok)
+        cm.all_reduce_sum(dT2)                                     # = broadcast from rank 0
+        mgr = {"d_ln_w": gv["merge.norm.weight"], "d_ln_b": gv["merge.norm.bias"], "d_wkv": gv["merge.attn.to_kv.weight"],
+               "d_wq": gv["merge.attn.to_q.weight"], "d_wo": gv["merge.attn.to_out.0.weight"], "d_bo": gv["merge.attn.to_out.0.bias"]}
+        mg = ops.merge_bwd(s._merge_w(plan, need_t=True, q=q_old), Hm, dT2, mws, grads=mgr)
+        if n_merge:
+            dH[n_stay:] = mg["dX"].index_select(0, merge_pos)
+        ops.act_bwd(dH, H, PRE, L.act_code(s.act, _FEATURE_ACTS), s.dropout_p, local_seed, None, rows_local,
+                    colsum_out=gv["feature.0.bias"], want_colsum=True)
+        ops.gemm_tn(dH, x, out=gv["feature.0.weight"], rows=rows_local, splits=8 if n_loc >= 2048 else 1,
+                    prec="f32" if s.prec == "f32" else "bf16x3", M=n_loc)
+        if cm.rank != 0:                                           # replicated terms: counted once in the SUM
+            for name in fl.train_names:
+                if name.startswith("predictor.") or name.startswith("merge."):
+                    gv[name].zero_()
+        cm.all_reduce_sum(fl.grad[:fl.n_train])
+
+        # ---- optimiser + EMA teacher (replicated, identical inputs on every rank)
+        self.step_count += 1
+        ops.tick(self.opt_step)
+        ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher, fl.n_train, self.step_count, lr=self.lr, beta1=self.betas[0],
+                     beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, grad_scale=1.0, ema_mm=self.mm, zero_grad=True,
+                     step_dev=self.opt_step)
+        self.last = {"logits": logits, "losses": losses, "patch_num": N, "keep_num": Lk + s.merge.k, "rows": rows,
+                     "len_keep": len_keep, "score": score, "teacher_feat": t_feat}
+        return logits, losses

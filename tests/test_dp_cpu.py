@@ -57,3 +57,72 @@ def test_flat_gradient_allreduce_two_ranks(tmp_path):
     pn, _, _ = O.adam_step(p0[:N_TRAIN], acc[:N_TRAIN], torch.zeros(N_TRAIN), torch.zeros(N_TRAIN), 1)
     pn2, _, _ = O.adam_step(p0[:N_TRAIN], (res[1]["g"] * 0.5)[:N_TRAIN], torch.zeros(N_TRAIN), torch.zeros(N_TRAIN), 1)
     np.testing.assert_allclose(pn.numpy(), pn2.numpy(), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Instance-sharded bag (BASELINE config c5): the exchange + partition logic of mhim_mil_amd/sharded.py on 2 gloo ranks,
+# with the oracle's math standing in for the shard-local kernels.  (The kernels themselves need a GPU: tests/test_sharded_gpu.py.)
+# ---------------------------------------------------------------------------------------------------------------------
+SH_N, SH_D, SH_COUNTS = 900, 64, [500, 400]
+
+
+def _lse_merge_np(parts):
+    """What mhimx_lse_merge computes: parts [W, 2+E] = (max_w, L_w, z_w) -> (max, L, z)."""
+    live = parts[:, 1] > 0
+    M = parts[live, 0].max()
+    w = parts[:, 1] * np.where(live, np.exp(parts[:, 0] - M), 0.0)
+    return M, w.sum(), (parts[:, 2:] * w[:, None]).sum(0) / w.sum()
+
+
+def _shard_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from mhim_mil_amd.sharded import _Comm, partition_rows
+    cm = _Comm()
+    assert (cm.world, cm.rank, cm.stage) == (WORLD, rank, True)
+    p = O.as_torch(synth.mhim_state(5, input_dim=SH_D, merge_k=3))
+    lo = sum(SH_COUNTS[:rank])
+    x = torch.from_numpy(synth.bag(77, SH_N, SH_D))[lo:lo + SH_COUNTS[rank]]
+    # shard-local teacher: scorer logits, local softmax statistics and pooled feature
+    h = O.feature(x, p, "gelu")
+    s = O.scorer_logits(h, p["online_encoder.attention.attention.0.weight"], p["online_encoder.attention.attention.2.weight"], "relu").view(-1)
+    mx = s.max()
+    e = torch.exp(s - mx)
+    part = torch.cat([mx.view(1), e.sum().view(1), (e[:, None] * h).sum(0) / e.sum()])
+    parts = cm.all_gather(part)                                            # [W, 2+E]
+    M, Lsum, z = _lse_merge_np(parts.double().numpy())
+    attn_local = torch.exp(s - M) / Lsum                                   # needs the GLOBAL denominators
+    attn = cm.all_gather_rows(attn_local.float(), SH_COUNTS)               # unequal shard sizes
+    # replicated row list [stay | merge] and this shard's slice of it
+    rows = torch.from_numpy(synth.permutation(9, SH_N)[:800].astype(np.int64))
+    Lk = 720
+    rows_local, n_stay, merge_pos = partition_rows(rows, Lk, lo, SH_COUNTS[rank])
+    Hm = torch.zeros(800 - Lk, 4)
+    Hm[merge_pos] = (rows_local[n_stay:] + lo).float()[:, None].expand(-1, 4)      # "features" = the global row id
+    cm.all_reduce_sum(Hm)
+    torch.save({"z": torch.from_numpy(z), "attn": attn, "rows_local": rows_local + lo, "n_stay": n_stay, "Hm": Hm},
+               os.path.join(out, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_bag_exchanges_two_ranks(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_shard_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"s{r}.pt")) for r in range(WORLD)]
+    p = O.as_torch(synth.mhim_state(5, input_dim=SH_D, merge_k=3))
+    x = torch.from_numpy(synth.bag(77, SH_N, SH_D))
+    h = O.feature(x, p, "gelu")
+    z_ref, a_ref, _ = O.dattention(h, p, "relu")                           # the unsharded softmax pool
+    rows = torch.from_numpy(synth.permutation(9, SH_N)[:800].astype(np.int64))
+    for r in res:
+        np.testing.assert_allclose(r["z"].numpy(), z_ref.numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(r["attn"].numpy(), a_ref.view(-1).numpy(), rtol=2e-5, atol=1e-9)
+        # the all-reduced merge block holds every merge row exactly once, in merge-list order
+        np.testing.assert_array_equal(r["Hm"][:, 0].long().numpy(), rows[720:].numpy())
+    # the shards' row lists partition the replicated list: stay rows first, order preserved
+    stay = torch.cat([r["rows_local"][:r["n_stay"]] for r in res])
+    merge = torch.cat([r["rows_local"][r["n_stay"]:] for r in res])
+    assert sorted(stay.tolist()) == sorted(rows[:720].tolist()) and sorted(merge.tolist()) == sorted(rows[720:].tolist())
+    lo1 = SH_COUNTS[0]
+    assert all(v < lo1 for v in res[0]["rows_local"].tolist()) and all(v >= lo1 for v in res[1]["rows_local"].tolist())
