@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=40, help="oracle steps for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2 (default, BASELINE.json's metric): MHIM(ABMIL) N=10k D=1024, one bag per GPU per step; "
+                         "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs")
     return ap.parse_args()
 
 
@@ -96,6 +99,77 @@ def cpu_baseline(steps, base):
                       f"{ncpu}-thread host, dropout off) on one N={N_INST} D={D_IN} bag, {dt:.1f} s"}
 
 
+def timed(a, world, dev, step):
+    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def other_workload(a, world, rank, dev):
+    """c3 / c5: parity-test configurations of BASELINE.json, timed for DESIGN.md (not the headline metric)."""
+    from mhim_mil_amd import synth
+    from mhim_mil_amd.mhim import MHIM
+    c3 = a.workload == "c3"
+    n_total, d = (50000, 1024) if c3 else (200000, 1536)
+    base = synth.mhim_state(7, input_dim=d, merge_k=5, baseline="selfattn" if c3 else "attn")
+
+    def mk():
+        m = MHIM(input_dim=d, n_classes=2, baseline="selfattn" if c3 else "attn", prec=a.prec, **CFG)
+        sd = dict(base)
+        sd["merge.global_q"] = sd["merge.global_q_mm"]
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        return m.to(dev).train()
+
+    student, teacher = mk(), mk()
+    g = torch.Generator(device=dev)
+    lab = torch.tensor([1], device=dev)
+    if c3:
+        from mhim_mil_amd.engine import FusedTrainer
+        g.manual_seed(3000 + rank)
+        tr = FusedTrainer(student, teacher, aux_alpha=0.5, mm=0.9997)
+        bags = [torch.randn(n_total, d, device=dev, generator=g).abs_() for _ in range(2)]
+        graphs = None if a.no_graph else [tr.capture(b, lab, warmup=2) for b in bags]
+        step = (lambda i: tr.train_step(bags[i % 2], lab)) if graphs is None else (lambda i: graphs[i % 2].replay())
+        per_step, scaling, par = n_total * world, "weak", f"dp{world} (replicas, one bag per GPU per step)"
+        name = f"c3: MHIM(TransMIL/Nystrom) train step, one bag N={n_total} D={d} per GPU per step"
+    else:
+        from mhim_mil_amd.sharded import ShardedBagTrainer
+        assert n_total % world == 0
+        n = n_total // world
+        g.manual_seed(5000 + rank)
+        tr = ShardedBagTrainer(student, teacher, counts=[n] * world, seed=11, aux_alpha=0.5, mm=0.9997)
+        bags = [torch.randn(n, d, device=dev, generator=g).abs_() for _ in range(2)]
+        step = lambda i: tr.train_step(bags[i % 2], lab)
+        per_step, scaling, par = n_total, "strong", f"instance-sharded over {world} GPU(s), {n} rows each"
+        name = f"c5: MHIM(ABMIL) train step on ONE bag N={n_total} D={d} sharded by rows"
+    dt = timed(a, world, dev, step)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"patch-instances/sec through MHIM fwd+bwd ({a.workload})", "value": per_step * a.steps / dt,
+            "unit": "patch-instances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic |N(0,1)| bags resident in HBM, random-init weights (reference init law)",
+            "config": {"workload": name, "parallelism": par, "dropout": CFG["dropout"],
+                       "launch": "hipGraph replay" if (c3 and not a.no_graph) else "eager"}}), flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +182,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.workload != "c2":
+        other_workload(a, world, rank, dev)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     from mhim_mil_amd import ops
     from mhim_mil_amd.engine import FusedTrainer
@@ -145,25 +224,9 @@ def main():
         else:
             trainer.train_step(bags[i % N_BAGS], labels[i % N_BAGS])
 
-    for i in range(a.warmup):
-        step(i)
-    ev.clear()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = timed(a, world, dev, step)
+    if graphs is None:
+        ev[:] = ev[-a.steps:]                   # eager: keep the events of the timed steps only
     events_from = "the timed region"
     if graphs is not None and not a.no_kernel_events:
         # Host-side HIP event records cannot be placed between the nodes of a replayed hipGraph (ROCm rejects external

@@ -452,6 +452,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
   if (tn_dma_ok(g)) {
     int64_t avail = g.ws ? (g.ws_floats > 0 ? g.ws_floats : (int64_t)(g.splits > 1 ? g.splits : 0) * g.K1 * g.K2) : 0;
     const int used = gemm_tn_dma(st, g, avail);
+    if (used == -2) goto generic;         // reduction too long for the LDS row table with this much workspace
     if (used < 0) return used;
     if (used > 1) {
       const int64_t n = g.K1 * g.K2;
@@ -461,6 +462,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
     }
     return 0;
   }
+generic:
   switch (g.prec) {
     case MHIMX_PREC_F32: return launch_tn<MHIMX_PREC_F32>(st, g);
     case MHIMX_PREC_F16S:      // fp16 has no headroom for gradients: use the bf16 3-term form

@@ -654,7 +654,7 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   while (splits > 1 && (int64_t)splits * g.K1 * g.K2 > ws_floats_avail) --splits;
   while (cdiv(g.M, splits) > MAX_TN_CHUNK) {
     ++splits;
-    if ((int64_t)splits * g.K1 * g.K2 > ws_floats_avail) return fail(-1, "gemm_tn: workspace too small for M=%lld", (long long)g.M);
+    if ((int64_t)splits * g.K1 * g.K2 > ws_floats_avail) return -2;      // caller falls back to the register-staged kernel
   }
   g.splits = splits;
   const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);

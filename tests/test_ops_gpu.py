@@ -93,7 +93,8 @@ def test_gemm_nt_dropout_mask_and_hash():
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-@pytest.mark.parametrize("M,K1,K2,splits", [(5, 512, 512, 1), (1000, 128, 512, 1), (3000, 512, 64, 4), (2500, 130, 200, 3)])
+@pytest.mark.parametrize("M,K1,K2,splits", [(5, 512, 512, 1), (1000, 128, 512, 1), (3000, 512, 64, 4), (2500, 130, 200, 3),
+                                            (70000, 128, 512, 2)])      # last: reduction too long for the LDS row table with 2
 def test_gemm_tn(prec, M, K1, K2, splits):
     ops = _ops()
     a, b = rnd(11, (M, K1), std=1e-3), rnd(12, (M + 50, K2)).abs()
