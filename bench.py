@@ -260,9 +260,18 @@ def main():
             avg = sum(ms) / len(ms)
             algo = N_INST * D_IN * 4                      # D*4 B per instance for one forward pass over X
             ach = algo / (avg * 1e-3) / 1e9
+            # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
+            # (tools/pmc.sh + tools/pmc_feature.py; counters cannot be read from inside the process being timed)
+            traffic, tsrc = None, None
+            pmc = os.path.join(ROOT, "profiles", "pmc_feature_gemm.json")
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                traffic, tsrc = pj["traffic_bytes"], ("profiles/pmc_feature_gemm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                                                      f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
+                                                      f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
             out["roofline"] = {"kernel": "gemm_nt_dma_kernel<BF16X3,8> (teacher feature projection X[N,D] -> H[N,512], fused bias+GELU+dropout)",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "avg_kernel_ms": avg, "launches_timed": len(ms), "hip_events_over": events_from,
+                               "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "avg_kernel_ms": avg, "launches_timed": len(ms), "hip_events_over": events_from,
                                "algorithmic_bytes_per_launch": algo,
                                "mfma_TFLOPs_fp32_equivalent": 2.0 * N_INST * D_IN * 512 / (avg * 1e-3) / 1e12}
         if world == 1 and a.cpu_steps > 0:
