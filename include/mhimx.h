@@ -63,6 +63,7 @@ typedef struct {
   int32_t prec;                                          /* MHIMX_PREC_*                          */
   const uint64_t* drop_tick;                             /* optional device step counter mixed into drop_seed (graph replay) */
   const uint16_t* B_hi; const uint16_t* B_lo;            /* optional pre-split 16-bit planes of B [N,K] (mhimx_split_planes) */
+  int32_t paired;                                        /* 1: A and B are paired-plane images made by mhimx_pair_planes      */
 } mhimx_gemm_nt_args;
 int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
 
@@ -95,6 +96,12 @@ int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a);
 /* hi[i], lo[i] = 16-bit split of w[i] (bf16 planes for MHIMX_PREC_BF16X3, fp16 for F16S): lets a weight operand go
  * LDS -> MFMA with no per-tile conversion.  Done once per step per weight (weights change every step). */
 int mhimx_split_planes(void* stream, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int32_t prec);
+
+/* Paired planes: out[m, k] ("floats", same shape and pitch as x[M,K]) holds, for every 8 consecutive k of a row, 8 bf16
+ * hi values followed by 8 bf16 lo values (x = hi + lo to ~2^-16).  A GEMM whose operands are both in this form
+ * (args.paired = 1, MHIMX_PREC_BF16X3) moves 16-bit MFMA fragments HBM -> LDS -> matrix core with no conversion in its
+ * inner loop; the bag X is paired once per step and shared by the teacher's and the student's projection. */
+int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int64_t K, float* out);
 
 /* out[c,r] = in[r,c]  (weights are transposed once per step so that dX = dY W is also an NT GEMM) */
 int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C);

@@ -32,7 +32,8 @@ class GemmNT(C.Structure):
                 ("pre", c_f32p), ("ldpre", C.c_int64),
                 ("act", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p),
-                ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p), ("B_hi", C.c_void_p), ("B_lo", C.c_void_p)]
+                ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p), ("B_hi", C.c_void_p), ("B_lo", C.c_void_p),
+                ("paired", C.c_int32)]
 
 
 class GemmTN(C.Structure):
@@ -87,6 +88,7 @@ SYMBOLS = {
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
     "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),
+    "mhimx_pair_planes": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
     "mhimx_lse_merge": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "mhimx_gemm_batched": (C.c_int, [_P, _I32, C.POINTER(GemmNT), _I32, _I64, _I64, _I64, _F, _I32, _P]),
     "mhimx_gemm_tn": (C.c_int, [_P, C.POINTER(GemmTN)]),

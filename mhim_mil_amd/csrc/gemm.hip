@@ -29,6 +29,9 @@ bool tn_dma_ok(const mhimx_gemm_tn_args& g);
 int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_avail);
 bool nt_planes_ok(const mhimx_gemm_nt_args& g);
 int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g);
+int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t K, float* out);
+bool feat_gemm_ok(const mhimx_gemm_nt_args& g);
+int feat_gemm(hipStream_t st, const mhimx_gemm_nt_args& g);
 int split_planes(hipStream_t st, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int prec);
 
 // A launch may cover `batch` independent GEMMs (the heads of an attention product): blockIdx.z = b * splits + split,
@@ -309,6 +312,11 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
   MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_nt: null operand");
   MHIMX_CHECK_ARG(!g.rowv || g.colv, "gemm_nt: rowv needs colv");
   MHIMX_CHECK_ARG(g.drop_p >= 0.f && g.drop_p < 1.f, "gemm_nt: drop_p out of range");
+  if (g.paired) {
+    MHIMX_CHECK_ARG(g.M > SKINNY_M && g.K % 32 == 0 && nt_dma_ok(g), "gemm_nt: paired-plane operands need M > 16, K % 32 == 0, aligned rows");
+    if (feat_gemm_ok(g)) return feat_gemm(st, g);          // 160 x 128 tiles: one balanced round over the chip
+    return gemm_nt_dma(st, g);
+  }
   if (g.M <= SKINNY_M) {
     hipLaunchKernelGGL(skinny_nt_kernel, dim3((unsigned)cdiv(g.N, 4)), dim3(256), 0, st, g);
     MHIMX_LAUNCH_CHECK();
@@ -670,6 +678,9 @@ int transpose(hipStream_t st, const float* in, float* out, int64_t R, int64_t C)
 extern "C" int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_nt: null args");
   return mhimx::gemm_nt((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int64_t K, float* out) {
+  return mhimx::pair_planes((hipStream_t)stream, x, ldx, M, K, out);
 }
 extern "C" int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA,
                                   int64_t strideB, int64_t strideC, float alpha, int32_t splits, float* ws) {

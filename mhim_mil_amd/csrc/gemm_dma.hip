@@ -159,7 +159,11 @@ MHIMX_DEV void dma16(const float* src, char* lds_wave_base) {
 // NW = 4: 2x2 waves, 64x64 per wave (12 MFMAs per 16-deep k slice);  NW = 8: 2x4 waves, 64x32 per wave (6 MFMAs).
 // Eight waves put two waves on every SIMD even when a CU holds a single workgroup: one wave's DMA issue (~100
 // cycles per LDS-DMA instruction), fragment reads and fp32->bf16 splitting then overlap the other wave's MFMAs.
-template <int PREC, int NW>
+// PAIRED: both operands arrive as "paired planes" (mhimx_pair_planes): every 8 consecutive k of a row are stored as
+// 16 B of bf16 hi followed by 16 B of bf16 lo, i.e. the same 128 B per row per 32-deep k-step and therefore the SAME LDS
+// image, DMA pattern and swizzle as the fp32 form — but the two 16-B slots a lane reads ARE its (hi, lo) MFMA fragments:
+// no VALU conversion in the loop at all.
+template <int PREC, int NW, int PAIRED = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args g) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
@@ -255,23 +259,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
     lds_read<NRD>(x, fa, so, 0u);                         // ks = 0
     lds_wait<NRD>(x);
     lds_read<NRD>(y, fa, so, 64u);                     // ks = 1 in flight under the first MFMA batch
-    {
+    auto frags = [&](const f4 (&z)[NRD]) {
       V8 ah[2], al[2], bh[NT], bl[NT];
+      if constexpr (PAIRED) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) FR::split2(x[q * 2], x[q * 2 + 1], ah[q], al[q]);
+        for (int q = 0; q < 2; ++q) { ah[q] = __builtin_bit_cast(V8, z[q * 2]); al[q] = __builtin_bit_cast(V8, z[q * 2 + 1]); }
 #pragma unroll
-      for (int q = 0; q < NT; ++q) FR::split2(x[4 + q * 2], x[4 + q * 2 + 1], bh[q], bl[q]);
+        for (int q = 0; q < NT; ++q) { bh[q] = __builtin_bit_cast(V8, z[4 + q * 2]); bl[q] = __builtin_bit_cast(V8, z[4 + q * 2 + 1]); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) FR::split2(z[q * 2], z[q * 2 + 1], ah[q], al[q]);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) FR::split2(z[4 + q * 2], z[4 + q * 2 + 1], bh[q], bl[q]);
+      }
       mma_tile<PREC, NT>(ah, al, bh, bl, acc);
-    }
+    };
+    frags(x);
     lds_wait<NRD>(y);
-    {
-      V8 ah[2], al[2], bh[NT], bl[NT];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) FR::split2(y[q * 2], y[q * 2 + 1], ah[q], al[q]);
-#pragma unroll
-      for (int q = 0; q < NT; ++q) FR::split2(y[4 + q * 2], y[4 + q * 2 + 1], bh[q], bl[q]);
-      mma_tile<PREC, NT>(ah, al, bh, bl, acc);
-    }
+    frags(y);
   }
 
   // ---- epilogue (same contract as gemm.hip)
@@ -611,6 +616,31 @@ int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g) {
 }
 
 // ---- host ------------------------------------------------------------------------------------------
+// x[M,K] fp32 (row pitch ldx) -> out[M,K] "floats": per 8 consecutive k, 8 bf16 hi then 8 bf16 lo (32 B in, 32 B out)
+__global__ void pair_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int64_t K8, float* __restrict__ out) {
+  const int64_t n = M * K8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / K8, g8 = i % K8;
+    const f4 a = *reinterpret_cast<const f4*>(x + m * ldx + g8 * 8);
+    const f4 b = *reinterpret_cast<const f4*>(x + m * ldx + g8 * 8 + 4);
+    b8 hi, lo;
+    Frag<MHIMX_PREC_BF16X3>::split2(a, b, hi, lo);
+    f4* o = reinterpret_cast<f4*>(out + (m * K8 + g8) * 8);
+    o[0] = __builtin_bit_cast(f4, hi);
+    o[1] = __builtin_bit_cast(f4, lo);
+  }
+}
+int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t K, float* out) {
+  MHIMX_CHECK_ARG(x && out && M > 0 && K > 0 && K % 8 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(out),
+                  "pair_planes: K must be a multiple of 8, rows 16-byte aligned");
+  const int64_t n = M * (K / 8);
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pair_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, M, K / 8, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 bool nt_dma_ok(const mhimx_gemm_nt_args& g) {
   return (g.prec == MHIMX_PREC_BF16X3 || g.prec == MHIMX_PREC_F16S) && g.K % DBK == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
          aligned16(g.A) && aligned16(g.B) && g.M > 16;
@@ -628,7 +658,14 @@ int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
     MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
     attr = true;
   }
-  if (g.prec == MHIMX_PREC_BF16X3)
+  if (g.paired) {
+    static bool attr2 = false;
+    if (!attr2) {
+      MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
+  } else if (g.prec == MHIMX_PREC_BF16X3)
     hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
   else
     hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);

@@ -166,8 +166,9 @@ class FusedTrainer:
         ps = x.shape[0]
         first = self._micro == 0
         gv = fl.grad_views
+        xp = s._pair(x) if s.baseline == "attn" else None        # one bf16 hi/lo image of the bag for both projections
         if self.model_kind == "mhim":
-            teacher_feat, score = t.forward_teacher(x)
+            teacher_feat, score = t.forward_teacher(x, xp=xp)
             rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle)
             plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True)
             keep_num = Lk + s.merge.k
@@ -182,7 +183,7 @@ class FusedTrainer:
         if self.model_kind != "mhim":
             s.merge_enable = False
         try:
-            z, saved = s._bag_forward(x, plan)
+            z, saved = s._bag_forward(x, plan, xp=xp)
             t_in = teacher_feat.view(-1) if (teacher_feat is not None and self.aux_alpha != 0.) else None
             logits, losses, g_z, _, _ = ops.head_fwd_bwd(
                 z, t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),

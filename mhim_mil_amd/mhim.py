@@ -290,10 +290,25 @@ class MHIM(nn.Module):
             x = x[0]
         return x.contiguous().float()
 
-    def _feature(self, x, rows=None, drop_p=0.0, drop_seed=0, drop_mask=None, want_pre=False, out=None, pre_out=None, M=None):
+    def _pair(self, x):
+        """Paired-plane image of the bag (8 bf16 hi | 8 bf16 lo per 8 consecutive features), made ONCE per step and shared
+        by every projection that streams X: the GEMM inner loop then has no fp32 -> bf16 conversion.  None when the
+        projection does not run in the 3-term bf16 form or the shape is not tileable."""
+        if self._feature_prec(x.shape[0]) != "bf16x3" or x.shape[1] % 32 != 0 or x.shape[0] <= 16:
+            return None
+        return ops.pair_planes(x)
+
+    def _feature(self, x, rows=None, drop_p=0.0, drop_seed=0, drop_mask=None, want_pre=False, out=None, pre_out=None, M=None,
+                 xp=None):
         f = self.feature[0]
         act = L.act_code(self.act, _FEATURE_ACTS)
         nrows = M if M is not None else (rows.shape[0] if rows is not None else x.shape[0])
+        if xp is None and nrows >= 1024:
+            xp = self._pair(x)
+        if xp is not None and nrows > 16:
+            return ops.gemm_nt(xp, ops.pair_planes(f.weight.data), out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out,
+                               drop_p=drop_p, drop_seed=drop_seed, drop_mask=drop_mask, prec="bf16x3", M=M, drop_tick=self._tick,
+                               paired=True)
         return ops.gemm_nt(x, f.weight.data, out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out, drop_p=drop_p,
                            drop_seed=drop_seed, drop_mask=drop_mask, prec=self._feature_prec(nrows), M=M, drop_tick=self._tick)
 
@@ -316,7 +331,7 @@ class MHIM(nn.Module):
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ student bag forward / backward
-    def _bag_forward(self, x, plan: BagPlan):
+    def _bag_forward(self, x, plan: BagPlan, xp=None):
         E = self.mlp_dim
         Lrows = plan.L
         dev = x.device
@@ -324,7 +339,7 @@ class MHIM(nn.Module):
         H = torch.empty((Lrows, E), device=dev)
         PRE = torch.empty((Lrows, E), device=dev) if need_pre else None
         p = self.dropout_p if plan.training else 0.0
-        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows)
+        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp)
         saved = {"H": H, "PRE": PRE}
         sc = self._scorer()
         if self.merge_enable and plan.R > 0:
@@ -490,10 +505,10 @@ class MHIM(nn.Module):
 
     # ------------------------------------------------------------------ reference entry points
     @torch.no_grad()
-    def forward_teacher(self, x, drop_mask=None):
+    def forward_teacher(self, x, drop_mask=None, xp=None):
         x = self._check_x(x)
         p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
-        H = self._feature(x, None, p, self._next_seed(), drop_mask)
+        H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp)
         p0 = H.shape[0]
         T2 = None
         if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)

@@ -44,7 +44,7 @@ def prec_code(prec) -> int:
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, colv=None, drop_p=0.0, drop_seed=0,
-            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, b_planes=None):
+            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, b_planes=None, paired=False):
     """out[m,n] = epi(sum_k a[rows[m] or m, k] * b[n,k]) — see mhimx_gemm_nt."""
     for t, nm in ((a, "a"), (b, "b"), (bias, "bias"), (pre, "pre"), (rowv, "rowv"), (colv, "colv"), (out, "out")):
         _chk(t, name=nm)
@@ -61,13 +61,22 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
                  ldpre=pre.stride(0) if pre is not None else 0, act=int(act), drop_p=float(drop_p),
                  drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(drop_mask), accumulate=int(bool(accumulate)),
                  prec=prec_code(prec), drop_tick=_p(drop_tick), B_hi=_p(b_planes[0]) if b_planes is not None else None,
-                 B_lo=_p(b_planes[1]) if b_planes is not None else None)
+                 B_lo=_p(b_planes[1]) if b_planes is not None else None, paired=int(bool(paired)))
     evs = KERNEL_EVENT_HOOK("gemm_nt", M, N, K) if KERNEL_EVENT_HOOK is not None else None
     if evs:
         evs[0].record()
     L.check(L.lib().mhimx_gemm_nt(_stream(), C.byref(g)), "mhimx_gemm_nt")
     if evs:
         evs[1].record()
+    return out
+
+
+def pair_planes(x):
+    """x [M,K] fp32 -> its paired-plane image (same shape; 8 bf16 hi | 8 bf16 lo per 8 consecutive k) for gemm_nt(paired=True)."""
+    _chk(x, name="x")
+    M, K = x.shape
+    out = torch.empty_like(x)
+    L.check(L.lib().mhimx_pair_planes(_stream(), _p(x), x.stride(0), M, K, _p(out)), "mhimx_pair_planes")
     return out
 
 

@@ -102,10 +102,28 @@ def test_gemm_tn(prec, M, K1, K2, splits):
     ref = (a.double().t() @ b[rows].double()).float()
     out = ops.gemm_tn(a.to(DEV), b.to(DEV), rows=rows.to(DEV), splits=splits, prec=prec).cpu()
     atol, rtol = TOL[prec]
+    atol *= max(1.0, (M / 3000) ** 0.5)              # fp32 accumulation over M terms: rounding grows ~ sqrt(M)
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=atol * ref.abs().max().item(), rtol=rtol)
     out2 = ops.gemm_tn(a.to(DEV), b.to(DEV), out=out.to(DEV).clone(), rows=rows.to(DEV), splits=splits, accumulate=True,
                        prec=prec).cpu()
     np.testing.assert_allclose(out2.numpy(), 2 * ref.numpy(), atol=2 * atol * ref.abs().max().item(), rtol=rtol)
+
+
+@pytest.mark.parametrize("M,N,K,gather", [(300, 512, 1024, False), (1000, 128, 64, True), (10000, 512, 1024, True)])
+def test_gemm_nt_paired_planes(M, N, K, gather):
+    """Both operands pre-split into paired bf16 planes: same result as the in-kernel 3-term split (to fp32 rounding)."""
+    ops = _ops()
+    a, b = rnd(31, (M + 40, K)).abs(), rnd(32, (N, K), std=0.05)
+    rows = torch.from_numpy(synth.permutation(33, M + 40)[:M].copy()) if gather else None
+    ref = (a[rows] if gather else a[:M]).double() @ b.double().t()
+    ap, bp = ops.pair_planes(a.to(DEV)), ops.pair_planes(b.to(DEV))
+    # the pairing itself: hi + lo reproduces x to ~2^-16 relative
+    v = ap.cpu().view(torch.bfloat16).view(M + 40, K // 8, 2, 8).float()
+    np.testing.assert_allclose((v[:, :, 0] + v[:, :, 1]).reshape(M + 40, K).numpy(), a.numpy(), rtol=2e-5, atol=1e-30)
+    out = ops.gemm_nt(ap, bp, rows=None if rows is None else rows.to(DEV), M=M, prec="bf16x3", paired=True).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.float().numpy(), atol=2e-5 * ref.abs().max().item(), rtol=1e-4)
+    plain = ops.gemm_nt(a.to(DEV), b.to(DEV), rows=None if rows is None else rows.to(DEV), M=M, prec="bf16x3").cpu()
+    np.testing.assert_allclose(out.numpy(), plain.numpy(), atol=2e-6 * ref.abs().max().item(), rtol=1e-5)
 
 
 def test_transpose():
