@@ -64,6 +64,8 @@ typedef struct {
   const uint64_t* drop_tick;                             /* optional device step counter mixed into drop_seed (graph replay) */
   const uint16_t* B_hi; const uint16_t* B_lo;            /* optional pre-split 16-bit planes of B [N,K] (mhimx_split_planes) */
   int32_t paired;                                        /* 1: A and B are paired-plane images made by mhimx_pair_planes      */
+  float* ws; int64_t ws_floats;                          /* optional scratch: lets a GEMM with few output tiles and a long K   */
+                                                         /* split its reduction over up to ws_floats/(M*N) slabs (epilogue-free calls) */
 } mhimx_gemm_nt_args;
 int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
 

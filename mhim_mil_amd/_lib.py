@@ -33,7 +33,7 @@ class GemmNT(C.Structure):
                 ("act", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p),
                 ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p), ("B_hi", C.c_void_p), ("B_lo", C.c_void_p),
-                ("paired", C.c_int32)]
+                ("paired", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
 
 
 class GemmTN(C.Structure):

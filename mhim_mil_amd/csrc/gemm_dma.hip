@@ -163,8 +163,11 @@ MHIMX_DEV void dma16(const float* src, char* lds_wave_base) {
 // 16 B of bf16 hi followed by 16 B of bf16 lo, i.e. the same 128 B per row per 32-deep k-step and therefore the SAME LDS
 // image, DMA pattern and swizzle as the fp32 form — but the two 16-B slots a lane reads ARE its (hi, lo) MFMA fragments:
 // no VALU conversion in the loop at all.
+// ksteps > 0: split-K form — blockIdx.y owns k-steps [y*ksteps, (y+1)*ksteps) and writes its raw partial tile to slab y
+// of g.ws ([M,N] each); reduce_slabs_kernel sums the slabs in a fixed order.  Used when a GEMM has few output tiles and a
+// long reduction (the K loop is a serial chain of DMA round trips; 32 tiles on 256 CUs leave the chip idle).
 template <int PREC, int NW, int PAIRED = 0>
-__global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args g) {
+__global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args g, int ksteps) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   constexpr int NT = NW == 4 ? 2 : 1;               // 32-column tiles per wave
@@ -234,7 +237,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
 
   // NSTAGE-deep LDS ring, ONE barrier per k-step, counted vmcnt so younger tiles stay in flight across it.
   // LDS reads are inline asm: a compiler-visible ds_read after an LDS-DMA makes hipcc drain the queue (vmcnt(0)).
-  const int nk = (int)(g.K / DBK);
+  const int nk_all = (int)(g.K / DBK);
+  const int kb = ksteps > 0 ? (int)blockIdx.y * ksteps : 0;
+  const int nk = ksteps > 0 ? (nk_all - kb < ksteps ? nk_all - kb : ksteps) : nk_all;
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) { asrc[j] += (int64_t)kb * DBK; bsrc[j] += (int64_t)kb * DBK; }
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue((int64_t)s * DBK, s);
@@ -279,8 +286,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
     frags(y);
   }
 
-  // ---- epilogue (same contract as gemm.hip)
   const int cl = lane & 31, rh = lane >> 5;
+  if (ksteps > 0) {                                      // split-K: raw partial tile -> slab blockIdx.y
+    float* slab = g.ws + (int64_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int64_t n = n0 + wn * (32 * NT) + nt * 32 + cl;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+          if (m < g.M) slab[m * g.N + n] = acc[mt][nt][e];
+        }
+      }
+    return;
+  }
+  // ---- epilogue (same contract as gemm.hip)
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -649,9 +672,39 @@ bool nt_dma_ok(const mhimx_gemm_nt_args& g) {
 #ifndef MHIMX_NT_WAVES
 #define MHIMX_NT_WAVES 8
 #endif
+__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2, int64_t ldc,
+                                    int splits, int accumulate, int64_t sC);
+
 int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
   constexpr int NW = MHIMX_NT_WAVES;
   dim3 grid((unsigned)(8 * cdiv(g.N, DBN) * cdiv(cdiv(g.M, DBM), 8)));
+  // split-K when the launch would leave most CUs idle behind a long serial K loop
+  int ksteps = 0, ksplit = 1;
+  {
+    const int64_t tiles = cdiv(g.N, DBN) * cdiv(g.M, DBM), nk = g.K / DBK;
+    const bool plain = !g.bias && !g.rowv && !g.pre && g.act == 0 && g.drop_p == 0.f && !g.drop_mask;
+    if (plain && g.ws && tiles <= 128 && nk >= 8) {
+      int64_t want = 256 / tiles;
+      if (want > nk / 4) want = nk / 4;
+      if (want > g.ws_floats / (g.M * g.N)) want = g.ws_floats / (g.M * g.N);
+      if (want >= 2) {
+        ksteps = (int)cdiv(nk, want);
+        ksplit = (int)cdiv(nk, ksteps);
+        grid.y = (unsigned)ksplit;
+      }
+    }
+  }
+  struct Reduce {
+    hipStream_t st; const mhimx_gemm_nt_args& g; int ksplit;
+    int run() const {
+      if (ksplit <= 1) return 0;
+      const int64_t n = g.M * g.N;
+      const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.M, g.N, g.ldc, ksplit, g.accumulate, (int64_t)0);
+      MHIMX_LAUNCH_CHECK();
+      return 0;
+    }
+  } reduce{st, g, ksplit};
   static bool attr = false;
   if (!attr) {
     MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
@@ -664,13 +717,13 @@ int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
       MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
       attr2 = true;
     }
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g, ksteps);
   } else if (g.prec == MHIMX_PREC_BF16X3)
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g, ksteps);
   else
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g, ksteps);
   MHIMX_LAUNCH_CHECK();
-  return 0;
+  return reduce.run();
 }
 
 bool tn_dma_ok(const mhimx_gemm_tn_args& g) {

@@ -321,6 +321,8 @@ struct MergeWs {
   float *stats, *pm, *pl, *po, *prd, *pdq;
   int nb;
   int64_t scratch_bytes;
+  float* nt_ws;
+  int64_t nt_ws_floats;
 };
 
 static int64_t merge_ws_layout(Arena& ar, int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dh, MergeWs* out) {
@@ -354,6 +356,8 @@ static int64_t merge_ws_layout(Arena& ar, int64_t R, int64_t E, int64_t k, int64
   w.pdq = ar.take<float>((int64_t)w.nb * k * I);
   w.scratch_bytes = 8 * 2 * I * E * 4;         // split-K slabs for dWkv (8 x [2I,E]) / colsum partials
   w.scratch = (float*)ar.take<char>(w.scratch_bytes);
+  w.nt_ws_floats = 8 * R * (2 * I > E ? 2 * I : E);      // split-K slabs of the two row GEMMs (few tiles, long K)
+  w.nt_ws = ar.take<float>(w.nt_ws_floats);
   if (out) *out = w;
   return ar.off;
 }
@@ -379,6 +383,7 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   if (int r = layernorm_fwd(st, m->q_param, k, E, m->ln_w, m->ln_b, w.gq, w.gmean, w.grstd)) return r;
   mhimx_gemm_nt_args g = {};
   g.A = w.xn; g.lda = E; g.B = m->wkv; g.ldb = E; g.C = w.KV; g.ldc = 2 * I; g.M = R; g.N = 2 * I; g.K = E; g.prec = fprec;
+  g.ws = w.nt_ws; g.ws_floats = w.nt_ws_floats;
   if (int r = gemm_nt(st, g)) return r;
   g = {};
   g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
@@ -447,6 +452,7 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   // projections
   g = {};
   g.A = w.dKV; g.lda = 2 * I; g.B = m->wkv_t; g.ldb = 2 * I; g.C = w.dxn; g.ldc = E; g.M = R; g.N = E; g.K = 2 * I; g.prec = gprec;
+  g.ws = w.nt_ws; g.ws_floats = w.nt_ws_floats;
   if (int r = gemm_nt(st, g)) return r;
   t = {};
   t.A = w.dKV; t.lda = 2 * I; t.B = w.xn; t.ldb = E; t.C = gr->d_wkv; t.ldc = E; t.M = R; t.K1 = 2 * I; t.K2 = E;

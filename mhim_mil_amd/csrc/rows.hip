@@ -13,6 +13,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
+constexpr int TN_SLABS = 64;           // split-reduction slabs for d_wa = du^T T (fills the chip: 4 tiles x 64 = 256 workgroups)
 
 MHIMX_DEV float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -423,7 +424,7 @@ static int grid_for_rows(int64_t M) {
 }
 
 struct PoolWs {
-  float *pm, *pl, *pz, *attn, *du, *dwc_part, *dbc_part, *u_pre;
+  float *pm, *pl, *pz, *attn, *du, *dwc_part, *dbc_part, *u_pre, *tn_ws, *nt_ws;
 };
 
 static int64_t pool_ws_layout(Arena& ar, int64_t M, int64_t E, int64_t A, int gated, PoolWs* w) {
@@ -437,6 +438,8 @@ static int64_t pool_ws_layout(Arena& ar, int64_t M, int64_t E, int64_t A, int ga
   t.dwc_part = ar.take<float>(G * A);
   t.dbc_part = ar.take<float>(G);
   t.u_pre = ar.take<float>(M * A * (1 + gated));
+  t.tn_ws = ar.take<float>((int64_t)TN_SLABS * A * E);
+  t.nt_ws = ar.take<float>(4 * M * A);                  // split-K slabs of the scorer GEMM (79 tiles at N = 10 000)
   if (w) *w = t;
   return ar.off;
 }
@@ -481,6 +484,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     mhimx_gemm_nt_args g = {};
     g.A = Ts[seg]; g.lda = E; g.B = sc->wa; g.ldb = E; g.C = u_pre + off * ldu; g.ldc = ldu;
     g.M = Ms[seg]; g.N = A; g.K = E; g.bias = sc->ba;
+    g.ws = w.nt_ws; g.ws_floats = 4 * M * A;
     // instance-level scores feed the top-k: keep them at ~fp32 accuracy (3-term bf16) unless exact f32 was asked for
     g.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
     if (int r = gemm_nt(st, g)) return r;
@@ -570,11 +574,11 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     t.A = w.du + off * ldu; t.lda = ldu; t.B = Ts[seg]; t.ldb = E; t.C = gr->d_wa; t.ldc = E;
     t.M = Ms[seg]; t.K1 = A; t.K2 = E; t.splits = 1; t.accumulate = (gr->accumulate || seg > 0) ? 1 : 0;
     t.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
-    // split the long reduction over the pz scratch (free at this point): needs splits*A*E floats
+    // split the long reduction (the library raises the slab count until the launch fills the chip, up to the workspace)
     int splits = gr->splits > 1 ? gr->splits : 1;
-    while (splits > 1 && (int64_t)splits * A * E > (int64_t)2 * MAX_PART * E) splits >>= 1;
+    if (splits > TN_SLABS) splits = TN_SLABS;
     if (Ms[seg] < 2048) splits = 1;
-    t.splits = splits; t.ws = w.pz; t.ws_floats = (int64_t)2 * MAX_PART * E;
+    t.splits = splits; t.ws = w.tn_ws; t.ws_floats = (int64_t)TN_SLABS * A * E;
     if (int r = gemm_tn(st, t)) return r;
     if (gated) {
       t.A = w.du + off * ldu + A; t.C = gr->d_wb;

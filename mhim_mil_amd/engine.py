@@ -153,6 +153,7 @@ class FusedTrainer:
             teacher._tick = self.tick
         self._graph_pool = None
         self._cap_stream = None
+        self._side = None
 
     def _dist(self):
         return torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -163,12 +164,19 @@ class FusedTrainer:
         s, t, fl = self.s, self.t, self.flat
         ops.tick(self.tick)
         x = s._check_x(bag)
+        # parameter-only preparation of the step: weight transposes, paired-plane weights, query snapshot
+        # (kept on the launch stream: a parallel branch in the captured hipGraph costs ~60 us of cross-queue signalling on
+        # ROCm 7.2 — measured, profiles/ r01 notes — against ~40 us of kernels it would hide)
+        prep_s = prep_t = None
+        if s.baseline == "attn":
+            prep_t = t.prepare_step(backward=False) if self.model_kind == "mhim" else None
+            prep_s = s.prepare_step(backward=True)
         ps = x.shape[0]
         first = self._micro == 0
         gv = fl.grad_views
         xp = s._pair(x) if s.baseline == "attn" else None        # one bf16 hi/lo image of the bag for both projections
         if self.model_kind == "mhim":
-            teacher_feat, score = t.forward_teacher(x, xp=xp)
+            teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"])
             rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle)
             plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True)
             keep_num = Lk + s.merge.k
@@ -183,7 +191,7 @@ class FusedTrainer:
         if self.model_kind != "mhim":
             s.merge_enable = False
         try:
-            z, saved = s._bag_forward(x, plan, xp=xp)
+            z, saved = s._bag_forward(x, plan, xp=xp, prep=prep_s)
             t_in = teacher_feat.view(-1) if (teacher_feat is not None and self.aux_alpha != 0.) else None
             logits, losses, g_z, _, _ = ops.head_fwd_bwd(
                 z, t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),

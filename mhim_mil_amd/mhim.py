@@ -267,10 +267,29 @@ class MHIM(nn.Module):
                                wb=att.attention_b[0].weight.data, prec=self._op_prec)
         return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec)
 
-    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None):
+    def prepare_step(self, backward=True):
+        """Parameter-only work of one step — weight transposes for the dX GEMMs, the paired-plane image of the projection
+        weight, a snapshot of the global queries — as a dict the forward/backward use instead of recomputing.  It depends on
+        nothing but the parameters, so a trainer runs it on a side stream beside the teacher's projection."""
+        prep = {"w1p": ops.pair_planes(self.feature[0].weight.data) if self._feature_prec(1 << 20) == "bf16x3"
+                and self.input_dim % 32 == 0 else None}
+        if backward and self.baseline == "attn":
+            att = self.online_encoder.attention
+            if self.online_encoder.gated:
+                prep["wa_t"] = ops.transpose(att.attention_a[0].weight.data)
+                prep["wb_t"] = ops.transpose(att.attention_b[0].weight.data)
+            else:
+                prep["wa_t"] = ops.transpose(att.attention[0].weight.data)
+            if self.merge_enable:
+                m = self.merge
+                prep["merge_t"] = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
+                                   ops.transpose(m.attn.to_out[0].weight.data))
+                prep["q_old"] = m.global_q_mm.data.clone()
+        return prep
+
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None):
         m = self.merge
-        tr = None
-        if need_t:
+        if need_t and tr is None:
             tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
                   ops.transpose(m.attn.to_out[0].weight.data))
         drop = m.dropout if (plan is not None and plan.training) else 0.0
@@ -299,14 +318,14 @@ class MHIM(nn.Module):
         return ops.pair_planes(x)
 
     def _feature(self, x, rows=None, drop_p=0.0, drop_seed=0, drop_mask=None, want_pre=False, out=None, pre_out=None, M=None,
-                 xp=None):
+                 xp=None, w1p=None):
         f = self.feature[0]
         act = L.act_code(self.act, _FEATURE_ACTS)
         nrows = M if M is not None else (rows.shape[0] if rows is not None else x.shape[0])
         if xp is None and nrows >= 1024:
             xp = self._pair(x)
         if xp is not None and nrows > 16:
-            return ops.gemm_nt(xp, ops.pair_planes(f.weight.data), out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out,
+            return ops.gemm_nt(xp, w1p if w1p is not None else ops.pair_planes(f.weight.data), out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out,
                                drop_p=drop_p, drop_seed=drop_seed, drop_mask=drop_mask, prec="bf16x3", M=M, drop_tick=self._tick,
                                paired=True)
         return ops.gemm_nt(x, f.weight.data, out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out, drop_p=drop_p,
@@ -331,7 +350,8 @@ class MHIM(nn.Module):
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ student bag forward / backward
-    def _bag_forward(self, x, plan: BagPlan, xp=None):
+    def _bag_forward(self, x, plan: BagPlan, xp=None, prep=None):
+        prep = prep or {}
         E = self.mlp_dim
         Lrows = plan.L
         dev = x.device
@@ -339,14 +359,17 @@ class MHIM(nn.Module):
         H = torch.empty((Lrows, E), device=dev)
         PRE = torch.empty((Lrows, E), device=dev) if need_pre else None
         p = self.dropout_p if plan.training else 0.0
-        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp)
-        saved = {"H": H, "PRE": PRE}
+        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp, w1p=prep.get("w1p"))
+        saved = {"H": H, "PRE": PRE, "prep": prep}
         sc = self._scorer()
         if self.merge_enable and plan.R > 0:
             mw = self._merge_w(plan, need_t=False)
             z_tok, q_new, mws = ops.merge_fwd(mw, H[plan.Lk:], update_q=plan.training)
             st = ops.abmil_pool_fwd(sc, H[:plan.Lk], z_tok)
-            saved.update(z_tok=z_tok, mws=mws, q_old=self.merge.global_q_mm.data.clone() if plan.training else None)
+            q_old = prep.get("q_old")
+            if q_old is None and plan.training:
+                q_old = self.merge.global_q_mm.data.clone()
+            saved.update(z_tok=z_tok, mws=mws, q_old=q_old)
             if plan.training:                       # in-forward EMA of the global queries (merge.py:142-143)
                 self.merge.global_q_mm.data.copy_(q_new.view_as(self.merge.global_q_mm))
         else:
@@ -360,6 +383,7 @@ class MHIM(nn.Module):
         E = self.mlp_dim
         dev = x.device
         H, PRE, st = saved["H"], saved["PRE"], saved["pool"]
+        prep = saved.get("prep") or {}
         sc = self._scorer()
         att = self.online_encoder.attention
         dH = torch.empty_like(H)
@@ -372,19 +396,20 @@ class MHIM(nn.Module):
             if pre + nm in out:
                 pool_g[key] = out[pre + nm]
         if self.online_encoder.gated:
-            g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(att.attention_a[0].weight.data),
-                                   ops.transpose(att.attention_b[0].weight.data), grads=pool_g)
+            g = ops.abmil_pool_bwd(sc, st, g_z, prep.get("wa_t") if "wa_t" in prep else ops.transpose(att.attention_a[0].weight.data),
+                                   prep.get("wb_t") if "wb_t" in prep else ops.transpose(att.attention_b[0].weight.data), grads=pool_g)
             grads["online_encoder.attention.attention_a.0.weight"] = g["d_wa"]
             grads["online_encoder.attention.attention_b.0.weight"] = g["d_wb"]
             grads["online_encoder.attention.attention_c.weight"] = g["d_wc"]
         else:
-            g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(att.attention[0].weight.data), grads=pool_g)
+            g = ops.abmil_pool_bwd(sc, st, g_z, prep.get("wa_t") if "wa_t" in prep else ops.transpose(att.attention[0].weight.data),
+                                   grads=pool_g)
             grads["online_encoder.attention.attention.0.weight"] = g["d_wa"]
             grads["online_encoder.attention.attention.2.weight"] = g["d_wc"]
         if self.merge_enable and plan.R > 0:
             # LayerNorm(global_q) backward uses the PRE-update queries (the reference sees post-update values through
             # an in-place .data write, a 1e-4-relative quirk: SURVEY.md §7 H7)
-            mw = self._merge_w(plan, need_t=True, q=saved["q_old"])
+            mw = self._merge_w(plan, need_t=True, q=saved["q_old"], tr=prep.get("merge_t"))
             mgr = {"dX": dH[plan.Lk:]}
             for key, nm in (("d_ln_w", "merge.norm.weight"), ("d_ln_b", "merge.norm.bias"), ("d_wkv", "merge.attn.to_kv.weight"),
                             ("d_wq", "merge.attn.to_q.weight"), ("d_wo", "merge.attn.to_out.0.weight"),
@@ -505,10 +530,10 @@ class MHIM(nn.Module):
 
     # ------------------------------------------------------------------ reference entry points
     @torch.no_grad()
-    def forward_teacher(self, x, drop_mask=None, xp=None):
+    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None):
         x = self._check_x(x)
         p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
-        H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp)
+        H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp, w1p=w1p)
         p0 = H.shape[0]
         T2 = None
         if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)
