@@ -105,6 +105,13 @@ int mhimx_split_planes(void* stream, const float* w, uint16_t* hi, uint16_t* lo,
  * inner loop; the bag X is paired once per step and shared by the teacher's and the student's projection. */
 int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int64_t K, float* out);
 
+/* The parameter-only preparation of one train step as ONE launch (each tiny kernel costs ~5 us of dispatch latency on the
+ * step's serial chain): up to MHIMX_PREP_MAX jobs of kind 0 = transpose in[R,C] -> out[C,R], 1 = paired planes of in[R,C],
+ * 2 = copy R*C floats, 3 = *(uint64_t*)out += 1 (the device-resident dropout / Adam step counters). */
+#define MHIMX_PREP_MAX 12
+typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
+int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
+
 /* out[c,r] = in[r,c]  (weights are transposed once per step so that dX = dY W is also an NT GEMM) */
 int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C);
 

@@ -36,6 +36,10 @@ class GemmNT(C.Structure):
                 ("paired", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
 
 
+class PrepJob(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("inp", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64), ("C", C.c_int64)]
+
+
 class GemmTN(C.Structure):
     _fields_ = [("A", c_f32p), ("lda", C.c_int64),
                 ("B", c_f32p), ("ldb", C.c_int64), ("rows", c_i64p),
@@ -88,6 +92,7 @@ SYMBOLS = {
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
     "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),
+    "mhimx_prep_batch": (C.c_int, [_P, C.POINTER(PrepJob), _I32]),
     "mhimx_pair_planes": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
     "mhimx_lse_merge": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "mhimx_gemm_batched": (C.c_int, [_P, _I32, C.POINTER(GemmNT), _I32, _I64, _I64, _I64, _F, _I32, _P]),

@@ -30,6 +30,7 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_a
 bool nt_planes_ok(const mhimx_gemm_nt_args& g);
 int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g);
 int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t K, float* out);
+int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);
 bool feat_gemm_ok(const mhimx_gemm_nt_args& g);
 int feat_gemm(hipStream_t st, const mhimx_gemm_nt_args& g);
 int split_planes(hipStream_t st, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int prec);
@@ -678,6 +679,9 @@ int transpose(hipStream_t st, const float* in, float* out, int64_t R, int64_t C)
 extern "C" int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_nt: null args");
   return mhimx::gemm_nt((hipStream_t)stream, *a);
+}
+extern "C" int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n) {
+  return mhimx::prep_batch((hipStream_t)stream, jobs, n);
 }
 extern "C" int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int64_t K, float* out) {
   return mhimx::pair_planes((hipStream_t)stream, x, ldx, M, K, out);

@@ -385,7 +385,15 @@ __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_arg
   const int nk = (nrows + DBK - 1) / DBK;
   if (nk > 0) issue(0, 0);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+    // tile t must have landed for EVERY wave before anyone reads it: each wave drains its own tile-t DMAs (all but the 8
+    // instructions of tile t+1 it issues now), THEN the barrier.  (Waiting after the barrier only covers a wave's own
+    // DMAs — on a cold first tile another wave's rows could still be in flight.)
+    if (t + 1 < nk) {
+      issue(t + 1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const float* sa = reinterpret_cast<const float*>(smem + (t & 1) * STAGE_BYTES);
@@ -660,6 +668,63 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
   int64_t blocks = cdiv(n, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(pair_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, M, K / 8, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+// One launch for the parameter-only preparation of a train step: blockIdx.y = job.  kind 0: out[c,r] = in[r,c];
+// kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters).
+struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int n; };
+__global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
+  const mhimx_prep_job jb = pj.j[blockIdx.y];
+  const int64_t R = jb.R, C = jb.C;
+  if (jb.kind == 0) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                   // 32 x 8
+    const int64_t tiles_c = (C + 31) / 32, ntiles = ((R + 31) / 32) * tiles_c;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int64_t r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+      for (int i = ty; i < 32; i += 8) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? jb.in[r * C + c] : 0.f;
+      }
+      __syncthreads();
+      for (int i = ty; i < 32; i += 8) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) jb.out[c * R + r] = tile[tx][i];
+      }
+      __syncthreads();
+    }
+  } else if (jb.kind == 1) {
+    const int64_t K8 = C / 8, n = R * K8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const f4 a = *reinterpret_cast<const f4*>(jb.in + i * 8);
+      const f4 b = *reinterpret_cast<const f4*>(jb.in + i * 8 + 4);
+      b8 hi, lo;
+      Frag<MHIMX_PREC_BF16X3>::split2(a, b, hi, lo);
+      f4* o = reinterpret_cast<f4*>(jb.out + i * 8);
+      o[0] = __builtin_bit_cast(f4, hi);
+      o[1] = __builtin_bit_cast(f4, lo);
+    }
+  } else if (jb.kind == 2) {
+    const int64_t n = R * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) jb.out[i] = jb.in[i];
+  } else if (jb.kind == 3) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint64_t*>(jb.out) += 1;
+  }
+}
+int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
+  MHIMX_CHECK_ARG(jobs && n >= 1 && n <= MHIMX_PREP_MAX, "prep_batch: 1..%d jobs", MHIMX_PREP_MAX);
+  PrepJobs pj;
+  pj.n = n;
+  for (int i = 0; i < n; ++i) {
+    pj.j[i] = jobs[i];
+    MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 3, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
+                    "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
+  }
+  hipLaunchKernelGGL(prep_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, pj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

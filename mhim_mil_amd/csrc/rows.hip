@@ -234,6 +234,31 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
   }
 }
 
+// two independent partial sets in one launch (blockIdx.y selects): LayerNorm's d_w and d_b
+__global__ __launch_bounds__(RP_THREADS) void reduce_parts2_kernel(const float* __restrict__ part0, const float* __restrict__ part1,
+                                                                    int G, int W, int ld, float* __restrict__ out0,
+                                                                    float* __restrict__ out1, int accumulate) {
+  __shared__ float red[32][33];
+  const float* part = blockIdx.y ? part1 : part0;
+  float* out = blockIdx.y ? out1 : out0;
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  for (int j0 = blockIdx.x * 32; j0 < W; j0 += gridDim.x * 32) {
+    const int j = j0 + c;
+    float acc = 0.f;
+    if (j < W)
+      for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * ld + j];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (rg == 0 && j < W) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v += red[q][c];
+      out[j] = accumulate ? out[j] + v : v;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void softmax_from_stats_kernel(const float* __restrict__ s, const float* __restrict__ stats,
                                           float* __restrict__ attn, int64_t M) {
   const float mx = stats[0], invL = 1.f / stats[1];
@@ -626,9 +651,8 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
                      w, mean, rstd, dx, dw_part, db_part);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, st, dw_part, grid, (int)E, (int)E, d_w, accumulate);
-  MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, st, db_part, grid, (int)E, (int)E, d_b, accumulate);
+  hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(E, 32), 2), dim3(RP_THREADS), 0, st, dw_part, db_part, grid, (int)E, (int)E,
+                     d_w, d_b, accumulate);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -162,15 +162,22 @@ class FusedTrainer:
     def forward_backward(self, bag, label, perm=None, ids_shuffle=None, i=None):
         """Teacher fwd + select + student fwd + head + backward into the flat gradient buffer (accumulating)."""
         s, t, fl = self.s, self.t, self.flat
-        ops.tick(self.tick)
         x = s._check_x(bag)
         # parameter-only preparation of the step: weight transposes, paired-plane weights, query snapshot
         # (kept on the launch stream: a parallel branch in the captured hipGraph costs ~60 us of cross-queue signalling on
         # ROCm 7.2 — measured, profiles/ r01 notes — against ~40 us of kernels it would hide)
+        # together with the two device counters (dropout stream position, Adam step) it is ONE launch
         prep_s = prep_t = None
+        jobs = [(ops.PREP_TICK, None, self.tick)]
+        if self._micro == 0:
+            jobs.append((ops.PREP_TICK, None, self.opt_step))
         if s.baseline == "attn":
-            prep_t = t.prepare_step(backward=False) if self.model_kind == "mhim" else None
-            prep_s = s.prepare_step(backward=True)
+            if self.model_kind == "mhim":
+                jt, prep_t = t.prep_jobs(backward=False)
+                jobs += jt
+            js, prep_s = s.prep_jobs(backward=True)
+            jobs += js
+        ops.prep_batch(jobs)
         ps = x.shape[0]
         first = self._micro == 0
         gv = fl.grad_views
@@ -240,8 +247,7 @@ class FusedTrainer:
         """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
         fl = self.flat
         scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
-        fl.step += 1
-        ops.tick(self.opt_step)
+        fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
         ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                      fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
                      grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step)

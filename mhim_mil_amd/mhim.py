@@ -267,24 +267,38 @@ class MHIM(nn.Module):
                                wb=att.attention_b[0].weight.data, prec=self._op_prec)
         return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec)
 
-    def prepare_step(self, backward=True):
-        """Parameter-only work of one step — weight transposes for the dX GEMMs, the paired-plane image of the projection
-        weight, a snapshot of the global queries — as a dict the forward/backward use instead of recomputing.  It depends on
-        nothing but the parameters, so a trainer runs it on a side stream beside the teacher's projection."""
-        prep = {"w1p": ops.pair_planes(self.feature[0].weight.data) if self._feature_prec(1 << 20) == "bf16x3"
-                and self.input_dim % 32 == 0 else None}
+    def prep_jobs(self, backward=True):
+        """Parameter-only work of one step — the paired-plane image of the projection weight, weight transposes for the dX
+        GEMMs, a snapshot of the global queries — as (jobs for ops.prep_batch, dict of their outputs).  It depends on nothing
+        but the parameters, so a trainer folds the teacher's and the student's jobs and its step counters into ONE launch."""
+        jobs, prep = [], {"w1p": None}
+        w1 = self.feature[0].weight.data
+        if self._feature_prec(1 << 20) == "bf16x3" and self.input_dim % 32 == 0:
+            prep["w1p"] = torch.empty_like(w1)
+            jobs.append((ops.PREP_PAIR, w1, prep["w1p"]))
+
+        def tr(w):
+            out = torch.empty((w.shape[1], w.shape[0]), device=w.device)
+            jobs.append((ops.PREP_TRANSPOSE, w, out))
+            return out
+
         if backward and self.baseline == "attn":
             att = self.online_encoder.attention
             if self.online_encoder.gated:
-                prep["wa_t"] = ops.transpose(att.attention_a[0].weight.data)
-                prep["wb_t"] = ops.transpose(att.attention_b[0].weight.data)
+                prep["wa_t"], prep["wb_t"] = tr(att.attention_a[0].weight.data), tr(att.attention_b[0].weight.data)
             else:
-                prep["wa_t"] = ops.transpose(att.attention[0].weight.data)
+                prep["wa_t"] = tr(att.attention[0].weight.data)
             if self.merge_enable:
                 m = self.merge
-                prep["merge_t"] = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
-                                   ops.transpose(m.attn.to_out[0].weight.data))
-                prep["q_old"] = m.global_q_mm.data.clone()
+                prep["merge_t"] = (tr(m.attn.to_kv.weight.data), tr(m.attn.to_q.weight.data), tr(m.attn.to_out[0].weight.data))
+                prep["q_old"] = torch.empty_like(m.global_q_mm.data)
+                jobs.append((ops.PREP_COPY, m.global_q_mm.data, prep["q_old"]))
+        return jobs, prep
+
+    def prepare_step(self, backward=True):
+        jobs, prep = self.prep_jobs(backward)
+        if jobs:
+            ops.prep_batch(jobs)
         return prep
 
     def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None):

@@ -71,6 +71,23 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
     return out
 
 
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK = 0, 1, 2, 3
+
+
+def prep_batch(jobs):
+    """jobs: list of (kind, in_tensor | None, out_tensor) -> ONE launch.  kind: PREP_TRANSPOSE (out = in^T), PREP_PAIR
+    (paired bf16 planes), PREP_COPY, PREP_TICK (out: int64/uint64 [1] counter += 1)."""
+    arr = (L.PrepJob * len(jobs))()
+    for i, (kind, src, dst) in enumerate(jobs):
+        if kind == PREP_TICK:
+            arr[i] = L.PrepJob(kind, None, _p(dst), 1, 1)
+        else:
+            _chk(src, name="prep in"); _chk(dst, name="prep out")
+            R, Cc = (src.shape[0], src.numel() // src.shape[0]) if src.dim() >= 2 else (1, src.numel())
+            arr[i] = L.PrepJob(kind, _p(src), _p(dst), R, Cc)
+    L.check(L.lib().mhimx_prep_batch(_stream(), arr, len(jobs)), "mhimx_prep_batch")
+
+
 def pair_planes(x):
     """x [M,K] fp32 -> its paired-plane image (same shape; 8 bf16 hi | 8 bf16 lo per 8 consecutive k) for gemm_nt(paired=True)."""
     _chk(x, name="x")
