@@ -215,38 +215,82 @@ MHIMX_DEV uint32_t block_scan_excl(uint32_t v, uint32_t* wave_tot /*[16] LDS*/, 
 }
 
 // radix select over register-resident keys: returns the k-th largest key T among the valid ones and, in *remaining,
-// how many T-valued keys belong to the top-k.  hist: [16][256] LDS, misc: [>=2] LDS.
+// how many T-valued keys belong to the top-k.  hist: [16][256] LDS, misc: [>=8] LDS.
+// Scores are low-entropy in their leading bits (a softmax-derived score in [0.5, 1) has 9 identical leading bits): a
+// histogram pass over such a digit is 64 lanes x 10 keys of LDS atomics on ONE address.  So the passes start at the
+// highest bit in which the block's keys actually differ (min ^ max), and a digit is 8 bits of real entropy.
 template <int KPT>
 MHIMX_DEV uint32_t radix_select_regs(const uint32_t (&key)[KPT], const bool (&valid)[KPT], uint32_t k, uint32_t* hist,
                                      uint32_t* misc, uint32_t* remaining_out) {
-  const int tid = threadIdx.x, wave = tid >> 6;
-  uint32_t prefix = 0, remaining = k;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // ---- block min / max of the valid keys
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+  for (int j = 0; j < KPT; ++j)
+    if (valid[j]) { mn = key[j] < mn ? key[j] : mn; mx = key[j] > mx ? key[j] : mx; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_xor((int)mn, o, 64), c = (uint32_t)__shfl_xor((int)mx, o, 64);
+    mn = a < mn ? a : mn;
+    mx = c > mx ? c : mx;
+  }
+  if (lane == 0) { hist[wave] = mn; hist[SEL_WAVES + wave] = mx; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < SEL_WAVES; ++w) {
+    const uint32_t a = hist[w], c = hist[SEL_WAVES + w];
+    mn = a < mn ? a : mn;
+    mx = c > mx ? c : mx;
+  }
+  __syncthreads();
+  const uint32_t diff = mn ^ mx;
+  if (diff == 0u) {                          // every key equal
+    *remaining_out = k;
+    return mx;
+  }
+  const int hb = 31 - __clz(diff);           // highest differing bit
+  uint32_t prefix = hb >= 31 ? 0u : (mx & ~((2u << hb) - 1u));     // the common leading bits
+  uint32_t remaining = k;
+  int shift = hb - 7 < 0 ? 0 : hb - 7;
+  uint32_t fixed_mask = hb >= 31 ? 0u : ~((2u << hb) - 1u);        // bits already decided
+  while (true) {
     for (int i = tid; i < SEL_WAVES * 256; i += SEL_THREADS) hist[i] = 0;
     __syncthreads();
-    const uint32_t hmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
-      if (valid[j] && (key[j] & hmask) == prefix) atomicAdd(&hist[wave * 256 + ((key[j] >> shift) & 255u)], 1u);
+      if (valid[j] && (key[j] & fixed_mask) == prefix) atomicAdd(&hist[wave * 256 + ((key[j] >> shift) & 255u)], 1u);
     __syncthreads();
+    uint32_t cnt = 0;
     if (tid < 256) {
-      uint32_t c = 0;
 #pragma unroll
-      for (int w = 0; w < SEL_WAVES; ++w) c += hist[w * 256 + tid];
-      hist[tid] = c;
+      for (int w = 0; w < SEL_WAVES; ++w) cnt += hist[w * 256 + tid];
     }
     __syncthreads();
-    if (tid < 256) {                       // every bin computes the population above it: no serial scan
-      uint32_t above = 0;
-      for (int d = tid + 1; d < 256; ++d) above += hist[d];
-      const uint32_t mine = hist[tid];
-      if (above < remaining && remaining <= above + mine) { misc[0] = (uint32_t)tid; misc[1] = remaining - above; }
+    // population ABOVE each bin: suffix sum over the 256 bins held by threads 0..255 (4 waves): wave-level shuffle scan
+    // plus the totals of the higher waves
+    if (tid < 256) {
+      uint32_t inc = cnt;                    // inclusive suffix sum inside the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t dn = (uint32_t)__shfl_down((int)inc, o, 64);
+        if (lane + o < 64) inc += dn;
+      }
+      if (lane == 0) hist[wave] = inc;       // wave total (bins wave*64 .. wave*64+63)
+      hist[256 + tid] = inc - cnt;           // population above, within the wave
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t above = hist[256 + tid];
+      for (int w = wave + 1; w < 4; ++w) above += hist[w];
+      if (above < remaining && remaining <= above + cnt) { misc[0] = (uint32_t)tid; misc[1] = remaining - above; }
     }
     __syncthreads();
     prefix |= misc[0] << shift;
     remaining = misc[1];
+    fixed_mask |= 0xFFu << shift;
     __syncthreads();
+    if (shift == 0) break;
+    shift = shift - 8 < 0 ? 0 : shift - 8;
   }
   *remaining_out = remaining;
   return prefix;
