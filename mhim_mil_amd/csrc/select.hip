@@ -60,38 +60,67 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(
   const bool lg = largest != 0;
 
   // ---- 1. radix select ------------------------------------------------------------------------
-  uint32_t prefix = 0, remaining = (uint32_t)k;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    for (int i = tid; i < SEL_WAVES * 256; i += SEL_THREADS) hist[i] = 0;
-    __syncthreads();
-    const uint32_t hmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int64_t i = tid; i < N; i += SEL_THREADS) {
-      const uint32_t key = mono32(score[i], lg);
-      if ((key & hmask) == prefix) atomicAdd(&hist[wave * 256 + ((key >> shift) & 255u)], 1u);
-    }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t c = 0;
+  // passes start at the highest bit in which the keys differ (see radix_select_regs): a score in [0.5, 1) has 9 common
+  // leading bits, and a histogram pass over a constant digit is N LDS atomics on one address
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  for (int64_t i = tid; i < N; i += SEL_THREADS) {
+    const uint32_t key = mono32(score[i], lg);
+    mn = key < mn ? key : mn;
+    mx = key > mx ? key : mx;
+  }
 #pragma unroll
-      for (int w = 0; w < SEL_WAVES; ++w) c += hist[w * 256 + tid];
-      hist[tid] = c;                       // bins of wave 0 now hold the totals
-    }
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t above = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (above + hist[d] >= remaining) break;
-        above += hist[d];
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_xor((int)mn, o, 64), c = (uint32_t)__shfl_xor((int)mx, o, 64);
+    mn = a < mn ? a : mn;
+    mx = c > mx ? c : mx;
+  }
+  if (lane == 0) { hist[wave] = mn; hist[SEL_WAVES + wave] = mx; }
+  __syncthreads();
+  for (int w = 0; w < SEL_WAVES; ++w) {
+    const uint32_t a = hist[w], c = hist[SEL_WAVES + w];
+    mn = a < mn ? a : mn;
+    mx = c > mx ? c : mx;
+  }
+  __syncthreads();
+  uint32_t prefix = mx, remaining = (uint32_t)k;
+  if (mn != mx) {
+    const int hb = 31 - __clz(mn ^ mx);
+    uint32_t fixed_mask = hb >= 31 ? 0u : ~((2u << hb) - 1u);
+    prefix = mx & fixed_mask;
+    int shift = hb - 7 < 0 ? 0 : hb - 7;
+    while (true) {
+      for (int i = tid; i < SEL_WAVES * 256; i += SEL_THREADS) hist[i] = 0;
+      __syncthreads();
+      for (int64_t i = tid; i < N; i += SEL_THREADS) {
+        const uint32_t key = mono32(score[i], lg);
+        if ((key & fixed_mask) == prefix) atomicAdd(&hist[wave * 256 + ((key >> shift) & 255u)], 1u);
       }
-      misc[0] = (uint32_t)d;
-      misc[1] = remaining - above;
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < SEL_WAVES; ++w) c += hist[w * 256 + tid];
+        hist[tid] = c;                       // bins of wave 0 now hold the totals
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t above = 0;
+        int d = 255;
+        for (; d > 0; --d) {
+          if (above + hist[d] >= remaining) break;
+          above += hist[d];
+        }
+        misc[0] = (uint32_t)d;
+        misc[1] = remaining - above;
+      }
+      __syncthreads();
+      prefix |= misc[0] << shift;
+      remaining = misc[1];
+      fixed_mask |= 0xFFu << shift;
+      __syncthreads();
+      if (shift == 0) break;
+      shift = shift - 8 < 0 ? 0 : shift - 8;
     }
-    __syncthreads();
-    prefix |= misc[0] << shift;
-    remaining = misc[1];
-    __syncthreads();
   }
   const uint32_t T = prefix;                 // k-th largest key; `remaining` T-valued elements are in the top-k
 
