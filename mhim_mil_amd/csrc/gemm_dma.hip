@@ -43,6 +43,7 @@ constexpr int NSTAGE = MHIMX_NT_STAGES;           // LDS ring depth of the NT ke
                :                                                                                                      \
                : "memory")
 
+constexpr int TN_STAGES = 2;                       // LDS ring depth of the TN kernel (x 32 KiB)
 constexpr int MAX_TN_CHUNK = 4096;                 // rows of the reduction one workgroup may own (row-id table in LDS)
 
 __device__ float g_zero_row[256];                  // 1 KiB of zeros: source for out-of-range reduction rows
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_arg
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int64_t* rowtab = reinterpret_cast<int64_t*>(smem + 2 * STAGE_BYTES);       // [mchunk] B-row element offsets
+  int64_t* rowtab = reinterpret_cast<int64_t*>(smem + TN_STAGES * STAGE_BYTES);       // [mchunk] B-row element offsets
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware order: all output tiles of one reduction slab run on one XCD (its rows of A and B are shared via L2)
@@ -383,20 +384,19 @@ __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_arg
 
   const int r = lane & 31, kh = lane >> 5;
   const int nk = (nrows + DBK - 1) / DBK;
-  if (nk > 0) issue(0, 0);
+  // TN_STAGES-deep ring: tiles t+1 .. t+TN_STAGES-1 are in flight while tile t is consumed.  Tile t must have landed for
+  // EVERY wave before anyone reads it: each wave drains its own DMAs down to the younger tiles (8 instructions per tile),
+  // THEN the barrier.  (Waiting after the barrier only covers a wave's own DMAs — on a cold first tile another wave's
+  // rows could still be in flight: a race the 70 000-row test caught.)
+  for (int t = 0; t < TN_STAGES - 1 && t < nk; ++t) issue(t, t);
   for (int t = 0; t < nk; ++t) {
-    // tile t must have landed for EVERY wave before anyone reads it: each wave drains its own tile-t DMAs (all but the 8
-    // instructions of tile t+1 it issues now), THEN the barrier.  (Waiting after the barrier only covers a wave's own
-    // DMAs — on a cold first tile another wave's rows could still be in flight.)
-    if (t + 1 < nk) {
-      issue(t + 1, (t + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+    const int younger = (nk - 1 - t) < (TN_STAGES - 2) ? (nk - 1 - t) : (TN_STAGES - 2);
+    if (younger >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // tile t landed everywhere; everyone has left tile t-1's stage
+    if (t + TN_STAGES - 1 < nk) issue(t + TN_STAGES - 1, (t + TN_STAGES - 1) % TN_STAGES);
     asm volatile("" ::: "memory");
-    const float* sa = reinterpret_cast<const float*>(smem + (t & 1) * STAGE_BYTES);
+    const float* sa = reinterpret_cast<const float*>(smem + (t % TN_STAGES) * STAGE_BYTES);
     const float* sb = sa + TILE_BYTES / 4;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -417,7 +417,6 @@ __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_arg
       mma12<PREC>(ah, al, bh, bl, acc);
     }
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
   }
 
   float* out = g.splits > 1 ? g.ws + (int64_t)zslab * g.K1 * g.K2 : g.C;
@@ -813,11 +812,11 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   }
   g.splits = splits;
   const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);
-  const size_t smem = 2 * STAGE_BYTES + (size_t)mchunk * 8;
+  const size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;
   static bool attr = false;
   if (!attr) {
     MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8));
+                                  TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8));
     attr = true;
   }
   dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8)));
