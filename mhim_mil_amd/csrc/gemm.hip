@@ -422,8 +422,18 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
   ws += (int64_t)blockIdx.y * splits * n;          // batch element blockIdx.y
   C += (int64_t)blockIdx.y * sC;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * n + idx];       // fixed order: deterministic
+    // four independent partial sums keep four slab loads in flight (the slabs are n floats apart: every load is its own
+    // cache line); the final combination order is fixed => deterministic
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {
+      s0 += ws[(int64_t)(z + 0) * n + idx];
+      s1 += ws[(int64_t)(z + 1) * n + idx];
+      s2 += ws[(int64_t)(z + 2) * n + idx];
+      s3 += ws[(int64_t)(z + 3) * n + idx];
+    }
+    for (; z < splits; ++z) s0 += ws[(int64_t)z * n + idx];
+    const float s = (s0 + s1) + (s2 + s3);
     float* p = C + (idx / K2) * ldc + (idx % K2);
     *p = accumulate ? *p + s : s;
   }

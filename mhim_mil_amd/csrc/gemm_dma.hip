@@ -723,7 +723,7 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
   }
-  hipLaunchKernelGGL(prep_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, pj);
+  hipLaunchKernelGGL(prep_batch_kernel, dim3(256, (unsigned)n), dim3(256), 0, st, pj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
