@@ -247,7 +247,7 @@ int mhimx_select_mask(void* stream, const float* score, int64_t N, int64_t k, in
  *  N <= 16384, k <= 4096. */
 int mhimx_select_rows(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
                       uint64_t rand_seed, const uint64_t* tick, int64_t merge_R, int64_t* rows_out, int64_t* mask_ids,
-                      void* ws, int64_t ws_bytes);
+                      void* ws, int64_t ws_bytes, int32_t merge_first /* 1: rows_out = [rows to merge | rows that stay] */);
 
 /* vote[n] = number of heads whose top-k contains n (masking.py:49-57, msa_fusion='vote'); attn [H,N] */
 int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,

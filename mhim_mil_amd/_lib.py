@@ -106,7 +106,7 @@ SYMBOLS = {
     "mhimx_pseudo_score": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64]),
     "mhimx_select_ws_bytes": (_I64, [_I64]),
     "mhimx_select_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64, _P, _P, _P, _P, _I64]),
-    "mhimx_select_rows": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _U64, _P, _I64, _P, _P, _P, _I64]),
+    "mhimx_select_rows": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _U64, _P, _I64, _P, _P, _P, _I64, _I32]),
     "mhimx_vote_scores": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64]),
     "mhimx_compose_ids": (C.c_int, [_P, _P, _P, _P, _I64]),
     "mhimx_merge_ws_bytes": (_I64, [_I64, _I64, _I64, _I64, _I64]),

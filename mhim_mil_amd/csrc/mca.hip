@@ -298,7 +298,7 @@ static int dispatch_kq(int64_t k, F&& f) {
   return fail(-1, "merge: k=%lld global queries unsupported (max 16)", (long long)k);
 }
 
-__global__ void ema_kernel(const float* __restrict__ q, const float* __restrict__ z, float* __restrict__ out, int64_t n, float mm) {
+__global__ void ema_kernel(const float* q, const float* __restrict__ z, float* out, int64_t n, float mm) {   // out may alias q
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = q[i] * mm + z[i] * (1.f - mm);
 }

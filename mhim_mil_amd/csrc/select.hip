@@ -502,8 +502,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     nmrg += m ? 1u : 0u;
     nstay += (kv[j] && !m) ? 1u : 0u;
   }
-  uint32_t spos = block_scan_excl(nstay, wave_tot, &t2);
-  uint32_t mpos2 = (uint32_t)Lk + block_scan_excl(nmrg, wave_tot, &t2);
+  // use_rand == 2: rows to merge FIRST ([merge | stay]: lets the caller keep [stay rows | merged tokens] contiguous)
+  uint32_t spos = (use_rand == 2 ? (uint32_t)(Lrows - Lk) : 0u) + block_scan_excl(nstay, wave_tot, &t2);
+  uint32_t mpos2 = (use_rand == 2 ? 0u : (uint32_t)Lk) + block_scan_excl(nmrg, wave_tot, &t2);
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     if (!kv[j]) continue;
@@ -582,10 +583,10 @@ extern "C" int mhimx_select_mask(void* stream, const float* score, int64_t N, in
 
 extern "C" int mhimx_select_rows(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
                                  uint64_t rand_seed, const uint64_t* tick, int64_t merge_R, int64_t* rows_out, int64_t* mask_ids,
-                                 void* ws, int64_t ws_bytes) {
+                                 void* ws, int64_t ws_bytes, int32_t merge_first) {
   MHIMX_CHECK_ARG(rows_out && merge_R >= 0 && merge_R <= N - n_sel, "select_rows: bad args");
-  return select_impl(stream, score, N, k, n_sel, largest, nullptr, nullptr, 0, mask_ids, nullptr, nullptr, ws, ws_bytes, 1, rand_seed,
-                     tick, (int)merge_R, rows_out);
+  return select_impl(stream, score, N, k, n_sel, largest, nullptr, nullptr, 0, mask_ids, nullptr, nullptr, ws, ws_bytes,
+                     merge_first ? 2 : 1, rand_seed, tick, (int)merge_R, rows_out);
 }
 
 extern "C" int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,

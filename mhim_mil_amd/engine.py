@@ -184,8 +184,10 @@ class FusedTrainer:
         xp = s._pair(x) if s.baseline == "attn" else None        # one bf16 hi/lo image of the bag for both projections
         if self.model_kind == "mhim":
             teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"])
-            rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle)
-            plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True)
+            mf = s.baseline == "attn"                       # [merge | stay] rows: the pool reads [stay | merged tokens] contiguously
+            rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle, merge_first=mf)
+            plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True,
+                           merge_first=mf)
             keep_num = Lk + s.merge.k
         else:
             teacher_feat = None

@@ -199,8 +199,9 @@ class _MergeFn(torch.autograd.Function):
 class BagPlan:
     """Row bookkeeping of one student forward (all device tensors; no host sync)."""
 
-    def __init__(self, rows=None, L=0, Lk=0, R=0, drop_seed=0, drop_mask=None, mca_seed=0, training=True):
+    def __init__(self, rows=None, L=0, Lk=0, R=0, drop_seed=0, drop_mask=None, mca_seed=0, training=True, merge_first=False):
         self.rows, self.L, self.Lk, self.R = rows, L, Lk, R
+        self.merge_first = merge_first            # rows = [rows to merge (R) | rows that stay (Lk)] instead of [stay | merge]
         self.drop_seed, self.drop_mask, self.mca_seed, self.training = drop_seed, drop_mask, mca_seed, training
 
 
@@ -370,22 +371,33 @@ class MHIM(nn.Module):
         Lrows = plan.L
         dev = x.device
         need_pre = L.act_code(self.act, _FEATURE_ACTS) == L.ACT["gelu"] and plan.training
-        H = torch.empty((Lrows, E), device=dev)
+        merging = self.merge_enable and plan.R > 0
+        k = self.merge.k if merging else 0
+        # One buffer [rows | k merged tokens].  With plan.merge_first the rows are [merge (R) | stay (Lk)], so the pool's
+        # input [stay rows | merged tokens] is ONE contiguous segment (no separate 5-row scorer / score kernels).
+        Hbuf = torch.empty((Lrows + k, E), device=dev)
+        H = Hbuf[:Lrows]
         PRE = torch.empty((Lrows, E), device=dev) if need_pre else None
         p = self.dropout_p if plan.training else 0.0
         self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp, w1p=prep.get("w1p"))
-        saved = {"H": H, "PRE": PRE, "prep": prep}
+        saved = {"H": H, "Hbuf": Hbuf, "PRE": PRE, "prep": prep}
         sc = self._scorer()
-        if self.merge_enable and plan.R > 0:
+        if merging:
             mw = self._merge_w(plan, need_t=False)
-            z_tok, q_new, mws = ops.merge_fwd(mw, H[plan.Lk:], update_q=plan.training)
-            st = ops.abmil_pool_fwd(sc, H[:plan.Lk], z_tok)
             q_old = prep.get("q_old")
             if q_old is None and plan.training:
                 q_old = self.merge.global_q_mm.data.clone()
+            # in-forward EMA of the global queries (merge.py:142-143), written in place: the pre-update values the
+            # backward needs were snapshotted above
+            q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
+            Hm = H[:plan.R] if plan.merge_first else H[plan.Lk:]
+            z_tok, _, mws = ops.merge_fwd(mw, Hm, z_out=Hbuf[Lrows:], update_q=plan.training,
+                                          q_out=q_param if plan.training else None)
+            if plan.merge_first:
+                st = ops.abmil_pool_fwd(sc, Hbuf[plan.R:], None)
+            else:
+                st = ops.abmil_pool_fwd(sc, H[:plan.Lk], z_tok)
             saved.update(z_tok=z_tok, mws=mws, q_old=q_old)
-            if plan.training:                       # in-forward EMA of the global queries (merge.py:142-143)
-                self.merge.global_q_mm.data.copy_(q_new.view_as(self.merge.global_q_mm))
         else:
             st = ops.abmil_pool_fwd(sc, H, None)
         saved["pool"] = st
@@ -400,9 +412,12 @@ class MHIM(nn.Module):
         prep = saved.get("prep") or {}
         sc = self._scorer()
         att = self.online_encoder.attention
-        dH = torch.empty_like(H)
+        merging = self.merge_enable and plan.R > 0
+        mf = merging and plan.merge_first
+        dHbuf = torch.empty_like(saved["Hbuf"])
+        dH = dHbuf[:plan.L]
         grads = {}
-        pool_g = {"dT1": dH[:plan.Lk] if (self.merge_enable and plan.R > 0) else dH}
+        pool_g = {"dT1": dHbuf[plan.R:] if mf else (dH[:plan.Lk] if merging else dH)}
         pre = "online_encoder.attention."
         for key, nm in (("d_wa", "attention_a.0.weight" if self.online_encoder.gated else "attention.0.weight"),
                         ("d_wb", "attention_b.0.weight"),
@@ -424,13 +439,13 @@ class MHIM(nn.Module):
             # LayerNorm(global_q) backward uses the PRE-update queries (the reference sees post-update values through
             # an in-place .data write, a 1e-4-relative quirk: SURVEY.md §7 H7)
             mw = self._merge_w(plan, need_t=True, q=saved["q_old"], tr=prep.get("merge_t"))
-            mgr = {"dX": dH[plan.Lk:]}
+            mgr = {"dX": dH[:plan.R] if mf else dH[plan.Lk:]}
             for key, nm in (("d_ln_w", "merge.norm.weight"), ("d_ln_b", "merge.norm.bias"), ("d_wkv", "merge.attn.to_kv.weight"),
                             ("d_wq", "merge.attn.to_q.weight"), ("d_wo", "merge.attn.to_out.0.weight"),
                             ("d_bo", "merge.attn.to_out.0.bias")):
                 if nm in out:
                     mgr[key] = out[nm]
-            mg = ops.merge_bwd(mw, H[plan.Lk:], g["dT2"], saved["mws"], grads=mgr)
+            mg = ops.merge_bwd(mw, H[:plan.R] if mf else H[plan.Lk:], dHbuf[plan.L:] if mf else g["dT2"], saved["mws"], grads=mgr)
             grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
             grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
@@ -496,10 +511,11 @@ class MHIM(nn.Module):
             run(True, mask_ratio_h, self.mask_ratio_hr, perms[2])
         return len_keep, (None if mask_ids is None else mask_ids.view(1, -1))
 
-    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None):
+    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None, merge_first=False):
         """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
 
-        Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R).
+        Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R); with ``merge_first`` the
+        two groups are swapped ([merge | stay]: the fused trainer's layout, see _bag_forward).
         Production (no injected draws, v2 recipe, N <= 16384, ABMIL whose pool is order-free): ONE kernel draws both
         random subsets on the device (mhimx_select_rows).  The TransMIL encoder sees the token ORDER (landmark means,
         PPEG grid), so it always takes the literal two-stage form with a device-drawn shuffle.  With injected ``perm`` / ``ids_shuffle`` (parity tests) or v1 masks the reference's
@@ -524,7 +540,8 @@ class MHIM(nn.Module):
                 R = len_keep - Lk
                 if R == 0:
                     raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
-                rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed(), tick=self._tick)
+                rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed(), tick=self._tick,
+                                       merge_first=merge_first)
                 return rows, len_keep, Lk, R
         len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm, generator=generator)
         if mask_ids is None:
@@ -540,6 +557,8 @@ class MHIM(nn.Module):
         elif not torch.is_tensor(ids_shuffle):
             ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=dev)
         rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
+        if merge_first:
+            rows = torch.cat([rows[Lk:], rows[:Lk]])
         return rows, len_keep, Lk, R
 
     # ------------------------------------------------------------------ reference entry points

@@ -249,8 +249,9 @@ def select_mask(score, k, n_sel, largest=True, perm=None, other=None, want_topk=
     return mask_ids, len_keep, topk
 
 
-def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, want_mask_ids=False):
-    """Fused HAM mask + Merge split with device-side random subsets -> rows int64 [N - n_sel] (stay | merge)."""
+def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, want_mask_ids=False, merge_first=False):
+    """Fused HAM mask + Merge split with device-side random subsets -> rows int64 [N - n_sel] (stay | merge), or
+    (merge | stay) with merge_first."""
     _chk(score, name="score")
     N = score.numel()
     dev = score.device
@@ -259,7 +260,7 @@ def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, wa
     ws = torch.empty(L.lib().mhimx_select_ws_bytes(N), device=dev, dtype=torch.uint8)
     L.check(L.lib().mhimx_select_rows(_stream(), _p(score), N, int(k), int(n_sel), int(bool(largest)),
                                       int(rand_seed) & 0xFFFFFFFFFFFFFFFF, _p(tick), int(merge_R), _p(rows), _p(mask_ids), _p(ws),
-                                      ws.numel()), "mhimx_select_rows")
+                                      ws.numel(), int(bool(merge_first))), "mhimx_select_rows")
     return (rows, mask_ids) if want_mask_ids else rows
 
 
@@ -299,12 +300,14 @@ class MergeW:
         return torch.empty(n, device=device, dtype=torch.uint8)
 
 
-def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None):
+def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
+    """q_out: where the EMA-updated queries go (may be the query parameter itself: the update is element-wise and the
+    forward has consumed LayerNorm(q) by then)."""
     _chk(X, name="X")
     R = X.shape[0]
     dev = X.device
     z = z_out if z_out is not None else torch.empty((mw.k, mw.E), device=dev)
-    q_new = torch.empty((mw.k, mw.E), device=dev) if update_q else None
+    q_new = (q_out if q_out is not None else torch.empty((mw.k, mw.E), device=dev)) if update_q else None
     ws = ws if ws is not None else mw.ws_for(R, dev)
     L.check(L.lib().mhimx_merge_fwd(_stream(), C.byref(mw.c), _p(X), R, _p(z), _p(q_new), int(bool(update_q)), _p(ws),
                                     ws.numel()), "mhimx_merge_fwd")
