@@ -66,6 +66,9 @@ typedef struct {
   int32_t paired;                                        /* 1: A and B are paired-plane images made by mhimx_pair_planes      */
   float* ws; int64_t ws_floats;                          /* optional scratch: lets a GEMM with few output tiles and a long K   */
                                                          /* split its reduction over up to ws_floats/(M*N) slabs (epilogue-free calls) */
+  float* dact; int64_t lddact;                           /* optional: d(output)/d(pre-activation) = act'(pre) * keep/(1-p) per element, */
+                                                         /* so the backward through act+dropout is one multiply (mhimx_mul_colsum).      */
+                                                         /* Only the paired-plane projection kernel writes it (else the call fails).      */
 } mhimx_gemm_nt_args;
 int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
 
@@ -293,6 +296,10 @@ int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t 
 int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int64_t M, int64_t E, int32_t act,
                   float drop_p, uint64_t drop_seed, const uint8_t* drop_mask, const int64_t* rows, float* colsum_out,
                   int32_t accumulate, void* ws, int64_t ws_bytes, const uint64_t* drop_tick);
+/* dH *= dact in place (dact from mhimx_gemm_nt's `dact` output) and colsum_out[e] (+)= sum_m dH[m,e]: the backward
+ * through activation + dropout and the bias gradient in one streaming pass.  ws: 1024*E floats. */
+int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,
+                     void* ws, int64_t ws_bytes);
 /* out[e] (+)= sum_m X[m,e] */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);

@@ -33,7 +33,8 @@ class GemmNT(C.Structure):
                 ("act", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p),
                 ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p), ("B_hi", C.c_void_p), ("B_lo", C.c_void_p),
-                ("paired", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
+                ("paired", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+                ("dact", C.c_void_p), ("lddact", C.c_int64)]
 
 
 class PrepJob(C.Structure):
@@ -113,6 +114,7 @@ SYMBOLS = {
     "mhimx_merge_fwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I32, _P, _I64]),
     "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
     "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P]),

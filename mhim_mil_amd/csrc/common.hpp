@@ -76,6 +76,21 @@ MHIMX_DEV float act_grad(float x, float y, int act) {
   }
 }
 
+// y = act(x) and dy/dx in one evaluation (the erf is shared)
+MHIMX_DEV void act_fwd_grad(float x, int act, float& y, float& g) {
+  switch (act) {
+    case MHIMX_ACT_RELU: y = x > 0.f ? x : 0.f; g = x > 0.f ? 1.f : 0.f; return;
+    case MHIMX_ACT_GELU: {
+      const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      y = x * cdf;
+      g = cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+      return;
+    }
+    case MHIMX_ACT_TANH: y = tanhf(x); g = 1.f - y * y; return;
+    default: y = x; g = 1.f; return;
+  }
+}
+
 // Counter-based keep/drop decision: one 32-bit mix of (seed, row, col) per element.  The same
 // (seed,row,col) gives the same bit in forward and backward, so no mask is ever stored.
 MHIMX_DEV uint32_t mix32(uint32_t x) {

@@ -237,12 +237,20 @@ __global__ __launch_bounds__(FTHREADS) void feat_gemm_kernel(mhimx_gemm_nt_args 
     }
     if (g.pre) *reinterpret_cast<f32x4*>(g.pre + m * g.ldpre + n) = f32x4{v[0], v[1], v[2], v[3]};
     const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
+    float da[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      v[q] = act_fwd(v[q], g.act);
-      if (g.drop_mask) v[q] = g.drop_mask[m * g.N + n + q] ? v[q] * inv_keep : 0.f;
-      else if (g.drop_p > 0.f) v[q] = drop_keep(dseed, rid, (uint32_t)(n + q), g.drop_p) ? v[q] * inv_keep : 0.f;
+      const float xq = v[q];
+      float gq = 0.f;
+      if (g.dact) act_fwd_grad(xq, g.act, v[q], gq);          // d out / d pre for the backward (shares the erf)
+      else v[q] = act_fwd(xq, g.act);
+      float ks = 1.f;
+      if (g.drop_mask) ks = g.drop_mask[m * g.N + n + q] ? inv_keep : 0.f;
+      else if (g.drop_p > 0.f) ks = drop_keep(dseed, rid, (uint32_t)(n + q), g.drop_p) ? inv_keep : 0.f;
+      da[q] = gq * ks;
+      v[q] *= ks;
     }
+    if (g.dact) *reinterpret_cast<f32x4*>(g.dact + m * g.lddact + n) = f32x4{da[0], da[1], da[2], da[3]};
     f32x4* c = reinterpret_cast<f32x4*>(g.C + m * g.ldc + n);
     f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
     if (g.accumulate) { const f32x4 old = *c; o += old; }
@@ -257,7 +265,7 @@ bool feat_gemm_ok(const mhimx_gemm_nt_args& g) {
   return g.paired && g.prec == MHIMX_PREC_BF16X3 && g.N % FBN == 0 && g.K % FBK == 0 && g.M >= 64 &&
          g.lda % 4 == 0 && g.ldb % 4 == 0 && aligned16(g.A) && aligned16(g.B) &&
          g.ldc % 4 == 0 && aligned16(g.C) && (!g.pre || (g.ldpre % 4 == 0 && aligned16(g.pre))) && (!g.bias || aligned16(g.bias)) &&
-         (!g.colv || aligned16(g.colv));
+         (!g.colv || aligned16(g.colv)) && (!g.dact || (g.lddact % 4 == 0 && aligned16(g.dact)));
 }
 
 int feat_gemm(hipStream_t st, const mhimx_gemm_nt_args& g) {

@@ -313,6 +313,7 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
   MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_nt: null operand");
   MHIMX_CHECK_ARG(!g.rowv || g.colv, "gemm_nt: rowv needs colv");
   MHIMX_CHECK_ARG(g.drop_p >= 0.f && g.drop_p < 1.f, "gemm_nt: drop_p out of range");
+  MHIMX_CHECK_ARG(!g.dact || (g.paired && feat_gemm_ok(g)), "gemm_nt: the dact output exists only on the paired-plane projection kernel");
   if (g.paired) {
     MHIMX_CHECK_ARG(g.M > SKINNY_M && g.K % 32 == 0 && nt_dma_ok(g), "gemm_nt: paired-plane operands need M > 16, K % 32 == 0, aligned rows");
     if (feat_gemm_ok(g)) return feat_gemm(st, g);          // 160 x 128 tiles: one balanced round over the chip

@@ -417,6 +417,25 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dH, co
   }
 }
 
+// dH *= dact (float4 per thread, 128 threads per 512-wide row) + per-block column sums
+__global__ __launch_bounds__(256) void mul_colsum_kernel(float* __restrict__ dH, const float* __restrict__ dact, int64_t M, int E,
+                                                        int64_t chunk, float* __restrict__ part) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const int e4 = E / 4;
+  const int64_t mb = (int64_t)blockIdx.x * chunk;
+  const int64_t me = mb + chunk < M ? mb + chunk : M;
+  for (int c = threadIdx.x; c < e4; c += 256) {
+    f4v cs = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int64_t m = mb; m < me; ++m) {
+      f4v* p = reinterpret_cast<f4v*>(dH + m * E) + c;
+      const f4v g = *p * reinterpret_cast<const f4v*>(dact + m * E)[c];
+      *p = g;
+      cs += g;
+    }
+    if (part) *(reinterpret_cast<f4v*>(part + (int64_t)blockIdx.x * E) + c) = cs;
+  }
+}
+
 __global__ void colsum_part_kernel(const float* __restrict__ X, int64_t M, int E, int64_t chunk, float* __restrict__ part) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -719,6 +738,25 @@ extern "C" int mhimx_act_bwd(void* stream, float* dH, const float* H, const floa
                   (long long)(nblk * E * 4));
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dH, H, pre, M, (int)E, act, drop_p,
                      drop_seed, drop_mask, rows, chunk, colsum_out ? (float*)ws : nullptr, drop_tick);
+  MHIMX_LAUNCH_CHECK();
+  if (colsum_out) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, (hipStream_t)stream, (const float*)ws, (int)nblk,
+                       (int)E, (int)E, colsum_out, accumulate);
+    MHIMX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,
+                                void* ws, int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(dH && dact && E % 4 == 0 && aligned16(dH) && aligned16(dact), "mul_colsum: bad args");
+  if (M <= 0) return 0;
+  int64_t nblk = cdiv(M, 8);
+  if (nblk > 1024) nblk = 1024;
+  const int64_t chunk = cdiv(M, nblk);
+  nblk = cdiv(M, chunk);
+  MHIMX_CHECK_ARG(!colsum_out || (ws && ws_bytes >= nblk * E * 4), "mul_colsum: workspace too small (%lld bytes)", (long long)(nblk * E * 4));
+  hipLaunchKernelGGL(mul_colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dH, dact, M, (int)E, chunk,
+                     colsum_out ? (float*)ws : nullptr);
   MHIMX_LAUNCH_CHECK();
   if (colsum_out) {
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, (hipStream_t)stream, (const float*)ws, (int)nblk,

@@ -333,7 +333,7 @@ class MHIM(nn.Module):
         return ops.pair_planes(x)
 
     def _feature(self, x, rows=None, drop_p=0.0, drop_seed=0, drop_mask=None, want_pre=False, out=None, pre_out=None, M=None,
-                 xp=None, w1p=None):
+                 xp=None, w1p=None, dact=None):
         f = self.feature[0]
         act = L.act_code(self.act, _FEATURE_ACTS)
         nrows = M if M is not None else (rows.shape[0] if rows is not None else x.shape[0])
@@ -342,7 +342,9 @@ class MHIM(nn.Module):
         if xp is not None and nrows > 16:
             return ops.gemm_nt(xp, w1p if w1p is not None else ops.pair_planes(f.weight.data), out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out,
                                drop_p=drop_p, drop_seed=drop_seed, drop_mask=drop_mask, prec="bf16x3", M=M, drop_tick=self._tick,
-                               paired=True)
+                               paired=True, dact=dact)
+        if dact is not None:
+            raise L.MhimxError("the dact output needs the paired-plane projection path")
         return ops.gemm_nt(x, f.weight.data, out=out, rows=rows, bias=f.bias.data, act=act, pre=pre_out, drop_p=drop_p,
                            drop_seed=drop_seed, drop_mask=drop_mask, prec=self._feature_prec(nrows), M=M, drop_tick=self._tick)
 
@@ -377,10 +379,15 @@ class MHIM(nn.Module):
         # input [stay rows | merged tokens] is ONE contiguous segment (no separate 5-row scorer / score kernels).
         Hbuf = torch.empty((Lrows + k, E), device=dev)
         H = Hbuf[:Lrows]
-        PRE = torch.empty((Lrows, E), device=dev) if need_pre else None
+        # backward through act + dropout: the projection's epilogue can emit d out / d pre (act'(pre) * keep/(1-p)) instead of
+        # the pre-activation — the backward is then one multiply with no erf / exp / hash (paired-plane kernel only)
+        use_dact = plan.training and xp is not None and E % 128 == 0 and x.shape[1] % 32 == 0 and Lrows >= 64
+        DACT = torch.empty((Lrows, E), device=dev) if use_dact else None
+        PRE = torch.empty((Lrows, E), device=dev) if (need_pre and not use_dact) else None
         p = self.dropout_p if plan.training else 0.0
-        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp, w1p=prep.get("w1p"))
-        saved = {"H": H, "Hbuf": Hbuf, "PRE": PRE, "prep": prep}
+        self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp, w1p=prep.get("w1p"),
+                      dact=DACT)
+        saved = {"H": H, "Hbuf": Hbuf, "PRE": PRE, "DACT": DACT, "prep": prep}
         sc = self._scorer()
         if merging:
             mw = self._merge_w(plan, need_t=False)
@@ -450,8 +457,11 @@ class MHIM(nn.Module):
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
             grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
         p = self.dropout_p if plan.training else 0.0
-        _, db1 = ops.act_bwd(dH, H, PRE, L.act_code(self.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
-                             colsum_out=out.get("feature.0.bias"), want_colsum=True, drop_tick=self._tick)
+        if saved.get("DACT") is not None:
+            _, db1 = ops.mul_colsum(dH, saved["DACT"], colsum_out=out.get("feature.0.bias"))
+        else:
+            _, db1 = ops.act_bwd(dH, H, PRE, L.act_code(self.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
+                                 colsum_out=out.get("feature.0.bias"), want_colsum=True, drop_tick=self._tick)
         splits = 8 if plan.L >= 2048 else 1
         grads["feature.0.weight"] = ops.gemm_tn(dH, x, out=out.get("feature.0.weight"), rows=plan.rows, splits=splits,
                                                 prec="f32" if self.prec == "f32" else "bf16x3", M=plan.L)

@@ -44,7 +44,7 @@ def prec_code(prec) -> int:
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, colv=None, drop_p=0.0, drop_seed=0,
-            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, b_planes=None, paired=False):
+            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, b_planes=None, paired=False, dact=None):
     """out[m,n] = epi(sum_k a[rows[m] or m, k] * b[n,k]) — see mhimx_gemm_nt."""
     for t, nm in ((a, "a"), (b, "b"), (bias, "bias"), (pre, "pre"), (rowv, "rowv"), (colv, "colv"), (out, "out")):
         _chk(t, name=nm)
@@ -61,7 +61,8 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
                  ldpre=pre.stride(0) if pre is not None else 0, act=int(act), drop_p=float(drop_p),
                  drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(drop_mask), accumulate=int(bool(accumulate)),
                  prec=prec_code(prec), drop_tick=_p(drop_tick), B_hi=_p(b_planes[0]) if b_planes is not None else None,
-                 B_lo=_p(b_planes[1]) if b_planes is not None else None, paired=int(bool(paired)))
+                 B_lo=_p(b_planes[1]) if b_planes is not None else None, paired=int(bool(paired)), dact=_p(dact),
+                 lddact=dact.stride(0) if dact is not None else 0)
     evs = KERNEL_EVENT_HOOK("gemm_nt", M, N, K) if KERNEL_EVENT_HOOK is not None else None
     if evs:
         evs[0].record()
@@ -345,6 +346,18 @@ def act_bwd(dH, H, pre, act, drop_p=0.0, drop_seed=0, drop_mask=None, rows=None,
                                   int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(drop_mask), _p(rows), _p(colsum_out),
                                   int(bool(accumulate)), _p(ws), 0 if ws is None else ws.numel() * 4, _p(drop_tick)), "mhimx_act_bwd")
     return (dH, colsum_out) if colsum_out is not None else dH
+
+
+def mul_colsum(dH, dact, colsum_out=None, want_colsum=True, accumulate=False):
+    """dH *= dact in place; column sums of the result (the feature-bias gradient) in the same pass."""
+    _chk(dH, name="dH"); _chk(dact, name="dact")
+    M, E = dH.shape
+    if want_colsum and colsum_out is None:
+        colsum_out = torch.empty(E, device=dH.device)
+    ws = torch.empty(1024 * E, device=dH.device) if colsum_out is not None else None
+    L.check(L.lib().mhimx_mul_colsum(_stream(), _p(dH), _p(dact), M, E, _p(colsum_out), int(bool(accumulate)), _p(ws),
+                                     0 if ws is None else ws.numel() * 4), "mhimx_mul_colsum")
+    return dH, colsum_out
 
 
 def colsum(X, out=None, accumulate=False):

@@ -126,6 +126,31 @@ def test_gemm_nt_paired_planes(M, N, K, gather):
     np.testing.assert_allclose(out.numpy(), plain.numpy(), atol=2e-6 * ref.abs().max().item(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("act", [1, 2])
+def test_projection_dact_output_and_mul_colsum(act):
+    """The paired projection's `dact` output = d out / d pre (act' * keep/(1-p)); mul_colsum applies it and sums columns."""
+    ops = _ops()
+    M, N, K, p = 700, 256, 128, 0.25
+    a, b, bias = rnd(41, (M, K)).abs(), rnd(42, (N, K), std=0.1), rnd(43, (N,), std=0.1)
+    ap, bp = ops.pair_planes(a.to(DEV)), ops.pair_planes(b.to(DEV))
+    dact = torch.empty((M, N), device=DEV)
+    pre = torch.empty((M, N), device=DEV)
+    out = ops.gemm_nt(ap, bp, bias=bias.to(DEV), act=act, pre=pre, drop_p=p, drop_seed=77, prec="bf16x3", paired=True, dact=dact)
+    x = pre.cpu().double().requires_grad_()
+    y = torch.relu(x) if act == 1 else torch.nn.functional.gelu(x)
+    keep = (out.cpu() != 0) | (y.detach() == 0)                   # dropped elements are exact zeros
+    gref, = torch.autograd.grad(y.sum(), x)
+    ref = (gref * keep / (1 - p)).float()
+    np.testing.assert_allclose(dact.cpu().numpy(), ref.numpy(), atol=2e-6, rtol=2e-5)
+    g = rnd(44, (M, N))
+    gd = g.to(DEV).clone()
+    _, cs = ops.mul_colsum(gd, dact)
+    np.testing.assert_allclose(gd.cpu().numpy(), (g * dact.cpu()).numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(cs.cpu().numpy(), (g * dact.cpu()).double().sum(0).float().numpy(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(Exception):                                # dact exists only on the paired projection kernel
+        ops.gemm_nt(a.to(DEV), b.to(DEV), prec="bf16x3", dact=dact)
+
+
 def test_transpose():
     ops = _ops()
     x = rnd(1, (130, 77))
