@@ -97,11 +97,17 @@ MHIMX_DEV uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// two-level form: a per-(seed,row) key (two mixes, amortised over the columns a thread handles) and ONE mix per element
+MHIMX_DEV uint32_t drop_row_key(uint64_t seed, uint64_t row) {
+  const uint32_t r = mix32((uint32_t)row * 0x9E3779B1u ^ (uint32_t)seed);
+  return mix32(r + (uint32_t)(seed >> 32) + (uint32_t)(row >> 32) * 0x85EBCA77u);
+}
+MHIMX_DEV bool drop_keep_k(uint32_t row_key, uint32_t col, float p) {
+  const uint32_t h = mix32(row_key + col * 0x85EBCA77u);
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;        // keep with probability 1-p
+}
 MHIMX_DEV bool drop_keep(uint64_t seed, uint64_t row, uint32_t col, float p) {
-  uint32_t h = mix32((uint32_t)seed ^ mix32((uint32_t)(row * 0x9E3779B1u) + col * 0x85EBCA77u + (uint32_t)(seed >> 32)));
-  h = mix32(h + (uint32_t)(row >> 16));
-  // keep with probability 1-p
-  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+  return drop_keep_k(drop_row_key(seed, row), col, p);
 }
 
 // Wave64 all-reduce on the VALU's DPP network (no LDS round trips: __shfl_xor lowers to ds_bpermute, ~6 dependent

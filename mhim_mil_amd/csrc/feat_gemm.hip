@@ -236,7 +236,7 @@ __global__ __launch_bounds__(FTHREADS) void feat_gemm_kernel(mhimx_gemm_nt_args 
       for (int q = 0; q < 4; ++q) v[q] += rv * colv[q];
     }
     if (g.pre) *reinterpret_cast<f32x4*>(g.pre + m * g.ldpre + n) = f32x4{v[0], v[1], v[2], v[3]};
-    const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
+    const uint32_t rkey = g.drop_p > 0.f ? drop_row_key(dseed, g.rows ? (uint64_t)g.rows[m] : (uint64_t)m) : 0u;
     float da[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(FTHREADS) void feat_gemm_kernel(mhimx_gemm_nt_args 
       else v[q] = act_fwd(xq, g.act);
       float ks = 1.f;
       if (g.drop_mask) ks = g.drop_mask[m * g.N + n + q] ? inv_keep : 0.f;
-      else if (g.drop_p > 0.f) ks = drop_keep(dseed, rid, (uint32_t)(n + q), g.drop_p) ? inv_keep : 0.f;
+      else if (g.drop_p > 0.f) ks = drop_keep_k(rkey, (uint32_t)(n + q), g.drop_p) ? inv_keep : 0.f;
       da[q] = gq * ks;
       v[q] *= ks;
     }
