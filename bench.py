@@ -211,12 +211,25 @@ def main():
             return None
         ops.KERNEL_EVENT_HOOK = hook
 
-    graphs = None
+    graphs, graph_note = None, None
     if not a.no_graph:
         # one captured hipGraph per resident bag (the bag pointer is a kernel argument); they share one memory pool.
-        # Each replay runs the complete step: tick, teacher fwd, randperm, select, student fwd, head, bwd,
-        # [all-reduce], Adam + EMA.
-        graphs = [trainer.capture(bags[i], labels[i], warmup=1) for i in range(N_BAGS)]
+        # Each replay runs the complete step: prep, teacher fwd, select, student fwd, head, bwd, [all-reduce], Adam + EMA.
+        # If capture is refused (e.g. a collective that cannot be captured on this RCCL build) every rank falls back to
+        # eager launches together — the decision is all-reduced so that no rank replays while another launches eagerly.
+        ok = 1
+        try:
+            graphs = [trainer.capture(bags[i], labels[i], warmup=1) for i in range(N_BAGS)]
+        except Exception as exc:            # noqa: BLE001 — any capture failure means "run eagerly"
+            ok, graph_note = 0, f"{type(exc).__name__}: {str(exc)[:160]}"
+            torch.cuda.synchronize()
+        if world > 1:
+            flag = torch.tensor([ok], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            graphs = None
+            graph_note = graph_note or "another rank could not capture"
 
     def step(i):
         if graphs is not None:
@@ -250,7 +263,8 @@ def main():
                                    "(teacher fwd + select + student fwd + bwd + Adam + EMA"
                                    + (" + RCCL all-reduce of the 6.6 MB flat gradient" if world > 1 else "") + ")",
                        "bags_per_step": world, "rotating_bags_per_gpu": N_BAGS, "matrix_core_form": student._feature_prec(N_INST),
-                       "dropout": CFG["dropout"], "parallelism": f"dp{world}", "launch": "eager" if graphs is None else "hipGraph replay, one graph per resident bag"},
+                       "dropout": CFG["dropout"], "parallelism": f"dp{world}", "launch": ("eager" + (f" (graph capture failed: {graph_note})" if graph_note else "")) if graphs is None
+                                 else "hipGraph replay, one graph per resident bag"},
             "whole_step_hbm_roofline": {"algorithmic_bytes_per_instance": ALGO_BYTES_PER_INST_STEP,
                                         "achieved_GBps": value / world * ALGO_BYTES_PER_INST_STEP / 1e9,
                                         "frac_of_8TBps": value / world * ALGO_BYTES_PER_INST_STEP / 1e9 / HBM_PEAK_GBS},

@@ -13,7 +13,8 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g);
 int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y, float* mean, float* rstd);
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
-                  const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate);
+                  const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
+                  int max_parts);
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes);
 
 constexpr int MCA_THREADS = 256;
@@ -466,8 +467,8 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   g.A = w.dQ; g.lda = I; g.B = m->wq_t; g.ldb = I; g.C = w.dgq; g.ldc = E; g.M = k; g.N = E; g.K = I; g.prec = gprec;
   if (int r = gemm_nt(st, g)) return r;
   // LayerNorm: rows (dX + weight grads), then the global queries (weight grads only; the queries are not trained)
-  if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc)) return r;
-  if (int r = layernorm_bwd(st, w.dgq, m->q_param, k, E, m->ln_w, w.gmean, w.grstd, nullptr, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, 1)) return r;
+  if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256)) return r;
+  if (int r = layernorm_bwd(st, w.dgq, m->q_param, k, E, m->ln_w, w.gmean, w.grstd, nullptr, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, 1, 256)) return r;
   return 0;
 }
 

@@ -661,12 +661,15 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 
 // partials: dw_part/db_part [grid][E] scratch; d_w/d_b (+)= reduced
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
-                  const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate) {
+                  const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
+                  int max_parts) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
-  int grid = (int)cdiv(M, 16);            // few partial rows: the weight-gradient reduce that follows is serial in them
+  // one wave per row, 4 rows per block pass: the row loop is a latency chain, so use as many blocks as the partial
+  // workspace (max_parts rows of dw / db partials) allows
+  int grid = (int)cdiv(M, 4);
   if (grid < 1) grid = 1;
-  if (grid > 96) grid = 96;
+  if (grid > max_parts) grid = max_parts;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
                      w, mean, rstd, dx, dw_part, db_part);
   MHIMX_LAUNCH_CHECK();
@@ -751,7 +754,7 @@ extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int6
   MHIMX_CHECK_ARG(dH && dact && E % 4 == 0 && aligned16(dH) && aligned16(dact), "mul_colsum: bad args");
   if (M <= 0) return 0;
   int64_t nblk = cdiv(M, 8);
-  if (nblk > 1024) nblk = 1024;
+  if (nblk > 512) nblk = 512;
   const int64_t chunk = cdiv(M, nblk);
   nblk = cdiv(M, chunk);
   MHIMX_CHECK_ARG(!colsum_out || (ws && ws_bytes >= nblk * E * 4), "mul_colsum: workspace too small (%lld bytes)", (long long)(nblk * E * 4));
@@ -778,7 +781,7 @@ extern "C" int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int6
 extern "C" int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                                    const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws) {
   MHIMX_CHECK_ARG(dy && x && w && mean && rstd && d_w && d_b && ws, "layernorm_bwd: null args");
-  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate);
+  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate, 96);
 }
 extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {
   if (n <= 0) return 0;
