@@ -461,7 +461,7 @@ static int grid_for_ln(int64_t M) {       // LayerNorm: one row per wave, no par
 }
 
 static int grid_for_rows(int64_t M) {
-  int64_t g = cdiv(M, 32);
+  int64_t g = cdiv(M, 20);              // 5 rows per wave: the per-row chain (2 KB read, dot, exp) is latency bound
   if (g < 1) g = 1;
   if (g > MAX_PART) g = MAX_PART;
   return (int)g;
