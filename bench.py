@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prec", default="auto", help="auto|bf16x3|f16s|f32 (matrix-core form of the feature GEMM)")
-    ap.add_argument("--cpu-steps", type=int, default=40, help="oracle steps for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=400, help="oracle steps for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
@@ -283,7 +283,7 @@ def main():
                 traffic, tsrc = pj["traffic_bytes"], ("profiles/pmc_feature_gemm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
                                                       f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
                                                       f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
-            out["roofline"] = {"kernel": "gemm_nt_dma_kernel<BF16X3,8> (teacher feature projection X[N,D] -> H[N,512], fused bias+GELU+dropout)",
+            out["roofline"] = {"kernel": "feat_gemm_kernel (teacher feature projection X[N,D] -> H[N,512] on paired bf16 planes, 3-term bf16 MFMA, fused bias+GELU+dropout)",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "avg_kernel_ms": avg, "launches_timed": len(ms), "hip_events_over": events_from,
                                "algorithmic_bytes_per_launch": algo,

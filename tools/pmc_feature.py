@@ -15,11 +15,9 @@ N, D, E = 10000, 1024, 512
 def per_launch(path, counter):
     cur = sqlite3.connect(path).cursor()
     q = """select p.dispatch_id, sum(p.counter_value), k.duration, k.grid_x from pmc_events p join kernels k
-           on k.dispatch_id = p.dispatch_id where k.name like '%gemm_nt_dma%' and p.counter_name = ?
+           on k.dispatch_id = p.dispatch_id where k.name like '%feat_gemm%' and p.counter_name = ?
            group by p.dispatch_id order by p.dispatch_id"""
-    rows = [r for r in cur.execute(q, (counter,))]
-    big = max(r[3] for r in rows)
-    rows = [r for r in rows if r[3] == big]                 # the two N x D -> E projections of a step share the largest grid
+    rows = [r for r in cur.execute(q, (counter,))]          # the two N x D -> E projections of a step: feat_gemm_kernel
     return rows[0::2], rows[1::2]                           # (teacher launches, student launches): teacher runs first
 
 
@@ -36,7 +34,7 @@ def main():
     write_t, write_s = avg(wt, 1) * kib, avg(ws, 1) * kib
     algo_read = N * D * 4 + E * D * 4
     algo_write_t = N * E * 4
-    res = {"kernel": "gemm_nt_dma_kernel<BF16X3,8> (teacher feature projection, M=10000 N=512 K=1024)",
+    res = {"kernel": "feat_gemm_kernel (teacher feature projection on paired bf16 planes, M=10000 N=512 K=1024)",
            "launches": len(ft), "fetch_bytes": fetch_t, "write_bytes": write_t, "traffic_bytes": fetch_t + write_t,
            "fetch_size_raw_KiB": avg(ft, 1), "write_size_raw_KiB": avg(wt, 1),
            "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": algo_write_t,
@@ -52,12 +50,12 @@ def main():
         f.write("# rocprofv3 --pmc: HBM-side traffic of the feature projection (bench.py c2, eager launches)\n\n")
         f.write("Two separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each with `--kernel-trace` only) of\n"
                 "`python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-graph --no-kernel-events`; per-dispatch sums over all\n"
-                "counter instances, averaged over the launches of the largest `gemm_nt_dma_kernel` grid.\n\n")
+                "counter instances, averaged over the launches of `feat_gemm_kernel` (teacher = first of each step, student = second).\n\n")
         f.write("| launch | FETCH_SIZE raw KiB | fetch bytes (x2) | WRITE_SIZE raw KiB | write bytes | algorithmic read | algorithmic write |\n")
         f.write("|---|---:|---:|---:|---:|---:|---:|\n")
         f.write(f"| teacher X[10000,1024] -> H | {avg(ft, 1):.1f} | {fetch_t / 1e6:.2f} MB | {avg(wt, 1):.1f} | {write_t / 1e6:.2f} MB | "
                 f"{algo_read / 1e6:.2f} MB | {algo_write_t / 1e6:.2f} MB |\n")
-        f.write(f"| student X[rows 9700] -> H, PRE | {avg(fs, 1):.1f} | {fetch_s / 1e6:.2f} MB | {avg(ws, 1):.1f} | {write_s / 1e6:.2f} MB | "
+        f.write(f"| student X[rows 9700] -> H, dact | {avg(fs, 1):.1f} | {fetch_s / 1e6:.2f} MB | {avg(ws, 1):.1f} | {write_s / 1e6:.2f} MB | "
                 f"{(9700 * D * 4 + E * D * 4) / 1e6:.2f} MB | {2 * 9700 * E * 4 / 1e6:.2f} MB |\n\n")
         f.write(f"WRITE_SIZE calibration (teacher): reported / known = {res['write_calibration']:.4f}.\n\n"
                 f"Read over-fetch of the teacher launch: {fetch_t / algo_read:.2f}x the algorithmic bytes.  The floor for this tiling is\n"
