@@ -317,6 +317,56 @@ __global__ void drop_bwd_kernel(const float* __restrict__ dz, float* __restrict_
   }
 }
 
+// dz0 = dz * keep/(1-p) (the forward's output-dropout mask) and d_bo[e] (+)= sum_i dz0[i,e], k <= 16 rows: one launch
+__global__ void mca_dz0_kernel(const float* __restrict__ dz, float* __restrict__ dz0, int k, int E, float p, uint64_t seed0,
+                               const uint64_t* __restrict__ tick, float* __restrict__ d_bo, int accumulate) {
+  const uint64_t seed = eff_seed(seed0, tick);
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float cs = 0.f;
+  for (int i = 0; i < k; ++i) {
+    const float v = (p > 0.f && !drop_keep(seed, (uint64_t)i, (uint32_t)e, p)) ? 0.f : dz[(int64_t)i * E + e] * ks;
+    dz0[(int64_t)i * E + e] = v;
+    cs += v;
+  }
+  d_bo[e] = accumulate ? d_bo[e] + cs : cs;
+}
+
+// z = dropout(O Wo^T + bo) for the k merged tokens and, fused, the EMA of the global queries q_new = mm q + (1-mm) z
+// (merge.py:127-129,142-143).  One wave per output column; q_new may alias q.
+__global__ __launch_bounds__(256) void mca_out_kernel(const float* __restrict__ O, const float* __restrict__ wo, const float* __restrict__ bo,
+                                                     int k, int E, int I, float p, uint64_t seed0, const uint64_t* __restrict__ tick,
+                                                     float* __restrict__ z, const float* q, float* q_new, float mm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= E) return;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const float* wrow = wo + (int64_t)n * I;
+  for (int c = lane * 4; c < I; c += 256) {
+    const float4 w = *reinterpret_cast<const float4*>(wrow + c);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < k) {
+        const float4 a = *reinterpret_cast<const float4*>(O + (int64_t)i * I + c);
+        acc[i] += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = wave_sum(acc[i]);
+  if (lane != 0) return;
+  const uint64_t seed = eff_seed(seed0, tick);
+  const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int i = 0; i < k; ++i) {
+    float v = acc[i] + bo[n];
+    if (p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)n, p) ? v * ks : 0.f;
+    z[(int64_t)i * E + n] = v;
+    if (q_new) q_new[(int64_t)i * E + n] = q[(int64_t)i * E + n] * mm + v * (1.f - mm);
+  }
+}
+
 struct MergeWs {
   float *xn, *mean, *rstd, *gq, *gmean, *grstd, *KV, *Q, *P, *O, *dd, *dKV, *dQ, *dO, *dxn, *dgq, *dz0, *lnp_w, *lnp_b, *scratch;
   float *stats, *pm, *pl, *po, *prd, *pdq;
@@ -399,15 +449,11 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
       })) return r;
   hipLaunchKernelGGL(mca_fwd_final_kernel, dim3((unsigned)(H * k)), dim3(1024), 0, st, w.pm, w.pl, w.po, w.nb, (int)H, (int)k, w.stats, w.O);
   MHIMX_LAUNCH_CHECK();
-  g = {};
-  g.A = w.O; g.lda = I; g.B = m->wo; g.ldb = I; g.C = z; g.ldc = E; g.M = k; g.N = E; g.K = I; g.bias = m->bo; g.prec = fprec;
-  g.drop_p = m->drop_p; g.drop_seed = m->drop_seed + 0x9E3779B97F4A7C15ull; g.drop_tick = m->drop_tick;
-  if (int r = gemm_nt(st, g)) return r;
-  if (update_q) {
-    MHIMX_CHECK_ARG(q_new, "merge_fwd: update_q needs q_new");
-    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)cdiv(k * E, 256)), dim3(256), 0, st, m->q_param, z, q_new, k * E, m->mm);
-    MHIMX_LAUNCH_CHECK();
-  }
+  MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd: update_q needs q_new");
+  MHIMX_CHECK_ARG(I % 4 == 0, "merge_fwd: inner width must be a multiple of 4");
+  hipLaunchKernelGGL(mca_out_kernel, dim3((unsigned)cdiv(E, 4)), dim3(256), 0, st, w.O, m->wo, m->bo, (int)k, (int)E, (int)I, m->drop_p,
+                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, z, m->q_param, update_q ? q_new : (float*)nullptr, m->mm);
+  MHIMX_LAUNCH_CHECK();
   return 0;
 }
 
@@ -425,10 +471,9 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   const int gprec = m->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
   const int acc = gr->accumulate;
   // through the output dropout and projection
-  hipLaunchKernelGGL(drop_bwd_kernel, dim3((unsigned)cdiv(k * E, 256)), dim3(256), 0, st, dz, w.dz0, k, (int)E, m->drop_p,
-                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick);
+  hipLaunchKernelGGL(mca_dz0_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, dz, w.dz0, (int)k, (int)E, m->drop_p,
+                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, gr->d_bo, acc);
   MHIMX_LAUNCH_CHECK();
-  if (int r = colsum(st, w.dz0, k, E, gr->d_bo, acc, w.scratch, w.scratch_bytes)) return r;
   mhimx_gemm_tn_args t = {};
   t.A = w.dz0; t.lda = E; t.B = w.O; t.ldb = I; t.C = gr->d_wo; t.ldc = I; t.M = k; t.K1 = E; t.K2 = I; t.splits = 1;
   t.accumulate = acc; t.prec = gprec;

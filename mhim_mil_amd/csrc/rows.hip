@@ -331,7 +331,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_fwd_kernel(const float
 __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int E, const float* __restrict__ w,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-    float* __restrict__ dw_part, float* __restrict__ db_part) {
+    float* __restrict__ dw_part, float* __restrict__ db_part, int direct_accumulate /* -1: partial rows; 0/1: one block writes d_w, d_b */) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dw, [4][E] db
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int MAXQ = 16;                    // E <= 1024
@@ -372,8 +372,15 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
   }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += ROWS_THREADS) {
-    dw_part[(int64_t)blockIdx.x * E + e] = sm[e] + sm[E + e] + sm[2 * E + e] + sm[3 * E + e];
-    db_part[(int64_t)blockIdx.x * E + e] = sm[4 * E + e] + sm[5 * E + e] + sm[6 * E + e] + sm[7 * E + e];
+    const float a = sm[e] + sm[E + e] + sm[2 * E + e] + sm[3 * E + e];
+    const float b = sm[4 * E + e] + sm[5 * E + e] + sm[6 * E + e] + sm[7 * E + e];
+    if (direct_accumulate < 0) {
+      dw_part[(int64_t)blockIdx.x * E + e] = a;
+      db_part[(int64_t)blockIdx.x * E + e] = b;
+    } else {                                          // single block (a handful of rows): the final gradients, no reduce launch
+      dw_part[e] = direct_accumulate ? dw_part[e] + a : a;
+      db_part[e] = direct_accumulate ? db_part[e] + b : b;
+    }
   }
 }
 
@@ -670,8 +677,14 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   int grid = (int)cdiv(M, 4);
   if (grid < 1) grid = 1;
   if (grid > max_parts) grid = max_parts;
+  if (M <= 16) {                            // a few rows (the k global queries): ONE block writes d_w / d_b itself
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E, w, mean,
+                       rstd, dx, d_w, d_b, accumulate ? 1 : 0);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                     w, mean, rstd, dx, dw_part, db_part);
+                     w, mean, rstd, dx, dw_part, db_part, -1);
   MHIMX_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(E, 32), 2), dim3(RP_THREADS), 0, st, dw_part, db_part, grid, (int)E, (int)E,
                      d_w, d_b, accumulate);
