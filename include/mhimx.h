@@ -329,7 +329,9 @@ int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float
 int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
                    int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                    float grad_scale, float ema_mm, int32_t zero_grad /* also clears g (cast away const) */,
-                   const uint64_t* step_dev /* optional: Adam step read from device memory (graph replay) */);
+                   const uint64_t* step_dev /* optional: Adam step read from device memory (graph replay) */,
+                   const float* mm_table, int64_t mm_len /* optional device table: EMA momentum of iteration `step`
+                                                           (the reference's cosine `mm_sche`, base_engine.py:160-161) */);
 
 /* *counter += 1 (device-resident step counters for dropout streams / Adam under hipGraph replay) */
 int mhimx_tick(void* stream, uint64_t* counter);

@@ -117,7 +117,7 @@ SYMBOLS = {
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
-    "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P]),
+    "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P, _P, _I64]),
     "mhimx_tick": (C.c_int, [_P, _P]),
     "mhimx_layernorm_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "mhimx_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),

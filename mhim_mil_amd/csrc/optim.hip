@@ -103,11 +103,19 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restr
 __global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                 float* __restrict__ teacher, int64_t n_train, int64_t n_all, float lr_over_bc1, float bc2s,
                                 float beta1, float beta2, float eps, float wd, float gscale, float mm, int zero_grad,
-                                const uint64_t* __restrict__ step_dev, float lr) {
+                                const uint64_t* __restrict__ step_dev, float lr, const float* __restrict__ mm_table,
+                                int64_t mm_len, int64_t step_host) {
+  int64_t step = step_host;
   if (step_dev) {                       // graph replay: the step count lives on the device
-    const double t = (double)step_dev[0];
+    step = (int64_t)step_dev[0];
+    const double t = (double)step;
     lr_over_bc1 = (float)((double)lr / (1.0 - pow((double)beta1, t)));
     bc2s = (float)sqrt(1.0 - pow((double)beta2, t));
+  }
+  if (mm_table) {                       // EMA momentum schedule (base_engine.py:160-161): entry of this iteration, last one held
+    int64_t i = step - 1;
+    i = i < 0 ? 0 : (i >= mm_len ? mm_len - 1 : i);
+    mm = mm_table[i];
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
     float w = p[i];
@@ -144,7 +152,9 @@ extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, 
 
 extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
                               int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
-                              float grad_scale, float ema_mm, int32_t zero_grad, const uint64_t* step_dev) {
+                              float grad_scale, float ema_mm, int32_t zero_grad, const uint64_t* step_dev,
+                              const float* mm_table, int64_t mm_len) {
+  MHIMX_CHECK_ARG(!mm_table || mm_len > 0, "adam_ema: empty momentum schedule");
   MHIMX_CHECK_ARG(p && g && m && v && n_train >= 0 && n_all >= n_train && (step >= 1 || step_dev), "adam_ema: bad args");
   if (step < 1) step = 1;
   if (n_all == 0) return 0;
@@ -153,7 +163,7 @@ extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, 
   const int64_t blocks = cdiv(n_all, 256) < 2048 ? cdiv(n_all, 256) : 2048;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v,
                      teacher, n_train, n_all, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, weight_decay,
-                     grad_scale, ema_mm, zero_grad, step_dev, lr);
+                     grad_scale, ema_mm, zero_grad, step_dev, lr, mm_table, mm_len, step);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

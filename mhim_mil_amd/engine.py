@@ -65,6 +65,19 @@ class CommonMIL:
         return model.forward_test(bag), label
 
 
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
+    """The reference's per-iteration cosine schedule (utils.py:199-210): used for `mm_sche` (EMA momentum mm -> 1,
+    modules/__init__.py:177-181) and `mrh_sche` (HAM ratio mask_ratio_h -> 0, modules/__init__.py:72-75)."""
+    import numpy as np
+    warmup_iters = warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warmup_iters) if warmup_epochs > 0 else np.array([])
+    iters = np.arange(epochs * niter_per_ep - warmup_iters)
+    sched = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * iters / len(iters)))
+    sched = np.concatenate((warm, sched))
+    assert len(sched) == epochs * niter_per_ep
+    return sched
+
+
 class FlatState:
     """Flat fp32 buffers behind a student/teacher pair.
 
@@ -132,7 +145,7 @@ class FusedTrainer:
     """One-call MHIM(ABMIL) train step on flat buffers (the benchmarked path)."""
 
     def __init__(self, student: MHIM, teacher: Optional[MHIM], lr=2e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
-                 mm=0.9997, main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, process_group=None, model="mhim"):
+                 mm=0.9997, main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, process_group=None, model="mhim", mm_sche=None):
         self.s, self.t = student, teacher
         self.flat = FlatState(student, teacher)
         self.lr, self.wd, self.betas, self.eps, self.mm = lr, weight_decay, betas, eps, mm
@@ -151,6 +164,9 @@ class FusedTrainer:
         student._tick = self.tick
         if teacher is not None:
             teacher._tick = self.tick
+        # optional EMA-momentum schedule (one value per optimiser step): a device table indexed by the device-resident step
+        # counter, so it also advances under hipGraph replay
+        self.mm_table = None if mm_sche is None else torch.as_tensor(mm_sche, dtype=torch.float32).to(dev).contiguous()
         self._graph_pool = None
         self._cap_stream = None
         self._side = None
@@ -252,7 +268,7 @@ class FusedTrainer:
         fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
         ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                      fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
-                     grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step)
+                     grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step, mm_table=self.mm_table)
         self._micro = 0
 
     def capture(self, bag, label, warmup=2, **kw):

@@ -387,11 +387,12 @@ def head_fwd_bwd(z, t, wp, bp, label, temp_t=1.0, main_alpha=1.0, aux_alpha=0.0,
 
 
 def adam_ema(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5,
-             grad_scale=1.0, ema_mm=0.9997, zero_grad=True, step_dev=None):
+             grad_scale=1.0, ema_mm=0.9997, zero_grad=True, step_dev=None, mm_table=None):
     n_all = p.numel()
     L.check(L.lib().mhimx_adam_ema(_stream(), _p(p), _p(g), _p(m), _p(v), _p(teacher), int(n_train), int(n_all), int(step),
                                    float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                   float(grad_scale), float(ema_mm), int(bool(zero_grad)), _p(step_dev)), "mhimx_adam_ema")
+                                   float(grad_scale), float(ema_mm), int(bool(zero_grad)), _p(step_dev), _p(mm_table),
+                                   0 if mm_table is None else mm_table.numel()), "mhimx_adam_ema")
 
 
 def tick(counter):

@@ -372,11 +372,27 @@ def g11_forward_func(ns):
     _save("g11_forward_func", dict(seed=7, xseed=11000, n=n, d=d, **V2), **out)
 
 
+def g12_cosine_scheduler(ns):
+    """utils.cosine_scheduler (utils.py:199-210) for the two schedules the trainer builds (modules/__init__.py:72-75,177-181).
+    utils.py imports the whole training stack, so only this function's AST node is compiled and run."""
+    import ast
+    with open(os.path.join(_refimport.REF_ROOT, "utils.py")) as f:
+        tree = ast.parse(f.read())
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "cosine_scheduler")
+    g = {"np": np}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "utils.py", "exec"), g)
+    cs = g["cosine_scheduler"]
+    _save("g12_cosine_scheduler", dict(cases=[[0.9997, 1.0, 5, 7, 0, 1.0], [0.03, 0.0, 4, 9, 0, 0.0], [0.9998, 1.0, 6, 5, 2, 1.0]]),
+          c0=cs(0.9997, 1.0, epochs=5, niter_per_ep=7, start_warmup_value=1.0),
+          c1=cs(0.03, 0.0, epochs=4, niter_per_ep=9),
+          c2=cs(0.9998, 1.0, epochs=6, niter_per_ep=5, warmup_epochs=2, start_warmup_value=1.0))
+
+
 def main():
     ns = _refimport.load()
     torch.set_num_threads(8)
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
-               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func):
+               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler):
         print(fn.__name__)
         fn(ns)
 

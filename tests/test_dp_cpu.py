@@ -126,3 +126,13 @@ def test_sharded_bag_exchanges_two_ranks(tmp_path):
     assert sorted(stay.tolist()) == sorted(rows[:720].tolist()) and sorted(merge.tolist()) == sorted(rows[720:].tolist())
     lo1 = SH_COUNTS[0]
     assert all(v < lo1 for v in res[0]["rows_local"].tolist()) and all(v >= lo1 for v in res[1]["rows_local"].tolist())
+
+
+def test_cosine_scheduler_matches_reference_fixture():
+    """engine.cosine_scheduler == utils.cosine_scheduler (utils.py:199-210) on the fixture made from the reference."""
+    from tests import golden_util as G
+    from mhim_mil_amd.engine import cosine_scheduler
+    meta, a = G.load("g12_cosine_scheduler")
+    for i, (base, final, ep, nit, warm, start) in enumerate(meta["cases"]):
+        got = cosine_scheduler(base, final, epochs=ep, niter_per_ep=nit, warmup_epochs=warm, start_warmup_value=start)
+        np.testing.assert_allclose(got, a[f"c{i}"], rtol=0, atol=1e-15)

@@ -270,3 +270,43 @@ def test_rejects_cpu_tensors_and_missing_paths():
         MHIM(input_dim=64, baseline="dsmil")                # scope row N1
     extra = MHIM(input_dim=64, baseline="attn", attn_layer=0, select_mask=False)      # tolerated kwargs
     assert isinstance(extra, torch.nn.Module)
+
+
+def test_mm_schedule_under_graph_replay():
+    """EMA-momentum schedule (`mm_sche`, base_engine.py:160-161) as a device table indexed by the device step counter:
+    replaying ONE captured graph applies a different momentum on every step, equal to the eager trainer's and the oracle's
+    EMA formula."""
+    from mhim_mil_amd.engine import FusedTrainer, cosine_scheduler
+    d, n = 64, 700
+    base = synth.mhim_state(3, input_dim=d, merge_k=5)
+    sche = cosine_scheduler(0.99, 1.0, epochs=2, niter_per_ep=3, start_warmup_value=1.0)         # 6 values, 0.99 -> ~1
+    x = X(321, n, d)
+    label = torch.tensor([1], device=DEV)
+    k, n_sel, _ = O.mask_count(n, V2["mask_ratio_h"], V2["mask_ratio_hr"])
+    perm = torch.from_numpy(synth.permutation(5, k)).to(DEV)
+    shuf = torch.from_numpy(synth.permutation(6, n - n_sel)).to(DEV)
+
+    def run(graph):
+        s = build(base, input_dim=d, **V2).train()
+        t = build(synth.spread_teacher(base), input_dim=d, **V2).train()
+        tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.5, mm_sche=sche)
+        tea0 = tr.flat.teacher.clone()
+        if graph:
+            g = tr.capture(x, label, warmup=0, perm=perm, ids_shuffle=shuf)          # capture runs no eager step first
+            for _ in range(4):
+                g.replay()
+        else:
+            for _ in range(4):
+                tr.train_step(x, label, perm=perm, ids_shuffle=shuf)
+        torch.cuda.synchronize()
+        return tr, tea0
+
+    tr_e, tea0 = run(False)
+    tr_g, _ = run(True)
+    np.testing.assert_allclose(tr_g.flat.teacher.cpu().numpy(), tr_e.flat.teacher.cpu().numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(tr_g.flat.student.cpu().numpy(), tr_e.flat.student.cpu().numpy(), atol=2e-6, rtol=0)
+    # with a constant momentum of 0.5 the teacher would have moved most of the way to the student; the schedule (~0.99)
+    # keeps it near its start
+    moved = (tr_e.flat.teacher - tea0).abs().max().item()
+    gap = (tr_e.flat.student - tea0).abs().max().item()
+    assert moved < 0.1 * gap
