@@ -127,8 +127,20 @@ def mhim_state(seed: int, input_dim: int = 1024, mlp_dim: int = 512, n_classes: 
             p = f"online_encoder.pos_embedding.{nm}."
             sd[p + "weight"] = normal(seed, (E, 1, k, k), std=1.0 / k, lane=nxt()).astype(np.float32)
             sd[p + "bias"] = normal(seed, (E,), std=0.02, lane=nxt()).astype(np.float32)
+    elif baseline == "dsmil":
+        # DSMIL (mhim_modules/baseline.py:112-194).  Biases get small non-zero values here (the init law zeroes them) so that
+        # parity runs exercise every bias term.
+        def linb(name, o, i):
+            lin(name, o, i)
+            sd[name + ".bias"] = normal(seed, (o,), std=0.05, lane=nxt()).astype(np.float32)
+        linb("online_encoder.i_classifier.0", n_classes, E)
+        linb("online_encoder.b_classifier.q.0", 128, E)
+        linb("online_encoder.b_classifier.q.2", 128, 128)
+        linb("online_encoder.b_classifier.v.1", E, E)
+        sd["online_encoder.b_classifier.fcc.weight"] = normal(seed, (n_classes, n_classes, E), std=0.03, lane=nxt()).astype(np.float32)
+        sd["online_encoder.b_classifier.fcc.bias"] = normal(seed, (n_classes,), std=0.05, lane=nxt()).astype(np.float32)
     else:
-        raise ValueError(f"baseline {baseline!r} not on the hot path (SURVEY.md §8(f) N1)")
+        raise ValueError(f"unknown baseline {baseline!r}")
     lin("predictor", n_classes, E)
     return sd
 

@@ -372,6 +372,63 @@ def g11_forward_func(ns):
     _save("g11_forward_func", dict(seed=7, xseed=11000, n=n, d=d, **V2), **out)
 
 
+def g13_dsmil(ns):
+    """MHIM(baseline='dsmil') (scope row N1): eval forward_test (+attn), teacher, student step with gradients, pure train."""
+    d, n = 64, 500
+    cfg = {**V2, "merge_k": 5}
+    base = synth.mhim_state(19, input_dim=d, merge_k=5, baseline="dsmil")
+    x = torch.from_numpy(synth.bag(13000, n, d)).unsqueeze(0)
+    m = _refimport.build_mhim(ns, base, input_dim=d, baseline="dsmil", **cfg)
+    _refimport.zero_aux_dropouts(m)
+    out = {}
+    m.eval()
+    with torch.no_grad():
+        lg = m.forward_test(x)
+        lg2, a = m.forward_test(x, return_attn=True)
+        _, a_raw = m.forward_test(x, return_attn=True, no_norm=True)
+    assert isinstance(lg, tuple) and lg[1].shape == (1, 2, 512)          # (mhim.py:262: the encoder's ([l, l_ins], B) tuple)
+    out["test_logits_bag"], out["test_logits_ins"] = lg[0][0][0].numpy(), lg[0][1][0].numpy()
+    out["test_B"] = lg[1][0].numpy()
+    np.testing.assert_allclose(lg2[0][0].numpy(), lg[0][0][0].numpy())
+    out["test_attn"] = a[0].numpy()
+    np.testing.assert_allclose(a_raw[0].numpy(), a[0].numpy())          # cls_attn: the instance logits either way
+    m.train()
+    tsd = synth.spread_teacher(base) if False else base
+    t = _refimport.build_mhim(ns, tsd, input_dim=d, baseline="dsmil", **cfg)
+    _refimport.zero_aux_dropouts(t)
+    t.train()
+    with torch.no_grad():
+        tfeat, tscore = t.forward_teacher(x)
+    out["teacher_feat"], out["teacher_score"] = tfeat[0].numpy(), tscore[0].numpy()
+    k = int(np.ceil(n * min(cfg["mask_ratio_h"] / cfg["mask_ratio_hr"], 1.0)))
+    n_sel = int(np.ceil(k * cfg["mask_ratio_hr"]))
+    torch.manual_seed(29)                                   # the student's two draws, replayed (cf. _student_case)
+    perm = torch.randperm(k).numpy()
+    shuf = torch.argsort(torch.rand(n - n_sel), dim=0).numpy()
+    torch.manual_seed(29)
+    logits, cl, ps, keep = m(x, tscore, tfeat[0], i=0)
+    mixed = 0.5 * logits[0].view(1, -1) + 0.5 * logits[1].view(1, -1)
+    loss = torch.nn.functional.cross_entropy(mixed, torch.tensor([1])) + 0.5 * cl
+    loss.backward()
+    out["logits_bag"], out["logits_ins"] = logits[0][0].detach().numpy(), logits[1][0].detach().numpy()
+    out["cls_loss"], out["loss"], out["keep"] = float(cl), float(loss), keep
+    keys, norms = [], []
+    for k_, p_ in m.named_parameters():
+        if p_.grad is not None and k_ != "merge.global_q":
+            keys.append(k_)
+            norms.append(float(p_.grad.norm()))
+            out.update(compact(f"grad:{k_}", p_.grad.numpy()))
+    out["grad_keys"], out["grad_norms"] = np.array(json.dumps(keys)), np.array(norms)
+    out["perm"], out["ids_shuffle"] = perm, shuf
+    # pure (no mask / merge) train-mode logits
+    mp = _refimport.build_mhim(ns, synth.mhim_state(19, input_dim=d, baseline="dsmil", merge_enable=False), input_dim=d,
+                               baseline="dsmil", **{**cfg, "merge_enable": False})
+    mp.train()
+    pl, _, _, _ = mp.pure(x)
+    out["pure_logits_bag"], out["pure_logits_ins"] = pl[0][0].detach().numpy(), pl[1][0].detach().numpy()
+    _save("g13_dsmil", dict(seed=19, xseed=13000, n=n, d=d, label=1, aux_alpha=0.5, **cfg), **out)
+
+
 def g12_cosine_scheduler(ns):
     """utils.cosine_scheduler (utils.py:199-210) for the two schedules the trainer builds (modules/__init__.py:72-75,177-181).
     utils.py imports the whole training stack, so only this function's AST node is compiled and run."""
@@ -392,7 +449,7 @@ def main():
     ns = _refimport.load()
     torch.set_num_threads(8)
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
-               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler):
+               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil):
         print(fn.__name__)
         fn(ns)
 

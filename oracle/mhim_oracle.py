@@ -445,6 +445,33 @@ def pseudo_score_trans(v, attn, params, to_out_prefix="online_encoder.layer1.att
 # --------------------------------------------------------------------------- #
 
 
+# --------------------------------------------------------------------------- #
+# N1  DSMIL encoder   (mhim_modules/baseline.py:112-194)
+# --------------------------------------------------------------------------- #
+
+
+def dsmil(h, params, cls_attn=True, no_norm=False, prefix="online_encoder."):
+    """DSMIL.attention (baseline.py:166-186) over BClassifier.forward (:133-157), dropout_v = 0.
+    h [N,E] -> (logits_bag [C], logits_ins [C], attn [N], B [C,E], A [N,C] (softmax unless no_norm))."""
+    P = lambda n: params[prefix + n]
+    classes = _linear(h, P("i_classifier.0.weight"), P("i_classifier.0.bias"))                   # [N,C]
+    b = prefix + "b_classifier."
+    qnet = lambda t: torch.tanh(_linear(torch.relu(_linear(t, params[b + "q.0.weight"], params[b + "q.0.bias"])),
+                                        params[b + "q.2.weight"], params[b + "q.2.bias"]))
+    V = torch.relu(_linear(h, params[b + "v.1.weight"], params[b + "v.1.bias"]))                  # [N,E]
+    Q = qnet(h)                                                                                   # [N,128]
+    _, m_indices = torch.sort(classes, 0, descending=True)                                        # baseline.py:139
+    m_feats = h[m_indices[0]]                                                                     # critical instance per class [C,E]
+    q_max = qnet(m_feats)                                                                         # [C,128]
+    A_raw = (Q @ q_max.t()) / math.sqrt(Q.shape[1])                                               # [N,C]
+    A = torch.softmax(A_raw, 0)
+    B = A.t() @ V                                                                                 # [C,E]
+    Cc = torch.einsum("ocv,cv->o", params[b + "fcc.weight"], B) + params[b + "fcc.bias"]          # Conv1d(C,C,kernel=E) on [1,C,E]
+    classes_bag = classes.max(0).values
+    attn = classes.max(-1).values if cls_attn else A.max(-1).values                               # attn_index == 'max'
+    return Cc, classes_bag, attn, B, (A_raw if no_norm else A)
+
+
 class Cfg:
     """Hyper-parameters of MHIM.__init__ (mhim.py:22-27) that the functions below read."""
 
@@ -462,7 +489,7 @@ def _encode(h, params, cfg: Cfg, return_attn=False, no_norm=False):
         return (z, a, act) if return_attn else z
     if cfg.baseline == "selfattn":
         return sattention(h, params, return_attn, no_norm)
-    raise ValueError(cfg.baseline)
+    raise ValueError(cfg.baseline)            # 'dsmil' returns two logit vectors: handled by the entry points themselves
 
 
 def forward_teacher(x, params, cfg: Cfg, drop_mask=None):
@@ -471,6 +498,9 @@ def forward_teacher(x, params, cfg: Cfg, drop_mask=None):
     p0 = h.shape[0]
     if cfg.merge_test:                                              # mhim.py:196-200
         h = merge_eval(h, params)
+    if cfg.baseline == "dsmil":                                     # mhim.py:202-205: feat = B [C,E], score = max-class logits
+        _, _, attn, B, _ = dsmil(h, params, cls_attn=cfg.attn2score)
+        return B, (attn[:p0] if cfg.merge_test else attn)
     z, attn, act = _encode(h, params, cfg, return_attn=True)
     if cfg.merge_test:                                              # mhim.py:207-213
         attn = [a[:, :p0] for a in attn] if isinstance(attn, list) else attn[:p0]
@@ -489,6 +519,9 @@ def forward_test(x, params, cfg: Cfg, return_attn=False, no_norm=False):
     h = feature(x, params, cfg.act)
     if cfg.merge_test:
         h = merge_eval(h, params)
+    if cfg.baseline == "dsmil":                                     # mhim.py:257-258,264-265: [bag logits, max instance logits]
+        lb, li, a, B, _ = dsmil(h, params, cls_attn=cfg.attn2score, no_norm=no_norm)
+        return ([lb, li], a) if return_attn else ([lb, li], B)      # without return_attn the encoder's tuple passes through (:262)
     if return_attn:
         z, a, _ = _encode(h, params, cfg, True, no_norm)
         return predictor(z, params), a
@@ -498,6 +531,9 @@ def forward_test(x, params, cfg: Cfg, return_attn=False, no_norm=False):
 def pure(x, params, cfg: Cfg, drop_mask=None):
     """MHIM.pure (mhim.py:274-298): logits [C]."""
     h = feature(x, params, cfg.act, drop_mask, cfg.dropout)
+    if cfg.baseline == "dsmil":                                     # mhim.py:289-290
+        lb, li, _, _, _ = dsmil(h, params, cls_attn=cfg.attn2score)
+        return [lb, li]
     return predictor(_encode(h, params, cfg), params)
 
 
@@ -520,6 +556,11 @@ def forward_student(x, params, cfg: Cfg, attn, teacher_feat=None, perm=None, ids
     g_new = None
     if cfg.merge_enable:
         hk, g_new = merge_train(hk, ids_shuffle, params, cfg.merge_ratio, cfg.merge_mm)
+    if cfg.baseline == "dsmil":                                     # mhim.py:355-364: distillation on B [C,E], mean over classes
+        lb, li, _, B, _ = dsmil(hk, params, cls_attn=cfg.attn2score)
+        cls_loss = soft_target_ce(B, teacher_feat.detach(), cfg.temp_t).mean() if teacher_feat is not None else 0.0
+        return [lb, li], cls_loss, ps, hk.shape[0], {"len_keep_mask": len_keep, "mask_ids": mask_ids, "global_q_new": g_new,
+                                                     "feat": B}
     z = _encode(hk, params, cfg)
     logits = predictor(z, params)
     cls_loss = soft_target_ce(z, teacher_feat.detach(), cfg.temp_t) if teacher_feat is not None else 0.0
@@ -569,6 +610,8 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
         logits, cls_loss, ps, keep, ex = forward_student(x, stu_g, cfg, score, t_in, perm, ids_shuffle)
     else:
         logits, cls_loss, ps, keep, ex = pure(x, stu_g, cfg), 0.0, x.shape[0], x.shape[0], {}
+    if isinstance(logits, list):                                    # dsmil: common_mil.py:26-28 mixes the two logit vectors
+        logits = 0.5 * logits[0] + 0.5 * logits[1]
     loss = main_alpha * cross_entropy(logits, label) + aux_alpha * cls_loss   # base_engine.py:99-100
     loss.backward()
     new_stu, new_opt = {}, {}

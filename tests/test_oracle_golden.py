@@ -293,3 +293,42 @@ def test_g11_forward_func():
     lg = O.pure(x, pure, O.Cfg(act="gelu", da_act="relu", merge_enable=False))
     np.testing.assert_allclose(lg.numpy(), a["pure_logits"], atol=2e-6, rtol=1e-5)
     assert list(a["pure_tuple"]) == [0.0, meta["n"], meta["n"], 0.0, 0.0]
+
+
+def test_g13_dsmil():
+    """MHIM(baseline='dsmil') (scope row N1): the oracle's restatement vs the reference fixture — eval logits + attention,
+    teacher (B, max-class score), student step (both logit vectors, distillation loss, every gradient), pure train."""
+    meta, a = G.load("g13_dsmil")
+    d, n = meta["d"], meta["n"]
+    base = synth.mhim_state(meta["seed"], input_dim=d, merge_k=5, baseline="dsmil")
+    cfg = _cfg(meta, baseline="dsmil")
+    x = _x(meta["xseed"], n, d)
+    lg, attn = O.forward_test(x, O.as_torch(base), cfg, return_attn=True)
+    np.testing.assert_allclose(lg[0].numpy(), a["test_logits_bag"].reshape(-1) if a["test_logits_bag"].ndim > 1 and "feat" not in "test_logits_bag" else a["test_logits_bag"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(lg[1].numpy(), a["test_logits_ins"].reshape(-1) if a["test_logits_ins"].ndim > 1 and "feat" not in "test_logits_ins" else a["test_logits_ins"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(attn.numpy(), a["test_attn"].reshape(-1) if a["test_attn"].ndim > 1 and "feat" not in "test_attn" else a["test_attn"], atol=2e-6, rtol=1e-5)
+    feat, score = O.forward_teacher(x, O.as_torch(base), cfg)
+    np.testing.assert_allclose(feat.numpy(), a["teacher_feat"].reshape(-1) if a["teacher_feat"].ndim > 1 and "feat" not in "teacher_feat" else a["teacher_feat"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(score.numpy(), a["teacher_score"].reshape(-1) if a["teacher_score"].ndim > 1 and "feat" not in "teacher_score" else a["teacher_score"], atol=2e-6, rtol=1e-5)
+    p = O.as_torch(base)
+    for k, v in p.items():
+        v.requires_grad_(k not in O.TRAINABLE_EXCLUDE)
+    logits, cl, ps, keep, _ = O.forward_student(x, p, cfg, a["teacher_score"].reshape(-1) if a["teacher_score"].ndim > 1 and "feat" not in "teacher_score" else a["teacher_score"], torch.from_numpy(a["teacher_feat"]),
+                                                perm=a["perm"], ids_shuffle=a["ids_shuffle"])
+    assert keep == int(a["keep"])
+    np.testing.assert_allclose(logits[0].detach().numpy(), a["logits_bag"].reshape(-1) if a["logits_bag"].ndim > 1 and "feat" not in "logits_bag" else a["logits_bag"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(logits[1].detach().numpy(), a["logits_ins"].reshape(-1) if a["logits_ins"].ndim > 1 and "feat" not in "logits_ins" else a["logits_ins"], atol=2e-6, rtol=1e-5)
+    assert abs(float(cl) - float(a["cls_loss"])) < 1e-5
+    loss = O.cross_entropy(0.5 * logits[0] + 0.5 * logits[1], meta["label"]) + meta["aux_alpha"] * cl
+    assert abs(float(loss) - float(a["loss"])) < 1e-5
+    loss.backward()
+    for k, exp in G.tagged(a, "grad").items():
+        # merge.norm.*: the reference's LayerNorm(global_q) backward sees the post-EMA queries (quirk H7, ~1e-4 of scale)
+        scale = float(np.abs(exp["full"]).max()) if "full" in exp else float(exp["norm"]) / np.sqrt(p[k].numel())
+        G.check_compact(p[k].grad.numpy(), exp, rtol=2e-4, atol=(1e-3 if k.startswith("merge.norm") else 1e-6) * scale + 1e-9, what=k)
+    (lb, li), B = O.forward_test(x, O.as_torch(base), cfg)
+    np.testing.assert_allclose(B.numpy(), a["test_B"], atol=2e-6, rtol=1e-5)
+    pl = O.pure(x, O.as_torch(synth.mhim_state(meta["seed"], input_dim=d, baseline="dsmil", merge_enable=False)),
+                _cfg(meta, baseline="dsmil", merge_enable=False))
+    np.testing.assert_allclose(pl[0].numpy(), a["pure_logits_bag"].reshape(-1) if a["pure_logits_bag"].ndim > 1 and "feat" not in "pure_logits_bag" else a["pure_logits_bag"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(pl[1].numpy(), a["pure_logits_ins"].reshape(-1) if a["pure_logits_ins"].ndim > 1 and "feat" not in "pure_logits_ins" else a["pure_logits_ins"], atol=2e-6, rtol=1e-5)
