@@ -39,9 +39,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=400, help="oracle steps for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil"],
                     help="c2 (default, BASELINE.json's metric): MHIM(ABMIL) N=10k D=1024, one bag per GPU per step; "
-                         "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs")
+                         "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs; "
+                         "c2-dsmil: MHIM(DSMIL) N=10k D=1024 (scope row N1)")
     return ap.parse_args()
 
 
@@ -126,12 +127,13 @@ def other_workload(a, world, rank, dev):
     """c3 / c5: parity-test configurations of BASELINE.json, timed for DESIGN.md (not the headline metric)."""
     from mhim_mil_amd import synth
     from mhim_mil_amd.mhim import MHIM
-    c3 = a.workload == "c3"
-    n_total, d = (50000, 1024) if c3 else (200000, 1536)
-    base = synth.mhim_state(7, input_dim=d, merge_k=5, baseline="selfattn" if c3 else "attn")
+    c3 = a.workload in ("c3", "c2-dsmil")                 # replicas driven by FusedTrainer's autograd path
+    bl = {"c3": "selfattn", "c5": "attn", "c2-dsmil": "dsmil"}[a.workload]
+    n_total, d = {"c3": (50000, 1024), "c5": (200000, 1536), "c2-dsmil": (N_INST, D_IN)}[a.workload]
+    base = synth.mhim_state(7, input_dim=d, merge_k=5, baseline=bl)
 
     def mk():
-        m = MHIM(input_dim=d, n_classes=2, baseline="selfattn" if c3 else "attn", prec=a.prec, **CFG)
+        m = MHIM(input_dim=d, n_classes=2, baseline=bl, prec=a.prec, **CFG)
         sd = dict(base)
         sd["merge.global_q"] = sd["merge.global_q_mm"]
         m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
@@ -148,7 +150,7 @@ def other_workload(a, world, rank, dev):
         graphs = None if a.no_graph else [tr.capture(b, lab, warmup=2) for b in bags]
         step = (lambda i: tr.train_step(bags[i % 2], lab)) if graphs is None else (lambda i: graphs[i % 2].replay())
         per_step, scaling, par = n_total * world, "weak", f"dp{world} (replicas, one bag per GPU per step)"
-        name = f"c3: MHIM(TransMIL/Nystrom) train step, one bag N={n_total} D={d} per GPU per step"
+        name = (f"c3: MHIM(TransMIL/Nystrom)" if bl == "selfattn" else "MHIM(DSMIL)") + f" train step, one bag N={n_total} D={d} per GPU per step"
     else:
         from mhim_mil_amd.sharded import ShardedBagTrainer
         assert n_total % world == 0

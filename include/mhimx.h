@@ -319,6 +319,22 @@ int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float
                        float* d_bp, int32_t accumulate, const float* g_logits_in, const float* g_cl_in);
 
 /* ------------------------------------------------------------------------------------------
+ * DSMIL encoder pieces                        replaces: mhim_modules/baseline.py:112-194
+ * The encoder is composed from the GEMMs, mhimx_softmax_rows and these; see mhim_mil_amd/dsmil.py.
+ * ---------------------------------------------------------------------------------------- */
+/* vals[c] = max_m x[m,c], idx[c] = arg max (lowest m on ties): the critical instance per class (baseline.py:139-140) and the
+ * max-instance logits (:172).  x[M,C] contiguous, C <= 16. */
+int mhimx_colmax(void* stream, const float* x, int64_t M, int64_t C, float* vals, int64_t* idx);
+/* out[m] = max_c x[m,c]: the per-instance score of DSMIL with cls_attn (baseline.py:176). */
+int mhimx_rowmax(void* stream, const float* x, int64_t M, int64_t C, float* out);
+/* Head: logits = 0.5 (bag + max instance) (common_mil.py:26-28), CE, and cl = mean_c SoftTargetCE(Bs[c], Bt[c]) on the
+ * per-class bag features [C,V] (mhim.py:355-364).  losses[3] = {main_alpha*ce + aux_alpha*cl, ce, cl}; g_* of loss*inv_accum.
+ * Autograd form: label_dev == NULL (no CE) and g_cl_in[1] (device) = upstream d loss / d cl.  Bt may be NULL. */
+int mhimx_dsmil_head(void* stream, const float* logits_bag, const float* logits_ins, const int64_t* label_dev, const float* Bs,
+                     const float* Bt, int64_t C, int64_t V, float temp_t, float main_alpha, float aux_alpha, float inv_accum,
+                     float* losses, float* g_logits_bag, float* g_logits_ins, float* g_B, const float* g_cl_in);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser + EMA teacher                                       
  * replaces: torch.optim.Adam as built in train_utils.py:58-65 (L2 weight decay added to the gradient)
  *           and the per-parameter EMA loop base_engine.py:166-167.

@@ -98,6 +98,63 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restr
   if (d_bp && tid < C) d_bp[tid] = accumulate ? d_bp[tid] + gl[tid] : gl[tid];
 }
 
+// DSMIL head (common_mil.py:26-28, mhim.py:355-364, losses.py:26-45): logits = 0.5 (bag + max-instance), CE on them, and the
+// distillation loss cl = mean_c [ -sum_v softmax(Bt[c]/temp_t)_v log_softmax(Bs[c])_v ] on the per-class bag features.
+// Label given: loss and all gradients in one launch.  label == NULL: the autograd form (cl only, upstream scale g_cl_in).
+__global__ __launch_bounds__(HEAD_THREADS) void dsmil_head_kernel(const float* __restrict__ lb, const float* __restrict__ li,
+                                                                  const int64_t* __restrict__ label, const float* __restrict__ Bs,
+                                                                  const float* __restrict__ Bt, int C, int V, float temp_t,
+                                                                  float main_alpha, float aux_alpha, float inv_accum,
+                                                                  float* __restrict__ losses, float* __restrict__ g_lb,
+                                                                  float* __restrict__ g_li, float* __restrict__ g_B,
+                                                                  const float* __restrict__ g_cl_in) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float ce = 0.f;
+  if (label) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, 0.5f * (lb[c] + li[c]));
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(0.5f * (lb[c] + li[c]) - mx);
+    const int y = (int)label[0];
+    ce = -(0.5f * (lb[y] + li[y]) - mx - logf(den));
+    if (tid < C) {
+      const float g = 0.5f * main_alpha * inv_accum * (expf(0.5f * (lb[tid] + li[tid]) - mx) / den - (tid == y ? 1.f : 0.f));
+      g_lb[tid] = g;
+      g_li[tid] = g;
+    }
+  }
+  if (g_cl_in) aux_alpha = g_cl_in[0];
+  float cl = 0.f;
+  if (Bt) {
+    for (int c = 0; c < C; ++c) {
+      const float* s = Bs + (int64_t)c * V;
+      const float* t = Bt + (int64_t)c * V;
+      float a = -INFINITY, b = -INFINITY;
+      for (int e = tid; e < V; e += HEAD_THREADS) { a = fmaxf(a, s[e]); b = fmaxf(b, t[e] / temp_t); }
+      const float smx = blk_max(a, red), tmx = blk_max(b, red);
+      float sa = 0.f, sb = 0.f;
+      for (int e = tid; e < V; e += HEAD_THREADS) { sa += expf(s[e] - smx); sb += expf(t[e] / temp_t - tmx); }
+      const float sden = blk_sum(sa, red), tden = blk_sum(sb, red);
+      const float ls = logf(sden);
+      float acc = 0.f;
+      for (int e = tid; e < V; e += HEAD_THREADS) {
+        const float pt = expf(t[e] / temp_t - tmx) / tden;
+        acc += pt * (s[e] - smx - ls);
+        if (g_B) g_B[(int64_t)c * V + e] = aux_alpha * inv_accum / (float)C * (expf(s[e] - smx) / sden - pt);
+      }
+      cl -= blk_sum(acc, red) / (float)C;
+    }
+  } else if (g_B) {
+    for (int i = tid; i < C * V; i += HEAD_THREADS) g_B[i] = 0.f;
+  }
+  if (tid == 0) {
+    losses[0] = main_alpha * ce + aux_alpha * cl;
+    losses[1] = ce;
+    losses[2] = cl;
+  }
+}
+
 // torch.optim.Adam semantics (weight decay folded into the gradient, bias-corrected, eps outside the sqrt of
 // the corrected second moment) + EMA teacher.  bc1 = 1-beta1^t, bc2s = sqrt(1-beta2^t) come from the host in fp64.
 __global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
@@ -146,6 +203,18 @@ extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, 
   MHIMX_CHECK_ARG(C > 0 && C <= 16 && E > 0, "head: bad dims");
   hipLaunchKernelGGL(head_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
                      temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mhimx_dsmil_head(void* stream, const float* logits_bag, const float* logits_ins, const int64_t* label_dev,
+                                const float* Bs, const float* Bt, int64_t C, int64_t V, float temp_t, float main_alpha,
+                                float aux_alpha, float inv_accum, float* losses, float* g_logits_bag, float* g_logits_ins,
+                                float* g_B, const float* g_cl_in) {
+  MHIMX_CHECK_ARG(losses && Bs && C > 0 && C <= 16 && V > 0, "dsmil_head: bad args");
+  MHIMX_CHECK_ARG(!label_dev || (logits_bag && logits_ins && g_logits_bag && g_logits_ins), "dsmil_head: label needs the logits and their gradients");
+  hipLaunchKernelGGL(dsmil_head_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, logits_bag, logits_ins, label_dev, Bs, Bt,
+                     (int)C, (int)V, temp_t, main_alpha, aux_alpha, inv_accum, losses, g_logits_bag, g_logits_ins, g_B, g_cl_in);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

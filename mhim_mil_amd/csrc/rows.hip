@@ -443,6 +443,48 @@ __global__ __launch_bounds__(256) void mul_colsum_kernel(float* __restrict__ dH,
   }
 }
 
+// per-column max and arg-max (lowest row on ties) of x[M,C], C <= 16: DSMIL's critical instance per class
+// (baseline.py:139-140) and its max-instance logits (:172).  One block.
+__global__ __launch_bounds__(1024) void colmax_kernel(const float* __restrict__ x, int64_t M, int C, float* __restrict__ vals,
+                                                      int64_t* __restrict__ idx) {
+  __shared__ float bv[16][16];
+  __shared__ int64_t bi[16][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < C; ++c) {
+    float best = -INFINITY;
+    int64_t arg = 0;
+    for (int64_t m = threadIdx.x; m < M; m += 1024) {
+      const float v = x[m * C + c];
+      if (v > best) { best = v; arg = m; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int64_t oi = __shfl_xor(arg, o, 64);
+      if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+    }
+    if (lane == 0) { bv[c][wave] = best; bi[c][wave] = arg; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    float best = bv[c][0];
+    int64_t arg = bi[c][0];
+    for (int w = 1; w < 16; ++w)
+      if (bv[c][w] > best || (bv[c][w] == best && bi[c][w] < arg)) { best = bv[c][w]; arg = bi[c][w]; }
+    vals[c] = best;
+    idx[c] = arg;
+  }
+}
+// out[m] = max_c x[m,c]  (DSMIL's instance score with cls_attn, baseline.py:176)
+__global__ void rowmax_kernel(const float* __restrict__ x, int64_t M, int C, float* __restrict__ out) {
+  for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (int64_t)gridDim.x * blockDim.x) {
+    float v = x[m * C];
+    for (int c = 1; c < C; ++c) v = fmaxf(v, x[m * C + c]);
+    out[m] = v;
+  }
+}
+
 __global__ void colsum_part_kernel(const float* __restrict__ X, int64_t M, int E, int64_t chunk, float* __restrict__ part) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -760,6 +802,19 @@ extern "C" int mhimx_act_bwd(void* stream, float* dH, const float* H, const floa
                        (int)E, (int)E, colsum_out, accumulate);
     MHIMX_LAUNCH_CHECK();
   }
+  return 0;
+}
+extern "C" int mhimx_colmax(void* stream, const float* x, int64_t M, int64_t C, float* vals, int64_t* idx) {
+  MHIMX_CHECK_ARG(x && vals && idx && M > 0 && C > 0 && C <= 16, "colmax: bad args (C <= 16)");
+  hipLaunchKernelGGL(colmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, M, (int)C, vals, idx);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_rowmax(void* stream, const float* x, int64_t M, int64_t C, float* out) {
+  MHIMX_CHECK_ARG(x && out && M > 0 && C > 0, "rowmax: bad args");
+  hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0, (hipStream_t)stream, x, M,
+                     (int)C, out);
+  MHIMX_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,

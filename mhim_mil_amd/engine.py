@@ -43,17 +43,22 @@ class CommonMIL:
 
     def forward_func(self, args, model, model_ema, bag, label, criterion, batch_size, i, epoch, n_iter, pos, **kwargs):
         """-> (logits, label, aux_loss, patch_num, keep_num, pad_ratio, kn_std)   (common_mil.py:14-48)"""
-        if getattr(args, "baseline", "attn") == "dsmil":
-            raise NotImplementedError("dsmil baseline: scope row N1 (SURVEY.md §8(f))")
+        dsmil = getattr(args, "baseline", "attn") == "dsmil"
         if args.model == "mhim":
             teacher_feat, score = (None, None)
             if model_ema is not None:
                 teacher_feat, score = model_ema.forward_teacher(bag)
             if args.aux_alpha == 0.:
                 teacher_feat = None                                        # common_mil.py:24
+            if dsmil and teacher_feat is not None:
+                teacher_feat = teacher_feat[0]                              # common_mil.py:27: cls_tea[0] = B [C,E]
             logits, aux_loss, patch_num, keep_num = model(bag, score, teacher_feat, i=n_iter, **kwargs)
+            if dsmil:                                                       # common_mil.py:28
+                logits = 0.5 * logits[0].view(batch_size, -1) + 0.5 * logits[1].view(batch_size, -1)
         elif args.model == "mhim_pure":
             logits, aux_loss, patch_num, keep_num = model.pure(bag)
+            if dsmil:                                                       # common_mil.py:34-35
+                logits = 0.5 * logits[0].view(batch_size, -1) + 0.5 * logits[1].view(batch_size, -1)
         else:
             raise NotImplementedError(f"model {args.model!r} is outside the MHIM hot path")
         return logits, label, aux_loss, patch_num, keep_num, 0., 0.
@@ -62,7 +67,11 @@ class CommonMIL:
         """-> (logits, label)   (common_mil.py:56-68)"""
         if args.model not in ("mhim", "mhim_pure"):
             raise NotImplementedError(f"model {args.model!r} is outside the MHIM hot path")
-        return model.forward_test(bag), label
+        logits = model.forward_test(bag)
+        if getattr(args, "baseline", "attn") == "dsmil":                    # common_mil.py:59-60,66-67
+            logits = logits[0]
+            logits = 0.5 * logits[0] + 0.5 * logits[1]
+        return logits, label
 
 
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0):
@@ -88,8 +97,11 @@ class FlatState:
 
     def __init__(self, student: MHIM, teacher: Optional[MHIM]):
         named = list(student.named_parameters())          # de-duplicated (global_q alias appears once)
-        self.train_names = [n for n, p in named if p.requires_grad]
-        self.fixed_names = [n for n, p in named if not p.requires_grad]
+        # parameters the forward never touches get no gradient; torch.optim.Adam skips those (no update, no weight decay),
+        # so they sit in the non-trainable tail here (DSMIL never uses MHIM.predictor: mhim.py:264-265)
+        unused = set(getattr(student, "unused_parameter_names", lambda: ())())
+        self.train_names = [n for n, p in named if p.requires_grad and n not in unused]
+        self.fixed_names = [n for n, p in named if not p.requires_grad or n in unused]
         self.names = self.train_names + self.fixed_names
         dev = named[0][1].device
         sizes = {n: p.numel() for n, p in named}
@@ -212,6 +224,8 @@ class FusedTrainer:
             keep_num = ps
         if s.baseline == "selfattn":
             return self._selfattn_forward_backward(x, label, plan, teacher_feat, keep_num, first)
+        if s.baseline == "dsmil":
+            return self._dsmil_forward_backward(x, label, plan, teacher_feat, keep_num)
         merge_on = s.merge_enable
         if self.model_kind != "mhim":
             s.merge_enable = False
@@ -234,17 +248,42 @@ class FusedTrainer:
         self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num}
         return logits, losses
 
+    def _bind_grads(self):
+        """Every trainable parameter's .grad IS its view of the flat gradient buffer: autograd accumulates straight into the
+        buffer the single all-reduce and the fused Adam read."""
+        if not getattr(self, "_grads_bound", False):
+            pd = dict(self.s.named_parameters())
+            for n in self.flat.train_names:
+                pd[n].grad = self.flat.grad_views[n]
+            self._grads_bound = True
+
+    def _dsmil_forward_backward(self, x, label, plan, teacher_feat, keep_num):
+        """DSMIL student (scope row N1): kernel-backed autograd primitives (dsmil.py); loss, CE on the mixed logits and the
+        per-class distillation with all three output gradients come from ONE head kernel."""
+        from . import dsmil as DS
+        from .mhim import _FeatureFn
+        s = self.s
+        self._bind_grads()
+        if self.model_kind == "mhim":
+            lb, li, B = s._dsmil_student(x, plan)
+        else:
+            lb, li, B, _ = s.online_encoder(_FeatureFn.apply(s, x, plan, s.feature[0].weight, s.feature[0].bias))
+        Bt = teacher_feat[0].contiguous() if (teacher_feat is not None and self.aux_alpha != 0.) else None
+        losses, g_lb, g_li, g_B = DS.dsmil_head(lb.detach(), li.detach(), label, B.detach().contiguous(), Bt, float(s.temp_t),
+                                                self.main_alpha, self.aux_alpha, 1.0 / self.accum)
+        torch.autograd.backward([lb, li, B], [g_lb, g_li, g_B])
+        logits = 0.5 * (lb.detach() + li.detach())
+        self._micro += 1
+        self.last = {"logits": logits, "losses": losses, "patch_num": x.shape[0], "keep_num": keep_num}
+        return logits, losses
+
     def _selfattn_forward_backward(self, x, label, plan, teacher_feat, keep_num, first):
         """TransMIL student: the encoder is a graph of kernel-backed autograd primitives (nystrom.py); every parameter's
         .grad IS its view of the flat gradient buffer, so autograd accumulates straight into the buffer the single
         all-reduce and the fused Adam read."""
         s, fl = self.s, self.flat
         gv = fl.grad_views
-        if not getattr(self, "_grads_bound", False):
-            pd = dict(s.named_parameters())
-            for n in fl.train_names:
-                pd[n].grad = gv[n]
-            self._grads_bound = True
+        self._bind_grads()
         if self.model_kind == "mhim":
             z = s._selfattn_student(x, plan)
         else:

@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
+from . import dsmil as DS
 from . import nystrom as NY
 from . import ops
 
@@ -229,12 +230,17 @@ class MHIM(nn.Module):
         self.dropout_p = float(dropout)
         self.prec = prec
         self.merge_enable = bool(merge_enable)
-        if baseline not in ("attn", "selfattn"):
-            raise NotImplementedError(f"baseline={baseline!r}: 'attn' (ABMIL) and 'selfattn' (TransMIL/Nystrom) have HIP "
-                                      "kernels; 'dsmil' is scope row N1 (SURVEY.md §8(f))")
+        if baseline not in ("attn", "selfattn", "dsmil"):
+            raise NotImplementedError(f"baseline={baseline!r}: the reference knows 'attn' (ABMIL), 'selfattn' (TransMIL/Nystrom) "
+                                      "and 'dsmil'")
         self.merge = _Merge(mlp_dim, merge_k, merge_mm, merge_ratio) if merge_enable else nn.Identity()
         self.feature = nn.Sequential(_Lin(input_dim, mlp_dim), _Slot())
-        self.online_encoder = _DAttention(mlp_dim, gated=gated) if baseline == "attn" else NY.SAttention(mlp_dim, head)
+        if baseline == "attn":
+            self.online_encoder = _DAttention(mlp_dim, gated=gated)
+        elif baseline == "selfattn":
+            self.online_encoder = NY.SAttention(mlp_dim, head)
+        else:
+            self.online_encoder = DS.DSMIL(n_classes=n_classes, mlp_dim=mlp_dim, cls_attn=attn2score)      # mhim.py:91-95
         self.predictor = _Lin(mlp_dim, n_classes)
         self._step = 0
         self._tick = None          # optional device step counter (uint64 [1]) mixed into every dropout seed: set by
@@ -253,6 +259,10 @@ class MHIM(nn.Module):
             names += ["merge.norm.weight", "merge.norm.bias", "merge.attn.to_kv.weight", "merge.attn.to_q.weight",
                       "merge.attn.to_out.0.weight", "merge.attn.to_out.0.bias"]
         return names
+
+    def unused_parameter_names(self):
+        """Parameters no entry point reads (they never receive a gradient, so the reference's Adam never moves them)."""
+        return ("predictor.weight", "predictor.bias") if self.baseline == "dsmil" else ()
 
     def _param(self, name):
         obj = self
@@ -537,7 +547,7 @@ class MHIM(nn.Module):
         if mrh is not None:
             mask_ratio_h = mrh
         v2 = self.mask_ratio == 0 and self.mask_ratio_l == 0 and mask_ratio_h > 0
-        if (v2 and self.baseline == "attn" and perm is None and ids_shuffle is None and generator is None and attn is not None
+        if (v2 and self.baseline in ("attn", "dsmil") and perm is None and ids_shuffle is None and generator is None and attn is not None
                 and attn.numel() == ps and ps <= 16384):
             eff, rr = mask_ratio_h / self.mask_ratio_hr, self.mask_ratio_hr
             if eff > 1:
@@ -582,6 +592,10 @@ class MHIM(nn.Module):
         if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)
             mw = self._merge_w(None)
             T2, _, _ = ops.merge_fwd(mw, H, update_q=False)
+        if self.baseline == "dsmil":                           # mhim.py:202-205: feature = B [1,C,E], score = instance score
+            tok = H if T2 is None else torch.cat([H, T2], 0)
+            _, _, B, attn = self.online_encoder(tok, want_attn=True)
+            return B.unsqueeze(0), attn[:p0].view(1, -1)
         if self.baseline == "selfattn":
             tok = H if T2 is None else torch.cat([H, T2], 0)
             z, attn, v = self._encode(tok, return_attn=True)
@@ -606,6 +620,11 @@ class MHIM(nn.Module):
         T2 = None
         if self.merge_test:
             T2, _, _ = ops.merge_fwd(self._merge_w(None), H, update_q=False)
+        if self.baseline == "dsmil":                           # mhim.py:257-265: no predictor; ([bag, max-instance], B | attn)
+            tok = H if T2 is None else torch.cat([H, T2], 0)
+            lb, li, B, attn = self.online_encoder(tok, want_attn=return_attn, no_norm=no_norm)
+            logits = [lb.view(1, -1), li.view(1, -1)]
+            return (logits, attn.view(1, -1)) if return_attn else (logits, B.unsqueeze(0))
         if self.baseline == "selfattn":
             tok = H if T2 is None else torch.cat([H, T2], 0)
             pw, pb = self.predictor.weight.data, self.predictor.bias.data
@@ -648,6 +667,14 @@ class MHIM(nn.Module):
         cam = ops.gemm_nt(f, self.predictor.weight.data, prec="bf16x3")
         return ops.pseudo_score(None, None, cam, self.predictor.bias.data)
 
+    def _dsmil_student(self, x, plan):
+        H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
+        if self.merge_enable and plan.R > 0:
+            z_tok = _MergeFn.apply(self, plan, H[plan.Lk:], *[self._param(n) for n in _MergeFn.NAMES])
+            H = torch.cat([H[:plan.Lk], z_tok], 0)
+        lb, li, B, _ = self.online_encoder(H)
+        return lb, li, B
+
     def _selfattn_student(self, x, plan):
         H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
         if self.merge_enable and plan.R > 0:
@@ -667,6 +694,11 @@ class MHIM(nn.Module):
         ps = x.shape[0]
         if not self.training:
             return self.forward_test(x)
+        if self.baseline == "dsmil":                           # mhim.py:289-290
+            plan = self._plan_all_rows(ps)
+            H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
+            lb, li, _, _ = self.online_encoder(H)
+            return [lb.view(1, -1), li.view(1, -1)], 0, ps, ps
         if self.baseline == "selfattn":
             plan = self._plan_all_rows(ps)
             H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
@@ -697,6 +729,12 @@ class MHIM(nn.Module):
         rows, len_keep, Lk, R = self.student_rows(ps, i, attn, perm=perm, ids_shuffle=ids_shuffle)
         plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=self._next_seed(), drop_mask=drop_mask,
                        mca_seed=self._next_seed(), training=self.training)
+        if self.baseline == "dsmil":                           # mhim.py:355-364
+            lb, li, B = self._dsmil_student(x, plan)
+            cls_loss = 0.
+            if teacher_cls_feat is not None:
+                cls_loss = DS.SoftTargetCE.apply(B, teacher_cls_feat.detach().reshape(B.shape).float(), float(self.temp_t))
+            return [lb.view(1, -1), li.view(1, -1)], cls_loss, ps, Lk + self.merge.k
         if self.baseline == "selfattn":
             z = self._selfattn_student(x, plan).view(1, -1)
         else:

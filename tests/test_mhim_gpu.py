@@ -267,7 +267,7 @@ def test_rejects_cpu_tensors_and_missing_paths():
     with pytest.raises(MhimxError):
         m.forward_test(torch.zeros(1, 10, 64))
     with pytest.raises(NotImplementedError):
-        MHIM(input_dim=64, baseline="dsmil")                # scope row N1
+        MHIM(input_dim=64, baseline="clam")                 # not one of the reference's three MHIM baselines
     extra = MHIM(input_dim=64, baseline="attn", attn_layer=0, select_mask=False)      # tolerated kwargs
     assert isinstance(extra, torch.nn.Module)
 
