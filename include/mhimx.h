@@ -322,6 +322,10 @@ int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, const float
  * DSMIL encoder pieces                        replaces: mhim_modules/baseline.py:112-194
  * The encoder is composed from the GEMMs, mhimx_softmax_rows and these; see mhim_mil_amd/dsmil.py.
  * ---------------------------------------------------------------------------------------- */
+/* y[:,c] = softmax over the M rows of alpha * x[:,c] (x[M,C] contiguous, few columns); bwd: dx = alpha*y*(dy - sum_m y*dy).
+ * replaces: F.softmax(A, 0) (baseline.py:147) and its autograd. */
+int mhimx_softmax_cols(void* stream, const float* x, float* y, int64_t M, int64_t C, float alpha);
+int mhimx_softmax_cols_bwd(void* stream, const float* y, const float* dy, float* dx, int64_t M, int64_t C, float alpha);
 /* vals[c] = max_m x[m,c], idx[c] = arg max (lowest m on ties): the critical instance per class (baseline.py:139-140) and the
  * max-instance logits (:172).  x[M,C] contiguous, C <= 16. */
 int mhimx_colmax(void* stream, const float* x, int64_t M, int64_t C, float* vals, int64_t* idx);

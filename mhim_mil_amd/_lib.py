@@ -114,6 +114,8 @@ SYMBOLS = {
     "mhimx_merge_fwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I32, _P, _I64]),
     "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
     "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_softmax_cols": (C.c_int, [_P, _P, _P, _I64, _I64, _F]),
+    "mhimx_softmax_cols_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F]),
     "mhimx_colmax": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "mhimx_rowmax": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),

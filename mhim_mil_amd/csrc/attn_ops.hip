@@ -130,6 +130,50 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
 }
 
 // ------------------------------------------------------------------------------------------------
+// column softmax of x[M,C] (C <= 16 columns, normalised over the M rows): DSMIL's attention over instances
+// (mhim_modules/baseline.py:147).  One block per column.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void softmax_cols_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t M, int C,
+                                                                float alpha) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -INFINITY;
+  for (int64_t r = threadIdx.x; r < M; r += 1024) m = fmaxf(m, x[r * C + c] * alpha);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  float s = 0.f;
+  for (int64_t r = threadIdx.x; r < M; r += 1024) s += __expf(x[r * C + c] * alpha - m);
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red[w];
+  const float inv = 1.f / tot;
+  for (int64_t r = threadIdx.x; r < M; r += 1024) y[r * C + c] = __expf(x[r * C + c] * alpha - m) * inv;
+}
+// dx = alpha * y * (dy - sum_rows(y * dy)) per column
+__global__ __launch_bounds__(1024) void softmax_cols_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, int64_t M, int C, float alpha) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int64_t r = threadIdx.x; r < M; r += 1024) s += y[r * C + c] * dy[r * C + c];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red[w];
+  for (int64_t r = threadIdx.x; r < M; r += 1024) dx[r * C + c] = alpha * y[r * C + c] * (dy[r * C + c] - tot);
+}
+
+// ------------------------------------------------------------------------------------------------
 // pseudo-inverse initialisation (nystrom_attention.py:15-18): z0 = a^T / (max_{b,i} sum_j |a_ij| * max_{b,j} sum_i |a_ij|)
 // with GLOBAL maxima over the batch of heads.  stats: [0]=c (max row sum), [1]=r (max col sum), [2]=argmax row (b*n+i),
 // [3]=argmax col (b*n+j), stored as floats.
@@ -558,6 +602,18 @@ extern "C" int mhimx_softmax_rows(void* stream, const float* x, float* y, int64_
 extern "C" int mhimx_softmax_rows_bwd(void* stream, const float* y, const float* dy, float* dx, int64_t R, int64_t L, float alpha) {
   MHIMX_CHECK_ARG(y && dy && dx && R > 0 && L > 0, "softmax_rows_bwd: bad args");
   hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(grid1d(R, 1, 65535)), dim3(AT), 0, (hipStream_t)stream, y, dy, dx, R, L, alpha);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_softmax_cols(void* stream, const float* x, float* y, int64_t M, int64_t C, float alpha) {
+  MHIMX_CHECK_ARG(x && y && M > 0 && C > 0 && C <= 64, "softmax_cols: bad args");
+  hipLaunchKernelGGL(softmax_cols_fwd_kernel, dim3((unsigned)C), dim3(1024), 0, (hipStream_t)stream, x, y, M, (int)C, alpha);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_softmax_cols_bwd(void* stream, const float* y, const float* dy, float* dx, int64_t M, int64_t C, float alpha) {
+  MHIMX_CHECK_ARG(y && dy && dx && M > 0 && C > 0 && C <= 64, "softmax_cols_bwd: bad args");
+  hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3((unsigned)C), dim3(1024), 0, (hipStream_t)stream, y, dy, dx, M, (int)C, alpha);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -601,20 +601,21 @@ static int launch_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, i
 
 // unaligned / odd-shaped operands (K or lda not a multiple of 4): one thread per output element, fp32 FMA
 __global__ void gemm_nn_scalar_kernel(mhimx_gemm_nt_args g, float alpha) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= g.N) return;
-  float acc = 0.f;
-  for (int64_t k = 0; k < g.K; ++k) acc = fmaf(g.A[m * g.lda + k], g.B[k * g.ldb + n], acc);
-  float* c = g.C + m * g.ldc + n;
-  *c = g.accumulate ? *c + alpha * acc : alpha * acc;
+  for (int64_t m = blockIdx.y; m < g.M; m += gridDim.y) {
+    float acc = 0.f;
+    for (int64_t k = 0; k < g.K; ++k) acc = fmaf(g.A[m * g.lda + k], g.B[k * g.ldb + n], acc);
+    float* c = g.C + m * g.ldc + n;
+    *c = g.accumulate ? *c + alpha * acc : alpha * acc;
+  }
 }
 
 int gemm_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits, float* ws) {
   MHIMX_CHECK_ARG(g.M >= 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_nn: bad args");
   if (g.M == 0) return 0;
   if (!(g.K % 4 == 0 && g.lda % 4 == 0 && aligned16(g.A))) {
-    MHIMX_CHECK_ARG(g.M < 65536, "gemm_nn: unaligned operands are only supported for M < 65536");
-    hipLaunchKernelGGL(gemm_nn_scalar_kernel, dim3((unsigned)cdiv(g.N, 256), (unsigned)g.M), dim3(256), 0, st, g, alpha);
+    hipLaunchKernelGGL(gemm_nn_scalar_kernel, dim3((unsigned)cdiv(g.N, 256), (unsigned)(g.M < 65535 ? g.M : 65535)), dim3(256), 0, st, g, alpha);
     MHIMX_LAUNCH_CHECK();
     return 0;
   }

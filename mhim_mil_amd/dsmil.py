@@ -89,6 +89,28 @@ class ColMax(torch.autograd.Function):
         return dx
 
 
+class SoftmaxCols(torch.autograd.Function):
+    """softmax over the M instances of every column of x [M,C] (baseline.py:147)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.lib().mhimx_softmax_cols(ops._stream(), ops._p(x), ops._p(y), x.shape[0], x.shape[1], float(alpha)), "mhimx_softmax_cols")
+        ctx.save_for_backward(y)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.check(L.lib().mhimx_softmax_cols_bwd(ops._stream(), ops._p(y), ops._p(dy), ops._p(dx), y.shape[0], y.shape[1], float(ctx.alpha)),
+                "mhimx_softmax_cols_bwd")
+        return dx, None
+
+
 def rowmax(x):
     x = x.contiguous()
     out = torch.empty(x.shape[0], device=x.device)
@@ -193,9 +215,11 @@ class DSMIL(nn.Module):
         Q = self._q(h)                                                                          # [M,128]
         logits_ins, crit = ColMax.apply(classes)                                                # [C], critical rows
         q_max = self._q(h, rows=crit)                                                           # [C,128]
-        at_raw = NY.heads_mm(q_max, Q, "nt", (0, 0, QDIM, Cc, QDIM), (0, 0, QDIM, M, QDIM), (1, Cc, M), (0, 0, M, Cc, M), heads=1)
-        at = NY.Softmax.apply(at_raw, 1.0 / math.sqrt(QDIM))                                    # softmax over the M instances
-        B = NY.heads_mm(at, V, "nn", (0, 0, M, Cc, M), (0, 0, E, M, E), (Cc, E), (0, 0, E, Cc, E), heads=1)   # [C,E]
+        # A [M,C] keeps the instances as ROWS: every reduction over M is then a TN GEMM (any M, split over slabs) and the
+        # K = C contractions of the backward are a couple of FMAs per output
+        a_raw = NY.heads_mm(Q, q_max, "nt", (0, 0, QDIM, M, QDIM), (0, 0, QDIM, Cc, QDIM), (M, Cc), (0, 0, Cc, M, Cc), heads=1)
+        A = SoftmaxCols.apply(a_raw, 1.0 / math.sqrt(QDIM))                                     # softmax over the M instances
+        B = NY.heads_mm(A, V, "tn", (0, 0, Cc, M, Cc), (0, 0, E, M, E), (Cc, E), (0, 0, E, Cc, E), heads=1)   # A^T V  [C,E]
         fcc = self.b_classifier.fcc
         logits = NY.Linear.apply(B.reshape(1, Cc * E), fcc.weight.view(Cc, Cc * E), fcc.bias, 0.0, 0, None)[0]
         attn = None
@@ -204,6 +228,5 @@ class DSMIL(nn.Module):
                 if self.cls_attn:
                     attn = rowmax(classes)                                                      # baseline.py:176 (raw logits either way)
                 else:
-                    a = (at_raw[0] * (1.0 / math.sqrt(QDIM))) if no_norm else at[0]             # [C,M]
-                    attn = rowmax(a.t().contiguous())
+                    attn = rowmax((a_raw * (1.0 / math.sqrt(QDIM))) if no_norm else A)           # [M]
         return logits, logits_ins, B, attn
