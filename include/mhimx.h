@@ -62,7 +62,6 @@ typedef struct {
   int32_t accumulate;                                    /* C += ...                              */
   int32_t prec;                                          /* MHIMX_PREC_*                          */
   const uint64_t* drop_tick;                             /* optional device step counter mixed into drop_seed (graph replay) */
-  const uint16_t* B_hi; const uint16_t* B_lo;            /* optional pre-split 16-bit planes of B [N,K] (mhimx_split_planes) */
   int32_t paired;                                        /* 1: A and B are paired-plane images made by mhimx_pair_planes      */
   float* ws; int64_t ws_floats;                          /* optional scratch: lets a GEMM with few output tiles and a long K   */
                                                          /* split its reduction over up to ws_floats/(M*N) slabs (epilogue-free calls) */
@@ -97,10 +96,6 @@ typedef struct {
   int64_t ws_floats;                                     /* capacity of ws; the library may raise `splits` up to it   */
 } mhimx_gemm_tn_args;
 int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a);
-
-/* hi[i], lo[i] = 16-bit split of w[i] (bf16 planes for MHIMX_PREC_BF16X3, fp16 for F16S): lets a weight operand go
- * LDS -> MFMA with no per-tile conversion.  Done once per step per weight (weights change every step). */
-int mhimx_split_planes(void* stream, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int32_t prec);
 
 /* Paired planes: out[m, k] ("floats", same shape and pitch as x[M,K]) holds, for every 8 consecutive k of a row, 8 bf16
  * hi values followed by 8 bf16 lo values (x = hi + lo to ~2^-16).  A GEMM whose operands are both in this form

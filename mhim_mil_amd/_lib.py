@@ -32,7 +32,7 @@ class GemmNT(C.Structure):
                 ("pre", c_f32p), ("ldpre", C.c_int64),
                 ("act", C.c_int32),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p),
-                ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p), ("B_hi", C.c_void_p), ("B_lo", C.c_void_p),
+                ("accumulate", C.c_int32), ("prec", C.c_int32), ("drop_tick", C.c_void_p),
                 ("paired", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
                 ("dact", C.c_void_p), ("lddact", C.c_int64)]
 
@@ -98,7 +98,6 @@ SYMBOLS = {
     "mhimx_lse_merge": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "mhimx_gemm_batched": (C.c_int, [_P, _I32, C.POINTER(GemmNT), _I32, _I64, _I64, _I64, _F, _I32, _P]),
     "mhimx_gemm_tn": (C.c_int, [_P, C.POINTER(GemmTN)]),
-    "mhimx_split_planes": (C.c_int, [_P, _P, _P, _P, _I64, _I32]),
     "mhimx_transpose": (C.c_int, [_P, _P, _P, _I64, _I64]),
     "mhimx_abmil_pool_ws_bytes": (_I64, [_I64, _I64, _I64, _I32]),
     "mhimx_abmil_pool_fwd": (C.c_int, [_P, C.POINTER(Scorer), C.POINTER(PoolIO)]),

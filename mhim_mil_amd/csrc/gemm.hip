@@ -27,13 +27,10 @@ bool nt_dma_ok(const mhimx_gemm_nt_args& g);
 int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g);
 bool tn_dma_ok(const mhimx_gemm_tn_args& g);
 int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_avail);
-bool nt_planes_ok(const mhimx_gemm_nt_args& g);
-int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g);
 int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t K, float* out);
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);
 bool feat_gemm_ok(const mhimx_gemm_nt_args& g);
 int feat_gemm(hipStream_t st, const mhimx_gemm_nt_args& g);
-int split_planes(hipStream_t st, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int prec);
 
 // A launch may cover `batch` independent GEMMs (the heads of an attention product): blockIdx.z = b * splits + split,
 // operand b lives at base + b * stride.  {0,0,0,splits} = a single GEMM.
@@ -324,7 +321,6 @@ int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g) {
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
-  if (nt_planes_ok(g)) return gemm_nt_planes(st, g);
   if (nt_dma_ok(g)) return gemm_nt_dma(st, g);
   switch (g.prec) {
     case MHIMX_PREC_F32: return launch_nt<MHIMX_PREC_F32>(st, g);
@@ -710,9 +706,6 @@ extern "C" int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float al
 extern "C" int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a) {
   if (!a) return mhimx::fail(-1, "gemm_tn: null args");
   return mhimx::gemm_tn((hipStream_t)stream, *a);
-}
-extern "C" int mhimx_split_planes(void* stream, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int32_t prec) {
-  return mhimx::split_planes((hipStream_t)stream, w, hi, lo, n, prec);
 }
 extern "C" int mhimx_transpose(void* stream, const float* in, float* out, int64_t R, int64_t C) {
   return mhimx::transpose((hipStream_t)stream, in, out, R, C);

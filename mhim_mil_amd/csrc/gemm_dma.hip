@@ -440,211 +440,6 @@ __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_arg
 }
 
 
-// =================================================================================================
-// NT with a PRE-SPLIT weight operand: B arrives as two 16-bit planes (hi, lo) [N,K] produced once per step by
-// split_planes_kernel, so the B fragments go LDS -> MFMA with no VALU work at all and only the activation tile is
-// split in-kernel.  Tile 128 x 256 (two workgroups cover the 512-wide feature), 8 waves as 2x4, 64x64 per wave:
-// 12 MFMAs per 16-deep k slice against 2 fragment conversions (vs 4 in the generic kernel).
-//   LDS per stage: A fp32 [128][32] 16 KiB (swizzle as above) + B_hi, B_lo bf16/fp16 [256][32] 16 KiB each
-//   (64-B rows; 16-B slot ^= (row>>2)&3 so a 16-lane ds_read_b128 group covers the 256-B bank row exactly once).
-// =================================================================================================
-constexpr int PBN = 256;
-constexpr int PSTAGE_BYTES = TILE_BYTES + 2 * (PBN * DBK * 2);      // 48 KiB
-constexpr int PSTAGES = 2;
-
-template <int PREC>
-__global__ __launch_bounds__(512) void gemm_nt_planes_kernel(mhimx_gemm_nt_args g, const uint16_t* __restrict__ Bhi,
-                                                             const uint16_t* __restrict__ Blo) {
-  using FR = Frag<PREC>;
-  using V8 = typename FR::V8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nN = (int)((g.N + PBN - 1) / PBN), nM = (int)((g.M + DBM - 1) / DBM);
-  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
-  const int m_tile = (sidx / nN) * 8 + xcd, n_tile = sidx % nN;
-  if (m_tile >= nM) return;
-  const int64_t m0 = (int64_t)m_tile * DBM, n0 = (int64_t)n_tile * PBN;
-
-  const float* asrc[2];
-  const uint16_t* hsrc[2];
-  const uint16_t* lsrc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int p = tid + 512 * j;
-    {  // A: [128 rows][8 slots]
-      const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
-      int64_t m = m0 + row;
-      if (m >= g.M) m = g.M - 1;
-      asrc[j] = g.A + (g.rows ? g.rows[m] : m) * g.lda + slot * 4;
-    }
-    {  // B planes: [256 rows][4 slots of 8 elements]
-      const int row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-      int64_t n = n0 + row;
-      if (n >= g.N) n = g.N - 1;
-      hsrc[j] = Bhi + n * g.K + slot * 8;
-      lsrc[j] = Blo + n * g.K + slot * 8;
-    }
-  }
-  auto issue = [&](int64_t k0, int stage) {
-    char* sa = smem + stage * PSTAGE_BYTES + wave * 1024;
-    char* sh = sa + TILE_BYTES;
-    char* sl = sh + PBN * DBK * 2;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      dma16(asrc[j] + k0, sa + j * 8192);
-      dma16(reinterpret_cast<const float*>(hsrc[j] + k0), sh + j * 8192);
-      dma16(reinterpret_cast<const float*>(lsrc[j] + k0), sl + j * 8192);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // fragment addresses, stage 0, ks = 0.  fa[0..3]: A (two 16-B halves per 32-row tile, fp32);
-  // fa[4..7]: B hi (q=0,1), B lo (q=0,1): one 16-B read = 8 k-contiguous 16-bit elements.
-  const int r = lane & 31, kh = lane >> 5;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
-  unsigned fa[8];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int ra = wm * 64 + q * 32 + r;
-    fa[q * 2 + 0] = lds0 + ra * 128 + (((kh * 2) ^ ((ra >> 1) & 7)) << 4);
-    fa[q * 2 + 1] = lds0 + ra * 128 + (((kh * 2 + 1) ^ ((ra >> 1) & 7)) << 4);
-    const int rb = wn * 64 + q * 32 + r;
-    fa[4 + q] = lds0 + TILE_BYTES + rb * 64 + (((kh) ^ ((rb >> 2) & 3)) << 4);
-    fa[6 + q] = fa[4 + q] + PBN * DBK * 2;
-  }
-  // ks = 1: A slot index +4 (address ^ 64); B slot index +2 (address ^ 32)
-  const unsigned flip1[8] = {64u, 64u, 64u, 64u, 32u, 32u, 32u, 32u};
-
-  const int nk = (int)(g.K / DBK);
-  issue(0, 0);
-  for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#ifndef MHIMX_DBG_NODMA
-    if (t + 1 < nk) issue((int64_t)(t + 1) * DBK, (t + 1) & 1);
-#endif
-#ifdef MHIMX_DBG_NOCOMPUTE
-    continue;
-#endif
-    const unsigned so = (unsigned)((t & 1) * PSTAGE_BYTES);
-    f4 x[8], y[8];
-    unsigned a0[8], a1[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { a0[i] = fa[i] + so; a1[i] = (fa[i] + so) ^ flip1[i]; }
-    lds_read<8>(x, a0, 0u, 0u);
-    lds_wait<8>(x);
-    lds_read<8>(y, a1, 0u, 0u);
-    {
-      V8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        FR::split2(x[q * 2], x[q * 2 + 1], ah[q], al[q]);
-        bh[q] = __builtin_bit_cast(V8, x[4 + q]);
-        bl[q] = __builtin_bit_cast(V8, x[6 + q]);
-      }
-      mma_tile<PREC, 2>(ah, al, bh, bl, acc);
-    }
-    lds_wait<8>(y);
-    {
-      V8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        FR::split2(y[q * 2], y[q * 2 + 1], ah[q], al[q]);
-        bh[q] = __builtin_bit_cast(V8, y[4 + q]);
-        bl[q] = __builtin_bit_cast(V8, y[6 + q]);
-      }
-      mma_tile<PREC, 2>(ah, al, bh, bl, acc);
-    }
-  }
-
-  const int cl = lane & 31, rh = lane >> 5;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int64_t n = n0 + wn * 64 + nt * 32 + cl;
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.f;
-      const float colv = g.rowv ? g.colv[n] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
-        if (m >= g.M) continue;
-        float v = acc[mt][nt][e] + bias;
-        if (g.rowv) v += g.rowv[m] * colv;
-        if (g.pre) g.pre[m * g.ldpre + n] = v;
-        v = act_fwd(v, g.act);
-        if (g.drop_mask) {
-          v = g.drop_mask[m * g.N + n] ? v / (1.f - g.drop_p) : 0.f;
-        } else if (g.drop_p > 0.f) {
-          const uint64_t rid = g.rows ? (uint64_t)g.rows[m] : (uint64_t)m;
-          v = drop_keep(eff_seed(g.drop_seed, g.drop_tick), rid, (uint32_t)n, g.drop_p) ? v / (1.f - g.drop_p) : 0.f;
-        }
-        float* c = g.C + m * g.ldc + n;
-        if (g.accumulate) v += *c;
-        *c = v;
-      }
-    }
-}
-
-// fp32 [n] -> hi[n], lo[n] 16-bit planes (bf16 for BF16X3, fp16 for F16S)
-template <int PREC>
-__global__ void split_planes_kernel(const float* __restrict__ w, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float x = w[i];
-    if constexpr (PREC == MHIMX_PREC_BF16X3) {
-      const __bf16 h = (__bf16)x;
-      const __bf16 l = (__bf16)(x - (float)h);
-      hi[i] = __builtin_bit_cast(uint16_t, h);
-      lo[i] = __builtin_bit_cast(uint16_t, l);
-    } else {
-      const _Float16 h = (_Float16)x;
-      const _Float16 l = (_Float16)(x - (float)h);
-      hi[i] = __builtin_bit_cast(uint16_t, h);
-      lo[i] = __builtin_bit_cast(uint16_t, l);
-    }
-  }
-}
-
-int split_planes(hipStream_t st, const float* w, uint16_t* hi, uint16_t* lo, int64_t n, int prec) {
-  MHIMX_CHECK_ARG(w && hi && lo && n > 0, "split_planes: bad args");
-  const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-  if (prec == MHIMX_PREC_BF16X3) hipLaunchKernelGGL(split_planes_kernel<MHIMX_PREC_BF16X3>, dim3(blocks), dim3(256), 0, st, w, hi, lo, n);
-  else if (prec == MHIMX_PREC_F16S) hipLaunchKernelGGL(split_planes_kernel<MHIMX_PREC_F16S>, dim3(blocks), dim3(256), 0, st, w, hi, lo, n);
-  else return fail(-1, "split_planes: prec must be bf16x3 or f16s");
-  MHIMX_LAUNCH_CHECK();
-  return 0;
-}
-
-bool nt_planes_ok(const mhimx_gemm_nt_args& g) {
-  return g.B_hi && g.B_lo && (g.prec == MHIMX_PREC_BF16X3 || g.prec == MHIMX_PREC_F16S) && g.K % DBK == 0 && g.lda % 4 == 0 &&
-         aligned16(g.A) && aligned16(g.B_hi) && aligned16(g.B_lo) && g.M > 16 && g.N >= 256;
-}
-
-int gemm_nt_planes(hipStream_t st, const mhimx_gemm_nt_args& g) {
-  dim3 grid((unsigned)(8 * cdiv(g.N, PBN) * cdiv(cdiv(g.M, DBM), 8)));
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_planes_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, PSTAGES * PSTAGE_BYTES));
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_planes_kernel<MHIMX_PREC_F16S>, hipFuncAttributeMaxDynamicSharedMemorySize, PSTAGES * PSTAGE_BYTES));
-    attr = true;
-  }
-  if (g.prec == MHIMX_PREC_BF16X3)
-    hipLaunchKernelGGL(gemm_nt_planes_kernel<MHIMX_PREC_BF16X3>, grid, dim3(512), PSTAGES * PSTAGE_BYTES, st, g, g.B_hi, g.B_lo);
-  else
-    hipLaunchKernelGGL(gemm_nt_planes_kernel<MHIMX_PREC_F16S>, grid, dim3(512), PSTAGES * PSTAGE_BYTES, st, g, g.B_hi, g.B_lo);
-  MHIMX_LAUNCH_CHECK();
-  return 0;
-}
-
 // ---- host ------------------------------------------------------------------------------------------
 // x[M,K] fp32 (row pitch ldx) -> out[M,K] "floats": per 8 consecutive k, 8 bf16 hi then 8 bf16 lo (32 B in, 32 B out)
 __global__ void pair_planes_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int64_t K8, float* __restrict__ out) {

@@ -44,7 +44,7 @@ def prec_code(prec) -> int:
 
 # ------------------------------------------------------------------------------------------------ GEMMs
 def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, colv=None, drop_p=0.0, drop_seed=0,
-            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, b_planes=None, paired=False, dact=None):
+            drop_mask=None, accumulate=False, prec="f16s", M=None, drop_tick=None, paired=False, dact=None):
     """out[m,n] = epi(sum_k a[rows[m] or m, k] * b[n,k]) — see mhimx_gemm_nt."""
     for t, nm in ((a, "a"), (b, "b"), (bias, "bias"), (pre, "pre"), (rowv, "rowv"), (colv, "colv"), (out, "out")):
         _chk(t, name=nm)
@@ -60,8 +60,7 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
                  ldc=out.stride(0), M=M, N=N, K=K, bias=_p(bias), rowv=_p(rowv), colv=_p(colv), pre=_p(pre),
                  ldpre=pre.stride(0) if pre is not None else 0, act=int(act), drop_p=float(drop_p),
                  drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(drop_mask), accumulate=int(bool(accumulate)),
-                 prec=prec_code(prec), drop_tick=_p(drop_tick), B_hi=_p(b_planes[0]) if b_planes is not None else None,
-                 B_lo=_p(b_planes[1]) if b_planes is not None else None, paired=int(bool(paired)), dact=_p(dact),
+                 prec=prec_code(prec), drop_tick=_p(drop_tick), paired=int(bool(paired)), dact=_p(dact),
                  lddact=dact.stride(0) if dact is not None else 0)
     evs = KERNEL_EVENT_HOOK("gemm_nt", M, N, K) if KERNEL_EVENT_HOOK is not None else None
     if evs:
@@ -115,15 +114,6 @@ def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3"
                  ws_floats=0 if ws is None else ws.numel())
     L.check(L.lib().mhimx_gemm_tn(_stream(), C.byref(g)), "mhimx_gemm_tn")
     return out
-
-
-def split_planes(w, prec="bf16x3", out=None):
-    """(hi, lo) 16-bit planes of an fp32 weight (int16 tensors holding bf16/fp16 bits) — see mhimx_split_planes."""
-    _chk(w, name="w")
-    hi, lo = out if out is not None else (torch.empty(w.shape, device=w.device, dtype=torch.int16),
-                                          torch.empty(w.shape, device=w.device, dtype=torch.int16))
-    L.check(L.lib().mhimx_split_planes(_stream(), _p(w), _p(hi), _p(lo), w.numel(), prec_code(prec)), "mhimx_split_planes")
-    return hi, lo
 
 
 def transpose(x, out=None):

@@ -448,22 +448,3 @@ def test_select_rows_fused_random_subsets():
     never = np.setdiff1d(np.arange(n), cand)
     g = cnt_merge[never] / T
     assert abs(g.mean() - R / L_) < 0.002 and g.max() < 0.25                            # p = 0.1, sigma = 0.021
-
-
-@pytest.mark.parametrize("prec", ["bf16x3", "f16s"])
-@pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (300, 1024, 512), (257, 300, 64), (10000, 512, 128)])
-def test_gemm_nt_presplit_weight_planes(prec, M, N, K):
-    """The 128x256 kernel that takes the weight as pre-split 16-bit planes == the fp32-operand kernels == fp64 math."""
-    ops = _ops()
-    R = M + 37
-    x, w, bias = rnd(3, (R, K)).abs(), rnd(4, (N, K), std=0.05), rnd(5, (N,), std=0.1)
-    rows = torch.from_numpy(synth.permutation(9, R)[:M].copy())
-    ref = O._act(x[rows].double() @ w.double().t() + bias.double(), "gelu").float()
-    wd = w.to(DEV)
-    planes = ops.split_planes(wd, prec)
-    pre = torch.empty(M, N, device=DEV)
-    out = ops.gemm_nt(x.to(DEV), wd, rows=rows.to(DEV), bias=bias.to(DEV), act=2, pre=pre, prec=prec, b_planes=planes).cpu()
-    atol, rtol = TOL[prec]
-    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=atol * ref.abs().max().item(), rtol=rtol)
-    plain = ops.gemm_nt(x.to(DEV), wd, rows=rows.to(DEV), bias=bias.to(DEV), act=2, prec=prec).cpu()
-    np.testing.assert_allclose(out.numpy(), plain.numpy(), atol=2e-6 * ref.abs().max().item(), rtol=2e-5)
