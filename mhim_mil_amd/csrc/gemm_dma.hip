@@ -29,6 +29,8 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 #define MHIMX_NT_STAGES 2
 #endif
 constexpr int NSTAGE = MHIMX_NT_STAGES;           // LDS ring depth of the NT kernel (x 32 KiB); 2 => two workgroups per CU
+// dynamic LDS of the NT kernel: the ring, or the epilogue's 128 x 136 fp32 output tile (68 KiB), whichever is larger
+constexpr int NT_LDS_BYTES = NSTAGE * STAGE_BYTES > DBM * (DBN + 8) * 4 ? NSTAGE * STAGE_BYTES : DBM * (DBN + 8) * 4;
 // 8 x ds_read_b128 from per-lane LDS byte addresses a[0..7] + off (issue only; pair with LDS_WAIT8 before use)
 #define LDS_READ8(x, a, off)                                                                                         \
   asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"       \
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
   constexpr int NTHR = 64 * NW;
   constexpr int NDMA = 1024 / NTHR;                 // DMA instructions per thread per operand per k-step
   constexpr int NRD = 4 + 2 * NT;                   // ds_read_b128 per 16-deep k slice
+  constexpr bool EPI_LDS_OK = NT_LDS_BYTES >= DBM * (DBN + 8) * 4;     // room for the epilogue's staged output tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = NW == 4 ? (wave >> 1) : (wave >> 2), wn = NW == 4 ? (wave & 1) : (wave & 3);
@@ -304,7 +307,53 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
       }
     return;
   }
-  // ---- epilogue (same contract as gemm.hip)
+  // ---- epilogue (same contract as gemm.hip).  Vector form: the accumulators go through LDS (the ring is free now) and a
+  // compact loop applies the element-wise work on float4 rows — one copy of the code instead of 32 unrolled ones (cold
+  // I-cache lines at every launch) and 512-B row stores.  Needs 16-byte aligned rows; otherwise the scalar form below.
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (EPI_LDS_OK && n0 + DBN <= g.N && g.ldc % 4 == 0 && al16(g.C) && (!g.pre || (g.ldpre % 4 == 0 && al16(g.pre))) &&
+      (!g.bias || al16(g.bias)) && (!g.colv || al16(g.colv))) {
+    constexpr int TP = DBN + 8;                            // row pitch: the two half-waves of a store land 32 banks apart
+    float* tile = reinterpret_cast<float*>(smem);
+    __builtin_amdgcn_s_barrier();                         // every wave has left its last fragment reads
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          tile[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh) * TP + wn * (32 * NT) + nt * 32 + cl] = acc[mt][nt][e];
+    __syncthreads();
+    const int c4 = (tid & 31) * 4, r0 = tid >> 5;
+    const int64_t n = n0 + c4;
+    f4 bias = f4{0.f, 0.f, 0.f, 0.f}, colv = f4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bias = *reinterpret_cast<const f4*>(g.bias + n);
+    if (g.rowv) colv = *reinterpret_cast<const f4*>(g.colv + n);
+    const uint64_t dseed = g.drop_p > 0.f ? eff_seed(g.drop_seed, g.drop_tick) : 0;
+    const float inv_keep = 1.f / (1.f - g.drop_p);
+#pragma unroll 1
+    for (int r = r0; r < DBM; r += NTHR / 32) {
+      const int64_t m = m0 + r;
+      if (m >= g.M) break;
+      f4 v = *reinterpret_cast<const f4*>(tile + r * TP + c4) + bias;
+      if (g.rowv) v += g.rowv[m] * colv;
+      if (g.pre) *reinterpret_cast<f4*>(g.pre + m * g.ldpre + n) = v;
+      if (g.act != MHIMX_ACT_NONE || g.drop_mask || g.drop_p > 0.f) {
+        const uint32_t rkey = g.drop_p > 0.f ? drop_row_key(dseed, g.rows ? (uint64_t)g.rows[m] : (uint64_t)m) : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = act_fwd(v[q], g.act);
+          if (g.drop_mask) x = g.drop_mask[m * g.N + n + q] ? x * inv_keep : 0.f;
+          else if (g.drop_p > 0.f) x = drop_keep_k(rkey, (uint32_t)(n + q), g.drop_p) ? x * inv_keep : 0.f;
+          v[q] = x;
+        }
+      }
+      f4* c = reinterpret_cast<f4*>(g.C + m * g.ldc + n);
+      if (g.accumulate) v += *c;
+      *c = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -566,21 +615,21 @@ int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
   } reduce{st, g, ksplit};
   static bool attr = false;
   if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
+    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
+    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
     attr = true;
   }
   if (g.paired) {
     static bool attr2 = false;
     if (!attr2) {
-      MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES));
+      MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
       attr2 = true;
     }
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g, ksteps);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>), grid, dim3(64 * NW), NT_LDS_BYTES, st, g, ksteps);
   } else if (g.prec == MHIMX_PREC_BF16X3)
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g, ksteps);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NT_LDS_BYTES, st, g, ksteps);
   else
-    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>), grid, dim3(64 * NW), NSTAGE * STAGE_BYTES, st, g, ksteps);
+    hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>), grid, dim3(64 * NW), NT_LDS_BYTES, st, g, ksteps);
   MHIMX_LAUNCH_CHECK();
   return reduce.run();
 }
