@@ -20,14 +20,16 @@ MHIMX_DEV float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 // ------------------------------------------------------------------------------------------------
 // forward: s[n] = wc . (act(a_n) [* sigmoid(b_n)]) + bc ; per-block LSE partial of sum_n e^{s_n} T[n,:]
 // ------------------------------------------------------------------------------------------------
+constexpr int FWD_WAVES = 16;            // waves per block of the forward row pass: 16 => 4x fewer partials for pool_finalize
 template <int EPL>   // E = 64*EPL
-__global__ __launch_bounds__(ROWS_THREADS) void score_rows_fwd_kernel(
+__global__ __launch_bounds__(64 * FWD_WAVES) void score_rows_fwd_kernel(
     const float* __restrict__ T, int64_t M, int E, int A, int act, int gated, const float* __restrict__ u_pre,
     const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ wp, int C,
     float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl,
     float* __restrict__ pz) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  // sm: [4][E] wave z-accumulators, then [4] m, [4] l
+  // sm: [FWD_WAVES][E] wave z-accumulators, then [FWD_WAVES] m, [FWD_WAVES] l
+  constexpr int NWV = FWD_WAVES;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ldu = A * (1 + gated);
   const float bias_c = bc ? bc[0] : 0.f;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_fwd_kernel(
 #pragma unroll
   for (int q = 0; q < EPL; ++q) zacc[q] = 0.f;
 
-  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+  for (int64_t n = (int64_t)blockIdx.x * NWV + wave; n < M; n += (int64_t)gridDim.x * NWV) {
     const float* up = u_pre + n * ldu;
     float part = 0.f;
     for (int j = lane; j < A; j += 64) {
@@ -73,21 +75,30 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_fwd_kernel(
     }
   }
   float* zs = sm;
-  float* ms = sm + 4 * E;
-  float* ls = ms + 4;
+  float* ms = sm + NWV * E;
+  float* ls = ms + NWV;
 #pragma unroll
   for (int q = 0; q < EPL; ++q) zs[wave * E + lane + 64 * q] = zacc[q];
   if (lane == 0) { ms[wave] = mw; ls[wave] = lw; }
   __syncthreads();
-  const float mb = fmaxf(fmaxf(ms[0], ms[1]), fmaxf(ms[2], ms[3]));
-  float w[4];
+  float mb = ms[0];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (ms[i] == -INFINITY) ? 0.f : __expf(ms[i] - mb);
-  for (int e = threadIdx.x; e < E; e += ROWS_THREADS)
-    pz[(int64_t)blockIdx.x * E + e] = zs[e] * w[0] + zs[E + e] * w[1] + zs[2 * E + e] * w[2] + zs[3 * E + e] * w[3];
+  for (int i = 1; i < NWV; ++i) mb = fmaxf(mb, ms[i]);
+  float w[NWV];
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) w[i] = (ms[i] == -INFINITY) ? 0.f : __expf(ms[i] - mb);
+  for (int e = threadIdx.x; e < E; e += 64 * NWV) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) a += zs[i * E + e] * w[i];          // fixed order: deterministic
+    pz[(int64_t)blockIdx.x * E + e] = a;
+  }
   if (threadIdx.x == 0) {
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) l += ls[i] * w[i];
     pm[blockIdx.x] = mb;
-    pl[blockIdx.x] = ls[0] * w[0] + ls[1] * w[1] + ls[2] * w[2] + ls[3] * w[3];
+    pl[blockIdx.x] = l;
   }
 }
 
@@ -585,13 +596,20 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       g.B = sc->wb; g.bias = sc->bb; g.C = u_pre + off * ldu + A;
       if (int r = gemm_nt(st, g)) return r;
     }
-    const int grid = grid_for_rows(Ms[seg]);
+    int grid = (int)cdiv(Ms[seg], 5 * FWD_WAVES);        // 5 rows per wave: the per-row chain (2 KB read, dot, exp) is latency bound
+    if (grid < 1) grid = 1;
+    if (grid > MAX_PART) grid = MAX_PART;
     const float* Tseg = Ts[seg];
     const int64_t Mseg = Ms[seg];
     int r = dispatch_epl(E, [&](auto epl) {
       constexpr int EPL = decltype(epl)::value;
-      const size_t smem = (size_t)(4 * E + 8) * sizeof(float);
-      hipLaunchKernelGGL(score_rows_fwd_kernel<EPL>, dim3(grid), dim3(ROWS_THREADS), smem, st, Tseg, Mseg, (int)E, (int)A,
+      const size_t smem = (size_t)(FWD_WAVES * E + 2 * FWD_WAVES) * sizeof(float);
+      static bool attr = false;                              // one flag per EPL instantiation
+      if (!attr && smem > 48 * 1024) {
+        MHIMX_HIP(hipFuncSetAttribute((const void*)score_rows_fwd_kernel<EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+      }
+      hipLaunchKernelGGL(score_rows_fwd_kernel<EPL>, dim3(grid), dim3(64 * FWD_WAVES), smem, st, Tseg, Mseg, (int)E, (int)A,
                          sc->act, gated, u_pre + off * ldu, sc->wc, sc->bc, io->cproj ? io->wp : nullptr, (int)io->C,
                          io->s + off, io->cproj ? io->cproj + off * io->C : nullptr, w.pm + G, w.pl + G,
                          w.pz + (int64_t)G * E);
