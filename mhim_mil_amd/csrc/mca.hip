@@ -146,9 +146,11 @@ __global__ __launch_bounds__(1024) void mca_fwd_final_kernel(const float* __rest
   L = wave_sum(L);
   if (lane == 0) red[wave] = L;
   float acc = 0.f;
-  for (int b = wave; b < nb; b += 16) {
+#pragma unroll 4
+  for (int b = wave; b < nb; b += 16) {                   // unrolled: several partial loads in flight per wave
     const float pmb = pm[(int64_t)b * HK + hi];
-    if (pmb != -INFINITY) acc += po[((int64_t)b * HK + hi) * 64 + lane] * __expf(pmb - mx);
+    const float w = (pmb != -INFINITY) ? __expf(pmb - mx) : 0.f;
+    acc += po[((int64_t)b * HK + hi) * 64 + lane] * w;
   }
   osum[wave][lane] = acc;
   __syncthreads();
@@ -283,8 +285,10 @@ __global__ void mca_reduce_kernel(const float* __restrict__ part, int nb, int W,
   __shared__ float red[4][64];
   const int j = blockIdx.x * 64 + threadIdx.x;
   float acc = 0.f;
-  if (j < W)
+  if (j < W) {
+#pragma unroll 8
     for (int b = threadIdx.y; b < nb; b += 4) acc += part[(int64_t)b * W + j];
+  }
   red[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.y == 0 && j < W) out[j] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
   for (int w = 0; w < 16; ++w) L += red[w];                   // fixed order: deterministic
   const int e = blockIdx.x * 64 + lane;
   float acc = 0.f;
-  if (e < E)
+  if (e < E) {
+#pragma unroll 4
     for (int b = wave; b < G; b += 16) acc += pz[(int64_t)b * E + e] * wgt[b];
+  }
   acc16[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && e < E) {
@@ -231,8 +233,10 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
   for (int j0 = blockIdx.x * 32; j0 < W; j0 += gridDim.x * 32) {
     const int j = j0 + c;
     float acc = 0.f;
-    if (j < W)
+    if (j < W) {
+#pragma unroll 4
       for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * ld + j];
+    }
     red[rg][c] = acc;
     __syncthreads();
     if (rg == 0 && j < W) {
@@ -256,8 +260,10 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts2_kernel(const float* 
   for (int j0 = blockIdx.x * 32; j0 < W; j0 += gridDim.x * 32) {
     const int j = j0 + c;
     float acc = 0.f;
-    if (j < W)
+    if (j < W) {
+#pragma unroll 4
       for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * ld + j];
+    }
     red[rg][c] = acc;
     __syncthreads();
     if (rg == 0 && j < W) {
