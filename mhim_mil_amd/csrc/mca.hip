@@ -187,12 +187,28 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dp_kernel(const float* __
     }
   const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
   const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
-  for (int64_t r = r0; r < r1; ++r) {
+  // all loads of the block's rows are issued up front (the row loop is otherwise a chain of load -> reduce -> load)
+  float vbuf[MCA_ROWS][MCA_HPW], dbuf[MCA_ROWS][MCA_HPW][KQ];
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr)
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      const int64_t r = r0 + rr;
+      const bool ok = h < heads && r < r1;
+      vbuf[rr][hh] = ok ? KV[r * 2 * inner + inner + h * 64 + lane] : 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) dbuf[rr][hh][i] = (ok && i < kq) ? dots[((int64_t)h * kq + i) * R + r] : 0.f;
+    }
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr) {
+    const int64_t r = r0 + rr;
+    if (r >= r1) break;
 #pragma unroll
     for (int hh = 0; hh < MCA_HPW; ++hh) {
       const int h = wave + 4 * hh;
       if (h >= heads) continue;
-      const float vv = KV[r * 2 * inner + inner + h * 64 + lane];
+      const float vv = vbuf[rr][hh];
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
         if (i >= kq) continue;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dp_kernel(const float* __
         if (drop_p > 0.f) dp = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? dp * keep_scale : 0.f;
         const int64_t o = ((int64_t)h * kq + i) * R + r;
         if (lane == 0) dP[o] = dp;
-        rd[hh][i] += __expf(dots[o] - mx[hh][i]) * il[hh][i] * dp;
+        rd[hh][i] += __expf(dbuf[rr][hh][i] - mx[hh][i]) * il[hh][i] * dp;
       }
     }
   }
@@ -247,19 +263,37 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
     }
   const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
   const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
-  for (int64_t r = r0; r < r1; ++r) {
+  float kbuf[MCA_ROWS][MCA_HPW], dbuf[MCA_ROWS][MCA_HPW][KQ], pbuf[MCA_ROWS][MCA_HPW][KQ];       // loads issued up front
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr)
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh) {
+      const int h = wave + 4 * hh;
+      const int64_t r = r0 + rr;
+      const bool ok = h < heads && r < r1;
+      kbuf[rr][hh] = ok ? KV[r * 2 * inner + h * 64 + lane] : 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        const int64_t o = ((int64_t)h * kq + i) * R + r;
+        dbuf[rr][hh][i] = (ok && i < kq) ? dots[o] : 0.f;
+        pbuf[rr][hh][i] = (ok && i < kq) ? dP[o] : 0.f;
+      }
+    }
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr) {
+    const int64_t r = r0 + rr;
+    if (r >= r1) break;
 #pragma unroll
     for (int hh = 0; hh < MCA_HPW; ++hh) {
       const int h = wave + 4 * hh;
       if (h >= heads) continue;
-      const float kv = KV[r * 2 * inner + h * 64 + lane];
+      const float kv = kbuf[rr][hh];
       float dk = 0.f, dv = 0.f;
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
         if (i >= kq) continue;
-        const int64_t o = ((int64_t)h * kq + i) * R + r;
-        const float p = __expf(dots[o] - mx[hh][i]) * il[hh][i];
-        const float dd = scale * p * (dP[o] - rd[hh][i]);
+        const float p = __expf(dbuf[rr][hh][i] - mx[hh][i]) * il[hh][i];
+        const float dd = scale * p * (pbuf[rr][hh][i] - rd[hh][i]);
         float pd = p;
         if (drop_p > 0.f) pd = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? p * keep_scale : 0.f;
         dk += dd * q[hh][i];
