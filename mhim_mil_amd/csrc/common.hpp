@@ -93,10 +93,17 @@ MHIMX_DEV float act_grad(float x, float y, int act) {
 MHIMX_DEV void act_fwd_grad(float x, int act, float& y, float& g) {
   switch (act) {
     case MHIMX_ACT_RELU: y = x > 0.f ? x : 0.f; g = x > 0.f ? 1.f : 0.f; return;
-    case MHIMX_ACT_GELU: {
-      const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752440f));
+    case MHIMX_ACT_GELU: {                                  // erf_fast inlined: its e^{-(x/sqrt2)^2} IS the Gaussian of phi(x)
+      const float ax = fabsf(x) * 0.70710678118654752440f;
+      const float ex = __expf(-ax * ax);
+      const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+      float p = fmaf(1.061405429f, t, -1.453152027f);
+      p = fmaf(p, t, 1.421413741f);
+      p = fmaf(p, t, -0.284496736f);
+      p = fmaf(p, t, 0.254829592f);
+      const float cdf = 0.5f * (1.f + copysignf(1.f - p * t * ex, x));
       y = x * cdf;
-      g = cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+      g = cdf + x * 0.39894228040143267794f * ex;
       return;
     }
     case MHIMX_ACT_TANH: y = tanhf(x); g = 1.f - y * y; return;
