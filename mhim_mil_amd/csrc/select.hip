@@ -16,6 +16,13 @@
 
 namespace mhimx {
 
+#ifdef MHIMX_SEL_PROF
+__device__ unsigned long long sel_prof[32];
+#define SEL_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) sel_prof[i] = wall_clock64(); } while (0)
+#else
+#define SEL_STAMP(i)
+#endif
+
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_WAVES = SEL_THREADS / 64;
 
@@ -220,108 +227,179 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(
 // in registers (scores are read from HBM exactly once), flags are an LDS bitmap, the k candidates are ordered
 // by rank counting (k^2/1024 LDS compares per thread, no barriers) when k <= 2048.
 // ------------------------------------------------------------------------------------------------
-// exclusive prefix sum of one integer per thread over the 1024 threads (thread order); *total = block sum
-MHIMX_DEV uint32_t block_scan_excl(uint32_t v, uint32_t* wave_tot /*[16] LDS*/, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = v;
+// Wave64 integer scans / reductions on the DPP network (a __shfl_* is a ds_bpermute: an LDS-crossbar round trip per step,
+// and this kernel is one long dependent chain).  row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+MHIMX_DEV uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+MHIMX_DEV uint32_t wave_scan_incl(uint32_t v) {       // inclusive prefix sum in lane order
+  v += dpp_u32<0x111, 0xf>(0u, v);
+  v += dpp_u32<0x112, 0xf>(0u, v);
+  v += dpp_u32<0x114, 0xf>(0u, v);
+  v += dpp_u32<0x118, 0xf>(0u, v);                    // inclusive inside each 16-lane row
+  v += dpp_u32<0x142, 0xa>(0u, v);                    // rows 1,3 += last lane of rows 0,2
+  v += dpp_u32<0x143, 0xc>(0u, v);                    // rows 2,3 += lane 31
+  return v;
+}
+MHIMX_DEV uint32_t wave_min_u32(uint32_t v) {
+  uint32_t t;
+  t = dpp_u32<0xB1, 0xf>(v, v); v = t < v ? t : v;
+  t = dpp_u32<0x4E, 0xf>(v, v); v = t < v ? t : v;
+  t = dpp_u32<0x141, 0xf>(v, v); v = t < v ? t : v;
+  t = dpp_u32<0x140, 0xf>(v, v); v = t < v ? t : v;
+  t = dpp_u32<0x142, 0xa>(v, v); v = t < v ? t : v;
+  t = dpp_u32<0x143, 0xc>(v, v); v = t < v ? t : v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+MHIMX_DEV uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+// sum of the per-wave totals below `wave` and of all 16 (four 16-byte LDS reads)
+MHIMX_DEV void wave_tot_combine(const uint32_t* wave_tot, int wave, uint32_t* below, uint32_t* total) {
+  uint32_t w[SEL_WAVES];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += up;
+  for (int q = 0; q < SEL_WAVES / 4; ++q) {
+    const uint4 v = reinterpret_cast<const uint4*>(wave_tot)[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
+  uint32_t b = 0, t = 0;
+#pragma unroll
+  for (int q = 0; q < SEL_WAVES; ++q) {
+    b += q < wave ? w[q] : 0u;
+    t += w[q];
+  }
+  *below = b;
+  *total = t;
+}
+
+// exclusive prefix sum of one integer per thread over the 1024 threads (thread order); *total = block sum
+MHIMX_DEV uint32_t block_scan_excl(uint32_t v, uint32_t* wave_tot /*[16] LDS, 16-byte aligned*/, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_scan_incl(v);
   if (lane == 63) wave_tot[wave] = inc;
   __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < SEL_WAVES; ++w) {
-    const uint32_t c = wave_tot[w];
-    if (w < wave) base += c;
-    tot += c;
-  }
+  uint32_t base;
+  wave_tot_combine(wave_tot, wave, &base, total);
   __syncthreads();
-  *total = tot;
   return base + inc - v;
 }
 
-// radix select over register-resident keys: returns the k-th largest key T among the valid ones and, in *remaining,
-// how many T-valued keys belong to the top-k.  hist: [16][256] LDS, misc: [>=8] LDS.
-// Scores are low-entropy in their leading bits (a softmax-derived score in [0.5, 1) has 9 identical leading bits): a
-// histogram pass over such a digit is 64 lanes x 10 keys of LDS atomics on ONE address.  So the passes start at the
-// highest bit in which the block's keys actually differ (min ^ max), and a digit is 8 bits of real entropy.
-template <int KPT>
+// radix select over register-resident keys: returns the k-th largest key T among the valid ones, in *remaining_out how
+// many T-valued keys belong to the top-k and in *n_eq_out how many T-valued keys exist (remaining == n_eq: every tie is
+// taken and the caller needs no tie ranking).
+//   * Scores are low-entropy in their leading bits (a softmax-derived score in [0.5, 1) has 9 identical leading bits) and
+//     a histogram pass over such a digit is 64 lanes x 10 keys of LDS atomics on ONE address: the passes start at the
+//     highest bit in which the block's keys differ (min ^ max).  FULL32 (hashed keys) skips that pre-pass.
+//   * One workgroup on one CU is a latency chain (a block barrier ~0.15 us, a pass ~7 of them): digits are 11 bits
+//     (4 histogram copies of 2048 bins, wave w -> copy w & 3), and as soon as the threshold bin holds <= SEL_LIST keys
+//     they are appended to an LDS list and the threshold is found by rank counting among them - for 1e4 continuous
+//     scores that is ONE histogram pass + one list step instead of three or four passes.
+// hist: [4][2048] LDS (also the list), wave_tot: [16], misc: [>=8] LDS.
+constexpr int SEL_DIGIT = 11, SEL_BINS = 1 << SEL_DIGIT, SEL_COPIES = 4, SEL_LIST = 1024;
+
+template <int KPT, bool FULL32>
 MHIMX_DEV uint32_t radix_select_regs(const uint32_t (&key)[KPT], const bool (&valid)[KPT], uint32_t k, uint32_t* hist,
-                                     uint32_t* misc, uint32_t* remaining_out) {
+                                     uint32_t* wave_tot, uint32_t* misc, uint32_t* remaining_out, uint32_t* n_eq_out) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // ---- block min / max of the valid keys
-  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  uint32_t prefix = 0u, fixed_mask = 0u;
+  int hb = 31;
+  if (!FULL32) {
+    // ---- block min / max of the valid keys
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
-  for (int j = 0; j < KPT; ++j)
-    if (valid[j]) { mn = key[j] < mn ? key[j] : mn; mx = key[j] > mx ? key[j] : mx; }
+    for (int j = 0; j < KPT; ++j)
+      if (valid[j]) { mn = key[j] < mn ? key[j] : mn; mx = key[j] > mx ? key[j] : mx; }
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if (lane == 0) { hist[wave] = mn; hist[SEL_WAVES + wave] = mx; }
+    __syncthreads();
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t a = (uint32_t)__shfl_xor((int)mn, o, 64), c = (uint32_t)__shfl_xor((int)mx, o, 64);
-    mn = a < mn ? a : mn;
-    mx = c > mx ? c : mx;
-  }
-  if (lane == 0) { hist[wave] = mn; hist[SEL_WAVES + wave] = mx; }
-  __syncthreads();
+    for (int q = 0; q < SEL_WAVES / 4; ++q) {
+      const uint4 a = reinterpret_cast<const uint4*>(hist)[q], c = reinterpret_cast<const uint4*>(hist + SEL_WAVES)[q];
+      mn = min(min(mn, min(a.x, a.y)), min(a.z, a.w));
+      mx = max(max(mx, max(c.x, c.y)), max(c.z, c.w));
+    }
+    __syncthreads();
+    const uint32_t diff = mn ^ mx;
+    if (diff == 0u) {                          // every key equal: all of them are T-valued
+      uint32_t nv = 0;
 #pragma unroll
-  for (int w = 0; w < SEL_WAVES; ++w) {
-    const uint32_t a = hist[w], c = hist[SEL_WAVES + w];
-    mn = a < mn ? a : mn;
-    mx = c > mx ? c : mx;
+      for (int j = 0; j < KPT; ++j) nv += valid[j] ? 1u : 0u;
+      uint32_t tot;
+      block_scan_excl(nv, wave_tot, &tot);
+      *remaining_out = k;
+      *n_eq_out = tot;
+      return mx;
+    }
+    hb = 31 - __clz(diff);                     // highest differing bit
+    fixed_mask = hb >= 31 ? 0u : ~((2u << hb) - 1u);               // the common leading bits are decided
+    prefix = mx & fixed_mask;
   }
-  __syncthreads();
-  const uint32_t diff = mn ^ mx;
-  if (diff == 0u) {                          // every key equal
-    *remaining_out = k;
-    return mx;
-  }
-  const int hb = 31 - __clz(diff);           // highest differing bit
-  uint32_t prefix = hb >= 31 ? 0u : (mx & ~((2u << hb) - 1u));     // the common leading bits
-  uint32_t remaining = k;
-  int shift = hb - 7 < 0 ? 0 : hb - 7;
-  uint32_t fixed_mask = hb >= 31 ? 0u : ~((2u << hb) - 1u);        // bits already decided
+  uint32_t remaining = k, n_eq = 0;
+  int shift = hb - (SEL_DIGIT - 1) < 0 ? 0 : hb - (SEL_DIGIT - 1);
+  uint32_t* copy = hist + (wave & (SEL_COPIES - 1)) * SEL_BINS;
   while (true) {
-    for (int i = tid; i < SEL_WAVES * 256; i += SEL_THREADS) hist[i] = 0;
+    {
+      uint4* h4 = reinterpret_cast<uint4*>(hist);
+      for (int i = tid; i < SEL_COPIES * SEL_BINS / 4; i += SEL_THREADS) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
-      if (valid[j] && (key[j] & fixed_mask) == prefix) atomicAdd(&hist[wave * 256 + ((key[j] >> shift) & 255u)], 1u);
+      if (valid[j] && (key[j] & fixed_mask) == prefix) atomicAdd(&copy[(key[j] >> shift) & (SEL_BINS - 1)], 1u);
     __syncthreads();
-    uint32_t cnt = 0;
-    if (tid < 256) {
+    // thread t owns bins 2t, 2t+1; population ABOVE them = reversed block scan of the per-thread sums
+    uint32_t c0 = 0, c1 = 0;
 #pragma unroll
-      for (int w = 0; w < SEL_WAVES; ++w) cnt += hist[w * 256 + tid];
+    for (int c = 0; c < SEL_COPIES; ++c) {
+      const uint2 v = reinterpret_cast<const uint2*>(hist + c * SEL_BINS)[tid];
+      c0 += v.x;
+      c1 += v.y;
     }
+    const uint32_t pre = wave_scan_incl(c0 + c1);                       // inclusive prefix in bin order
+    if (lane == 63) wave_tot[wave] = pre;
     __syncthreads();
-    // population ABOVE each bin: suffix sum over the 256 bins held by threads 0..255 (4 waves): wave-level shuffle scan
-    // plus the totals of the higher waves
-    if (tid < 256) {
-      uint32_t inc = cnt;                    // inclusive suffix sum inside the wave
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t dn = (uint32_t)__shfl_down((int)inc, o, 64);
-        if (lane + o < 64) inc += dn;
-      }
-      if (lane == 0) hist[wave] = inc;       // wave total (bins wave*64 .. wave*64+63)
-      hist[256 + tid] = inc - cnt;           // population above, within the wave
-    }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t above = hist[256 + tid];
-      for (int w = wave + 1; w < 4; ++w) above += hist[w];
-      if (above < remaining && remaining <= above + cnt) { misc[0] = (uint32_t)tid; misc[1] = remaining - above; }
-    }
+    uint32_t below, total;
+    wave_tot_combine(wave_tot, wave, &below, &total);
+    const uint32_t above = total - (below + pre);                       // population in the bins above 2t+1
+    if (above < remaining && remaining <= above + c1) { misc[0] = 2u * tid + 1u; misc[1] = remaining - above; misc[3] = c1; }
+    else if (above + c1 < remaining && remaining <= above + c1 + c0) { misc[0] = 2u * tid; misc[1] = remaining - above - c1; misc[3] = c0; }
     __syncthreads();
     prefix |= misc[0] << shift;
     remaining = misc[1];
-    fixed_mask |= 0xFFu << shift;
-    __syncthreads();
-    if (shift == 0) break;
-    shift = shift - 8 < 0 ? 0 : shift - 8;
+    n_eq = misc[3];                            // keys in the threshold bin
+    fixed_mask |= (uint32_t)(SEL_BINS - 1) << shift;
+    if (shift == 0) break;                     // all bits decided: the bin IS the value T
+    if (n_eq <= (uint32_t)SEL_LIST) {
+      // ---- finish among the bin's keys: T = the remaining-th largest of the list
+      if (tid == 0) misc[4] = 0;
+      __syncthreads();                         // (also: everyone has read misc[0..3] and the histogram)
+#pragma unroll
+      for (int j = 0; j < KPT; ++j)
+        if (valid[j] && (key[j] & fixed_mask) == prefix) hist[atomicAdd(&misc[4], 1u)] = key[j];
+      __syncthreads();
+      for (uint32_t j = tid; j < n_eq; j += SEL_THREADS) {
+        const uint32_t mine = hist[j];
+        uint32_t g = 0, e = 0;
+        for (uint32_t q = 0; q < n_eq; ++q) {
+          const uint32_t o = hist[q];
+          g += o > mine ? 1u : 0u;
+          e += o == mine ? 1u : 0u;
+        }
+        if (g < remaining && remaining <= g + e) { misc[5] = mine; misc[6] = remaining - g; misc[7] = e; }   // duplicates agree
+      }
+      __syncthreads();
+      prefix = misc[5];
+      remaining = misc[6];
+      n_eq = misc[7];
+      break;
+    }
+    __syncthreads();                           // misc / histogram are rewritten by the next pass
+    shift = shift - SEL_DIGIT < 0 ? 0 : shift - SEL_DIGIT;
   }
+  __syncthreads();
   *remaining_out = remaining;
+  *n_eq_out = n_eq;
   return prefix;
 }
 
@@ -335,16 +413,19 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     int64_t* __restrict__ rows_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint64_t rand_seed = eff_seed(rand_seed0, tick);
-  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);               // [P] gathered, [P] sorted
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);               // [P] gathered, [P] sorted / random keys
   uint64_t* sorted = keys + P;
-  uint32_t* hist = reinterpret_cast<uint32_t*>(sorted + P);             // [16][256]
-  uint32_t* wave_tot = hist + SEL_WAVES * 256;                          // [16]
+  uint32_t* hist = reinterpret_cast<uint32_t*>(sorted + P);             // [4][2048]
+  uint32_t* wave_tot = hist + SEL_COPIES * SEL_BINS;                    // [16]
   uint32_t* misc = wave_tot + SEL_WAVES;                                // [8]
   uint32_t* bitmap = misc + 8;                                          // [512] = 16384 bits
+  uint32_t* rank = bitmap + 512;                                        // [P]
+  uint16_t* stage = reinterpret_cast<uint16_t*>(smem_raw);              // [N] row list staging (aliases everything: last phase)
   const int tid = threadIdx.x;
   const bool lg = largest != 0;
   const int i0 = tid * KPT;
 
+  SEL_STAMP(8);
   uint32_t key[KPT];
   bool valid[KPT];
 #pragma unroll
@@ -352,38 +433,58 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     valid[j] = (i0 + j) < N;
     key[j] = valid[j] ? mono32(score[i0 + j], lg) : 0u;
   }
+  SEL_STAMP(0);
   for (int i = tid; i < 512; i += SEL_THREADS) bitmap[i] = 0;
   if (tid == 0) misc[2] = 0;
 
   // ---- 1. threshold
-  uint32_t remaining;
-  const uint32_t T = radix_select_regs<KPT>(key, valid, (uint32_t)k, hist, misc, &remaining);
+  uint32_t remaining, n_eq;
+  const uint32_t T = radix_select_regs<KPT, false>(key, valid, (uint32_t)k, hist, wave_tot, misc, &remaining, &n_eq);
 
+  SEL_STAMP(1);
   // ---- 2. gather exactly k keys (ties: lowest index first)
-  uint32_t neq = 0;
+  uint32_t eq_rank = 0;
+  if (remaining != n_eq) {                 // only some of the T-valued keys belong to the top-k: rank them by index
+    uint32_t neq = 0;
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) neq += (valid[j] && key[j] == T) ? 1u : 0u;
-  uint32_t tot;
-  uint32_t eq_rank = block_scan_excl(neq, wave_tot, &tot);
+    for (int j = 0; j < KPT; ++j) neq += (valid[j] && key[j] == T) ? 1u : 0u;
+    uint32_t tot;
+    eq_rank = block_scan_excl(neq, wave_tot, &tot);
+  }
+  // (one LDS atomic per WAVE reserves the wave's slots: k same-address returning atomics would serialise)
+  bool take[KPT];
+  uint32_t ntake = 0;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    if (!valid[j]) continue;
-    bool take = key[j] > T;
-    if (key[j] == T) { take = eq_rank < remaining; ++eq_rank; }
-    if (take) {
-      const uint32_t pos = atomicAdd(&misc[2], 1u);
-      keys[pos] = ((uint64_t)key[j] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(i0 + j));
-    }
+    bool t = valid[j] && key[j] > T;
+    if (valid[j] && key[j] == T) { t = remaining == n_eq || eq_rank < remaining; ++eq_rank; }
+    take[j] = t;
+    ntake += t ? 1u : 0u;
+  }
+  {
+    const uint32_t inc = wave_scan_incl(ntake);
+    uint32_t base = 0;
+    if ((tid & 63) == 63 && inc) base = atomicAdd(&misc[2], inc);
+    uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - ntake;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (take[j]) keys[pos++] = ((uint64_t)key[j] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(i0 + j));
   }
   __syncthreads();
 
+  SEL_STAMP(2);
   // ---- 3. order the candidates: (value desc, index asc) == key desc
-  if (k <= 2048) {
+  // (the device-drawn random subset below depends on the candidate SET only: no ordering needed unless it is returned)
+  const bool dev_rand = use_rand && !perm && n_sel < k;
+  const uint64_t* cand = sorted;
+  if (dev_rand && !topk_out) {
+    cand = keys;
+  } else if (k <= 2048) {
     for (int j = tid; j < k; j += SEL_THREADS) {
       const uint64_t mine = keys[j];
-      int rank = 0;
-      for (int q = 0; q < k; ++q) rank += keys[q] > mine ? 1 : 0;
-      sorted[rank] = mine;
+      int r = 0;
+      for (int q = 0; q < k; ++q) r += keys[q] > mine ? 1 : 0;
+      sorted[r] = mine;
     }
     __syncthreads();
   } else {
@@ -403,25 +504,49 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   if (topk_out)
     for (int j = tid; j < k; j += SEL_THREADS) topk_out[j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(sorted[j] & 0xFFFFFFFFull));
 
+  SEL_STAMP(3);
   // ---- 4. flags (LDS bitmap)
   const bool has_other = other != nullptr && n_other > 0;
   const int len_keep_simple = N - n_sel;
-  if (use_rand && !perm && n_sel < k) {
+  if (dev_rand) {
     // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host
-    // permutation: every candidate gets a counter-based random key; the n_sel smallest keys win (rank counting).
-    for (int j = tid; j < k; j += SEL_THREADS) {
-      const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(sorted[j] & 0xFFFFFFFFull);
-      keys[j] = ((uint64_t)mix32(mix32(idx ^ (uint32_t)rand_seed) + (uint32_t)(rand_seed >> 32)) << 32) | idx;
+    // permutation: every candidate gets a counter-based random key (a bijection of its index: no ties); the n_sel
+    // smallest keys win.  Rank counting over all 1024 threads: thread (j, seg) counts segment seg of the keys.
+    uint32_t* rk32 = reinterpret_cast<uint32_t*>((cand == keys) ? sorted : keys);   // [<= 2P] 32-bit random keys, 0xFFFFFFFF pad
+    const int kpad = (k + 3) & ~3;
+    for (int j = tid; j < kpad; j += SEL_THREADS) {
+      uint32_t r = 0xFFFFFFFFu;
+      if (j < k) {
+        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
+        r = mix32(mix32(idx ^ (uint32_t)rand_seed) + (uint32_t)(rand_seed >> 32));
+        rank[j] = 0;
+      }
+      rk32[j] = r;
+    }
+    __syncthreads();
+    int S = SEL_THREADS / k;
+    S = S < 1 ? 1 : (S > 8 ? 8 : S);
+    const int seg4 = (kpad / 4 + S - 1) / S;                 // uint4 groups per segment
+    for (int it = tid; it < k * S; it += SEL_THREADS) {
+      const int j = it % k, seg = it / k;
+      const uint32_t mine = rk32[j];
+      const int g1 = min(kpad / 4, (seg + 1) * seg4);
+      uint32_t r = 0;
+#pragma unroll 8
+      for (int g = seg * seg4; g < g1; ++g) {
+        const uint4 o = reinterpret_cast<const uint4*>(rk32)[g];
+        r += (o.x < mine ? 1u : 0u) + (o.y < mine ? 1u : 0u) + (o.z < mine ? 1u : 0u) + (o.w < mine ? 1u : 0u);
+      }
+      if (S > 1) atomicAdd(&rank[j], r);
+      else rank[j] = r;
     }
     __syncthreads();
     for (int j = tid; j < k; j += SEL_THREADS) {
-      const uint64_t mine = keys[j];
-      int rank = 0;
-      for (int q = 0; q < k; ++q) rank += keys[q] < mine ? 1 : 0;
-      if (rank < n_sel) {
-        const uint32_t idx = (uint32_t)(mine & 0xFFFFFFFFull);
+      const int r = (int)rank[j];
+      if (r < n_sel) {
+        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
         atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
-        if (!has_other && mask_ids) mask_ids[len_keep_simple + rank] = (int64_t)idx;
+        if (!has_other && mask_ids) mask_ids[len_keep_simple + r] = (int64_t)idx;
       }
     }
   } else {
@@ -439,6 +564,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     }
   __syncthreads();
 
+  SEL_STAMP(4);
   // ---- 5. ordered compaction: kept ids ascending (and, for a union with an earlier mask, masked ids ascending)
   bool kv[KPT];
   uint32_t nkeep = 0;
@@ -466,6 +592,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     }
   }
   if (tid == 0 && len_keep_dev) *len_keep_dev = (int64_t)kept_total;
+  SEL_STAMP(5);
   if (!rows_out) return;
 
   // ---- 6. Merge.masking (merge.py:158-176): a uniformly random R-subset of the kept rows is merged away.  Same device:
@@ -478,42 +605,44 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
 #pragma unroll
   for (int j = 0; j < KPT; ++j)
     rk[j] = mix32(mix32((uint32_t)(i0 + j) ^ (uint32_t)(rand_seed >> 17)) + (uint32_t)rand_seed * 0x9E3779B1u);
-  uint32_t T2 = 0, remaining2 = 0;
+  // the keys are a bijection of the row index (xor / odd multiplies / xor-shifts): no two rows tie
+  uint32_t T2 = 0, remaining2 = 0, neq2 = 0;
   const bool partial = merge_R > 0 && merge_R < Lrows;
-  if (partial) T2 = radix_select_regs<KPT>(rk, kv, (uint32_t)merge_R, hist, misc, &remaining2);
-  uint32_t neq2 = 0;
-#pragma unroll
-  for (int j = 0; j < KPT; ++j) neq2 += (partial && kv[j] && rk[j] == T2) ? 1u : 0u;
-  uint32_t t2;
-  uint32_t eq2 = block_scan_excl(neq2, wave_tot, &t2);
+  if (partial) T2 = radix_select_regs<KPT, true>(rk, kv, (uint32_t)merge_R, hist, wave_tot, misc, &remaining2, &neq2);
+  SEL_STAMP(6);
   bool mrg[KPT];
   uint32_t nstay = 0, nmrg = 0;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    bool m = false;
-    if (kv[j]) {
-      if (merge_R >= Lrows) m = true;
-      else if (partial) {
-        m = rk[j] > T2;
-        if (rk[j] == T2) { m = eq2 < remaining2; ++eq2; }
-      }
-    }
+    const bool m = kv[j] && (merge_R >= Lrows || (partial && rk[j] >= T2));
     mrg[j] = m;
     nmrg += m ? 1u : 0u;
     nstay += (kv[j] && !m) ? 1u : 0u;
   }
+  // one scan for both lists (each total <= 16384 fits 16 bits).
   // use_rand == 2: rows to merge FIRST ([merge | stay]: lets the caller keep [stay rows | merged tokens] contiguous)
-  uint32_t spos = (use_rand == 2 ? (uint32_t)(Lrows - Lk) : 0u) + block_scan_excl(nstay, wave_tot, &t2);
-  uint32_t mpos2 = (use_rand == 2 ? 0u : (uint32_t)Lk) + block_scan_excl(nmrg, wave_tot, &t2);
+  uint32_t t2;
+  const uint32_t packed = block_scan_excl(nstay | (nmrg << 16), wave_tot, &t2);
+  uint32_t spos = (use_rand == 2 ? (uint32_t)(Lrows - Lk) : 0u) + (packed & 0xFFFFu);
+  uint32_t mpos2 = (use_rand == 2 ? 0u : (uint32_t)Lk) + (packed >> 16);
+  SEL_STAMP(10);
+  // staged in LDS so the 8-byte row ids leave as full coalesced lines (a thread's own rows are 80 B apart from its
+  // neighbour's: 10 scattered store instructions per wave otherwise)
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     if (!kv[j]) continue;
-    if (mrg[j]) rows_out[mpos2++] = i0 + j;
-    else rows_out[spos++] = i0 + j;
+    if (mrg[j]) stage[mpos2++] = (uint16_t)(i0 + j);
+    else stage[spos++] = (uint16_t)(i0 + j);
   }
+  __syncthreads();
+  for (int i = tid; i < Lrows; i += SEL_THREADS) rows_out[i] = (int64_t)stage[i];
+  SEL_STAMP(7);
 }
 
-static size_t select_small_smem(int P) { return (size_t)2 * P * 8 + (SEL_WAVES * 256 + SEL_WAVES + 8 + 512) * 4; }
+static size_t select_small_smem(int P) {          // keys+sorted, hist, wave_tot, misc, bitmap, rank; >= the 32 KB row staging
+  const size_t a = (size_t)2 * P * 8 + (size_t)(SEL_COPIES * SEL_BINS + SEL_WAVES + 8 + 512 + P) * 4;
+  return a < 32768 ? 32768 : a;
+}
 
 static int next_pow2(int v) {
   int p = 1;
@@ -526,6 +655,12 @@ static size_t select_smem(int P) { return (size_t)P * 8 + (SEL_WAVES * 256 + SEL
 }  // namespace mhimx
 
 using namespace mhimx;
+
+#ifdef MHIMX_SEL_PROF
+extern "C" int mhimx_sel_prof_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mhimx::sel_prof), 32 * 8);
+}
+#endif
 
 extern "C" int64_t mhimx_select_ws_bytes(int64_t N) { return align_up(N, 256); }
 
