@@ -157,37 +157,77 @@ __global__ __launch_bounds__(HEAD_THREADS) void dsmil_head_kernel(const float* _
 
 // torch.optim.Adam semantics (weight decay folded into the gradient, bias-corrected, eps outside the sqrt of
 // the corrected second moment) + EMA teacher.  bc1 = 1-beta1^t, bc2s = sqrt(1-beta2^t) come from the host in fp64.
-__global__ void adam_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                float* __restrict__ teacher, int64_t n_train, int64_t n_all, float lr_over_bc1, float bc2s,
-                                float beta1, float beta2, float eps, float wd, float gscale, float mm, int zero_grad,
-                                const uint64_t* __restrict__ step_dev, float lr, const float* __restrict__ mm_table,
-                                int64_t mm_len, int64_t step_host) {
-  int64_t step = step_host;
-  if (step_dev) {                       // graph replay: the step count lives on the device
-    step = (int64_t)step_dev[0];
-    const double t = (double)step;
-    lr_over_bc1 = (float)((double)lr / (1.0 - pow((double)beta1, t)));
-    bc2s = (float)sqrt(1.0 - pow((double)beta2, t));
-  }
-  if (mm_table) {                       // EMA momentum schedule (base_engine.py:160-161): entry of this iteration, last one held
-    int64_t i = step - 1;
-    i = i < 0 ? 0 : (i >= mm_len ? mm_len - 1 : i);
-    mm = mm_table[i];
-  }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
-    float w = p[i];
-    if (i < n_train) {
-      float gi = g[i] * gscale + wd * w;
-      const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-      const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-      m[i] = mi;
-      v[i] = vi;
-      const float denom = sqrtf(vi) / bc2s + eps;
-      w = w - lr_over_bc1 * (mi / denom);
-      p[i] = w;
-      if (zero_grad) g[i] = 0.f;
+MHIMX_DEV void adam_one(float& w, float& gi, float& mi, float& vi, float lr_over_bc1, float bc2s, float beta1, float beta2,
+                        float eps, float wd, float gscale) {
+  gi = gi * gscale + wd * w;
+  mi = beta1 * mi + (1.f - beta1) * gi;
+  vi = beta2 * vi + (1.f - beta2) * gi * gi;
+  w = w - lr_over_bc1 * (mi / (sqrtf(vi) / bc2s + eps));
+}
+
+__global__ __launch_bounds__(256) void adam_ema_kernel(
+    float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ teacher,
+    int64_t n_train, int64_t n_all, float lr_over_bc1, float bc2s, float beta1, float beta2, float eps, float wd, float gscale,
+    float mm, int zero_grad, const uint64_t* __restrict__ step_dev, float lr, const float* __restrict__ mm_table, int64_t mm_len,
+    int64_t step_host, double ln_beta1, double ln_beta2) {
+  __shared__ float sc[3];
+  if (threadIdx.x == 0) {               // the fp64 pow()s of the bias corrections: once per block, not once per thread
+    int64_t step = step_host;
+    if (step_dev) {                     // graph replay: the step count lives on the device
+      step = (int64_t)step_dev[0];
+      const double t = (double)step;
+      lr_over_bc1 = (float)((double)lr / (1.0 - exp(t * ln_beta1)));       // beta^t = e^(t ln beta), ln beta from the host in fp64
+      bc2s = (float)sqrt(1.0 - exp(t * ln_beta2));
     }
-    if (teacher) teacher[i] = teacher[i] * mm + w * (1.f - mm);
+    if (mm_table) {                     // EMA momentum schedule (base_engine.py:160-161): entry of this iteration, last one held
+      int64_t i = step - 1;
+      i = i < 0 ? 0 : (i >= mm_len ? mm_len - 1 : i);
+      mm = mm_table[i];
+    }
+    sc[0] = lr_over_bc1; sc[1] = bc2s; sc[2] = mm;
+  }
+  __syncthreads();
+  lr_over_bc1 = sc[0];
+  bc2s = sc[1];
+  mm = sc[2];
+  const int64_t n4 = n_all / 4;
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                        reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(teacher)) & 15) == 0;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n_all; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q * 4;
+    if (vec_ok && q < n4 && (i0 + 4 <= n_train || i0 >= n_train)) {
+      float4 w = reinterpret_cast<float4*>(p)[q];
+      if (i0 < n_train) {
+        float4 gi = reinterpret_cast<float4*>(g)[q], mi = reinterpret_cast<float4*>(m)[q], vi = reinterpret_cast<float4*>(v)[q];
+        adam_one(w.x, gi.x, mi.x, vi.x, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
+        adam_one(w.y, gi.y, mi.y, vi.y, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
+        adam_one(w.z, gi.z, mi.z, vi.z, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
+        adam_one(w.w, gi.w, mi.w, vi.w, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
+        reinterpret_cast<float4*>(m)[q] = mi;
+        reinterpret_cast<float4*>(v)[q] = vi;
+        reinterpret_cast<float4*>(p)[q] = w;
+        if (zero_grad) reinterpret_cast<float4*>(g)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (teacher) {
+        float4 t = reinterpret_cast<float4*>(teacher)[q];
+        t.x = t.x * mm + w.x * (1.f - mm); t.y = t.y * mm + w.y * (1.f - mm);
+        t.z = t.z * mm + w.z * (1.f - mm); t.w = t.w * mm + w.w * (1.f - mm);
+        reinterpret_cast<float4*>(teacher)[q] = t;
+      }
+      continue;
+    }
+    for (int64_t i = i0; i < i0 + 4 && i < n_all; ++i) {
+      float w = p[i];
+      if (i < n_train) {
+        float gi = g[i], mi = m[i], vi = v[i];
+        adam_one(w, gi, mi, vi, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = w;
+        if (zero_grad) g[i] = 0.f;
+      }
+      if (teacher) teacher[i] = teacher[i] * mm + w * (1.f - mm);
+    }
   }
 }
 
@@ -229,10 +269,10 @@ extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, 
   if (n_all == 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const int64_t blocks = cdiv(n_all, 256) < 2048 ? cdiv(n_all, 256) : 2048;
+  const int64_t blocks = cdiv(n_all, 1024) < 2048 ? cdiv(n_all, 1024) : 2048;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v,
                      teacher, n_train, n_all, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, weight_decay,
-                     grad_scale, ema_mm, zero_grad, step_dev, lr, mm_table, mm_len, step);
+                     grad_scale, ema_mm, zero_grad, step_dev, lr, mm_table, mm_len, step, log((double)beta1), log((double)beta2));
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
