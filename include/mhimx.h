@@ -105,7 +105,10 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
 
 /* The parameter-only preparation of one train step as ONE launch (each tiny kernel costs ~5 us of dispatch latency on the
  * step's serial chain): up to MHIMX_PREP_MAX jobs of kind 0 = transpose in[R,C] -> out[C,R], 1 = paired planes of in[R,C],
- * 2 = copy R*C floats, 3 = *(uint64_t*)out += 1 (the device-resident dropout / Adam step counters). */
+ * 2 = copy R*C floats, 3 = *(uint64_t*)out += 1 (the device-resident dropout / Adam step counters),
+ * 4 = matrix-core fragment image of in[R,C] (R % 32 == 0, C % 16 == 0; same size as in): for every 32-row block nt and
+ *     16-column step ks, 64 consecutive 32-byte items (item l: 8 bf16 hi | 8 bf16 lo of in[32 nt + l % 32][16 ks + 8 (l / 32) ..])
+ *     - what mhimx_scorer.wa_frag takes. */
 #define MHIMX_PREP_MAX 12
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
@@ -127,6 +130,8 @@ typedef struct {
   const float* wa; const float* ba;     /* [A,E], [A]|NULL   attention.0 / attention_a.0            */
   const float* wb; const float* bb;     /* gated: [A,E], [A]|NULL   attention_b.0                   */
   const float* wc; const float* bc;     /* [A], [1]|NULL     attention.2 / attention_c              */
+  const float* wa_frag;                 /* optional: prep kind-4 image of wa (made once per step with the other parameter
+                                           preparation); NULL: the fused scorer splits wa to bf16 hi/lo on the fly   */
 } mhimx_scorer;
 
 /* Forward over up to two token segments (segment 1 = feature rows, segment 2 = merged tokens).

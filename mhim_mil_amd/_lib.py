@@ -52,7 +52,8 @@ class GemmTN(C.Structure):
 
 class Scorer(C.Structure):
     _fields_ = [("E", C.c_int64), ("A", C.c_int64), ("act", C.c_int32), ("gated", C.c_int32), ("prec", C.c_int32),
-                ("wa", c_f32p), ("ba", c_f32p), ("wb", c_f32p), ("bb", c_f32p), ("wc", c_f32p), ("bc", c_f32p)]
+                ("wa", c_f32p), ("ba", c_f32p), ("wb", c_f32p), ("bb", c_f32p), ("wc", c_f32p), ("bc", c_f32p),
+                ("wa_frag", c_f32p)]
 
 
 class PoolIO(C.Structure):

@@ -67,11 +67,17 @@ MHIMX_DEV float erf_fast(float x) {
   return copysignf(r, x);
 }
 
+// tanh from one exp: (1 - e^{-2|x|}) / (1 + e^{-2|x|}), absolute error < 1e-7 (the library tanhf is ~40 branchy operations)
+MHIMX_DEV float tanh_fast(float x) {
+  const float t = __expf(-2.f * fabsf(x));
+  return copysignf((1.f - t) * __frcp_rn(1.f + t), x);
+}
+
 MHIMX_DEV float act_fwd(float x, int act) {
   switch (act) {
     case MHIMX_ACT_RELU: return x > 0.f ? x : 0.f;
     case MHIMX_ACT_GELU: return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752440f));   // exact-erf GELU (erf to 1.5e-7)
-    case MHIMX_ACT_TANH: return tanhf(x);
+    case MHIMX_ACT_TANH: return tanh_fast(x);
     default: return x;
   }
 }
@@ -106,7 +112,7 @@ MHIMX_DEV void act_fwd_grad(float x, int act, float& y, float& g) {
       g = cdf + x * 0.39894228040143267794f * ex;
       return;
     }
-    case MHIMX_ACT_TANH: y = tanhf(x); g = 1.f - y * y; return;
+    case MHIMX_ACT_TANH: y = tanh_fast(x); g = 1.f - y * y; return;
     default: y = x; g = 1.f; return;
   }
 }

@@ -516,7 +516,8 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
 }
 
 // One launch for the parameter-only preparation of a train step: blockIdx.y = job.  kind 0: out[c,r] = in[r,c];
-// kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters).
+// kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters);
+// kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip).
 struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int n; };
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
   const mhimx_prep_job jb = pj.j[blockIdx.y];
@@ -554,6 +555,21 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) jb.out[i] = jb.in[i];
   } else if (jb.kind == 3) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint64_t*>(jb.out) += 1;
+  } else if (jb.kind == 4) {
+    // B-operand fragment image for v_mfma_f32_32x32x16_bf16: item (nt, ks, lane) holds the 8 hi | 8 lo bf16 of
+    // in[32 nt + (lane & 31)][16 ks + 8 (lane >> 5) .. + 8]: a wave's fragment load is 2 KB contiguous
+    const int64_t KS = C / 16, n = R * C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      const int64_t lane = i & 63, ks = (i >> 6) % KS, nt = (i >> 6) / KS;
+      const float* src = jb.in + (32 * nt + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5);
+      const f4 a = *reinterpret_cast<const f4*>(src);
+      const f4 b = *reinterpret_cast<const f4*>(src + 4);
+      b8 hi, lo;
+      Frag<MHIMX_PREC_BF16X3>::split2(a, b, hi, lo);
+      f4* o = reinterpret_cast<f4*>(jb.out + i * 8);
+      o[0] = __builtin_bit_cast(f4, hi);
+      o[1] = __builtin_bit_cast(f4, lo);
+    }
   }
 }
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
@@ -563,7 +579,9 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
   for (int i = 0; i < n; ++i) {
     pj.j[i] = jobs[i];
     MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
-    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 3, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 4, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind != 4 || (jobs[i].R % 32 == 0 && jobs[i].C % 16 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
+                    "prep_batch: the fragment image needs R % 32 == 0, C % 16 == 0 and 16-byte aligned buffers");
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
   }

@@ -10,6 +10,10 @@ namespace mhimx {
 
 int gemm_nt(hipStream_t st, const mhimx_gemm_nt_args& g);
 int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
+bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, const float* wa, const float* wp, int64_t C);
+int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
+                     const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
+                     float* pz, int max_parts);
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
@@ -591,6 +595,16 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   int G = 0;
   for (int seg = 0; seg < 2; ++seg) {
     if (Ms[seg] == 0) continue;
+    if (scorer_fused_ok(E, A, gated, sc->prec, Ts[seg], sc->wa, io->cproj ? io->wp : nullptr, io->C)) {
+      // one pass over the rows: GEMM + scores + class projections + pool partials (scorer_fused.hip)
+      const int g1 = scorer_fused_fwd(st, Ts[seg], Ms[seg], sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, io->cproj ? io->wp : nullptr,
+                                      (int)io->C, u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
+                                      w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART);
+      if (g1 < 0) return g1;
+      G += g1;
+      off += Ms[seg];
+      continue;
+    }
     mhimx_gemm_nt_args g = {};
     g.A = Ts[seg]; g.lda = E; g.B = sc->wa; g.ldb = E; g.C = u_pre + off * ldu; g.ldc = ldu;
     g.M = Ms[seg]; g.N = A; g.K = E; g.bias = sc->ba;

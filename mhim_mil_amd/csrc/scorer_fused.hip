@@ -1,0 +1,239 @@
+// scorer_fused.hip — the ABMIL scorer + softmax-pool forward of one token matrix in ONE pass over it
+// (modules/mhim.py:14-63 DAttention.forward restated: a = act(T Wa^T + ba), s = a.wc + bc, z = softmax(s) T).
+//
+// The three-kernel form (split-K scorer GEMM -> slab reduce -> row pass) reads T twice and pays three launch floors on the
+// teacher -> select -> student critical path.  Here one workgroup owns 32 token rows:
+//   1. the 32 x 512 fp32 rows land in LDS once (64.5 KB, rows padded by 16 B so the MFMA operand reads spread over banks);
+//   2. U = T Wa^T (32 x 128, K = 512) on the matrix cores in the bf16x3 form (hi*hi + hi*lo + lo*hi, ~fp32 accuracy: the scores
+//      feed the top-k); wave w owns output columns [32w, 32w+32) - v_mfma_f32_32x32x16_bf16, A from LDS, B (Wa, 256 KB, L2
+//      resident for every workgroup) straight from global memory one k-step ahead;
+//   3. epilogue in registers: + ba, pre-activation stored for the backward, act, * wc, 32-lane DPP row sums -> s;
+//   4. the per-class projections cproj = T wp^T (pseudo score) and the log-sum-exp partial (m, l, sum_r e^{s_r - m} T[r,:])
+//      come from the LDS copy of the rows - no second read of T.
+// Partials are merged by pool_finalize_kernel (rows.hip) in a fixed order: deterministic.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mhimx {
+
+typedef float sf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float sf_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sf_b8 __attribute__((ext_vector_type(8)));
+
+#ifdef MHIMX_SF_PROF
+__device__ unsigned long long sf_prof[16];
+#define SF_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 7) sf_prof[i] = wall_clock64(); } while (0)
+#else
+#define SF_STAMP(i)
+#endif
+
+constexpr int SF_ROWS = 32, SF_E = 512, SF_A = 128, SF_LD = SF_E + 4, SF_THREADS = 256;
+constexpr int SF_MAXC = 4;                  // class projections staged in LDS (more classes: the row-pass form)
+constexpr size_t SF_SMEM = (size_t)(SF_ROWS * SF_LD + 4 * SF_ROWS + 2 * SF_ROWS + SF_MAXC * SF_E) * sizeof(float);
+
+MHIMX_DEV void sf_split(const sf_f4& a, const sf_f4& b, sf_b8& hi, sf_b8& lo) {
+  const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(x[i] - (float)h);
+  }
+}
+
+// sum over the 32 lanes that share (lane >> 5); valid in lanes 16..31 and 48..63
+MHIMX_DEV float sf_sum32(float v) {
+  v += dpp_mov<0xB1, 0xf>(0.f, v);
+  v += dpp_mov<0x4E, 0xf>(0.f, v);
+  v += dpp_mov<0x141, 0xf>(0.f, v);
+  v += dpp_mov<0x140, 0xf>(0.f, v);          // every lane of a 16-lane row holds its row sum
+  v += dpp_mov<0x142, 0xa>(0.f, v);          // rows 1,3 += rows 0,2
+  return v;
+}
+
+__global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
+    const float* __restrict__ T, int64_t M, const float* __restrict__ wa, const float* __restrict__ wa_frag,
+    const float* __restrict__ ba, int act,
+    const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ wp, int C, float* __restrict__ u_pre,
+    float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl, float* __restrict__ pz,
+    int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float sf_sm[];
+  float* Hs = sf_sm;                          // [32][516]
+  float* sred = Hs + SF_ROWS * SF_LD;         // [4][32] per-wave partial scores
+  float* srow = sred + 4 * SF_ROWS;           // [32] scores
+  float* prow = srow + SF_ROWS;               // [32] e^{s - m}
+  float* wps = prow + SF_ROWS;                // [C][512] predictor rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, kg = lane >> 5;
+  const int n_col = 32 * wave + r32;
+  const float bias_c = bc ? bc[0] : 0.f;
+  const float bn = ba ? ba[n_col] : 0.f, wn = wc[n_col];
+  const float* bptr = wa + (int64_t)n_col * SF_E + 8 * kg;
+  const float* fptr = wa_frag ? wa_frag + ((int64_t)wave * (SF_E / 16) * 64 + lane) * 8 : nullptr;   // + ks * 512 floats
+  const float* aptr = Hs + r32 * SF_LD + 8 * kg;
+  if (wp)
+    for (int i = tid; i < C * SF_E / 4; i += SF_THREADS) reinterpret_cast<sf_f4*>(wps)[i] = reinterpret_cast<const sf_f4*>(wp)[i];
+
+  float m_run = -INFINITY, l_run = 0.f, z0 = 0.f, z1 = 0.f;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * SF_ROWS;
+    SF_STAMP(0);
+    // ---- 1. rows -> LDS
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = tid + SF_THREADS * i, r = f >> 7, c4 = f & 127;
+      const int64_t n = row0 + r;
+      sf_f4 v = reinterpret_cast<const sf_f4*>(T + (n < M ? n : M - 1) * SF_E)[c4];      // clamped: all 16 loads in flight
+      if (n >= M) v = sf_f4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<sf_f4*>(Hs + r * SF_LD + 4 * c4) = v;
+    }
+    __syncthreads();
+    SF_STAMP(1);
+    // ---- 2. U tile on the matrix cores
+    // two accumulators: the cross terms and hi*hi form independent MFMA chains
+    sf_f32x16 acc, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    if (fptr) {
+      // B fragments ready-made (prep kind 4): two coalesced 16-byte loads per k-step, four k-steps ahead
+      constexpr int PF = 4;
+      sf_f4 bh_[PF], bl_[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        bh_[q] = *reinterpret_cast<const sf_f4*>(fptr + 512 * q);
+        bl_[q] = *reinterpret_cast<const sf_f4*>(fptr + 512 * q + 4);
+      }
+#pragma unroll 4
+      for (int ks = 0; ks < SF_E / 16; ++ks) {
+        const sf_f4 a0 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks), a1 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks + 4);
+        sf_b8 ah, al;
+        sf_split(a0, a1, ah, al);
+        const sf_b8 bh = __builtin_bit_cast(sf_b8, bh_[ks % PF]), bl = __builtin_bit_cast(sf_b8, bl_[ks % PF]);
+        const int kn = ks + PF < SF_E / 16 ? ks + PF : ks;
+        bh_[ks % PF] = *reinterpret_cast<const sf_f4*>(fptr + 512 * kn);
+        bl_[ks % PF] = *reinterpret_cast<const sf_f4*>(fptr + 512 * kn + 4);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+      }
+    } else {
+      sf_f4 b0 = *reinterpret_cast<const sf_f4*>(bptr), b1 = *reinterpret_cast<const sf_f4*>(bptr + 4);
+#pragma unroll 4
+      for (int ks = 0; ks < SF_E / 16; ++ks) {
+        const int kn = ks + 1 < SF_E / 16 ? ks + 1 : ks;
+        const sf_f4 nb0 = *reinterpret_cast<const sf_f4*>(bptr + 16 * kn), nb1 = *reinterpret_cast<const sf_f4*>(bptr + 16 * kn + 4);
+        const sf_f4 a0 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks), a1 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks + 4);
+        sf_b8 ah, al, bh, bl;
+        sf_split(a0, a1, ah, al);
+        sf_split(b0, b1, bh, bl);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+        b0 = nb0;
+        b1 = nb1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    // ---- 3. epilogue: acc[i] = U[row = 8*(i>>2) + 4*kg + (i&3)][n_col]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
+      const int64_t n = row0 + row;
+      const float u = acc[i] + bn;
+      if (n < M) u_pre[n * SF_A + n_col] = u;
+      const float v = sf_sum32(wn * act_fwd(u, act));
+      if (r32 == 31) sred[wave * SF_ROWS + row] = v;
+    }
+    __syncthreads();
+    if (tid < SF_ROWS) {
+      const int64_t n = row0 + tid;
+      float s = (sred[tid] + sred[SF_ROWS + tid]) + (sred[2 * SF_ROWS + tid] + sred[3 * SF_ROWS + tid]) + bias_c;
+      if (n < M) s_out[n] = s;
+      else s = -INFINITY;
+      srow[tid] = s;
+    }
+    __syncthreads();
+    SF_STAMP(3);
+    // ---- 4. log-sum-exp partial over the tile (running over this workgroup's tiles)
+    float mt = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < SF_ROWS / 4; ++q) {
+      const sf_f4 v = reinterpret_cast<const sf_f4*>(srow)[q];
+      mt = fmaxf(fmaxf(mt, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    const float m_new = fmaxf(m_run, mt);
+    const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    if (tid < SF_ROWS) prow[tid] = __expf(srow[tid] - m_new);          // -inf rows -> 0
+    __syncthreads();
+    float lsum = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < SF_ROWS / 4; ++q) {
+      const sf_f4 p = reinterpret_cast<const sf_f4*>(prow)[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* hr = Hs + (4 * q + j) * SF_LD;
+        lsum += p[j];
+        a0 += p[j] * hr[tid];
+        a1 += p[j] * hr[tid + SF_THREADS];
+      }
+    }
+    l_run = l_run * scale + lsum;
+    z0 = z0 * scale + a0;
+    z1 = z1 * scale + a1;
+    m_run = m_new;
+    SF_STAMP(4);
+    // ---- class projections of the rows (pseudo score): 8 lanes per row, 64 columns each
+    if (wp) {
+      const int r = tid >> 3, seg = tid & 7;
+      const int64_t n = row0 + r;
+      const float* hr = Hs + r * SF_LD + 64 * seg;
+      for (int c = 0; c < C; ++c) {
+        const float* w = wps + c * SF_E + 64 * seg;
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const sf_f4 h = reinterpret_cast<const sf_f4*>(hr)[q], ww = reinterpret_cast<const sf_f4*>(w)[q];
+          d += h[0] * ww[0] + h[1] * ww[1] + h[2] * ww[2] + h[3] * ww[3];
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (seg == 0 && n < M) cproj[n * C + c] = d;
+      }
+    }
+    __syncthreads();                           // the next tile overwrites Hs / srow
+    SF_STAMP(5);
+  }
+  if (tid == 0) { pm[blockIdx.x] = m_run; pl[blockIdx.x] = l_run; }
+  pz[(int64_t)blockIdx.x * SF_E + tid] = z0;
+  pz[(int64_t)blockIdx.x * SF_E + tid + SF_THREADS] = z1;
+}
+
+#ifdef MHIMX_SF_PROF
+extern "C" int mhimx_sf_prof_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sf_prof), 16 * 8); }
+#endif
+
+bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, const float* wa, const float* wp, int64_t C) {
+  return E == SF_E && A == SF_A && !gated && prec != MHIMX_PREC_F32 && aligned16(T) && aligned16(wa) && (!wp || (aligned16(wp) && C <= SF_MAXC));
+}
+
+// one launch per token segment; returns the number of partials written to pm/pl/pz (<= max_parts), < 0 on error
+int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
+                     const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
+                     float* pz, int max_parts) {
+  static bool attr = false;
+  if (!attr) {
+    MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM));
+    attr = true;
+  }
+  const int tiles = (int)cdiv(M, SF_ROWS);
+  const int grid = tiles < max_parts ? tiles : max_parts;
+  hipLaunchKernelGGL(scorer_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
+                     cproj, pm, pl, pz, tiles);
+  MHIMX_LAUNCH_CHECK();
+  return grid;
+}
+
+}  // namespace mhimx

@@ -211,7 +211,8 @@ class FusedTrainer:
         gv = fl.grad_views
         xp = s._pair(x) if s.baseline == "attn" else None        # one bf16 hi/lo image of the bag for both projections
         if self.model_kind == "mhim":
-            teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"])
+            teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"],
+                                                    wa_frag=None if prep_t is None else prep_t.get("wa_frag"))
             mf = s.baseline == "attn"                       # [merge | stay] rows: the pool reads [stay | merged tokens] contiguously
             rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle, merge_first=mf)
             plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True,

@@ -270,13 +270,13 @@ class MHIM(nn.Module):
             obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
         return obj
 
-    def _scorer(self):
+    def _scorer(self, wa_frag=None):
         att = self.online_encoder.attention
         act = L.act_code(self.da_act, _SCORER_ACTS)
         if self.online_encoder.gated:
             return ops.ScorerW(att.attention_a[0].weight.data, att.attention_c.weight.data, act,
                                wb=att.attention_b[0].weight.data, prec=self._op_prec)
-        return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec)
+        return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec, wa_frag=wa_frag)
 
     def prep_jobs(self, backward=True):
         """Parameter-only work of one step — the paired-plane image of the projection weight, weight transposes for the dX
@@ -293,6 +293,11 @@ class MHIM(nn.Module):
             jobs.append((ops.PREP_TRANSPOSE, w, out))
             return out
 
+        if self.baseline == "attn" and not self.online_encoder.gated:
+            wa = self.online_encoder.attention.attention[0].weight.data
+            if wa.shape[0] % 32 == 0 and wa.shape[1] % 16 == 0:           # matrix-core image of the scorer weight (fused scorer)
+                prep["wa_frag"] = torch.empty_like(wa)
+                jobs.append((ops.PREP_FRAG, wa, prep["wa_frag"]))
         if backward and self.baseline == "attn":
             att = self.online_encoder.attention
             if self.online_encoder.gated:
@@ -398,7 +403,7 @@ class MHIM(nn.Module):
         self._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=Lrows, xp=xp, w1p=prep.get("w1p"),
                       dact=DACT)
         saved = {"H": H, "Hbuf": Hbuf, "PRE": PRE, "DACT": DACT, "prep": prep}
-        sc = self._scorer()
+        sc = self._scorer(prep.get("wa_frag"))
         if merging:
             mw = self._merge_w(plan, need_t=False)
             q_old = prep.get("q_old")
@@ -583,7 +588,7 @@ class MHIM(nn.Module):
 
     # ------------------------------------------------------------------ reference entry points
     @torch.no_grad()
-    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None):
+    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None, wa_frag=None):
         x = self._check_x(x)
         p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
         H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp, w1p=w1p)
@@ -605,7 +610,7 @@ class MHIM(nn.Module):
                 score = attn[self.attn_layer][:, :p0].contiguous().unsqueeze(0)          # [1,h,N] (mhim.py:224-225)
             return z.view(1, -1), score
         wp = self.predictor.weight.data if self.attn2score else None
-        st = ops.abmil_pool_fwd(self._scorer(), H, T2, wp=wp)
+        st = ops.abmil_pool_fwd(self._scorer(wa_frag), H, T2, wp=wp)
         if self.attn2score:
             score = ops.pseudo_score(st.s[:p0], st.stats, st.cproj[:p0], self.predictor.bias.data)
         else:

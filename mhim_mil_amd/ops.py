@@ -71,12 +71,13 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
     return out
 
 
-PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK = 0, 1, 2, 3
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG = 0, 1, 2, 3, 4
 
 
 def prep_batch(jobs):
     """jobs: list of (kind, in_tensor | None, out_tensor) -> ONE launch.  kind: PREP_TRANSPOSE (out = in^T), PREP_PAIR
-    (paired bf16 planes), PREP_COPY, PREP_TICK (out: int64/uint64 [1] counter += 1)."""
+    (paired bf16 planes), PREP_COPY, PREP_TICK (out: int64/uint64 [1] counter += 1), PREP_FRAG (matrix-core fragment image
+    of a [32a, 16b] weight, see mhimx.h)."""
     arr = (L.PrepJob * len(jobs))()
     for i, (kind, src, dst) in enumerate(jobs):
         if kind == PREP_TICK:
@@ -129,14 +130,14 @@ def transpose(x, out=None):
 class ScorerW:
     """Scorer weights in the C layout (keeps the tensors alive)."""
 
-    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="f16s"):
-        self.t = (wa, wc, ba, wb, bb, bc)
+    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="f16s", wa_frag=None):
+        self.t = (wa, wc, ba, wb, bb, bc, wa_frag)
         for t in self.t:
             _chk(t, name="scorer weight")
         self.A, self.E = wa.shape
         self.gated = wb is not None
         self.c = L.Scorer(E=self.E, A=self.A, act=int(act), gated=int(self.gated), prec=prec_code(prec), wa=_p(wa),
-                          ba=_p(ba), wb=_p(wb), bb=_p(bb), wc=_p(wc), bc=_p(bc))
+                          ba=_p(ba), wb=_p(wb), bb=_p(bb), wc=_p(wc), bc=_p(bc), wa_frag=_p(wa_frag))
 
 
 class PoolState:

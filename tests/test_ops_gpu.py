@@ -448,3 +448,29 @@ def test_select_rows_fused_random_subsets():
     never = np.setdiff1d(np.arange(n), cand)
     g = cnt_merge[never] / T
     assert abs(g.mean() - R / L_) < 0.002 and g.max() < 0.25                            # p = 0.1, sigma = 0.021
+
+
+@pytest.mark.parametrize("M", [31, 1000, 20000])
+def test_fused_scorer_fragment_image(M):
+    """The one-pass scorer (scorer_fused.hip) with the prep kind-4 fragment image of Wa == the same kernel splitting Wa on
+    the fly, bit for bit; against the fp64 oracle within the bf16x3 tolerance.  M = 20000: several tiles per workgroup."""
+    ops = _ops()
+    E, A, Cc = 512, 128, 2
+    T = rnd(51, (M, E)).abs()
+    wa, wc, _, ba, _, bc = _scorer_params(52, E, A, False, True)
+    wp = rnd(53, (Cc, E), std=0.05)
+    s_ref = O.scorer_logits(T.double(), wa.double(), wc.double(), "tanh", ba=ba.double(), b2=bc.double())
+    z_ref, _ = O.softmax_pool(T.double(), s_ref)
+    d = lambda t: t.to(DEV)
+    frag = torch.empty(A, E, device=DEV)
+    ops.prep_batch([(ops.PREP_FRAG, d(wa), frag)])
+    res = []
+    for wf in (None, frag):
+        sc = ops.ScorerW(d(wa), d(wc), 3, ba=d(ba), bc=d(bc), prec="bf16x3", wa_frag=wf)
+        st = ops.abmil_pool_fwd(sc, d(T), wp=d(wp))
+        res.append((st.s.clone(), st.z.clone(), st.cproj.clone(), st.stats.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), s_ref.float().numpy(), atol=8e-5, rtol=4e-5)
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), z_ref.float().numpy(), atol=1.2e-5, rtol=4e-5)
+    np.testing.assert_allclose(res[1][2].cpu().numpy(), (T.double() @ wp.double().t()).float().numpy(), atol=2e-5, rtol=1e-5)
