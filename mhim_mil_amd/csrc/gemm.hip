@@ -243,9 +243,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g,
 // =================================================================================================
 constexpr int SKINNY_M = 16;
 
-__global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) {
+MHIMX_DEV void skinny_nt_body(const mhimx_gemm_nt_args& g, int64_t block) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t n = block * 4 + wave;
   if (n >= g.N) return;
   float acc[SKINNY_M];
 #pragma unroll
@@ -281,15 +281,28 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) {
     *c = v;
   }
 }
+__global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) { skinny_nt_body(g, blockIdx.x); }
 
-__global__ void skinny_tn_kernel(mhimx_gemm_tn_args g) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i = blockIdx.y;
+MHIMX_DEV void skinny_tn_body(const mhimx_gemm_tn_args& g, int64_t i, int64_t jblock) {
+  const int64_t j = jblock * 256 + threadIdx.x;
   if (j >= g.K2) return;
   float acc = 0.f;
   for (int64_t m = 0; m < g.M; ++m) acc += g.A[m * g.lda + i] * g.B[(g.rows ? g.rows[m] : m) * g.ldb + j];
   float* p = g.C + i * g.ldc + j;
   *p = g.accumulate ? *p + acc : acc;
+}
+__global__ __launch_bounds__(256) void skinny_tn_kernel(mhimx_gemm_tn_args g) { skinny_tn_body(g, blockIdx.y, blockIdx.x); }
+
+// Two independent skinny products that read the same few rows (the Merge backward has two such pairs: d_W = d^T x and
+// d_in = d W^T) as ONE launch: blocks [0, nt_blocks) run the NT form, the rest the TN form.  Each tiny kernel on the step's
+// serial chain costs a ~5 us launch floor.
+__global__ __launch_bounds__(256) void skinny_pair_kernel(mhimx_gemm_tn_args t, mhimx_gemm_nt_args g, int nt_blocks, int tn_jblocks) {
+  if ((int)blockIdx.x < nt_blocks) {
+    skinny_nt_body(g, blockIdx.x);
+  } else {
+    const int b = (int)blockIdx.x - nt_blocks;
+    skinny_tn_body(t, b / tn_jblocks, b % tn_jblocks);
+  }
 }
 
 template <int PREC>
@@ -298,6 +311,16 @@ static int launch_nt(hipStream_t st, const mhimx_gemm_nt_args& g, int batch = 1,
   const size_t smem = (size_t)(PP::NA + PP::NB) * 128 * PP::PITCH * sizeof(typename PP::T);
   dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)batch);
   hipLaunchKernelGGL(gemm_nt_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, bt);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g) {
+  MHIMX_CHECK_ARG(t.M > 0 && t.M <= SKINNY_M && g.M > 0 && g.M <= SKINNY_M && t.A && t.B && t.C && g.A && g.B && g.C,
+                  "skinny_pair: both products need 1..%d rows and non-null operands", SKINNY_M);
+  MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && aligned16(g.A) && aligned16(g.B), "skinny_pair: NT operands must be 16-byte aligned rows");
+  const int nt_blocks = (int)cdiv(g.N, 4), tn_jblocks = (int)cdiv(t.K2, 256);
+  hipLaunchKernelGGL(skinny_pair_kernel, dim3((unsigned)(nt_blocks + tn_jblocks * t.K1)), dim3(256), 0, st, t, g, nt_blocks, tn_jblocks);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -14,7 +14,8 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y, float* mean, float* rstd);
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
-                  int max_parts);
+                  int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2);
+int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g);
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes);
 
 constexpr int MCA_THREADS = 256;
@@ -328,6 +329,81 @@ __global__ void mca_reduce_kernel(const float* __restrict__ part, int nb, int W,
   if (threadIdx.y == 0 && j < W) out[j] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Forward prologue in ONE launch: blocks [0, nbx) LayerNorm the key rows (one wave per row); the next I/8 blocks handle the
+// k global queries - each LayerNorms them into LDS (k x E floats, a few KB: cheaper than a launch of its own and a grid
+// dependency) and projects them onto its 8 columns of Wq (exact fp32 FMA, wave per output column, as the skinny GEMM does).
+// Replaces layernorm(x), layernorm(q), q-projection: three launch floors on the step's serial chain.
+// ---------------------------------------------------------------------------------------------------
+constexpr int MCA_PRE_COLS = 8;       // Wq columns per query block (4 waves x 2)
+MHIMX_DEV void ln_row(const float* __restrict__ xr, int E, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                      float* mu_out, float* rs_out) {
+  const int lane = threadIdx.x & 63;
+  float sum = 0.f;
+  for (int e = lane; e < E; e += 64) sum += xr[e];
+  const float mu = wave_sum(sum) / (float)E;
+  float var = 0.f;
+  for (int e = lane; e < E; e += 64) { const float d = xr[e] - mu; var += d * d; }
+  const float rs = rsqrtf(wave_sum(var) / (float)E + 1e-5f);
+  for (int e = lane; e < E; e += 64) y[e] = (xr[e] - mu) * rs * w[e] + b[e];
+  *mu_out = mu;
+  *rs_out = rs;
+}
+
+__global__ __launch_bounds__(256) void mca_pre_kernel(const float* __restrict__ x, int64_t R, int E, const float* __restrict__ ln_w,
+                                                      const float* __restrict__ ln_b, float* __restrict__ xn, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, const float* __restrict__ q_param, int k,
+                                                      float* __restrict__ gq, float* __restrict__ gmean, float* __restrict__ grstd,
+                                                      const float* __restrict__ wq, int I, float* __restrict__ Q, int nbx) {
+  extern __shared__ __attribute__((aligned(16))) float gqs[];          // [k][E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < nbx) {
+    for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < R; n += (int64_t)nbx * 4) {
+      float mu, rs;
+      ln_row(x + n * (int64_t)E, E, ln_w, ln_b, xn + n * (int64_t)E, &mu, &rs);
+      if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
+    }
+    return;
+  }
+  const int qb = (int)blockIdx.x - nbx;
+  for (int i = wave; i < k; i += 4) {
+    float mu, rs;
+    ln_row(q_param + (int64_t)i * E, E, ln_w, ln_b, gqs + i * E, &mu, &rs);
+    if (qb == 0 && lane == 0) { gmean[i] = mu; grstd[i] = rs; }
+  }
+  __syncthreads();
+  if (qb == 0)
+    for (int i = threadIdx.x; i < k * E; i += 256) gq[i] = gqs[i];       // kept for the backward
+  // two output columns per wave, both weight rows in flight before the first use (the chain is global-load latency)
+  const int c0 = qb * MCA_PRE_COLS + wave * 2;
+  if (c0 >= I) return;
+  const bool two = c0 + 1 < I;
+  const float* w0 = wq + (int64_t)c0 * E;
+  const float* w1 = wq + (int64_t)(two ? c0 + 1 : c0) * E;
+  float acc0[16], acc1[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+  for (int e = lane * 4; e < E; e += 256) {                             // the summation order of skinny_nt_kernel
+    const float4 u = *reinterpret_cast<const float4*>(w0 + e), v = *reinterpret_cast<const float4*>(w1 + e);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < k) {
+        const float4 a = *reinterpret_cast<const float4*>(gqs + i * E + e);
+        acc0[i] += a.x * u.x + a.y * u.y + a.z * u.z + a.w * u.w;
+        acc1[i] += a.x * v.x + a.y * v.y + a.z * v.z + a.w * v.w;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < k) {
+      const float s0 = wave_sum(acc0[i]), s1 = wave_sum(acc1[i]);
+      if (lane == 0) {
+        Q[(int64_t)i * I + c0] = s0;
+        if (two) Q[(int64_t)i * I + c0 + 1] = s1;
+      }
+    }
+}
+
 template <typename F>
 static int dispatch_kq(int64_t k, F&& f) {
   if (k <= 1) return f(std::integral_constant<int, 1>());
@@ -468,15 +544,31 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   merge_ws_layout(ar, R, E, k, H, m->dim_head, &w);
   MHIMX_CHECK_ARG(ar.ok(), "merge_fwd: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ar.off);
   const int fprec = m->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;   // small GEMMs: ~fp32 accuracy
-  if (int r = layernorm_fwd(st, X, R, E, m->ln_w, m->ln_b, w.xn, w.mean, w.rstd)) return r;
-  if (int r = layernorm_fwd(st, m->q_param, k, E, m->ln_w, m->ln_b, w.gq, w.gmean, w.grstd)) return r;
+  const bool pre_ok = E % 4 == 0 && E <= 1024 && k * E * 4 <= 64 * 1024 && aligned16(m->wq) && aligned16(w.gq);
+  if (pre_ok) {
+    int nbx = (int)cdiv(R, 4);
+    if (nbx > 512) nbx = 512;
+    static bool attr = false;
+    if (!attr) {
+      MHIMX_HIP(hipFuncSetAttribute((const void*)mca_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(mca_pre_kernel, dim3((unsigned)(nbx + cdiv(I, MCA_PRE_COLS))), dim3(256), (size_t)(k * E * 4), st, X, R, (int)E, m->ln_w, m->ln_b,
+                       w.xn, w.mean, w.rstd, m->q_param, (int)k, w.gq, w.gmean, w.grstd, m->wq, (int)I, w.Q, nbx);
+    MHIMX_LAUNCH_CHECK();
+  } else {
+    if (int r = layernorm_fwd(st, X, R, E, m->ln_w, m->ln_b, w.xn, w.mean, w.rstd)) return r;
+    if (int r = layernorm_fwd(st, m->q_param, k, E, m->ln_w, m->ln_b, w.gq, w.gmean, w.grstd)) return r;
+  }
   mhimx_gemm_nt_args g = {};
   g.A = w.xn; g.lda = E; g.B = m->wkv; g.ldb = E; g.C = w.KV; g.ldc = 2 * I; g.M = R; g.N = 2 * I; g.K = E; g.prec = fprec;
   g.ws = w.nt_ws; g.ws_floats = w.nt_ws_floats;
   if (int r = gemm_nt(st, g)) return r;
-  g = {};
-  g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
-  if (int r = gemm_nt(st, g)) return r;
+  if (!pre_ok) {
+    g = {};
+    g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
+    if (int r = gemm_nt(st, g)) return r;
+  }
   const float scale = 1.0f / sqrtf((float)m->dim_head);
   if (int r = dispatch_kq(k, [&](auto kqc) {
         constexpr int KQ = decltype(kqc)::value;
@@ -515,10 +607,9 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   mhimx_gemm_tn_args t = {};
   t.A = w.dz0; t.lda = E; t.B = w.O; t.ldb = I; t.C = gr->d_wo; t.ldc = I; t.M = k; t.K1 = E; t.K2 = I; t.splits = 1;
   t.accumulate = acc; t.prec = gprec;
-  if (int r = gemm_tn(st, t)) return r;
   mhimx_gemm_nt_args g = {};
   g.A = w.dz0; g.lda = E; g.B = m->wo_t; g.ldb = E; g.C = w.dO; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = gprec;
-  if (int r = gemm_nt(st, g)) return r;
+  if (int r = skinny_pair(st, t, g)) return r;                    // d_wo = dz0^T O  and  dO = dz0 Wo: one launch
   // attention
   const float scale = 1.0f / sqrtf((float)m->dim_head);
   if (int r = dispatch_kq(k, [&](auto kqc) {
@@ -545,13 +636,19 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   t = {};
   t.A = w.dQ; t.lda = I; t.B = w.gq; t.ldb = E; t.C = gr->d_wq; t.ldc = E; t.M = k; t.K1 = I; t.K2 = E; t.splits = 1;
   t.accumulate = acc; t.prec = gprec;
-  if (int r = gemm_tn(st, t)) return r;
   g = {};
   g.A = w.dQ; g.lda = I; g.B = m->wq_t; g.ldb = I; g.C = w.dgq; g.ldc = E; g.M = k; g.N = E; g.K = I; g.prec = gprec;
-  if (int r = gemm_nt(st, g)) return r;
+  if (int r = skinny_pair(st, t, g)) return r;                    // d_wq = dQ^T LN(q)  and  d LN(q) = dQ Wq: one launch
   // LayerNorm: rows (dX + weight grads), then the global queries (weight grads only; the queries are not trained)
-  if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256)) return r;
-  if (int r = layernorm_bwd(st, w.dgq, m->q_param, k, E, m->ln_w, w.gmean, w.grstd, nullptr, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, 1, 256)) return r;
+  if (R > 16) {                                  // the k query rows ride along as the last block of the row launch
+    if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256, w.dgq,
+                              m->q_param, w.gmean, w.grstd, k)) return r;
+  } else {
+    if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256, nullptr,
+                              nullptr, nullptr, nullptr, 0)) return r;
+    if (int r = layernorm_bwd(st, w.dgq, m->q_param, k, E, m->ln_w, w.gmean, w.grstd, nullptr, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, 1, 256,
+                              nullptr, nullptr, nullptr, nullptr, 0)) return r;
+  }
   return 0;
 }
 

@@ -348,18 +348,28 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_fwd_kernel(const float
   }
 }
 
+struct LnSeg2 { const float* dy; const float* x; const float* mean; const float* rstd; int64_t M; };
+
 // dx = rstd*(dy*w - mean(dy*w) - xhat*mean(dy*w*xhat)); per-block partial dw = sum dy*xhat, db = sum dy
 __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int E, const float* __restrict__ w,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-    float* __restrict__ dw_part, float* __restrict__ db_part, int direct_accumulate /* -1: partial rows; 0/1: one block writes d_w, d_b */) {
+    float* __restrict__ dw_part, float* __restrict__ db_part, int direct_accumulate /* -1: partial rows; 0/1: one block writes d_w, d_b */,
+    LnSeg2 s2) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dw, [4][E] db
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int MAXQ = 16;                    // E <= 1024
   float dwa[MAXQ], dba[MAXQ];
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) dwa[q] = dba[q] = 0.f;
-  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+  // a second row set that shares the weight (the k global queries of Merge; weight gradients only) rides along as the
+  // LAST block of the launch instead of as a launch of its own
+  int64_t nblk = gridDim.x, first = blockIdx.x;
+  if (s2.M > 0) {
+    if (blockIdx.x == gridDim.x - 1) { dy = s2.dy; x = s2.x; mean = s2.mean; rstd = s2.rstd; M = s2.M; dx = nullptr; nblk = 1; first = 0; }
+    else nblk = gridDim.x - 1;
+  }
+  for (int64_t n = first * 4 + wave; n < M; n += nblk * 4) {
     const float mu = mean[n], rs = rstd[n];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -749,9 +759,21 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 // partials: dw_part/db_part [grid][E] scratch; d_w/d_b (+)= reduced
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
-                  int max_parts) {
+                  int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
+  if (M2 > 0 && M > 16) {                   // rows + a few extra rows (weight gradients only) in one launch
+    int grid = (int)cdiv(M, 4);
+    if (grid > max_parts - 1) grid = max_parts - 1;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid + 1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
+                       w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{dy2, x2, mean2, rstd2, M2});
+    MHIMX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(E, 32), 2), dim3(RP_THREADS), 0, st, dw_part, db_part, grid + 1, (int)E, (int)E,
+                       d_w, d_b, accumulate);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
+  MHIMX_CHECK_ARG(M2 == 0, "layernorm_bwd: the ride-along rows need a main segment of more than 16 rows");
   // one wave per row, 4 rows per block pass: the row loop is a latency chain, so use as many blocks as the partial
   // workspace (max_parts rows of dw / db partials) allows
   int grid = (int)cdiv(M, 4);
@@ -759,12 +781,12 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   if (grid > max_parts) grid = max_parts;
   if (M <= 16) {                            // a few rows (the k global queries): ONE block writes d_w / d_b itself
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E, w, mean,
-                       rstd, dx, d_w, d_b, accumulate ? 1 : 0);
+                       rstd, dx, d_w, d_b, accumulate ? 1 : 0, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0});
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                     w, mean, rstd, dx, dw_part, db_part, -1);
+                     w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0});
   MHIMX_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(E, 32), 2), dim3(RP_THREADS), 0, st, dw_part, db_part, grid, (int)E, (int)E,
                      d_w, d_b, accumulate);
@@ -887,7 +909,8 @@ extern "C" int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int6
 extern "C" int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                                    const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws) {
   MHIMX_CHECK_ARG(dy && x && w && mean && rstd && d_w && d_b && ws, "layernorm_bwd: null args");
-  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate, 96);
+  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate, 96, nullptr, nullptr, nullptr,
+                       nullptr, 0);
 }
 extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {
   if (n <= 0) return 0;

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    SF_STAMP(2);
     // ---- 3. epilogue: acc[i] = U[row = 8*(i>>2) + 4*kg + (i&3)][n_col]
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -184,22 +185,26 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     z1 = z1 * scale + a1;
     m_run = m_new;
     SF_STAMP(4);
-    // ---- class projections of the rows (pseudo score): 8 lanes per row, 64 columns each
+    // ---- class projections of the rows (pseudo score): 8 lanes per row; lane `seg` takes the 16-byte groups seg, seg+8, ...
+    // (neighbouring lanes read neighbouring groups: no bank conflicts)
     if (wp) {
       const int r = tid >> 3, seg = tid & 7;
       const int64_t n = row0 + r;
-      const float* hr = Hs + r * SF_LD + 64 * seg;
+      const sf_f4* hr = reinterpret_cast<const sf_f4*>(Hs + r * SF_LD) + seg;
+      sf_f4 hv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hv[q] = hr[8 * q];
       for (int c = 0; c < C; ++c) {
-        const float* w = wps + c * SF_E + 64 * seg;
+        const sf_f4* w = reinterpret_cast<const sf_f4*>(wps + c * SF_E) + seg;
         float d = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const sf_f4 h = reinterpret_cast<const sf_f4*>(hr)[q], ww = reinterpret_cast<const sf_f4*>(w)[q];
-          d += h[0] * ww[0] + h[1] * ww[1] + h[2] * ww[2] + h[3] * ww[3];
+          const sf_f4 ww = w[8 * q];
+          d += hv[q][0] * ww[0] + hv[q][1] * ww[1] + hv[q][2] * ww[2] + hv[q][3] * ww[3];
         }
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
+        d += dpp_mov<0xB1, 0xf>(0.f, d);                      // lanes ^1
+        d += dpp_mov<0x4E, 0xf>(0.f, d);                      // lanes ^2
+        d += dpp_mov<0x141, 0xf>(0.f, d);                     // row_half_mirror: the other quad of the 8
         if (seg == 0 && n < M) cproj[n * C + c] = d;
       }
     }

@@ -9,8 +9,11 @@ dev = "cuda"
 torch.manual_seed(0)
 M, E, A = 10000, 512, 128
 H = torch.randn(M, E, device=dev).abs()
-sc = ops.ScorerW(torch.randn(A, E, device=dev) * 0.05, torch.randn(1, A, device=dev) * 0.1, L.ACT["tanh"], ba=torch.zeros(A, device=dev),
-                 bc=torch.zeros(1, device=dev), prec="bf16x3")
+wa = torch.randn(A, E, device=dev) * 0.05
+frag = torch.empty_like(wa)
+ops.prep_batch([(ops.PREP_FRAG, wa, frag)])
+sc = ops.ScorerW(wa, torch.randn(1, A, device=dev) * 0.1, L.ACT["tanh"], ba=torch.zeros(A, device=dev),
+                 bc=torch.zeros(1, device=dev), prec="bf16x3", wa_frag=frag)
 wp = torch.randn(2, E, device=dev) * 0.05
 lib = L.lib()
 lib.mhimx_sf_prof_read.argtypes = [C.c_void_p]
