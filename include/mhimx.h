@@ -82,6 +82,22 @@ int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float alpha, int32_
 int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* args, int32_t batch, int64_t strideA,
                        int64_t strideB, int64_t strideC, float alpha, int32_t splits, float* ws);
 
+/* Deferred final reductions.  Weight / bias gradients are consumed only by the optimizer, so the last stage of their
+ * two-stage reductions (summing split-GEMM slabs, summing per-block column partials) need not run where it is produced:
+ * a producer given a list appends a job instead of launching its reduce kernel, and mhimx_reduce_flush runs every pending
+ * job in ONE launch (each tiny launch is ~5 us on the step's serial chain; a train step has six of these).  The partial
+ * buffers (workspaces passed to the producers) must stay untouched until the flush.
+ *   kind 0: out[j] (+)= sum_{b<G} parts[b*ld + j], j < W        (per-block column partials)
+ *   kind 1: out[i*ldo + j] (+)= sum_{z<G} parts[z*K1*K2 + i*K2 + j]   (split-GEMM slabs) */
+typedef struct {
+  int32_t kind; int32_t accumulate;
+  const float* parts; float* out;
+  int64_t G, W, ld, K1, K2, ldo;
+} mhimx_reduce_job;
+#define MHIMX_REDUCE_MAX 16
+typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; } mhimx_reduce_list;
+int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list);      /* no-op when list->n == 0; list->n = 0 on return */
+
 /* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over
  * `splits` slabs: ws must hold splits*K1*K2 floats when splits>1 (deterministic two-stage reduction).
  * accumulate: C += result.   replaces: autograd of every nn.Linear weight on the path. */
@@ -94,6 +110,7 @@ typedef struct {
   int32_t accumulate;
   int32_t prec;
   int64_t ws_floats;                                     /* capacity of ws; the library may raise `splits` up to it   */
+  mhimx_reduce_list* defer;                              /* optional: queue the slab reduction instead of launching it */
 } mhimx_gemm_tn_args;
 int mhimx_gemm_tn(void* stream, const mhimx_gemm_tn_args* a);
 
@@ -160,6 +177,7 @@ typedef struct {
   const float* wa_t; const float* wb_t;
   int32_t accumulate;
   int32_t splits;
+  mhimx_reduce_list* defer;           /* optional: queue the d_wa / d_wc / d_bc final reductions                 */
 } mhimx_pool_grad;
 int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* g);
 
@@ -282,6 +300,7 @@ int mhimx_merge_fwd(void* stream, const mhimx_merge* m, const float* X, int64_t 
 typedef struct {
   float* d_ln_w; float* d_ln_b; float* d_wkv; float* d_wq; float* d_wo; float* d_bo;
   int32_t accumulate; int32_t splits;
+  mhimx_reduce_list* defer;           /* optional: queue the d_ln_w / d_ln_b / d_wkv final reductions            */
 } mhimx_merge_grad;
 /* dz[k,E] -> dX[R,E] (overwritten) and parameter gradients. */
 int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX,
@@ -299,7 +318,7 @@ int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int
 /* dH *= dact in place (dact from mhimx_gemm_nt's `dact` output) and colsum_out[e] (+)= sum_m dH[m,e]: the backward
  * through activation + dropout and the bias gradient in one streaming pass.  ws: 1024*E floats. */
 int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,
-                     void* ws, int64_t ws_bytes);
+                     void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
 /* out[e] (+)= sum_m X[m,e] */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);

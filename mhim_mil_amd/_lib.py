@@ -41,13 +41,26 @@ class PrepJob(C.Structure):
     _fields_ = [("kind", C.c_int32), ("inp", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64), ("C", C.c_int64)]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("accumulate", C.c_int32), ("parts", c_f32p), ("out", c_f32p),
+                ("G", C.c_int64), ("W", C.c_int64), ("ld", C.c_int64), ("K1", C.c_int64), ("K2", C.c_int64), ("ldo", C.c_int64)]
+
+
+REDUCE_MAX = 16
+
+
+class ReduceListC(C.Structure):
+    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32)]
+
+
 class GemmTN(C.Structure):
     _fields_ = [("A", c_f32p), ("lda", C.c_int64),
                 ("B", c_f32p), ("ldb", C.c_int64), ("rows", c_i64p),
                 ("C", c_f32p), ("ldc", C.c_int64),
                 ("M", C.c_int64), ("K1", C.c_int64), ("K2", C.c_int64),
                 ("splits", C.c_int32), ("ws", c_f32p),
-                ("accumulate", C.c_int32), ("prec", C.c_int32), ("ws_floats", C.c_int64)]
+                ("accumulate", C.c_int32), ("prec", C.c_int32), ("ws_floats", C.c_int64),
+                ("defer", C.c_void_p)]
 
 
 class Scorer(C.Structure):
@@ -67,7 +80,7 @@ class PoolGrad(C.Structure):
     _fields_ = [("g_z", c_f32p), ("dT1", c_f32p), ("dT2", c_f32p),
                 ("d_wa", c_f32p), ("d_ba", c_f32p), ("d_wb", c_f32p), ("d_bb", c_f32p), ("d_wc", c_f32p),
                 ("d_bc", c_f32p), ("wa_t", c_f32p), ("wb_t", c_f32p),
-                ("accumulate", C.c_int32), ("splits", C.c_int32)]
+                ("accumulate", C.c_int32), ("splits", C.c_int32), ("defer", C.c_void_p)]
 
 
 class Merge(C.Structure):
@@ -80,7 +93,7 @@ class Merge(C.Structure):
 
 class MergeGrad(C.Structure):
     _fields_ = [("d_ln_w", c_f32p), ("d_ln_b", c_f32p), ("d_wkv", c_f32p), ("d_wq", c_f32p), ("d_wo", c_f32p),
-                ("d_bo", c_f32p), ("accumulate", C.c_int32), ("splits", C.c_int32)]
+                ("d_bo", c_f32p), ("accumulate", C.c_int32), ("splits", C.c_int32), ("defer", C.c_void_p)]
 
 
 # symbol -> (restype, argtypes); every symbol include/mhimx.h declares must be listed here
@@ -119,7 +132,8 @@ SYMBOLS = {
     "mhimx_colmax": (C.c_int, [_P, _P, _I64, _I64, _P, _P]),
     "mhimx_rowmax": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
-    "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64]),
+    "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
+    "mhimx_reduce_flush": (C.c_int, [_P, _P]),
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P, _P, _I64]),

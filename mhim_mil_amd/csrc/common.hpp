@@ -35,6 +35,22 @@ const std::string& last_error();
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+// queue a final reduction on the caller's list (mhimx_reduce_flush runs it); false: no list / list full -> launch it now
+inline bool defer_push(mhimx_reduce_list* l, const mhimx_reduce_job& j) {
+  if (!l || l->n >= MHIMX_REDUCE_MAX) return false;
+  l->j[l->n++] = j;
+  return true;
+}
+inline mhimx_reduce_job reduce_job_parts(const float* parts, int64_t G, int64_t W, int64_t ld, float* out, int accumulate) {
+  mhimx_reduce_job j = {};
+  j.kind = 0; j.accumulate = accumulate; j.parts = parts; j.out = out; j.G = G; j.W = W; j.ld = ld;
+  return j;
+}
+inline mhimx_reduce_job reduce_job_slabs(const float* ws, int64_t splits, int64_t K1, int64_t K2, int64_t ldo, float* out, int accumulate) {
+  mhimx_reduce_job j = {};
+  j.kind = 1; j.accumulate = accumulate; j.parts = ws; j.out = out; j.G = splits; j.K1 = K1; j.K2 = K2; j.ldo = ldo;
+  return j;
+}
 
 // bump allocator over a caller-provided workspace (256-byte granules)
 struct Arena {

@@ -493,7 +493,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
     const int used = gemm_tn_dma(st, g, avail);
     if (used == -2) goto generic;         // reduction too long for the LDS row table with this much workspace
     if (used < 0) return used;
-    if (used > 1) {
+    if (used > 1 && !defer_push(g.defer, reduce_job_slabs(g.ws, used, g.K1, g.K2, g.ldc, g.C, g.accumulate))) {
       const int64_t n = g.K1 * g.K2;
       const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, used, g.accumulate);

@@ -14,7 +14,8 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y, float* mean, float* rstd);
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
-                  int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2);
+                  int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
+                  mhimx_reduce_list* defer);
 int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g);
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes);
 
@@ -632,6 +633,7 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   t = {};
   t.A = w.dKV; t.lda = 2 * I; t.B = w.xn; t.ldb = E; t.C = gr->d_wkv; t.ldc = E; t.M = R; t.K1 = 2 * I; t.K2 = E;
   t.splits = 1; t.ws = w.scratch; t.ws_floats = w.scratch_bytes / 4; t.accumulate = acc; t.prec = gprec;
+  t.defer = gr->defer;                           // nothing else uses the scratch slabs before the flush
   if (int r = gemm_tn(st, t)) return r;
   t = {};
   t.A = w.dQ; t.lda = I; t.B = w.gq; t.ldb = E; t.C = gr->d_wq; t.ldc = E; t.M = k; t.K1 = I; t.K2 = E; t.splits = 1;
@@ -642,12 +644,12 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   // LayerNorm: rows (dX + weight grads), then the global queries (weight grads only; the queries are not trained)
   if (R > 16) {                                  // the k query rows ride along as the last block of the row launch
     if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256, w.dgq,
-                              m->q_param, w.gmean, w.grstd, k)) return r;
+                              m->q_param, w.gmean, w.grstd, k, gr->defer)) return r;
   } else {
     if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256, nullptr,
-                              nullptr, nullptr, nullptr, 0)) return r;
+                              nullptr, nullptr, nullptr, 0, nullptr)) return r;
     if (int r = layernorm_bwd(st, w.dgq, m->q_param, k, E, m->ln_w, w.gmean, w.grstd, nullptr, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, 1, 256,
-                              nullptr, nullptr, nullptr, nullptr, 0)) return r;
+                              nullptr, nullptr, nullptr, nullptr, 0, nullptr)) return r;
   }
   return 0;
 }

@@ -253,6 +253,53 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
   }
 }
 
+// every queued final reduction of a step in one launch (mhimx_reduce_flush): job jb owns blocks [first[jb], first[jb+1]).
+// Same arithmetic as reduce_parts_kernel (kind 0) and reduce_slabs_kernel (kind 1): queued or not, the bits are the same.
+struct ReduceJobs { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int first[MHIMX_REDUCE_MAX + 1]; int n; };
+__global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj) {
+  __shared__ float red[32][33];
+  int jb = 0;
+  while (jb + 1 < rj.n && (int)blockIdx.x >= rj.first[jb + 1]) ++jb;
+  const mhimx_reduce_job J = rj.j[jb];
+  const int blk = (int)blockIdx.x - rj.first[jb], nblk = rj.first[jb + 1] - rj.first[jb];
+  if (J.kind == 0) {
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    for (int64_t j0 = (int64_t)blk * 32; j0 < J.W; j0 += (int64_t)nblk * 32) {
+      const int64_t j = j0 + c;
+      float acc = 0.f;
+      if (j < J.W) {
+#pragma unroll 4
+        for (int64_t b = rg; b < J.G; b += 32) acc += J.parts[b * J.ld + j];
+      }
+      red[rg][c] = acc;
+      __syncthreads();
+      if (rg == 0 && j < J.W) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v += red[q][c];
+        J.out[j] = J.accumulate ? J.out[j] + v : v;
+      }
+      __syncthreads();
+    }
+  } else {
+    const int64_t n = J.K1 * J.K2;
+    for (int64_t idx = (int64_t)blk * RP_THREADS + threadIdx.x; idx < n; idx += (int64_t)nblk * RP_THREADS) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int64_t z = 0;
+      for (; z + 4 <= J.G; z += 4) {
+        s0 += J.parts[(z + 0) * n + idx];
+        s1 += J.parts[(z + 1) * n + idx];
+        s2 += J.parts[(z + 2) * n + idx];
+        s3 += J.parts[(z + 3) * n + idx];
+      }
+      for (; z < J.G; ++z) s0 += J.parts[z * n + idx];
+      const float v = (s0 + s1) + (s2 + s3);
+      float* p = J.out + (idx / J.K2) * J.ldo + (idx % J.K2);
+      *p = J.accumulate ? *p + v : v;
+    }
+  }
+}
+
 // two independent partial sets in one launch (blockIdx.y selects): LayerNorm's d_w and d_b
 __global__ __launch_bounds__(RP_THREADS) void reduce_parts2_kernel(const float* __restrict__ part0, const float* __restrict__ part1,
                                                                     int G, int W, int ld, float* __restrict__ out0,
@@ -692,10 +739,12 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(RP_THREADS), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
+  if (!defer_push(gr->defer, reduce_job_parts(w.dwc_part, G, A, A, gr->d_wc, gr->accumulate)))
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(A, 32)), dim3(RP_THREADS), 0, st, w.dwc_part, G, (int)A, (int)A, gr->d_wc, gr->accumulate);
   MHIMX_LAUNCH_CHECK();
   if (gr->d_bc) {
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(RP_THREADS), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
+    if (!defer_push(gr->defer, reduce_job_parts(w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate)))
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(RP_THREADS), 0, st, w.dbc_part, G, 1, 1, gr->d_bc, gr->accumulate);
     MHIMX_LAUNCH_CHECK();
   }
   off = 0;
@@ -720,6 +769,7 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     if (splits > TN_SLABS) splits = TN_SLABS;
     if (Ms[seg] < 2048) splits = 1;
     t.splits = splits; t.ws = w.tn_ws; t.ws_floats = (int64_t)TN_SLABS * A * E;
+    t.defer = (io->M2 == 0 && !gated) ? gr->defer : nullptr;        // one GEMM per workspace: its slabs may wait for the flush
     if (int r = gemm_tn(st, t)) return r;
     if (gated) {
       t.A = w.du + off * ldu + A; t.C = gr->d_wb;
@@ -759,7 +809,8 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 // partials: dw_part/db_part [grid][E] scratch; d_w/d_b (+)= reduced
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
-                  int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2) {
+                  int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
+                  mhimx_reduce_list* defer) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
   if (M2 > 0 && M > 16) {                   // rows + a few extra rows (weight gradients only) in one launch
@@ -768,6 +819,11 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid + 1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
                        w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{dy2, x2, mean2, rstd2, M2});
     MHIMX_LAUNCH_CHECK();
+    if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
+      defer_push(defer, reduce_job_parts(dw_part, grid + 1, E, E, d_w, accumulate));
+      defer_push(defer, reduce_job_parts(db_part, grid + 1, E, E, d_b, accumulate));
+      return 0;
+    }
     hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(E, 32), 2), dim3(RP_THREADS), 0, st, dw_part, db_part, grid + 1, (int)E, (int)E,
                        d_w, d_b, accumulate);
     MHIMX_LAUNCH_CHECK();
@@ -788,8 +844,35 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
                      w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0});
   MHIMX_LAUNCH_CHECK();
+  if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
+    defer_push(defer, reduce_job_parts(dw_part, grid, E, E, d_w, accumulate));
+    defer_push(defer, reduce_job_parts(db_part, grid, E, E, d_b, accumulate));
+    return 0;
+  }
   hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(E, 32), 2), dim3(RP_THREADS), 0, st, dw_part, db_part, grid, (int)E, (int)E,
                      d_w, d_b, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
+  MHIMX_CHECK_ARG(list && list->n >= 0 && list->n <= MHIMX_REDUCE_MAX, "reduce_flush: bad list");
+  if (list->n == 0) return 0;
+  ReduceJobs rj;
+  rj.n = list->n;
+  int first = 0;
+  for (int i = 0; i < list->n; ++i) {
+    const mhimx_reduce_job& j = list->j[i];
+    MHIMX_CHECK_ARG(j.parts && j.out && j.G > 0 && (j.kind == 0 ? j.W > 0 : (j.kind == 1 && j.K1 > 0 && j.K2 > 0)), "reduce_flush: bad job %d", i);
+    rj.j[i] = j;
+    rj.first[i] = first;
+    int64_t nb = j.kind == 0 ? cdiv(j.W, 32) : cdiv(j.K1 * j.K2, RP_THREADS);
+    if (nb > 512) nb = 512;
+    first += (int)nb;
+  }
+  rj.first[list->n] = first;
+  list->n = 0;
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)first), dim3(RP_THREADS), 0, st, rj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -878,7 +961,7 @@ extern "C" int mhimx_rowmax(void* stream, const float* x, int64_t M, int64_t C, 
   return 0;
 }
 extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,
-                                void* ws, int64_t ws_bytes) {
+                                void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
   MHIMX_CHECK_ARG(dH && dact && E % 4 == 0 && aligned16(dH) && aligned16(dact), "mul_colsum: bad args");
   if (M <= 0) return 0;
   int64_t nblk = cdiv(M, 8);
@@ -889,13 +972,14 @@ extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int6
   hipLaunchKernelGGL(mul_colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dH, dact, M, (int)E, chunk,
                      colsum_out ? (float*)ws : nullptr);
   MHIMX_LAUNCH_CHECK();
-  if (colsum_out) {
+  if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, (hipStream_t)stream, (const float*)ws, (int)nblk,
                        (int)E, (int)E, colsum_out, accumulate);
     MHIMX_LAUNCH_CHECK();
   }
   return 0;
 }
+extern "C" int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list) { return reduce_flush((hipStream_t)stream, list); }
 extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate, void* ws,
                             int64_t ws_bytes) {
   return colsum((hipStream_t)stream, X, M, E, out, accumulate, ws, ws_bytes);
@@ -910,7 +994,7 @@ extern "C" int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x
                                    const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws) {
   MHIMX_CHECK_ARG(dy && x && w && mean && rstd && d_w && d_b && ws, "layernorm_bwd: null args");
   return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate, 96, nullptr, nullptr, nullptr,
-                       nullptr, 0);
+                       nullptr, 0, nullptr);
 }
 extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {
   if (n <= 0) return 0;

@@ -173,6 +173,7 @@ class FusedTrainer:
         # Adam step count live in HBM and are advanced by one-thread kernels that are part of the captured step
         self.tick = torch.zeros(1, dtype=torch.int64, device=dev)
         self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._defer = ops.ReduceList()                 # final gradient reductions of a step, flushed as one launch
         student._tick = self.tick
         if teacher is not None:
             teacher._tick = self.tick
@@ -238,7 +239,9 @@ class FusedTrainer:
                 main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
                 d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
             if first:
-                s._bag_backward(x, plan, saved, g_z, out=gv)
+                # the six final gradient reductions of the backward (slab sums, column partials) run as ONE launch
+                s._bag_backward(x, plan, saved, g_z, out=gv, defer=self._defer)
+                ops.reduce_flush(self._defer)
             else:                                   # gradient accumulation: fresh buffers, then add (rare path)
                 g = s._bag_backward(x, plan, saved, g_z)
                 for n, v in g.items():

@@ -425,8 +425,10 @@ class MHIM(nn.Module):
         saved["pool"] = st
         return st.z, saved
 
-    def _bag_backward(self, x, plan: BagPlan, saved, g_z, out=None):
-        """Returns {param name: gradient}.  ``out`` may map names to preallocated (flat-buffer) views to fill."""
+    def _bag_backward(self, x, plan: BagPlan, saved, g_z, out=None, defer=None):
+        """Returns {param name: gradient}.  ``out`` may map names to preallocated (flat-buffer) views to fill.  ``defer``
+        (ops.ReduceList): the final stages of the weight / bias gradient reductions are queued on it; the caller runs
+        ``ops.reduce_flush`` before reading any gradient."""
         out = out or {}
         E = self.mlp_dim
         dev = x.device
@@ -454,7 +456,7 @@ class MHIM(nn.Module):
             grads["online_encoder.attention.attention_c.weight"] = g["d_wc"]
         else:
             g = ops.abmil_pool_bwd(sc, st, g_z, prep.get("wa_t") if "wa_t" in prep else ops.transpose(att.attention[0].weight.data),
-                                   grads=pool_g)
+                                   grads=pool_g, defer=defer)
             grads["online_encoder.attention.attention.0.weight"] = g["d_wa"]
             grads["online_encoder.attention.attention.2.weight"] = g["d_wc"]
         if self.merge_enable and plan.R > 0:
@@ -467,19 +469,20 @@ class MHIM(nn.Module):
                             ("d_bo", "merge.attn.to_out.0.bias")):
                 if nm in out:
                     mgr[key] = out[nm]
-            mg = ops.merge_bwd(mw, H[:plan.R] if mf else H[plan.Lk:], dHbuf[plan.L:] if mf else g["dT2"], saved["mws"], grads=mgr)
+            mg = ops.merge_bwd(mw, H[:plan.R] if mf else H[plan.Lk:], dHbuf[plan.L:] if mf else g["dT2"], saved["mws"], grads=mgr,
+                               defer=defer)
             grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
             grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
         p = self.dropout_p if plan.training else 0.0
         if saved.get("DACT") is not None:
-            _, db1 = ops.mul_colsum(dH, saved["DACT"], colsum_out=out.get("feature.0.bias"))
+            _, db1 = ops.mul_colsum(dH, saved["DACT"], colsum_out=out.get("feature.0.bias"), defer=defer)
         else:
             _, db1 = ops.act_bwd(dH, H, PRE, L.act_code(self.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
                                  colsum_out=out.get("feature.0.bias"), want_colsum=True, drop_tick=self._tick)
         splits = 8 if plan.L >= 2048 else 1
         grads["feature.0.weight"] = ops.gemm_tn(dH, x, out=out.get("feature.0.weight"), rows=plan.rows, splits=splits,
-                                                prec="f32" if self.prec == "f32" else "bf16x3", M=plan.L)
+                                                prec="f32" if self.prec == "f32" else "bf16x3", M=plan.L, defer=defer)
         grads["feature.0.bias"] = db1
         return grads
 

@@ -98,7 +98,30 @@ def pair_planes(x):
     return out
 
 
-def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3", M=None):
+class ReduceList:
+    """Deferred final reductions of one step (mhimx_reduce_list): producers given ``defer=lst`` queue the last stage of their
+    gradient reductions instead of launching it; ``reduce_flush(lst)`` runs all of them in one launch.  The object keeps
+    the partial buffers alive until the flush (a captured graph's allocator would otherwise hand them to a later tensor)."""
+
+    def __init__(self):
+        self.c = L.ReduceListC()
+        self.c.n = 0
+        self.keep = []
+
+    def ptr(self):
+        return C.addressof(self.c)
+
+
+def _dp(defer):
+    return None if defer is None else defer.ptr()
+
+
+def reduce_flush(lst: "ReduceList"):
+    L.check(L.lib().mhimx_reduce_flush(_stream(), lst.ptr()), "mhimx_reduce_flush")
+    lst.keep.clear()
+
+
+def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3", M=None, defer=None):
     """out[i,j] = sum_m a[m,i] * b[rows[m] or m, j] — see mhimx_gemm_tn."""
     _chk(a, name="a"); _chk(b, name="b"); _chk(out, name="out"); _chk(rows, torch.int64, "rows")
     if M is None:
@@ -112,8 +135,10 @@ def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3"
     ws = torch.empty((nslab, K1, K2), device=a.device, dtype=torch.float32) if nslab > 1 else None
     g = L.GemmTN(A=_p(a), lda=a.stride(0), B=_p(b), ldb=b.stride(0), rows=_p(rows), C=_p(out), ldc=out.stride(0), M=M,
                  K1=K1, K2=K2, splits=int(splits), ws=_p(ws), accumulate=int(bool(accumulate)), prec=prec_code(prec),
-                 ws_floats=0 if ws is None else ws.numel())
+                 ws_floats=0 if ws is None else ws.numel(), defer=_dp(defer))
     L.check(L.lib().mhimx_gemm_tn(_stream(), C.byref(g)), "mhimx_gemm_tn")
+    if defer is not None:
+        defer.keep.append(ws)
     return out
 
 
@@ -176,7 +201,7 @@ def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None):
 
 
 def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=False, splits=8, grads=None,
-                   accumulate=False):
+                   accumulate=False, defer=None):
     """Backward of the pool.  Returns dict(dT1, dT2, d_wa, d_wc, [d_wb, d_ba, d_bb, d_bc])."""
     dev = g_z.device
     E, A = sc.E, sc.A
@@ -196,7 +221,9 @@ def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=F
     io = st.io(sc)
     g = L.PoolGrad(g_z=_p(g_z), dT1=_p(out["dT1"]), dT2=_p(out.get("dT2")), d_wa=_p(out["d_wa"]), d_ba=_p(out.get("d_ba")),
                    d_wb=_p(out.get("d_wb")), d_bb=_p(out.get("d_bb")), d_wc=_p(out["d_wc"]), d_bc=_p(out.get("d_bc")),
-                   wa_t=_p(wa_t), wb_t=_p(wb_t), accumulate=int(bool(accumulate)), splits=int(splits))
+                   wa_t=_p(wa_t), wb_t=_p(wb_t), accumulate=int(bool(accumulate)), splits=int(splits), defer=_dp(defer))
+    if defer is not None:
+        defer.keep.append(st)
     L.check(L.lib().mhimx_abmil_pool_bwd(_stream(), C.byref(sc.c), C.byref(io), C.byref(g)), "mhimx_abmil_pool_bwd")
     return out
 
@@ -306,7 +333,7 @@ def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
     return z, q_new, ws
 
 
-def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False):
+def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False, defer=None):
     dev = X.device
     R, E = X.shape
     I = mw.heads * mw.dim_head
@@ -319,7 +346,10 @@ def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False):
     out.setdefault("d_wo", torch.empty((E, I), device=dev))
     out.setdefault("d_bo", torch.empty(E, device=dev))
     g = L.MergeGrad(d_ln_w=_p(out["d_ln_w"]), d_ln_b=_p(out["d_ln_b"]), d_wkv=_p(out["d_wkv"]), d_wq=_p(out["d_wq"]),
-                    d_wo=_p(out["d_wo"]), d_bo=_p(out["d_bo"]), accumulate=int(bool(accumulate)), splits=int(splits))
+                    d_wo=_p(out["d_wo"]), d_bo=_p(out["d_bo"]), accumulate=int(bool(accumulate)), splits=int(splits),
+                    defer=_dp(defer))
+    if defer is not None:
+        defer.keep.append(ws)
     L.check(L.lib().mhimx_merge_bwd(_stream(), C.byref(mw.c), _p(X), R, _p(dz), _p(out["dX"]), C.byref(g), _p(ws),
                                     ws.numel()), "mhimx_merge_bwd")
     return out
@@ -339,7 +369,7 @@ def act_bwd(dH, H, pre, act, drop_p=0.0, drop_seed=0, drop_mask=None, rows=None,
     return (dH, colsum_out) if colsum_out is not None else dH
 
 
-def mul_colsum(dH, dact, colsum_out=None, want_colsum=True, accumulate=False):
+def mul_colsum(dH, dact, colsum_out=None, want_colsum=True, accumulate=False, defer=None):
     """dH *= dact in place; column sums of the result (the feature-bias gradient) in the same pass."""
     _chk(dH, name="dH"); _chk(dact, name="dact")
     M, E = dH.shape
@@ -347,7 +377,9 @@ def mul_colsum(dH, dact, colsum_out=None, want_colsum=True, accumulate=False):
         colsum_out = torch.empty(E, device=dH.device)
     ws = torch.empty(1024 * E, device=dH.device) if colsum_out is not None else None
     L.check(L.lib().mhimx_mul_colsum(_stream(), _p(dH), _p(dact), M, E, _p(colsum_out), int(bool(accumulate)), _p(ws),
-                                     0 if ws is None else ws.numel() * 4), "mhimx_mul_colsum")
+                                     0 if ws is None else ws.numel() * 4, _dp(defer)), "mhimx_mul_colsum")
+    if defer is not None:
+        defer.keep.append(ws)
     return dH, colsum_out
 
 

@@ -474,3 +474,24 @@ def test_fused_scorer_fragment_image(M):
     np.testing.assert_allclose(res[1][0].cpu().numpy(), s_ref.float().numpy(), atol=8e-5, rtol=4e-5)
     np.testing.assert_allclose(res[1][1].cpu().numpy(), z_ref.float().numpy(), atol=1.2e-5, rtol=4e-5)
     np.testing.assert_allclose(res[1][2].cpu().numpy(), (T.double() @ wp.double().t()).float().numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_deferred_reductions_match_immediate():
+    """mhimx_reduce_flush: a split TN GEMM and a column-sum pass with their final reductions queued and flushed in one
+    launch give the same bits as the immediate two-launch forms (accumulate on and off)."""
+    ops = _ops()
+    M, K1, K2 = 5000, 512, 1024
+    a, b = rnd(71, (M, K1)).to(DEV), rnd(72, (M, K2)).to(DEV)
+    dH, dact = rnd(73, (M, K1)).to(DEV), rnd(74, (M, K1)).abs().to(DEV)
+    for acc in (False, True):
+        base = rnd(75, (K1, K2)).to(DEV)
+        base_b = rnd(76, (K1,)).to(DEV)
+        ref = ops.gemm_tn(a, b, out=base.clone(), splits=8, accumulate=acc)
+        _, ref_b = ops.mul_colsum(dH.clone(), dact, colsum_out=base_b.clone(), accumulate=acc)
+        lst = ops.ReduceList()
+        got = ops.gemm_tn(a, b, out=base.clone(), splits=8, accumulate=acc, defer=lst)
+        _, got_b = ops.mul_colsum(dH.clone(), dact, colsum_out=base_b.clone(), accumulate=acc, defer=lst)
+        assert lst.c.n == 2
+        ops.reduce_flush(lst)
+        assert lst.c.n == 0 and not lst.keep
+        assert torch.equal(got, ref) and torch.equal(got_b, ref_b)
