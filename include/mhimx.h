@@ -126,7 +126,7 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  * 4 = matrix-core fragment image of in[R,C] (R % 32 == 0, C % 16 == 0; same size as in): for every 32-row block nt and
  *     16-column step ks, 64 consecutive 32-byte items (item l: 8 bf16 hi | 8 bf16 lo of in[32 nt + l % 32][16 ks + 8 (l / 32) ..])
  *     - what mhimx_scorer.wa_frag takes. */
-#define MHIMX_PREP_MAX 12
+#define MHIMX_PREP_MAX 16
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
 

@@ -585,7 +585,16 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
   }
-  hipLaunchKernelGGL(prep_batch_kernel, dim3(256, (unsigned)n), dim3(256), 0, st, pj);
+  // every job loop is grid-stride: size the launch for the largest job (the bag's paired-plane image streams ~80 MB and wants
+  // thousands of workgroups; the blocks of the small jobs beyond their work find nothing to do)
+  int64_t gx = 256;
+  for (int i = 0; i < n; ++i) {
+    const int64_t items = jobs[i].kind == 3 ? 1 : (jobs[i].kind == 0 ? cdiv(jobs[i].R, 32) * cdiv(jobs[i].C, 32) : jobs[i].R * jobs[i].C / 8);
+    const int64_t want = jobs[i].kind == 0 ? items : cdiv(items, 256);
+    if (want > gx) gx = want;
+  }
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(prep_batch_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, st, pj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

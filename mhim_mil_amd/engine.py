@@ -206,11 +206,15 @@ class FusedTrainer:
                 jobs += jt
             js, prep_s = s.prep_jobs(backward=True)
             jobs += js
+        # one bf16 hi/lo image of the bag for both projections: it depends on nothing either, so it rides in the same launch
+        xp = None
+        if s.baseline == "attn" and s._pairable(x):
+            xp = torch.empty_like(x)
+            jobs.append((ops.PREP_PAIR, x, xp))
         ops.prep_batch(jobs)
         ps = x.shape[0]
         first = self._micro == 0
         gv = fl.grad_views
-        xp = s._pair(x) if s.baseline == "attn" else None        # one bf16 hi/lo image of the bag for both projections
         if self.model_kind == "mhim":
             teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"],
                                                     wa_frag=None if prep_t is None else prep_t.get("wa_frag"))

@@ -343,9 +343,12 @@ class MHIM(nn.Module):
         """Paired-plane image of the bag (8 bf16 hi | 8 bf16 lo per 8 consecutive features), made ONCE per step and shared
         by every projection that streams X: the GEMM inner loop then has no fp32 -> bf16 conversion.  None when the
         projection does not run in the 3-term bf16 form or the shape is not tileable."""
-        if self._feature_prec(x.shape[0]) != "bf16x3" or x.shape[1] % 32 != 0 or x.shape[0] <= 16:
+        if not self._pairable(x):
             return None
         return ops.pair_planes(x)
+
+    def _pairable(self, x):
+        return self._feature_prec(x.shape[0]) == "bf16x3" and x.shape[1] % 32 == 0 and x.shape[0] > 16
 
     def _feature(self, x, rows=None, drop_p=0.0, drop_seed=0, drop_mask=None, want_pre=False, out=None, pre_out=None, M=None,
                  xp=None, w1p=None, dact=None):
