@@ -375,6 +375,18 @@ int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, f
 /* *counter += 1 (device-resident step counters for dropout streams / Adam under hipGraph replay) */
 int mhimx_tick(void* stream, uint64_t* counter);
 
+/* ------------------------------------------------------------------------------------------
+ * Validation metrics on the device                                   
+ * replaces: engines/metrics.py:125-159 (metrics_base: the torchmetrics collection), :104-123 (get_cls_metrics),
+ *           :35-78 (DeterministicBootStrapper: B resamples, mean / std taken by the caller)
+ * logits [n, C] (row pitch ld), labels [n] int64.  out [B, 7] = Acc (macro), AUC (macro one-vs-rest, exact ROC area),
+ * Precision, Recall, F1 (macro), Cohen kappa, Acc_micro.  bin_metric (C == 2): the binary task on logits[:, 1].
+ * Predictions not all inside [0,1] go through softmax / sigmoid first (torchmetrics' format rule), per resample.
+ * sample_idx [B, n] (NULL with B == 1): row ids of every bootstrap resample. */
+int64_t mhimx_cls_metrics_ws_bytes(int64_t n, int64_t C, int64_t B);
+int mhimx_cls_metrics(void* stream, const float* logits, int64_t ld, const int64_t* labels, int64_t n, int64_t C,
+                      int32_t bin_metric, const int64_t* sample_idx, int64_t B, float* out, void* ws, int64_t ws_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,8 @@ SYMBOLS = {
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "mhimx_reduce_flush": (C.c_int, [_P, _P]),
+    "mhimx_cls_metrics_ws_bytes": (C.c_int64, [_I64, _I64, _I64]),
+    "mhimx_cls_metrics": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I32, _P, _I64, _P, _P, _I64]),
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P, _P, _I64]),

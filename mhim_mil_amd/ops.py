@@ -421,3 +421,22 @@ def adam_ema(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999
 def tick(counter):
     """counter (uint64/int64 [1], device) += 1 on the current stream."""
     L.check(L.lib().mhimx_tick(_stream(), _p(counter)), "mhimx_tick")
+
+
+# ------------------------------------------------------------------------------------------------ validation metrics
+METRIC_KEYS = ("Acc", "AUC", "Precision", "Recall", "F1", "CK", "Acc_micro")
+
+
+def cls_metrics(logits, labels, n_classes, bin_metric=False, sample_idx=None):
+    """Device metrics of engines/metrics.py (mhimx_cls_metrics).  logits [n, C] fp32, labels [n] int64 -> out [B, 7] in the
+    order METRIC_KEYS; ``sample_idx`` [B, n] int64 evaluates B bootstrap resamples in the same launches (B = 1 without)."""
+    _chk(logits, name="logits"); _chk(labels, torch.int64, "labels"); _chk(sample_idx, torch.int64, "sample_idx")
+    n, Cc = logits.shape
+    if Cc != n_classes:
+        raise L.MhimxError(f"cls_metrics: logits have {Cc} columns, n_classes = {n_classes}")
+    B = 1 if sample_idx is None else sample_idx.shape[0]
+    out = torch.empty((B, 7), device=logits.device)
+    ws = torch.empty(L.lib().mhimx_cls_metrics_ws_bytes(n, Cc, B), device=logits.device, dtype=torch.uint8)
+    L.check(L.lib().mhimx_cls_metrics(_stream(), _p(logits), logits.stride(0), _p(labels), n, Cc, int(bool(bin_metric)), _p(sample_idx), B,
+                                      _p(out), _p(ws), ws.numel()), "mhimx_cls_metrics")
+    return out
