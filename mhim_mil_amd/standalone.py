@@ -1,0 +1,183 @@
+"""The standalone attention-MIL models of the reference's model factory on the MHIM path's kernels.
+
+``build_model`` mirrors the branches of modules/__init__.py:71-116 that share the hot path's kernels:
+
+    'mhim' / 'mhim_pure'  -> mhim.MHIM                     (modules/mhim.py)
+    'abmil'               -> DAttention                    (modules/abmil.py:145-251: biased scorer, tanh, classifier)
+    'gabmil'              -> AttentionGated                (modules/abmil.py:51-143: D = 384, tanh x sigmoid gate)
+
+Same parameter names and shapes as the reference modules (a reference checkpoint loads with ``load_state_dict``), the
+reference initialisation (xavier-normal weights, zero biases: abmil.py:8-21), and trainable through autograd: the
+embedding and the scorer + softmax pool are ``torch.autograd.Function``s over libmhimx.so (GEMM with fused bias /
+activation / counter-based dropout; mhimx_abmil_pool_fwd / _bwd with the bias gradients).  Supported configuration: the
+factory's defaults (``mil_norm=None``, ``pos=None``, ``embed_feat=True``); the gated scorer's inner dropouts
+(abmil.py:96-98, active only when ``dropout`` is set) are not fused into the scorer kernel: AttentionGated raises in
+training mode when ``dropout > 0``.  'transmil', CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import nystrom as NY
+from . import ops
+from .mhim import MHIM
+
+
+class _EmbedFn(torch.autograd.Function):
+    """H = dropout(act(x W^T + b)) in one GEMM launch; backward: act/dropout backward + bias column sums in one pass, then
+    dW = dPre^T x (the bag x is data: no input gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, drop_p, seed):
+        need_pre = act == L.ACT["gelu"]
+        pre = torch.empty((x.shape[0], w.shape[0]), device=x.device) if need_pre else None
+        H = ops.gemm_nt(x, w, bias=b, act=act, pre=pre, drop_p=drop_p, drop_seed=seed, prec="bf16x3")
+        ctx.save_for_backward(x, H, pre)
+        ctx.cfg = (act, drop_p, seed, b is not None)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        x, H, pre = ctx.saved_tensors
+        act, drop_p, seed, has_b = ctx.cfg
+        g = dH.contiguous().clone()
+        g, db = ops.act_bwd(g, H, pre, act, drop_p, seed, None, None, want_colsum=True)
+        dw = ops.gemm_tn(g, x, splits=8 if x.shape[0] >= 2048 else 1, prec="bf16x3")
+        return None, dw, (db if has_b else None), None, None, None
+
+
+class _PoolFn(torch.autograd.Function):
+    """z = softmax_n(scorer(T)) T  (mhimx_abmil_pool_fwd) with every scorer weight and bias trainable."""
+
+    @staticmethod
+    def forward(ctx, T, wa, ba, wc, bc, wb, bb, act):
+        T = T.contiguous()
+        sc = ops.ScorerW(wa, wc, act, ba=ba, wb=wb, bb=bb, bc=bc, prec="bf16x3")
+        st = ops.abmil_pool_fwd(sc, T)
+        ctx.sc, ctx.st = sc, st
+        ctx.gated = wb is not None
+        ctx.mark_non_differentiable(st.s, st.stats)
+        return st.z, st.s, st.stats
+
+    @staticmethod
+    def backward(ctx, g_z, _gs, _gst):
+        sc, st = ctx.sc, ctx.st
+        wa, wc, ba, wb, bb, bc = sc.t[:6]
+        g = ops.abmil_pool_bwd(sc, st, g_z.contiguous(), ops.transpose(wa), ops.transpose(wb) if ctx.gated else None,
+                               need_bias=ba is not None or bc is not None)
+        return (g["dT1"], g["d_wa"], g.get("d_ba") if ba is not None else None, g["d_wc"], g.get("d_bc") if bc is not None else None,
+                g.get("d_wb") if ctx.gated else None, g.get("d_bb") if (ctx.gated and bb is not None) else None, None)
+
+
+def _linear(i, o, bias=True):
+    m = nn.Linear(i, o, bias=bias)
+    nn.init.xavier_normal_(m.weight)                      # abmil.py:8-14
+    if m.bias is not None:
+        m.bias.data.zero_()
+    return m
+
+
+class _Slot(nn.Module):                                   # a parameter-free layer of the reference's nn.Sequential (keeps the indices)
+    pass
+
+
+class _AttnMILBase(nn.Module):
+    def _check(self, x):
+        if not x.is_cuda:
+            raise L.MhimxError("standalone MIL (mhimx): the bag must be a CUDA tensor; there is no CPU path")
+        if x.dim() == 3:
+            if x.shape[0] != 1:
+                raise L.MhimxError("one bag per call (batch_size = 1, as the reference trainer does)")
+            x = x[0]
+        return x.contiguous().float()
+
+    def _seed(self):
+        self._step = getattr(self, "_step", 0) + 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def _embed(self, x):
+        f = self.feature[0]
+        p = self.embed_drop if self.training else 0.0
+        return _EmbedFn.apply(x, f.weight, f.bias, L.ACT[self.act], float(p), self._seed())
+
+
+class DAttention(_AttnMILBase):
+    """modules/abmil.py:145-251."""
+
+    def __init__(self, input_dim, n_classes, dropout, act, mil_norm=None, mil_bias=True, mil_cls_bias=True, inner_dim=512,
+                 embed_feat=True, embed_norm_pos=0, pos=None, **kwargs):
+        super().__init__()
+        if mil_norm is not None or pos not in (None, "none") or not embed_feat:
+            raise L.MhimxError("DAttention (mhimx): only the factory defaults (mil_norm=None, pos=None, embed_feat=True) are built")
+        if mil_bias:
+            mil_cls_bias = True
+        self.L, self.D, self.K = inner_dim, 128, 1
+        self.act = "gelu" if act.lower() == "gelu" else "relu"
+        self.embed_drop = 0.25 if dropout else 0.0                          # abmil.py:190-191: a FIXED 0.25 when dropout is set
+        layers = [_linear(input_dim, inner_dim, mil_bias), _Slot()] + ([_Slot()] if dropout else [])
+        self.feature = nn.Sequential(*layers)
+        self.attention = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot(), _linear(self.D, self.K, mil_bias))
+        self.classifier = _linear(self.L * self.K, n_classes, mil_cls_bias)
+
+    def forward(self, x, return_attn=False, no_norm=False, return_act=False, pos=None, return_img_feat=False, **kwargs):
+        x = self._check(x)
+        H = self._embed(x)
+        a0, a2 = self.attention[0], self.attention[2]
+        z, s, stats = _PoolFn.apply(H, a0.weight, a0.bias, a2.weight, a2.bias, None, None, L.ACT["tanh"])
+        logits = NY.Linear.apply(z.view(1, -1), self.classifier.weight, self.classifier.bias, 0.0, 0, None)
+        out = [logits, z.view(1, -1).clone()] if return_img_feat else logits
+        if not return_attn:
+            return out
+        res = [out, ops.softmax_from_stats(s, stats).view(1, -1)]            # abmil.py:236-241 (always the normalised attention)
+        if return_act:
+            res.append(H)
+        return res
+
+
+class AttentionGated(_AttnMILBase):
+    """modules/abmil.py:51-143."""
+
+    def __init__(self, input_dim, n_classes, act="relu", dropout=0., mil_norm=None, mil_bias=True, mil_cls_bias=True, inner_dim=512,
+                 embed_feat=True, embed_norm_pos=0, pos=None, **kwargs):
+        super().__init__()
+        if mil_norm is not None:
+            raise L.MhimxError("AttentionGated (mhimx): only mil_norm=None is built")
+        self.L, self.D, self.K = inner_dim, 384, 1
+        self.act = act if act in ("gelu", "relu") else "none"
+        self.embed_drop = float(dropout)                                    # abmil.py:79: nn.Dropout(dropout)
+        self.scorer_drop = 0.25 if dropout else 0.0                         # abmil.py:96-98
+        self.feature = nn.Sequential(*([_linear(input_dim, inner_dim, mil_bias)] + ([_Slot()] if act in ("gelu", "relu") else []) + [_Slot()]))
+        self.attention_a = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot())
+        self.attention_b = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot())
+        self.attention_c = _linear(self.D, self.K, mil_bias)
+        self.classifier = nn.Sequential(_linear(self.L * self.K, n_classes, mil_bias))
+
+    def forward(self, x, **kwargs):
+        if self.training and self.scorer_drop > 0:
+            raise L.MhimxError("AttentionGated (mhimx): the dropouts inside the gated scorer (abmil.py:96-98) are not fused into the "
+                               "scorer kernel; train with dropout=0 or evaluate with model.eval()")
+        x = self._check(x)
+        H = self._embed(x)
+        a, b, c = self.attention_a[0], self.attention_b[0], self.attention_c
+        z, _, _ = _PoolFn.apply(H, a.weight, a.bias, c.weight, c.bias, b.weight, b.bias, L.ACT["tanh"])
+        cl = self.classifier[0]
+        return NY.Linear.apply(z.view(1, -1), cl.weight, cl.bias, 0.0, 0, None)
+
+
+def build_model(model_name, **params):
+    """The kernel-sharing branches of modules/__init__.py:71-116; ``params`` are the constructor arguments the reference's
+    factory assembles (``genera_model_params`` / the MHIM ``model_params``)."""
+    name = model_name.lower()
+    if name == "mhim":
+        return MHIM(**params)
+    if name == "mhim_pure":
+        params = dict(params)
+        params.update(select_mask=False, merge_enable=False)
+        return MHIM(**params)
+    if name == "abmil":
+        return DAttention(**params)
+    if name == "gabmil":
+        return AttentionGated(**params)
+    raise NotImplementedError(f"model {model_name!r}: not a branch of the MHIM / attention-MIL hot path (SURVEY.md §8)")

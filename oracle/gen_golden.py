@@ -429,6 +429,30 @@ def g13_dsmil(ns):
     _save("g13_dsmil", dict(seed=19, xseed=13000, n=n, d=d, label=1, aux_alpha=0.5, **cfg), **out)
 
 
+def g14_standalone_train(ns):
+    """Standalone abmil / gabmil (modules/abmil.py) in train mode, dropout off: logits, attention and every parameter
+    gradient of CE(logits, label) - fixtures for mhim_mil_amd/standalone.py."""
+    if ns.abmil is None:
+        print("  (modules/abmil.py not importable: skipped)")
+        return
+    n, d = 300, 64
+    x = _x(33, n, d)
+    for name, mod, pseed in (("abmil_gelu", ns.abmil.DAttention(d, 2, dropout=0.0, act="gelu"), 43),
+                             ("abmil_relu", ns.abmil.DAttention(d, 2, dropout=0.0, act="relu"), 44),
+                             ("gabmil_relu", ns.abmil.AttentionGated(d, 2, act="relu", dropout=0.), 45),
+                             ("gabmil_gelu", ns.abmil.AttentionGated(d, 2, act="gelu", dropout=0.), 46)):
+        m = _fill_module(mod, pseed).train()
+        out = m(x.clone(), return_attn=True) if name.startswith("abmil") else m(x.clone())
+        logits = out[0] if isinstance(out, (list, tuple)) else out
+        loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([1]))
+        loss.backward()
+        extra = {"attn": out[1][0].detach().numpy()} if isinstance(out, (list, tuple)) else {}
+        _save(f"g14_standalone_train_{name}", dict(n=n, d=d, xseed=33, pseed=pseed, std=0.05, label=1, kind=name.split("_")[0],
+                                                   act=name.split("_")[1], keys=list(m.state_dict().keys()),
+                                                   shapes=[list(v.shape) for v in m.state_dict().values()]),
+              logits=logits[0].detach().numpy(), loss=loss.item(), **extra, **_compact_all("grad", _grads(m)))
+
+
 def g12_cosine_scheduler(ns):
     """utils.cosine_scheduler (utils.py:199-210) for the two schedules the trainer builds (modules/__init__.py:72-75,177-181).
     utils.py imports the whole training stack, so only this function's AST node is compiled and run."""
@@ -448,8 +472,12 @@ def g12_cosine_scheduler(ns):
 def main():
     ns = _refimport.load()
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])                     # python -m oracle.gen_golden g14_standalone_train  -> just that family
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
-               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil):
+               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil,
+               g14_standalone_train):
+        if only and fn.__name__ not in only:
+            continue
         print(fn.__name__)
         fn(ns)
 

@@ -1,0 +1,87 @@
+"""Standalone abmil / gabmil models (mhim_mil_amd/standalone.py) against fixtures produced by
+importing the reference's modules/abmil.py (oracle/gen_golden.py: g3_standalone_*, g14_standalone_train_*)."""
+import numpy as np
+import pytest
+import torch
+
+from mhim_mil_amd import synth
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(meta, kind, act, train):
+    from mhim_mil_amd.standalone import build_model
+    if kind == "abmil":
+        m = build_model("abmil", input_dim=meta["d"], n_classes=2, dropout=0.0, act=act)
+    else:
+        m = build_model("gabmil", input_dim=meta["d"], n_classes=2, act=act, dropout=0.)
+    sd = {k: torch.from_numpy(synth.normal(meta["pseed"], tuple(shape), std=meta["std"], lane=i + 1).astype(np.float32))
+          for i, (k, shape) in enumerate(zip(meta["keys"], meta["shapes"]))}
+    missing, unexpected = m.load_state_dict(sd, strict=True)            # same names and shapes as the reference module
+    assert not missing and not unexpected
+    m = m.to(DEV)
+    return m.train() if train else m.eval()
+
+
+def _x(meta):
+    return torch.from_numpy(synth.bag(meta["xseed"], meta["n"], meta["d"])).to(DEV).unsqueeze(0)
+
+
+def test_eval_forward_fixtures():
+    meta, a = G.load("g3_standalone_dattention")
+    m = _build(meta, "abmil", "relu", False)
+    with torch.no_grad():
+        logits, attn, act = m(_x(meta), return_attn=True, return_act=True)
+    np.testing.assert_allclose(logits.cpu().numpy().reshape(-1), a["logits"].reshape(-1), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(attn.cpu().numpy().reshape(-1), a["attn"].reshape(-1), atol=1e-7, rtol=2e-4)
+    assert act.shape == (meta["n"], 512)
+    meta, a = G.load("g3_standalone_gated")
+    m = _build(meta, "gabmil", "relu", False)
+    with torch.no_grad():
+        logits = m(_x(meta))
+    np.testing.assert_allclose(logits.cpu().numpy().reshape(-1), a["logits"].reshape(-1), atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", G.names("g14_standalone_train"))
+def test_train_mode_gradients(name):
+    meta, a = G.load(name)
+    m = _build(meta, meta["kind"], meta["act"], True)
+    x = _x(meta)
+    out = m(x, return_attn=True) if meta["kind"] == "abmil" else m(x)
+    logits = out[0] if isinstance(out, (list, tuple)) else out
+    loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([meta["label"]], device=DEV))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy().reshape(-1), a["logits"].reshape(-1), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), float(a["loss"]), rtol=1e-4)
+    if meta["kind"] == "abmil":
+        np.testing.assert_allclose(out[1].detach().cpu().numpy().reshape(-1), a["attn"].reshape(-1), atol=1e-7, rtol=2e-4)
+    grads = G.tagged(a, "grad")
+    params = dict(m.named_parameters())
+    assert set(grads) == set(params)
+    for k, exp in grads.items():
+        g = params[k].grad
+        assert g is not None, k
+        scale = max(float(np.abs(exp["full"]).max()) if "full" in exp else float(exp["norm"]) / np.sqrt(max(1, g.numel())), 1e-12)
+        # (the scorer's output bias has an analytically ZERO gradient - softmax is shift invariant - both sides hold rounding noise)
+        # ReLU embeddings: a pre-activation within rounding of 0 may fall on the other side of the kink (3-term bf16 vs fp32): one
+        # instance's contribution to a weight-gradient element flips -> a looser absolute floor for those fixtures
+        rel_floor = 2e-2 if meta["act"] == "relu" else 2e-4
+        G.check_compact(g.cpu().numpy(), exp, rtol=2e-3, atol=max(rel_floor * scale, 1e-6), what=f"{name}:{k}")
+
+
+def test_factory_and_guards():
+    from mhim_mil_amd import _lib as L
+    from mhim_mil_amd.mhim import MHIM
+    from mhim_mil_amd.standalone import build_model
+    assert isinstance(build_model("mhim", input_dim=64, n_classes=2), MHIM)
+    pure = build_model("mhim_pure", input_dim=64, n_classes=2, baseline="attn")
+    assert isinstance(pure, MHIM) and not pure.merge_enable
+    with pytest.raises(NotImplementedError):
+        build_model("clam_sb", input_dim=64, n_classes=2)
+    g = build_model("gabmil", input_dim=64, n_classes=2, act="relu", dropout=0.25).to(DEV).train()
+    with pytest.raises(L.MhimxError):
+        g(torch.zeros(1, 8, 64, device=DEV))
+    with pytest.raises(L.MhimxError):
+        build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="ln")
