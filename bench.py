@@ -266,7 +266,8 @@ def main():
                                    + (" + RCCL all-reduce of the 6.6 MB flat gradient" if world > 1 else "") + ")",
                        "bags_per_step": world, "rotating_bags_per_gpu": N_BAGS, "matrix_core_form": student._feature_prec(N_INST),
                        "dropout": CFG["dropout"], "parallelism": f"dp{world}", "launch": ("eager" + (f" (graph capture failed: {graph_note})" if graph_note else "")) if graphs is None
-                                 else "hipGraph replay, one graph per resident bag"},
+                                 else ("hipGraph replay, one graph per resident bag" if world == 1 else
+                                       "hipGraph replay per resident bag: graph(fwd+bwd) | eager RCCL all-reduce | graph(Adam+EMA)")},
             "whole_step_hbm_roofline": {"algorithmic_bytes_per_instance": ALGO_BYTES_PER_INST_STEP,
                                         "achieved_GBps": value / world * ALGO_BYTES_PER_INST_STEP / 1e9,
                                         "frac_of_8TBps": value / world * ALGO_BYTES_PER_INST_STEP / 1e9 / HBM_PEAK_GBS},

@@ -153,6 +153,19 @@ def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, 
     return scale
 
 
+class _SplitStep:
+    """A captured data-parallel step: graph(forward + backward) -> eager all-reduce of the flat gradient -> graph(Adam + EMA)."""
+
+    def __init__(self, trainer, g_fb, g_up):
+        self.tr, self.g_fb, self.g_up = trainer, g_fb, g_up
+
+    def replay(self):
+        tr = self.tr
+        self.g_fb.replay()
+        sync_flat_gradient(tr.flat.grad, tr.flat.student, tr.flat.n_train, tr.world, tr.pg)
+        self.g_up.replay()
+
+
 class FusedTrainer:
     """One-call MHIM(ABMIL) train step on flat buffers (the benchmarked path)."""
 
@@ -312,6 +325,10 @@ class FusedTrainer:
         """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
         fl = self.flat
         scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
+        self._apply(scale)
+
+    def _apply(self, scale):
+        fl = self.flat
         fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
         ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                      fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
@@ -334,9 +351,21 @@ class FusedTrainer:
                 self.train_step(bag, label, **kw)
         torch.cuda.current_stream().wait_stream(cs)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
+        if self.world > 1:
+            # data parallel: the gradient all-reduce stays OUTSIDE the graphs (compute | RCCL all-reduce | optimiser): a
+            # collective inside a captured graph depends on the RCCL build, and a rank that replays while another launches
+            # eagerly would deadlock - two graph launches and one eager collective per step cost ~20 us of host time
+            g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb, pool=self._graph_pool, stream=cs):
+                self.forward_backward(bag, label, **kw)
+            scale = sync_flat_gradient(self.flat.grad, self.flat.student, self.flat.n_train, self.world, self.pg)
+            with torch.cuda.graph(g_up, pool=self._graph_pool, stream=cs):
+                self._apply(scale)
+            self.flat.grad.zero_()                         # (the capture-time all-reduce summed stale values)
+            return _SplitStep(self, g_fb, g_up)
+        g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):
             self.train_step(bag, label, **kw)
         return g

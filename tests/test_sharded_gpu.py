@@ -157,3 +157,51 @@ def test_c5_shard_size_steps_and_teacher_pool_matches_oracle():
     logits, losses = tr.train_step(x, torch.tensor([0], device=DEV))
     assert torch.isfinite(logits).all() and torch.isfinite(losses).all()
     assert all(torch.isfinite(v).all() for v in s.state_dict().values())
+
+
+def _dp_run(tr):
+    x = torch.from_numpy(synth.bag(700, N, D)).to(DEV)
+    lab = torch.tensor([1], device=DEV)
+    g = tr.capture(x, lab, warmup=1)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    return g
+
+
+def _dp_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from mhim_mil_amd.engine import FusedTrainer, _SplitStep
+    torch.manual_seed(77)
+    s, t = _models()
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
+    assert tr.world == 2
+    g = _dp_run(tr)
+    assert isinstance(g, _SplitStep)                          # compute graph | eager all-reduce | optimiser graph
+    torch.save({"stu": {k: v.detach().cpu() for k, v in s.state_dict().items()},
+                "tea": {k: v.detach().cpu() for k, v in t.state_dict().items()}}, os.path.join(out, f"dp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_captured_step_two_ranks_one_gpu(tmp_path):
+    """c4 data parallelism with the step captured as graph(fwd+bwd) | all-reduce | graph(Adam+EMA): two ranks fed the SAME
+    bag must reproduce the single-process captured run (the average of two equal gradients is that gradient, exactly)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    torch.manual_seed(77)
+    s, t = _models()
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
+    _dp_run(tr)
+    s_ref = {k: v.detach().cpu() for k, v in s.state_dict().items()}
+    t_ref = {k: v.detach().cpu() for k, v in t.state_dict().items()}
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"dp{r}.pt")) for r in range(2)]
+    for r in res:
+        _assert_state_close(r["stu"], s_ref, 1e-7)
+        _assert_state_close(r["tea"], t_ref, 1e-7)
+    for k in res[0]["stu"]:
+        assert torch.equal(res[0]["stu"][k], res[1]["stu"][k]), k
