@@ -165,81 +165,15 @@ __global__ __launch_bounds__(1024) void mca_fwd_final_kernel(const float* __rest
   }
 }
 
-// backward pass 1: dP[h,i,r] = (dO_i . v_r) * keep/(1-p) ; per-block partial of sum_r P dP
-template <int KQ>
-__global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dp_kernel(const float* __restrict__ KV, const float* __restrict__ dO,
-                                                                 const float* __restrict__ dots, const float* __restrict__ stats,
-                                                                 int64_t R, int heads, int kq, float drop_p, uint64_t seed0,
-                                                                 const uint64_t* __restrict__ tick, float* __restrict__ dP, float* __restrict__ prd) {
-  const uint64_t seed = eff_seed(seed0, tick);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int inner = heads * 64;
-  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float go[MCA_HPW][KQ], rd[MCA_HPW][KQ], mx[MCA_HPW][KQ], il[MCA_HPW][KQ];
-#pragma unroll
-  for (int hh = 0; hh < MCA_HPW; ++hh)
-#pragma unroll
-    for (int i = 0; i < KQ; ++i) {
-      const int h = wave + 4 * hh;
-      const bool ok = h < heads && i < kq;
-      go[hh][i] = ok ? dO[(int64_t)i * inner + h * 64 + lane] : 0.f;
-      mx[hh][i] = ok ? stats[2 * (h * kq + i)] : 0.f;
-      il[hh][i] = ok ? 1.f / stats[2 * (h * kq + i) + 1] : 0.f;
-      rd[hh][i] = 0.f;
-    }
-  const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
-  const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
-  // all loads of the block's rows are issued up front (the row loop is otherwise a chain of load -> reduce -> load)
-  float vbuf[MCA_ROWS][MCA_HPW], dbuf[MCA_ROWS][MCA_HPW][KQ];
-#pragma unroll
-  for (int rr = 0; rr < MCA_ROWS; ++rr)
-#pragma unroll
-    for (int hh = 0; hh < MCA_HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      const int64_t r = r0 + rr;
-      const bool ok = h < heads && r < r1;
-      vbuf[rr][hh] = ok ? KV[r * 2 * inner + inner + h * 64 + lane] : 0.f;
-#pragma unroll
-      for (int i = 0; i < KQ; ++i) dbuf[rr][hh][i] = (ok && i < kq) ? dots[((int64_t)h * kq + i) * R + r] : 0.f;
-    }
-#pragma unroll
-  for (int rr = 0; rr < MCA_ROWS; ++rr) {
-    const int64_t r = r0 + rr;
-    if (r >= r1) break;
-#pragma unroll
-    for (int hh = 0; hh < MCA_HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      if (h >= heads) continue;
-      const float vv = vbuf[rr][hh];
-#pragma unroll
-      for (int i = 0; i < KQ; ++i) {
-        if (i >= kq) continue;
-        float dp = wave_sum(go[hh][i] * vv);
-        if (drop_p > 0.f) dp = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? dp * keep_scale : 0.f;
-        const int64_t o = ((int64_t)h * kq + i) * R + r;
-        if (lane == 0) dP[o] = dp;
-        rd[hh][i] += __expf(dbuf[rr][hh][i] - mx[hh][i]) * il[hh][i] * dp;
-      }
-    }
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int hh = 0; hh < MCA_HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      if (h >= heads) continue;
-#pragma unroll
-      for (int i = 0; i < KQ; ++i)
-        if (i < kq) prd[(int64_t)blockIdx.x * heads * kq + h * kq + i] = rd[hh][i];
-    }
-  }
-}
-
-// backward pass 2: dd = scale * P (dP - rowdot); dK_r = sum_i dd q_i; dV_r = sum_i Pd dO_i; per-block partial dQ_i += dd k_r
+// The attention backward in ONE pass over the key rows: dP_r = keep_r (dO_i . V_r), dd = scale * P (dP - rowdot),
+// dK_r = sum_i dd q_i, dV_r = sum_i Pd dO_i, per-block partial dQ_i += dd k_r.
+// The softmax's row dot  sum_r P_r dP_r  needs no pass of its own: sum_r P_r keep_r (dO_i . V_r) = dO_i . O_i with
+// O = sum_r Pd_r V_r, the forward output that is kept anyway (a second row kernel + a [heads,k,R] buffer less).
 template <int KQ>
 __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* __restrict__ KV, const float* __restrict__ Q,
                                                                   const float* __restrict__ dO, const float* __restrict__ dots,
-                                                                  const float* __restrict__ stats, const float* __restrict__ dP,
-                                                                  const float* __restrict__ prd, int nb, int64_t R, int heads,
+                                                                  const float* __restrict__ stats, const float* __restrict__ O,
+                                                                  int64_t R, int heads,
                                                                   int kq, float scale, float drop_p, uint64_t seed0,
                                                                   const uint64_t* __restrict__ tick, float* __restrict__ dKV, float* __restrict__ pdq) {
   const uint64_t seed = eff_seed(seed0, tick);
@@ -257,15 +191,12 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
       go[hh][i] = ok ? dO[(int64_t)i * inner + h * 64 + lane] : 0.f;
       mx[hh][i] = ok ? stats[2 * (h * kq + i)] : 0.f;
       il[hh][i] = ok ? 1.f / stats[2 * (h * kq + i) + 1] : 0.f;
-      float s = 0.f;
-      if (ok)
-        for (int b = lane; b < nb; b += 64) s += prd[(int64_t)b * heads * kq + h * kq + i];
-      rd[hh][i] = wave_sum(s);
+      rd[hh][i] = wave_sum(ok ? go[hh][i] * O[(int64_t)i * inner + h * 64 + lane] : 0.f);
       dq[hh][i] = 0.f;
     }
   const int64_t r0 = (int64_t)blockIdx.x * MCA_ROWS;
   const int64_t r1 = r0 + MCA_ROWS < R ? r0 + MCA_ROWS : R;
-  float kbuf[MCA_ROWS][MCA_HPW], dbuf[MCA_ROWS][MCA_HPW][KQ], pbuf[MCA_ROWS][MCA_HPW][KQ];       // loads issued up front
+  float kbuf[MCA_ROWS][MCA_HPW], vbuf[MCA_ROWS][MCA_HPW], dbuf[MCA_ROWS][MCA_HPW][KQ];       // loads issued up front
 #pragma unroll
   for (int rr = 0; rr < MCA_ROWS; ++rr)
 #pragma unroll
@@ -274,12 +205,9 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
       const int64_t r = r0 + rr;
       const bool ok = h < heads && r < r1;
       kbuf[rr][hh] = ok ? KV[r * 2 * inner + h * 64 + lane] : 0.f;
+      vbuf[rr][hh] = ok ? KV[r * 2 * inner + inner + h * 64 + lane] : 0.f;
 #pragma unroll
-      for (int i = 0; i < KQ; ++i) {
-        const int64_t o = ((int64_t)h * kq + i) * R + r;
-        dbuf[rr][hh][i] = (ok && i < kq) ? dots[o] : 0.f;
-        pbuf[rr][hh][i] = (ok && i < kq) ? dP[o] : 0.f;
-      }
+      for (int i = 0; i < KQ; ++i) dbuf[rr][hh][i] = (ok && i < kq) ? dots[((int64_t)h * kq + i) * R + r] : 0.f;
     }
 #pragma unroll
   for (int rr = 0; rr < MCA_ROWS; ++rr) {
@@ -289,15 +217,17 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
     for (int hh = 0; hh < MCA_HPW; ++hh) {
       const int h = wave + 4 * hh;
       if (h >= heads) continue;
-      const float kv = kbuf[rr][hh];
+      const float kv = kbuf[rr][hh], vv = vbuf[rr][hh];
       float dk = 0.f, dv = 0.f;
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
         if (i >= kq) continue;
         const float p = __expf(dbuf[rr][hh][i] - mx[hh][i]) * il[hh][i];
-        const float dd = scale * p * (pbuf[rr][hh][i] - rd[hh][i]);
-        float pd = p;
-        if (drop_p > 0.f) pd = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? p * keep_scale : 0.f;
+        float ks = 1.f;
+        if (drop_p > 0.f) ks = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? keep_scale : 0.f;
+        const float dp = wave_sum(go[hh][i] * vv) * ks;
+        const float dd = scale * p * (dp - rd[hh][i]);
+        const float pd = p * ks;
         dk += dd * q[hh][i];
         dv += pd * go[hh][i];
         dq[hh][i] += dd * kv;
@@ -615,11 +545,8 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   const float scale = 1.0f / sqrtf((float)m->dim_head);
   if (int r = dispatch_kq(k, [&](auto kqc) {
         constexpr int KQ = decltype(kqc)::value;
-        hipLaunchKernelGGL(mca_bwd_dp_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.dO, w.P, w.stats, R, (int)H,
-                           (int)k, m->drop_p, m->drop_seed, m->drop_tick, w.dd, w.prd);
-        MHIMX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(mca_bwd_dkv_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, w.dO, w.P, w.stats, w.dd,
-                           w.prd, w.nb, R, (int)H, (int)k, scale, m->drop_p, m->drop_seed, m->drop_tick, w.dKV, w.pdq);
+        hipLaunchKernelGGL(mca_bwd_dkv_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, w.dO, w.P, w.stats, w.O,
+                           R, (int)H, (int)k, scale, m->drop_p, m->drop_seed, m->drop_tick, w.dKV, w.pdq);
         MHIMX_LAUNCH_CHECK();
         return 0;
       })) return r;
