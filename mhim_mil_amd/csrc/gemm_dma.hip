@@ -515,18 +515,23 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
   return 0;
 }
 
-// One launch for the parameter-only preparation of a train step: blockIdx.y = job.  kind 0: out[c,r] = in[r,c];
+// One launch for the parameter-only preparation of a train step (a block range per job).  kind 0: out[c,r] = in[r,c];
 // kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters);
 // kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip).
-struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int n; };
+struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; };
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
-  const mhimx_prep_job jb = pj.j[blockIdx.y];
+  // 1-D grid: job q owns blocks [first[q], first[q+1]) - sized per job (the bag's paired-plane image wants thousands of
+  // workgroups, a weight transpose a few dozen; a rectangular grid would launch tens of thousands of empty blocks)
+  int q = 0;
+  while (q + 1 < pj.n && (int)blockIdx.x >= pj.first[q + 1]) ++q;
+  const mhimx_prep_job jb = pj.j[q];
+  const int bid = (int)blockIdx.x - pj.first[q], nblk = pj.first[q + 1] - pj.first[q];
   const int64_t R = jb.R, C = jb.C;
   if (jb.kind == 0) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                   // 32 x 8
     const int64_t tiles_c = (C + 31) / 32, ntiles = ((R + 31) / 32) * tiles_c;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int64_t t = bid; t < ntiles; t += nblk) {
       const int64_t r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
       for (int i = ty; i < 32; i += 8) {
         const int64_t r = r0 + i, c = c0 + tx;
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
     }
   } else if (jb.kind == 1) {
     const int64_t K8 = C / 8, n = R * K8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
       const f4 a = *reinterpret_cast<const f4*>(jb.in + i * 8);
       const f4 b = *reinterpret_cast<const f4*>(jb.in + i * 8 + 4);
       b8 hi, lo;
@@ -552,14 +557,14 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
     }
   } else if (jb.kind == 2) {
     const int64_t n = R * C;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) jb.out[i] = jb.in[i];
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) jb.out[i] = jb.in[i];
   } else if (jb.kind == 3) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<uint64_t*>(jb.out) += 1;
+    if (bid == 0 && threadIdx.x == 0) *reinterpret_cast<uint64_t*>(jb.out) += 1;
   } else if (jb.kind == 4) {
     // B-operand fragment image for v_mfma_f32_32x32x16_bf16: item (nt, ks, lane) holds the 8 hi | 8 lo bf16 of
     // in[32 nt + (lane & 31)][16 ks + 8 (lane >> 5) .. + 8]: a wave's fragment load is 2 KB contiguous
     const int64_t KS = C / 16, n = R * C / 8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
       const int64_t lane = i & 63, ks = (i >> 6) % KS, nt = (i >> 6) / KS;
       const float* src = jb.in + (32 * nt + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5);
       const f4 a = *reinterpret_cast<const f4*>(src);
@@ -585,16 +590,17 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
   }
-  // every job loop is grid-stride: size the launch for the largest job (the bag's paired-plane image streams ~80 MB and wants
-  // thousands of workgroups; the blocks of the small jobs beyond their work find nothing to do)
-  int64_t gx = 256;
+  int first = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t items = jobs[i].kind == 3 ? 1 : (jobs[i].kind == 0 ? cdiv(jobs[i].R, 32) * cdiv(jobs[i].C, 32) : jobs[i].R * jobs[i].C / 8);
-    const int64_t want = jobs[i].kind == 0 ? items : cdiv(items, 256);
-    if (want > gx) gx = want;
+    int64_t want = jobs[i].kind == 0 ? items : cdiv(items, 256);
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;                      // every job loop is grid-stride
+    pj.first[i] = first;
+    first += (int)want;
   }
-  if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(prep_batch_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, st, pj);
+  pj.first[n] = first;
+  hipLaunchKernelGGL(prep_batch_kernel, dim3((unsigned)first), dim3(256), 0, st, pj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
