@@ -125,7 +125,9 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  * 2 = copy R*C floats, 3 = *(uint64_t*)out += 1 (the device-resident dropout / Adam step counters),
  * 4 = matrix-core fragment image of in[R,C] (R % 32 == 0, C % 16 == 0; same size as in): for every 32-row block nt and
  *     16-column step ks, 64 consecutive 32-byte items (item l: 8 bf16 hi | 8 bf16 lo of in[32 nt + l % 32][16 ks + 8 (l / 32) ..])
- *     - what mhimx_scorer.wa_frag takes. */
+ *     - what mhimx_scorer.wa_frag takes,
+ * 5 = the kind-4 image of the TRANSPOSE in^T [C,R] made straight from in[R,C] (C % 32 == 0, R % 16 == 0) - what
+ *     mhimx_pool_grad.wa_t_frag takes (jobs of one launch run concurrently: one cannot read another's output). */
 #define MHIMX_PREP_MAX 16
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
@@ -178,6 +180,7 @@ typedef struct {
   int32_t accumulate;
   int32_t splits;
   mhimx_reduce_list* defer;           /* optional: queue the d_wa / d_wc / d_bc final reductions                 */
+  const float* wa_t_frag;             /* optional: prep kind-4 image of wa_t [E,A] for the one-pass backward      */
 } mhimx_pool_grad;
 int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* g);
 

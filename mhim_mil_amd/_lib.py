@@ -80,7 +80,7 @@ class PoolGrad(C.Structure):
     _fields_ = [("g_z", c_f32p), ("dT1", c_f32p), ("dT2", c_f32p),
                 ("d_wa", c_f32p), ("d_ba", c_f32p), ("d_wb", c_f32p), ("d_bb", c_f32p), ("d_wc", c_f32p),
                 ("d_bc", c_f32p), ("wa_t", c_f32p), ("wb_t", c_f32p),
-                ("accumulate", C.c_int32), ("splits", C.c_int32), ("defer", C.c_void_p)]
+                ("accumulate", C.c_int32), ("splits", C.c_int32), ("defer", C.c_void_p), ("wa_t_frag", c_f32p)]
 
 
 class Merge(C.Structure):

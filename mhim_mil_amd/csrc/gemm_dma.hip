@@ -517,7 +517,7 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
 
 // One launch for the parameter-only preparation of a train step (a block range per job).  kind 0: out[c,r] = in[r,c];
 // kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters);
-// kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip).
+// kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip); kind 5: the same image of in^T.
 struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; };
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
   // 1-D grid: job q owns blocks [first[q], first[q+1]) - sized per job (the bag's paired-plane image wants thousands of
@@ -575,6 +575,22 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
       o[0] = __builtin_bit_cast(f4, hi);
       o[1] = __builtin_bit_cast(f4, lo);
     }
+  } else if (jb.kind == 5) {
+    // the kind-4 image of in^T ([C, R]) made straight from in[R,C]: item (nt, ks, lane) holds in[16 ks + 8 (lane >> 5) + u][32 nt + (lane & 31)],
+    // u < 8 (a job of the same launch cannot read the transpose another job is still writing)
+    const int64_t KS = R / 16, n = R * C / 8;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
+      const int64_t lane = i & 63, ks = (i >> 6) % KS, nt = (i >> 6) / KS;
+      const float* src = jb.in + (16 * ks + 8 * (lane >> 5)) * C + 32 * nt + (lane & 31);
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = src[u * C];
+      b8 hi, lo;
+      Frag<MHIMX_PREC_BF16X3>::split(x, hi, lo);
+      f4* o = reinterpret_cast<f4*>(jb.out + i * 8);
+      o[0] = __builtin_bit_cast(f4, hi);
+      o[1] = __builtin_bit_cast(f4, lo);
+    }
   }
 }
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
@@ -584,7 +600,9 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
   for (int i = 0; i < n; ++i) {
     pj.j[i] = jobs[i];
     MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
-    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 4, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 5, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind != 5 || (jobs[i].C % 32 == 0 && jobs[i].R % 16 == 0 && aligned16(jobs[i].out)),
+                    "prep_batch: the transposed fragment image needs C % 32 == 0, R % 16 == 0 and a 16-byte aligned output");
     MHIMX_CHECK_ARG(jobs[i].kind != 4 || (jobs[i].R % 32 == 0 && jobs[i].C % 16 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: the fragment image needs R % 32 == 0, C % 16 == 0 and 16-byte aligned buffers");
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),

@@ -14,6 +14,9 @@ bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, 
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
                      float* pz, int max_parts);
+int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
+                     const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts);
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
@@ -721,7 +724,19 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
 
   int64_t off = 0;
   int G = 0;
-  for (int seg = 0; seg < 2; ++seg) {
+  // one pass over the rows for ds / du / dT / the d_wc, d_bc partials (scorer_fused.hip) where the shapes allow
+  const bool fused = scorer_fused_ok(E, A, gated, sc->prec, io->T1, gr->wa_t, nullptr, 0) && aligned16(gr->dT1) &&
+                     (io->M2 == 0 || (aligned16(io->T2) && aligned16(gr->dT2))) && aligned16(u_pre) && aligned16(w.du);
+  for (int seg = 0; seg < 2 && fused; ++seg) {
+    if (Ms[seg] == 0) continue;
+    const int g1 = scorer_fused_bwd(st, Ts[seg], Ms[seg], u_pre + off * ldu, io->s + off, io->stats, gr->g_z, io->z, sc->wc, sc->act,
+                                    gr->wa_t, gr->wa_t_frag, w.du + off * ldu, dTs[seg], w.dwc_part + (int64_t)G * A, w.dbc_part + G,
+                                    MAX_PART);
+    if (g1 < 0) return g1;
+    G += g1;
+    off += Ms[seg];
+  }
+  for (int seg = 0; seg < 2 && !fused; ++seg) {
     if (Ms[seg] == 0) continue;
     const int grid = grid_for_rows(Ms[seg]);
     const float* Tseg = Ts[seg];
@@ -754,7 +769,8 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     mhimx_gemm_nt_args g = {};
     g.A = w.du + off * ldu; g.lda = ldu; g.B = gr->wa_t; g.ldb = A; g.C = dTs[seg]; g.ldc = E;
     g.M = Ms[seg]; g.N = E; g.K = A; g.rowv = w.attn + off; g.colv = gr->g_z; g.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
-    if (int r = gemm_nt(st, g)) return r;
+    if (!fused)
+      if (int r = gemm_nt(st, g)) return r;
     if (gated) {
       g.A = w.du + off * ldu + A; g.B = gr->wb_t; g.rowv = nullptr; g.colv = nullptr; g.accumulate = 1;
       if (int r = gemm_nt(st, g)) return r;

@@ -191,16 +191,13 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
       const int r = tid >> 3, seg = tid & 7;
       const int64_t n = row0 + r;
       const sf_f4* hr = reinterpret_cast<const sf_f4*>(Hs + r * SF_LD) + seg;
-      sf_f4 hv[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) hv[q] = hr[8 * q];
       for (int c = 0; c < C; ++c) {
         const sf_f4* w = reinterpret_cast<const sf_f4*>(wps + c * SF_E) + seg;
         float d = 0.f;
-#pragma unroll
+#pragma unroll 8
         for (int q = 0; q < 16; ++q) {
-          const sf_f4 ww = w[8 * q];
-          d += hv[q][0] * ww[0] + hv[q][1] * ww[1] + hv[q][2] * ww[2] + hv[q][3] * ww[3];
+          const sf_f4 hv = hr[8 * q], ww = w[8 * q];
+          d += hv[0] * ww[0] + hv[1] * ww[1] + hv[2] * ww[2] + hv[3] * ww[3];
         }
         d += dpp_mov<0xB1, 0xf>(0.f, d);                      // lanes ^1
         d += dpp_mov<0x4E, 0xf>(0.f, d);                      // lanes ^2
@@ -214,6 +211,170 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
   if (tid == 0) { pm[blockIdx.x] = m_run; pl[blockIdx.x] = l_run; }
   pz[(int64_t)blockIdx.x * SF_E + tid] = z0;
   pz[(int64_t)blockIdx.x * SF_E + tid + SF_THREADS] = z1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward of the same block in one pass over the rows (replaces the row pass + the dT GEMM of rows.hip):
+//   attn_n = e^{s_n - max} / L,  ds_n = attn_n (T_n.g_z - z.g_z),  du[n,a] = ds_n wc[a] act'(u_pre[n,a])   (stored: d_wa = du^T T)
+//   dT[n,:] = du[n,:] Wa + attn_n g_z                              (32 x 512 tile, K = 128, on the matrix cores)
+//   per-workgroup partials of d_wc[a] = sum_n ds_n act(u_pre[n,a]) and d_bc = sum_n ds_n
+// T is read once, straight into registers for the row dots (8 lanes per row); du goes to LDS as the A operand; Wa^T comes as
+// the prep-time fragment image (or is split on the fly).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int SB_LD = SF_A + 4;
+constexpr size_t SB_SMEM = (size_t)(SF_ROWS * SB_LD + SF_E + 3 * SF_ROWS + 2 * SF_A + 8) * sizeof(float);
+
+__global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
+    const float* __restrict__ T, int64_t M, const float* __restrict__ u_pre, const float* __restrict__ s_in,
+    const float* __restrict__ stats, const float* __restrict__ g_z, const float* __restrict__ z, const float* __restrict__ wc, int act,
+    const float* __restrict__ wat, const float* __restrict__ wat_frag, float* __restrict__ du, float* __restrict__ dT,
+    float* __restrict__ dwc_part, float* __restrict__ dbc_part, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float sb_sm[];
+  float* Ds = sb_sm;                           // [32][132] du tile (A operand)
+  float* gzs = Ds + SF_ROWS * SB_LD;           // [512]
+  float* an_s = gzs + SF_E;                    // [32] attn
+  float* gs_s = an_s + SF_ROWS;                // [32] ds
+  float* red = gs_s + SF_ROWS;                 // [32] scratch: c0 partials (4 used)
+  float* dwc_s = red + SF_ROWS;                // [2][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r32 = lane & 31, kg = lane >> 5;
+  // g_z -> LDS, c0 = z . g_z
+  float c0p = 0.f;
+  for (int e = tid; e < SF_E; e += SF_THREADS) {
+    const float g = g_z[e];
+    gzs[e] = g;
+    c0p += g * z[e];
+  }
+  c0p = wave_sum(c0p);
+  if (lane == 0) red[wave] = c0p;
+  __syncthreads();
+  const float c0 = (red[0] + red[1]) + (red[2] + red[3]);
+  const float mx = stats[0], invL = 1.f / stats[1];
+  const int a_col = tid & (SF_A - 1), half = tid >> 7;           // du / d_wc column of this thread
+  const float wca = wc[a_col];
+  float dwc_run = 0.f, dbc_run = 0.f;
+
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * SF_ROWS;
+    // ---- 1. row dots T_n . g_z: 8 lanes per row, lane `seg` takes the 16-byte groups seg, seg+8, ...
+    {
+      const int r = tid >> 3, seg = tid & 7;
+      const int64_t n = row0 + r;
+      const sf_f4* tr = reinterpret_cast<const sf_f4*>(T + (n < M ? n : M - 1) * SF_E) + seg;
+      const sf_f4* gr = reinterpret_cast<const sf_f4*>(gzs) + seg;
+      sf_f4 tv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tv[q] = tr[8 * q];
+      float d = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const sf_f4 g = gr[8 * q];
+        d += tv[q][0] * g[0] + tv[q][1] * g[1] + tv[q][2] * g[2] + tv[q][3] * g[3];
+      }
+      d += dpp_mov<0xB1, 0xf>(0.f, d);
+      d += dpp_mov<0x4E, 0xf>(0.f, d);
+      d += dpp_mov<0x141, 0xf>(0.f, d);
+      if (seg == 0) {
+        const float an = n < M ? __expf(s_in[n] - mx) * invL : 0.f;
+        an_s[r] = an;
+        gs_s[r] = an * (d - c0);
+      }
+    }
+    __syncthreads();
+    // ---- 2. du tile (global + LDS), d_wc / d_bc partials
+#pragma unroll 4
+    for (int k = 0; k < SF_ROWS / 2; ++k) {
+      const int r = half + 2 * k;
+      const int64_t n = row0 + r;
+      float d = 0.f;
+      if (n < M) {
+        const float u = u_pre[n * SF_A + a_col];
+        float ya, ga;
+        act_fwd_grad(u, act, ya, ga);
+        const float ds = gs_s[r];
+        d = ds * wca * ga;
+        du[n * SF_A + a_col] = d;
+        dwc_run += ds * ya;
+      }
+      Ds[r * SB_LD + a_col] = d;
+    }
+    if (tid == 0) {
+      float b = 0.f;
+      for (int r = 0; r < SF_ROWS; ++r) b += gs_s[r];
+      dbc_run += b;
+    }
+    __syncthreads();
+    // ---- 3. dT tile = du Wa (+ attn g_z): wave w owns columns [128 w, 128 w + 128)
+    sf_f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    const float* aptr = Ds + r32 * SB_LD + 8 * kg;
+    if (wat_frag) {
+      const float* fptr = wat_frag + ((int64_t)(4 * wave) * (SF_A / 16) * 64 + lane) * 8;     // + (nt * 8 + ks) * 512 floats
+      sf_f4 bh_[4], bl_[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bh_[nt] = *reinterpret_cast<const sf_f4*>(fptr + (nt * 8) * 512);
+        bl_[nt] = *reinterpret_cast<const sf_f4*>(fptr + (nt * 8) * 512 + 4);
+      }
+#pragma unroll 1
+      for (int ks = 0; ks < SF_A / 16; ++ks) {
+        const sf_f4 a0 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks), a1 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks + 4);
+        sf_b8 ah, al;
+        sf_split(a0, a1, ah, al);
+        sf_f4 nh[4], nl[4];
+        const int kn = ks + 1 < SF_A / 16 ? ks + 1 : ks;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          nh[nt] = *reinterpret_cast<const sf_f4*>(fptr + (nt * 8 + kn) * 512);
+          nl[nt] = *reinterpret_cast<const sf_f4*>(fptr + (nt * 8 + kn) * 512 + 4);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const sf_b8 bh = __builtin_bit_cast(sf_b8, bh_[nt]), bl = __builtin_bit_cast(sf_b8, bl_[nt]);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+          bh_[nt] = nh[nt];
+          bl_[nt] = nl[nt];
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int ks = 0; ks < SF_A / 16; ++ks) {
+        const sf_f4 a0 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks), a1 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks + 4);
+        sf_b8 ah, al;
+        sf_split(a0, a1, ah, al);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float* bp = wat + (int64_t)(128 * wave + 32 * nt + r32) * SF_A + 16 * ks + 8 * kg;
+          sf_b8 bh, bl;
+          sf_split(*reinterpret_cast<const sf_f4*>(bp), *reinterpret_cast<const sf_f4*>(bp + 4), bh, bl);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int e = 128 * wave + 32 * nt + r32;
+      const float ge = gzs[e];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
+        const int64_t n = row0 + row;
+        if (n < M) dT[n * SF_E + e] = acc[nt][i] + an_s[row] * ge;
+      }
+    }
+    __syncthreads();                           // Ds / an_s / gs_s are rewritten by the next tile
+  }
+  dwc_s[half * SF_A + a_col] = dwc_run;
+  __syncthreads();
+  if (tid < SF_A) dwc_part[(int64_t)blockIdx.x * SF_A + tid] = dwc_s[tid] + dwc_s[SF_A + tid];
+  if (tid == 0) dbc_part[blockIdx.x] = dbc_run;
 }
 
 #ifdef MHIMX_SF_PROF
@@ -237,6 +398,23 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
   const int grid = tiles < max_parts ? tiles : max_parts;
   hipLaunchKernelGGL(scorer_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
                      cproj, pm, pl, pz, tiles);
+  MHIMX_LAUNCH_CHECK();
+  return grid;
+}
+
+// returns the number of d_wc / d_bc partial rows written (<= max_parts), < 0 on error
+int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
+                     const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts) {
+  static bool attr = false;
+  if (!attr) {
+    MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM));
+    attr = true;
+  }
+  const int tiles = (int)cdiv(M, SF_ROWS);
+  const int grid = tiles < max_parts ? tiles : max_parts;
+  hipLaunchKernelGGL(scorer_fused_bwd_kernel, dim3(grid), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
+                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

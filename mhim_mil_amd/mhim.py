@@ -304,6 +304,11 @@ class MHIM(nn.Module):
                 prep["wa_t"], prep["wb_t"] = tr(att.attention_a[0].weight.data), tr(att.attention_b[0].weight.data)
             else:
                 prep["wa_t"] = tr(att.attention[0].weight.data)
+                if prep["wa_t"].shape[0] % 32 == 0 and prep["wa_t"].shape[1] % 16 == 0:
+                    # matrix-core image of Wa^T for the one-pass scorer backward.  It reads the transpose made by an EARLIER job
+                    # of the same launch - so it is made from the weight itself, by a transposing fragment job
+                    prep["wa_t_frag"] = torch.empty_like(prep["wa_t"])
+                    jobs.append((ops.PREP_FRAG_T, att.attention[0].weight.data, prep["wa_t_frag"]))
             if self.merge_enable:
                 m = self.merge
                 prep["merge_t"] = (tr(m.attn.to_kv.weight.data), tr(m.attn.to_q.weight.data), tr(m.attn.to_out[0].weight.data))
@@ -459,7 +464,7 @@ class MHIM(nn.Module):
             grads["online_encoder.attention.attention_c.weight"] = g["d_wc"]
         else:
             g = ops.abmil_pool_bwd(sc, st, g_z, prep.get("wa_t") if "wa_t" in prep else ops.transpose(att.attention[0].weight.data),
-                                   grads=pool_g, defer=defer)
+                                   grads=pool_g, defer=defer, wa_t_frag=prep.get("wa_t_frag"))
             grads["online_encoder.attention.attention.0.weight"] = g["d_wa"]
             grads["online_encoder.attention.attention.2.weight"] = g["d_wc"]
         if self.merge_enable and plan.R > 0:

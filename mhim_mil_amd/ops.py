@@ -71,7 +71,7 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
     return out
 
 
-PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG = 0, 1, 2, 3, 4
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T = 0, 1, 2, 3, 4, 5
 
 
 def prep_batch(jobs):
@@ -201,7 +201,7 @@ def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None):
 
 
 def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=False, splits=8, grads=None,
-                   accumulate=False, defer=None):
+                   accumulate=False, defer=None, wa_t_frag=None):
     """Backward of the pool.  Returns dict(dT1, dT2, d_wa, d_wc, [d_wb, d_ba, d_bb, d_bc])."""
     dev = g_z.device
     E, A = sc.E, sc.A
@@ -221,7 +221,8 @@ def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=F
     io = st.io(sc)
     g = L.PoolGrad(g_z=_p(g_z), dT1=_p(out["dT1"]), dT2=_p(out.get("dT2")), d_wa=_p(out["d_wa"]), d_ba=_p(out.get("d_ba")),
                    d_wb=_p(out.get("d_wb")), d_bb=_p(out.get("d_bb")), d_wc=_p(out["d_wc"]), d_bc=_p(out.get("d_bc")),
-                   wa_t=_p(wa_t), wb_t=_p(wb_t), accumulate=int(bool(accumulate)), splits=int(splits), defer=_dp(defer))
+                   wa_t=_p(wa_t), wb_t=_p(wb_t), accumulate=int(bool(accumulate)), splits=int(splits), defer=_dp(defer),
+                   wa_t_frag=_p(wa_t_frag))
     if defer is not None:
         defer.keep.append(st)
     L.check(L.lib().mhimx_abmil_pool_bwd(_stream(), C.byref(sc.c), C.byref(io), C.byref(g)), "mhimx_abmil_pool_bwd")

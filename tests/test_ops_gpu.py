@@ -495,3 +495,25 @@ def test_deferred_reductions_match_immediate():
         ops.reduce_flush(lst)
         assert lst.c.n == 0 and not lst.keep
         assert torch.equal(got, ref) and torch.equal(got_b, ref_b)
+
+
+def test_fused_scorer_backward_and_transposed_fragment_image():
+    """prep kind 5 (fragment image of the transpose, made from the untransposed weight) == kind 4 of the transposed weight;
+    the one-pass scorer backward with that image == the same kernel splitting Wa^T on the fly, bit for bit (the fp64
+    comparison of the fused backward is test_pool_fwd_bwd's)."""
+    ops = _ops()
+    E, A, M = 512, 128, 3001
+    wa, wc, _, ba, _, bc = _scorer_params(61, E, A, False, True)
+    d = lambda t: t.to(DEV)
+    wat = ops.transpose(d(wa))
+    f4, f5 = torch.empty(E, A, device=DEV), torch.empty(E, A, device=DEV)
+    ops.prep_batch([(ops.PREP_FRAG, wat, f4), (ops.PREP_FRAG_T, d(wa), f5)])
+    assert torch.equal(f4, f5)
+    T = d(rnd(62, (M, E)).abs())
+    gz = d(rnd(63, (E,), std=0.01))
+    sc = ops.ScorerW(d(wa), d(wc), 3, ba=d(ba), bc=d(bc), prec="bf16x3")
+    st = ops.abmil_pool_fwd(sc, T)
+    g0 = ops.abmil_pool_bwd(sc, st, gz, wat, need_bias=True)
+    g1 = ops.abmil_pool_bwd(sc, st, gz, wat, need_bias=True, wa_t_frag=f5)
+    for k in ("dT1", "d_wa", "d_wc", "d_bc", "d_ba"):
+        assert torch.equal(g0[k], g1[k]), k
