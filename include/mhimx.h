@@ -159,6 +159,8 @@ typedef struct {
  *  z[E]      = sum_n softmax(s)_n T[n,:]
  *  u_pre     [M, A*(1+gated)] scorer pre-activations (kept for backward), may be NULL only if ws holds it
  *  cproj     optional [M,C] = T Wp^T (class projections for the pseudo score), needs wp [C,E]
+ *  pscore    optional [M1]: the pseudo score of the segment-1 instances (mhimx_pseudo_score's arithmetic and bits, with the
+ *            predictor bias bp) written by the pool's own finalize launch - one launch less on the teacher's chain; needs cproj
  *  ws        workspace, mhimx_abmil_pool_ws_bytes(M, E, A, gated) bytes                           */
 typedef struct {
   const float* T1; int64_t M1; const float* T2; int64_t M2;
@@ -166,6 +168,7 @@ typedef struct {
   float* u_pre;
   const float* wp; int64_t C; float* cproj;
   void* ws; int64_t ws_bytes;
+  const float* bp; float* pscore;
 } mhimx_pool_io;
 int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
 int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io);

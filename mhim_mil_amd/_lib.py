@@ -73,7 +73,7 @@ class PoolIO(C.Structure):
     _fields_ = [("T1", c_f32p), ("M1", C.c_int64), ("T2", c_f32p), ("M2", C.c_int64),
                 ("s", c_f32p), ("stats", c_f32p), ("z", c_f32p), ("u_pre", c_f32p),
                 ("wp", c_f32p), ("C", C.c_int64), ("cproj", c_f32p),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p)]
 
 
 class PoolGrad(C.Structure):

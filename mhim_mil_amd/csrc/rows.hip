@@ -114,7 +114,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void score_rows_fwd_kernel(
 constexpr int FIN_THREADS = 1024;
 __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                                      const float* __restrict__ pz, int G, int E,
-                                                                     float* __restrict__ stats, float* __restrict__ z) {
+                                                                     float* __restrict__ stats, float* __restrict__ z,
+                                                                     const float* __restrict__ s, const float* __restrict__ cproj,
+                                                                     const float* __restrict__ bp, int C, int64_t M1,
+                                                                     float* __restrict__ pscore) {
   __shared__ float red[16];
   __shared__ float wgt[2 * MAX_PART];
   __shared__ float acc16[16][64];
@@ -155,6 +158,17 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
     z[e] = a / L;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = mx; stats[1] = L; }
+  if (pscore) {                                // the pseudo score of the instances rides along (pseudo_score_kernel's arithmetic)
+    const float invL = 1.f / L, b0 = bp ? bp[0] : 0.f;
+    for (int64_t n = (int64_t)blockIdx.x * FIN_THREADS + threadIdx.x; n < M1; n += (int64_t)gridDim.x * FIN_THREADS) {
+      const float an = __expf(s[n] - mx) * invL;
+      float cm = -INFINITY;
+      for (int c = 0; c < C; ++c) cm = fmaxf(cm, an * cproj[n * C + c] + b0);
+      float den = 0.f;
+      for (int c = 0; c < C; ++c) den += expf((an * cproj[n * C + c] + b0) - cm);
+      pscore[n] = 1.f / den;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,7 +714,9 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
-  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z);
+  MHIMX_CHECK_ARG(!io->pscore || io->cproj, "pool_fwd: pscore needs cproj (and wp)");
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z,
+                     io->s, io->cproj, io->bp, (int)io->C, io->M1, io->pscore);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

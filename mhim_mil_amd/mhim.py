@@ -621,9 +621,9 @@ class MHIM(nn.Module):
                 score = attn[self.attn_layer][:, :p0].contiguous().unsqueeze(0)          # [1,h,N] (mhim.py:224-225)
             return z.view(1, -1), score
         wp = self.predictor.weight.data if self.attn2score else None
-        st = ops.abmil_pool_fwd(self._scorer(wa_frag), H, T2, wp=wp)
+        st = ops.abmil_pool_fwd(self._scorer(wa_frag), H, T2, wp=wp, bp=self.predictor.bias.data if self.attn2score else None)
         if self.attn2score:
-            score = ops.pseudo_score(st.s[:p0], st.stats, st.cproj[:p0], self.predictor.bias.data)
+            score = st.pscore                                  # written by the pool's finalize launch (mhimx_pseudo_score's bits)
         else:
             score = ops.softmax_from_stats(st.s, st.stats)[:p0]
         return st.z.view(1, -1), score.view(1, -1)

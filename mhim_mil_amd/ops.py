@@ -168,7 +168,7 @@ class ScorerW:
 class PoolState:
     """Buffers of one pool forward (kept for the backward)."""
 
-    def __init__(self, T1, T2, C_classes=0, wp=None, device=None):
+    def __init__(self, T1, T2, C_classes=0, wp=None, device=None, bp=None):
         dev = T1.device
         M1 = T1.shape[0]
         M2 = 0 if T2 is None else T2.shape[0]
@@ -179,6 +179,8 @@ class PoolState:
         self.z = torch.empty(T1.shape[1], device=dev)
         self.cproj = torch.empty((M, C_classes), device=dev) if wp is not None else None
         self.wp = wp
+        self.bp = bp
+        self.pscore = torch.empty(M1, device=dev) if (wp is not None and bp is not None) else None
         self.ws = None
 
     def io(self, sc: ScorerW):
@@ -188,13 +190,14 @@ class PoolState:
             self.ws = torch.empty(nbytes, device=self.T1.device, dtype=torch.uint8)
         return L.PoolIO(T1=_p(self.T1), M1=self.M1, T2=_p(self.T2), M2=self.M2, s=_p(self.s), stats=_p(self.stats),
                         z=_p(self.z), u_pre=None, wp=_p(self.wp), C=0 if self.cproj is None else self.cproj.shape[1],
-                        cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel())
+                        cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel(), bp=_p(self.bp), pscore=_p(self.pscore))
 
 
-def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None):
-    """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj)."""
-    _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp")
-    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp)
+def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None):
+    """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj; with ``bp`` also ``pscore`` [M1], the
+    pseudo score of the T1 instances, written by the pool's finalize launch)."""
+    _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp"); _chk(bp, name="bp")
+    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp)
     io = st.io(sc)
     L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd")
     return st

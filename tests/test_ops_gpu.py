@@ -517,3 +517,18 @@ def test_fused_scorer_backward_and_transposed_fragment_image():
     g1 = ops.abmil_pool_bwd(sc, st, gz, wat, need_bias=True, wa_t_frag=f5)
     for k in ("dT1", "d_wa", "d_wc", "d_bc", "d_ba"):
         assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("M2", [0, 5])
+def test_pool_finalize_writes_the_pseudo_score(M2):
+    """pool_io.pscore (written by the pool's finalize launch) == mhimx_pseudo_score on the same s / stats / cproj, bit for bit."""
+    ops = _ops()
+    E, A, M1, Cc = 512, 128, 2500, 2
+    wa, wc, _, _, _, _ = _scorer_params(65, E, A, False, False)
+    d = lambda t: t.to(DEV)
+    T1, T2 = d(rnd(66, (M1, E)).abs()), (d(rnd(67, (M2, E))) if M2 else None)
+    wp, bp = d(rnd(68, (Cc, E), std=0.05)), d(rnd(69, (Cc,), std=0.1))
+    sc = ops.ScorerW(d(wa), d(wc), 1, prec="bf16x3")
+    st = ops.abmil_pool_fwd(sc, T1, T2, wp=wp, bp=bp)
+    ref = ops.pseudo_score(st.s[:M1], st.stats, st.cproj[:M1], bp)
+    assert torch.equal(st.pscore, ref)
