@@ -20,6 +20,13 @@ int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes);
 
 constexpr int MCA_THREADS = 256;
+#ifdef MHIMX_MCA_PROF
+__device__ unsigned long long mca_prof[16];
+#define MCA_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 100) mca_prof[i] = wall_clock64(); } while (0)
+extern "C" int mhimx_mca_prof_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mca_prof), 16 * 8); }
+#else
+#define MCA_STAMP(i)
+#endif
 
 MHIMX_DEV float block_reduce_sum(float v, float* red /*[4]*/) {
   v = wave_sum(v);
@@ -51,6 +58,7 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* 
                                                                    uint64_t seed0, const uint64_t* __restrict__ tick, float* __restrict__ dots,
                                                                    float* __restrict__ pm, float* __restrict__ pl,
                                                                    float* __restrict__ po) {
+  MCA_STAMP(0);
   const uint64_t seed = eff_seed(seed0, tick);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int inner = heads * 64;
@@ -77,36 +85,48 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* 
       kbuf[rr][hh] = ok ? KV[r * 2 * inner + h * 64 + lane] : 0.f;
       vbuf[rr][hh] = ok ? KV[r * 2 * inner + inner + h * 64 + lane] : 0.f;
     }
+  MCA_STAMP(1);
+#ifdef MHIMX_MCA_PROF
+  if (threadIdx.x == 0 && blockIdx.x == 100) mca_prof[8] = __float_as_uint(kbuf[0][0] + q[0][0]);   // force the loads
+#endif
+  MCA_STAMP(2);
+  // One wave per SIMD: a dependent instruction chain runs at its full latency.  So first ALL the block's dot products - 40
+  // independent wave reductions whose DPP steps interleave - then, per (head, query), a plain two-pass softmax over the
+  // block's MCA_ROWS rows in registers (no running max to rescale).
+  float d[MCA_ROWS][MCA_HPW][KQ];
 #pragma unroll
-  for (int rr = 0; rr < MCA_ROWS; ++rr) {
-    const int64_t r = r0 + rr;
-    if (r >= r1) break;
+  for (int rr = 0; rr < MCA_ROWS; ++rr)
 #pragma unroll
-    for (int hh = 0; hh < MCA_HPW; ++hh) {
-      const int h = wave + 4 * hh;
-      if (h >= heads) continue;
-      const float kv = kbuf[rr][hh];
-      const float vv = vbuf[rr][hh];
+    for (int hh = 0; hh < MCA_HPW; ++hh)
 #pragma unroll
-      for (int i = 0; i < KQ; ++i) {
-        if (i >= kq) continue;
-        const float d = wave_sum(q[hh][i] * kv);
-        if (lane == 0) dots[((int64_t)h * kq + i) * R + r] = d;
+      for (int i = 0; i < KQ; ++i) d[rr][hh][i] = wave_sum(q[hh][i] * kbuf[rr][hh]);
+#pragma unroll
+  for (int hh = 0; hh < MCA_HPW; ++hh) {
+    const int h = wave + 4 * hh;
+    if (h >= heads) continue;
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (i >= kq) continue;
+      float mm = -INFINITY;
+#pragma unroll
+      for (int rr = 0; rr < MCA_ROWS; ++rr)
+        if (r0 + rr < r1) mm = fmaxf(mm, d[rr][hh][i]);
+      float ll = 0.f, oo = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < MCA_ROWS; ++rr) {
+        const int64_t r = r0 + rr;
+        if (r >= r1) continue;
+        if (lane == 0) dots[((int64_t)h * kq + i) * R + r] = d[rr][hh][i];
         float ks = 1.f;
         if (drop_p > 0.f) ks = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? keep_scale : 0.f;
-        if (d > m[hh][i]) {
-          const float sc = (m[hh][i] == -INFINITY) ? 0.f : __expf(m[hh][i] - d);
-          l[hh][i] = l[hh][i] * sc + 1.f;
-          o[hh][i] = o[hh][i] * sc + ks * vv;
-          m[hh][i] = d;
-        } else {
-          const float p = __expf(d - m[hh][i]);
-          l[hh][i] += p;
-          o[hh][i] += p * ks * vv;
-        }
+        const float p = __expf(d[rr][hh][i] - mm);
+        ll += p;
+        oo += p * ks * vbuf[rr][hh];
       }
+      m[hh][i] = mm; l[hh][i] = ll; o[hh][i] = oo;
     }
   }
+  MCA_STAMP(3);
 #pragma unroll
   for (int hh = 0; hh < MCA_HPW; ++hh) {
     const int h = wave + 4 * hh;
@@ -119,6 +139,7 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_fwd_part_kernel(const float* 
       po[slot * 64 + lane] = o[hh][i];
     }
   }
+  MCA_STAMP(4);
 }
 
 // grid (heads*k), 1024 threads (16 waves split the partial blocks): merge the per-block partials ->
