@@ -5,6 +5,8 @@
     'mhim' / 'mhim_pure'  -> mhim.MHIM                     (modules/mhim.py)
     'abmil'               -> DAttention                    (modules/abmil.py:145-251: biased scorer, tanh, classifier)
     'gabmil'              -> AttentionGated                (modules/abmil.py:51-143: D = 384, tanh x sigmoid gate)
+    'transmil'            -> TransMIL                      (modules/transmil.py:66-175: wrap-padded tokens, cls token, two Nystrom
+                                                            TransLayers around a PPEG, LayerNorm, classifier)
 
 Same parameter names and shapes as the reference modules (a reference checkpoint loads with ``load_state_dict``), the
 reference initialisation (xavier-normal weights, zero biases: abmil.py:8-21), and trainable through autograd: the
@@ -12,7 +14,7 @@ embedding and the scorer + softmax pool are ``torch.autograd.Function``s over li
 activation / counter-based dropout; mhimx_abmil_pool_fwd / _bwd with the bias gradients).  Supported configuration: the
 factory's defaults (``mil_norm=None``, ``pos=None``, ``embed_feat=True``); the gated scorer's inner dropouts
 (abmil.py:96-98, active only when ``dropout`` is set) are not fused into the scorer kernel: AttentionGated raises in
-training mode when ``dropout > 0``.  'transmil', CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
+training mode when ``dropout > 0``.  CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
 """
 from __future__ import annotations
 
@@ -26,26 +28,27 @@ from .mhim import MHIM
 
 
 class _EmbedFn(torch.autograd.Function):
-    """H = dropout(act(x W^T + b)) in one GEMM launch; backward: act/dropout backward + bias column sums in one pass, then
-    dW = dPre^T x (the bag x is data: no input gradient)."""
+    """H = dropout(act(x[rows] W^T + b)) in one GEMM launch (``rows``: optional row gather, fused into the A loads); backward:
+    act/dropout backward + bias column sums in one pass, then dW = dPre^T x[rows] (the bag x is data: no input gradient)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, drop_p, seed):
+    def forward(ctx, x, w, b, act, drop_p, seed, rows=None):
         need_pre = act == L.ACT["gelu"]
-        pre = torch.empty((x.shape[0], w.shape[0]), device=x.device) if need_pre else None
-        H = ops.gemm_nt(x, w, bias=b, act=act, pre=pre, drop_p=drop_p, drop_seed=seed, prec="bf16x3")
-        ctx.save_for_backward(x, H, pre)
+        M = x.shape[0] if rows is None else rows.shape[0]
+        pre = torch.empty((M, w.shape[0]), device=x.device) if need_pre else None
+        H = ops.gemm_nt(x, w, rows=rows, bias=b, act=act, pre=pre, drop_p=drop_p, drop_seed=seed, prec="bf16x3")
+        ctx.save_for_backward(x, H, pre, rows)
         ctx.cfg = (act, drop_p, seed, b is not None)
         return H
 
     @staticmethod
     def backward(ctx, dH):
-        x, H, pre = ctx.saved_tensors
+        x, H, pre, rows = ctx.saved_tensors
         act, drop_p, seed, has_b = ctx.cfg
         g = dH.contiguous().clone()
-        g, db = ops.act_bwd(g, H, pre, act, drop_p, seed, None, None, want_colsum=True)
-        dw = ops.gemm_tn(g, x, splits=8 if x.shape[0] >= 2048 else 1, prec="bf16x3")
-        return None, dw, (db if has_b else None), None, None, None
+        g, db = ops.act_bwd(g, H, pre, act, drop_p, seed, None, rows, want_colsum=True)
+        dw = ops.gemm_tn(g, x, rows=rows, splits=8 if g.shape[0] >= 2048 else 1, prec="bf16x3")
+        return None, dw, (db if has_b else None), None, None, None, None
 
 
 class _PoolFn(torch.autograd.Function):
@@ -97,10 +100,10 @@ class _AttnMILBase(nn.Module):
         self._step = getattr(self, "_step", 0) + 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
-    def _embed(self, x):
+    def _embed(self, x, rows=None):
         f = self.feature[0]
         p = self.embed_drop if self.training else 0.0
-        return _EmbedFn.apply(x, f.weight, f.bias, L.ACT[self.act], float(p), self._seed())
+        return _EmbedFn.apply(x, f.weight, f.bias, L.ACT[self.act], float(p), self._seed(), rows)
 
 
 class DAttention(_AttnMILBase):
@@ -166,6 +169,59 @@ class AttentionGated(_AttnMILBase):
         return NY.Linear.apply(z.view(1, -1), cl.weight, cl.bias, 0.0, 0, None)
 
 
+class TransMIL(_AttnMILBase):
+    """modules/transmil.py:66-175 (pos='ppeg', mil_norm=None): tokens wrap-padded to a square (transmil.py:124-128) - a row gather
+    fused into the embedding GEMM, no copy - then the encoder of SURVEY rows A9/A10 (mhim_mil_amd/nystrom.py) and a classifier.
+    Bags need at least 37 patches (a 7 x 7 grid for the PPEG stencils, as the MHIM encoder's PPEG pads below that)."""
+
+    def __init__(self, input_dim, n_classes, dropout, act, mil_norm=None, mil_bias=True, inner_dim=512, embed_feat=True, pos="ppeg",
+                 n_heads=8, **kwargs):
+        super().__init__()
+        if mil_norm is not None or pos != "ppeg" or not embed_feat or inner_dim != 512 or n_heads != 8:
+            raise L.MhimxError("TransMIL (mhimx): built for the factory defaults (mil_norm=None, pos='ppeg', inner_dim=512, 8 heads)")
+        self.act = "gelu" if act.lower() == "gelu" else "relu"
+        self.embed_drop = 0.25 if dropout else 0.0
+        self.feature = nn.Sequential(*([_linear(input_dim, inner_dim, mil_bias), _Slot()] + ([_Slot()] if dropout else [])))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, inner_dim) * 1e-6)      # transmil.py:99-100
+        self.layer1, self.layer2 = NY.TransLayer(inner_dim), NY.TransLayer(inner_dim)
+        self.pos_layer = NY._PPEG(inner_dim)
+        self.norm = NY._P(weight=torch.ones(inner_dim), bias=torch.zeros(inner_dim))
+        self.classifier = _linear(inner_dim, n_classes, mil_bias)
+        self.n_classes = n_classes
+
+    def forward(self, x, return_attn=False, return_act=False, **kwargs):
+        x = self._check(x)
+        n = x.shape[0]
+        side = int(torch.ceil(torch.sqrt(torch.tensor(float(n)))).item())
+        if side < 7:
+            raise L.MhimxError("TransMIL (mhimx): bags need at least 37 patches (7 x 7 PPEG grid)")
+        add = side * side - n
+        rows = None
+        if add > 0:                                                      # x = cat([x, x[:add]]) as a gather index
+            rows = torch.cat([torch.arange(n, device=x.device), torch.arange(add, device=x.device)])
+        h = self._embed(x, rows)
+        tr = self.training
+        s1, s2 = self._seed(), self._seed()
+        t = torch.cat([self.cls_token.view(1, -1), h], 0)
+        attn = []
+        if return_attn:
+            t, a, v = self.layer1(t, True, False, s1, None, tr)
+            attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))     # transmil.py:138-141
+        else:
+            t = self.layer1(t, False, False, s1, None, tr)
+        t = torch.cat([t[:1], self.pos_layer(t[1:])], 0)
+        if return_attn:
+            t, a, _ = self.layer2(t, True, False, s2, None, tr)
+            attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))
+        else:
+            t = self.layer2(t, False, False, s2, None, tr)
+        z = NY.LayerNorm.apply(t[:1].contiguous(), self.norm.weight, self.norm.bias)
+        logits = NY.Linear.apply(z, self.classifier.weight, self.classifier.bias, 0.0, 0, None)
+        if not return_attn:
+            return logits
+        return [logits, attn, v] if return_act else [logits, attn]
+
+
 def build_model(model_name, **params):
     """The kernel-sharing branches of modules/__init__.py:71-116; ``params`` are the constructor arguments the reference's
     factory assembles (``genera_model_params`` / the MHIM ``model_params``)."""
@@ -180,4 +236,6 @@ def build_model(model_name, **params):
         return DAttention(**params)
     if name == "gabmil":
         return AttentionGated(**params)
+    if name == "transmil":
+        return TransMIL(**params)
     raise NotImplementedError(f"model {model_name!r}: not a branch of the MHIM / attention-MIL hot path (SURVEY.md §8)")

@@ -453,6 +453,27 @@ def g14_standalone_train(ns):
               logits=logits[0].detach().numpy(), loss=loss.item(), **extra, **_compact_all("grad", _grads(m)))
 
 
+def g15_standalone_transmil(ns):
+    """Standalone TransMIL (modules/transmil.py) in eval mode (its attention dropouts off): logits, the two cls-row attention
+    maps and every parameter gradient of CE(logits, label) - fixtures for mhim_mil_amd/standalone.TransMIL."""
+    if getattr(ns, "transmil", None) is None:
+        print("  (modules/transmil.py not importable: skipped)")
+        return
+    d = 64
+    for n, act, pseed in ((300, "relu", 47), (441, "gelu", 48)):           # 300 -> 18 x 18 grid with 24 wrapped tokens; 441 = 21 x 21
+        x = _x(34 + n, n, d)
+        m = _fill_module(ns.transmil.TransMIL(d, 2, dropout=False, act=act), pseed).eval()
+        out = m(x.clone(), return_attn=True)
+        logits, attn = out[0], out[1]
+        loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([1]))
+        loss.backward()
+        _save(f"g15_standalone_transmil_n{n}_{act}", dict(n=n, d=d, xseed=34 + n, pseed=pseed, std=0.05, label=1, act=act,
+                                                          keys=list(m.state_dict().keys()),
+                                                          shapes=[list(v.shape) for v in m.state_dict().values()]),
+              logits=logits[0].detach().numpy(), loss=loss.item(), attn0=attn[0][0].detach().numpy(), attn1=attn[1][0].detach().numpy(),
+              **_compact_all("grad", _grads(m)))
+
+
 def g12_cosine_scheduler(ns):
     """utils.cosine_scheduler (utils.py:199-210) for the two schedules the trainer builds (modules/__init__.py:72-75,177-181).
     utils.py imports the whole training stack, so only this function's AST node is compiled and run."""
@@ -475,7 +496,7 @@ def main():
     only = set(sys.argv[1:])                     # python -m oracle.gen_golden g14_standalone_train  -> just that family
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
                g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil,
-               g14_standalone_train):
+               g14_standalone_train, g15_standalone_transmil):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -85,3 +85,34 @@ def test_factory_and_guards():
         g(torch.zeros(1, 8, 64, device=DEV))
     with pytest.raises(L.MhimxError):
         build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="ln")
+
+
+@pytest.mark.parametrize("name", G.names("g15_standalone_transmil"))
+def test_standalone_transmil_fixture(name):
+    """Standalone TransMIL (wrap-padded tokens as a gather in the embedding GEMM, Nystrom layers, PPEG) vs the fixture made by
+    importing modules/transmil.py: logits, both attention maps, every parameter gradient (eval mode: attention dropouts off)."""
+    from mhim_mil_amd.standalone import build_model
+    meta, a = G.load(name)
+    m = build_model("transmil", input_dim=meta["d"], n_classes=2, dropout=False, act=meta["act"])
+    sd = {k: torch.from_numpy(synth.normal(meta["pseed"], tuple(shape), std=meta["std"], lane=i + 1).astype(np.float32))
+          for i, (k, shape) in enumerate(zip(meta["keys"], meta["shapes"]))}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    m = m.to(DEV).eval()
+    x = _x(meta)
+    logits, attn = m(x, return_attn=True)
+    loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([meta["label"]], device=DEV))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy().reshape(-1), a["logits"].reshape(-1), atol=1e-4, rtol=1e-3)
+    for i, key in enumerate(("attn0", "attn1")):
+        got = attn[i].detach().cpu().numpy().reshape(a[key].shape)
+        np.testing.assert_allclose(got, a[key], atol=2e-6, rtol=2e-3, err_msg=key)
+    grads = G.tagged(a, "grad")
+    params = dict(m.named_parameters())
+    assert set(grads) == set(params)
+    rel_floor = 2e-2 if meta["act"] == "relu" else 5e-3
+    for k, exp in grads.items():
+        g = params[k].grad
+        assert g is not None, k
+        scale = max(float(np.abs(exp["full"]).max()) if "full" in exp else float(exp["norm"]) / np.sqrt(max(1, g.numel())), 1e-12)
+        G.check_compact(g.cpu().numpy(), exp, rtol=5e-3, atol=max(rel_floor * scale, 1e-7), what=f"{name}:{k}")
