@@ -298,6 +298,8 @@ typedef struct {
   float drop_p; uint64_t drop_seed;   /* MCA dropout (merge.py:33,40), hashed RNG; 0 = off           */
   int32_t prec;
   const uint64_t* drop_tick;          /* optional device step counter mixed into drop_seed           */
+  const float* wkv_frag;              /* optional: prep kind-4 image of wkv [2*heads*dim_head, E]: with it (E = 512, 8 x 64) the K/V
+                                         projection, its dots and the softmax partials are ONE kernel per row tile       */
 } mhimx_merge;
 int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
 /* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */

@@ -88,7 +88,8 @@ class Merge(C.Structure):
                 ("q_param", c_f32p), ("ln_w", c_f32p), ("ln_b", c_f32p),
                 ("wkv", c_f32p), ("wq", c_f32p), ("wo", c_f32p), ("bo", c_f32p),
                 ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
-                ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p)]
+                ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p),
+                ("wkv_frag", c_f32p)]
 
 
 class MergeGrad(C.Structure):

@@ -17,6 +17,9 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
                   int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
                   mhimx_reduce_list* defer);
 int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g);
+bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* wkv_frag, const float* xn, const float* KV);
+int mca_fused_fwd(hipStream_t st, const float* xn, int64_t R, const float* wkv_frag, const float* Q, int kq, int heads, float scale,
+                  float drop_p, uint64_t seed, const uint64_t* tick, float* KV, float* dots, float* pm, float* pl, float* po);
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes);
 
 constexpr int MCA_THREADS = 256;
@@ -513,23 +516,32 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
     if (int r = layernorm_fwd(st, m->q_param, k, E, m->ln_w, m->ln_b, w.gq, w.gmean, w.grstd)) return r;
   }
   mhimx_gemm_nt_args g = {};
-  g.A = w.xn; g.lda = E; g.B = m->wkv; g.ldb = E; g.C = w.KV; g.ldc = 2 * I; g.M = R; g.N = 2 * I; g.K = E; g.prec = fprec;
-  g.ws = w.nt_ws; g.ws_floats = w.nt_ws_floats;
-  if (int r = gemm_nt(st, g)) return r;
-  if (!pre_ok) {
-    g = {};
-    g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
-    if (int r = gemm_nt(st, g)) return r;
-  }
   const float scale = 1.0f / sqrtf((float)m->dim_head);
-  if (int r = dispatch_kq(k, [&](auto kqc) {
-        constexpr int KQ = decltype(kqc)::value;
-        hipLaunchKernelGGL(mca_fwd_part_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, R, (int)H, (int)k, scale,
-                           m->drop_p, m->drop_seed, m->drop_tick, w.P, w.pm, w.pl, w.po);
-        MHIMX_LAUNCH_CHECK();
-        return 0;
-      })) return r;
-  hipLaunchKernelGGL(mca_fwd_final_kernel, dim3((unsigned)(H * k)), dim3(1024), 0, st, w.pm, w.pl, w.po, w.nb, (int)H, (int)k, w.stats, w.O);
+  const bool fused = pre_ok && mca_fused_ok(E, H, m->dim_head, k, m->wkv_frag, w.xn, w.KV) && m->prec != MHIMX_PREC_F32;
+  int nparts = w.nb;
+  if (fused) {
+    // K/V projection + dots + softmax partials of a row tile in one kernel (mca_fused.hip); Q comes from the prologue launch
+    nparts = mca_fused_fwd(st, w.xn, R, m->wkv_frag, w.Q, (int)k, (int)H, scale, m->drop_p, m->drop_seed, m->drop_tick, w.KV, w.P, w.pm,
+                           w.pl, w.po);
+    if (nparts < 0) return nparts;
+  } else {
+    g.A = w.xn; g.lda = E; g.B = m->wkv; g.ldb = E; g.C = w.KV; g.ldc = 2 * I; g.M = R; g.N = 2 * I; g.K = E; g.prec = fprec;
+    g.ws = w.nt_ws; g.ws_floats = w.nt_ws_floats;
+    if (int r = gemm_nt(st, g)) return r;
+    if (!pre_ok) {
+      g = {};
+      g.A = w.gq; g.lda = E; g.B = m->wq; g.ldb = E; g.C = w.Q; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = fprec;
+      if (int r = gemm_nt(st, g)) return r;
+    }
+    if (int r = dispatch_kq(k, [&](auto kqc) {
+          constexpr int KQ = decltype(kqc)::value;
+          hipLaunchKernelGGL(mca_fwd_part_kernel<KQ>, dim3((unsigned)w.nb), dim3(MCA_THREADS), 0, st, w.KV, w.Q, R, (int)H, (int)k, scale,
+                             m->drop_p, m->drop_seed, m->drop_tick, w.P, w.pm, w.pl, w.po);
+          MHIMX_LAUNCH_CHECK();
+          return 0;
+        })) return r;
+  }
+  hipLaunchKernelGGL(mca_fwd_final_kernel, dim3((unsigned)(H * k)), dim3(1024), 0, st, w.pm, w.pl, w.po, nparts, (int)H, (int)k, w.stats, w.O);
   MHIMX_LAUNCH_CHECK();
   MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd: update_q needs q_new");
   MHIMX_CHECK_ARG(I % 4 == 0, "merge_fwd: inner width must be a multiple of 4");

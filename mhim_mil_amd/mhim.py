@@ -311,6 +311,10 @@ class MHIM(nn.Module):
                     jobs.append((ops.PREP_FRAG_T, att.attention[0].weight.data, prep["wa_t_frag"]))
             if self.merge_enable:
                 m = self.merge
+                wkv = m.attn.to_kv.weight.data
+                if wkv.shape[0] % 32 == 0 and wkv.shape[1] % 16 == 0:     # matrix-core image of Wkv (one-kernel cross attention)
+                    prep["wkv_frag"] = torch.empty_like(wkv)
+                    jobs.append((ops.PREP_FRAG, wkv, prep["wkv_frag"]))
                 prep["merge_t"] = (tr(m.attn.to_kv.weight.data), tr(m.attn.to_q.weight.data), tr(m.attn.to_out[0].weight.data))
                 prep["q_old"] = torch.empty_like(m.global_q_mm.data)
                 jobs.append((ops.PREP_COPY, m.global_q_mm.data, prep["q_old"]))
@@ -322,7 +326,7 @@ class MHIM(nn.Module):
             ops.prep_batch(jobs)
         return prep
 
-    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None):
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None):
         m = self.merge
         if need_t and tr is None:
             tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
@@ -332,7 +336,7 @@ class MHIM(nn.Module):
         return ops.MergeW(q, m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
                           m.attn.to_q.weight.data, m.attn.to_out[0].weight.data, m.attn.to_out[0].bias.data, m.g_q_mm,
                           drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr,
-                          drop_tick=self._tick)
+                          drop_tick=self._tick, wkv_frag=wkv_frag)
 
     # ------------------------------------------------------------------ kernels: feature rows
     def _check_x(self, x):
@@ -413,7 +417,7 @@ class MHIM(nn.Module):
         saved = {"H": H, "Hbuf": Hbuf, "PRE": PRE, "DACT": DACT, "prep": prep}
         sc = self._scorer(prep.get("wa_frag"))
         if merging:
-            mw = self._merge_w(plan, need_t=False)
+            mw = self._merge_w(plan, need_t=False, wkv_frag=prep.get("wkv_frag"))
             q_old = prep.get("q_old")
             if q_old is None and plan.training:
                 q_old = self.merge.global_q_mm.data.clone()

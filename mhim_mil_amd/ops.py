@@ -306,8 +306,8 @@ def compose_ids(a, b):
 # ------------------------------------------------------------------------------------------------ merge
 class MergeW:
     def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
-                 prec="f16s", transposes=None, drop_tick=None):
-        self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo]
+                 prec="f16s", transposes=None, drop_tick=None, wkv_frag=None):
+        self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo, wkv_frag]
         for t in self.t:
             _chk(t, name="merge weight")
         self.k, self.E = q_param.shape[-2], q_param.shape[-1]
@@ -316,7 +316,8 @@ class MergeW:
         self.c = L.Merge(E=self.E, k=self.k, heads=heads, dim_head=dim_head, q_param=_p(q_param), ln_w=_p(ln_w),
                          ln_b=_p(ln_b), wkv=_p(wkv), wq=_p(wq), wo=_p(wo), bo=_p(bo), wkv_t=_p(self.tr[0]),
                          wq_t=_p(self.tr[1]), wo_t=_p(self.tr[2]), mm=float(mm), drop_p=float(drop_p),
-                         drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec), drop_tick=_p(drop_tick))
+                         drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec), drop_tick=_p(drop_tick),
+                         wkv_frag=_p(wkv_frag))
 
     def ws_for(self, R, device):
         n = L.lib().mhimx_merge_ws_bytes(R, self.E, self.k, self.heads, self.dim_head)
