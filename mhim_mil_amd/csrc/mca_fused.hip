@@ -18,6 +18,13 @@ typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
 typedef float mf_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
 
+#ifdef MHIMX_MF_PROF
+__device__ unsigned long long mf_prof[16];
+#define MF_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 50) mf_prof[i] = wall_clock64(); } while (0)
+extern "C" int mhimx_mf_prof_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mf_prof), 16 * 8); }
+#else
+#define MF_STAMP(i)
+#endif
 constexpr int MF_ROWS = 32, MF_E = 512, MF_I = 512, MF_LD = MF_E + 4, MF_KVLD = 256 + 4, MF_THREADS = 256, MF_MAXK = 16;
 constexpr size_t MF_SMEM = (size_t)(MF_ROWS * MF_LD + MF_ROWS * MF_KVLD + MF_MAXK * 128 + 3 * MF_ROWS * 2 * MF_MAXK + 4 * MF_MAXK) * sizeof(float);
 
@@ -51,6 +58,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
   const int inner = heads * 64;                         // = 512
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 
+  MF_STAMP(0);
   // ---- 1. rows and queries -> LDS
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -65,6 +73,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
     qs[i] = Q[(int64_t)qi * inner + (2 * hg) * 64 + c] * scale;
   }
   __syncthreads();
+  MF_STAMP(1);
   // ---- 2. K / V tile on the matrix cores: wave 0/1 -> K of heads 2hg, 2hg+1; wave 2/3 -> V of the same heads
   {
     const int h = 2 * hg + (wave & 1);
@@ -94,20 +103,28 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
       const int k1 = ks + 1 < KS ? ks + 1 : ks;
       const mf_f4 na0 = *reinterpret_cast<const mf_f4*>(aptr + 16 * k1), na1 = *reinterpret_cast<const mf_f4*>(aptr + 16 * k1 + 4);
       const int kn = ks + PF < KS ? ks + PF : ks;
+      // term-major issue order: two MFMAs into the same accumulator are at least two others apart (a dependent MFMA issued
+      // back to back waits out the first one's full latency)
+      mf_b8 bh[2], bl[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const mf_b8 bh = __builtin_bit_cast(mf_b8, bh_[ks % PF][nt]), bl = __builtin_bit_cast(mf_b8, bl_[ks % PF][nt]);
+        bh[nt] = __builtin_bit_cast(mf_b8, bh_[ks % PF][nt]);
+        bl[nt] = __builtin_bit_cast(mf_b8, bl_[ks % PF][nt]);
         bh_[ks % PF][nt] = *reinterpret_cast<const mf_f4*>(fptr + (nt * KS + kn) * 512);
         bl_[ks % PF][nt] = *reinterpret_cast<const mf_f4*>(fptr + (nt * KS + kn) * 512 + 4);
-        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
-        acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2[nt], 0, 0, 0);
       }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], acc2[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], acc2[nt], 0, 0, 0);
       mf_b8 nh, nl;
       mf_split(na0, na1, nh, nl);
       ah = nh;
       al = nl;
     }
+    MF_STAMP(2);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
       }
   }
   __syncthreads();
+  MF_STAMP(3);
   // ---- 3. dots: 8 lanes per row = 2 heads x 4 quarters of the 64-dim dot product
   {
     const int row = tid >> 3, hs = (tid >> 2) & 1, qt = tid & 3;
@@ -145,6 +163,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
     }
   }
   __syncthreads();
+  MF_STAMP(4);
   // ---- 4. per (head, query): max over the tile's rows, probabilities, sum
   const int nrows = (int)((R - row0) < MF_ROWS ? (R - row0) : MF_ROWS);
   if (tid < 2 * kq) {
@@ -167,6 +186,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
     pk[(r * 2 + hs) * MF_MAXK + i] = k;
   }
   __syncthreads();
+  MF_STAMP(5);
   if (tid < 128) {
     const int hs = tid >> 6, c = tid & 63;
     const int h = 2 * hg + hs;
@@ -182,6 +202,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
       po[slot * 64 + c] = o;
     }
   }
+  MF_STAMP(6);
 }
 
 bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* wkv_frag, const float* xn, const float* KV) {

@@ -91,10 +91,10 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     __syncthreads();
     SF_STAMP(1);
     // ---- 2. U tile on the matrix cores
-    // two accumulators: the cross terms and hi*hi form independent MFMA chains
-    sf_f32x16 acc, acc2;
+    // one accumulator per bf16x3 term: an MFMA into the accumulator of the previous one waits out its full latency
+    sf_f32x16 acc, acc2, acc3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
     if (fptr) {
       // B fragments ready-made (prep kind 4): two coalesced 16-byte loads per k-step, four k-steps ahead
       constexpr int PF = 4;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
         bl_[ks % PF] = *reinterpret_cast<const sf_f4*>(fptr + 512 * kn + 4);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc3, 0, 0, 0);
       }
     } else {
       sf_f4 b0 = *reinterpret_cast<const sf_f4*>(bptr), b1 = *reinterpret_cast<const sf_f4*>(bptr + 4);
@@ -129,13 +129,13 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
         sf_split(b0, b1, bh, bl);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc3, 0, 0, 0);
         b0 = nb0;
         b1 = nb1;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i] + acc3[i];
     SF_STAMP(2);
     // ---- 3. epilogue: acc[i] = U[row = 8*(i>>2) + 4*kg + (i&3)][n_col]
 #pragma unroll
@@ -331,12 +331,15 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
           nh[nt] = *reinterpret_cast<const sf_f4*>(fptr + (nt * 8 + kn) * 512);
           nl[nt] = *reinterpret_cast<const sf_f4*>(fptr + (nt * 8 + kn) * 512 + 4);
         }
+        // term-major: the three MFMAs into acc[nt] are three others apart (no dependent back-to-back issue)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(sf_b8, bh_[nt]), acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(sf_b8, bl_[nt]), acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(sf_b8, bh_[nt]), acc[nt], 0, 0, 0);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const sf_b8 bh = __builtin_bit_cast(sf_b8, bh_[nt]), bl = __builtin_bit_cast(sf_b8, bl_[nt]);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
           bh_[nt] = nh[nt];
           bl_[nt] = nl[nt];
         }

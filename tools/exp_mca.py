@@ -12,12 +12,16 @@ m = MHIM(input_dim=1024, n_classes=2, merge_enable=True, merge_k=5).to(dev).trai
 H = torch.randn(985, 512, device=dev).abs()
 mw = m._merge_w(None)
 lib = L.lib()
-lib.mhimx_mca_prof_read.argtypes = [C.c_void_p]
+lib.mhimx_mf_prof_read.argtypes = [C.c_void_p]
+wkv = m.merge.attn.to_kv.weight.data
+frag = torch.empty_like(wkv)
+ops.prep_batch([(ops.PREP_FRAG, wkv, frag)])
+mw = m._merge_w(None, wkv_frag=frag)
 for it in range(4):
     z, _, mws = ops.merge_fwd(mw, H, update_q=False)
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 16)()
-    lib.mhimx_mca_prof_read(C.cast(buf, C.c_void_p))
+    lib.mhimx_mf_prof_read(C.cast(buf, C.c_void_p))
     t = list(buf)
-    names = ["issue loads", "loads land", "row loop", "partials out"]
-    print(" ".join(f"{n}={(t[i+1]-t[i])/100:.2f}us" for i, n in enumerate(names)), f"total={(t[4]-t[0])/100:.2f}us")
+    names = ["load", "gemm", "kv out", "dots", "softmax", "o sums"]
+    print(" ".join(f"{n}={(t[i+1]-t[i])/100:.2f}us" for i, n in enumerate(names)), f"total={(t[6]-t[0])/100:.2f}us")
