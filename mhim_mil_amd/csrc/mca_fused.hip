@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc[nt][i] = 0.f; acc2[nt][i] = 0.f; }
-    constexpr int PF = 2, KS = MF_E / 16;
+    constexpr int PF = 4, KS = MF_E / 16;
     mf_f4 bh_[PF][2], bl_[PF][2];
 #pragma unroll
     for (int q = 0; q < PF; ++q)
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
     // MFMAs are in flight - one wave per SIMD has no other wave to hide that latency behind
     mf_b8 ah, al;
     mf_split(*reinterpret_cast<const mf_f4*>(aptr), *reinterpret_cast<const mf_f4*>(aptr + 4), ah, al);
-#pragma unroll 2
+#pragma unroll 4
     for (int ks = 0; ks < KS; ++ks) {
       const int k1 = ks + 1 < KS ? ks + 1 : ks;
       const mf_f4 na0 = *reinterpret_cast<const mf_f4*>(aptr + 16 * k1), na1 = *reinterpret_cast<const mf_f4*>(aptr + 16 * k1 + 4);
@@ -164,42 +164,59 @@ __global__ __launch_bounds__(MF_THREADS) void mca_fused_fwd_kernel(
   }
   __syncthreads();
   MF_STAMP(4);
-  // ---- 4. per (head, query): max over the tile's rows, probabilities, sum
+  // ---- 4. per (head, query): a half-wave owns one (head, query) pair - lane = row: max, e^{d - max} (x dropout keep), sum by
+  // 32-lane butterflies; no serial row loops, no extra LDS round trips
   const int nrows = (int)((R - row0) < MF_ROWS ? (R - row0) : MF_ROWS);
-  if (tid < 2 * kq) {
-    const int hs = tid / kq, i = tid % kq;
-    float m = -INFINITY;
-    for (int r = 0; r < nrows; ++r) m = fmaxf(m, ds[(r * 2 + hs) * MF_MAXK + i]);
-    ms[hs * MF_MAXK + i] = m;
-  }
-  __syncthreads();
-  for (int it = tid; it < MF_ROWS * 2 * kq; it += MF_THREADS) {
-    const int r = it / (2 * kq), rem = it % (2 * kq), hs = rem / kq, i = rem % kq;
-    float p = 0.f, k = 0.f;
-    if (r < nrows) {
-      p = __expf(ds[(r * 2 + hs) * MF_MAXK + i] - ms[hs * MF_MAXK + i]);
-      float ksf = 1.f;
-      if (drop_p > 0.f) ksf = drop_keep(seed, (uint64_t)((2 * hg + hs) * kq + i), (uint32_t)(row0 + r), drop_p) ? keep_scale : 0.f;
-      k = p * ksf;
-    }
-    ps[(r * 2 + hs) * MF_MAXK + i] = p;
-    pk[(r * 2 + hs) * MF_MAXK + i] = k;
+  for (int combo = tid >> 5; combo < 2 * kq; combo += MF_THREADS / 32) {
+    const int hs = combo / kq, i = combo % kq, r = tid & 31;
+    const float d = r < nrows ? ds[(r * 2 + hs) * MF_MAXK + i] : -INFINITY;
+    float m = d;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float p = r < nrows ? __expf(d - m) : 0.f;
+    float ksf = 1.f;
+    if (drop_p > 0.f) ksf = drop_keep(seed, (uint64_t)((2 * hg + hs) * kq + i), (uint32_t)(row0 + r), drop_p) ? keep_scale : 0.f;
+    pk[(r * 2 + hs) * MF_MAXK + i] = p * ksf;
+    float l = p;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+    if (r == 0) { ms[hs * MF_MAXK + i] = m; ms[2 * MF_MAXK + hs * MF_MAXK + i] = l; }
   }
   __syncthreads();
   MF_STAMP(5);
+  // probability-weighted V sums: thread = (head, column, half of the rows); V[r, c] is read once per row for all the queries
+  {
+    const int hs = tid >> 7, rh = (tid >> 6) & 1, c = tid & 63;
+    float o[MF_MAXK];
+#pragma unroll
+    for (int i = 0; i < MF_MAXK; ++i) o[i] = 0.f;
+#pragma unroll 4
+    for (int rr = 0; rr < MF_ROWS / 2; ++rr) {
+      const int r = rh * (MF_ROWS / 2) + rr;
+      const float v = KVs[r * MF_KVLD + 128 + 64 * hs + c];
+      const mf_f4* pr = reinterpret_cast<const mf_f4*>(pk + (r * 2 + hs) * MF_MAXK);
+#pragma unroll
+      for (int q = 0; q < MF_MAXK / 4; ++q) {
+        if (4 * q < kq) {
+          const mf_f4 p4 = pr[q];
+          o[4 * q] += p4[0] * v; o[4 * q + 1] += p4[1] * v; o[4 * q + 2] += p4[2] * v; o[4 * q + 3] += p4[3] * v;
+        }
+      }
+    }
+    float* osum = Xs;                                  // [2 halves][2 heads][16][64] (the row tile is dead by now)
+#pragma unroll
+    for (int i = 0; i < MF_MAXK; ++i)
+      if (i < kq) osum[((rh * 2 + hs) * MF_MAXK + i) * 64 + c] = o[i];
+  }
+  __syncthreads();
   if (tid < 128) {
     const int hs = tid >> 6, c = tid & 63;
     const int h = 2 * hg + hs;
+    const float* osum = Xs;
     for (int i = 0; i < kq; ++i) {
-      float l = 0.f, o = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < MF_ROWS; ++r) {
-        l += ps[(r * 2 + hs) * MF_MAXK + i];
-        o += pk[(r * 2 + hs) * MF_MAXK + i] * KVs[r * MF_KVLD + 128 + 64 * hs + c];
-      }
       const int64_t slot = (int64_t)tile * heads * kq + h * kq + i;
-      if (c == 0) { pm[slot] = ms[hs * MF_MAXK + i]; pl[slot] = l; }
-      po[slot * 64 + c] = o;
+      if (c == 0) { pm[slot] = ms[hs * MF_MAXK + i]; pl[slot] = ms[2 * MF_MAXK + hs * MF_MAXK + i]; }
+      po[slot * 64 + c] = osum[((0 * 2 + hs) * MF_MAXK + i) * 64 + c] + osum[((1 * 2 + hs) * MF_MAXK + i) * 64 + c];
     }
   }
   MF_STAMP(6);
