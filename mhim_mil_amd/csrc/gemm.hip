@@ -243,7 +243,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(mhimx_gemm_nt_args g,
 // =================================================================================================
 constexpr int SKINNY_M = 16;
 
-MHIMX_DEV void skinny_nt_body(const mhimx_gemm_nt_args& g, int64_t block) {
+// optional on-the-fly transform of the shared left operand of a skinny pair: a(m, col) = A[m, col] * keep(seed, m, col) / (1 - p)
+// (the backward through an output dropout whose mask is the counter hash - no masked copy of A, no launch to make one), and
+// colsum[col] (+)= sum_m a(m, col)
+struct SkinnyADrop { float p; uint64_t seed; const uint64_t* tick; float* colsum; int accumulate; };
+
+MHIMX_DEV float skinny_a(const SkinnyADrop& d, uint64_t seed, float v, int64_t m, int64_t col) {
+  if (d.p <= 0.f) return v;
+  const float ks = 1.f / (1.f - d.p);
+  return drop_keep(seed, (uint64_t)m, (uint32_t)col, d.p) ? v * ks : 0.f;
+}
+
+template <bool AD>
+MHIMX_DEV void skinny_nt_body(const mhimx_gemm_nt_args& g, int64_t block, const SkinnyADrop& ad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n = block * 4 + wave;
   if (n >= g.N) return;
@@ -256,7 +268,12 @@ MHIMX_DEV void skinny_nt_body(const mhimx_gemm_nt_args& g, int64_t block) {
 #pragma unroll
     for (int m = 0; m < SKINNY_M; ++m) {
       if (m < g.M) {
-        const float4 a = *reinterpret_cast<const float4*>(g.A + (g.rows ? g.rows[m] : (int64_t)m) * g.lda + k);
+        float4 a = *reinterpret_cast<const float4*>(g.A + (g.rows ? g.rows[m] : (int64_t)m) * g.lda + k);
+        if constexpr (AD) {
+          const uint64_t sd = eff_seed(ad.seed, ad.tick);
+          a.x = skinny_a(ad, sd, a.x, m, k); a.y = skinny_a(ad, sd, a.y, m, k + 1);
+          a.z = skinny_a(ad, sd, a.z, m, k + 2); a.w = skinny_a(ad, sd, a.w, m, k + 3);
+        }
         acc[m] += a.x * w.x + a.y * w.y + a.z * w.z + a.w * w.w;
       }
     }
@@ -281,27 +298,39 @@ MHIMX_DEV void skinny_nt_body(const mhimx_gemm_nt_args& g, int64_t block) {
     *c = v;
   }
 }
-__global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) { skinny_nt_body(g, blockIdx.x); }
+__global__ __launch_bounds__(256) void skinny_nt_kernel(mhimx_gemm_nt_args g) { skinny_nt_body<false>(g, blockIdx.x, SkinnyADrop{}); }
 
-MHIMX_DEV void skinny_tn_body(const mhimx_gemm_tn_args& g, int64_t i, int64_t jblock) {
+template <bool AD>
+MHIMX_DEV void skinny_tn_body(const mhimx_gemm_tn_args& g, int64_t i, int64_t jblock, const SkinnyADrop& ad) {
   const int64_t j = jblock * 256 + threadIdx.x;
   if (j >= g.K2) return;
-  float acc = 0.f;
-  for (int64_t m = 0; m < g.M; ++m) acc += g.A[m * g.lda + i] * g.B[(g.rows ? g.rows[m] : m) * g.ldb + j];
+  float acc = 0.f, cs = 0.f;
+  uint64_t sd = 0;
+  if constexpr (AD) sd = eff_seed(ad.seed, ad.tick);
+  for (int64_t m = 0; m < g.M; ++m) {
+    float a = g.A[m * g.lda + i];
+    if constexpr (AD) a = skinny_a(ad, sd, a, m, i);
+    cs += a;
+    acc += a * g.B[(g.rows ? g.rows[m] : m) * g.ldb + j];
+  }
   float* p = g.C + i * g.ldc + j;
   *p = g.accumulate ? *p + acc : acc;
+  if constexpr (AD)
+    if (ad.colsum && j == 0) ad.colsum[i] = ad.accumulate ? ad.colsum[i] + cs : cs;
 }
-__global__ __launch_bounds__(256) void skinny_tn_kernel(mhimx_gemm_tn_args g) { skinny_tn_body(g, blockIdx.y, blockIdx.x); }
+__global__ __launch_bounds__(256) void skinny_tn_kernel(mhimx_gemm_tn_args g) { skinny_tn_body<false>(g, blockIdx.y, blockIdx.x, SkinnyADrop{}); }
 
 // Two independent skinny products that read the same few rows (the Merge backward has two such pairs: d_W = d^T x and
 // d_in = d W^T) as ONE launch: blocks [0, nt_blocks) run the NT form, the rest the TN form.  Each tiny kernel on the step's
 // serial chain costs a ~5 us launch floor.
-__global__ __launch_bounds__(256) void skinny_pair_kernel(mhimx_gemm_tn_args t, mhimx_gemm_nt_args g, int nt_blocks, int tn_jblocks) {
+template <bool AD>
+__global__ __launch_bounds__(256) void skinny_pair_kernel(mhimx_gemm_tn_args t, mhimx_gemm_nt_args g, int nt_blocks, int tn_jblocks,
+                                                          SkinnyADrop ad) {
   if ((int)blockIdx.x < nt_blocks) {
-    skinny_nt_body(g, blockIdx.x);
+    skinny_nt_body<AD>(g, blockIdx.x, ad);
   } else {
     const int b = (int)blockIdx.x - nt_blocks;
-    skinny_tn_body(t, b / tn_jblocks, b % tn_jblocks);
+    skinny_tn_body<AD>(t, b / tn_jblocks, b % tn_jblocks, ad);
   }
 }
 
@@ -315,12 +344,20 @@ static int launch_nt(hipStream_t st, const mhimx_gemm_nt_args& g, int batch = 1,
   return 0;
 }
 
-int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g) {
+// a_drop_*: the shared left operand is dropout(A) with the counter-hash mask (p, seed, tick); a_colsum (+)= its column sums
+int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g, float a_drop_p, uint64_t a_seed,
+                const uint64_t* a_tick, float* a_colsum, int a_accumulate, int use_a_drop) {
   MHIMX_CHECK_ARG(t.M > 0 && t.M <= SKINNY_M && g.M > 0 && g.M <= SKINNY_M && t.A && t.B && t.C && g.A && g.B && g.C,
                   "skinny_pair: both products need 1..%d rows and non-null operands", SKINNY_M);
   MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && aligned16(g.A) && aligned16(g.B), "skinny_pair: NT operands must be 16-byte aligned rows");
   const int nt_blocks = (int)cdiv(g.N, 4), tn_jblocks = (int)cdiv(t.K2, 256);
-  hipLaunchKernelGGL(skinny_pair_kernel, dim3((unsigned)(nt_blocks + tn_jblocks * t.K1)), dim3(256), 0, st, t, g, nt_blocks, tn_jblocks);
+  MHIMX_CHECK_ARG(!use_a_drop || (t.A == g.A && t.lda == g.lda && !g.rows && a_drop_p >= 0.f && a_drop_p < 1.f),
+                  "skinny_pair: the operand transform needs the two products to share A");
+  const SkinnyADrop ad{a_drop_p, a_seed, a_tick, a_colsum, a_accumulate};
+  if (use_a_drop)
+    hipLaunchKernelGGL(skinny_pair_kernel<true>, dim3((unsigned)(nt_blocks + tn_jblocks * t.K1)), dim3(256), 0, st, t, g, nt_blocks, tn_jblocks, ad);
+  else
+    hipLaunchKernelGGL(skinny_pair_kernel<false>, dim3((unsigned)(nt_blocks + tn_jblocks * t.K1)), dim3(256), 0, st, t, g, nt_blocks, tn_jblocks, ad);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -16,7 +16,8 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
                   int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
                   mhimx_reduce_list* defer);
-int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g);
+int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g, float a_drop_p = 0.f, uint64_t a_seed = 0,
+                const uint64_t* a_tick = nullptr, float* a_colsum = nullptr, int a_accumulate = 0, int use_a_drop = 0);
 bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* wkv_frag, const float* xn, const float* KV);
 int mca_fused_fwd(hipStream_t st, const float* xn, int64_t R, const float* wkv_frag, const float* Q, int kq, int heads, float scale,
                   float drop_p, uint64_t seed, const uint64_t* tick, float* KV, float* dots, float* pm, float* pl, float* po);
@@ -564,16 +565,14 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   MHIMX_CHECK_ARG(ar.ok(), "merge_bwd: workspace too small");
   const int gprec = m->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
   const int acc = gr->accumulate;
-  // through the output dropout and projection
-  hipLaunchKernelGGL(mca_dz0_kernel, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, dz, w.dz0, (int)k, (int)E, m->drop_p,
-                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, gr->d_bo, acc);
-  MHIMX_LAUNCH_CHECK();
+  // through the output dropout and projection: d_wo = dz0^T O and dO = dz0 Wo with dz0 = dz * keep/(1-p) applied as the two
+  // products read dz (and d_bo = column sums of dz0 on the side) - one launch, no dz0 buffer
   mhimx_gemm_tn_args t = {};
-  t.A = w.dz0; t.lda = E; t.B = w.O; t.ldb = I; t.C = gr->d_wo; t.ldc = I; t.M = k; t.K1 = E; t.K2 = I; t.splits = 1;
+  t.A = dz; t.lda = E; t.B = w.O; t.ldb = I; t.C = gr->d_wo; t.ldc = I; t.M = k; t.K1 = E; t.K2 = I; t.splits = 1;
   t.accumulate = acc; t.prec = gprec;
   mhimx_gemm_nt_args g = {};
-  g.A = w.dz0; g.lda = E; g.B = m->wo_t; g.ldb = E; g.C = w.dO; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = gprec;
-  if (int r = skinny_pair(st, t, g)) return r;                    // d_wo = dz0^T O  and  dO = dz0 Wo: one launch
+  g.A = dz; g.lda = E; g.B = m->wo_t; g.ldb = E; g.C = w.dO; g.ldc = I; g.M = k; g.N = I; g.K = E; g.prec = gprec;
+  if (int r = skinny_pair(st, t, g, m->drop_p, m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, gr->d_bo, acc, 1)) return r;
   // attention
   const float scale = 1.0f / sqrtf((float)m->dim_head);
   if (int r = dispatch_kq(k, [&](auto kqc) {
