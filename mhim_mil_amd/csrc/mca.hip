@@ -234,6 +234,15 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
 #pragma unroll
       for (int i = 0; i < KQ; ++i) dbuf[rr][hh][i] = (ok && i < kq) ? dots[((int64_t)h * kq + i) * R + r] : 0.f;
     }
+  // all the block's dO.V dot products first: 40 independent wave reductions whose steps interleave (one wave per SIMD runs a
+  // dependent chain at its full latency)
+  float dpb[MCA_ROWS][MCA_HPW][KQ];
+#pragma unroll
+  for (int rr = 0; rr < MCA_ROWS; ++rr)
+#pragma unroll
+    for (int hh = 0; hh < MCA_HPW; ++hh)
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) dpb[rr][hh][i] = wave_sum(go[hh][i] * vbuf[rr][hh]);
 #pragma unroll
   for (int rr = 0; rr < MCA_ROWS; ++rr) {
     const int64_t r = r0 + rr;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
     for (int hh = 0; hh < MCA_HPW; ++hh) {
       const int h = wave + 4 * hh;
       if (h >= heads) continue;
-      const float kv = kbuf[rr][hh], vv = vbuf[rr][hh];
+      const float kv = kbuf[rr][hh];
       float dk = 0.f, dv = 0.f;
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(MCA_THREADS) void mca_bwd_dkv_kernel(const float* _
         const float p = __expf(dbuf[rr][hh][i] - mx[hh][i]) * il[hh][i];
         float ks = 1.f;
         if (drop_p > 0.f) ks = drop_keep(seed, (uint64_t)(h * kq + i), (uint32_t)r, drop_p) ? keep_scale : 0.f;
-        const float dp = wave_sum(go[hh][i] * vv) * ks;
+        const float dp = dpb[rr][hh][i] * ks;
         const float dd = scale * p * (dp - rd[hh][i]);
         const float pd = p * ks;
         dk += dd * q[hh][i];
