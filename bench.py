@@ -33,8 +33,8 @@ ALGO_BYTES_PER_INST_STEP = 3 * D_IN * 4 + 4 * (1 + 2) + 8          # SURVEY.md Â
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--prec", default="auto", help="auto|bf16x3|f16s|f32 (matrix-core form of the feature GEMM)")
     ap.add_argument("--cpu-steps", type=int, default=400, help="oracle steps for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
