@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=400, help="oracle steps for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--dp-graph", action="store_true",
+                    help="N > 1: replay graph(fwd+bwd) | all-reduce | graph(Adam) instead of eager steps whose all-reduce overlaps the backward")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil"],
                     help="c2 (default, BASELINE.json's metric): MHIM(ABMIL) N=10k D=1024, one bag per GPU per step; "
                          "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs; "
@@ -214,7 +216,10 @@ def main():
         ops.KERNEL_EVENT_HOOK = hook
 
     graphs, graph_note = None, None
-    if not a.no_graph:
+    # N > 1 defaults to EAGER steps: the all-reduce of every gradient but the projection's starts in the middle of the backward
+    # and overlaps its longest kernels (FusedTrainer._mid_hook); eager launches cost ~3 % against graph replay at N = 1, the
+    # overlap hides up to ~80 us of collective per step.  --dp-graph selects the graph | all-reduce | graph form instead.
+    if not a.no_graph and (world == 1 or a.dp_graph):
         # one captured hipGraph per resident bag (the bag pointer is a kernel argument); they share one memory pool.
         # Each replay runs the complete step: prep, teacher fwd, select, student fwd, head, bwd, [all-reduce], Adam + EMA.
         # If capture is refused (e.g. a collective that cannot be captured on this RCCL build) every rank falls back to
@@ -265,7 +270,8 @@ def main():
                                    "(teacher fwd + select + student fwd + bwd + Adam + EMA"
                                    + (" + RCCL all-reduce of the 6.6 MB flat gradient" if world > 1 else "") + ")",
                        "bags_per_step": world, "rotating_bags_per_gpu": N_BAGS, "matrix_core_form": student._feature_prec(N_INST),
-                       "dropout": CFG["dropout"], "parallelism": f"dp{world}", "launch": ("eager" + (f" (graph capture failed: {graph_note})" if graph_note else "")) if graphs is None
+                       "dropout": CFG["dropout"], "parallelism": f"dp{world}", "launch": (("eager" if world == 1 else "eager, gradient all-reduce in two pieces, the first overlapped with the dW1 GEMM of the backward")
+                                  + (f" (graph capture failed: {graph_note})" if graph_note else "")) if graphs is None
                                  else ("hipGraph replay, one graph per resident bag" if world == 1 else
                                        "hipGraph replay per resident bag: graph(fwd+bwd) | eager RCCL all-reduce | graph(Adam+EMA)")},
             "whole_step_hbm_roofline": {"algorithmic_bytes_per_instance": ALGO_BYTES_PER_INST_STEP,

@@ -101,6 +101,10 @@ class FlatState:
         # so they sit in the non-trainable tail here (DSMIL never uses MHIM.predictor: mhim.py:264-265)
         unused = set(getattr(student, "unused_parameter_names", lambda: ())())
         self.train_names = [n for n, p in named if p.requires_grad and n not in unused]
+        # the projection's weight and bias lead the buffer: their gradient is the last to become final in a backward, so a data-
+        # parallel step all-reduces [the rest] first, overlapped with the projection's weight-gradient GEMM (FusedTrainer._mid_hook)
+        head = [n for n in ("feature.0.weight", "feature.0.bias") if n in self.train_names]
+        self.train_names = head + [n for n in self.train_names if n not in head]
         self.fixed_names = [n for n, p in named if not p.requires_grad or n in unused]
         self.names = self.train_names + self.fixed_names
         dev = named[0][1].device
@@ -187,6 +191,15 @@ class FusedTrainer:
         self.tick = torch.zeros(1, dtype=torch.int64, device=dev)
         self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)
         self._defer = ops.ReduceList()                 # final gradient reductions of a step, flushed as one launch
+        # data parallel: the flat gradient is all-reduced in two pieces, [projection weight + bias | everything else + tail]; the
+        # second piece is final before the backward's longest kernel and its all-reduce overlaps it (eager steps only)
+        self.overlap_comm = True
+        self._work_a = None
+        self._capturing = False
+        fo = self.flat.offsets
+        self._split = fo["feature.0.bias"] + (student.feature[0].bias.numel() + 3) // 4 * 4 if "feature.0.bias" in fo else 0
+        if not (self.flat.names[:2] == ["feature.0.weight", "feature.0.bias"]):
+            self._split = 0                            # unexpected parameter order: one all-reduce of the whole buffer
         student._tick = self.tick
         if teacher is not None:
             teacher._tick = self.tick
@@ -257,7 +270,9 @@ class FusedTrainer:
                 d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
             if first:
                 # the six final gradient reductions of the backward (slab sums, column partials) run as ONE launch
-                s._bag_backward(x, plan, saved, g_z, out=gv, defer=self._defer)
+                hook = self._mid_hook if (self.overlap_comm and self.world > 1 and self.accum == 1 and not self._capturing
+                                          and self._split > 0) else None
+                s._bag_backward(x, plan, saved, g_z, out=gv, defer=self._defer, mid_hook=hook)
                 ops.reduce_flush(self._defer)
             else:                                   # gradient accumulation: fresh buffers, then add (rare path)
                 g = s._bag_backward(x, plan, saved, g_z)
@@ -321,10 +336,26 @@ class FusedTrainer:
         self.last = {"logits": logits, "losses": losses, "patch_num": x.shape[0], "keep_num": keep_num}
         return logits, losses
 
+    def _mid_hook(self):
+        """Data parallel, eager steps: everything but the projection's gradient (the head of the flat buffer) is final - start its
+        all-reduce (with the global-query tail) on RCCL's stream while mul_colsum + the dW1 GEMM + its slab reduction still run."""
+        fl = self.flat
+        fl.grad[fl.n_train:].copy_(fl.student[fl.n_train:])
+        self._work_a = torch.distributed.all_reduce(fl.grad[self._split:], group=self.pg, async_op=True)
+
     def update(self):
         """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
         fl = self.flat
-        scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
+        if self._work_a is not None:                       # overlapped form: the rest of the buffer, then wait for both halves
+            work_b = torch.distributed.all_reduce(fl.grad[:self._split], group=self.pg, async_op=True)
+            self._work_a.wait()
+            work_b.wait()
+            self._work_a = None
+            scale = 1.0 / self.world
+            fl.student[fl.n_train:].copy_(fl.grad[fl.n_train:] * scale)
+            fl.grad[fl.n_train:].zero_()
+        else:
+            scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
         self._apply(scale)
 
     def _apply(self, scale):
@@ -340,6 +371,13 @@ class FusedTrainer:
         launch instead of ~80.  The step must already have run eagerly (lazy one-time setup such as
         hipFuncSetAttribute cannot happen under capture), hence the warm-up calls."""
         assert self.accum == 1, "graph capture covers a full step (accumulation_steps == 1)"
+        self._capturing = True                             # (collectives stay outside the graphs: no mid-backward all-reduce)
+        try:
+            return self._capture(bag, label, warmup, **kw)
+        finally:
+            self._capturing = False
+
+    def _capture(self, bag, label, warmup, **kw):
         # warm up ON the capture stream: autograd's gradient-accumulation nodes (TransMIL student) remember the stream they
         # were created on, and a node living on another stream would need a cross-stream event inside the capture
         if self._cap_stream is None:

@@ -437,10 +437,12 @@ class MHIM(nn.Module):
         saved["pool"] = st
         return st.z, saved
 
-    def _bag_backward(self, x, plan: BagPlan, saved, g_z, out=None, defer=None):
+    def _bag_backward(self, x, plan: BagPlan, saved, g_z, out=None, defer=None, mid_hook=None):
         """Returns {param name: gradient}.  ``out`` may map names to preallocated (flat-buffer) views to fill.  ``defer``
         (ops.ReduceList): the final stages of the weight / bias gradient reductions are queued on it; the caller runs
-        ``ops.reduce_flush`` before reading any gradient."""
+        ``ops.reduce_flush`` before reading any gradient.  ``mid_hook``: called once every gradient except the projection's
+        (feature.0.weight / .bias) is final - pending reductions are flushed first - so a data-parallel trainer can start
+        all-reducing those while the projection's weight-gradient GEMM, the longest kernel of the backward, still runs."""
         out = out or {}
         E = self.mlp_dim
         dev = x.device
@@ -486,6 +488,10 @@ class MHIM(nn.Module):
             grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
             grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
+        if mid_hook is not None:
+            if defer is not None:
+                ops.reduce_flush(defer)
+            mid_hook()
         p = self.dropout_p if plan.training else 0.0
         if saved.get("DACT") is not None:
             _, db1 = ops.mul_colsum(dH, saved["DACT"], colsum_out=out.get("feature.0.bias"), defer=defer)

@@ -205,3 +205,52 @@ def test_data_parallel_captured_step_two_ranks_one_gpu(tmp_path):
         _assert_state_close(r["tea"], t_ref, 1e-7)
     for k in res[0]["stu"]:
         assert torch.equal(res[0]["stu"][k], res[1]["stu"][k]), k
+
+
+def _dp_eager_run(tr):
+    x = torch.from_numpy(synth.bag(700, N, D)).to(DEV)
+    lab = torch.tensor([1], device=DEV)
+    for _ in range(3):
+        tr.train_step(x, lab)
+    torch.cuda.synchronize()
+
+
+def _dp_eager_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from mhim_mil_amd.engine import FusedTrainer
+    torch.manual_seed(77)
+    s, t = _models()
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
+    assert tr.world == 2 and tr.overlap_comm and tr._split == 512 * D + 512
+    calls = []
+    orig = tr._mid_hook
+    tr._mid_hook = lambda: (calls.append(1), orig())[1]
+    _dp_eager_run(tr)
+    assert len(calls) == 3                                       # the mid-backward all-reduce ran in every step
+    torch.save({"stu": {k: v.detach().cpu() for k, v in s.state_dict().items()},
+                "tea": {k: v.detach().cpu() for k, v in t.state_dict().items()}}, os.path.join(out, f"dpe{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_overlapped_eager_two_ranks_one_gpu(tmp_path):
+    """c4 data parallelism, eager steps: the all-reduce of every gradient but the projection's starts in the middle of the
+    backward (two asynchronous collectives per step).  Two ranks fed the SAME bag reproduce the single-process run."""
+    from mhim_mil_amd.engine import FusedTrainer
+    torch.manual_seed(77)
+    s, t = _models()
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
+    _dp_eager_run(tr)
+    s_ref = {k: v.detach().cpu() for k, v in s.state_dict().items()}
+    t_ref = {k: v.detach().cpu() for k, v in t.state_dict().items()}
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_dp_eager_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"dpe{r}.pt")) for r in range(2)]
+    for r in res:
+        _assert_state_close(r["stu"], s_ref, 1e-7)
+        _assert_state_close(r["tea"], t_ref, 1e-7)
+    for k in res[0]["stu"]:
+        assert torch.equal(res[0]["stu"][k], res[1]["stu"][k]), k
