@@ -305,6 +305,17 @@ def test_select_mask_union_and_vote():
 @pytest.mark.parametrize("prec", ["f32", "f16s"])
 @pytest.mark.parametrize("R,k", [(970, 5), (33, 1), (300, 10)])
 def test_merge_fwd_bwd(prec, R, k):
+    _merge_fwd_bwd(prec, R, k, False)
+
+
+@pytest.mark.parametrize("R,k", [(970, 5), (33, 3), (2000, 16)])
+def test_merge_fwd_bwd_tile_kernel(R, k):
+    """The same comparison with the prep-time fragment image of Wkv: the forward takes the one-kernel-per-row-tile form
+    (mca_fused.hip) and the backward consumes the K / V / dots it stored."""
+    _merge_fwd_bwd("bf16x3", R, k, True)
+
+
+def _merge_fwd_bwd(prec, R, k, frag):
     """Merge.merge (LN -> MCA -> to_out -> EMA) forward/backward vs fp64 autograd of the oracle."""
     ops = _ops()
     E = 512
@@ -325,6 +336,13 @@ def test_merge_fwd_bwd(prec, R, k):
     mw = ops.MergeW(f32(p["merge.global_q_mm"]).reshape(k, E), f32(p["merge.norm.weight"]), f32(p["merge.norm.bias"]),
                     f32(p["merge.attn.to_kv.weight"]), f32(p["merge.attn.to_q.weight"]), f32(p["merge.attn.to_out.0.weight"]),
                     f32(p["merge.attn.to_out.0.bias"]), 0.9999, prec=prec, transposes=tr)
+    if frag:
+        wkv = f32(p["merge.attn.to_kv.weight"])
+        img = torch.empty_like(wkv)
+        ops.prep_batch([(ops.PREP_FRAG, wkv, img)])
+        mw = ops.MergeW(f32(p["merge.global_q_mm"]).reshape(k, E), f32(p["merge.norm.weight"]), f32(p["merge.norm.bias"]), wkv,
+                        f32(p["merge.attn.to_q.weight"]), f32(p["merge.attn.to_out.0.weight"]), f32(p["merge.attn.to_out.0.bias"]),
+                        0.9999, prec=prec, transposes=tr, wkv_frag=img)
     Xd = f32(X)
     zd, qn, ws = ops.merge_fwd(mw, Xd)
     f = 1.0 if prec == "f32" else 4.0
