@@ -207,7 +207,7 @@ int mhimx_pseudo_score(void* stream, const float* s, const float* stats, const f
  * [n_pad, 3*inner] output of to_qkv and every per-head matrix is addressed by (pointer offset, row pitch).
  * ---------------------------------------------------------------------------------------- */
 /* LayerNorm over the last dim (eps 1e-5, biased variance) and its backward (dx may be NULL; d_w, d_b (+)= if accumulate).
- * ws (bwd): 2*96*E floats.   replaces: nn.LayerNorm at baseline.py:199,222 / merge.py:96 and its autograd. */
+ * ws (bwd): 2*512*E floats.   replaces: nn.LayerNorm at baseline.py:199,222 / merge.py:96 and its autograd. */
 int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y, float* mean,
                         float* rstd);
 int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,

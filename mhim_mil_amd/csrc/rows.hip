@@ -1016,7 +1016,7 @@ extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, 
                             int64_t ws_bytes) {
   return colsum((hipStream_t)stream, X, M, E, out, accumulate, ws, ws_bytes);
 }
-// ws: 2*96*E floats (partial rows of the weight/bias gradients)
+// ws: 2*512*E floats (partial rows of the weight/bias gradients)
 extern "C" int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int64_t E, const float* w, const float* b, float* y,
                                    float* mean, float* rstd) {
   MHIMX_CHECK_ARG(x && w && b && y && mean && rstd, "layernorm_fwd: null args");
@@ -1025,7 +1025,7 @@ extern "C" int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int6
 extern "C" int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                                    const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws) {
   MHIMX_CHECK_ARG(dy && x && w && mean && rstd && d_w && d_b && ws, "layernorm_bwd: null args");
-  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 96 * E, d_w, d_b, accumulate, 96, nullptr, nullptr, nullptr,
+  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 512 * E, d_w, d_b, accumulate, 512, nullptr, nullptr, nullptr,
                        nullptr, 0, nullptr);
 }
 extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {

@@ -205,7 +205,7 @@ class LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         M, E = x.shape
         dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
-        ws = torch.empty(2 * 96 * E, device=x.device)
+        ws = torch.empty(2 * 512 * E, device=x.device)
         L.check(L.lib().mhimx_layernorm_bwd(_st(), _ptr(dy), _ptr(x), M, E, _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dw),
                                             _ptr(db), 0, _ptr(ws)), "layernorm_bwd")
         return dx, dw, db
