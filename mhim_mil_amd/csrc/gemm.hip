@@ -688,6 +688,35 @@ int gemm_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, int splits
 // mode 0: C_b = A_b B_b^T (nt)   1: C_b = alpha A_b B_b (nn)   2: C_b = A_b^T B_b (tn; A_b is [K,M], B_b is [K,N])
 // splits > 1 (nn / tn): split the reduction dimension, ws >= batch*splits*M*N floats.
 // =================================================================================================
+// C[i,j] = sum_m A[m,i] B[m,j] with a THIN left operand (K1 <= 16 columns, e.g. DSMIL's per-class attention A [M,C] against
+// V [M,E]): a streaming pass over B - thread = column j, K1 accumulators, A's few values per row are wave-uniform loads - instead
+// of a 128 x 128 matrix-core tile that is 98 % padding.  Row chunks -> slabs -> reduce_slabs_kernel (fixed order).
+__global__ __launch_bounds__(256) void thin_tn_kernel(mhimx_gemm_tn_args t, int64_t chunk, float* __restrict__ out, int64_t out_ld,
+                                                      int to_ws) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= t.K2) return;
+  const int64_t m0 = (int64_t)blockIdx.y * chunk, m1 = m0 + chunk < t.M ? m0 + chunk : t.M;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  const int K1 = (int)t.K1;
+#pragma unroll 4
+  for (int64_t m = m0; m < m1; ++m) {
+    const float b = t.B[m * t.ldb + j];
+    const float* ar = t.A + m * t.lda;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < K1) acc[c] += ar[c] * b;
+  }
+  float* o = to_ws ? out + (int64_t)blockIdx.y * t.K1 * t.K2 : out;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < K1) {
+      float* p = o + c * out_ld + j;
+      *p = (!to_ws && t.accumulate) ? *p + acc[c] : acc[c];
+    }
+}
+
 int gemm_batched(hipStream_t st, int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
                  int splits, float* ws) {
   MHIMX_CHECK_ARG(batch >= 1 && batch <= 4096 && g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0, "gemm_batched: bad args");
@@ -712,6 +741,20 @@ int gemm_batched(hipStream_t st, int mode, const mhimx_gemm_nt_args& g, int batc
     mhimx_gemm_tn_args t{};
     t.A = g.A; t.lda = g.lda; t.B = g.B; t.ldb = g.ldb; t.rows = nullptr; t.C = g.C; t.ldc = g.ldc;
     t.M = g.K; t.K1 = g.M; t.K2 = g.N; t.splits = splits; t.ws = ws; t.accumulate = g.accumulate; t.prec = g.prec;
+    if (batch == 1 && t.K1 <= 16 && t.M >= 1024) {             // thin left operand: streaming form (exact fp32 FMA)
+      const int nchunks = (splits > 1 && ws) ? splits : 1;
+      const int64_t chunk = cdiv(t.M, nchunks);
+      hipLaunchKernelGGL(thin_tn_kernel, dim3((unsigned)cdiv(t.K2, 256), (unsigned)nchunks), dim3(256), 0, st, t, chunk,
+                         nchunks > 1 ? ws : t.C, nchunks > 1 ? t.K2 : t.ldc, nchunks > 1 ? 1 : 0);
+      MHIMX_LAUNCH_CHECK();
+      if (nchunks > 1) {
+        const int64_t n = t.K1 * t.K2;
+        const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, t.C, t.K1, t.K2, t.ldc, nchunks, t.accumulate, (int64_t)0);
+        MHIMX_LAUNCH_CHECK();
+      }
+      return 0;
+    }
     return f32 ? launch_tn<MHIMX_PREC_F32>(st, t, batch, bt) : launch_tn<MHIMX_PREC_BF16X3>(st, t, batch, bt);
   }
   return fail(-1, "gemm_batched: unknown mode %d", mode);

@@ -111,6 +111,8 @@ def _heads_mm(mode, A: Op, Bo: Op, Co: Op, heads, accumulate=False):
     if mode != "nt" and K >= 2048:
         tiles = heads * ((M + 127) // 128) * ((N + 127) // 128)
         splits = max(1, min((1024 + tiles - 1) // tiles, K // 256, 65535 // heads))
+        if mode == "tn" and M <= 16 and heads == 1:          # thin left operand: a streaming kernel, one short row chunk per workgroup
+            splits = max(1, min(256, K // 32))
         if splits > 1:
             ws = torch.empty(heads * splits * M * N, device=Co.t.device)
     g = L.GemmNT(A=_ptr(A.t, A.base), lda=A.ld, rows=None, B=_ptr(Bo.t, Bo.base), ldb=Bo.ld, C=_ptr(Co.t, Co.base), ldc=Co.ld, M=M, N=N,
