@@ -180,11 +180,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # MHIMX_BENCH_SELFTEST=1 (one-GPU boxes only): every rank on cuda:0 over gloo - exercises the multi-rank control flow of this
+    # script (barriers, max-over-ranks timing, rank-0 JSON, the overlapped all-reduce); its numbers mean nothing
+    selftest = os.environ.get("MHIMX_BENCH_SELFTEST") == "1"
+    if selftest:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if selftest:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if a.workload != "c2":
         other_workload(a, world, rank, dev)
