@@ -71,6 +71,32 @@ typedef struct {
 } mhimx_gemm_nt_args;
 int mhimx_gemm_nt(void* stream, const mhimx_gemm_nt_args* a);
 
+/* The bag projection of up to TWO models in ONE pass over the raw fp32 bag (teacher and student share the bag: the reference's
+ * student computes the feature on all N rows before it masks, modules/mhim.py:335-336, and its teacher does the same on the same
+ * bag, mhim.py:186):   H_g[N,E] = dropout_g( act( X[N,D] W_g[E,D]^T + b_g ) ),  g < n_heads.
+ * X is plain fp32 (split to bf16 hi/lo on its way into LDS); each W_g is the paired-plane image of the weight (mhimx_pair_planes /
+ * prep kind 1).  3-term bf16 (~2^-16).  dact (optional, fp16 [N,E]): d out / d pre = act'(pre) * keep/(1-p), so the backward through
+ * activation + dropout is one multiply (mhimx_rows_dpre).  Dropout: counter hash of (seed + *drop_tick, row, column pair), or an
+ * injected keep-mask u8 [N,E].  D % 32 == 0, E % 256 == 0.
+ * replaces: mhim.py:69-76 (self.feature) applied at mhim.py:186 (teacher) and :336 (student). */
+#define MHIMX_PROJ_MAX_HEADS 2
+typedef struct {
+  const float* wp;                    /* paired-plane image of the weight [E,D]                            */
+  const float* bias;                  /* [E] or NULL                                                       */
+  float* H; int64_t ldh;              /* output rows [N, ldh >= E]                                         */
+  void* dact;                         /* optional fp16 [N,E]                                               */
+  float drop_p; uint64_t drop_seed; const uint8_t* drop_mask;
+} mhimx_proj_head;
+typedef struct {
+  const float* X; int64_t ldx;        /* the bag [N, D] fp32                                               */
+  int64_t N, D, E;
+  int32_t act;                        /* MHIMX_ACT_*                                                       */
+  int32_t n_heads;
+  mhimx_proj_head head[MHIMX_PROJ_MAX_HEADS];
+  const uint64_t* drop_tick;          /* optional device step counter mixed into every drop_seed           */
+} mhimx_bag_project_args;
+int mhimx_bag_project(void* stream, const mhimx_bag_project_args* a);
+
 /* C[m,n] (+)= alpha * sum_k A[m,k] * B[k,n]   with B row-major [K,N] (ldb = its row pitch).  Only A, lda, rows, B, ldb,
  * C, ldc, M, N, K, accumulate and prec of the argument block are read.  Both operands may be activations (attention
  * products, the Nystrom pseudo-inverse iterations, dX = dY . W).   replaces: torch.matmul / `@` on the path. */
@@ -169,6 +195,10 @@ typedef struct {
   const float* wp; int64_t C; float* cproj;
   void* ws; int64_t ws_bytes;
   const float* bp; float* pscore;
+  const int64_t* rows1;               /* optional gather (M2 == 0): token n of segment 1 is T1[rows1[n]] and, in the backward, its gradient
+                                         goes to dT1[rows1[n]] - the student reads the kept rows and the merged tokens straight out of the
+                                         bag's feature buffer [N + k, E] (masking.py:107 mask_fn and merge.py:190-194 without any copy).
+                                         One-pass scorer shapes only (E = 512, A = 128, plain form). */
 } mhimx_pool_io;
 int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
 int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io);
@@ -300,6 +330,8 @@ typedef struct {
   const uint64_t* drop_tick;          /* optional device step counter mixed into drop_seed           */
   const float* wkv_frag;              /* optional: prep kind-4 image of wkv [2*heads*dim_head, E]: with it (E = 512, 8 x 64) the K/V
                                          projection, its dots and the softmax partials are ONE kernel per row tile       */
+  const int64_t* x_rows;              /* optional gather: row n of the block to merge is X[x_rows[n]] (forward) and its gradient goes to
+                                         dX[x_rows[n]] (backward): merge.py:158-176 masking without a row copy         */
 } mhimx_merge;
 int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
 /* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */
@@ -327,6 +359,11 @@ int mhimx_act_bwd(void* stream, float* dH, const float* H, const float* pre, int
  * through activation + dropout and the bias gradient in one streaming pass.  ws: 1024*E floats. */
 int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,
                      void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
+/* dpre[p,:] = dH[rows ? rows[p] : p, :] * dact16[same row, :] for p < L (compact [L,E]): the backward through activation + dropout of
+ * the rows that took part in the step, gathered from the bag-ordered gradient buffer dH [*,E] and the fp16 d out / d pre image that
+ * mhimx_bag_project wrote; colsum_out[e] (+)= sum_p dpre[p,e] (the projection's bias gradient) in the same pass.  ws: 1024*E floats. */
+int mhimx_rows_dpre(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, float* dpre,
+                    float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
 /* out[e] (+)= sum_m X[m,e] */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);

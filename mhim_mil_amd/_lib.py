@@ -37,6 +37,16 @@ class GemmNT(C.Structure):
                 ("dact", C.c_void_p), ("lddact", C.c_int64)]
 
 
+class ProjHead(C.Structure):
+    _fields_ = [("wp", c_f32p), ("bias", c_f32p), ("H", c_f32p), ("ldh", C.c_int64), ("dact", C.c_void_p),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p)]
+
+
+class BagProject(C.Structure):
+    _fields_ = [("X", c_f32p), ("ldx", C.c_int64), ("N", C.c_int64), ("D", C.c_int64), ("E", C.c_int64),
+                ("act", C.c_int32), ("n_heads", C.c_int32), ("head", ProjHead * 2), ("drop_tick", C.c_void_p)]
+
+
 class PrepJob(C.Structure):
     _fields_ = [("kind", C.c_int32), ("inp", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64), ("C", C.c_int64)]
 
@@ -73,7 +83,7 @@ class PoolIO(C.Structure):
     _fields_ = [("T1", c_f32p), ("M1", C.c_int64), ("T2", c_f32p), ("M2", C.c_int64),
                 ("s", c_f32p), ("stats", c_f32p), ("z", c_f32p), ("u_pre", c_f32p),
                 ("wp", c_f32p), ("C", C.c_int64), ("cproj", c_f32p),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p), ("rows1", c_i64p)]
 
 
 class PoolGrad(C.Structure):
@@ -89,7 +99,7 @@ class Merge(C.Structure):
                 ("wkv", c_f32p), ("wq", c_f32p), ("wo", c_f32p), ("bo", c_f32p),
                 ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
                 ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p),
-                ("wkv_frag", c_f32p)]
+                ("wkv_frag", c_f32p), ("x_rows", c_i64p)]
 
 
 class MergeGrad(C.Structure):
@@ -107,6 +117,7 @@ SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
+    "mhimx_bag_project": (C.c_int, [_P, C.POINTER(BagProject)]),
     "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),
     "mhimx_prep_batch": (C.c_int, [_P, C.POINTER(PrepJob), _I32]),
     "mhimx_pair_planes": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
@@ -134,6 +145,7 @@ SYMBOLS = {
     "mhimx_rowmax": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
+    "mhimx_rows_dpre": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_reduce_flush": (C.c_int, [_P, _P]),
     "mhimx_cls_metrics_ws_bytes": (C.c_int64, [_I64, _I64, _I64]),
     "mhimx_cls_metrics": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I32, _P, _I64, _P, _P, _I64]),
@@ -174,6 +186,10 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} not found: the MI355X HIP library has not been built "
             f"(run `python -m mhim_mil_amd.build` or __graft_entry__.build()); there is no fallback path")
+    # torch first: its wheel bundles its own HIP runtime, and libmhimx.so must bind to THAT copy (the one that owns the device
+    # context and the pointers we are handed).  Loaded the other way round, the system runtime gets pulled in first and every
+    # launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol

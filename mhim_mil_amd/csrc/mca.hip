@@ -15,7 +15,7 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
                   int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
-                  mhimx_reduce_list* defer);
+                  mhimx_reduce_list* defer, const int64_t* xrows = nullptr);
 int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g, float a_drop_p = 0.f, uint64_t a_seed = 0,
                 const uint64_t* a_tick = nullptr, float* a_colsum = nullptr, int a_accumulate = 0, int use_a_drop = 0);
 bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* wkv_frag, const float* xn, const float* KV);
@@ -319,13 +319,14 @@ __global__ __launch_bounds__(256) void mca_pre_kernel(const float* __restrict__ 
                                                       const float* __restrict__ ln_b, float* __restrict__ xn, float* __restrict__ mean,
                                                       float* __restrict__ rstd, const float* __restrict__ q_param, int k,
                                                       float* __restrict__ gq, float* __restrict__ gmean, float* __restrict__ grstd,
-                                                      const float* __restrict__ wq, int I, float* __restrict__ Q, int nbx) {
+                                                      const float* __restrict__ wq, int I, float* __restrict__ Q, int nbx,
+                                                      const int64_t* __restrict__ xrows /* optional: row n of the block is x[xrows[n]] */) {
   extern __shared__ __attribute__((aligned(16))) float gqs[];          // [k][E]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < nbx) {
     for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < R; n += (int64_t)nbx * 4) {
       float mu, rs;
-      ln_row(x + n * (int64_t)E, E, ln_w, ln_b, xn + n * (int64_t)E, &mu, &rs);
+      ln_row(x + (xrows ? xrows[n] : n) * (int64_t)E, E, ln_w, ln_b, xn + n * (int64_t)E, &mu, &rs);
       if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
     }
     return;
@@ -519,9 +520,10 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
       attr = true;
     }
     hipLaunchKernelGGL(mca_pre_kernel, dim3((unsigned)(nbx + cdiv(I, MCA_PRE_COLS))), dim3(256), (size_t)(k * E * 4), st, X, R, (int)E, m->ln_w, m->ln_b,
-                       w.xn, w.mean, w.rstd, m->q_param, (int)k, w.gq, w.gmean, w.grstd, m->wq, (int)I, w.Q, nbx);
+                       w.xn, w.mean, w.rstd, m->q_param, (int)k, w.gq, w.gmean, w.grstd, m->wq, (int)I, w.Q, nbx, m->x_rows);
     MHIMX_LAUNCH_CHECK();
   } else {
+    MHIMX_CHECK_ARG(!m->x_rows, "merge_fwd: gathered rows (x_rows) need E %% 4 == 0, E <= 1024 and k E <= 16384");
     if (int r = layernorm_fwd(st, X, R, E, m->ln_w, m->ln_b, w.xn, w.mean, w.rstd)) return r;
     if (int r = layernorm_fwd(st, m->q_param, k, E, m->ln_w, m->ln_b, w.gq, w.gmean, w.grstd)) return r;
   }
@@ -612,10 +614,10 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   // LayerNorm: rows (dX + weight grads), then the global queries (weight grads only; the queries are not trained)
   if (R > 16) {                                  // the k query rows ride along as the last block of the row launch
     if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256, w.dgq,
-                              m->q_param, w.gmean, w.grstd, k, gr->defer)) return r;
+                              m->q_param, w.gmean, w.grstd, k, gr->defer, m->x_rows)) return r;
   } else {
     if (int r = layernorm_bwd(st, w.dxn, X, R, E, m->ln_w, w.mean, w.rstd, dX, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, acc, 256, nullptr,
-                              nullptr, nullptr, nullptr, 0, nullptr)) return r;
+                              nullptr, nullptr, nullptr, 0, nullptr, m->x_rows)) return r;
     if (int r = layernorm_bwd(st, w.dgq, m->q_param, k, E, m->ln_w, w.gmean, w.grstd, nullptr, w.lnp_w, w.lnp_b, gr->d_ln_w, gr->d_ln_b, 1, 256,
                               nullptr, nullptr, nullptr, nullptr, 0, nullptr)) return r;
   }

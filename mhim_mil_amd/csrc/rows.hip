@@ -13,10 +13,10 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, const float* wa, const float* wp, int64_t C);
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts);
+                     float* pz, int max_parts, const int64_t* rows);
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
-                     float* dT, float* dwc_part, float* dbc_part, int max_parts);
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows);
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int E, const float* __restrict__ w,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
     float* __restrict__ dw_part, float* __restrict__ db_part, int direct_accumulate /* -1: partial rows; 0/1: one block writes d_w, d_b */,
-    LnSeg2 s2) {
+    LnSeg2 s2, const int64_t* __restrict__ xrows /* optional: x and dx rows of the main segment live at xrows[n] */) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dw, [4][E] db
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int MAXQ = 16;                    // E <= 1024
@@ -430,18 +430,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
   // LAST block of the launch instead of as a launch of its own
   int64_t nblk = gridDim.x, first = blockIdx.x;
   if (s2.M > 0) {
-    if (blockIdx.x == gridDim.x - 1) { dy = s2.dy; x = s2.x; mean = s2.mean; rstd = s2.rstd; M = s2.M; dx = nullptr; nblk = 1; first = 0; }
+    if (blockIdx.x == gridDim.x - 1) { dy = s2.dy; x = s2.x; mean = s2.mean; rstd = s2.rstd; M = s2.M; dx = nullptr; nblk = 1; first = 0; xrows = nullptr; }
     else nblk = gridDim.x - 1;
   }
   for (int64_t n = first * 4 + wave; n < M; n += nblk * 4) {
     const float mu = mean[n], rs = rstd[n];
+    const int64_t xn = xrows ? xrows[n] : n;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
       const int e = lane + 64 * q;
       if (e < E) {
         const float g = dy[n * (int64_t)E + e];
-        const float xh = (x[n * (int64_t)E + e] - mu) * rs;
+        const float xh = (x[xn * (int64_t)E + e] - mu) * rs;
         const float gw = g * w[e];
         s1 += gw; s2 += gw * xh;
         dwa[q] += g * xh; dba[q] += g;
@@ -454,8 +455,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
       for (int q = 0; q < MAXQ; ++q) {
         const int e = lane + 64 * q;
         if (e < E) {
-          const float xh = (x[n * (int64_t)E + e] - mu) * rs;
-          dx[n * (int64_t)E + e] = rs * (dy[n * (int64_t)E + e] * w[e] - s1 - xh * s2);
+          const float xh = (x[xn * (int64_t)E + e] - mu) * rs;
+          dx[xn * (int64_t)E + e] = rs * (dy[n * (int64_t)E + e] * w[e] - s1 - xh * s2);
         }
       }
     }
@@ -532,6 +533,29 @@ __global__ __launch_bounds__(256) void mul_colsum_kernel(float* __restrict__ dH,
       f4v* p = reinterpret_cast<f4v*>(dH + m * E) + c;
       const f4v g = *p * reinterpret_cast<const f4v*>(dact + m * E)[c];
       *p = g;
+      cs += g;
+    }
+    if (part) *(reinterpret_cast<f4v*>(part + (int64_t)blockIdx.x * E) + c) = cs;
+  }
+}
+
+// dpre[p,:] = dH[rows[p],:] * dact16[rows[p],:] (fp16 d out / d pre from bag_project) -> compact [L,E] + per-block column sums:
+// the backward through activation + dropout of the rows that took part in the step, gathered out of the bag-ordered buffers
+__global__ __launch_bounds__(256) void rows_dpre_kernel(const float* __restrict__ dH, const _Float16* __restrict__ dact,
+                                                       const int64_t* __restrict__ rows, int64_t L, int E, int64_t chunk,
+                                                       float* __restrict__ dpre, float* __restrict__ part) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+  const int e4 = E / 4;
+  const int64_t mb = (int64_t)blockIdx.x * chunk;
+  const int64_t me = mb + chunk < L ? mb + chunk : L;
+  for (int c = threadIdx.x; c < e4; c += 256) {
+    f4v cs = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int64_t m = mb; m < me; ++m) {
+      const int64_t r = rows ? rows[m] : m;
+      const h4v d = reinterpret_cast<const h4v*>(dact + r * E)[c];
+      const f4v g = reinterpret_cast<const f4v*>(dH + r * E)[c] * f4v{(float)d[0], (float)d[1], (float)d[2], (float)d[3]};
+      reinterpret_cast<f4v*>(dpre + m * E)[c] = g;
       cs += g;
     }
     if (part) *(reinterpret_cast<f4v*>(part + (int64_t)blockIdx.x * E) + c) = cs;
@@ -654,6 +678,8 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   MHIMX_CHECK_ARG(io && io->T1 && io->M1 > 0 && io->s && io->stats && io->z, "pool_fwd: null io");
   MHIMX_CHECK_ARG(io->M2 == 0 || io->T2, "pool_fwd: M2>0 needs T2");
   MHIMX_CHECK_ARG(!io->cproj || (io->wp && io->C > 0), "pool_fwd: cproj needs wp, C");
+  MHIMX_CHECK_ARG(!io->rows1 || (io->M2 == 0 && scorer_fused_ok(sc->E, sc->A, sc->gated, sc->prec, io->T1, sc->wa, io->cproj ? io->wp : nullptr, io->C)),
+                  "pool_fwd: gathered tokens (rows1) need the one-pass scorer (E = 512, A = 128, plain form, not f32) and a single segment");
   const int64_t M = io->M1 + io->M2, E = sc->E, A = sc->A;
   const int gated = sc->gated ? 1 : 0;
   Arena ar(io->ws, io->ws_bytes);
@@ -673,7 +699,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       // one pass over the rows: GEMM + scores + class projections + pool partials (scorer_fused.hip)
       const int g1 = scorer_fused_fwd(st, Ts[seg], Ms[seg], sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, io->cproj ? io->wp : nullptr,
                                       (int)io->C, u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
-                                      w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART);
+                                      w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART, seg == 0 ? io->rows1 : nullptr);
       if (g1 < 0) return g1;
       G += g1;
       off += Ms[seg];
@@ -743,11 +769,12 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   // one pass over the rows for ds / du / dT / the d_wc, d_bc partials (scorer_fused.hip) where the shapes allow
   const bool fused = scorer_fused_ok(E, A, gated, sc->prec, io->T1, gr->wa_t, nullptr, 0) && aligned16(gr->dT1) &&
                      (io->M2 == 0 || (aligned16(io->T2) && aligned16(gr->dT2))) && aligned16(u_pre) && aligned16(w.du);
+  MHIMX_CHECK_ARG(!io->rows1 || (fused && io->M2 == 0), "pool_bwd: gathered tokens (rows1) need the one-pass backward and a single segment");
   for (int seg = 0; seg < 2 && fused; ++seg) {
     if (Ms[seg] == 0) continue;
     const int g1 = scorer_fused_bwd(st, Ts[seg], Ms[seg], u_pre + off * ldu, io->s + off, io->stats, gr->g_z, io->z, sc->wc, sc->act,
                                     gr->wa_t, gr->wa_t_frag, w.du + off * ldu, dTs[seg], w.dwc_part + (int64_t)G * A, w.dbc_part + G,
-                                    MAX_PART);
+                                    MAX_PART, seg == 0 ? io->rows1 : nullptr);
     if (g1 < 0) return g1;
     G += g1;
     off += Ms[seg];
@@ -794,6 +821,7 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     // d_wa (+)= du_a^T T ; d_wb likewise
     mhimx_gemm_tn_args t = {};
     t.A = w.du + off * ldu; t.lda = ldu; t.B = Ts[seg]; t.ldb = E; t.C = gr->d_wa; t.ldc = E;
+    t.rows = seg == 0 ? io->rows1 : nullptr;
     t.M = Ms[seg]; t.K1 = A; t.K2 = E; t.splits = 1; t.accumulate = (gr->accumulate || seg > 0) ? 1 : 0;
     t.prec = sc->prec == MHIMX_PREC_F32 ? MHIMX_PREC_F32 : MHIMX_PREC_BF16X3;
     // split the long reduction (the library raises the slab count until the launch fills the chip, up to the workspace)
@@ -842,14 +870,14 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
                   int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
-                  mhimx_reduce_list* defer) {
+                  mhimx_reduce_list* defer, const int64_t* xrows = nullptr) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
   if (M2 > 0 && M > 16) {                   // rows + a few extra rows (weight gradients only) in one launch
     int grid = (int)cdiv(M, 4);
     if (grid > max_parts - 1) grid = max_parts - 1;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid + 1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                       w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{dy2, x2, mean2, rstd2, M2});
+                       w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{dy2, x2, mean2, rstd2, M2}, xrows);
     MHIMX_LAUNCH_CHECK();
     if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
       defer_push(defer, reduce_job_parts(dw_part, grid + 1, E, E, d_w, accumulate));
@@ -869,12 +897,12 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   if (grid > max_parts) grid = max_parts;
   if (M <= 16) {                            // a few rows (the k global queries): ONE block writes d_w / d_b itself
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E, w, mean,
-                       rstd, dx, d_w, d_b, accumulate ? 1 : 0, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0});
+                       rstd, dx, d_w, d_b, accumulate ? 1 : 0, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows);
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                     w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0});
+                     w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows);
   MHIMX_LAUNCH_CHECK();
   if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
     defer_push(defer, reduce_job_parts(dw_part, grid, E, E, d_w, accumulate));
@@ -990,6 +1018,26 @@ extern "C" int mhimx_rowmax(void* stream, const float* x, int64_t M, int64_t C, 
   hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0, (hipStream_t)stream, x, M,
                      (int)C, out);
   MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_rows_dpre(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, float* dpre,
+                               float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
+  MHIMX_CHECK_ARG(dH && dact16 && dpre && E % 4 == 0 && aligned16(dH) && aligned16(dpre) && (reinterpret_cast<uintptr_t>(dact16) & 7) == 0,
+                  "rows_dpre: bad args");
+  if (L <= 0) return 0;
+  int64_t nblk = cdiv(L, 8);
+  if (nblk > 512) nblk = 512;
+  const int64_t chunk = cdiv(L, nblk);
+  nblk = cdiv(L, chunk);
+  MHIMX_CHECK_ARG(!colsum_out || (ws && ws_bytes >= nblk * E * 4), "rows_dpre: workspace too small (%lld bytes)", (long long)(nblk * E * 4));
+  hipLaunchKernelGGL(rows_dpre_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16, rows, L, (int)E, chunk,
+                     dpre, colsum_out ? (float*)ws : nullptr);
+  MHIMX_LAUNCH_CHECK();
+  if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, (hipStream_t)stream, (const float*)ws, (int)nblk,
+                       (int)E, (int)E, colsum_out, accumulate);
+    MHIMX_LAUNCH_CHECK();
+  }
   return 0;
 }
 extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int64_t E, float* colsum_out, int32_t accumulate,

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     const float* __restrict__ ba, int act,
     const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ wp, int C, float* __restrict__ u_pre,
     float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl, float* __restrict__ pz,
-    int tiles) {
+    int tiles, const int64_t* __restrict__ rows /* optional gather: token n is T[rows[n]] */) {
   extern __shared__ __attribute__((aligned(16))) float sf_sm[];
   float* Hs = sf_sm;                          // [32][516]
   float* sred = Hs + SF_ROWS * SF_LD;         // [4][32] per-wave partial scores
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     for (int i = 0; i < 16; ++i) {
       const int f = tid + SF_THREADS * i, r = f >> 7, c4 = f & 127;
       const int64_t n = row0 + r;
-      sf_f4 v = reinterpret_cast<const sf_f4*>(T + (n < M ? n : M - 1) * SF_E)[c4];      // clamped: all 16 loads in flight
+      const int64_t nc = n < M ? n : M - 1;                                                // clamped: all 16 loads in flight
+      sf_f4 v = reinterpret_cast<const sf_f4*>(T + (rows ? rows[nc] : nc) * SF_E)[c4];
       if (n >= M) v = sf_f4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<sf_f4*>(Hs + r * SF_LD + 4 * c4) = v;
     }
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     const float* __restrict__ T, int64_t M, const float* __restrict__ u_pre, const float* __restrict__ s_in,
     const float* __restrict__ stats, const float* __restrict__ g_z, const float* __restrict__ z, const float* __restrict__ wc, int act,
     const float* __restrict__ wat, const float* __restrict__ wat_frag, float* __restrict__ du, float* __restrict__ dT,
-    float* __restrict__ dwc_part, float* __restrict__ dbc_part, int tiles) {
+    float* __restrict__ dwc_part, float* __restrict__ dbc_part, int tiles,
+    const int64_t* __restrict__ rows /* optional: token n is T[rows[n]] and its gradient goes to dT[rows[n]] */) {
   extern __shared__ __attribute__((aligned(16))) float sb_sm[];
   float* Ds = sb_sm;                           // [32][132] du tile (A operand)
   float* gzs = Ds + SF_ROWS * SB_LD;           // [512]
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     {
       const int r = tid >> 3, seg = tid & 7;
       const int64_t n = row0 + r;
-      const sf_f4* tr = reinterpret_cast<const sf_f4*>(T + (n < M ? n : M - 1) * SF_E) + seg;
+      const int64_t nc = n < M ? n : M - 1;
+      const sf_f4* tr = reinterpret_cast<const sf_f4*>(T + (rows ? rows[nc] : nc) * SF_E) + seg;
       const sf_f4* gr = reinterpret_cast<const sf_f4*>(gzs) + seg;
       sf_f4 tv[16];
 #pragma unroll
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
       for (int i = 0; i < 16; ++i) {
         const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
         const int64_t n = row0 + row;
-        if (n < M) dT[n * SF_E + e] = acc[nt][i] + an_s[row] * ge;
+        if (n < M) dT[(rows ? rows[n] : n) * SF_E + e] = acc[nt][i] + an_s[row] * ge;
       }
     }
     __syncthreads();                           // Ds / an_s / gs_s are rewritten by the next tile
@@ -391,7 +394,7 @@ bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, 
 // one launch per token segment; returns the number of partials written to pm/pl/pz (<= max_parts), < 0 on error
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts) {
+                     float* pz, int max_parts, const int64_t* rows) {
   static bool attr = false;
   if (!attr) {
     MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM));
@@ -400,7 +403,7 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   hipLaunchKernelGGL(scorer_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
-                     cproj, pm, pl, pz, tiles);
+                     cproj, pm, pl, pz, tiles, rows);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }
@@ -408,7 +411,7 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
 // returns the number of d_wc / d_bc partial rows written (<= max_parts), < 0 on error
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
-                     float* dT, float* dwc_part, float* dbc_part, int max_parts) {
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows) {
   static bool attr = false;
   if (!attr) {
     MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM));
@@ -417,7 +420,7 @@ int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_p
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   hipLaunchKernelGGL(scorer_fused_bwd_kernel, dim3(grid), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
-                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles);
+                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

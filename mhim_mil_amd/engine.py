@@ -16,6 +16,7 @@ from typing import Optional
 
 import torch
 
+from . import mhim as mh
 from . import ops
 from .mhim import MHIM, BagPlan
 
@@ -209,6 +210,8 @@ class FusedTrainer:
         self._graph_pool = None
         self._cap_stream = None
         self._side = None
+        self.single_pass = True            # ABMIL: one projection launch for teacher + student, bag-ordered buffers (when shapes allow)
+        self._rows_cache = {}
 
     def _dist(self):
         return torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -222,6 +225,9 @@ class FusedTrainer:
         # (kept on the launch stream: a parallel branch in the captured hipGraph costs ~60 us of cross-queue signalling on
         # ROCm 7.2 — measured, profiles/ r01 notes — against ~40 us of kernels it would hide)
         # together with the two device counters (dropout stream position, Adam step) it is ONE launch
+        if self.single_pass and s.baseline == "attn" and s.bag_ordered_ok(x) and (self.model_kind != "mhim" or (
+                t is not None and t.bag_ordered_ok(x) and not t.merge_test and s.merge_enable and s.v2_counts(x.shape[0], i) is not None)):
+            return self._forward_backward_nat(x, label, perm, ids_shuffle, i)
         prep_s = prep_t = None
         jobs = [(ops.PREP_TICK, None, self.tick)]
         if self._micro == 0:
@@ -282,6 +288,81 @@ class FusedTrainer:
             s.merge_enable = merge_on
         self._micro += 1
         self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num}
+        return logits, losses
+
+    def _forward_backward_nat(self, x, label, perm, ids_shuffle, i):
+        """The single-pass ABMIL step: ONE projection launch computes the teacher's and the student's feature rows from the raw bag
+        (the reference's student projects all N rows before it masks, mhim.py:335-336); the rows stay in bag order and the scorer,
+        Merge, their backwards and the projection's weight-gradient GEMM gather the rows that take part by index."""
+        s, t, fl = self.s, self.t, self.flat
+        mhim = self.model_kind == "mhim"
+        ps, E = x.shape[0], s.mlp_dim
+        dev = x.device
+        jobs = [(ops.PREP_TICK, None, self.tick)]
+        if self._micro == 0:
+            jobs.append((ops.PREP_TICK, None, self.opt_step))
+        prep_t = None
+        if mhim:
+            jt, prep_t = t.prep_jobs(backward=False)
+            jobs += jt
+        merge_on = s.merge_enable
+        if not mhim:
+            s.merge_enable = False
+        try:
+            js, prep_s = s.prep_jobs(backward=True)
+            ops.prep_batch(jobs + js)
+            first = self._micro == 0
+            gv = fl.grad_views
+            k = s.merge.k if mhim else 0
+            act = mh.L.act_code(s.act, mh._FEATURE_ACTS)
+            Hbuf = torch.empty((ps + k, E), device=dev)
+            heads = []
+            if mhim:
+                p_t = t.dropout_p if t.training else 0.0            # the trainer keeps the teacher in train mode
+                heads.append(ops.ProjHead(prep_t["w1p"], t.feature[0].bias.data, drop_p=p_t, drop_seed=t._next_seed()))
+            heads.append(ops.ProjHead(prep_s["w1p"], s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=s._next_seed(), out=Hbuf,
+                                      want_dact=True))
+            ops.bag_project(x, heads, act=act, drop_tick=self.tick)
+            DACT = heads[-1].dact
+            teacher_feat, rows_all = None, None
+            if mhim:
+                wp = t.predictor.weight.data if t.attn2score else None
+                st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp,
+                                          bp=t.predictor.bias.data if t.attn2score else None)
+                score = st_t.pscore if t.attn2score else ops.softmax_from_stats(st_t.s, st_t.stats)
+                teacher_feat = st_t.z
+                _, _, len_keep, Lk, R = s.v2_counts(ps, i)
+                key = (ps, len_keep, k)
+                rows_all = self._rows_cache.get(key)
+                if rows_all is None:                                  # [rows to merge | rows that stay | the k token rows ps .. ps+k-1]
+                    rows_all = torch.empty(len_keep + k, dtype=torch.int64, device=dev)
+                    rows_all[len_keep:] = torch.arange(ps, ps + k, device=dev)
+                    self._rows_cache[key] = rows_all
+                s.student_rows(ps, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, merge_first=True, rows_out=rows_all)
+                plan = BagPlan(rows=rows_all[:len_keep], L=len_keep, Lk=Lk, R=R, mca_seed=s._next_seed(), training=True, merge_first=True)
+                keep_num = Lk + k
+            else:
+                plan = BagPlan(rows=None, L=ps, Lk=ps, R=0, training=True)
+                keep_num = ps
+            z, saved = s._bag_forward_nat(x, plan, Hbuf, DACT, rows_all, prep_s)
+            t_in = teacher_feat.view(-1) if (teacher_feat is not None and self.aux_alpha != 0.) else None
+            logits, losses, g_z, _, _ = ops.head_fwd_bwd(
+                z, t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),
+                main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
+                d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
+            if first:
+                hook = self._mid_hook if (self.overlap_comm and self.world > 1 and self.accum == 1 and not self._capturing
+                                          and self._split > 0) else None
+                s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=hook)
+                ops.reduce_flush(self._defer)
+            else:                                   # gradient accumulation: fresh buffers, then add (rare path)
+                g = s._bag_backward_nat(x, plan, saved, g_z, {})
+                for n, v in g.items():
+                    gv[n].add_(v)
+        finally:
+            s.merge_enable = merge_on
+        self._micro += 1
+        self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num, "rows": plan.rows}
         return logits, losses
 
     def _bind_grads(self):

@@ -16,7 +16,7 @@ fallback: inputs must be CUDA tensors and the library must be built.
 
 ``baseline='attn'`` (ABMIL) runs the fused hand-derived forward/backward; ``baseline='selfattn'`` (TransMIL /
 Nystrom, SURVEY.md §8 rows A9/A10) composes the encoder from kernel-backed autograd primitives (nystrom.py);
-'dsmil' is scope row N1 and raises NotImplementedError.
+``baseline='dsmil'`` (scope row N1) composes the DSMIL encoder the same way (dsmil.py).
 """
 from __future__ import annotations
 
@@ -326,7 +326,7 @@ class MHIM(nn.Module):
             ops.prep_batch(jobs)
         return prep
 
-    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None):
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None, x_rows=None):
         m = self.merge
         if need_t and tr is None:
             tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
@@ -336,7 +336,7 @@ class MHIM(nn.Module):
         return ops.MergeW(q, m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
                           m.attn.to_q.weight.data, m.attn.to_out[0].weight.data, m.attn.to_out[0].bias.data, m.g_q_mm,
                           drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr,
-                          drop_tick=self._tick, wkv_frag=wkv_frag)
+                          drop_tick=self._tick, wkv_frag=wkv_frag, x_rows=x_rows)
 
     # ------------------------------------------------------------------ kernels: feature rows
     def _check_x(self, x):
@@ -504,6 +504,72 @@ class MHIM(nn.Module):
         grads["feature.0.bias"] = db1
         return grads
 
+    # ------------------------------------------------------------------ student bag forward / backward, bag-ordered buffers
+    def bag_ordered_ok(self, x):
+        """The fused trainer's single-pass form: one projection launch for teacher AND student over the raw bag (ops.bag_project),
+        feature rows kept in BAG order and every consumer gathering rows by index.  Needs the shapes the one-pass kernels are built
+        for (E = 512, scorer width 128, plain scorer, 8 x 64 merge heads) and the 3-term bf16 form."""
+        att = self.online_encoder.attention if self.baseline == "attn" else None
+        return (self.baseline == "attn" and not self.online_encoder.gated and self.mlp_dim == 512 and x.shape[1] % 32 == 0
+                and att.attention[0].weight.shape[0] == 128 and self._feature_prec(x.shape[0]) == "bf16x3" and x.shape[0] >= 64
+                and self.n_classes <= 4 and L.act_code(self.da_act, _SCORER_ACTS) in (L.ACT["relu"], L.ACT["gelu"], L.ACT["tanh"], 0))
+
+    def _bag_forward_nat(self, x, plan: BagPlan, Hbuf, DACT, rows_all, prep):
+        """Student forward on bag-ordered feature rows Hbuf [N + k, E] (rows N.. receive the k merged tokens).
+        rows_all int64 [R + Lk + k] = [rows to merge | rows that stay | N .. N+k-1]; None: every row takes part, no merge."""
+        N = x.shape[0]
+        sc = self._scorer(prep.get("wa_frag"))
+        saved = {"Hbuf": Hbuf, "DACT": DACT, "rows_all": rows_all, "prep": prep}
+        if rows_all is not None:
+            mw = self._merge_w(plan, need_t=False, wkv_frag=prep.get("wkv_frag"), x_rows=rows_all[:plan.R])
+            q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
+            _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None)
+            st = ops.abmil_pool_fwd(sc, Hbuf, None, rows1=rows_all[plan.R:])
+            saved.update(mws=mws, q_old=prep.get("q_old"))
+        else:
+            st = ops.abmil_pool_fwd(sc, Hbuf[:N], None)
+        saved["pool"] = st
+        return st.z, saved
+
+    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None):
+        """Backward of _bag_forward_nat: every gradient buffer is bag-ordered too (dH [N + k, E]); the rows that took part are
+        gathered once more by the activation backward (ops.rows_dpre) and the projection's weight-gradient GEMM."""
+        N = x.shape[0]
+        Hbuf, rows_all, st, prep = saved["Hbuf"], saved["rows_all"], saved["pool"], saved["prep"]
+        sc = self._scorer()
+        dHbuf = torch.empty_like(Hbuf)
+        grads = {}
+        pre = "online_encoder.attention.attention."
+        pool_g = {"dT1": dHbuf if rows_all is not None else dHbuf[:N]}
+        for key, nm in (("d_wa", "0.weight"), ("d_wc", "2.weight")):
+            if pre + nm in out:
+                pool_g[key] = out[pre + nm]
+        g = ops.abmil_pool_bwd(sc, st, g_z, prep["wa_t"], grads=pool_g, defer=defer, wa_t_frag=prep.get("wa_t_frag"))
+        grads[pre + "0.weight"], grads[pre + "2.weight"] = g["d_wa"], g["d_wc"]
+        if rows_all is not None:
+            mw = self._merge_w(plan, need_t=True, q=saved["q_old"], tr=prep.get("merge_t"), x_rows=rows_all[:plan.R])
+            mgr = {"dX": dHbuf}
+            for key, nm in (("d_ln_w", "merge.norm.weight"), ("d_ln_b", "merge.norm.bias"), ("d_wkv", "merge.attn.to_kv.weight"),
+                            ("d_wq", "merge.attn.to_q.weight"), ("d_wo", "merge.attn.to_out.0.weight"),
+                            ("d_bo", "merge.attn.to_out.0.bias")):
+                if nm in out:
+                    mgr[key] = out[nm]
+            mg = ops.merge_bwd(mw, Hbuf, dHbuf[N:], saved["mws"], grads=mgr, defer=defer)
+            grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
+            grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
+            grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
+        if mid_hook is not None:
+            if defer is not None:
+                ops.reduce_flush(defer)
+            mid_hook()
+        Lr = plan.L
+        rows = None if rows_all is None else rows_all[:Lr]
+        dpre, db1 = ops.rows_dpre(dHbuf, saved["DACT"], rows, Lr, colsum_out=out.get("feature.0.bias"), defer=defer)
+        grads["feature.0.weight"] = ops.gemm_tn(dpre, x, out=out.get("feature.0.weight"), rows=rows, splits=8 if Lr >= 2048 else 1,
+                                                prec="bf16x3", M=Lr, defer=defer)
+        grads["feature.0.bias"] = db1
+        return grads
+
     # ------------------------------------------------------------------ masking (mhim.py:109-179)
     def get_mask(self, ps, i, attn, mrh=None, perm=None, perms=None, generator=None):
         """Device-side get_mask.  Returns (len_keep:int, mask_ids [1,ps] int64).  ``perm``/``perms`` inject the
@@ -557,7 +623,26 @@ class MHIM(nn.Module):
             run(True, mask_ratio_h, self.mask_ratio_hr, perms[2])
         return len_keep, (None if mask_ids is None else mask_ids.view(1, -1))
 
-    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None, merge_first=False):
+    def v2_counts(self, ps, i=None, mrh=None):
+        """(k, n_sel, len_keep, L_keep, R) of the v2 recipe (HAM mask only: masking.py:30-35,61 + merge.py:163), or None when a
+        v1 ratio makes the number of masked rows data dependent."""
+        mask_ratio_h = self.mask_ratio_h
+        if self.mrh_sche is not None and i is not None:
+            mask_ratio_h = self.mrh_sche[i]
+        if mrh is not None:
+            mask_ratio_h = mrh
+        if not (self.mask_ratio == 0 and self.mask_ratio_l == 0 and mask_ratio_h > 0):
+            return None
+        eff, rr = mask_ratio_h / self.mask_ratio_hr, self.mask_ratio_hr
+        if eff > 1:
+            rr, eff = mask_ratio_h, 1.0
+        k = int(np.ceil(ps * eff))
+        n_sel = int(np.ceil(k * rr)) if rr < 1.0 else k
+        len_keep = ps - n_sel
+        Lk = int(len_keep * self.merge.merge_ratio)
+        return k, n_sel, len_keep, Lk, len_keep - Lk
+
+    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None, merge_first=False, rows_out=None):
         """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
 
         Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R); with ``merge_first`` the
@@ -587,7 +672,7 @@ class MHIM(nn.Module):
                 if R == 0:
                     raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
                 rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed(), tick=self._tick,
-                                       merge_first=merge_first)
+                                       merge_first=merge_first, out=None if rows_out is None else rows_out[:len_keep])
                 return rows, len_keep, Lk, R
         len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm, generator=generator)
         if mask_ids is None:
@@ -605,6 +690,9 @@ class MHIM(nn.Module):
         rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
         if merge_first:
             rows = torch.cat([rows[Lk:], rows[:Lk]])
+        if rows_out is not None:
+            rows_out[:len_keep].copy_(rows)
+            rows = rows_out[:len_keep]
         return rows, len_keep, Lk, R
 
     # ------------------------------------------------------------------ reference entry points

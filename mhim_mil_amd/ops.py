@@ -71,6 +71,40 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
     return out
 
 
+class ProjHead:
+    """One model of a bag projection (ops.bag_project): paired-plane weight image, bias, dropout stream, outputs."""
+
+    def __init__(self, wp, bias=None, drop_p=0.0, drop_seed=0, drop_mask=None, out=None, want_dact=False, dact=None):
+        self.wp, self.bias, self.drop_p, self.drop_seed, self.drop_mask = wp, bias, float(drop_p), int(drop_seed), drop_mask
+        self.out, self.want_dact, self.dact = out, want_dact, dact
+
+
+def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
+    """Every model's feature rows H_g = dropout_g(act(x W_g^T + b_g)) in ONE pass over the fp32 bag x [N,D] (mhimx_bag_project).
+    heads: 1 or 2 ProjHead (teacher, student).  Fills head.out [N + extra_rows, E] fp32 (the extra rows are left for the caller:
+    merged tokens) and, with want_dact, head.dact [N, E] fp16 (d out / d pre).  Returns the heads."""
+    _chk(x, name="x")
+    N, D = x.shape
+    E = heads[0].wp.shape[0]
+    a = L.BagProject(X=_p(x), ldx=x.stride(0), N=N, D=D, E=E, act=int(act), n_heads=len(heads), drop_tick=_p(drop_tick))
+    for i, h in enumerate(heads):
+        _chk(h.wp, name="wp"); _chk(h.bias, name="bias"); _chk(h.drop_mask, torch.uint8, "drop_mask")
+        if h.out is None:
+            h.out = torch.empty((N + extra_rows, E), device=x.device)
+        _chk(h.out, name="out")
+        if h.want_dact and h.dact is None:
+            h.dact = torch.empty((N, E), device=x.device, dtype=torch.float16)
+        a.head[i] = L.ProjHead(wp=_p(h.wp), bias=_p(h.bias), H=_p(h.out), ldh=h.out.stride(0), dact=_p(h.dact),
+                               drop_p=h.drop_p, drop_seed=h.drop_seed & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(h.drop_mask))
+    evs = KERNEL_EVENT_HOOK("bag_project", N, E * len(heads), D) if KERNEL_EVENT_HOOK is not None else None
+    if evs:
+        evs[0].record()
+    L.check(L.lib().mhimx_bag_project(_stream(), C.byref(a)), "mhimx_bag_project")
+    if evs:
+        evs[1].record()
+    return heads
+
+
 PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T = 0, 1, 2, 3, 4, 5
 
 
@@ -168,9 +202,10 @@ class ScorerW:
 class PoolState:
     """Buffers of one pool forward (kept for the backward)."""
 
-    def __init__(self, T1, T2, C_classes=0, wp=None, device=None, bp=None):
+    def __init__(self, T1, T2, C_classes=0, wp=None, device=None, bp=None, rows1=None):
         dev = T1.device
-        M1 = T1.shape[0]
+        M1 = T1.shape[0] if rows1 is None else rows1.shape[0]
+        self.rows1 = rows1
         M2 = 0 if T2 is None else T2.shape[0]
         self.T1, self.T2, self.M1, self.M2 = T1, T2, M1, M2
         M = M1 + M2
@@ -190,14 +225,15 @@ class PoolState:
             self.ws = torch.empty(nbytes, device=self.T1.device, dtype=torch.uint8)
         return L.PoolIO(T1=_p(self.T1), M1=self.M1, T2=_p(self.T2), M2=self.M2, s=_p(self.s), stats=_p(self.stats),
                         z=_p(self.z), u_pre=None, wp=_p(self.wp), C=0 if self.cproj is None else self.cproj.shape[1],
-                        cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel(), bp=_p(self.bp), pscore=_p(self.pscore))
+                        cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel(), bp=_p(self.bp), pscore=_p(self.pscore),
+                        rows1=_p(self.rows1))
 
 
-def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None):
+def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None):
     """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj; with ``bp`` also ``pscore`` [M1], the
-    pseudo score of the T1 instances, written by the pool's finalize launch)."""
-    _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp"); _chk(bp, name="bp")
-    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp)
+    pseudo score of the T1 instances, written by the pool's finalize launch).  ``rows1`` (int64): the tokens are T1[rows1]."""
+    _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp"); _chk(bp, name="bp"); _chk(rows1, torch.int64, "rows1")
+    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp, rows1=rows1)
     io = st.io(sc)
     L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd")
     return st
@@ -272,13 +308,14 @@ def select_mask(score, k, n_sel, largest=True, perm=None, other=None, want_topk=
     return mask_ids, len_keep, topk
 
 
-def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, want_mask_ids=False, merge_first=False):
+def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, want_mask_ids=False, merge_first=False, out=None):
     """Fused HAM mask + Merge split with device-side random subsets -> rows int64 [N - n_sel] (stay | merge), or
     (merge | stay) with merge_first."""
     _chk(score, name="score")
     N = score.numel()
     dev = score.device
-    rows = torch.empty(N - n_sel, device=dev, dtype=torch.int64)
+    rows = out if out is not None else torch.empty(N - n_sel, device=dev, dtype=torch.int64)
+    _chk(rows, torch.int64, "rows out")
     mask_ids = torch.empty(N, device=dev, dtype=torch.int64) if want_mask_ids else None
     ws = torch.empty(L.lib().mhimx_select_ws_bytes(N), device=dev, dtype=torch.uint8)
     L.check(L.lib().mhimx_select_rows(_stream(), _p(score), N, int(k), int(n_sel), int(bool(largest)),
@@ -306,8 +343,10 @@ def compose_ids(a, b):
 # ------------------------------------------------------------------------------------------------ merge
 class MergeW:
     def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
-                 prec="f16s", transposes=None, drop_tick=None, wkv_frag=None):
+                 prec="f16s", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None):
         self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo, wkv_frag]
+        _chk(x_rows, torch.int64, "x_rows")
+        self.x_rows = x_rows
         for t in self.t:
             _chk(t, name="merge weight")
         self.k, self.E = q_param.shape[-2], q_param.shape[-1]
@@ -317,7 +356,7 @@ class MergeW:
                          ln_b=_p(ln_b), wkv=_p(wkv), wq=_p(wq), wo=_p(wo), bo=_p(bo), wkv_t=_p(self.tr[0]),
                          wq_t=_p(self.tr[1]), wo_t=_p(self.tr[2]), mm=float(mm), drop_p=float(drop_p),
                          drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec), drop_tick=_p(drop_tick),
-                         wkv_frag=_p(wkv_frag))
+                         wkv_frag=_p(wkv_frag), x_rows=_p(x_rows))
 
     def ws_for(self, R, device):
         n = L.lib().mhimx_merge_ws_bytes(R, self.E, self.k, self.heads, self.dim_head)
@@ -328,7 +367,7 @@ def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
     """q_out: where the EMA-updated queries go (may be the query parameter itself: the update is element-wise and the
     forward has consumed LayerNorm(q) by then)."""
     _chk(X, name="X")
-    R = X.shape[0]
+    R = X.shape[0] if mw.x_rows is None else mw.x_rows.shape[0]
     dev = X.device
     z = z_out if z_out is not None else torch.empty((mw.k, mw.E), device=dev)
     q_new = (q_out if q_out is not None else torch.empty((mw.k, mw.E), device=dev)) if update_q else None
@@ -341,6 +380,10 @@ def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
 def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False, defer=None):
     dev = X.device
     R, E = X.shape
+    if mw.x_rows is not None:
+        R = mw.x_rows.shape[0]
+        if not grads or "dX" not in grads:
+            raise L.MhimxError("merge_bwd with gathered rows scatters into a caller-provided dX buffer")
     I = mw.heads * mw.dim_head
     out = grads or {}
     out.setdefault("dX", torch.empty((R, E), device=dev))
@@ -386,6 +429,21 @@ def mul_colsum(dH, dact, colsum_out=None, want_colsum=True, accumulate=False, de
     if defer is not None:
         defer.keep.append(ws)
     return dH, colsum_out
+
+
+def rows_dpre(dH, dact16, rows, n_rows, colsum_out=None, accumulate=False, defer=None):
+    """dpre [L,E] = dH[rows] * dact16[rows] (compact) and colsum_out[e] (+)= sum_p dpre[p,e]  (mhimx_rows_dpre)."""
+    _chk(dH, name="dH"); _chk(dact16, torch.float16, "dact16"); _chk(rows, torch.int64, "rows")
+    E = dH.shape[1]
+    dpre = torch.empty((n_rows, E), device=dH.device)
+    if colsum_out is None:
+        colsum_out = torch.empty(E, device=dH.device)
+    ws = torch.empty(1024 * E, device=dH.device)
+    L.check(L.lib().mhimx_rows_dpre(_stream(), _p(dH), _p(dact16), _p(rows), int(n_rows), E, _p(dpre), _p(colsum_out), int(bool(accumulate)),
+                                      _p(ws), ws.numel() * 4, _dp(defer)), "mhimx_rows_dpre")
+    if defer is not None:
+        defer.keep.append(ws)
+    return dpre, colsum_out
 
 
 def colsum(X, out=None, accumulate=False):
