@@ -1,0 +1,189 @@
+"""GPU tests of the single-pass ABMIL step: mhimx_bag_project (teacher + student projection in one launch over the raw bag) and
+the row-gather forms of the pool / Merge / activation-backward kernels that read its bag-ordered buffers."""
+import numpy as np
+import pytest
+import torch
+
+from mhim_mil_amd import synth
+from oracle import mhim_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from mhim_mil_amd import ops
+    return ops
+
+
+def rnd(seed, shape, std=1.0):
+    return torch.from_numpy((synth.normal(seed, shape) * std).astype(np.float32))
+
+
+@pytest.mark.parametrize("N,D,heads", [(1, 32, 2), (79, 64, 2), (160, 1024, 1), (801, 128, 2), (10000, 1024, 2), (3333, 1536, 2)])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_bag_project_vs_fp64(N, D, heads, act):
+    """H_g = act(X W_g^T + b_g) for both models from one launch, 3-term bf16 (~2^-16), and d out / d pre (fp16)."""
+    ops = _ops()
+    E = 512
+    x = rnd(1, (N, D)).abs()
+    ws = [rnd(2 + g, (E, D), std=(2.0 / (E + D)) ** 0.5) for g in range(heads)]
+    bs = [rnd(7 + g, (E,), std=0.1) for g in range(heads)]
+    hs = [ops.ProjHead(ops.pair_planes(w.to(DEV)), b.to(DEV), want_dact=(g == heads - 1)) for g, (w, b) in enumerate(zip(ws, bs))]
+    ops.bag_project(x.to(DEV), hs, act={"gelu": 2, "relu": 1}[act], extra_rows=3)
+    for h, w, b in zip(hs, ws, bs):
+        assert h.out.shape == (N + 3, E)
+        pre = x.double() @ w.double().t() + b.double()
+        ref = O._act(pre, act)
+        scale = max(1.0, pre.abs().max().item())
+        np.testing.assert_allclose(h.out[:N].cpu().numpy(), ref.float().numpy(), atol=2e-5 * scale, rtol=2e-5)
+    pre = x.double() @ ws[-1].double().t() + bs[-1].double()
+    if act == "gelu":
+        gref = 0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * np.pi) ** 0.5
+    else:
+        gref = (pre > 0).double()
+    got = hs[-1].dact.double().cpu()
+    near0 = pre.abs() < 1e-4 if act == "relu" else torch.zeros_like(pre, dtype=torch.bool)       # relu'(0) is a convention
+    assert ((got - gref).abs() <= 1e-3)[~near0].all()
+
+
+def test_bag_project_dropout_mask_and_hash():
+    ops = _ops()
+    N, D, E = 700, 64, 512
+    x, w, b = rnd(1, (N, D)).abs(), rnd(2, (E, D), std=0.1), rnd(3, (E,), std=0.1)
+    wp = ops.pair_planes(w.to(DEV))
+    xd = x.to(DEV)
+    full = ops.bag_project(xd, [ops.ProjHead(wp, b.to(DEV), want_dact=True)], act=2)[0]
+    mask = (torch.from_numpy(synth.uniform(5, (N, E))) >= 0.25).to(torch.uint8)
+    m = ops.bag_project(xd, [ops.ProjHead(wp, b.to(DEV), drop_p=0.25, drop_mask=mask.to(DEV), want_dact=True)], act=2)[0]
+    keep = mask.bool()
+    np.testing.assert_allclose(m.out.cpu()[keep].numpy(), (full.out.cpu()[keep] / 0.75).numpy(), rtol=1e-6)
+    assert (m.out.cpu()[~keep] == 0).all() and (m.dact.cpu()[~keep] == 0).all()
+    np.testing.assert_allclose(m.dact.float().cpu()[keep].numpy(), (full.dact.float().cpu()[keep] / 0.75).numpy(), rtol=2e-3, atol=1e-6)
+    # hashed stream: deterministic in (seed, row, column), keep rate 1 - p, the two models of one launch draw different masks
+    tick = torch.zeros(1, dtype=torch.int64, device=DEV)
+    def run(seed_a, seed_b):
+        hs = [ops.ProjHead(wp, b.to(DEV), drop_p=0.25, drop_seed=seed_a), ops.ProjHead(wp, b.to(DEV), drop_p=0.25, drop_seed=seed_b)]
+        ops.bag_project(xd, hs, act=2, drop_tick=tick)
+        return hs[0].out.cpu(), hs[1].out.cpu()
+    a1, b1 = run(77, 78)
+    a2, b2 = run(77, 78)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a1 != 0, b1 != 0)
+    tick += 1
+    a3, _ = run(77, 78)
+    assert not torch.equal(a1 != 0, a3 != 0)                   # the device step counter moves the stream (graph replays)
+    kept = (a1 != 0) | (full.out.cpu() == 0)
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    assert (kept.float().mean(0) - 0.75).abs().max() < 0.08 and (kept.float().mean(1) - 0.75).abs().max() < 0.1
+    np.testing.assert_allclose(a1[a1 != 0].numpy(), (full.out.cpu()[a1 != 0] / 0.75).numpy(), rtol=1e-6)
+
+
+def test_bag_project_argument_errors():
+    ops = _ops()
+    from mhim_mil_amd import _lib as L
+    x = torch.zeros(100, 48, device=DEV)                        # D % 32 != 0
+    wp = torch.zeros(512, 48, device=DEV)
+    with pytest.raises(L.MhimxError):
+        ops.bag_project(x, [ops.ProjHead(wp)])
+    with pytest.raises(L.MhimxError):
+        ops.bag_project(torch.zeros(100, 64, device=DEV), [ops.ProjHead(torch.zeros(384, 64, device=DEV))])   # E % 256 != 0
+
+
+def test_pool_with_gathered_rows_matches_contiguous():
+    """abmil_pool_fwd / bwd with rows1: same scores, pool and gradients as on a gathered copy; gradients land at rows1."""
+    ops = _ops()
+    from mhim_mil_amd import _lib as L
+    M, E, A, n = 1500, 512, 128, 1100
+    T = rnd(1, (M, E)).to(DEV)
+    rows = torch.from_numpy(synth.permutation(2, M)[:n].copy()).to(DEV)
+    wa, wc = rnd(3, (A, E), std=0.05).to(DEV), rnd(4, (1, A), std=0.3).to(DEV)
+    sc = ops.ScorerW(wa, wc, L.ACT["relu"], prec="bf16x3")
+    st_g = ops.abmil_pool_fwd(sc, T, None, rows1=rows)
+    st_c = ops.abmil_pool_fwd(sc, T[rows].contiguous(), None)
+    assert torch.equal(st_g.s, st_c.s) and torch.equal(st_g.z, st_c.z) and torch.equal(st_g.stats, st_c.stats)
+    g_z = rnd(5, (E,)).to(DEV)
+    wa_t = ops.transpose(wa)
+    dT = torch.zeros(M, E, device=DEV)
+    gg = ops.abmil_pool_bwd(sc, st_g, g_z, wa_t, grads={"dT1": dT})
+    gc = ops.abmil_pool_bwd(sc, st_c, g_z, wa_t)
+    assert torch.equal(dT[rows], gc["dT1"])
+    untouched = torch.ones(M, dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    assert (dT[untouched] == 0).all()
+    np.testing.assert_allclose(gg["d_wa"].cpu().numpy(), gc["d_wa"].cpu().numpy(), rtol=1e-5, atol=1e-6 * gc["d_wa"].abs().max().item())
+    assert torch.equal(gg["d_wc"], gc["d_wc"])
+
+
+def test_merge_with_gathered_rows_matches_contiguous():
+    ops = _ops()
+    from mhim_mil_amd import _lib as L
+    M, E, k, R = 900, 512, 5, 333
+    X = rnd(1, (M, E)).to(DEV)
+    rows = torch.from_numpy(synth.permutation(2, M)[:R].copy()).to(DEV)
+    q = rnd(3, (k, E), std=0.05).to(DEV)
+    lnw, lnb = (1 + rnd(4, (E,), std=0.1)).to(DEV), rnd(5, (E,), std=0.1).to(DEV)
+    wkv, wq, wo, bo = rnd(6, (1024, E), std=0.04).to(DEV), rnd(7, (512, E), std=0.04).to(DEV), rnd(8, (E, 512), std=0.04).to(DEV), rnd(9, (E,), std=0.1).to(DEV)
+    tr = (ops.transpose(wkv), ops.transpose(wq), ops.transpose(wo))
+    def mw(xr):
+        return ops.MergeW(q, lnw, lnb, wkv, wq, wo, bo, 0.999, prec="bf16x3", transposes=tr, x_rows=xr)
+    zg, _, wsg = ops.merge_fwd(mw(rows), X, update_q=False)
+    zc, _, wsc = ops.merge_fwd(mw(None), X[rows].contiguous(), update_q=False)
+    assert torch.equal(zg, zc)
+    dz = rnd(10, (k, E)).to(DEV)
+    dX = torch.zeros(M, E, device=DEV)
+    gg = ops.merge_bwd(mw(rows), X, dz, wsg, grads={"dX": dX})
+    gc = ops.merge_bwd(mw(None), X[rows].contiguous(), dz, wsc)
+    assert torch.equal(dX[rows], gc["dX"])
+    for key in ("d_ln_w", "d_ln_b", "d_wkv", "d_wq", "d_wo", "d_bo"):
+        assert torch.equal(gg[key], gc[key]), key
+
+
+def test_rows_dpre():
+    ops = _ops()
+    M, E, n = 1300, 512, 1000
+    dH = rnd(1, (M, E), std=1e-3).to(DEV)
+    dact = rnd(2, (M, E)).to(DEV).half()
+    rows = torch.from_numpy(synth.permutation(3, M)[:n].copy()).to(DEV)
+    dpre, cs = ops.rows_dpre(dH, dact, rows, n)
+    ref = dH[rows].double() * dact[rows].double()
+    np.testing.assert_allclose(dpre.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(cs.cpu().numpy(), ref.sum(0).float().cpu().numpy(), rtol=1e-4, atol=1e-7)
+    dpre2, cs2 = ops.rows_dpre(dH, dact, None, M)
+    np.testing.assert_allclose(dpre2.cpu().numpy(), (dH.double() * dact.double()).float().cpu().numpy(), rtol=1e-6)
+
+
+def test_single_pass_step_equals_two_launch_step():
+    """FusedTrainer: the single-pass step (bag-ordered buffers) against the two-projection step on the same draws (dropout off:
+    the two forms draw different dropout streams)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    from mhim_mil_amd.mhim import MHIM
+    n, d = 2100, 256
+    cfg = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True,
+               merge_k=5, merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.0)
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+
+    def mk(sd):
+        m = MHIM(input_dim=d, n_classes=2, baseline="attn", **cfg)
+        sd = dict(sd)
+        sd["merge.global_q"] = sd["merge.global_q_mm"]
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        m = m.to(DEV).train()
+        m.merge.dropout = 0.0
+        return m
+
+    x = torch.from_numpy(synth.bag(99, n, d)).to(DEV)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    perm, shuf = torch.from_numpy(synth.permutation(1, k)).to(DEV), torch.from_numpy(synth.permutation(2, n - n_sel)).to(DEV)
+    res = []
+    for single in (True, False):
+        s, t = mk(base), mk(tsd)
+        tr = FusedTrainer(s, t)
+        tr.single_pass = single
+        label = torch.tensor([1], device=DEV)
+        logits, losses = tr.forward_backward(x[None], label, perm=perm, ids_shuffle=shuf)
+        res.append((logits.clone(), losses.clone(), tr.flat.grad.clone()))
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), atol=5e-5, rtol=0)
+    g0, g1 = res[0][2].cpu().numpy(), res[1][2].cpu().numpy()
+    np.testing.assert_allclose(g0, g1, atol=1e-3 * np.abs(g1).max(), rtol=1e-3)
