@@ -216,7 +216,7 @@ def main():
     ev = []
     if not a.no_kernel_events:
         def hook(tag, M, N, K):
-            if tag == "gemm_nt" and M >= N_INST and N == 512 and K == D_IN:       # teacher's full-bag projection
+            if tag == "bag_project" and M >= N_INST and K == D_IN:                # the teacher + student projection launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev.append((e0, e1))
                 return e0, e1
@@ -289,7 +289,9 @@ def main():
         if ev:
             ms = [e0.elapsed_time(e1) for e0, e1 in ev]
             avg = sum(ms) / len(ms)
-            algo = N_INST * D_IN * 4                      # D*4 B per instance for one forward pass over X
+            # D*4 B per instance for one forward pass over X; this ONE launch is the teacher's pass AND the student's
+            # pass of the step's byte budget (3 passes: teacher fwd, student fwd, weight-gradient bwd) - X itself is read once
+            algo = 2 * N_INST * D_IN * 4
             ach = algo / (avg * 1e-3) / 1e9
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc.sh + tools/pmc_feature.py; counters cannot be read from inside the process being timed)
@@ -300,11 +302,12 @@ def main():
                 traffic, tsrc = pj["traffic_bytes"], ("profiles/pmc_feature_gemm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
                                                       f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
                                                       f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
-            out["roofline"] = {"kernel": "feat_gemm_kernel (teacher feature projection X[N,D] -> H[N,512] on paired bf16 planes, 3-term bf16 MFMA, fused bias+GELU+dropout)",
+            out["roofline"] = {"kernel": "bag_project_kernel (teacher AND student feature projection X[N,D] -> 2 x H[N,512] in one pass over the raw fp32 bag, 3-term bf16 MFMA, fused bias+GELU+dropout, fp16 d out/d pre)",
                                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "avg_kernel_ms": avg, "launches_timed": len(ms), "hip_events_over": events_from,
                                "algorithmic_bytes_per_launch": algo,
-                               "mfma_TFLOPs_fp32_equivalent": 2.0 * N_INST * D_IN * 512 / (avg * 1e-3) / 1e12}
+                               "algorithmic_bytes_note": "two of the step's three budgeted passes over X (teacher forward + student forward, 4096 B/instance each) are this one launch",
+                               "mfma_TFLOPs_fp32_equivalent": 2.0 * N_INST * D_IN * 1024 / (avg * 1e-3) / 1e12}
         if world == 1 and a.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps, base)
         print(json.dumps(out), flush=True)
