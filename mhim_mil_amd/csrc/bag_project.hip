@@ -327,13 +327,7 @@ int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
     MHIMX_CHECK_ARG(H.drop_p >= 0.f && H.drop_p < 1.f, "bag_project: model %d: dropout probability outside [0,1)", h);
     MHIMX_CHECK_ARG(!H.drop_mask || (reinterpret_cast<uintptr_t>(H.drop_mask) & 3) == 0, "bag_project: model %d: unaligned mask", h);
   }
-  int dev = 0;
-  MHIMX_HIP(hipGetDevice(&dev));
-  static bool attr[64] = {};
-  if (dev >= 0 && dev < 64 && !attr[dev]) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE));
-    attr[dev] = true;
-  }
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE)));
   const int nN = (int)(g.n_heads * g.E / PBN), nM = (int)cdiv(g.N, PBM);
   dim3 grid((unsigned)(8 * nN * cdiv(nM, 8)));
   hipLaunchKernelGGL(bag_project_kernel, grid, dim3(PTHREADS), PNST * PSTAGE, st, g);

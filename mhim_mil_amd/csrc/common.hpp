@@ -32,6 +32,27 @@ const std::string& last_error();
     if (_e != hipSuccess) return ::mhimx::fail((int)_e, "kernel launch: %s", hipGetErrorString(_e)); \
   } while (0)
 
+// hipFuncSetAttribute is a per-DEVICE setting: the "done" flag of a call site is kept per device (a process may drive several
+// GPUs), and the first call on each device must happen outside stream capture (the trainers run a warm-up step first).
+struct DeviceOnce {
+  bool done[64] = {};
+  bool need(int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *dev_out = -1; return true; }
+    *dev_out = dev;
+    return !done[dev];
+  }
+};
+#define MHIMX_ONCE_PER_DEVICE(...)                         \
+  do {                                                     \
+    static ::mhimx::DeviceOnce _once;                      \
+    int _dev;                                              \
+    if (_once.need(&_dev)) {                               \
+      __VA_ARGS__;                                         \
+      if (_dev >= 0) _once.done[_dev] = true;              \
+    }                                                      \
+  } while (0)
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t align_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }

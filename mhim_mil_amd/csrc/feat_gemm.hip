@@ -269,11 +269,7 @@ bool feat_gemm_ok(const mhimx_gemm_nt_args& g) {
 }
 
 int feat_gemm(hipStream_t st, const mhimx_gemm_nt_args& g) {
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)feat_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FNST * FSTAGE));
-    attr = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)feat_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FNST * FSTAGE)));
   const int nN = (int)(g.N / FBN), nM = (int)cdiv(g.M, FBM);
   dim3 grid((unsigned)(8 * nN * cdiv(nM, 8)));
   hipLaunchKernelGGL(feat_gemm_kernel, grid, dim3(FTHREADS), FNST * FSTAGE, st, g);

@@ -664,18 +664,9 @@ int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
       return 0;
     }
   } reduce{st, g, ksplit};
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-    attr = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES)); MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES)));
   if (g.paired) {
-    static bool attr2 = false;
-    if (!attr2) {
-      MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-      attr2 = true;
-    }
+        MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES)));
     hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW, 1>), grid, dim3(64 * NW), NT_LDS_BYTES, st, g, ksteps);
   } else if (g.prec == MHIMX_PREC_BF16X3)
     hipLaunchKernelGGL((gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>), grid, dim3(64 * NW), NT_LDS_BYTES, st, g, ksteps);
@@ -708,12 +699,7 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   g.splits = splits;
   const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);
   const size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8));
-    attr = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8)));
   dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8)));
   hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk);
   MHIMX_LAUNCH_CHECK();

@@ -514,11 +514,7 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   if (pre_ok) {
     int nbx = (int)cdiv(R, 4);
     if (nbx > 512) nbx = 512;
-    static bool attr = false;
-    if (!attr) {
-      MHIMX_HIP(hipFuncSetAttribute((const void*)mca_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      attr = true;
-    }
+        MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)mca_pre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)));
     hipLaunchKernelGGL(mca_pre_kernel, dim3((unsigned)(nbx + cdiv(I, MCA_PRE_COLS))), dim3(256), (size_t)(k * E * 4), st, X, R, (int)E, m->ln_w, m->ln_b,
                        w.xn, w.mean, w.rstd, m->q_param, (int)k, w.gq, w.gmean, w.grstd, m->wq, (int)I, w.Q, nbx, m->x_rows);
     MHIMX_LAUNCH_CHECK();

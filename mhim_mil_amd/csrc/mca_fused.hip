@@ -229,11 +229,7 @@ bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* 
 // returns the number of partial blocks written to pm / pl / po (= row tiles), < 0 on error
 int mca_fused_fwd(hipStream_t st, const float* xn, int64_t R, const float* wkv_frag, const float* Q, int kq, int heads, float scale,
                   float drop_p, uint64_t seed, const uint64_t* tick, float* KV, float* dots, float* pm, float* pl, float* po) {
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)mca_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_SMEM));
-    attr = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)mca_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MF_SMEM)));
   const int tiles = (int)cdiv(R, MF_ROWS);
   hipLaunchKernelGGL(mca_fused_fwd_kernel, dim3((unsigned)(tiles * 4)), dim3(MF_THREADS), MF_SMEM, st, xn, R, wkv_frag, Q, kq, heads, scale,
                      drop_p, seed, tick, KV, dots, pm, pl, po);

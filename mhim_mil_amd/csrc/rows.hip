@@ -724,11 +724,8 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     int r = dispatch_epl(E, [&](auto epl) {
       constexpr int EPL = decltype(epl)::value;
       const size_t smem = (size_t)(FWD_WAVES * E + 2 * FWD_WAVES) * sizeof(float);
-      static bool attr = false;                              // one flag per EPL instantiation
-      if (!attr && smem > 48 * 1024) {
-        MHIMX_HIP(hipFuncSetAttribute((const void*)score_rows_fwd_kernel<EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-      }
+      if (smem > 48 * 1024)                                  // one flag set per EPL instantiation
+        MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)score_rows_fwd_kernel<EPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)));
       hipLaunchKernelGGL(score_rows_fwd_kernel<EPL>, dim3(grid), dim3(64 * FWD_WAVES), smem, st, Tseg, Mseg, (int)E, (int)A,
                          sc->act, gated, u_pre + off * ldu, sc->wc, sc->bc, io->cproj ? io->wp : nullptr, (int)io->C,
                          io->s + off, io->cproj ? io->cproj + off * io->C : nullptr, w.pm + G, w.pl + G,

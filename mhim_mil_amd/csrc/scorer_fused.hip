@@ -395,11 +395,7 @@ bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, 
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
                      float* pz, int max_parts, const int64_t* rows) {
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM));
-    attr = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   hipLaunchKernelGGL(scorer_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
@@ -412,11 +408,7 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
                      float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows) {
-  static bool attr = false;
-  if (!attr) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM));
-    attr = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM)));
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   hipLaunchKernelGGL(scorer_fused_bwd_kernel, dim3(grid), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,

@@ -696,12 +696,7 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
     return 0;
   }
   const size_t smem = select_smem(P);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384)));
-    MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384)));
-    attr_set = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))); MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))));
   MHIMX_CHECK_ARG(!g_use_rand && !g_rows_out, "select: the random-subset forms need N <= 16384 and k <= 4096");
   hipLaunchKernelGGL(select_kernel<false>, dim3(1), dim3(SEL_THREADS), smem, (hipStream_t)stream, score, N, (int)k, (int)n_sel,
                      largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, (uint8_t*)ws, (float*)nullptr, P);
@@ -731,11 +726,7 @@ extern "C" int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int
   MHIMX_CHECK_ARG(k >= 1 && k <= N && k <= 16384, "vote_scores: k out of range");
   MHIMX_HIP(hipMemsetAsync(vote, 0, (size_t)N * 4, (hipStream_t)stream));
   const int P = next_pow2((int)k < 2 ? 2 : (int)k);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384)));
-    attr_set = true;
-  }
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))));
   hipLaunchKernelGGL(select_kernel<true>, dim3((unsigned)H), dim3(SEL_THREADS), select_smem(P), (hipStream_t)stream, attn, N, (int)k,
                      0, largest, (const int64_t*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr,
                      (int64_t*)nullptr, (int64_t*)nullptr, (uint8_t*)nullptr, vote, P);

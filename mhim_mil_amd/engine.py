@@ -53,7 +53,10 @@ class CommonMIL:
                 teacher_feat = None                                        # common_mil.py:24
             if dsmil and teacher_feat is not None:
                 teacher_feat = teacher_feat[0]                              # common_mil.py:27: cls_tea[0] = B [C,E]
-            logits, aux_loss, patch_num, keep_num = model(bag, score, teacher_feat, i=n_iter, **kwargs)
+            # the reference trainer calls forward_func with loader=, device=, others=, idx=, feat= ... (base_engine.py:77-93) and its
+            # CommonMIL hands none of them to the model (common_mil.py:30); only the parity tests' injected draws go through
+            extra = {k: kwargs[k] for k in ("perm", "ids_shuffle", "drop_mask") if k in kwargs}
+            logits, aux_loss, patch_num, keep_num = model(bag, score, teacher_feat, i=n_iter, **extra)
             if dsmil:                                                       # common_mil.py:28
                 logits = 0.5 * logits[0].view(batch_size, -1) + 0.5 * logits[1].view(batch_size, -1)
         elif args.model == "mhim_pure":
@@ -96,11 +99,13 @@ class FlatState:
     keep working and the fused optimiser touches each byte once.
     """
 
-    def __init__(self, student: MHIM, teacher: Optional[MHIM]):
+    def __init__(self, student: MHIM, teacher: Optional[MHIM], step_merges=True):
         named = list(student.named_parameters())          # de-duplicated (global_q alias appears once)
         # parameters the forward never touches get no gradient; torch.optim.Adam skips those (no update, no weight decay),
         # so they sit in the non-trainable tail here (DSMIL never uses MHIM.predictor: mhim.py:264-265)
         unused = set(getattr(student, "unused_parameter_names", lambda: ())())
+        if not step_merges:                               # 'mhim_pure' never calls Merge: its parameters get no gradient either
+            unused |= {n for n, _ in named if n.startswith("merge.")}
         self.train_names = [n for n, p in named if p.requires_grad and n not in unused]
         # the projection's weight and bias lead the buffer: their gradient is the last to become final in a backward, so a data-
         # parallel step all-reduces [the rest] first, overlapped with the projection's weight-gradient GEMM (FusedTrainer._mid_hook)
@@ -176,8 +181,15 @@ class FusedTrainer:
 
     def __init__(self, student: MHIM, teacher: Optional[MHIM], lr=2e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
                  mm=0.9997, main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, process_group=None, model="mhim", mm_sche=None):
+        if model not in ("mhim", "mhim_pure"):
+            raise mh.L.MhimxError(f"FusedTrainer: model={model!r} (the path knows 'mhim' and 'mhim_pure')")
+        if model == "mhim" and teacher is None:
+            raise mh.L.MhimxError("FusedTrainer(model='mhim') needs the EMA teacher (modules/__init__.py:176-214 builds it)")
+        if model == "mhim" and not student.merge_enable:
+            raise mh.L.MhimxError("FusedTrainer(model='mhim') needs merge_enable=True: the reference's MHIM.forward rejects the Identity "
+                                  "merge (mhim.py:82,351)")
         self.s, self.t = student, teacher
-        self.flat = FlatState(student, teacher)
+        self.flat = FlatState(student, teacher, step_merges=(model == "mhim"))
         self.lr, self.wd, self.betas, self.eps, self.mm = lr, weight_decay, betas, eps, mm
         self.main_alpha, self.aux_alpha = main_alpha, aux_alpha
         self.accum = max(1, int(accumulation_steps))
@@ -362,7 +374,9 @@ class FusedTrainer:
         finally:
             s.merge_enable = merge_on
         self._micro += 1
-        self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num, "rows": plan.rows}
+        # (kept for inspection / parity tests: under graph replay these are the static buffers the replay rewrites)
+        self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num, "rows": plan.rows,
+                     "score": score if mhim else None, "R": plan.R}
         return logits, losses
 
     def _bind_grads(self):
@@ -452,6 +466,12 @@ class FusedTrainer:
         launch instead of ~80.  The step must already have run eagerly (lazy one-time setup such as
         hipFuncSetAttribute cannot happen under capture), hence the warm-up calls."""
         assert self.accum == 1, "graph capture covers a full step (accumulation_steps == 1)"
+        if self.s.mrh_sche is not None:
+            # a captured graph freezes host-side schedule values: k, n_sel and len_keep are launch arguments and buffer shapes
+            raise mh.L.MhimxError("capture(): the HAM-ratio schedule (mrh_sche) changes the number of masked rows per iteration; "
+                                  "run such a model with eager train_step calls, or capture one graph per schedule value")
+        # (the learning rate is a by-value kernel argument: constant under replay - re-capture to change it; the EMA momentum
+        # schedule is a device table indexed by the device step counter and does advance)
         self._capturing = True                             # (collectives stay outside the graphs: no mid-backward all-reduce)
         try:
             return self._capture(bag, label, warmup, **kw)

@@ -387,7 +387,9 @@ class MHIM(nn.Module):
 
     @property
     def _op_prec(self):
-        return "f16s" if self.prec == "auto" else self.prec
+        """Matrix-core form of the scorer / Merge GEMMs: the library runs every form but exact 'f32' as 3-term bf16 there (their
+        outputs are instance scores and gradients), so 'auto' and 'f16s' mean 'bf16x3' for these operators."""
+        return "f32" if self.prec == "f32" else "bf16x3"
 
     def _next_seed(self):
         self._step += 1

@@ -505,6 +505,10 @@ class SAttention(nn.Module):
         super().__init__()
         if mlp_dim != 512:
             raise L.MhimxError("the Nystrom encoder kernels are built for mlp_dim = 512 (8 heads x 64, 256 landmarks)")
+        if head != HEADS:
+            # the reference builds heads=head, dim_head=dim//8 (baseline.py:202): another head count is another model (to_qkv is
+            # 3*head*64 wide, res_conv has `head` channels) - refuse it instead of silently building the 8-head one
+            raise L.MhimxError(f"the Nystrom encoder kernels are built for 8 heads (got head={head})")
         self.norm = _P(weight=torch.ones(mlp_dim), bias=torch.zeros(mlp_dim))
         self.cls_token = nn.Parameter(torch.randn(1, 1, mlp_dim))
         self.layer1 = TransLayer(mlp_dim)

@@ -189,7 +189,7 @@ def transpose(x, out=None):
 class ScorerW:
     """Scorer weights in the C layout (keeps the tensors alive)."""
 
-    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="f16s", wa_frag=None):
+    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="bf16x3", wa_frag=None):
         self.t = (wa, wc, ba, wb, bb, bc, wa_frag)
         for t in self.t:
             _chk(t, name="scorer weight")
@@ -343,7 +343,7 @@ def compose_ids(a, b):
 # ------------------------------------------------------------------------------------------------ merge
 class MergeW:
     def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
-                 prec="f16s", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None):
+                 prec="bf16x3", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None):
         self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo, wkv_frag]
         _chk(x_rows, torch.int64, "x_rows")
         self.x_rows = x_rows

@@ -89,6 +89,10 @@ class ShardedBagTrainer:
             raise NotImplementedError("instance sharding is built for the ABMIL encoder; Nystrom bags are replicas only "
                                       "(SURVEY.md §8(e))")
         self.s, self.t = student, teacher
+        # this trainer's kernels take their dropout stream position from the by-value seeds alone: a device tick left behind by
+        # a FusedTrainer that held these models earlier would enter the forward's seed but not the backward's
+        student._tick = None
+        teacher._tick = None
         self.comm = _Comm(group)
         self.flat = FlatState(student, teacher)
         self.lr, self.wd, self.betas, self.eps, self.mm = lr, weight_decay, betas, eps, mm

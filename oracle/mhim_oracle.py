@@ -596,7 +596,7 @@ TRAINABLE_EXCLUDE = ("merge.global_q_mm",)                            # requires
 
 
 def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shuffle=None,
-               aux_alpha=0.5, main_alpha=1.0, mm=0.9997, lr=2e-4, wd=1e-5, model="mhim"):
+               aux_alpha=0.5, main_alpha=1.0, mm=0.9997, lr=2e-4, wd=1e-5, model="mhim", score_override=None):
     """One CommonMIL.forward_func + BaseTrainer step (accumulation 1), dropout off.
 
     stu/tea: dicts of fp32 tensors (reference key names).  opt_state: {name: (m, v)}.
@@ -606,6 +606,8 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
     if model == "mhim":
         with torch.no_grad():
             t_feat, score = forward_teacher(x, tea, cfg)
+        if score_override is not None:      # tests: select on the scores the device saw (its random subsets are read back as perm)
+            score = score_override
         t_in = None if aux_alpha == 0.0 else t_feat                 # common_mil.py:24
         logits, cls_loss, ps, keep, ex = forward_student(x, stu_g, cfg, score, t_in, perm, ids_shuffle)
     else:
@@ -625,6 +627,6 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
     if ex.get("global_q_new") is not None:                          # in-forward EMA of the global queries
         new_stu["merge.global_q_mm"] = ex["global_q_new"].reshape(stu["merge.global_q_mm"].shape).detach()
     new_tea = ema_update(tea, new_stu, mm) if model == "mhim" else tea
-    info = {"loss": float(loss.detach()), "logits": logits.detach(), "cls_loss": float(cls_loss.detach() if torch.is_tensor(cls_loss) else cls_loss), "ps": ps, "keep": keep,
+    info = {"teacher_score": score if model == "mhim" else None, "loss": float(loss.detach()), "logits": logits.detach(), "cls_loss": float(cls_loss.detach() if torch.is_tensor(cls_loss) else cls_loss), "ps": ps, "keep": keep,
             "grads": {k: p.grad.detach() for k, p in stu_g.items() if p.grad is not None}}
     return new_stu, new_tea, new_opt, info

@@ -141,7 +141,9 @@ def test_forward_func_golden():
     q0 = s.merge.global_q_mm.detach().clone()
     for aux in (0.5, 0.0):
         args = types.SimpleNamespace(model="mhim", baseline="attn", aux_alpha=aux)
-        r = eng.forward_func(args, s, t, x, label, None, 1, 0, 0, 0, None, perm=a["perm"], ids_shuffle=a["ids_shuffle"])
+        # with every keyword the reference trainer passes (base_engine.py:77-93): none of them may reach the model
+        r = eng.forward_func(args, s, t, x, label, None, 1, 0, 0, 0, None, perm=a["perm"], ids_shuffle=a["ids_shuffle"],
+                             loader=None, device=DEV, others={"epoch": 0}, idx=torch.tensor([3]), feat=None)
         s.merge.global_q_mm.data.copy_(q0)
         assert len(r) == 7 and r[1] is label
         np.testing.assert_allclose(r[0][0].detach().cpu().numpy(), a[f"logits_aux{aux}"], atol=1e-4, rtol=0)
@@ -153,7 +155,7 @@ def test_forward_func_golden():
     pure = build(synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_enable=False), input_dim=meta["d"], act="gelu",
                  da_act="relu", merge_enable=False, dropout=0.0).train()
     r = eng.forward_func(types.SimpleNamespace(model="mhim_pure", baseline="attn", aux_alpha=0.0), pure, None, x, label, None,
-                         1, 0, 0, 0, None)
+                         1, 0, 0, 0, None, loader=None, device=DEV, others=None, idx=None, feat=None)
     np.testing.assert_allclose(r[0][0].detach().cpu().numpy(), a["pure_logits"], atol=1e-4, rtol=0)
     assert [float(r[2]), r[3], r[4], r[5], r[6]] == list(a["pure_tuple"])
 

@@ -187,3 +187,109 @@ def test_single_pass_step_equals_two_launch_step():
     np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), atol=5e-5, rtol=0)
     g0, g1 = res[0][2].cpu().numpy(), res[1][2].cpu().numpy()
     np.testing.assert_allclose(g0, g1, atol=1e-3 * np.abs(g1).max(), rtol=1e-3)
+
+
+def _draws_from_device(score_dev, rows_dev, R, n, k, n_sel):
+    """The (perm, ids_shuffle) that make the oracle pick the row sets the device drew: rows_dev = [rows to merge (R) | rows that
+    stay]; the masked rows are the rest.  The oracle selects on the SAME scores (score_dev), so its candidate list is the device's."""
+    top = O.topk_indices(score_dev, k, True)
+    part = np.zeros(n, dtype=bool)
+    part[rows_dev] = True
+    masked = np.nonzero(~part)[0]
+    assert masked.shape[0] == n_sel
+    pos = {int(v): i for i, v in enumerate(top)}
+    assert all(int(m) in pos for m in masked), "a masked row is not among the top-k candidates"
+    first = np.array([pos[int(m)] for m in masked], dtype=np.int64)
+    rest = np.setdiff1d(np.arange(k), first)
+    perm = np.concatenate([first, rest])
+    kept = np.nonzero(part)[0]                                   # ascending, as the oracle's select emits them
+    where = {int(v): i for i, v in enumerate(kept)}
+    merge_rows, stay_rows = rows_dev[:R], rows_dev[R:]
+    ids_shuffle = np.array([where[int(v)] for v in stay_rows] + [where[int(v)] for v in merge_rows], dtype=np.int64)
+    return perm, ids_shuffle
+
+
+def test_production_step_vs_oracle_c2():
+    """The path bench.py times, at BASELINE's c2 size (N = 10 000, D = 1024): device-drawn hard-instance subsets
+    (mhimx_select_rows, rows = [merge | stay]), single-pass projection, bag-ordered buffers, then a captured hipGraph replayed on
+    a second bag.  The row sets and the teacher scores the device used are read back and handed to the oracle as its
+    perm / ids_shuffle draws: logits 1e-4, every gradient 2e-3 of its scale, parameters after Adam + EMA.  Dropout off (the
+    counter-hash masks have no CPU twin; tests above pin them)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    from mhim_mil_amd.mhim import MHIM
+    n, d = 10000, 1024
+    cfg = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True,
+               merge_k=5, merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.0)
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+
+    def mk(sd):
+        m = MHIM(input_dim=d, n_classes=2, baseline="attn", **cfg)
+        sd = dict(sd)
+        sd["merge.global_q"] = sd["merge.global_q_mm"]
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        m = m.to(DEV).train()
+        m.merge.dropout = 0.0
+        return m
+
+    s, t = mk(base), mk(tsd)
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997)
+    ocfg = O.Cfg(**cfg)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    stu, tea, opt = O.as_torch(base), O.as_torch(tsd), {}
+    bags = [torch.from_numpy(synth.bag(300 + i, n, d)) for i in range(2)]
+    labels = [1, 0]
+
+    def check(step, info, stu_new, tea_new, logits, losses):
+        np.testing.assert_allclose(logits.cpu().numpy().ravel(), info["logits"].numpy().ravel(), atol=1e-4, rtol=0)
+        assert abs(float(losses[0]) - info["loss"]) < 3e-4
+        sd, td = s.state_dict(), t.state_dict()
+        for name, ref in stu_new.items():          # Adam's first steps are sign-like: rounding-level gradient differences move the
+            if name == "merge.global_q":           # few elements whose gradient is ~0 by up to 2 lr; the bulk must agree tightly
+                continue
+            err = (sd[name].detach().cpu().double() - ref.double()).abs()
+            assert err.mean().item() <= 3e-6 and err.max().item() <= 4.1e-4 * (step + 1), (step, name, err.mean().item(), err.max().item())
+            err = (td[name].detach().cpu().double() - tea_new[name].double()).abs()
+            assert err.max().item() <= 2e-6, (step, "teacher", name, err.max().item())
+
+    # ---- step 0, eager, gradients inspected before the update
+    x0 = bags[0].to(DEV)
+    logits, losses = tr.forward_backward(x0[None], torch.tensor([labels[0]], device=DEV))
+    torch.cuda.synchronize()
+    rows = tr.last["rows"].cpu().numpy()
+    score = tr.last["score"].cpu().numpy()
+    R = tr.last["R"]
+    assert rows.shape[0] == n - n_sel and np.unique(rows).shape[0] == rows.shape[0]
+    perm, shuf = _draws_from_device(score, rows, R, n, k, n_sel)
+    stu1, tea1, opt, info = O.train_step(bags[0], labels[0], stu, tea, opt, ocfg, 1, perm=perm, ids_shuffle=shuf,
+                                         score_override=torch.from_numpy(score))
+    np.testing.assert_allclose(score, O.forward_teacher(bags[0], tea, ocfg)[1].numpy().ravel(), atol=1e-4, rtol=2e-3)
+    gv = tr.flat.grad_views
+    for name, ref in info["grads"].items():
+        g, r = gv[name].cpu().numpy(), ref.numpy()
+        np.testing.assert_allclose(g, r.reshape(g.shape), atol=2e-3 * (np.abs(r).max() + 1e-30), rtol=2e-3, err_msg=name)
+    tr.update()
+    torch.cuda.synchronize()
+    check(0, info, stu1, tea1, logits, losses)
+
+    # ---- step 1: the whole step as ONE captured hipGraph, replayed on the second bag
+    s.load_state_dict({**{kk: vv for kk, vv in stu1.items()}, "merge.global_q": stu1["merge.global_q_mm"]})
+    t.load_state_dict({**{kk: vv for kk, vv in tea1.items()}, "merge.global_q": tea1["merge.global_q_mm"]})
+    x1 = bags[1].to(DEV)
+    lab1 = torch.tensor([labels[1]], device=DEV)
+    # Adam moments continue from step 0 on the device; the oracle carries `opt`.  (capture() warms up with real steps: snapshot
+    # and restore the whole flat state around it so that exactly ONE step separates the states compared below.)
+    snap = [tr.flat.student.clone(), tr.flat.teacher.clone(), tr.flat.m.clone(), tr.flat.v.clone(), tr.opt_step.clone(), tr.tick.clone(),
+            tr.flat.step]
+    g = tr.capture(x1[None], lab1, warmup=1)
+    tr.flat.student.copy_(snap[0]); tr.flat.teacher.copy_(snap[1]); tr.flat.m.copy_(snap[2]); tr.flat.v.copy_(snap[3])
+    tr.opt_step.copy_(snap[4]); tr.tick.copy_(snap[5]); tr.flat.step = snap[6]
+    tr.flat.grad.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    rows = tr.last["rows"].cpu().numpy()
+    score = tr.last["score"].cpu().numpy()
+    perm, shuf = _draws_from_device(score, rows, tr.last["R"], n, k, n_sel)
+    stu2, tea2, opt, info = O.train_step(bags[1], labels[1], stu1, tea1, opt, ocfg, 2, perm=perm, ids_shuffle=shuf,
+                                         score_override=torch.from_numpy(score))
+    check(1, info, stu2, tea2, tr.last["logits"], tr.last["losses"])
