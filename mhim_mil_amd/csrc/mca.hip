@@ -22,6 +22,12 @@ bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* 
 int mca_fused_fwd(hipStream_t st, const float* xn, int64_t R, const float* wkv_frag, const float* Q, int kq, int heads, float scale,
                   float drop_p, uint64_t seed, const uint64_t* tick, float* KV, float* dots, float* pm, float* pl, float* po);
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes);
+// mca2.hip: the projection-free form (k <= 6 queries, E = 512, 8 x 64)
+bool merge2_ok(const mhimx_merge* m, int64_t R);
+int64_t merge2_ws_bytes(int64_t R, int64_t k);
+int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new, int update_q, void* ws, int64_t ws_bytes);
+int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* gr, void* ws,
+               int64_t ws_bytes);
 
 constexpr int MCA_THREADS = 256;
 #ifdef MHIMX_MCA_PROF
@@ -447,6 +453,13 @@ __global__ __launch_bounds__(256) void mca_out_kernel(const float* __restrict__ 
   }
 }
 
+int mca_out(hipStream_t st, const float* O, const float* wo, const float* bo, int k, int E, int I, float p, uint64_t seed0, const uint64_t* tick,
+            float* z, const float* q, float* q_new, float mm) {
+  hipLaunchKernelGGL(mca_out_kernel, dim3((unsigned)cdiv(E, 4)), dim3(256), 0, st, O, wo, bo, k, E, I, p, seed0, tick, z, q, q_new, mm);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 struct MergeWs {
   float *xn, *mean, *rstd, *gq, *gmean, *grstd, *KV, *Q, *P, *O, *dd, *dKV, *dQ, *dO, *dxn, *dgq, *dz0, *lnp_w, *lnp_b, *scratch;
   float *stats, *pm, *pl, *po, *prd, *pdq;
@@ -504,6 +517,7 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
               void* ws, int64_t ws_bytes) {
   if (int r = check_merge(m)) return r;
   MHIMX_CHECK_ARG(X && z && R > 0, "merge_fwd: null args");
+  if (merge2_ok(m, R)) return merge2_fwd(st, m, X, R, z, q_new, update_q, ws, ws_bytes);
   const int64_t E = m->E, k = m->k, H = m->heads, I = H * m->dim_head;
   Arena ar(ws, ws_bytes);
   MergeWs w;
@@ -563,8 +577,9 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
               const mhimx_merge_grad* gr, void* ws, int64_t ws_bytes) {
   if (int r = check_merge(m)) return r;
   MHIMX_CHECK_ARG(X && dz && dX && gr && R > 0, "merge_bwd: null args");
-  MHIMX_CHECK_ARG(m->wkv_t && m->wq_t && m->wo_t, "merge_bwd: transposed weights missing");
   MHIMX_CHECK_ARG(gr->d_ln_w && gr->d_ln_b && gr->d_wkv && gr->d_wq && gr->d_wo && gr->d_bo, "merge_bwd: null grads");
+  if (merge2_ok(m, R)) return merge2_bwd(st, m, X, R, dz, dX, gr, ws, ws_bytes);
+  MHIMX_CHECK_ARG(m->wkv_t && m->wq_t && m->wo_t, "merge_bwd: transposed weights missing");
   const int64_t E = m->E, k = m->k, H = m->heads, I = H * m->dim_head;
   Arena ar(ws, ws_bytes);
   MergeWs w;
@@ -638,7 +653,9 @@ extern "C" int mhimx_dropout_apply(void* stream, const float* x, float* out, int
 
 extern "C" int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head) {
   Arena ar(nullptr, 0);
-  return merge_ws_layout(ar, R, E, k, heads, dim_head, nullptr);
+  const int64_t a = merge_ws_layout(ar, R, E, k, heads, dim_head, nullptr);
+  const int64_t b = (E == 512 && heads == 8 && dim_head == 64 && heads * k <= 48) ? merge2_ws_bytes(R, k) : 0;   // either form may run
+  return a > b ? a : b;
 }
 extern "C" int mhimx_merge_fwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new,
                                int32_t update_q, void* ws, int64_t ws_bytes) {

@@ -912,6 +912,12 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   return 0;
 }
 
+int reduce_parts2(hipStream_t st, const float* part0, const float* part1, int G, int W, int ld, float* out0, float* out1, int accumulate) {
+  hipLaunchKernelGGL(reduce_parts2_kernel, dim3((unsigned)cdiv(W, 32), 2), dim3(RP_THREADS), 0, st, part0, part1, G, W, ld, out0, out1, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   MHIMX_CHECK_ARG(list && list->n >= 0 && list->n <= MHIMX_REDUCE_MAX, "reduce_flush: bad list");
   if (list->n == 0) return 0;
