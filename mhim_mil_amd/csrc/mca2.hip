@@ -126,6 +126,40 @@ MHIMX_DEV void m2_ln_stats(const m2_f4& a, const m2_f4& b, float& mu, float& rs)
   rs = rsqrtf(wave_sum(v) * (1.f / M2_E) + 1e-5f);
 }
 
+// out[i][d] = rows[d][:] . vec[i][:] for NR consecutive weight rows (row pitch 512) and the 6 vectors vec[6][512] in LDS (rows >= k
+// zero): one wave per row, NR / 4 rows per wave, all of them fetched before any arithmetic; the inner loop over the vectors is a
+// compile-time 6 (a run-time k leaves every LDS read a dependent round trip).  gout (optional): the same values to global [i][512].
+template <int NR>
+MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, int k, float* out, int out_ld, float* gout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PW = NR / 4;
+  m2_f4 ra[PW], rb[PW];
+#pragma unroll
+  for (int q = 0; q < PW; ++q) {
+    const float* row = rows + (int64_t)(wave * PW + q) * M2_E;
+    ra[q] = *reinterpret_cast<const m2_f4*>(row + 4 * lane);
+    rb[q] = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const m2_f4 ga = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 256 + 4 * lane);
+#pragma unroll
+    for (int q = 0; q < PW; ++q) {
+      const m2_f4 a = ra[q], b = rb[q];
+      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
+      s = wave_sum(s);
+      if (lane == 0 && i < k) {
+        out[i * out_ld + wave * PW + q] = s;
+        if (gout) gout[i * M2_I + wave * PW + q] = s;
+      }
+    }
+  }
+}
+// zero the rows k..5 of a [6][512] LDS block (so that loops over the queries can be a compile-time 6)
+MHIMX_DEV void m2_zero_tail(float* v, int k) {
+  for (int idx = k * M2_E + threadIdx.x; idx < 6 * M2_E; idx += M2_THREADS) v[idx] = 0.f;
+}
+
 // ----------------------------------------------------------------------------------------------------------------------
 // 1. parameters: gq = LN(q), Q = gq Wq^T, aq[(h,i),:] = scale sum_d Q[i,h,d] Wk[h*64+d,:] and its two fragment images.
 //    grid = 8 heads x 8 column blocks of 64.
@@ -138,6 +172,12 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x >> 3, eb = blockIdx.x & 7;
   const int J = M2_H * k;
+  const int c = tid & 63, e = eb * 64 + c;
+  float wv[64];                                               // this thread's column of the head's Wk block: in flight from the start
+#pragma unroll
+  for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(h * 64 + d) * M2_E + e];
+  m2_zero_tail(gqs, k);
+  for (int idx = k * 64 + tid; idx < 6 * 64; idx += M2_THREADS) qh[idx] = 0.f;
   for (int i = wave; i < k; i += 4) {
     const float* row = q_param + (int64_t)i * M2_E;
     const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
@@ -155,64 +195,52 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(const float* __
     }
   }
   __syncthreads();
-  // Q of this head: one wave per output column d, all k queries against the same weight row
-  for (int d = wave; d < 64; d += 4) {
-    const float* row = wq + (int64_t)(h * 64 + d) * M2_E;
-    const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
-    for (int i = 0; i < k; ++i) {
-      const m2_f4 ga = *reinterpret_cast<const m2_f4*>(gqs + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(gqs + i * M2_E + 256 + 4 * lane);
-      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
-      s = wave_sum(s);
-      if (lane == 0) {
-        qh[i * 64 + d] = s;
-        if (eb == 0) w.Q[i * M2_I + h * 64 + d] = s;
-      }
-    }
-  }
+  m2_head_dots<64>(wq + (int64_t)h * 64 * M2_E, gqs, k, qh, 64, eb == 0 ? w.Q + h * 64 : nullptr);     // Q of this head
   __syncthreads();
-  // aq for the 64 columns of this block (rows of Wk are read as 256-byte segments), then the images
-  const int c = tid & 63, e = eb * 64 + c;
+  // aq for the 64 columns of this block, then the images
   for (int i = tid >> 6; i < k; i += 4) {
     float acc = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < 64; ++d) acc += qh[i * 64 + d] * wkv[(int64_t)(h * 64 + d) * M2_E + e];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc += qh[i * 64 + d] * wv[d];
     acc *= scale;
     const int j = h * k + i;
-    w.aq[j * M2_E + e] = acc;
     m2_store_images(w.aqf, w.gtf_aq, j, e, acc);
   }
   for (int j = J + h; j < M2_JK; j += M2_H)                 // zero padding slots (this head's share), 4 threads per column
-    if ((tid >> 6) == ((j - J) >> 3) % 4) {
-      if (j < M2_JP) w.aq[j * M2_E + e] = 0.f;
-      m2_store_images(w.aqf, w.gtf_aq, j, e, 0.f);
-    }
+    if ((tid >> 6) == ((j - J) >> 3) % 4) m2_store_images(w.aqf, w.gtf_aq, j, e, 0.f);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // shared pieces of the two row kernels
 // ----------------------------------------------------------------------------------------------------------------------
-// rows of the tile -> xhat = (x - mean) rstd in LDS [32][516]; `have_stats`: mean / rstd are read instead of computed
+// rows of the tile -> xhat = (x - mean) rstd in LDS [32][516]; HAVE_STATS: mean / rstd are read instead of computed.
+// Also stages the LayerNorm weight and bias in LDS (lnw[512], lnb[512]).
 template <bool HAVE_STATS>
 MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R, int64_t row0, float* xh, float* mean,
-                            float* rstd) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                            float* rstd, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* lnw, float* lnb, float* rs_tile) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   m2_f4 a[8], b[8];
+  float mu8[8], rs8[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {                               // all 16 loads of this wave's rows in flight
+  for (int q = 0; q < 8; ++q) {                               // all 16 row loads of this wave in flight
     const int64_t n = row0 + wave + 4 * q;
     const int64_t nc = n < R ? n : R - 1;
     const float* src = X + (xrows ? xrows[nc] : nc) * M2_E;
     a[q] = *reinterpret_cast<const m2_f4*>(src + 4 * lane);
     b[q] = *reinterpret_cast<const m2_f4*>(src + 256 + 4 * lane);
+    if (HAVE_STATS) { mu8[q] = mean[nc]; rs8[q] = rstd[nc]; }
   }
+  if (tid < 128) *reinterpret_cast<m2_f4*>(lnw + 4 * tid) = *reinterpret_cast<const m2_f4*>(ln_w + 4 * tid);
+  else *reinterpret_cast<m2_f4*>(lnb + 4 * (tid - 128)) = *reinterpret_cast<const m2_f4*>(ln_b + 4 * (tid - 128));
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int rr = wave + 4 * q;
     const int64_t n = row0 + rr;
     float mu, rs;
     if (HAVE_STATS) {
-      mu = n < R ? mean[n] : 0.f;
-      rs = n < R ? rstd[n] : 0.f;
+      mu = mu8[q];
+      rs = rs8[q];
+      if (lane == 0) rs_tile[rr] = rs;
     } else {
       m2_ln_stats(a[q], b[q], mu, rs);
       if (lane == 0 && n < R) { mean[n] = mu; rstd[n] = rs; }
@@ -224,9 +252,22 @@ MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restri
   }
 }
 
-// red[wave][32][48] += (xhat w + b)[32 x 512] . img^T over this wave's quarter of the 512-deep reduction (3-term bf16)
-MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* __restrict__ ln_w, const float* __restrict__ ln_b, const float* __restrict__ img,
-                                   float* red) {
+// the 12 B fragments (3 slot blocks x this wave's 4 k-steps) of a rows x slots product, fetched before the rows are even loaded
+struct M2Frags { m2_f4 h[3][4], l[3][4]; };
+MHIMX_DEV void m2_fetch_frags(const float* __restrict__ img, M2Frags& f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const m2_f4* p = reinterpret_cast<const m2_f4*>(img + ((int64_t)(nb * 16 + 4 * wave + q) * 64 + lane) * 8);
+      f.h[nb][q] = p[0];
+      f.l[nb][q] = p[1];
+    }
+}
+
+// red[wave][32][48] = (xhat w + b)[32 x 512] . img^T over this wave's quarter of the 512-deep reduction (3-term bf16)
+MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* lnw, const float* lnb, const M2Frags& f, float* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
   f32x4 acc[2][3];
@@ -234,11 +275,11 @@ MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* __restrict__ ln
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int ks = 4 * wave; ks < 4 * wave + 4; ++ks) {
-    const int e0 = ks * 32 + kg * 8;
-    const m2_f4 w0 = *reinterpret_cast<const m2_f4*>(ln_w + e0), w1 = *reinterpret_cast<const m2_f4*>(ln_w + e0 + 4);
-    const m2_f4 b0 = *reinterpret_cast<const m2_f4*>(ln_b + e0), b1 = *reinterpret_cast<const m2_f4*>(ln_b + e0 + 4);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e0 = (4 * wave + q) * 32 + kg * 8;
+    const m2_f4 w0 = *reinterpret_cast<const m2_f4*>(lnw + e0), w1 = *reinterpret_cast<const m2_f4*>(lnw + e0 + 4);
+    const m2_f4 b0 = *reinterpret_cast<const m2_f4*>(lnb + e0), b1 = *reinterpret_cast<const m2_f4*>(lnb + e0 + 4);
     bf8 ah[2], al[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -249,8 +290,7 @@ MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* __restrict__ ln
     }
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) {
-      bf8 bh, bl;
-      m2_load_frag(img, nb * 16 + ks, lane, bh, bl);
+      const bf8 bh = __builtin_bit_cast(bf8, f.h[nb][q]), bl = __builtin_bit_cast(bf8, f.l[nb][q]);
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) acc[rb][nb] = m2_mfma3(ah[rb], al[rb], bh, bl, acc[rb][nb]);
     }
@@ -297,7 +337,7 @@ MHIMX_DEV bool m2_keep(uint64_t seed, int j, int64_t r, float p) { return drop_k
 // ----------------------------------------------------------------------------------------------------------------------
 // 2. rows forward: LayerNorm, scores against the J slots, per-tile softmax partials, pooled rows.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t M2_FWD_SMEM = (size_t)(M2_ROWS * M2_XLD + 4 * M2_ROWS * M2_JP + M2_JP * M2_PLD) * sizeof(float);
+constexpr size_t M2_FWD_SMEM = (size_t)(M2_ROWS * M2_XLD + 4 * M2_ROWS * M2_JP + M2_JP * M2_PLD + 2 * M2_E) * sizeof(float);
 
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
@@ -306,12 +346,16 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
   float* xh = m2sm;                                  // [32][516]
   float* red = xh + M2_ROWS * M2_XLD;                // [4][32][48]
   float* pdT = red + 4 * M2_ROWS * M2_JP;            // [48][36]
+  float* lnw = pdT + M2_JP * M2_PLD;                 // [512]
+  float* lnb = lnw + M2_E;                           // [512]
   const int tid = threadIdx.x;
   const int t = blockIdx.x;
   const int64_t row0 = (int64_t)t * M2_ROWS;
-  m2_load_rows<false>(X, xrows, R, row0, xh, w.mean, w.rstd);
+  M2Frags fr;
+  m2_fetch_frags(w.aqf, fr);
+  m2_load_rows<false>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr);
   __syncthreads();
-  m2_rows_times_slots(xh, ln_w, ln_b, w.aqf, red);
+  m2_rows_times_slots(xh, lnw, lnb, fr, red);
   __syncthreads();
   for (int idx = tid; idx < M2_ROWS * M2_JP; idx += M2_THREADS) {
     const float s = (red[idx] + red[M2_ROWS * M2_JP + idx]) + (red[2 * M2_ROWS * M2_JP + idx] + red[3 * M2_ROWS * M2_JP + idx]);
@@ -320,97 +364,122 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
     if (row0 + r < R) w.S[(row0 + r) * M2_JP + (idx - r * M2_JP)] = s;
   }
   __syncthreads();
-  if (tid < M2_JP) {
-    const int j = tid;
-    const int nv = (int)((R - row0) < M2_ROWS ? (R - row0) : M2_ROWS);
-    float m = -INFINITY;
-    if (j < J)
-      for (int r = 0; r < nv; ++r) m = fmaxf(m, red[r * M2_JP + j]);
+  // per-slot softmax partials of the tile: 4 threads per slot (8 rows each), combined through LDS
+  float* sc = red + M2_ROWS * M2_JP;                 // [3][4][48] scratch (the partial-product slabs 1..3 are free)
+  const int j = tid % M2_JP, rq = tid / M2_JP;        // rq < 4 for the first 192 threads
+  const int nv = (int)((R - row0) < M2_ROWS ? (R - row0) : M2_ROWS);
+  float sreg[8], m = -INFINITY;
+  if (rq < 4) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = rq * 8 + q;
+      sreg[q] = red[r * M2_JP + j];
+      if (j < J && r < nv) m = fmaxf(m, sreg[q]);
+    }
+    sc[rq * M2_JP + j] = m;
+  }
+  __syncthreads();
+  if (rq < 4) {
+    m = fmaxf(fmaxf(sc[j], sc[M2_JP + j]), fmaxf(sc[2 * M2_JP + j], sc[3 * M2_JP + j]));
     const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
     const float ks = 1.f / (1.f - drop_p);
     float l = 0.f, sd = 0.f;
-    for (int r = 0; r < M2_ROWS; ++r) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = rq * 8 + q;
       float p = 0.f, pd = 0.f;
       if (j < J && r < nv) {
-        p = __expf(red[r * M2_JP + j] - m);
+        p = __expf(sreg[q] - m);
         pd = (drop_p > 0.f && !m2_keep(seed, j, row0 + r, drop_p)) ? 0.f : p * ks;
       }
       l += p;
       sd += pd;
       pdT[j * M2_PLD + r] = pd;
     }
-    w.pm[t * M2_JP + j] = m;
-    w.pl[t * M2_JP + j] = l;
-    w.psd[t * M2_JP + j] = sd;
+    sc[(4 + rq) * M2_JP + j] = l;
+    sc[(8 + rq) * M2_JP + j] = sd;
   }
   __syncthreads();
+  if (tid < M2_JP) {
+    w.pm[t * M2_JP + tid] = fmaxf(fmaxf(sc[tid], sc[M2_JP + tid]), fmaxf(sc[2 * M2_JP + tid], sc[3 * M2_JP + tid]));
+    w.pl[t * M2_JP + tid] = (sc[4 * M2_JP + tid] + sc[5 * M2_JP + tid]) + (sc[6 * M2_JP + tid] + sc[7 * M2_JP + tid]);
+    w.psd[t * M2_JP + tid] = (sc[8 * M2_JP + tid] + sc[9 * M2_JP + tid]) + (sc[10 * M2_JP + tid] + sc[11 * M2_JP + tid]);
+  }
   m2_pool_rows(pdT, xh, w.ypart + (int64_t)t * M2_JP * M2_E);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
-// 3. merge the tile partials of one head's slots (online softmax, fixed order), Y = Yh w + (sum Pd) b, O = Wv_h Y.
-//    grid = 8 heads x 2 halves of the head's 64 output columns.
+// 3a. merge the T tile partials of every slot: out[j][e] = (sum_t part[t][j][e] wgt_t) scaled.   grid = J slots x 4 column blocks
+//     of 128; 256 threads = 128 columns x 2 halves of the tiles, 16 loads in flight per thread.
+//     SOFTMAX: wgt_t = e^{pm_t - M} / L (online softmax merge, fixed order), out = y ln_w + (sum_t psd_t wgt_t) ln_b, stats = (M, L);
+//     else wgt_t = 1 and out = u ln_w.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_fin_kernel(const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                               const float* __restrict__ wkv, int k, Merge2Ws w) {
-  __shared__ __attribute__((aligned(16))) float ys[6 * M2_E];
-  __shared__ float wt[1024];
+template <bool SOFTMAX>
+__global__ __launch_bounds__(M2_THREADS) void merge2_partials_kernel(const float* __restrict__ part, const float* __restrict__ ln_w,
+                                                                    const float* __restrict__ ln_b, float* __restrict__ out, Merge2Ws w) {
+  __shared__ float wt[256];
   __shared__ float red[8];
+  __shared__ float half1[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int j = blockIdx.x >> 2, e = (blockIdx.x & 3) * 128 + (tid & 127), half = tid >> 7;
   const int T = w.T;
-  for (int i = 0; i < k; ++i) {
-    const int j = h * k + i;
-    float m = -INFINITY;
-    for (int t = tid; t < T; t += M2_THREADS) m = fmaxf(m, w.pm[t * M2_JP + j]);
-    m = wave_max(m);
+  float sdl = 0.f;
+  if (SOFTMAX) {
+    const float pm = tid < T ? w.pm[tid * M2_JP + j] : -INFINITY;
+    const float pl = tid < T ? w.pl[tid * M2_JP + j] : 0.f;
+    const float ps = tid < T ? w.psd[tid * M2_JP + j] : 0.f;
+    float m = wave_max(pm);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float wgt = tid < T ? __expf(pm - M) : 0.f;
+    const float l = wave_sum(pl * wgt), sd = wave_sum(ps * wgt);
+    if (lane == 0) { red[4 + wave] = l; wt[252 + wave] = sd; }      // (wt[252..255] are beyond any tile: T <= 256 uses wt[0..T-1])
     __syncthreads();
-    float L = 0.f, SD = 0.f, y0 = 0.f, y1 = 0.f;
-    for (int t0 = 0; t0 < T; t0 += 1024) {
-      const int nt = T - t0 < 1024 ? T - t0 : 1024;
-      for (int t = tid; t < nt; t += M2_THREADS) wt[t] = __expf(w.pm[(t0 + t) * M2_JP + j] - M);
-      __syncthreads();
-      if (tid == 0) {                                   // fixed order: deterministic
-        float l = 0.f, s = 0.f;
-        for (int t = 0; t < nt; ++t) { l += w.pl[(t0 + t) * M2_JP + j] * wt[t]; s += w.psd[(t0 + t) * M2_JP + j] * wt[t]; }
-        red[4] = l;
-        red[5] = s;
-      }
-      const float* yp = w.ypart + ((int64_t)t0 * M2_JP + j) * M2_E;
-#pragma unroll 4
-      for (int t = 0; t < nt; ++t) {
-        y0 += yp[(int64_t)t * M2_JP * M2_E + tid] * wt[t];
-        y1 += yp[(int64_t)t * M2_JP * M2_E + tid + 256] * wt[t];
-      }
-      __syncthreads();
-      L += red[4];
-      SD += red[5];
-      __syncthreads();
-    }
-    const float inv = 1.f / L;
-    const float v0 = y0 * inv * ln_w[tid] + SD * inv * ln_b[tid], v1 = y1 * inv * ln_w[tid + 256] + SD * inv * ln_b[tid + 256];
-    ys[i * M2_E + tid] = v0;
-    ys[i * M2_E + tid + 256] = v1;
-    if (half == 0) {
-      w.Y[j * M2_E + tid] = v0;
-      w.Y[j * M2_E + tid + 256] = v1;
-      if (tid == 0) { w.stats[2 * j] = M; w.stats[2 * j + 1] = L; }
-    }
+    const float L = (red[4] + red[5]) + (red[6] + red[7]);
+    const float SD = (wt[252] + wt[253]) + (wt[254] + wt[255]);
+    __syncthreads();
+    wt[tid] = wgt / L;
+    sdl = SD / L;
+    if ((blockIdx.x & 3) == 0 && tid == 0) { w.stats[2 * j] = M; w.stats[2 * j + 1] = L; }
+  } else {
+    wt[tid] = tid < T ? 1.f : 0.f;
   }
   __syncthreads();
-  for (int d = half * 32 + wave; d < half * 32 + 32; d += 4) {
-    const float* row = wkv + (int64_t)(M2_I + h * 64 + d) * M2_E;          // the V half of to_kv
-    const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
-    for (int i = 0; i < k; ++i) {
-      const m2_f4 ga = *reinterpret_cast<const m2_f4*>(ys + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(ys + i * M2_E + 256 + 4 * lane);
-      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
-      s = wave_sum(s);
-      if (lane == 0) w.O[i * M2_I + h * 64 + d] = s;
+  float acc = 0.f;
+  const float* pj = part + (int64_t)j * M2_E + e;
+#pragma unroll 1
+  for (int t0 = 0; t0 < T; t0 += 32) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int t = t0 + half * 16 + q;
+      v[q] = t < T ? pj[(int64_t)t * M2_JP * M2_E] : 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += v[q] * wt[(t0 + half * 16 + q) & 255];
   }
+  if (half == 1) half1[tid & 127] = acc;
+  __syncthreads();
+  if (half == 0) {
+    acc += half1[tid];
+    out[j * M2_E + e] = SOFTMAX ? acc * ln_w[e] + sdl * ln_b[e] : acc * ln_w[e];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// 3b. O[i, h*64+d] = Wv[h*64+d, :] . Y[(h,i), :].   grid = 8 heads x 4 quarters of the head's 64 columns
+// ----------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(M2_THREADS) void merge2_o_kernel(const float* __restrict__ wkv, int k, Merge2Ws w) {
+  __shared__ __attribute__((aligned(16))) float ys[6 * M2_E];
+  __shared__ float oh[6 * 16];
+  const int tid = threadIdx.x;
+  const int h = blockIdx.x >> 2, qd = blockIdx.x & 3;
+  m2_zero_tail(ys, k);
+  for (int idx = tid; idx < k * (M2_E / 4); idx += M2_THREADS)
+    reinterpret_cast<m2_f4*>(ys)[idx] = reinterpret_cast<const m2_f4*>(w.Y + (int64_t)h * k * M2_E)[idx];
+  __syncthreads();
+  m2_head_dots<16>(wkv + (int64_t)(M2_I + h * 64 + qd * 16) * M2_E, ys, k, oh, 16, w.O + h * 64 + qd * 16);       // the V half of to_kv
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -427,62 +496,48 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_bwd_pre_kernel(const float*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x >> 3, eb = blockIdx.x & 7;
   const int J = M2_H * k;
+  const int c = tid & 63, e = eb * 64 + c;
+  float wv[64];                                               // this thread's column of the head's Wv block: in flight from the start
+#pragma unroll
+  for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(M2_I + h * 64 + d) * M2_E + e];
+  float yv[2] = {0.f, 0.f};
+  for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) yv[q] = w.Y[(h * k + i) * M2_E + e];
   const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
   const float ks = 1.f / (1.f - drop_p);
   for (int idx = tid; idx < k * M2_E; idx += M2_THREADS) {
-    const int i = idx >> 9, e = idx & 511;
+    const int i = idx >> 9, ee = idx & 511;
     float v = dz[idx];
-    if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)e, drop_p) ? v * ks : 0.f;
+    if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)ee, drop_p) ? v * ks : 0.f;
     dzs[idx] = v;
   }
+  m2_zero_tail(dzs, k);
   __syncthreads();
   if (h == 0 && tid < 64) {
-    const int e = eb * 64 + tid;
     float s = 0.f;
     for (int i = 0; i < k; ++i) s += dzs[i * M2_E + e];
     d_bo[e] = accumulate ? d_bo[e] + s : s;
   }
-  for (int d = wave; d < 64; d += 4) {
-    const float* row = wo_t + (int64_t)(h * 64 + d) * M2_E;
-    const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
-    for (int i = 0; i < k; ++i) {
-      const m2_f4 ga = *reinterpret_cast<const m2_f4*>(dzs + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(dzs + i * M2_E + 256 + 4 * lane);
-      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
-      s = wave_sum(s);
-      if (lane == 0) {
-        doh[i * 64 + d] = s;
-        if (eb == 0) w.dO[i * M2_I + h * 64 + d] = s;
-      }
-    }
-  }
+  m2_head_dots<64>(wo_t + (int64_t)h * 64 * M2_E, dzs, k, doh, 64, eb == 0 ? w.dO + h * 64 : nullptr);
   __syncthreads();
-  const int c = tid & 63, e = eb * 64 + c;
-  for (int i = tid >> 6; i < k; i += 4) {
+  for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) {
     float acc = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < 64; ++d) acc += doh[i * 64 + d] * wkv[(int64_t)(M2_I + h * 64 + d) * M2_E + e];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc += doh[i * 64 + d] * wv[d];
     const int j = h * k + i;
-    dys[i * 64 + c] = acc;
     m2_store_images(w.dyf, w.gtf_dy, j, e, acc);
+    const float s = wave_sum(acc * yv[q]);                    // (a wave = one query i x the 64 columns of this block)
+    if (lane == 0) w.dpart[j * 8 + eb] = s;
   }
   for (int j = J + h; j < M2_JK; j += M2_H)
     if ((tid >> 6) == ((j - J) >> 3) % 4) m2_store_images(w.dyf, w.gtf_dy, j, e, 0.f);
-  __syncthreads();
-  for (int i = wave; i < k; i += 4) {
-    const int j = h * k + i;
-    const float s = wave_sum(dys[i * 64 + lane] * w.Y[j * M2_E + eb * 64 + lane]);
-    if (lane == 0) w.dpart[j * 8 + eb] = s;
-  }
-  if (h == 0 && eb == 0)
-    for (int j = J + tid; j < M2_JP; j += M2_THREADS)
-      for (int q = 0; q < 8; ++q) w.dpart[j * 8 + q] = 0.f;
+  (void)dys; (void)wave;
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // 5. rows backward: dPd = xn dY^T, softmax backward, dxn = ds aq + Pd dY, LayerNorm backward (dX scattered to the rows' places,
 //    per-tile d_ln_w / d_ln_b partials), pooled U partials.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t M2_BWD_SMEM = (size_t)(2 * M2_ROWS * M2_XLD + M2_ROWS * M2_CLD + M2_JP * M2_PLD) * sizeof(float);
+constexpr size_t M2_BWD_SMEM = (size_t)(2 * M2_ROWS * M2_XLD + M2_ROWS * M2_CLD + M2_JP * M2_PLD + 2 * M2_E + 3 * M2_JK + M2_ROWS) * sizeof(float);
 static_assert(M2_ROWS * M2_CLD >= 8 * M2_E, "the LayerNorm partials reuse the coefficient tile");
 
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
@@ -494,31 +549,54 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
   float* dxs = xh + M2_ROWS * M2_XLD;                 // [32][516]; first the [4][32][48] reduction buffer of dPd
   float* cf = dxs + M2_ROWS * M2_XLD;                 // [32][132]: ds (slots 0..63) | Pd (64..127)
   float* dsT = cf + M2_ROWS * M2_CLD;                 // [48][36]
+  float* lnw = dsT + M2_JP * M2_PLD;                  // [512]
+  float* lnb = lnw + M2_E;                            // [512]
+  float* sst = lnb + M2_E;                            // [64][3]: softmax max, 1 / sum, delta of every slot
+  float* rst = sst + 3 * M2_JK;                       // [32] rstd of the tile's rows
   float* lnred = cf;                                  // [4][2][512]: the coefficient tile is in registers by then
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
   const int t = blockIdx.x;
   const int64_t row0 = (int64_t)t * M2_ROWS;
-  m2_load_rows<true>(X, xrows, R, row0, xh, w.mean, w.rstd);
+  M2Frags fr;
+  m2_fetch_frags(w.dyf, fr);
+  if (tid < M2_JK) {
+    const int j = tid;
+    float mx = 0.f, il = 0.f, de = 0.f;
+    if (j < J) {
+      mx = w.stats[2 * j];
+      il = 1.f / w.stats[2 * j + 1];
+      const m2_f4 d0 = *reinterpret_cast<const m2_f4*>(w.dpart + j * 8), d1 = *reinterpret_cast<const m2_f4*>(w.dpart + j * 8 + 4);
+      de = ((d0[0] + d0[1]) + (d0[2] + d0[3])) + ((d1[0] + d1[1]) + (d1[2] + d1[3]));
+    }
+    sst[3 * j] = mx; sst[3 * j + 1] = il; sst[3 * j + 2] = de;
+  }
+  // the scores of the tile's (row, slot) pairs this thread will turn into probabilities: in flight under the row loads
+  float sv[M2_ROWS * M2_JK / M2_THREADS];
+#pragma unroll
+  for (int q = 0; q < M2_ROWS * M2_JK / M2_THREADS; ++q) {
+    const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
+    sv[q] = (j < J && row0 + r < R) ? w.S[(row0 + r) * M2_JP + j] : 0.f;
+  }
+  m2_load_rows<true>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, rst);
   __syncthreads();
-  m2_rows_times_slots(xh, ln_w, ln_b, w.dyf, dxs);
+  m2_rows_times_slots(xh, lnw, lnb, fr, dxs);
   __syncthreads();
   // ---- softmax backward per (row, slot)
   {
     const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
     const float ks = 1.f / (1.f - drop_p);
-    for (int idx = tid; idx < M2_ROWS * M2_JK; idx += M2_THREADS) {
-      const int r = idx >> 6, j = idx & 63;
+#pragma unroll
+    for (int q = 0; q < M2_ROWS * M2_JK / M2_THREADS; ++q) {
+      const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
       float ds = 0.f, pd = 0.f;
       if (j < J && row0 + r < R) {
-        const int q = r * M2_JP + j;
-        const float dpd = (dxs[q] + dxs[M2_ROWS * M2_JP + q]) + (dxs[2 * M2_ROWS * M2_JP + q] + dxs[3 * M2_ROWS * M2_JP + q]);
-        const float p = __expf(w.S[(row0 + r) * M2_JP + j] - w.stats[2 * j]) / w.stats[2 * j + 1];
-        const float* dp8 = w.dpart + j * 8;
-        const float delta = ((dp8[0] + dp8[1]) + (dp8[2] + dp8[3])) + ((dp8[4] + dp8[5]) + (dp8[6] + dp8[7]));
+        const int qq = r * M2_JP + j;
+        const float dpd = (dxs[qq] + dxs[M2_ROWS * M2_JP + qq]) + (dxs[2 * M2_ROWS * M2_JP + qq] + dxs[3 * M2_ROWS * M2_JP + qq]);
+        const float p = __expf(sv[q] - sst[3 * j]) * sst[3 * j + 1];
         const float kf = (drop_p > 0.f && !m2_keep(seed, j, row0 + r, drop_p)) ? 0.f : ks;
         pd = p * kf;
-        ds = p * (dpd * kf - delta);
+        ds = p * (dpd * kf - sst[3 * j + 2]);
       }
       cf[r * M2_CLD + j] = ds;
       cf[r * M2_CLD + M2_JK + j] = pd;
@@ -526,7 +604,8 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
     }
   }
   __syncthreads();
-  // ---- dxn[32 x 512] = cf[32 x 128] . [aq ; dY]  (K = 128 = 4 steps of 32; B from the transposed fragment images)
+  // ---- dxn[32 x 512] = cf[32 x 128] . [aq ; dY]  (K = 128 = 4 steps of 32; B from the transposed fragment images, 4 column blocks
+  //      = 32 fragment loads in flight at a time)
   {
     bf8 ah[2][4], al[2][4];
 #pragma unroll
@@ -538,33 +617,48 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
         const float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
         m2_split8(v, ah[rb][ks], al[rb][ks]);
       }
-    __syncthreads();                                  // (every wave has read its dPd partials: dxs is free)
+    __syncthreads();                                  // (every wave has read its dPd partials and the coefficient tile: both free)
 #pragma unroll 1
-    for (int eb = 8 * wave; eb < 8 * wave + 8; ++eb) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int eb0 = 8 * wave; eb0 < 8 * wave + 8; eb0 += 4) {
+      m2_f4 bh[4][4], bl[4][4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf8 bh, bl;
-        m2_load_frag(ks < 2 ? w.gtf_aq : w.gtf_dy, eb * 2 + (ks & 1), lane, bh, bl);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[rb] = m2_mfma3(ah[rb][ks], al[rb][ks], bh, bl, acc[rb]);
+        for (int ks = 0; ks < 4; ++ks) {
+          const m2_f4* p = reinterpret_cast<const m2_f4*>((ks < 2 ? w.gtf_aq : w.gtf_dy) + ((int64_t)((eb0 + q) * 2 + (ks & 1)) * 64 + lane) * 8);
+          bh[q][ks] = p[0];
+          bl[q][ks] = p[1];
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+            acc[rb] = m2_mfma3(ah[rb][ks], al[rb][ks], __builtin_bit_cast(bf8, bh[q][ks]), __builtin_bit_cast(bf8, bl[q][ks]), acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dxs[(rb * 16 + 4 * kg + i) * M2_XLD + (eb0 + q) * 16 + r16] = acc[rb][i];
       }
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dxs[(rb * 16 + 4 * kg + i) * M2_XLD + eb * 16 + r16] = acc[rb][i];
     }
   }
   __syncthreads();
   // ---- LayerNorm backward, 8 rows per wave: dxhat = dxn w;  dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat))
   {
-    const m2_f4 wa = *reinterpret_cast<const m2_f4*>(ln_w + 4 * lane), wb = *reinterpret_cast<const m2_f4*>(ln_w + 256 + 4 * lane);
+    const m2_f4 wa = *reinterpret_cast<const m2_f4*>(lnw + 4 * lane), wb = *reinterpret_cast<const m2_f4*>(lnw + 256 + 4 * lane);
     m2_f4 dwa = m2_f4{0.f, 0.f, 0.f, 0.f}, dwb = dwa, dba = dwa, dbb = dwa;
-#pragma unroll 2
+    int64_t dst_row[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t n = row0 + wave + 4 * q;
+      dst_row[q] = n < R ? (xrows ? xrows[n] : n) : -1;
+    }
+#pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int rr = wave + 4 * q;
-      const int64_t n = row0 + rr;
-      if (n >= R) continue;
+      if (dst_row[q] < 0) continue;
       const m2_f4 ga = *reinterpret_cast<const m2_f4*>(dxs + rr * M2_XLD + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(dxs + rr * M2_XLD + 256 + 4 * lane);
       const m2_f4 xa = *reinterpret_cast<const m2_f4*>(xh + rr * M2_XLD + 4 * lane), xb = *reinterpret_cast<const m2_f4*>(xh + rr * M2_XLD + 256 + 4 * lane);
       dwa += ga * xa; dwb += gb * xb; dba += ga; dbb += gb;
@@ -574,11 +668,12 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
       float s2 = (pa[0] + pa[1]) + (pa[2] + pa[3]) + (pb[0] + pb[1]) + (pb[2] + pb[3]);
       s1 = wave_sum(s1) * (1.f / M2_E);
       s2 = wave_sum(s2) * (1.f / M2_E);
-      const float rs = w.rstd[n];
-      float* dst = dX + (xrows ? xrows[n] : n) * M2_E;
+      const float rs = rst[rr];
+      float* dst = dX + dst_row[q] * M2_E;
       *reinterpret_cast<m2_f4*>(dst + 4 * lane) = (ha - s1 - xa * s2) * rs;
       *reinterpret_cast<m2_f4*>(dst + 256 + 4 * lane) = (hb - s1 - xb * s2) * rs;
     }
+    __syncthreads();                                  // (lnred aliases cf; nobody reads cf any more, but keep the waves together)
     *reinterpret_cast<m2_f4*>(lnred + (wave * 2) * M2_E + 4 * lane) = dwa;
     *reinterpret_cast<m2_f4*>(lnred + (wave * 2) * M2_E + 256 + 4 * lane) = dwb;
     *reinterpret_cast<m2_f4*>(lnred + (wave * 2 + 1) * M2_E + 4 * lane) = dba;
@@ -592,82 +687,84 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
-// 6. rank-k gradients, first launch.   blocks 0..15: (head, half): U = (sum_t upart) w, dQ = scale Wk U, d_wkv rows of this half
-//    (K part: scale Q (x) U, V part: dO (x) Y);   blocks 16..31: 32 rows of d_wo = dz0^T O.
+// 6. rank-k gradients, first launch (U merged by merge2_partials_kernel<false> before).   blocks 0..31: (head, quarter): dQ = scale Wk U and
+//    16 + 16 rows of d_wkv (K part: scale Q (x) U, V part: dO (x) Y);   blocks 32..47: 32 rows of d_wo = dz0^T O.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(const float* __restrict__ dz, const float* __restrict__ ln_w,
+__global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(const float* __restrict__ dz, const float* __restrict__ U,
                                                                   const float* __restrict__ wkv, int k, float scale, float drop_p, uint64_t seed0,
                                                                   const uint64_t* __restrict__ tick, float* __restrict__ d_wkv,
                                                                   float* __restrict__ d_wo, int accumulate, Merge2Ws w) {
   __shared__ __attribute__((aligned(16))) float us[6 * M2_E];
   __shared__ __attribute__((aligned(16))) float ysh[6 * M2_E];
-  __shared__ float qd[2 * 6 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x >= 16) {
-    const int e0 = (blockIdx.x - 16) * 32;
+  __shared__ __attribute__((aligned(16))) float qd[32 * 12];        // [row][6 x scale Q | 6 x dO]  (d_wo blocks: [32][8] dz0)
+  __shared__ float dqh[6 * 16];
+  const int tid = threadIdx.x;
+  if (blockIdx.x >= 32) {
+    // 32 rows of d_wo[e, c] = sum_i dz0[i, e] O[i, c]: thread = two columns c, the k values of O in registers
+    const int e0 = (blockIdx.x - 32) * 32;
     const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
     const float ks = 1.f / (1.f - drop_p);
-    float* dzr = us;                                     // [k][32] dz0 of these rows
-    for (int idx = tid; idx < k * 32; idx += M2_THREADS) {
-      const int i = idx >> 5, e = e0 + (idx & 31);
-      float v = dz[i * M2_E + e];
-      if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)e, drop_p) ? v * ks : 0.f;
-      dzr[idx] = v;
+    float o0[6], o1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      o0[i] = i < k ? w.O[i * M2_I + tid] : 0.f;
+      o1[i] = i < k ? w.O[i * M2_I + tid + 256] : 0.f;
     }
-    for (int idx = tid; idx < k * M2_I; idx += M2_THREADS) ysh[idx] = w.O[idx];
+    for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
+      const int r = idx >> 3, i = idx & 7, e = e0 + r;
+      float v = 0.f;
+      if (i < k) {
+        v = dz[i * M2_E + e];
+        if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)e, drop_p) ? v * ks : 0.f;
+      }
+      qd[idx] = v;
+    }
     __syncthreads();
-    for (int idx = tid; idx < 32 * M2_I; idx += M2_THREADS) {
-      const int r = idx >> 9, c = idx & 511;
-      float s = 0.f;
-      for (int i = 0; i < k; ++i) s += dzr[i * 32 + r] * ysh[i * M2_I + c];
-      float* o = d_wo + (int64_t)(e0 + r) * M2_I + c;
-      *o = accumulate ? *o + s : s;
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      const m2_f4 z0 = *reinterpret_cast<const m2_f4*>(qd + r * 8), z1 = *reinterpret_cast<const m2_f4*>(qd + r * 8 + 4);
+      const float s0 = z0[0] * o0[0] + z0[1] * o0[1] + z0[2] * o0[2] + z0[3] * o0[3] + z1[0] * o0[4] + z1[1] * o0[5];
+      const float s1 = z0[0] * o1[0] + z0[1] * o1[1] + z0[2] * o1[2] + z0[3] * o1[3] + z1[0] * o1[4] + z1[1] * o1[5];
+      float* o = d_wo + (int64_t)(e0 + r) * M2_I + tid;
+      o[0] = accumulate ? o[0] + s0 : s0;
+      o[256] = accumulate ? o[256] + s1 : s1;
     }
     return;
   }
-  const int h = blockIdx.x >> 1, half = blockIdx.x & 1;
-  const int T = w.T;
-  for (int i = 0; i < k; ++i) {
-    const int j = h * k + i;
-    const float* up = w.upart + (int64_t)j * M2_E;
-    float u0 = 0.f, u1 = 0.f;
-#pragma unroll 4
-    for (int t = 0; t < T; ++t) {                        // fixed order: deterministic
-      u0 += up[(int64_t)t * M2_JP * M2_E + tid];
-      u1 += up[(int64_t)t * M2_JP * M2_E + tid + 256];
-    }
-    us[i * M2_E + tid] = u0 * ln_w[tid];
-    us[i * M2_E + tid + 256] = u1 * ln_w[tid + 256];
-    ysh[i * M2_E + tid] = w.Y[j * M2_E + tid];
-    ysh[i * M2_E + tid + 256] = w.Y[j * M2_E + tid + 256];
+  const int h = blockIdx.x >> 2, qr = blockIdx.x & 3;             // 16 of the head's 64 rows
+  m2_zero_tail(us, k);
+  for (int idx = tid; idx < k * (M2_E / 4); idx += M2_THREADS) reinterpret_cast<m2_f4*>(us)[idx] = reinterpret_cast<const m2_f4*>(U + (int64_t)h * k * M2_E)[idx];
+  float y0[6], y1[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    y0[i] = i < k ? w.Y[(h * k + i) * M2_E + tid] : 0.f;
+    y1[i] = i < k ? w.Y[(h * k + i) * M2_E + tid + 256] : 0.f;
   }
-  for (int idx = tid; idx < k * 32; idx += M2_THREADS) {
-    const int i = idx >> 5, d = half * 32 + (idx & 31);
-    qd[idx] = scale * w.Q[i * M2_I + h * 64 + d];
-    qd[6 * 32 + idx] = w.dO[i * M2_I + h * 64 + d];
+  for (int idx = tid; idx < 16 * 12; idx += M2_THREADS) {
+    const int dl = idx / 12, c = idx - dl * 12, i = c % 6, d = h * 64 + qr * 16 + dl;
+    qd[idx] = i < k ? (c < 6 ? scale * w.Q[i * M2_I + d] : w.dO[i * M2_I + d]) : 0.f;
   }
   __syncthreads();
-  for (int d = half * 32 + wave; d < half * 32 + 32; d += 4) {
-    const float* row = wkv + (int64_t)(h * 64 + d) * M2_E;            // the K half of to_kv
-    const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
-    for (int i = 0; i < k; ++i) {
-      const m2_f4 ga = *reinterpret_cast<const m2_f4*>(us + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(us + i * M2_E + 256 + 4 * lane);
-      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
-      s = wave_sum(s);
-      if (lane == 0) w.dQ[i * M2_I + h * 64 + d] = scale * s;
-    }
-  }
-  for (int idx = tid; idx < 32 * M2_E; idx += M2_THREADS) {
-    const int dl = idx >> 9, e = idx & 511;
-    float sk = 0.f, sv = 0.f;
-    for (int i = 0; i < k; ++i) {
-      sk += qd[i * 32 + dl] * us[i * M2_E + e];
-      sv += qd[6 * 32 + i * 32 + dl] * ysh[i * M2_E + e];
-    }
-    float* ok = d_wkv + (int64_t)(h * 64 + half * 32 + dl) * M2_E + e;
-    float* ov = d_wkv + (int64_t)(M2_I + h * 64 + half * 32 + dl) * M2_E + e;
-    *ok = accumulate ? *ok + sk : sk;
-    *ov = accumulate ? *ov + sv : sv;
+  m2_head_dots<16>(wkv + (int64_t)(h * 64 + qr * 16) * M2_E, us, k, dqh, 16, nullptr);             // the K half of to_kv
+  float u0[6], u1[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { u0[i] = us[i * M2_E + tid]; u1[i] = us[i * M2_E + tid + 256]; }
+  __syncthreads();
+  if (tid < 16 * 6 && (tid / 16) < k) w.dQ[(tid / 16) * M2_I + h * 64 + qr * 16 + (tid & 15)] = scale * dqh[tid];
+#pragma unroll 4
+  for (int dl = 0; dl < 16; ++dl) {
+    const m2_f4 c0 = *reinterpret_cast<const m2_f4*>(qd + dl * 12), c1 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 4),
+                c2 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 8);
+    const float q6[6] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1]}, o6[6] = {c1[2], c1[3], c2[0], c2[1], c2[2], c2[3]};
+    float sk0 = 0.f, sk1 = 0.f, sv0 = 0.f, sv1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { sk0 += q6[i] * u0[i]; sk1 += q6[i] * u1[i]; sv0 += o6[i] * y0[i]; sv1 += o6[i] * y1[i]; }
+    float* ok = d_wkv + (int64_t)(h * 64 + qr * 16 + dl) * M2_E + tid;
+    float* ov = d_wkv + (int64_t)(M2_I + h * 64 + qr * 16 + dl) * M2_E + tid;
+    ok[0] = accumulate ? ok[0] + sk0 : sk0;
+    ok[256] = accumulate ? ok[256] + sk1 : sk1;
+    ov[0] = accumulate ? ov[0] + sv0 : sv0;
+    ov[256] = accumulate ? ov[256] + sv1 : sv1;
   }
 }
 
@@ -677,34 +774,50 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(const float* 
 // ----------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(M2_THREADS) void merge2_grads2_kernel(const float* __restrict__ q_param, const float* __restrict__ wq, int k,
                                                                   float* __restrict__ d_wq, int accumulate, Merge2Ws w) {
-  __shared__ __attribute__((aligned(16))) float gqs[6 * M2_E];
   __shared__ float dqs[6 * M2_I];
-  __shared__ float part[4 * 6 * 64];
+  __shared__ __attribute__((aligned(16))) float part[4 * 6 * 64];
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < k * M2_I; idx += M2_THREADS) dqs[idx] = w.dQ[idx];
   if (blockIdx.x < 16) {
-    for (int idx = tid; idx < k * M2_E; idx += M2_THREADS) gqs[idx] = w.gq[idx];
-    __syncthreads();
+    // 32 rows of d_wq[c, e] = sum_i dQ[i, c] gq[i, e]: thread = two columns e, the k values of gq in registers
     const int c0 = blockIdx.x * 32;
-    for (int idx = tid; idx < 32 * M2_E; idx += M2_THREADS) {
-      const int r = idx >> 9, e = idx & 511;
-      float s = 0.f;
-      for (int i = 0; i < k; ++i) s += dqs[i * M2_I + c0 + r] * gqs[i * M2_E + e];
-      float* o = d_wq + (int64_t)(c0 + r) * M2_E + e;
-      *o = accumulate ? *o + s : s;
+    float g0[6], g1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      g0[i] = i < k ? w.gq[i * M2_E + tid] : 0.f;
+      g1[i] = i < k ? w.gq[i * M2_E + tid + 256] : 0.f;
+    }
+    for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
+      const int r = idx >> 3, i = idx & 7;
+      part[idx] = i < k ? w.dQ[i * M2_I + c0 + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      const m2_f4 z0 = *reinterpret_cast<const m2_f4*>(part + r * 8), z1 = *reinterpret_cast<const m2_f4*>(part + r * 8 + 4);
+      const float s0 = z0[0] * g0[0] + z0[1] * g0[1] + z0[2] * g0[2] + z0[3] * g0[3] + z1[0] * g0[4] + z1[1] * g0[5];
+      const float s1 = z0[0] * g1[0] + z0[1] * g1[1] + z0[2] * g1[2] + z0[3] * g1[3] + z1[0] * g1[4] + z1[1] * g1[5];
+      float* o = d_wq + (int64_t)(c0 + r) * M2_E + tid;
+      o[0] = accumulate ? o[0] + s0 : s0;
+      o[256] = accumulate ? o[256] + s1 : s1;
     }
     return;
   }
-  __syncthreads();
   const int eb = blockIdx.x - 16, c = tid & 63, e = eb * 64 + c, cq = tid >> 6;
+  // this thread's 128 values of column e (rows cq, cq + 4, ...): fetched 32 at a time, before the query gradients are needed
   float acc[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
-  for (int cc = cq; cc < M2_I; cc += 4) {                  // rows of Wq as 256-byte segments, 4 row groups
-    const float wv = wq[(int64_t)cc * M2_E + e];
+  for (int idx = tid; idx < 6 * M2_I; idx += M2_THREADS) dqs[idx] = idx < k * M2_I ? w.dQ[idx] : 0.f;
+  __syncthreads();
+#pragma unroll 1
+  for (int c0 = 0; c0 < M2_I; c0 += 128) {
+    float wv[32];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      if (i < k) acc[i] += dqs[i * M2_I + cc] * wv;
+    for (int q = 0; q < 32; ++q) wv[q] = wq[(int64_t)(c0 + cq + 4 * q) * M2_E + e];
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i] += dqs[i * M2_I + c0 + cq + 4 * q] * wv[q];
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) part[(cq * 6 + i) * 64 + c] = acc[i];
@@ -743,7 +856,9 @@ int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   hipLaunchKernelGGL(merge2_rows_fwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_FWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
                      m->drop_seed, m->drop_tick, w);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(merge2_fin_kernel, dim3(16), dim3(M2_THREADS), 0, st, m->ln_w, m->ln_b, m->wkv, k, w);
+  hipLaunchKernelGGL(merge2_partials_kernel<true>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, w.ypart, m->ln_w, m->ln_b, w.Y, w);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(merge2_o_kernel, dim3(M2_H * 4), dim3(M2_THREADS), 0, st, m->wkv, k, w);
   MHIMX_LAUNCH_CHECK();
   return mca_out(st, w.O, m->wo, m->bo, k, M2_E, M2_I, m->drop_p, m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, z, m->q_param,
                  update_q ? q_new : (float*)nullptr, m->mm);
@@ -766,7 +881,10 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   hipLaunchKernelGGL(merge2_rows_bwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_BWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
                      m->drop_seed, m->drop_tick, dX, w);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(merge2_grads1_kernel, dim3(32), dim3(M2_THREADS), 0, st, dz, m->ln_w, m->wkv, k, scale, m->drop_p, oseed, m->drop_tick, gr->d_wkv,
+  float* U = w.aq;                                         // (the fp32 copy of aq is not needed any more: its place takes U [J, E])
+  hipLaunchKernelGGL(merge2_partials_kernel<false>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, w.upart, m->ln_w, m->ln_b, U, w);
+  MHIMX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(merge2_grads1_kernel, dim3(48), dim3(M2_THREADS), 0, st, dz, U, m->wkv, k, scale, m->drop_p, oseed, m->drop_tick, gr->d_wkv,
                      gr->d_wo, acc, w);
   MHIMX_LAUNCH_CHECK();
   hipLaunchKernelGGL(merge2_grads2_kernel, dim3(24), dim3(M2_THREADS), 0, st, m->q_param, m->wq, k, gr->d_wq, acc, w);
