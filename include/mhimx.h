@@ -121,7 +121,14 @@ typedef struct {
   int64_t G, W, ld, K1, K2, ldo;
 } mhimx_reduce_job;
 #define MHIMX_REDUCE_MAX 16
-typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; } mhimx_reduce_list;
+/* Deferred side work.  The tail of the Merge backward (merging its pooled-row partials, rank-k weight gradients: three small dependent
+ * launches) feeds nothing but the optimiser either.  With a list, mhimx_merge_bwd parks it here (an opaque argument block) and the later
+ * launches of the same backward that take the list give its stages a ride as extra workgroups: stage 1 in mhimx_rows_dpre, stage 2 in the
+ * projection's weight-gradient mhimx_gemm_tn, stage 3 in mhimx_reduce_flush; mhimx_reduce_flush first launches whatever got no ride.
+ * pending: 0 = nothing parked, else the next stage to run. */
+#define MHIMX_SIDE_BYTES 384
+typedef struct { int32_t pending; int32_t reserved; unsigned char blob[MHIMX_SIDE_BYTES]; } mhimx_side_work;
+typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; mhimx_side_work side; } mhimx_reduce_list;
 int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list);      /* no-op when list->n == 0; list->n = 0 on return */
 
 /* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over
@@ -153,7 +160,9 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  *     16-column step ks, 64 consecutive 32-byte items (item l: 8 bf16 hi | 8 bf16 lo of in[32 nt + l % 32][16 ks + 8 (l / 32) ..])
  *     - what mhimx_scorer.wa_frag takes,
  * 5 = the kind-4 image of the TRANSPOSE in^T [C,R] made straight from in[R,C] (C % 32 == 0, R % 16 == 0) - what
- *     mhimx_pool_grad.wa_t_frag takes (jobs of one launch run concurrently: one cannot read another's output). */
+ *     mhimx_pool_grad.wa_t_frag takes (jobs of one launch run concurrently: one cannot read another's output),
+ * 6 = the parameter-only part of a Merge forward (mhimx_merge_fwd with .prepared = 1 then skips it): `in` is the HOST address of the
+ *     mhimx_merge block (read while enqueueing), out = the Merge workspace (device), R = rows to merge, C = workspace bytes. */
 #define MHIMX_PREP_MAX 16
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
@@ -332,6 +341,8 @@ typedef struct {
                                          projection, its dots and the softmax partials are ONE kernel per row tile       */
   const int64_t* x_rows;              /* optional gather: row n of the block to merge is X[x_rows[n]] (forward) and its gradient goes to
                                          dX[x_rows[n]] (backward): merge.py:158-176 masking without a row copy         */
+  int32_t prepared;                   /* 1: the parameter-only part (LN(q), Q, the score vectors) is already in the workspace, written by a
+                                         kind-6 job of mhimx_prep_batch on the same stream, for the same weights, R and workspace */
 } mhimx_merge;
 int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
 /* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */

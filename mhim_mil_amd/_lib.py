@@ -59,8 +59,15 @@ class ReduceJob(C.Structure):
 REDUCE_MAX = 16
 
 
+SIDE_BYTES = 384
+
+
+class SideWork(C.Structure):
+    _fields_ = [("pending", C.c_int32), ("reserved", C.c_int32), ("blob", C.c_ubyte * SIDE_BYTES)]
+
+
 class ReduceListC(C.Structure):
-    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32)]
+    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32), ("side", SideWork)]
 
 
 class GemmTN(C.Structure):
@@ -99,7 +106,7 @@ class Merge(C.Structure):
                 ("wkv", c_f32p), ("wq", c_f32p), ("wo", c_f32p), ("bo", c_f32p),
                 ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
                 ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p),
-                ("wkv_frag", c_f32p), ("x_rows", c_i64p)]
+                ("wkv_frag", c_f32p), ("x_rows", c_i64p), ("prepared", C.c_int32)]
 
 
 class MergeGrad(C.Structure):

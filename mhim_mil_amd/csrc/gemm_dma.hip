@@ -11,7 +11,10 @@
 //       image: 8 x ds_read_b32 with consecutive lanes on consecutive banks.  No transposing stores.
 // Requirements (else the register-staged kernels in gemm.hip run): K % 32 == 0 (nt); K1,K2 % 128 == 0 (tn);
 // 16-byte aligned rows.
+#include <string.h>
+
 #include "common.hpp"
+#include "mca2_side.hpp"
 
 namespace mhimx {
 
@@ -387,16 +390,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
 // TN
 // =================================================================================================
 template <int PREC>
-__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk) {
+__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, Merge2Side side) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2): its few short workgroups are
+    merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);      // dispatched first and free their slots early
+    return;
+  }
+  const unsigned bx = blockIdx.x - (unsigned)side_blocks;      // (side_blocks % 8 == 0: the XCD of a tile does not move)
   int64_t* rowtab = reinterpret_cast<int64_t*>(smem + TN_STAGES * STAGE_BYTES);       // [mchunk] B-row element offsets
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware order: all output tiles of one reduction slab run on one XCD (its rows of A and B are shared via L2)
   const int nJ = (int)(g.K2 / DBN), nT = (int)(g.K1 / DBM) * nJ;
-  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int xcd = bx & 7, sidx = bx >> 3;
   const int zslab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
   if (zslab >= g.splits && !(g.splits <= 1 && zslab == 0)) return;
   const int64_t i0 = (int64_t)(tile / nJ) * DBM, j0 = (int64_t)(tile % nJ) * DBN;
@@ -518,7 +526,8 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
 // One launch for the parameter-only preparation of a train step (a block range per job).  kind 0: out[c,r] = in[r,c];
 // kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters);
 // kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip); kind 5: the same image of in^T.
-struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; };
+struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; Merge2PrepArgs m2; };
+int merge2_prep_args(const mhimx_merge* m, int64_t R, void* ws, int64_t ws_bytes, Merge2PrepArgs* out);      // mca2.hip
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
   // 1-D grid: job q owns blocks [first[q], first[q+1]) - sized per job (the bag's paired-plane image wants thousands of
   // workgroups, a weight transpose a few dozen; a rectangular grid would launch tens of thousands of empty blocks)
@@ -591,16 +600,23 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
       o[0] = __builtin_bit_cast(f4, hi);
       o[1] = __builtin_bit_cast(f4, lo);
     }
+  } else if (jb.kind == 6) {
+    merge2_prep_body(bid, pj.m2.q_param, pj.m2.ln_w, pj.m2.ln_b, pj.m2.wq, pj.m2.wkv, pj.m2.k, pj.m2.scale, pj.m2.w);
   }
 }
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
   MHIMX_CHECK_ARG(jobs && n >= 1 && n <= MHIMX_PREP_MAX, "prep_batch: 1..%d jobs", MHIMX_PREP_MAX);
   PrepJobs pj;
   pj.n = n;
+  int n_merge = 0;
   for (int i = 0; i < n; ++i) {
     pj.j[i] = jobs[i];
     MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
-    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 5, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 6, "prep_batch: unknown job kind");
+    if (jobs[i].kind == 6) {
+      MHIMX_CHECK_ARG(n_merge++ == 0, "prep_batch: one Merge preparation job per launch");
+      if (int r = merge2_prep_args(reinterpret_cast<const mhimx_merge*>(jobs[i].in), jobs[i].R, jobs[i].out, jobs[i].C, &pj.m2)) return r;
+    }
     MHIMX_CHECK_ARG(jobs[i].kind != 5 || (jobs[i].C % 32 == 0 && jobs[i].R % 16 == 0 && aligned16(jobs[i].out)),
                     "prep_batch: the transposed fragment image needs C % 32 == 0, R % 16 == 0 and a 16-byte aligned output");
     MHIMX_CHECK_ARG(jobs[i].kind != 4 || (jobs[i].R % 32 == 0 && jobs[i].C % 16 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
@@ -612,6 +628,7 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
   for (int i = 0; i < n; ++i) {
     const int64_t items = jobs[i].kind == 3 ? 1 : (jobs[i].kind == 0 ? cdiv(jobs[i].R, 32) * cdiv(jobs[i].C, 32) : jobs[i].R * jobs[i].C / 8);
     int64_t want = jobs[i].kind == 0 ? items : cdiv(items, 256);
+    if (jobs[i].kind == 6) want = 64;                  // 8 heads x 8 column blocks
     if (want < 1) want = 1;
     if (want > 4096) want = 4096;                      // every job loop is grid-stride
     pj.first[i] = first;
@@ -700,8 +717,16 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);
   const size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8)));
-  dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8)));
-  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk);
+  Merge2Side side = {};
+  int side_blocks = 0;
+  if (g.defer && g.defer->side.pending == 2 && DTHREADS == M2_THREADS && smem >= M2_SIDE_LDS * sizeof(float) && splits > 1) {
+    memcpy(&side, g.defer->side.blob, sizeof(side));           // a parked Merge-backward tail: stage 2 rides in this launch
+    side_blocks = merge2_side_blocks(2, side);
+    if (side_blocks % 8 == 0) g.defer->side.pending = 3;
+    else side_blocks = 0;
+  }
+  dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + side_blocks));
+  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk, side_blocks, side);
   MHIMX_LAUNCH_CHECK();
   return splits;
 }

@@ -19,55 +19,11 @@
 // backward: parameters x dz (1), rows backward incl. LayerNorm backward (1), two rank-k gradient launches.
 // Built for E = 512, 8 heads x 64, k <= 6 (J <= 48), R <= 8192; other shapes take mca.hip's general path.
 #include <math.h>
+#include <string.h>
 
-#include "mma_tile.hpp"
+#include "mca2_side.hpp"
 
 namespace mhimx {
-
-constexpr int M2_E = 512, M2_H = 8, M2_DH = 64, M2_I = 512, M2_JP = 48, M2_JK = 64, M2_ROWS = 32, M2_THREADS = 256;
-constexpr int M2_XLD = M2_E + 4;           // LDS pitch of a row tile (floats)
-constexpr int M2_PLD = 36;                 // LDS pitch of the transposed [slot][row] tiles
-constexpr int M2_CLD = 2 * M2_JK + 4;      // LDS pitch of the [row][2 x 64 slots] coefficient tile
-
-typedef float m2_f4 __attribute__((ext_vector_type(4)));
-
-struct Merge2Ws {
-  float *gq, *gmean, *grstd, *Q, *aq, *aqf, *gtf_aq, *mean, *rstd, *S, *pm, *pl, *psd, *ypart, *stats, *Y, *O;
-  float *dO, *dyf, *gtf_dy, *dpart, *upart, *lnpart, *dQ;
-  int T;
-};
-
-int64_t merge2_ws_layout(Arena& ar, int64_t R, int64_t k, Merge2Ws* out) {
-  Merge2Ws w;
-  const int64_t T = cdiv(R, M2_ROWS);
-  w.T = (int)T;
-  w.gq = ar.take<float>(k * M2_E);
-  w.gmean = ar.take<float>(k);
-  w.grstd = ar.take<float>(k);
-  w.Q = ar.take<float>(k * M2_I);
-  w.aq = ar.take<float>(M2_JP * M2_E);
-  w.aqf = ar.take<float>(3 * 16 * 64 * 8);
-  w.gtf_aq = ar.take<float>(32 * 2 * 64 * 8);
-  w.mean = ar.take<float>(R);
-  w.rstd = ar.take<float>(R);
-  w.S = ar.take<float>(R * M2_JP);
-  w.pm = ar.take<float>(T * M2_JP);
-  w.pl = ar.take<float>(T * M2_JP);
-  w.psd = ar.take<float>(T * M2_JP);
-  w.ypart = ar.take<float>(T * M2_JP * M2_E);
-  w.stats = ar.take<float>(M2_JP * 2);
-  w.Y = ar.take<float>(M2_JP * M2_E);
-  w.O = ar.take<float>(k * M2_I);
-  w.dO = ar.take<float>(k * M2_I);
-  w.dyf = ar.take<float>(3 * 16 * 64 * 8);
-  w.gtf_dy = ar.take<float>(32 * 2 * 64 * 8);
-  w.dpart = ar.take<float>(M2_JP * 8);
-  w.upart = ar.take<float>(T * M2_JP * M2_E);
-  w.lnpart = ar.take<float>((T + 1) * 2 * M2_E);
-  w.dQ = ar.take<float>(k * M2_I);
-  if (out) *out = w;
-  return ar.off;
-}
 
 int64_t merge2_ws_bytes(int64_t R, int64_t k) {
   Arena ar(nullptr, 0);
@@ -80,134 +36,11 @@ bool merge2_ok(const mhimx_merge* m, int64_t R) {
          aligned16(m->q_param);
 }
 
-MHIMX_DEV void m2_split8(const float (&v)[8], bf8& hi, bf8& lo) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = (__bf16)v[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(v[i] - (float)h);
-  }
-}
-MHIMX_DEV f32x4 m2_mfma(const bf8& a, const bf8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-// acc += A B^T in the 3-term bf16 form
-MHIMX_DEV f32x4 m2_mfma3(const bf8& ah, const bf8& al, const bf8& bh, const bf8& bl, f32x4 c) {
-  c = m2_mfma(al, bh, c);
-  c = m2_mfma(ah, bl, c);
-  return m2_mfma(ah, bh, c);
-}
-// 16 bytes of hi + 16 bytes of lo of a prep-time fragment image entry (32 bytes per lane)
-MHIMX_DEV void m2_load_frag(const float* img, int entry, int lane, bf8& hi, bf8& lo) {
-  const m2_f4* p = reinterpret_cast<const m2_f4*>(img + ((int64_t)entry * 64 + lane) * 8);
-  hi = __builtin_bit_cast(bf8, p[0]);
-  lo = __builtin_bit_cast(bf8, p[1]);
-}
-// store element (j, e) of a [slots, E] matrix into its two fragment images:
-//   f   (B operand of  rows x slots  products, K = e):  entry (j / 16) * 16 + e / 32, lane ((e % 32) / 8) * 16 + j % 16, element e % 8
-//   gtf (B operand of  rows x E  products, K = slot, padded to 64):  entry (e / 16) * 2 + j / 32, lane ((j % 32) / 8) * 16 + e % 16, element j % 8
-MHIMX_DEV void m2_store_images(float* f, float* gtf, int j, int e, float v) {
-  const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
-  if (j < M2_JP) {
-    __bf16* p = reinterpret_cast<__bf16*>(f) + (((int64_t)((j >> 4) * 16 + (e >> 5)) * 64 + ((e & 31) >> 3) * 16 + (j & 15)) * 16) + (e & 7);
-    p[0] = h;
-    p[8] = l;
-  }
-  __bf16* q = reinterpret_cast<__bf16*>(gtf) + (((int64_t)((e >> 4) * 2 + (j >> 5)) * 64 + ((j & 31) >> 3) * 16 + (e & 15)) * 16) + (j & 7);
-  q[0] = h;
-  q[8] = l;
-}
-
-// LayerNorm of one 512-wide row by one wave: lane holds e = 4 lane .. +3 and 256 + 4 lane .. +3
-MHIMX_DEV void m2_ln_stats(const m2_f4& a, const m2_f4& b, float& mu, float& rs) {
-  const float s = wave_sum((a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]));
-  mu = s * (1.f / M2_E);
-  float v = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { const float d0 = a[q] - mu, d1 = b[q] - mu; v += d0 * d0 + d1 * d1; }
-  rs = rsqrtf(wave_sum(v) * (1.f / M2_E) + 1e-5f);
-}
-
-// out[i][d] = rows[d][:] . vec[i][:] for NR consecutive weight rows (row pitch 512) and the 6 vectors vec[6][512] in LDS (rows >= k
-// zero): one wave per row, NR / 4 rows per wave, all of them fetched before any arithmetic; the inner loop over the vectors is a
-// compile-time 6 (a run-time k leaves every LDS read a dependent round trip).  gout (optional): the same values to global [i][512].
-template <int NR>
-MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, int k, float* out, int out_ld, float* gout) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int PW = NR / 4;
-  m2_f4 ra[PW], rb[PW];
-#pragma unroll
-  for (int q = 0; q < PW; ++q) {
-    const float* row = rows + (int64_t)(wave * PW + q) * M2_E;
-    ra[q] = *reinterpret_cast<const m2_f4*>(row + 4 * lane);
-    rb[q] = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const m2_f4 ga = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 256 + 4 * lane);
-#pragma unroll
-    for (int q = 0; q < PW; ++q) {
-      const m2_f4 a = ra[q], b = rb[q];
-      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
-      s = wave_sum(s);
-      if (lane == 0 && i < k) {
-        out[i * out_ld + wave * PW + q] = s;
-        if (gout) gout[i * M2_I + wave * PW + q] = s;
-      }
-    }
-  }
-}
-// zero the rows k..5 of a [6][512] LDS block (so that loops over the queries can be a compile-time 6)
-MHIMX_DEV void m2_zero_tail(float* v, int k) {
-  for (int idx = k * M2_E + threadIdx.x; idx < 6 * M2_E; idx += M2_THREADS) v[idx] = 0.f;
-}
-
 // ----------------------------------------------------------------------------------------------------------------------
-// 1. parameters: gq = LN(q), Q = gq Wq^T, aq[(h,i),:] = scale sum_d Q[i,h,d] Wk[h*64+d,:] and its two fragment images.
-//    grid = 8 heads x 8 column blocks of 64.
+// 1. parameters (mca2_prep.hpp): standalone launch; a trainer runs the same body as a job of its preparation launch instead
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(const float* __restrict__ q_param, const float* __restrict__ ln_w,
-                                                                const float* __restrict__ ln_b, const float* __restrict__ wq,
-                                                                const float* __restrict__ wkv, int k, float scale, Merge2Ws w) {
-  __shared__ __attribute__((aligned(16))) float gqs[6 * M2_E];
-  __shared__ float qh[6 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x >> 3, eb = blockIdx.x & 7;
-  const int J = M2_H * k;
-  const int c = tid & 63, e = eb * 64 + c;
-  float wv[64];                                               // this thread's column of the head's Wk block: in flight from the start
-#pragma unroll
-  for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(h * 64 + d) * M2_E + e];
-  m2_zero_tail(gqs, k);
-  for (int idx = k * 64 + tid; idx < 6 * 64; idx += M2_THREADS) qh[idx] = 0.f;
-  for (int i = wave; i < k; i += 4) {
-    const float* row = q_param + (int64_t)i * M2_E;
-    const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
-    float mu, rs;
-    m2_ln_stats(a, b, mu, rs);
-    const m2_f4 wa = *reinterpret_cast<const m2_f4*>(ln_w + 4 * lane), wb = *reinterpret_cast<const m2_f4*>(ln_w + 256 + 4 * lane);
-    const m2_f4 ba = *reinterpret_cast<const m2_f4*>(ln_b + 4 * lane), bb = *reinterpret_cast<const m2_f4*>(ln_b + 256 + 4 * lane);
-    const m2_f4 ya = (a - mu) * rs * wa + ba, yb = (b - mu) * rs * wb + bb;
-    *reinterpret_cast<m2_f4*>(gqs + i * M2_E + 4 * lane) = ya;
-    *reinterpret_cast<m2_f4*>(gqs + i * M2_E + 256 + 4 * lane) = yb;
-    if (blockIdx.x == 0) {
-      *reinterpret_cast<m2_f4*>(w.gq + i * M2_E + 4 * lane) = ya;
-      *reinterpret_cast<m2_f4*>(w.gq + i * M2_E + 256 + 4 * lane) = yb;
-      if (lane == 0) { w.gmean[i] = mu; w.grstd[i] = rs; }
-    }
-  }
-  __syncthreads();
-  m2_head_dots<64>(wq + (int64_t)h * 64 * M2_E, gqs, k, qh, 64, eb == 0 ? w.Q + h * 64 : nullptr);     // Q of this head
-  __syncthreads();
-  // aq for the 64 columns of this block, then the images
-  for (int i = tid >> 6; i < k; i += 4) {
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 64; ++d) acc += qh[i * 64 + d] * wv[d];
-    acc *= scale;
-    const int j = h * k + i;
-    m2_store_images(w.aqf, w.gtf_aq, j, e, acc);
-  }
-  for (int j = J + h; j < M2_JK; j += M2_H)                 // zero padding slots (this head's share), 4 threads per column
-    if ((tid >> 6) == ((j - J) >> 3) % 4) m2_store_images(w.aqf, w.gtf_aq, j, e, 0.f);
+__global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(Merge2PrepArgs a) {
+  merge2_prep_body((int)blockIdx.x, a.q_param, a.ln_w, a.ln_b, a.wq, a.wkv, a.k, a.scale, a.w);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -417,54 +250,8 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
 template <bool SOFTMAX>
 __global__ __launch_bounds__(M2_THREADS) void merge2_partials_kernel(const float* __restrict__ part, const float* __restrict__ ln_w,
                                                                     const float* __restrict__ ln_b, float* __restrict__ out, Merge2Ws w) {
-  __shared__ float wt[256];
-  __shared__ float red[8];
-  __shared__ float half1[128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = blockIdx.x >> 2, e = (blockIdx.x & 3) * 128 + (tid & 127), half = tid >> 7;
-  const int T = w.T;
-  float sdl = 0.f;
-  if (SOFTMAX) {
-    const float pm = tid < T ? w.pm[tid * M2_JP + j] : -INFINITY;
-    const float pl = tid < T ? w.pl[tid * M2_JP + j] : 0.f;
-    const float ps = tid < T ? w.psd[tid * M2_JP + j] : 0.f;
-    float m = wave_max(pm);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float wgt = tid < T ? __expf(pm - M) : 0.f;
-    const float l = wave_sum(pl * wgt), sd = wave_sum(ps * wgt);
-    if (lane == 0) { red[4 + wave] = l; wt[252 + wave] = sd; }      // (wt[252..255] are beyond any tile: T <= 256 uses wt[0..T-1])
-    __syncthreads();
-    const float L = (red[4] + red[5]) + (red[6] + red[7]);
-    const float SD = (wt[252] + wt[253]) + (wt[254] + wt[255]);
-    __syncthreads();
-    wt[tid] = wgt / L;
-    sdl = SD / L;
-    if ((blockIdx.x & 3) == 0 && tid == 0) { w.stats[2 * j] = M; w.stats[2 * j + 1] = L; }
-  } else {
-    wt[tid] = tid < T ? 1.f : 0.f;
-  }
-  __syncthreads();
-  float acc = 0.f;
-  const float* pj = part + (int64_t)j * M2_E + e;
-#pragma unroll 1
-  for (int t0 = 0; t0 < T; t0 += 32) {
-    float v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int t = t0 + half * 16 + q;
-      v[q] = t < T ? pj[(int64_t)t * M2_JP * M2_E] : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc += v[q] * wt[(t0 + half * 16 + q) & 255];
-  }
-  if (half == 1) half1[tid & 127] = acc;
-  __syncthreads();
-  if (half == 0) {
-    acc += half1[tid];
-    out[j * M2_E + e] = SOFTMAX ? acc * ln_w[e] + sdl * ln_b[e] : acc * ln_w[e];
-  }
+  __shared__ float lds[M2_PARTIALS_LDS];
+  merge2_partials_body<SOFTMAX>((int)blockIdx.x, lds, part, ln_w, ln_b, out, w);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -690,149 +477,18 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
 // 6. rank-k gradients, first launch (U merged by merge2_partials_kernel<false> before).   blocks 0..31: (head, quarter): dQ = scale Wk U and
 //    16 + 16 rows of d_wkv (K part: scale Q (x) U, V part: dO (x) Y);   blocks 32..47: 32 rows of d_wo = dz0^T O.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(const float* __restrict__ dz, const float* __restrict__ U,
-                                                                  const float* __restrict__ wkv, int k, float scale, float drop_p, uint64_t seed0,
-                                                                  const uint64_t* __restrict__ tick, float* __restrict__ d_wkv,
-                                                                  float* __restrict__ d_wo, int accumulate, Merge2Ws w) {
-  __shared__ __attribute__((aligned(16))) float us[6 * M2_E];
-  __shared__ __attribute__((aligned(16))) float ysh[6 * M2_E];
-  __shared__ __attribute__((aligned(16))) float qd[32 * 12];        // [row][6 x scale Q | 6 x dO]  (d_wo blocks: [32][8] dz0)
-  __shared__ float dqh[6 * 16];
-  const int tid = threadIdx.x;
-  if (blockIdx.x >= 32) {
-    // 32 rows of d_wo[e, c] = sum_i dz0[i, e] O[i, c]: thread = two columns c, the k values of O in registers
-    const int e0 = (blockIdx.x - 32) * 32;
-    const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
-    const float ks = 1.f / (1.f - drop_p);
-    float o0[6], o1[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      o0[i] = i < k ? w.O[i * M2_I + tid] : 0.f;
-      o1[i] = i < k ? w.O[i * M2_I + tid + 256] : 0.f;
-    }
-    for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
-      const int r = idx >> 3, i = idx & 7, e = e0 + r;
-      float v = 0.f;
-      if (i < k) {
-        v = dz[i * M2_E + e];
-        if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)e, drop_p) ? v * ks : 0.f;
-      }
-      qd[idx] = v;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-      const m2_f4 z0 = *reinterpret_cast<const m2_f4*>(qd + r * 8), z1 = *reinterpret_cast<const m2_f4*>(qd + r * 8 + 4);
-      const float s0 = z0[0] * o0[0] + z0[1] * o0[1] + z0[2] * o0[2] + z0[3] * o0[3] + z1[0] * o0[4] + z1[1] * o0[5];
-      const float s1 = z0[0] * o1[0] + z0[1] * o1[1] + z0[2] * o1[2] + z0[3] * o1[3] + z1[0] * o1[4] + z1[1] * o1[5];
-      float* o = d_wo + (int64_t)(e0 + r) * M2_I + tid;
-      o[0] = accumulate ? o[0] + s0 : s0;
-      o[256] = accumulate ? o[256] + s1 : s1;
-    }
-    return;
-  }
-  const int h = blockIdx.x >> 2, qr = blockIdx.x & 3;             // 16 of the head's 64 rows
-  m2_zero_tail(us, k);
-  for (int idx = tid; idx < k * (M2_E / 4); idx += M2_THREADS) reinterpret_cast<m2_f4*>(us)[idx] = reinterpret_cast<const m2_f4*>(U + (int64_t)h * k * M2_E)[idx];
-  float y0[6], y1[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    y0[i] = i < k ? w.Y[(h * k + i) * M2_E + tid] : 0.f;
-    y1[i] = i < k ? w.Y[(h * k + i) * M2_E + tid + 256] : 0.f;
-  }
-  for (int idx = tid; idx < 16 * 12; idx += M2_THREADS) {
-    const int dl = idx / 12, c = idx - dl * 12, i = c % 6, d = h * 64 + qr * 16 + dl;
-    qd[idx] = i < k ? (c < 6 ? scale * w.Q[i * M2_I + d] : w.dO[i * M2_I + d]) : 0.f;
-  }
-  __syncthreads();
-  m2_head_dots<16>(wkv + (int64_t)(h * 64 + qr * 16) * M2_E, us, k, dqh, 16, nullptr);             // the K half of to_kv
-  float u0[6], u1[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { u0[i] = us[i * M2_E + tid]; u1[i] = us[i * M2_E + tid + 256]; }
-  __syncthreads();
-  if (tid < 16 * 6 && (tid / 16) < k) w.dQ[(tid / 16) * M2_I + h * 64 + qr * 16 + (tid & 15)] = scale * dqh[tid];
-#pragma unroll 4
-  for (int dl = 0; dl < 16; ++dl) {
-    const m2_f4 c0 = *reinterpret_cast<const m2_f4*>(qd + dl * 12), c1 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 4),
-                c2 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 8);
-    const float q6[6] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1]}, o6[6] = {c1[2], c1[3], c2[0], c2[1], c2[2], c2[3]};
-    float sk0 = 0.f, sk1 = 0.f, sv0 = 0.f, sv1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { sk0 += q6[i] * u0[i]; sk1 += q6[i] * u1[i]; sv0 += o6[i] * y0[i]; sv1 += o6[i] * y1[i]; }
-    float* ok = d_wkv + (int64_t)(h * 64 + qr * 16 + dl) * M2_E + tid;
-    float* ov = d_wkv + (int64_t)(M2_I + h * 64 + qr * 16 + dl) * M2_E + tid;
-    ok[0] = accumulate ? ok[0] + sk0 : sk0;
-    ok[256] = accumulate ? ok[256] + sk1 : sk1;
-    ov[0] = accumulate ? ov[0] + sv0 : sv0;
-    ov[256] = accumulate ? ov[256] + sv1 : sv1;
-  }
+__global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(Merge2Side a) {
+  __shared__ __attribute__((aligned(16))) float lds[M2_GRADS1_LDS];
+  merge2_grads1_body((int)blockIdx.x, lds, a);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // 7. rank-k gradients, second launch (needs all of dQ).   blocks 0..15: 32 rows of d_wq = dQ^T gq;   blocks 16..23: 64 columns of
 //    dgq = dQ Wq and their LayerNorm-parameter gradients (the queries themselves are not trained) -> partial row T of lnpart.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_grads2_kernel(const float* __restrict__ q_param, const float* __restrict__ wq, int k,
-                                                                  float* __restrict__ d_wq, int accumulate, Merge2Ws w) {
-  __shared__ float dqs[6 * M2_I];
-  __shared__ __attribute__((aligned(16))) float part[4 * 6 * 64];
-  const int tid = threadIdx.x;
-  if (blockIdx.x < 16) {
-    // 32 rows of d_wq[c, e] = sum_i dQ[i, c] gq[i, e]: thread = two columns e, the k values of gq in registers
-    const int c0 = blockIdx.x * 32;
-    float g0[6], g1[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      g0[i] = i < k ? w.gq[i * M2_E + tid] : 0.f;
-      g1[i] = i < k ? w.gq[i * M2_E + tid + 256] : 0.f;
-    }
-    for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
-      const int r = idx >> 3, i = idx & 7;
-      part[idx] = i < k ? w.dQ[i * M2_I + c0 + r] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-      const m2_f4 z0 = *reinterpret_cast<const m2_f4*>(part + r * 8), z1 = *reinterpret_cast<const m2_f4*>(part + r * 8 + 4);
-      const float s0 = z0[0] * g0[0] + z0[1] * g0[1] + z0[2] * g0[2] + z0[3] * g0[3] + z1[0] * g0[4] + z1[1] * g0[5];
-      const float s1 = z0[0] * g1[0] + z0[1] * g1[1] + z0[2] * g1[2] + z0[3] * g1[3] + z1[0] * g1[4] + z1[1] * g1[5];
-      float* o = d_wq + (int64_t)(c0 + r) * M2_E + tid;
-      o[0] = accumulate ? o[0] + s0 : s0;
-      o[256] = accumulate ? o[256] + s1 : s1;
-    }
-    return;
-  }
-  const int eb = blockIdx.x - 16, c = tid & 63, e = eb * 64 + c, cq = tid >> 6;
-  // this thread's 128 values of column e (rows cq, cq + 4, ...): fetched 32 at a time, before the query gradients are needed
-  float acc[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) acc[i] = 0.f;
-  for (int idx = tid; idx < 6 * M2_I; idx += M2_THREADS) dqs[idx] = idx < k * M2_I ? w.dQ[idx] : 0.f;
-  __syncthreads();
-#pragma unroll 1
-  for (int c0 = 0; c0 < M2_I; c0 += 128) {
-    float wv[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) wv[q] = wq[(int64_t)(c0 + cq + 4 * q) * M2_E + e];
-#pragma unroll
-    for (int q = 0; q < 32; ++q)
-#pragma unroll
-      for (int i = 0; i < 6; ++i) acc[i] += dqs[i * M2_I + c0 + cq + 4 * q] * wv[q];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) part[(cq * 6 + i) * 64 + c] = acc[i];
-  __syncthreads();
-  if (tid < 64) {
-    float dw = 0.f, db = 0.f;
-    for (int i = 0; i < k; ++i) {
-      const float g = (part[(0 * 6 + i) * 64 + c] + part[(1 * 6 + i) * 64 + c]) + (part[(2 * 6 + i) * 64 + c] + part[(3 * 6 + i) * 64 + c]);
-      const float xhat = (q_param[(int64_t)i * M2_E + e] - w.gmean[i]) * w.grstd[i];
-      dw += g * xhat;
-      db += g;
-    }
-    w.lnpart[(int64_t)w.T * 2 * M2_E + e] = dw;
-    w.lnpart[(int64_t)w.T * 2 * M2_E + M2_E + e] = db;
-  }
+__global__ __launch_bounds__(M2_THREADS) void merge2_grads2_kernel(Merge2Side a) {
+  __shared__ __attribute__((aligned(16))) float lds[M2_GRADS2_LDS];
+  merge2_grads2_body((int)blockIdx.x, lds, a);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -842,6 +498,25 @@ int mca_out(hipStream_t st, const float* O, const float* wo, const float* bo, in
             float* z, const float* q, float* q_new, float mm);                                      // mca.hip
 int reduce_parts2(hipStream_t st, const float* part0, const float* part1, int G, int W, int ld, float* out0, float* out1, int accumulate);   // rows.hip
 
+int merge2_side_launch(hipStream_t st, int stage, const Merge2Side& sd) {
+  if (stage == 1) hipLaunchKernelGGL(merge2_partials_kernel<false>, dim3((unsigned)(sd.J * 4)), dim3(M2_THREADS), 0, st, sd.w.upart, sd.ln_w, sd.ln_b,
+                                     const_cast<float*>(sd.U), sd.w);
+  else if (stage == 2) hipLaunchKernelGGL(merge2_grads1_kernel, dim3(M2_GRADS1_BLOCKS), dim3(M2_THREADS), 0, st, sd);
+  else hipLaunchKernelGGL(merge2_grads2_kernel, dim3(M2_GRADS2_BLOCKS), dim3(M2_THREADS), 0, st, sd);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+// run every stage of a deferred tail that has not had its ride yet, as launches of its own (mhimx_reduce_flush, rows.hip)
+int merge2_side_finish(hipStream_t st, mhimx_side_work* side, int upto_stage) {
+  Merge2Side sd;
+  while (side->pending != 0 && side->pending <= upto_stage) {
+    memcpy(&sd, side->blob, sizeof(sd));
+    if (int r = merge2_side_launch(st, side->pending, sd)) return r;
+    side->pending = side->pending == 3 ? 0 : side->pending + 1;
+  }
+  return 0;
+}
+
 int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new, int update_q, void* ws, int64_t ws_bytes) {
   Arena ar(ws, ws_bytes);
   Merge2Ws w;
@@ -850,8 +525,10 @@ int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd: update_q needs q_new");
   const int k = (int)m->k, J = M2_H * k;
   const float scale = 1.0f / sqrtf((float)M2_DH);
-  hipLaunchKernelGGL(merge2_prep_kernel, dim3(64), dim3(M2_THREADS), 0, st, m->q_param, m->ln_w, m->ln_b, m->wq, m->wkv, k, scale, w);
-  MHIMX_LAUNCH_CHECK();
+  if (!m->prepared) {
+    hipLaunchKernelGGL(merge2_prep_kernel, dim3(64), dim3(M2_THREADS), 0, st, Merge2PrepArgs{m->q_param, m->ln_w, m->ln_b, m->wq, m->wkv, k, scale, w});
+    MHIMX_LAUNCH_CHECK();
+  }
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M2_FWD_SMEM)));
   hipLaunchKernelGGL(merge2_rows_fwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_FWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
                      m->drop_seed, m->drop_tick, w);
@@ -881,21 +558,34 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   hipLaunchKernelGGL(merge2_rows_bwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_BWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
                      m->drop_seed, m->drop_tick, dX, w);
   MHIMX_LAUNCH_CHECK();
-  float* U = w.aq;                                         // (the fp32 copy of aq is not needed any more: its place takes U [J, E])
-  hipLaunchKernelGGL(merge2_partials_kernel<false>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, w.upart, m->ln_w, m->ln_b, U, w);
-  MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(merge2_grads1_kernel, dim3(48), dim3(M2_THREADS), 0, st, dz, U, m->wkv, k, scale, m->drop_p, oseed, m->drop_tick, gr->d_wkv,
-                     gr->d_wo, acc, w);
-  MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(merge2_grads2_kernel, dim3(24), dim3(M2_THREADS), 0, st, m->q_param, m->wq, k, gr->d_wq, acc, w);
-  MHIMX_LAUNCH_CHECK();
-  // d_ln_w / d_ln_b: T row-tile partials + one row from the queries
-  if (gr->defer && gr->defer->n + 2 <= MHIMX_REDUCE_MAX) {
-    defer_push(gr->defer, reduce_job_parts(w.lnpart, w.T + 1, M2_E, 2 * M2_E, gr->d_ln_w, acc));
-    defer_push(gr->defer, reduce_job_parts(w.lnpart + M2_E, w.T + 1, M2_E, 2 * M2_E, gr->d_ln_b, acc));
-    return 0;
+  // the parameter-gradient tail: U [J, E] takes the place of the fp32 copy of aq (not needed any more)
+  Merge2Side sd;
+  sd.w = w; sd.dz = dz; sd.U = w.aq; sd.ln_w = m->ln_w; sd.ln_b = m->ln_b; sd.wkv = m->wkv; sd.wq = m->wq; sd.q_param = m->q_param;
+  sd.d_wkv = gr->d_wkv; sd.d_wo = gr->d_wo; sd.d_wq = gr->d_wq; sd.d_ln_w = gr->d_ln_w; sd.d_ln_b = gr->d_ln_b; sd.tick = m->drop_tick; sd.oseed = oseed; sd.scale = scale;
+  sd.drop_p = m->drop_p; sd.k = k; sd.accumulate = acc; sd.J = J;
+  if (gr->defer && gr->defer->side.pending == 0) {
+    // deferred: the three stages ride in later launches of this backward (mhimx_rows_dpre, the weight-gradient mhimx_gemm_tn,
+    // mhimx_reduce_flush); whatever did not get a ride is launched by mhimx_reduce_flush before the reductions
+    memcpy(gr->defer->side.blob, &sd, sizeof(sd));
+    gr->defer->side.pending = 1;
+  } else {
+    for (int stage = 1; stage <= 3; ++stage)
+      if (int r = merge2_side_launch(st, stage, sd)) return r;
   }
-  return reduce_parts2(st, w.lnpart, w.lnpart + M2_E, w.T + 1, M2_E, 2 * M2_E, gr->d_ln_w, gr->d_ln_b, acc);
+  return 0;
 }
 
+}  // namespace mhimx
+
+// host side of prep job kind 6 (gemm_dma.hip): the kernel arguments of the parameter-only part for this Merge and workspace
+namespace mhimx {
+int merge2_prep_args(const mhimx_merge* m, int64_t R, void* ws, int64_t ws_bytes, Merge2PrepArgs* out) {
+  MHIMX_CHECK_ARG(m && merge2_ok(m, R), "prep_batch: the Merge preparation job needs the projection-free form (E = 512, 8 x 64, k <= 6, R <= 8192)");
+  Arena ar(ws, ws_bytes);
+  Merge2Ws w;
+  merge2_ws_layout(ar, R, m->k, &w);
+  MHIMX_CHECK_ARG(ar.ok(), "prep_batch: Merge workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ar.off);
+  *out = Merge2PrepArgs{m->q_param, m->ln_w, m->ln_b, m->wq, m->wkv, (int)m->k, 1.0f / sqrtf((float)M2_DH), w};
+  return 0;
+}
 }  // namespace mhimx

@@ -1,0 +1,187 @@
+// mca2_prep.hpp — the pieces of the projection-free Merge (mca2.hip) that the step's preparation launch (gemm_dma.hip) shares: workspace
+// layout, fragment-image stores, and the parameter-only kernel body (gq = LN(q), Q, aq and its images).
+#pragma once
+#include "mma_tile.hpp"
+
+namespace mhimx {
+
+constexpr int M2_E = 512, M2_H = 8, M2_DH = 64, M2_I = 512, M2_JP = 48, M2_JK = 64, M2_ROWS = 32, M2_THREADS = 256;
+constexpr int M2_XLD = M2_E + 4;           // LDS pitch of a row tile (floats)
+constexpr int M2_PLD = 36;                 // LDS pitch of the transposed [slot][row] tiles
+constexpr int M2_CLD = 2 * M2_JK + 4;      // LDS pitch of the [row][2 x 64 slots] coefficient tile
+
+typedef float m2_f4 __attribute__((ext_vector_type(4)));
+
+struct Merge2Ws {
+  float *gq, *gmean, *grstd, *Q, *aq, *aqf, *gtf_aq, *mean, *rstd, *S, *pm, *pl, *psd, *ypart, *stats, *Y, *O;
+  float *dO, *dyf, *gtf_dy, *dpart, *upart, *lnpart, *dQ;
+  int T;
+};
+
+inline int64_t merge2_ws_layout(Arena& ar, int64_t R, int64_t k, Merge2Ws* out) {
+  Merge2Ws w;
+  const int64_t T = cdiv(R, M2_ROWS);
+  w.T = (int)T;
+  w.gq = ar.take<float>(k * M2_E);
+  w.gmean = ar.take<float>(k);
+  w.grstd = ar.take<float>(k);
+  w.Q = ar.take<float>(k * M2_I);
+  w.aq = ar.take<float>(M2_JP * M2_E);
+  w.aqf = ar.take<float>(3 * 16 * 64 * 8);
+  w.gtf_aq = ar.take<float>(32 * 2 * 64 * 8);
+  w.mean = ar.take<float>(R);
+  w.rstd = ar.take<float>(R);
+  w.S = ar.take<float>(R * M2_JP);
+  w.pm = ar.take<float>(T * M2_JP);
+  w.pl = ar.take<float>(T * M2_JP);
+  w.psd = ar.take<float>(T * M2_JP);
+  w.ypart = ar.take<float>(T * M2_JP * M2_E);
+  w.stats = ar.take<float>(M2_JP * 2);
+  w.Y = ar.take<float>(M2_JP * M2_E);
+  w.O = ar.take<float>(k * M2_I);
+  w.dO = ar.take<float>(k * M2_I);
+  w.dyf = ar.take<float>(3 * 16 * 64 * 8);
+  w.gtf_dy = ar.take<float>(32 * 2 * 64 * 8);
+  w.dpart = ar.take<float>(M2_JP * 8);
+  w.upart = ar.take<float>(T * M2_JP * M2_E);
+  w.lnpart = ar.take<float>(T * 2 * M2_E);
+  w.dQ = ar.take<float>(k * M2_I);
+  if (out) *out = w;
+  return ar.off;
+}
+
+MHIMX_DEV void m2_split8(const float (&v)[8], bf8& hi, bf8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+MHIMX_DEV f32x4 m2_mfma(const bf8& a, const bf8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// acc += A B^T in the 3-term bf16 form
+MHIMX_DEV f32x4 m2_mfma3(const bf8& ah, const bf8& al, const bf8& bh, const bf8& bl, f32x4 c) {
+  c = m2_mfma(al, bh, c);
+  c = m2_mfma(ah, bl, c);
+  return m2_mfma(ah, bh, c);
+}
+// 16 bytes of hi + 16 bytes of lo of a prep-time fragment image entry (32 bytes per lane)
+MHIMX_DEV void m2_load_frag(const float* img, int entry, int lane, bf8& hi, bf8& lo) {
+  const m2_f4* p = reinterpret_cast<const m2_f4*>(img + ((int64_t)entry * 64 + lane) * 8);
+  hi = __builtin_bit_cast(bf8, p[0]);
+  lo = __builtin_bit_cast(bf8, p[1]);
+}
+// store element (j, e) of a [slots, E] matrix into its two fragment images:
+//   f   (B operand of  rows x slots  products, K = e):  entry (j / 16) * 16 + e / 32, lane ((e % 32) / 8) * 16 + j % 16, element e % 8
+//   gtf (B operand of  rows x E  products, K = slot, padded to 64):  entry (e / 16) * 2 + j / 32, lane ((j % 32) / 8) * 16 + e % 16, element j % 8
+MHIMX_DEV void m2_store_images(float* f, float* gtf, int j, int e, float v) {
+  const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+  if (j < M2_JP) {
+    __bf16* p = reinterpret_cast<__bf16*>(f) + (((int64_t)((j >> 4) * 16 + (e >> 5)) * 64 + ((e & 31) >> 3) * 16 + (j & 15)) * 16) + (e & 7);
+    p[0] = h;
+    p[8] = l;
+  }
+  __bf16* q = reinterpret_cast<__bf16*>(gtf) + (((int64_t)((e >> 4) * 2 + (j >> 5)) * 64 + ((j & 31) >> 3) * 16 + (e & 15)) * 16) + (j & 7);
+  q[0] = h;
+  q[8] = l;
+}
+
+// LayerNorm of one 512-wide row by one wave: lane holds e = 4 lane .. +3 and 256 + 4 lane .. +3
+MHIMX_DEV void m2_ln_stats(const m2_f4& a, const m2_f4& b, float& mu, float& rs) {
+  const float s = wave_sum((a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]));
+  mu = s * (1.f / M2_E);
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const float d0 = a[q] - mu, d1 = b[q] - mu; v += d0 * d0 + d1 * d1; }
+  rs = rsqrtf(wave_sum(v) * (1.f / M2_E) + 1e-5f);
+}
+
+// out[i][d] = rows[d][:] . vec[i][:] for NR consecutive weight rows (row pitch 512) and the 6 vectors vec[6][512] in LDS (rows >= k
+// zero): one wave per row, NR / 4 rows per wave, all of them fetched before any arithmetic; the inner loop over the vectors is a
+// compile-time 6 (a run-time k leaves every LDS read a dependent round trip).  gout (optional): the same values to global [i][512].
+template <int NR>
+MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, int k, float* out, int out_ld, float* gout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PW = NR / 4;
+  m2_f4 ra[PW], rb[PW];
+#pragma unroll
+  for (int q = 0; q < PW; ++q) {
+    const float* row = rows + (int64_t)(wave * PW + q) * M2_E;
+    ra[q] = *reinterpret_cast<const m2_f4*>(row + 4 * lane);
+    rb[q] = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const m2_f4 ga = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 256 + 4 * lane);
+#pragma unroll
+    for (int q = 0; q < PW; ++q) {
+      const m2_f4 a = ra[q], b = rb[q];
+      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
+      s = wave_sum(s);
+      if (lane == 0 && i < k) {
+        out[i * out_ld + wave * PW + q] = s;
+        if (gout) gout[i * M2_I + wave * PW + q] = s;
+      }
+    }
+  }
+}
+// zero the rows k..5 of a [6][512] LDS block (so that loops over the queries can be a compile-time 6)
+MHIMX_DEV void m2_zero_tail(float* v, int k) {
+  for (int idx = k * M2_E + threadIdx.x; idx < 6 * M2_E; idx += M2_THREADS) v[idx] = 0.f;
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// 1. parameters: gq = LN(q), Q = gq Wq^T, aq[(h,i),:] = scale sum_d Q[i,h,d] Wk[h*64+d,:] and its two fragment images.
+//    grid = 8 heads x 8 column blocks of 64.
+// ----------------------------------------------------------------------------------------------------------------------
+// (a device function: it is the body of merge2_prep_kernel (mca2.hip) and of job kind 6 of the step's ONE preparation launch
+// (prep_batch_kernel, gemm_dma.hip), where it runs beside the other parameter-only jobs instead of on the student's chain)
+MHIMX_DEV void merge2_prep_body(int block, const float* __restrict__ q_param, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                const float* __restrict__ wq, const float* __restrict__ wkv, int k, float scale, const Merge2Ws& w) {
+  __shared__ __attribute__((aligned(16))) float gqs[6 * M2_E];
+  __shared__ float qh[6 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = block >> 3, eb = block & 7;
+  const int J = M2_H * k;
+  const int c = tid & 63, e = eb * 64 + c;
+  float wv[64];                                               // this thread's column of the head's Wk block: in flight from the start
+#pragma unroll
+  for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(h * 64 + d) * M2_E + e];
+  m2_zero_tail(gqs, k);
+  for (int idx = k * 64 + tid; idx < 6 * 64; idx += M2_THREADS) qh[idx] = 0.f;
+  for (int i = wave; i < k; i += 4) {
+    const float* row = q_param + (int64_t)i * M2_E;
+    const m2_f4 a = *reinterpret_cast<const m2_f4*>(row + 4 * lane), b = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
+    float mu, rs;
+    m2_ln_stats(a, b, mu, rs);
+    const m2_f4 wa = *reinterpret_cast<const m2_f4*>(ln_w + 4 * lane), wb = *reinterpret_cast<const m2_f4*>(ln_w + 256 + 4 * lane);
+    const m2_f4 ba = *reinterpret_cast<const m2_f4*>(ln_b + 4 * lane), bb = *reinterpret_cast<const m2_f4*>(ln_b + 256 + 4 * lane);
+    const m2_f4 ya = (a - mu) * rs * wa + ba, yb = (b - mu) * rs * wb + bb;
+    *reinterpret_cast<m2_f4*>(gqs + i * M2_E + 4 * lane) = ya;
+    *reinterpret_cast<m2_f4*>(gqs + i * M2_E + 256 + 4 * lane) = yb;
+    if (block == 0) {
+      *reinterpret_cast<m2_f4*>(w.gq + i * M2_E + 4 * lane) = ya;
+      *reinterpret_cast<m2_f4*>(w.gq + i * M2_E + 256 + 4 * lane) = yb;
+      if (lane == 0) { w.gmean[i] = mu; w.grstd[i] = rs; }
+    }
+  }
+  __syncthreads();
+  m2_head_dots<64>(wq + (int64_t)h * 64 * M2_E, gqs, k, qh, 64, eb == 0 ? w.Q + h * 64 : nullptr);     // Q of this head
+  __syncthreads();
+  // aq for the 64 columns of this block, then the images
+  for (int i = tid >> 6; i < k; i += 4) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc += qh[i * 64 + d] * wv[d];
+    acc *= scale;
+    const int j = h * k + i;
+    m2_store_images(w.aqf, w.gtf_aq, j, e, acc);
+  }
+  for (int j = J + h; j < M2_JK; j += M2_H)                 // zero padding slots (this head's share), 4 threads per column
+    if ((tid >> 6) == ((j - J) >> 3) % 4) m2_store_images(w.aqf, w.gtf_aq, j, e, 0.f);
+}
+
+
+struct Merge2PrepArgs { const float *q_param, *ln_w, *ln_b, *wq, *wkv; int k; float scale; Merge2Ws w; };
+
+}  // namespace mhimx

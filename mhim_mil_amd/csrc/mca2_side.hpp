@@ -1,0 +1,258 @@
+// mca2_side.hpp — the parameter-gradient tail of the projection-free Merge backward (mca2.hip) as device functions: merging the pooled-row
+// partials U, the rank-k weight gradients, the query-side LayerNorm gradients.  Nothing on the data path waits for them (only the optimiser
+// reads their outputs), so a trainer lets them RIDE in later launches of the backward instead of paying three launches on the step's serial
+// chain: stage 1 in the activation-backward launch (rows.hip), stage 2 in the projection's weight-gradient GEMM (gemm_dma.hip), stage 3 in the
+// deferred-reduction launch (rows.hip) - see mhimx_reduce_list.side.  The standalone kernels of mca2.hip run the same bodies.
+#pragma once
+#include "mca2_prep.hpp"
+
+namespace mhimx {
+
+struct Merge2Side {
+  Merge2Ws w;
+  const float *dz, *U, *ln_w, *ln_b, *wkv, *wq, *q_param;
+  float *d_wkv, *d_wo, *d_wq, *d_ln_w, *d_ln_b;
+  const uint64_t* tick;
+  uint64_t oseed;
+  float scale, drop_p;
+  int k, accumulate, J;
+};
+static_assert(sizeof(Merge2Side) <= MHIMX_SIDE_BYTES, "Merge2Side must fit the opaque side-work block of mhimx_reduce_list");
+
+constexpr int M2_PARTIALS_LDS = 256 + 8 + 128;
+template <bool SOFTMAX>
+MHIMX_DEV void merge2_partials_body(int block, float* lds, const float* __restrict__ part, const float* __restrict__ ln_w,
+                                    const float* __restrict__ ln_b, float* __restrict__ out, const Merge2Ws& w) {
+  float* wt = lds;              // [256]
+  float* red = wt + 256;        // [8]
+  float* half1 = red + 8;       // [128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = block >> 2, e = (block & 3) * 128 + (tid & 127), half = tid >> 7;
+  const int T = w.T;
+  float sdl = 0.f;
+  if (SOFTMAX) {
+    const float pm = tid < T ? w.pm[tid * M2_JP + j] : -INFINITY;
+    const float pl = tid < T ? w.pl[tid * M2_JP + j] : 0.f;
+    const float ps = tid < T ? w.psd[tid * M2_JP + j] : 0.f;
+    float m = wave_max(pm);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float wgt = tid < T ? __expf(pm - M) : 0.f;
+    const float l = wave_sum(pl * wgt), sd = wave_sum(ps * wgt);
+    if (lane == 0) { red[4 + wave] = l; wt[252 + wave] = sd; }      // (wt[252..255] are beyond any tile: T <= 256 uses wt[0..T-1])
+    __syncthreads();
+    const float L = (red[4] + red[5]) + (red[6] + red[7]);
+    const float SD = (wt[252] + wt[253]) + (wt[254] + wt[255]);
+    __syncthreads();
+    wt[tid] = wgt / L;
+    sdl = SD / L;
+    if ((block & 3) == 0 && tid == 0) { w.stats[2 * j] = M; w.stats[2 * j + 1] = L; }
+  } else {
+    wt[tid] = tid < T ? 1.f : 0.f;
+  }
+  __syncthreads();
+  float acc = 0.f;
+  const float* pj = part + (int64_t)j * M2_E + e;
+#pragma unroll 1
+  for (int t0 = 0; t0 < T; t0 += 32) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int t = t0 + half * 16 + q;
+      v[q] = t < T ? pj[(int64_t)t * M2_JP * M2_E] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc += v[q] * wt[(t0 + half * 16 + q) & 255];
+  }
+  if (half == 1) half1[tid & 127] = acc;
+  __syncthreads();
+  if (half == 0) {
+    acc += half1[tid];
+    out[j * M2_E + e] = SOFTMAX ? acc * ln_w[e] + sdl * ln_b[e] : acc * ln_w[e];
+  }
+}
+
+
+constexpr int M2_GRADS1_LDS = 12 * M2_E + 32 * 12 + 6 * 16;
+constexpr int M2_GRADS1_BLOCKS = 48;
+MHIMX_DEV void merge2_grads1_body(int block, float* lds, const Merge2Side& a) {
+  const float* __restrict__ dz = a.dz;
+  const float* __restrict__ U = a.U;
+  const float* __restrict__ wkv = a.wkv;
+  const int k = a.k, accumulate = a.accumulate;
+  const float scale = a.scale, drop_p = a.drop_p;
+  const uint64_t seed0 = a.oseed;
+  const uint64_t* __restrict__ tick = a.tick;
+  float* __restrict__ d_wkv = a.d_wkv;
+  float* __restrict__ d_wo = a.d_wo;
+  const Merge2Ws& w = a.w;
+  float* us = lds;                                    // [6][512]
+  float* ysh = us + 6 * M2_E;                         // [6][512]
+  float* qd = ysh + 6 * M2_E;                         // [32][12]: [row][6 x scale Q | 6 x dO]  (d_wo blocks: [32][8] dz0)
+  float* dqh = qd + 32 * 12;                          // [6][16]
+  const int tid = threadIdx.x;
+  if (block >= 32) {
+    // 32 rows of d_wo[e, c] = sum_i dz0[i, e] O[i, c]: thread = two columns c, the k values of O in registers
+    const int e0 = (block - 32) * 32;
+    const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
+    const float ks = 1.f / (1.f - drop_p);
+    float o0[6], o1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      o0[i] = i < k ? w.O[i * M2_I + tid] : 0.f;
+      o1[i] = i < k ? w.O[i * M2_I + tid + 256] : 0.f;
+    }
+    for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
+      const int r = idx >> 3, i = idx & 7, e = e0 + r;
+      float v = 0.f;
+      if (i < k) {
+        v = dz[i * M2_E + e];
+        if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)e, drop_p) ? v * ks : 0.f;
+      }
+      qd[idx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      const m2_f4 z0 = *reinterpret_cast<const m2_f4*>(qd + r * 8), z1 = *reinterpret_cast<const m2_f4*>(qd + r * 8 + 4);
+      const float s0 = z0[0] * o0[0] + z0[1] * o0[1] + z0[2] * o0[2] + z0[3] * o0[3] + z1[0] * o0[4] + z1[1] * o0[5];
+      const float s1 = z0[0] * o1[0] + z0[1] * o1[1] + z0[2] * o1[2] + z0[3] * o1[3] + z1[0] * o1[4] + z1[1] * o1[5];
+      float* o = d_wo + (int64_t)(e0 + r) * M2_I + tid;
+      o[0] = accumulate ? o[0] + s0 : s0;
+      o[256] = accumulate ? o[256] + s1 : s1;
+    }
+    return;
+  }
+  const int h = block >> 2, qr = block & 3;             // 16 of the head's 64 rows
+  m2_zero_tail(us, k);
+  for (int idx = tid; idx < k * (M2_E / 4); idx += M2_THREADS) reinterpret_cast<m2_f4*>(us)[idx] = reinterpret_cast<const m2_f4*>(U + (int64_t)h * k * M2_E)[idx];
+  float y0[6], y1[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    y0[i] = i < k ? w.Y[(h * k + i) * M2_E + tid] : 0.f;
+    y1[i] = i < k ? w.Y[(h * k + i) * M2_E + tid + 256] : 0.f;
+  }
+  for (int idx = tid; idx < 16 * 12; idx += M2_THREADS) {
+    const int dl = idx / 12, c = idx - dl * 12, i = c % 6, d = h * 64 + qr * 16 + dl;
+    qd[idx] = i < k ? (c < 6 ? scale * w.Q[i * M2_I + d] : w.dO[i * M2_I + d]) : 0.f;
+  }
+  __syncthreads();
+  m2_head_dots<16>(wkv + (int64_t)(h * 64 + qr * 16) * M2_E, us, k, dqh, 16, nullptr);             // the K half of to_kv
+  float u0[6], u1[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { u0[i] = us[i * M2_E + tid]; u1[i] = us[i * M2_E + tid + 256]; }
+  __syncthreads();
+  if (tid < 16 * 6 && (tid / 16) < k) w.dQ[(tid / 16) * M2_I + h * 64 + qr * 16 + (tid & 15)] = scale * dqh[tid];
+#pragma unroll 4
+  for (int dl = 0; dl < 16; ++dl) {
+    const m2_f4 c0 = *reinterpret_cast<const m2_f4*>(qd + dl * 12), c1 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 4),
+                c2 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 8);
+    const float q6[6] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1]}, o6[6] = {c1[2], c1[3], c2[0], c2[1], c2[2], c2[3]};
+    float sk0 = 0.f, sk1 = 0.f, sv0 = 0.f, sv1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { sk0 += q6[i] * u0[i]; sk1 += q6[i] * u1[i]; sv0 += o6[i] * y0[i]; sv1 += o6[i] * y1[i]; }
+    float* ok = d_wkv + (int64_t)(h * 64 + qr * 16 + dl) * M2_E + tid;
+    float* ov = d_wkv + (int64_t)(M2_I + h * 64 + qr * 16 + dl) * M2_E + tid;
+    ok[0] = accumulate ? ok[0] + sk0 : sk0;
+    ok[256] = accumulate ? ok[256] + sk1 : sk1;
+    ov[0] = accumulate ? ov[0] + sv0 : sv0;
+    ov[256] = accumulate ? ov[256] + sv1 : sv1;
+  }
+}
+
+
+constexpr int M2_GRADS2_LDS = 6 * M2_I + 4 * 6 * 64;
+constexpr int M2_GRADS2_BLOCKS = 24;
+MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
+  const float* __restrict__ q_param = a.q_param;
+  const float* __restrict__ wq = a.wq;
+  const int k = a.k, accumulate = a.accumulate;
+  float* __restrict__ d_wq = a.d_wq;
+  const Merge2Ws& w = a.w;
+  float* part = lds;                                  // [4][6][64]  (d_wq blocks: [32][8])
+  float* dqs = part + 4 * 6 * 64;                     // [6][512]
+  const int tid = threadIdx.x;
+  if (block < 16) {
+    // 32 rows of d_wq[c, e] = sum_i dQ[i, c] gq[i, e]: thread = two columns e, the k values of gq in registers
+    const int c0 = block * 32;
+    float g0[6], g1[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      g0[i] = i < k ? w.gq[i * M2_E + tid] : 0.f;
+      g1[i] = i < k ? w.gq[i * M2_E + tid + 256] : 0.f;
+    }
+    for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
+      const int r = idx >> 3, i = idx & 7;
+      part[idx] = i < k ? w.dQ[i * M2_I + c0 + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      const m2_f4 z0 = *reinterpret_cast<const m2_f4*>(part + r * 8), z1 = *reinterpret_cast<const m2_f4*>(part + r * 8 + 4);
+      const float s0 = z0[0] * g0[0] + z0[1] * g0[1] + z0[2] * g0[2] + z0[3] * g0[3] + z1[0] * g0[4] + z1[1] * g0[5];
+      const float s1 = z0[0] * g1[0] + z0[1] * g1[1] + z0[2] * g1[2] + z0[3] * g1[3] + z1[0] * g1[4] + z1[1] * g1[5];
+      float* o = d_wq + (int64_t)(c0 + r) * M2_E + tid;
+      o[0] = accumulate ? o[0] + s0 : s0;
+      o[256] = accumulate ? o[256] + s1 : s1;
+    }
+    return;
+  }
+  const int eb = block - 16, c = tid & 63, e = eb * 64 + c, cq = tid >> 6;
+  // this thread's 128 values of column e (rows cq, cq + 4, ...): fetched 32 at a time, before the query gradients are needed
+  float acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = 0.f;
+  for (int idx = tid; idx < 6 * M2_I; idx += M2_THREADS) dqs[idx] = idx < k * M2_I ? w.dQ[idx] : 0.f;
+  __syncthreads();
+#pragma unroll 1
+  for (int c0 = 0; c0 < M2_I; c0 += 128) {
+    float wv[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) wv[q] = wq[(int64_t)(c0 + cq + 4 * q) * M2_E + e];
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i] += dqs[i * M2_I + c0 + cq + 4 * q] * wv[q];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) part[(cq * 6 + i) * 64 + c] = acc[i];
+  __syncthreads();
+  if (tid < 64) {
+    float dw = 0.f, db = 0.f;
+    for (int i = 0; i < k; ++i) {
+      const float g = (part[(0 * 6 + i) * 64 + c] + part[(1 * 6 + i) * 64 + c]) + (part[(2 * 6 + i) * 64 + c] + part[(3 * 6 + i) * 64 + c]);
+      const float xhat = (q_param[(int64_t)i * M2_E + e] - w.gmean[i]) * w.grstd[i];
+      dw += g * xhat;
+      db += g;
+    }
+    // + the T row-tile partials of the rows' LayerNorm backward (fixed order): the final d_ln_w / d_ln_b, no reduction launch after this
+    const float* lp = w.lnpart + e;
+    for (int t0 = 0; t0 < w.T; t0 += 16) {
+      float pw[16], pb[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const bool ok = t0 + q < w.T;
+        pw[q] = ok ? lp[(int64_t)(t0 + q) * 2 * M2_E] : 0.f;
+        pb[q] = ok ? lp[(int64_t)(t0 + q) * 2 * M2_E + M2_E] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { dw += pw[q]; db += pb[q]; }
+    }
+    a.d_ln_w[e] = accumulate ? a.d_ln_w[e] + dw : dw;
+    a.d_ln_b[e] = accumulate ? a.d_ln_b[e] + db : db;
+  }
+}
+
+
+constexpr int M2_SIDE_LDS = M2_GRADS1_LDS;                   // floats: the largest of the three stages
+
+// block `b` of stage `stage` (1: U partials, 2: rank-k gradients I, 3: rank-k gradients II); lds: >= M2_SIDE_LDS floats, 16-byte aligned
+MHIMX_DEV void merge2_side_stage(int stage, int b, float* lds, const Merge2Side& a) {
+  if (stage == 1) merge2_partials_body<false>(b, lds, a.w.upart, a.ln_w, a.ln_b, const_cast<float*>(a.U), a.w);
+  else if (stage == 2) merge2_grads1_body(b, lds, a);
+  else merge2_grads2_body(b, lds, a);
+}
+inline int merge2_side_blocks(int stage, const Merge2Side& a) { return stage == 1 ? a.J * 4 : (stage == 2 ? M2_GRADS1_BLOCKS : M2_GRADS2_BLOCKS); }
+
+}  // namespace mhimx

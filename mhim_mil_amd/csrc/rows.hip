@@ -3,8 +3,9 @@
 // one token row at a time, lanes stride the row (coalesced 256-B segments), wave reductions by DPP
 // shuffles, cross-wave/-block merging by log-sum-exp partials (deterministic fixed-order finalize).
 #include <math.h>
+#include <string.h>
 
-#include "common.hpp"
+#include "mca2_side.hpp"
 
 namespace mhimx {
 
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
   const int e = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (e < E) {
-#pragma unroll 4
-    for (int b = wave; b < G; b += 16) acc += pz[(int64_t)b * E + e] * wgt[b];
+#pragma unroll 8
+    for (int b = wave; b < G; b += 16) acc += pz[(int64_t)b * E + e] * wgt[b];       // (8 partial rows in flight per lane)
   }
   acc16[wave][lane] = acc;
   __syncthreads();
@@ -272,8 +273,13 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
 
 // every queued final reduction of a step in one launch (mhimx_reduce_flush): job jb owns blocks [first[jb], first[jb+1]).
 // Same arithmetic as reduce_parts_kernel (kind 0) and reduce_slabs_kernel (kind 1): queued or not, the bits are the same.
-struct ReduceJobs { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int first[MHIMX_REDUCE_MAX + 1]; int n; };
+struct ReduceJobs { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int first[MHIMX_REDUCE_MAX + 1]; int n; int side_blocks; Merge2Side side; };
 __global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj) {
+  if ((int)blockIdx.x >= rj.first[rj.n]) {      // the last stage of a parked Merge-backward tail rides along (256 of the 1024 threads)
+    __shared__ __attribute__((aligned(16))) float side_lds[M2_GRADS2_LDS];
+    if (threadIdx.x < M2_THREADS) merge2_side_stage(3, (int)blockIdx.x - rj.first[rj.n], side_lds, rj.side);
+    return;
+  }
   __shared__ float red[32][33];
   int jb = 0;
   while (jb + 1 < rj.n && (int)blockIdx.x >= rj.first[jb + 1]) ++jb;
@@ -543,11 +549,17 @@ __global__ __launch_bounds__(256) void mul_colsum_kernel(float* __restrict__ dH,
 // the backward through activation + dropout of the rows that took part in the step, gathered out of the bag-ordered buffers
 __global__ __launch_bounds__(256) void rows_dpre_kernel(const float* __restrict__ dH, const _Float16* __restrict__ dact,
                                                        const int64_t* __restrict__ rows, int64_t L, int E, int64_t chunk,
-                                                       float* __restrict__ dpre, float* __restrict__ part) {
+                                                       float* __restrict__ dpre, float* __restrict__ part, int side_blocks, Merge2Side side) {
   typedef float f4v __attribute__((ext_vector_type(4)));
+  if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 1), its workgroups first
+    __shared__ float side_lds[M2_PARTIALS_LDS];
+    merge2_side_stage(1, (int)blockIdx.x, side_lds, side);
+    return;
+  }
+  const int bid = (int)blockIdx.x - side_blocks;
   typedef _Float16 h4v __attribute__((ext_vector_type(4)));
   const int e4 = E / 4;
-  const int64_t mb = (int64_t)blockIdx.x * chunk;
+  const int64_t mb = (int64_t)bid * chunk;
   const int64_t me = mb + chunk < L ? mb + chunk : L;
   for (int c = threadIdx.x; c < e4; c += 256) {
     f4v cs = f4v{0.f, 0.f, 0.f, 0.f};
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(256) void rows_dpre_kernel(const float* __restrict_
       reinterpret_cast<f4v*>(dpre + m * E)[c] = g;
       cs += g;
     }
-    if (part) *(reinterpret_cast<f4v*>(part + (int64_t)blockIdx.x * E) + c) = cs;
+    if (part) *(reinterpret_cast<f4v*>(part + (int64_t)bid * E) + c) = cs;
   }
 }
 
@@ -918,11 +930,21 @@ int reduce_parts2(hipStream_t st, const float* part0, const float* part1, int G,
   return 0;
 }
 
+int merge2_side_finish(hipStream_t st, mhimx_side_work* side, int upto_stage);      // mca2.hip
+
 int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   MHIMX_CHECK_ARG(list && list->n >= 0 && list->n <= MHIMX_REDUCE_MAX, "reduce_flush: bad list");
+  // a parked Merge-backward tail: the stages that found no ride run now, in order; the last one may ride in the reduction launch
+  if (int r = merge2_side_finish(st, &list->side, list->n == 0 ? 3 : 2)) return r;
   if (list->n == 0) return 0;
   ReduceJobs rj;
   rj.n = list->n;
+  rj.side_blocks = 0;
+  if (list->side.pending == 3) {
+    memcpy(&rj.side, list->side.blob, sizeof(rj.side));
+    rj.side_blocks = merge2_side_blocks(3, rj.side);
+    list->side.pending = 0;
+  }
   int first = 0;
   for (int i = 0; i < list->n; ++i) {
     const mhimx_reduce_job& j = list->j[i];
@@ -935,7 +957,7 @@ int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   }
   rj.first[list->n] = first;
   list->n = 0;
-  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)first), dim3(RP_THREADS), 0, st, rj);
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(first + rj.side_blocks)), dim3(RP_THREADS), 0, st, rj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -1033,8 +1055,15 @@ extern "C" int mhimx_rows_dpre(void* stream, const float* dH, const void* dact16
   const int64_t chunk = cdiv(L, nblk);
   nblk = cdiv(L, chunk);
   MHIMX_CHECK_ARG(!colsum_out || (ws && ws_bytes >= nblk * E * 4), "rows_dpre: workspace too small (%lld bytes)", (long long)(nblk * E * 4));
-  hipLaunchKernelGGL(rows_dpre_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16, rows, L, (int)E, chunk,
-                     dpre, colsum_out ? (float*)ws : nullptr);
+  Merge2Side side = {};
+  int side_blocks = 0;
+  if (defer && defer->side.pending == 1) {       // a parked Merge-backward tail: stage 1 rides in this launch
+    memcpy(&side, defer->side.blob, sizeof(side));
+    side_blocks = merge2_side_blocks(1, side);
+    defer->side.pending = 2;
+  }
+  hipLaunchKernelGGL(rows_dpre_kernel, dim3((unsigned)(nblk + side_blocks)), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16, rows, L,
+                     (int)E, chunk, dpre, colsum_out ? (float*)ws : nullptr, side_blocks, side);
   MHIMX_LAUNCH_CHECK();
   if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, (hipStream_t)stream, (const float*)ws, (int)nblk,

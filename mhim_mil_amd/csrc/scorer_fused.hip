@@ -30,7 +30,7 @@ __device__ unsigned long long sf_prof[16];
 
 constexpr int SF_ROWS = 32, SF_E = 512, SF_A = 128, SF_LD = SF_E + 4, SF_THREADS = 256;
 constexpr int SF_MAXC = 4;                  // class projections staged in LDS (more classes: the row-pass form)
-constexpr size_t SF_SMEM = (size_t)(SF_ROWS * SF_LD + 4 * SF_ROWS + 2 * SF_ROWS + SF_MAXC * SF_E) * sizeof(float);
+constexpr size_t SF_SMEM = (size_t)(SF_ROWS * SF_LD + 4 * SF_ROWS + 2 * SF_ROWS + SF_MAXC * SF_E + 2 * SF_ROWS) * sizeof(float);
 
 MHIMX_DEV void sf_split(const sf_f4& a, const sf_f4& b, sf_b8& hi, sf_b8& lo) {
   const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
   float* srow = sred + 4 * SF_ROWS;           // [32] scores
   float* prow = srow + SF_ROWS;               // [32] e^{s - m}
   float* wps = prow + SF_ROWS;                // [C][512] predictor rows
+  int64_t* ridx = reinterpret_cast<int64_t*>(wps + SF_MAXC * SF_E);   // [32] source rows of the tile (gathered form)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, kg = lane >> 5;
   const int n_col = 32 * wave + r32;
@@ -79,13 +80,17 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t row0 = (int64_t)tile * SF_ROWS;
     SF_STAMP(0);
-    // ---- 1. rows -> LDS
+    // ---- 1. rows -> LDS (gathered form: the tile's 32 row indices first, ONE coalesced load instead of 16 dependent ones per thread)
+    if (rows) {
+      if (tid < SF_ROWS) { const int64_t n = row0 + tid; ridx[tid] = rows[n < M ? n : M - 1]; }
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int f = tid + SF_THREADS * i, r = f >> 7, c4 = f & 127;
       const int64_t n = row0 + r;
       const int64_t nc = n < M ? n : M - 1;                                                // clamped: all 16 loads in flight
-      sf_f4 v = reinterpret_cast<const sf_f4*>(T + (rows ? rows[nc] : nc) * SF_E)[c4];
+      sf_f4 v = reinterpret_cast<const sf_f4*>(T + (rows ? ridx[r] : nc) * SF_E)[c4];
       if (n >= M) v = sf_f4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<sf_f4*>(Hs + r * SF_LD + 4 * c4) = v;
     }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
 // the prep-time fragment image (or is split on the fly).
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int SB_LD = SF_A + 4;
-constexpr size_t SB_SMEM = (size_t)(SF_ROWS * SB_LD + SF_E + 3 * SF_ROWS + 2 * SF_A + 8) * sizeof(float);
+constexpr size_t SB_SMEM = (size_t)(SF_ROWS * SB_LD + SF_E + 3 * SF_ROWS + 2 * SF_A + 8 + 2 * SF_ROWS) * sizeof(float);
 
 __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     const float* __restrict__ T, int64_t M, const float* __restrict__ u_pre, const float* __restrict__ s_in,
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
   float* gs_s = an_s + SF_ROWS;                // [32] ds
   float* red = gs_s + SF_ROWS;                 // [32] scratch: c0 partials (4 used)
   float* dwc_s = red + SF_ROWS;                // [2][128]
+  int64_t* ridx = reinterpret_cast<int64_t*>(dwc_s + 2 * SF_A + 8);   // [32] source / destination rows of the tile (gathered form)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, kg = lane >> 5;
   // g_z -> LDS, c0 = z . g_z
@@ -258,12 +264,16 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
 
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t row0 = (int64_t)tile * SF_ROWS;
+    if (rows) {
+      if (tid < SF_ROWS) { const int64_t n = row0 + tid; ridx[tid] = rows[n < M ? n : M - 1]; }
+      __syncthreads();
+    }
     // ---- 1. row dots T_n . g_z: 8 lanes per row, lane `seg` takes the 16-byte groups seg, seg+8, ...
     {
       const int r = tid >> 3, seg = tid & 7;
       const int64_t n = row0 + r;
       const int64_t nc = n < M ? n : M - 1;
-      const sf_f4* tr = reinterpret_cast<const sf_f4*>(T + (rows ? rows[nc] : nc) * SF_E) + seg;
+      const sf_f4* tr = reinterpret_cast<const sf_f4*>(T + (rows ? ridx[r] : nc) * SF_E) + seg;
       const sf_f4* gr = reinterpret_cast<const sf_f4*>(gzs) + seg;
       sf_f4 tv[16];
 #pragma unroll
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
       for (int i = 0; i < 16; ++i) {
         const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
         const int64_t n = row0 + row;
-        if (n < M) dT[(rows ? rows[n] : n) * SF_E + e] = acc[nt][i] + an_s[row] * ge;
+        if (n < M) dT[(rows ? ridx[row] : n) * SF_E + e] = acc[nt][i] + an_s[row] * ge;
       }
     }
     __syncthreads();                           // Ds / an_s / gs_s are rewritten by the next tile

@@ -321,7 +321,17 @@ class FusedTrainer:
         if not mhim:
             s.merge_enable = False
         try:
-            js, prep_s = s.prep_jobs(backward=True)
+            R_merge = s.v2_counts(ps, i)[4] if mhim else 0
+            lean = mhim and s.merge.k * 8 <= 48 and 1 <= R_merge <= 8192 and s._op_prec != "f32"
+            js, prep_s = s.prep_jobs(backward=True, lean_merge=lean)
+            if lean:
+                # the parameter-only part of the student's Merge (LayerNorm of the queries, their projection, the score vectors) rides
+                # in the preparation launch: off the teacher -> select -> student chain
+                if True:
+                    mw_prep = s._merge_w(None)
+                    prep_s["merge_ws"] = mw_prep.ws_for(R_merge, dev)
+                    prep_s["_merge_prep_w"] = mw_prep                      # (keeps the weight struct alive until the launch is enqueued)
+                    js.append((ops.PREP_MERGE, mw_prep, (prep_s["merge_ws"], R_merge)))
             ops.prep_batch(jobs + js)
             first = self._micro == 0
             gv = fl.grad_views

@@ -278,7 +278,7 @@ class MHIM(nn.Module):
                                wb=att.attention_b[0].weight.data, prec=self._op_prec)
         return ops.ScorerW(att.attention[0].weight.data, att.attention[2].weight.data, act, prec=self._op_prec, wa_frag=wa_frag)
 
-    def prep_jobs(self, backward=True):
+    def prep_jobs(self, backward=True, lean_merge=False):
         """Parameter-only work of one step — the paired-plane image of the projection weight, weight transposes for the dX
         GEMMs, a snapshot of the global queries — as (jobs for ops.prep_batch, dict of their outputs).  It depends on nothing
         but the parameters, so a trainer folds the teacher's and the student's jobs and its step counters into ONE launch."""
@@ -312,10 +312,14 @@ class MHIM(nn.Module):
             if self.merge_enable:
                 m = self.merge
                 wkv = m.attn.to_kv.weight.data
-                if wkv.shape[0] % 32 == 0 and wkv.shape[1] % 16 == 0:     # matrix-core image of Wkv (one-kernel cross attention)
-                    prep["wkv_frag"] = torch.empty_like(wkv)
-                    jobs.append((ops.PREP_FRAG, wkv, prep["wkv_frag"]))
-                prep["merge_t"] = (tr(m.attn.to_kv.weight.data), tr(m.attn.to_q.weight.data), tr(m.attn.to_out[0].weight.data))
+                if lean_merge:
+                    # the projection-free Merge (mca2.hip) reads to_kv / to_q as they are; only to_out is wanted transposed
+                    prep["merge_t"] = (None, None, tr(m.attn.to_out[0].weight.data))
+                else:
+                    if wkv.shape[0] % 32 == 0 and wkv.shape[1] % 16 == 0:     # matrix-core image of Wkv (one-kernel cross attention)
+                        prep["wkv_frag"] = torch.empty_like(wkv)
+                        jobs.append((ops.PREP_FRAG, wkv, prep["wkv_frag"]))
+                    prep["merge_t"] = (tr(m.attn.to_kv.weight.data), tr(m.attn.to_q.weight.data), tr(m.attn.to_out[0].weight.data))
                 prep["q_old"] = torch.empty_like(m.global_q_mm.data)
                 jobs.append((ops.PREP_COPY, m.global_q_mm.data, prep["q_old"]))
         return jobs, prep
@@ -326,7 +330,7 @@ class MHIM(nn.Module):
             ops.prep_batch(jobs)
         return prep
 
-    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None, x_rows=None):
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None, x_rows=None, prepared=False):
         m = self.merge
         if need_t and tr is None:
             tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
@@ -336,7 +340,7 @@ class MHIM(nn.Module):
         return ops.MergeW(q, m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
                           m.attn.to_q.weight.data, m.attn.to_out[0].weight.data, m.attn.to_out[0].bias.data, m.g_q_mm,
                           drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr,
-                          drop_tick=self._tick, wkv_frag=wkv_frag, x_rows=x_rows)
+                          drop_tick=self._tick, wkv_frag=wkv_frag, x_rows=x_rows, prepared=prepared)
 
     # ------------------------------------------------------------------ kernels: feature rows
     def _check_x(self, x):
@@ -523,9 +527,11 @@ class MHIM(nn.Module):
         sc = self._scorer(prep.get("wa_frag"))
         saved = {"Hbuf": Hbuf, "DACT": DACT, "rows_all": rows_all, "prep": prep}
         if rows_all is not None:
-            mw = self._merge_w(plan, need_t=False, wkv_frag=prep.get("wkv_frag"), x_rows=rows_all[:plan.R])
+            # (prep["merge_ws"]: the parameter-only part of Merge already ran as a job of the step's preparation launch)
+            mw = self._merge_w(plan, need_t=False, wkv_frag=prep.get("wkv_frag"), x_rows=rows_all[:plan.R], prepared="merge_ws" in prep)
             q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
-            _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None)
+            _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None,
+                                      ws=prep.get("merge_ws"))
             st = ops.abmil_pool_fwd(sc, Hbuf, None, rows1=rows_all[plan.R:])
             saved.update(mws=mws, q_old=prep.get("q_old"))
         else:

@@ -105,7 +105,7 @@ def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
     return heads
 
 
-PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T = 0, 1, 2, 3, 4, 5
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE = 0, 1, 2, 3, 4, 5, 6
 
 
 def prep_batch(jobs):
@@ -116,6 +116,9 @@ def prep_batch(jobs):
     for i, (kind, src, dst) in enumerate(jobs):
         if kind == PREP_TICK:
             arr[i] = L.PrepJob(kind, None, _p(dst), 1, 1)
+        elif kind == PREP_MERGE:                  # (MergeW, (workspace uint8 tensor, rows to merge)): the struct is read at enqueue time
+            ws, n_rows = dst
+            arr[i] = L.PrepJob(kind, C.c_void_p(C.addressof(src.c)), _p(ws), int(n_rows), ws.numel())
         else:
             _chk(src, name="prep in"); _chk(dst, name="prep out")
             R, Cc = (src.shape[0], src.numel() // src.shape[0]) if src.dim() >= 2 else (1, src.numel())
@@ -140,6 +143,7 @@ class ReduceList:
     def __init__(self):
         self.c = L.ReduceListC()
         self.c.n = 0
+        self.c.side.pending = 0
         self.keep = []
 
     def ptr(self):
@@ -343,7 +347,7 @@ def compose_ids(a, b):
 # ------------------------------------------------------------------------------------------------ merge
 class MergeW:
     def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
-                 prec="bf16x3", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None):
+                 prec="bf16x3", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None, prepared=False):
         self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo, wkv_frag]
         _chk(x_rows, torch.int64, "x_rows")
         self.x_rows = x_rows
@@ -356,7 +360,7 @@ class MergeW:
                          ln_b=_p(ln_b), wkv=_p(wkv), wq=_p(wq), wo=_p(wo), bo=_p(bo), wkv_t=_p(self.tr[0]),
                          wq_t=_p(self.tr[1]), wo_t=_p(self.tr[2]), mm=float(mm), drop_p=float(drop_p),
                          drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec), drop_tick=_p(drop_tick),
-                         wkv_frag=_p(wkv_frag), x_rows=_p(x_rows))
+                         wkv_frag=_p(wkv_frag), x_rows=_p(x_rows), prepared=int(bool(prepared)))
 
     def ws_for(self, R, device):
         n = L.lib().mhimx_merge_ws_bytes(R, self.E, self.k, self.heads, self.dim_head)
