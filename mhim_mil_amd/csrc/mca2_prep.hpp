@@ -96,32 +96,42 @@ MHIMX_DEV void m2_ln_stats(const m2_f4& a, const m2_f4& b, float& mu, float& rs)
   rs = rsqrtf(wave_sum(v) * (1.f / M2_E) + 1e-5f);
 }
 
-// out[i][d] = rows[d][:] . vec[i][:] for NR consecutive weight rows (row pitch 512) and the 6 vectors vec[6][512] in LDS (rows >= k
-// zero): one wave per row, NR / 4 rows per wave, all of them fetched before any arithmetic; the inner loop over the vectors is a
-// compile-time 6 (a run-time k leaves every LDS read a dependent round trip).  gout (optional): the same values to global [i][512].
+// out[i][d] = rows[d][:] . vec[i][:] for NR (16 or 64) consecutive weight rows (row pitch 512) and the 6 vectors vec[6][512] in LDS (rows >= k
+// zero), on the matrix cores (3-term bf16): [6 -> 16 x 512] . [512 x 16 rows per wave] = 16 MFMA steps per wave and NO cross-lane
+// reductions (the wave-per-row form spent most of its time in 96 DPP reductions per wave).  Every load of the wave's 16 rows is in flight
+// before the first MFMA.  gout (optional): the same values to global [i][512].
 template <int NR>
 MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, int k, float* out, int out_ld, float* gout) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int PW = NR / 4;
-  m2_f4 ra[PW], rb[PW];
+  if (NR == 16 && wave != 0) return;
+  const int n = lane & 15, kg = lane >> 4, wrow0 = NR == 16 ? 0 : wave * 16;
+  const float* rp = rows + (int64_t)(wrow0 + n) * M2_E + kg * 8;
+  m2_f4 b0[16], b1[16];
 #pragma unroll
-  for (int q = 0; q < PW; ++q) {
-    const float* row = rows + (int64_t)(wave * PW + q) * M2_E;
-    ra[q] = *reinterpret_cast<const m2_f4*>(row + 4 * lane);
-    rb[q] = *reinterpret_cast<const m2_f4*>(row + 256 + 4 * lane);
+  for (int ks = 0; ks < 16; ++ks) {
+    b0[ks] = *reinterpret_cast<const m2_f4*>(rp + ks * 32);
+    b1[ks] = *reinterpret_cast<const m2_f4*>(rp + ks * 32 + 4);
+  }
+  const bool am = n < 6;                                     // A row m = lane & 15: vector m (zero beyond the 6th)
+  const float* ap = vec + (am ? n : 0) * M2_E + kg * 8;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    m2_f4 a0 = *reinterpret_cast<const m2_f4*>(ap + ks * 32), a1 = *reinterpret_cast<const m2_f4*>(ap + ks * 32 + 4);
+    if (!am) { a0 = m2_f4{0.f, 0.f, 0.f, 0.f}; a1 = a0; }
+    const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const float bv[8] = {b0[ks][0], b0[ks][1], b0[ks][2], b0[ks][3], b1[ks][0], b1[ks][1], b1[ks][2], b1[ks][3]};
+    bf8 ah, al, bh, bl;
+    m2_split8(av, ah, al);
+    m2_split8(bv, bh, bl);
+    acc = m2_mfma3(ah, al, bh, bl, acc);
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const m2_f4 ga = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(vec + i * M2_E + 256 + 4 * lane);
-#pragma unroll
-    for (int q = 0; q < PW; ++q) {
-      const m2_f4 a = ra[q], b = rb[q];
-      float s = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2] + a[3] * ga[3] + b[0] * gb[0] + b[1] * gb[1] + b[2] * gb[2] + b[3] * gb[3];
-      s = wave_sum(s);
-      if (lane == 0 && i < k) {
-        out[i * out_ld + wave * PW + q] = s;
-        if (gout) gout[i * M2_I + wave * PW + q] = s;
-      }
+  for (int i = 0; i < 4; ++i) {
+    const int m = 4 * kg + i;                                // C: row m = vector, column n = weight row
+    if (m < k) {
+      out[m * out_ld + wrow0 + n] = acc[i];
+      if (gout) gout[m * M2_I + wrow0 + n] = acc[i];
     }
   }
 }

@@ -163,7 +163,7 @@ MHIMX_DEV void merge2_grads1_body(int block, float* lds, const Merge2Side& a) {
 
 
 constexpr int M2_GRADS2_LDS = 6 * M2_I + 4 * 6 * 64;
-constexpr int M2_GRADS2_BLOCKS = 24;
+constexpr int M2_GRADS2_BLOCKS = 48;
 MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
   const float* __restrict__ q_param = a.q_param;
   const float* __restrict__ wq = a.wq;
@@ -198,30 +198,29 @@ MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
     }
     return;
   }
-  const int eb = block - 16, c = tid & 63, e = eb * 64 + c, cq = tid >> 6;
-  // this thread's 128 values of column e (rows cq, cq + 4, ...): fetched 32 at a time, before the query gradients are needed
+  // 16 columns of dgq per block: thread = (column, one of 16 row groups of Wq), its 32 weights in flight at once
+  const int eb = block - 16, c = tid & 15, e = eb * 16 + c, cq = tid >> 4;
   float acc[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
+  float wv[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) wv[q] = wq[(int64_t)(cq + 16 * q) * M2_E + e];
   for (int idx = tid; idx < 6 * M2_I; idx += M2_THREADS) dqs[idx] = idx < k * M2_I ? w.dQ[idx] : 0.f;
   __syncthreads();
-#pragma unroll 1
-  for (int c0 = 0; c0 < M2_I; c0 += 128) {
-    float wv[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) wv[q] = wq[(int64_t)(c0 + cq + 4 * q) * M2_E + e];
+  for (int q = 0; q < 32; ++q)
 #pragma unroll
-    for (int q = 0; q < 32; ++q)
+    for (int i = 0; i < 6; ++i) acc[i] += dqs[i * M2_I + cq + 16 * q] * wv[q];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) acc[i] += dqs[i * M2_I + c0 + cq + 4 * q] * wv[q];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) part[(cq * 6 + i) * 64 + c] = acc[i];
+  for (int i = 0; i < 6; ++i) part[(cq * 6 + i) * 16 + c] = acc[i];
   __syncthreads();
-  if (tid < 64) {
+  if (tid < 16) {
     float dw = 0.f, db = 0.f;
     for (int i = 0; i < k; ++i) {
-      const float g = (part[(0 * 6 + i) * 64 + c] + part[(1 * 6 + i) * 64 + c]) + (part[(2 * 6 + i) * 64 + c] + part[(3 * 6 + i) * 64 + c]);
+      float g = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) g += part[(q * 6 + i) * 16 + c];
       const float xhat = (q_param[(int64_t)i * M2_E + e] - w.gmean[i]) * w.grstd[i];
       dw += g * xhat;
       db += g;
