@@ -279,10 +279,11 @@ int mhimx_resconv_dw(void* stream, const float* dout, int64_t ldo, const float* 
  * fwd: y[N,C] = depth-wise 7x7 stencil of the wrap-padded H x H token grid; bwd: dx, dwc [C,49], dbc [C]. */
 int mhimx_ppeg_combine(void* stream, const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,
                        const float* b3, int64_t C, float* wc, float* bc);
-int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const float* wc, const float* bc, float* y);
+int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const float* wc, const float* bc, float* y,
+                   int64_t grid /* 0: emb_position.PPEG's own grid rule; > 0: an explicit grid x grid layout (transmil.py:57-64) */);
 int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C);
 int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc, float* dbc,
-                   float* ws);
+                   float* ws, int64_t grid);
 /* out[t,c] = v[t,c] * a[c/dh, t]   (scoring.py:25: per-head value x attention, heads interleaved as (h d)) */
 int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, const float* a, int64_t lda, int64_t dh, int64_t T, int64_t C, float* out);
 

@@ -175,9 +175,9 @@ SYMBOLS = {
     "mhimx_resconv_dw_ws_floats": (_I64, [_I64, _I64, _I64, _I64]),
     "mhimx_resconv_dw": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "mhimx_ppeg_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
-    "mhimx_ppeg_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
+    "mhimx_ppeg_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _I64]),
     "mhimx_ppeg_bwd_ws_floats": (_I64, [_I64, _I64]),
-    "mhimx_ppeg_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mhimx_ppeg_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64]),
     "mhimx_scale_heads": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
 }
 

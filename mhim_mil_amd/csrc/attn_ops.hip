@@ -747,17 +747,26 @@ extern "C" int mhimx_ppeg_combine(void* stream, const float* w7, const float* w5
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
-static void ppeg_geom(int64_t N, int* H, int64_t* wrapN) {
+// grid == 0: the rule of emb_position.PPEG (MHIM's encoder): side ceil(sqrt(N)), the first side^2 - N tokens appended again, zero-padded
+// to 7 x 7 below that.  grid > 0: an explicit grid x grid layout (modules/transmil.PPEG.forward(x, H, W): the caller has padded the tokens).
+static void ppeg_geom(int64_t N, int64_t grid, int* H, int64_t* wrapN) {
+  if (grid > 0) {
+    *H = (int)grid;
+    *wrapN = grid * grid;
+    return;
+  }
   int h0 = (int)ceil(sqrt((double)N));
   while ((int64_t)h0 * h0 < N) ++h0;
   while (h0 > 1 && (int64_t)(h0 - 1) * (h0 - 1) >= N) --h0;
   *wrapN = (int64_t)h0 * h0;
   *H = h0 < 7 ? 7 : h0;
 }
-extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const float* wc, const float* bc, float* y) {
+extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const float* wc, const float* bc, float* y, int64_t grid) {
   MHIMX_CHECK_ARG(x && wc && bc && y && N > 0, "ppeg_fwd: bad args");
+  MHIMX_CHECK_ARG(grid == 0 || (grid * grid >= N && grid * grid - N <= N && grid <= 32768), "ppeg_fwd: a %lld x %lld grid does not hold %lld tokens",
+                  (long long)grid, (long long)grid, (long long)N);
   int H; int64_t wrapN;
-  ppeg_geom(N, &H, &wrapN);
+  ppeg_geom(N, grid, &H, &wrapN);
   const int nsx = (int)cdiv(H, PS);
   hipLaunchKernelGGL(ppeg_strip_kernel<0>, dim3((unsigned)(nsx * H), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, x, N, (int)C, H,
                      wrapN, wc, bc, y, nsx);
@@ -766,10 +775,11 @@ extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C
 }
 extern "C" int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C) { return cdiv(N, 256) * C * 50 + 49 * C; }
 extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc,
-                              float* dbc, float* ws) {
+                              float* dbc, float* ws, int64_t grid) {
   MHIMX_CHECK_ARG(dy && x && wc && dx && dwc && dbc && ws, "ppeg_bwd: null args");
+  MHIMX_CHECK_ARG(grid == 0 || (grid * grid >= N && grid * grid - N <= N && grid <= 32768), "ppeg_bwd: bad grid");
   int H; int64_t wrapN;
-  ppeg_geom(N, &H, &wrapN);
+  ppeg_geom(N, grid, &H, &wrapN);
   hipStream_t st = (hipStream_t)stream;
   const int nsx = (int)cdiv(H, PS);
   hipLaunchKernelGGL(ppeg_strip_kernel<1>, dim3((unsigned)(nsx * H), (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc,

@@ -12,6 +12,11 @@ time (0.73 ms from pinned memory), so the MI355X-first feeder has two modes:
   the buffer's previous step has finished).
 
 Sources are tensors / arrays already in memory or paths of ``torch.save``d feature matrices ([N, D] float).
+
+``BagLoader`` is the same feeder behind the reference's LOADER seam: it yields the batch dictionaries the reference's train /
+validate loops unpack (datasets/dataset_feat.py:93-111 through a batch_size-1 DataLoader and datasets/data_utils.PrefetchLoader,
+:484-521): ``{'input': bag [1, N, D] on the device, 'target': label [1] int64 on the device[, 'idx': [name]]}``, with ``len()``.
+``BaseTrainer.train`` (engines/base_engine.py:46-60, ``args.prefetch`` set: the batch is already on the device) consumes it as is.
 """
 from __future__ import annotations
 
@@ -93,3 +98,24 @@ class BagFeeder:
             main.wait_event(self._landed[slot])
             yield self._buf[slot][:self.host[idx].shape[0]], self.labels[idx], idx
             self._released[slot].record(main)                      # everything the consumer enqueued on `main` is ordered before
+
+
+class BagLoader:
+    """The reference's loader contract over a BagFeeder (PrefetchLoader stand-in: batches arrive on the device)."""
+
+    def __init__(self, bags: Sequence, labels: Sequence[int], device="cuda", resident=True, order: Iterable[int] | None = None,
+                 names: Sequence[str] | None = None, return_id=False):
+        self.feeder = BagFeeder(bags, labels, device=device, resident=resident, order=order)
+        self.names = list(names) if names is not None else [str(i) for i in range(len(bags))]
+        self.return_id = bool(return_id)
+        self.device = self.feeder.device
+
+    def __len__(self):
+        return len(self.feeder)
+
+    def __iter__(self):
+        for bag, label, idx in self.feeder:
+            batch = {"input": bag.unsqueeze(0), "target": label}            # the default collate of a batch_size-1 DataLoader
+            if self.return_id:
+                batch["idx"] = [self.names[idx]]                             # dataset_feat.py:108-109
+            yield batch

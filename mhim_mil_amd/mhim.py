@@ -840,6 +840,33 @@ class MHIM(nn.Module):
             return 0.
         return self._head(student_cls_feat, teacher_cls_feat)[1]
 
+    @torch.no_grad()
+    def _forward_eval(self, x, ps, i, attn, teacher_cls_feat, perm):
+        """MHIM.forward with the module in eval mode (mhim.py:318-378 as written: the mask is applied whatever the mode; Merge in
+        eval keeps EVERY surviving row and appends the k tokens merged from all of them, merge.py:197-203; no EMA of the global
+        queries, no dropout).  No gradient path (the reference's trainer never calls it in eval mode; validation uses forward_test)."""
+        len_keep, mask_ids = self.get_mask(ps, i, attn, perm=perm)
+        if mask_ids is None:
+            raise AssertionError("MHIM.forward needs a mask (mask_ratio_h > 0 or a v1 ratio), as the reference does (masking.py:104)")
+        rows = mask_ids.view(-1)[:len_keep].contiguous()
+        H = self._feature(x, rows, 0.0, 0, M=len_keep)
+        z_tok, _, _ = ops.merge_fwd(self._merge_w(None), H, update_q=False)
+        k = z_tok.shape[0]
+        if self.baseline == "dsmil":
+            lb, li, B, _ = self.online_encoder(torch.cat([H, z_tok], 0))
+            cls_loss = 0.
+            if teacher_cls_feat is not None:
+                cls_loss = DS.SoftTargetCE.apply(B, teacher_cls_feat.detach().reshape(B.shape).float(), float(self.temp_t))
+            return [lb.view(1, -1), li.view(1, -1)], cls_loss, ps, len_keep + k
+        if self.baseline == "selfattn":
+            z = self._encode(torch.cat([H, z_tok], 0)).view(1, -1)
+        else:
+            z = ops.abmil_pool_fwd(self._scorer(), H, z_tok).z.view(1, -1)
+        logits, cls_loss = self._head(z, teacher_cls_feat)
+        if teacher_cls_feat is None:
+            cls_loss = 0.
+        return logits, cls_loss, ps, len_keep + k
+
     def forward(self, x, attn=None, teacher_cls_feat=None, i=None, pos=None, perm=None, ids_shuffle=None, drop_mask=None):
         x = self._check_x(x)
         ps = x.shape[0]
@@ -847,7 +874,7 @@ class MHIM(nn.Module):
             raise TypeError("MHIM.forward requires merge_enable=True (the reference's Identity merge rejects the "
                             "second argument, mhim.py:82,351)")
         if not self.training:
-            raise NotImplementedError("MHIM.forward in eval mode is not used by the reference trainer; use forward_test")
+            return self._forward_eval(x, ps, i, attn, teacher_cls_feat, perm)
         rows, len_keep, Lk, R = self.student_rows(ps, i, attn, perm=perm, ids_shuffle=ids_shuffle)
         plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=self._next_seed(), drop_mask=drop_mask,
                        mca_seed=self._next_seed(), training=self.training)

@@ -342,15 +342,16 @@ class ResConv(torch.autograd.Function):
 
 class PPEG(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w7, w5, w3, b7, b5, b3):
+    def forward(ctx, x, w7, w5, w3, b7, b5, b3, grid=0):
         x = x.contiguous()
         N, Cc = x.shape
+        ctx.grid = int(grid)
         wc, bc = torch.empty((Cc, 49), device=x.device), torch.empty(Cc, device=x.device)
         lib = L.lib()
         L.check(lib.mhimx_ppeg_combine(_st(), _ptr(w7.contiguous()), _ptr(w5.contiguous()), _ptr(w3.contiguous()), _ptr(b7), _ptr(b5),
                                        _ptr(b3), Cc, _ptr(wc), _ptr(bc)), "ppeg_combine")
         y = torch.empty_like(x)
-        L.check(lib.mhimx_ppeg_fwd(_st(), _ptr(x), N, Cc, _ptr(wc), _ptr(bc), _ptr(y)), "ppeg_fwd")
+        L.check(lib.mhimx_ppeg_fwd(_st(), _ptr(x), N, Cc, _ptr(wc), _ptr(bc), _ptr(y), int(grid)), "ppeg_fwd")
         ctx.save_for_backward(x, wc)
         return y
 
@@ -361,10 +362,10 @@ class PPEG(torch.autograd.Function):
         N, Cc = x.shape
         dx, dwc, dbc = torch.empty_like(x), torch.empty_like(wc), torch.empty(Cc, device=x.device)
         ws = torch.empty(L.lib().mhimx_ppeg_bwd_ws_floats(N, Cc), device=x.device)
-        L.check(L.lib().mhimx_ppeg_bwd(_st(), _ptr(dy), _ptr(x), N, Cc, _ptr(wc), _ptr(dx), _ptr(dwc), _ptr(dbc), _ptr(ws)), "ppeg_bwd")
+        L.check(L.lib().mhimx_ppeg_bwd(_st(), _ptr(dy), _ptr(x), N, Cc, _ptr(wc), _ptr(dx), _ptr(dwc), _ptr(dbc), _ptr(ws), ctx.grid), "ppeg_bwd")
         g = dwc.view(Cc, 1, 7, 7)
         # the three kernels were summed centre-aligned into one 7x7 stencil: their gradients are its centred windows
-        return (dx, g.contiguous(), g[:, :, 1:6, 1:6].contiguous(), g[:, :, 2:5, 2:5].contiguous(), dbc, dbc.clone(), dbc.clone())
+        return (dx, g.contiguous(), g[:, :, 1:6, 1:6].contiguous(), g[:, :, 2:5, 2:5].contiguous(), dbc, dbc.clone(), dbc.clone(), None)
 
 
 class Add(torch.autograd.Function):
@@ -494,8 +495,10 @@ class _PPEG(nn.Module):
         super().__init__()
         self.proj, self.proj1, self.proj2 = _Conv(dim, 7), _Conv(dim, 5), _Conv(dim, 3)
 
-    def forward(self, x):
-        return PPEG.apply(x, self.proj.weight, self.proj1.weight, self.proj2.weight, self.proj.bias, self.proj1.bias, self.proj2.bias)
+    def forward(self, x, grid=0):
+        """grid = 0: emb_position.PPEG (side ceil(sqrt(N)), wrap, zero-padded to 7 x 7 below 37 tokens); grid > 0: the explicit
+        grid x grid layout of modules/transmil.PPEG.forward(x, H, W)."""
+        return PPEG.apply(x, self.proj.weight, self.proj1.weight, self.proj2.weight, self.proj.bias, self.proj1.bias, self.proj2.bias, grid)
 
 
 class SAttention(nn.Module):

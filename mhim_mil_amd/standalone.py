@@ -18,6 +18,8 @@ training mode when ``dropout > 0``.  CLAM, DTFD, RRT, ... are other model famili
 """
 from __future__ import annotations
 
+import math
+
 import torch
 from torch import nn
 
@@ -172,7 +174,7 @@ class AttentionGated(_AttnMILBase):
 class TransMIL(_AttnMILBase):
     """modules/transmil.py:66-175 (pos='ppeg', mil_norm=None): tokens wrap-padded to a square (transmil.py:124-128) - a row gather
     fused into the embedding GEMM, no copy - then the encoder of SURVEY rows A9/A10 (mhim_mil_amd/nystrom.py) and a classifier.
-    Bags need at least 37 patches (a 7 x 7 grid for the PPEG stencils, as the MHIM encoder's PPEG pads below that)."""
+    Any bag size: this model's PPEG is told the grid (transmil.py:57-64), it does not zero-pad to 7 x 7 as emb_position.PPEG does."""
 
     def __init__(self, input_dim, n_classes, dropout, act, mil_norm=None, mil_bias=True, inner_dim=512, embed_feat=True, pos="ppeg",
                  n_heads=8, **kwargs):
@@ -192,9 +194,9 @@ class TransMIL(_AttnMILBase):
     def forward(self, x, return_attn=False, return_act=False, **kwargs):
         x = self._check(x)
         n = x.shape[0]
-        side = int(torch.ceil(torch.sqrt(torch.tensor(float(n)))).item())
-        if side < 7:
-            raise L.MhimxError("TransMIL (mhimx): bags need at least 37 patches (7 x 7 PPEG grid)")
+        side = int(math.ceil(math.sqrt(n)))             # transmil.py:124-126 (any side: its PPEG takes the grid explicitly, :57-64)
+        while side * side < n:
+            side += 1
         add = side * side - n
         rows = None
         if add > 0:                                                      # x = cat([x, x[:add]]) as a gather index
@@ -209,7 +211,7 @@ class TransMIL(_AttnMILBase):
             attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))     # transmil.py:138-141
         else:
             t = self.layer1(t, False, False, s1, None, tr)
-        t = torch.cat([t[:1], self.pos_layer(t[1:])], 0)
+        t = torch.cat([t[:1], self.pos_layer(t[1:], grid=side)], 0)
         if return_attn:
             t, a, _ = self.layer2(t, True, False, s2, None, tr)
             attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))

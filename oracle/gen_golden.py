@@ -267,7 +267,7 @@ def g7_nystrom(ns):
 
 
 def g8_sattention(ns):
-    for n in (48, 600, 1500):
+    for n in (20, 48, 600, 1500):                 # 20 < 37 tokens: PPEG's zero-padding to a 7 x 7 grid (emb_position.py:100-104)
         sd = synth.mhim_state(13, input_dim=64, baseline="selfattn", merge_enable=False)
         m = _refimport.build_mhim(ns, sd, input_dim=64, n_classes=2, act="gelu", baseline="selfattn",
                                   merge_enable=False, dropout=0.0).eval()
@@ -460,7 +460,8 @@ def g15_standalone_transmil(ns):
         print("  (modules/transmil.py not importable: skipped)")
         return
     d = 64
-    for n, act, pseed in ((300, "relu", 47), (441, "gelu", 48)):           # 300 -> 18 x 18 grid with 24 wrapped tokens; 441 = 21 x 21
+    # 300 -> 18 x 18 grid with 24 wrapped tokens; 441 = 21 x 21; 20 -> 5 x 5 (a grid below the 7 x 7 stencil, transmil.py:57-64)
+    for n, act, pseed in ((300, "relu", 47), (441, "gelu", 48), (20, "gelu", 49)):
         x = _x(34 + n, n, d)
         m = _fill_module(ns.transmil.TransMIL(d, 2, dropout=False, act=act), pseed).eval()
         out = m(x.clone(), return_attn=True)
@@ -472,6 +473,27 @@ def g15_standalone_transmil(ns):
                                                           shapes=[list(v.shape) for v in m.state_dict().values()]),
               logits=logits[0].detach().numpy(), loss=loss.item(), attn0=attn[0][0].detach().numpy(), attn1=attn[1][0].detach().numpy(),
               **_compact_all("grad", _grads(m)))
+
+
+def g16_student_eval(ns):
+    """MHIM.forward with the module in eval mode (mhim.py:318-378: mask applied, Merge keeps every surviving row and appends the k tokens
+    merged from all of them, merge.py:197-203) - the branch the reference's trainer never takes but the class allows."""
+    n, d = 600, 64
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    t = _teacher(ns, synth.spread_teacher(base), d).eval()
+    s = _teacher(ns, base, d).eval()
+    x = _x(16000, n, d)
+    feat, score = t.forward_teacher(x)
+    k = int(np.ceil(n * min(V2["mask_ratio_h"] / V2["mask_ratio_hr"], 1.0)))
+    torch.manual_seed(23)
+    perm = torch.randperm(k)
+    torch.manual_seed(23)
+    q0 = s.merge.global_q_mm.detach().clone()
+    with torch.no_grad():
+        logits, cls_loss, ps, keep = s(x, score, feat, i=0)
+    assert torch.equal(q0, s.merge.global_q_mm.detach())
+    _save("g16_student_eval_attn", dict(seed=7, xseed=16000, n=n, d=d, **V2), teacher_feat=feat[0].numpy(), teacher_score=score[0].numpy(),
+          perm=perm.numpy(), logits=logits[0].numpy(), cls_loss=float(cls_loss), ps=ps, keep=keep)
 
 
 def g12_cosine_scheduler(ns):
@@ -496,7 +518,7 @@ def main():
     only = set(sys.argv[1:])                     # python -m oracle.gen_golden g14_standalone_train  -> just that family
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
                g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil,
-               g14_standalone_train, g15_standalone_transmil):
+               g14_standalone_train, g15_standalone_transmil, g16_student_eval):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

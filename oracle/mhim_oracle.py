@@ -568,6 +568,21 @@ def forward_student(x, params, cfg: Cfg, attn, teacher_feat=None, perm=None, ids
                                                "global_q_new": g_new, "feat": z}
 
 
+def forward_student_eval(x, params, cfg: Cfg, attn, teacher_feat=None, perm=None):
+    """MHIM.forward with the module in eval mode (mhim.py:318-378): the mask is applied whatever the mode; Merge's eval branch keeps
+    every surviving row and appends the k tokens merged from all of them (merge.py:197-198); no EMA, no dropout."""
+    h = feature(x, params, cfg.act, None, 0.0)
+    ps = h.shape[0]
+    a_np = attn.detach().cpu().numpy() if torch.is_tensor(attn) else np.asarray(attn)
+    len_keep, mask_ids = get_mask(ps, a_np, cfg.mask_ratio, cfg.mask_ratio_l, cfg.mask_ratio_h, cfg.mask_ratio_hr, (None, None, perm),
+                                  cfg.msa_fusion)
+    hk = merge_eval(h[torch.as_tensor(mask_ids[:len_keep], dtype=torch.long)], params)
+    z = _encode(hk, params, cfg)
+    logits = predictor(z, params)
+    cls_loss = soft_target_ce(z, teacher_feat.detach(), cfg.temp_t) if teacher_feat is not None else 0.0
+    return logits, cls_loss, ps, hk.shape[0]
+
+
 # --------------------------------------------------------------------------- #
 # A14  trainer step semantics   (engines/base_engine.py:76-134,151,155-167; train_utils.py:58-65)
 # --------------------------------------------------------------------------- #

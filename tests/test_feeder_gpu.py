@@ -75,3 +75,37 @@ def test_trainer_state_is_independent_of_the_feeding_mode(tmp_path):
         return tr.flat.student.cpu().numpy()
 
     np.testing.assert_array_equal(run(True), run(False))
+
+
+def test_bag_loader_feeds_the_reference_train_loop_body():
+    """BagLoader yields the batch dictionaries of the reference's loader seam (dataset_feat.py:93-111 + PrefetchLoader); the body of
+    BaseTrainer.train (base_engine.py:52-93) is restated around CommonMIL.forward_func with the keyword set the reference passes."""
+    import types
+    from mhim_mil_amd.engine import CommonMIL
+    from mhim_mil_amd.feeder import BagLoader
+    from mhim_mil_amd.mhim import MHIM
+    d = 64
+    cfg = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True, merge_k=5,
+               merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.25)
+    s = MHIM(input_dim=d, n_classes=2, baseline="attn", **cfg).to(DEV).train()
+    t = MHIM(input_dim=d, n_classes=2, baseline="attn", **cfg).to(DEV).train()
+    t.load_state_dict(s.state_dict())
+    bags = [torch.from_numpy(synth.bag(40 + i, 300 + 57 * i, d)) for i in range(4)]
+    for resident in (True, False):
+        loader = BagLoader(bags, [0, 1, 1, 0], device=DEV, resident=resident, return_id=True, names=[f"slide_{i}.pt" for i in range(4)])
+        assert len(loader) == 4
+        eng = CommonMIL(None)
+        args = types.SimpleNamespace(model="mhim", baseline="attn", aux_alpha=0.5)
+        eng.init_func_train(args)
+        seen = []
+        for batch_idx, batch in enumerate(loader):
+            bag, label = batch["input"], batch["target"]                    # base_engine.py:59-64
+            batch_size = label.size(0)
+            pos, idx, feat = batch.get("pos", None), batch.get("idx", None), batch.get("feat", None)
+            assert bag.is_cuda and bag.dim() == 3 and bag.shape[0] == 1 and label.is_cuda and label.dtype == torch.int64 and batch_size == 1
+            out = eng.forward_func(args, s, t, bag, label, None, batch_size, batch_idx, 0, batch_idx, pos, loader=loader, device=DEV,
+                                   others={}, idx=idx, feat=feat)
+            logits, lab, aux, patch_num, keep_num = out[:5]
+            assert logits.shape == (1, 2) and lab is label and patch_num == bags[batch_idx].shape[0] and 0 < keep_num < patch_num
+            seen.append(idx[0])
+        assert seen == [f"slide_{i}.pt" for i in range(4)]

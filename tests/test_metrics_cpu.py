@@ -72,3 +72,12 @@ def test_bootstrap_mean_std():
     for j, k in enumerate(MO.KEYS):
         np.testing.assert_allclose(b[k][0], rows[:, j].mean(), atol=1e-12)
         np.testing.assert_allclose(b[k][1], rows[:, j].std(ddof=1), atol=1e-12)
+
+
+def test_known_answer_vectors():
+    """Hand-computed cases (tests/metrics_known_answers.py): torchmetrics cannot be imported here, so the oracle is also pinned to
+    numbers worked out from the definitions, independent of scikit-learn and of the oracle's own code."""
+    from tests.metrics_known_answers import CASES
+    for name, logits, labels, C, binm, expect in CASES:
+        m = MO.cls_metrics(logits, labels, C, bin_metric=binm)
+        np.testing.assert_allclose([m[k] for k in MO.KEYS], expect, atol=1e-12, err_msg=name)

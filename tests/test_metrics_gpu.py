@@ -105,3 +105,12 @@ def test_validate_loop_matches_oracle_forward_and_metrics():
     ce = torch.nn.functional.cross_entropy(lg, torch.tensor(labels)).item()
     np.testing.assert_allclose(out[2], ce, rtol=2e-4)
     assert list(out[4].keys()) == ["acc", "precision", "recall", "fscore", "auc", "ck", "acc_micro", "loss"]
+
+
+def test_known_answer_vectors_on_device():
+    """The same hand-computed cases through mhimx_cls_metrics (csrc/metrics.hip): exact counts, AUROC as pair counts."""
+    from tests.metrics_known_answers import CASES
+    ops = _ops()
+    for name, logits, labels, C, binm, expect in CASES:
+        got = ops.cls_metrics(torch.from_numpy(logits).to(DEV), torch.from_numpy(labels).to(DEV), C, binm).cpu().numpy()[0]
+        np.testing.assert_allclose(got, expect, atol=1e-6, err_msg=name)

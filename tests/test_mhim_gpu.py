@@ -312,3 +312,17 @@ def test_mm_schedule_under_graph_replay():
     moved = (tr_e.flat.teacher - tea0).abs().max().item()
     gap = (tr_e.flat.student - tea0).abs().max().item()
     assert moved < 0.1 * gap
+
+
+def test_forward_eval_mode_golden():
+    """MHIM.forward with the module in eval mode (the reference's class allows it, mhim.py:318-378): fixture from the reference import."""
+    meta, a = G.load("g16_student_eval_attn")
+    base = synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_k=meta["merge_k"])
+    s = build(base, input_dim=meta["d"], **{k: meta[k] for k in V2}).eval()
+    x = X(meta["xseed"], meta["n"], meta["d"])
+    q0 = s.merge.global_q_mm.detach().clone()
+    logits, cl, ps, keep = s(x, torch.from_numpy(a["teacher_score"]).to(DEV).view(1, -1), torch.from_numpy(a["teacher_feat"]).to(DEV).view(1, -1),
+                             i=0, perm=a["perm"])
+    np.testing.assert_allclose(logits[0].cpu().numpy(), a["logits"], atol=1e-4, rtol=0)
+    assert abs(float(cl) - float(a["cls_loss"])) < 2e-4 and ps == int(a["ps"]) and keep == int(a["keep"])
+    assert torch.equal(q0, s.merge.global_q_mm.detach())             # no EMA of the global queries in eval mode

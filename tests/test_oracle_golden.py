@@ -332,3 +332,15 @@ def test_g13_dsmil():
                 _cfg(meta, baseline="dsmil", merge_enable=False))
     np.testing.assert_allclose(pl[0].numpy(), a["pure_logits_bag"].reshape(-1) if a["pure_logits_bag"].ndim > 1 and "feat" not in "pure_logits_bag" else a["pure_logits_bag"], atol=2e-6, rtol=1e-5)
     np.testing.assert_allclose(pl[1].numpy(), a["pure_logits_ins"].reshape(-1) if a["pure_logits_ins"].ndim > 1 and "feat" not in "pure_logits_ins" else a["pure_logits_ins"], atol=2e-6, rtol=1e-5)
+
+
+def test_g16_student_eval():
+    """MHIM.forward in eval mode (mask applied, Merge keeps every surviving row + k merged tokens, no EMA): reference fixture."""
+    meta, a = G.load("g16_student_eval_attn")
+    base = synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_k=meta["merge_k"])
+    cfg = O.Cfg(**{k: meta[k] for k in V2})
+    x = torch.from_numpy(synth.bag(meta["xseed"], meta["n"], meta["d"]))
+    logits, cl, ps, keep = O.forward_student_eval(x, O.as_torch(base), cfg, a["teacher_score"], torch.from_numpy(a["teacher_feat"]),
+                                                  perm=a["perm"])
+    np.testing.assert_allclose(logits.numpy().ravel(), a["logits"].ravel(), atol=2e-6, rtol=0)
+    assert abs(float(cl) - float(a["cls_loss"])) < 1e-5 and ps == int(a["ps"]) and keep == int(a["keep"])
