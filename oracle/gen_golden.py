@@ -464,10 +464,15 @@ def g15_standalone_transmil(ns):
     for n, act, pseed in ((300, "relu", 47), (441, "gelu", 48), (20, "gelu", 49)):
         x = _x(34 + n, n, d)
         m = _fill_module(ns.transmil.TransMIL(d, 2, dropout=False, act=act), pseed).eval()
-        out = m(x.clone(), return_attn=True)
-        logits, attn = out[0], out[1]
-        loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([1]))
-        loss.backward()
+        # Host-library note: this image's torch-CPU oneDNN path returns a WRONG fp32 weight gradient for the depth-wise 33-tap
+        # res_conv when the padded token count is exactly 256 (taps 17..31 off by up to 5 % against fp64 and against the native ATen
+        # path; 512 and up are right - tools/exp_onednn_conv.py).  Bags of fewer than 256 tokens are therefore run on ATen's own
+        # convolution: same reference code, correct arithmetic.
+        with torch.backends.mkldnn.flags(enabled=n + 1 > 256):
+            out = m(x.clone(), return_attn=True)
+            logits, attn = out[0], out[1]
+            loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([1]))
+            loss.backward()
         _save(f"g15_standalone_transmil_n{n}_{act}", dict(n=n, d=d, xseed=34 + n, pseed=pseed, std=0.05, label=1, act=act,
                                                           keys=list(m.state_dict().keys()),
                                                           shapes=[list(v.shape) for v in m.state_dict().values()]),

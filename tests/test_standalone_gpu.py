@@ -93,6 +93,10 @@ def test_standalone_transmil_fixture(name):
     importing modules/transmil.py: logits, both attention maps, every parameter gradient (eval mode: attention dropouts off)."""
     from mhim_mil_amd.standalone import build_model
     meta, a = G.load(name)
+    _standalone_transmil_case(build_model, meta, a, name, 5e-3)
+
+
+def _standalone_transmil_case(build_model, meta, a, name, grad_rtol):
     m = build_model("transmil", input_dim=meta["d"], n_classes=2, dropout=False, act=meta["act"])
     sd = {k: torch.from_numpy(synth.normal(meta["pseed"], tuple(shape), std=meta["std"], lane=i + 1).astype(np.float32))
           for i, (k, shape) in enumerate(zip(meta["keys"], meta["shapes"]))}
@@ -115,4 +119,4 @@ def test_standalone_transmil_fixture(name):
         g = params[k].grad
         assert g is not None, k
         scale = max(float(np.abs(exp["full"]).max()) if "full" in exp else float(exp["norm"]) / np.sqrt(max(1, g.numel())), 1e-12)
-        G.check_compact(g.cpu().numpy(), exp, rtol=5e-3, atol=max(rel_floor * scale, 1e-7), what=f"{name}:{k}")
+        G.check_compact(g.cpu().numpy(), exp, rtol=grad_rtol, atol=max(rel_floor * scale, 1e-7) * (grad_rtol / 5e-3), what=f"{name}:{k}")
