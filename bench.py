@@ -294,12 +294,12 @@ def main():
             algo = 2 * N_INST * D_IN * 4
             ach = algo / (avg * 1e-3) / 1e9
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
-            # (tools/pmc.sh + tools/pmc_feature.py; counters cannot be read from inside the process being timed)
+            # (tools/pmc.sh + tools/pmc_project.py; counters cannot be read from inside the process being timed)
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_feature_gemm.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_bag_project.json")
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
-                traffic, tsrc = pj["traffic_bytes"], ("profiles/pmc_feature_gemm.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                traffic, tsrc = pj["traffic_bytes"], ("profiles/r02_pmc_bag_project.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
                                                       f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
                                                       f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
             out["roofline"] = {"kernel": "bag_project_kernel (teacher AND student feature projection X[N,D] -> 2 x H[N,512] in one pass over the raw fp32 bag, 3-term bf16 MFMA, fused bias+GELU+dropout, fp16 d out/d pre)",
