@@ -376,6 +376,29 @@ int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int64_t M, int6
  * mhimx_bag_project wrote; colsum_out[e] (+)= sum_p dpre[p,e] (the projection's bias gradient) in the same pass.  ws: 1024*E floats. */
 int mhimx_rows_dpre(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, float* dpre,
                     float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
+/* The same backward with dPre emitted as the MATRIX-CORE IMAGE of its transpose instead of an fp32 matrix (E % 128 == 0): for every
+ * 32-row step ks and 128-column block it, 16 KiB at img + (ks * E/128 + it) * 16384 laid out [row octet 4][hi | lo][slot 128][8 bf16],
+ * slot of column c = (c % 4) * 32 + (c % 128) / 4, value = hi + lo to ~2^-16; rows past L are zero.  mhimx_wgrad_image_bytes(L, E)
+ * bytes.  colsum_out as above (ws: ceil(L/32) * E floats).  Feeds mhimx_bag_wgrad. */
+int64_t mhimx_wgrad_image_bytes(int64_t L, int64_t E);
+int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
+                          float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
+/* The projection's weight gradient (modules/mhim.py:69-76 backward; the last GEMM of the step):
+ *     C[E,D] (+)= dPre[L,E]^T . X[rows ? rows[p] : p][D],   p < L
+ * dPre as the image above, X the raw fp32 bag (split to bf16 hi/lo on its way into LDS, transposed with v_permlane32_swap); 3-term bf16
+ * (~2^-16); the L reduction is split over slabs in ws (mhimx_wgrad_ws_floats(L, E, D) floats), summed by a queued reduction job (defer)
+ * or a second launch.  Needs E % 128 == 0, D % 256 == 0, ldx % 4 == 0 and n_bag_rows * ldx * 4 < 2^32 (row offsets are 32-bit). */
+typedef struct {
+  const void* img;                                       /* mhimx_rows_dpre_image output                                */
+  const float* X; int64_t ldx; int64_t n_bag_rows;       /* the bag [n_bag_rows, D], row pitch ldx                      */
+  const int64_t* rows;                                   /* optional [L] row ids into X                                 */
+  int64_t L, E, D;
+  float* C; int64_t ldc; int32_t accumulate;
+  float* ws; int64_t ws_floats;
+  mhimx_reduce_list* defer;                              /* optional: queue the slab sum                                */
+} mhimx_bag_wgrad_args;
+int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D);
+int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a);
 /* out[e] (+)= sum_m X[m,e] */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);

@@ -47,6 +47,12 @@ class BagProject(C.Structure):
                 ("act", C.c_int32), ("n_heads", C.c_int32), ("head", ProjHead * 2), ("drop_tick", C.c_void_p)]
 
 
+class BagWgrad(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("X", c_f32p), ("ldx", C.c_int64), ("n_bag_rows", C.c_int64), ("rows", C.c_void_p),
+                ("L", C.c_int64), ("E", C.c_int64), ("D", C.c_int64), ("C", c_f32p), ("ldc", C.c_int64), ("accumulate", C.c_int32),
+                ("ws", c_f32p), ("ws_floats", C.c_int64), ("defer", C.c_void_p)]
+
+
 class PrepJob(C.Structure):
     _fields_ = [("kind", C.c_int32), ("inp", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64), ("C", C.c_int64)]
 
@@ -153,6 +159,10 @@ SYMBOLS = {
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "mhimx_rows_dpre": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_rows_dpre_image": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_wgrad_image_bytes": (_I64, [_I64, _I64]),
+    "mhimx_wgrad_ws_floats": (_I64, [_I64, _I64, _I64]),
+    "mhimx_bag_wgrad": (C.c_int, [_P, _P]),
     "mhimx_reduce_flush": (C.c_int, [_P, _P]),
     "mhimx_cls_metrics_ws_bytes": (C.c_int64, [_I64, _I64, _I64]),
     "mhimx_cls_metrics": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I32, _P, _I64, _P, _P, _I64]),

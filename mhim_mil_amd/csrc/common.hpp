@@ -73,6 +73,12 @@ inline mhimx_reduce_job reduce_job_slabs(const float* ws, int64_t splits, int64_
   return j;
 }
 
+// the two final-reduction launches when they are not queued (definitions: rows.hip, gemm.hip) — the one place each kernel is launched from
+// other translation units
+int reduce_parts_now(hipStream_t st, const float* part, int64_t G, int64_t W, int64_t ld, float* out, int accumulate);
+int reduce_slabs_now(hipStream_t st, const float* ws, float* C, int64_t K1, int64_t K2, int64_t ldc, int splits, int accumulate,
+                     int batch = 1, int64_t sC = 0);
+
 // bump allocator over a caller-provided workspace (256-byte granules)
 struct Arena {
   char* base;

@@ -496,6 +496,15 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+int reduce_slabs_now(hipStream_t st, const float* ws, float* C, int64_t K1, int64_t K2, int64_t ldc, int splits, int accumulate, int batch,
+                     int64_t sC) {
+  const int64_t n = K1 * K2;
+  const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, ws, C, K1, K2, ldc, splits, accumulate, sC);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int PREC>
 static int launch_tn(hipStream_t st, const mhimx_gemm_tn_args& g, int batch = 1, Batch bt = Batch{0, 0, 0, 1}) {
   using PP = Prec<PREC>;
@@ -506,13 +515,7 @@ static int launch_tn(hipStream_t st, const mhimx_gemm_tn_args& g, int batch = 1,
   dim3 grid((unsigned)cdiv(g.K2, BN), (unsigned)cdiv(g.K1, BM), (unsigned)(splits * batch));
   hipLaunchKernelGGL(gemm_tn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, mchunk, bt);
   MHIMX_LAUNCH_CHECK();
-  if (splits > 1) {
-    const int64_t n = g.K1 * g.K2;
-    const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, splits, g.accumulate,
-                       bt.sC);
-    MHIMX_LAUNCH_CHECK();
-  }
+  if (splits > 1) return reduce_slabs_now(st, g.ws, g.C, g.K1, g.K2, g.ldc, splits, g.accumulate, batch, bt.sC);
   return 0;
 }
 
@@ -530,12 +533,8 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
     const int used = gemm_tn_dma(st, g, avail);
     if (used == -2) goto generic;         // reduction too long for the LDS row table with this much workspace
     if (used < 0) return used;
-    if (used > 1 && !defer_push(g.defer, reduce_job_slabs(g.ws, used, g.K1, g.K2, g.ldc, g.C, g.accumulate))) {
-      const int64_t n = g.K1 * g.K2;
-      const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.K1, g.K2, g.ldc, used, g.accumulate);
-      MHIMX_LAUNCH_CHECK();
-    }
+    if (used > 1 && !defer_push(g.defer, reduce_job_slabs(g.ws, used, g.K1, g.K2, g.ldc, g.C, g.accumulate)))
+      return reduce_slabs_now(st, g.ws, g.C, g.K1, g.K2, g.ldc, used, g.accumulate);
     return 0;
   }
 generic:
@@ -546,9 +545,6 @@ generic:
     default: return fail(-1, "gemm_tn: unknown prec %d", g.prec);
   }
 }
-
-__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2, int64_t ldc,
-                                    int splits, int accumulate, int64_t sC);
 
 // =================================================================================================
 // gemm_nn : C[M,N] = A[M,K] . B[K,N]   (B row-major [K,N]: the k-strided operand is staged like gemm_tn's)
@@ -646,12 +642,7 @@ static int launch_nn(hipStream_t st, const mhimx_gemm_nt_args& g, float alpha, i
   dim3 grid((unsigned)cdiv(g.N, BN), (unsigned)cdiv(g.M, BM), (unsigned)(splits * batch));
   hipLaunchKernelGGL(gemm_nn_kernel<PREC>, grid, dim3(NTHREADS), smem, st, g, alpha, kchunk, splits > 1 ? ws : (float*)nullptr, bt);
   MHIMX_LAUNCH_CHECK();
-  if (splits > 1) {
-    const int64_t n = g.M * g.N;
-    const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, ws, g.C, g.M, g.N, g.ldc, splits, g.accumulate, bt.sC);
-    MHIMX_LAUNCH_CHECK();
-  }
+  if (splits > 1) return reduce_slabs_now(st, ws, g.C, g.M, g.N, g.ldc, splits, g.accumulate, batch, bt.sC);
   return 0;
 }
 
@@ -748,10 +739,8 @@ int gemm_batched(hipStream_t st, int mode, const mhimx_gemm_nt_args& g, int batc
                          nchunks > 1 ? ws : t.C, nchunks > 1 ? t.K2 : t.ldc, nchunks > 1 ? 1 : 0);
       MHIMX_LAUNCH_CHECK();
       if (nchunks > 1) {
-        const int64_t n = t.K1 * t.K2;
-        const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ws, t.C, t.K1, t.K2, t.ldc, nchunks, t.accumulate, (int64_t)0);
-        MHIMX_LAUNCH_CHECK();
+        const int rc = reduce_slabs_now(st, ws, t.C, t.K1, t.K2, t.ldc, nchunks, t.accumulate);
+        if (rc) return rc;
       }
       return 0;
     }

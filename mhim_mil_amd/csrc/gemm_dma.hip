@@ -648,9 +648,6 @@ bool nt_dma_ok(const mhimx_gemm_nt_args& g) {
 #ifndef MHIMX_NT_WAVES
 #define MHIMX_NT_WAVES 8
 #endif
-__global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t K1, int64_t K2, int64_t ldc,
-                                    int splits, int accumulate, int64_t sC);
-
 int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
   constexpr int NW = MHIMX_NT_WAVES;
   dim3 grid((unsigned)(8 * cdiv(g.N, DBN) * cdiv(cdiv(g.M, DBM), 8)));
@@ -674,11 +671,7 @@ int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g) {
     hipStream_t st; const mhimx_gemm_nt_args& g; int ksplit;
     int run() const {
       if (ksplit <= 1) return 0;
-      const int64_t n = g.M * g.N;
-      const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, g.ws, g.C, g.M, g.N, g.ldc, ksplit, g.accumulate, (int64_t)0);
-      MHIMX_LAUNCH_CHECK();
-      return 0;
+      return reduce_slabs_now(st, g.ws, g.C, g.M, g.N, g.ldc, ksplit, g.accumulate);
     }
   } reduce{st, g, ksplit};
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_BF16X3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES)); MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MHIMX_PREC_F16S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES)));

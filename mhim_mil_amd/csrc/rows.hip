@@ -271,6 +271,12 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
   }
 }
 
+int reduce_parts_now(hipStream_t st, const float* part, int64_t G, int64_t W, int64_t ld, float* out, int accumulate) {
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(W, 32)), dim3(RP_THREADS), 0, st, part, (int)G, (int)W, (int)ld, out, accumulate);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 // every queued final reduction of a step in one launch (mhimx_reduce_flush): job jb owns blocks [first[jb], first[jb+1]).
 // Same arithmetic as reduce_parts_kernel (kind 0) and reduce_slabs_kernel (kind 1): queued or not, the bits are the same.
 struct ReduceJobs { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int first[MHIMX_REDUCE_MAX + 1]; int n; int side_blocks; Merge2Side side; };

@@ -1,0 +1,443 @@
+// wgrad.hip — the weight gradient of the bag projection,  dW1[E,D] = dPRE[L,E]^T . X[rows[0..L)][D]   (mhim.py:69-76 backward),
+// as two launches that share one operand format:
+//
+//   rows_dpre_image : dPRE[p,:] = dH[rows[p],:] * dact16[rows[p],:]  (activation + dropout backward of the rows that took part),
+//                     its column sums (the bias gradient) and — instead of an fp32 [L,E] matrix — the MATRIX-CORE IMAGE of dPRE^T:
+//                     per 32-row k-step and 128-column block one contiguous 16 KiB tile [k-octet 4][hi|lo 2][column slot 128][8 bf16].
+//   bag_wgrad       : the TN product on v_mfma_f32_16x16x32_bf16, 3-term bf16 (hi*hi + hi*lo + lo*hi), split over the L reduction.
+//
+// Why: the generic TN kernel (gemm_dma.hip) keeps both operands fp32 in LDS, reads every k-contiguous fragment as 8 strided
+// ds_read_b32 and splits it to bf16 hi/lo in EVERY consuming wave (~400 VALU per 24 MFMAs: the loop is VALU-bound, 50 us).
+// Here the fp32 -> bf16 hi/lo split happens once per element: dPRE's inside the elementwise kernel that makes it (and lays
+// it out k-contiguous, so the TN product needs no transposing read at all), X's on the way into LDS —
+//   * X (raw fp32, gathered by row id) goes through registers: a wave loads 8 rows x 512 B (lanes 0-31: rows 0-3 of its octet,
+//     lanes 32-63: rows 4-7, 16 B per lane, full 512-B segments), v_permlane32_swap gives every lane the 8 k-consecutive values of
+//     two columns, which are split and written as two ds_write_b128 (hi, lo) per column: the transposition costs 8 swaps.
+//   * LDS images are [k-octet][hi|lo][column slot][16 B]: the 16 lanes of a fragment read and the 32 lanes of a half-wave write hit
+//     consecutive 16-byte slots — no bank conflicts, no swizzle.  The column slot of column c is (c % 4) * (cols/4) + c / 4, i.e. an
+//     MFMA tile covers every 4th column: the four tiles of a lane are four CONSECUTIVE output columns (one 16-byte store each).
+//   * dPRE^T tiles go L2 -> LDS by direct DMA, 16 KiB linear per k-step.
+//   * workgroup tile 128 (E) x 256 (D), 8 waves as 2 x 4, 64 x 64 per wave = 48 MFMAs against 16 ds_read_b128 per k-step;
+//     one s_barrier per k-step; the schedule of bag_project.hip (MFMAs of tile t-1 under the reads of tile t).  Both operands are
+//     requested THREE k-steps ahead (144 KB in flight per CU: at ~2 us of loaded-memory latency two tiles ahead starve the ~70 KB/us a
+//     CU can ingest): the image in a 5-deep LDS ring, X in three rotating register sets in front of a 2-deep LDS ring.
+//   * 16 reduction slabs x 16 output tiles = 256 workgroups (one per CU); the tiles of a slab run on ONE XCD (its X rows and dPRE
+//     tiles are shared through that L2); the slab sum is a job of the step's deferred reduction launch, as before.
+#include <string.h>
+
+#include "mma_tile.hpp"
+#include "mca2_side.hpp"
+
+namespace mhimx {
+
+constexpr int WBI = 128, WBN = 256, WBK = 32, WTHREADS = 512;
+constexpr int WA_BYTES = WBI * 128, WB_BYTES = WBN * 128;                                         // 16 KiB, 32 KiB per k-step
+constexpr int WNA = 5, WNB = 2;                      // ring depths: dPRE^T image tiles (DMA, three tiles ahead), X tiles (through registers)
+constexpr int WRING = WNA * WA_BYTES + WNB * WB_BYTES;                                            // 144 KiB
+constexpr int W_MAX_CHUNK = 3072;                                                                 // rows of one slab (row table: 12 KiB)
+constexpr int WNF = 16;                              // fragments of a k-step: x[0..3] A hi, x[4..7] A lo, x[8..11] B hi, x[12..15] B lo
+
+// four 16-row blocks of the E-side operand (512 B apart) into x[oa..oa+3], four of the D-side operand (1 KiB apart) into x[ob..ob+3]
+#define WG_READ8(x, oa, ob, a, b)                                                                                       \
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:512\n\tds_read_b128 %2, %8 offset:1024\n\t"           \
+               "ds_read_b128 %3, %8 offset:1536\n\t"                                                                    \
+               "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\tds_read_b128 %6, %9 offset:2048\n\t"          \
+               "ds_read_b128 %7, %9 offset:3072"                                                                        \
+               : "=&v"(x[oa]), "=&v"(x[oa + 1]), "=&v"(x[oa + 2]), "=&v"(x[oa + 3]), "=&v"(x[ob]), "=&v"(x[ob + 1]),       \
+                 "=&v"(x[ob + 2]), "=&v"(x[ob + 3])                                                                      \
+               : "v"(a), "v"(b)                                                                                         \
+               : "memory")
+#define WG_WAIT8(n, x, oa, ob)                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                              \
+               : "+v"(x[oa]), "+v"(x[oa + 1]), "+v"(x[oa + 2]), "+v"(x[oa + 3]), "+v"(x[ob]), "+v"(x[ob + 1]),             \
+                 "+v"(x[ob + 2]), "+v"(x[ob + 3])                                                                        \
+               :                                                                                                        \
+               : "memory")
+
+MHIMX_DEV void wg_term(const f32x4 (&x)[WNF], int oa, int ob, f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = mt_mfma(x[oa + i], x[ob + j], acc[i][j]);
+}
+
+// a's lanes 32..63 <-> b's lanes 0..31.  Inline asm: this compiler's __builtin_amdgcn_permlane32_swap drops the second result (both
+// elements of the returned pair read back as the first operand).  The s_nop covers the VALU-write -> permlane-swap hazard the
+// assembler does not see inside an asm block.
+MHIMX_DEV void wg_swap(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+MHIMX_DEV void wg_split8(const float (&v)[8], f32x4& hi_o, f32x4& lo_o) {
+  bf8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const __bf16 h = (__bf16)v[q];
+    hi[q] = h;
+    lo[q] = (__bf16)(v[q] - (float)h);
+  }
+  hi_o = __builtin_bit_cast(f32x4, hi);
+  lo_o = __builtin_bit_cast(f32x4, lo);
+}
+
+struct WgradArgs {
+  const char* img;            // dPRE^T image (rows_dpre_image)
+  const float* X;
+  int64_t ldx;
+  const int64_t* rows;        // [L] row ids into X, or null
+  int64_t L, E, D;
+  int ksteps, kps, splits;    // k-steps in all, per slab, slabs
+  float* out;                 // slabs [splits][E][D]
+};
+
+__global__ __launch_bounds__(WTHREADS) void bag_wgrad_kernel(WgradArgs g, int side_blocks, Merge2Side side) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2, 256 of the 512 threads): its few
+    if (threadIdx.x < M2_THREADS) merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);   // short workgroups go first
+    return;
+  }
+  const unsigned bx = blockIdx.x - (unsigned)side_blocks;      // (side_blocks % 8 == 0: the XCD of a tile does not move)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nJ = (int)(g.D / WBN), nIT = (int)(g.E / WBI), nT = nIT * nJ;
+  const int xcd = bx & 7, sidx = bx >> 3;
+  const int slab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
+  if (slab >= g.splits) return;
+  const int itile = tile / nJ;
+  const int64_t i0 = (int64_t)itile * WBI, n0 = (int64_t)(tile % nJ) * WBN;
+  const int ks0 = slab * g.kps;
+  const int nk = (ks0 + g.kps < g.ksteps ? ks0 + g.kps : g.ksteps) - ks0;       // >= 1 by the host's choice of splits
+
+  // byte offsets of this slab's X rows (a bag is < 4 GiB); rows past L repeat the last one (their dPRE image rows are zero)
+  unsigned* rowtab = reinterpret_cast<unsigned*>(smem + WRING);
+
+  // ---- X: wave -> (row octet o of the k-step, column half ch); lane -> (rows 4 half .. 4 half + 3 of the octet, columns 4c .. 4c+3)
+  const int oct = wave & 3, ch = wave >> 2, half = lane >> 5, c = lane & 31;
+  const unsigned colb = (unsigned)((n0 + ch * 128 + 4 * c) * 4);
+  const unsigned rt_lds = (unsigned)(uintptr_t)(lptr_f)rowtab + (unsigned)((oct * 8 + half * 4) * 4);    // + t * 128
+  struct XRegs { f32x4 v[4]; };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto load_x_async = [&](const u32x4& ro, XRegs& r) {
+    asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\t"
+                 "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"
+                 : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3])
+                 : "v"(ro[0] + colb), "v"(ro[1] + colb), "v"(ro[2] + colb), "v"(ro[3] + colb), "s"(g.X)
+                 : "memory");
+  };
+  // LDS slot of this lane's two columns after the half-wave swap: column 4c + j, j = s + 2 half (s = 0, 1) -> slot j * 64 + ch * 32 + c
+  const unsigned xs0 = (unsigned)(WNA * WA_BYTES + ((oct * 2) * 256 + (2 * half) * 64 + ch * 32 + c) * 16);
+  auto store_x = [&](int t, XRegs& r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a0 = r.v[q][0], a1 = r.v[q][1], a2 = r.v[q][2], a3 = r.v[q][3];
+      wg_swap(a0, a2);
+      wg_swap(a1, a3);
+      r.v[q] = f32x4{a0, a1, a2, a3};
+    }
+    char* sb = smem + (t % WNB) * WB_BYTES + xs0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float kv[8] = {r.v[0][s], r.v[1][s], r.v[2][s], r.v[3][s], r.v[0][s + 2], r.v[1][s + 2], r.v[2][s + 2], r.v[3][s + 2]};
+      f32x4 hi, lo;
+      wg_split8(kv, hi, lo);
+      *reinterpret_cast<f32x4*>(sb + s * 1024) = hi;
+      *reinterpret_cast<f32x4*>(sb + s * 1024 + 4096) = lo;
+    }
+  };
+  // ---- dPRE^T image tiles by DMA: 16 KiB linear, 2 x 16 B per thread.  `live` false: the pieces come from ONE address (a stage nobody
+  // reads any more) so that every iteration has the same VMEM count and the hand-written vmcnt waits need no branch.
+  const char* abase = g.img + ((int64_t)ks0 * nIT + itile) * WA_BYTES + tid * 16;
+  auto issue_a = [&](int t, bool live) {
+    char* sa = smem + (t % WNA) * WA_BYTES + wave * 1024;
+    const char* src = live ? abase + (int64_t)t * nIT * WA_BYTES : g.img;
+    __builtin_amdgcn_global_load_lds((gptr_f)src, (lptr_f)sa, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_f)(live ? src + 8192 : src), (lptr_f)(sa + 8192), 16, 0, 0);
+  };
+
+  issue_a(0, true);                                           // (before the row table: it does not depend on it)
+  for (int q = tid; q < nk * WBK; q += WTHREADS) {
+    int64_t l = (int64_t)ks0 * WBK + q;
+    if (l >= g.L) l = g.L - 1;
+    rowtab[q] = (unsigned)((g.rows ? g.rows[l] : l) * g.ldx * 4);
+  }
+  __syncthreads();
+  // fragment addresses (stage 0): slot r = lane & 15 of a 16-slot block, k-octet kg = lane >> 4
+  const int r16 = lane & 15, kg = lane >> 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+  const unsigned fa_hi = lds0 + ((kg * 2) * 128 + 16 * wm + r16) * 16, fa_lo = fa_hi + 2048;
+  const unsigned fb_hi = lds0 + WNA * WA_BYTES + ((kg * 2) * 256 + 16 * wn + r16) * 16, fb_lo = fb_hi + 4096;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: image tile 0, X(0) -> stage 0 (plain loads: the compiler's wait drains both); then, in the loop's own order,
+  // {X(1), image 1}, {X(2), image 2} in flight; row offsets of tile 3 in registers
+  XRegs rg0, rg1, rg2;
+  auto row_offsets = [&](int t) { return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(rowtab) + (oct * 8 + half * 4) * 4 + (t < nk ? t : nk - 1) * 128); };
+  {
+    const u32x4 r0o = row_offsets(0);
+    XRegs r0;
+    const char* xb = reinterpret_cast<const char*>(g.X);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r0.v[q] = *reinterpret_cast<const f32x4*>(xb + r0o[q] + colb);
+    store_x(0, r0);
+  }
+  load_x_async(row_offsets(1), rg1);
+  issue_a(1, nk > 1);
+  load_x_async(row_offsets(2), rg2);
+  issue_a(2, nk > 2);
+  u32x4 ro = row_offsets(3);
+
+  f32x4 x[WNF];
+#ifdef WG_NOREAD
+  for (int q = 0; q < WNF; ++q) x[q] = f32x4{1.f, 2.f, 3.f, 4.f};
+#endif
+  // Iteration t:  [barrier: tile t complete in its stages]  X(t+3) loads -> the free register set, image DMA(t+3) -> stage (t+3)%5
+  // (tile t-2's: every wave is past its reads); reads g1 = {A lo, B hi}; row offsets of tile t+4; 16 MFMAs hi*lo of tile t-1 (operands
+  // still in registers); reads g2 = {A hi, B lo}; 16 MFMAs lo*hi; wait until only the last two iterations' 12 VMEM operations are in
+  // flight (X(t+1) is in its registers, image t+1 has landed); 16 MFMAs hi*hi with the swap / split / LDS stores of X(t+1) into stage
+  // (t+1)%2 (tile t-1's) in their shadow.
+  auto body = [&](int t, XRegs& r_load, XRegs& r_use) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ro) : : "memory");       // my X(t) stores are done; the row offsets are here
+    __builtin_amdgcn_s_barrier();
+    const unsigned soa = (unsigned)((t % WNA) * WA_BYTES), sob = (unsigned)((t % WNB) * WB_BYTES);
+#ifndef WG_NOX
+    load_x_async(ro, r_load);
+#endif
+#ifndef WG_NODMA
+    issue_a(t + 3, t + 3 < nk);
+#endif
+#ifndef WG_NOREAD
+    WG_READ8(x, 4, 8, fa_lo + soa, fb_hi + sob);
+#endif
+    {
+      const unsigned ra = rt_lds + (unsigned)((t + 4 < nk ? t + 4 : nk - 1) * 128);
+      asm volatile("ds_read_b128 %0, %1" : "=&v"(ro) : "v"(ra) : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WG_NOMMA
+    if (t > 0) wg_term(x, 0, 12, acc);                        // hi*lo of tile t-1
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WG_NOREAD
+    WG_WAIT8(0, x, 4, 8);
+    WG_READ8(x, 0, 12, fa_hi + soa, fb_lo + sob);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WG_NOMMA
+    wg_term(x, 4, 8, acc);                                    // lo*hi
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WG_NOREAD
+    WG_WAIT8(0, x, 0, 12);
+#endif
+#if defined(WG_NOX) && defined(WG_NODMA)
+#elif defined(WG_NOX)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#elif defined(WG_NODMA)
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(r_use.v[0]), "+v"(r_use.v[1]), "+v"(r_use.v[2]), "+v"(r_use.v[3]) : : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(r_use.v[0]), "+v"(r_use.v[1]), "+v"(r_use.v[2]), "+v"(r_use.v[3]) : : "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WG_NOMMA
+    wg_term(x, 0, 8, acc);                                    // hi*hi
+#endif
+#if !defined(WG_NOX) && !defined(WG_NOSTORE)
+    if (t + 1 < nk) store_x(t + 1, r_use);
+#endif
+#if !defined(WG_NOINTERLEAVE) && !defined(WG_NOMMA) && !defined(WG_NOX) && !defined(WG_NOSTORE)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // four VALU
+      if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // a DS write
+    }
+#endif
+  };
+  int t = 0;
+#pragma unroll 1
+  for (; t + 2 < nk; t += 3) {
+    body(t, rg0, rg1);
+    body(t + 1, rg1, rg2);
+    body(t + 2, rg2, rg0);
+  }
+  if (t < nk) body(t, rg0, rg1);
+  if (t + 1 < nk) body(t + 1, rg1, rg2);
+#ifndef WG_NOMMA
+  wg_term(x, 0, 12, acc);                                     // hi*lo of the last tile
+#endif
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+               : "+v"(rg0.v[0]), "+v"(rg0.v[1]), "+v"(rg0.v[2]), "+v"(rg0.v[3]), "+v"(rg1.v[0]), "+v"(rg1.v[1]), "+v"(rg1.v[2]), "+v"(rg1.v[3]),
+                 "+v"(rg2.v[0]), "+v"(rg2.v[1]), "+v"(rg2.v[2]), "+v"(rg2.v[3]), "+v"(ro)
+               :
+               : "memory");
+
+#ifdef WG_NOEPI
+  {
+    float sacc = 0.f;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc != 1.2345e-30f) return;
+  }
+#endif
+  // ---- epilogue: tile (ja, jb) of a lane is row 4 (16 wm + 4 (lane >> 4) + e) + ja, column 4 (16 wn + (lane & 15)) + jb: 16-byte stores
+  float* out = g.out + (int64_t)slab * g.E * g.D;
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i0 + 4 * (16 * wm + 4 * kg + e) + ja;
+      const int64_t n = n0 + 4 * (16 * wn + r16);
+      *reinterpret_cast<f32x4*>(out + i * g.D + n) = f32x4{acc[ja][0][e], acc[ja][1][e], acc[ja][2][e], acc[ja][3][e]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dPRE -> matrix-core image + column-sum partials.  One workgroup per (32-row k-step, 256 columns); thread -> (4 columns, one row
+// octet): 8 x (16 B of dH + 8 B of dact16) in flight per thread, ~10 waves per CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __restrict__ dH, const _Float16* __restrict__ dact,
+                                                             const int64_t* __restrict__ rows, int64_t L, int E, char* __restrict__ img,
+                                                             float* __restrict__ part, int side_blocks, Merge2Side side) {
+  __shared__ __attribute__((aligned(16))) float lds[M2_PARTIALS_LDS > 3 * 256 * 4 ? M2_PARTIALS_LDS : 3 * 256 * 4];
+  if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 1), its workgroups first
+    merge2_side_stage(1, (int)blockIdx.x, lds, side);
+    return;
+  }
+  typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+  const int nCB = E / 256 > 0 ? (E + 255) / 256 : 1;            // column blocks of 256 (E % 128 == 0: the last one may be half)
+  const int bid = (int)blockIdx.x - side_blocks;
+  const int ks = bid / nCB, cb = bid % nCB;
+  const int nIT = E / WBI;
+  const int tid = threadIdx.x, koct = tid >> 6, cq = cb * 64 + (tid & 63);      // columns 4 cq .. 4 cq + 3
+  const bool live = cq < E / 4;
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const int itile = cq >> 5, cl = cq & 31;                    // slots j * 32 + cl of tile itile
+    int64_t r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t l = (int64_t)ks * WBK + koct * 8 + q;
+      r[q] = l < L ? (rows ? rows[l] : l) : -1;
+    }
+    f32x4 gv[8];
+    h4v dv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t rr = r[q] < 0 ? 0 : r[q];
+      gv[q] = reinterpret_cast<const f32x4*>(dH + rr * E)[cq];
+      dv[q] = reinterpret_cast<const h4v*>(dact + rr * E)[cq];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      gv[q] = r[q] < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : gv[q] * f32x4{(float)dv[q][0], (float)dv[q][1], (float)dv[q][2], (float)dv[q][3]};
+      cs += gv[q];
+    }
+    char* tile = img + ((int64_t)ks * nIT + itile) * WA_BYTES + (koct * 2 * 128 + cl) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float kv[8] = {gv[0][j], gv[1][j], gv[2][j], gv[3][j], gv[4][j], gv[5][j], gv[6][j], gv[7][j]};
+      f32x4 hi, lo;
+      wg_split8(kv, hi, lo);
+      *reinterpret_cast<f32x4*>(tile + j * 512) = hi;
+      *reinterpret_cast<f32x4*>(tile + j * 512 + 2048) = lo;
+    }
+  }
+  if (part) {                                                   // the four octets' column sums -> one partial row per k-step
+    if (koct > 0) reinterpret_cast<f32x4*>(lds)[(koct - 1) * 64 + (tid & 63)] = cs;
+    __syncthreads();
+    if (koct == 0 && live) {
+      const f32x4* o = reinterpret_cast<const f32x4*>(lds) + (tid & 63);
+      cs = (cs + o[0]) + (o[64] + o[128]);
+      reinterpret_cast<f32x4*>(part + (int64_t)ks * E)[cq] = cs;
+    }
+  }
+}
+
+static bool wgrad_shape_ok(int64_t L, int64_t E, int64_t D, int64_t ldx, int64_t n_bag_rows) {
+  return L >= 1 && E >= WBI && E % WBI == 0 && D >= WBN && D % WBN == 0 && ldx % 4 == 0 && ldx >= D &&
+         n_bag_rows * ldx * 4 < ((int64_t)1 << 32);
+}
+
+}  // namespace mhimx
+
+using namespace mhimx;
+
+extern "C" int64_t mhimx_wgrad_image_bytes(int64_t L, int64_t E) { return cdiv(L, WBK) * WBK * E * 4; }
+
+// slabs the product will use for L rows, and the workspace (floats) they take
+static int wgrad_plan(int64_t L, int64_t E, int64_t D, int* kps_out) {
+  const int ksteps = (int)cdiv(L, WBK);
+  const int64_t tiles = (E / WBI) * (D / WBN);
+  int64_t want = cdiv(256, tiles);                            // one workgroup per CU
+  if (want > cdiv(ksteps, 4)) want = cdiv(ksteps, 4);         // at least 4 k-steps each
+  if (want < 1) want = 1;
+  int kps = (int)cdiv(ksteps, want);
+  if (kps * WBK > W_MAX_CHUNK) kps = W_MAX_CHUNK / WBK;
+  *kps_out = kps;
+  return (int)cdiv(ksteps, kps);
+}
+extern "C" int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D) {
+  int kps;
+  return (int64_t)wgrad_plan(L, E, D, &kps) * E * D;
+}
+
+extern "C" int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
+                                     float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
+  MHIMX_CHECK_ARG(dH && dact16 && img && L >= 1 && E >= WBI && E % WBI == 0 && aligned16(dH) && aligned16(img) &&
+                      (reinterpret_cast<uintptr_t>(dact16) & 7) == 0,
+                  "rows_dpre_image: E must be a multiple of 128, buffers aligned");
+  const int64_t ksteps = cdiv(L, WBK), nblk = ksteps, ncb = cdiv(E, 256);
+  MHIMX_CHECK_ARG(!colsum_out || (ws && ws_bytes >= nblk * E * 4), "rows_dpre_image: workspace too small (%lld bytes)", (long long)(nblk * E * 4));
+  Merge2Side side = {};
+  int side_blocks = 0;
+  if (defer && defer->side.pending == 1) {       // a parked Merge-backward tail: stage 1 rides in this launch
+    memcpy(&side, defer->side.blob, sizeof(side));
+    side_blocks = merge2_side_blocks(1, side);
+    defer->side.pending = 2;
+  }
+  hipLaunchKernelGGL(rows_dpre_image_kernel, dim3((unsigned)(ksteps * ncb + side_blocks)), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16,
+                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side);
+  MHIMX_LAUNCH_CHECK();
+  if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
+    const int rc = reduce_parts_now((hipStream_t)stream, (const float*)ws, nblk, E, E, colsum_out, accumulate);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
+  if (!a) return fail(-1, "bag_wgrad: null argument block");
+  MHIMX_CHECK_ARG(a->img && a->X && a->C && a->ws && aligned16(a->img) && aligned16(a->X) && aligned16(a->C) && aligned16(a->ws) && a->ldc % 4 == 0,
+                  "bag_wgrad: null / unaligned operand");
+  MHIMX_CHECK_ARG(wgrad_shape_ok(a->L, a->E, a->D, a->ldx, a->n_bag_rows),
+                  "bag_wgrad: needs E %% 128 == 0, D %% 256 == 0, 16-byte aligned rows and a bag below 4 GiB");
+  WgradArgs g;
+  g.img = (const char*)a->img; g.X = a->X; g.ldx = a->ldx; g.rows = a->rows; g.L = a->L; g.E = a->E; g.D = a->D;
+  g.ksteps = (int)cdiv(a->L, WBK);
+  g.splits = wgrad_plan(a->L, a->E, a->D, &g.kps);
+  MHIMX_CHECK_ARG(a->ws_floats >= (int64_t)g.splits * a->E * a->D, "bag_wgrad: workspace too small (%lld floats)", (long long)((int64_t)g.splits * a->E * a->D));
+  g.out = a->ws;
+  const size_t smem = WRING + (size_t)g.kps * WBK * 4;
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WRING + W_MAX_CHUNK * 4)));
+  Merge2Side side = {};
+  int side_blocks = 0;
+  mhimx_reduce_list* defer = a->defer;
+  if (defer && defer->side.pending == 2 && smem >= M2_SIDE_LDS * sizeof(float)) {
+    memcpy(&side, defer->side.blob, sizeof(side));           // a parked Merge-backward tail: stage 2 rides in this launch
+    side_blocks = merge2_side_blocks(2, side);
+    if (side_blocks % 8 == 0) defer->side.pending = 3;
+    else side_blocks = 0;
+  }
+  const int64_t tiles = (a->E / WBI) * (a->D / WBN);
+  dim3 grid((unsigned)(8 * tiles * cdiv(g.splits, 8) + side_blocks));
+  hipLaunchKernelGGL(bag_wgrad_kernel, grid, dim3(WTHREADS), smem, (hipStream_t)stream, g, side_blocks, side);
+  MHIMX_LAUNCH_CHECK();
+  if (!defer_push(defer, reduce_job_slabs(a->ws, g.splits, a->E, a->D, a->ldc, a->C, a->accumulate))) {
+    const int rc = reduce_slabs_now((hipStream_t)stream, a->ws, a->C, a->E, a->D, a->ldc, g.splits, a->accumulate);
+    if (rc) return rc;
+  }
+  return 0;
+}

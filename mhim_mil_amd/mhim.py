@@ -572,9 +572,13 @@ class MHIM(nn.Module):
             mid_hook()
         Lr = plan.L
         rows = None if rows_all is None else rows_all[:Lr]
-        dpre, db1 = ops.rows_dpre(dHbuf, saved["DACT"], rows, Lr, colsum_out=out.get("feature.0.bias"), defer=defer)
-        grads["feature.0.weight"] = ops.gemm_tn(dpre, x, out=out.get("feature.0.weight"), rows=rows, splits=8 if Lr >= 2048 else 1,
-                                                prec="bf16x3", M=Lr, defer=defer)
+        if ops.bag_wgrad_ok(x, dHbuf.shape[1], Lr):
+            grads["feature.0.weight"], db1 = ops.bag_wgrad(dHbuf, saved["DACT"], x, rows, Lr, out_w=out.get("feature.0.weight"),
+                                                           out_b=out.get("feature.0.bias"), defer=defer)
+        else:
+            dpre, db1 = ops.rows_dpre(dHbuf, saved["DACT"], rows, Lr, colsum_out=out.get("feature.0.bias"), defer=defer)
+            grads["feature.0.weight"] = ops.gemm_tn(dpre, x, out=out.get("feature.0.weight"), rows=rows, splits=8 if Lr >= 2048 else 1,
+                                                    prec="bf16x3", M=Lr, defer=defer)
         grads["feature.0.bias"] = db1
         return grads
 

@@ -1,0 +1,56 @@
+"""Timing of the projection's weight gradient at c2 size: the two kernels of the dedicated pair (wgrad.hip) and the generic pair."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from mhim_mil_amd import _lib as L
+from mhim_mil_amd import ops
+
+N, L_, E, D = 10000, 9705, 512, 1024
+torch.manual_seed(0)
+x = torch.randn(N, D, device="cuda").abs()
+dH = torch.randn(N + 6, E, device="cuda") * 1e-3
+dact = torch.randn(N + 6, E, device="cuda").half()
+rows = torch.randperm(N, device="cuda")[:L_].sort().values
+ow, ob = torch.empty(E, D, device="cuda"), torch.empty(E, device="cuda")
+lib = L.lib()
+img = torch.empty(lib.mhimx_wgrad_image_bytes(L_, E) // 4, device="cuda")
+ws_b = torch.empty(2 * -(-L_ // 32) * E, device="cuda")
+ws = torch.empty(lib.mhimx_wgrad_ws_floats(L_, E, D), device="cuda")
+g = L.BagWgrad(img=img.data_ptr(), X=x.data_ptr(), ldx=D, n_bag_rows=N, rows=rows.data_ptr(), L=L_, E=E, D=D, C=ow.data_ptr(), ldc=D,
+               accumulate=0, ws=ws.data_ptr(), ws_floats=ws.numel(), defer=None)
+lst = ops.ReduceList()                       # queue the final reductions (never flushed: the kernels alone are timed)
+
+
+def image():
+    lst.c.n = 0
+    L.check(lib.mhimx_rows_dpre_image(None, dH.data_ptr(), dact.data_ptr(), rows.data_ptr(), L_, E, img.data_ptr(), ob.data_ptr(), 0,
+                                      ws_b.data_ptr(), ws_b.numel() * 4, lst.ptr()), "image")
+
+
+def wgrad():
+    lst.c.n = 0
+    g.defer = lst.ptr()
+    L.check(lib.mhimx_bag_wgrad(None, C.byref(g)), "wgrad")
+
+
+def old():
+    dpre, _ = ops.rows_dpre(dH, dact, rows, L_, colsum_out=ob)
+    ops.gemm_tn(dpre, x, out=ow, rows=rows, splits=8, prec="bf16x3", M=L_)
+
+
+which = sys.argv[1:] or ["image", "wgrad", "old", "image", "wgrad"]
+for name in which:
+    fn = {"image": image, "wgrad": wgrad, "old": old}[name]
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    print("%-6s %.1f us per call (back-to-back launches)" % (name, e0.elapsed_time(e1) * 1e3 / 100))
