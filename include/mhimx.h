@@ -208,6 +208,10 @@ typedef struct {
                                          goes to dT1[rows1[n]] - the student reads the kept rows and the merged tokens straight out of the
                                          bag's feature buffer [N + k, E] (masking.py:107 mask_fn and merge.py:190-194 without any copy).
                                          One-pass scorer shapes only (E = 512, A = 128, plain form). */
+  const uint8_t* excl;                /* optional, indexed by SOURCE row (rows1[n] or n) of segment 1: non-zero = the row does not take part
+                                         (its score is written as -inf: softmax weight 0, zero gradient in the backward).  Lets a shard of an
+                                         instance-sharded bag run the pool over ALL its rows with fixed launch shapes (no data-dependent
+                                         counts, no host sync).  One-pass scorer shapes only. */
 } mhimx_pool_io;
 int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
 int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io);
@@ -399,6 +403,16 @@ typedef struct {
 } mhimx_bag_wgrad_args;
 int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D);
 int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a);
+/* Instance-sharded bags: a shard holds bag rows [lo, lo + n).  The student's row lists are replicated
+ * (every rank runs the same select); these three turn them into fixed-shape local work, with no data-dependent count on the host:
+ *   shard_flags   excl[i] = 1 for i < n + k_tokens, then excl[row - lo] = 0 for every stay row (rows_all[R .. R+Lk)) inside the shard and
+ *                 excl[n ..] = !tokens_live  (the merged tokens are counted on one rank only)                  -> mhimx_pool_io.excl
+ *   shard_gather  out[j,:] = H[rows[j] - lo, :] if the shard owns rows[j], else 0   (j < R; the [R,E] block is then all-reduced: exact)
+ *   shard_scatter dH[rows[j] - lo, :] = dX[j,:] for the rows the shard owns */
+int mhimx_shard_flags(void* stream, const int64_t* rows_all, int64_t R, int64_t Lk, int64_t lo, int64_t n, int64_t k_tokens,
+                      int32_t tokens_live, uint8_t* excl);
+int mhimx_shard_gather(void* stream, const float* H, int64_t E, const int64_t* rows, int64_t R, int64_t lo, int64_t n, float* out);
+int mhimx_shard_scatter(void* stream, const float* dX, int64_t E, const int64_t* rows, int64_t R, int64_t lo, int64_t n, float* dH);
 /* out[e] (+)= sum_m X[m,e] */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);

@@ -96,7 +96,8 @@ class PoolIO(C.Structure):
     _fields_ = [("T1", c_f32p), ("M1", C.c_int64), ("T2", c_f32p), ("M2", C.c_int64),
                 ("s", c_f32p), ("stats", c_f32p), ("z", c_f32p), ("u_pre", c_f32p),
                 ("wp", c_f32p), ("C", C.c_int64), ("cproj", c_f32p),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p), ("rows1", c_i64p)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p), ("rows1", c_i64p),
+                ("excl", C.c_void_p)]
 
 
 class PoolGrad(C.Structure):
@@ -159,6 +160,9 @@ SYMBOLS = {
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "mhimx_rows_dpre": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_shard_flags": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P]),
+    "mhimx_shard_gather": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),
+    "mhimx_shard_scatter": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),
     "mhimx_rows_dpre_image": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_wgrad_image_bytes": (_I64, [_I64, _I64]),
     "mhimx_wgrad_ws_floats": (_I64, [_I64, _I64, _I64]),

@@ -14,7 +14,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, const float* wa, const float* wp, int64_t C);
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts, const int64_t* rows);
+                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl);
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
                      float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows);
@@ -698,6 +698,8 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   MHIMX_CHECK_ARG(!io->cproj || (io->wp && io->C > 0), "pool_fwd: cproj needs wp, C");
   MHIMX_CHECK_ARG(!io->rows1 || (io->M2 == 0 && scorer_fused_ok(sc->E, sc->A, sc->gated, sc->prec, io->T1, sc->wa, io->cproj ? io->wp : nullptr, io->C)),
                   "pool_fwd: gathered tokens (rows1) need the one-pass scorer (E = 512, A = 128, plain form, not f32) and a single segment");
+  MHIMX_CHECK_ARG(!io->excl || scorer_fused_ok(sc->E, sc->A, sc->gated, sc->prec, io->T1, sc->wa, io->cproj ? io->wp : nullptr, io->C),
+                  "pool_fwd: excluded rows (excl) need the one-pass scorer (E = 512, A = 128, plain form, not f32)");
   const int64_t M = io->M1 + io->M2, E = sc->E, A = sc->A;
   const int gated = sc->gated ? 1 : 0;
   Arena ar(io->ws, io->ws_bytes);
@@ -717,7 +719,8 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       // one pass over the rows: GEMM + scores + class projections + pool partials (scorer_fused.hip)
       const int g1 = scorer_fused_fwd(st, Ts[seg], Ms[seg], sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, io->cproj ? io->wp : nullptr,
                                       (int)io->C, u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
-                                      w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART, seg == 0 ? io->rows1 : nullptr);
+                                      w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART, seg == 0 ? io->rows1 : nullptr,
+                                      seg == 0 ? io->excl : nullptr);
       if (g1 < 0) return g1;
       G += g1;
       off += Ms[seg];

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     const float* __restrict__ ba, int act,
     const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ wp, int C, float* __restrict__ u_pre,
     float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl, float* __restrict__ pz,
-    int tiles, const int64_t* __restrict__ rows /* optional gather: token n is T[rows[n]] */) {
+    int tiles, const int64_t* __restrict__ rows /* optional gather: token n is T[rows[n]] */,
+    const uint8_t* __restrict__ excl /* optional, by source row: the row does not take part (score -inf) */) {
   extern __shared__ __attribute__((aligned(16))) float sf_sm[];
   float* Hs = sf_sm;                          // [32][516]
   float* sred = Hs + SF_ROWS * SF_LD;         // [4][32] per-wave partial scores
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     if (tid < SF_ROWS) {
       const int64_t n = row0 + tid;
       float s = (sred[tid] + sred[SF_ROWS + tid]) + (sred[2 * SF_ROWS + tid] + sred[3 * SF_ROWS + tid]) + bias_c;
+      if (n >= M || (excl && excl[rows ? ridx[tid] : n])) s = -INFINITY;
       if (n < M) s_out[n] = s;
-      else s = -INFINITY;
       srow[tid] = s;
     }
     __syncthreads();
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     }
     const float m_new = fmaxf(m_run, mt);
     const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
-    if (tid < SF_ROWS) prow[tid] = __expf(srow[tid] - m_new);          // -inf rows -> 0
+    if (tid < SF_ROWS) prow[tid] = srow[tid] == -INFINITY ? 0.f : __expf(srow[tid] - m_new);   // (a tile of excluded rows only: m_new = -inf)
     __syncthreads();
     float lsum = 0.f, a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -404,12 +405,12 @@ bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, 
 // one launch per token segment; returns the number of partials written to pm/pl/pz (<= max_parts), < 0 on error
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts, const int64_t* rows) {
+                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl) {
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   hipLaunchKernelGGL(scorer_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
-                     cproj, pm, pl, pz, tiles, rows);
+                     cproj, pm, pl, pz, tiles, rows, excl);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

@@ -654,7 +654,7 @@ class MHIM(nn.Module):
         Lk = int(len_keep * self.merge.merge_ratio)
         return k, n_sel, len_keep, Lk, len_keep - Lk
 
-    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None, merge_first=False, rows_out=None):
+    def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None, merge_first=False, rows_out=None, seed=None):
         """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
 
         Returns (rows int64 [L] = [rows that stay (L_keep) | rows to merge (R)], L, L_keep, R); with ``merge_first`` the
@@ -663,6 +663,8 @@ class MHIM(nn.Module):
         random subsets on the device (mhimx_select_rows).  The TransMIL encoder sees the token ORDER (landmark means,
         PPEG grid), so it always takes the literal two-stage form with a device-drawn shuffle.  With injected ``perm`` / ``ids_shuffle`` (parity tests) or v1 masks the reference's
         two-stage form is followed literally: select_mask -> mask_ids, then ids_keep[ids_shuffle].
+        ``seed``: the device draw's seed (default: this model's own counter, which starts from the PROCESS seed - replicas of an
+        instance-sharded bag pass a seed they share).
         """
         mask_ratio_h = self.mask_ratio_h
         if self.mrh_sche is not None:
@@ -683,7 +685,7 @@ class MHIM(nn.Module):
                 R = len_keep - Lk
                 if R == 0:
                     raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
-                rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed(), tick=self._tick,
+                rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed() if seed is None else seed, tick=self._tick,
                                        merge_first=merge_first, out=None if rows_out is None else rows_out[:len_keep])
                 return rows, len_keep, Lk, R
         len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm, generator=generator)

@@ -206,10 +206,11 @@ class ScorerW:
 class PoolState:
     """Buffers of one pool forward (kept for the backward)."""
 
-    def __init__(self, T1, T2, C_classes=0, wp=None, device=None, bp=None, rows1=None):
+    def __init__(self, T1, T2, C_classes=0, wp=None, device=None, bp=None, rows1=None, excl=None):
         dev = T1.device
         M1 = T1.shape[0] if rows1 is None else rows1.shape[0]
         self.rows1 = rows1
+        self.excl = excl
         M2 = 0 if T2 is None else T2.shape[0]
         self.T1, self.T2, self.M1, self.M2 = T1, T2, M1, M2
         M = M1 + M2
@@ -230,14 +231,16 @@ class PoolState:
         return L.PoolIO(T1=_p(self.T1), M1=self.M1, T2=_p(self.T2), M2=self.M2, s=_p(self.s), stats=_p(self.stats),
                         z=_p(self.z), u_pre=None, wp=_p(self.wp), C=0 if self.cproj is None else self.cproj.shape[1],
                         cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel(), bp=_p(self.bp), pscore=_p(self.pscore),
-                        rows1=_p(self.rows1))
+                        rows1=_p(self.rows1), excl=_p(self.excl))
 
 
-def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None):
+def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=None):
     """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj; with ``bp`` also ``pscore`` [M1], the
-    pseudo score of the T1 instances, written by the pool's finalize launch).  ``rows1`` (int64): the tokens are T1[rows1]."""
+    pseudo score of the T1 instances, written by the pool's finalize launch).  ``rows1`` (int64): the tokens are T1[rows1].
+    ``excl`` (uint8, by source row): rows that do not take part (score -inf; see mhimx_pool_io.excl)."""
     _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp"); _chk(bp, name="bp"); _chk(rows1, torch.int64, "rows1")
-    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp, rows1=rows1)
+    _chk(excl, torch.uint8, "excl")
+    st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp, rows1=rows1, excl=excl)
     io = st.io(sc)
     L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd")
     return st
@@ -482,6 +485,33 @@ def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=Fa
     if defer is not None:
         defer.keep.extend((ws_b, ws, img))
     return out_w, out_b
+
+
+def shard_flags(rows_all, R, Lk, lo, n, k_tokens, tokens_live, out=None):
+    """uint8 [n + k_tokens]: 0 for the shard's stay rows (rows_all[R:R+Lk] inside [lo, lo+n)) and, if tokens_live, the token rows; else 1."""
+    _chk(rows_all, torch.int64, "rows_all")
+    if out is None:
+        out = torch.empty(n + k_tokens, dtype=torch.uint8, device=rows_all.device)
+    L.check(L.lib().mhimx_shard_flags(_stream(), _p(rows_all), int(R), int(Lk), int(lo), int(n), int(k_tokens), int(bool(tokens_live)), _p(out)),
+            "mhimx_shard_flags")
+    return out
+
+
+def shard_gather(H, rows, lo, n, out=None):
+    """out[j] = H[rows[j] - lo] where the shard [lo, lo+n) owns rows[j], zero elsewhere."""
+    _chk(H, name="H"); _chk(rows, torch.int64, "rows")
+    R, E = rows.numel(), H.shape[1]
+    if out is None:
+        out = torch.empty((R, E), device=H.device)
+    L.check(L.lib().mhimx_shard_gather(_stream(), _p(H), E, _p(rows), R, int(lo), int(n), _p(out)), "mhimx_shard_gather")
+    return out
+
+
+def shard_scatter(dX, rows, lo, n, dH):
+    """dH[rows[j] - lo] = dX[j] for the rows the shard [lo, lo+n) owns."""
+    _chk(dX, name="dX"); _chk(rows, torch.int64, "rows"); _chk(dH, name="dH")
+    L.check(L.lib().mhimx_shard_scatter(_stream(), _p(dX), dX.shape[1], _p(rows), rows.numel(), int(lo), int(n), _p(dH)), "mhimx_shard_scatter")
+    return dH
 
 
 def colsum(X, out=None, accumulate=False):

@@ -59,6 +59,19 @@ class _Comm:
         dist.all_gather_into_tensor(out, src.reshape(-1), group=self.group)
         return out.view((self.world,) + tuple(src.shape)).to(t.device)
 
+    def all_gather_into(self, out, t):
+        """out [W, *t.shape] (preallocated, static under graph replay) <- every rank's t."""
+        if self.world == 1:
+            out[0].copy_(t)
+            return out
+        if self.stage:
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h.view(-1), t.cpu().reshape(-1), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out
+
     def all_gather_rows(self, t, counts):
         """Concatenate per-rank vectors of (known) different lengths."""
         if self.world == 1:
@@ -103,6 +116,7 @@ class ShardedBagTrainer:
         self.seed, self._n = int(seed), 0
         self.counts = counts                         # rows per rank (list); None = equal shards
         self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.tick = torch.zeros(1, dtype=torch.int64, device=dev)           # device step counter mixed into the fixed-shape step's dropout seeds
         self.step_count = 0
         self.last = {}
 
@@ -123,8 +137,209 @@ class ShardedBagTrainer:
         return ops.lse_merge(self.comm.all_gather(part).contiguous())
 
     # -------------------------------------------------------------------------------------------------
+    def fixed_shape_ok(self, x):
+        """The sync-free step needs the one-pass scorer (its ``excl`` flags) and the single-pass projection."""
+        s = self.s
+        att = s.online_encoder.attention
+        return (not s.online_encoder.gated and s.prec != "f32" and s.mlp_dim == 512 and att.attention[0].weight.shape[0] == 128
+                and x.shape[1] % 32 == 0 and s._feature_prec(1 << 20) == "bf16x3" and s.merge_enable)
+
     def train_step(self, x_local, label, perm=None, ids_shuffle=None, i=None):
         """x_local [n_r, D]: this rank's rows (rank order = row order of the bag).  Returns (logits [C], losses [3])."""
+        if self.fixed_shape_ok(x_local):
+            return self._step_fixed(x_local, label, perm, ids_shuffle, i)
+        return self._step_generic(x_local, label, perm, ids_shuffle, i)
+
+    def _step_fixed(self, x_local, label, perm, ids_shuffle, i):
+        for exchange in self._fixed_gen(x_local, label, perm, ids_shuffle, i):
+            exchange()
+        return self.last["logits"], self.last["losses"]
+
+    def _fixed_gen(self, x_local, label, perm, ids_shuffle, i):
+        """The step with every launch shape fixed by (n, R, Lk, k): NO host read-back, no torch index op on the row lists.  A
+        generator: it yields a thunk at every exchange (the caller runs it: eagerly, or between two captured graph segments).
+
+        Each rank keeps its rows in bag order.  ONE projection launch makes the teacher's and the student's feature rows of all n local
+        rows (mhimx_bag_project; the reference's student projects every row before it masks, mhim.py:335-336).  The student's pool runs
+        over all n rows (+ the k merged tokens on rank 0) with a per-row exclusion flag (mhimx_pool_io.excl: masked rows, rows that were
+        merged away, tokens on the other ranks get score -inf: weight 0, gradient 0), the rows to merge are collected into the replicated
+        [R, E] block by ownership (mhimx_shard_gather, zero elsewhere, then all-reduce: exact), and the weight-gradient pair runs over
+        all n rows (excluded rows carry a zero gradient).  Costs ~3 % more scorer rows than a compacted list, removes both host syncs."""
+        s, t, fl, cm = self.s, self.t, self.flat, self.comm
+        gv = fl.grad_views
+        x = s._check_x(x_local)
+        n, dev, E = x.shape[0], x.device, s.mlp_dim
+        counts = self.counts if self.counts is not None else [n] * cm.world
+        N, lo = sum(counts), sum(counts[:cm.rank])
+        assert counts[cm.rank] == n, "counts[rank] must equal the local row count"
+        shared_seed, local_seed = self._seeds()
+        k = s.merge.k
+        defer = ops.ReduceList()
+        tick = self.tick                                           # device step counter: the dropout streams advance under graph replay
+        s._tick = t._tick = tick
+        try:
+            # ---- parameter-only preparation of both models + the step counters: one launch
+            jt, prep_t = t.prep_jobs(backward=False)
+            js, prep_s = s.prep_jobs(backward=True, lean_merge=False)
+            ops.prep_batch([(ops.PREP_TICK, None, tick), (ops.PREP_TICK, None, self.opt_step)] + jt + js)
+
+            # ---- one projection launch: teacher rows, student rows (+ room for the k tokens), fp16 d out / d pre
+            act = L.act_code(s.act, _FEATURE_ACTS)
+            Hbuf = torch.empty((n + k, E), device=dev)
+            p_t = t.dropout_p if t.training else 0.0
+            heads = [ops.ProjHead(prep_t["w1p"], t.feature[0].bias.data, drop_p=p_t, drop_seed=local_seed ^ 0x5bd1e995),
+                     ops.ProjHead(prep_s["w1p"], s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=local_seed, out=Hbuf, want_dact=True)]
+            ops.bag_project(x, heads, act=act, drop_tick=tick)
+            DACT = heads[1].dact
+
+            # ---- teacher: partial pool -> the bag's (stats, z); scores need the bag's denominators
+            wp = t.predictor.weight.data if t.attn2score else None
+            st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp)
+            part = torch.empty(E + 2, device=dev)
+            parts = torch.empty((cm.world, E + 2), device=dev)
+            part[:2].copy_(st_t.stats)
+            part[2:].copy_(st_t.z)
+            yield lambda: cm.all_gather_into(parts, part)
+            gstats, t_feat = ops.lse_merge(parts)
+            if t.attn2score:
+                sc_loc = ops.pseudo_score(st_t.s, gstats, st_t.cproj, t.predictor.bias.data)
+            else:
+                sc_loc = ops.softmax_from_stats(st_t.s, gstats)
+            if cm.world == 1:
+                score = sc_loc
+            else:                                                  # ragged shards: gather at the widest shard's length, then one fixed-shape copy per rank
+                m = max(counts)
+                pad = torch.zeros(m, device=dev)
+                pad[:n].copy_(sc_loc)
+                gathered = torch.empty((cm.world, m), device=dev)
+                yield lambda: cm.all_gather_into(gathered, pad)
+                score = torch.empty(N, device=dev)
+                o = 0
+                for r, c in enumerate(counts):
+                    score[o:o + c].copy_(gathered[r, :c])
+                    o += c
+
+            # ---- select: replicated, identical on every rank -> [rows to merge (R) | rows that stay (Lk)]
+            # (draws: injected, or - up to 16 384 instances - made inside the select kernel from the model's seed counter and the device
+            # tick, the same on every rank; larger bags draw from the shared-seed generator)
+            injected = perm is not None and ids_shuffle is not None
+            rows, len_keep, Lk, R = s.student_rows(N, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, merge_first=True,
+                                                   generator=None if (injected or N <= 16384) else self.gen, seed=shared_seed)
+            plan = BagPlan(rows=None, L=n, Lk=Lk, R=R, drop_seed=local_seed, mca_seed=shared_seed, training=True)
+            excl = ops.shard_flags(rows, R, Lk, lo, n, k, cm.rank == 0)
+
+            # ---- Merge on the replicated [R, E] block (each row comes from exactly one rank)
+            Hm = ops.shard_gather(Hbuf, rows[:R], lo, n)
+            if cm.world > 1:
+                yield lambda: cm.all_reduce_sum(Hm)
+            z_tok, q_new, mws = ops.merge_fwd(s._merge_w(plan, wkv_frag=prep_s.get("wkv_frag")), Hm, z_out=Hbuf[n:], update_q=True)
+            q_old = prep_s["q_old"]
+            s.merge.global_q_mm.data.copy_(q_new.view_as(s.merge.global_q_mm))
+
+            # ---- student pool over all local rows + tokens, excluded rows flagged
+            sc = s._scorer(prep_s.get("wa_frag"))
+            st = ops.abmil_pool_fwd(sc, Hbuf, None, excl=excl)
+            part2 = torch.empty(E + 2, device=dev)
+            parts2 = torch.empty((cm.world, E + 2), device=dev)
+            part2[:2].copy_(st.stats)
+            part2[2:].copy_(st.z)
+            yield lambda: cm.all_gather_into(parts2, part2)
+            gstats, z = ops.lse_merge(parts2)
+
+            # ---- head (replicated)
+            t_in = t_feat if self.aux_alpha != 0. else None
+            logits, losses, g_z, _, _ = ops.head_fwd_bwd(z, t_in, s.predictor.weight.data, s.predictor.bias.data, label,
+                                                         temp_t=float(s.temp_t), main_alpha=self.main_alpha, aux_alpha=self.aux_alpha,
+                                                         d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"])
+
+            # ---- backward: the pool backward sees the BAG's softmax statistics and pooled feature
+            st.stats.copy_(gstats)
+            st.z.copy_(z)
+            dHbuf = torch.empty_like(Hbuf)
+            pre = "online_encoder.attention.attention."
+            pool_g = {"dT1": dHbuf, "d_wa": gv[pre + "0.weight"], "d_wc": gv[pre + "2.weight"]}
+            ops.abmil_pool_bwd(sc, st, g_z, prep_s["wa_t"], grads=pool_g, defer=defer, wa_t_frag=prep_s.get("wa_t_frag"))
+            dT2 = dHbuf[n:]                                        # zero on the ranks whose tokens were excluded
+            if cm.world > 1:
+                yield lambda: cm.all_reduce_sum(dT2)               # = broadcast from rank 0
+            mgr = {"d_ln_w": gv["merge.norm.weight"], "d_ln_b": gv["merge.norm.bias"], "d_wkv": gv["merge.attn.to_kv.weight"],
+                   "d_wq": gv["merge.attn.to_q.weight"], "d_wo": gv["merge.attn.to_out.0.weight"], "d_bo": gv["merge.attn.to_out.0.bias"]}
+            mg = ops.merge_bwd(s._merge_w(plan, need_t=True, q=q_old, tr=prep_s.get("merge_t")), Hm, dT2, mws, grads=mgr, defer=defer)
+            ops.shard_scatter(mg["dX"], rows[:R], lo, n, dHbuf)    # (those rows were excluded from the pool: their slots hold zeros)
+            if ops.bag_wgrad_ok(x, E, n):
+                ops.bag_wgrad(dHbuf, DACT, x, None, n, out_w=gv["feature.0.weight"], out_b=gv["feature.0.bias"], defer=defer)
+            else:
+                dpre, _ = ops.rows_dpre(dHbuf, DACT, None, n, colsum_out=gv["feature.0.bias"], defer=defer)
+                ops.gemm_tn(dpre, x, out=gv["feature.0.weight"], splits=8 if n >= 2048 else 1, prec="bf16x3", M=n, defer=defer)
+            ops.reduce_flush(defer)
+            if cm.world > 1:
+                if cm.rank != 0:                                   # replicated terms: counted once in the SUM
+                    for name in fl.train_names:
+                        if name.startswith("predictor.") or name.startswith("merge."):
+                            gv[name].zero_()
+                yield lambda: cm.all_reduce_sum(fl.grad[:fl.n_train])
+
+            self.step_count += 1
+            ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher, fl.n_train, self.step_count, lr=self.lr, beta1=self.betas[0],
+                         beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, grad_scale=1.0, ema_mm=self.mm, zero_grad=True,
+                         step_dev=self.opt_step)
+        finally:
+            s._tick = t._tick = None
+        self.last = {"logits": logits, "losses": losses, "patch_num": N, "keep_num": Lk + k, "rows": rows,
+                     "len_keep": len_keep, "score": score, "teacher_feat": t_feat}
+
+    # -------------------------------------------------------------------------------------------------
+    def capture(self, x_local, label, warmup=2, i=None):
+        """Capture the fixed-shape step as hipGraph segments with the exchanges between them (graph | collective | graph ...: a
+        collective inside a captured graph depends on the RCCL build, and ranks must not mix replayed and eager collectives).  Returns
+        a callable; every call replays one step on the SAME (x_local, label) buffers (copy the next shard into them)."""
+        if not self.fixed_shape_ok(x_local):
+            raise L.MhimxError("capture(): this model takes the generic sharded step (one host read-back per step): run it eagerly")
+        if self.s.mrh_sche is not None:
+            raise L.MhimxError("capture(): the HAM-ratio schedule changes the launch shapes per iteration")
+        cs = torch.cuda.Stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            for _ in range(warmup):
+                self.train_step(x_local, label, i=i)
+        torch.cuda.current_stream().wait_stream(cs)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        plan = []
+
+        def new_graph():
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(self.gen)
+            g.capture_begin(pool=pool)
+            return g
+
+        with torch.cuda.stream(cs):
+            gen = self._fixed_gen(x_local, label, None, None, i)
+            g = new_graph()
+            while True:
+                try:
+                    exchange = next(gen)
+                except StopIteration:
+                    g.capture_end()
+                    plan.append(g.replay)
+                    break
+                g.capture_end()
+                plan.append(g.replay)
+                exchange()                                         # (runs now too: the capture pass is a real step)
+                plan.append(exchange)
+                g = new_graph()
+        torch.cuda.current_stream().wait_stream(cs)
+        self._captured = plan                                      # keeps graphs and thunks (and, through them, the static buffers) alive
+
+        def replay():
+            for f in plan:
+                f()
+            return self.last["logits"], self.last["losses"]
+
+        return replay
+
+    def _step_generic(self, x_local, label, perm=None, ids_shuffle=None, i=None):
+        """Any scorer / feature shape: compacted local row lists (ONE host read-back of the data-dependent local counts per step)."""
         s, t, fl, cm = self.s, self.t, self.flat, self.comm
         gv = fl.grad_views
         x = s._check_x(x_local)

@@ -164,6 +164,134 @@ def test_c5_shard_size_steps_and_teacher_pool_matches_oracle():
     assert all(torch.isfinite(v).all() for v in s.state_dict().values())
 
 
+def test_pool_excl_equals_the_compacted_pool():
+    """mhimx_pool_io.excl: the pool over all rows with excluded rows flagged == the pool over the remaining rows, forward and backward
+    (excluded rows get a zero gradient), including a 32-row tile with no live row."""
+    from mhim_mil_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, E, A = 200, 512, 128
+    T = torch.randn((n, E), generator=g).to(DEV)
+    wa, wc = (torch.randn((A, E), generator=g) * 0.05).to(DEV), (torch.randn((1, A), generator=g) * 0.3).to(DEV)
+    excl = (torch.rand(n, generator=g) < 0.3).to(torch.uint8)
+    excl[64:96] = 1                                                         # a whole tile
+    live = (excl == 0).nonzero().view(-1).to(DEV)
+    excl = excl.to(DEV)
+    sc = ops.ScorerW(wa, wc, act=2)
+    st = ops.abmil_pool_fwd(sc, T, None, excl=excl)
+    ref = ops.abmil_pool_fwd(sc, T, None, rows1=live)
+    np.testing.assert_allclose(st.stats.cpu().numpy(), ref.stats.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(st.z.cpu().numpy(), ref.z.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert torch.isinf(st.s[excl.bool()]).all() and torch.equal(st.s[live], ref.s)
+    g_z = torch.randn(E, generator=g).to(DEV)
+    wa_t = ops.transpose(wa)
+    d1 = ops.abmil_pool_bwd(sc, st, g_z, wa_t)
+    dref = ops.abmil_pool_bwd(sc, ref, g_z, wa_t, grads={"dT1": torch.zeros((n, E), device=DEV)})
+    assert float(d1["dT1"][excl.bool()].abs().max()) == 0.0
+    # (other tile boundaries: the 3-term bf16 products round differently, ~2^-16 of the largest term)
+    sc_t, sc_w = float(dref["dT1"].abs().max()), float(dref["d_wa"].abs().max())
+    np.testing.assert_allclose(d1["dT1"].cpu().numpy(), dref["dT1"].cpu().numpy(), rtol=1e-5, atol=3e-5 * sc_t)
+    np.testing.assert_allclose(d1["d_wa"].cpu().numpy(), dref["d_wa"].cpu().numpy(), rtol=1e-4, atol=3e-5 * sc_w)
+
+
+def test_shard_index_kernels():
+    from mhim_mil_amd import ops
+    g = torch.Generator().manual_seed(4)
+    Nn, lo, n, E, R, Lk, k = 500, 120, 200, 64, 40, 300, 3
+    rows = torch.randperm(Nn, generator=g)[:R + Lk]
+    rows = torch.cat([rows[:R].sort().values, rows[R:].sort().values]).to(DEV)
+    fl = ops.shard_flags(rows, R, Lk, lo, n, k, True).cpu().numpy()
+    exp = np.ones(n + k, dtype=np.uint8)
+    stay = rows[R:].cpu().numpy()
+    exp[stay[(stay >= lo) & (stay < lo + n)] - lo] = 0
+    exp[n:] = 0
+    assert (fl == exp).all()
+    assert (ops.shard_flags(rows, R, Lk, lo, n, k, False).cpu().numpy()[n:] == 1).all()
+    H = torch.randn((n, E), generator=g).to(DEV)
+    out = ops.shard_gather(H, rows[:R], lo, n).cpu()
+    mr = rows[:R].cpu()
+    for j in range(R):
+        r = int(mr[j]) - lo
+        assert torch.equal(out[j], H[r].cpu() if 0 <= r < n else torch.zeros(E))
+    dX = torch.randn((R, E), generator=g).to(DEV)
+    dH = torch.zeros((n + k, E), device=DEV)
+    ops.shard_scatter(dX, rows[:R], lo, n, dH)
+    ref = torch.zeros((n + k, E))
+    for j in range(R):
+        r = int(mr[j]) - lo
+        if 0 <= r < n:
+            ref[r] = dX[j].cpu()
+    assert torch.equal(dH.cpu(), ref)
+
+
+def _valid_rows(rows, n_total):
+    r = rows.cpu().numpy()
+    return len(np.unique(r)) == len(r) and r.min() >= 0 and r.max() < n_total
+
+
+def test_fixed_shape_step_has_no_host_sync_and_captures():
+    """The sharded step on the fused-trainer kernels: no host read-back (torch's sync debug mode raises on any), and the same step
+    captured as hipGraph segments replays without one."""
+    from mhim_mil_amd.sharded import ShardedBagTrainer
+    s, t = _models()
+    tr = ShardedBagTrainer(s, t, aux_alpha=0.5, mm=0.999)
+    x = torch.from_numpy(synth.bag(601, N, D)).to(DEV)
+    lab = torch.tensor([1], device=DEV)
+    assert tr.fixed_shape_ok(x)
+    tr.train_step(x, lab)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        logits, losses = tr.train_step(x, lab)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(logits).all() and _valid_rows(tr.last["rows"], N)
+    step = tr.capture(x, lab, warmup=1)
+    before = {k_: v.detach().clone() for k_, v in s.state_dict().items()}
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(3):
+            logits, losses = step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(losses).all() and _valid_rows(tr.last["rows"], N)
+    assert int(tr.opt_step.item()) == 2 + 1 + 3                             # eager steps + capture warm-up + replays (the capture pass runs no kernel)
+    sd = s.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    assert any(not torch.equal(sd[k_], before[k_]) for k_ in before)         # the replays trained
+
+
+def _cap_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from mhim_mil_amd.sharded import ShardedBagTrainer
+    s, t = _models()
+    tr = ShardedBagTrainer(s, t, counts=COUNTS, aux_alpha=0.5, mm=0.999)
+    lo = sum(COUNTS[:rank])
+    x = torch.from_numpy(synth.bag(602, N, D))[lo:lo + COUNTS[rank]].to(DEV)
+    step = tr.capture(x, torch.tensor([1], device=DEV), warmup=1)
+    for _ in range(3):
+        logits, losses = step()
+    torch.cuda.synchronize()
+    torch.save({"stu": {k: v.detach().cpu() for k, v in s.state_dict().items()}, "rows": tr.last["rows"].cpu(), "logits": logits.cpu()},
+               os.path.join(out, f"c{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_captured_sharded_step_two_ranks_one_gpu(tmp_path):
+    """graph | exchange | graph ... on two ranks sharing the GPU (gloo staging): the replicas stay bit-identical."""
+    port = 36500 + (os.getpid() % 2000)
+    mp.spawn(_cap_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"c{r}.pt")) for r in range(2)]
+    assert torch.equal(res[0]["rows"], res[1]["rows"]) and _valid_rows(res[0]["rows"], N)
+    assert torch.equal(res[0]["logits"], res[1]["logits"]) and torch.isfinite(res[0]["logits"]).all()
+    for k in res[0]["stu"]:
+        assert torch.equal(res[0]["stu"][k], res[1]["stu"][k]), k
+
+
 def _dp_run(tr):
     x = torch.from_numpy(synth.bag(700, N, D)).to(DEV)
     lab = torch.tensor([1], device=DEV)
