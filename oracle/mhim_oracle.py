@@ -644,4 +644,6 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
     new_tea = ema_update(tea, new_stu, mm) if model == "mhim" else tea
     info = {"teacher_score": score if model == "mhim" else None, "loss": float(loss.detach()), "logits": logits.detach(), "cls_loss": float(cls_loss.detach() if torch.is_tensor(cls_loss) else cls_loss), "ps": ps, "keep": keep,
             "grads": {k: p.grad.detach() for k, p in stu_g.items() if p.grad is not None}}
+    if "mask_ids" in ex:                                            # the rows the student kept (masking.py:107), before Merge's shuffle
+        info["rows"] = np.asarray(ex["mask_ids"][:ex["len_keep_mask"]])
     return new_stu, new_tea, new_opt, info
