@@ -107,6 +107,12 @@ int mhimx_gemm_nn(void* stream, const mhimx_gemm_nt_args* a, float alpha, int32_
  * reduction; ws >= batch*splits*M*N floats.   replaces: batched torch.matmul / einsum on [b h n d] tensors. */
 int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* args, int32_t batch, int64_t strideA,
                        int64_t strideB, int64_t strideC, float alpha, int32_t splits, float* ws);
+/* Batches of SMALL products with an affine epilogue, one launch:  C_b (+)= ident * I + alpha * op(A_b, B_b)   (modes as above).
+ * M, N multiples of 64 (<= 512), K a multiple of 32 (<= 1024), 16-byte aligned operands, 3-term bf16.  The Nystrom pseudo-inverse
+ * iteration z <- 0.25 z (13 I - az (15 I - az (7 I - az)))  (nystrom_attention.py:21-25) is four of these per step; mhimx_gemm_batched
+ * takes the same kernel for such shapes.   replaces: torch.matmul + the scalar * eye arithmetic around it. */
+int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_args* args, int32_t batch, int64_t strideA, int64_t strideB,
+                     int64_t strideC, float alpha, float ident);
 
 /* Deferred final reductions.  Weight / bias gradients are consumed only by the optimizer, so the last stage of their
  * two-stage reductions (summing split-GEMM slabs, summing per-block column partials) need not run where it is produced:

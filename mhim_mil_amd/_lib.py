@@ -160,6 +160,7 @@ SYMBOLS = {
     "mhimx_dsmil_head": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "mhimx_rows_dpre": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_bmm_affine": (C.c_int, [_P, _I32, _P, _I32, _I64, _I64, _I64, C.c_float, C.c_float]),
     "mhimx_shard_flags": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P]),
     "mhimx_shard_gather": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),
     "mhimx_shard_scatter": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),

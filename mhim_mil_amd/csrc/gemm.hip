@@ -708,6 +708,9 @@ __global__ __launch_bounds__(256) void thin_tn_kernel(mhimx_gemm_tn_args t, int6
     }
 }
 
+bool small_bmm_ok(int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC);                        // small_bmm.hip
+int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident);
+
 int gemm_batched(hipStream_t st, int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha,
                  int splits, float* ws) {
   MHIMX_CHECK_ARG(batch >= 1 && batch <= 4096 && g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0, "gemm_batched: bad args");
@@ -717,6 +720,8 @@ int gemm_batched(hipStream_t st, int mode, const mhimx_gemm_nt_args& g, int batc
   MHIMX_CHECK_ARG((int64_t)batch * splits <= 65535, "gemm_batched: batch*splits > 65535");
   const Batch bt{sA, sB, sC, splits};
   const bool f32 = g.prec == MHIMX_PREC_F32;
+  if (splits == 1 && (mode != 0 || alpha == 1.f) && small_bmm_ok(mode, g, batch, sA, sB, sC))     // batches of small products: small_bmm.hip
+    return small_bmm(st, mode, g, batch, sA, sB, sC, mode == 1 ? alpha : 1.f, 0.f);
   if (mode == 0) {
     MHIMX_CHECK_ARG(g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 && aligned16(g.A) && aligned16(g.B),
                     "gemm_batched(nt): K, lda, ldb, strides must be multiples of 4 and A, B 16-byte aligned");

@@ -1,0 +1,142 @@
+// small_bmm.hip — batches of SMALL square-ish products in one launch:  C_b = ident * I + alpha * op(A_b, B_b)  (+ C_b)
+//
+// The Nystrom pseudo-inverse (nystrom_attention.py:12-27, six iterations of four 256 x 256 x 256 products per head, forward and
+// backward: ~200 launches per TransMIL train step) ran on the generic 128 x 128-tile kernels: 8 heads x 4 tiles = 32 workgroups on 256
+// CUs, 18-57 us per launch.  Here a workgroup owns a 64 x 64 tile (8 heads x 16 tiles = 128 workgroups), 4 waves x one
+// v_mfma_f32_32x32x16_bf16 block each, 3-term bf16 (hi*hi + hi*lo + lo*hi, ~2^-16), K in steps of 32 with the next step's global loads
+// in flight; both operand tiles sit in LDS k-contiguous ([row][32 k], pitch 36), whatever their layout in memory - the operand that
+// is not k-contiguous in memory is transposed by its LDS stores - so all three modes share the fragment path.  The affine epilogue
+// (ident * I + alpha * product) fuses the "a I - M" steps of the iteration.   mode 0: A[M,K] B[N,K]^T, 1: A[M,K] B[K,N], 2: A[K,M]^T B[K,N].
+#include "common.hpp"
+
+namespace mhimx {
+
+typedef float sb_f4 __attribute__((ext_vector_type(4)));
+typedef float sb_f16 __attribute__((ext_vector_type(16)));
+typedef __bf16 sb_b8 __attribute__((ext_vector_type(8)));
+constexpr int SB_T = 64, SB_K = 32, SB_PITCH = 36, SB_THREADS = 256;
+
+struct SmallBmm {
+  const float* A; const float* B; float* C;
+  int64_t lda, ldb, ldc, sA, sB, sC;
+  int M, N, K;
+  float alpha, ident;
+  int accumulate;
+};
+
+MHIMX_DEV void sb_split(const sb_f4& a, const sb_f4& b, sb_b8& hi, sb_b8& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const __bf16 h = (__bf16)v[q];
+    hi[q] = h;
+    lo[q] = (__bf16)(v[q] - (float)h);
+  }
+}
+
+// TA / TB: the operand is stored [K, rows] in memory (rows contiguous) and is transposed on its way into LDS
+template <bool TA, bool TB>
+__global__ __launch_bounds__(SB_THREADS) void small_bmm_kernel(SmallBmm g) {
+  __shared__ __attribute__((aligned(16))) float As[SB_T * SB_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[SB_T * SB_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * SB_T, n0 = (int64_t)blockIdx.x * SB_T;
+  const float* A = g.A + (int64_t)blockIdx.z * g.sA;
+  const float* B = g.B + (int64_t)blockIdx.z * g.sB;
+  float* C = g.C + (int64_t)blockIdx.z * g.sC;
+
+  sb_f4 ra[2], rb[2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f = tid + SB_THREADS * j;
+      if (TA) ra[j] = *reinterpret_cast<const sb_f4*>(A + (int64_t)(k0 + (f >> 4)) * g.lda + m0 + (f & 15) * 4);
+      else ra[j] = *reinterpret_cast<const sb_f4*>(A + (m0 + (f >> 3)) * g.lda + k0 + (f & 7) * 4);
+      if (TB) rb[j] = *reinterpret_cast<const sb_f4*>(B + (int64_t)(k0 + (f >> 4)) * g.ldb + n0 + (f & 15) * 4);
+      else rb[j] = *reinterpret_cast<const sb_f4*>(B + (n0 + (f >> 3)) * g.ldb + k0 + (f & 7) * 4);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f = tid + SB_THREADS * j;
+      if (TA) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) As[((f & 15) * 4 + c) * SB_PITCH + (f >> 4)] = ra[j][c];
+      } else {
+        *reinterpret_cast<sb_f4*>(As + (f >> 3) * SB_PITCH + (f & 7) * 4) = ra[j];
+      }
+      if (TB) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Bs[((f & 15) * 4 + c) * SB_PITCH + (f >> 4)] = rb[j][c];
+      } else {
+        *reinterpret_cast<sb_f4*>(Bs + (f >> 3) * SB_PITCH + (f & 7) * 4) = rb[j];
+      }
+    }
+  };
+
+  sb_f16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int r = lane & 31, kh = lane >> 5;
+  const float* ap = As + (wm * 32 + r) * SB_PITCH + 8 * kh;
+  const float* bp = Bs + (wn * 32 + r) * SB_PITCH + 8 * kh;
+  load(0);
+  for (int k0 = 0; k0 < g.K; k0 += SB_K) {
+    __syncthreads();                                       // the previous step's fragment reads are over
+    store();
+    __syncthreads();
+    if (k0 + SB_K < g.K) load(k0 + SB_K);                  // in flight under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      sb_b8 ah, al, bh, bl;
+      sb_split(*reinterpret_cast<const sb_f4*>(ap + 16 * s), *reinterpret_cast<const sb_f4*>(ap + 16 * s + 4), ah, al);
+      sb_split(*reinterpret_cast<const sb_f4*>(bp + 16 * s), *reinterpret_cast<const sb_f4*>(bp + 16 * s + 4), bh, bl);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  }
+  const int64_t n = n0 + wn * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int64_t m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+    float v = g.alpha * acc[e];
+    if (m == n) v += g.ident;
+    float* p = C + m * g.ldc + n;
+    if (g.accumulate) v += *p;
+    *p = v;
+  }
+}
+
+bool small_bmm_ok(int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC) {
+  if (g.prec == MHIMX_PREC_F32 || g.rows || g.bias || g.M % SB_T || g.N % SB_T || g.K % SB_K) return false;
+  if (g.M > 512 || g.N > 512 || g.K > 1024 || batch > 65535) return false;
+  if ((g.M / SB_T) * (g.N / SB_T) * batch < 32) return false;                 // too few workgroups to be worth it
+  return g.lda % 4 == 0 && g.ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 && aligned16(g.A) && aligned16(g.B) && mode >= 0 && mode <= 2;
+}
+
+int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident) {
+  SmallBmm g;
+  g.A = a.A; g.B = a.B; g.C = a.C; g.lda = a.lda; g.ldb = a.ldb; g.ldc = a.ldc; g.sA = sA; g.sB = sB; g.sC = sC;
+  g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K; g.alpha = alpha; g.ident = ident; g.accumulate = a.accumulate;
+  dim3 grid((unsigned)(a.N / SB_T), (unsigned)(a.M / SB_T), (unsigned)batch);
+  if (mode == 0) hipLaunchKernelGGL((small_bmm_kernel<false, false>), grid, dim3(SB_THREADS), 0, st, g);
+  else if (mode == 1) hipLaunchKernelGGL((small_bmm_kernel<false, true>), grid, dim3(SB_THREADS), 0, st, g);
+  else hipLaunchKernelGGL((small_bmm_kernel<true, true>), grid, dim3(SB_THREADS), 0, st, g);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mhimx
+
+extern "C" int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA, int64_t strideB,
+                                int64_t strideC, float alpha, float ident) {
+  using namespace mhimx;
+  MHIMX_CHECK_ARG(a && a->A && a->B && a->C && batch >= 1, "bmm_affine: null args");
+  MHIMX_CHECK_ARG(ident == 0.f || a->M == a->N, "bmm_affine: ident * I needs square outputs");
+  MHIMX_CHECK_ARG(small_bmm_ok(mode, *a, batch, strideA, strideB, strideC),
+                  "bmm_affine: M, N multiples of 64 (<= 512), K a multiple of 32 (<= 1024), 16-byte aligned operands, not the f32 mode");
+  return small_bmm((hipStream_t)stream, mode, *a, batch, strideA, strideB, strideC, alpha, ident);
+}

@@ -395,3 +395,33 @@ def test_c3_size_teacher_and_student_forward_vs_oracle():
     # tensor's largest gradient entry
     bad = {k_: v for k_, v in worst.items() if v > 5e-3}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("mode", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("n,B", [(256, 8), (64, 40), (512, 2)])
+def test_bmm_affine_vs_fp64(mode, n, B):
+    """mhimx_bmm_affine (csrc/small_bmm.hip): ident * I + alpha * op(a, b) for batches of small square matrices."""
+    from mhim_mil_amd import nystrom as NY
+    g = torch.Generator().manual_seed(n + B)
+    a = torch.randn((B, n, n), generator=g).to(DEV)
+    b = torch.randn((B, n, n), generator=g).to(DEV)
+    out = NY._bmm_affine(mode, a, b, torch.empty_like(a), -0.75, 13.0)
+    ad, bd = a.double(), b.double()
+    prod = {"nt": ad @ bd.transpose(1, 2), "nn": ad @ bd, "tn": ad.transpose(1, 2) @ bd}[mode]
+    ref = 13.0 * torch.eye(n, device=DEV, dtype=torch.float64) - 0.75 * prod
+    assert float((out.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+def test_gemm_batched_takes_the_small_kernel_and_agrees():
+    """mhimx_gemm_batched on pseudo-inverse-sized operands (8 x 256^3) dispatches to small_bmm.hip: same numbers as fp64."""
+    from mhim_mil_amd import nystrom as NY
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn((8, 256, 256), generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn((8, 256, 256), generator=g).to(DEV).requires_grad_(True)
+    bat = (0, 256 * 256, 256, 256, 256)
+    c = NY.heads_mm(a, b, "nn", bat, bat, (8, 256, 256), bat, 8)
+    w = torch.randn((8, 256, 256), generator=g).to(DEV)
+    (c * w).sum().backward()
+    ad, bd, wd = a.detach().double(), b.detach().double(), w.double()
+    for got, ref in ((c.detach(), ad @ bd), (a.grad, wd @ bd.transpose(1, 2)), (b.grad, ad.transpose(1, 2) @ wd)):
+        assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
