@@ -102,6 +102,24 @@ def cpu_baseline(steps, base):
                       f"{ncpu}-thread host, dropout off) on one N={N_INST} D={D_IN} bag, {dt:.1f} s"}
 
 
+def cpu_baseline_other(workload, base, n, d, bl):
+    """c3 / c5 / c2-dsmil: ONE oracle train step of the same configuration on the host cores (a bounded sample: 10-40 s)."""
+    from mhim_mil_amd import synth
+    from oracle import mhim_oracle as O
+    cfg = O.Cfg(**{**CFG, "dropout": 0.0, "baseline": bl})
+    stu, tea = O.as_torch(base), O.as_torch(base)
+    x = torch.from_numpy(synth.bag(4242, n, d))
+    k, n_sel, _ = O.mask_count(n, CFG["mask_ratio_h"], CFG["mask_ratio_hr"])
+    perm, shuf = synth.permutation(1, k), synth.permutation(2, n - n_sel)
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    O.train_step(x, 1, stu, tea, {}, cfg, 1, perm=perm, ids_shuffle=shuf)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "patch-instances/s", "cores": cores, "kind": "port",
+            "sample": f"1 oracle train step (torch CPU fp32, {cores} threads, dropout off, no warm-up) on one N={n} D={d} bag, {dt:.1f} s"}
+
+
 def timed(a, world, dev, step):
     """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
     for i in range(a.warmup):
@@ -174,7 +192,17 @@ def other_workload(a, world, rank, dev):
         name = f"c5: MHIM(ABMIL) train step on ONE bag N={n_total} D={d} sharded by rows"
     dt = timed(a, world, dev, step)
     if rank == 0:
+        algo = 3 * d * 4 + 4 * (1 + 2) + 8                   # three passes over X + score / ids, per instance per step
+        extra = {"whole_step_hbm_roofline": {"algorithmic_bytes_per_instance": algo,
+                                             "achieved_GBps": per_step * a.steps / dt / world * algo / 1e9,
+                                             "frac_of_8TBps": per_step * a.steps / dt / world * algo / 1e9 / HBM_PEAK_GBS,
+                                             "note": "step-level figure (no single dominant kernel): the TransMIL step is bound by its "
+                                                     "materialised 8 x 256 x N attention blocks and small-K products, see DESIGN.md"
+                                             if a.workload == "c3" else "step-level figure"}}
+        if world == 1 and a.cpu_steps > 0:
+            extra["cpu_baseline"] = cpu_baseline_other(a.workload, base, n_total, d, bl)
         print(json.dumps({
+            **extra,
             "metric": f"patch-instances/sec through MHIM fwd+bwd ({a.workload})", "value": per_step * a.steps / dt,
             "unit": "patch-instances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",

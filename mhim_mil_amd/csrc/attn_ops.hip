@@ -47,6 +47,40 @@ __global__ __launch_bounds__(AT) void softmax_rows_fwd_kernel(const float* __res
     __syncthreads();
   }
 }
+// long rows, 16-byte aligned (L % 4 == 0): ONE read pass for max and sum (online rescaling), 16-byte loads with four in flight, then
+// the write pass re-reads the row while it is still in L2 (a 48 500-token row is 194 KB)
+__global__ __launch_bounds__(AT) void softmax_rows_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t R,
+                                                                  int64_t L, float alpha) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[4];
+  const int64_t L4 = L / 4;
+  for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    const f4* xr = reinterpret_cast<const f4*>(x + r * L);
+    f4* yr = reinterpret_cast<f4*>(y + r * L);
+    float m = -INFINITY, s = 0.f;
+    for (int64_t i = threadIdx.x; i < L4; i += 4 * AT) {
+      f4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (i + q * AT) < L4 ? xr[i + q * AT] * alpha : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      float mq = m;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mq = fmaxf(mq, fmaxf(fmaxf(v[q][0], v[q][1]), fmaxf(v[q][2], v[q][3])));
+      float add = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) add += (__expf(v[q][0] - mq) + __expf(v[q][1] - mq)) + (__expf(v[q][2] - mq) + __expf(v[q][3] - mq));
+      s = (m == -INFINITY ? 0.f : s * __expf(m - mq)) + add;
+      m = mq;
+    }
+    const float mb = blk_max4(m, red);
+    s = blk_sum4(m == -INFINITY ? 0.f : s * __expf(m - mb), red);
+    const float inv = 1.f / s;
+    for (int64_t i = threadIdx.x; i < L4; i += AT) {
+      const f4 v = xr[i] * alpha;
+      yr[i] = f4{__expf(v[0] - mb), __expf(v[1] - mb), __expf(v[2] - mb), __expf(v[3] - mb)} * inv;
+    }
+    __syncthreads();
+  }
+}
 // wave-per-row variant for short rows (L <= 1024): 4 rows per block
 __global__ __launch_bounds__(AT) void softmax_rows_fwd_short_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t R,
                                                                     int L, float alpha) {
@@ -99,6 +133,32 @@ __global__ void landmark_fwd_kernel(const float* __restrict__ x, int64_t ldx, in
     float acc = 0.f;
     for (int t = 0; t < l; ++t) acc += x[((int64_t)j * l + t) * ldx + c];
     out[(int64_t)j * C + c] = acc / (float)l;
+  }
+}
+// the same sums for 16-byte aligned rows with C % 256 == 0: block = (landmark, 256 columns); its four waves take the rows t = w mod 4
+// with four independent 16-byte loads in flight each (the scalar form above is one l-long dependent chain per thread: latency bound)
+__global__ __launch_bounds__(256) void landmark_fwd_vec_kernel(const float* __restrict__ x, int64_t ldx, int l, int C, float* __restrict__ out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ f4 part[3][64];
+  const int j = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const f4* base = reinterpret_cast<const f4*>(x + (int64_t)j * l * ldx + blockIdx.y * 256) + lane;
+  const int64_t ld4 = ldx / 4;
+  f4 a0 = f4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int t = w;
+  for (; t + 12 < l; t += 16) {
+    a0 += base[(int64_t)t * ld4];
+    a1 += base[(int64_t)(t + 4) * ld4];
+    a2 += base[(int64_t)(t + 8) * ld4];
+    a3 += base[(int64_t)(t + 12) * ld4];
+  }
+  for (; t < l; t += 4) a0 += base[(int64_t)t * ld4];
+  f4 acc = (a0 + a1) + (a2 + a3);
+  if (w > 0) part[w - 1][lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    acc = (acc + part[0][lane]) + (part[1][lane] + part[2][lane]);
+    const float inv = 1.f / (float)l;
+    reinterpret_cast<f4*>(out + (int64_t)j * C + blockIdx.y * 256)[lane] = acc * inv;
   }
 }
 __global__ void landmark_bwd_kernel(const float* __restrict__ dout, int l, int C, float* __restrict__ dx, int64_t ldx, int64_t T,
@@ -594,6 +654,8 @@ extern "C" int mhimx_softmax_rows(void* stream, const float* x, float* y, int64_
   MHIMX_CHECK_ARG(x && y && R > 0 && L > 0, "softmax_rows: bad args");
   if (L <= 1024)
     hipLaunchKernelGGL(softmax_rows_fwd_short_kernel, dim3(grid1d(R, 4, 65535)), dim3(AT), 0, (hipStream_t)stream, x, y, R, (int)L, alpha);
+  else if (L % 4 == 0 && aligned16(x) && aligned16(y))
+    hipLaunchKernelGGL(softmax_rows_fwd_vec_kernel, dim3(grid1d(R, 1, 65535)), dim3(AT), 0, (hipStream_t)stream, x, y, R, L, alpha);
   else
     hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(grid1d(R, 1, 65535)), dim3(AT), 0, (hipStream_t)stream, x, y, R, L, alpha);
   MHIMX_LAUNCH_CHECK();
@@ -619,7 +681,10 @@ extern "C" int mhimx_softmax_cols_bwd(void* stream, const float* y, const float*
 }
 extern "C" int mhimx_landmark_mean(void* stream, const float* x, int64_t ldx, int64_t T, int64_t l, int64_t C, float* out) {
   MHIMX_CHECK_ARG(x && out && l > 0 && T % l == 0 && C > 0, "landmark_mean: T must be a multiple of l");
-  hipLaunchKernelGGL(landmark_fwd_kernel, dim3((unsigned)(T / l)), dim3(AT), 0, (hipStream_t)stream, x, ldx, (int)l, (int)C, out);
+  if (C % 256 == 0 && ldx % 4 == 0 && aligned16(x) && aligned16(out))
+    hipLaunchKernelGGL(landmark_fwd_vec_kernel, dim3((unsigned)(T / l), (unsigned)(C / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)l, (int)C, out);
+  else
+    hipLaunchKernelGGL(landmark_fwd_kernel, dim3((unsigned)(T / l)), dim3(AT), 0, (hipStream_t)stream, x, ldx, (int)l, (int)C, out);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
