@@ -128,6 +128,63 @@ def test_sharded_bag_exchanges_two_ranks(tmp_path):
     assert all(v < lo1 for v in res[0]["rows_local"].tolist()) and all(v >= lo1 for v in res[1]["rows_local"].tolist())
 
 
+def _fixed_worker(rank, port, out):
+    """The fixed-shape formulation of the sharded student (sharded._fixed_gen), restated with torch-CPU math: every rank pools ALL its
+    rows with excluded rows at score -inf (what mhimx_pool_io.excl does), collects the merge rows by ownership (mhimx_shard_gather) and
+    exchanges through _Comm's in-place collectives."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from mhim_mil_amd.sharded import _Comm
+    cm = _Comm()
+    p = O.as_torch(synth.mhim_state(5, input_dim=SH_D, merge_k=3))
+    n, lo = SH_COUNTS[rank], sum(SH_COUNTS[:rank])
+    x = torch.from_numpy(synth.bag(77, SH_N, SH_D))[lo:lo + n]
+    rows_all = torch.from_numpy(synth.permutation(9, SH_N)[:800].astype(np.int64))          # [merge R | stay Lk]
+    R, Lk, k_tok = 80, 720, 3
+    h = O.feature(x, p, "gelu")
+    tokens = torch.from_numpy(synth.normal(123, (k_tok, h.shape[1]), std=0.3).astype(np.float32))   # "merged tokens" (replicated)
+    hbuf = torch.cat([h, tokens])
+    # mhimx_shard_flags
+    excl = torch.ones(n + k_tok, dtype=torch.bool)
+    stay = rows_all[R:R + Lk]
+    own = (stay >= lo) & (stay < lo + n)
+    excl[stay[own] - lo] = False
+    excl[n:] = rank != 0
+    # pool with flags: excluded rows get score -inf
+    s = O.scorer_logits(hbuf, p["online_encoder.attention.attention.0.weight"], p["online_encoder.attention.attention.2.weight"], "relu").view(-1)
+    s = torch.where(excl, torch.full_like(s, float("-inf")), s)
+    mx = s.max()
+    e = torch.exp(s - mx)
+    part = torch.cat([mx.view(1), e.sum().view(1), (e[:, None] * hbuf).sum(0) / e.sum()])
+    parts = torch.empty((WORLD, part.numel()))
+    cm.all_gather_into(parts, part)
+    M, Lsum, z = _lse_merge_np(parts.double().numpy())
+    # mhimx_shard_gather + all-reduce
+    mr = rows_all[:R]
+    ownm = (mr >= lo) & (mr < lo + n)
+    Hm = torch.zeros((R, h.shape[1]))
+    Hm[ownm] = h[mr[ownm] - lo]
+    cm.all_reduce_sum(Hm)
+    torch.save({"z": torch.from_numpy(z), "Hm": Hm}, os.path.join(out, f"f{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_fixed_shape_sharded_student_two_ranks(tmp_path):
+    port = 32500 + (os.getpid() % 2000)
+    mp.spawn(_fixed_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"f{r}.pt")) for r in range(WORLD)]
+    p = O.as_torch(synth.mhim_state(5, input_dim=SH_D, merge_k=3))
+    x = torch.from_numpy(synth.bag(77, SH_N, SH_D))
+    h = O.feature(x, p, "gelu")
+    rows_all = torch.from_numpy(synth.permutation(9, SH_N)[:800].astype(np.int64))
+    tokens = torch.from_numpy(synth.normal(123, (3, h.shape[1]), std=0.3).astype(np.float32))
+    z_ref, _, _ = O.dattention(torch.cat([h[rows_all[80:]], tokens]), p, "relu")             # the unsharded pool over [stay | tokens]
+    for r in res:
+        np.testing.assert_allclose(r["z"].numpy(), z_ref.numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_array_equal(r["Hm"].numpy(), h[rows_all[:80]].numpy())                # every merge row exactly once, in list order
+
+
 def test_cosine_scheduler_matches_reference_fixture():
     """engine.cosine_scheduler == utils.cosine_scheduler (utils.py:199-210) on the fixture made from the reference."""
     from tests import golden_util as G
