@@ -134,7 +134,12 @@ typedef struct {
  * pending: 0 = nothing parked, else the next stage to run. */
 #define MHIMX_SIDE_BYTES 384
 typedef struct { int32_t pending; int32_t reserved; unsigned char blob[MHIMX_SIDE_BYTES]; } mhimx_side_work;
-typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; mhimx_side_work side; } mhimx_reduce_list;
+/* A parked GEMM: with a list, mhimx_abmil_pool_bwd does not launch its scorer-weight gradient GEMM (d_wa = du^T T, ~12 us, needed by the
+ * optimiser only) but parks its arguments here; the Merge backward that follows (mhimx_merge_bwd with the same list) launches it with
+ * its own first, parameter-only stage riding along as extra workgroups - one launch instead of two on the serial chain; without a Merge
+ * backward mhimx_reduce_flush launches it.  blob = a mhimx_gemm_tn_args. */
+typedef struct { int32_t pending; int32_t reserved; unsigned char blob[128]; } mhimx_parked_gemm;
+typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; mhimx_side_work side; mhimx_parked_gemm parked; } mhimx_reduce_list;
 int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list);      /* no-op when list->n == 0; list->n = 0 on return */
 
 /* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over

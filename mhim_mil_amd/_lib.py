@@ -72,8 +72,12 @@ class SideWork(C.Structure):
     _fields_ = [("pending", C.c_int32), ("reserved", C.c_int32), ("blob", C.c_ubyte * SIDE_BYTES)]
 
 
+class ParkedGemm(C.Structure):
+    _fields_ = [("pending", C.c_int32), ("reserved", C.c_int32), ("blob", C.c_ubyte * 128)]
+
+
 class ReduceListC(C.Structure):
-    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32), ("side", SideWork)]
+    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32), ("side", SideWork), ("parked", ParkedGemm)]
 
 
 class GemmTN(C.Structure):

@@ -26,7 +26,9 @@ constexpr int BM = 128, BN = 128, NTHREADS = 256;
 bool nt_dma_ok(const mhimx_gemm_nt_args& g);
 int gemm_nt_dma(hipStream_t st, const mhimx_gemm_nt_args& g);
 bool tn_dma_ok(const mhimx_gemm_tn_args& g);
-int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_avail);
+struct Merge2Side;
+int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g, int64_t ws_floats_avail, const Merge2Side* rider = nullptr, int rider_stage = 0,
+                bool* rode = nullptr);
 int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t K, float* out);
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);
 bool feat_gemm_ok(const mhimx_gemm_nt_args& g);
@@ -519,7 +521,16 @@ static int launch_tn(hipStream_t st, const mhimx_gemm_tn_args& g, int batch = 1,
   return 0;
 }
 
-int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
+static int gemm_tn_impl(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge2Side* rider, int rider_stage, bool* rode);
+int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) { return gemm_tn_impl(st, g, nullptr, 0, nullptr); }
+// the product with a stage of a Merge backward's side work riding along; returns 1 if it rode, 0 if the product ran without it, < 0 on error
+int gemm_tn_rider(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge2Side* rider, int stage) {
+  bool rode = false;
+  const int rc = gemm_tn_impl(st, g, rider, stage, &rode);
+  return rc < 0 ? rc : (rode ? 1 : 0);
+}
+static int gemm_tn_impl(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge2Side* rider, int rider_stage, bool* rode) {
+  if (rode) *rode = false;
   MHIMX_CHECK_ARG(g.M >= 0 && g.K1 > 0 && g.K2 > 0, "gemm_tn: bad dims");
   MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_tn: null operand");
   MHIMX_CHECK_ARG(g.splits <= 1 || g.ws, "gemm_tn: splits>1 needs ws");
@@ -530,7 +541,7 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g) {
   }
   if (tn_dma_ok(g)) {
     int64_t avail = g.ws ? (g.ws_floats > 0 ? g.ws_floats : (int64_t)(g.splits > 1 ? g.splits : 0) * g.K1 * g.K2) : 0;
-    const int used = gemm_tn_dma(st, g, avail);
+    const int used = gemm_tn_dma(st, g, avail, rider, rider_stage, rode);
     if (used == -2) goto generic;         // reduction too long for the LDS row table with this much workspace
     if (used < 0) return used;
     if (used > 1 && !defer_push(g.defer, reduce_job_slabs(g.ws, used, g.K1, g.K2, g.ldc, g.C, g.accumulate)))

@@ -390,12 +390,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
 // TN
 // =================================================================================================
 template <int PREC>
-__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, Merge2Side side) {
+__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, int side_stage, Merge2Side side) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2): its few short workgroups are
-    merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);      // dispatched first and free their slots early
+    merge2_side_stage(side_stage, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);      // dispatched first and free their slots early
     return;
   }
   const unsigned bx = blockIdx.x - (unsigned)side_blocks;      // (side_blocks % 8 == 0: the XCD of a tile does not move)
@@ -692,7 +692,9 @@ bool tn_dma_ok(const mhimx_gemm_tn_args& g) {
 }
 
 // picks the split count itself when the caller passes splits <= 0; returns the splits used through *splits_out
-int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_avail) {
+// rider (optional): a stage of a Merge backward's side work that runs as the launch's first workgroups (mca2_side.hpp); *rode says whether
+// it got its ride (the block count must keep the tiles' XCD mapping: a multiple of 8)
+int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_avail, const Merge2Side* rider, int rider_stage, bool* rode) {
   mhimx_gemm_tn_args g = g0;
   const int64_t tiles = (g.K1 / DBM) * (g.K2 / DBN);
   int splits = g.splits > 1 ? g.splits : 1;
@@ -711,15 +713,21 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   const size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8)));
   Merge2Side side = {};
-  int side_blocks = 0;
-  if (g.defer && g.defer->side.pending == 2 && DTHREADS == M2_THREADS && smem >= M2_SIDE_LDS * sizeof(float) && splits > 1) {
+  int side_blocks = 0, side_stage = 2;
+  if (rode) *rode = false;
+  if (rider && DTHREADS == M2_THREADS && smem >= M2_SIDE_LDS * sizeof(float) && merge2_side_blocks(rider_stage, *rider) % 8 == 0) {
+    side = *rider;
+    side_stage = rider_stage;
+    side_blocks = merge2_side_blocks(rider_stage, side);
+    if (rode) *rode = true;
+  } else if (g.defer && g.defer->side.pending == 2 && DTHREADS == M2_THREADS && smem >= M2_SIDE_LDS * sizeof(float) && splits > 1) {
     memcpy(&side, g.defer->side.blob, sizeof(side));           // a parked Merge-backward tail: stage 2 rides in this launch
     side_blocks = merge2_side_blocks(2, side);
     if (side_blocks % 8 == 0) g.defer->side.pending = 3;
     else side_blocks = 0;
   }
   dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + side_blocks));
-  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk, side_blocks, side);
+  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk, side_blocks, side_stage, side);
   MHIMX_LAUNCH_CHECK();
   return splits;
 }

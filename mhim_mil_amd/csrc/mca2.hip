@@ -277,47 +277,8 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_bwd_pre_kernel(const float*
                                                                    const float* __restrict__ wkv, int k, float drop_p, uint64_t seed0,
                                                                    const uint64_t* __restrict__ tick, float* __restrict__ d_bo, int accumulate,
                                                                    Merge2Ws w) {
-  __shared__ __attribute__((aligned(16))) float dzs[6 * M2_E];
-  __shared__ float doh[6 * 64];
-  __shared__ float dys[6 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x >> 3, eb = blockIdx.x & 7;
-  const int J = M2_H * k;
-  const int c = tid & 63, e = eb * 64 + c;
-  float wv[64];                                               // this thread's column of the head's Wv block: in flight from the start
-#pragma unroll
-  for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(M2_I + h * 64 + d) * M2_E + e];
-  float yv[2] = {0.f, 0.f};
-  for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) yv[q] = w.Y[(h * k + i) * M2_E + e];
-  const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
-  const float ks = 1.f / (1.f - drop_p);
-  for (int idx = tid; idx < k * M2_E; idx += M2_THREADS) {
-    const int i = idx >> 9, ee = idx & 511;
-    float v = dz[idx];
-    if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)ee, drop_p) ? v * ks : 0.f;
-    dzs[idx] = v;
-  }
-  m2_zero_tail(dzs, k);
-  __syncthreads();
-  if (h == 0 && tid < 64) {
-    float s = 0.f;
-    for (int i = 0; i < k; ++i) s += dzs[i * M2_E + e];
-    d_bo[e] = accumulate ? d_bo[e] + s : s;
-  }
-  m2_head_dots<64>(wo_t + (int64_t)h * 64 * M2_E, dzs, k, doh, 64, eb == 0 ? w.dO + h * 64 : nullptr);
-  __syncthreads();
-  for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) {
-    float acc = 0.f;
-#pragma unroll
-    for (int d = 0; d < 64; ++d) acc += doh[i * 64 + d] * wv[d];
-    const int j = h * k + i;
-    m2_store_images(w.dyf, w.gtf_dy, j, e, acc);
-    const float s = wave_sum(acc * yv[q]);                    // (a wave = one query i x the 64 columns of this block)
-    if (lane == 0) w.dpart[j * 8 + eb] = s;
-  }
-  for (int j = J + h; j < M2_JK; j += M2_H)
-    if ((tid >> 6) == ((j - J) >> 3) % 4) m2_store_images(w.dyf, w.gtf_dy, j, e, 0.f);
-  (void)dys; (void)wave;
+  __shared__ __attribute__((aligned(16))) float lds[M2_BWD_PRE_LDS];
+  merge2_bwd_pre_body((int)blockIdx.x, lds, dz, wo_t, wkv, k, drop_p, seed0, tick, d_bo, accumulate, w);      // (mca2_side.hpp)
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -541,6 +502,8 @@ int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
                  update_q ? q_new : (float*)nullptr, m->mm);
 }
 
+int gemm_tn_rider(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge2Side* rider, int stage);      // gemm.hip
+
 int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* gr, void* ws,
                int64_t ws_bytes) {
   Arena ar(ws, ws_bytes);
@@ -552,17 +515,30 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   const float scale = 1.0f / sqrtf((float)M2_DH);
   const int acc = gr->accumulate;
   const uint64_t oseed = m->drop_seed + 0x9E3779B97F4A7C15ull;
-  hipLaunchKernelGGL(merge2_bwd_pre_kernel, dim3(64), dim3(M2_THREADS), 0, st, dz, m->wo_t, m->wkv, k, m->drop_p, oseed, m->drop_tick, gr->d_bo, acc, w);
-  MHIMX_LAUNCH_CHECK();
+  Merge2Side sd;
+  sd.w = w; sd.dz = dz; sd.U = w.aq; sd.ln_w = m->ln_w; sd.ln_b = m->ln_b; sd.wkv = m->wkv; sd.wq = m->wq; sd.q_param = m->q_param; sd.wo_t = m->wo_t;
+  sd.d_wkv = gr->d_wkv; sd.d_wo = gr->d_wo; sd.d_wq = gr->d_wq; sd.d_ln_w = gr->d_ln_w; sd.d_ln_b = gr->d_ln_b; sd.d_bo = gr->d_bo; sd.tick = m->drop_tick;
+  sd.oseed = oseed; sd.scale = scale; sd.drop_p = m->drop_p; sd.k = k; sd.accumulate = acc; sd.J = J;
+  bool pre_done = false;
+  if (gr->defer && gr->defer->parked.pending) {
+    // the pool backward's scorer-weight-gradient GEMM waits in the list: launch it now, with this backward's parameter-only first stage
+    // riding along as its first 64 workgroups (both depend only on the pool backward's outputs)
+    mhimx_gemm_tn_args pg;
+    memcpy(&pg, gr->defer->parked.blob, sizeof(pg));
+    gr->defer->parked.pending = 0;
+    const int rc = gemm_tn_rider(st, pg, &sd, 0);
+    if (rc < 0) return rc;
+    pre_done = rc == 1;
+  }
+  if (!pre_done) {
+    hipLaunchKernelGGL(merge2_bwd_pre_kernel, dim3(M2_BWD_PRE_BLOCKS), dim3(M2_THREADS), 0, st, dz, m->wo_t, m->wkv, k, m->drop_p, oseed, m->drop_tick, gr->d_bo, acc, w);
+    MHIMX_LAUNCH_CHECK();
+  }
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M2_BWD_SMEM)));
   hipLaunchKernelGGL(merge2_rows_bwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_BWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
                      m->drop_seed, m->drop_tick, dX, w);
   MHIMX_LAUNCH_CHECK();
   // the parameter-gradient tail: U [J, E] takes the place of the fp32 copy of aq (not needed any more)
-  Merge2Side sd;
-  sd.w = w; sd.dz = dz; sd.U = w.aq; sd.ln_w = m->ln_w; sd.ln_b = m->ln_b; sd.wkv = m->wkv; sd.wq = m->wq; sd.q_param = m->q_param;
-  sd.d_wkv = gr->d_wkv; sd.d_wo = gr->d_wo; sd.d_wq = gr->d_wq; sd.d_ln_w = gr->d_ln_w; sd.d_ln_b = gr->d_ln_b; sd.tick = m->drop_tick; sd.oseed = oseed; sd.scale = scale;
-  sd.drop_p = m->drop_p; sd.k = k; sd.accumulate = acc; sd.J = J;
   if (gr->defer && gr->defer->side.pending == 0) {
     // deferred: the three stages ride in later launches of this backward (mhimx_rows_dpre, the weight-gradient mhimx_gemm_tn,
     // mhimx_reduce_flush); whatever did not get a ride is launched by mhimx_reduce_flush before the reductions

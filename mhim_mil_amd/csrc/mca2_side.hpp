@@ -10,8 +10,8 @@ namespace mhimx {
 
 struct Merge2Side {
   Merge2Ws w;
-  const float *dz, *U, *ln_w, *ln_b, *wkv, *wq, *q_param;
-  float *d_wkv, *d_wo, *d_wq, *d_ln_w, *d_ln_b;
+  const float *dz, *U, *ln_w, *ln_b, *wkv, *wq, *q_param, *wo_t;
+  float *d_wkv, *d_wo, *d_wq, *d_ln_w, *d_ln_b, *d_bo;
   const uint64_t* tick;
   uint64_t oseed;
   float scale, drop_p;
@@ -247,11 +247,63 @@ MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
 constexpr int M2_SIDE_LDS = M2_GRADS1_LDS;                   // floats: the largest of the three stages
 
 // block `b` of stage `stage` (1: U partials, 2: rank-k gradients I, 3: rank-k gradients II); lds: >= M2_SIDE_LDS floats, 16-byte aligned
+
+// Stage 0 (the first stage of the backward, parameters x dz): dz0 = dz keep/(1-p), d_bo, dO = dz0 Wo, dY[(h,i),:] = sum_d dO[i,h,d] Wv[h*64+d,:]
+// (as the two fragment images), delta partials dY.Y.   64 blocks = 8 heads x 8 column blocks of 64.  lds: 6 * 512 + 6 * 64 floats.
+constexpr int M2_BWD_PRE_BLOCKS = 64, M2_BWD_PRE_LDS = 6 * M2_E + 6 * 64;
+MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restrict__ dz, const float* __restrict__ wo_t,
+                                   const float* __restrict__ wkv, int k, float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick,
+                                   float* __restrict__ d_bo, int accumulate, const Merge2Ws& w) {
+  float* dzs = lds;                 // [6][512]
+  float* doh = dzs + 6 * M2_E;      // [6][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int h = block >> 3, eb = block & 7;
+  const int J = M2_H * k;
+  const int c = tid & 63, e = eb * 64 + c;
+  float wv[64];                                               // this thread's column of the head's Wv block: in flight from the start
+#pragma unroll
+  for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(M2_I + h * 64 + d) * M2_E + e];
+  float yv[2] = {0.f, 0.f};
+  for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) yv[q] = w.Y[(h * k + i) * M2_E + e];
+  const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
+  const float ks = 1.f / (1.f - drop_p);
+  for (int idx = tid; idx < k * M2_E; idx += M2_THREADS) {
+    const int i = idx >> 9, ee = idx & 511;
+    float v = dz[idx];
+    if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)ee, drop_p) ? v * ks : 0.f;
+    dzs[idx] = v;
+  }
+  m2_zero_tail(dzs, k);
+  __syncthreads();
+  if (h == 0 && tid < 64) {
+    float s = 0.f;
+    for (int i = 0; i < k; ++i) s += dzs[i * M2_E + e];
+    d_bo[e] = accumulate ? d_bo[e] + s : s;
+  }
+  m2_head_dots<64>(wo_t + (int64_t)h * 64 * M2_E, dzs, k, doh, 64, eb == 0 ? w.dO + h * 64 : nullptr);
+  __syncthreads();
+  for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc += doh[i * 64 + d] * wv[d];
+    const int j = h * k + i;
+    m2_store_images(w.dyf, w.gtf_dy, j, e, acc);
+    const float s = wave_sum(acc * yv[q]);                    // (a wave = one query i x the 64 columns of this block)
+    if (lane == 0) w.dpart[j * 8 + eb] = s;
+  }
+  for (int j = J + h; j < M2_JK; j += M2_H)
+    if ((tid >> 6) == ((j - J) >> 3) % 4) m2_store_images(w.dyf, w.gtf_dy, j, e, 0.f);
+}
+
 MHIMX_DEV void merge2_side_stage(int stage, int b, float* lds, const Merge2Side& a) {
-  if (stage == 1) merge2_partials_body<false>(b, lds, a.w.upart, a.ln_w, a.ln_b, const_cast<float*>(a.U), a.w);
+  if (stage == 0) merge2_bwd_pre_body(b, lds, a.dz, a.wo_t, a.wkv, a.k, a.drop_p, a.oseed, a.tick, a.d_bo, a.accumulate, a.w);
+  else if (stage == 1) merge2_partials_body<false>(b, lds, a.w.upart, a.ln_w, a.ln_b, const_cast<float*>(a.U), a.w);
   else if (stage == 2) merge2_grads1_body(b, lds, a);
   else merge2_grads2_body(b, lds, a);
 }
-inline int merge2_side_blocks(int stage, const Merge2Side& a) { return stage == 1 ? a.J * 4 : (stage == 2 ? M2_GRADS1_BLOCKS : M2_GRADS2_BLOCKS); }
+inline int merge2_side_blocks(int stage, const Merge2Side& a) {
+  return stage == 0 ? M2_BWD_PRE_BLOCKS : (stage == 1 ? a.J * 4 : (stage == 2 ? M2_GRADS1_BLOCKS : M2_GRADS2_BLOCKS));
+}
+static_assert(M2_BWD_PRE_LDS <= M2_SIDE_LDS, "stage 0 must fit the riders' LDS");
 
 }  // namespace mhimx

@@ -848,7 +848,13 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     if (Ms[seg] < 2048) splits = 1;
     t.splits = splits; t.ws = w.tn_ws; t.ws_floats = (int64_t)TN_SLABS * A * E;
     t.defer = (io->M2 == 0 && !gated) ? gr->defer : nullptr;        // one GEMM per workspace: its slabs may wait for the flush
-    if (int r = gemm_tn(st, t)) return r;
+    static_assert(sizeof(mhimx_gemm_tn_args) <= sizeof(((mhimx_parked_gemm*)nullptr)->blob), "mhimx_parked_gemm.blob too small");
+    if (t.defer && fused && !t.defer->parked.pending) {
+      // nothing on the data path reads d_wa: the launch waits in the list for the Merge backward (which gives its first stage a ride in
+      // it) or for mhimx_reduce_flush
+      memcpy(t.defer->parked.blob, &t, sizeof(t));
+      t.defer->parked.pending = 1;
+    } else if (int r = gemm_tn(st, t)) return r;
     if (gated) {
       t.A = w.du + off * ldu + A; t.C = gr->d_wb;
       if (int r = gemm_tn(st, t)) return r;
@@ -943,6 +949,12 @@ int merge2_side_finish(hipStream_t st, mhimx_side_work* side, int upto_stage);  
 
 int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   MHIMX_CHECK_ARG(list && list->n >= 0 && list->n <= MHIMX_REDUCE_MAX, "reduce_flush: bad list");
+  if (list->parked.pending) {                                   // a GEMM nobody gave a launch to (no Merge backward followed)
+    mhimx_gemm_tn_args pg;
+    memcpy(&pg, list->parked.blob, sizeof(pg));
+    list->parked.pending = 0;
+    if (int r = gemm_tn(st, pg)) return r;                      // (queues its slab sum on this same list)
+  }
   // a parked Merge-backward tail: the stages that found no ride run now, in order; the last one may ride in the reduction launch
   if (int r = merge2_side_finish(st, &list->side, list->n == 0 ? 3 : 2)) return r;
   if (list->n == 0) return 0;

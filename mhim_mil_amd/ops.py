@@ -144,6 +144,7 @@ class ReduceList:
         self.c = L.ReduceListC()
         self.c.n = 0
         self.c.side.pending = 0
+        self.c.parked.pending = 0
         self.keep = []
 
     def ptr(self):
