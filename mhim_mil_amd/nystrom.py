@@ -284,10 +284,11 @@ class AffineIdent(torch.autograd.Function):
         return dx, None, None
 
 
-def _bmm_affine(mode, a, b, out, alpha, ident):
-    """out[h] = ident * I + alpha * op(a[h], b[h]) on contiguous [B, n, n] batches (mhimx_bmm_affine)."""
+def _bmm_affine(mode, a, b, out, alpha, ident, accumulate=False):
+    """out[h] (+)= ident * I + alpha * op(a[h], b[h]) on contiguous [B, n, n] batches (mhimx_bmm_affine)."""
     B, n, _ = a.shape
-    g = L.GemmNT(A=_ptr(a), lda=n, rows=None, B=_ptr(b), ldb=n, C=_ptr(out), ldc=n, M=n, N=n, K=n, accumulate=0, prec=L.PREC[_PREC])
+    g = L.GemmNT(A=_ptr(a), lda=n, rows=None, B=_ptr(b), ldb=n, C=_ptr(out), ldc=n, M=n, N=n, K=n, accumulate=int(bool(accumulate)),
+                 prec=L.PREC[_PREC])
     L.check(L.lib().mhimx_bmm_affine(_st(), _MODE[mode], C.byref(g), B, n * n, n * n, n * n, float(alpha), float(ident)), "mhimx_bmm_affine")
     return out
 
@@ -309,6 +310,126 @@ class MatmulAffine(torch.autograd.Function):
         da = _bmm_affine("nt", dy, b, torch.empty_like(a), ctx.alpha, 0.0) if ctx.needs_input_grad[0] else None      # alpha dy b^T
         db = _bmm_affine("tn", a, dy, torch.empty_like(b), ctx.alpha, 0.0) if ctx.needs_input_grad[1] else None      # alpha a^T dy
         return da, db, None, None
+
+
+class NystromCore(torch.autograd.Function):
+    """The attention block between to_qkv and to_out (nystrom_attention.py:93-136) as ONE autograd node with a hand-written backward:
+    landmark means, the three score products, their softmaxes, the pseudo-inverse, a1 (pinv (a3 v)) and the residual convolution.
+    qkv is read by five of these; as separate autograd nodes each backward zero-filled a [T, 1536] gradient and torch summed the five
+    (~1.5 ms of fills and adds per c3 step).  Here every gradient lands in ONE dqkv buffer through the kernels' accumulate flags, the
+    softmaxes run in place, and no torch arithmetic touches token data.
+    Returns (out [T, 512], a1, z, a3) - the last three (not differentiable) for the cls-row attention map of return_attn."""
+
+    @staticmethod
+    def forward(ctx, qkv, conv_w, l, scale):
+        lib = L.lib()
+        T, ld = qkv.shape
+        m, dev = LANDMARKS, qkv.device
+        lm = torch.empty((m, 2 * INNER), device=dev)
+        L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
+        q, k, v = Op(qkv, 0, DH, ld, T, DH), Op(qkv, INNER, DH, ld, T, DH), Op(qkv, 2 * INNER, DH, ld, T, DH)
+        ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
+        a1, a2, a3 = torch.empty((HEADS, T, m), device=dev), torch.empty((HEADS, m, m), device=dev), torch.empty((HEADS, m, T), device=dev)
+        _heads_mm("nt", q, kl, batched(a1), HEADS)                        # q k~^T        nystrom:114
+        _heads_mm("nt", ql, kl, batched(a2), HEADS)                       # q~ k~^T       nystrom:115
+        _heads_mm("nt", ql, k, batched(a3), HEADS)                        # q~ k^T        nystrom:116
+        for t_ in (a1, a2, a3):                                           # softmax(scale * s), in place
+            Lr = t_.shape[-1]
+            L.check(lib.mhimx_softmax_rows(_st(), _ptr(t_), _ptr(t_), t_.numel() // Lr, Lr, float(scale)), "softmax_rows")
+        # pseudo-inverse (nystrom_attention.py:12-27): z0 = a2^T / (max col sum * max row sum), six iterations, every intermediate kept
+        z = torch.empty_like(a2)
+        stats = torch.empty(4, device=dev)
+        ws = torch.empty(2 * HEADS * m, device=dev)
+        L.check(lib.mhimx_pinv_init(_st(), _ptr(a2), HEADS, m, _ptr(z), _ptr(stats), _ptr(ws)), "pinv_init")
+        z0, chain = z, []
+        for _ in range(PINV_ITERS):
+            az = _bmm_affine("nn", a2, z, torch.empty_like(a2), 1.0, 0.0)
+            t1 = torch.empty_like(a2)
+            L.check(lib.mhimx_affine_ident(_st(), _ptr(az), _ptr(t1), HEADS, m, 7.0, -1.0), "affine_ident")
+            t2 = _bmm_affine("nn", az, t1, torch.empty_like(a2), -1.0, 15.0)
+            t3 = _bmm_affine("nn", az, t2, torch.empty_like(a2), -1.0, 13.0)
+            zn = _bmm_affine("nn", z, t3, torch.empty_like(a2), 0.25, 0.0)
+            chain.append((z, az, t1, t2, t3))
+            z = zn
+        a3v, w2 = torch.empty((HEADS, m, DH), device=dev), torch.empty((HEADS, m, DH), device=dev)
+        _heads_mm("nn", batched(a3), v, batched(a3v), HEADS)              # a3 v
+        _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
+        out = torch.empty((T, INNER), device=dev)
+        _heads_mm("nn", batched(a1), batched(w2), Op(out, 0, DH, INNER, T, DH), HEADS)        # a1 (pinv a3 v) -> [T, (h d)]
+        wc = conv_w.reshape(HEADS, -1).contiguous()
+        L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 1, 0),
+                "resconv")                                                # out += res_conv(v)   nystrom:135-136
+        ctx.saved = (qkv, lm, a1, a2, a3, z, z0, stats, chain, a3v, w2, wc)
+        ctx.cfg = (l, scale, conv_w.shape)
+        ctx.mark_non_differentiable(a1, z, a3)
+        return out, a1, z, a3
+
+    @staticmethod
+    def backward(ctx, dout, _g1, _g2, _g3):
+        lib = L.lib()
+        qkv, lm, a1, a2, a3, z, z0, stats, chain, a3v, w2, wc = ctx.saved
+        ctx.saved = None
+        l, scale, wshape = ctx.cfg
+        dout = dout.contiguous()
+        T, ld = qkv.shape
+        m, dev, KS = LANDMARKS, qkv.device, wc.shape[1]
+        q, k, v = Op(qkv, 0, DH, ld, T, DH), Op(qkv, INNER, DH, ld, T, DH), Op(qkv, 2 * INNER, DH, ld, T, DH)
+        ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
+        do = Op(dout, 0, DH, INNER, T, DH)
+        dqkv = torch.empty_like(qkv)                                       # every column block is written before it is added to
+        dq, dk, dv = q.like(dqkv), k.like(dqkv), v.like(dqkv)
+        dlm = torch.empty_like(lm)
+        dql, dkl = ql.like(dlm), kl.like(dlm)
+        # residual convolution: dv = flip-conv(dout), d(conv weight)
+        L.check(lib.mhimx_resconv(_st(), _ptr(dout), INNER, _ptr(wc), KS, DH, T, INNER, _ptr(dqkv, 2 * INNER), ld, 0, 1), "resconv")
+        dwc = torch.empty_like(wc)
+        ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(T, INNER, DH, KS), device=dev)
+        L.check(lib.mhimx_resconv_dw(_st(), _ptr(dout), INNER, _ptr(qkv, 2 * INNER), ld, KS, DH, T, INNER, _ptr(dwc), _ptr(ws)), "resconv_dw")
+        # out = a1 w2
+        da1 = torch.empty_like(a1)
+        _heads_mm("nt", do, batched(w2), batched(da1), HEADS)              # da1 = dout w2^T
+        dw2 = torch.empty_like(w2)
+        _heads_mm("tn", batched(a1), do, batched(dw2), HEADS)              # dw2 = a1^T dout
+        # w2 = z a3v
+        dz = torch.empty_like(z)
+        _heads_mm("nt", batched(dw2), batched(a3v), batched(dz), HEADS)    # dz = dw2 a3v^T
+        da3v = torch.empty_like(a3v)
+        _heads_mm("tn", batched(z), batched(dw2), batched(da3v), HEADS)    # da3v = z^T dw2
+        # a3v = a3 v
+        da3 = torch.empty_like(a3)
+        _heads_mm("nt", batched(da3v), v, batched(da3), HEADS)             # da3 = da3v v^T
+        _heads_mm("tn", batched(a3), batched(da3v), dv, HEADS, accumulate=True)   # dv += a3^T da3v
+        # pseudo-inverse, backwards through the six iterations
+        da2 = torch.empty_like(a2)
+        first = True
+        for (zp, az, t1, t2, t3) in reversed(chain):
+            dzp = _bmm_affine("nt", dz, t3, torch.empty_like(dz), 0.25, 0.0)          # z' = 0.25 zp t3
+            dt3 = _bmm_affine("tn", zp, dz, torch.empty_like(dz), 0.25, 0.0)
+            daz = _bmm_affine("nt", dt3, t2, torch.empty_like(dz), -1.0, 0.0)         # t3 = 13 I - az t2
+            dt2 = _bmm_affine("tn", az, dt3, torch.empty_like(dz), -1.0, 0.0)
+            _bmm_affine("nt", dt2, t1, daz, -1.0, 0.0, accumulate=True)               # t2 = 15 I - az t1
+            dt1 = _bmm_affine("tn", az, dt2, torch.empty_like(dz), -1.0, 0.0)
+            L.check(lib.mhimx_axpby(_st(), _ptr(dt1), _ptr(daz), daz.numel(), -1.0, 1.0), "axpby")      # t1 = 7 I - az
+            _bmm_affine("nt", daz, zp, da2, 1.0, 0.0, accumulate=not first)            # az = a2 zp
+            _bmm_affine("tn", a2, daz, dzp, 1.0, 0.0, accumulate=True)
+            dz, first = dzp, False
+        dinit = torch.empty_like(a2)
+        ws2 = torch.empty(256, device=dev)
+        L.check(lib.mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z0), _ptr(stats), HEADS, m, _ptr(dinit), _ptr(ws2)), "pinv_init_bwd")
+        L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
+        # softmax backward, in place on the gradient buffers
+        for y_, g_ in ((a1, da1), (a2, da2), (a3, da3)):
+            Lr = y_.shape[-1]
+            L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(y_), _ptr(g_), _ptr(g_), y_.numel() // Lr, Lr, float(scale)), "softmax_rows_bwd")
+        ds1, ds2, ds3 = batched(da1), batched(da2), batched(da3)
+        _heads_mm("nn", ds1, kl, dq, HEADS)                                # s1 = q k~^T : dq = ds1 k~
+        _heads_mm("tn", ds1, q, dkl, HEADS)                                #               dk~ = ds1^T q
+        _heads_mm("nn", ds2, kl, dql, HEADS)                               # s2 = q~ k~^T: dq~ = ds2 k~
+        _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
+        _heads_mm("nn", ds3, k, dql, HEADS, accumulate=True)               # s3 = q~ k^T : dq~ += ds3 k
+        _heads_mm("tn", ds3, ql, dk, HEADS)                                #               dk = ds3^T q~
+        L.check(lib.mhimx_landmark_mean_bwd(_st(), _ptr(dlm), T, l, 2 * INNER, _ptr(dqkv), ld, 1), "landmark_mean_bwd")
+        return dqkv, dwc.reshape(wshape), None, None
 
 
 class PinvInit(torch.autograd.Function):
@@ -449,6 +570,18 @@ class NystromAttention(nn.Module):
         l = math.ceil(n / m)
         qkv = Linear.apply(x, self.to_qkv.weight, None, 0.0, 0, None)          # [T, 1536]: q | k | v, heads = 64-column groups
         ld = 3 * INNER
+        p = self.dropout if training else 0.0
+        if _PREC != "f32" and not (return_attn and no_norm):
+            # one autograd node for the whole block (hand-written backward, no torch arithmetic on token data)
+            out, a1, z, a3 = NystromCore.apply(qkv, self.res_conv.weight, l, self.scale)
+            y = Linear.apply(out[pad:], self.to_out[0].weight, self.to_out[0].bias, p, seed, tick)   # last n rows (nystrom:142)
+            if not return_attn:
+                return y
+            with torch.no_grad():                                              # nystrom:143-150: the cls token's attention row
+                bat = lambda r, c: (0, r * c, c, r, c)
+                u = heads_mm(a1[:, pad:pad + 1].contiguous(), z, "nn", bat(1, m), bat(m, m), (HEADS, 1, m), bat(1, m))
+                r = heads_mm(u, a3, "nn", bat(1, m), bat(m, T), (HEADS, 1, T), bat(1, T))
+                return y, r[:, 0, pad + 1:], qkv[pad + 1:, 2 * INNER:]
         lm = Landmarks.apply(qkv, l)                                          # [256, 1024]: q~ | k~
         q_d, k_d, v_d = (0, DH, ld, T, DH), (INNER, DH, ld, T, DH), (2 * INNER, DH, ld, T, DH)
         ql_d, kl_d = (0, DH, 2 * INNER, m, DH), (INNER, DH, 2 * INNER, m, DH)
@@ -462,7 +595,6 @@ class NystromAttention(nn.Module):
         w2 = heads_mm(z, a3v, "nn", bat(m, m), bat(m, DH), (HEADS, m, DH), bat(m, DH))    # pinv (a3 v)
         out = heads_mm(a1, w2, "nn", bat(T, m), bat(m, DH), (T, INNER), (0, DH, INNER, T, DH))   # a1 (pinv a3 v) -> [T, (h d)]
         out = Add.apply(out, ResConv.apply(qkv, self.res_conv.weight))         # nystrom:135-136
-        p = self.dropout if training else 0.0
         y = Linear.apply(out[pad:], self.to_out[0].weight, self.to_out[0].bias, p, seed, tick)   # last n rows (nystrom:142)
         if not return_attn:
             return y
