@@ -639,6 +639,251 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   SEL_STAMP(7);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Large bags (N > 16384: the c5 score vector has 200 000 entries and every rank of a sharded bag runs the same select): the
+// same five steps spread over the chip.  One workgroup walking 200 000 keys several times is 0.6 ms; here every pass over the keys is
+// a launch of up to 256 workgroups, the candidates' order included.
+//   hist x3   three 11/11/10-bit digit histograms of the 32-bit key (per-workgroup LDS histogram, then global atomics); pass p
+//             derives the digits fixed so far from the earlier histograms itself (every workgroup scans 2048 bins: no state kernel)
+//   count     T = k-th largest key, `remaining` = how many T-valued keys belong to the top-k; per-workgroup counts of keys > T and == T
+//   gather    exactly k 64-bit keys (value << 32 | ~index) at positions fixed by the counts: ties lowest index first
+//   rank      place of every candidate in the (value desc, index asc) order by counting: k^2 compares over (k/1024) x (k/2048) workgroups
+//   finish    top-k list, flags of the n_sel candidates the permutation picks (+ an earlier mask), the masked-id list
+//   keep x2   per-workgroup counts of unflagged ids, then the ordered compaction (kept ids ascending, then - for a union - masked ids)
+// Same outputs, same tie contract, bit for bit, as select_kernel<false>.
+// ------------------------------------------------------------------------------------------------
+constexpr int SELM_BINS = 2048, SELM_MAXG = 256;
+// zero fill as a kernel of the same stream (a memset node of a captured graph is not ordered like a kernel node on every ROCm build)
+__global__ void sel_zero_kernel(uint4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static int sel_zero(hipStream_t st, void* p, int64_t bytes) {           // bytes % 16 == 0, p 16-byte aligned
+  const int64_t n16 = bytes / 16;
+  int64_t blocks = cdiv(n16, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sel_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n16);
+  return 0;
+}
+struct SelMultiWs {
+  uint32_t* hist;        // [3][2048], zeroed by the host's memset
+  uint32_t* rank;        // [16384] rank of candidate j among the candidates (zeroed)
+  uint32_t* selpos;      // [16384] selpos[r] = 1 + the place of sorted candidate r in the masked list, 0 = not selected (zeroed)
+  uint32_t* blk_gt;      // [G]
+  uint32_t* blk_eq;      // [G]
+  uint32_t* blk_keep;    // [G]
+  uint32_t* blk_mask;    // [G]
+  uint32_t* state;       // [4]: T, remaining
+  uint64_t* cand;        // [k]
+  uint8_t* flags;        // [N], zeroed by the host's memset
+};
+
+// thread t owns bins 2t, 2t+1 of a 2048-bin histogram: find the bin in which the cumulative count FROM THE TOP reaches `remaining`
+MHIMX_DEV void selm_find_bin(const uint32_t* __restrict__ h, uint32_t remaining, uint32_t* wave_tot, uint32_t* misc, uint32_t* bin_out,
+                             uint32_t* rem_out) {
+  const int tid = threadIdx.x;
+  const uint2 v = reinterpret_cast<const uint2*>(h)[tid];
+  uint32_t total;
+  const uint32_t below = block_scan_excl(v.x + v.y, wave_tot, &total);
+  const uint32_t above = total - (below + v.x + v.y);                 // population in the bins above 2t+1
+  if (above < remaining && remaining <= above + v.y) { misc[0] = 2u * tid + 1u; misc[1] = remaining - above; }
+  else if (above + v.y < remaining && remaining <= above + v.y + v.x) { misc[0] = 2u * tid; misc[1] = remaining - above - v.y; }
+  __syncthreads();
+  *bin_out = misc[0];
+  *rem_out = misc[1];
+  __syncthreads();
+}
+
+// digits fixed by the first `passes` histograms -> (prefix, remaining)
+MHIMX_DEV void selm_prefix(const uint32_t* __restrict__ hist, int passes, uint32_t k, uint32_t* wave_tot, uint32_t* misc, uint32_t* prefix_out,
+                           uint32_t* rem_out) {
+  uint32_t prefix = 0, remaining = k, bin;
+  if (passes >= 1) { selm_find_bin(hist, remaining, wave_tot, misc, &bin, &remaining); prefix = bin << 21; }
+  if (passes >= 2) { selm_find_bin(hist + SELM_BINS, remaining, wave_tot, misc, &bin, &remaining); prefix |= bin << 10; }
+  if (passes >= 3) { selm_find_bin(hist + 2 * SELM_BINS, remaining, wave_tot, misc, &bin, &remaining); prefix |= bin; }
+  *prefix_out = prefix;
+  *rem_out = remaining;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(SEL_THREADS) void selm_hist_kernel(const float* __restrict__ score, int64_t N, int largest, int k, SelMultiWs w) {
+  __shared__ uint32_t lh[SELM_BINS];
+  __shared__ __attribute__((aligned(16))) uint32_t wave_tot[SEL_WAVES];
+  __shared__ uint32_t misc[8];
+  const int tid = threadIdx.x;
+  const bool lg = largest != 0;
+  uint32_t prefix = 0, rem = 0;
+  selm_prefix(w.hist, PASS, (uint32_t)k, wave_tot, misc, &prefix, &rem);
+  const uint32_t fixed_mask = PASS == 0 ? 0u : (PASS == 1 ? 0xFFE00000u : 0xFFFFFC00u);
+  const int shift = PASS == 0 ? 21 : (PASS == 1 ? 10 : 0);
+  const uint32_t dmask = PASS == 2 ? 1023u : 2047u;
+  for (int i = tid; i < SELM_BINS; i += SEL_THREADS) lh[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * SEL_THREADS + tid; i < N; i += (int64_t)gridDim.x * SEL_THREADS) {
+    const uint32_t key = mono32(score[i], lg);
+    if ((key & fixed_mask) == prefix) atomicAdd(&lh[(key >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = w.hist + PASS * SELM_BINS;
+  for (int i = tid; i < SELM_BINS; i += SEL_THREADS)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// chunked walk: workgroup b owns instances [b*chunk, (b+1)*chunk)
+__global__ __launch_bounds__(SEL_THREADS) void selm_count_kernel(const float* __restrict__ score, int64_t N, int largest, int k, int64_t chunk,
+                                                                SelMultiWs w) {
+  __shared__ __attribute__((aligned(16))) uint32_t wave_tot[SEL_WAVES];
+  __shared__ uint32_t misc[8];
+  const int tid = threadIdx.x;
+  const bool lg = largest != 0;
+  uint32_t T, remaining;
+  selm_prefix(w.hist, 3, (uint32_t)k, wave_tot, misc, &T, &remaining);
+  if (blockIdx.x == 0 && tid == 0) { w.state[0] = T; w.state[1] = remaining; }
+  const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = b0 + chunk < N ? b0 + chunk : N;
+  uint32_t gt = 0, eq = 0;
+  for (int64_t i = b0 + tid; i < b1; i += SEL_THREADS) {
+    const uint32_t key = mono32(score[i], lg);
+    gt += key > T ? 1u : 0u;
+    eq += key == T ? 1u : 0u;
+  }
+  uint32_t tg, te;
+  block_scan_excl(gt, wave_tot, &tg);
+  block_scan_excl(eq, wave_tot, &te);
+  if (tid == 0) { w.blk_gt[blockIdx.x] = tg; w.blk_eq[blockIdx.x] = te; }
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void selm_gather_kernel(const float* __restrict__ score, int64_t N, int largest, int64_t chunk,
+                                                                 SelMultiWs w) {
+  __shared__ __attribute__((aligned(16))) uint32_t wave_tot[SEL_WAVES];
+  __shared__ uint32_t misc[8];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const bool lg = largest != 0;
+  const uint32_t T = w.state[0], remaining = w.state[1];
+  // positions: workgroup b' < b took gt[b'] + min(max(remaining - eq_before[b'], 0), eq[b']) candidates
+  if (tid == 0) {
+    uint32_t eqb = 0, pos = 0;
+    for (int q = 0; q < b; ++q) {
+      const uint32_t e = w.blk_eq[q];
+      const uint32_t room = remaining > eqb ? remaining - eqb : 0u;
+      pos += w.blk_gt[q] + (e < room ? e : room);
+      eqb += e;
+    }
+    misc[0] = eqb;
+    misc[1] = pos;
+  }
+  __syncthreads();
+  uint32_t eq_base = misc[0], pos_base = misc[1];
+  __syncthreads();
+  const int64_t b0 = (int64_t)b * chunk, b1 = b0 + chunk < N ? b0 + chunk : N;
+  for (int64_t c0 = b0; c0 < b1; c0 += SEL_THREADS) {
+    const int64_t i = c0 + tid;
+    uint32_t key = 0;
+    bool gt = false, eq = false;
+    if (i < b1) {
+      key = mono32(score[i], lg);
+      gt = key > T;
+      eq = key == T;
+    }
+    uint32_t tot_eq, tot_take;
+    const uint32_t erank = block_prefix(eq, wave_tot, &tot_eq);
+    const bool take = gt || (eq && (eq_base + erank) < remaining);
+    const uint32_t trank = block_prefix(take, wave_tot, &tot_take);
+    if (take) w.cand[pos_base + trank] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+    eq_base += tot_eq;
+    pos_base += tot_take;
+  }
+}
+
+// rank of every candidate by counting (the keys are distinct: value << 32 | ~index): workgroup (x, y) compares candidates
+// [1024 x, 1024 x + 1024) against the 2048-key segment y held in LDS (broadcast reads) - k^2 compares spread over the chip instead of a
+// 105-step bitonic sort in one workgroup's LDS.  Integer atomics: the result does not depend on the order.
+constexpr int SELM_SEG = 2048;
+__global__ __launch_bounds__(SEL_THREADS) void selm_rank_kernel(int k, int n_sel, const int64_t* __restrict__ perm, SelMultiWs w) {
+  __shared__ uint64_t seg[SELM_SEG];
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.y * SELM_SEG;
+  for (int i = tid; i < SELM_SEG; i += SEL_THREADS) seg[i] = (s0 + i) < k ? w.cand[s0 + i] : 0ull;       // (0 is below every key)
+  if (blockIdx.y == 0) {                     // which sorted places the permutation picks (masking.py:66-71): a table for the finish launch
+    for (int j = blockIdx.x * SEL_THREADS + tid; j < n_sel; j += gridDim.x * SEL_THREADS) w.selpos[perm ? perm[j] : (int64_t)j] = (uint32_t)j + 1u;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * SEL_THREADS + tid;
+  if (j >= k) return;
+  const uint64_t mine = w.cand[j];
+  uint32_t r = 0;
+#pragma unroll 8
+  for (int q = 0; q < SELM_SEG; ++q) r += seg[q] > mine ? 1u : 0u;
+  if (r) atomicAdd(&w.rank[j], r);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void selm_finish_kernel(int k, int n_sel, int64_t N, const int64_t* __restrict__ other, int64_t n_other,
+                                                                 int64_t* __restrict__ mask_ids, int64_t* __restrict__ topk_out, SelMultiWs w) {
+  const bool has_other = other != nullptr && n_other > 0;
+  const int64_t len_keep_simple = N - n_sel;
+  const int64_t t0 = (int64_t)blockIdx.x * SEL_THREADS + threadIdx.x, stride = (int64_t)gridDim.x * SEL_THREADS;
+  for (int64_t j = t0; j < k; j += stride) {
+    const uint32_t r = w.rank[j];                             // place in the (value desc, index asc) order
+    const int64_t idx = (int64_t)(0xFFFFFFFFu - (uint32_t)(w.cand[j] & 0xFFFFFFFFull));
+    if (topk_out) topk_out[r] = idx;
+    const uint32_t sp = w.selpos[r];
+    if (sp) {
+      w.flags[idx] = 1;
+      if (!has_other) mask_ids[len_keep_simple + (sp - 1)] = idx;       // masked ids keep candidate-order o perm
+    }
+  }
+  if (has_other)
+    for (int64_t j = t0; j < n_other; j += stride) w.flags[other[j]] = 1;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void selm_keepcount_kernel(int64_t N, int64_t chunk, SelMultiWs w) {
+  __shared__ __attribute__((aligned(16))) uint32_t wave_tot[SEL_WAVES];
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = b0 + chunk < N ? b0 + chunk : N;
+  uint32_t keep = 0, n = 0;
+  for (int64_t i = b0 + tid; i < b1; i += SEL_THREADS) { keep += w.flags[i] == 0 ? 1u : 0u; ++n; }
+  uint32_t tk, tn;
+  block_scan_excl(keep, wave_tot, &tk);
+  block_scan_excl(n, wave_tot, &tn);
+  if (tid == 0) { w.blk_keep[blockIdx.x] = tk; w.blk_mask[blockIdx.x] = tn - tk; }
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void selm_compact_kernel(int64_t N, int64_t chunk, int has_other, int64_t* __restrict__ mask_ids,
+                                                                  int64_t* __restrict__ len_keep_dev, SelMultiWs w) {
+  __shared__ __attribute__((aligned(16))) uint32_t wave_tot[SEL_WAVES];
+  __shared__ uint32_t misc[8];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (tid == 0) {
+    uint32_t kb = 0, mb = 0, kt = 0;
+    for (int q = 0; q < (int)gridDim.x; ++q) {
+      if (q < b) { kb += w.blk_keep[q]; mb += w.blk_mask[q]; }
+      kt += w.blk_keep[q];
+    }
+    misc[0] = kb; misc[1] = mb; misc[2] = kt;
+  }
+  __syncthreads();
+  uint32_t kept_base = misc[0], m_base = misc[1];
+  const uint32_t kept_total = misc[2];
+  __syncthreads();
+  if (b == 0 && tid == 0 && len_keep_dev) *len_keep_dev = (int64_t)kept_total;
+  const int64_t b0 = (int64_t)b * chunk, b1 = b0 + chunk < N ? b0 + chunk : N;
+  for (int64_t c0 = b0; c0 < b1; c0 += SEL_THREADS) {
+    const int64_t i = c0 + tid;
+    const bool in = i < b1;
+    const bool keep = in && w.flags[i] == 0;
+    uint32_t tot;
+    const uint32_t rank = block_prefix(keep, wave_tot, &tot);
+    if (keep) mask_ids[kept_base + rank] = i;
+    kept_base += tot;
+    if (has_other) {                         // union: masked ids sorted ascending after the kept ones (torch.unique, masking.py:75)
+      const bool msk = in && !keep;
+      uint32_t mt;
+      const uint32_t mr = block_prefix(msk, wave_tot, &mt);
+      if (msk) mask_ids[kept_total + m_base + mr] = i;
+      m_base += mt;
+    }
+  }
+}
+
 static size_t select_small_smem(int P) {          // keys+sorted, hist, wave_tot, misc, bitmap, rank; >= the 32 KB row staging
   const size_t a = (size_t)2 * P * 8 + (size_t)(SEL_COPIES * SEL_BINS + SEL_WAVES + 8 + 512 + P) * 4;
   return a < 32768 ? 32768 : a;
@@ -662,7 +907,46 @@ extern "C" int mhimx_sel_prof_read(unsigned long long* out) {
 }
 #endif
 
-extern "C" int64_t mhimx_select_ws_bytes(int64_t N) { return align_up(N, 256); }
+// flags [N]; large bags also: 3 histograms, per-workgroup counts, the candidate list (select_multi)
+static int64_t selm_extra_bytes() { return 3 * SELM_BINS * 4 + 2 * 16384 * 4 + 4 * SELM_MAXG * 4 + 256 + 16384 * 8; }
+extern "C" int64_t mhimx_select_ws_bytes(int64_t N) { return align_up(N, 256) + (N > 16384 ? selm_extra_bytes() : 0); }
+
+static int select_multi(hipStream_t st, const float* score, int64_t N, int k, int n_sel, int largest, const int64_t* perm, const int64_t* other,
+                        int64_t n_other, int64_t* mask_ids, int64_t* len_keep_dev, int64_t* topk_sorted, void* ws, int P) {
+  char* base = (char*)ws;
+  SelMultiWs w;
+  const int64_t nf = align_up(N, 256);
+  w.flags = (uint8_t*)base;
+  w.hist = (uint32_t*)(base + nf);
+  w.rank = w.hist + 3 * SELM_BINS;
+  w.selpos = w.rank + 16384;
+  w.blk_gt = w.selpos + 16384;
+  w.blk_eq = w.blk_gt + SELM_MAXG;
+  w.blk_keep = w.blk_eq + SELM_MAXG;
+  w.blk_mask = w.blk_keep + SELM_MAXG;
+  w.state = w.blk_mask + SELM_MAXG;
+  w.cand = (uint64_t*)((char*)w.state + 256);
+  MHIMX_CHECK_ARG(aligned16(ws), "select_mask: workspace must be 16-byte aligned");
+  sel_zero(st, base, nf + (3 * SELM_BINS + 2 * 16384) * 4);                 // flags, histograms, ranks, selection table
+  int G = (int)cdiv(N, 4 * SEL_THREADS);
+  if (G > SELM_MAXG) G = SELM_MAXG;
+  if (G < 1) G = 1;
+  const int64_t chunk = cdiv(N, G);
+  hipLaunchKernelGGL(selm_hist_kernel<0>, dim3(G), dim3(SEL_THREADS), 0, st, score, N, largest, k, w);
+  hipLaunchKernelGGL(selm_hist_kernel<1>, dim3(G), dim3(SEL_THREADS), 0, st, score, N, largest, k, w);
+  hipLaunchKernelGGL(selm_hist_kernel<2>, dim3(G), dim3(SEL_THREADS), 0, st, score, N, largest, k, w);
+  hipLaunchKernelGGL(selm_count_kernel, dim3(G), dim3(SEL_THREADS), 0, st, score, N, largest, k, chunk, w);
+  hipLaunchKernelGGL(selm_gather_kernel, dim3(G), dim3(SEL_THREADS), 0, st, score, N, largest, chunk, w);
+  (void)P;
+  hipLaunchKernelGGL(selm_rank_kernel, dim3((unsigned)cdiv(k, SEL_THREADS), (unsigned)cdiv(k, SELM_SEG)), dim3(SEL_THREADS), 0, st, k, n_sel, perm, w);
+  hipLaunchKernelGGL(selm_finish_kernel, dim3((unsigned)(cdiv(k, SEL_THREADS) < 16 ? 16 : cdiv(k, SEL_THREADS))), dim3(SEL_THREADS), 0, st, k, n_sel, N,
+                     other, n_other, mask_ids, topk_sorted, w);
+  hipLaunchKernelGGL(selm_keepcount_kernel, dim3(G), dim3(SEL_THREADS), 0, st, N, chunk, w);
+  hipLaunchKernelGGL(selm_compact_kernel, dim3(G), dim3(SEL_THREADS), 0, st, N, chunk, (other != nullptr && n_other > 0) ? 1 : 0, mask_ids,
+                     len_keep_dev, w);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
 
 static int select_impl(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
                        const int64_t* perm, const int64_t* other, int64_t n_other, int64_t* mask_ids,
@@ -681,13 +965,10 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
     hipLaunchKernelGGL(select_small_kernel<KPT>, dim3(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
                        (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,          \
                        g_rand_seed, g_tick, g_merge_R, g_rows_out)
-    static bool small_attr = false;
-    if (!small_attr) {
-      MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
-      MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
-      MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
-      small_attr = true;
-    }
+    MHIMX_ONCE_PER_DEVICE(
+        MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+        MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+        MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096))));
     if (N <= 4096) MHIMX_SEL_SMALL(4);
     else if (N <= 10240) MHIMX_SEL_SMALL(10);
     else MHIMX_SEL_SMALL(16);          // thread t owns instances [t*KPT, (t+1)*KPT)
@@ -698,6 +979,8 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
   const size_t smem = select_smem(P);
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))); MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))));
   MHIMX_CHECK_ARG(!g_use_rand && !g_rows_out, "select: the random-subset forms need N <= 16384 and k <= 4096");
+  if (N > 16384 && ws_bytes >= mhimx_select_ws_bytes(N) && mask_ids)
+    return select_multi((hipStream_t)stream, score, N, (int)k, (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, ws, P);
   hipLaunchKernelGGL(select_kernel<false>, dim3(1), dim3(SEL_THREADS), smem, (hipStream_t)stream, score, N, (int)k, (int)n_sel,
                      largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, (uint8_t*)ws, (float*)nullptr, P);
   MHIMX_LAUNCH_CHECK();
@@ -724,7 +1007,11 @@ extern "C" int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int
   (void)ws; (void)ws_bytes;
   MHIMX_CHECK_ARG(attn && vote && H > 0 && N > 0 && N <= (1ll << 24), "vote_scores: bad args");
   MHIMX_CHECK_ARG(k >= 1 && k <= N && k <= 16384, "vote_scores: k out of range");
-  MHIMX_HIP(hipMemsetAsync(vote, 0, (size_t)N * 4, (hipStream_t)stream));
+  {
+    const int64_t nb = (N * 4 / 16) * 16;                                    // (the tail below 16 bytes: one more tiny launch)
+    if (aligned16(vote) && nb) sel_zero((hipStream_t)stream, vote, nb);
+    if (!aligned16(vote) || nb != N * 4) MHIMX_HIP(hipMemsetAsync((char*)vote + (aligned16(vote) ? nb : 0), 0, (size_t)(N * 4 - (aligned16(vote) ? nb : 0)), (hipStream_t)stream));
+  }
   const int P = next_pow2((int)k < 2 ? 2 : (int)k);
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))));
   hipLaunchKernelGGL(select_kernel<true>, dim3((unsigned)H), dim3(SEL_THREADS), select_smem(P), (hipStream_t)stream, attn, N, (int)k,

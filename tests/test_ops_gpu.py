@@ -254,7 +254,8 @@ def test_select_mask_golden(name):
 
 
 @pytest.mark.parametrize("n,k,largest", [(1, 1, True), (2, 1, False), (63, 63, True), (1000, 1, True), (1025, 513, False),
-                                          (5000, 5000, True), (50000, 3000, True), (200000, 12000, True)])
+                                          (5000, 5000, True), (50000, 3000, True), (200000, 12000, True), (30000, 700, False),
+                                          (16385, 16384, True), (262144, 1, True)])
 def test_select_mask_edges(n, k, largest):
     """Edge sizes incl. k = N, k = 1, non-multiples of the block, and BASELINE configs c3/c5 (k=3000/12000)."""
     ops = _ops()
@@ -300,6 +301,30 @@ def test_select_mask_union_and_vote():
     for h in range(meta["heads"]):
         ref[O.topk_indices(a["attn"][h], meta["k"])] += 1
     assert np.array_equal(vote, ref)
+
+
+def test_select_mask_union_large_bag():
+    """The multi-workgroup form (N > 16384) with an earlier mask (masking.py:74-75): kept ids ascending, then the union ascending; an
+    all-equal score vector (every key ties: lowest indices win)."""
+    ops = _ops()
+    n, k = 40000, 2000
+    s = synth.uniform(77, (n,)).astype(np.float32)
+    s[::97] = s[5]
+    other = np.sort(synth.permutation(8, n)[:3000]).astype(np.int64)
+    perm = synth.permutation(9, k)
+    n_sel = 1200
+    ids, len_keep, topk = ops.select_mask(torch.from_numpy(s).to(DEV), k, n_sel, True, torch.from_numpy(perm).to(DEV),
+                                          other=torch.from_numpy(other).to(DEV), want_topk=True)
+    top = O.topk_indices(s, k, True)
+    assert np.array_equal(topk.cpu().numpy(), top)
+    flag = np.zeros(n, bool); flag[top[perm[:n_sel]]] = True; flag[other] = True
+    lk = int(len_keep.item())
+    assert lk == int((~flag).sum())
+    got = ids.cpu().numpy()
+    assert np.array_equal(got[:lk], np.nonzero(~flag)[0]) and np.array_equal(got[lk:], np.nonzero(flag)[0])
+    flat = np.full(20000, 0.25, np.float32)
+    ids, len_keep, topk = ops.select_mask(torch.from_numpy(flat).to(DEV), 500, 500, True, None, want_topk=True)
+    assert np.array_equal(topk.cpu().numpy(), np.arange(500)) and np.array_equal(ids.cpu().numpy()[:19500], np.arange(500, 20000))
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16s"])
