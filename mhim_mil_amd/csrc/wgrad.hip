@@ -23,6 +23,7 @@
 //     CU can ingest): the image in a 5-deep LDS ring, X in three rotating register sets in front of a 2-deep LDS ring.
 //   * 16 reduction slabs x 16 output tiles = 256 workgroups (one per CU); the tiles of a slab run on ONE XCD (its X rows and dPRE
 //     tiles are shared through that L2); the slab sum is a job of the step's deferred reduction launch, as before.
+#include <stdlib.h>
 #include <string.h>
 
 #include "mma_tile.hpp"
@@ -295,6 +296,226 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_kernel(WgradArgs g, int si
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same product with SPECIALISED waves.  In bag_wgrad_kernel every wave loads, splits, stores, reads fragments and multiplies; the
+// counters say its waves wait 46 % of their time with the matrix pipe 44 % busy (two waves per SIMD in lock-step phases: when one
+// waits on memory so does the other).  Here waves 0-3 (one per SIMD) are PRODUCERS - X loads, half-wave swap, bf16 split, LDS stores,
+// the image DMA - and waves 4-7 CONSUMERS that touch no global memory in the loop: 64 x 128 outputs each (32 accumulator tiles), 24
+// fragment reads and 96 MFMAs per k-step, fragments of tile t+1 requested while tile t multiplies.  A producer's instructions issue in
+// the shadow of its SIMD's consumer MFMAs; fragment reads per MFMA drop by a quarter (96 KB instead of 128 KB per k-step per CU).
+// One s_barrier per k-step: it publishes tile t+2 and retires tile t; 3-deep rings for both operands (144 KB).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SNA = 3, SNB = 3, SRING = SNA * WA_BYTES + SNB * WB_BYTES;
+
+// four fragment blocks of the E-side operand (512 B apart) / of one column half of the D-side operand (1 KiB apart)
+#define WS_READ4A(d, p)                                                                                                  \
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:1024\n\tds_read_b128 %3, %4 offset:1536" \
+               : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(p) : "memory")
+#define WS_READ4B(d, p)                                                                                                  \
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072" \
+               : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(p) : "memory")
+// wait until at most n LDS operations are outstanding; names the two groups the following MFMAs read
+#define WS_WAIT8(n, a, b)                                                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory")
+
+// 16 MFMAs: four E-side blocks x four D-side blocks of column half `cb`
+template <int CB>
+MHIMX_DEV void ws_unit(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[4][8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][4 * CB + j] = mt_mfma(a[i], b[j], acc[i][4 * CB + j]);
+}
+
+__global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int side_blocks, Merge2Side side) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < side_blocks) {
+    if (threadIdx.x < M2_THREADS) merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
+    return;
+  }
+  const unsigned bx = blockIdx.x - (unsigned)side_blocks;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nJ = (int)(g.D / WBN), nIT = (int)(g.E / WBI), nT = nIT * nJ;
+  const int xcd = bx & 7, sidx = bx >> 3;
+  const int slab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
+  if (slab >= g.splits) return;
+  const int itile = tile / nJ;
+  const int64_t i0 = (int64_t)itile * WBI, n0 = (int64_t)(tile % nJ) * WBN;
+  const int ks0 = slab * g.kps;
+  const int nk = (ks0 + g.kps < g.ksteps ? ks0 + g.kps : g.ksteps) - ks0;
+  unsigned* rowtab = reinterpret_cast<unsigned*>(smem + SRING);
+  for (int q = tid; q < nk * WBK; q += WTHREADS) {
+    int64_t l = (int64_t)ks0 * WBK + q;
+    if (l >= g.L) l = g.L - 1;
+    rowtab[q] = (unsigned)((g.rows ? g.rows[l] : l) * g.ldx * 4);
+  }
+  __syncthreads();
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+
+  if (wave < 4) {
+    // =========================================================== producers: wave = row octet of the k-step
+    const int oct = wave, half = lane >> 5, c = lane & 31;
+    const unsigned colb0 = (unsigned)((n0 + 4 * c) * 4), colb1 = colb0 + 128 * 4;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct XSet { f32x4 v[8]; };                               // [column half][row of the lane's four]
+    auto row_offsets = [&](int t) {
+      return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(rowtab) + (oct * 8 + half * 4) * 4 + (t < nk ? t : nk - 1) * 128);
+    };
+    auto load_x_async = [&](const u32x4& ro, XSet& r) {
+      asm volatile("global_load_dwordx4 %0, %8, %16\n\tglobal_load_dwordx4 %1, %9, %16\n\tglobal_load_dwordx4 %2, %10, %16\n\t"
+                   "global_load_dwordx4 %3, %11, %16\n\tglobal_load_dwordx4 %4, %12, %16\n\tglobal_load_dwordx4 %5, %13, %16\n\t"
+                   "global_load_dwordx4 %6, %14, %16\n\tglobal_load_dwordx4 %7, %15, %16"
+                   : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+                   : "v"(ro[0] + colb0), "v"(ro[1] + colb0), "v"(ro[2] + colb0), "v"(ro[3] + colb0), "v"(ro[0] + colb1), "v"(ro[1] + colb1),
+                     "v"(ro[2] + colb1), "v"(ro[3] + colb1), "s"(g.X)
+                   : "memory");
+    };
+    const unsigned xs0 = (unsigned)(SNA * WA_BYTES + ((oct * 2) * 256 + (2 * half) * 64 + c) * 16);
+    auto store_x = [&](int t, XSet& r) {
+      char* sb = smem + (t % SNB) * WB_BYTES + xs0;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        float a[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[q][0] = r.v[ch * 4 + q][0]; a[q][1] = r.v[ch * 4 + q][1]; a[q][2] = r.v[ch * 4 + q][2]; a[q][3] = r.v[ch * 4 + q][3];
+          wg_swap(a[q][0], a[q][2]);
+          wg_swap(a[q][1], a[q][3]);
+        }
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const float kv[8] = {a[0][sx], a[1][sx], a[2][sx], a[3][sx], a[0][sx + 2], a[1][sx + 2], a[2][sx + 2], a[3][sx + 2]};
+          f32x4 hi, lo;
+          wg_split8(kv, hi, lo);
+          *reinterpret_cast<f32x4*>(sb + ch * 512 + sx * 1024) = hi;
+          *reinterpret_cast<f32x4*>(sb + ch * 512 + sx * 1024 + 4096) = lo;
+        }
+      }
+    };
+    const char* abase = g.img + ((int64_t)ks0 * nIT + itile) * WA_BYTES + (wave * 64 + lane) * 16;
+    auto issue_a = [&](int t, bool live) {                     // 16 KiB by 256 threads: four 4 KiB pieces
+      char* sa = smem + (t % SNA) * WA_BYTES + wave * 1024;
+      const char* src = live ? abase + (int64_t)t * nIT * WA_BYTES : g.img;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_f)(live ? src + j * 4096 : src), (lptr_f)(sa + j * 4096), 16, 0, 0);
+    };
+    XSet s0, s1, s2;
+    issue_a(0, true);
+    issue_a(1, nk > 1);
+    {
+      const char* xb = reinterpret_cast<const char*>(g.X);
+      for (int t = 0; t < 2 && t < nk; ++t) {
+        const u32x4 ro = row_offsets(t);
+        XSet r0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          r0.v[q] = *reinterpret_cast<const f32x4*>(xb + ro[q] + colb0);
+          r0.v[4 + q] = *reinterpret_cast<const f32x4*>(xb + ro[q] + colb1);
+        }
+        store_x(t, r0);
+      }
+    }
+    // in the loop's own order from here on: {4 image pieces, 8 X loads} per tile
+    load_x_async(row_offsets(2), s2);
+    issue_a(2, false);                                        // (four dummy pieces: keeps the loop's VMEM count)
+    load_x_async(row_offsets(3), s0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // #0: tiles 0 and 1 are in LDS
+    auto body = [&](int t, XSet& r_load, XSet& r_use) {
+      issue_a(t + 2, t + 2 < nk);
+      load_x_async(row_offsets(t + 4), r_load);
+      asm volatile("s_waitcnt vmcnt(24)" : "+v"(r_use.v[0]), "+v"(r_use.v[1]), "+v"(r_use.v[2]), "+v"(r_use.v[3]), "+v"(r_use.v[4]),
+                   "+v"(r_use.v[5]), "+v"(r_use.v[6]), "+v"(r_use.v[7]) : : "memory");
+      if (t + 2 < nk) store_x(t + 2, r_use);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // image tile t+2 landed, my X(t+2) stores are done
+      __builtin_amdgcn_s_barrier();                           // #t+1
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 2 < nk; t += 3) {
+      body(t, s1, s2);                                        // X(t+4) -> s1, X(t+2) from s2
+      body(t + 1, s2, s0);
+      body(t + 2, s0, s1);
+    }
+    if (t < nk) body(t, s1, s2);
+    if (t + 1 < nk) body(t + 1, s2, s0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0.v[0]), "+v"(s0.v[7]), "+v"(s1.v[0]), "+v"(s1.v[7]), "+v"(s2.v[0]), "+v"(s2.v[7]) : : "memory");
+    return;
+  }
+
+  // =============================================================== consumers: 2 x 2 waves of 64 (E) x 128 (D)
+  const int cw = wave - 4, wm = cw >> 1, wn = cw & 1;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const unsigned fa_hi = lds0 + ((kg * 2) * 128 + 16 * wm + r16) * 16, fa_lo = fa_hi + 2048;
+  const unsigned fb_hi = lds0 + SNA * WA_BYTES + ((kg * 2) * 256 + 32 * wn + r16) * 16, fb_lo = fb_hi + 4096;
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Fragments: A lo, A hi and two D-side slots P, Q (four blocks each).  Per k-step six units of 16 MFMAs, ordered so that a slot is
+  // refilled as soon as its last reader has issued and is needed again >= 256 cycles later:
+  //   u1 Alo x P(Bhi0)   u2 Alo x Q(Bhi1)   [Alo <- tile t+1]   u3 Ahi x P(Bhi0)   [P <- Blo0]   u4 Ahi x Q(Bhi1)   [Q <- Blo1]
+  //   u5 Ahi x P(Blo0)   [P <- Bhi0 of t+1]   u6 Ahi x Q(Blo1)   [Q <- Bhi1 of t+1, Ahi <- t+1]
+  f32x4 alo[4], ahi[4], P[4], Q[4];
+  __builtin_amdgcn_s_barrier();                               // #0
+  WS_READ4A(alo, fa_lo);
+  WS_READ4B(P, fb_hi);
+  WS_READ4B(Q, fb_hi + 256);
+  WS_READ4A(ahi, fa_hi);
+#pragma unroll 1
+  for (int t = 0; t < nk; ++t) {
+    const unsigned ca = (unsigned)((t % SNA) * WA_BYTES), cbo = (unsigned)((t % SNB) * WB_BYTES);
+    const unsigned na = (unsigned)(((t + 1) % SNA) * WA_BYTES), nb = (unsigned)(((t + 1) % SNB) * WB_BYTES);
+    const bool more = t + 1 < nk;                             // (past the end the prefetches re-read the last tile: harmless, keeps the counts)
+    const unsigned pa = more ? na : ca, pb = more ? nb : cbo;
+    WS_WAIT8(8, alo, P);
+    __builtin_amdgcn_sched_barrier(0);
+    ws_unit<0>(alo, P, acc);                                  // u1  lo*hi, column half 0
+    __builtin_amdgcn_sched_barrier(0);
+    WS_WAIT8(4, alo, Q);
+    __builtin_amdgcn_sched_barrier(0);
+    ws_unit<1>(alo, Q, acc);                                  // u2  lo*hi, half 1
+    __builtin_amdgcn_sched_barrier(0);
+    WS_READ4A(alo, fa_lo + pa);                               // tile t+1 was published by barrier #t
+    WS_WAIT8(4, ahi, P);
+    __builtin_amdgcn_sched_barrier(0);
+    ws_unit<0>(ahi, P, acc);                                  // u3  hi*hi, half 0
+    __builtin_amdgcn_sched_barrier(0);
+    WS_READ4B(P, fb_lo + cbo);
+    ws_unit<1>(ahi, Q, acc);                                  // u4  hi*hi, half 1
+    __builtin_amdgcn_sched_barrier(0);
+    WS_READ4B(Q, fb_lo + cbo + 256);
+    WS_WAIT8(4, ahi, P);
+    __builtin_amdgcn_sched_barrier(0);
+    ws_unit<0>(ahi, P, acc);                                  // u5  hi*lo, half 0
+    __builtin_amdgcn_sched_barrier(0);
+    WS_READ4B(P, fb_hi + pb);
+    WS_WAIT8(4, ahi, Q);
+    __builtin_amdgcn_sched_barrier(0);
+    ws_unit<1>(ahi, Q, acc);                                  // u6  hi*lo, half 1
+    __builtin_amdgcn_sched_barrier(0);
+    WS_READ4B(Q, fb_hi + pb + 256);
+    WS_READ4A(ahi, fa_hi + pa);
+    __builtin_amdgcn_s_barrier();                             // #t+1: tile t is retired, tile t+2 published
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // epilogue: block (ja, jq = 4 cb + jb) of a lane is row 4 (16 wm + 4 kg + e) + ja, column 4 (16 (2 wn + cb) + r16) + jb
+  float* out = g.out + (int64_t)slab * g.E * g.D;
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = i0 + 4 * (16 * wm + 4 * kg + e) + ja;
+        const int64_t n = n0 + 4 * (16 * (2 * wn + cb) + r16);
+        *reinterpret_cast<f32x4*>(out + i * g.D + n) =
+            f32x4{acc[ja][4 * cb + 0][e], acc[ja][4 * cb + 1][e], acc[ja][4 * cb + 2][e], acc[ja][4 * cb + 3][e]};
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // dPRE -> matrix-core image + column-sum partials.  One workgroup per (32-row k-step, 256 columns); thread -> (4 columns, one row
 // octet): 8 x (16 B of dH + 8 B of dact16) in flight per thread, ~10 waves per CU.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -433,6 +654,12 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   }
   const int64_t tiles = (a->E / WBI) * (a->D / WBN);
   dim3 grid((unsigned)(8 * tiles * cdiv(g.splits, 8) + side_blocks));
+  static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;        // (experiments: the uniform-wave form)
+  if (ws_form) {
+    const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
+    hipLaunchKernelGGL(bag_wgrad_ws_kernel, grid, dim3(WTHREADS), smem2, (hipStream_t)stream, g, side_blocks, side);
+  } else
   hipLaunchKernelGGL(bag_wgrad_kernel, grid, dim3(WTHREADS), smem, (hipStream_t)stream, g, side_blocks, side);
   MHIMX_LAUNCH_CHECK();
   if (!defer_push(defer, reduce_job_slabs(a->ws, g.splits, a->E, a->D, a->ldc, a->C, a->accumulate))) {
