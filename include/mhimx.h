@@ -290,6 +290,34 @@ int mhimx_resconv(void* stream, const float* v, int64_t ldv, const float* w, int
 int64_t mhimx_resconv_dw_ws_floats(int64_t T, int64_t C, int64_t dh, int64_t KS);
 int mhimx_resconv_dw(void* stream, const float* dout, int64_t ldo, const float* v, int64_t ldv, int64_t KS, int64_t dh, int64_t T,
                      int64_t C, float* dw, float* ws);
+/* The Nystrom attention block WITHOUT its n x m matrices (nystrom_attention.py:111-136): attn1 = softmax(q k~^T) and attn3 =
+ * softmax(q~ k^T) are never written; token tiles are streamed, scores recomputed from q / k with saved log-sum-exps (csrc/nys_flash.hip).
+ * 8 heads x 64 dims, 256 landmarks.  q, k, v: head h = 64 columns at +64h of a row of pitch ld (the packed to_qkv output); ql, kl: the
+ * landmark means [256, .] (row pitch ldl, head h at +64h); T tokens (multiple of 64); scale multiplies every score (nystrom:83).
+ * ws: >= mhimx_nys_ws_floats(T) floats.  Log-sum-exps are base 2 of the scaled scores: P = 2^(s * scale * log2 e - lse). */
+typedef struct mhimx_nys {
+  const float* q; const float* k; const float* v;
+  int64_t ld, T;
+  const float* ql; const float* kl;
+  int64_t ldl;
+  float scale;
+  float* ws;
+  int64_t ws_floats;
+} mhimx_nys;
+int64_t mhimx_nys_ws_floats(int64_t T);
+/* a3v[8,256,64] = softmax_n(scale q~ k^T) v  (nystrom:116,131 + the attn3 @ v of :133), lse3[8,256] */
+int mhimx_nys_a3v_fwd(void* stream, const mhimx_nys* a, float* a3v, float* lse3);
+/* out[T, 64h..] (row pitch ldo) = softmax_m(scale q k~^T) w2, w2[8,256,64] = pinv(attn2) a3v  (nystrom:114,129,133); lse1[8,T] */
+int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* w2, float* out, int64_t ldo, float* lse1);
+/* its backward: dq (into [T, 64h..], pitch lddq), dkl (landmark layout, pitch lddl; the S1 term only), dw2[8,256,64];
+ * delta1[8,T] is scratch (rowsum(P dP)). */
+int mhimx_nys_out_bwd(void* stream, const mhimx_nys* a, const float* w2, const float* dout, int64_t ldd, const float* lse1,
+                      float* delta1, float* dq, int64_t lddq, float* dkl, int64_t lddl, float* dw2);
+/* backward of a3v: dk (=), dv (= or += when accumulate_dv), both pitch lddk, dql (landmark layout, pitch lddl; the S3 term only) */
+int mhimx_nys_a3v_bwd(void* stream, const mhimx_nys* a, const float* a3v, const float* da3v, const float* lse3, float* dk, float* dv,
+                      int64_t lddk, int32_t accumulate_dv, float* dql, int64_t lddl);
+/* r[8,T] = u attn3 with u[8,256] = attn1[cls] pinv: the cls token's attention row (nystrom:143-150) */
+int mhimx_nys_cls_attn(void* stream, const mhimx_nys* a, const float* lse3, const float* u, float* r);
 /* PPEG (emb_position.py:85-120).  combine: wc[C,49] = w7 + pad(w5) + pad(w3) + identity, bc = b7+b5+b3;
  * fwd: y[N,C] = depth-wise 7x7 stencil of the wrap-padded H x H token grid; bwd: dx, dwc [C,49], dbc [C]. */
 int mhimx_ppeg_combine(void* stream, const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,

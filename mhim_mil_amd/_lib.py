@@ -131,6 +131,15 @@ _I64 = C.c_int64
 _I32 = C.c_int32
 _F = C.c_float
 _U64 = C.c_uint64
+
+
+class Nys(C.Structure):
+    """mhimx_nys (include/mhimx.h): the streamed Nystrom attention's operands."""
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ld", C.c_int64), ("T", C.c_int64),
+                ("ql", C.c_void_p), ("kl", C.c_void_p), ("ldl", C.c_int64), ("scale", C.c_float),
+                ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
+
+
 SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
@@ -190,6 +199,12 @@ SYMBOLS = {
     "mhimx_axpby": (C.c_int, [_P, _P, _P, _I64, _F, _F]),
     "mhimx_pinv_init": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "mhimx_pinv_init_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "mhimx_nys_ws_floats": (_I64, [_I64]),
+    "mhimx_nys_a3v_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P]),
+    "mhimx_nys_out_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P]),
+    "mhimx_nys_out_bwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P]),
+    "mhimx_nys_a3v_bwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _P, _P, _P, _I64, _I32, _P, _I64]),
+    "mhimx_nys_cls_attn": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _P]),
     "mhimx_resconv": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I32, _I32]),
     "mhimx_resconv_dw_ws_floats": (_I64, [_I64, _I64, _I64, _I64]),
     "mhimx_resconv_dw": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P, _P]),

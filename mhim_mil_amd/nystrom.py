@@ -315,10 +315,11 @@ class MatmulAffine(torch.autograd.Function):
 class NystromCore(torch.autograd.Function):
     """The attention block between to_qkv and to_out (nystrom_attention.py:93-136) as ONE autograd node with a hand-written backward:
     landmark means, the three score products, their softmaxes, the pseudo-inverse, a1 (pinv (a3 v)) and the residual convolution.
-    qkv is read by five of these; as separate autograd nodes each backward zero-filled a [T, 1536] gradient and torch summed the five
-    (~1.5 ms of fills and adds per c3 step).  Here every gradient lands in ONE dqkv buffer through the kernels' accumulate flags, the
-    softmaxes run in place, and no torch arithmetic touches token data.
-    Returns (out [T, 512], a1, z, a3) - the last three (not differentiable) for the cls-row attention map of return_attn."""
+    attn1 [n, 256] and attn3 [256, n] are NEVER materialised (csrc/nys_flash.hip): a3 v is an online-softmax pass over the tokens,
+    a1 w2 a second pass, and the backward recomputes every score tile from q / k with the saved log-sum-exps (two passes per product:
+    one for the token-side gradients, one for the landmark-side reductions).  Every gradient lands in ONE dqkv buffer; no torch
+    arithmetic touches token data.
+    Returns (out [T, 512], lm, z, lse3) - the last three (not differentiable) for the cls-row attention map of return_attn."""
 
     @staticmethod
     def forward(ctx, qkv, conv_w, l, scale):
@@ -327,15 +328,11 @@ class NystromCore(torch.autograd.Function):
         m, dev = LANDMARKS, qkv.device
         lm = torch.empty((m, 2 * INNER), device=dev)
         L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
-        q, k, v = Op(qkv, 0, DH, ld, T, DH), Op(qkv, INNER, DH, ld, T, DH), Op(qkv, 2 * INNER, DH, ld, T, DH)
         ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
-        a1, a2, a3 = torch.empty((HEADS, T, m), device=dev), torch.empty((HEADS, m, m), device=dev), torch.empty((HEADS, m, T), device=dev)
-        _heads_mm("nt", q, kl, batched(a1), HEADS)                        # q k~^T        nystrom:114
+        no = ops.NysOperands(qkv, lm, scale)
+        a2 = torch.empty((HEADS, m, m), device=dev)
         _heads_mm("nt", ql, kl, batched(a2), HEADS)                       # q~ k~^T       nystrom:115
-        _heads_mm("nt", ql, k, batched(a3), HEADS)                        # q~ k^T        nystrom:116
-        for t_ in (a1, a2, a3):                                           # softmax(scale * s), in place
-            Lr = t_.shape[-1]
-            L.check(lib.mhimx_softmax_rows(_st(), _ptr(t_), _ptr(t_), t_.numel() // Lr, Lr, float(scale)), "softmax_rows")
+        L.check(lib.mhimx_softmax_rows(_st(), _ptr(a2), _ptr(a2), HEADS * m, m, float(scale)), "softmax_rows")
         # pseudo-inverse (nystrom_attention.py:12-27): z0 = a2^T / (max col sum * max row sum), six iterations, every intermediate kept
         z = torch.empty_like(a2)
         stats = torch.empty(4, device=dev)
@@ -351,33 +348,30 @@ class NystromCore(torch.autograd.Function):
             zn = _bmm_affine("nn", z, t3, torch.empty_like(a2), 0.25, 0.0)
             chain.append((z, az, t1, t2, t3))
             z = zn
-        a3v, w2 = torch.empty((HEADS, m, DH), device=dev), torch.empty((HEADS, m, DH), device=dev)
-        _heads_mm("nn", batched(a3), v, batched(a3v), HEADS)              # a3 v
+        a3v, lse3 = ops.nys_a3v_fwd(no)                                    # softmax_n(q~ k^T) v   nystrom:116,131,133
+        w2 = torch.empty((HEADS, m, DH), device=dev)
         _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
-        out = torch.empty((T, INNER), device=dev)
-        _heads_mm("nn", batched(a1), batched(w2), Op(out, 0, DH, INNER, T, DH), HEADS)        # a1 (pinv a3 v) -> [T, (h d)]
+        out, lse1 = ops.nys_out_fwd(no, w2)                                # softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
         wc = conv_w.reshape(HEADS, -1).contiguous()
         L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 1, 0),
                 "resconv")                                                # out += res_conv(v)   nystrom:135-136
-        ctx.saved = (qkv, lm, a1, a2, a3, z, z0, stats, chain, a3v, w2, wc)
+        ctx.saved = (qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws)
         ctx.cfg = (l, scale, conv_w.shape)
-        ctx.mark_non_differentiable(a1, z, a3)
-        return out, a1, z, a3
+        ctx.mark_non_differentiable(lm, z, lse3)
+        return out, lm, z, lse3
 
     @staticmethod
     def backward(ctx, dout, _g1, _g2, _g3):
         lib = L.lib()
-        qkv, lm, a1, a2, a3, z, z0, stats, chain, a3v, w2, wc = ctx.saved
+        qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws = ctx.saved
         ctx.saved = None
         l, scale, wshape = ctx.cfg
         dout = dout.contiguous()
         T, ld = qkv.shape
         m, dev, KS = LANDMARKS, qkv.device, wc.shape[1]
-        q, k, v = Op(qkv, 0, DH, ld, T, DH), Op(qkv, INNER, DH, ld, T, DH), Op(qkv, 2 * INNER, DH, ld, T, DH)
         ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
-        do = Op(dout, 0, DH, INNER, T, DH)
+        no = ops.NysOperands(qkv, lm, scale, ws=nws)
         dqkv = torch.empty_like(qkv)                                       # every column block is written before it is added to
-        dq, dk, dv = q.like(dqkv), k.like(dqkv), v.like(dqkv)
         dlm = torch.empty_like(lm)
         dql, dkl = ql.like(dlm), kl.like(dlm)
         # residual convolution: dv = flip-conv(dout), d(conv weight)
@@ -385,20 +379,15 @@ class NystromCore(torch.autograd.Function):
         dwc = torch.empty_like(wc)
         ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(T, INNER, DH, KS), device=dev)
         L.check(lib.mhimx_resconv_dw(_st(), _ptr(dout), INNER, _ptr(qkv, 2 * INNER), ld, KS, DH, T, INNER, _ptr(dwc), _ptr(ws)), "resconv_dw")
-        # out = a1 w2
-        da1 = torch.empty_like(a1)
-        _heads_mm("nt", do, batched(w2), batched(da1), HEADS)              # da1 = dout w2^T
-        dw2 = torch.empty_like(w2)
-        _heads_mm("tn", batched(a1), do, batched(dw2), HEADS)              # dw2 = a1^T dout
+        # out = a1 w2: dq, the S1 term of dk~, dw2 = a1^T dout
+        dw2 = ops.nys_out_bwd(no, w2, dout, lse1, dqkv, dlm)
         # w2 = z a3v
         dz = torch.empty_like(z)
         _heads_mm("nt", batched(dw2), batched(a3v), batched(dz), HEADS)    # dz = dw2 a3v^T
         da3v = torch.empty_like(a3v)
         _heads_mm("tn", batched(z), batched(dw2), batched(da3v), HEADS)    # da3v = z^T dw2
-        # a3v = a3 v
-        da3 = torch.empty_like(a3)
-        _heads_mm("nt", batched(da3v), v, batched(da3), HEADS)             # da3 = da3v v^T
-        _heads_mm("tn", batched(a3), batched(da3v), dv, HEADS, accumulate=True)   # dv += a3^T da3v
+        # a3v = a3 v: dk, dv +=, the S3 term of dq~
+        ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, accumulate_dv=True)
         # pseudo-inverse, backwards through the six iterations
         da2 = torch.empty_like(a2)
         first = True
@@ -417,17 +406,10 @@ class NystromCore(torch.autograd.Function):
         ws2 = torch.empty(256, device=dev)
         L.check(lib.mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z0), _ptr(stats), HEADS, m, _ptr(dinit), _ptr(ws2)), "pinv_init_bwd")
         L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
-        # softmax backward, in place on the gradient buffers
-        for y_, g_ in ((a1, da1), (a2, da2), (a3, da3)):
-            Lr = y_.shape[-1]
-            L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(y_), _ptr(g_), _ptr(g_), y_.numel() // Lr, Lr, float(scale)), "softmax_rows_bwd")
-        ds1, ds2, ds3 = batched(da1), batched(da2), batched(da3)
-        _heads_mm("nn", ds1, kl, dq, HEADS)                                # s1 = q k~^T : dq = ds1 k~
-        _heads_mm("tn", ds1, q, dkl, HEADS)                                #               dk~ = ds1^T q
-        _heads_mm("nn", ds2, kl, dql, HEADS)                               # s2 = q~ k~^T: dq~ = ds2 k~
+        L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(a2), _ptr(da2), _ptr(da2), HEADS * m, m, float(scale)), "softmax_rows_bwd")
+        ds2 = batched(da2)
+        _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=True)              # s2 = q~ k~^T: dq~ += ds2 k~
         _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
-        _heads_mm("nn", ds3, k, dql, HEADS, accumulate=True)               # s3 = q~ k^T : dq~ += ds3 k
-        _heads_mm("tn", ds3, ql, dk, HEADS)                                #               dk = ds3^T q~
         L.check(lib.mhimx_landmark_mean_bwd(_st(), _ptr(dlm), T, l, 2 * INNER, _ptr(dqkv), ld, 1), "landmark_mean_bwd")
         return dqkv, dwc.reshape(wshape), None, None
 
@@ -573,15 +555,18 @@ class NystromAttention(nn.Module):
         p = self.dropout if training else 0.0
         if _PREC != "f32" and not (return_attn and no_norm):
             # one autograd node for the whole block (hand-written backward, no torch arithmetic on token data)
-            out, a1, z, a3 = NystromCore.apply(qkv, self.res_conv.weight, l, self.scale)
+            out, lm, z, lse3 = NystromCore.apply(qkv, self.res_conv.weight, l, self.scale)
             y = Linear.apply(out[pad:], self.to_out[0].weight, self.to_out[0].bias, p, seed, tick)   # last n rows (nystrom:142)
             if not return_attn:
                 return y
             with torch.no_grad():                                              # nystrom:143-150: the cls token's attention row
+                a1c = torch.empty((HEADS, 1, m), device=x.device)              # attn1's cls row: softmax(scale q_cls k~^T)
+                _heads_mm("nt", Op(qkv, pad * ld, DH, ld, 1, DH), Op(lm, INNER, DH, 2 * INNER, m, DH), batched(a1c), HEADS)
+                L.check(L.lib().mhimx_softmax_rows(_st(), _ptr(a1c), _ptr(a1c), HEADS, m, float(self.scale)), "softmax_rows")
                 bat = lambda r, c: (0, r * c, c, r, c)
-                u = heads_mm(a1[:, pad:pad + 1].contiguous(), z, "nn", bat(1, m), bat(m, m), (HEADS, 1, m), bat(1, m))
-                r = heads_mm(u, a3, "nn", bat(1, m), bat(m, T), (HEADS, 1, T), bat(1, T))
-                return y, r[:, 0, pad + 1:], qkv[pad + 1:, 2 * INNER:]
+                u = heads_mm(a1c, z, "nn", bat(1, m), bat(m, m), (HEADS, 1, m), bat(1, m))
+                r = ops.nys_cls_attn(ops.NysOperands(qkv, lm, self.scale), lse3, u.reshape(HEADS, m).contiguous())
+                return y, r[:, pad + 1:], qkv[pad + 1:, 2 * INNER:]
         lm = Landmarks.apply(qkv, l)                                          # [256, 1024]: q~ | k~
         q_d, k_d, v_d = (0, DH, ld, T, DH), (INNER, DH, ld, T, DH), (2 * INNER, DH, ld, T, DH)
         ql_d, kl_d = (0, DH, 2 * INNER, m, DH), (INNER, DH, 2 * INNER, m, DH)

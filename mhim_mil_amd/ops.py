@@ -572,3 +572,67 @@ def cls_metrics(logits, labels, n_classes, bin_metric=False, sample_idx=None):
     L.check(L.lib().mhimx_cls_metrics(_stream(), _p(logits), logits.stride(0), _p(labels), n, Cc, int(bool(bin_metric)), _p(sample_idx), B,
                                       _p(out), _p(ws), ws.numel()), "mhimx_cls_metrics")
     return out
+
+
+# ------------------------------------------------------------------------------------------- streamed Nystrom attention
+class NysOperands:
+    """mhimx_nys: the packed to_qkv output qkv [T, 1536] (q | k | v, heads = 64-column groups), the landmark means lm [256, 1024]
+    (q~ | k~) and a workspace; keeps the tensors alive as long as the struct."""
+
+    def __init__(self, qkv, lm, scale, ws=None):
+        _chk(qkv, name="qkv"); _chk(lm, name="lm")
+        T, ld = qkv.shape
+        if ld != 1536 or tuple(lm.shape) != (256, 1024):
+            raise L.MhimxError("nys: qkv must be [T, 1536] and lm [256, 1024] (8 heads x 64, 256 landmarks)")
+        n = L.lib().mhimx_nys_ws_floats(T)
+        self.ws = ws if ws is not None and ws.numel() >= n else torch.empty(n, device=qkv.device)
+        self.qkv, self.lm, self.T = qkv, lm, T
+        b = qkv.data_ptr()
+        self.c = L.Nys(q=b, k=b + 512 * 4, v=b + 1024 * 4, ld=ld, T=T, ql=lm.data_ptr(), kl=lm.data_ptr() + 512 * 4, ldl=1024,
+                       scale=float(scale), ws=self.ws.data_ptr(), ws_floats=self.ws.numel())
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def nys_a3v_fwd(o: NysOperands):
+    """a3v [8,256,64] = softmax_n(scale q~ k^T) v and the base-2 log-sum-exp of its rows [8,256]."""
+    a3v = torch.empty((8, 256, 64), device=o.qkv.device)
+    lse3 = torch.empty((8, 256), device=o.qkv.device)
+    L.check(L.lib().mhimx_nys_a3v_fwd(_stream(), o.ref(), _p(a3v), _p(lse3)), "mhimx_nys_a3v_fwd")
+    return a3v, lse3
+
+
+def nys_out_fwd(o: NysOperands, w2, out=None):
+    """out [T, 512] = softmax_m(scale q k~^T) w2 (heads side by side), lse1 [8, T]."""
+    _chk(w2, name="w2")
+    out = torch.empty((o.T, 512), device=w2.device) if out is None else out
+    lse1 = torch.empty((8, o.T), device=w2.device)
+    L.check(L.lib().mhimx_nys_out_fwd(_stream(), o.ref(), _p(w2), _p(out), out.stride(0), _p(lse1)), "mhimx_nys_out_fwd")
+    return out, lse1
+
+
+def nys_out_bwd(o: NysOperands, w2, dout, lse1, dqkv, dlm):
+    """Writes dq into dqkv[:, :512] and the S1 term of dk~ into dlm[:, 512:]; returns dw2 [8,256,64]."""
+    _chk(dout, name="dout")
+    dw2 = torch.empty_like(w2)
+    delta = torch.empty_like(lse1)
+    L.check(L.lib().mhimx_nys_out_bwd(_stream(), o.ref(), _p(w2), _p(dout), dout.stride(0), _p(lse1), _p(delta), _p(dqkv), dqkv.stride(0),
+                                       C.c_void_p(dlm.data_ptr() + 512 * 4), dlm.stride(0), _p(dw2)), "mhimx_nys_out_bwd")
+    return dw2
+
+
+def nys_a3v_bwd(o: NysOperands, a3v, da3v, lse3, dqkv, dlm, accumulate_dv):
+    """Writes dk into dqkv[:, 512:1024], dv (= or +=) into dqkv[:, 1024:], the S3 term of dq~ into dlm[:, :512]."""
+    _chk(da3v, name="da3v")
+    b = dqkv.data_ptr()
+    L.check(L.lib().mhimx_nys_a3v_bwd(_stream(), o.ref(), _p(a3v), _p(da3v), _p(lse3), C.c_void_p(b + 512 * 4), C.c_void_p(b + 1024 * 4),
+                                       dqkv.stride(0), int(bool(accumulate_dv)), _p(dlm), dlm.stride(0)), "mhimx_nys_a3v_bwd")
+
+
+def nys_cls_attn(o: NysOperands, lse3, u):
+    """r [8, T] = u attn3 (u [8, 256]): the cls token's attention row without attn3."""
+    _chk(u, name="u")
+    r = torch.empty((8, o.T), device=u.device)
+    L.check(L.lib().mhimx_nys_cls_attn(_stream(), o.ref(), _p(lse3), _p(u), _p(r)), "mhimx_nys_cls_attn")
+    return r
