@@ -9,9 +9,10 @@
 //   and the cls token's attention row  r = (attn1[cls] pinv) attn3  (nystrom:143-150) : ny_cls_attn.
 // Every score tile is recomputed from q / k (K = 64: cheap) with the saved log-sum-exps; nothing of size n x 256 touches HBM.
 //
-// One scheme for all of them.  A workgroup = (head, token chunk), 4 waves; wave w OWNS landmarks 64w .. 64w+63 and keeps the
-// landmark-side operands of its products in REGISTERS for the whole chunk as ready bf16 hi/lo MFMA fragments ("LM" fragments: rows =
-// landmarks, k = the 64 head dims; "LT" fragments: rows = head dims, k = its 64 landmarks).  Token tiles (64 tokens x 64 dims of q / k /
+// One scheme for all of them.  A workgroup = (head, token chunk), 8 waves (two per SIMD: one wave's exp / split VALU phase runs under
+// the other's MFMAs); wave w OWNS landmarks 32w .. 32w+31 and keeps the landmark-side operands of its products in REGISTERS for the
+// whole chunk as ready bf16 hi/lo MFMA fragments ("LM" fragments: rows = landmarks, k = the 64 head dims; "LT" fragments: rows = head
+// dims, k = its 32 landmarks = one MFMA k-step).  Token tiles (64 tokens x 64 dims of q / k /
 // v / dout) are split to bf16 hi/lo ONCE by the loading threads and staged in LDS as fragment images: "RM" (index = token, k = dims)
 // and "TR" (index = dim, k = tokens), 1 KiB per fragment = 64 lanes x 16 B contiguous (conflict-free ds_read_b128).
 // v_mfma_f32_16x16x32_bf16: A/B lane = (index lane & 15, k-octet lane >> 4), C lane = (col lane & 15, rows 4 (lane >> 4) + i).
@@ -25,31 +26,12 @@
 // Sums across the four waves (softmax statistics, partial outputs) go through LDS in a FIXED order: results are run-to-run identical.
 #include <string.h>
 
-#include "mma_tile.hpp"
+#include "nys_args.hpp"
 
 namespace mhimx {
 
-constexpr int NY_H = 8, NY_D = 64, NY_M = 256, NY_TT = 64, NY_THREADS = 256, NY_MAXCH = 32;
-constexpr int NY_IMG = 16384;                        // one fragment image of a 64 x 64 tile (hi + lo)
-constexpr int NY_PART = NY_M * NY_D;                 // floats of one [256, 64] partial
+constexpr int NY_THREADS = 512, NY_NW = 8, NY_LB = 2;
 
-struct NyArgs {
-  const float* q; const float* k; const float* v;
-  int64_t ld, T;
-  const float* ql; const float* kl; int64_t ldl;
-  float scale, sl2e;                                 // sl2e = scale * log2(e): P = exp2(s * sl2e - lse2)
-  int nch;
-  // per entry point
-  const float* w2; const float* dout; int64_t ldd;
-  const float* lse1; float* lse1_o; float* delta; const float* delta_i;
-  const float* lse3; const float* delta3; const float* da3v; const float* u;
-  float* out; int64_t ldo;
-  float* out2; int64_t ldo2;
-  float* part; float* part2;
-  int accumulate;
-};
-
-#define NY_EXP2(x) __builtin_amdgcn_exp2f(x)
 MHIMX_DEV float ny_kgsum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
 MHIMX_DEV float ny_kgmax(float v) { v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32)); return v; }
 
@@ -69,40 +51,47 @@ MHIMX_DEV void ny_split44(const f32x4& a, const f32x4& b, f32x4& hi, f32x4& lo) 
   ny_split8(v, hi, lo);
 }
 
-// ---- token tile: thread = (token pair p = tid >> 3, dim octet g = tid & 7); r[0..1] = token 2p dims 8g..8g+7, r[2..3] = token 2p+1
-MHIMX_DEV void ny_load(const float* base, int64_t ld, int64_t t0, int tid, f32x4 (&r)[4]) {
-  const float* p = base + (t0 + 2 * (tid >> 3)) * ld + 8 * (tid & 7);
+// ---- token tile: thread = (token pair p = tid >> 4, dim quad g = tid & 15); r[0] = token 2p dims 4g..4g+3, r[1] = token 2p+1
+MHIMX_DEV void ny_load(const float* base, int64_t ld, int64_t t0, int tid, f32x4 (&r)[2]) {
+  const float* p = base + (t0 + 2 * (tid >> 4)) * ld + 4 * (tid & 15);
   r[0] = *reinterpret_cast<const f32x4*>(p);
-  r[1] = *reinterpret_cast<const f32x4*>(p + 4);
-  r[2] = *reinterpret_cast<const f32x4*>(p + ld);
-  r[3] = *reinterpret_cast<const f32x4*>(p + ld + 4);
+  r[1] = *reinterpret_cast<const f32x4*>(p + ld);
 }
-// RM image: fragment (tb, ks, hl) at ((tb*2 + ks)*2 + hl) KiB, lane (token & 15, dim octet & 3) x 16 B
-MHIMX_DEV void ny_store_rm(char* img, int tid, const f32x4 (&r)[4]) {
-  const int g = tid & 7, t = 2 * (tid >> 3);
-  f32x4 hi, lo;
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+MHIMX_DEV void ny_split4(const f32x4& a, bf4& hi, bf4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const __bf16 h = (__bf16)a[q];
+    hi[q] = h;
+    lo[q] = (__bf16)(a[q] - (float)h);
+  }
+}
+// RM image: fragment (tb, ks, hl) at ((tb*2 + ks)*2 + hl) KiB, lane (token & 15, dim octet & 3) x 16 B (a thread owns half a slot)
+MHIMX_DEV void ny_store_rm(char* img, int tid, const f32x4 (&r)[2]) {
+  const int g = tid & 15, t = 2 * (tid >> 4);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    ny_split44(r[2 * e], r[2 * e + 1], hi, lo);
-    char* p = img + ((((t + e) >> 4) * 2 + (g >> 2)) * 2) * 1024 + ((g & 3) * 16 + ((t + e) & 15)) * 16;
-    *reinterpret_cast<f32x4*>(p) = hi;
-    *reinterpret_cast<f32x4*>(p + 1024) = lo;
+    bf4 hi, lo;
+    ny_split4(r[e], hi, lo);
+    char* p = img + ((((t + e) >> 4) * 2 + (g >> 3)) * 2) * 1024 + (((g >> 1) & 3) * 16 + ((t + e) & 15)) * 16 + (g & 1) * 8;
+    *reinterpret_cast<bf4*>(p) = hi;
+    *reinterpret_cast<bf4*>(p + 1024) = lo;
   }
 }
 // TR image: fragment (db, ts, hl) at ((db*2 + ts)*2 + hl) KiB, lane (dim & 15, kg) x 16 B; token u of a 32-token step sits in
 // k-octet kg = (u & 15) >> 2 at slot j = 4 (u >> 4) + (u & 3) - the order of an accumulator pair
-MHIMX_DEV void ny_store_tr(char* img, int tid, const f32x4 (&r)[4]) {
-  const int g = tid & 7, t = 2 * (tid >> 3), u = t & 31;
+MHIMX_DEV void ny_store_tr(char* img, int tid, const f32x4 (&r)[2]) {
+  const int g = tid & 15, t = 2 * (tid >> 4), u = t & 31;
   const int j = 4 * (u >> 4) + (u & 3), kgt = (u & 15) >> 2;
-  char* base = img + (((g >> 1) * 2 + (t >> 5)) * 2) * 1024 + (kgt * 16 + (g & 1) * 8) * 16 + j * 2;
+  char* base = img + (((g >> 2) * 2 + (t >> 5)) * 2) * 1024 + (kgt * 16 + (g & 3) * 4) * 16 + j * 2;
+  bf4 ah, al, bh, bl;
+  ny_split4(r[0], ah, al);
+  ny_split4(r[1], bh, bl);
 #pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    const float a = r[x >> 2][x & 3], b = r[2 + (x >> 2)][x & 3];
-    const __bf16 ah = (__bf16)a, bh = (__bf16)b;
-    const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  for (int x = 0; x < 4; ++x) {
     bf2 h2, l2;
-    h2[0] = ah; h2[1] = bh; l2[0] = al; l2[1] = bl;
+    h2[0] = ah[x]; h2[1] = bh[x]; l2[0] = al[x]; l2[1] = bl[x];
     *reinterpret_cast<bf2*>(base + x * 16) = h2;
     *reinterpret_cast<bf2*>(base + x * 16 + 1024) = l2;
   }
@@ -112,30 +101,27 @@ MHIMX_DEV f32x4 ny_frag(const char* img, int blk, int step, int hl, int lane) {
 }
 
 // ---- landmark-side fragments (global fp32 -> registers), M = [256, 64] of this head with row pitch ldm, the wave's landmarks at lm0
-struct NyFrag { f32x4 h[4][2], l[4][2]; };
-// LM: [lb][ks] : lane (c, kg) holds M[lm0 + 16 lb + c][32 ks + 8 kg .. +7]
-MHIMX_DEV void ny_lm_frags(const float* M, int64_t ldm, int lm0, int lane, NyFrag& f) {
+struct NyLM { f32x4 h[NY_LB][2], l[NY_LB][2]; };   // [lb][ks] : lane (c, kg) holds M[lm0 + 16 lb + c][32 ks + 8 kg .. +7]
+struct NyLT { f32x4 h[4], l[4]; };                 // [db]     : lane (c, kg) holds M[lm0 + 16 blk + 4 kg + i][16 db + c] at slot 4 blk + i
+MHIMX_DEV void ny_lm_frags(const float* M, int64_t ldm, int lm0, int lane, NyLM& f) {
   const int c = lane & 15, kg = lane >> 4;
 #pragma unroll
-  for (int lb = 0; lb < 4; ++lb)
+  for (int lb = 0; lb < NY_LB; ++lb)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const float* p = M + (int64_t)(lm0 + 16 * lb + c) * ldm + 32 * ks + 8 * kg;
       ny_split44(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), f.h[lb][ks], f.l[lb][ks]);
     }
 }
-// LT: [db][s] : lane (c, kg) holds M[lm0 + 32 s + 16 blk + 4 kg + i][16 db + c] at slot 4 blk + i
-MHIMX_DEV void ny_lt_frags(const float* M, int64_t ldm, int lm0, int lane, NyFrag& f) {
+MHIMX_DEV void ny_lt_frags(const float* M, int64_t ldm, int lm0, int lane, NyLT& f) {
   const int c = lane & 15, kg = lane >> 4;
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < 4; ++db) {
+    float v[8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = M[(int64_t)(lm0 + 32 * s + 16 * (j >> 2) + 4 * kg + (j & 3)) * ldm + 16 * db + c];
-      ny_split8(v, f.h[db][s], f.l[db][s]);
-    }
+    for (int j = 0; j < 8; ++j) v[j] = M[(int64_t)(lm0 + 16 * (j >> 2) + 4 * kg + (j & 3)) * ldm + 16 * db + c];
+    ny_split8(v, f.h[db], f.l[db]);
+  }
 }
 
 // c[j] += a x b[j], j < NB, 3 bf16 terms, term-major (NB independent MFMAs between two on the same accumulator)
@@ -148,11 +134,6 @@ MHIMX_DEV void ny_mma_a(const f32x4& ah, const f32x4& al, const f32x4 (&bh)[NB],
 #pragma unroll
   for (int j = 0; j < NB; ++j) c[j] = mt_mfma(ah, bh[j], c[j]);
 }
-MHIMX_DEV void ny_mma1(const f32x4& ah, const f32x4& al, const f32x4& bh, const f32x4& bl, f32x4& c) {
-  c = mt_mfma(al, bh, c);
-  c = mt_mfma(ah, bl, c);
-  c = mt_mfma(ah, bh, c);
-}
 
 MHIMX_DEV void ny_chunk(const NyArgs& g, int ch, int& t_begin, int& t_end) {
   const int64_t tiles = g.T / NY_TT;
@@ -162,6 +143,12 @@ MHIMX_DEV void ny_chunk(const NyArgs& g, int ch, int& t_begin, int& t_end) {
 
 #define NY_ZERO(a, n1, n2)                \
   _Pragma("unroll") for (int _i = 0; _i < n1; ++_i) _Pragma("unroll") for (int _j = 0; _j < n2; ++_j) a[_i][_j] = f32x4{0.f, 0.f, 0.f, 0.f}
+#define NY_IDS                                                                                              \
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;                \
+  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 16 * NY_LB * w;                                          \
+  int t_begin, t_end;                                                                                       \
+  ny_chunk(g, ch, t_begin, t_end);                                                                          \
+  (void)c; (void)kg
 
 // ===========================================================================================================================
 // forward 1: a3v partials.  landmark-column: S[tb][lb] = RM(k) x LM(q~); online softmax per landmark (= per lane column);
@@ -169,20 +156,17 @@ MHIMX_DEV void ny_chunk(const NyArgs& g, int ch, int& t_begin, int& t_end) {
 // ===========================================================================================================================
 __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
   __shared__ __attribute__((aligned(16))) char sm[2 * NY_IMG];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
-  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
-  int t_begin, t_end;
-  ny_chunk(g, ch, t_begin, t_end);
-  NyFrag qf;
+  NY_IDS;
+  NyLM qf;
   ny_lm_frags(g.ql + h * NY_D, g.ldl, lm0, lane, qf);
-  f32x4 o[4][4];
-  NY_ZERO(o, 4, 4);
-  float m[4], l[4];
+  f32x4 o[4][NY_LB];
+  NY_ZERO(o, 4, NY_LB);
+  float m[NY_LB], l[NY_LB];
 #pragma unroll
-  for (int lb = 0; lb < 4; ++lb) { m[lb] = -__builtin_inff(); l[lb] = 0.f; }
+  for (int lb = 0; lb < NY_LB; ++lb) { m[lb] = -__builtin_inff(); l[lb] = 0.f; }
   const float* kb = g.k + h * NY_D;
   const float* vb = g.v + h * NY_D;
-  f32x4 rk[4], rv[4];
+  f32x4 rk[2], rv[2];
   ny_load(kb, g.ld, (int64_t)t_begin * NY_TT, tid, rk);
   ny_load(vb, g.ld, (int64_t)t_begin * NY_TT, tid, rv);
   for (int t = t_begin; t < t_end; ++t) {
@@ -194,20 +178,18 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
       ny_load(kb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rk);
       ny_load(vb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rv);
     }
-    f32x4 s[4][4];                                            // [tb][lb]
-    NY_ZERO(s, 4, 4);
+    f32x4 s[4][NY_LB];                                        // [tb][lb]
+    NY_ZERO(s, 4, NY_LB);
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb)
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 bh[NY_LB], bl[NY_LB];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const f32x4 ah = ny_frag(sm, tb, ks, 0, lane), al = ny_frag(sm, tb, ks, 1, lane);
-        f32x4 bh[4], bl[4];
+      for (int lb = 0; lb < NY_LB; ++lb) { bh[lb] = qf.h[lb][ks]; bl[lb] = qf.l[lb][ks]; }
 #pragma unroll
-        for (int lb = 0; lb < 4; ++lb) { bh[lb] = qf.h[lb][ks]; bl[lb] = qf.l[lb][ks]; }
-        ny_mma_a<4>(ah, al, bh, bl, s[tb]);
-      }
+      for (int tb = 0; tb < 4; ++tb) ny_mma_a<NY_LB>(ny_frag(sm, tb, ks, 0, lane), ny_frag(sm, tb, ks, 1, lane), bh, bl, s[tb]);
+    }
 #pragma unroll
-    for (int lb = 0; lb < 4; ++lb) {
+    for (int lb = 0; lb < NY_LB; ++lb) {
       float mx = s[0][lb][0];
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb)
@@ -217,12 +199,13 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
       const float mn = fmaxf(m[lb], mx);
       const float alpha = NY_EXP2((m[lb] - mn) * g.sl2e);
       m[lb] = mn;
+      const float off = mn * g.sl2e;
       float sum = 0.f;
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p = NY_EXP2((s[tb][lb][i] - mn) * g.sl2e);
+          const float p = NY_EXP2(fmaf(s[tb][lb][i], g.sl2e, -off));
           s[tb][lb][i] = p;
           sum += p;
         }
@@ -232,24 +215,22 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
     }
 #pragma unroll
     for (int ts = 0; ts < 2; ++ts) {
-      f32x4 ph[4], pl[4];
+      f32x4 ph[NY_LB], pl[NY_LB];
 #pragma unroll
-      for (int lb = 0; lb < 4; ++lb) ny_split44(s[2 * ts][lb], s[2 * ts + 1][lb], ph[lb], pl[lb]);
+      for (int lb = 0; lb < NY_LB; ++lb) ny_split44(s[2 * ts][lb], s[2 * ts + 1][lb], ph[lb], pl[lb]);
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const f32x4 ah = ny_frag(sm + NY_IMG, db, ts, 0, lane), al = ny_frag(sm + NY_IMG, db, ts, 1, lane);
-        ny_mma_a<4>(ah, al, ph, pl, o[db]);
-      }
+      for (int db = 0; db < 4; ++db)
+        ny_mma_a<NY_LB>(ny_frag(sm + NY_IMG, db, ts, 0, lane), ny_frag(sm + NY_IMG, db, ts, 1, lane), ph, pl, o[db]);
     }
   }
   float* pp = g.part + ((int64_t)h * g.nch + ch) * (NY_PART + 2 * NY_M);
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int lb = 0; lb < 4; ++lb) *reinterpret_cast<f32x4*>(pp + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = o[db][lb];
+    for (int lb = 0; lb < NY_LB; ++lb) *reinterpret_cast<f32x4*>(pp + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = o[db][lb];
   if (kg == 0) {
 #pragma unroll
-    for (int lb = 0; lb < 4; ++lb) {
+    for (int lb = 0; lb < NY_LB; ++lb) {
       pp[NY_PART + lm0 + 16 * lb + c] = m[lb];
       pp[NY_PART + NY_M + lm0 + 16 * lb + c] = l[lb];
     }
@@ -277,239 +258,22 @@ __global__ __launch_bounds__(256) void ny_a3v_merge_kernel(const float* part, in
 }
 
 // ===========================================================================================================================
-// forward 2: out = softmax_m(q k~^T) w2.   token-column: S^T[lb][tb] = LM(k~) x RM(q); softmax over all 256 landmarks = over the
-// lane's rows, its k-octet lanes and the four waves (LDS); o^T[db][tb] = LT(w2) x P^T, summed over the waves through LDS.
-// ===========================================================================================================================
-constexpr int NY_P68 = 68, NY_P36 = 36;
-__global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_kernel(NyArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];
-  float* red = reinterpret_cast<float*>(sm + NY_IMG);          // [2][4][64]
-  float* part = red + 512;                                     // [4][64 d][68]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
-  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
-  int t_begin, t_end;
-  ny_chunk(g, ch, t_begin, t_end);
-  NyFrag kf, wt;
-  ny_lm_frags(g.kl + h * NY_D, g.ldl, lm0, lane, kf);
-  ny_lt_frags(g.w2 + (int64_t)h * NY_PART, NY_D, lm0, lane, wt);
-  const float* qb = g.q + h * NY_D;
-  f32x4 rq[4];
-  ny_load(qb, g.ld, (int64_t)t_begin * NY_TT, tid, rq);
-  for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();
-    ny_store_rm(sm, tid, rq);
-    __syncthreads();
-    if (t + 1 < t_end) ny_load(qb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rq);
-    f32x4 s[4][4];                                            // [lb][tb]
-    NY_ZERO(s, 4, 4);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f32x4 bh[4], bl[4];
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) { bh[tb] = ny_frag(sm, tb, ks, 0, lane); bl[tb] = ny_frag(sm, tb, ks, 1, lane); }
-#pragma unroll
-      for (int lb = 0; lb < 4; ++lb) ny_mma_a<4>(kf.h[lb][ks], kf.l[lb][ks], bh, bl, s[lb]);
-    }
-    float mx[4];
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-      float v = s[0][tb][0];
-#pragma unroll
-      for (int lb = 0; lb < 4; ++lb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v = fmaxf(v, s[lb][tb][i]);
-      v = ny_kgmax(v);
-      if (kg == 0) red[w * 64 + 16 * tb + c] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-      const int tk = 16 * tb + c;
-      mx[tb] = fmaxf(fmaxf(red[tk], red[64 + tk]), fmaxf(red[128 + tk], red[192 + tk]));
-      float sum = 0.f;
-#pragma unroll
-      for (int lb = 0; lb < 4; ++lb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float p = NY_EXP2((s[lb][tb][i] - mx[tb]) * g.sl2e);
-          s[lb][tb][i] = p;
-          sum += p;
-        }
-      sum = ny_kgsum(sum);
-      if (kg == 0) red[256 + w * 64 + tk] = sum;
-    }
-    f32x4 o[4][4];                                            // [db][tb]
-    NY_ZERO(o, 4, 4);
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx) {
-      f32x4 ph[4], pl[4];
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) ny_split44(s[2 * sx][tb], s[2 * sx + 1][tb], ph[tb], pl[tb]);
-#pragma unroll
-      for (int db = 0; db < 4; ++db) ny_mma_a<4>(wt.h[db][sx], wt.l[db][sx], ph, pl, o[db]);
-    }
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[(w * 64 + 16 * db + 4 * kg + i) * NY_P68 + 16 * tb + c] = o[db][tb][i];
-    __syncthreads();
-    {
-      const int tk = tid >> 2, qd = tid & 3;
-      const float L = ((red[256 + tk] + red[320 + tk]) + red[384 + tk]) + red[448 + tk];
-      const float inv = 1.f / L;
-      const int64_t row = (int64_t)t * NY_TT + tk;
-      float* op = g.out + row * g.ldo + h * NY_D + 16 * qd;
-#pragma unroll
-      for (int x4 = 0; x4 < 4; ++x4) {
-        f32x4 v;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int d = 16 * qd + 4 * x4 + x;
-          v[x] = (((part[d * NY_P68 + tk] + part[(64 + d) * NY_P68 + tk]) + part[(128 + d) * NY_P68 + tk]) + part[(192 + d) * NY_P68 + tk]) * inv;
-        }
-        *reinterpret_cast<f32x4*>(op + 4 * x4) = v;
-      }
-      if (qd == 0 && g.lse1_o) {
-        const float M = fmaxf(fmaxf(red[tk], red[64 + tk]), fmaxf(red[128 + tk], red[192 + tk]));
-        g.lse1_o[(int64_t)h * g.T + row] = M * g.sl2e + log2f(L);
-      }
-    }
-  }
-}
-
-// ===========================================================================================================================
-// backward of out, token side: dq (and delta = sum_m P dP, saved for the landmark-side kernel).  token-column, 32-token halves:
-// S^T = LM(k~) x RM(q), dP^T = LM(w2) x RM(dout), P = exp2(S sl2e - lse1), dS = scale P (dP - delta), dq^T = LT(k~) x dS^T.
-// ===========================================================================================================================
-__global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_q_kernel(NyArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];
-  float* red = reinterpret_cast<float*>(sm + 2 * NY_IMG);      // [4][32]
-  float* part = red + 128;                                     // [4][64 d][36]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
-  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
-  int t_begin, t_end;
-  ny_chunk(g, ch, t_begin, t_end);
-  NyFrag kf, wf, kt;
-  ny_lm_frags(g.kl + h * NY_D, g.ldl, lm0, lane, kf);
-  ny_lm_frags(g.w2 + (int64_t)h * NY_PART, NY_D, lm0, lane, wf);
-  ny_lt_frags(g.kl + h * NY_D, g.ldl, lm0, lane, kt);
-  const float* qb = g.q + h * NY_D;
-  const float* gb = g.dout + h * NY_D;
-  const float* lse = g.lse1 + (int64_t)h * g.T;
-  f32x4 rq[4], rg[4];
-  ny_load(qb, g.ld, (int64_t)t_begin * NY_TT, tid, rq);
-  ny_load(gb, g.ldd, (int64_t)t_begin * NY_TT, tid, rg);
-  for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();
-    ny_store_rm(sm, tid, rq);
-    ny_store_rm(sm + NY_IMG, tid, rg);
-    __syncthreads();
-    if (t + 1 < t_end) {
-      ny_load(qb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rq);
-      ny_load(gb, g.ldd, (int64_t)(t + 1) * NY_TT, tid, rg);
-    }
-    for (int hf = 0; hf < 2; ++hf) {
-      f32x4 s[4][2], dp[4][2];                                // [lb][tb2]
-      NY_ZERO(s, 4, 2);
-      NY_ZERO(dp, 4, 2);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f32x4 bh[2], bl[2], eh[2], el[2];
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-          bh[tb] = ny_frag(sm, 2 * hf + tb, ks, 0, lane); bl[tb] = ny_frag(sm, 2 * hf + tb, ks, 1, lane);
-          eh[tb] = ny_frag(sm + NY_IMG, 2 * hf + tb, ks, 0, lane); el[tb] = ny_frag(sm + NY_IMG, 2 * hf + tb, ks, 1, lane);
-        }
-#pragma unroll
-        for (int lb = 0; lb < 4; ++lb) {
-          ny_mma_a<2>(kf.h[lb][ks], kf.l[lb][ks], bh, bl, s[lb]);
-          ny_mma_a<2>(wf.h[lb][ks], wf.l[lb][ks], eh, el, dp[lb]);
-        }
-      }
-      const int64_t tok0 = (int64_t)t * NY_TT + 32 * hf;
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const float ls = lse[tok0 + 16 * tb + c];
-        float dl = 0.f;
-#pragma unroll
-        for (int lb = 0; lb < 4; ++lb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float p = NY_EXP2(s[lb][tb][i] * g.sl2e - ls);
-            s[lb][tb][i] = p;
-            dl += p * dp[lb][tb][i];
-          }
-        dl = ny_kgsum(dl);
-        if (kg == 0) red[w * 32 + 16 * tb + c] = dl;
-      }
-      __syncthreads();
-      f32x4 o[4][2];                                          // [db][tb2]
-      NY_ZERO(o, 4, 2);
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        const int tk = 16 * tb + c;
-        const float dl = ((red[tk] + red[32 + tk]) + red[64 + tk]) + red[96 + tk];
-        if (w == 0 && kg == 0) g.delta[(int64_t)h * g.T + tok0 + tk] = dl;
-#pragma unroll
-        for (int lb = 0; lb < 4; ++lb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) s[lb][tb][i] = g.scale * s[lb][tb][i] * (dp[lb][tb][i] - dl);
-      }
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
-        f32x4 ph[2], pl[2];
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx][tb], s[2 * sx + 1][tb], ph[tb], pl[tb]);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) ny_mma_a<2>(kt.h[db][sx], kt.l[db][sx], ph, pl, o[db]);
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part[(w * 64 + 16 * db + 4 * kg + i) * NY_P36 + 16 * tb + c] = o[db][tb][i];
-      __syncthreads();
-      {
-        const int tk = tid >> 3, d0 = 8 * (tid & 7);
-        float* op = g.out + (tok0 + tk) * g.ldo + h * NY_D + d0;
-#pragma unroll
-        for (int x4 = 0; x4 < 2; ++x4) {
-          f32x4 v;
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const int d = d0 + 4 * x4 + x;
-            v[x] = ((part[d * NY_P36 + tk] + part[(64 + d) * NY_P36 + tk]) + part[(128 + d) * NY_P36 + tk]) + part[(192 + d) * NY_P36 + tk];
-          }
-          *reinterpret_cast<f32x4*>(op + 4 * x4) = v;
-        }
-      }
-    }
-  }
-}
-
-// ===========================================================================================================================
 // backward of out, landmark side: dk~ and dw2 partials.  landmark-column, 32-token steps:
 // S = RM(q) x LM(k~), dP = RM(dout) x LM(w2), P, dS with the row's lse1 / delta;  dw2^T += TR(dout) x P,  dk~^T += TR(q) x dS.
 // ===========================================================================================================================
 __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   float* rowst = reinterpret_cast<float*>(sm + 4 * NY_IMG);    // lse1[64] | delta[64]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
-  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
-  int t_begin, t_end;
-  ny_chunk(g, ch, t_begin, t_end);
-  NyFrag kf, wf;
+  NY_IDS;
+  NyLM kf, wf;
   ny_lm_frags(g.kl + h * NY_D, g.ldl, lm0, lane, kf);
   ny_lm_frags(g.w2 + (int64_t)h * NY_PART, NY_D, lm0, lane, wf);
-  f32x4 dkl[4][4], dw2[4][4];                                  // [db][lb]
-  NY_ZERO(dkl, 4, 4);
-  NY_ZERO(dw2, 4, 4);
+  f32x4 dkl[4][NY_LB], dw2[4][NY_LB];                          // [db][lb]
+  NY_ZERO(dkl, 4, NY_LB);
+  NY_ZERO(dw2, 4, NY_LB);
   const float* qb = g.q + h * NY_D;
   const float* gb = g.dout + h * NY_D;
-  f32x4 rq[4], rg[4];
+  f32x4 rq[2], rg[2];
   float rst = 0.f;
   auto load_st = [&](int t) {
     if (tid < 64) rst = g.lse1[(int64_t)h * g.T + (int64_t)t * NY_TT + tid];
@@ -531,43 +295,45 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
       ny_load(gb, g.ldd, (int64_t)(t + 1) * NY_TT, tid, rg);
       load_st(t + 1);
     }
+#pragma unroll
     for (int ts = 0; ts < 2; ++ts) {
-      f32x4 s[2][4], dp[2][4];                                // [tb2][lb]
-      NY_ZERO(s, 2, 4);
-      NY_ZERO(dp, 2, 4);
+      f32x4 s[2][NY_LB], dp[2][NY_LB];                        // [tb2][lb]
+      NY_ZERO(s, 2, NY_LB);
+      NY_ZERO(dp, 2, NY_LB);
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 bh[NY_LB], bl[NY_LB], eh[NY_LB], el[NY_LB];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          f32x4 bh[4], bl[4], eh[4], el[4];
+        for (int lb = 0; lb < NY_LB; ++lb) { bh[lb] = kf.h[lb][ks]; bl[lb] = kf.l[lb][ks]; eh[lb] = wf.h[lb][ks]; el[lb] = wf.l[lb][ks]; }
 #pragma unroll
-          for (int lb = 0; lb < 4; ++lb) { bh[lb] = kf.h[lb][ks]; bl[lb] = kf.l[lb][ks]; eh[lb] = wf.h[lb][ks]; el[lb] = wf.l[lb][ks]; }
-          ny_mma_a<4>(ny_frag(sm, 2 * ts + tb, ks, 0, lane), ny_frag(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
-          ny_mma_a<4>(ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
+        for (int tb = 0; tb < 2; ++tb) {
+          ny_mma_a<NY_LB>(ny_frag(sm, 2 * ts + tb, ks, 0, lane), ny_frag(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
+          ny_mma_a<NY_LB>(ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
         }
+      }
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
         const f32x4 ls = *reinterpret_cast<const f32x4*>(rowst + 32 * ts + 16 * tb + 4 * kg);
         const f32x4 dl = *reinterpret_cast<const f32x4*>(rowst + 64 + 32 * ts + 16 * tb + 4 * kg);
 #pragma unroll
-        for (int lb = 0; lb < 4; ++lb)
+        for (int lb = 0; lb < NY_LB; ++lb)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float p = NY_EXP2(s[tb][lb][i] * g.sl2e - ls[i]);
+            const float p = NY_EXP2(fmaf(s[tb][lb][i], g.sl2e, -ls[i]));
             s[tb][lb][i] = p;
             dp[tb][lb][i] = g.scale * p * (dp[tb][lb][i] - dl[i]);
           }
       }
-      f32x4 ph[4], pl[4], sh[4], sl[4];
+      f32x4 ph[NY_LB], pl[NY_LB], sh[NY_LB], sl[NY_LB];
 #pragma unroll
-      for (int lb = 0; lb < 4; ++lb) {
+      for (int lb = 0; lb < NY_LB; ++lb) {
         ny_split44(s[0][lb], s[1][lb], ph[lb], pl[lb]);
         ny_split44(dp[0][lb], dp[1][lb], sh[lb], sl[lb]);
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        ny_mma_a<4>(ny_frag(sm + 3 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 3 * NY_IMG, db, ts, 1, lane), ph, pl, dw2[db]);
-        ny_mma_a<4>(ny_frag(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dkl[db]);
+        ny_mma_a<NY_LB>(ny_frag(sm + 3 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 3 * NY_IMG, db, ts, 1, lane), ph, pl, dw2[db]);
+        ny_mma_a<NY_LB>(ny_frag(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dkl[db]);
       }
     }
   }
@@ -576,7 +342,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int lb = 0; lb < 4; ++lb) {
+    for (int lb = 0; lb < NY_LB; ++lb) {
       *reinterpret_cast<f32x4*>(p1 + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = dkl[db][lb];
       *reinterpret_cast<f32x4*>(p2 + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = dw2[db][lb];
     }
@@ -607,198 +373,26 @@ __global__ __launch_bounds__(256) void ny_delta3_kernel(const float* a3v, const 
 }
 
 // ===========================================================================================================================
-// backward of a3v, token side: dk and dv.  token-column, 32-token halves:  S3^T = LM(q~) x RM(k), dP3^T = LM(da3v) x RM(v),
-// P = exp2(S sl2e - lse3[lm]), dS = scale P (dP - delta3[lm]);  dv^T = LT(da3v) x P^T,  dk^T = LT(q~) x dS^T.
-// MODE 1 (the cls row, no gradients): r[token] = sum_lm u[lm] P[lm, token].
-// ===========================================================================================================================
-template <int MODE>
-__global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_t_kernel(NyArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];
-  float* lmst = reinterpret_cast<float*>(sm + 2 * NY_IMG);     // lse3[256] | delta3 or u [256]
-  float* part = lmst + 512;                                    // MODE 0: [2][4][64 d][36] ; MODE 1: red [4][64]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
-  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
-  int t_begin, t_end;
-  ny_chunk(g, ch, t_begin, t_end);
-  lmst[tid] = g.lse3[h * NY_M + tid];
-  lmst[256 + tid] = MODE == 0 ? g.delta3[h * NY_M + tid] : g.u[h * NY_M + tid];
-  NyFrag qf;
-  ny_lm_frags(g.ql + h * NY_D, g.ldl, lm0, lane, qf);
-  const float* kb = g.k + h * NY_D;
-  const float* vb = g.v + h * NY_D;
-  if constexpr (MODE == 1) {
-    f32x4 rk[4];
-    ny_load(kb, g.ld, (int64_t)t_begin * NY_TT, tid, rk);
-    for (int t = t_begin; t < t_end; ++t) {
-      __syncthreads();
-      ny_store_rm(sm, tid, rk);
-      __syncthreads();
-      if (t + 1 < t_end) ny_load(kb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rk);
-      f32x4 s[4][4];                                          // [lb][tb]
-      NY_ZERO(s, 4, 4);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f32x4 bh[4], bl[4];
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb) { bh[tb] = ny_frag(sm, tb, ks, 0, lane); bl[tb] = ny_frag(sm, tb, ks, 1, lane); }
-#pragma unroll
-        for (int lb = 0; lb < 4; ++lb) ny_mma_a<4>(qf.h[lb][ks], qf.l[lb][ks], bh, bl, s[lb]);
-      }
-      float r[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int lb = 0; lb < 4; ++lb) {
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(lmst + lm0 + 16 * lb + 4 * kg);
-        const f32x4 uu = *reinterpret_cast<const f32x4*>(lmst + 256 + lm0 + 16 * lb + 4 * kg);
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) r[tb] += uu[i] * NY_EXP2(s[lb][tb][i] * g.sl2e - ls[i]);
-      }
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        const float v = ny_kgsum(r[tb]);
-        if (kg == 0) part[w * 64 + 16 * tb + c] = v;
-      }
-      __syncthreads();
-      if (tid < 64) g.out[(int64_t)h * g.T + (int64_t)t * NY_TT + tid] = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];
-    }
-    return;
-  } else {
-    NyFrag af, qt, at;
-    ny_lm_frags(g.da3v + (int64_t)h * NY_PART, NY_D, lm0, lane, af);
-    ny_lt_frags(g.ql + h * NY_D, g.ldl, lm0, lane, qt);
-    ny_lt_frags(g.da3v + (int64_t)h * NY_PART, NY_D, lm0, lane, at);
-    float* part_k = part;
-    float* part_v = part + 4 * 64 * NY_P36;
-    f32x4 rk[4], rv[4];
-    ny_load(kb, g.ld, (int64_t)t_begin * NY_TT, tid, rk);
-    ny_load(vb, g.ld, (int64_t)t_begin * NY_TT, tid, rv);
-    for (int t = t_begin; t < t_end; ++t) {
-      __syncthreads();
-      ny_store_rm(sm, tid, rk);
-      ny_store_rm(sm + NY_IMG, tid, rv);
-      __syncthreads();
-      if (t + 1 < t_end) {
-        ny_load(kb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rk);
-        ny_load(vb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rv);
-      }
-      for (int hf = 0; hf < 2; ++hf) {
-        f32x4 s[4][2], dp[4][2];                              // [lb][tb2]
-        NY_ZERO(s, 4, 2);
-        NY_ZERO(dp, 4, 2);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          f32x4 bh[2], bl[2], eh[2], el[2];
-#pragma unroll
-          for (int tb = 0; tb < 2; ++tb) {
-            bh[tb] = ny_frag(sm, 2 * hf + tb, ks, 0, lane); bl[tb] = ny_frag(sm, 2 * hf + tb, ks, 1, lane);
-            eh[tb] = ny_frag(sm + NY_IMG, 2 * hf + tb, ks, 0, lane); el[tb] = ny_frag(sm + NY_IMG, 2 * hf + tb, ks, 1, lane);
-          }
-#pragma unroll
-          for (int lb = 0; lb < 4; ++lb) {
-            ny_mma_a<2>(qf.h[lb][ks], qf.l[lb][ks], bh, bl, s[lb]);
-            ny_mma_a<2>(af.h[lb][ks], af.l[lb][ks], eh, el, dp[lb]);
-          }
-        }
-#pragma unroll
-        for (int lb = 0; lb < 4; ++lb) {
-          const f32x4 ls = *reinterpret_cast<const f32x4*>(lmst + lm0 + 16 * lb + 4 * kg);
-          const f32x4 dl = *reinterpret_cast<const f32x4*>(lmst + 256 + lm0 + 16 * lb + 4 * kg);
-#pragma unroll
-          for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float p = NY_EXP2(s[lb][tb][i] * g.sl2e - ls[i]);
-              s[lb][tb][i] = p;
-              dp[lb][tb][i] = g.scale * p * (dp[lb][tb][i] - dl[i]);
-            }
-        }
-        __syncthreads();                                      // the previous half's partials have been read
-        {
-          f32x4 ov[4][2];                                     // [db][tb2]
-          NY_ZERO(ov, 4, 2);
-#pragma unroll
-          for (int sx = 0; sx < 2; ++sx) {
-            f32x4 ph[2], pl[2];
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx][tb], s[2 * sx + 1][tb], ph[tb], pl[tb]);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) ny_mma_a<2>(at.h[db][sx], at.l[db][sx], ph, pl, ov[db]);
-          }
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) part_v[(w * 64 + 16 * db + 4 * kg + i) * NY_P36 + 16 * tb + c] = ov[db][tb][i];
-        }
-        {
-          f32x4 ok[4][2];
-          NY_ZERO(ok, 4, 2);
-#pragma unroll
-          for (int sx = 0; sx < 2; ++sx) {
-            f32x4 sh[2], sl[2];
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) ny_split44(dp[2 * sx][tb], dp[2 * sx + 1][tb], sh[tb], sl[tb]);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) ny_mma_a<2>(qt.h[db][sx], qt.l[db][sx], sh, sl, ok[db]);
-          }
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) part_k[(w * 64 + 16 * db + 4 * kg + i) * NY_P36 + 16 * tb + c] = ok[db][tb][i];
-        }
-        __syncthreads();
-        {
-          const int tk = tid >> 3, d0 = 8 * (tid & 7);
-          const int64_t row = (int64_t)t * NY_TT + 32 * hf + tk;
-          float* okp = g.out + row * g.ldo + h * NY_D + d0;
-          float* ovp = g.out2 + row * g.ldo2 + h * NY_D + d0;
-#pragma unroll
-          for (int x4 = 0; x4 < 2; ++x4) {
-            f32x4 a, b;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const int d = d0 + 4 * x4 + x;
-              a[x] = ((part_k[d * NY_P36 + tk] + part_k[(64 + d) * NY_P36 + tk]) + part_k[(128 + d) * NY_P36 + tk]) + part_k[(192 + d) * NY_P36 + tk];
-              b[x] = ((part_v[d * NY_P36 + tk] + part_v[(64 + d) * NY_P36 + tk]) + part_v[(128 + d) * NY_P36 + tk]) + part_v[(192 + d) * NY_P36 + tk];
-            }
-            *reinterpret_cast<f32x4*>(okp + 4 * x4) = a;
-            if (g.accumulate) b += *reinterpret_cast<const f32x4*>(ovp + 4 * x4);
-            *reinterpret_cast<f32x4*>(ovp + 4 * x4) = b;
-          }
-        }
-      }
-    }
-  }
-}
-
-// ===========================================================================================================================
 // backward of a3v, landmark side: dq~ partials.  landmark-column:  S3 = RM(k) x LM(q~), dP3 = RM(v) x LM(da3v),
 // dS = scale P (dP - delta3) with the lane's landmark statistics;  dq~^T += TR(k) x dS.
 // ===========================================================================================================================
 __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
-  const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
-  int t_begin, t_end;
-  ny_chunk(g, ch, t_begin, t_end);
-  NyFrag qf, af;
+  NY_IDS;
+  NyLM qf, af;
   ny_lm_frags(g.ql + h * NY_D, g.ldl, lm0, lane, qf);
   ny_lm_frags(g.da3v + (int64_t)h * NY_PART, NY_D, lm0, lane, af);
-  float ls[4], dl[4];
+  float ls[NY_LB], dl[NY_LB];
 #pragma unroll
-  for (int lb = 0; lb < 4; ++lb) {
+  for (int lb = 0; lb < NY_LB; ++lb) {
     ls[lb] = g.lse3[h * NY_M + lm0 + 16 * lb + c];
     dl[lb] = g.delta3[h * NY_M + lm0 + 16 * lb + c];
   }
-  f32x4 dq[4][4];                                              // [db][lb]
-  NY_ZERO(dq, 4, 4);
+  f32x4 dq[4][NY_LB];                                          // [db][lb]
+  NY_ZERO(dq, 4, NY_LB);
   const float* kb = g.k + h * NY_D;
   const float* vb = g.v + h * NY_D;
-  f32x4 rk[4], rv[4];
+  f32x4 rk[2], rv[2];
   ny_load(kb, g.ld, (int64_t)t_begin * NY_TT, tid, rk);
   ny_load(vb, g.ld, (int64_t)t_begin * NY_TT, tid, rv);
   for (int t = t_begin; t < t_end; ++t) {
@@ -811,46 +405,46 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
       ny_load(kb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rk);
       ny_load(vb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rv);
     }
+#pragma unroll
     for (int ts = 0; ts < 2; ++ts) {
-      f32x4 s[2][4], dp[2][4];                                // [tb2][lb]
-      NY_ZERO(s, 2, 4);
-      NY_ZERO(dp, 2, 4);
+      f32x4 s[2][NY_LB], dp[2][NY_LB];                        // [tb2][lb]
+      NY_ZERO(s, 2, NY_LB);
+      NY_ZERO(dp, 2, NY_LB);
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 bh[NY_LB], bl[NY_LB], eh[NY_LB], el[NY_LB];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          f32x4 bh[4], bl[4], eh[4], el[4];
+        for (int lb = 0; lb < NY_LB; ++lb) { bh[lb] = qf.h[lb][ks]; bl[lb] = qf.l[lb][ks]; eh[lb] = af.h[lb][ks]; el[lb] = af.l[lb][ks]; }
 #pragma unroll
-          for (int lb = 0; lb < 4; ++lb) { bh[lb] = qf.h[lb][ks]; bl[lb] = qf.l[lb][ks]; eh[lb] = af.h[lb][ks]; el[lb] = af.l[lb][ks]; }
-          ny_mma_a<4>(ny_frag(sm, 2 * ts + tb, ks, 0, lane), ny_frag(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
-          ny_mma_a<4>(ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
+        for (int tb = 0; tb < 2; ++tb) {
+          ny_mma_a<NY_LB>(ny_frag(sm, 2 * ts + tb, ks, 0, lane), ny_frag(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
+          ny_mma_a<NY_LB>(ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
         }
-      f32x4 sh[4], sl[4];
+      }
+      f32x4 sh[NY_LB], sl[NY_LB];
 #pragma unroll
-      for (int lb = 0; lb < 4; ++lb) {
+      for (int lb = 0; lb < NY_LB; ++lb) {
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dp[tb][lb][i] = g.scale * NY_EXP2(s[tb][lb][i] * g.sl2e - ls[lb]) * (dp[tb][lb][i] - dl[lb]);
+          for (int i = 0; i < 4; ++i)
+            dp[tb][lb][i] = g.scale * NY_EXP2(fmaf(s[tb][lb][i], g.sl2e, -ls[lb])) * (dp[tb][lb][i] - dl[lb]);
         ny_split44(dp[0][lb], dp[1][lb], sh[lb], sl[lb]);
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db)
-        ny_mma_a<4>(ny_frag(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dq[db]);
+        ny_mma_a<NY_LB>(ny_frag(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dq[db]);
     }
   }
   float* p1 = g.part + ((int64_t)h * g.nch + ch) * NY_PART;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int lb = 0; lb < 4; ++lb) *reinterpret_cast<f32x4*>(p1 + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = dq[db][lb];
+    for (int lb = 0; lb < NY_LB; ++lb) *reinterpret_cast<f32x4*>(p1 + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = dq[db][lb];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int NY_SM_OUT_FWD = NY_IMG + 512 * 4 + 4 * 64 * NY_P68 * 4;
-constexpr int NY_SM_BWD_Q = 2 * NY_IMG + 128 * 4 + 4 * 64 * NY_P36 * 4;
 constexpr int NY_SM_BWD_L = 4 * NY_IMG + 128 * 4;
-constexpr int NY_SM_A3_T = 2 * NY_IMG + 512 * 4 + 2 * 4 * 64 * NY_P36 * 4;
 constexpr int NY_SM_A3_L = 3 * NY_IMG;
 
 static int ny_base(const mhimx_nys* a, NyArgs& g, const char* who) {
@@ -891,10 +485,7 @@ extern "C" int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* 
   if (int e = ny_base(a, g, "nys_out_fwd")) return e;
   MHIMX_CHECK_ARG(a->q && a->kl && w2 && out && aligned16(a->q) && aligned16(a->kl) && aligned16(out) && ldo % 4 == 0, "nys_out_fwd: null / unaligned operands");
   g.w2 = w2; g.out = out; g.ldo = ldo; g.lse1_o = lse1;
-  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_OUT_FWD)));
-  hipLaunchKernelGGL(ny_out_fwd_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_OUT_FWD, (hipStream_t)stream, g);
-  MHIMX_LAUNCH_CHECK();
-  return 0;
+  return nytok_out_fwd((hipStream_t)stream, g);
 }
 
 extern "C" int mhimx_nys_out_bwd(void* stream, const mhimx_nys* a, const float* w2, const float* dout, int64_t ldd, const float* lse1,
@@ -906,10 +497,9 @@ extern "C" int mhimx_nys_out_bwd(void* stream, const mhimx_nys* a, const float* 
                   "nys_out_bwd: unaligned operands");
   g.w2 = w2; g.dout = dout; g.ldd = ldd; g.lse1 = lse1; g.delta = delta1; g.delta_i = delta1; g.out = dq; g.ldo = lddq;
   g.part = a->ws; g.part2 = a->ws + (int64_t)NY_H * NY_MAXCH * NY_PART;
-  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_BWD_Q));
-                        MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_bwd_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_BWD_L)));
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_bwd_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_BWD_L)));
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ny_out_bwd_q_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_BWD_Q, st, g);
+  if (int e = nytok_out_bwd_q(st, g)) return e;
   hipLaunchKernelGGL(ny_out_bwd_l_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_BWD_L, st, g);
   hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, st, g.part, g.nch, dkl, lddl, (int64_t)NY_D);
   hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, st, g.part2, g.nch, dw2, (int64_t)NY_D, (int64_t)NY_PART);
@@ -927,11 +517,10 @@ extern "C" int mhimx_nys_a3v_bwd(void* stream, const mhimx_nys* a, const float* 
   float* delta3 = a->ws + (int64_t)NY_H * NY_MAXCH * (2 * NY_PART + 2 * NY_M);
   g.da3v = da3v; g.lse3 = lse3; g.delta3 = delta3; g.out = dk; g.ldo = lddk; g.out2 = dv; g.ldo2 = lddk; g.accumulate = accumulate_dv;
   g.part = a->ws;
-  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_T));
-                        MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_L)));
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_L)));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ny_delta3_kernel, dim3(NY_H * NY_M / 256), dim3(256), 0, st, a3v, da3v, delta3);
-  hipLaunchKernelGGL(ny_a3v_bwd_t_kernel<0>, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_A3_T, st, g);
+  if (int e = nytok_a3v_bwd_t(st, g, 0)) return e;
   hipLaunchKernelGGL(ny_a3v_bwd_l_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_A3_L, st, g);
   hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, st, g.part, g.nch, dql, lddl, (int64_t)NY_D);
   MHIMX_LAUNCH_CHECK();
@@ -943,9 +532,5 @@ extern "C" int mhimx_nys_cls_attn(void* stream, const mhimx_nys* a, const float*
   if (int e = ny_base(a, g, "nys_cls_attn")) return e;
   MHIMX_CHECK_ARG(a->k && a->ql && lse3 && u && r && aligned16(a->k) && aligned16(a->ql), "nys_cls_attn: null / unaligned operands");
   g.lse3 = lse3; g.u = u; g.out = r;
-  constexpr int SM = 2 * NY_IMG + 512 * 4 + 256 * 4;
-  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SM)));
-  hipLaunchKernelGGL(ny_a3v_bwd_t_kernel<1>, dim3(g.nch, NY_H), dim3(NY_THREADS), SM, (hipStream_t)stream, g);
-  MHIMX_LAUNCH_CHECK();
-  return 0;
+  return nytok_a3v_bwd_t((hipStream_t)stream, g, 1);
 }
