@@ -266,6 +266,10 @@ int mhimx_layernorm_fwd(void* stream, const float* x, int64_t M, int64_t E, cons
                         float* rstd);
 int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                         const float* rstd, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws);
+/* the same with dx = (LayerNorm backward) + resid: the gradient of y = x + f(LayerNorm(x)) (baseline.py:213-218) in one pass instead
+ * of a LayerNorm backward and an addition of the residual branch's gradient */
+int mhimx_layernorm_bwd_res(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
+                            const float* rstd, const float* resid, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws);
 /* out = x * keep/(1-p) with the counter-based mask of (seed + *tick, row, col): re-applies a forward dropout to a gradient */
 int mhimx_dropout_apply(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed, const uint64_t* tick);
 /* y[r,:] = softmax(alpha * x[r,:]) over the last dim of x[R,L]; bwd: dx = alpha*y*(dy - sum(y*dy)).

@@ -15,7 +15,7 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
                   int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
-                  mhimx_reduce_list* defer, const int64_t* xrows = nullptr);
+                  mhimx_reduce_list* defer, const int64_t* xrows = nullptr, const float* resid = nullptr);
 int skinny_pair(hipStream_t st, const mhimx_gemm_tn_args& t, const mhimx_gemm_nt_args& g, float a_drop_p = 0.f, uint64_t a_seed = 0,
                 const uint64_t* a_tick = nullptr, float* a_colsum = nullptr, int a_accumulate = 0, int use_a_drop = 0);
 bool mca_fused_ok(int64_t E, int64_t heads, int64_t dh, int64_t k, const float* wkv_frag, const float* xn, const float* KV);

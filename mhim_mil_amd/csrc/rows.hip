@@ -431,7 +431,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, int64_t M, int E, const float* __restrict__ w,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
     float* __restrict__ dw_part, float* __restrict__ db_part, int direct_accumulate /* -1: partial rows; 0/1: one block writes d_w, d_b */,
-    LnSeg2 s2, const int64_t* __restrict__ xrows /* optional: x and dx rows of the main segment live at xrows[n] */) {
+    LnSeg2 s2, const int64_t* __restrict__ xrows /* optional: x and dx rows of the main segment live at xrows[n] */,
+    const float* __restrict__ resid /* optional: dx = (LayerNorm backward) + resid, the residual branch's gradient */) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dw, [4][E] db
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int MAXQ = 16;                    // E <= 1024
@@ -468,7 +469,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
         const int e = lane + 64 * q;
         if (e < E) {
           const float xh = (x[xn * (int64_t)E + e] - mu) * rs;
-          dx[xn * (int64_t)E + e] = rs * (dy[n * (int64_t)E + e] * w[e] - s1 - xh * s2);
+          float o = rs * (dy[n * (int64_t)E + e] * w[e] - s1 - xh * s2);
+          if (resid) o += resid[xn * (int64_t)E + e];
+          dx[xn * (int64_t)E + e] = o;
         }
       }
     }
@@ -894,14 +897,14 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
 int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
                   const float* rstd, float* dx, float* dw_part, float* db_part, float* d_w, float* d_b, int accumulate,
                   int max_parts, const float* dy2, const float* x2, const float* mean2, const float* rstd2, int64_t M2,
-                  mhimx_reduce_list* defer, const int64_t* xrows = nullptr) {
+                  mhimx_reduce_list* defer, const int64_t* xrows = nullptr, const float* resid = nullptr) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
   if (M2 > 0 && M > 16) {                   // rows + a few extra rows (weight gradients only) in one launch
     int grid = (int)cdiv(M, 4);
     if (grid > max_parts - 1) grid = max_parts - 1;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid + 1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                       w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{dy2, x2, mean2, rstd2, M2}, xrows);
+                       w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{dy2, x2, mean2, rstd2, M2}, xrows, resid);
     MHIMX_LAUNCH_CHECK();
     if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
       defer_push(defer, reduce_job_parts(dw_part, grid + 1, E, E, d_w, accumulate));
@@ -921,12 +924,12 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
   if (grid > max_parts) grid = max_parts;
   if (M <= 16) {                            // a few rows (the k global queries): ONE block writes d_w / d_b itself
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(1), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E, w, mean,
-                       rstd, dx, d_w, d_b, accumulate ? 1 : 0, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows);
+                       rstd, dx, d_w, d_b, accumulate ? 1 : 0, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows, resid);
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                     w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows);
+                     w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows, resid);
   MHIMX_LAUNCH_CHECK();
   if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
     defer_push(defer, reduce_job_parts(dw_part, grid, E, E, d_w, accumulate));
@@ -1128,6 +1131,12 @@ extern "C" int mhimx_layernorm_bwd(void* stream, const float* dy, const float* x
   MHIMX_CHECK_ARG(dy && x && w && mean && rstd && d_w && d_b && ws, "layernorm_bwd: null args");
   return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 512 * E, d_w, d_b, accumulate, 512, nullptr, nullptr, nullptr,
                        nullptr, 0, nullptr);
+}
+extern "C" int mhimx_layernorm_bwd_res(void* stream, const float* dy, const float* x, int64_t M, int64_t E, const float* w, const float* mean,
+                                       const float* rstd, const float* resid, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws) {
+  MHIMX_CHECK_ARG(dy && x && w && mean && rstd && resid && dx && d_w && d_b && ws, "layernorm_bwd_res: null args");
+  return layernorm_bwd((hipStream_t)stream, dy, x, M, E, w, mean, rstd, dx, ws, ws + 512 * E, d_w, d_b, accumulate, 512, nullptr, nullptr, nullptr,
+                       nullptr, 0, nullptr, nullptr, resid);
 }
 extern "C" int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n) {
   if (n <= 0) return 0;

@@ -312,6 +312,95 @@ class MatmulAffine(torch.autograd.Function):
         return da, db, None, None
 
 
+def _core_forward(qkv, conv_w, l, scale):
+    """The block between to_qkv and to_out (nystrom_attention.py:93-136) on the streamed kernels; returns (out [T, 512], saved)."""
+    lib = L.lib()
+    T, ld = qkv.shape
+    m, dev = LANDMARKS, qkv.device
+    lm = torch.empty((m, 2 * INNER), device=dev)
+    L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
+    ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
+    no = ops.NysOperands(qkv, lm, scale)
+    a2 = torch.empty((HEADS, m, m), device=dev)
+    _heads_mm("nt", ql, kl, batched(a2), HEADS)                       # q~ k~^T       nystrom:115
+    L.check(lib.mhimx_softmax_rows(_st(), _ptr(a2), _ptr(a2), HEADS * m, m, float(scale)), "softmax_rows")
+    # pseudo-inverse (nystrom_attention.py:12-27): z0 = a2^T / (max col sum * max row sum), six iterations, every intermediate kept
+    z = torch.empty_like(a2)
+    stats = torch.empty(4, device=dev)
+    ws = torch.empty(2 * HEADS * m, device=dev)
+    L.check(lib.mhimx_pinv_init(_st(), _ptr(a2), HEADS, m, _ptr(z), _ptr(stats), _ptr(ws)), "pinv_init")
+    z0, chain = z, []
+    for _ in range(PINV_ITERS):
+        az = _bmm_affine("nn", a2, z, torch.empty_like(a2), 1.0, 0.0)
+        t1 = torch.empty_like(a2)
+        L.check(lib.mhimx_affine_ident(_st(), _ptr(az), _ptr(t1), HEADS, m, 7.0, -1.0), "affine_ident")
+        t2 = _bmm_affine("nn", az, t1, torch.empty_like(a2), -1.0, 15.0)
+        t3 = _bmm_affine("nn", az, t2, torch.empty_like(a2), -1.0, 13.0)
+        zn = _bmm_affine("nn", z, t3, torch.empty_like(a2), 0.25, 0.0)
+        chain.append((z, az, t1, t2, t3))
+        z = zn
+    a3v, lse3 = ops.nys_a3v_fwd(no)                                    # softmax_n(q~ k^T) v   nystrom:116,131,133
+    w2 = torch.empty((HEADS, m, DH), device=dev)
+    _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
+    out, lse1 = ops.nys_out_fwd(no, w2)                                # softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
+    wc = conv_w.reshape(HEADS, -1).contiguous()
+    L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 1, 0),
+            "resconv")                                                # out += res_conv(v)   nystrom:135-136
+    return out, (qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, l, scale, conv_w.shape)
+
+
+def _core_backward(saved, dout):
+    """Gradients of _core_forward w.r.t. qkv and the residual-convolution weight."""
+    lib = L.lib()
+    qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, l, scale, wshape = saved
+    T, ld = qkv.shape
+    m, dev, KS = LANDMARKS, qkv.device, wc.shape[1]
+    ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
+    no = ops.NysOperands(qkv, lm, scale, ws=nws)
+    dqkv = torch.empty_like(qkv)                                       # every column block is written before it is added to
+    dlm = torch.empty_like(lm)
+    dql, dkl = ql.like(dlm), kl.like(dlm)
+    # residual convolution: dv = flip-conv(dout), d(conv weight)
+    L.check(lib.mhimx_resconv(_st(), _ptr(dout), INNER, _ptr(wc), KS, DH, T, INNER, _ptr(dqkv, 2 * INNER), ld, 0, 1), "resconv")
+    dwc = torch.empty_like(wc)
+    ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(T, INNER, DH, KS), device=dev)
+    L.check(lib.mhimx_resconv_dw(_st(), _ptr(dout), INNER, _ptr(qkv, 2 * INNER), ld, KS, DH, T, INNER, _ptr(dwc), _ptr(ws)), "resconv_dw")
+    # out = a1 w2: dq, the S1 term of dk~, dw2 = a1^T dout
+    dw2 = ops.nys_out_bwd(no, w2, dout, lse1, dqkv, dlm)
+    # w2 = z a3v
+    dz = torch.empty_like(z)
+    _heads_mm("nt", batched(dw2), batched(a3v), batched(dz), HEADS)    # dz = dw2 a3v^T
+    da3v = torch.empty_like(a3v)
+    _heads_mm("tn", batched(z), batched(dw2), batched(da3v), HEADS)    # da3v = z^T dw2
+    # a3v = a3 v: dk, dv +=, the S3 term of dq~
+    ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, accumulate_dv=True)
+    # pseudo-inverse, backwards through the six iterations
+    da2 = torch.empty_like(a2)
+    first = True
+    for (zp, az, t1, t2, t3) in reversed(chain):
+        dzp = _bmm_affine("nt", dz, t3, torch.empty_like(dz), 0.25, 0.0)          # z' = 0.25 zp t3
+        dt3 = _bmm_affine("tn", zp, dz, torch.empty_like(dz), 0.25, 0.0)
+        daz = _bmm_affine("nt", dt3, t2, torch.empty_like(dz), -1.0, 0.0)         # t3 = 13 I - az t2
+        dt2 = _bmm_affine("tn", az, dt3, torch.empty_like(dz), -1.0, 0.0)
+        _bmm_affine("nt", dt2, t1, daz, -1.0, 0.0, accumulate=True)               # t2 = 15 I - az t1
+        dt1 = _bmm_affine("tn", az, dt2, torch.empty_like(dz), -1.0, 0.0)
+        L.check(lib.mhimx_axpby(_st(), _ptr(dt1), _ptr(daz), daz.numel(), -1.0, 1.0), "axpby")      # t1 = 7 I - az
+        _bmm_affine("nt", daz, zp, da2, 1.0, 0.0, accumulate=not first)            # az = a2 zp
+        _bmm_affine("tn", a2, daz, dzp, 1.0, 0.0, accumulate=True)
+        dz, first = dzp, False
+    dinit = torch.empty_like(a2)
+    ws2 = torch.empty(256, device=dev)
+    L.check(lib.mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z0), _ptr(stats), HEADS, m, _ptr(dinit), _ptr(ws2)), "pinv_init_bwd")
+    L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
+    L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(a2), _ptr(da2), _ptr(da2), HEADS * m, m, float(scale)), "softmax_rows_bwd")
+    ds2 = batched(da2)
+    _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=True)              # s2 = q~ k~^T: dq~ += ds2 k~
+    _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
+    L.check(lib.mhimx_landmark_mean_bwd(_st(), _ptr(dlm), T, l, 2 * INNER, _ptr(dqkv), ld, 1), "landmark_mean_bwd")
+    return dqkv, dwc.reshape(wshape)
+
+
+
 class NystromCore(torch.autograd.Function):
     """The attention block between to_qkv and to_out (nystrom_attention.py:93-136) as ONE autograd node with a hand-written backward:
     landmark means, the three score products, their softmaxes, the pseudo-inverse, a1 (pinv (a3 v)) and the residual convolution.
@@ -323,95 +412,94 @@ class NystromCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, conv_w, l, scale):
-        lib = L.lib()
-        T, ld = qkv.shape
-        m, dev = LANDMARKS, qkv.device
-        lm = torch.empty((m, 2 * INNER), device=dev)
-        L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
-        ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
-        no = ops.NysOperands(qkv, lm, scale)
-        a2 = torch.empty((HEADS, m, m), device=dev)
-        _heads_mm("nt", ql, kl, batched(a2), HEADS)                       # q~ k~^T       nystrom:115
-        L.check(lib.mhimx_softmax_rows(_st(), _ptr(a2), _ptr(a2), HEADS * m, m, float(scale)), "softmax_rows")
-        # pseudo-inverse (nystrom_attention.py:12-27): z0 = a2^T / (max col sum * max row sum), six iterations, every intermediate kept
-        z = torch.empty_like(a2)
-        stats = torch.empty(4, device=dev)
-        ws = torch.empty(2 * HEADS * m, device=dev)
-        L.check(lib.mhimx_pinv_init(_st(), _ptr(a2), HEADS, m, _ptr(z), _ptr(stats), _ptr(ws)), "pinv_init")
-        z0, chain = z, []
-        for _ in range(PINV_ITERS):
-            az = _bmm_affine("nn", a2, z, torch.empty_like(a2), 1.0, 0.0)
-            t1 = torch.empty_like(a2)
-            L.check(lib.mhimx_affine_ident(_st(), _ptr(az), _ptr(t1), HEADS, m, 7.0, -1.0), "affine_ident")
-            t2 = _bmm_affine("nn", az, t1, torch.empty_like(a2), -1.0, 15.0)
-            t3 = _bmm_affine("nn", az, t2, torch.empty_like(a2), -1.0, 13.0)
-            zn = _bmm_affine("nn", z, t3, torch.empty_like(a2), 0.25, 0.0)
-            chain.append((z, az, t1, t2, t3))
-            z = zn
-        a3v, lse3 = ops.nys_a3v_fwd(no)                                    # softmax_n(q~ k^T) v   nystrom:116,131,133
-        w2 = torch.empty((HEADS, m, DH), device=dev)
-        _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
-        out, lse1 = ops.nys_out_fwd(no, w2)                                # softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
-        wc = conv_w.reshape(HEADS, -1).contiguous()
-        L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 1, 0),
-                "resconv")                                                # out += res_conv(v)   nystrom:135-136
-        ctx.saved = (qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws)
-        ctx.cfg = (l, scale, conv_w.shape)
+        out, saved = _core_forward(qkv, conv_w, l, scale)
+        ctx.saved = saved
+        lm, z, lse3 = saved[1], saved[3], saved[11]
         ctx.mark_non_differentiable(lm, z, lse3)
         return out, lm, z, lse3
 
     @staticmethod
     def backward(ctx, dout, _g1, _g2, _g3):
+        saved, ctx.saved = ctx.saved, None
+        dqkv, dwc = _core_backward(saved, dout.contiguous())
+        return dqkv, dwc, None, None
+
+
+def _cls_attention(qkv, lm, z, lse3, pad, scale):
+    """nystrom:143-150: the cls token's attention row [8, T] = (attn1[cls] pinv) attn3, without attn1 / attn3."""
+    m = LANDMARKS
+    ld = qkv.shape[1]
+    a1c = torch.empty((HEADS, 1, m), device=qkv.device)                    # attn1's cls row: softmax(scale q_cls k~^T)
+    _heads_mm("nt", Op(qkv, pad * ld, DH, ld, 1, DH), Op(lm, INNER, DH, 2 * INNER, m, DH), batched(a1c), HEADS)
+    L.check(L.lib().mhimx_softmax_rows(_st(), _ptr(a1c), _ptr(a1c), HEADS, m, float(scale)), "softmax_rows")
+    u = torch.empty((HEADS, 1, m), device=qkv.device)
+    _heads_mm("nn", batched(a1c), batched(z), batched(u), HEADS)
+    return ops.nys_cls_attn(ops.NysOperands(qkv, lm, scale), lse3, u.reshape(HEADS, m))
+
+
+class TransLayerFn(torch.autograd.Function):
+    """y = x + to_out(Nystrom(to_qkv(LayerNorm(x))))  (baseline.py:213-218, nystrom_attention.py:65-152) as ONE autograd node.
+    The front zero padding (nystrom:70-73) is a zero fill of the first rows of the qkv buffer (to_qkv has no bias), the last-n-rows
+    slice (nystrom:142) a pointer offset, and the residual's gradient is added inside the LayerNorm backward: no cat / slice copy, no
+    zero-filled gradient, no autograd addition touches token data."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, conv_w, drop_p, seed, tick, scale, need_attn):
         lib = L.lib()
-        qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws = ctx.saved
+        x = x.contiguous()
+        n, E = x.shape
+        m, dev = LANDMARKS, x.device
+        pad = (m - n % m) % m
+        T, l = n + pad, math.ceil(n / m)
+        xn = torch.empty_like(x)
+        mean, rstd = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        L.check(lib.mhimx_layernorm_fwd(_st(), _ptr(x), n, E, _ptr(ln_w), _ptr(ln_b), _ptr(xn), _ptr(mean), _ptr(rstd)), "layernorm_fwd")
+        qkv = torch.empty((T, 3 * INNER), device=dev)
+        if pad:
+            qkv[:pad].zero_()
+        ops.gemm_nt(xn, w_qkv, out=qkv[pad:], prec=_PREC)
+        out, saved = _core_forward(qkv, conv_w, l, scale)
+        y = ops.gemm_nt(out[pad:], w_out, bias=b_out, drop_p=drop_p, drop_seed=seed, drop_tick=tick, prec=_PREC)
+        L.check(lib.mhimx_axpby(_st(), _ptr(x), _ptr(y), y.numel(), 1.0, 1.0), "axpby")                 # y += x
+        ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, saved)
+        ctx.cfg = (pad, drop_p, seed, tick)
+        if not need_attn:
+            return y
+        lm, z, lse3 = saved[1], saved[3], saved[11]
+        r = _cls_attention(qkv, lm, z, lse3, pad, scale)
+        attn, v = r[:, pad + 1:], qkv[pad + 1:, 2 * INNER:]
+        ctx.mark_non_differentiable(attn, v)
+        return y, attn, v
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        lib = L.lib()
+        x, xn, mean, rstd, ln_w, w_qkv, w_out, out, saved = ctx.saved
         ctx.saved = None
-        l, scale, wshape = ctx.cfg
-        dout = dout.contiguous()
-        T, ld = qkv.shape
-        m, dev, KS = LANDMARKS, qkv.device, wc.shape[1]
-        ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
-        no = ops.NysOperands(qkv, lm, scale, ws=nws)
-        dqkv = torch.empty_like(qkv)                                       # every column block is written before it is added to
-        dlm = torch.empty_like(lm)
-        dql, dkl = ql.like(dlm), kl.like(dlm)
-        # residual convolution: dv = flip-conv(dout), d(conv weight)
-        L.check(lib.mhimx_resconv(_st(), _ptr(dout), INNER, _ptr(wc), KS, DH, T, INNER, _ptr(dqkv, 2 * INNER), ld, 0, 1), "resconv")
-        dwc = torch.empty_like(wc)
-        ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(T, INNER, DH, KS), device=dev)
-        L.check(lib.mhimx_resconv_dw(_st(), _ptr(dout), INNER, _ptr(qkv, 2 * INNER), ld, KS, DH, T, INNER, _ptr(dwc), _ptr(ws)), "resconv_dw")
-        # out = a1 w2: dq, the S1 term of dk~, dw2 = a1^T dout
-        dw2 = ops.nys_out_bwd(no, w2, dout, lse1, dqkv, dlm)
-        # w2 = z a3v
-        dz = torch.empty_like(z)
-        _heads_mm("nt", batched(dw2), batched(a3v), batched(dz), HEADS)    # dz = dw2 a3v^T
-        da3v = torch.empty_like(a3v)
-        _heads_mm("tn", batched(z), batched(dw2), batched(da3v), HEADS)    # da3v = z^T dw2
-        # a3v = a3 v: dk, dv +=, the S3 term of dq~
-        ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, accumulate_dv=True)
-        # pseudo-inverse, backwards through the six iterations
-        da2 = torch.empty_like(a2)
-        first = True
-        for (zp, az, t1, t2, t3) in reversed(chain):
-            dzp = _bmm_affine("nt", dz, t3, torch.empty_like(dz), 0.25, 0.0)          # z' = 0.25 zp t3
-            dt3 = _bmm_affine("tn", zp, dz, torch.empty_like(dz), 0.25, 0.0)
-            daz = _bmm_affine("nt", dt3, t2, torch.empty_like(dz), -1.0, 0.0)         # t3 = 13 I - az t2
-            dt2 = _bmm_affine("tn", az, dt3, torch.empty_like(dz), -1.0, 0.0)
-            _bmm_affine("nt", dt2, t1, daz, -1.0, 0.0, accumulate=True)               # t2 = 15 I - az t1
-            dt1 = _bmm_affine("tn", az, dt2, torch.empty_like(dz), -1.0, 0.0)
-            L.check(lib.mhimx_axpby(_st(), _ptr(dt1), _ptr(daz), daz.numel(), -1.0, 1.0), "axpby")      # t1 = 7 I - az
-            _bmm_affine("nt", daz, zp, da2, 1.0, 0.0, accumulate=not first)            # az = a2 zp
-            _bmm_affine("tn", a2, daz, dzp, 1.0, 0.0, accumulate=True)
-            dz, first = dzp, False
-        dinit = torch.empty_like(a2)
-        ws2 = torch.empty(256, device=dev)
-        L.check(lib.mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z0), _ptr(stats), HEADS, m, _ptr(dinit), _ptr(ws2)), "pinv_init_bwd")
-        L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
-        L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(a2), _ptr(da2), _ptr(da2), HEADS * m, m, float(scale)), "softmax_rows_bwd")
-        ds2 = batched(da2)
-        _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=True)              # s2 = q~ k~^T: dq~ += ds2 k~
-        _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
-        L.check(lib.mhimx_landmark_mean_bwd(_st(), _ptr(dlm), T, l, 2 * INNER, _ptr(dqkv), ld, 1), "landmark_mean_bwd")
-        return dqkv, dwc.reshape(wshape), None, None
+        pad, drop_p, seed, tick = ctx.cfg
+        dy = dy.contiguous()
+        n, E = x.shape
+        T, dev = n + pad, x.device
+        g = dy
+        if drop_p > 0:
+            g = torch.empty_like(dy)
+            L.check(lib.mhimx_dropout_apply(_st(), _ptr(dy), _ptr(g), n, E, float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                            None if tick is None else _ptr(tick)), "dropout_apply")
+        dout = torch.empty((T, INNER), device=dev)
+        if pad:
+            dout[:pad].zero_()
+        _gemm("nn", g, 0, E, w_out, 0, INNER, dout, pad * INNER, INNER, n, INNER, E)
+        dw_out = ops.gemm_tn(g, out[pad:], splits=8 if n >= 4096 else 1, prec=_PREC)
+        db_out = ops.colsum(g)
+        dqkv, dwc = _core_backward(saved, dout)
+        dxn = torch.empty_like(x)
+        _gemm("nn", dqkv, pad * 3 * INNER, 3 * INNER, w_qkv, 0, E, dxn, 0, E, n, E, 3 * INNER)
+        dw_qkv = ops.gemm_tn(dqkv[pad:], xn, splits=8 if n >= 4096 else 1, prec=_PREC)
+        dx, dlw, dlb = torch.empty_like(x), torch.empty_like(ln_w), torch.empty_like(ln_w)
+        ws = torch.empty(2 * 512 * E, device=dev)
+        L.check(lib.mhimx_layernorm_bwd_res(_st(), _ptr(dxn), _ptr(x), n, E, _ptr(ln_w), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx),
+                                            _ptr(dlw), _ptr(dlb), 0, _ptr(ws)), "layernorm_bwd_res")
+        return dx, dlw, dlb, dw_qkv, dw_out, db_out, dwc, None, None, None, None, None
 
 
 class PinvInit(torch.autograd.Function):
@@ -560,12 +648,7 @@ class NystromAttention(nn.Module):
             if not return_attn:
                 return y
             with torch.no_grad():                                              # nystrom:143-150: the cls token's attention row
-                a1c = torch.empty((HEADS, 1, m), device=x.device)              # attn1's cls row: softmax(scale q_cls k~^T)
-                _heads_mm("nt", Op(qkv, pad * ld, DH, ld, 1, DH), Op(lm, INNER, DH, 2 * INNER, m, DH), batched(a1c), HEADS)
-                L.check(L.lib().mhimx_softmax_rows(_st(), _ptr(a1c), _ptr(a1c), HEADS, m, float(self.scale)), "softmax_rows")
-                bat = lambda r, c: (0, r * c, c, r, c)
-                u = heads_mm(a1c, z, "nn", bat(1, m), bat(m, m), (HEADS, 1, m), bat(1, m))
-                r = ops.nys_cls_attn(ops.NysOperands(qkv, lm, self.scale), lse3, u.reshape(HEADS, m).contiguous())
+                r = _cls_attention(qkv, lm, z, lse3, pad, self.scale)
                 return y, r[:, pad + 1:], qkv[pad + 1:, 2 * INNER:]
         lm = Landmarks.apply(qkv, l)                                          # [256, 1024]: q~ | k~
         q_d, k_d, v_d = (0, DH, ld, T, DH), (INNER, DH, ld, T, DH), (2 * INNER, DH, ld, T, DH)
@@ -625,6 +708,10 @@ class TransLayer(nn.Module):
         self.attn = NystromAttention(dim)
 
     def forward(self, x, need_attn=False, no_norm=False, seed=0, tick=None, training=False):
+        if _PREC != "f32" and not (need_attn and no_norm):
+            a = self.attn
+            return TransLayerFn.apply(x, self.norm.weight, self.norm.bias, a.to_qkv.weight, a.to_out[0].weight, a.to_out[0].bias,
+                                      a.res_conv.weight, a.dropout if training else 0.0, seed, tick, a.scale, bool(need_attn))
         xn = LayerNorm.apply(x, self.norm.weight, self.norm.bias)
         if need_attn:
             z, attn, v = self.attn(xn, True, no_norm, seed, tick, training)
