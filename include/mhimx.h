@@ -113,6 +113,10 @@ int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* arg
  * takes the same kernel for such shapes.   replaces: torch.matmul + the scalar * eye arithmetic around it. */
 int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_args* args, int32_t batch, int64_t strideA, int64_t strideB,
                      int64_t strideC, float alpha, float ident);
+/* two INDEPENDENT batches of 256 x 256 x 256 products in one launch (contiguous [batch, 256, 256] operands, stride = 65536): the
+ * backward of a pseudo-inverse iteration is four such pairs (nystrom_attention.py:21-26 under autograd). */
+int mhimx_bmm_affine_pair(void* stream, int32_t mode0, const mhimx_gemm_nt_args* a0, float alpha0, float ident0, int32_t mode1,
+                          const mhimx_gemm_nt_args* a1, float alpha1, float ident1, int32_t batch, int64_t stride);
 
 /* Deferred final reductions.  Weight / bias gradients are consumed only by the optimizer, so the last stage of their
  * two-stage reductions (summing split-GEMM slabs, summing per-block column partials) need not run where it is produced:

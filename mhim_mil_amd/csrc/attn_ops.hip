@@ -838,7 +838,7 @@ extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C) { return cdiv(N, 256) * C * 50 + 49 * C; }
+extern "C" int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C) { return cdiv(N, 64) * C * 50 + 49 * C; }
 extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc,
                               float* dbc, float* ws, int64_t grid) {
   MHIMX_CHECK_ARG(dy && x && wc && dx && dwc && dbc && ws, "ppeg_bwd: null args");
@@ -854,7 +854,7 @@ extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int
     hipLaunchKernelGGL(ppeg_bwd_dx_kernel, dim3(grid1d(wrapN - N, 1, 32768)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc, dx, N, wrapN, 1);
     MHIMX_LAUNCH_CHECK();
   }
-  const int nblk = (int)cdiv(N, 256);
+  const int nblk = (int)cdiv(N, 64);          // strips of one block are a latency chain: many short blocks (1368 -> 5472 waves at N = 43 776)
   float* part = ws;
   float* part_b = ws + (int64_t)nblk * C * 49;
   float* dwc_t = part_b + (int64_t)nblk * C;                    // [49, C], transposed into dwc [C, 49] at the end

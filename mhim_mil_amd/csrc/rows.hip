@@ -424,6 +424,43 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_fwd_kernel(const float
   }
 }
 
+// E = 256 Q (the 512-wide TransMIL tokens): the row is read ONCE, 16 bytes per lane per 256 columns, and stays in registers for the
+// mean, the variance and the output - one wave per row, as many blocks as rows / 4 (no partial-count cap: nothing is reduced across rows)
+template <int Q>
+__global__ __launch_bounds__(ROWS_THREADS) void layernorm_fwd_vec_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ w,
+                                                                         const float* __restrict__ b, float* __restrict__ y,
+                                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int E = 256 * Q;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f4 wv[Q], bv[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    wv[q] = *reinterpret_cast<const f4*>(w + 256 * q + 4 * lane);
+    bv[q] = *reinterpret_cast<const f4*>(b + 256 * q + 4 * lane);
+  }
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+    f4 v[Q];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      v[q] = *reinterpret_cast<const f4*>(x + n * E + 256 * q + 4 * lane);
+      sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+    const float mu = wave_sum(sum) / (float)E;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      v[q] -= mu;
+      var += (v[q][0] * v[q][0] + v[q][1] * v[q][1]) + (v[q][2] * v[q][2] + v[q][3] * v[q][3]);
+    }
+    const float rs = rsqrtf(wave_sum(var) / (float)E + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) *reinterpret_cast<f4*>(y + n * E + 256 * q + 4 * lane) = v[q] * rs * wv[q] + bv[q];
+    if (lane == 0) { mean[n] = mu; rstd[n] = rs; }
+  }
+}
+
 struct LnSeg2 { const float* dy; const float* x; const float* mean; const float* rstd; int64_t M; };
 
 // dx = rstd*(dy*w - mean(dy*w) - xhat*mean(dy*w*xhat)); per-block partial dw = sum dy*xhat, db = sum dy
@@ -492,6 +529,61 @@ __global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_kernel(
       dw_part[e] = direct_accumulate ? dw_part[e] + a : a;
       db_part[e] = direct_accumulate ? db_part[e] + b : b;
     }
+  }
+}
+
+// E = 512 rows without a ride-along segment or row map (the TransMIL token stream): dy, x (and the residual) are read ONCE, 16 bytes per
+// lane per 256 columns, and stay in registers for the two row sums, dx and the weight-gradient partials (lane-owned columns).
+__global__ __launch_bounds__(ROWS_THREADS) void layernorm_bwd_vec512_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, int64_t M, const float* __restrict__ w, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dw_part, float* __restrict__ db_part,
+    const float* __restrict__ resid) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int E = 512;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][E] dw, [4][E] db
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f4 wv[2], dwa[2], dba[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    wv[q] = *reinterpret_cast<const f4*>(w + 256 * q + 4 * lane);
+    dwa[q] = f4{0.f, 0.f, 0.f, 0.f};
+    dba[q] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < M; n += (int64_t)gridDim.x * 4) {
+    const float mu = mean[n], rs = rstd[n];
+    f4 g[2], xh[2], rr[2];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      g[q] = *reinterpret_cast<const f4*>(dy + n * E + 256 * q + 4 * lane);
+      xh[q] = (*reinterpret_cast<const f4*>(x + n * E + 256 * q + 4 * lane) - mu) * rs;
+      if (resid) rr[q] = *reinterpret_cast<const f4*>(resid + n * E + 256 * q + 4 * lane);
+      const f4 gw = g[q] * wv[q], gx = gw * xh[q];
+      s1 += (gw[0] + gw[1]) + (gw[2] + gw[3]);
+      s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+      dwa[q] += g[q] * xh[q];
+      dba[q] += g[q];
+    }
+    s1 = wave_sum(s1) / (float)E;
+    s2 = wave_sum(s2) / (float)E;
+    if (dx) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f4 o = (g[q] * wv[q] - s1 - xh[q] * s2) * rs;
+        if (resid) o += rr[q];
+        *reinterpret_cast<f4*>(dx + n * E + 256 * q + 4 * lane) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    *reinterpret_cast<f4*>(sm + wave * E + 256 * q + 4 * lane) = dwa[q];
+    *reinterpret_cast<f4*>(sm + (4 + wave) * E + 256 * q + 4 * lane) = dba[q];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += ROWS_THREADS) {
+    dw_part[(int64_t)blockIdx.x * E + e] = sm[e] + sm[E + e] + sm[2 * E + e] + sm[3 * E + e];
+    db_part[(int64_t)blockIdx.x * E + e] = sm[4 * E + e] + sm[5 * E + e] + sm[6 * E + e] + sm[7 * E + e];
   }
 }
 
@@ -888,6 +980,12 @@ int layernorm_fwd(hipStream_t st, const float* x, int64_t M, int64_t E, const fl
                   float* mean, float* rstd) {
   MHIMX_CHECK_ARG(E <= 1024 && E % 64 == 0, "layernorm: E must be a multiple of 64, <= 1024");
   if (M == 0) return 0;
+  if (E == 512 && M >= 64 && aligned16(x) && aligned16(y) && aligned16(w) && aligned16(b)) {
+    const int64_t g = cdiv(M, 8) < 8192 ? cdiv(M, 8) : 8192;
+    hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, dim3((unsigned)g), dim3(ROWS_THREADS), 0, st, x, M, w, b, y, mean, rstd);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for_ln(M)), dim3(ROWS_THREADS), 0, st, x, M, (int)E, w, b, y, mean, rstd);
   MHIMX_LAUNCH_CHECK();
   return 0;
@@ -928,8 +1026,12 @@ int layernorm_bwd(hipStream_t st, const float* dy, const float* x, int64_t M, in
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
-                     w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows, resid);
+  if (E == 512 && !xrows && aligned16(dy) && aligned16(x) && aligned16(w) && (!dx || aligned16(dx)) && (!resid || aligned16(resid)))
+    hipLaunchKernelGGL(layernorm_bwd_vec512_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, w, mean, rstd, dx,
+                       dw_part, db_part, resid);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(ROWS_THREADS), (size_t)8 * E * sizeof(float), st, dy, x, M, (int)E,
+                       w, mean, rstd, dx, dw_part, db_part, -1, LnSeg2{nullptr, nullptr, nullptr, nullptr, 0}, xrows, resid);
   MHIMX_LAUNCH_CHECK();
   if (defer && defer->n + 2 <= MHIMX_REDUCE_MAX) {
     defer_push(defer, reduce_job_parts(dw_part, grid, E, E, d_w, accumulate));

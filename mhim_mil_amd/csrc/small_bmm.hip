@@ -110,6 +110,96 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_kernel(SmallBmm g) {
   }
 }
 
+// The same product with the WHOLE K panel of both operands in LDS (K <= 256: the 256 x 256 x 256 products of the pseudo-inverse):
+// the eight k-steps of small_bmm_kernel are eight global-load -> barrier -> store -> barrier rounds; here the panel is staged behind
+// ONE barrier and the 8 x 6 MFMAs per wave run with no barrier between (8.5 -> 7.4 us per 8-head product; forcing all 32 loads of a
+// thread in flight before the first store, or two accumulator chains, measured slower: 8.8 us).
+constexpr int SBF_KMAX = 256, SBF_PITCH = SBF_KMAX + 4;
+template <bool TA, bool TB>
+MHIMX_DEV void small_bmm_full_body(const SmallBmm& g, int z, float* sbf) {
+  float* As = sbf;
+  float* Bs = sbf + SB_T * SBF_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * SB_T, n0 = (int64_t)blockIdx.x * SB_T;
+  const float* A = g.A + (int64_t)z * g.sA;
+  const float* B = g.B + (int64_t)z * g.sB;
+  float* C = g.C + (int64_t)z * g.sC;
+  // K == SBF_KMAX (checked by the launcher): all 32 loads of the thread are in flight together, then the LDS stores
+  constexpr int NKS = SBF_KMAX / SB_K;
+  sb_f4 ra[NKS][2], rb[NKS][2];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f = tid + SB_THREADS * j, k0 = ks * SB_K;
+      if (TA) ra[ks][j] = *reinterpret_cast<const sb_f4*>(A + (int64_t)(k0 + (f >> 4)) * g.lda + m0 + (f & 15) * 4);
+      else ra[ks][j] = *reinterpret_cast<const sb_f4*>(A + (m0 + (f >> 3)) * g.lda + k0 + (f & 7) * 4);
+      if (TB) rb[ks][j] = *reinterpret_cast<const sb_f4*>(B + (int64_t)(k0 + (f >> 4)) * g.ldb + n0 + (f & 15) * 4);
+      else rb[ks][j] = *reinterpret_cast<const sb_f4*>(B + (n0 + (f >> 3)) * g.ldb + k0 + (f & 7) * 4);
+    }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int f = tid + SB_THREADS * j, k0 = ks * SB_K;
+      if (TA) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) As[((f & 15) * 4 + c) * SBF_PITCH + k0 + (f >> 4)] = ra[ks][j][c];
+      } else {
+        *reinterpret_cast<sb_f4*>(As + (f >> 3) * SBF_PITCH + k0 + (f & 7) * 4) = ra[ks][j];
+      }
+      if (TB) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Bs[((f & 15) * 4 + c) * SBF_PITCH + k0 + (f >> 4)] = rb[ks][j][c];
+      } else {
+        *reinterpret_cast<sb_f4*>(Bs + (f >> 3) * SBF_PITCH + k0 + (f & 7) * 4) = rb[ks][j];
+      }
+    }
+  __syncthreads();
+  sb_f16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int r = lane & 31, kh = lane >> 5;
+  const float* ap = As + (wm * 32 + r) * SBF_PITCH + 8 * kh;
+  const float* bp = Bs + (wn * 32 + r) * SBF_PITCH + 8 * kh;
+  for (int k0 = 0; k0 < SBF_KMAX; k0 += 16) {
+    sb_b8 ah, al, bh, bl;
+    sb_split(*reinterpret_cast<const sb_f4*>(ap + k0), *reinterpret_cast<const sb_f4*>(ap + k0 + 4), ah, al);
+    sb_split(*reinterpret_cast<const sb_f4*>(bp + k0), *reinterpret_cast<const sb_f4*>(bp + k0 + 4), bh, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  }
+  const int64_t n = n0 + wn * 32 + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int64_t m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+    float v = g.alpha * acc[e];
+    if (m == n) v += g.ident;
+    float* p = C + m * g.ldc + n;
+    if (g.accumulate) v += *p;
+    *p = v;
+  }
+}
+template <bool TA, bool TB>
+__global__ __launch_bounds__(SB_THREADS) void small_bmm_full_kernel(SmallBmm g) {
+  extern __shared__ __attribute__((aligned(16))) float sbf[];
+  small_bmm_full_body<TA, TB>(g, (int)blockIdx.z, sbf);
+}
+// TWO independent batches of products in one launch (same shapes, any two modes): blockIdx.z < batch -> the first.  The backward of a
+// pseudo-inverse iteration is four pairs of independent 256^3 products (e.g. dzp = dz t3^T and dt3 = zp^T dz): 9 launches become 5.
+MHIMX_DEV void small_bmm_full_any(const SmallBmm& g, int mode, int z, float* sbf) {
+  if (mode == 0) small_bmm_full_body<false, false>(g, z, sbf);
+  else if (mode == 1) small_bmm_full_body<false, true>(g, z, sbf);
+  else small_bmm_full_body<true, true>(g, z, sbf);
+}
+__global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0, int mode0, SmallBmm g1, int mode1, int batch) {
+  extern __shared__ __attribute__((aligned(16))) float sbf[];
+  if ((int)blockIdx.z < batch) small_bmm_full_any(g0, mode0, (int)blockIdx.z, sbf);
+  else small_bmm_full_any(g1, mode1, (int)blockIdx.z - batch, sbf);
+}
+
 bool small_bmm_ok(int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC) {
   if (g.prec == MHIMX_PREC_F32 || g.rows || g.bias || g.M % SB_T || g.N % SB_T || g.K % SB_K) return false;
   if (g.M > 512 || g.N > 512 || g.K > 1024 || batch > 65535) return false;
@@ -122,6 +212,17 @@ int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, 
   g.A = a.A; g.B = a.B; g.C = a.C; g.lda = a.lda; g.ldb = a.ldb; g.ldc = a.ldc; g.sA = sA; g.sB = sB; g.sC = sC;
   g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K; g.alpha = alpha; g.ident = ident; g.accumulate = a.accumulate;
   dim3 grid((unsigned)(a.N / SB_T), (unsigned)(a.M / SB_T), (unsigned)batch);
+  if (g.K == SBF_KMAX) {
+    constexpr int SM = 2 * SB_T * SBF_PITCH * 4;
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)small_bmm_full_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+                          MHIMX_HIP(hipFuncSetAttribute((const void*)small_bmm_full_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM));
+                          MHIMX_HIP(hipFuncSetAttribute((const void*)small_bmm_full_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM)));
+    if (mode == 0) hipLaunchKernelGGL((small_bmm_full_kernel<false, false>), grid, dim3(SB_THREADS), SM, st, g);
+    else if (mode == 1) hipLaunchKernelGGL((small_bmm_full_kernel<false, true>), grid, dim3(SB_THREADS), SM, st, g);
+    else hipLaunchKernelGGL((small_bmm_full_kernel<true, true>), grid, dim3(SB_THREADS), SM, st, g);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   if (mode == 0) hipLaunchKernelGGL((small_bmm_kernel<false, false>), grid, dim3(SB_THREADS), 0, st, g);
   else if (mode == 1) hipLaunchKernelGGL((small_bmm_kernel<false, true>), grid, dim3(SB_THREADS), 0, st, g);
   else hipLaunchKernelGGL((small_bmm_kernel<true, true>), grid, dim3(SB_THREADS), 0, st, g);
@@ -129,7 +230,32 @@ int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, 
   return 0;
 }
 
+static SmallBmm sb_args(const mhimx_gemm_nt_args& a, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident) {
+  SmallBmm g;
+  g.A = a.A; g.B = a.B; g.C = a.C; g.lda = a.lda; g.ldb = a.ldb; g.ldc = a.ldc; g.sA = sA; g.sB = sB; g.sC = sC;
+  g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K; g.alpha = alpha; g.ident = ident; g.accumulate = a.accumulate;
+  return g;
+}
+
 }  // namespace mhimx
+
+extern "C" int mhimx_bmm_affine_pair(void* stream, int32_t mode0, const mhimx_gemm_nt_args* a0, float alpha0, float ident0, int32_t mode1,
+                                     const mhimx_gemm_nt_args* a1, float alpha1, float ident1, int32_t batch, int64_t stride) {
+  using namespace mhimx;
+  MHIMX_CHECK_ARG(a0 && a1 && a0->A && a0->B && a0->C && a1->A && a1->B && a1->C && batch >= 1, "bmm_affine_pair: null args");
+  MHIMX_CHECK_ARG(a0->M == SBF_KMAX && a0->N == SBF_KMAX && a0->K == SBF_KMAX && a1->M == SBF_KMAX && a1->N == SBF_KMAX && a1->K == SBF_KMAX,
+                  "bmm_affine_pair: 256 x 256 x 256 products only");
+  MHIMX_CHECK_ARG(a0->C != a1->C, "bmm_affine_pair: the two products must write different outputs");
+  MHIMX_CHECK_ARG(small_bmm_ok(mode0, *a0, 2 * batch, stride, stride, stride) && small_bmm_ok(mode1, *a1, 2 * batch, stride, stride, stride),
+                  "bmm_affine_pair: 16-byte aligned contiguous operands, not the f32 mode");
+  constexpr int SM = 2 * SB_T * SBF_PITCH * 4;
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)small_bmm_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM)));
+  hipLaunchKernelGGL(small_bmm_pair_kernel, dim3(SBF_KMAX / SB_T, SBF_KMAX / SB_T, (unsigned)(2 * batch)), dim3(SB_THREADS), SM, (hipStream_t)stream,
+                     sb_args(*a0, stride, stride, stride, alpha0, ident0), (int)mode0, sb_args(*a1, stride, stride, stride, alpha1, ident1), (int)mode1,
+                     (int)batch);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA, int64_t strideB,
                                 int64_t strideC, float alpha, float ident) {

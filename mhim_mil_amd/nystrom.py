@@ -293,6 +293,22 @@ def _bmm_affine(mode, a, b, out, alpha, ident, accumulate=False):
     return out
 
 
+def _bmm_pair(p0, p1):
+    """Two independent products (mode, a, b, out, alpha, accumulate) on [B, 256, 256] batches in ONE launch (mhimx_bmm_affine_pair)."""
+    gs = []
+    for (mode, a, b, out, alpha, acc) in (p0, p1):
+        n = a.shape[-1]
+        gs.append((_MODE[mode], L.GemmNT(A=_ptr(a), lda=n, rows=None, B=_ptr(b), ldb=n, C=_ptr(out), ldc=n, M=n, N=n, K=n,
+                                         accumulate=int(bool(acc)), prec=L.PREC[_PREC]), float(alpha)))
+    B, n, _ = p0[1].shape
+    if n != 256:
+        for (mode, a, b, out, alpha, acc) in (p0, p1):
+            _bmm_affine(mode, a, b, out, alpha, 0.0, accumulate=acc)
+        return
+    L.check(L.lib().mhimx_bmm_affine_pair(_st(), gs[0][0], C.byref(gs[0][1]), gs[0][2], 0.0, gs[1][0], C.byref(gs[1][1]), gs[1][2], 0.0, B, n * n),
+            "mhimx_bmm_affine_pair")
+
+
 class MatmulAffine(torch.autograd.Function):
     """ident * I + alpha * (a @ b) on [B, n, n] in ONE launch (the pseudo-inverse iteration's "c I - M N" steps)."""
 
@@ -377,16 +393,13 @@ def _core_backward(saved, dout):
     # pseudo-inverse, backwards through the six iterations
     da2 = torch.empty_like(a2)
     first = True
-    for (zp, az, t1, t2, t3) in reversed(chain):
-        dzp = _bmm_affine("nt", dz, t3, torch.empty_like(dz), 0.25, 0.0)          # z' = 0.25 zp t3
-        dt3 = _bmm_affine("tn", zp, dz, torch.empty_like(dz), 0.25, 0.0)
-        daz = _bmm_affine("nt", dt3, t2, torch.empty_like(dz), -1.0, 0.0)         # t3 = 13 I - az t2
-        dt2 = _bmm_affine("tn", az, dt3, torch.empty_like(dz), -1.0, 0.0)
-        _bmm_affine("nt", dt2, t1, daz, -1.0, 0.0, accumulate=True)               # t2 = 15 I - az t1
-        dt1 = _bmm_affine("tn", az, dt2, torch.empty_like(dz), -1.0, 0.0)
+    for (zp, az, t1, t2, t3) in reversed(chain):                                  # four pairs of independent products per iteration
+        dzp, dt3, daz, dt2, dt1 = (torch.empty_like(dz) for _ in range(5))
+        _bmm_pair(("nt", dz, t3, dzp, 0.25, False), ("tn", zp, dz, dt3, 0.25, False))        # z' = 0.25 zp t3
+        _bmm_pair(("nt", dt3, t2, daz, -1.0, False), ("tn", az, dt3, dt2, -1.0, False))      # t3 = 13 I - az t2
+        _bmm_pair(("nt", dt2, t1, daz, -1.0, True), ("tn", az, dt2, dt1, -1.0, False))       # t2 = 15 I - az t1
         L.check(lib.mhimx_axpby(_st(), _ptr(dt1), _ptr(daz), daz.numel(), -1.0, 1.0), "axpby")      # t1 = 7 I - az
-        _bmm_affine("nt", daz, zp, da2, 1.0, 0.0, accumulate=not first)            # az = a2 zp
-        _bmm_affine("tn", a2, daz, dzp, 1.0, 0.0, accumulate=True)
+        _bmm_pair(("nt", daz, zp, da2, 1.0, not first), ("tn", a2, daz, dzp, 1.0, True))      # az = a2 zp
         dz, first = dzp, False
     dinit = torch.empty_like(a2)
     ws2 = torch.empty(256, device=dev)
