@@ -528,6 +528,18 @@ int64_t mhimx_cls_metrics_ws_bytes(int64_t n, int64_t C, int64_t B);
 int mhimx_cls_metrics(void* stream, const float* logits, int64_t ld, const int64_t* labels, int64_t n, int64_t C,
                       int32_t bin_metric, const int64_t* sample_idx, int64_t B, float* out, void* ws, int64_t ws_bytes);
 
+/* ------------------------------------------------------------------------------------------
+ * Communicator handle: the data-parallel update's ONE collective behind the C boundary.
+ * replaces: DistributedDataParallel's bucketed all-reduce (options.py:287, engines/base_engine.py:112-139); RCCL is loaded at run
+ * time (dlopen).  unique_id: 128 bytes made on rank 0 and handed to every rank by the host (any side channel); init is collective.
+ * allreduce: in-place fp32 SUM on the caller's stream; mode 0 = ncclAllReduce, 1 = reduce-scatter + all-gather (full-mesh form).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mhimx_comm mhimx_comm;
+int mhimx_comm_unique_id(void* id128);
+int mhimx_comm_init(mhimx_comm** out, const void* id128, int32_t rank, int32_t world);
+int mhimx_comm_allreduce(mhimx_comm* c, void* stream, float* buf, int64_t count, int32_t mode);
+int mhimx_comm_destroy(mhimx_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,6 +201,10 @@ SYMBOLS = {
     "mhimx_axpby": (C.c_int, [_P, _P, _P, _I64, _F, _F]),
     "mhimx_pinv_init": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "mhimx_pinv_init_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "mhimx_comm_unique_id": (C.c_int, [_P]),
+    "mhimx_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _P, _I32, _I32]),
+    "mhimx_comm_allreduce": (C.c_int, [_P, _P, _P, _I64, _I32]),
+    "mhimx_comm_destroy": (C.c_int, [_P]),
     "mhimx_nys_ws_floats": (_I64, [_I64]),
     "mhimx_nys_a3v_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P]),
     "mhimx_nys_out_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P]),

@@ -144,19 +144,23 @@ class FlatState:
         return flat
 
 
-def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, world: int, group=None) -> float:
+def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, world: int, group=None, comm=None) -> float:
     """The ONE collective of a data-parallel update (RCCL on GPUs; any backend works, gloo in the CPU tests).
 
     Everything that must agree across ranks rides in the same flat buffer: the gradient (first n_train floats) and,
     in the tail, the non-trainable parameters that each rank mutated in its own forward (merge.global_q_mm's EMA,
     merge.py:142-143).  After the SUM all-reduce the tail is averaged back into ``student``; the
     returned scale (1/world) is applied to the gradient inside the fused Adam kernel.  No data-path collective exists:
-    bags are independent units.
+    bags are independent units.  ``comm``: a ``comm.NativeComm`` (the C-ABI's own RCCL handle, ``mhimx_comm_allreduce``) instead of
+    torch.distributed - the same collective for hosts that do not run torch.distributed.
     """
     if world <= 1:
         return 1.0
     grad[n_train:].copy_(student[n_train:])
-    torch.distributed.all_reduce(grad, group=group)
+    if comm is not None:
+        comm.allreduce(grad)
+    else:
+        torch.distributed.all_reduce(grad, group=group)
     scale = 1.0 / world
     student[n_train:].copy_(grad[n_train:] * scale)
     grad[n_train:].zero_()
@@ -172,7 +176,7 @@ class _SplitStep:
     def replay(self):
         tr = self.tr
         self.g_fb.replay()
-        sync_flat_gradient(tr.flat.grad, tr.flat.student, tr.flat.n_train, tr.world, tr.pg)
+        sync_flat_gradient(tr.flat.grad, tr.flat.student, tr.flat.n_train, tr.world, tr.pg, tr.comm)
         self.g_up.replay()
 
 
@@ -194,6 +198,7 @@ class FusedTrainer:
         self.main_alpha, self.aux_alpha = main_alpha, aux_alpha
         self.accum = max(1, int(accumulation_steps))
         self.pg = process_group
+        self.comm = None                 # optional comm.NativeComm: the flat-gradient all-reduce through mhimx_comm_allreduce (C-ABI) instead
         self.world = torch.distributed.get_world_size(process_group) if self._dist() else 1
         self.model_kind = model
         self._micro = 0
@@ -288,7 +293,7 @@ class FusedTrainer:
                 d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
             if first:
                 # the six final gradient reductions of the backward (slab sums, column partials) run as ONE launch
-                hook = self._mid_hook if (self.overlap_comm and self.world > 1 and self.accum == 1 and not self._capturing
+                hook = self._mid_hook if (self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1 and not self._capturing
                                           and self._split > 0) else None
                 s._bag_backward(x, plan, saved, g_z, out=gv, defer=self._defer, mid_hook=hook)
                 ops.reduce_flush(self._defer)
@@ -373,7 +378,7 @@ class FusedTrainer:
                 main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
                 d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
             if first:
-                hook = self._mid_hook if (self.overlap_comm and self.world > 1 and self.accum == 1 and not self._capturing
+                hook = self._mid_hook if (self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1 and not self._capturing
                                           and self._split > 0) else None
                 s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=hook)
                 ops.reduce_flush(self._defer)
@@ -460,7 +465,7 @@ class FusedTrainer:
             fl.student[fl.n_train:].copy_(fl.grad[fl.n_train:] * scale)
             fl.grad[fl.n_train:].zero_()
         else:
-            scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg)
+            scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg, self.comm)
         self._apply(scale)
 
     def _apply(self, scale):
@@ -509,7 +514,7 @@ class FusedTrainer:
             g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb, pool=self._graph_pool, stream=cs):
                 self.forward_backward(bag, label, **kw)
-            scale = sync_flat_gradient(self.flat.grad, self.flat.student, self.flat.n_train, self.world, self.pg)
+            scale = sync_flat_gradient(self.flat.grad, self.flat.student, self.flat.n_train, self.world, self.pg, self.comm)
             with torch.cuda.graph(g_up, pool=self._graph_pool, stream=cs):
                 self._apply(scale)
             self.flat.grad.zero_()                         # (the capture-time all-reduce summed stale values)

@@ -32,3 +32,15 @@ def test_argument_errors_are_reported_not_thrown():
     assert lib.mhimx_abmil_pool_ws_bytes(1000, 512, 128, 0) > 0
     assert lib.mhimx_merge_ws_bytes(970, 512, 5, 8, 64) > 0
     assert lib.mhimx_select_ws_bytes(10000) >= 10000
+
+
+def test_comm_handle_argument_errors():
+    """mhimx_comm_*: argument validation needs neither a GPU nor RCCL; destroying a null handle is a no-op."""
+    import ctypes as C
+    lib = L.lib()
+    assert lib.mhimx_comm_destroy(None) == 0
+    h = C.c_void_p()
+    assert lib.mhimx_comm_init(C.byref(h), None, 0, 1) < 0
+    assert lib.mhimx_comm_init(C.byref(h), C.create_string_buffer(128), 3, 2) < 0
+    assert lib.mhimx_comm_allreduce(None, None, None, 4, 0) < 0
+    assert lib.mhimx_comm_unique_id(None) < 0
