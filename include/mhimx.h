@@ -201,6 +201,10 @@ typedef struct {
   const float* wc; const float* bc;     /* [A], [1]|NULL     attention.2 / attention_c              */
   const float* wa_frag;                 /* optional: prep kind-4 image of wa (made once per step with the other parameter
                                            preparation); NULL: the fused scorer splits wa to bf16 hi/lo on the fly   */
+  float gate_drop_p;                    /* gated form only: dropout inside the scorer (modules/abmil.py:96-98: nn.Dropout(0.25) after the
+                                           tanh and after the sigmoid branch, training mode); 0 = none                */
+  uint64_t gate_drop_seed;              /* counter-based mask of (seed, row, column j) for the tanh branch, (seed, row, A + j) for the gate:
+                                           the masks of mhimx_dropout_apply on an [M, 2A] matrix                      */
 } mhimx_scorer;
 
 /* Forward over up to two token segments (segment 1 = feature rows, segment 2 = merged tokens).
@@ -326,6 +330,9 @@ int mhimx_nys_a3v_bwd(void* stream, const mhimx_nys* a, const float* a3v, const 
                       int64_t lddk, int32_t accumulate_dv, float* dql, int64_t lddl);
 /* r[8,T] = u attn3 with u[8,256] = attn1[cls] pinv: the cls token's attention row (nystrom:143-150) */
 int mhimx_nys_cls_attn(void* stream, const mhimx_nys* a, const float* lse3, const float* u, float* r);
+/* out = x + SINCOS(pos): the parameter-free 2-d sin-cos position embedding of modules/abmil.DAttention(pos='sincos')
+ * (emb_position.py:5-83); pos_xy[N,2] = the patch grid coordinates (x, y) of every row. */
+int mhimx_sincos_add(void* stream, const float* x, const int64_t* pos_xy, int64_t N, int64_t C, float* out);
 /* PPEG (emb_position.py:85-120).  combine: wc[C,49] = w7 + pad(w5) + pad(w3) + identity, bc = b7+b5+b3;
  * fwd: y[N,C] = depth-wise 7x7 stencil of the wrap-padded H x H token grid; bwd: dx, dwc [C,49], dbc [C]. */
 int mhimx_ppeg_combine(void* stream, const float* w7, const float* w5, const float* w3, const float* b7, const float* b5,

@@ -93,7 +93,7 @@ class GemmTN(C.Structure):
 class Scorer(C.Structure):
     _fields_ = [("E", C.c_int64), ("A", C.c_int64), ("act", C.c_int32), ("gated", C.c_int32), ("prec", C.c_int32),
                 ("wa", c_f32p), ("ba", c_f32p), ("wb", c_f32p), ("bb", c_f32p), ("wc", c_f32p), ("bc", c_f32p),
-                ("wa_frag", c_f32p)]
+                ("wa_frag", c_f32p), ("gate_drop_p", C.c_float), ("gate_drop_seed", C.c_uint64)]
 
 
 class PoolIO(C.Structure):
@@ -205,6 +205,7 @@ SYMBOLS = {
     "mhimx_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _P, _I32, _I32]),
     "mhimx_comm_allreduce": (C.c_int, [_P, _P, _P, _I64, _I32]),
     "mhimx_comm_destroy": (C.c_int, [_P]),
+    "mhimx_sincos_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "mhimx_nys_ws_floats": (_I64, [_I64]),
     "mhimx_nys_a3v_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P]),
     "mhimx_nys_out_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P]),

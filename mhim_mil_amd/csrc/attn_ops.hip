@@ -639,6 +639,22 @@ __global__ void scale_heads_kernel(const float* __restrict__ v, int64_t ldv, con
     for (int c = threadIdx.x; c < C; c += blockDim.x) out[t * C + c] = v[t * ldv + c] * a[(int64_t)(c / dh) * lda + t];
 }
 
+// out[n, :] = x[n, :] + 2-d sin-cos embedding of the patch coordinate (px, py) (emb_position.py:5-83, SINCOS): four blocks of C/4 columns,
+// sin(px w_k), cos(px w_k), sin(py w_k), cos(py w_k), w_k = 10000^(-k / (C/4)).  (The reference builds the H x W table and gathers row
+// py * W + px: the same value.)
+__global__ void sincos_add_kernel(const float* __restrict__ x, const int64_t* __restrict__ pos, int64_t N, int C, float* __restrict__ out) {
+  const int Q = C / 4;
+  for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+    const float px = (float)pos[2 * n], py = (float)pos[2 * n + 1];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const int blk = c / Q, k = c % Q;
+      const float omega = 1.f / powf(10000.f, (float)k / (float)Q);
+      const float a = (blk < 2 ? px : py) * omega;
+      out[n * C + c] = x[n * C + c] + ((blk & 1) ? cosf(a) : sinf(a));
+    }
+  }
+}
+
 }  // namespace mhimx
 
 using namespace mhimx;
@@ -870,6 +886,14 @@ extern "C" int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, cons
                                  float* out) {
   MHIMX_CHECK_ARG(v && a && out && C % dh == 0, "scale_heads: bad args");
   hipLaunchKernelGGL(scale_heads_kernel, dim3(grid1d(T, 1, 16384)), dim3(AT), 0, (hipStream_t)stream, v, ldv, a, lda, (int)dh, T, (int)C, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mhimx_sincos_add(void* stream, const float* x, const int64_t* pos_xy, int64_t N, int64_t C, float* out) {
+  MHIMX_CHECK_ARG(x && pos_xy && out && C % 4 == 0 && N >= 0, "sincos_add: bad args");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(sincos_add_kernel, dim3(grid1d(N, 1, 16384)), dim3(AT), 0, (hipStream_t)stream, x, pos_xy, N, (int)C, out);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

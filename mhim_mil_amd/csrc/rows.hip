@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void score_rows_fwd_kernel(
     const float* __restrict__ T, int64_t M, int E, int A, int act, int gated, const float* __restrict__ u_pre,
     const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ wp, int C,
     float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl,
-    float* __restrict__ pz) {
+    float* __restrict__ pz, float gdrop_p, uint64_t gdrop_seed, int64_t row0 /* dropout row id of the segment's first row */) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   // sm: [FWD_WAVES][E] wave z-accumulators, then [FWD_WAVES] m, [FWD_WAVES] l
   constexpr int NWV = FWD_WAVES;
@@ -49,9 +49,19 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void score_rows_fwd_kernel(
   for (int64_t n = (int64_t)blockIdx.x * NWV + wave; n < M; n += (int64_t)gridDim.x * NWV) {
     const float* up = u_pre + n * ldu;
     float part = 0.f;
+    const bool gdrop = gated && gdrop_p > 0.f;                  // abmil.py:96-98: dropout after the tanh and after the gate
+    const uint32_t rkey = gdrop ? drop_row_key(gdrop_seed, (uint64_t)(row0 + n)) : 0u;
+    const float ginv = gdrop ? 1.f / (1.f - gdrop_p) : 1.f;
     for (int j = lane; j < A; j += 64) {
       float u = act_fwd(up[j], act);
-      if (gated) u *= sigmoidf_(up[A + j]);
+      if (gated) {
+        float sg = sigmoidf_(up[A + j]);
+        if (gdrop) {
+          u = drop_keep_k(rkey, (uint32_t)j, gdrop_p) ? u * ginv : 0.f;
+          sg = drop_keep_k(rkey, (uint32_t)(A + j), gdrop_p) ? sg * ginv : 0.f;
+        }
+        u *= sg;
+      }
       part += wc[j] * u;
     }
     const float s = wave_sum(part) + bias_c;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_bwd_kernel(
     const float* __restrict__ T, int64_t M, int E, int A, int act, int gated, const float* __restrict__ u_pre,
     const float* __restrict__ wc, const float* __restrict__ s_in, const float* __restrict__ stats,
     const float* __restrict__ g_z, const float* __restrict__ z, float* __restrict__ du, float* __restrict__ attn,
-    float* __restrict__ dwc_part, float* __restrict__ dbc_part) {
+    float* __restrict__ dwc_part, float* __restrict__ dbc_part, float gdrop_p, uint64_t gdrop_seed, int64_t row0) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][A] dwc, [4] dbc
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ldu = A * (1 + gated);
@@ -211,6 +221,9 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_bwd_kernel(
     dbc += ds;
     const float* up = u_pre + n * ldu;
     float* dp = du + n * ldu;
+    const bool gdrop = gated && gdrop_p > 0.f;
+    const uint32_t rkey = gdrop ? drop_row_key(gdrop_seed, (uint64_t)(row0 + n)) : 0u;
+    const float ginv = gdrop ? 1.f / (1.f - gdrop_p) : 1.f;
 #pragma unroll
     for (int i = 0; i < MAXJ; ++i) {
       const int j = lane + 64 * i;
@@ -220,9 +233,11 @@ __global__ __launch_bounds__(ROWS_THREADS) void score_rows_bwd_kernel(
         const float ga = act_grad(a, ya, act);
         if (gated) {
           const float sg = sigmoidf_(up[A + j]);
-          dp[j] = ds * wc[j] * sg * ga;
-          dp[A + j] = ds * wc[j] * ya * sg * (1.f - sg);
-          dwc[i] += ds * ya * sg;
+          const float ma = gdrop ? (drop_keep_k(rkey, (uint32_t)j, gdrop_p) ? ginv : 0.f) : 1.f;       // the forward's two masks
+          const float mb = gdrop ? (drop_keep_k(rkey, (uint32_t)(A + j), gdrop_p) ? ginv : 0.f) : 1.f;
+          dp[j] = ds * wc[j] * (sg * mb) * ga * ma;
+          dp[A + j] = ds * wc[j] * (ya * ma) * sg * (1.f - sg) * mb;
+          dwc[i] += ds * (ya * ma) * (sg * mb);
         } else {
           dp[j] = ds * wc[j] * ga;
           dwc[i] += ds * ya;
@@ -845,7 +860,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       hipLaunchKernelGGL(score_rows_fwd_kernel<EPL>, dim3(grid), dim3(64 * FWD_WAVES), smem, st, Tseg, Mseg, (int)E, (int)A,
                          sc->act, gated, u_pre + off * ldu, sc->wc, sc->bc, io->cproj ? io->wp : nullptr, (int)io->C,
                          io->s + off, io->cproj ? io->cproj + off * io->C : nullptr, w.pm + G, w.pl + G,
-                         w.pz + (int64_t)G * E);
+                         w.pz + (int64_t)G * E, sc->gate_drop_p, sc->gate_drop_seed, off);
       MHIMX_LAUNCH_CHECK();
       return 0;
     });
@@ -902,7 +917,8 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       const size_t smem = (size_t)(4 * A + 8) * sizeof(float);
       hipLaunchKernelGGL(score_rows_bwd_kernel<EPL>, dim3(grid), dim3(ROWS_THREADS), smem, st, Tseg, Mseg, (int)E, (int)A,
                          sc->act, gated, u_pre + off * ldu, sc->wc, io->s + off, io->stats, gr->g_z, io->z,
-                         w.du + off * ldu, w.attn + off, w.dwc_part + (int64_t)G * A, w.dbc_part + G);
+                         w.du + off * ldu, w.attn + off, w.dwc_part + (int64_t)G * A, w.dbc_part + G, sc->gate_drop_p,
+                         sc->gate_drop_seed, off);
       MHIMX_LAUNCH_CHECK();
       return 0;
     });

@@ -194,14 +194,15 @@ def transpose(x, out=None):
 class ScorerW:
     """Scorer weights in the C layout (keeps the tensors alive)."""
 
-    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="bf16x3", wa_frag=None):
+    def __init__(self, wa, wc, act, ba=None, wb=None, bb=None, bc=None, prec="bf16x3", wa_frag=None, gate_drop_p=0.0, gate_drop_seed=0):
         self.t = (wa, wc, ba, wb, bb, bc, wa_frag)
         for t in self.t:
             _chk(t, name="scorer weight")
         self.A, self.E = wa.shape
         self.gated = wb is not None
         self.c = L.Scorer(E=self.E, A=self.A, act=int(act), gated=int(self.gated), prec=prec_code(prec), wa=_p(wa),
-                          ba=_p(ba), wb=_p(wb), bb=_p(bb), wc=_p(wc), bc=_p(bc), wa_frag=_p(wa_frag))
+                          ba=_p(ba), wb=_p(wb), bb=_p(bb), wc=_p(wc), bc=_p(bc), wa_frag=_p(wa_frag),
+                          gate_drop_p=float(gate_drop_p), gate_drop_seed=int(gate_drop_seed) & 0xFFFFFFFFFFFFFFFF)
 
 
 class PoolState:

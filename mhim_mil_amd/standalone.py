@@ -11,10 +11,12 @@
 Same parameter names and shapes as the reference modules (a reference checkpoint loads with ``load_state_dict``), the
 reference initialisation (xavier-normal weights, zero biases: abmil.py:8-21), and trainable through autograd: the
 embedding and the scorer + softmax pool are ``torch.autograd.Function``s over libmhimx.so (GEMM with fused bias /
-activation / counter-based dropout; mhimx_abmil_pool_fwd / _bwd with the bias gradients).  Supported configuration: the
-factory's defaults (``mil_norm=None``, ``pos=None``, ``embed_feat=True``); the gated scorer's inner dropouts
-(abmil.py:96-98, active only when ``dropout`` is set) are not fused into the scorer kernel: AttentionGated raises in
-training mode when ``dropout > 0``.  CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
+activation / counter-based dropout; mhimx_abmil_pool_fwd / _bwd with the bias gradients).  Options: ``mil_norm`` None / 'ln'
+(LayerNorm before the embedding, ``embed_norm_pos=0``, or after it, ``=1``, plus ``norm1`` on the pooled vector: abmil.py:171-178,
+transmil.py:83-84), ``pos`` None / 'none' / 'sincos' (abmil, emb_position.py:5-83) and 'ppeg' / 'none' (transmil); the gated
+scorer's inner dropouts (abmil.py:96-98, active in training when ``dropout`` is set) run inside the scorer's row kernels
+(``mhimx_scorer.gate_drop_p``).  Not built: ``mil_norm='bn'`` (BatchNorm over the instances of ONE bag) and ``embed_feat=False``.
+CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
 """
 from __future__ import annotations
 
@@ -41,6 +43,7 @@ class _EmbedFn(torch.autograd.Function):
         H = ops.gemm_nt(x, w, rows=rows, bias=b, act=act, pre=pre, drop_p=drop_p, drop_seed=seed, prec="bf16x3")
         ctx.save_for_backward(x, H, pre, rows)
         ctx.cfg = (act, drop_p, seed, b is not None)
+        ctx.w = w
         return H
 
     @staticmethod
@@ -50,16 +53,23 @@ class _EmbedFn(torch.autograd.Function):
         g = dH.contiguous().clone()
         g, db = ops.act_bwd(g, H, pre, act, drop_p, seed, None, rows, want_colsum=True)
         dw = ops.gemm_tn(g, x, rows=rows, splits=8 if g.shape[0] >= 2048 else 1, prec="bf16x3")
-        return None, dw, (db if has_b else None), None, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:                              # a LayerNorm in front of the embedding (mil_norm='ln'): dx = dPre W
+            if rows is not None:
+                raise L.MhimxError("_EmbedFn: an input gradient through a row gather is not built")
+            w = ctx.w
+            dx = torch.empty_like(x)
+            NY._gemm("nn", g, 0, g.shape[1], w, 0, w.shape[1], dx, 0, x.shape[1], g.shape[0], x.shape[1], g.shape[1])
+        return dx, dw, (db if has_b else None), None, None, None, None
 
 
 class _PoolFn(torch.autograd.Function):
     """z = softmax_n(scorer(T)) T  (mhimx_abmil_pool_fwd) with every scorer weight and bias trainable."""
 
     @staticmethod
-    def forward(ctx, T, wa, ba, wc, bc, wb, bb, act):
+    def forward(ctx, T, wa, ba, wc, bc, wb, bb, act, gate_p=0.0, gate_seed=0):
         T = T.contiguous()
-        sc = ops.ScorerW(wa, wc, act, ba=ba, wb=wb, bb=bb, bc=bc, prec="bf16x3")
+        sc = ops.ScorerW(wa, wc, act, ba=ba, wb=wb, bb=bb, bc=bc, prec="bf16x3", gate_drop_p=gate_p, gate_drop_seed=gate_seed)
         st = ops.abmil_pool_fwd(sc, T)
         ctx.sc, ctx.st = sc, st
         ctx.gated = wb is not None
@@ -73,7 +83,7 @@ class _PoolFn(torch.autograd.Function):
         g = ops.abmil_pool_bwd(sc, st, g_z.contiguous(), ops.transpose(wa), ops.transpose(wb) if ctx.gated else None,
                                need_bias=ba is not None or bc is not None)
         return (g["dT1"], g["d_wa"], g.get("d_ba") if ba is not None else None, g["d_wc"], g.get("d_bc") if bc is not None else None,
-                g.get("d_wb") if ctx.gated else None, g.get("d_bb") if (ctx.gated and bb is not None) else None, None)
+                g.get("d_wb") if ctx.gated else None, g.get("d_bb") if (ctx.gated and bb is not None) else None, None, None, None)
 
 
 def _linear(i, o, bias=True):
@@ -86,6 +96,34 @@ def _linear(i, o, bias=True):
 
 class _Slot(nn.Module):                                   # a parameter-free layer of the reference's nn.Sequential (keeps the indices)
     pass
+
+
+class _SinCosAdd(torch.autograd.Function):
+    """x + SINCOS(pos) (emb_position.py:5-83): parameter-free, the gradient passes through."""
+
+    @staticmethod
+    def forward(ctx, x, pos_xy):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        L.check(L.lib().mhimx_sincos_add(NY._st(), NY._ptr(x), ops._p(pos_xy), x.shape[0], x.shape[1], NY._ptr(out)), "mhimx_sincos_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def _layernorm(dim, bias=True):
+    """nn.LayerNorm(dim, bias=mil_bias) under the reference's initialisation (weight 1, bias 0: abmil.py:15-17)."""
+    m = nn.Module()
+    m.weight = nn.Parameter(torch.ones(dim))
+    m.bias = nn.Parameter(torch.zeros(dim)) if bias else None
+    return m
+
+
+def _ln(x, m):
+    b = m.bias if m.bias is not None else torch.zeros_like(m.weight)
+    return NY.LayerNorm.apply(x, m.weight, b)
 
 
 class _AttnMILBase(nn.Module):
@@ -102,8 +140,20 @@ class _AttnMILBase(nn.Module):
         self._step = getattr(self, "_step", 0) + 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
+    def _norm_cfg(self, mil_norm, who):
+        if mil_norm not in (None, "ln"):
+            raise L.MhimxError(f"{who} (mhimx): mil_norm={mil_norm!r} is not built (None and 'ln' are; 'bn' normalises over the "
+                               "instances of one bag with running statistics - not on this path)")
+        return mil_norm
+
     def _embed(self, x, rows=None):
-        f = self.feature[0]
+        """self.feature: [LayerNorm(input_dim)]? + Linear + act? + Dropout?  (the reference's nn.Sequential indices)"""
+        i = 1 if getattr(self, "_ln_first", False) else 0
+        if i:
+            if rows is not None:
+                raise L.MhimxError("_embed: LayerNorm + row gather is handled by the caller")
+            x = _ln(x, self.feature[0])
+        f = self.feature[i]
         p = self.embed_drop if self.training else 0.0
         return _EmbedFn.apply(x, f.weight, f.bias, L.ACT[self.act], float(p), self._seed(), rows)
 
@@ -114,14 +164,23 @@ class DAttention(_AttnMILBase):
     def __init__(self, input_dim, n_classes, dropout, act, mil_norm=None, mil_bias=True, mil_cls_bias=True, inner_dim=512,
                  embed_feat=True, embed_norm_pos=0, pos=None, **kwargs):
         super().__init__()
-        if mil_norm is not None or pos not in (None, "none") or not embed_feat:
-            raise L.MhimxError("DAttention (mhimx): only the factory defaults (mil_norm=None, pos=None, embed_feat=True) are built")
+        if pos not in (None, "none", "sincos") or embed_norm_pos not in (0, 1):
+            raise L.MhimxError("DAttention: pos in ('sincos', 'none', None), embed_norm_pos in (0, 1) (abmil.py:159-160)")
+        if not embed_feat:
+            raise L.MhimxError("DAttention (mhimx): embed_feat=False is not built")
+        self.mil_norm, self.embed_norm_pos, self.pos = self._norm_cfg(mil_norm, "DAttention"), embed_norm_pos, pos
         if mil_bias:
             mil_cls_bias = True
         self.L, self.D, self.K = inner_dim, 128, 1
         self.act = "gelu" if act.lower() == "gelu" else "relu"
         self.embed_drop = 0.25 if dropout else 0.0                          # abmil.py:190-191: a FIXED 0.25 when dropout is set
-        layers = [_linear(input_dim, inner_dim, mil_bias), _Slot()] + ([_Slot()] if dropout else [])
+        self._ln_first = mil_norm == "ln" and embed_norm_pos == 0
+        layers = ([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + [_linear(input_dim, inner_dim, mil_bias), _Slot()] \
+            + ([_Slot()] if dropout else [])
+        if mil_norm == "ln":
+            if embed_norm_pos == 1:
+                self.norm = _layernorm(inner_dim, mil_bias)
+            self.norm1 = _layernorm(self.L * self.K, mil_bias)
         self.feature = nn.Sequential(*layers)
         self.attention = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot(), _linear(self.D, self.K, mil_bias))
         self.classifier = _linear(self.L * self.K, n_classes, mil_cls_bias)
@@ -129,10 +188,19 @@ class DAttention(_AttnMILBase):
     def forward(self, x, return_attn=False, no_norm=False, return_act=False, pos=None, return_img_feat=False, **kwargs):
         x = self._check(x)
         H = self._embed(x)
+        if self.pos == "sincos":                                             # abmil.py:216-217, emb_position.py:62-83
+            if pos is None:
+                raise L.MhimxError("DAttention(pos='sincos'): forward needs the patch coordinates `pos`")
+            pp = pos[0] if pos.dim() == 3 else pos                            # [1 + N, 2]: (W, H) of the grid, then (x, y) per patch
+            H = _SinCosAdd.apply(H, pp[1:].to(device=H.device, dtype=torch.int64).contiguous())
+        if self.mil_norm == "ln" and self.embed_norm_pos == 1:
+            H = _ln(H, self.norm)
         a0, a2 = self.attention[0], self.attention[2]
         z, s, stats = _PoolFn.apply(H, a0.weight, a0.bias, a2.weight, a2.bias, None, None, L.ACT["tanh"])
-        logits = NY.Linear.apply(z.view(1, -1), self.classifier.weight, self.classifier.bias, 0.0, 0, None)
-        out = [logits, z.view(1, -1).clone()] if return_img_feat else logits
+        zz = z.view(1, -1)
+        zc = _ln(zz, self.norm1) if self.mil_norm == "ln" else zz           # abmil.py:237
+        logits = NY.Linear.apply(zc, self.classifier.weight, self.classifier.bias, 0.0, 0, None)
+        out = [logits, zz.clone()] if return_img_feat else logits
         if not return_attn:
             return out
         res = [out, ops.softmax_from_stats(s, stats).view(1, -1)]            # abmil.py:236-241 (always the normalised attention)
@@ -147,12 +215,18 @@ class AttentionGated(_AttnMILBase):
     def __init__(self, input_dim, n_classes, act="relu", dropout=0., mil_norm=None, mil_bias=True, mil_cls_bias=True, inner_dim=512,
                  embed_feat=True, embed_norm_pos=0, pos=None, **kwargs):
         super().__init__()
-        if mil_norm is not None:
-            raise L.MhimxError("AttentionGated (mhimx): only mil_norm=None is built")
+        self.mil_norm, self.embed_norm_pos = self._norm_cfg(mil_norm, "AttentionGated"), embed_norm_pos
+        if mil_norm == "ln" and embed_norm_pos == 0:
+            # abmil.py:66 appends to self.feature before it exists: the reference constructor raises AttributeError for this setting
+            raise L.MhimxError("AttentionGated(mil_norm='ln', embed_norm_pos=0): the reference constructor fails here (abmil.py:66); "
+                               "use embed_norm_pos=1")
         self.L, self.D, self.K = inner_dim, 384, 1
         self.act = act if act in ("gelu", "relu") else "none"
         self.embed_drop = float(dropout)                                    # abmil.py:79: nn.Dropout(dropout)
         self.scorer_drop = 0.25 if dropout else 0.0                         # abmil.py:96-98
+        if mil_norm == "ln":
+            self.norm = _layernorm(inner_dim, mil_bias)
+            self.norm1 = _layernorm(self.L * self.K, mil_bias)              # (constructed, never applied: abmil.py:111-143)
         self.feature = nn.Sequential(*([_linear(input_dim, inner_dim, mil_bias)] + ([_Slot()] if act in ("gelu", "relu") else []) + [_Slot()]))
         self.attention_a = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot())
         self.attention_b = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot())
@@ -160,33 +234,37 @@ class AttentionGated(_AttnMILBase):
         self.classifier = nn.Sequential(_linear(self.L * self.K, n_classes, mil_bias))
 
     def forward(self, x, **kwargs):
-        if self.training and self.scorer_drop > 0:
-            raise L.MhimxError("AttentionGated (mhimx): the dropouts inside the gated scorer (abmil.py:96-98) are not fused into the "
-                               "scorer kernel; train with dropout=0 or evaluate with model.eval()")
         x = self._check(x)
         H = self._embed(x)
+        if self.mil_norm == "ln":
+            H = _ln(H, self.norm)
         a, b, c = self.attention_a[0], self.attention_b[0], self.attention_c
-        z, _, _ = _PoolFn.apply(H, a.weight, a.bias, c.weight, c.bias, b.weight, b.bias, L.ACT["tanh"])
+        gp = self.scorer_drop if self.training else 0.0                     # abmil.py:96-98: Dropout(0.25) after the tanh and after the gate
+        z, _, _ = _PoolFn.apply(H, a.weight, a.bias, c.weight, c.bias, b.weight, b.bias, L.ACT["tanh"], float(gp), self._seed())
         cl = self.classifier[0]
         return NY.Linear.apply(z.view(1, -1), cl.weight, cl.bias, 0.0, 0, None)
 
 
 class TransMIL(_AttnMILBase):
-    """modules/transmil.py:66-175 (pos='ppeg', mil_norm=None): tokens wrap-padded to a square (transmil.py:124-128) - a row gather
+    """modules/transmil.py:66-175: tokens wrap-padded to a square (transmil.py:124-128) - a row gather
     fused into the embedding GEMM, no copy - then the encoder of SURVEY rows A9/A10 (mhim_mil_amd/nystrom.py) and a classifier.
-    Any bag size: this model's PPEG is told the grid (transmil.py:57-64), it does not zero-pad to 7 x 7 as emb_position.PPEG does."""
+    Any bag size: this model's PPEG is told the grid (transmil.py:57-64), it does not zero-pad to 7 x 7 as emb_position.PPEG does.
+    pos='none' drops the PPEG (transmil.py:73-74,145-146); mil_norm='ln' puts a LayerNorm in front of the embedding (:83-84)."""
 
     def __init__(self, input_dim, n_classes, dropout, act, mil_norm=None, mil_bias=True, inner_dim=512, embed_feat=True, pos="ppeg",
                  n_heads=8, **kwargs):
         super().__init__()
-        if mil_norm is not None or pos != "ppeg" or not embed_feat or inner_dim != 512 or n_heads != 8:
-            raise L.MhimxError("TransMIL (mhimx): built for the factory defaults (mil_norm=None, pos='ppeg', inner_dim=512, 8 heads)")
-        self.act = "gelu" if act.lower() == "gelu" else "relu"
+        if not embed_feat or inner_dim != 512 or n_heads != 8:
+            raise L.MhimxError("TransMIL (mhimx): built for embed_feat=True, inner_dim=512, 8 heads")
+        self.mil_norm, self.pos = self._norm_cfg(mil_norm, "TransMIL"), pos
+        self.act = "gelu" if act.lower() == "gelu" else ("relu" if act.lower() == "relu" else "none")
         self.embed_drop = 0.25 if dropout else 0.0
-        self.feature = nn.Sequential(*([_linear(input_dim, inner_dim, mil_bias), _Slot()] + ([_Slot()] if dropout else [])))
+        self._ln_first = mil_norm == "ln"
+        self.feature = nn.Sequential(*(([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + [_linear(input_dim, inner_dim, mil_bias)]
+                                       + ([_Slot()] if self.act != "none" else []) + ([_Slot()] if dropout else [])))
         self.cls_token = nn.Parameter(torch.randn(1, 1, inner_dim) * 1e-6)      # transmil.py:99-100
         self.layer1, self.layer2 = NY.TransLayer(inner_dim), NY.TransLayer(inner_dim)
-        self.pos_layer = NY._PPEG(inner_dim)
+        self.pos_layer = NY._PPEG(inner_dim) if pos != "none" else nn.Identity()
         self.norm = NY._P(weight=torch.ones(inner_dim), bias=torch.zeros(inner_dim))
         self.classifier = _linear(inner_dim, n_classes, mil_bias)
         self.n_classes = n_classes
@@ -201,7 +279,15 @@ class TransMIL(_AttnMILBase):
         rows = None
         if add > 0:                                                      # x = cat([x, x[:add]]) as a gather index
             rows = torch.cat([torch.arange(n, device=x.device), torch.arange(add, device=x.device)])
-        h = self._embed(x, rows)
+        if self._ln_first and rows is not None:
+            # LayerNorm is row-wise: normalise the n bag rows once, append the wrapped rows as an autograd index (rows 0..add-1 get both
+            # gradients), and embed without a gather
+            xn = _ln(x, self.feature[0])
+            xn = torch.cat([xn, xn[:add]], 0)
+            f = self.feature[1]
+            h = _EmbedFn.apply(xn, f.weight, f.bias, L.ACT[self.act], float(self.embed_drop if self.training else 0.0), self._seed(), None)
+        else:
+            h = self._embed(x, rows)
         tr = self.training
         s1, s2 = self._seed(), self._seed()
         t = torch.cat([self.cls_token.view(1, -1), h], 0)
@@ -211,7 +297,8 @@ class TransMIL(_AttnMILBase):
             attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))     # transmil.py:138-141
         else:
             t = self.layer1(t, False, False, s1, None, tr)
-        t = torch.cat([t[:1], self.pos_layer(t[1:], grid=side)], 0)
+        if self.pos != "none":
+            t = torch.cat([t[:1], self.pos_layer(t[1:], grid=side)], 0)
         if return_attn:
             t, a, _ = self.layer2(t, True, False, s2, None, tr)
             attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))

@@ -480,6 +480,39 @@ def g15_standalone_transmil(ns):
               **_compact_all("grad", _grads(m)))
 
 
+def g17_standalone_options(ns):
+    """The non-default options of the standalone models (VERDICT r1 N4 gaps): mil_norm='ln' at both positions and norm1 (abmil.py:171-178,
+    :237), pos='sincos' (emb_position.py:5-83), the gated model with a LayerNorm (abmil.py:68-70), TransMIL with mil_norm='ln' and with
+    pos='none' (transmil.py:73-74,83-84).  Train mode, dropout off; logits and every parameter gradient of CE(logits, label)."""
+    if ns.abmil is None or getattr(ns, "transmil", None) is None:
+        print("  (modules/abmil.py / transmil.py not importable: skipped)")
+        return
+    n, d = 300, 64
+    x = _x(35, n, d)
+    W, Hh = 23, 17
+    rs = np.random.RandomState(5)
+    cells = rs.permutation(W * Hh)[:n]
+    pos = torch.from_numpy(np.concatenate([[[W, Hh]], np.stack([cells % W, cells // W], 1)], 0).astype(np.int64)).unsqueeze(0)
+    cases = (("abmil_ln0", "abmil", dict(dropout=0.0, act="gelu", mil_norm="ln", embed_norm_pos=0), 51, {}),
+             ("abmil_ln1", "abmil", dict(dropout=0.0, act="relu", mil_norm="ln", embed_norm_pos=1), 52, {}),
+             ("abmil_sincos", "abmil", dict(dropout=0.0, act="gelu", pos="sincos"), 53, {"pos": pos}),
+             ("gabmil_ln1", "gabmil", dict(act="gelu", dropout=0., mil_norm="ln", embed_norm_pos=1), 54, {}),
+             ("transmil_ln", "transmil", dict(dropout=False, act="gelu", mil_norm="ln"), 55, {}),
+             ("transmil_posnone", "transmil", dict(dropout=False, act="relu", pos="none"), 56, {}))
+    for name, kind, kw, pseed, fkw in cases:
+        cls = {"abmil": ns.abmil.DAttention, "gabmil": ns.abmil.AttentionGated, "transmil": ns.transmil.TransMIL}[kind]
+        m = _fill_module(cls(d, 2, **kw), pseed)
+        m = m.eval() if kind == "transmil" else m.train()
+        out = m(x.clone(), **fkw)
+        logits = out[0] if isinstance(out, (list, tuple)) else out
+        loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([1]))
+        loss.backward()
+        extra = {"pos": pos.numpy()} if fkw else {}
+        _save(f"g17_standalone_opt_{name}", dict(n=n, d=d, xseed=35, pseed=pseed, std=0.05, label=1, kind=kind, kwargs=kw,
+                                                 keys=list(m.state_dict().keys()), shapes=[list(v.shape) for v in m.state_dict().values()]),
+              logits=logits.view(-1).detach().numpy(), loss=loss.item(), **extra, **_compact_all("grad", _grads(m)))
+
+
 def g16_student_eval(ns):
     """MHIM.forward with the module in eval mode (mhim.py:318-378: mask applied, Merge keeps every surviving row and appends the k tokens
     merged from all of them, merge.py:197-203) - the branch the reference's trainer never takes but the class allows."""
@@ -523,7 +556,7 @@ def main():
     only = set(sys.argv[1:])                     # python -m oracle.gen_golden g14_standalone_train  -> just that family
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
                g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil,
-               g14_standalone_train, g15_standalone_transmil, g16_student_eval):
+               g14_standalone_train, g15_standalone_transmil, g16_student_eval, g17_standalone_options):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

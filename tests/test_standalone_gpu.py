@@ -80,11 +80,91 @@ def test_factory_and_guards():
     assert isinstance(pure, MHIM) and not pure.merge_enable
     with pytest.raises(NotImplementedError):
         build_model("clam_sb", input_dim=64, n_classes=2)
-    g = build_model("gabmil", input_dim=64, n_classes=2, act="relu", dropout=0.25).to(DEV).train()
     with pytest.raises(L.MhimxError):
-        g(torch.zeros(1, 8, 64, device=DEV))
-    with pytest.raises(L.MhimxError):
-        build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="ln")
+        build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="bn")
+    with pytest.raises(L.MhimxError):                     # the reference constructor itself fails here (abmil.py:66)
+        build_model("gabmil", input_dim=64, n_classes=2, act="relu", mil_norm="ln", embed_norm_pos=0)
+
+
+@pytest.mark.parametrize("name", G.names("g17_standalone_opt"))
+def test_standalone_options_fixture(name):
+    """mil_norm='ln' (both positions, norm1), pos='sincos', the gated model with a LayerNorm, TransMIL with mil_norm='ln' / pos='none':
+    logits and every parameter gradient vs fixtures made by importing the reference modules (oracle/gen_golden.py g17)."""
+    from mhim_mil_amd.standalone import build_model
+    meta, a = G.load(name)
+    m = build_model(meta["kind"], input_dim=meta["d"], n_classes=2, **meta["kwargs"])
+    sd = {k: torch.from_numpy(synth.normal(meta["pseed"], tuple(shape), std=meta["std"], lane=i + 1).astype(np.float32))
+          for i, (k, shape) in enumerate(zip(meta["keys"], meta["shapes"]))}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    m = m.to(DEV)
+    m = m.eval() if meta["kind"] == "transmil" else m.train()
+    fkw = {"pos": torch.from_numpy(a["pos"]).to(DEV)} if "pos" in a else {}
+    logits = m(_x(meta), **fkw)
+    loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([meta["label"]], device=DEV))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy().reshape(-1), a["logits"].reshape(-1), atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), float(a["loss"]), rtol=1e-3)
+    grads = G.tagged(a, "grad")
+    params = dict(m.named_parameters())
+    assert set(grads) <= set(params)
+    for k in set(params) - set(grads):                  # constructed but never applied in the reference (AttentionGated.norm1): no gradient there either
+        assert params[k].grad is None, k
+    relu = meta["kwargs"].get("act") == "relu"
+    tm = meta["kind"] == "transmil"
+    for k, exp in grads.items():
+        g = params[k].grad
+        assert g is not None, k
+        scale = max(float(np.abs(exp["full"]).max()) if "full" in exp else float(exp["norm"]) / np.sqrt(max(1, g.numel())), 1e-12)
+        G.check_compact(g.cpu().numpy(), exp, rtol=5e-3 if tm else 2e-3, atol=max((2e-2 if relu else (5e-3 if tm else 2e-4)) * scale, 1e-6),
+                        what=f"{name}:{k}")
+
+
+def test_gated_scorer_dropouts_match_the_masked_math():
+    """modules/abmil.py:96-98: Dropout(0.25) after the tanh and after the sigmoid gate, inside the scorer's row kernels
+    (mhimx_scorer.gate_drop_p).  torch's Philox masks cannot be reproduced, so the kernel's own counter-based masks are read back
+    through mhimx_dropout_apply on an [M, 2A] matrix of ones and the masked scorer is recomputed in fp64 (forward and every gradient)."""
+    import ctypes as C
+    from mhim_mil_amd import _lib as L, ops
+    torch.manual_seed(3)
+    M, E, A, p, seed = 700, 512, 384, 0.25, 0x1234567
+    T = (torch.randn(M, E, device=DEV) * 0.5).requires_grad_()
+    wa, wb = (torch.randn(A, E, device=DEV) * 0.05 for _ in range(2))
+    ba, bb = (torch.randn(A, device=DEV) * 0.1 for _ in range(2))
+    wc, bc = torch.randn(1, A, device=DEV) * 0.3, torch.randn(1, device=DEV)
+    ones = torch.ones(M, 2 * A, device=DEV)
+    mask = torch.empty_like(ones)
+    L.check(L.lib().mhimx_dropout_apply(ops._stream(), ops._p(ones), ops._p(mask), M, 2 * A, p, seed, None), "dropout_apply")
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - 0.75) < 0.01 and torch.unique(mask).numel() == 2
+    sc = ops.ScorerW(wa, wc, L.ACT["tanh"], ba=ba, wb=wb, bb=bb, bc=bc, prec="bf16x3", gate_drop_p=p, gate_drop_seed=seed)
+    st = ops.abmil_pool_fwd(sc, T.detach())
+    g_z = torch.randn(E, device=DEV)
+    g = ops.abmil_pool_bwd(sc, st, g_z, ops.transpose(wa), ops.transpose(wb), need_bias=True)
+    # fp64 restatement with the same masks
+    Td = T.detach().double().requires_grad_()
+    P = [t.double().requires_grad_() for t in (wa, ba, wb, bb, wc)]
+    md = mask.double()
+    u = torch.tanh(Td @ P[0].t() + P[1]) * md[:, :A]
+    gt = torch.sigmoid(Td @ P[2].t() + P[3]) * md[:, A:]
+    s = (u * gt) @ P[4].t() + bc.double()
+    z = (torch.softmax(s.view(-1), 0).unsqueeze(0) @ Td).view(-1)
+    z.backward(g_z.double())
+    rel = lambda x, y: float((x.double() - y).abs().max() / y.abs().max().clamp_min(1e-30))
+    assert rel(st.z.view(-1), z.detach()) < 2e-5
+    assert rel(g["dT1"], Td.grad) < 2e-4
+    for key, ref in (("d_wa", P[0].grad), ("d_ba", P[1].grad), ("d_wb", P[2].grad), ("d_bb", P[3].grad), ("d_wc", P[4].grad)):
+        assert rel(g[key].view(ref.shape), ref) < 5e-4, key
+    # p = 0 leaves the scorer unchanged, and the standalone model trains with its dropouts on
+    from mhim_mil_amd.standalone import build_model
+    gm = build_model("gabmil", input_dim=64, n_classes=2, act="relu", dropout=0.25).to(DEV).train()
+    x = torch.randn(1, 200, 64, device=DEV)
+    l1 = gm(x)
+    l1.sum().backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in gm.parameters())
+    gm.eval()
+    with torch.no_grad():
+        assert torch.equal(gm(x), gm(x))
 
 
 @pytest.mark.parametrize("name", G.names("g15_standalone_transmil"))
