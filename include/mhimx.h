@@ -437,7 +437,8 @@ int mhimx_rows_dpre(void* stream, const float* dH, const void* dact16, const int
 /* The same backward with dPre emitted as the MATRIX-CORE IMAGE of its transpose instead of an fp32 matrix (E % 128 == 0): for every
  * 32-row step ks and 128-column block it, 16 KiB at img + (ks * E/128 + it) * 16384 laid out [row octet 4][hi | lo][slot 128][8 bf16],
  * slot of column c = (c % 4) * 32 + (c % 128) / 4, value = hi + lo to ~2^-16; rows past L are zero.  mhimx_wgrad_image_bytes(L, E)
- * bytes.  colsum_out as above (ws: ceil(L/32) * E floats).  Feeds mhimx_bag_wgrad. */
+ * bytes.  colsum_out as above (ws: ceil(L/32) * E floats).  Feeds mhimx_bag_wgrad.  dact16 NULL: dPre = dH[rows] as it is - the
+ * image of ANY [L, E] gradient matrix (the Linear layers of the TransMIL encoder: nystrom_attention.py:55,57 under autograd). */
 int64_t mhimx_wgrad_image_bytes(int64_t L, int64_t E);
 int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
                           float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);

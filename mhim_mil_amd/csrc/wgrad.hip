@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __res
     for (int q = 0; q < 8; ++q) {
       const int64_t rr = r[q] < 0 ? 0 : r[q];
       gv[q] = reinterpret_cast<const f32x4*>(dH + rr * E)[cq];
-      dv[q] = reinterpret_cast<const h4v*>(dact + rr * E)[cq];
+      dv[q] = dact ? reinterpret_cast<const h4v*>(dact + rr * E)[cq] : h4v{(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -607,7 +607,7 @@ extern "C" int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D) {
 
 extern "C" int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
                                      float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
-  MHIMX_CHECK_ARG(dH && dact16 && img && L >= 1 && E >= WBI && E % WBI == 0 && aligned16(dH) && aligned16(img) &&
+  MHIMX_CHECK_ARG(dH && img && L >= 1 && E >= WBI && E % WBI == 0 && aligned16(dH) && aligned16(img) &&
                       (reinterpret_cast<uintptr_t>(dact16) & 7) == 0,
                   "rows_dpre_image: E must be a multiple of 128, buffers aligned");
   const int64_t ksteps = cdiv(L, WBK), nblk = ksteps, ncb = cdiv(E, 256);

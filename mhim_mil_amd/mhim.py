@@ -168,8 +168,12 @@ class _FeatureFn(torch.autograd.Function):
         p = model.dropout_p if plan.training else 0.0
         _, db = ops.act_bwd(dH, ctx.H, ctx.PRE, L.act_code(model.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
                             want_colsum=True, drop_tick=model._tick)
-        dW = ops.gemm_tn(dH, ctx.x, rows=plan.rows, splits=8 if plan.L >= 2048 else 1,
-                         prec="f32" if model.prec == "f32" else "bf16x3", M=plan.L)
+        if plan.L >= 2048 and model.prec != "f32" and ops.bag_wgrad_ok(ctx.x, dH.shape[1], plan.L):
+            # the matrix-core-image weight-gradient pair (csrc/wgrad.hip): dH is compact, the bag rows are gathered
+            dW, _ = ops.bag_wgrad(dH, None, ctx.x, plan.rows, plan.L, rows_dh=None, want_bias=False)
+        else:
+            dW = ops.gemm_tn(dH, ctx.x, rows=plan.rows, splits=8 if plan.L >= 2048 else 1,
+                             prec="f32" if model.prec == "f32" else "bf16x3", M=plan.L)
         return None, None, None, dW, db
 
 

@@ -502,12 +502,19 @@ class TransLayerFn(torch.autograd.Function):
         if pad:
             dout[:pad].zero_()
         _gemm("nn", g, 0, E, w_out, 0, INNER, dout, pad * INNER, INNER, n, INNER, E)
-        dw_out = ops.gemm_tn(g, out[pad:], splits=8 if n >= 4096 else 1, prec=_PREC)
-        db_out = ops.colsum(g)
+        big = n >= 2048 and _PREC == "bf16x3" and ops.bag_wgrad_ok(x, INNER, n)      # the matrix-core-image weight-gradient pair (csrc/wgrad.hip)
+        if big:
+            dw_out, db_out = ops.bag_wgrad(g, None, out[pad:], None, n)
+        else:
+            dw_out = ops.gemm_tn(g, out[pad:], splits=8 if n >= 4096 else 1, prec=_PREC)
+            db_out = ops.colsum(g)
         dqkv, dwc = _core_backward(saved, dout)
         dxn = torch.empty_like(x)
         _gemm("nn", dqkv, pad * 3 * INNER, 3 * INNER, w_qkv, 0, E, dxn, 0, E, n, E, 3 * INNER)
-        dw_qkv = ops.gemm_tn(dqkv[pad:], xn, splits=8 if n >= 4096 else 1, prec=_PREC)
+        if big:
+            dw_qkv, _ = ops.bag_wgrad(dqkv[pad:], None, xn, None, n, want_bias=False)
+        else:
+            dw_qkv = ops.gemm_tn(dqkv[pad:], xn, splits=8 if n >= 4096 else 1, prec=_PREC)
         dx, dlw, dlb = torch.empty_like(x), torch.empty_like(ln_w), torch.empty_like(ln_w)
         ws = torch.empty(2 * 512 * E, device=dev)
         L.check(lib.mhimx_layernorm_bwd_res(_st(), _ptr(dxn), _ptr(x), n, E, _ptr(ln_w), _ptr(mean), _ptr(rstd), _ptr(dy), _ptr(dx),
