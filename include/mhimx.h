@@ -113,6 +113,10 @@ int mhimx_gemm_batched(void* stream, int32_t mode, const mhimx_gemm_nt_args* arg
  * takes the same kernel for such shapes.   replaces: torch.matmul + the scalar * eye arithmetic around it. */
 int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_args* args, int32_t batch, int64_t strideA, int64_t strideB,
                      int64_t strideC, float alpha, float ident);
+/* the same product with TWO outputs: C = ident I + alpha P and C2 = ident2 I + alpha2 P (K = 256; C2 laid out like C): `xz = x @ z` and
+ * `7 I - xz` of nystrom_attention.py:23-25 in one launch */
+int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA, int64_t strideB,
+                      int64_t strideC, float alpha, float ident, float* C2, float alpha2, float ident2);
 /* two INDEPENDENT batches of 256 x 256 x 256 products in one launch (contiguous [batch, 256, 256] operands, stride = 65536): the
  * backward of a pseudo-inverse iteration is four such pairs (nystrom_attention.py:21-26 under autograd). */
 int mhimx_bmm_affine_pair(void* stream, int32_t mode0, const mhimx_gemm_nt_args* a0, float alpha0, float ident0, int32_t mode1,

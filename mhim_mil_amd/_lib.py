@@ -174,6 +174,7 @@ SYMBOLS = {
     "mhimx_mul_colsum": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I64, _P]),
     "mhimx_rows_dpre": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_bmm_affine": (C.c_int, [_P, _I32, _P, _I32, _I64, _I64, _I64, C.c_float, C.c_float]),
+    "mhimx_bmm_affine2": (C.c_int, [_P, _I32, _P, _I32, _I64, _I64, _I64, C.c_float, C.c_float, _P, C.c_float, C.c_float]),
     "mhimx_bmm_affine_pair": (C.c_int, [_P, _I32, C.POINTER(GemmNT), _F, _F, _I32, C.POINTER(GemmNT), _F, _F, _I32, _I64]),
     "mhimx_shard_flags": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _I64, _I32, _P]),
     "mhimx_shard_gather": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),

@@ -22,6 +22,8 @@ struct SmallBmm {
   int M, N, K;
   float alpha, ident;
   int accumulate;
+  float* C2;              // optional second output of the same product: C2 = ident2 * I + alpha2 * op(A, B)  (whole-panel kernel only)
+  float alpha2, ident2;
 };
 
 MHIMX_DEV void sb_split(const sb_f4& a, const sb_f4& b, sb_b8& hi, sb_b8& lo) {
@@ -180,6 +182,7 @@ MHIMX_DEV void small_bmm_full_body(const SmallBmm& g, int z, float* sbf) {
     float* p = C + m * g.ldc + n;
     if (g.accumulate) v += *p;
     *p = v;
+    if (g.C2) g.C2[(int64_t)z * g.sC + m * g.ldc + n] = g.alpha2 * acc[e] + (m == n ? g.ident2 : 0.f);
   }
 }
 template <bool TA, bool TB>
@@ -207,10 +210,13 @@ bool small_bmm_ok(int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, 
   return g.lda % 4 == 0 && g.ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 && aligned16(g.A) && aligned16(g.B) && mode >= 0 && mode <= 2;
 }
 
-int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident) {
+int small_bmm2(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident,
+               float* c2, float alpha2, float ident2) {
   SmallBmm g;
   g.A = a.A; g.B = a.B; g.C = a.C; g.lda = a.lda; g.ldb = a.ldb; g.ldc = a.ldc; g.sA = sA; g.sB = sB; g.sC = sC;
   g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K; g.alpha = alpha; g.ident = ident; g.accumulate = a.accumulate;
+  g.C2 = c2; g.alpha2 = alpha2; g.ident2 = ident2;
+  if (c2 && g.K != SBF_KMAX) return fail(-1, "bmm_affine2: the second output needs the whole-panel kernel (K = 256)");
   dim3 grid((unsigned)(a.N / SB_T), (unsigned)(a.M / SB_T), (unsigned)batch);
   if (g.K == SBF_KMAX) {
     constexpr int SM = 2 * SB_T * SBF_PITCH * 4;
@@ -230,10 +236,15 @@ int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, 
   return 0;
 }
 
+int small_bmm(hipStream_t st, int mode, const mhimx_gemm_nt_args& a, int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident) {
+  return small_bmm2(st, mode, a, batch, sA, sB, sC, alpha, ident, nullptr, 0.f, 0.f);
+}
+
 static SmallBmm sb_args(const mhimx_gemm_nt_args& a, int64_t sA, int64_t sB, int64_t sC, float alpha, float ident) {
   SmallBmm g;
   g.A = a.A; g.B = a.B; g.C = a.C; g.lda = a.lda; g.ldb = a.ldb; g.ldc = a.ldc; g.sA = sA; g.sB = sB; g.sC = sC;
   g.M = (int)a.M; g.N = (int)a.N; g.K = (int)a.K; g.alpha = alpha; g.ident = ident; g.accumulate = a.accumulate;
+  g.C2 = nullptr; g.alpha2 = g.ident2 = 0.f;
   return g;
 }
 
@@ -265,4 +276,13 @@ extern "C" int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_
   MHIMX_CHECK_ARG(small_bmm_ok(mode, *a, batch, strideA, strideB, strideC),
                   "bmm_affine: M, N multiples of 64 (<= 512), K a multiple of 32 (<= 1024), 16-byte aligned operands, not the f32 mode");
   return small_bmm((hipStream_t)stream, mode, *a, batch, strideA, strideB, strideC, alpha, ident);
+}
+
+extern "C" int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA, int64_t strideB,
+                                 int64_t strideC, float alpha, float ident, float* C2, float alpha2, float ident2) {
+  using namespace mhimx;
+  MHIMX_CHECK_ARG(a && a->A && a->B && a->C && C2 && batch >= 1 && a->M == a->N, "bmm_affine2: null args / non-square output");
+  MHIMX_CHECK_ARG(small_bmm_ok(mode, *a, batch, strideA, strideB, strideC),
+                  "bmm_affine2: M, N multiples of 64 (<= 512), K = 256, 16-byte aligned operands, not the f32 mode");
+  return small_bmm2((hipStream_t)stream, mode, *a, batch, strideA, strideB, strideC, alpha, ident, C2, alpha2, ident2);
 }

@@ -347,9 +347,9 @@ def _core_forward(qkv, conv_w, l, scale):
     L.check(lib.mhimx_pinv_init(_st(), _ptr(a2), HEADS, m, _ptr(z), _ptr(stats), _ptr(ws)), "pinv_init")
     z0, chain = z, []
     for _ in range(PINV_ITERS):
-        az = _bmm_affine("nn", a2, z, torch.empty_like(a2), 1.0, 0.0)
-        t1 = torch.empty_like(a2)
-        L.check(lib.mhimx_affine_ident(_st(), _ptr(az), _ptr(t1), HEADS, m, 7.0, -1.0), "affine_ident")
+        az, t1 = torch.empty_like(a2), torch.empty_like(a2)                 # az = a2 z and t1 = 7 I - az from ONE launch
+        g_ = L.GemmNT(A=_ptr(a2), lda=m, rows=None, B=_ptr(z), ldb=m, C=_ptr(az), ldc=m, M=m, N=m, K=m, accumulate=0, prec=L.PREC[_PREC])
+        L.check(lib.mhimx_bmm_affine2(_st(), _MODE["nn"], C.byref(g_), HEADS, m * m, m * m, m * m, 1.0, 0.0, _ptr(t1), -1.0, 7.0), "mhimx_bmm_affine2")
         t2 = _bmm_affine("nn", az, t1, torch.empty_like(a2), -1.0, 15.0)
         t3 = _bmm_affine("nn", az, t2, torch.empty_like(a2), -1.0, 13.0)
         zn = _bmm_affine("nn", z, t3, torch.empty_like(a2), 0.25, 0.0)
@@ -585,17 +585,23 @@ class ResConv(torch.autograd.Function):
 
 
 class PPEG(torch.autograd.Function):
+    """y = PPEG(x) (emb_position.py:85-120).  skip > 0: the first `skip` rows (the cls token: baseline.py:265-266
+    `cat([x[:1], ppeg(x[1:])])`) pass through unchanged and the stencil runs on the rest - the kernels take the row offset as a pointer
+    offset, so neither the slice, the cat, nor their zero-filled / summed gradients exist."""
+
     @staticmethod
-    def forward(ctx, x, w7, w5, w3, b7, b5, b3, grid=0):
+    def forward(ctx, x, w7, w5, w3, b7, b5, b3, grid=0, skip=0):
         x = x.contiguous()
-        N, Cc = x.shape
-        ctx.grid = int(grid)
+        N, Cc = x.shape[0] - skip, x.shape[1]
+        ctx.grid, ctx.skip = int(grid), int(skip)
         wc, bc = torch.empty((Cc, 49), device=x.device), torch.empty(Cc, device=x.device)
         lib = L.lib()
         L.check(lib.mhimx_ppeg_combine(_st(), _ptr(w7.contiguous()), _ptr(w5.contiguous()), _ptr(w3.contiguous()), _ptr(b7), _ptr(b5),
                                        _ptr(b3), Cc, _ptr(wc), _ptr(bc)), "ppeg_combine")
         y = torch.empty_like(x)
-        L.check(lib.mhimx_ppeg_fwd(_st(), _ptr(x), N, Cc, _ptr(wc), _ptr(bc), _ptr(y), int(grid)), "ppeg_fwd")
+        if skip:
+            y[:skip].copy_(x[:skip])
+        L.check(lib.mhimx_ppeg_fwd(_st(), _ptr(x, skip * Cc), N, Cc, _ptr(wc), _ptr(bc), _ptr(y, skip * Cc), int(grid)), "ppeg_fwd")
         ctx.save_for_backward(x, wc)
         return y
 
@@ -603,13 +609,17 @@ class PPEG(torch.autograd.Function):
     def backward(ctx, dy):
         x, wc = ctx.saved_tensors
         dy = dy.contiguous()
-        N, Cc = x.shape
+        skip = ctx.skip
+        N, Cc = x.shape[0] - skip, x.shape[1]
         dx, dwc, dbc = torch.empty_like(x), torch.empty_like(wc), torch.empty(Cc, device=x.device)
+        if skip:
+            dx[:skip].copy_(dy[:skip])
         ws = torch.empty(L.lib().mhimx_ppeg_bwd_ws_floats(N, Cc), device=x.device)
-        L.check(L.lib().mhimx_ppeg_bwd(_st(), _ptr(dy), _ptr(x), N, Cc, _ptr(wc), _ptr(dx), _ptr(dwc), _ptr(dbc), _ptr(ws), ctx.grid), "ppeg_bwd")
+        L.check(L.lib().mhimx_ppeg_bwd(_st(), _ptr(dy, skip * Cc), _ptr(x, skip * Cc), N, Cc, _ptr(wc), _ptr(dx, skip * Cc), _ptr(dwc), _ptr(dbc),
+                                       _ptr(ws), ctx.grid), "ppeg_bwd")
         g = dwc.view(Cc, 1, 7, 7)
         # the three kernels were summed centre-aligned into one 7x7 stencil: their gradients are its centred windows
-        return (dx, g.contiguous(), g[:, :, 1:6, 1:6].contiguous(), g[:, :, 2:5, 2:5].contiguous(), dbc, dbc.clone(), dbc.clone(), None)
+        return (dx, g.contiguous(), g[:, :, 1:6, 1:6].contiguous(), g[:, :, 2:5, 2:5].contiguous(), dbc, dbc.clone(), dbc.clone(), None, None)
 
 
 class Add(torch.autograd.Function):
@@ -760,10 +770,10 @@ class _PPEG(nn.Module):
         super().__init__()
         self.proj, self.proj1, self.proj2 = _Conv(dim, 7), _Conv(dim, 5), _Conv(dim, 3)
 
-    def forward(self, x, grid=0):
+    def forward(self, x, grid=0, skip=0):
         """grid = 0: emb_position.PPEG (side ceil(sqrt(N)), wrap, zero-padded to 7 x 7 below 37 tokens); grid > 0: the explicit
-        grid x grid layout of modules/transmil.PPEG.forward(x, H, W)."""
-        return PPEG.apply(x, self.proj.weight, self.proj1.weight, self.proj2.weight, self.proj.bias, self.proj1.bias, self.proj2.bias, grid)
+        grid x grid layout of modules/transmil.PPEG.forward(x, H, W).  skip: leading rows (the cls token) that pass through."""
+        return PPEG.apply(x, self.proj.weight, self.proj1.weight, self.proj2.weight, self.proj.bias, self.proj1.bias, self.proj2.bias, grid, skip)
 
 
 class SAttention(nn.Module):
@@ -792,7 +802,7 @@ class SAttention(nn.Module):
             attn.append(a)
         else:
             x = self.layer1(x, False, no_norm, seeds[0], tick, training)
-        x = torch.cat([x[:1], self.pos_embedding(x[1:])], 0)                    # baseline.py:265-266
+        x = self.pos_embedding(x, skip=1)                                       # baseline.py:265-266: cat([x[:1], ppeg(x[1:])])
         if return_attn:
             x, a, _ = self.layer2(x, True, no_norm, seeds[1], tick, training)
             attn.append(a)

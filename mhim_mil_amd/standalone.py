@@ -298,7 +298,7 @@ class TransMIL(_AttnMILBase):
         else:
             t = self.layer1(t, False, False, s1, None, tr)
         if self.pos != "none":
-            t = torch.cat([t[:1], self.pos_layer(t[1:], grid=side)], 0)
+            t = self.pos_layer(t, grid=side, skip=1)                     # transmil.py:62-63: cat([cls, ppeg(tokens)])
         if return_attn:
             t, a, _ = self.layer2(t, True, False, s2, None, tr)
             attn.append((a[:, :a.shape[1] - add] if add > 0 else a).unsqueeze(0))
