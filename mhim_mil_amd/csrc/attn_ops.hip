@@ -541,23 +541,29 @@ __global__ __launch_bounds__(AT) void resconv_dw_strip_kernel(const float* __res
 constexpr int PS = 8;                   // PPEG: outputs per thread along a grid row
 // FLIP = 0: y[cell] = bc + sum_tap wc[tap] * x[src(cell + tap)]            (forward)
 // FLIP = 1: dx[cell] = sum_tap wc[flipped tap] * dy[cell + tap] (dy = 0 beyond N)   (backward w.r.t. x for cell < N)
+// A thread owns one channel of a PS x PSY patch of grid cells: every input row it loads (PS + 6 values) feeds up to PSY output rows,
+// (PSY + 6)(PS + 6) loads for PS PSY outputs = 4.4 per output instead of 12.25 with one-row strips - the stencil is bound by L2 -> L1
+// traffic of the re-read neighbour rows (1.2 GB per launch at N = 50 000, C = 512 with one-row strips).
+constexpr int PSY = 4;
 template <int FLIP>
 __global__ __launch_bounds__(AT) void ppeg_strip_kernel(const float* __restrict__ in, int64_t N, int C, int H, int64_t wrapN,
                                                         const float* __restrict__ wc, const float* __restrict__ bc,
                                                         float* __restrict__ out, int nsx) {
   const int c = blockIdx.y * AT + threadIdx.x;
   if (c >= C) return;
-  const int gy = blockIdx.x / nsx, gx0 = (blockIdx.x % nsx) * PS;
+  const int gy0 = (blockIdx.x / nsx) * PSY, gx0 = (blockIdx.x % nsx) * PS;
   float w[49];
 #pragma unroll
   for (int i = 0; i < 49; ++i) w[i] = wc[c * 49 + i];
-  float acc[PS];
+  float acc[PSY][PS];
   const float b0 = FLIP ? 0.f : bc[c];
 #pragma unroll
-  for (int j = 0; j < PS; ++j) acc[j] = b0;
+  for (int jy = 0; jy < PSY; ++jy)
 #pragma unroll
-  for (int dy = -3; dy <= 3; ++dy) {
-    const int yy = gy + dy;
+    for (int j = 0; j < PS; ++j) acc[jy][j] = b0;
+#pragma unroll
+  for (int r = 0; r < PSY + 6; ++r) {
+    const int yy = gy0 - 3 + r;
     if (yy < 0 || yy >= H) continue;
     float xin[PS + 6];
 #pragma unroll
@@ -572,18 +578,25 @@ __global__ __launch_bounds__(AT) void ppeg_strip_kernel(const float* __restrict_
       xin[i] = val;
     }
 #pragma unroll
-    for (int j = 0; j < PS; ++j)
+    for (int jy = 0; jy < PSY; ++jy) {
+      const int dy = r - 3 - jy;                              // input row relative to output row gy0 + jy
+      if (dy < -3 || dy > 3) continue;
 #pragma unroll
-      for (int dx = -3; dx <= 3; ++dx) {
-        const int tap = FLIP ? (3 - dy) * 7 + (3 - dx) : (dy + 3) * 7 + (dx + 3);
-        acc[j] = fmaf(w[tap], xin[j + dx + 3], acc[j]);
-      }
+      for (int j = 0; j < PS; ++j)
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) {
+          const int tap = FLIP ? (3 - dy) * 7 + (3 - dx) : (dy + 3) * 7 + (dx + 3);
+          acc[jy][j] = fmaf(w[tap], xin[j + dx + 3], acc[jy][j]);
+        }
+    }
   }
 #pragma unroll
-  for (int j = 0; j < PS; ++j) {
-    const int64_t cell = (int64_t)gy * H + gx0 + j;
-    if (gx0 + j < H && cell < N) out[cell * C + c] = acc[j];
-  }
+  for (int jy = 0; jy < PSY; ++jy)
+#pragma unroll
+    for (int j = 0; j < PS; ++j) {
+      const int64_t cell = (int64_t)(gy0 + jy) * H + gx0 + j;
+      if (gy0 + jy < H && gx0 + j < H && cell < N) out[cell * C + c] = acc[jy][j];
+    }
 }
 // dwc / dbc partials, coalesced layout: part[blk][tap*C + c], part_b[blk][c]
 __global__ __launch_bounds__(AT) void ppeg_dw_strip_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t N, int C,
@@ -849,7 +862,7 @@ extern "C" int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C
   int H; int64_t wrapN;
   ppeg_geom(N, grid, &H, &wrapN);
   const int nsx = (int)cdiv(H, PS);
-  hipLaunchKernelGGL(ppeg_strip_kernel<0>, dim3((unsigned)(nsx * H), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, x, N, (int)C, H,
+  hipLaunchKernelGGL(ppeg_strip_kernel<0>, dim3((unsigned)(nsx * cdiv(H, PSY)), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, x, N, (int)C, H,
                      wrapN, wc, bc, y, nsx);
   MHIMX_LAUNCH_CHECK();
   return 0;
@@ -863,7 +876,7 @@ extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int
   ppeg_geom(N, grid, &H, &wrapN);
   hipStream_t st = (hipStream_t)stream;
   const int nsx = (int)cdiv(H, PS);
-  hipLaunchKernelGGL(ppeg_strip_kernel<1>, dim3((unsigned)(nsx * H), (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc,
+  hipLaunchKernelGGL(ppeg_strip_kernel<1>, dim3((unsigned)(nsx * cdiv(H, PSY)), (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dy, N, (int)C, H, wrapN, wc,
                      (const float*)nullptr, dx, nsx);
   MHIMX_LAUNCH_CHECK();
   if (wrapN > N) {
