@@ -608,20 +608,22 @@ __global__ __launch_bounds__(AT) void ppeg_dw_strip_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < 49; ++i) acc[i] = 0.f;
   float ab = 0.f;
-  const int nstrips = H * nsx;
-  for (int s = blockIdx.x * spb; s < (int)(blockIdx.x + 1) * spb && s < nstrips; ++s) {
-    const int gy = s / nsx, gx0 = (s % nsx) * PS;
-    if ((int64_t)gy * H + gx0 >= N) break;
-    float g[PS];
+  const int npatch = ((H + PSY - 1) / PSY) * nsx;            // PS x PSY patches, row-major (as the stencil kernel: input rows are reused)
+  for (int s = blockIdx.x * spb; s < (int)(blockIdx.x + 1) * spb && s < npatch; ++s) {
+    const int gy0 = (s / nsx) * PSY, gx0 = (s % nsx) * PS;
+    if ((int64_t)gy0 * H + gx0 >= N) break;
+    float g[PSY][PS];
 #pragma unroll
-    for (int j = 0; j < PS; ++j) {
-      const int64_t cell = (int64_t)gy * H + gx0 + j;
-      g[j] = (gx0 + j < H && cell < N) ? dy[cell * C + c] : 0.f;
-      ab += g[j];
-    }
+    for (int jy = 0; jy < PSY; ++jy)
 #pragma unroll
-    for (int ddy = -3; ddy <= 3; ++ddy) {
-      const int yy = gy + ddy;
+      for (int j = 0; j < PS; ++j) {
+        const int64_t cell = (int64_t)(gy0 + jy) * H + gx0 + j;
+        g[jy][j] = (gy0 + jy < H && gx0 + j < H && cell < N) ? dy[cell * C + c] : 0.f;
+        ab += g[jy][j];
+      }
+#pragma unroll
+    for (int r = 0; r < PSY + 6; ++r) {
+      const int yy = gy0 - 3 + r;
       if (yy < 0 || yy >= H) continue;
       float xin[PS + 6];
 #pragma unroll
@@ -635,9 +637,14 @@ __global__ __launch_bounds__(AT) void ppeg_dw_strip_kernel(const float* __restri
         xin[i] = val;
       }
 #pragma unroll
-      for (int j = 0; j < PS; ++j)
+      for (int jy = 0; jy < PSY; ++jy) {
+        const int ddy = r - 3 - jy;
+        if (ddy < -3 || ddy > 3) continue;
 #pragma unroll
-        for (int dx = -3; dx <= 3; ++dx) acc[(ddy + 3) * 7 + dx + 3] = fmaf(g[j], xin[j + dx + 3], acc[(ddy + 3) * 7 + dx + 3]);
+        for (int j = 0; j < PS; ++j)
+#pragma unroll
+          for (int dx = -3; dx <= 3; ++dx) acc[(ddy + 3) * 7 + dx + 3] = fmaf(g[jy][j], xin[j + dx + 3], acc[(ddy + 3) * 7 + dx + 3]);
+      }
     }
   }
 #pragma unroll
@@ -887,7 +894,7 @@ extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int
   float* part = ws;
   float* part_b = ws + (int64_t)nblk * C * 49;
   float* dwc_t = part_b + (int64_t)nblk * C;                    // [49, C], transposed into dwc [C, 49] at the end
-  const int spb = (int)cdiv((int64_t)H * nsx, nblk);
+  const int spb = (int)cdiv((int64_t)cdiv(H, PSY) * nsx, nblk);        // patches per block
   hipLaunchKernelGGL(ppeg_dw_strip_kernel, dim3((unsigned)nblk, (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dy, x, N, (int)C, H, wrapN, nsx, spb,
                      part, part_b);
   MHIMX_LAUNCH_CHECK();
