@@ -3,7 +3,7 @@
 # the two PMC passes of the dominant kernel, the other workloads.  Everything lands under gpurun_out/.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > gpurun_out/final_tests.log
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/final_tests.log
 python bench.py > gpurun_out/final_bench_c2.json 2> gpurun_out/final_bench_c2.err
 tools/prof.sh final --steps 100 --warmup 20 > gpurun_out/final_prof.log 2>&1
 python tools/timeline.py gpurun_out/prof_final/final_results.db > gpurun_out/final_timeline.txt 2>&1
