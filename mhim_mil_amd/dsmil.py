@@ -60,7 +60,7 @@ class LinearAct(torch.autograd.Function):
                 dx = torch.zeros_like(x)
                 dx.index_add_(0, rows, dsub)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(g, x, rows=rows, splits=8 if M >= 4096 else 1, prec=NY._PREC)
+            dw = ops.gemm_tn(g, x, rows=rows, splits=min(64, max(8, M // 256)) if M >= 4096 else 1, prec=NY._PREC)   # (few output tiles: split the long reduction over the chip)
         if ctx.needs_input_grad[2]:
             db = ops.colsum(g)
         return dx, dw, db, None, None

@@ -240,7 +240,13 @@ class Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             _gemm("nn", dy, 0, N, w, 0, w.shape[1], dx, 0, x.shape[1], M, x.shape[1], N)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy, x, splits=8 if M >= 4096 else 1, prec=_PREC)
+            if N <= 16 and M >= 4096 and _PREC != "f32":
+                # a few output rows (DSMIL's instance classifier, 512 -> C): the streaming thin-left-operand kernel instead of 128 x 128
+                # tiles that are 98 % padding (4 tiles x 8 slabs = 32 workgroups: 167 us at M = 9705; this: ~20 us)
+                dw = torch.empty((N, x.shape[1]), device=x.device)
+                _heads_mm("tn", Op(dy, 0, 0, N, M, N), Op(x, 0, 0, x.shape[1], M, x.shape[1]), Op(dw, 0, 0, x.shape[1], N, x.shape[1]), 1)
+            else:
+                dw = ops.gemm_tn(dy, x, splits=8 if M >= 4096 else 1, prec=_PREC)
         if has_b and ctx.needs_input_grad[2]:
             db = ops.colsum(dy)
         return dx, dw, db, None, None, None
