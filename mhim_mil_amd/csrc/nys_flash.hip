@@ -24,6 +24,7 @@
 // k-octet kg the eight k {16(2s) + 4kg + i, 16(2s+1) + 4kg + i}; the LT fragments and TR images are laid out in exactly that order.
 // Products are 3-term bf16 (hi hi + hi lo + lo hi, ~2^-16), as everywhere on this path.
 // Sums across the four waves (softmax statistics, partial outputs) go through LDS in a FIXED order: results are run-to-run identical.
+#include <stdlib.h>
 #include <string.h>
 
 #include "nys_args.hpp"
@@ -443,6 +444,152 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
     for (int lb = 0; lb < NY_LB; ++lb) *reinterpret_cast<f32x4*>(p1 + (lm0 + 16 * lb + c) * NY_D + 16 * db + 4 * kg) = dq[db][lb];
 }
 
+// ===========================================================================================================================
+// forward 2, token-owning form: out = softmax_m(q k~^T) w2 with NO barrier in the loop.  The landmark-side operands of BOTH products
+// sit in LDS as ready fragments for the whole chunk (k~: [16 lb][2 ks] LM fragments, w2: [4 db][8 s] LT fragments: 64 KiB each);
+// a wave owns 32 tokens and ALL 256 landmarks: S^T[16 lb][2 tb] in registers, the softmax over the landmarks is the lane's own rows
+// plus its three k-octet lanes, o^T[4 db][2 tb] = LT(w2) x P^T needs no cross-wave sum.  q fragments come straight from global
+// memory (a lane's 8 consecutive head dims of its token: two 16-byte loads per k-step).  8 independent waves per workgroup.
+// ===========================================================================================================================
+constexpr int NY_SM_OUT8 = 2 * 65536;
+__global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_tok8_kernel(NyArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
+  const int h = blockIdx.y, ch = blockIdx.x;
+  int t_begin, t_end;
+  ny_chunk(g, ch, t_begin, t_end);
+  {
+    const float* kl = g.kl + h * NY_D;
+    const float* w2 = g.w2 + (int64_t)h * NY_PART;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int unit = tid + NY_THREADS * u, fl = unit & 63, f = unit >> 6;           // fragment f (0..31), lane fl
+      const int fc = fl & 15, fk = fl >> 4;
+      {                                                                               // k~ LM fragment f = lb * 2 + ks
+        const int lb = f >> 1, ks = f & 1;
+        const float* p = kl + (int64_t)(16 * lb + fc) * g.ldl + 32 * ks + 8 * fk;
+        f32x4 hi, lo;
+        ny_split44(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), hi, lo);
+        *reinterpret_cast<f32x4*>(sm + (f * 2) * 1024 + fl * 16) = hi;
+        *reinterpret_cast<f32x4*>(sm + (f * 2 + 1) * 1024 + fl * 16) = lo;
+      }
+      {                                                                               // w2 LT fragment f = db * 8 + s
+        const int db = f >> 3, sx = f & 7;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w2[(int64_t)(32 * sx + 16 * (j >> 2) + 4 * fk + (j & 3)) * NY_D + 16 * db + fc];
+        f32x4 hi, lo;
+        ny_split8(v, hi, lo);
+        *reinterpret_cast<f32x4*>(sm + 65536 + (f * 2) * 1024 + fl * 16) = hi;
+        *reinterpret_cast<f32x4*>(sm + 65536 + (f * 2 + 1) * 1024 + fl * 16) = lo;
+      }
+    }
+  }
+  __syncthreads();
+  const float* qb = g.q + h * NY_D;
+  f32x4 raw[2][2][2];                                          // [tb][ks][half]: the NEXT group's q rows, in flight under the softmax / PV
+  auto ld_q = [&](int64_t tk) {
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* p = qb + (tk + 16 * tb + c) * g.ld + 32 * ks + 8 * kg;
+        raw[tb][ks][0] = *reinterpret_cast<const f32x4*>(p);
+        raw[tb][ks][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+  };
+  const int64_t grp0 = (int64_t)t_begin * 2 + w, grp_end = (int64_t)t_end * 2;
+  if (grp0 < grp_end) ld_q(grp0 * 32);
+  for (int64_t grp = grp0; grp < grp_end; grp += NY_NW) {
+    const int64_t tk0 = grp * 32;
+    f32x4 qh[2][2], ql[2][2];                                  // [ks][tb]
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ny_split44(raw[tb][ks][0], raw[tb][ks][1], qh[ks][tb], ql[ks][tb]);
+    f32x4 s[16][2];                                            // [lb][tb]
+    NY_ZERO(s, 16, 2);
+    // fragments of landmark block lb + 1 are requested before the MFMAs of block lb; the scheduling barrier keeps the compiler from
+    // hoisting all 64 fragment reads to the top (256 VGPRs of fragments: 1.8 KB of scratch per lane without it)
+    f32x4 fa[4], fb[4];
+    auto ld_k = [&](int lb, f32x4 (&f)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) f[q] = *reinterpret_cast<const f32x4*>(sm + (lb * 4 + q) * 1024 + lane * 16);      // ks0 hi, ks0 lo, ks1 hi, ks1 lo
+    };
+    ld_k(0, fa);
+#pragma unroll
+    for (int lb = 0; lb < 16; lb += 2) {
+      ld_k(lb + 1, fb);
+      ny_mma_a<2>(fa[0], fa[1], qh[0], ql[0], s[lb]);
+      ny_mma_a<2>(fa[2], fa[3], qh[1], ql[1], s[lb]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (lb + 2 < 16) ld_k(lb + 2, fa);
+      ny_mma_a<2>(fb[0], fb[1], qh[0], ql[0], s[lb + 1]);
+      ny_mma_a<2>(fb[2], fb[3], qh[1], ql[1], s[lb + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp + NY_NW < grp_end) ld_q((grp + NY_NW) * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    float inv[2], lse[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      float mx = s[0][tb][0];
+#pragma unroll
+      for (int lb = 0; lb < 16; ++lb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[lb][tb][i]);
+      mx = ny_kgmax(mx);
+      const float off = mx * g.sl2e;
+      float sum = 0.f;
+#pragma unroll
+      for (int lb = 0; lb < 16; ++lb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = NY_EXP2(fmaf(s[lb][tb][i], g.sl2e, -off));
+          s[lb][tb][i] = p;
+          sum += p;
+        }
+      sum = ny_kgsum(sum);
+      inv[tb] = 1.f / sum;
+      lse[tb] = off + log2f(sum);
+    }
+    f32x4 o[4][2];                                             // [db][tb]
+    NY_ZERO(o, 4, 2);
+    auto ld_w = [&](int sx, f32x4 (&f)[8]) {                     // the four d blocks of landmark step sx: hi, lo each
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        f[2 * db] = *reinterpret_cast<const f32x4*>(sm + 65536 + ((db * 8 + sx) * 2) * 1024 + lane * 16);
+        f[2 * db + 1] = *reinterpret_cast<const f32x4*>(sm + 65536 + ((db * 8 + sx) * 2 + 1) * 1024 + lane * 16);
+      }
+    };
+    f32x4 wa[8], wb[8];
+    ld_w(0, wa);
+#pragma unroll
+    for (int sx = 0; sx < 8; sx += 2) {
+      f32x4 ph[2], pl[2];
+      ld_w(sx + 1, wb);
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx][tb], s[2 * sx + 1][tb], ph[tb], pl[tb]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) ny_mma_a<2>(wa[2 * db], wa[2 * db + 1], ph, pl, o[db]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (sx + 2 < 8) ld_w(sx + 2, wa);
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx + 2][tb], s[2 * sx + 3][tb], ph[tb], pl[tb]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) ny_mma_a<2>(wb[2 * db], wb[2 * db + 1], ph, pl, o[db]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const int64_t row = tk0 + 16 * tb + c;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(g.out + row * g.ldo + h * NY_D + 16 * db + 4 * kg) = o[db][tb] * inv[tb];
+      if (kg == 0 && g.lse1_o) g.lse1_o[(int64_t)h * g.T + row] = lse[tb];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int NY_SM_BWD_L = 4 * NY_IMG + 128 * 4;
 constexpr int NY_SM_A3_L = 3 * NY_IMG;
@@ -485,7 +632,12 @@ extern "C" int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* 
   if (int e = ny_base(a, g, "nys_out_fwd")) return e;
   MHIMX_CHECK_ARG(a->q && a->kl && w2 && out && aligned16(a->q) && aligned16(a->kl) && aligned16(out) && ldo % 4 == 0, "nys_out_fwd: null / unaligned operands");
   g.w2 = w2; g.out = out; g.ldo = ldo; g.lse1_o = lse1;
-  return nytok_out_fwd((hipStream_t)stream, g);
+  static const bool v1 = getenv("MHIMX_NYS_OUT_V1") != nullptr;         // (experiments: the landmark-split form with cross-wave sums)
+  if (v1) return nytok_out_fwd((hipStream_t)stream, g);
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_fwd_tok8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_OUT8)));
+  hipLaunchKernelGGL(ny_out_fwd_tok8_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_OUT8, (hipStream_t)stream, g);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int mhimx_nys_out_bwd(void* stream, const mhimx_nys* a, const float* w2, const float* dout, int64_t ldd, const float* lse1,
