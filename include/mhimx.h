@@ -446,6 +446,10 @@ int mhimx_rows_dpre(void* stream, const float* dH, const void* dact16, const int
 int64_t mhimx_wgrad_image_bytes(int64_t L, int64_t E);
 int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
                           float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
+/* the same with dH COMPACT (row p of dH belongs to list position p) while dact16 stays bag-ordered (row rows[p]): the gradient of token
+ * rows that were gathered out of a bag-ordered projection (the TransMIL / DSMIL students: masking.py:107 after mhim.py:335-336) */
+int mhimx_rows_dpre_image_c(void* stream, const float* dH_compact, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
+                            float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
 /* The projection's weight gradient (modules/mhim.py:69-76 backward; the last GEMM of the step):
  *     C[E,D] (+)= dPre[L,E]^T . X[rows ? rows[p] : p][D],   p < L
  * dPre as the image above, X the raw fp32 bag (split to bf16 hi/lo on its way into LDS, transposed with v_permlane32_swap); 3-term bf16

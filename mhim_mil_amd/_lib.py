@@ -180,6 +180,7 @@ SYMBOLS = {
     "mhimx_shard_gather": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),
     "mhimx_shard_scatter": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),
     "mhimx_rows_dpre_image": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_rows_dpre_image_c": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_wgrad_image_bytes": (_I64, [_I64, _I64]),
     "mhimx_wgrad_ws_floats": (_I64, [_I64, _I64, _I64]),
     "mhimx_bag_wgrad": (C.c_int, [_P, _P]),

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __restrict__ dH, const _Float16* __restrict__ dact,
                                                              const int64_t* __restrict__ rows, int64_t L, int E, char* __restrict__ img,
-                                                             float* __restrict__ part, int side_blocks, Merge2Side side) {
+                                                             float* __restrict__ part, int side_blocks, Merge2Side side, int dh_compact) {
   __shared__ __attribute__((aligned(16))) float lds[M2_PARTIALS_LDS > 3 * 256 * 4 ? M2_PARTIALS_LDS : 3 * 256 * 4];
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 1), its workgroups first
     merge2_side_stage(1, (int)blockIdx.x, lds, side);
@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int64_t rr = r[q] < 0 ? 0 : r[q];
-      gv[q] = reinterpret_cast<const f32x4*>(dH + rr * E)[cq];
+      const int64_t lq = (int64_t)ks * WBK + koct * 8 + q;                        // dh_compact: dH row = list position (rows address dact only)
+      gv[q] = reinterpret_cast<const f32x4*>(dH + (dh_compact ? (lq < L ? lq : 0) : rr) * E)[cq];
       dv[q] = dact ? reinterpret_cast<const h4v*>(dact + rr * E)[cq] : h4v{(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     }
 #pragma unroll
@@ -605,8 +606,8 @@ extern "C" int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D) {
   return (int64_t)wgrad_plan(L, E, D, &kps) * E * D;
 }
 
-extern "C" int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
-                                     float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
+static int rows_dpre_image_impl(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
+                                float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer, int dh_compact) {
   MHIMX_CHECK_ARG(dH && img && L >= 1 && E >= WBI && E % WBI == 0 && aligned16(dH) && aligned16(img) &&
                       (reinterpret_cast<uintptr_t>(dact16) & 7) == 0,
                   "rows_dpre_image: E must be a multiple of 128, buffers aligned");
@@ -620,13 +621,22 @@ extern "C" int mhimx_rows_dpre_image(void* stream, const float* dH, const void* 
     defer->side.pending = 2;
   }
   hipLaunchKernelGGL(rows_dpre_image_kernel, dim3((unsigned)(ksteps * ncb + side_blocks)), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16,
-                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side);
+                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side, dh_compact);
   MHIMX_LAUNCH_CHECK();
   if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
     const int rc = reduce_parts_now((hipStream_t)stream, (const float*)ws, nblk, E, E, colsum_out, accumulate);
     if (rc) return rc;
   }
   return 0;
+}
+
+extern "C" int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
+                                     float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
+  return rows_dpre_image_impl(stream, dH, dact16, rows, L, E, img, colsum_out, accumulate, ws, ws_bytes, defer, 0);
+}
+extern "C" int mhimx_rows_dpre_image_c(void* stream, const float* dH_compact, const void* dact16, const int64_t* rows, int64_t L, int64_t E,
+                                       void* img, float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
+  return rows_dpre_image_impl(stream, dH_compact, dact16, rows, L, E, img, colsum_out, accumulate, ws, ws_bytes, defer, 1);
 }
 
 extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {

@@ -265,12 +265,29 @@ class FusedTrainer:
         first = self._micro == 0
         gv = fl.grad_views
         if self.model_kind == "mhim":
-            teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"],
-                                                    wa_frag=None if prep_t is None else prep_t.get("wa_frag"))
+            pre, seed_s = None, None
+            if (self.single_pass and s.baseline in ("selfattn", "dsmil") and s.single_projection_ok(x) and t.single_projection_ok(x)
+                    and s.act == t.act):
+                # TransMIL / DSMIL: teacher AND student feature rows of all N bag rows in ONE pass over the raw bag (the reference's
+                # student projects every row before it masks, mhim.py:335-336); the student's token rows are a gather, its projection
+                # gradient the matrix-core-image pair on (d tokens, d out / d pre in fp16)
+                heads = [ops.ProjHead(ops.pair_planes(t.feature[0].weight.data), t.feature[0].bias.data,
+                                      drop_p=t.dropout_p if t.training else 0.0, drop_seed=t._next_seed()),
+                         None]
+                seed_s = s._next_seed()
+                heads[1] = ops.ProjHead(ops.pair_planes(s.feature[0].weight.data), s.feature[0].bias.data, drop_p=s.dropout_p,
+                                        drop_seed=seed_s, want_dact=True)
+                ops.bag_project(x, heads, act=mh.L.act_code(s.act, mh._FEATURE_ACTS), drop_tick=self.tick)
+                pre = (heads[1].out, heads[1].dact)
+                teacher_feat, score = t.forward_teacher(x, H=heads[0].out)
+            else:
+                teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"],
+                                                        wa_frag=None if prep_t is None else prep_t.get("wa_frag"))
             mf = s.baseline == "attn"                       # [merge | stay] rows: the pool reads [stay | merged tokens] contiguously
             rows, len_keep, Lk, R = s.student_rows(ps, i, score, perm=perm, ids_shuffle=ids_shuffle, merge_first=mf)
-            plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed(), mca_seed=s._next_seed(), training=True,
-                           merge_first=mf)
+            plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed() if seed_s is None else seed_s,
+                           mca_seed=s._next_seed(), training=True, merge_first=mf)
+            plan.pre = pre
             keep_num = Lk + s.merge.k
         else:
             teacher_feat = None

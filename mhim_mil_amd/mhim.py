@@ -153,17 +153,33 @@ class _FeatureFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, plan, w, b):
+        pre = getattr(plan, "pre", None)
+        if pre is not None:
+            # the single-pass projection (ops.bag_project) already holds the student's feature rows of ALL bag rows (bag order) and
+            # d out / d pre in fp16: the token rows are a gather, the backward the matrix-core-image weight-gradient pair
+            Hs, dact = pre
+            H = ops.shard_gather(Hs, plan.rows, 0, Hs.shape[0]) if plan.rows is not None else Hs
+            ctx.model, ctx.plan, ctx.x, ctx.dact = model, plan, x, dact
+            return H
         need_pre = L.act_code(model.act, _FEATURE_ACTS) == L.ACT["gelu"]
         H = torch.empty((plan.L, model.mlp_dim), device=x.device)
         PRE = torch.empty_like(H) if need_pre else None
         p = model.dropout_p if plan.training else 0.0
         model._feature(x, plan.rows, p, plan.drop_seed, plan.drop_mask, out=H, pre_out=PRE, M=plan.L)
         ctx.model, ctx.plan, ctx.x, ctx.H, ctx.PRE = model, plan, x, H, PRE
+        ctx.dact = None
         return H
 
     @staticmethod
     def backward(ctx, dH):
         model, plan = ctx.model, ctx.plan
+        if ctx.dact is not None:
+            dH = dH.contiguous()
+            if plan.rows is None:
+                dW, db = ops.bag_wgrad(dH, ctx.dact, ctx.x, None, plan.L)
+            else:
+                dW, db = ops.bag_wgrad(dH, ctx.dact, ctx.x, plan.rows, plan.L, dh_compact=True)
+            return None, None, None, dW, db
         dH = dH.contiguous().clone()
         p = model.dropout_p if plan.training else 0.0
         _, db = ops.act_bwd(dH, ctx.H, ctx.PRE, L.act_code(model.act, _FEATURE_ACTS), p, plan.drop_seed, plan.drop_mask, plan.rows,
@@ -515,6 +531,11 @@ class MHIM(nn.Module):
         return grads
 
     # ------------------------------------------------------------------ student bag forward / backward, bag-ordered buffers
+    def single_projection_ok(self, x):
+        """Shapes ops.bag_project takes for this model's feature projection (any baseline): E = 512, D % 32 == 0, the 3-term bf16 form."""
+        return (self.mlp_dim == 512 and x.shape[1] % 32 == 0 and x.shape[0] >= 64 and self._feature_prec(x.shape[0]) == "bf16x3"
+                and ops.bag_wgrad_ok(x, self.mlp_dim, x.shape[0]))
+
     def bag_ordered_ok(self, x):
         """The fused trainer's single-pass form: one projection launch for teacher AND student over the raw bag (ops.bag_project),
         feature rows kept in BAG order and every consumer gathering rows by index.  Needs the shapes the one-pass kernels are built
@@ -715,10 +736,11 @@ class MHIM(nn.Module):
 
     # ------------------------------------------------------------------ reference entry points
     @torch.no_grad()
-    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None, wa_frag=None):
+    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None, wa_frag=None, H=None):
         x = self._check_x(x)
         p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
-        H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp, w1p=w1p)
+        if H is None:                                          # (H: the teacher's feature rows from the trainer's single-pass projection)
+            H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp, w1p=w1p)
         p0 = H.shape[0]
         T2 = None
         if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)

@@ -461,12 +461,13 @@ def bag_wgrad_ok(x, E, n_rows):
             and x.shape[0] * x.stride(0) * 4 < (1 << 32))
 
 
-def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=False, defer=None, rows_dh="same", want_bias=True):
+def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=False, defer=None, rows_dh="same", want_bias=True,
+              dh_compact=False):
     """The projection's weight and bias gradient from the bag-ordered buffers:
     dPre[p] = dH[rows[p]] * dact16[rows[p]],  out_b (+)= sum_p dPre[p],  out_w [E,D] (+)= dPre^T x[rows]   (p < n_rows)
     — mhimx_rows_dpre_image (dPre as a bf16 hi/lo matrix-core image) + mhimx_bag_wgrad.
     dact16 None: dPre = dH (any Linear's weight gradient dy^T x); rows_dh: the row list of dH when it differs from x's (None: dH is
-    compact); want_bias False: no column sums."""
+    compact); want_bias False: no column sums; dh_compact: dH is compact while dact16 is gathered by rows (mhimx_rows_dpre_image_c)."""
     _chk(dH, name="dH"); _chk(dact16, torch.float16, "dact16"); _chk(rows, torch.int64, "rows")
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise L.MhimxError("x: expected a GPU fp32 matrix with contiguous rows")
@@ -482,7 +483,8 @@ def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=Fa
         out_b = torch.empty(E, device=dev)
     img = torch.empty(lib.mhimx_wgrad_image_bytes(n_rows, E) // 4, device=dev)
     ws_b = torch.empty(-(-n_rows // 32) * E, device=dev) if want_bias else None
-    L.check(lib.mhimx_rows_dpre_image(_stream(), _p(dH), _p(dact16), _p(rows_h), n_rows, E, _p(img), _p(out_b) if want_bias else None,
+    fn = lib.mhimx_rows_dpre_image_c if dh_compact else lib.mhimx_rows_dpre_image
+    L.check(fn(_stream(), _p(dH), _p(dact16), _p(rows_h), n_rows, E, _p(img), _p(out_b) if want_bias else None,
                                       int(bool(accumulate)), _p(ws_b), ws_b.numel() * 4 if want_bias else 0, _dp(defer)), "mhimx_rows_dpre_image")
     ws = torch.empty(lib.mhimx_wgrad_ws_floats(n_rows, E, D), device=dev)
     g = L.BagWgrad(img=_p(img), X=_p(x), ldx=x.stride(0), n_bag_rows=x.shape[0], rows=_p(rows), L=n_rows, E=E, D=D, C=_p(out_w),
