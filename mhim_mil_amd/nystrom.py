@@ -476,7 +476,12 @@ class TransLayerFn(torch.autograd.Function):
         qkv = torch.empty((T, 3 * INNER), device=dev)
         if pad:
             qkv[:pad].zero_()
-        ops.gemm_nt(xn, w_qkv, out=qkv[pad:], prec=_PREC)
+        if n >= 2048 and _PREC == "bf16x3":
+            # to_qkv on the single-pass projection kernel (one "model" of width 1536: raw fp32 rows split on their way into LDS,
+            # 160 x 256 tiles; 330 -> ~270 us at n = 50 000)
+            ops.bag_project(xn, [ops.ProjHead(ops.pair_planes(w_qkv), None, out=qkv[pad:])], act=0)
+        else:
+            ops.gemm_nt(xn, w_qkv, out=qkv[pad:], prec=_PREC)
         out, saved = _core_forward(qkv, conv_w, l, scale)
         y = ops.gemm_nt(out[pad:], w_out, bias=b_out, drop_p=drop_p, drop_seed=seed, drop_tick=tick, prec=_PREC)
         L.check(lib.mhimx_axpby(_st(), _ptr(x), _ptr(y), y.numel(), 1.0, 1.0), "axpby")                 # y += x
@@ -507,7 +512,9 @@ class TransLayerFn(torch.autograd.Function):
         dout = torch.empty((T, INNER), device=dev)
         if pad:
             dout[:pad].zero_()
-        if n >= 2048 and _PREC != "f32":          # data gradients as NT products on the transposed weights (the DMA kernel: 374 -> ~290 us)
+        if n >= 2048 and _PREC == "bf16x3":        # data gradients as products with the transposed weights on the projection kernel
+            ops.bag_project(g, [ops.ProjHead(ops.pair_planes(ops.transpose(w_out)), None, out=dout[pad:])], act=0)
+        elif n >= 2048 and _PREC != "f32":
             ops.gemm_nt(g, ops.transpose(w_out), out=dout[pad:], prec=_PREC)
         else:
             _gemm("nn", g, 0, E, w_out, 0, INNER, dout, pad * INNER, INNER, n, INNER, E)
@@ -519,7 +526,9 @@ class TransLayerFn(torch.autograd.Function):
             db_out = ops.colsum(g)
         dqkv, dwc = _core_backward(saved, dout)
         dxn = torch.empty_like(x)
-        if n >= 2048 and _PREC != "f32":
+        if n >= 2048 and _PREC == "bf16x3":
+            ops.bag_project(dqkv[pad:], [ops.ProjHead(ops.pair_planes(ops.transpose(w_qkv)), None, out=dxn)], act=0)
+        elif n >= 2048 and _PREC != "f32":
             ops.gemm_nt(dqkv[pad:], ops.transpose(w_qkv), out=dxn, prec=_PREC)
         else:
             _gemm("nn", dqkv, pad * 3 * INNER, 3 * INNER, w_qkv, 0, E, dxn, 0, E, n, E, 3 * INNER)
