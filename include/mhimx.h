@@ -334,6 +334,15 @@ int mhimx_nys_a3v_bwd(void* stream, const mhimx_nys* a, const float* a3v, const 
                       int64_t lddk, int32_t accumulate_dv, float* dql, int64_t lddl);
 /* r[8,T] = u attn3 with u[8,256] = attn1[cls] pinv: the cls token's attention row (nystrom:143-150) */
 int mhimx_nys_cls_attn(void* stream, const mhimx_nys* a, const float* lse3, const float* u, float* r);
+/* BatchNorm1d over the M instances of one bag (mil_norm='bn': modules/abmil.py:167-169,206-225, transmil.py:79-81,112-115).
+ * fwd, training: mean / rstd / var_out [C] are OUTPUTS (biased variance; the host updates the running statistics from mean and var_out);
+ *      eval: mean = running mean (in), rstd = 1/sqrt(running var + eps) (in).  y = (x - mean) rstd w + b.
+ * bwd: dw = sum dy xhat, db = sum dy, dx (training: through the batch statistics; eval: dy w rstd).  ws: mhimx_bn_ws_floats(M, C). */
+int64_t mhimx_bn_ws_floats(int64_t M, int64_t C);
+int mhimx_bn_fwd(void* stream, const float* x, int64_t M, int64_t C, const float* w, const float* b, float eps, int32_t training, float* mean,
+                 float* rstd, float* var_out, float* y, float* ws);
+int mhimx_bn_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t C, const float* w, const float* mean, const float* rstd,
+                 int32_t training, float* dx, float* dw, float* db, float* ws);
 /* out = x + SINCOS(pos): the parameter-free 2-d sin-cos position embedding of modules/abmil.DAttention(pos='sincos')
  * (emb_position.py:5-83); pos_xy[N,2] = the patch grid coordinates (x, y) of every row. */
 int mhimx_sincos_add(void* stream, const float* x, const int64_t* pos_xy, int64_t N, int64_t C, float* out);

@@ -207,6 +207,9 @@ SYMBOLS = {
     "mhimx_comm_init": (C.c_int, [C.POINTER(C.c_void_p), _P, _I32, _I32]),
     "mhimx_comm_allreduce": (C.c_int, [_P, _P, _P, _I64, _I32]),
     "mhimx_comm_destroy": (C.c_int, [_P]),
+    "mhimx_bn_ws_floats": (_I64, [_I64, _I64]),
+    "mhimx_bn_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, C.c_float, _I32, _P, _P, _P, _P, _P]),
+    "mhimx_bn_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "mhimx_sincos_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "mhimx_nys_ws_floats": (_I64, [_I64]),
     "mhimx_nys_a3v_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P]),

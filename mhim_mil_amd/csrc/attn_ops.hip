@@ -675,6 +675,68 @@ __global__ void sincos_add_kernel(const float* __restrict__ x, const int64_t* __
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// BatchNorm1d over the M instances of ONE bag (mil_norm='bn': abmil.py:167-169,206-225, transmil.py:79-81,112-115): per column c,
+//   training:  mean_c, var_c (biased) over the rows;  y = (x - mean) rstd w + b;     eval: the running statistics instead.
+// Two launches each way: column statistics as per-row-chunk partials (thread = column: coalesced rows) + fixed-order reduction,
+// then one element-wise pass.
+// ---------------------------------------------------------------------------------------------------------------------------
+// part[blk][0][c] = sum_m a[m,c] (b ? b[m,c]-weighted: sum a*xhat) ... two statistics per column:
+//   MODE 0: s0 = sum x,  s1 = sum x^2                       (forward)
+//   MODE 1: s0 = sum dy, s1 = sum dy * xhat, xhat = (x - mean) rstd      (backward)
+template <int MODE>
+__global__ __launch_bounds__(AT) void bn_stats_kernel(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, int64_t M, int C, int64_t chunk, float* __restrict__ part) {
+  const int c = blockIdx.y * AT + threadIdx.x;
+  if (c >= C) return;
+  const int64_t m0 = (int64_t)blockIdx.x * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
+  float s0 = 0.f, s1 = 0.f;
+  const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
+  for (int64_t m = m0; m < m1; ++m) {
+    const float v = a[m * C + c];
+    s0 += v;
+    s1 += MODE ? v * (x[m * C + c] - mu) * rs : v * v;
+  }
+  part[((int64_t)blockIdx.x * 2) * C + c] = s0;
+  part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
+}
+// stats[2][C] = (sum, sumsq) -> mean, rstd (biased variance, eps); var_out = biased variance (for the running statistics)
+__global__ void bn_finish_kernel(const float* __restrict__ stats, int64_t M, int C, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                 float* __restrict__ var_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = stats[c] / (float)M;
+  const float var = fmaxf(stats[C + c] / (float)M - mu * mu, 0.f);
+  mean[c] = mu;
+  rstd[c] = rsqrtf(var + eps);
+  var_out[c] = var;
+}
+// y[m,c] = p[m,c] * A_c + q[m,c] * B_c + D_c   (q may be null)
+__global__ void bn_apply_kernel(const float* __restrict__ p, const float* __restrict__ q, const float* __restrict__ A, const float* __restrict__ B,
+                                const float* __restrict__ D, int64_t M, int C, float* __restrict__ y) {
+  for (int64_t m = blockIdx.x; m < M; m += gridDim.x)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float v = p[m * C + c] * A[c] + D[c];
+      if (q) v += q[m * C + c] * B[c];
+      y[m * C + c] = v;
+    }
+}
+// coefficient vectors.  forward: A = rstd w, D = b - mean A.   backward (xhat = (x - mean) rstd, db = s0, dw = s1):
+//   dx = w rstd (dy - db/M - xhat dw/M) = dy * (w rstd) + x * (-w rstd^2 dw / M) + (w rstd (mean rstd dw - db) / M)
+__global__ void bn_coef_kernel(int bwd, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ stats, int64_t M, int C, float* __restrict__ A,
+                               float* __restrict__ B, float* __restrict__ D) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float wr = w[c] * rstd[c];
+  if (!bwd) { A[c] = wr; B[c] = 0.f; D[c] = (b ? b[c] : 0.f) - mean[c] * wr; return; }
+  const float db = stats[c], dw = stats[C + c], inv = 1.f / (float)M;
+  A[c] = wr;
+  B[c] = -wr * rstd[c] * dw * inv;
+  D[c] = wr * (mean[c] * rstd[c] * dw - db) * inv;
+}
+
 }  // namespace mhimx
 
 using namespace mhimx;
@@ -914,6 +976,59 @@ extern "C" int mhimx_sincos_add(void* stream, const float* x, const int64_t* pos
   MHIMX_CHECK_ARG(x && pos_xy && out && C % 4 == 0 && N >= 0, "sincos_add: bad args");
   if (N == 0) return 0;
   hipLaunchKernelGGL(sincos_add_kernel, dim3(grid1d(N, 1, 16384)), dim3(AT), 0, (hipStream_t)stream, x, pos_xy, N, (int)C, out);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ws: mhimx_bn_ws_floats(M, C) floats
+extern "C" int64_t mhimx_bn_ws_floats(int64_t M, int64_t C) { return (cdiv(M, 64) * 2 + 8) * C; }
+static int bn_stats(hipStream_t st, int mode, const float* a, const float* x, const float* mean, const float* rstd, int64_t M, int64_t C, float* ws,
+                    float* stats) {
+  const int64_t chunk = 64;
+  const int nblk = (int)cdiv(M, chunk);
+  if (mode == 0) hipLaunchKernelGGL(bn_stats_kernel<0>, dim3((unsigned)nblk, (unsigned)cdiv(C, AT)), dim3(AT), 0, st, a, x, mean, rstd, M, (int)C, chunk, ws);
+  else hipLaunchKernelGGL(bn_stats_kernel<1>, dim3((unsigned)nblk, (unsigned)cdiv(C, AT)), dim3(AT), 0, st, a, x, mean, rstd, M, (int)C, chunk, ws);
+  MHIMX_LAUNCH_CHECK();
+  // partial rows are [blk][2][C]: even rows = s0, odd rows = s1 -> reduce as width 2C over nblk rows
+  return attn_reduce(st, ws, nblk, 2 * C, stats);
+}
+extern "C" int mhimx_bn_fwd(void* stream, const float* x, int64_t M, int64_t C, const float* w, const float* b, float eps, int32_t training,
+                            float* mean /* in (eval: running mean) / out */, float* rstd /* out; eval: in = running VAR */, float* var_out,
+                            float* y, float* ws) {
+  MHIMX_CHECK_ARG(x && w && mean && rstd && y && ws && M >= 1 && C >= 1, "bn_fwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  float* stats = ws + cdiv(M, 64) * 2 * C;
+  float* A = stats + 2 * C; float* B = A + C; float* D = B + C;
+  const unsigned gc = (unsigned)cdiv(C, 256);
+  if (training) {
+    MHIMX_CHECK_ARG(var_out, "bn_fwd: training needs var_out");
+    if (int r = bn_stats(st, 0, x, nullptr, nullptr, nullptr, M, C, ws, stats)) return r;
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(gc), dim3(256), 0, st, stats, M, (int)C, eps, mean, rstd, var_out);
+  }
+  hipLaunchKernelGGL(bn_coef_kernel, dim3(gc), dim3(256), 0, st, 0, w, b, mean, rstd, stats, M, (int)C, A, B, D);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1d(M, 1, 16384)), dim3(AT), 0, st, x, (const float*)nullptr, A, B, D, M, (int)C, y);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mhimx_bn_bwd(void* stream, const float* dy, const float* x, int64_t M, int64_t C, const float* w, const float* mean,
+                            const float* rstd, int32_t training, float* dx /* may be NULL */, float* dw, float* db, float* ws) {
+  MHIMX_CHECK_ARG(dy && x && w && mean && rstd && dw && db && ws && M >= 1, "bn_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  float* stats = ws + cdiv(M, 64) * 2 * C;
+  float* A = stats + 2 * C; float* B = A + C; float* D = B + C;
+  if (int r = bn_stats(st, 1, dy, x, mean, rstd, M, C, ws, stats)) return r;
+  MHIMX_HIP(hipMemcpyAsync(db, stats, C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MHIMX_HIP(hipMemcpyAsync(dw, stats + C, C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (!dx) return 0;
+  const unsigned gc = (unsigned)cdiv(C, 256);
+  if (training) {
+    hipLaunchKernelGGL(bn_coef_kernel, dim3(gc), dim3(256), 0, st, 1, w, (const float*)nullptr, mean, rstd, stats, M, (int)C, A, B, D);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1d(M, 1, 16384)), dim3(AT), 0, st, dy, x, A, B, D, M, (int)C, dx);
+  } else {                                                    // eval: the statistics are constants, dx = dy w rstd
+    hipLaunchKernelGGL(bn_coef_kernel, dim3(gc), dim3(256), 0, st, 0, w, (const float*)nullptr, mean, rstd, stats, M, (int)C, A, B, D);
+    hipMemsetAsync(D, 0, C * sizeof(float), st);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid1d(M, 1, 16384)), dim3(AT), 0, st, dy, (const float*)nullptr, A, B, D, M, (int)C, dx);
+  }
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -15,7 +15,9 @@ activation / counter-based dropout; mhimx_abmil_pool_fwd / _bwd with the bias gr
 (LayerNorm before the embedding, ``embed_norm_pos=0``, or after it, ``=1``, plus ``norm1`` on the pooled vector: abmil.py:171-178,
 transmil.py:83-84), ``pos`` None / 'none' / 'sincos' (abmil, emb_position.py:5-83) and 'ppeg' / 'none' (transmil); the gated
 scorer's inner dropouts (abmil.py:96-98, active in training when ``dropout`` is set) run inside the scorer's row kernels
-(``mhimx_scorer.gate_drop_p``).  Not built: ``mil_norm='bn'`` (BatchNorm over the instances of ONE bag) and ``embed_feat=False``.
+(``mhimx_scorer.gate_drop_p``); ``mil_norm='bn'`` is a BatchNorm over the instances of ONE bag (``mhimx_bn_fwd / _bwd``; running
+statistics kept in the ``nn.BatchNorm1d`` holder; DAttention's ``norm1`` on the single pooled row raises in training mode exactly as
+the reference does).  Not built: ``embed_feat=False``.
 CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
 """
 from __future__ import annotations
@@ -113,6 +115,52 @@ class _SinCosAdd(torch.autograd.Function):
         return dy, None
 
 
+class _BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm1d over the M instances of one bag ([1, M, C] transposed to [1, C, M] in the reference: abmil.py:206-210)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, bn, training):
+        x = x.contiguous()
+        M, Cc = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        ws = torch.empty(L.lib().mhimx_bn_ws_floats(M, Cc), device=dev)
+        if training:
+            mean, rstd, var = (torch.empty(Cc, device=dev) for _ in range(3))
+        else:
+            mean, var = bn.running_mean.detach().float().contiguous(), None
+            rstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps).contiguous()
+        L.check(L.lib().mhimx_bn_fwd(NY._st(), NY._ptr(x), M, Cc, NY._ptr(w), NY._ptr(b), float(bn.eps), int(training), NY._ptr(mean),
+                                     NY._ptr(rstd), None if var is None else NY._ptr(var), NY._ptr(y), NY._ptr(ws)), "mhimx_bn_fwd")
+        if training:                                             # running statistics (momentum 0.1, unbiased variance), on [C] vectors
+            with torch.no_grad():
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+                bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, Cc = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        ws = torch.empty(L.lib().mhimx_bn_ws_floats(M, Cc), device=x.device)
+        L.check(L.lib().mhimx_bn_bwd(NY._st(), NY._ptr(dy), NY._ptr(x), M, Cc, NY._ptr(w), NY._ptr(mean), NY._ptr(rstd), int(ctx.training),
+                                     None if dx is None else NY._ptr(dx), NY._ptr(dw), NY._ptr(db), NY._ptr(ws)), "mhimx_bn_bwd")
+        return dx, dw, db, None, None
+
+
+def _bn(x, m, training):
+    if training and x.shape[0] < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")    # as nn.BatchNorm1d
+    return _BatchNormFn.apply(x, m.weight, m.bias, m, bool(training))
+
+
 def _layernorm(dim, bias=True):
     """nn.LayerNorm(dim, bias=mil_bias) under the reference's initialisation (weight 1, bias 0: abmil.py:15-17)."""
     m = nn.Module()
@@ -141,9 +189,8 @@ class _AttnMILBase(nn.Module):
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
     def _norm_cfg(self, mil_norm, who):
-        if mil_norm not in (None, "ln"):
-            raise L.MhimxError(f"{who} (mhimx): mil_norm={mil_norm!r} is not built (None and 'ln' are; 'bn' normalises over the "
-                               "instances of one bag with running statistics - not on this path)")
+        if mil_norm not in (None, "ln", "bn"):
+            raise L.MhimxError(f"{who} (mhimx): mil_norm={mil_norm!r} (None, 'ln', 'bn')")
         return mil_norm
 
     def _embed(self, x, rows=None):
@@ -181,12 +228,17 @@ class DAttention(_AttnMILBase):
             if embed_norm_pos == 1:
                 self.norm = _layernorm(inner_dim, mil_bias)
             self.norm1 = _layernorm(self.L * self.K, mil_bias)
+        elif mil_norm == "bn":                                              # abmil.py:167-169
+            self.norm = nn.BatchNorm1d(input_dim if embed_norm_pos == 0 else inner_dim)
+            self.norm1 = nn.BatchNorm1d(self.L * self.K)
         self.feature = nn.Sequential(*layers)
         self.attention = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot(), _linear(self.D, self.K, mil_bias))
         self.classifier = _linear(self.L * self.K, n_classes, mil_cls_bias)
 
     def forward(self, x, return_attn=False, no_norm=False, return_act=False, pos=None, return_img_feat=False, **kwargs):
         x = self._check(x)
+        if self.mil_norm == "bn" and self.embed_norm_pos == 0:               # abmil.py:206-210
+            x = _bn(x, self.norm, self.norm.training)
         H = self._embed(x)
         if self.pos == "sincos":                                             # abmil.py:216-217, emb_position.py:62-83
             if pos is None:
@@ -195,10 +247,13 @@ class DAttention(_AttnMILBase):
             H = _SinCosAdd.apply(H, pp[1:].to(device=H.device, dtype=torch.int64).contiguous())
         if self.mil_norm == "ln" and self.embed_norm_pos == 1:
             H = _ln(H, self.norm)
+        elif self.mil_norm == "bn" and self.embed_norm_pos == 1:             # abmil.py:219-223
+            H = _bn(H, self.norm, self.norm.training)
         a0, a2 = self.attention[0], self.attention[2]
         z, s, stats = _PoolFn.apply(H, a0.weight, a0.bias, a2.weight, a2.bias, None, None, L.ACT["tanh"])
         zz = z.view(1, -1)
-        zc = _ln(zz, self.norm1) if self.mil_norm == "ln" else zz           # abmil.py:237
+        # abmil.py:237 (BatchNorm1d on the ONE pooled row raises in training mode, there as here: the reference cannot train this setting)
+        zc = _ln(zz, self.norm1) if self.mil_norm == "ln" else (_bn(zz, self.norm1, self.norm1.training) if self.mil_norm == "bn" else zz)
         logits = NY.Linear.apply(zc, self.classifier.weight, self.classifier.bias, 0.0, 0, None)
         out = [logits, zz.clone()] if return_img_feat else logits
         if not return_attn:
@@ -227,6 +282,9 @@ class AttentionGated(_AttnMILBase):
         if mil_norm == "ln":
             self.norm = _layernorm(inner_dim, mil_bias)
             self.norm1 = _layernorm(self.L * self.K, mil_bias)              # (constructed, never applied: abmil.py:111-143)
+        elif mil_norm == "bn":                                              # abmil.py:61-63
+            self.norm = nn.BatchNorm1d(input_dim if embed_norm_pos == 0 else inner_dim)
+            self.norm1 = nn.BatchNorm1d(self.L * self.K)
         self.feature = nn.Sequential(*([_linear(input_dim, inner_dim, mil_bias)] + ([_Slot()] if act in ("gelu", "relu") else []) + [_Slot()]))
         self.attention_a = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot())
         self.attention_b = nn.Sequential(_linear(self.L, self.D, mil_bias), _Slot())
@@ -235,9 +293,13 @@ class AttentionGated(_AttnMILBase):
 
     def forward(self, x, **kwargs):
         x = self._check(x)
+        if self.mil_norm == "bn" and self.embed_norm_pos == 0:               # abmil.py:115-119
+            x = _bn(x, self.norm, self.norm.training)
         H = self._embed(x)
         if self.mil_norm == "ln":
             H = _ln(H, self.norm)
+        elif self.mil_norm == "bn" and self.embed_norm_pos == 1:             # abmil.py:123-127
+            H = _bn(H, self.norm, self.norm.training)
         a, b, c = self.attention_a[0], self.attention_b[0], self.attention_c
         gp = self.scorer_drop if self.training else 0.0                     # abmil.py:96-98: Dropout(0.25) after the tanh and after the gate
         z, _, _ = _PoolFn.apply(H, a.weight, a.bias, c.weight, c.bias, b.weight, b.bias, L.ACT["tanh"], float(gp), self._seed())
@@ -260,6 +322,8 @@ class TransMIL(_AttnMILBase):
         self.act = "gelu" if act.lower() == "gelu" else ("relu" if act.lower() == "relu" else "none")
         self.embed_drop = 0.25 if dropout else 0.0
         self._ln_first = mil_norm == "ln"
+        if mil_norm == "bn":
+            self.norm1 = nn.BatchNorm1d(input_dim)                          # transmil.py:79-81
         self.feature = nn.Sequential(*(([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + [_linear(input_dim, inner_dim, mil_bias)]
                                        + ([_Slot()] if self.act != "none" else []) + ([_Slot()] if dropout else [])))
         self.cls_token = nn.Parameter(torch.randn(1, 1, inner_dim) * 1e-6)      # transmil.py:99-100
@@ -271,6 +335,8 @@ class TransMIL(_AttnMILBase):
 
     def forward(self, x, return_attn=False, return_act=False, **kwargs):
         x = self._check(x)
+        if self.mil_norm == "bn":                       # transmil.py:112-115
+            x = _bn(x, self.norm1, self.norm1.training)
         n = x.shape[0]
         side = int(math.ceil(math.sqrt(n)))             # transmil.py:124-126 (any side: its PPEG takes the grid explicitly, :57-64)
         while side * side < n:
@@ -279,12 +345,12 @@ class TransMIL(_AttnMILBase):
         rows = None
         if add > 0:                                                      # x = cat([x, x[:add]]) as a gather index
             rows = torch.cat([torch.arange(n, device=x.device), torch.arange(add, device=x.device)])
-        if self._ln_first and rows is not None:
-            # LayerNorm is row-wise: normalise the n bag rows once, append the wrapped rows as an autograd index (rows 0..add-1 get both
-            # gradients), and embed without a gather
-            xn = _ln(x, self.feature[0])
+        if (self._ln_first or self.mil_norm == "bn") and rows is not None:
+            # a trainable norm in front of the embedding: normalise the n bag rows once (LayerNorm is row-wise; the BatchNorm above ran on
+            # the bag already), append the wrapped rows as an autograd index (rows 0..add-1 get both gradients), embed without a gather
+            xn = _ln(x, self.feature[0]) if self._ln_first else x
             xn = torch.cat([xn, xn[:add]], 0)
-            f = self.feature[1]
+            f = self.feature[1 if self._ln_first else 0]
             h = _EmbedFn.apply(xn, f.weight, f.bias, L.ACT[self.act], float(self.embed_drop if self.training else 0.0), self._seed(), None)
         else:
             h = self._embed(x, rows)

@@ -498,16 +498,41 @@ def g17_standalone_options(ns):
              ("abmil_sincos", "abmil", dict(dropout=0.0, act="gelu", pos="sincos"), 53, {"pos": pos}),
              ("gabmil_ln1", "gabmil", dict(act="gelu", dropout=0., mil_norm="ln", embed_norm_pos=1), 54, {}),
              ("transmil_ln", "transmil", dict(dropout=False, act="gelu", mil_norm="ln"), 55, {}),
-             ("transmil_posnone", "transmil", dict(dropout=False, act="relu", pos="none"), 56, {}))
+             ("transmil_posnone", "transmil", dict(dropout=False, act="relu", pos="none"), 56, {}),
+             # mil_norm='bn': BatchNorm1d over the instances of the bag (train mode: batch statistics; the running statistics after the
+             # step are part of the fixture).  DAttention's norm1 sees ONE pooled row and raises in train mode (the reference cannot
+             # train that setting): its fixture is the eval forward with non-trivial running statistics
+             ("gabmil_bn0", "gabmil", dict(act="gelu", dropout=0., mil_norm="bn", embed_norm_pos=0), 57, {}),
+             ("gabmil_bn1", "gabmil", dict(act="relu", dropout=0., mil_norm="bn", embed_norm_pos=1), 58, {}),
+             ("transmil_bn", "transmil", dict(dropout=False, act="gelu", mil_norm="bn"), 59, {}),
+             ("abmil_bn1_eval", "abmil", dict(dropout=0.0, act="gelu", mil_norm="bn", embed_norm_pos=1), 60, {}))
     for name, kind, kw, pseed, fkw in cases:
         cls = {"abmil": ns.abmil.DAttention, "gabmil": ns.abmil.AttentionGated, "transmil": ns.transmil.TransMIL}[kind]
         m = _fill_module(cls(d, 2, **kw), pseed)
-        m = m.eval() if kind == "transmil" else m.train()
+        with torch.no_grad():                                     # (filled from N(0, 0.05): keep the variances positive, the counter integral)
+            for k_, v_ in m.state_dict().items():
+                if k_.endswith("running_var"):
+                    v_.copy_(v_.abs() + 0.5)
+                if k_.endswith("num_batches_tracked"):
+                    v_.zero_()
+        init_sd = {k_: v_.clone() for k_, v_ in m.state_dict().items()}
+        if name.endswith("_eval"):
+            m = m.eval()
+        elif kind == "transmil":
+            m = m.eval()
+            if kw.get("mil_norm") == "bn":
+                m.norm1.train()                                   # batch statistics in the input norm, attention dropouts off
+        else:
+            m = m.train()
         out = m(x.clone(), **fkw)
         logits = out[0] if isinstance(out, (list, tuple)) else out
         loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([1]))
         loss.backward()
         extra = {"pos": pos.numpy()} if fkw else {}
+        for k_, v_ in m.state_dict().items():                     # buffers: their values before and after the step
+            if "running_" in k_ or k_.endswith("num_batches_tracked"):
+                extra["buf0:" + k_] = init_sd[k_].numpy()
+                extra["buf1:" + k_] = v_.detach().numpy()
         _save(f"g17_standalone_opt_{name}", dict(n=n, d=d, xseed=35, pseed=pseed, std=0.05, label=1, kind=kind, kwargs=kw,
                                                  keys=list(m.state_dict().keys()), shapes=[list(v.shape) for v in m.state_dict().values()]),
               logits=logits.view(-1).detach().numpy(), loss=loss.item(), **extra, **_compact_all("grad", _grads(m)))

@@ -80,8 +80,11 @@ def test_factory_and_guards():
     assert isinstance(pure, MHIM) and not pure.merge_enable
     with pytest.raises(NotImplementedError):
         build_model("clam_sb", input_dim=64, n_classes=2)
+    bn = build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="bn").to(DEV).train()
+    with pytest.raises(ValueError):                        # BatchNorm1d on the ONE pooled row in training mode: the reference raises too
+        bn(torch.randn(1, 50, 64, device=DEV))
     with pytest.raises(L.MhimxError):
-        build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="bn")
+        build_model("abmil", input_dim=64, n_classes=2, dropout=0.0, act="relu", mil_norm="gn")
     with pytest.raises(L.MhimxError):                     # the reference constructor itself fails here (abmil.py:66)
         build_model("gabmil", input_dim=64, n_classes=2, act="relu", mil_norm="ln", embed_norm_pos=0)
 
@@ -95,16 +98,29 @@ def test_standalone_options_fixture(name):
     m = build_model(meta["kind"], input_dim=meta["d"], n_classes=2, **meta["kwargs"])
     sd = {k: torch.from_numpy(synth.normal(meta["pseed"], tuple(shape), std=meta["std"], lane=i + 1).astype(np.float32))
           for i, (k, shape) in enumerate(zip(meta["keys"], meta["shapes"]))}
+    for k in meta["keys"]:                              # BatchNorm buffers: the generator's start values (positive variances, counter 0)
+        if "buf0:" + k in a:
+            sd[k] = torch.from_numpy(np.asarray(a["buf0:" + k]))
     missing, unexpected = m.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
     m = m.to(DEV)
-    m = m.eval() if meta["kind"] == "transmil" else m.train()
+    if name.endswith("_eval"):
+        m = m.eval()
+    elif meta["kind"] == "transmil":
+        m = m.eval()
+        if meta["kwargs"].get("mil_norm") == "bn":
+            m.norm1.train()                             # batch statistics in the input norm, attention dropouts off (as the generator)
+    else:
+        m = m.train()
     fkw = {"pos": torch.from_numpy(a["pos"]).to(DEV)} if "pos" in a else {}
     logits = m(_x(meta), **fkw)
     loss = torch.nn.functional.cross_entropy(logits.view(1, -1), torch.tensor([meta["label"]], device=DEV))
     loss.backward()
     np.testing.assert_allclose(logits.detach().cpu().numpy().reshape(-1), a["logits"].reshape(-1), atol=1e-4, rtol=1e-3)
     np.testing.assert_allclose(loss.item(), float(a["loss"]), rtol=1e-3)
+    for k, v in m.state_dict().items():                 # running statistics after the step
+        if "buf1:" + k in a:
+            np.testing.assert_allclose(v.detach().cpu().numpy(), np.asarray(a["buf1:" + k]), rtol=1e-4, atol=1e-6, err_msg=k)
     grads = G.tagged(a, "grad")
     params = dict(m.named_parameters())
     assert set(grads) <= set(params)
