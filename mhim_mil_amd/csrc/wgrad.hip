@@ -664,7 +664,11 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   }
   const int64_t tiles = (a->E / WBI) * (a->D / WBN);
   dim3 grid((unsigned)(8 * tiles * cdiv(g.splits, 8) + side_blocks));
-  static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;        // (experiments: the uniform-wave form)
+  // The specialised-wave form (bag_wgrad_ws_kernel, ~5 % faster) is OPT-IN: with two processes time-slicing one GPU it ended in a GPU
+  // memory access fault on the long TransMIL-shaped launches (E = 1536 / D = 512, ~270 us each; tools/two_proc_c3.sh: 3 of 6 runs died,
+  // 0 of 12 with the uniform form; the c2 / c5 shapes never faulted) - not understood (every address is bounded on paper; suspect:
+  // wave save / restore around its producer-only DMA waves), so the uniform form is the default.
+  static const bool ws_form = getenv("MHIMX_WGRAD_WS") != nullptr;
   if (ws_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
