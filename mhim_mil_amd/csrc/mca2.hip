@@ -19,6 +19,7 @@
 // backward: parameters x dz (1), rows backward incl. LayerNorm backward (1), two rank-k gradient launches.
 // Built for E = 512, 8 heads x 64, k <= 6 (J <= 48), R <= 8192; other shapes take mca.hip's general path.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mca2_side.hpp"
@@ -539,7 +540,8 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
                      m->drop_seed, m->drop_tick, dX, w);
   MHIMX_LAUNCH_CHECK();
   // the parameter-gradient tail: U [J, E] takes the place of the fp32 copy of aq (not needed any more)
-  if (gr->defer && gr->defer->side.pending == 0) {
+  static const bool no_ride = getenv("MHIMX_MERGE_NO_RIDE") != nullptr;      // (experiments: the tail as three launches of its own)
+  if (!no_ride && gr->defer && gr->defer->side.pending == 0) {
     // deferred: the three stages ride in later launches of this backward (mhimx_rows_dpre, the weight-gradient mhimx_gemm_tn,
     // mhimx_reduce_flush); whatever did not get a ride is launched by mhimx_reduce_flush before the reductions
     memcpy(gr->defer->side.blob, &sd, sizeof(sd));
