@@ -334,15 +334,13 @@ class MatmulAffine(torch.autograd.Function):
         return da, db, None, None
 
 
-def _core_forward(qkv, conv_w, l, scale):
-    """The block between to_qkv and to_out (nystrom_attention.py:93-136) on the streamed kernels; returns (out [T, 512], saved)."""
+def _landmark_pinv_forward(lm, scale):
+    """The landmark-only part of the block: attn2 = softmax(scale q~ k~^T) and its iterative pseudo-inverse (nystrom_attention.py:12-27,
+    :115,:130): z0 = a2^T / (max col sum * max row sum), six iterations, every intermediate kept for the backward.  Depends on the
+    landmark means alone, so a sequence-parallel layer runs it replicated on every rank."""
     lib = L.lib()
-    T, ld = qkv.shape
-    m, dev = LANDMARKS, qkv.device
-    lm = torch.empty((m, 2 * INNER), device=dev)
-    L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
+    m, dev = LANDMARKS, lm.device
     ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
-    no = ops.NysOperands(qkv, lm, scale)
     a2 = torch.empty((HEADS, m, m), device=dev)
     _heads_mm("nt", ql, kl, batched(a2), HEADS)                       # q~ k~^T       nystrom:115
     L.check(lib.mhimx_softmax_rows(_st(), _ptr(a2), _ptr(a2), HEADS * m, m, float(scale)), "softmax_rows")
@@ -361,6 +359,46 @@ def _core_forward(qkv, conv_w, l, scale):
         zn = _bmm_affine("nn", z, t3, torch.empty_like(a2), 0.25, 0.0)
         chain.append((z, az, t1, t2, t3))
         z = zn
+    return a2, z, z0, stats, chain
+
+
+def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm):
+    """Backward of _landmark_pinv_forward: dz (gradient of the pseudo-inverse) -> the S2 terms of dq~ / dk~, ADDED into dlm."""
+    lib = L.lib()
+    m, dev = LANDMARKS, lm.device
+    ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
+    dql, dkl = ql.like(dlm), kl.like(dlm)
+    # pseudo-inverse, backwards through the six iterations
+    da2 = torch.empty_like(a2)
+    first = True
+    for (zp, az, t1, t2, t3) in reversed(chain):                                  # four pairs of independent products per iteration
+        dzp, dt3, daz, dt2, dt1 = (torch.empty_like(dz) for _ in range(5))
+        _bmm_pair(("nt", dz, t3, dzp, 0.25, False), ("tn", zp, dz, dt3, 0.25, False))        # z' = 0.25 zp t3
+        _bmm_pair(("nt", dt3, t2, daz, -1.0, False), ("tn", az, dt3, dt2, -1.0, False))      # t3 = 13 I - az t2
+        _bmm_pair(("nt", dt2, t1, daz, -1.0, True), ("tn", az, dt2, dt1, -1.0, False))       # t2 = 15 I - az t1
+        L.check(lib.mhimx_axpby(_st(), _ptr(dt1), _ptr(daz), daz.numel(), -1.0, 1.0), "axpby")      # t1 = 7 I - az
+        _bmm_pair(("nt", daz, zp, da2, 1.0, not first), ("tn", a2, daz, dzp, 1.0, True))      # az = a2 zp
+        dz, first = dzp, False
+    dinit = torch.empty_like(a2)
+    ws2 = torch.empty(256, device=dev)
+    L.check(lib.mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z0), _ptr(stats), HEADS, m, _ptr(dinit), _ptr(ws2)), "pinv_init_bwd")
+    L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
+    L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(a2), _ptr(da2), _ptr(da2), HEADS * m, m, float(scale)), "softmax_rows_bwd")
+    ds2 = batched(da2)
+    _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=True)              # s2 = q~ k~^T: dq~ += ds2 k~
+    _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
+
+
+def _core_forward(qkv, conv_w, l, scale):
+    """The block between to_qkv and to_out (nystrom_attention.py:93-136) on the streamed kernels; returns (out [T, 512], saved)."""
+    lib = L.lib()
+    T, ld = qkv.shape
+    m, dev = LANDMARKS, qkv.device
+    lm = torch.empty((m, 2 * INNER), device=dev)
+    L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
+    ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
+    no = ops.NysOperands(qkv, lm, scale)
+    a2, z, z0, stats, chain = _landmark_pinv_forward(lm, scale)
     a3v, lse3 = ops.nys_a3v_fwd(no)                                    # softmax_n(q~ k^T) v   nystrom:116,131,133
     w2 = torch.empty((HEADS, m, DH), device=dev)
     _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
@@ -396,25 +434,7 @@ def _core_backward(saved, dout):
     _heads_mm("tn", batched(z), batched(dw2), batched(da3v), HEADS)    # da3v = z^T dw2
     # a3v = a3 v: dk, dv +=, the S3 term of dq~
     ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, accumulate_dv=True)
-    # pseudo-inverse, backwards through the six iterations
-    da2 = torch.empty_like(a2)
-    first = True
-    for (zp, az, t1, t2, t3) in reversed(chain):                                  # four pairs of independent products per iteration
-        dzp, dt3, daz, dt2, dt1 = (torch.empty_like(dz) for _ in range(5))
-        _bmm_pair(("nt", dz, t3, dzp, 0.25, False), ("tn", zp, dz, dt3, 0.25, False))        # z' = 0.25 zp t3
-        _bmm_pair(("nt", dt3, t2, daz, -1.0, False), ("tn", az, dt3, dt2, -1.0, False))      # t3 = 13 I - az t2
-        _bmm_pair(("nt", dt2, t1, daz, -1.0, True), ("tn", az, dt2, dt1, -1.0, False))       # t2 = 15 I - az t1
-        L.check(lib.mhimx_axpby(_st(), _ptr(dt1), _ptr(daz), daz.numel(), -1.0, 1.0), "axpby")      # t1 = 7 I - az
-        _bmm_pair(("nt", daz, zp, da2, 1.0, not first), ("tn", a2, daz, dzp, 1.0, True))      # az = a2 zp
-        dz, first = dzp, False
-    dinit = torch.empty_like(a2)
-    ws2 = torch.empty(256, device=dev)
-    L.check(lib.mhimx_pinv_init_bwd(_st(), _ptr(dz), _ptr(z0), _ptr(stats), HEADS, m, _ptr(dinit), _ptr(ws2)), "pinv_init_bwd")
-    L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
-    L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(a2), _ptr(da2), _ptr(da2), HEADS * m, m, float(scale)), "softmax_rows_bwd")
-    ds2 = batched(da2)
-    _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=True)              # s2 = q~ k~^T: dq~ += ds2 k~
-    _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
+    _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm)
     L.check(lib.mhimx_landmark_mean_bwd(_st(), _ptr(dlm), T, l, 2 * INNER, _ptr(dqkv), ld, 1), "landmark_mean_bwd")
     return dqkv, dwc.reshape(wshape)
 

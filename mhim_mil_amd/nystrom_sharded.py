@@ -1,0 +1,149 @@
+"""Sequence-parallel Nystrom TransLayer: ONE bag's token sequence sharded over the ranks (third line).
+
+Rank r holds the contiguous token block [r T/W, (r+1) T/W) of a sequence of T tokens (T % 256 == 0, W | 256, T/W a multiple of 64:
+every rank owns 256/W WHOLE landmark groups - the caller re-balances ragged shards first).  What couples the shards in
+``y = x + to_out(Nystrom(to_qkv(LayerNorm(x))))`` (baseline.py:213-218, nystrom_attention.py:65-152), and how it is exchanged:
+
+  forward   landmark means q~, k~        own groups, all-gather of [256/W, 1024]
+            attn2, its pseudo-inverse    landmark-only: replicated on every rank (bit-identical replicas, no traffic)
+            a3v = softmax_T(q~ k^T) v    the streamed kernel's per-shard result (a3v_r, lse_r) merged over ranks in a fixed order:
+                                         lse = log2 sum_r 2^lse_r, a3v = sum_r 2^(lse_r - lse) a3v_r  (all-gather of 8 x 256 x 65 floats)
+            out = softmax(q k~^T) w2     per token: local
+            res_conv(v), 33 taps         16 halo rows of v from each neighbour
+  backward  dw2 (sum over tokens)        all-reduce [8, 256, 64]; dz, da3v and the pseudo-inverse backward replicated
+            dk, dv, dq                   local (the kernels take the GLOBAL a3v / lse3: the restriction of the global formula to the shard)
+            dq~, dk~                     token-side terms are partial sums: ONE all-reduce of [256, 1024]; the attn2 terms are added after it
+            conv backward                16 halo rows of dout; the conv weight gradient is a local partial sum
+Parameter gradients leave as LOCAL partial sums (the data-parallel flat-gradient all-reduce adds them up, as for instance-sharded ABMIL).
+
+Not here (still open for a sharded MHIM(TransMIL) step): ragged shards of a masked bag (a validity bound in the kernels), the PPEG's
+2-d halo and wrap rows, the cls token's placement and the front padding.  All exchanges go through ``sharded._Comm`` (RCCL; gloo with host
+staging in the one-GPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import nystrom as NY
+from . import ops
+from .sharded import _Comm
+
+HEADS, DH, INNER, M, KS, HALO = NY.HEADS, NY.DH, NY.INNER, NY.LANDMARKS, NY.CONV_K, NY.CONV_K // 2
+
+
+def _halo_rows(comm, block):
+    """block [Tr, C] (local rows, contiguous) -> [HALO + Tr + HALO, C]: the neighbours' boundary rows around it (zeros at the sequence ends)."""
+    Tr, Cc = block.shape
+    edges = torch.stack([block[:HALO], block[Tr - HALO:]]).contiguous()              # [2, 16, C]: my first / last rows
+    allg = comm.all_gather(edges)                                                      # [W, 2, 16, C]
+    ext = torch.zeros((Tr + 2 * HALO, Cc), device=block.device)
+    ext[HALO:HALO + Tr].copy_(block)
+    if comm.rank > 0:
+        ext[:HALO].copy_(allg[comm.rank - 1, 1])
+    if comm.rank < comm.world - 1:
+        ext[HALO + Tr:].copy_(allg[comm.rank + 1, 0])
+    return ext
+
+
+class ShardedTransLayerFn(torch.autograd.Function):
+    """y_r = x_r + to_out(Nystrom(to_qkv(LayerNorm(x))))_r for this rank's token block (no dropout: eval-mode attention)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, conv_w, scale, comm):
+        lib = L.lib()
+        x = x.contiguous()
+        Tr, E = x.shape
+        W, dev = comm.world, x.device
+        T = Tr * W
+        if T % M or M % W or Tr % 64 or Tr % (T // M):
+            raise L.MhimxError("sharded TransLayer: T % 256 == 0, world | 256 and aligned shards (T / world a multiple of 64 and of T / 256)")
+        l, gl = T // M, M // W
+        xn = torch.empty_like(x)
+        mean, rstd = torch.empty(Tr, device=dev), torch.empty(Tr, device=dev)
+        L.check(lib.mhimx_layernorm_fwd(NY._st(), NY._ptr(x), Tr, E, NY._ptr(ln_w), NY._ptr(ln_b), NY._ptr(xn), NY._ptr(mean), NY._ptr(rstd)),
+                "layernorm_fwd")
+        qkv = ops.gemm_nt(xn, w_qkv, prec=NY._PREC)                                     # [Tr, 1536]
+        ld = qkv.shape[1]
+        lm_loc = torch.empty((gl, 2 * INNER), device=dev)
+        L.check(lib.mhimx_landmark_mean(NY._st(), NY._ptr(qkv), ld, Tr, l, 2 * INNER, NY._ptr(lm_loc)), "landmark_mean")
+        lm = comm.all_gather(lm_loc).reshape(M, 2 * INNER).contiguous()                 # rank order = group order
+        a2, z, z0, stats, chain = NY._landmark_pinv_forward(lm, scale)                  # replicated
+        no = ops.NysOperands(qkv, lm, scale)
+        a3v_r, lse_r = ops.nys_a3v_fwd(no)
+        A, Ls = comm.all_gather(a3v_r), comm.all_gather(lse_r)                          # [W,8,256,64], [W,8,256]
+        mx = Ls.max(0).values
+        lse3 = (mx + torch.log2(torch.exp2(Ls - mx).sum(0))).contiguous()               # fixed rank order: every rank gets the same bits
+        a3v = (torch.exp2(Ls - lse3).unsqueeze(-1) * A).sum(0).contiguous()
+        w2 = torch.empty((HEADS, M, DH), device=dev)
+        NY._heads_mm("nn", NY.batched(z), NY.batched(a3v), NY.batched(w2), HEADS)
+        out, lse1 = ops.nys_out_fwd(no, w2)
+        wc = conv_w.reshape(HEADS, -1).contiguous()
+        v_ext = _halo_rows(comm, qkv[:, 2 * INNER:].contiguous())
+        conv = torch.empty((Tr + 2 * HALO, INNER), device=dev)
+        L.check(lib.mhimx_resconv(NY._st(), NY._ptr(v_ext), INNER, NY._ptr(wc), KS, DH, Tr + 2 * HALO, INNER, NY._ptr(conv), INNER, 0, 0), "resconv")
+        mid = conv[HALO:HALO + Tr]
+        L.check(lib.mhimx_axpby(NY._st(), NY._ptr(mid), NY._ptr(out), out.numel(), 1.0, 1.0), "axpby")      # out += res_conv(v) (nystrom:135-136)
+        y = ops.gemm_nt(out, w_out, bias=b_out, prec=NY._PREC)
+        L.check(lib.mhimx_axpby(NY._st(), NY._ptr(x), NY._ptr(y), y.numel(), 1.0, 1.0), "axpby")            # y += x
+        ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, v_ext)
+        ctx.cfg = (l, gl, scale, comm, conv_w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, v_ext = ctx.saved
+        ctx.saved = None
+        l, gl, scale, comm, wshape = ctx.cfg
+        dy = dy.contiguous()
+        Tr, E = x.shape
+        dev, ld = x.device, qkv.shape[1]
+        dout = torch.empty((Tr, INNER), device=dev)
+        NY._gemm("nn", dy, 0, E, w_out, 0, INNER, dout, 0, INNER, Tr, INNER, E)
+        dw_out = ops.gemm_tn(dy, out, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
+        db_out = ops.colsum(dy)
+        dqkv = torch.empty_like(qkv)
+        # residual convolution: dv = flip-conv(dout) with dout's halo rows; its weight gradient from the local outputs against v with halos
+        g_ext = _halo_rows(comm, dout)
+        dvx = torch.empty((Tr + 2 * HALO, INNER), device=dev)
+        L.check(lib.mhimx_resconv(NY._st(), NY._ptr(g_ext), INNER, NY._ptr(wc), KS, DH, Tr + 2 * HALO, INNER, NY._ptr(dvx), INNER, 0, 1), "resconv")
+        dqkv[:, 2 * INNER:].copy_(dvx[HALO:HALO + Tr])
+        g_own = torch.zeros_like(g_ext)
+        g_own[HALO:HALO + Tr].copy_(dout)                                                # (the halo rows belong to the neighbours' sums)
+        dwc = torch.empty_like(wc)
+        ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(Tr + 2 * HALO, INNER, DH, KS), device=dev)
+        L.check(lib.mhimx_resconv_dw(NY._st(), NY._ptr(g_own), INNER, NY._ptr(v_ext), INNER, KS, DH, Tr + 2 * HALO, INNER, NY._ptr(dwc), NY._ptr(ws)),
+                "resconv_dw")
+        # out = attn1 w2 : dq local, the token-side term of dk~ and dw2 are partial sums over this shard
+        no = ops.NysOperands(qkv, lm, scale, ws=nws)
+        dlm = torch.empty_like(lm)
+        dw2 = ops.nys_out_bwd(no, w2, dout, lse1, dqkv, dlm)
+        comm.all_reduce_sum(dw2)
+        dz = torch.empty_like(z)
+        NY._heads_mm("nt", NY.batched(dw2), NY.batched(a3v), NY.batched(dz), HEADS)
+        da3v = torch.empty_like(a3v)
+        NY._heads_mm("tn", NY.batched(z), NY.batched(dw2), NY.batched(da3v), HEADS)
+        ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, accumulate_dv=True)              # dk, dv += (local); the token-side term of dq~
+        comm.all_reduce_sum(dlm)
+        NY._landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm)             # + the attn2 terms (replicated: added after the sum)
+        own = dlm[comm.rank * gl:(comm.rank + 1) * gl].contiguous()
+        L.check(lib.mhimx_landmark_mean_bwd(NY._st(), NY._ptr(own), Tr, l, 2 * INNER, NY._ptr(dqkv), ld, 1), "landmark_mean_bwd")
+        dxn = torch.empty_like(x)
+        NY._gemm("nn", dqkv, 0, ld, w_qkv, 0, E, dxn, 0, E, Tr, E, ld)
+        dw_qkv = ops.gemm_tn(dqkv, xn, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
+        dx, dlw, dlb = torch.empty_like(x), torch.empty_like(ln_w), torch.empty_like(ln_w)
+        wsl = torch.empty(2 * 512 * E, device=dev)
+        L.check(lib.mhimx_layernorm_bwd_res(NY._st(), NY._ptr(dxn), NY._ptr(x), Tr, E, NY._ptr(ln_w), NY._ptr(mean), NY._ptr(rstd), NY._ptr(dy),
+                                            NY._ptr(dx), NY._ptr(dlw), NY._ptr(dlb), 0, NY._ptr(wsl)), "layernorm_bwd_res")
+        return dx, dlw, dlb, dw_qkv, dw_out, db_out, dwc.reshape(wshape), None, None
+
+
+def sharded_trans_layer(layer: "NY.TransLayer", x_local, comm=None):
+    """``layer`` (nystrom.TransLayer: the reference's parameter names) applied to this rank's token block of a sharded sequence."""
+    comm = comm if comm is not None else _Comm()
+    a = layer.attn
+    return ShardedTransLayerFn.apply(x_local, layer.norm.weight, layer.norm.bias, a.to_qkv.weight, a.to_out[0].weight, a.to_out[0].bias,
+                                     a.res_conv.weight, a.scale, comm)

@@ -1,0 +1,79 @@
+"""Sequence-parallel Nystrom TransLayer (mhim_mil_amd/nystrom_sharded.py): two and four ranks sharing the box's one GPU (gloo, host staging)
+against the single-rank layer on the whole sequence: outputs, input gradients and the SUM of the ranks' parameter gradients."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T, E = 2048, 512
+
+
+def _layer_and_input():
+    from mhim_mil_amd import nystrom as NY
+    torch.manual_seed(11)
+    layer = NY.TransLayer(E)
+    with torch.no_grad():                                  # non-trivial LayerNorm / bias / conv parameters
+        layer.norm.weight.add_(0.1 * torch.randn(E))
+        layer.norm.bias.add_(0.1 * torch.randn(E))
+        layer.attn.to_out[0].bias.add_(0.05 * torch.randn(E))
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(T, E, generator=g) * 0.7
+    dy = torch.randn(T, E, generator=g) * 0.1
+    return layer, x, dy
+
+
+def _reference():
+    layer, x, dy = _layer_and_input()
+    layer = layer.to(DEV).eval()
+    xd = x.to(DEV).requires_grad_()
+    y = layer(xd, False, False, 0, None, False)
+    y.backward(dy.to(DEV))
+    return y.detach().cpu(), xd.grad.cpu(), {k: p.grad.detach().cpu() for k, p in layer.named_parameters()}
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mhim_mil_amd.nystrom_sharded import sharded_trans_layer
+    layer, x, dy = _layer_and_input()
+    layer = layer.to(DEV).eval()
+    Tr = T // world
+    xl = x[rank * Tr:(rank + 1) * Tr].to(DEV).requires_grad_()
+    y = sharded_trans_layer(layer, xl)
+    y.backward(dy[rank * Tr:(rank + 1) * Tr].to(DEV))
+    torch.save({"y": y.detach().cpu(), "dx": xl.grad.cpu(), "g": {k: p.grad.detach().cpu() for k, p in layer.named_parameters()}},
+               os.path.join(out, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_layer_equals_the_whole_sequence(tmp_path, world):
+    y_ref, dx_ref, g_ref = _reference()
+    port = 34100 + (os.getpid() % 1500) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    y = torch.cat([r["y"] for r in res])
+    dx = torch.cat([r["dx"] for r in res])
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert rel(y, y_ref) < 2e-5
+    assert rel(dx, dx_ref) < 2e-4
+    for k, ref in g_ref.items():
+        tot = sum(r["g"][k] for r in res)                  # parameter gradients are local partial sums: the flat all-reduce adds them
+        assert rel(tot, ref) < 5e-4, (k, rel(tot, ref))
+
+
+def test_shard_alignment_is_checked():
+    from mhim_mil_amd import _lib as L
+    from mhim_mil_amd import nystrom as NY
+    from mhim_mil_amd.nystrom_sharded import sharded_trans_layer
+    layer = NY.TransLayer(E).to(DEV).eval()
+    with pytest.raises(L.MhimxError):
+        sharded_trans_layer(layer, torch.randn(200, E, device=DEV))            # (a world of one: 200 tokens are not 256 landmarks' worth)
