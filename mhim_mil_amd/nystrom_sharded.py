@@ -16,8 +16,9 @@ every rank owns 256/W WHOLE landmark groups - the caller re-balances ragged shar
             conv backward                16 halo rows of dout; the conv weight gradient is a local partial sum
 Parameter gradients leave as LOCAL partial sums (the data-parallel flat-gradient all-reduce adds them up, as for instance-sharded ABMIL).
 
-Not here (still open for a sharded MHIM(TransMIL) step): ragged shards of a masked bag (a validity bound in the kernels), the PPEG's
-2-d halo and wrap rows, the cls token's placement and the front padding.  All exchanges go through ``sharded._Comm`` (RCCL; gloo with host
+``sharded_sattention`` is the encoder level (cls token, front padding, the two layers, the PPEG between them - replicated on an
+all-gathered copy in this first cut, LayerNorm of the cls row).  Still open for a sharded MHIM(TransMIL) STEP: ragged shards of a masked
+bag (a validity bound in the kernels or a re-balancing all-to-all from the instance shards), the PPEG's 2-d halo instead of the replica.  All exchanges go through ``sharded._Comm`` (RCCL; gloo with host
 staging in the one-GPU tests).
 """
 from __future__ import annotations
@@ -52,12 +53,13 @@ class ShardedTransLayerFn(torch.autograd.Function):
     """y_r = x_r + to_out(Nystrom(to_qkv(LayerNorm(x))))_r for this rank's token block (no dropout: eval-mode attention)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, conv_w, scale, comm):
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, conv_w, scale, comm, pad=0):
         lib = L.lib()
         x = x.contiguous()
         Tr, E = x.shape
         W, dev = comm.world, x.device
         T = Tr * W
+        npad = max(0, min(int(pad) - comm.rank * Tr, Tr))            # leading rows of THIS block that are the front zero padding
         if T % M or M % W or Tr % 64 or Tr % (T // M):
             raise L.MhimxError("sharded TransLayer: T % 256 == 0, world | 256 and aligned shards (T / world a multiple of 64 and of T / 256)")
         l, gl = T // M, M // W
@@ -65,6 +67,8 @@ class ShardedTransLayerFn(torch.autograd.Function):
         mean, rstd = torch.empty(Tr, device=dev), torch.empty(Tr, device=dev)
         L.check(lib.mhimx_layernorm_fwd(NY._st(), NY._ptr(x), Tr, E, NY._ptr(ln_w), NY._ptr(ln_b), NY._ptr(xn), NY._ptr(mean), NY._ptr(rstd)),
                 "layernorm_fwd")
+        if npad:
+            xn[:npad].zero_()                        # nystrom_attention.py:70-73 pads AFTER the LayerNorm: pad tokens are zero rows of q, k, v
         qkv = ops.gemm_nt(xn, w_qkv, prec=NY._PREC)                                     # [Tr, 1536]
         ld = qkv.shape[1]
         lm_loc = torch.empty((gl, 2 * INNER), device=dev)
@@ -89,7 +93,7 @@ class ShardedTransLayerFn(torch.autograd.Function):
         y = ops.gemm_nt(out, w_out, bias=b_out, prec=NY._PREC)
         L.check(lib.mhimx_axpby(NY._st(), NY._ptr(x), NY._ptr(y), y.numel(), 1.0, 1.0), "axpby")            # y += x
         ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, v_ext)
-        ctx.cfg = (l, gl, scale, comm, conv_w.shape)
+        ctx.cfg = (l, gl, scale, comm, conv_w.shape, npad)
         return y
 
     @staticmethod
@@ -97,7 +101,7 @@ class ShardedTransLayerFn(torch.autograd.Function):
         lib = L.lib()
         x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, v_ext = ctx.saved
         ctx.saved = None
-        l, gl, scale, comm, wshape = ctx.cfg
+        l, gl, scale, comm, wshape, npad = ctx.cfg
         dy = dy.contiguous()
         Tr, E = x.shape
         dev, ld = x.device, qkv.shape[1]
@@ -133,17 +137,83 @@ class ShardedTransLayerFn(torch.autograd.Function):
         L.check(lib.mhimx_landmark_mean_bwd(NY._st(), NY._ptr(own), Tr, l, 2 * INNER, NY._ptr(dqkv), ld, 1), "landmark_mean_bwd")
         dxn = torch.empty_like(x)
         NY._gemm("nn", dqkv, 0, ld, w_qkv, 0, E, dxn, 0, E, Tr, E, ld)
+        if npad:
+            dxn[:npad].zero_()                       # the pad rows of xn are constants
         dw_qkv = ops.gemm_tn(dqkv, xn, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
         dx, dlw, dlb = torch.empty_like(x), torch.empty_like(ln_w), torch.empty_like(ln_w)
         wsl = torch.empty(2 * 512 * E, device=dev)
         L.check(lib.mhimx_layernorm_bwd_res(NY._st(), NY._ptr(dxn), NY._ptr(x), Tr, E, NY._ptr(ln_w), NY._ptr(mean), NY._ptr(rstd), NY._ptr(dy),
                                             NY._ptr(dx), NY._ptr(dlw), NY._ptr(dlb), 0, NY._ptr(wsl)), "layernorm_bwd_res")
-        return dx, dlw, dlb, dw_qkv, dw_out, db_out, dwc.reshape(wshape), None, None
+        return dx, dlw, dlb, dw_qkv, dw_out, db_out, dwc.reshape(wshape), None, None, None
 
 
-def sharded_trans_layer(layer: "NY.TransLayer", x_local, comm=None):
-    """``layer`` (nystrom.TransLayer: the reference's parameter names) applied to this rank's token block of a sharded sequence."""
+def sharded_trans_layer(layer: "NY.TransLayer", x_local, comm=None, pad=0):
+    """``layer`` (nystrom.TransLayer: the reference's parameter names) applied to this rank's token block of a sharded sequence whose
+    first ``pad`` rows (global indices) are the front zero padding of nystrom_attention.py:70-73."""
     comm = comm if comm is not None else _Comm()
     a = layer.attn
     return ShardedTransLayerFn.apply(x_local, layer.norm.weight, layer.norm.bias, a.to_qkv.weight, a.to_out[0].weight, a.to_out[0].bias,
-                                     a.res_conv.weight, a.scale, comm)
+                                     a.res_conv.weight, a.scale, comm, pad)
+
+
+class _GatherRows(torch.autograd.Function):
+    """Every rank's row block -> the whole [T, C] sequence on every rank; backward: the ranks' gradients of the whole sequence are SUMMED
+    (each rank differentiates only what it used of the replica) and the own block is returned."""
+
+    @staticmethod
+    def forward(ctx, x, comm):
+        ctx.comm, ctx.Tr = comm, x.shape[0]
+        return comm.all_gather(x.contiguous()).reshape(comm.world * x.shape[0], x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dfull):
+        comm, Tr = ctx.comm, ctx.Tr
+        dfull = comm.all_reduce_sum(dfull.contiguous().clone())
+        return dfull[comm.rank * Tr:(comm.rank + 1) * Tr].contiguous(), None
+
+
+class _OwnerRow(torch.autograd.Function):
+    """Row ``idx`` (global) of the sharded sequence on EVERY rank (an all-reduce of the owner's row against zeros); the gradient goes back to
+    the owner only (the consumers of the row are replicated: every rank holds the same gradient, it counts once)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, comm):
+        Tr = x.shape[0]
+        own = comm.rank * Tr <= idx < (comm.rank + 1) * Tr
+        ctx.cfg = (own, idx - comm.rank * Tr, x.shape)
+        row = x[idx - comm.rank * Tr:idx - comm.rank * Tr + 1].clone() if own else torch.zeros((1, x.shape[1]), device=x.device)
+        return comm.all_reduce_sum(row)
+
+    @staticmethod
+    def backward(ctx, drow):
+        own, i, shape = ctx.cfg
+        dx = torch.zeros(shape, device=drow.device)
+        if own:
+            dx[i:i + 1].copy_(drow)
+        return dx, None, None
+
+
+def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None):
+    """mhim_modules/baseline.SAttention (cls token, TransLayer, PPEG, TransLayer, LayerNorm of the cls row: baseline.py:222-288) on a
+    sequence sharded over the ranks.  h_local: this rank's block of the PADDED token sequence [zeros(pad) | cls slot | n - 1 token rows]
+    (T = pad + n, T % 256 == 0; the cls slot's content is ignored).  Returns the cls feature [512] on every rank.
+    First cut of the encoder level: the two layers are sequence-parallel (ShardedTransLayerFn); the PPEG between them runs REPLICATED on
+    an all-gathered copy of the sequence (one all-gather forward, one all-reduce of its gradient backward), each rank keeping its rows."""
+    comm = comm if comm is not None else _Comm()
+    Tr = h_local.shape[0]
+    g0 = comm.rank * Tr
+    x = h_local
+    if g0 <= pad < g0 + Tr:                                                  # the cls token's row lives here (baseline.py:253-255)
+        i = pad - g0
+        x = torch.cat([h_local[:i], enc.cls_token.view(1, -1), h_local[i + 1:]], 0)
+    x = sharded_trans_layer(enc.layer1, x, comm, pad)
+    full = _GatherRows.apply(x, comm)                                        # baseline.py:265-266: cat([cls, ppeg(tokens)])
+    full = enc.pos_embedding(full, skip=pad + 1)                             # rows [0, pad] pass through; the stencil sees the n - 1 tokens
+    x = full[g0:g0 + Tr]
+    x = sharded_trans_layer(enc.layer2, x, comm, pad)
+    row = _OwnerRow.apply(x, pad, comm)
+    # only the cls row is used (baseline.py:276-278).  The final LayerNorm runs replicated: its parameter gradient is counted ONCE, on the
+    # rank that owns the cls row (the others see constants), so that the flat-gradient SUM over the ranks is the gradient
+    own = g0 <= pad < g0 + Tr
+    w, b = (enc.norm.weight, enc.norm.bias) if own else (enc.norm.weight.detach(), enc.norm.bias.detach())
+    return NY.LayerNorm.apply(row, w, b)[0]

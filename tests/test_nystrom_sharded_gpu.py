@@ -77,3 +77,65 @@ def test_shard_alignment_is_checked():
     layer = NY.TransLayer(E).to(DEV).eval()
     with pytest.raises(L.MhimxError):
         sharded_trans_layer(layer, torch.randn(200, E, device=DEV))            # (a world of one: 200 tokens are not 256 landmarks' worth)
+
+
+# ---------------------------------------------------------------------------------------------------- encoder level
+N_TOK = 1850                                               # + cls = 1851 tokens -> 197 front pad rows -> T = 2048
+
+
+def _encoder_and_tokens():
+    from mhim_mil_amd import nystrom as NY
+    torch.manual_seed(21)
+    enc = NY.SAttention(E)
+    with torch.no_grad():
+        enc.cls_token.mul_(0.3)
+        enc.norm.weight.add_(0.1 * torch.randn(E))
+        enc.norm.bias.add_(0.1 * torch.randn(E))
+    g = torch.Generator().manual_seed(22)
+    h = torch.randn(N_TOK, E, generator=g) * 0.7
+    dz = torch.randn(E, generator=g)
+    return enc, h, dz
+
+
+def _enc_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mhim_mil_amd.nystrom_sharded import sharded_sattention
+    enc, h, dz = _encoder_and_tokens()
+    enc = enc.to(DEV).eval()
+    n = N_TOK + 1
+    pad = (256 - n % 256) % 256
+    seq = torch.cat([torch.zeros(pad + 1, E), h])          # [zeros(pad) | cls slot | tokens]
+    Tr = seq.shape[0] // world
+    hl = seq[rank * Tr:(rank + 1) * Tr].to(DEV).requires_grad_()
+    z = sharded_sattention(enc, hl, pad, n)
+    z.backward(dz.to(DEV))
+    torch.save({"z": z.detach().cpu(), "dh": hl.grad.cpu(), "g": {k: (p.grad.detach().cpu() if p.grad is not None else None)
+                                                                    for k, p in enc.named_parameters()}}, os.path.join(out, f"e{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_encoder_equals_the_single_rank_encoder(tmp_path, world):
+    enc, h, dz = _encoder_and_tokens()
+    enc = enc.to(DEV).eval()
+    hd = h.to(DEV).requires_grad_()
+    z_ref = enc(hd)
+    z_ref.backward(dz.to(DEV))
+    g_ref = {k: p.grad.detach().cpu() for k, p in enc.named_parameters()}
+    port = 35100 + (os.getpid() % 1500) + world
+    mp.spawn(_enc_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"e{r}.pt")) for r in range(world)]
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    for r in res:                                           # the cls feature is replicated
+        assert rel(r["z"], z_ref.detach().cpu()) < 5e-5
+    pad = (256 - (N_TOK + 1) % 256) % 256
+    dh = torch.cat([r["dh"] for r in res])[pad + 1:]        # the token rows of the padded sequence
+    assert rel(dh, hd.grad.cpu()) < 5e-4
+    for k, ref in g_ref.items():
+        parts = [r["g"][k] for r in res if r["g"][k] is not None]
+        assert parts, k
+        assert rel(sum(parts), ref) < 2e-3, (k, rel(sum(parts), ref))
