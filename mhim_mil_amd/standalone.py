@@ -17,7 +17,7 @@ transmil.py:83-84), ``pos`` None / 'none' / 'sincos' (abmil, emb_position.py:5-8
 scorer's inner dropouts (abmil.py:96-98, active in training when ``dropout`` is set) run inside the scorer's row kernels
 (``mhimx_scorer.gate_drop_p``); ``mil_norm='bn'`` is a BatchNorm over the instances of ONE bag (``mhimx_bn_fwd / _bwd``; running
 statistics kept in the ``nn.BatchNorm1d`` holder; DAttention's ``norm1`` on the single pooled row raises in training mode exactly as
-the reference does).  Not built: ``embed_feat=False``.
+the reference does); ``embed_feat=False`` (abmil / transmil: the bag rows are the tokens, ``input_dim == inner_dim``).
 CLAM, DTFD, RRT, ... are other model families (SURVEY.md §8 out of scope).
 """
 from __future__ import annotations
@@ -196,6 +196,9 @@ class _AttnMILBase(nn.Module):
     def _embed(self, x, rows=None):
         """self.feature: [LayerNorm(input_dim)]? + Linear + act? + Dropout?  (the reference's nn.Sequential indices)"""
         i = 1 if getattr(self, "_ln_first", False) else 0
+        if getattr(self, "_no_embed", False):                      # embed_feat=False (abmil.py:180, transmil.py:87): the bag rows ARE the tokens
+            x = _ln(x, self.feature[0]) if i else x
+            return x if rows is None else x.index_select(0, rows)
         if i:
             if rows is not None:
                 raise L.MhimxError("_embed: LayerNorm + row gather is handled by the caller")
@@ -213,8 +216,9 @@ class DAttention(_AttnMILBase):
         super().__init__()
         if pos not in (None, "none", "sincos") or embed_norm_pos not in (0, 1):
             raise L.MhimxError("DAttention: pos in ('sincos', 'none', None), embed_norm_pos in (0, 1) (abmil.py:159-160)")
-        if not embed_feat:
-            raise L.MhimxError("DAttention (mhimx): embed_feat=False is not built")
+        self._no_embed = not embed_feat
+        if self._no_embed and input_dim != inner_dim:
+            raise L.MhimxError("DAttention(embed_feat=False): the bag rows are the tokens, input_dim must equal inner_dim")
         self.mil_norm, self.embed_norm_pos, self.pos = self._norm_cfg(mil_norm, "DAttention"), embed_norm_pos, pos
         if mil_bias:
             mil_cls_bias = True
@@ -222,8 +226,8 @@ class DAttention(_AttnMILBase):
         self.act = "gelu" if act.lower() == "gelu" else "relu"
         self.embed_drop = 0.25 if dropout else 0.0                          # abmil.py:190-191: a FIXED 0.25 when dropout is set
         self._ln_first = mil_norm == "ln" and embed_norm_pos == 0
-        layers = ([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + [_linear(input_dim, inner_dim, mil_bias), _Slot()] \
-            + ([_Slot()] if dropout else [])
+        layers = ([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + \
+            ([] if self._no_embed else [_linear(input_dim, inner_dim, mil_bias), _Slot()] + ([_Slot()] if dropout else []))
         if mil_norm == "ln":
             if embed_norm_pos == 1:
                 self.norm = _layernorm(inner_dim, mil_bias)
@@ -316,16 +320,19 @@ class TransMIL(_AttnMILBase):
     def __init__(self, input_dim, n_classes, dropout, act, mil_norm=None, mil_bias=True, inner_dim=512, embed_feat=True, pos="ppeg",
                  n_heads=8, **kwargs):
         super().__init__()
-        if not embed_feat or inner_dim != 512 or n_heads != 8:
-            raise L.MhimxError("TransMIL (mhimx): built for embed_feat=True, inner_dim=512, 8 heads")
+        if inner_dim != 512 or n_heads != 8:
+            raise L.MhimxError("TransMIL (mhimx): built for inner_dim=512, 8 heads")
+        self._no_embed = not embed_feat
+        if self._no_embed and input_dim != inner_dim:
+            raise L.MhimxError("TransMIL(embed_feat=False): the bag rows are the tokens, input_dim must equal inner_dim")
         self.mil_norm, self.pos = self._norm_cfg(mil_norm, "TransMIL"), pos
         self.act = "gelu" if act.lower() == "gelu" else ("relu" if act.lower() == "relu" else "none")
         self.embed_drop = 0.25 if dropout else 0.0
         self._ln_first = mil_norm == "ln"
         if mil_norm == "bn":
             self.norm1 = nn.BatchNorm1d(input_dim)                          # transmil.py:79-81
-        self.feature = nn.Sequential(*(([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + [_linear(input_dim, inner_dim, mil_bias)]
-                                       + ([_Slot()] if self.act != "none" else []) + ([_Slot()] if dropout else [])))
+        self.feature = nn.Sequential(*(([_layernorm(input_dim, mil_bias)] if self._ln_first else []) + ([] if self._no_embed else (
+            [_linear(input_dim, inner_dim, mil_bias)] + ([_Slot()] if self.act != "none" else []) + ([_Slot()] if dropout else [])))))
         self.cls_token = nn.Parameter(torch.randn(1, 1, inner_dim) * 1e-6)      # transmil.py:99-100
         self.layer1, self.layer2 = NY.TransLayer(inner_dim), NY.TransLayer(inner_dim)
         self.pos_layer = NY._PPEG(inner_dim) if pos != "none" else nn.Identity()
@@ -345,7 +352,7 @@ class TransMIL(_AttnMILBase):
         rows = None
         if add > 0:                                                      # x = cat([x, x[:add]]) as a gather index
             rows = torch.cat([torch.arange(n, device=x.device), torch.arange(add, device=x.device)])
-        if (self._ln_first or self.mil_norm == "bn") and rows is not None:
+        if (self._ln_first or self.mil_norm == "bn") and rows is not None and not self._no_embed:
             # a trainable norm in front of the embedding: normalise the n bag rows once (LayerNorm is row-wise; the BatchNorm above ran on
             # the bag already), append the wrapped rows as an autograd index (rows 0..add-1 get both gradients), embed without a gather
             xn = _ln(x, self.feature[0]) if self._ln_first else x

@@ -505,9 +505,15 @@ def g17_standalone_options(ns):
              ("gabmil_bn0", "gabmil", dict(act="gelu", dropout=0., mil_norm="bn", embed_norm_pos=0), 57, {}),
              ("gabmil_bn1", "gabmil", dict(act="relu", dropout=0., mil_norm="bn", embed_norm_pos=1), 58, {}),
              ("transmil_bn", "transmil", dict(dropout=False, act="gelu", mil_norm="bn"), 59, {}),
-             ("abmil_bn1_eval", "abmil", dict(dropout=0.0, act="gelu", mil_norm="bn", embed_norm_pos=1), 60, {}))
+             ("abmil_bn1_eval", "abmil", dict(dropout=0.0, act="gelu", mil_norm="bn", embed_norm_pos=1), 60, {}),
+             # embed_feat=False: the bag rows are the tokens (input_dim == inner_dim = 512)
+             ("abmil_noembed", "abmil", dict(dropout=0.0, act="gelu", embed_feat=False, mil_norm="ln", embed_norm_pos=0), 61, {"_d": 512}),
+             ("transmil_noembed", "transmil", dict(dropout=False, act="gelu", embed_feat=False), 62, {"_d": 512}))
     for name, kind, kw, pseed, fkw in cases:
         cls = {"abmil": ns.abmil.DAttention, "gabmil": ns.abmil.AttentionGated, "transmil": ns.transmil.TransMIL}[kind]
+        fkw = dict(fkw)
+        d = fkw.pop("_d", 64)
+        x = _x(35, n, d)
         m = _fill_module(cls(d, 2, **kw), pseed)
         with torch.no_grad():                                     # (filled from N(0, 0.05): keep the variances positive, the counter integral)
             for k_, v_ in m.state_dict().items():
