@@ -114,3 +114,24 @@ def test_streamed_attention_backward_with_peaked_scores():
     dw2 = ops.nys_out_bwd(o, w2, dout, lse1, dqkv, dlm)
     assert torch.isfinite(dqkv[:, :512]).all() and _rel(H(out), ref.detach()) < 1e-4
     assert _rel(H(dqkv[:, :512]), q.grad) < 2e-4 and _rel(H(dlm[:, 512:]), kl.grad) < 2e-4 and _rel(dw2, w.grad) < 2e-4
+
+
+@pytest.mark.parametrize("L_", [2048, 5003])
+def test_weight_gradient_pair_with_compact_dh_and_optional_dact(L_):
+    """mhimx_rows_dpre_image_c (dH compact, dact gathered by the row list) and the dact-less image of any dy, both through
+    mhimx_bag_wgrad: dW = (dH * dact[rows])^T X[rows]  /  dy^T x."""
+    g = torch.Generator(device=DEV).manual_seed(L_)
+    N, E, D = 7000, 512, 1024
+    x = torch.randn(N, D, device=DEV, generator=g)
+    rows = torch.randperm(N, device=DEV, generator=g)[:L_].sort().values
+    dH = torch.randn(L_, E, device=DEV, generator=g) * 0.1
+    dact = (torch.rand(N, E, device=DEV, generator=g) * 1.5).half()
+    dW, db = ops.bag_wgrad(dH, dact, x, rows, L_, dh_compact=True)
+    dpre = dH.double() * dact[rows].double()
+    assert _rel(dW, dpre.t() @ x[rows].double()) < 2e-5 and _rel(db, dpre.sum(0)) < 2e-5
+    dW2, _ = ops.bag_wgrad(dH, None, x, rows, L_, rows_dh=None, want_bias=False)      # no activation factor, dH compact, X gathered
+    assert _rel(dW2, dH.double().t() @ x[rows].double()) < 2e-5
+    y = torch.randn(L_, 1536, device=DEV, generator=g) * 0.1                           # a [L, 1536] gradient against [L, 512] rows (to_qkv)
+    xs = torch.randn(L_, 512, device=DEV, generator=g)
+    dW3, b3 = ops.bag_wgrad(y, None, xs, None, L_)
+    assert _rel(dW3, y.double().t() @ xs.double()) < 2e-5 and _rel(b3, y.double().sum(0)) < 2e-5
