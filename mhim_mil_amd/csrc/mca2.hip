@@ -17,7 +17,8 @@
 // i.e. no [R, 1024] gradient, no R-long weight-gradient GEMMs.  Exact algebra; only the fp32 summation order differs from the
 // reference's.  Launches: parameters (1), rows forward (1), finalize + O (1), to_out (1, mca.hip's mca_out_kernel);
 // backward: parameters x dz (1), rows backward incl. LayerNorm backward (1), two rank-k gradient launches.
-// Built for E = 512, 8 heads x 64, k <= 6 (J <= 48), R <= 8192; other shapes take mca.hip's general path.
+// Built for E = 512, 8 heads x 64, k <= 6 (J <= 48), R <= 32768 (the merge of the row-tile partials walks chunks of 256 tiles); other
+// shapes take mca.hip's general path.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,7 +33,7 @@ int64_t merge2_ws_bytes(int64_t R, int64_t k) {
 }
 
 bool merge2_ok(const mhimx_merge* m, int64_t R) {
-  return m->E == M2_E && m->heads == M2_H && m->dim_head == M2_DH && m->k >= 1 && m->heads * m->k <= M2_JP && R >= 1 && R <= 8192 &&
+  return m->E == M2_E && m->heads == M2_H && m->dim_head == M2_DH && m->k >= 1 && m->heads * m->k <= M2_JP && R >= 1 && R <= 32768 &&
          m->prec != MHIMX_PREC_F32 && aligned16(m->wq) && aligned16(m->wkv) && aligned16(m->wo) && aligned16(m->ln_w) && aligned16(m->ln_b) &&
          aligned16(m->q_param);
 }
@@ -558,7 +559,7 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
 // host side of prep job kind 6 (gemm_dma.hip): the kernel arguments of the parameter-only part for this Merge and workspace
 namespace mhimx {
 int merge2_prep_args(const mhimx_merge* m, int64_t R, void* ws, int64_t ws_bytes, Merge2PrepArgs* out) {
-  MHIMX_CHECK_ARG(m && merge2_ok(m, R), "prep_batch: the Merge preparation job needs the projection-free form (E = 512, 8 x 64, k <= 6, R <= 8192)");
+  MHIMX_CHECK_ARG(m && merge2_ok(m, R), "prep_batch: the Merge preparation job needs the projection-free form (E = 512, 8 x 64, k <= 6, R <= 32768)");
   Arena ar(ws, ws_bytes);
   Merge2Ws w;
   merge2_ws_layout(ar, R, m->k, &w);

@@ -23,48 +23,58 @@ constexpr int M2_PARTIALS_LDS = 256 + 8 + 128;
 template <bool SOFTMAX>
 MHIMX_DEV void merge2_partials_body(int block, float* lds, const float* __restrict__ part, const float* __restrict__ ln_w,
                                     const float* __restrict__ ln_b, float* __restrict__ out, const Merge2Ws& w) {
-  float* wt = lds;              // [256]
+  float* wt = lds;              // [256]: the weights of one chunk of 256 row tiles
   float* red = wt + 256;        // [8]
   float* half1 = red + 8;       // [128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = block >> 2, e = (block & 3) * 128 + (tid & 127), half = tid >> 7;
   const int T = w.T;
-  float sdl = 0.f;
+  float sdl = 0.f, M = 0.f, Lsum = 1.f;
   if (SOFTMAX) {
-    const float pm = tid < T ? w.pm[tid * M2_JP + j] : -INFINITY;
-    const float pl = tid < T ? w.pl[tid * M2_JP + j] : 0.f;
-    const float ps = tid < T ? w.psd[tid * M2_JP + j] : 0.f;
+    // statistics over ALL T tiles (T <= 256: one element per thread, as before; more tiles: a strided loop - R up to 32 768 rows)
+    float pm = -INFINITY;
+    for (int tt = tid; tt < T; tt += M2_THREADS) pm = fmaxf(pm, w.pm[tt * M2_JP + j]);
     float m = wave_max(pm);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float wgt = tid < T ? __expf(pm - M) : 0.f;
-    const float l = wave_sum(pl * wgt), sd = wave_sum(ps * wgt);
-    if (lane == 0) { red[4 + wave] = l; wt[252 + wave] = sd; }      // (wt[252..255] are beyond any tile: T <= 256 uses wt[0..T-1])
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float pls = 0.f, pss = 0.f;
+    for (int tt = tid; tt < T; tt += M2_THREADS) {
+      const float wgt = __expf(w.pm[tt * M2_JP + j] - M);
+      pls += w.pl[tt * M2_JP + j] * wgt;
+      pss += w.psd[tt * M2_JP + j] * wgt;
+    }
+    const float l = wave_sum(pls), sd = wave_sum(pss);
+    if (lane == 0) { red[4 + wave] = l; half1[wave] = sd; }
     __syncthreads();
     const float L = (red[4] + red[5]) + (red[6] + red[7]);
-    const float SD = (wt[252] + wt[253]) + (wt[254] + wt[255]);
-    __syncthreads();
-    wt[tid] = wgt / L;
+    const float SD = (half1[0] + half1[1]) + (half1[2] + half1[3]);
+    Lsum = L;
     sdl = SD / L;
     if ((block & 3) == 0 && tid == 0) { w.stats[2 * j] = M; w.stats[2 * j + 1] = L; }
-  } else {
-    wt[tid] = tid < T ? 1.f : 0.f;
   }
-  __syncthreads();
   float acc = 0.f;
   const float* pj = part + (int64_t)j * M2_E + e;
 #pragma unroll 1
-  for (int t0 = 0; t0 < T; t0 += 32) {
-    float v[16];
+  for (int c0 = 0; c0 < T; c0 += 256) {                     // chunks of 256 tiles: their weights in LDS
+    __syncthreads();                                        // (the statistics scratch / the previous chunk's weights have been read)
+    const int tt = c0 + tid;
+    wt[tid] = tt < T ? (SOFTMAX ? __expf(w.pm[tt * M2_JP + j] - M) / Lsum : 1.f) : 0.f;
+    __syncthreads();
+    const int Tc = T - c0 < 256 ? T - c0 : 256;
+#pragma unroll 1
+    for (int t0 = 0; t0 < Tc; t0 += 32) {
+      float v[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int t = t0 + half * 16 + q;
-      v[q] = t < T ? pj[(int64_t)t * M2_JP * M2_E] : 0.f;
+      for (int q = 0; q < 16; ++q) {
+        const int t = t0 + half * 16 + q;
+        v[q] = t < Tc ? pj[(int64_t)(c0 + t) * M2_JP * M2_E] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += v[q] * wt[(t0 + half * 16 + q) & 255];
     }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc += v[q] * wt[(t0 + half * 16 + q) & 255];
   }
+  __syncthreads();
   if (half == 1) half1[tid & 127] = acc;
   __syncthreads();
   if (half == 0) {

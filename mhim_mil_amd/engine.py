@@ -344,7 +344,7 @@ class FusedTrainer:
             s.merge_enable = False
         try:
             R_merge = s.v2_counts(ps, i)[4] if mhim else 0
-            lean = mhim and s.merge.k * 8 <= 48 and 1 <= R_merge <= 8192 and s._op_prec != "f32"
+            lean = mhim and s.merge.k * 8 <= 48 and 1 <= R_merge <= 32768 and s._op_prec != "f32"
             js, prep_s = s.prep_jobs(backward=True, lean_merge=lean)
             if lean:
                 # the parameter-only part of the student's Merge (LayerNorm of the queries, their projection, the score vectors) rides

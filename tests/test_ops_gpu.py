@@ -333,6 +333,12 @@ def test_merge_fwd_bwd(prec, R, k):
     _merge_fwd_bwd(prec, R, k, False)
 
 
+@pytest.mark.parametrize("R", [8200, 19400, 32768])
+def test_merge_fwd_bwd_many_rows(R):
+    """The projection-free Merge beyond 256 row tiles (the c5 bag merges ~19 400 rows): the tile partials are merged in chunks of 256."""
+    _merge_fwd_bwd("bf16x3", R, 5, False)
+
+
 @pytest.mark.parametrize("R,k", [(970, 5), (33, 3), (2000, 16)])
 def test_merge_fwd_bwd_tile_kernel(R, k):
     """The same comparison with the prep-time fragment image of Wkv: the forward takes the one-kernel-per-row-tile form
