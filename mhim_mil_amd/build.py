@@ -21,6 +21,16 @@ LIB = os.path.join(HERE, "libmhimx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("MHIMX_EXTRA_FLAGS", "").split()          # experiments only (e.g. -DMHIMX_DBG_NOCOMPUTE)
+# The SLP vectorizer pairs scalar fp32 FMAs into v_pk_fma_f32 and, where the two lanes want the ODD register of a pair, sets op_sel
+# to swizzle it into the low half.  That form dropped its term in lanes 48..63 about once per 500 launches of merge2_grads1 when a second
+# process shared the GPU (tools/exp_merge_forensic.py, DESIGN section 5: 38 events in 30 000 passes, 0 in 60 000 without it), so every
+# file is built without SLP except the ones listed here, whose code has no such instruction and whose softmax VALU work profits from the
+# packed forms (c3: 2 %).  tests/test_isa_lint_cpu.py disassembles the library and fails on any op_sel-swizzled packed fp32 instruction.
+SLP_OK = {"nys_flash.hip", "nys_flash_tok.hip"}
+
+
+def flags_for(src):
+    return FLAGS if os.path.basename(src) in SLP_OK or "-fno-slp-vectorize" in FLAGS else FLAGS + ["-fno-slp-vectorize"]
 if os.environ.get("MHIMX_LIB_NAME"):
     LIB = os.path.join(HERE, os.environ["MHIMX_LIB_NAME"])
     OBJ = os.path.join(HERE, "build_" + os.environ["MHIMX_LIB_NAME"].replace(".", "_"))
@@ -50,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def cc(job):
         src, obj = job
         t0 = time.time()
-        r = subprocess.run([HIPCC, *FLAGS, "-c", src, "-o", obj], capture_output=True, text=True)
+        r = subprocess.run([HIPCC, *flags_for(src), "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         if verbose:

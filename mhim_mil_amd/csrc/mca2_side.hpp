@@ -161,6 +161,8 @@ MHIMX_DEV void merge2_grads1_body(int block, float* lds, const Merge2Side& a) {
     const float q6[6] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1]}, o6[6] = {c1[2], c1[3], c2[0], c2[1], c2[2], c2[3]};
     float sk0 = 0.f, sk1 = 0.f, sv0 = 0.f, sv1 = 0.f;
 #pragma unroll
+    // (scalar FMAs: this file is built with -fno-slp-vectorize - build.py; the packed form the SLP vectorizer made of the (sv0, sv1) pair
+    // lost the i = 3 term in lanes 48..63 about once per 500 launches when a second process shared the GPU)
     for (int i = 0; i < 6; ++i) { sk0 += q6[i] * u0[i]; sk1 += q6[i] * u1[i]; sv0 += o6[i] * y0[i]; sv1 += o6[i] * y1[i]; }
     float* ok = d_wkv + (int64_t)(h * 64 + qr * 16 + dl) * M2_E + tid;
     float* ov = d_wkv + (int64_t)(M2_I + h * 64 + qr * 16 + dl) * M2_E + tid;
