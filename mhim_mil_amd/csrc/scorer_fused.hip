@@ -52,6 +52,7 @@ MHIMX_DEV float sf_sum32(float v) {
   return v;
 }
 
+template <bool FRAG>
 __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     const float* __restrict__ T, int64_t M, const float* __restrict__ wa, const float* __restrict__ wa_frag,
     const float* __restrict__ ba, int act,
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
   const float bn = ba ? ba[n_col] : 0.f, wn = wc[n_col];
   const float* bptr = wa + (int64_t)n_col * SF_E + 8 * kg;
   const float* fptr = wa_frag ? wa_frag + ((int64_t)wave * (SF_E / 16) * 64 + lane) * 8 : nullptr;   // + ks * 512 floats
+  // (the same address as a uniform base + a 32-bit lane offset: the k-step term stays in scalar registers, one VGPR for all 32 k-steps)
+  const unsigned foff = ((unsigned)wave * (SF_E / 16) * 64 + (unsigned)lane) * 8;
   const float* aptr = Hs + r32 * SF_LD + 8 * kg;
   if (wp)
     for (int i = tid; i < C * SF_E / 4; i += SF_THREADS) reinterpret_cast<sf_f4*>(wps)[i] = reinterpret_cast<const sf_f4*>(wp)[i];
@@ -81,6 +84,90 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t row0 = (int64_t)tile * SF_ROWS;
     SF_STAMP(0);
+    sf_f32x16 acc, acc2, acc3;                  // one accumulator per bf16x3 term: an MFMA into the accumulator of the previous one waits out its latency
+    if constexpr (FRAG) {
+    // ---- 1 + 2. rows -> LDS in four 128-column chunks, the U product of chunk c on the matrix cores while chunks c+1, c+2 are on their way.
+    // Before, the whole tile was loaded (an HBM burst of every workgroup of the launch at once, ~5.5 us), THEN multiplied (~6.5 us, of which
+    // the MFMAs are 1.3: the k loop's back-edge made the compiler drain the fragment prefetch every fourth k-step).  Here every load is
+    // inline asm with hand-counted waits (vector loads return in order): straight-line code, the weight fragments (prep kind 4: two
+    // coalesced 16-byte loads per k-step) stay FOUR k-steps ahead, tile chunk c+2 is requested when chunk c starts.  (The k-step term of a
+    // fragment address goes into the VGPR offset and the base stays ONE scalar pair; 32 scalar pointers get spilled to VGPR lanes, and a
+    // v_readlane right in front of an asm VMEM instruction that uses the SGPR is a hazard the compiler cannot see: hence also the s_nop.)
+    // Load j of a thread: columns [128 (j >> 2) + 32 (j & 3), + 32) of row tid >> 3 (8 lanes x 16 B = one 128-byte line per row).
+    if (rows) {
+      if (tid < SF_ROWS) { const int64_t n = row0 + tid; ridx[tid] = rows[n < M ? n : M - 1]; }
+      __syncthreads();
+    }
+    const int lr = tid >> 3, ls = tid & 7;
+    const int64_t ln = row0 + lr;
+    const float* lsrc = T + (rows ? ridx[lr] : (ln < M ? ln : M - 1)) * SF_E + 4 * ls;      // (clamped row: every load is issued)
+    float* ldst = Hs + lr * SF_LD + 4 * ls;
+    const unsigned fo = foff * 4;                                                           // byte offset of this lane in a fragment block
+    sf_f4 av[16], bh_[4], bl_[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
+#define SF_LOAD_A(c)                                                                                                                          \
+    asm volatile("global_load_dwordx4 %0, %4, off offset:%5\n\tglobal_load_dwordx4 %1, %4, off offset:%6\n\t"                                  \
+                 "global_load_dwordx4 %2, %4, off offset:%7\n\tglobal_load_dwordx4 %3, %4, off offset:%8"                                      \
+                 : "=&v"(av[4 * (c)]), "=&v"(av[4 * (c) + 1]), "=&v"(av[4 * (c) + 2]), "=&v"(av[4 * (c) + 3])                                  \
+                 : "v"(lsrc), "i"(512 * (c)), "i"(512 * (c) + 128), "i"(512 * (c) + 256), "i"(512 * (c) + 384) : "memory")
+#define SF_LOAD_B(ks)                                                                                                                         \
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"                                      \
+                 : "=&v"(bh_[(ks) & 3]), "=&v"(bl_[(ks) & 3]) : "v"(fo + 2048u * (ks)), "s"(wa_frag) : "memory")
+#define SF_WAIT_B(n, ks) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(bh_[(ks) & 3]), "+v"(bl_[(ks) & 3]) : : "memory")
+#define SF_WAIT_A(n, c)                                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(av[4 * (c)]), "+v"(av[4 * (c) + 1]), "+v"(av[4 * (c) + 2]), "+v"(av[4 * (c) + 3]) : : "memory")
+    // one k-step: wait until its fragments are in (n = loads issued after them), copy them out of the ring, refill the slot, multiply
+#define SF_KSTEP(ks, n, refill)                                                                                                               \
+    {                                                                                                                                        \
+      SF_WAIT_B(n, ks);                                                                                                                      \
+      const sf_b8 bh = __builtin_bit_cast(sf_b8, bh_[(ks) & 3]), bl = __builtin_bit_cast(sf_b8, bl_[(ks) & 3]);                             \
+      if (refill) SF_LOAD_B((ks) + 4 < SF_E / 16 ? (ks) + 4 : (ks));                                                                         \
+      const sf_f4 a0 = *reinterpret_cast<const sf_f4*>(aptr + 16 * (ks)), a1 = *reinterpret_cast<const sf_f4*>(aptr + 16 * (ks) + 4);       \
+      sf_b8 ah, al;                                                                                                                          \
+      sf_split(a0, a1, ah, al);                                                                                                              \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);                                                                 \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);                                                                   \
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc3, 0, 0, 0);                                                                 \
+    }
+#define SF_STORE_A(c)                                                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                                            \
+        *reinterpret_cast<sf_f4*>(ldst + 128 * (c) + 32 * q) = ln < M ? av[4 * (c) + q] : sf_f4{0.f, 0.f, 0.f, 0.f};
+    // issue order: A0 A1 B0..B3 | chunk 0: A2, B4..B11 | chunk 1: A3, B12..B19 | chunk 2: B20..B27 | chunk 3: B28..B31
+    SF_LOAD_A(0);
+    SF_LOAD_A(1);
+    SF_LOAD_B(0); SF_LOAD_B(1); SF_LOAD_B(2); SF_LOAD_B(3);
+    SF_WAIT_A(12, 0);                            // behind chunk 0: A1 (4) + B0..B3 (8)
+    SF_STORE_A(0);
+    __syncthreads();
+    SF_STAMP(1);
+    SF_LOAD_A(2);
+    // k-steps 0..3: behind B(ks) are B(ks+1..3) + A2 (4) + the refills B(4..ks+3) = 6 + 4; k-steps 4..7: the three younger fragment pairs
+    SF_KSTEP(0, 10, true) SF_KSTEP(1, 10, true) SF_KSTEP(2, 10, true) SF_KSTEP(3, 10, true)
+    SF_KSTEP(4, 6, true) SF_KSTEP(5, 6, true) SF_KSTEP(6, 6, true) SF_KSTEP(7, 6, true)
+    SF_WAIT_A(8, 1);                             // (A1 is older than fragments already waited for; 8 = the four pairs in flight)
+    SF_STORE_A(1);
+    __syncthreads();
+    SF_LOAD_A(3);
+    SF_KSTEP(8, 10, true) SF_KSTEP(9, 10, true) SF_KSTEP(10, 10, true) SF_KSTEP(11, 10, true)
+    SF_KSTEP(12, 6, true) SF_KSTEP(13, 6, true) SF_KSTEP(14, 6, true) SF_KSTEP(15, 6, true)
+    SF_WAIT_A(8, 2);
+    SF_STORE_A(2);
+    __syncthreads();
+    SF_KSTEP(16, 6, true) SF_KSTEP(17, 6, true) SF_KSTEP(18, 6, true) SF_KSTEP(19, 6, true)
+    SF_KSTEP(20, 6, true) SF_KSTEP(21, 6, true) SF_KSTEP(22, 6, true) SF_KSTEP(23, 6, true)
+    SF_WAIT_A(8, 3);
+    SF_STORE_A(3);
+    __syncthreads();
+    SF_KSTEP(24, 6, true) SF_KSTEP(25, 6, true) SF_KSTEP(26, 6, true) SF_KSTEP(27, 6, true)
+    SF_KSTEP(28, 6, false) SF_KSTEP(29, 4, false) SF_KSTEP(30, 2, false) SF_KSTEP(31, 0, false)
+#undef SF_LOAD_A
+#undef SF_LOAD_B
+#undef SF_WAIT_A
+#undef SF_WAIT_B
+#undef SF_KSTEP
+#undef SF_STORE_A
+    } else {
     // ---- 1. rows -> LDS (gathered form: the tile's 32 row indices first, ONE coalesced load instead of 16 dependent ones per thread)
     if (rows) {
       if (tid < SF_ROWS) { const int64_t n = row0 + tid; ridx[tid] = rows[n < M ? n : M - 1]; }
@@ -99,32 +186,9 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     SF_STAMP(1);
     // ---- 2. U tile on the matrix cores
     // one accumulator per bf16x3 term: an MFMA into the accumulator of the previous one waits out its full latency
-    sf_f32x16 acc, acc2, acc3;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
-    if (fptr) {
-      // B fragments ready-made (prep kind 4): two coalesced 16-byte loads per k-step, four k-steps ahead
-      constexpr int PF = 4;
-      sf_f4 bh_[PF], bl_[PF];
-#pragma unroll
-      for (int q = 0; q < PF; ++q) {
-        bh_[q] = *reinterpret_cast<const sf_f4*>(fptr + 512 * q);
-        bl_[q] = *reinterpret_cast<const sf_f4*>(fptr + 512 * q + 4);
-      }
-#pragma unroll 4
-      for (int ks = 0; ks < SF_E / 16; ++ks) {
-        const sf_f4 a0 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks), a1 = *reinterpret_cast<const sf_f4*>(aptr + 16 * ks + 4);
-        sf_b8 ah, al;
-        sf_split(a0, a1, ah, al);
-        const sf_b8 bh = __builtin_bit_cast(sf_b8, bh_[ks % PF]), bl = __builtin_bit_cast(sf_b8, bl_[ks % PF]);
-        const int kn = ks + PF < SF_E / 16 ? ks + PF : ks;
-        bh_[ks % PF] = *reinterpret_cast<const sf_f4*>(fptr + 512 * kn);
-        bl_[ks % PF] = *reinterpret_cast<const sf_f4*>(fptr + 512 * kn + 4);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc3, 0, 0, 0);
-      }
-    } else {
+    {
       sf_f4 b0 = *reinterpret_cast<const sf_f4*>(bptr), b1 = *reinterpret_cast<const sf_f4*>(bptr + 4);
 #pragma unroll 4
       for (int ks = 0; ks < SF_E / 16; ++ks) {
@@ -140,6 +204,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
         b0 = nb0;
         b1 = nb1;
       }
+    }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i] + acc3[i];
@@ -270,6 +335,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
       __syncthreads();
     }
     // ---- 1. row dots T_n . g_z: 8 lanes per row, lane `seg` takes the 16-byte groups seg, seg+8, ...
+    float up[SF_ROWS / 2];
     {
       const int r = tid >> 3, seg = tid & 7;
       const int64_t n = row0 + r;
@@ -279,6 +345,12 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
       sf_f4 tv[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) tv[q] = tr[8 * q];
+      // the scorer pre-activations of step 2, requested now: their latency passes under the row dots
+#pragma unroll
+      for (int k = 0; k < SF_ROWS / 2; ++k) {
+        const int64_t nu = row0 + half + 2 * k;
+        up[k] = u_pre[(nu < M ? nu : M - 1) * SF_A + a_col];
+      }
       float d = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -296,13 +368,13 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     }
     __syncthreads();
     // ---- 2. du tile (global + LDS), d_wc / d_bc partials
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < SF_ROWS / 2; ++k) {
       const int r = half + 2 * k;
       const int64_t n = row0 + r;
       float d = 0.f;
       if (n < M) {
-        const float u = u_pre[n * SF_A + a_col];
+        const float u = up[k];
         float ya, ga;
         act_fwd_grad(u, act, ya, ga);
         const float ds = gs_s[r];
@@ -406,11 +478,16 @@ bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, 
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
                      float* pz, int max_parts, const int64_t* rows, const uint8_t* excl) {
-    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
-  hipLaunchKernelGGL(scorer_fused_kernel, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
-                     cproj, pm, pl, pz, tiles, rows, excl);
+  if (wa_frag)
+    hipLaunchKernelGGL(scorer_fused_kernel<true>, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
+                       cproj, pm, pl, pz, tiles, rows, excl);
+  else
+    hipLaunchKernelGGL(scorer_fused_kernel<false>, dim3(grid), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
+                       cproj, pm, pl, pz, tiles, rows, excl);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }
