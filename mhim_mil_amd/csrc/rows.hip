@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void score_rows_fwd_kernel(
 }
 
 // merge G partials: stats = {max, sumexp}, z[e] = sum_b pz[b][e] e^{pm[b]-max} / sumexp.
-// grid = E/64 blocks of 1024 threads (64 columns x 16 partial groups); every block re-derives the G weights.
+// grid = E/64 blocks of 1024 threads (64 columns x 16 partial groups) + the blocks of the pseudo score; every block re-derives the G weights.
 constexpr int FIN_THREADS = 1024;
 __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                                      const float* __restrict__ pz, int G, int E,
@@ -133,9 +133,10 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
   __shared__ float wgt[2 * MAX_PART];
   __shared__ float acc16[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float m = -INFINITY;
-  for (int b = threadIdx.x; b < G; b += FIN_THREADS) m = fmaxf(m, pm[b]);
-  m = wave_max(m);
+  // (G <= 2 MAX_PART = FIN_THREADS: one partial per thread, its max and its sum requested together)
+  const int b1 = threadIdx.x;
+  const float pm1 = b1 < G ? pm[b1] : -INFINITY, pl1 = b1 < G ? pl[b1] : 0.f;
+  float m = wave_max(pm1);
   if (lane == 0) red[wave] = m;
   __syncthreads();
   float mx = red[0];
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
   for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
   __syncthreads();
   float lp = 0.f;
-  for (int b = threadIdx.x; b < G; b += FIN_THREADS) {
-    const float w = (pm[b] == -INFINITY) ? 0.f : __expf(pm[b] - mx);
-    wgt[b] = w;
-    lp += pl[b] * w;
+  if (b1 < G) {
+    const float w = (pm1 == -INFINITY) ? 0.f : __expf(pm1 - mx);
+    wgt[b1] = w;
+    lp = pl1 * w;
   }
   lp = wave_sum(lp);
   if (lane == 0) red[wave] = lp;
@@ -154,6 +155,20 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
   float L = 0.f;
 #pragma unroll
   for (int w = 0; w < 16; ++w) L += red[w];                   // fixed order: deterministic
+  const int zblocks = (E + 63) / 64;
+  if ((int)blockIdx.x >= zblocks) {            // the extra blocks of the launch: the pseudo score of the instances (pseudo_score_kernel's arithmetic)
+    const float invL = 1.f / L, b0 = bp ? bp[0] : 0.f;
+    const int nb = (int)gridDim.x - zblocks;
+    for (int64_t n = (int64_t)((int)blockIdx.x - zblocks) * FIN_THREADS + threadIdx.x; n < M1; n += (int64_t)nb * FIN_THREADS) {
+      const float an = __expf(s[n] - mx) * invL;
+      float cm = -INFINITY;
+      for (int c = 0; c < C; ++c) cm = fmaxf(cm, an * cproj[n * C + c] + b0);
+      float den = 0.f;
+      for (int c = 0; c < C; ++c) den += expf((an * cproj[n * C + c] + b0) - cm);
+      pscore[n] = 1.f / den;
+    }
+    return;
+  }
   const int e = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (e < E) {
@@ -169,17 +184,6 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
     z[e] = a / L;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = mx; stats[1] = L; }
-  if (pscore) {                                // the pseudo score of the instances rides along (pseudo_score_kernel's arithmetic)
-    const float invL = 1.f / L, b0 = bp ? bp[0] : 0.f;
-    for (int64_t n = (int64_t)blockIdx.x * FIN_THREADS + threadIdx.x; n < M1; n += (int64_t)gridDim.x * FIN_THREADS) {
-      const float an = __expf(s[n] - mx) * invL;
-      float cm = -INFINITY;
-      for (int c = 0; c < C; ++c) cm = fmaxf(cm, an * cproj[n * C + c] + b0);
-      float den = 0.f;
-      for (int c = 0; c < C; ++c) den += expf((an * cproj[n * C + c] + b0) - cm);
-      pscore[n] = 1.f / den;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
     const int j = j0 + c;
     float acc = 0.f;
     if (j < W) {
-#pragma unroll 4
+#pragma unroll 8
       for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * ld + j];
     }
     red[rg][c] = acc;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj)
       const int64_t j = j0 + c;
       float acc = 0.f;
       if (j < J.W) {
-#pragma unroll 4
+#pragma unroll 8
         for (int64_t b = rg; b < J.G; b += 32) acc += J.parts[b * J.ld + j];
       }
       red[rg][c] = acc;
@@ -330,6 +334,13 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj)
     for (int64_t idx = (int64_t)blk * RP_THREADS + threadIdx.x; idx < n; idx += (int64_t)nblk * RP_THREADS) {
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int64_t z = 0;
+      for (; z + 8 <= J.G; z += 8) {                   // (eight slabs in flight; the same sums in the same order as four at a time)
+        const float p0 = J.parts[(z + 0) * n + idx], p1 = J.parts[(z + 1) * n + idx], p2 = J.parts[(z + 2) * n + idx],
+                    p3 = J.parts[(z + 3) * n + idx], p4 = J.parts[(z + 4) * n + idx], p5 = J.parts[(z + 5) * n + idx],
+                    p6 = J.parts[(z + 6) * n + idx], p7 = J.parts[(z + 7) * n + idx];
+        s0 += p0; s1 += p1; s2 += p2; s3 += p3;
+        s0 += p4; s1 += p5; s2 += p6; s3 += p7;
+      }
       for (; z + 4 <= J.G; z += 4) {
         s0 += J.parts[(z + 0) * n + idx];
         s1 += J.parts[(z + 1) * n + idx];
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts2_kernel(const float* 
     const int j = j0 + c;
     float acc = 0.f;
     if (j < W) {
-#pragma unroll 4
+#pragma unroll 8
       for (int b = rg; b < G; b += 32) acc += part[(int64_t)b * ld + j];
     }
     red[rg][c] = acc;
@@ -869,8 +880,11 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     off += Ms[seg];
   }
   MHIMX_CHECK_ARG(!io->pscore || io->cproj, "pool_fwd: pscore needs cproj (and wp)");
-  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats, io->z,
-                     io->s, io->cproj, io->bp, (int)io->C, io->M1, io->pscore);
+  static_assert(2 * MAX_PART <= FIN_THREADS, "pool_finalize_kernel reads one partial per thread");
+  // the pseudo score of the instances (if asked for) on blocks of its own, beside the E/64 blocks that merge the pooled row
+  const int64_t ps_blocks = io->pscore ? (cdiv(io->M1, FIN_THREADS) < 64 ? cdiv(io->M1, FIN_THREADS) : 64) : 0;
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)(cdiv(E, 64) + ps_blocks)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats,
+                     io->z, io->s, io->cproj, io->bp, (int)io->C, io->M1, io->pscore);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
