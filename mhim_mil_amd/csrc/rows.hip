@@ -300,16 +300,19 @@ int reduce_parts_now(hipStream_t st, const float* part, int64_t G, int64_t W, in
 // Same arithmetic as reduce_parts_kernel (kind 0) and reduce_slabs_kernel (kind 1): queued or not, the bits are the same.
 struct ReduceJobs { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int first[MHIMX_REDUCE_MAX + 1]; int n; int side_blocks; Merge2Side side; };
 __global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj) {
-  if ((int)blockIdx.x >= rj.first[rj.n]) {      // the last stage of a parked Merge-backward tail rides along (256 of the 1024 threads)
+  // the last stage of a parked Merge-backward tail rides along (256 of the 1024 threads).  Its workgroups come FIRST: they are a ~9 us
+  // latency chain, and behind 600 reduction workgroups (two resident per CU) they started a round late (reduce 11 us alone, 16 with them last)
+  if ((int)blockIdx.x < rj.side_blocks) {
     __shared__ __attribute__((aligned(16))) float side_lds[M2_GRADS2_LDS];
-    if (threadIdx.x < M2_THREADS) merge2_side_stage(3, (int)blockIdx.x - rj.first[rj.n], side_lds, rj.side);
+    if (threadIdx.x < M2_THREADS) merge2_side_stage(3, (int)blockIdx.x, side_lds, rj.side);
     return;
   }
   __shared__ float red[32][33];
+  const int bx = (int)blockIdx.x - rj.side_blocks;
   int jb = 0;
-  while (jb + 1 < rj.n && (int)blockIdx.x >= rj.first[jb + 1]) ++jb;
+  while (jb + 1 < rj.n && bx >= rj.first[jb + 1]) ++jb;
   const mhimx_reduce_job J = rj.j[jb];
-  const int blk = (int)blockIdx.x - rj.first[jb], nblk = rj.first[jb + 1] - rj.first[jb];
+  const int blk = bx - rj.first[jb], nblk = rj.first[jb + 1] - rj.first[jb];
   if (J.kind == 0) {
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     for (int64_t j0 = (int64_t)blk * 32; j0 < J.W; j0 += (int64_t)nblk * 32) {
