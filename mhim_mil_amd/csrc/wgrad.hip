@@ -439,7 +439,12 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
     }
     if (t < nk) body(t, s1, s2);
     if (t + 1 < nk) body(t + 1, s2, s0);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0.v[0]), "+v"(s0.v[7]), "+v"(s1.v[0]), "+v"(s1.v[7]), "+v"(s2.v[0]), "+v"(s2.v[7]) : : "memory");
+    // EVERY register of the three sets is named: the loads of the last (clamped, unused) prefetches are still in flight here, and a register the
+    // compiler believes dead is handed out again while its load has not landed - the in-flight data then overwrote the row offsets of the
+    // next asm loads (GPU memory access fault when a second process stretched the latency; tools/asm_lint.py)
+#define WS_ALL(s) "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]), "+v"(s.v[6]), "+v"(s.v[7])
+    asm volatile("s_waitcnt vmcnt(0)" : WS_ALL(s0), WS_ALL(s1), WS_ALL(s2) : : "memory");
+#undef WS_ALL
     return;
   }
 
@@ -664,11 +669,13 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   }
   const int64_t tiles = (a->E / WBI) * (a->D / WBN);
   dim3 grid((unsigned)(8 * tiles * cdiv(g.splits, 8) + side_blocks));
-  // The specialised-wave form (bag_wgrad_ws_kernel, ~5 % faster) is OPT-IN: with two processes time-slicing one GPU it ended in a GPU
-  // memory access fault on the long TransMIL-shaped launches (E = 1536 / D = 512, ~270 us each; tools/two_proc_c3.sh: 3 of 6 runs died,
-  // 0 of 12 with the uniform form; the c2 / c5 shapes never faulted) - not understood (every address is bounded on paper; suspect:
-  // wave save / restore around its producer-only DMA waves), so the uniform form is the default.
-  static const bool ws_form = getenv("MHIMX_WGRAD_WS") != nullptr;
+  // The specialised-wave form (bag_wgrad_ws_kernel, ~5 % faster) is the default again.  It was opt-in for a while: with two processes
+  // time-slicing one GPU it ended in a GPU memory access fault on the long TransMIL-shaped launches (tools/two_proc_c3.sh: 3 of 6 runs
+  // died).  Cause: its last asm wait named 6 of the 24 prefetch registers, so the compiler handed the other 18 out again while the
+  // (unused, clamped) last prefetch loads were still in flight, and their data landed on the row offsets of the next asm loads - only
+  // when latency was stretched.  Fixed there, checked by tools/asm_lint.py (tests/test_isa_lint_cpu.py); 12 of 12 two-process runs
+  // finish.  MHIMX_WGRAD_UNIFORM=1 selects the uniform kernel (experiments).
+  static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;
   if (ws_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));

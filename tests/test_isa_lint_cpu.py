@@ -41,3 +41,40 @@ def test_no_swizzled_packed_fp32_instruction(tmp_path):
                     bad.append(f"{kernel}: {line.strip()[:120]}")
     assert packed > 0, "the disassembly shows no packed fp32 instruction at all: the lint is not looking at the device code"
     assert not bad, "op_sel-swizzled packed fp32 instructions (build the file without SLP, mhim_mil_amd/build.py):\n" + "\n".join(bad[:20])
+
+
+ASM_LOAD_SOURCES = ("bag_project.hip", "wgrad.hip", "scorer_fused.hip")      # the files with inline-asm vector loads
+
+
+def test_asm_loads_keep_their_registers(tmp_path):
+    """tools/asm_lint.py on the assembly of every source with inline-asm vector loads: no instruction may read or overwrite the
+    destination of such a load before the wait that covers it (the compiler does not know the data is still in flight).  This is how
+    bag_wgrad_ws_kernel faulted under GPU sharing: its last wait named 6 of the 24 prefetch registers."""
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    from mhim_mil_amd import build
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import asm_lint
+    if not os.path.exists(build.HIPCC):
+        pytest.skip("hipcc not installed")
+    srcs = [s for s in build.sources() if os.path.basename(s) in ASM_LOAD_SOURCES]
+    assert len(srcs) == len(ASM_LOAD_SOURCES)
+    # (every inline-asm vector load of the library lives in these files)
+    for s in build.sources():
+        if os.path.basename(s) not in ASM_LOAD_SOURCES:
+            assert "global_load_dword" not in open(s).read(), f"{s}: inline-asm vector loads - add the file to ASM_LOAD_SOURCES"
+
+    def cc(src):
+        out = tmp_path / (os.path.basename(src)[:-4] + ".s")
+        flags = [f for f in build.flags_for(src) if f != "-fPIC"]
+        r = subprocess.run([build.HIPCC, *flags, "--cuda-device-only", "-S", src, "-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return str(out)
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        outs = list(ex.map(cc, srcs))
+    for o in outs:
+        text = open(o).read()
+        assert ";;#ASMSTART" in text, f"{o}: no inline asm found - the lint is not looking at the right thing"
+        bad = asm_lint.lint(o)
+        assert not bad, f"{o}: registers of in-flight asm loads are touched:\n" + "\n".join(f"{b[0]} line {b[1]} (load at {b[2]}): {b[3]}" for b in bad[:10])
