@@ -67,7 +67,13 @@ inline mhimx_reduce_job reduce_job_parts(const float* parts, int64_t G, int64_t 
   j.kind = 0; j.accumulate = accumulate; j.parts = parts; j.out = out; j.G = G; j.W = W; j.ld = ld;
   return j;
 }
+// A TALL set of slabs (>= 32 of them) with a contiguous output is summed as partial rows - 32 slabs at a time per column, the row-group form
+// of reduce_parts_kernel - instead of one serial chain per element (thin_tn's 256 row chunks: 64 dependent rounds, 21 us for 1 024 sums).
+// The rule lives HERE and in reduce_slabs_now, so that a sum has the same bits queued or not.
+// (small outputs only: with 65 536 sums - the scorer's weight gradient, 64 slabs - the element-parallel form has enough threads and is faster)
+inline bool reduce_slabs_as_parts(int64_t splits, int64_t K1, int64_t K2, int64_t ldo) { return splits >= 32 && ldo == K2 && K1 * K2 <= 16384; }
 inline mhimx_reduce_job reduce_job_slabs(const float* ws, int64_t splits, int64_t K1, int64_t K2, int64_t ldo, float* out, int accumulate) {
+  if (reduce_slabs_as_parts(splits, K1, K2, ldo)) return reduce_job_parts(ws, splits, K1 * K2, K1 * K2, out, accumulate);
   mhimx_reduce_job j = {};
   j.kind = 1; j.accumulate = accumulate; j.parts = ws; j.out = out; j.G = splits; j.K1 = K1; j.K2 = K2; j.ldo = ldo;
   return j;

@@ -501,6 +501,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 int reduce_slabs_now(hipStream_t st, const float* ws, float* C, int64_t K1, int64_t K2, int64_t ldc, int splits, int accumulate, int batch,
                      int64_t sC) {
   const int64_t n = K1 * K2;
+  if (batch == 1 && reduce_slabs_as_parts(splits, K1, K2, ldc)) return reduce_parts_now(st, ws, splits, n, n, C, accumulate);
   const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, ws, C, K1, K2, ldc, splits, accumulate, sC);
   MHIMX_LAUNCH_CHECK();
