@@ -13,6 +13,7 @@ per-head matrix is (pointer offset, row pitch), never a permuted copy.
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 import math
 
@@ -112,7 +113,7 @@ def _heads_mm(mode, A: Op, Bo: Op, Co: Op, heads, accumulate=False):
         tiles = heads * ((M + 127) // 128) * ((N + 127) // 128)
         splits = max(1, min((1024 + tiles - 1) // tiles, K // 256, 65535 // heads))
         if mode == "tn" and M <= 16 and heads == 1:          # thin left operand: a streaming kernel, one short row chunk per workgroup
-            splits = max(1, min(256, K // 32))
+            splits = max(1, min(512, K // 16))               # (~20 rows per thread; the slabs are summed 32 at a time per column)
         if splits > 1:
             ws = torch.empty(heads * splits * M * N, device=Co.t.device)
     g = L.GemmNT(A=_ptr(A.t, A.base), lda=A.ld, rows=None, B=_ptr(Bo.t, Bo.base), ldb=Bo.ld, C=_ptr(Co.t, Co.base), ldc=Co.ld, M=M, N=N,
