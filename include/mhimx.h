@@ -485,7 +485,7 @@ int mhimx_shard_flags(void* stream, const int64_t* rows_all, int64_t R, int64_t 
                       int32_t tokens_live, uint8_t* excl);
 int mhimx_shard_gather(void* stream, const float* H, int64_t E, const int64_t* rows, int64_t R, int64_t lo, int64_t n, float* out);
 int mhimx_shard_scatter(void* stream, const float* dX, int64_t E, const int64_t* rows, int64_t R, int64_t lo, int64_t n, float* dH);
-/* out[e] (+)= sum_m X[m,e] */
+/* out[e] (+)= sum_m X[m,e].  ws: min(128, ceil(M/16)) x E floats at least; up to 512 x E are used (more, shorter row chunks). */
 int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate,
                  void* ws, int64_t ws_bytes);
 

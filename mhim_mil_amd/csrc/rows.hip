@@ -752,6 +752,7 @@ __global__ void colsum_part_kernel(const float* __restrict__ X, int64_t M, int E
   const int64_t mb = (int64_t)blockIdx.y * chunk;
   const int64_t me = mb + chunk < M ? mb + chunk : M;
   float acc = 0.f;
+#pragma unroll 8
   for (int64_t m = mb; m < me; ++m) acc += X[m * (int64_t)E + e];
   part[(int64_t)blockIdx.y * E + e] = acc;
 }
@@ -1123,9 +1124,14 @@ int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
 
 int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int accumulate, void* ws, int64_t ws_bytes) {
   MHIMX_CHECK_ARG(X && out && E > 0 && M >= 0, "colsum: bad args");
-  const int64_t chunk = cdiv(M > 0 ? M : 1, 128);
+  // row chunks of >= 16 rows, up to 512 of them if the workspace holds that many (128 x E floats are always enough): a thread's rows are
+  // one serial chain of loads, the chunk partials are summed 32 at a time per column
+  const int64_t nrows = M > 0 ? M : 1, avail = ws ? ws_bytes / (E * 4) : 0;
+  int64_t want = cdiv(nrows, 16) < 512 ? cdiv(nrows, 16) : 512;
+  MHIMX_CHECK_ARG(avail >= (want < 128 ? want : 128), "colsum: workspace too small (need %lld bytes)", (long long)((want < 128 ? want : 128) * E * 4));
+  if (want > avail) want = avail;
+  const int64_t chunk = cdiv(M > 0 ? M : 1, want);
   const int gy = (int)cdiv(M > 0 ? M : 1, chunk);
-  MHIMX_CHECK_ARG(ws && ws_bytes >= (int64_t)gy * E * 4, "colsum: workspace too small (need %lld bytes)", (long long)(gy * E * 4));
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)cdiv(E, 128), gy), dim3(128), 0, st, X, M, (int)E, chunk, (float*)ws);
   MHIMX_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(E, 32)), dim3(RP_THREADS), 0, st, (const float*)ws, gy, (int)E, (int)E, out, accumulate);

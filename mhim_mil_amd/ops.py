@@ -526,7 +526,7 @@ def colsum(X, out=None, accumulate=False):
     M, E = X.shape
     if out is None:
         out = torch.empty(E, device=X.device)
-    ws = torch.empty(128 * E, device=X.device)
+    ws = torch.empty(512 * E, device=X.device)                 # (>= 128 x E required; more lets the kernel use more, shorter row chunks)
     L.check(L.lib().mhimx_colsum(_stream(), _p(X), M, E, _p(out), int(bool(accumulate)), _p(ws), ws.numel() * 4), "mhimx_colsum")
     return out
 
