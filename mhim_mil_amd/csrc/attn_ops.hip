@@ -871,20 +871,21 @@ static int attn_reduce(hipStream_t st, const float* part, int G, int64_t W, floa
 }
 
 // dw[h, tau] of the residual convolution.  ws: mhimx_resconv_dw_ws_floats(...) floats.
-extern "C" int64_t mhimx_resconv_dw_ws_floats(int64_t T, int64_t C, int64_t dh, int64_t KS) { return cdiv(T, 256) * (C / dh) * KS; }
+constexpr int64_t RC_CHUNK = 64;        // tokens per workgroup of the dw partials (256: 18 serial load rounds on 1.5 workgroups per CU)
+extern "C" int64_t mhimx_resconv_dw_ws_floats(int64_t T, int64_t C, int64_t dh, int64_t KS) { return cdiv(T, RC_CHUNK) * (C / dh) * KS; }
 extern "C" int mhimx_resconv_dw(void* stream, const float* dout, int64_t ldo, const float* v, int64_t ldv, int64_t KS, int64_t dh,
                                 int64_t T, int64_t C, float* dw, float* ws) {
   MHIMX_CHECK_ARG(dout && v && dw && ws && dh == 64 && C % dh == 0, "resconv_dw: dim_head must be 64");
-  const int nblk = (int)cdiv(T, 256);
+  const int nblk = (int)cdiv(T, RC_CHUNK);
   const int W = (int)((C / dh) * KS);
   if (KS == 33 && C % AT == 0) {
     hipLaunchKernelGGL(resconv_dw_strip_kernel<33>, dim3((unsigned)nblk, (unsigned)(C / AT)), dim3(AT), 0, (hipStream_t)stream, dout, ldo, v,
-                       ldv, (int)dh, T, (int)C, (int64_t)256, ws);
+                       ldv, (int)dh, T, (int)C, RC_CHUNK, ws);
     MHIMX_LAUNCH_CHECK();
     return attn_reduce((hipStream_t)stream, ws, nblk, W, dw);
   }
   hipLaunchKernelGGL(resconv_dw_kernel, dim3(nblk), dim3(AT), (size_t)W * 4, (hipStream_t)stream, dout, ldo, v, ldv, (int)KS, (int)dh, T, (int)C,
-                     (int64_t)256, ws);
+                     RC_CHUNK, ws);
   MHIMX_LAUNCH_CHECK();
   return attn_reduce((hipStream_t)stream, ws, nblk, W, dw);
 }
