@@ -47,7 +47,11 @@ Rccl& rccl() {
       r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
       if (r.h) break;
     }
-    if (!r.h) { r.err = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return; }
+    if (!r.h) {
+      const char* e = dlerror();               // (dlerror() clears the message: read it once)
+      r.err = std::string("dlopen(librccl.so): ") + (e ? e : "not found");
+      return;
+    }
     r.get_id = (fn_get_id)dlsym(r.h, "ncclGetUniqueId");
     r.init_rank = (fn_init_rank)dlsym(r.h, "ncclCommInitRank");
     r.allreduce = (fn_allreduce)dlsym(r.h, "ncclAllReduce");

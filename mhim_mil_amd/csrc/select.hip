@@ -795,7 +795,7 @@ __global__ __launch_bounds__(SEL_THREADS) void selm_gather_kernel(const float* _
 }
 
 // rank of every candidate by counting (the keys are distinct: value << 32 | ~index): workgroup (x, y) compares candidates
-// [1024 x, 1024 x + 1024) against the 2048-key segment y held in LDS (broadcast reads) - k^2 compares spread over the chip instead of a
+// [1024 x, 1024 x + 1024) against the SELM_SEG-key (256) segment y held in LDS (broadcast reads) - k^2 compares spread over the chip instead of a
 // 105-step bitonic sort in one workgroup's LDS.  Integer atomics: the result does not depend on the order.
 constexpr int SELM_SEG = 256;            // (2048: a c3 / c5 select ran its k^2 compares on 6 .. 70 workgroups of 16 waves, 42 .. 47 us)
 __global__ __launch_bounds__(SEL_THREADS) void selm_rank_kernel(int k, int n_sel, const int64_t* __restrict__ perm, SelMultiWs w) {

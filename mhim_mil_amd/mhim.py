@@ -679,6 +679,12 @@ class MHIM(nn.Module):
         Lk = int(len_keep * self.merge.merge_ratio)
         return k, n_sel, len_keep, Lk, len_keep - Lk
 
+    def device_draw_ok(self, ps, i=None, mrh=None):
+        """True when student_rows draws both random subsets inside the select kernel (no torch.randperm, no generator): the v2
+        recipe on an order-free pool (ABMIL / DSMIL) with ps <= 16384 and k <= 4096."""
+        c = self.v2_counts(ps, i, mrh)
+        return c is not None and self.baseline in ("attn", "dsmil") and ps <= 16384 and c[0] <= 4096
+
     def student_rows(self, ps, i, attn, perm=None, ids_shuffle=None, mrh=None, generator=None, merge_first=False, rows_out=None, seed=None):
         """Row list of one student forward: get_mask (mhim.py:341) + Merge.masking (merge.py:158-176) composed.
 

@@ -138,15 +138,19 @@ class ShardedBagTrainer:
 
     # -------------------------------------------------------------------------------------------------
     def fixed_shape_ok(self, x):
-        """The sync-free step needs the one-pass scorer (its ``excl`` flags) and the single-pass projection."""
+        """The sync-free step needs the one-pass scorer (its ``excl`` flags) and the single-pass projection; train_step also asks for
+        the v2 recipe (HAM mask only): a v1 ratio makes the number of masked rows data dependent (one host read-back in get_mask)."""
         s = self.s
         att = s.online_encoder.attention
         return (not s.online_encoder.gated and s.prec != "f32" and s.mlp_dim == 512 and att.attention[0].weight.shape[0] == 128
                 and x.shape[1] % 32 == 0 and s._feature_prec(1 << 20) == "bf16x3" and s.merge_enable)
 
+    def _bag_rows(self, x_local):
+        return sum(self.counts) if self.counts is not None else x_local.shape[-2] * self.comm.world
+
     def train_step(self, x_local, label, perm=None, ids_shuffle=None, i=None):
         """x_local [n_r, D]: this rank's rows (rank order = row order of the bag).  Returns (logits [C], losses [3])."""
-        if self.fixed_shape_ok(x_local):
+        if self.fixed_shape_ok(x_local) and self.s.v2_counts(self._bag_rows(x_local), i) is not None:
             return self._step_fixed(x_local, label, perm, ids_shuffle, i)
         return self._step_generic(x_local, label, perm, ids_shuffle, i)
 
@@ -223,8 +227,11 @@ class ShardedBagTrainer:
             # (draws: injected, or - up to 16 384 instances - made inside the select kernel from the model's seed counter and the device
             # tick, the same on every rank; larger bags draw from the shared-seed generator)
             injected = perm is not None and ids_shuffle is not None
+            # generator=None only when no host-side draw can happen: injected draws, or the in-kernel draw that MHIM.student_rows takes for
+            # the v2 recipe with N <= 16384 and k <= 4096 (seeded by shared_seed).  Everything else draws from the SHARED-seed generator:
+            # the process-default generator would give every rank its own "replicated" row list.
             rows, len_keep, Lk, R = s.student_rows(N, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, merge_first=True,
-                                                   generator=None if (injected or N <= 16384) else self.gen, seed=shared_seed)
+                                                   generator=None if (injected or s.device_draw_ok(N, i)) else self.gen, seed=shared_seed)
             plan = BagPlan(rows=None, L=n, Lk=Lk, R=R, drop_seed=local_seed, mca_seed=shared_seed, training=True)
             excl = ops.shard_flags(rows, R, Lk, lo, n, k, cm.rank == 0)
 
@@ -293,7 +300,7 @@ class ShardedBagTrainer:
         """Capture the fixed-shape step as hipGraph segments with the exchanges between them (graph | collective | graph ...: a
         collective inside a captured graph depends on the RCCL build, and ranks must not mix replayed and eager collectives).  Returns
         a callable; every call replays one step on the SAME (x_local, label) buffers (copy the next shard into them)."""
-        if not self.fixed_shape_ok(x_local):
+        if not (self.fixed_shape_ok(x_local) and self.s.v2_counts(self._bag_rows(x_local), i) is not None):
             raise L.MhimxError("capture(): this model takes the generic sharded step (one host read-back per step): run it eagerly")
         if self.s.mrh_sche is not None:
             raise L.MhimxError("capture(): the HAM-ratio schedule changes the launch shapes per iteration")

@@ -312,8 +312,8 @@ class AttentionGated(_AttnMILBase):
 
 
 class TransMIL(_AttnMILBase):
-    """modules/transmil.py:66-175: tokens wrap-padded to a square (transmil.py:124-128) - a row gather
-    fused into the embedding GEMM, no copy - then the encoder of SURVEY rows A9/A10 (mhim_mil_amd/nystrom.py) and a classifier.
+    """modules/transmil.py:66-175: embedded tokens wrap-padded to a square (transmil.py:124-128; one concatenation together with the
+    cls token) - then the encoder of SURVEY rows A9/A10 (mhim_mil_amd/nystrom.py) and a classifier.
     Any bag size: this model's PPEG is told the grid (transmil.py:57-64), it does not zero-pad to 7 x 7 as emb_position.PPEG does.
     pos='none' drops the PPEG (transmil.py:73-74,145-146); mil_norm='ln' puts a LayerNorm in front of the embedding (:83-84)."""
 
@@ -349,21 +349,13 @@ class TransMIL(_AttnMILBase):
         while side * side < n:
             side += 1
         add = side * side - n
-        rows = None
-        if add > 0:                                                      # x = cat([x, x[:add]]) as a gather index
-            rows = torch.cat([torch.arange(n, device=x.device), torch.arange(add, device=x.device)])
-        if (self._ln_first or self.mil_norm == "bn") and rows is not None and not self._no_embed:
-            # a trainable norm in front of the embedding: normalise the n bag rows once (LayerNorm is row-wise; the BatchNorm above ran on
-            # the bag already), append the wrapped rows as an autograd index (rows 0..add-1 get both gradients), embed without a gather
-            xn = _ln(x, self.feature[0]) if self._ln_first else x
-            xn = torch.cat([xn, xn[:add]], 0)
-            f = self.feature[1 if self._ln_first else 0]
-            h = _EmbedFn.apply(xn, f.weight, f.bias, L.ACT[self.act], float(self.embed_drop if self.training else 0.0), self._seed(), None)
-        else:
-            h = self._embed(x, rows)
+        # the reference embeds (Linear, act, Dropout) the n bag rows and THEN wraps: cat([h, h[:add]]) (transmil.py:117-127) - the wrapped
+        # rows are exact copies of rows 0..add-1 including their dropout mask, so the wrap is a concatenation of embedded rows here too
+        # (rows 0..add-1 receive both gradients through autograd's cat), and the embedding GEMM runs on n rows, not on side^2
+        h = self._embed(x, None)
         tr = self.training
         s1, s2 = self._seed(), self._seed()
-        t = torch.cat([self.cls_token.view(1, -1), h], 0)
+        t = torch.cat([self.cls_token.view(1, -1), h] + ([h[:add]] if add > 0 else []), 0)
         attn = []
         if return_attn:
             t, a, v = self.layer1(t, True, False, s1, None, tr)

@@ -292,6 +292,47 @@ def test_captured_sharded_step_two_ranks_one_gpu(tmp_path):
         assert torch.equal(res[0]["stu"][k], res[1]["stu"][k]), k
 
 
+def _undrawn_worker(rank, port, out, case):
+    """Two ranks, NO injected draws: the replicated row lists must agree although each process has its own default generator."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    torch.manual_seed(1000 + 77 * rank)                    # the process-default generators differ on purpose
+    from mhim_mil_amd.sharded import ShardedBagTrainer
+    n_bag, cfg = (8000, dict(V2, mask_ratio_h=0.3)) if case == "big_k" else (1800, dict(V2, mask_ratio_l=0.2))
+    counts = [n_bag // 2 + 100, n_bag - n_bag // 2 - 100]
+    base = synth.mhim_state(11, input_dim=D, merge_k=5)
+    s, t = build(base, input_dim=D, **cfg), build(synth.spread_teacher(base), input_dim=D, **cfg)
+    tr = ShardedBagTrainer(s, t, counts=counts, seed=5, aux_alpha=0.5, mm=0.999)
+    lo = sum(counts[:rank])
+    res = {"rows": [], "logits": []}
+    for step in range(2):
+        x = torch.from_numpy(synth.bag(700 + step, n_bag, D))[lo:lo + counts[rank]].to(DEV)
+        logits, _ = tr.train_step(x, torch.tensor([step % 2], device=DEV))
+        res["rows"].append(tr.last["rows"].cpu())
+        res["logits"].append(logits.cpu())
+    res["stu"] = {k: v.detach().cpu() for k, v in s.state_dict().items()}
+    torch.save(res, os.path.join(out, f"u{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["big_k", "v1_ratio"])
+def test_two_ranks_without_injected_draws_build_the_same_row_list(tmp_path, case):
+    """with k > 4096 (N <= 16384) or a v1 ratio MHIM.student_rows leaves the in-kernel draw and calls torch.randperm; the
+    sharded step must then hand it the SHARED-seed generator (the process-default one differs per rank: silently different
+    'replicated' row lists).  big_k: v2 recipe, N = 8000, k = 4800 (fixed-shape step); v1_ratio: mask_ratio_l = 0.2 (generic step)."""
+    port = 38500 + (os.getpid() % 1000) + (0 if case == "big_k" else 1000)
+    mp.spawn(_undrawn_worker, args=(port, str(tmp_path), case), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"u{r}.pt")) for r in range(2)]
+    for step in range(2):
+        assert torch.equal(res[0]["rows"][step], res[1]["rows"][step]), f"{case}: step {step}: the ranks drew different row lists"
+        assert torch.equal(res[0]["logits"][step], res[1]["logits"][step]) and torch.isfinite(res[0]["logits"][step]).all()
+    for k in res[0]["stu"]:
+        assert torch.equal(res[0]["stu"][k], res[1]["stu"][k]), k
+
+
 def test_c5_full_bag_step_vs_oracle():
     """BASELINE config c5, the WHOLE bag (N = 200 000, D = 1536) on one rank's code path (world size 1; the two-rank tests above pin
     the exchanges): teacher feature / scores, the student's row set, logits, losses and every parameter after Adam + EMA against the
