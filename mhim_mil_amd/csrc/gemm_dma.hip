@@ -526,7 +526,10 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
 // One launch for the parameter-only preparation of a train step (a block range per job).  kind 0: out[c,r] = in[r,c];
 // kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters);
 // kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip); kind 5: the same image of in^T.
-struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; Merge2PrepArgs m2; };
+// (kind 6, several per launch - the bags of an accumulation window share the parameters but each owns a Merge workspace whose head
+// holds the query-side images: job q's workspace starts m2_shift[q.R] floats behind the first one's; the layout is the same)
+constexpr int PREP_MERGE_MAX = 8;
+struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; Merge2PrepArgs m2; int64_t m2_shift[PREP_MERGE_MAX]; };
 int merge2_prep_args(const mhimx_merge* m, int64_t R, void* ws, int64_t ws_bytes, Merge2PrepArgs* out);      // mca2.hip
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
   // 1-D grid: job q owns blocks [first[q], first[q+1]) - sized per job (the bag's paired-plane image wants thousands of
@@ -601,7 +604,10 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
       o[1] = __builtin_bit_cast(f4, lo);
     }
   } else if (jb.kind == 6) {
-    merge2_prep_body(bid, pj.m2.q_param, pj.m2.ln_w, pj.m2.ln_b, pj.m2.wq, pj.m2.wkv, pj.m2.k, pj.m2.scale, pj.m2.w);
+    Merge2Ws w = pj.m2.w;
+    const int64_t sh = pj.m2_shift[jb.R];             // (only the fields the preparation writes are shifted)
+    w.gq += sh; w.gmean += sh; w.grstd += sh; w.Q += sh; w.aq += sh; w.aqf += sh; w.gtf_aq += sh;
+    merge2_prep_body(bid, pj.m2.q_param, pj.m2.ln_w, pj.m2.ln_b, pj.m2.wq, pj.m2.wkv, pj.m2.k, pj.m2.scale, w);
   }
 }
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
@@ -614,8 +620,15 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
     MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
     MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 6, "prep_batch: unknown job kind");
     if (jobs[i].kind == 6) {
-      MHIMX_CHECK_ARG(n_merge++ == 0, "prep_batch: one Merge preparation job per launch");
-      if (int r = merge2_prep_args(reinterpret_cast<const mhimx_merge*>(jobs[i].in), jobs[i].R, jobs[i].out, jobs[i].C, &pj.m2)) return r;
+      MHIMX_CHECK_ARG(n_merge < PREP_MERGE_MAX, "prep_batch: at most %d Merge preparation jobs per launch", PREP_MERGE_MAX);
+      Merge2PrepArgs m2;
+      if (int r = merge2_prep_args(reinterpret_cast<const mhimx_merge*>(jobs[i].in), jobs[i].R, jobs[i].out, jobs[i].C, &m2)) return r;
+      if (n_merge == 0) pj.m2 = m2;
+      MHIMX_CHECK_ARG(m2.q_param == pj.m2.q_param && m2.wq == pj.m2.wq && m2.wkv == pj.m2.wkv && m2.ln_w == pj.m2.ln_w && m2.k == pj.m2.k,
+                      "prep_batch: the Merge preparation jobs of one launch share their parameters");
+      MHIMX_CHECK_ARG((m2.w.gq - pj.m2.w.gq) == (m2.w.gtf_aq - pj.m2.w.gtf_aq), "prep_batch: Merge workspace layouts differ");
+      pj.m2_shift[n_merge] = m2.w.gq - pj.m2.w.gq;
+      pj.j[i].R = n_merge++;
     }
     MHIMX_CHECK_ARG(jobs[i].kind != 5 || (jobs[i].C % 32 == 0 && jobs[i].R % 16 == 0 && aligned16(jobs[i].out)),
                     "prep_batch: the transposed fragment image needs C % 32 == 0, R % 16 == 0 and a 16-byte aligned output");

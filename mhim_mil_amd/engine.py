@@ -228,6 +228,7 @@ class FusedTrainer:
         self._cap_stream = None
         self._side = None
         self.single_pass = True            # ABMIL: one projection launch for teacher + student, bag-ordered buffers (when shapes allow)
+        self.window_streams = 4            # accumulation windows (window_step): HIP streams the window's bags are issued on
         self._rows_cache = {}
 
     def _dist(self):
@@ -328,12 +329,24 @@ class FusedTrainer:
         """The single-pass ABMIL step: ONE projection launch computes the teacher's and the student's feature rows from the raw bag
         (the reference's student projects all N rows before it masks, mhim.py:335-336); the rows stay in bag order and the scorer,
         Merge, their backwards and the projection's weight-gradient GEMM gather the rows that take part by index."""
-        s, t, fl = self.s, self.t, self.flat
+        first = self._micro == 0
+        prep_t, preps = self._nat_prep([x], i, with_opt_tick=first)
+        hook = self._mid_hook if (first and self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1
+                                  and not self._capturing and self._split > 0) else None
+        out = self._nat_bag(x, label, prep_t, preps[0], self.flat.grad_views, accumulate=not first, perm=perm, ids_shuffle=ids_shuffle,
+                            i=i, mid_hook=hook)
+        self._micro += 1
+        return out
+
+    def _nat_prep(self, xs, i, with_opt_tick=True):
+        """The parameter-only preparation for the bags ``xs`` that share the current weights (one bag, or an accumulation window) as ONE
+        launch: device counters, paired-plane / fragment / transposed weight images of both models, and - per bag, because it lives at the
+        head of that bag's Merge workspace - the query side of the projection-free Merge.  Returns (teacher prep, [student prep per bag])."""
+        s, t = self.s, self.t
         mhim = self.model_kind == "mhim"
-        ps, E = x.shape[0], s.mlp_dim
-        dev = x.device
+        dev = xs[0].device
         jobs = [(ops.PREP_TICK, None, self.tick)]
-        if self._micro == 0:
+        if with_opt_tick:
             jobs.append((ops.PREP_TICK, None, self.opt_step))
         prep_t = None
         if mhim:
@@ -343,20 +356,37 @@ class FusedTrainer:
         if not mhim:
             s.merge_enable = False
         try:
-            R_merge = s.v2_counts(ps, i)[4] if mhim else 0
-            lean = mhim and s.merge.k * 8 <= 48 and 1 <= R_merge <= 32768 and s._op_prec != "f32"
+            Rs = [s.v2_counts(x.shape[0], i)[4] if mhim else 0 for x in xs]
+            lean = mhim and s.merge.k * 8 <= 48 and all(1 <= R <= 32768 for R in Rs) and s._op_prec != "f32"
             js, prep_s = s.prep_jobs(backward=True, lean_merge=lean)
-            if lean:
-                # the parameter-only part of the student's Merge (LayerNorm of the queries, their projection, the score vectors) rides
-                # in the preparation launch: off the teacher -> select -> student chain
-                if True:
+            preps = []
+            for R in Rs:
+                pb = dict(prep_s)
+                if lean:
+                    # the parameter-only part of the student's Merge (LayerNorm of the queries, their projection, the score vectors) rides
+                    # in the preparation launch: off the teacher -> select -> student chain
                     mw_prep = s._merge_w(None)
-                    prep_s["merge_ws"] = mw_prep.ws_for(R_merge, dev)
-                    prep_s["_merge_prep_w"] = mw_prep                      # (keeps the weight struct alive until the launch is enqueued)
-                    js.append((ops.PREP_MERGE, mw_prep, (prep_s["merge_ws"], R_merge)))
+                    pb["merge_ws"] = mw_prep.ws_for(R, dev)
+                    pb["_merge_prep_w"] = mw_prep                          # (keeps the weight struct alive until the launch is enqueued)
+                    js.append((ops.PREP_MERGE, mw_prep, (pb["merge_ws"], R)))
+                preps.append(pb)
             ops.prep_batch(jobs + js)
-            first = self._micro == 0
-            gv = fl.grad_views
+        finally:
+            s.merge_enable = merge_on
+        return prep_t, preps
+
+    def _nat_bag(self, x, label, prep_t, prep_s, gv, accumulate=False, perm=None, ids_shuffle=None, i=None, mid_hook=None, q_out=None, slot=0):
+        """One bag of the single-pass step after its preparation: projection (teacher + student), teacher pool, select, Merge, student
+        pool, head, backward.  ``gv``: the gradient views to fill (``accumulate``: add to them); ``q_out``: where Merge's EMA-updated
+        queries go (default: the parameter itself, merge.py:142-143)."""
+        s, t = self.s, self.t
+        mhim = self.model_kind == "mhim"
+        ps, E = x.shape[0], s.mlp_dim
+        dev = x.device
+        merge_on = s.merge_enable
+        if not mhim:
+            s.merge_enable = False
+        try:
             k = s.merge.k if mhim else 0
             act = mh.L.act_code(s.act, mh._FEATURE_ACTS)
             Hbuf = torch.empty((ps + k, E), device=dev)
@@ -368,7 +398,7 @@ class FusedTrainer:
                                       want_dact=True))
             ops.bag_project(x, heads, act=act, drop_tick=self.tick)
             DACT = heads[-1].dact
-            teacher_feat, rows_all = None, None
+            teacher_feat, rows_all, score = None, None, None
             if mhim:
                 wp = t.predictor.weight.data if t.attn2score else None
                 st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp,
@@ -376,14 +406,16 @@ class FusedTrainer:
                 score = st_t.pscore if t.attn2score else ops.softmax_from_stats(st_t.s, st_t.stats)
                 teacher_feat = st_t.z
                 _, _, len_keep, Lk, R = s.v2_counts(ps, i)
-                key = (ps, len_keep, k)
+                # [rows to merge | rows that stay | the k token rows ps .. ps+k-1]
+                key = (ps, len_keep, k, slot)                         # (one list per bag of a window: the bags may run concurrently)
                 rows_all = self._rows_cache.get(key)
-                if rows_all is None:                                  # [rows to merge | rows that stay | the k token rows ps .. ps+k-1]
+                if rows_all is None:
                     rows_all = torch.empty(len_keep + k, dtype=torch.int64, device=dev)
                     rows_all[len_keep:] = torch.arange(ps, ps + k, device=dev)
                     self._rows_cache[key] = rows_all
                 s.student_rows(ps, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, merge_first=True, rows_out=rows_all)
                 plan = BagPlan(rows=rows_all[:len_keep], L=len_keep, Lk=Lk, R=R, mca_seed=s._next_seed(), training=True, merge_first=True)
+                plan.q_out = q_out
                 keep_num = Lk + k
             else:
                 plan = BagPlan(rows=None, L=ps, Lk=ps, R=0, training=True)
@@ -393,23 +425,143 @@ class FusedTrainer:
             logits, losses, g_z, _, _ = ops.head_fwd_bwd(
                 z, t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),
                 main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
-                d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=not first)
-            if first:
-                hook = self._mid_hook if (self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1 and not self._capturing
-                                          and self._split > 0) else None
-                s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=hook)
-                ops.reduce_flush(self._defer)
-            else:                                   # gradient accumulation: fresh buffers, then add (rare path)
-                g = s._bag_backward_nat(x, plan, saved, g_z, {})
-                for n, v in g.items():
-                    gv[n].add_(v)
+                d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=accumulate)
+            # the six final gradient reductions of the backward (slab sums, column partials) run as ONE launch
+            s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=mid_hook, accumulate=accumulate)
+            ops.reduce_flush(self._defer)
         finally:
             s.merge_enable = merge_on
-        self._micro += 1
         # (kept for inspection / parity tests: under graph replay these are the static buffers the replay rewrites)
         self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num, "rows": plan.rows,
-                     "score": score if mhim else None, "R": plan.R}
+                     "score": score, "R": plan.R, "tokens": Hbuf[ps:] if mhim else None}
         return logits, losses
+
+    # ------------------------------------------------------------------------------------------------- accumulation windows
+    def window_ok(self, bags, i=None):
+        """The batched window takes the single-pass ABMIL step for every bag (the shapes _forward_backward_nat takes), one process."""
+        s, t = self.s, self.t
+        if self.model_kind != "mhim" or s.baseline != "attn" or not self.single_pass or s.mrh_sche is not None:
+            return False
+        for b in bags:
+            x = b[0] if b.dim() == 3 else b
+            if not (x.is_cuda and s.bag_ordered_ok(x) and t.bag_ordered_ok(x) and not t.merge_test and s.merge_enable
+                    and s.v2_counts(x.shape[0], i) is not None and s.device_draw_ok(x.shape[0], i)
+                    and ops.bag_wgrad_ok(x, s.mlp_dim, s.v2_counts(x.shape[0], i)[2])):
+                return False
+        return True
+
+    def _window_state(self, n_streams, dev):
+        """Side streams and their gradient slabs (stream 0 = the caller's stream accumulates straight into the flat gradient)."""
+        st = getattr(self, "_win", None)
+        if st is None or len(st["streams"]) < n_streams - 1:
+            fl = self.flat
+            slabs = torch.zeros((max(n_streams - 1, 1), fl.n_all), device=dev)
+            pd = dict(self.s.named_parameters())
+            views = [{n: slabs[j, fl.offsets[n]:fl.offsets[n] + pd[n].numel()].view_as(pd[n]) for n in fl.train_names}
+                     for j in range(n_streams - 1)]
+            st = self._win = {"streams": [torch.cuda.Stream() for _ in range(n_streams - 1)], "slabs": slabs, "views": views,
+                              "defers": [ops.ReduceList() for _ in range(n_streams - 1)]}
+        return st
+
+    def window_step(self, bags, labels, i=None, n_streams=None, perms=None, shuffles=None, update=True):
+        """ONE optimiser update over ``accumulation_steps`` bags that share the current weights (--accumulation_steps,
+        base_engine.py:29,47-49,100-119,146-167), as a batch instead of a loop:
+
+        * the parameter-only preparation (weight images, Merge's query side) runs ONCE for the window, Adam + EMA once (as in the loop);
+        * the k bags are independent until the gradient sum (teacher and student weights are fixed inside a window), so they are issued
+          round-robin on ``n_streams`` HIP streams: bag j's latency-bound launches (select, Merge, scorers, head: one to a few dozen
+          workgroups each) run beside bag j'+1's projection and weight-gradient GEMMs instead of on one serial chain.  Stream 0 (the
+          caller's) accumulates into the flat gradient, every other stream into its own slab; ONE reduce launch sums the slabs;
+        * Merge's in-forward EMA of the global queries (merge.py:142-143): every bag attends with the window's first queries, and the
+          window ends with the same chain of EMA steps on the tokens those forwards produced (oracle ``train_window(q_ema="window")``;
+          differs from the reference's bag-after-bag order in second order of 1 - merge_mm).
+        Each bag's loss is scaled by 1 / accumulation_steps in the head kernel (base_engine.py:102).  Capturable (``capture_window``).
+        Returns ([logits per bag], [losses per bag])."""
+        k = len(bags)
+        assert k == self.accum and len(labels) == k, "window_step takes exactly accumulation_steps bags"
+        xs = [self.s._check_x(b) for b in bags]
+        if not self.window_ok(xs, i) or perms is not None or self.world > 1:
+            outs = [self.train_step(b, l, i=i, **({} if perms is None else {"perm": perms[j], "ids_shuffle": shuffles[j]}))
+                    for j, (b, l) in enumerate(zip(bags, labels))]
+            return [o[0] for o in outs], [o[1] for o in outs]
+        assert self._micro == 0, "window_step starts a fresh accumulation window"
+        S = max(1, min(int(n_streams or self.window_streams), k))
+        dev = xs[0].device
+        s, fl = self.s, self.flat
+        prep_t, preps = self._nat_prep(xs, i, with_opt_tick=True)
+        st = self._window_state(S, dev)
+        km, E = s.merge.k, s.mlp_dim
+        q_new = torch.empty((k, km, E), device=dev)                   # per-bag EMA outputs (unused: the chain below runs on the tokens)
+        main = torch.cuda.current_stream()
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        logits, losses, tokens, per_bag = [None] * k, [None] * k, [None] * k, []
+        keep_defer = self._defer
+        try:
+            for j in range(k):
+                lane = j % S
+                stream = main if lane == 0 else st["streams"][lane - 1]
+                gv = fl.grad_views if lane == 0 else st["views"][lane - 1]
+                if lane and j < S:
+                    stream.wait_event(ev0)
+                self._defer = keep_defer if lane == 0 else st["defers"][lane - 1]
+                with torch.cuda.stream(stream):
+                    logits[j], losses[j] = self._nat_bag(xs[j], labels[j], prep_t, preps[j], gv, accumulate=(j >= S), i=i,
+                                                         q_out=q_new[j], slot=j)
+                    tokens[j] = self.last["tokens"]
+                    per_bag.append(self.last)
+        finally:
+            self._defer = keep_defer
+        for lane in range(1, S):
+            e = torch.cuda.Event()
+            e.record(st["streams"][lane - 1])
+            main.wait_event(e)
+        if S > 1:                                                     # flat gradient += the other streams' slabs: one launch
+            lst = ops.ReduceList()
+            ops.reduce_slabs_job(lst, st["slabs"][:S - 1], fl.grad, accumulate=True)
+            ops.reduce_flush(lst)
+        # the window's EMA chain on the k token sets: q <- mm^k q + (1 - mm) sum_j mm^(k-1-j) z_j
+        mm = float(s.merge.g_q_mm)
+        w = self._win_w.get(k) if hasattr(self, "_win_w") else None
+        if w is None:                                                 # (device arithmetic only: capture-safe)
+            if not hasattr(self, "_win_w"):
+                self._win_w = {}
+            w = self._win_w[k] = ((1.0 - mm) * mm ** torch.arange(k - 1, -1, -1, device=dev, dtype=torch.float64)).float()
+        Z = torch.stack(tokens)                                       # [k, km, E]
+        q = s.merge.global_q_mm.data.view(km, E)
+        q.mul_(mm ** k).add_((Z * w.view(k, 1, 1)).sum(0))
+        self._micro = k
+        if update:
+            self.update()
+        self.last = dict(self.last, logits=logits, losses=losses, bags=per_bag)
+        return logits, losses
+
+    def capture_window(self, bags, labels, warmup=1, n_streams=None, **kw):
+        """Capture one whole accumulation window (window_step) on static (bags, labels) into ONE hipGraph whose branches are the
+        window's streams; ``graph.replay()`` runs prep, the k bags, the slab sum, Adam + EMA."""
+        if self.world > 1:
+            raise mh.L.MhimxError("capture_window: one process (data-parallel ranks exchange gradients between windows: use capture())")
+        if not self.window_ok([self.s._check_x(b) for b in bags], kw.get("i")):
+            raise mh.L.MhimxError("capture_window: these bags / this model do not take the single-pass ABMIL step")
+        self._capturing = True
+        try:
+            if self._cap_stream is None:
+                self._cap_stream = torch.cuda.Stream()
+            cs = self._cap_stream
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                for _ in range(warmup):
+                    self.window_step(bags, labels, n_streams=n_streams, **kw)
+            torch.cuda.current_stream().wait_stream(cs)
+            torch.cuda.synchronize()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):
+                self.window_step(bags, labels, n_streams=n_streams, **kw)
+            return g
+        finally:
+            self._capturing = False
 
     def _bind_grads(self):
         """Every trainable parameter's .grad IS its view of the flat gradient buffer: autograd accumulates straight into the

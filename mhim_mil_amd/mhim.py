@@ -554,7 +554,9 @@ class MHIM(nn.Module):
         if rows_all is not None:
             # (prep["merge_ws"]: the parameter-only part of Merge already ran as a job of the step's preparation launch)
             mw = self._merge_w(plan, need_t=False, wkv_frag=prep.get("wkv_frag"), x_rows=rows_all[:plan.R], prepared="merge_ws" in prep)
-            q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
+            q_param = getattr(plan, "q_out", None)                          # (a window step sends the per-bag EMA result elsewhere)
+            if q_param is None:
+                q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
             _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None,
                                       ws=prep.get("merge_ws"))
             st = ops.abmil_pool_fwd(sc, Hbuf, None, rows1=rows_all[plan.R:])
@@ -564,7 +566,7 @@ class MHIM(nn.Module):
         saved["pool"] = st
         return st.z, saved
 
-    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None):
+    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None, accumulate=False):
         """Backward of _bag_forward_nat: every gradient buffer is bag-ordered too (dH [N + k, E]); the rows that took part are
         gathered once more by the activation backward (ops.rows_dpre) and the projection's weight-gradient GEMM."""
         N = x.shape[0]
@@ -577,7 +579,7 @@ class MHIM(nn.Module):
         for key, nm in (("d_wa", "0.weight"), ("d_wc", "2.weight")):
             if pre + nm in out:
                 pool_g[key] = out[pre + nm]
-        g = ops.abmil_pool_bwd(sc, st, g_z, prep["wa_t"], grads=pool_g, defer=defer, wa_t_frag=prep.get("wa_t_frag"))
+        g = ops.abmil_pool_bwd(sc, st, g_z, prep["wa_t"], grads=pool_g, defer=defer, wa_t_frag=prep.get("wa_t_frag"), accumulate=accumulate)
         grads[pre + "0.weight"], grads[pre + "2.weight"] = g["d_wa"], g["d_wc"]
         if rows_all is not None:
             mw = self._merge_w(plan, need_t=True, q=saved["q_old"], tr=prep.get("merge_t"), x_rows=rows_all[:plan.R])
@@ -587,7 +589,7 @@ class MHIM(nn.Module):
                             ("d_bo", "merge.attn.to_out.0.bias")):
                 if nm in out:
                     mgr[key] = out[nm]
-            mg = ops.merge_bwd(mw, Hbuf, dHbuf[N:], saved["mws"], grads=mgr, defer=defer)
+            mg = ops.merge_bwd(mw, Hbuf, dHbuf[N:], saved["mws"], grads=mgr, defer=defer, accumulate=accumulate)
             grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]
             grads["merge.attn.to_out.0.weight"], grads["merge.attn.to_out.0.bias"] = mg["d_wo"], mg["d_bo"]
@@ -599,11 +601,11 @@ class MHIM(nn.Module):
         rows = None if rows_all is None else rows_all[:Lr]
         if ops.bag_wgrad_ok(x, dHbuf.shape[1], Lr):
             grads["feature.0.weight"], db1 = ops.bag_wgrad(dHbuf, saved["DACT"], x, rows, Lr, out_w=out.get("feature.0.weight"),
-                                                           out_b=out.get("feature.0.bias"), defer=defer)
+                                                           out_b=out.get("feature.0.bias"), defer=defer, accumulate=accumulate)
         else:
-            dpre, db1 = ops.rows_dpre(dHbuf, saved["DACT"], rows, Lr, colsum_out=out.get("feature.0.bias"), defer=defer)
+            dpre, db1 = ops.rows_dpre(dHbuf, saved["DACT"], rows, Lr, colsum_out=out.get("feature.0.bias"), defer=defer, accumulate=accumulate)
             grads["feature.0.weight"] = ops.gemm_tn(dpre, x, out=out.get("feature.0.weight"), rows=rows, splits=8 if Lr >= 2048 else 1,
-                                                    prec="bf16x3", M=Lr, defer=defer)
+                                                    prec="bf16x3", M=Lr, defer=defer, accumulate=accumulate)
         grads["feature.0.bias"] = db1
         return grads
 

@@ -160,6 +160,18 @@ def reduce_flush(lst: "ReduceList"):
     lst.keep.clear()
 
 
+def reduce_slabs_job(lst: "ReduceList", slabs, out, accumulate=True):
+    """Queue ``out (+)= sum_z slabs[z]`` (slabs [G, n] contiguous, out [n]) on a reduce list: a kind-1 job of mhimx_reduce_flush
+    (the public mhimx_reduce_list struct: any caller may append jobs)."""
+    _chk(slabs, name="slabs"); _chk(out, name="out")
+    G, n = slabs.shape
+    if lst.c.n >= L.REDUCE_MAX:
+        raise L.MhimxError("reduce list full")
+    lst.c.j[lst.c.n] = L.ReduceJob(kind=1, accumulate=int(bool(accumulate)), parts=_p(slabs), out=_p(out), G=G, W=0, ld=0, K1=1, K2=n, ldo=n)
+    lst.c.n += 1
+    lst.keep.append(slabs)
+
+
 def gemm_tn(a, b, out=None, rows=None, splits=1, accumulate=False, prec="bf16x3", M=None, defer=None):
     """out[i,j] = sum_m a[m,i] * b[rows[m] or m, j] — see mhimx_gemm_tn."""
     _chk(a, name="a"); _chk(b, name="b"); _chk(out, name="out"); _chk(rows, torch.int64, "rows")

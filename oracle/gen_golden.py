@@ -334,6 +334,55 @@ def g10_train_steps(ns):
           shuf0=shuffles[0], shuf1=shuffles[1], shuf2=shuffles[2], **arrays)
 
 
+def g18_train_accum8(ns):
+    """2 optimiser updates with --accumulation_steps 8 (16 bags), restated from base_engine.py:29,47-49,100-119,146-167 with the
+    reference MHIM modules: loss / 8 per bag, gradients accumulate, ONE torch.optim.Adam step and ONE EMA-teacher update per window;
+    Merge's in-forward EMA of the global queries runs bag after bag (merge.py:142-143).  SURVEY Appendix C, G10 'accumulation 8'."""
+    n, d, mm, acc = 300, 256, 0.9997, 8
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    t = _teacher(ns, synth.spread_teacher(base), d)
+    s = _teacher(ns, base, d)
+    opt = torch.optim.Adam([p for p in s.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5)
+    perms, shuffles, losses, logits_all, q_trace = [], [], [], [], []
+    opt.zero_grad()
+    xseeds, cand = [], 18000
+    for b in range(2 * acc):
+        k = int(np.ceil(n * 0.06))
+        while True:                                        # torch.topk's tie order is implementation-defined (SURVEY 0.7): only bags whose
+            x = _x(cand, n, d)                             # k-th and (k+1)-th teacher scores are clearly apart enter the fixture
+            cand += 1
+            feat, score = t.forward_teacher(x)
+            srt = np.sort(score[0].numpy())[::-1]
+            if srt[k - 1] - srt[k] > 2e-5:
+                break
+        xseeds.append(cand - 1)
+        label = torch.tensor([b % 2])
+        torch.manual_seed(300 + b)
+        perm = torch.randperm(k)
+        L = n - int(np.ceil(k * 0.5))
+        ids = torch.argsort(torch.rand(L), dim=0)
+        torch.manual_seed(300 + b)
+        logits, cls_loss, ps, keep = s(x, score, feat, i=b)
+        loss = torch.nn.functional.cross_entropy(logits.view(1, -1), label) + 0.5 * cls_loss
+        (loss / acc).backward()
+        perms.append(perm.numpy()); shuffles.append(ids.numpy()); losses.append(loss.item())
+        logits_all.append(logits[0].detach().numpy().copy())
+        q_trace.append(float(s.merge.global_q_mm.detach().norm()))
+        if (b + 1) % acc == 0:
+            opt.step()
+            opt.zero_grad()
+            with torch.no_grad():
+                for pq, pk in zip(s.parameters(), t.parameters()):
+                    pk.mul_(mm).add_(pq.detach(), alpha=1.0 - mm)
+    arrays = {}
+    for nm, mdl in (("stu", s), ("tea", t)):
+        arrays.update(_compact_all(nm, {k_: v.numpy() for k_, v in mdl.state_dict().items() if k_ != "merge.global_q"}))
+    for b in range(2 * acc):
+        arrays[f"perm{b}"], arrays[f"shuf{b}"] = perms[b], shuffles[b]
+    _save("g18_train_accum8", dict(seed=7, n=n, d=d, mm=mm, accum=acc, updates=2, xseed0=18000, aux_alpha=0.5, lr=2e-4, wd=1e-5, **V2),
+          losses=np.array(losses), logits=np.array(logits_all), q_norms=np.array(q_trace), xseeds=np.array(xseeds), **arrays)
+
+
 def g11_forward_func(ns):
     import types
     n, d = 257, 64
@@ -586,7 +635,7 @@ def main():
     torch.set_num_threads(8)
     only = set(sys.argv[1:])                     # python -m oracle.gen_golden g14_standalone_train  -> just that family
     for fn in (g1_abmil_eval, g2_abmil_train, g3_scorers, g4_teacher, g5_select, g6_student, g7_nystrom,
-               g8_sattention, g9_transmil_teacher, g10_train_steps, g11_forward_func, g12_cosine_scheduler, g13_dsmil,
+               g8_sattention, g9_transmil_teacher, g10_train_steps, g18_train_accum8, g11_forward_func, g12_cosine_scheduler, g13_dsmil,
                g14_standalone_train, g15_standalone_transmil, g16_student_eval, g17_standalone_options):
         if only and fn.__name__ not in only:
             continue

@@ -647,3 +647,65 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
     if "mask_ids" in ex:                                            # the rows the student kept (masking.py:107), before Merge's shuffle
         info["rows"] = np.asarray(ex["mask_ids"][:ex["len_keep_mask"]])
     return new_stu, new_tea, new_opt, info
+
+
+def train_window(xs, labels, stu, tea, opt_state, cfg: Cfg, step, perms=None, shuffles=None, aux_alpha=0.5, main_alpha=1.0, mm=0.9997,
+                 lr=2e-4, wd=1e-5, q_ema="sequential", score_overrides=None):
+    """One optimiser update over an accumulation window of len(xs) bags (--accumulation_steps; base_engine.py:29,47-49,100-102,
+    146-153): every bag's loss is divided by the window length and back-propagated into the same gradients, then ONE Adam step
+    and ONE EMA-teacher update (need_update, base_engine.py:47,109-119,155-167).  Dropout off.
+
+    q_ema: how the in-forward EMA of Merge's global queries (merge.py:142-143) composes inside the window:
+      "sequential"  the reference's single process: bag j sees the queries as left by bag j-1;
+      "window"      the batched contract: every bag of the window attends with the window's FIRST queries q0 (the
+                    k bags run through the same launches, nothing orders them), and the window ends with the same chain of EMA steps
+                    applied to the tokens z_j those forwards produced:  q <- mm^k q0 + (1 - mm) sum_j mm^(k-1-j) z_j.  Differs from
+                    "sequential" only through d z_j / d q over a query drift of <= k (1 - mm): second order in (1 - mm).
+    Returns (new_stu, new_tea, new_opt_state, info) with per-bag lists in info.
+    """
+    k = len(xs)
+    stu_g = {n: v.clone().requires_grad_(n not in TRAINABLE_EXCLUDE) for n, v in stu.items()}
+    q0 = stu["merge.global_q_mm"].clone() if "merge.global_q_mm" in stu else None
+    q_news, infos = [], {"logits": [], "loss": [], "cls_loss": [], "rows": [], "teacher_score": []}
+    for j, x in enumerate(xs):
+        with torch.no_grad():
+            t_feat, score = forward_teacher(x, tea, cfg)
+        if score_overrides is not None and score_overrides[j] is not None:
+            score = score_overrides[j]
+        t_in = None if aux_alpha == 0.0 else t_feat
+        logits, cls_loss, ps, keep, ex = forward_student(x, stu_g, cfg, score, t_in, None if perms is None else perms[j],
+                                                         None if shuffles is None else shuffles[j])
+        loss = (main_alpha * cross_entropy(logits, int(labels[j])) + aux_alpha * cls_loss) / k       # base_engine.py:99-102
+        loss.backward()
+        infos["logits"].append(logits.detach()); infos["loss"].append(float(loss.detach()) * k)
+        infos["cls_loss"].append(float(cls_loss.detach()) if torch.is_tensor(cls_loss) else float(cls_loss))
+        infos["teacher_score"].append(score)
+        if "mask_ids" in ex:
+            infos["rows"].append(np.asarray(ex["mask_ids"][:ex["len_keep_mask"]]))
+        if ex.get("global_q_new") is not None:
+            qn = ex["global_q_new"].reshape(q0.shape).detach()
+            q_news.append(qn)
+            if q_ema == "sequential":
+                with torch.no_grad():
+                    stu_g["merge.global_q_mm"].copy_(qn)
+    new_stu, new_opt = {}, {}
+    for n, p in stu_g.items():
+        if p.grad is None:
+            new_stu[n] = p.detach()
+            continue
+        m, v = opt_state.get(n, (torch.zeros_like(p), torch.zeros_like(p)))
+        pn, m, v = adam_step(p.detach(), p.grad, m, v, step, lr=lr, wd=wd)
+        new_stu[n], new_opt[n] = pn, (m, v)
+    if q_news:
+        if q_ema == "sequential":
+            new_stu["merge.global_q_mm"] = q_news[-1]
+        else:
+            g_mm = float(cfg.merge_mm)
+            q = q0.double()
+            for qn in q_news:                                # z_j = (q_new_j - mm q0) / (1 - mm): the tokens of bag j (merge.py:142)
+                z = (qn.double() - g_mm * q0.double()) / (1.0 - g_mm)
+                q = g_mm * q + (1.0 - g_mm) * z
+            new_stu["merge.global_q_mm"] = q.float()
+    new_tea = ema_update(tea, new_stu, mm)
+    infos["grads"] = {n: p.grad.detach() for n, p in stu_g.items() if p.grad is not None}
+    return new_stu, new_tea, new_opt, infos

@@ -274,6 +274,43 @@ def test_g10_train_steps():
             G.check_compact(sd[k].numpy(), exp, rtol=1e-5, atol=2e-6, what=f"{tag}:{k}")
 
 
+def test_g18_train_accum8():
+    """Two optimiser updates with accumulation_steps = 8 (base_engine.py:29,47-49,100-119): the oracle's window step with the
+    reference's sequential in-forward query EMA == the reference modules; the batched contract ("window": every bag attends with the
+    window's first queries, the same EMA chain runs on the tokens those forwards produced) differs in second order of (1 - merge_mm)."""
+    meta, a = G.load("g18_train_accum8")
+    base = synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_k=meta["merge_k"])
+    cfg = _cfg(meta)
+    acc = meta["accum"]
+    res = {}
+    for mode in ("sequential", "window"):
+        stu, tea, opt = O.as_torch(base), O.as_torch(synth.spread_teacher(base)), {}
+        for u in range(meta["updates"]):
+            bs = range(u * acc, (u + 1) * acc)
+            xs = [_x(int(a["xseeds"][b]), meta["n"], meta["d"]) for b in bs]
+            stu, tea, opt, info = O.train_window(xs, [b % 2 for b in bs], stu, tea, opt, cfg, u + 1, perms=[a[f"perm{b}"] for b in bs],
+                                                 shuffles=[a[f"shuf{b}"] for b in bs], aux_alpha=meta["aux_alpha"], mm=meta["mm"],
+                                                 lr=meta["lr"], wd=meta["wd"], q_ema=mode)
+            tol = 2e-5 if mode == "sequential" else 5e-5
+            for j, b in enumerate(bs):
+                assert abs(info["loss"][j] - float(a["losses"][b])) < tol, (mode, b, info["loss"][j], a["losses"][b])
+                np.testing.assert_allclose(info["logits"][j].numpy(), a["logits"][b], atol=tol, rtol=0)
+        res[mode] = (stu, tea)
+    for tag, sd in (("stu", res["sequential"][0]), ("tea", res["sequential"][1])):
+        for k, exp in G.tagged(a, tag).items():
+            # (Adam turns a rounding-level difference of a near-zero accumulated gradient into a fraction of lr = 2e-4)
+            G.check_compact(sd[k].numpy(), exp, rtol=1e-5, atol=3e-5, what=f"{tag}:{k}")
+    for tag, sd in (("stu", res["window"][0]), ("tea", res["window"][1])):          # two Adam steps of lr 2e-4 each: bound by a tenth of one
+        for k, exp in G.tagged(a, tag).items():
+            # Adam's first steps move a weight by ~lr whatever the size of its gradient: a near-zero accumulated gradient whose sign
+            # the second-order difference flips shows up as ~1.5 lr on that one element - bound the mean tightly, the worst case by 2 lr
+            got = sd[k].numpy().astype(np.float64).reshape(-1)
+            want = exp["full"].astype(np.float64).reshape(-1) if "full" in exp else exp["sample"].astype(np.float64)
+            got = got if "full" in exp else got[::int(exp["stride"])][:want.shape[0]]
+            err = np.abs(got - want)
+            assert err.mean() <= 5e-6 and err.max() <= 4.1e-4, (f"window {tag}:{k}", err.mean(), err.max())
+
+
 def test_g11_forward_func():
     """CommonMIL.forward_func 7-tuple pieces (common_mil.py:14-48) and validate_func (:56-68)."""
     meta, a = G.load("g11_forward_func")

@@ -1,0 +1,174 @@
+"""Accumulation windows (--accumulation_steps k: base_engine.py:29,47-49,100-119,146-167) on the fused trainer — GPU box only.
+
+(1) the sequential form (k train_step calls, one update) against the REFERENCE fixture g18 (accumulation 8, two updates);
+(2) the batched form (FusedTrainer.window_step: one preparation, the k bags issued over several HIP streams, one slab sum, one Adam + EMA)
+    against the oracle's window step on the row sets and teacher scores the device drew — per-bag logits, the accumulated gradients
+    before the update, parameters and global queries after it; one stream == several streams on identical draws;
+(3) the captured window (ONE hipGraph with the streams as branches), replayed, against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mhim_mil_amd import synth
+from oracle import mhim_oracle as O
+from tests import golden_util as G
+from tests.test_single_pass_gpu import _draws_from_device
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+V2 = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True,
+          merge_k=5, merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.0)
+
+
+def _mk(sd, d, **cfg):
+    from mhim_mil_amd.mhim import MHIM
+    m = MHIM(input_dim=d, n_classes=2, baseline="attn", **cfg)
+    sd = dict(sd)
+    sd["merge.global_q"] = sd["merge.global_q_mm"]
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m = m.to(DEV).train()
+    m.merge.dropout = 0.0
+    return m
+
+
+def _check_params(mdl, ref, mean_tol, max_tol, what):
+    sd = mdl.state_dict()
+    for name, r in ref.items():
+        if name == "merge.global_q":
+            continue
+        err = (sd[name].detach().cpu().double() - r.double()).abs()
+        assert err.mean().item() <= mean_tol and err.max().item() <= max_tol, (what, name, err.mean().item(), err.max().item())
+
+
+def test_sequential_accumulation_vs_reference_fixture():
+    """FusedTrainer(accumulation_steps=8) stepping bag after bag == the reference modules with --accumulation_steps 8 (fixture g18 from the
+    reference import: 16 bags, two optimiser updates, injected draws; Merge's query EMA runs bag after bag as in the reference)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    meta, a = G.load("g18_train_accum8")
+    d, n, acc = meta["d"], meta["n"], meta["accum"]
+    base = synth.mhim_state(meta["seed"], input_dim=d, merge_k=meta["merge_k"])
+    cfg = {k: meta[k] for k in V2}
+    s, t = _mk(base, d, **cfg), _mk(synth.spread_teacher(base), d, **cfg)
+    tr = FusedTrainer(s, t, lr=meta["lr"], weight_decay=meta["wd"], mm=meta["mm"], aux_alpha=meta["aux_alpha"], accumulation_steps=acc)
+    for b in range(meta["updates"] * acc):
+        x = torch.from_numpy(synth.bag(int(a["xseeds"][b]), n, d)).to(DEV)
+        logits, losses = tr.train_step(x[None], torch.tensor([b % 2], device=DEV), perm=torch.from_numpy(a[f"perm{b}"]).to(DEV),
+                                       ids_shuffle=torch.from_numpy(a[f"shuf{b}"]).to(DEV))
+        np.testing.assert_allclose(logits.cpu().numpy().ravel(), a["logits"][b].ravel(), atol=1e-4, rtol=0)
+        assert abs(float(losses[0]) - float(a["losses"][b])) < 3e-4, (b, float(losses[0]), a["losses"][b])
+    assert tr.flat.step == meta["updates"] and tr._micro == 0
+    for tag, mdl in (("stu", s), ("tea", t)):
+        sd = mdl.state_dict()
+        for k, exp in G.tagged(a, tag).items():
+            got = sd[k].detach().cpu().numpy().astype(np.float64).reshape(-1)
+            want = exp["full"].astype(np.float64).reshape(-1) if "full" in exp else exp["sample"].astype(np.float64)
+            got = got if "full" in exp else got[::int(exp["stride"])][:want.shape[0]]
+            err = np.abs(got - want)           # (Adam: a rounding-level difference on a near-zero gradient moves that element by ~lr)
+            assert err.mean() <= 5e-6 and err.max() <= 4.1e-4, (tag, k, err.mean(), err.max())
+
+
+def _window_vs_oracle(tr, s, t, bags, labels, stu, tea, opt, ocfg, step, n, k, n_sel, run):
+    """run() executes one window on the device; the draws it made are read back and handed to the oracle."""
+    run()
+    torch.cuda.synchronize()
+    per = tr.last["bags"]
+    perms, shufs, scores = [], [], []
+    for j in range(len(bags)):
+        rows, score = per[j]["rows"].cpu().numpy(), per[j]["score"].cpu().numpy()
+        p, sh = _draws_from_device(score, rows, per[j]["R"], n, k, n_sel)
+        perms.append(p); shufs.append(sh); scores.append(torch.from_numpy(score))
+    stu2, tea2, opt2, info = O.train_window(bags, labels, stu, tea, opt, ocfg, step, perms=perms, shuffles=shufs, q_ema="window",
+                                            score_overrides=scores, mm=tr.mm)
+    for j in range(len(bags)):
+        np.testing.assert_allclose(per[j]["logits"].cpu().numpy().ravel(), info["logits"][j].numpy().ravel(), atol=1e-4, rtol=0)
+        assert abs(float(per[j]["losses"][0]) - info["loss"][j]) < 3e-4
+    return stu2, tea2, opt2, info
+
+
+@pytest.mark.parametrize("n_streams", [1, 3])
+def test_window_step_vs_oracle(n_streams):
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d, acc = 2100, 256, 4
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+    s, t = _mk(base, d, **V2), _mk(tsd, d, **V2)
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997, accumulation_steps=acc)
+    ocfg = O.Cfg(**V2)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    stu, tea, opt = O.as_torch(base), O.as_torch(tsd), {}
+    for u in range(2):
+        bags = [torch.from_numpy(synth.bag(500 + 10 * u + j, n, d)) for j in range(acc)]
+        labels = [(u + j) % 2 for j in range(acc)]
+        xs = [b.to(DEV)[None] for b in bags]
+        ls = [torch.tensor([l], device=DEV) for l in labels]
+        stu, tea, opt, info = _window_vs_oracle(tr, s, t, bags, labels, stu, tea, opt, ocfg, u + 1, n, k, n_sel,
+                                                lambda: tr.window_step(xs, ls, n_streams=n_streams, update=False))
+        gv = tr.flat.grad_views
+        for name, ref in info["grads"].items():                          # the accumulated gradient of the window, before the update
+            g, r = gv[name].cpu().numpy(), ref.numpy()
+            np.testing.assert_allclose(g, r.reshape(g.shape), atol=2e-3 * (np.abs(r).max() + 1e-30), rtol=2e-3, err_msg=name)
+        tr.update()
+        torch.cuda.synchronize()
+        _check_params(s, stu, 3e-6, 4.1e-4 * (u + 1), f"student, window {u}")
+        _check_params(t, tea, 1e-6, 2e-6, f"teacher, window {u}")
+        np.testing.assert_allclose(s.merge.global_q_mm.detach().cpu().numpy(), stu["merge.global_q_mm"].numpy(), atol=2e-6, rtol=0)
+        # keep the two sides on the oracle's trajectory (Adam's first steps amplify rounding on a few elements)
+        s.load_state_dict({**stu, "merge.global_q": stu["merge.global_q_mm"]})
+        t.load_state_dict({**tea, "merge.global_q": tea["merge.global_q_mm"]})
+
+
+def test_window_streams_do_not_change_the_result():
+    """The same window on 1 stream and on 4: identical draws (the seeds do not depend on the stream), bit-identical per-bag logits, the
+    accumulated gradient equal up to the order of the slab sum."""
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d, acc = 1500, 256, 8
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    cfg = dict(V2, dropout=0.25)
+    xs = [torch.from_numpy(synth.bag(900 + j, n, d)).to(DEV)[None] for j in range(acc)]
+    ls = [torch.tensor([j % 2], device=DEV) for j in range(acc)]
+    res = []
+    for S in (1, 4):
+        torch.manual_seed(5)
+        s, t = _mk(base, d, **cfg), _mk(synth.spread_teacher(base), d, **cfg)
+        tr = FusedTrainer(s, t, accumulation_steps=acc)
+        logits, _ = tr.window_step(xs, ls, n_streams=S, update=False)
+        torch.cuda.synchronize()
+        res.append((torch.stack(logits).cpu(), [b["rows"].cpu() for b in tr.last["bags"]], tr.flat.grad.cpu().clone(),
+                    s.merge.global_q_mm.detach().cpu().clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    g0, g1 = res[0][2].numpy(), res[1][2].numpy()
+    np.testing.assert_allclose(g0, g1, atol=2e-6 * np.abs(g0).max(), rtol=1e-4)
+    assert torch.equal(res[0][3], res[1][3])
+
+
+def test_captured_window_replays_vs_oracle():
+    """capture_window: the whole window (prep, 8 bags on 4 streams, slab sum, query chain, Adam + EMA) as ONE hipGraph; a replay from a
+    restored state against the oracle's window step, then a second replay advances the state again (fresh draws: the device tick)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d, acc = 2100, 256, 8
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+    s, t = _mk(base, d, **V2), _mk(tsd, d, **V2)
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997, accumulation_steps=acc)
+    bags = [torch.from_numpy(synth.bag(700 + j, n, d)) for j in range(acc)]
+    labels = [j % 2 for j in range(acc)]
+    xs = [b.to(DEV)[None] for b in bags]
+    ls = [torch.tensor([l], device=DEV) for l in labels]
+    snap = [tr.flat.student.clone(), tr.flat.teacher.clone(), tr.flat.m.clone(), tr.flat.v.clone(), tr.opt_step.clone(), tr.tick.clone(), tr.flat.step]
+    g = tr.capture_window(xs, ls, warmup=1, n_streams=4)
+    tr.flat.student.copy_(snap[0]); tr.flat.teacher.copy_(snap[1]); tr.flat.m.copy_(snap[2]); tr.flat.v.copy_(snap[3])
+    tr.opt_step.copy_(snap[4]); tr.tick.copy_(snap[5]); tr.flat.step = snap[6]
+    tr.flat.grad.zero_()
+    ocfg = O.Cfg(**V2)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    stu, tea, opt, _ = _window_vs_oracle(tr, s, t, bags, labels, O.as_torch(base), O.as_torch(tsd), {}, ocfg, 1, n, k, n_sel, g.replay)
+    _check_params(s, stu, 3e-6, 4.1e-4, "student after the replayed window")
+    _check_params(t, tea, 1e-6, 2e-6, "teacher after the replayed window")
+    rows0 = [b["rows"].clone() for b in tr.last["bags"]]
+    w0 = s.feature[0].weight.detach().clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(w0, s.feature[0].weight.detach()) and torch.isfinite(tr.flat.student).all()
+    assert any(not torch.equal(a, b["rows"]) for a, b in zip(rows0, tr.last["bags"])), "the second replay drew the same random subsets"
