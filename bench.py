@@ -8,6 +8,12 @@ One "step" = one complete train step on one synthetic bag per rank (N=10 000 ins
 teacher forward + hard-instance select + student forward + CE/distillation head + backward + [RCCL all-reduce of
 the flat gradient buffer] + fused Adam + EMA teacher.  Bags are resident in HBM before the timed region (8 distinct
 bags per rank = 328 MB > the 256 MB Infinity Cache, rotated).  Rank 0 prints ONE JSON line.
+
+The default one-GPU run also carries, inside the same JSON line (each with its own short, fixed step count):
+  "accumulate8"      the same step with --accumulation_steps 8 as ONE captured window (FusedTrainer.capture_window): ms per bag;
+  "hbm_copy"         the on-box float4 stream-copy rate (GB/s read + written) beside the nominal 8 TB/s;
+  "other_workloads"  c3 (MHIM(TransMIL) N=50k) and c5 (one bag N=200k D=1536, the sharded code path at world 1), each with its
+                     roofline figure and a one-step cpu_baseline.   --no-extras skips all three.
 """
 from __future__ import annotations
 
@@ -41,6 +47,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--dp-graph", action="store_true",
                     help="N > 1: replay graph(fwd+bwd) | all-reduce | graph(Adam) instead of eager steps whose all-reduce overlaps the backward")
+    ap.add_argument("--no-extras", action="store_true", help="c2, one GPU: skip the accumulate8 / hbm_copy / other_workloads legs")
+    ap.add_argument("--window-streams", type=int, default=4, help="HIP streams of the accumulate-8 window")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil"],
                     help="c2 (default, BASELINE.json's metric): MHIM(ABMIL) N=10k D=1024, one bag per GPU per step; "
                          "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs; "
@@ -68,7 +76,8 @@ def cpu_baseline(steps, base):
     import numpy as np
     from mhim_mil_amd import synth
     from oracle import mhim_oracle as O
-    cfg = O.Cfg(**{**CFG, "dropout": 0.0})
+    cfg = O.Cfg(**CFG)                       # dropout 0.25 as BASELINE.md section 3 has it: the masks are drawn by torch's CPU dropout
+    O.DRAW_DROPOUT = True
     stu, tea, opt = O.as_torch(base), O.as_torch(base), {}
     x = torch.from_numpy(synth.bag(4242, N_INST, D_IN))
     k, n_sel, _ = O.mask_count(N_INST, CFG["mask_ratio_h"], CFG["mask_ratio_hr"])
@@ -99,14 +108,15 @@ def cpu_baseline(steps, base):
     dt = time.perf_counter() - t0
     return {"value": N_INST * done / dt, "unit": "patch-instances/s", "cores": cores, "kind": "port",
             "sample": f"{done} oracle train steps (torch CPU fp32, {cores} threads = best of an 8/16/32/64 sweep on a "
-                      f"{ncpu}-thread host, dropout off) on one N={N_INST} D={D_IN} bag, {dt:.1f} s"}
+                      f"{ncpu}-thread host, dropout 0.25 drawn by torch) on one N={N_INST} D={D_IN} bag, {dt:.1f} s"}
 
 
 def cpu_baseline_other(workload, base, n, d, bl):
     """c3 / c5 / c2-dsmil: ONE oracle train step of the same configuration on the host cores (a bounded sample: 10-40 s)."""
     from mhim_mil_amd import synth
     from oracle import mhim_oracle as O
-    cfg = O.Cfg(**{**CFG, "dropout": 0.0, "baseline": bl})
+    cfg = O.Cfg(**{**CFG, "baseline": bl})
+    O.DRAW_DROPOUT = True
     stu, tea = O.as_torch(base), O.as_torch(base)
     x = torch.from_numpy(synth.bag(4242, n, d))
     k, n_sel, _ = O.mask_count(n, CFG["mask_ratio_h"], CFG["mask_ratio_hr"])
@@ -117,7 +127,7 @@ def cpu_baseline_other(workload, base, n, d, bl):
     O.train_step(x, 1, stu, tea, {}, cfg, 1, perm=perm, ids_shuffle=shuf)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "patch-instances/s", "cores": cores, "kind": "port",
-            "sample": f"1 oracle train step (torch CPU fp32, {cores} threads, dropout off, no warm-up) on one N={n} D={d} bag, {dt:.1f} s"}
+            "sample": f"1 oracle train step (torch CPU fp32, {cores} threads, dropout 0.25 drawn by torch, no warm-up) on one N={n} D={d} bag, {dt:.1f} s"}
 
 
 def timed(a, world, dev, step):
@@ -143,8 +153,9 @@ def timed(a, world, dev, step):
     return dt
 
 
-def other_workload(a, world, rank, dev):
-    """c3 / c5: parity-test configurations of BASELINE.json, timed for DESIGN.md (not the headline metric)."""
+def other_workload(a, world, rank, dev, embedded=False):
+    """c3 / c5: parity-test configurations of BASELINE.json (not the headline metric).  Returns rank 0's result dict (None elsewhere);
+    ``embedded``: called from the default c2 run with its own short step counts."""
     from mhim_mil_amd import synth
     from mhim_mil_amd.mhim import MHIM
     c3 = a.workload in ("c3", "c2-dsmil")                 # replicas driven by FusedTrainer's autograd path
@@ -206,16 +217,99 @@ def other_workload(a, world, rank, dev):
                                  "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
                                  "frac_counting_3_bf16_terms": 3 * tf / 2500.0, "traffic": None,
                                  "algorithmic_flops_per_instance": 38e6}
+        else:
+            hb = extra["whole_step_hbm_roofline"]
+            extra["roofline"] = {"kernel": "whole step (projection + weight-gradient GEMMs 63 %, scorer passes, select, Merge)", "bound": "hbm",
+                                 "achieved": hb["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb["frac_of_8TBps"], "traffic": None,
+                                 "algorithmic_bytes_per_instance": algo}
         if world == 1 and a.cpu_steps > 0:
             extra["cpu_baseline"] = cpu_baseline_other(a.workload, base, n_total, d, bl)
-        print(json.dumps({
+        return {
             **extra,
             "metric": f"patch-instances/sec through MHIM fwd+bwd ({a.workload})", "value": per_step * a.steps / dt,
             "unit": "patch-instances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic |N(0,1)| bags resident in HBM, random-init weights (reference init law)",
             "config": {"workload": name, "parallelism": par, "dropout": CFG["dropout"],
-                       "launch": ("hipGraph replay" if not a.no_graph else "eager") if c3 else c5_launch}}), flush=True)
+                       "launch": ("hipGraph replay" if not a.no_graph else "eager") if c3 else c5_launch}}
+    return None
+
+
+def hbm_copy_rate(dev):
+    """On-box stream-copy microbenchmark ('confirm with a copy microbenchmark on the box'): 1 GiB float4 copy through the
+    library's own kernel, HIP events, best of 5; bytes = read + written."""
+    from mhim_mil_amd import ops
+    n = 1 << 28
+    src, dst = torch.empty(n, device=dev).normal_(), torch.empty(n, device=dev)
+    best = 1e30
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.stream_copy(src, dst)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return {"GBps": 2 * n * 4 / (best * 1e-3) / 1e9, "bytes_moved": 2 * n * 4, "best_ms": best, "nominal_peak_GBps": HBM_PEAK_GBS,
+            "kernel": "mhimx_stream_copy (float4 grid-stride copy, 1 GiB -> 1 GiB: far beyond the 256 MB Infinity Cache)"}
+
+
+def accumulate8(a, dev, bags, labels):
+    """--accumulation_steps 8 (base_engine.py:29,100-119; SURVEY 8(d) c4: 'also report accumulate-8'): one optimiser update per 8 bags,
+    the window captured as ONE hipGraph (FusedTrainer.capture_window: one preparation, the 8 bags on HIP streams, one Adam + EMA)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    K, reps, warm = 8, 12, 3
+    student, teacher, _ = make_models(dev, a.prec)
+    tr = FusedTrainer(student, teacher, aux_alpha=0.5, mm=0.9997, accumulation_steps=K)
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)
+    more = [torch.randn(N_INST, D_IN, device=dev, generator=g).abs_() for _ in range(K)]     # second window: 16 distinct bags = 655 MB
+    sets = [(bags[:K], labels[:K]), (more, labels[:K])]
+    if a.no_graph:
+        run = [lambda b=b, l=l: tr.window_step(b, l, n_streams=a.window_streams) for b, l in sets]
+        launch = "eager"
+    else:
+        wins = [tr.capture_window(b, l, warmup=1, n_streams=a.window_streams) for b, l in sets]
+        run = [w.replay for w in wins]
+        launch = "ONE hipGraph per window, the HIP streams as its branches"
+    for i in range(warm):
+        run[i % 2]()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        run[i % 2]()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": N_INST * K / dt, "unit": "patch-instances/s", "ms_per_bag": 1e3 * dt / K, "ms_per_window": 1e3 * dt, "bags_per_update": K,
+            "windows_timed": reps, "warmup_windows": warm, "streams": a.window_streams, "launch": launch,
+            "whole_step_hbm_roofline_frac_of_8TBps": N_INST * K / dt * ALGO_BYTES_PER_INST_STEP / 1e9 / HBM_PEAK_GBS,
+            "semantics": "reference --accumulation_steps 8: loss/8 per bag, gradients summed, one Adam + EMA per window; Merge's query EMA "
+                         "chained over the window's tokens (every bag attends with the window's first queries: second order in 1 - merge_mm)"}
+
+
+def run_extras(a, dev, bags, labels):
+    """The legs the default one-GPU run adds to the headline line; each catches its own failure so the headline always prints."""
+    import copy
+    out = {}
+    for name, fn in (("hbm_copy", lambda: hbm_copy_rate(dev)), ("accumulate8", lambda: accumulate8(a, dev, bags, labels))):
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        torch.cuda.synchronize()
+    others = {}
+    for wl, steps, warm in (("c3", 8, 2), ("c5", 12, 3)):
+        b = copy.copy(a)
+        b.workload, b.steps, b.warmup = wl, steps, warm
+        try:
+            torch.cuda.empty_cache()
+            r = other_workload(b, 1, 0, dev, embedded=True)
+            others[wl] = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "roofline", "whole_step_hbm_roofline",
+                                            "cpu_baseline", "config") if k in r}
+        except Exception as e:  # noqa: BLE001
+            others[wl] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        torch.cuda.synchronize()
+    out["other_workloads"] = others
+    return out
 
 
 def main():
@@ -239,7 +333,9 @@ def main():
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if a.workload != "c2":
-        other_workload(a, world, rank, dev)
+        res = other_workload(a, world, rank, dev)
+        if res is not None:
+            print(json.dumps(res), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -311,6 +407,10 @@ def main():
         events_from = f"an eager pass of {min(a.steps, 20)} steps right after the timed region (graph nodes cannot carry host events)"
     ops.KERNEL_EVENT_HOOK = None
 
+    extras = {}
+    if world == 1 and not a.no_extras:
+        extras = run_extras(a, dev, bags, labels)
+
     if rank == 0:
         value = N_INST * a.steps * world / dt
         out = {
@@ -333,25 +433,39 @@ def main():
         if ev:
             ms = [e0.elapsed_time(e1) for e0, e1 in ev]
             avg = sum(ms) / len(ms)
-            # D*4 B per instance for one forward pass over X; this ONE launch is the teacher's pass AND the student's
-            # pass of the step's byte budget (3 passes: teacher fwd, student fwd, weight-gradient bwd) - X itself is read once
-            algo = 2 * N_INST * D_IN * 4
-            ach = algo / (avg * 1e-3) / 1e9
+            # The binding roofline of this kernel is the MATRIX CORE, not HBM: it issues 3 bf16 MFMA terms per product (fp32-class accuracy
+            # for the instance scores that feed a top-k) = 3 x 2 x N x D x 1024 flop per launch against 2.5 PFLOP/s dense bf16; its HBM
+            # floor (X read ONCE + 2 weight images + H_teacher, H_student fp32 + fp16 d out/d pre written) is ~12 us of the ~72.
+            flops_bf16 = 3 * 2.0 * N_INST * D_IN * 1024
+            tf = flops_bf16 / (avg * 1e-3) / 1e12
+            read_once = N_INST * D_IN * 4 + 2 * 512 * D_IN * 4
+            written = 2 * N_INST * 512 * 4 + N_INST * 512 * 2
+            budget = 2 * N_INST * D_IN * 4        # SURVEY 8(d) credits this launch with TWO of the step's three passes over X
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc.sh + tools/pmc_project.py; counters cannot be read from inside the process being timed)
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_bag_project.json")
-            if os.path.exists(pmc):
-                pj = json.load(open(pmc))
-                traffic, tsrc = pj["traffic_bytes"], ("profiles/r02_pmc_bag_project.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
-                                                      f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
-                                                      f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
+            for pmc_name in ("r03_pmc_bag_project.json", "r02_pmc_bag_project.json"):
+                pmc = os.path.join(ROOT, "profiles", pmc_name)
+                if os.path.exists(pmc):
+                    pj = json.load(open(pmc))
+                    traffic, tsrc = pj["traffic_bytes"], (f"profiles/{pmc_name}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                                                          f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
+                                                          f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
+                    break
             out["roofline"] = {"kernel": "bag_project_kernel (teacher AND student feature projection X[N,D] -> 2 x H[N,512] in one pass over the raw fp32 bag, 3-term bf16 MFMA, fused bias+GELU+dropout, fp16 d out/d pre)",
-                               "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "avg_kernel_ms": avg, "launches_timed": len(ms), "hip_events_over": events_from,
-                               "algorithmic_bytes_per_launch": algo,
-                               "algorithmic_bytes_note": "two of the step's three budgeted passes over X (teacher forward + student forward, 4096 B/instance each) are this one launch",
-                               "mfma_TFLOPs_fp32_equivalent": 2.0 * N_INST * D_IN * 1024 / (avg * 1e-3) / 1e12}
+                               "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                               "flops_note": "bf16 MFMA flop actually issued: 3 terms (hi*hi + hi*lo + lo*hi) x 2 N D 1024; fp32-equivalent = a third",
+                               "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "avg_kernel_ms": avg,
+                               "launches_timed": len(ms), "hip_events_over": events_from,
+                               "hbm": {"basis": "bytes the launch must move: X read once + both weight images + H_teacher, H_student (fp32) and d out/d pre (fp16) written",
+                                       "bytes_per_launch": read_once + written, "achieved_GBps": (read_once + written) / (avg * 1e-3) / 1e9,
+                                       "frac_of_8TBps": (read_once + written) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "read_only_bytes": read_once, "read_only_frac_of_8TBps": read_once / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                               "hbm_budget_basis": {"basis": "SURVEY 8(d) algorithmic budget: two of the step's three passes over X (teacher fwd + student fwd, 4096 B/instance each) are this one launch",
+                                                    "bytes_per_launch": budget, "achieved_GBps": budget / (avg * 1e-3) / 1e9,
+                                                    "frac_of_8TBps": budget / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                               "hbm_copy_peak_GBps_measured": (extras.get("hbm_copy") or {}).get("GBps")}
+        out.update(extras)
         if world == 1 and a.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps, base)
         print(json.dumps(out), flush=True)

@@ -539,6 +539,31 @@ int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, f
                    const float* mm_table, int64_t mm_len /* optional device table: EMA momentum of iteration `step`
                                                            (the reference's cosine `mm_sche`, base_engine.py:160-161) */);
 
+/* The same update with the trainer's optional pieces, all device-side so that a captured hipGraph keeps stepping them:
+ *  lr_table   per-update learning-rate schedule (train_utils.py:69-77 builds it, base_engine.py:152-153 steps it once per update):
+ *             the update with Adam step t uses lr_table[min(t - 1, lr_len - 1)]; NULL: the constant `lr`;
+ *  g_extra    n_extra gradient slabs (slab z at g_extra + z * extra_pitch) added to g before anything else, in slab order: the other
+ *             streams of an accumulation window (--accumulation_steps, base_engine.py:29,100-102) accumulate into their own slabs;
+ *  clip_norm  > 0: torch.nn.utils.clip_grad_norm_(parameters, clip_norm) on the scaled, summed gradient, i.e. --clip_grad
+ *             (base_engine.py:115-119, timm dispatch_clip_grad mode 'norm'): g *= min(1, clip_norm / (||g||_2 + 1e-6)); one extra
+ *             launch (per-block sums of squares into ws, >= 1024 floats), the final sum in every block of the update in a fixed order. */
+typedef struct {
+  float* p; float* g; float* m; float* v; float* teacher;
+  int64_t n_train, n_all;
+  int64_t step; const uint64_t* step_dev;
+  float lr; const float* lr_table; int64_t lr_len;
+  float beta1, beta2, eps, weight_decay, grad_scale;
+  float ema_mm; const float* mm_table; int64_t mm_len;
+  int32_t zero_grad;
+  const float* g_extra; int64_t n_extra; int64_t extra_pitch;
+  float clip_norm;
+  float* ws; int64_t ws_floats;
+} mhimx_optim_args;
+int mhimx_optim_step(void* stream, const mhimx_optim_args* a);
+
+/* dst = src (float4 grid-stride stream copy): the on-box HBM copy rate bench.py reports beside the nominal 8 TB/s */
+int mhimx_stream_copy(void* stream, const float* src, float* dst, int64_t n_floats);
+
 /* *counter += 1 (device-resident step counters for dropout streams / Adam under hipGraph replay) */
 int mhimx_tick(void* stream, uint64_t* counter);
 

@@ -140,6 +140,17 @@ class Nys(C.Structure):
                 ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
 
 
+class OptimArgs(C.Structure):
+    """mhimx_optim_args (include/mhimx.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("teacher", C.c_void_p),
+                ("n_train", C.c_int64), ("n_all", C.c_int64), ("step", C.c_int64), ("step_dev", C.c_void_p),
+                ("lr", C.c_float), ("lr_table", C.c_void_p), ("lr_len", C.c_int64),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float),
+                ("ema_mm", C.c_float), ("mm_table", C.c_void_p), ("mm_len", C.c_int64), ("zero_grad", C.c_int32),
+                ("g_extra", C.c_void_p), ("n_extra", C.c_int64), ("extra_pitch", C.c_int64), ("clip_norm", C.c_float),
+                ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
+
+
 SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
@@ -190,6 +201,8 @@ SYMBOLS = {
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P, _P, _I64]),
+    "mhimx_optim_step": (C.c_int, [_P, C.POINTER(OptimArgs)]),
+    "mhimx_stream_copy": (C.c_int, [_P, _P, _P, _I64]),
     "mhimx_tick": (C.c_int, [_P, _P]),
     "mhimx_layernorm_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "mhimx_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),

@@ -155,6 +155,29 @@ __global__ __launch_bounds__(HEAD_THREADS) void dsmil_head_kernel(const float* _
   }
 }
 
+// optional parts of an optimiser step (mhimx_optim_step): learning-rate table, gradient slabs to add, global-norm clipping
+struct OptimExtra { const float* lr_table; int64_t lr_len; const float* g_extra; int64_t n_extra, extra_pitch; float clip_norm;
+                    const float* sq_parts; int n_parts; };
+
+// per-block partial sums of squares of the (scaled, slab-summed) gradient: the first stage of clip_grad_norm_ (base_engine.py:115-119)
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float gscale, OptimExtra ex, float* __restrict__ parts) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = g[i];
+    for (int64_t z = 0; z < ex.n_extra; ++z) v += ex.g_extra[z * ex.extra_pitch + i];
+    v *= gscale;
+    a += v * v;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = red[0];
+}
+
 // torch.optim.Adam semantics (weight decay folded into the gradient, bias-corrected, eps outside the sqrt of
 // the corrected second moment) + EMA teacher.  bc1 = 1-beta1^t, bc2s = sqrt(1-beta2^t) come from the host in fp64.
 MHIMX_DEV void adam_one(float& w, float& gi, float& mi, float& vi, float lr_over_bc1, float bc2s, float beta1, float beta2,
@@ -169,16 +192,38 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
     float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ teacher,
     int64_t n_train, int64_t n_all, float lr_over_bc1, float bc2s, float beta1, float beta2, float eps, float wd, float gscale,
     float mm, int zero_grad, const uint64_t* __restrict__ step_dev, float lr, const float* __restrict__ mm_table, int64_t mm_len,
-    int64_t step_host, double ln_beta1, double ln_beta2) {
-  __shared__ float sc[3];
+    int64_t step_host, double ln_beta1, double ln_beta2, OptimExtra ex) {
+  __shared__ float sc[4];
+  __shared__ float clip_red[256];
+  if (ex.clip_norm > 0.f) {             // clip_grad_norm_: every block sums the per-block partial sums of squares in the same fixed order
+    float a = 0.f;
+    for (int i = threadIdx.x; i < ex.n_parts; i += 256) a += ex.sq_parts[i];
+    clip_red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) clip_red[threadIdx.x] += clip_red[threadIdx.x + o];
+      __syncthreads();
+    }
+  }
   if (threadIdx.x == 0) {               // the fp64 pow()s of the bias corrections: once per block, not once per thread
     int64_t step = step_host;
-    if (step_dev) {                     // graph replay: the step count lives on the device
-      step = (int64_t)step_dev[0];
+    if (step_dev) step = (int64_t)step_dev[0];      // graph replay: the step count lives on the device
+    if (ex.lr_table) {                  // per-update learning-rate schedule: entry of this update, last one held
+      int64_t i = step - 1;
+      i = i < 0 ? 0 : (i >= ex.lr_len ? ex.lr_len - 1 : i);
+      lr = ex.lr_table[i];
+    }
+    if (step_dev || ex.lr_table) {
       const double t = (double)step;
       lr_over_bc1 = (float)((double)lr / (1.0 - exp(t * ln_beta1)));       // beta^t = e^(t ln beta), ln beta from the host in fp64
       bc2s = (float)sqrt(1.0 - exp(t * ln_beta2));
     }
+    float coef = 1.f;
+    if (ex.clip_norm > 0.f) {           // torch.nn.utils.clip_grad_norm_: g *= min(1, max_norm / (total_norm + 1e-6))
+      coef = ex.clip_norm / (sqrtf(clip_red[0]) + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+    }
+    sc[3] = coef;
     if (mm_table) {                     // EMA momentum schedule (base_engine.py:160-161): entry of this iteration, last one held
       int64_t i = step - 1;
       i = i < 0 ? 0 : (i >= mm_len ? mm_len - 1 : i);
@@ -190,6 +235,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
   lr_over_bc1 = sc[0];
   bc2s = sc[1];
   mm = sc[2];
+  gscale *= sc[3];
   const int64_t n4 = n_all / 4;
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                         reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(teacher)) & 15) == 0;
@@ -199,6 +245,10 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
       float4 w = reinterpret_cast<float4*>(p)[q];
       if (i0 < n_train) {
         float4 gi = reinterpret_cast<float4*>(g)[q], mi = reinterpret_cast<float4*>(m)[q], vi = reinterpret_cast<float4*>(v)[q];
+        for (int64_t z = 0; z < ex.n_extra; ++z) {       // gradient slabs of the other streams of an accumulation window (fixed order)
+          const float4 e = *reinterpret_cast<const float4*>(ex.g_extra + z * ex.extra_pitch + i0);
+          gi.x += e.x; gi.y += e.y; gi.z += e.z; gi.w += e.w;
+        }
         adam_one(w.x, gi.x, mi.x, vi.x, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
         adam_one(w.y, gi.y, mi.y, vi.y, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
         adam_one(w.z, gi.z, mi.z, vi.z, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
@@ -220,6 +270,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
       float w = p[i];
       if (i < n_train) {
         float gi = g[i], mi = m[i], vi = v[i];
+        for (int64_t z = 0; z < ex.n_extra; ++z) gi += ex.g_extra[z * ex.extra_pitch + i];
         adam_one(w, gi, mi, vi, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
         m[i] = mi;
         v[i] = vi;
@@ -259,20 +310,65 @@ extern "C" int mhimx_dsmil_head(void* stream, const float* logits_bag, const flo
   return 0;
 }
 
+extern "C" int mhimx_optim_step(void* stream, const mhimx_optim_args* a) {
+  MHIMX_CHECK_ARG(a, "optim_step: null args");
+  MHIMX_CHECK_ARG(!a->mm_table || a->mm_len > 0, "optim_step: empty momentum schedule");
+  MHIMX_CHECK_ARG(!a->lr_table || a->lr_len > 0, "optim_step: empty learning-rate schedule");
+  MHIMX_CHECK_ARG(a->p && a->g && a->m && a->v && a->n_train >= 0 && a->n_all >= a->n_train && (a->step >= 1 || a->step_dev), "optim_step: bad args");
+  MHIMX_CHECK_ARG(a->n_extra >= 0 && (a->n_extra == 0 || (a->g_extra && a->extra_pitch >= a->n_train && a->extra_pitch % 4 == 0 && aligned16(a->g_extra))),
+                  "optim_step: gradient slabs need a 16-byte aligned base and a pitch >= n_train that is a multiple of 4");
+  MHIMX_CHECK_ARG(!(a->clip_norm > 0.f) || (a->ws && a->ws_floats >= 1024), "optim_step: clipping needs a workspace of 1024 floats");
+  int64_t step = a->step < 1 ? 1 : a->step;
+  if (a->n_all == 0) return 0;
+  OptimExtra ex{a->lr_table, a->lr_len, a->g_extra, a->n_extra, a->extra_pitch, a->clip_norm > 0.f ? a->clip_norm : 0.f, a->ws, 0};
+  if (ex.clip_norm > 0.f && a->n_train > 0) {
+    const int64_t nb = cdiv(a->n_train, 1024) < 1024 ? cdiv(a->n_train, 1024) : 1024;
+    ex.n_parts = (int)nb;
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a->g, a->n_train, a->grad_scale, ex, a->ws);
+    MHIMX_LAUNCH_CHECK();
+  } else {
+    ex.clip_norm = 0.f;
+  }
+  const double bc1 = 1.0 - pow((double)a->beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)a->beta2, (double)step);
+  const int64_t blocks = cdiv(a->n_all, 1024) < 2048 ? cdiv(a->n_all, 1024) : 2048;
+  hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v,
+                     a->teacher, a->n_train, a->n_all, (float)((double)a->lr / bc1), (float)sqrt(bc2), a->beta1, a->beta2, a->eps, a->weight_decay,
+                     a->grad_scale, a->ema_mm, a->zero_grad, a->step_dev, a->lr, a->mm_table, a->mm_len, step, log((double)a->beta1),
+                     log((double)a->beta2), ex);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, float* teacher, int64_t n_train,
                               int64_t n_all, int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                               float grad_scale, float ema_mm, int32_t zero_grad, const uint64_t* step_dev,
                               const float* mm_table, int64_t mm_len) {
-  MHIMX_CHECK_ARG(!mm_table || mm_len > 0, "adam_ema: empty momentum schedule");
-  MHIMX_CHECK_ARG(p && g && m && v && n_train >= 0 && n_all >= n_train && (step >= 1 || step_dev), "adam_ema: bad args");
-  if (step < 1) step = 1;
-  if (n_all == 0) return 0;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const int64_t blocks = cdiv(n_all, 1024) < 2048 ? cdiv(n_all, 1024) : 2048;
-  hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, const_cast<float*>(g), m, v,
-                     teacher, n_train, n_all, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, weight_decay,
-                     grad_scale, ema_mm, zero_grad, step_dev, lr, mm_table, mm_len, step, log((double)beta1), log((double)beta2));
+  mhimx_optim_args a{};
+  a.p = p; a.g = const_cast<float*>(g); a.m = m; a.v = v; a.teacher = teacher; a.n_train = n_train; a.n_all = n_all; a.step = step;
+  a.step_dev = step_dev; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.grad_scale = grad_scale;
+  a.ema_mm = ema_mm; a.mm_table = mm_table; a.mm_len = mm_len; a.zero_grad = zero_grad;
+  return mhimx_optim_step(stream, &a);
+}
+
+// float4 grid-stride copy: the on-box HBM stream rate bench.py prints beside the 8 TB/s nominal peak
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  // four 16-byte loads in flight per lane (1 KiB per wave-instruction, 4 KiB per wave), then the four stores
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+extern "C" int mhimx_stream_copy(void* stream, const float* src, float* dst, int64_t n_floats) {
+  MHIMX_CHECK_ARG(src && dst && n_floats >= 0 && n_floats % 4 == 0 && aligned16(src) && aligned16(dst), "stream_copy: 16-byte aligned buffers, n % 4 == 0");
+  if (n_floats == 0) return 0;
+  const int64_t n4 = n_floats / 4;
+  const int64_t blocks = cdiv(n4, 256) < 256 * 8 ? cdiv(n4, 256) : 256 * 8;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), n4);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

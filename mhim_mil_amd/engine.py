@@ -184,7 +184,8 @@ class FusedTrainer:
     """One-call MHIM(ABMIL) train step on flat buffers (the benchmarked path)."""
 
     def __init__(self, student: MHIM, teacher: Optional[MHIM], lr=2e-4, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
-                 mm=0.9997, main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, process_group=None, model="mhim", mm_sche=None):
+                 mm=0.9997, main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, process_group=None, model="mhim", mm_sche=None,
+                 clip_grad=None, lr_sche=None):
         if model not in ("mhim", "mhim_pure"):
             raise mh.L.MhimxError(f"FusedTrainer: model={model!r} (the path knows 'mhim' and 'mhim_pure')")
         if model == "mhim" and teacher is None:
@@ -224,6 +225,13 @@ class FusedTrainer:
         # optional EMA-momentum schedule (one value per optimiser step): a device table indexed by the device-resident step
         # counter, so it also advances under hipGraph replay
         self.mm_table = None if mm_sche is None else torch.as_tensor(mm_sche, dtype=torch.float32).to(dev).contiguous()
+        # --clip_grad (base_engine.py:115-119: clip_grad_norm_ on the accumulated gradient right before optimizer.step) and a per-update
+        # learning-rate schedule (train_utils.py:69-77, base_engine.py:152-153: scheduler.step() once per update): one value per update in a
+        # device table read by the optimiser kernel at the device step counter - both keep working under hipGraph replay
+        self.clip_grad = None if clip_grad is None else float(clip_grad)
+        self.lr_table = None if lr_sche is None else torch.as_tensor(lr_sche, dtype=torch.float32).to(dev).contiguous()
+        self._clip_ws = torch.empty(1024, device=dev) if self.clip_grad else None
+        self._g_extra = None
         self._graph_pool = None
         self._cap_stream = None
         self._side = None
@@ -516,10 +524,13 @@ class FusedTrainer:
             e = torch.cuda.Event()
             e.record(st["streams"][lane - 1])
             main.wait_event(e)
-        if S > 1:                                                     # flat gradient += the other streams' slabs: one launch
-            lst = ops.ReduceList()
-            ops.reduce_slabs_job(lst, st["slabs"][:S - 1], fl.grad, accumulate=True)
-            ops.reduce_flush(lst)
+        if S > 1:                                                     # the other streams' slabs: summed into the gradient by the optimiser
+            if update and self.world == 1:                            # kernel itself (mhimx_optim_args.g_extra); else by one reduce launch
+                self._g_extra = st["slabs"][:S - 1]
+            else:
+                lst = ops.ReduceList()
+                ops.reduce_slabs_job(lst, st["slabs"][:S - 1], fl.grad, accumulate=True)
+                ops.reduce_flush(lst)
         # the window's EMA chain on the k token sets: q <- mm^k q + (1 - mm) sum_j mm^(k-1-j) z_j
         mm = float(s.merge.g_q_mm)
         w = self._win_w.get(k) if hasattr(self, "_win_w") else None
@@ -640,9 +651,11 @@ class FusedTrainer:
     def _apply(self, scale):
         fl = self.flat
         fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
-        ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
-                     fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
-                     grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step, mm_table=self.mm_table)
+        ops.optim_step(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
+                       fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
+                       grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step, mm_table=self.mm_table,
+                       lr_table=self.lr_table, g_extra=self._g_extra, clip_norm=self.clip_grad, ws=self._clip_ws)
+        self._g_extra = None
         self._micro = 0
 
     def capture(self, bag, label, warmup=2, **kw):
@@ -654,8 +667,8 @@ class FusedTrainer:
             # a captured graph freezes host-side schedule values: k, n_sel and len_keep are launch arguments and buffer shapes
             raise mh.L.MhimxError("capture(): the HAM-ratio schedule (mrh_sche) changes the number of masked rows per iteration; "
                                   "run such a model with eager train_step calls, or capture one graph per schedule value")
-        # (the learning rate is a by-value kernel argument: constant under replay - re-capture to change it; the EMA momentum
-        # schedule is a device table indexed by the device step counter and does advance)
+        # (a learning-rate schedule given as lr_sche and the EMA momentum schedule are device tables indexed by the device step counter:
+        # they advance under replay; the scalar lr is a by-value kernel argument)
         self._capturing = True                             # (collectives stay outside the graphs: no mid-backward all-reduce)
         try:
             return self._capture(bag, label, warmup, **kw)

@@ -569,6 +569,31 @@ def adam_ema(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999
                                    0 if mm_table is None else mm_table.numel()), "mhimx_adam_ema")
 
 
+def optim_step(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5, grad_scale=1.0,
+               ema_mm=0.9997, zero_grad=True, step_dev=None, mm_table=None, lr_table=None, g_extra=None, clip_norm=None, ws=None):
+    """mhimx_optim_step: fused Adam + EMA with the optional device-side pieces - ``lr_table`` (per-update schedule), ``g_extra``
+    ([S, pitch] gradient slabs added to g first), ``clip_norm`` (clip_grad_norm_; ``ws``: >= 1024 floats)."""
+    _chk(g_extra, name="g_extra"); _chk(lr_table, name="lr_table"); _chk(mm_table, name="mm_table")
+    if clip_norm and ws is None:
+        ws = torch.empty(1024, device=p.device)
+    a = L.OptimArgs(p=_p(p), g=_p(g), m=_p(m), v=_p(v), teacher=_p(teacher), n_train=int(n_train), n_all=p.numel(), step=int(step),
+                    step_dev=_p(step_dev), lr=float(lr), lr_table=_p(lr_table), lr_len=0 if lr_table is None else lr_table.numel(),
+                    beta1=float(beta1), beta2=float(beta2), eps=float(eps), weight_decay=float(weight_decay), grad_scale=float(grad_scale),
+                    ema_mm=float(ema_mm), mm_table=_p(mm_table), mm_len=0 if mm_table is None else mm_table.numel(),
+                    zero_grad=int(bool(zero_grad)), g_extra=_p(g_extra), n_extra=0 if g_extra is None else g_extra.shape[0],
+                    extra_pitch=0 if g_extra is None else g_extra.stride(0), clip_norm=float(clip_norm or 0.0), ws=_p(ws),
+                    ws_floats=0 if ws is None else ws.numel())
+    L.check(L.lib().mhimx_optim_step(_stream(), C.byref(a)), "mhimx_optim_step")
+    return ws
+
+
+def stream_copy(src, dst):
+    """dst = src with the library's float4 stream-copy kernel (the HBM copy-rate microbenchmark of bench.py)."""
+    _chk(src, name="src"); _chk(dst, name="dst")
+    L.check(L.lib().mhimx_stream_copy(_stream(), _p(src), _p(dst), src.numel()), "mhimx_stream_copy")
+    return dst
+
+
 def tick(counter):
     """counter (uint64/int64 [1], device) += 1 on the current stream."""
     L.check(L.lib().mhimx_tick(_stream(), _p(counter)), "mhimx_tick")

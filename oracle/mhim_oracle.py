@@ -62,10 +62,16 @@ def _layer_norm(x, w, b, eps=1e-5):
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
+DRAW_DROPOUT = False       # timing runs only (bench.py cpu_baseline): with no injected mask, draw one with torch's own CPU dropout as the
+                           # reference does (mhim.py:76) - parity runs inject masks or run with p = 0
+
+
 def _drop(x, mask, p):
-    """Inverted dropout with an injected keep-mask (1 = keep).  p == 0 or mask None -> identity."""
-    if mask is None or p == 0.0:
+    """Inverted dropout with an injected keep-mask (1 = keep).  p == 0 or mask None -> identity (unless DRAW_DROPOUT)."""
+    if p == 0.0:
         return x
+    if mask is None:
+        return torch.nn.functional.dropout(x, p, True) if DRAW_DROPOUT else x
     return x * mask.to(x.dtype) / (1.0 - p)
 
 
@@ -610,8 +616,16 @@ def ema_update(teacher, student, mm):
 TRAINABLE_EXCLUDE = ("merge.global_q_mm",)                            # requires_grad=False (merge.py:108)
 
 
+def clip_grad_norm(grads, max_norm):
+    """--clip_grad (base_engine.py:115-119 -> timm dispatch_clip_grad(mode='norm') -> torch.nn.utils.clip_grad_norm_, 2-norm):
+    total = || all gradients ||_2, every gradient *= min(1, max_norm / (total + 1e-6)).  Returns (clipped dict, total norm)."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return {k: g * coef for k, g in grads.items()}, float(total)
+
+
 def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shuffle=None,
-               aux_alpha=0.5, main_alpha=1.0, mm=0.9997, lr=2e-4, wd=1e-5, model="mhim", score_override=None):
+               aux_alpha=0.5, main_alpha=1.0, mm=0.9997, lr=2e-4, wd=1e-5, model="mhim", score_override=None, clip_grad=None):
     """One CommonMIL.forward_func + BaseTrainer step (accumulation 1), dropout off.
 
     stu/tea: dicts of fp32 tensors (reference key names).  opt_state: {name: (m, v)}.
@@ -632,6 +646,12 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
     loss = main_alpha * cross_entropy(logits, label) + aux_alpha * cls_loss   # base_engine.py:99-100
     loss.backward()
     new_stu, new_opt = {}, {}
+    raw = {k: p.grad.detach().clone() for k, p in stu_g.items() if p.grad is not None}
+    if clip_grad is not None:                                       # base_engine.py:115-119, right before optimizer.step()
+        clipped, _ = clip_grad_norm(raw, clip_grad)
+        for k, p in stu_g.items():
+            if p.grad is not None:
+                p.grad = clipped[k]
     for k, p in stu_g.items():
         if p.grad is None:
             new_stu[k] = p.detach()
@@ -643,14 +663,14 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
         new_stu["merge.global_q_mm"] = ex["global_q_new"].reshape(stu["merge.global_q_mm"].shape).detach()
     new_tea = ema_update(tea, new_stu, mm) if model == "mhim" else tea
     info = {"teacher_score": score if model == "mhim" else None, "loss": float(loss.detach()), "logits": logits.detach(), "cls_loss": float(cls_loss.detach() if torch.is_tensor(cls_loss) else cls_loss), "ps": ps, "keep": keep,
-            "grads": {k: p.grad.detach() for k, p in stu_g.items() if p.grad is not None}}
+            "grads": raw}
     if "mask_ids" in ex:                                            # the rows the student kept (masking.py:107), before Merge's shuffle
         info["rows"] = np.asarray(ex["mask_ids"][:ex["len_keep_mask"]])
     return new_stu, new_tea, new_opt, info
 
 
 def train_window(xs, labels, stu, tea, opt_state, cfg: Cfg, step, perms=None, shuffles=None, aux_alpha=0.5, main_alpha=1.0, mm=0.9997,
-                 lr=2e-4, wd=1e-5, q_ema="sequential", score_overrides=None):
+                 lr=2e-4, wd=1e-5, q_ema="sequential", score_overrides=None, clip_grad=None):
     """One optimiser update over an accumulation window of len(xs) bags (--accumulation_steps; base_engine.py:29,47-49,100-102,
     146-153): every bag's loss is divided by the window length and back-propagated into the same gradients, then ONE Adam step
     and ONE EMA-teacher update (need_update, base_engine.py:47,109-119,155-167).  Dropout off.
@@ -689,6 +709,12 @@ def train_window(xs, labels, stu, tea, opt_state, cfg: Cfg, step, perms=None, sh
                 with torch.no_grad():
                     stu_g["merge.global_q_mm"].copy_(qn)
     new_stu, new_opt = {}, {}
+    infos["grads"] = {n: p.grad.detach().clone() for n, p in stu_g.items() if p.grad is not None}
+    if clip_grad is not None:
+        clipped, _ = clip_grad_norm(infos["grads"], clip_grad)
+        for n, p in stu_g.items():
+            if p.grad is not None:
+                p.grad = clipped[n]
     for n, p in stu_g.items():
         if p.grad is None:
             new_stu[n] = p.detach()
@@ -707,5 +733,4 @@ def train_window(xs, labels, stu, tea, opt_state, cfg: Cfg, step, perms=None, sh
                 q = g_mm * q + (1.0 - g_mm) * z
             new_stu["merge.global_q_mm"] = q.float()
     new_tea = ema_update(tea, new_stu, mm)
-    infos["grads"] = {n: p.grad.detach() for n, p in stu_g.items() if p.grad is not None}
     return new_stu, new_tea, new_opt, infos

@@ -311,6 +311,36 @@ def test_g18_train_accum8():
             assert err.mean() <= 5e-6 and err.max() <= 4.1e-4, (f"window {tag}:{k}", err.mean(), err.max())
 
 
+def test_clip_grad_norm_is_torchs():
+    """--clip_grad (base_engine.py:115-119): the oracle's restatement against torch.nn.utils.clip_grad_norm_ itself, and inside a
+    train step (a clip value below the gradient norm changes the update, one above does not)."""
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(7, 5, generator=g)), torch.nn.Parameter(torch.randn(11, generator=g))]
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g) * 3.0
+    raw = {str(i): p.grad.clone() for i, p in enumerate(ps)}
+    for max_norm in (0.5, 5.0, 1e3):
+        for p, (k, gr) in zip(ps, raw.items()):
+            p.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_(ps, max_norm)
+        mine, tot = O.clip_grad_norm(raw, max_norm)
+        assert abs(tot - float(total)) <= 1e-5 * float(total)
+        for p, k in zip(ps, raw):
+            np.testing.assert_allclose(mine[k].numpy(), p.grad.numpy(), rtol=1e-6, atol=1e-7)
+    meta, a = G.load("g10_train_steps")
+    base = synth.mhim_state(meta["seed"], input_dim=meta["d"], merge_k=meta["merge_k"])
+    cfg = _cfg(meta)
+    x = _x(meta["xseed0"], meta["n"], meta["d"])
+    outs = []
+    for clip in (None, 1e6, 1e-3):
+        stu, _, _, info = O.train_step(x, 0, O.as_torch(base), O.as_torch(synth.spread_teacher(base)), {}, cfg, 1, perm=a["perm0"],
+                                       ids_shuffle=a["shuf0"], clip_grad=clip)
+        outs.append(stu["feature.0.weight"])
+    assert torch.equal(outs[0], outs[1])
+    # Adam's first step is sign-like (|update| = lr): with the gradient clipped to 1e-3 the weight-decay term decides some signs: <= 2 lr
+    assert not torch.equal(outs[0], outs[2]) and (outs[0] - outs[2]).abs().max() < 4.1e-4
+
+
 def test_g11_forward_func():
     """CommonMIL.forward_func 7-tuple pieces (common_mil.py:14-48) and validate_func (:56-68)."""
     meta, a = G.load("g11_forward_func")

@@ -172,3 +172,54 @@ def test_captured_window_replays_vs_oracle():
     torch.cuda.synchronize()
     assert not torch.equal(w0, s.feature[0].weight.detach()) and torch.isfinite(tr.flat.student).all()
     assert any(not torch.equal(a, b["rows"]) for a, b in zip(rows0, tr.last["bags"])), "the second replay drew the same random subsets"
+
+
+def test_clip_grad_and_lr_schedule_on_the_device():
+    """--clip_grad (base_engine.py:115-119) and a per-update learning-rate schedule (train_utils.py:69-77, base_engine.py:152-153) inside
+    the fused optimiser launch (mhimx_optim_step): three eager steps and two replays of ONE captured graph against the oracle stepped
+    with the same clip value and the schedule's entries - the table is read at the DEVICE step counter, so it advances under replay."""
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d = 1200, 256
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+    lrs = [2e-4, 1.5e-4, 1e-4, 5e-5, 2.5e-5, 1e-5]
+    ocfg = O.Cfg(**V2)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    for clip in (0.05, None):
+        s, t = _mk(base, d, **V2), _mk(tsd, d, **V2)
+        tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997, clip_grad=clip, lr_sche=lrs)
+        stu, tea, opt = O.as_torch(base), O.as_torch(tsd), {}
+        x = torch.from_numpy(synth.bag(321, n, d))
+        xd, lab = x.to(DEV)[None], torch.tensor([1], device=DEV)
+        graph = None
+        for step in range(5):
+            if step < 3:
+                tr.forward_backward(xd, lab)
+                torch.cuda.synchronize()
+                if step == 0 and clip is not None:                      # the clip must actually bite in this test
+                    gn = float(tr.flat.grad[:tr.flat.n_train].double().norm())
+                    assert gn > 2 * clip, gn
+                tr.update()
+            else:
+                if graph is None:
+                    snap = [tr.flat.student.clone(), tr.flat.teacher.clone(), tr.flat.m.clone(), tr.flat.v.clone(), tr.opt_step.clone(),
+                            tr.tick.clone(), tr.flat.step]
+                    graph = tr.capture(xd, lab, warmup=1)
+                    tr.flat.student.copy_(snap[0]); tr.flat.teacher.copy_(snap[1]); tr.flat.m.copy_(snap[2]); tr.flat.v.copy_(snap[3])
+                    tr.opt_step.copy_(snap[4]); tr.tick.copy_(snap[5]); tr.flat.step = snap[6]
+                    tr.flat.grad.zero_()
+                graph.replay()
+            torch.cuda.synchronize()
+            rows, score = tr.last["rows"].cpu().numpy(), tr.last["score"].cpu().numpy()
+            perm, shuf = _draws_from_device(score, rows, tr.last["R"], n, k, n_sel)
+            stu, tea, opt, info = O.train_step(x, 1, stu, tea, opt, ocfg, step + 1, perm=perm, ids_shuffle=shuf, lr=lrs[step],
+                                               score_override=torch.from_numpy(score), clip_grad=clip)
+            # the update of this step has the schedule's size: |dw| <= lr_step (+ eps effects), so a frozen lr (2e-4) would overshoot
+            _check_params(s, stu, 3e-6, 2.05 * lrs[step] + 2e-5, f"clip={clip} step {step}")
+            s.load_state_dict({**stu, "merge.global_q": stu["merge.global_q_mm"]})
+            t.load_state_dict({**tea, "merge.global_q": tea["merge.global_q_mm"]})
+            # the Adam moments live on the device: bring them onto the oracle's trajectory too
+            for name in tr.flat.train_names:
+                o, nn_ = tr.flat.offsets[name], opt[name][0].numel()
+                tr.flat.m[o:o + nn_].copy_(opt[name][0].reshape(-1).to(DEV))
+                tr.flat.v[o:o + nn_].copy_(opt[name][1].reshape(-1).to(DEV))
