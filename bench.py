@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=400, help="oracle steps for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
-    ap.add_argument("--dp-graph", action="store_true",
-                    help="N > 1: replay graph(fwd+bwd) | all-reduce | graph(Adam) instead of eager steps whose all-reduce overlaps the backward")
+    ap.add_argument("--dp-graph", action="store_true", help="(default for N > 1; kept for old command lines)")
+    ap.add_argument("--dp-eager", action="store_true",
+                    help="N > 1: eager steps whose all-reduce overlaps the backward instead of graph(fwd+bwd) | all-reduce | graph(Adam+EMA)")
     ap.add_argument("--no-extras", action="store_true", help="c2, one GPU: skip the accumulate8 / hbm_copy / other_workloads legs")
     ap.add_argument("--window-streams", type=int, default=4, help="HIP streams of the accumulate-8 window")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil"],
@@ -237,12 +238,12 @@ def other_workload(a, world, rank, dev, embedded=False):
 
 def hbm_copy_rate(dev):
     """On-box stream-copy microbenchmark ('confirm with a copy microbenchmark on the box'): 1 GiB float4 copy through the
-    library's own kernel, HIP events, best of 5; bytes = read + written."""
+    library's own kernel, HIP events, best of 12; bytes = read + written."""
     from mhim_mil_amd import ops
     n = 1 << 28
     src, dst = torch.empty(n, device=dev).normal_(), torch.empty(n, device=dev)
     best = 1e30
-    for _ in range(6):
+    for _ in range(12):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.stream_copy(src, dst)
@@ -364,10 +365,11 @@ def main():
         ops.KERNEL_EVENT_HOOK = hook
 
     graphs, graph_note = None, None
-    # N > 1 defaults to EAGER steps: the all-reduce of every gradient but the projection's starts in the middle of the backward
-    # and overlaps its longest kernels (FusedTrainer._mid_hook); eager launches cost ~3 % against graph replay at N = 1, the
-    # overlap hides up to ~80 us of collective per step.  --dp-graph selects the graph | all-reduce | graph form instead.
-    if not a.no_graph and (world == 1 or a.dp_graph):
+    # N > 1 defaults to graph(fwd+bwd) | eager RCCL all-reduce | graph(Adam+EMA): no measurement on more than one GPU exists yet that
+    # shows the eager form (all-reduce of every gradient but the projection's started in the middle of the backward,
+    # FusedTrainer._mid_hook: hides up to ~80 us of collective, pays ~3 % of eager launches at N = 1) winning; --dp-eager selects it.
+    # The launch form used is printed in config.launch.
+    if not a.no_graph and (world == 1 or not a.dp_eager):
         # one captured hipGraph per resident bag (the bag pointer is a kernel argument); they share one memory pool.
         # Each replay runs the complete step: prep, teacher fwd, select, student fwd, head, bwd, [all-reduce], Adam + EMA.
         # If capture is refused (e.g. a collective that cannot be captured on this RCCL build) every rank falls back to

@@ -366,7 +366,7 @@ extern "C" int mhimx_stream_copy(void* stream, const float* src, float* dst, int
   MHIMX_CHECK_ARG(src && dst && n_floats >= 0 && n_floats % 4 == 0 && aligned16(src) && aligned16(dst), "stream_copy: 16-byte aligned buffers, n % 4 == 0");
   if (n_floats == 0) return 0;
   const int64_t n4 = n_floats / 4;
-  const int64_t blocks = cdiv(n4, 256) < 256 * 8 ? cdiv(n4, 256) : 256 * 8;
+  const int64_t blocks = cdiv(n4, 1024) < 65536 ? cdiv(n4, 1024) : 65536;        // (tools/micro/copy_bw.hip: many short workgroups stream fastest)
   hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src),
                      reinterpret_cast<float4*>(dst), n4);
   MHIMX_LAUNCH_CHECK();

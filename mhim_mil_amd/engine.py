@@ -144,7 +144,25 @@ class FlatState:
         return flat
 
 
-def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, world: int, group=None, comm=None) -> float:
+class QueryChain:
+    """How Merge's in-forward EMA of the global queries (merge.py:142-143) composes over the ranks of a data-parallel update.
+
+    A single process with accumulation_steps = W runs the EMA bag after bag: q <- mm q + (1 - mm) z_r, r = 0 .. W-1.  W ranks each see
+    the step's first queries q0 (nothing orders them), so the same chain is applied to the tokens z_r their forwards produced:
+        q <- mm^W q0 + (1 - mm) sum_r mm^(W-1-r) z_r
+    - rank r puts w_r z_r, w_r = (1 - mm) mm^(W-1-r), into its slice of the flat buffer's tail, the ONE SUM all-reduce adds them, and
+    every rank finishes with mm^W q0 + the sum.  The same contract as an accumulation window (FusedTrainer.window_step, oracle
+    ``train_window(q_ema="window")``): it differs from the bag-after-bag order only through d z_r / d q (second order in 1 - mm), where
+    averaging the ranks' one-step results would slow the EMA down W-fold (first order)."""
+
+    def __init__(self, offset, numel, mm, world, rank):
+        self.off, self.n = int(offset), int(numel)
+        self.w = (1.0 - mm) * mm ** (world - 1 - rank)
+        self.decay = mm ** world
+        self.tokens = None                       # [k, E] tokens of this rank's forward (set by the step)
+
+
+def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, world: int, group=None, comm=None, chain: QueryChain = None) -> float:
     """The ONE collective of a data-parallel update (RCCL on GPUs; any backend works, gloo in the CPU tests).
 
     Everything that must agree across ranks rides in the same flat buffer: the gradient (first n_train floats) and,
@@ -156,15 +174,33 @@ def sync_flat_gradient(grad: torch.Tensor, student: torch.Tensor, n_train: int, 
     """
     if world <= 1:
         return 1.0
-    grad[n_train:].copy_(student[n_train:])
+    fill_tail(grad, student, n_train, chain)
     if comm is not None:
         comm.allreduce(grad)
     else:
         torch.distributed.all_reduce(grad, group=group)
     scale = 1.0 / world
-    student[n_train:].copy_(grad[n_train:] * scale)
-    grad[n_train:].zero_()
+    finish_tail(grad, student, n_train, scale, chain)
     return scale
+
+
+def fill_tail(grad, student, n_train, chain=None):
+    """Before the SUM: the tail of the flat buffer carries the non-trainable parameters (averaged back afterwards); with a QueryChain
+    the global queries' slice carries this rank's weighted tokens instead."""
+    grad[n_train:].copy_(student[n_train:])
+    if chain is not None and chain.tokens is not None:
+        torch.mul(chain.tokens.reshape(-1), chain.w, out=grad[chain.off:chain.off + chain.n])
+
+
+def finish_tail(grad, student, n_train, scale, chain=None):
+    if chain is not None and chain.tokens is not None:
+        q0 = student[chain.off:chain.off + chain.n].clone()
+        student[n_train:].copy_(grad[n_train:] * scale)
+        torch.add(grad[chain.off:chain.off + chain.n], q0, alpha=chain.decay, out=student[chain.off:chain.off + chain.n])
+        chain.tokens = None
+    else:
+        student[n_train:].copy_(grad[n_train:] * scale)
+    grad[n_train:].zero_()
 
 
 class _SplitStep:
@@ -176,7 +212,9 @@ class _SplitStep:
     def replay(self):
         tr = self.tr
         self.g_fb.replay()
-        sync_flat_gradient(tr.flat.grad, tr.flat.student, tr.flat.n_train, tr.world, tr.pg, tr.comm)
+        if tr._chain is not None:
+            tr._chain.tokens = tr._chain_tokens                # (static buffer of the captured forward)
+        sync_flat_gradient(tr.flat.grad, tr.flat.student, tr.flat.n_train, tr.world, tr.pg, tr.comm, tr._chain)
         self.g_up.replay()
 
 
@@ -202,6 +240,12 @@ class FusedTrainer:
         self.comm = None                 # optional comm.NativeComm: the flat-gradient all-reduce through mhimx_comm_allreduce (C-ABI) instead
         self.world = torch.distributed.get_world_size(process_group) if self._dist() else 1
         self.model_kind = model
+        # data parallel, one bag per rank per update, single-pass ABMIL step: the queries' EMA is chained over the ranks (QueryChain)
+        self._chain, self._chain_tokens, self._q_scratch = None, None, None
+        if self.world > 1 and self.accum == 1 and model == "mhim" and student.merge_enable and "merge.global_q_mm" in self.flat.offsets:
+            rank = torch.distributed.get_rank(process_group)
+            self._chain = QueryChain(self.flat.offsets["merge.global_q_mm"], student.merge.global_q_mm.numel(), float(student.merge.g_q_mm),
+                                     self.world, rank)
         self._micro = 0
         self.last = {}
         dev = self.flat.student.device
@@ -423,6 +467,11 @@ class FusedTrainer:
                     self._rows_cache[key] = rows_all
                 s.student_rows(ps, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, merge_first=True, rows_out=rows_all)
                 plan = BagPlan(rows=rows_all[:len_keep], L=len_keep, Lk=Lk, R=R, mca_seed=s._next_seed(), training=True, merge_first=True)
+                if q_out is None and self._chain is not None:         # data parallel: the queries stay q0 until the update (QueryChain)
+                    if self._q_scratch is None:
+                        self._q_scratch = torch.empty((k, E), device=dev)
+                    q_out = self._q_scratch
+                    self._chain.tokens = self._chain_tokens = Hbuf[ps:]
                 plan.q_out = q_out
                 keep_num = Lk + k
             else:
@@ -630,7 +679,7 @@ class FusedTrainer:
         """Data parallel, eager steps: everything but the projection's gradient (the head of the flat buffer) is final - start its
         all-reduce (with the global-query tail) on RCCL's stream while mul_colsum + the dW1 GEMM + its slab reduction still run."""
         fl = self.flat
-        fl.grad[fl.n_train:].copy_(fl.student[fl.n_train:])
+        fill_tail(fl.grad, fl.student, fl.n_train, self._chain)
         self._work_a = torch.distributed.all_reduce(fl.grad[self._split:], group=self.pg, async_op=True)
 
     def update(self):
@@ -642,10 +691,9 @@ class FusedTrainer:
             work_b.wait()
             self._work_a = None
             scale = 1.0 / self.world
-            fl.student[fl.n_train:].copy_(fl.grad[fl.n_train:] * scale)
-            fl.grad[fl.n_train:].zero_()
+            finish_tail(fl.grad, fl.student, fl.n_train, scale, self._chain)
         else:
-            scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg, self.comm)
+            scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg, self.comm, self._chain)
         self._apply(scale)
 
     def _apply(self, scale):
@@ -696,7 +744,7 @@ class FusedTrainer:
             g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb, pool=self._graph_pool, stream=cs):
                 self.forward_backward(bag, label, **kw)
-            scale = sync_flat_gradient(self.flat.grad, self.flat.student, self.flat.n_train, self.world, self.pg, self.comm)
+            scale = sync_flat_gradient(self.flat.grad, self.flat.student, self.flat.n_train, self.world, self.pg, self.comm, self._chain)
             with torch.cuda.graph(g_up, pool=self._graph_pool, stream=cs):
                 self._apply(scale)
             self.flat.grad.zero_()                         # (the capture-time all-reduce summed stale values)

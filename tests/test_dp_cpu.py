@@ -59,6 +59,36 @@ def test_flat_gradient_allreduce_two_ranks(tmp_path):
     np.testing.assert_allclose(pn.numpy(), pn2.numpy(), rtol=1e-6)
 
 
+def _chain_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from mhim_mil_amd.engine import QueryChain, sync_flat_gradient
+    g, p = _rank_buffers(rank)
+    p[N_TRAIN:] = _rank_buffers(0)[1][N_TRAIN:]                 # the queries are q0 on every rank until the update
+    ch = QueryChain(N_TRAIN, 40, 0.99, WORLD, rank)
+    ch.tokens = torch.from_numpy(synth.normal(300 + rank, (5, 8), std=1.0).astype(np.float32))
+    sync_flat_gradient(g, p, N_TRAIN, WORLD, chain=ch)
+    torch.save({"g": g, "p": p}, os.path.join(out, f"c{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_query_chain_two_ranks(tmp_path):
+    """QueryChain: the EMA of Merge's global queries over the ranks of one update == the bag-after-bag chain of a single process on the
+    same tokens, q <- mm q + (1 - mm) z_r for r = 0, 1 (merge.py:142-143) - not the rank mean of one-step results."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_chain_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"c{r}.pt")) for r in range(WORLD)]
+    q = _rank_buffers(0)[1][N_TRAIN:].double()
+    for r in range(WORLD):
+        z = torch.from_numpy(synth.normal(300 + r, (5, 8), std=1.0)).double().reshape(-1)
+        q = 0.99 * q + 0.01 * z
+    for r in res:
+        np.testing.assert_allclose(r["p"][N_TRAIN:].double().numpy(), q.numpy(), rtol=0, atol=2e-7)
+        assert float(r["g"][N_TRAIN:].abs().max()) == 0.0
+    assert torch.equal(res[0]["p"], res[1]["p"])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Instance-sharded bag (BASELINE config c5): the exchange + partition logic of mhim_mil_amd/sharded.py on 2 gloo ranks,
 # with the oracle's math standing in for the shard-local kernels.  (The kernels themselves need a GPU: tests/test_sharded_gpu.py.)
