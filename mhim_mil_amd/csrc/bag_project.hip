@@ -148,8 +148,9 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
     for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (int)(g.D / PBK);
-  // prologue: B(0), B(1) in flight, A(0) -> stage 0 (the compiler's wait in front of the conversion drains all three), A(1) in flight
   ARegs rga, rgb;
+#ifndef PJ_PINGPONG
+  // prologue: B(0), B(1) in flight, A(0) -> stage 0 (the compiler's wait in front of the conversion drains all three), A(1) in flight
   issue_b(0, true);
   issue_b(1, nk > 1);
   {
@@ -161,7 +162,137 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
     store_a(0, r0);
   }
   load_a_async(nk > 1 ? 1 : 0, rga);
+#else
+  // prologue: tiles 0 and 1 complete in LDS (the compiler's wait in front of the first conversion drains the DMA pieces too), A(2), A(3)
+  // in flight in the two register sets
+  issue_b(0, true);
+  issue_b(1, nk > 1);
+  {
+    ARegs r0, r1;
+    const char* xb = reinterpret_cast<const char*>(g.X);
+    const char* xb1 = xb + (nk > 1 ? PBK * 4 : 0);
+    r0.v0 = *reinterpret_cast<const f32x4*>(xb + aoff[0]);
+    r0.v1 = *reinterpret_cast<const f32x4*>(xb + aoff[1]);
+    r0.v2 = *reinterpret_cast<const pj_f2*>(xb + aoff[2]);
+    r1.v0 = *reinterpret_cast<const f32x4*>(xb1 + aoff[0]);
+    r1.v1 = *reinterpret_cast<const f32x4*>(xb1 + aoff[1]);
+    r1.v2 = *reinterpret_cast<const pj_f2*>(xb1 + aoff[2]);
+    store_a(0, r0);
+    if (nk > 1) store_a(1, r1);
+  }
+  load_a_async(nk > 2 ? 2 : nk - 1, rga);
+  load_a_async(nk > 3 ? 3 : nk - 1, rgb);
+#endif
 
+#ifdef PJ_PINGPONG
+  // ---- (opt-in experiment, -DPJ_PINGPONG; the default is the lock-step loop below) the k loop as a PING-PONG of the two waves of every SIMD (waves w and w + 4 share a SIMD; group = wave >> 2 = the wave's M half).
+  // In lock-step (all eight waves read LDS, then all eight issue MFMAs: the default form below) the matrix pipe idles while the
+  // fragments are read and the LDS idles under the MFMAs - measured: MFMA-only loop 27 us, data movement only 35-38 us, together 57 us.
+  // Here every k-step is two slots with a workgroup barrier after each; in a slot one group is in its COMPUTE phase (the 60 MFMAs of a
+  // k-step, every fragment already in registers: nothing but matrix instructions) while the other is in its LOAD phase for the next tile
+  // it will multiply (its 18 fragment reads, its share of the split + LDS stores of the following A tile, the global loads and weight
+  // DMA two tiles ahead).  Slot 2t: group 0 loads tile t | group 1 computes tile t-1;  slot 2t+1: group 0 computes tile t | group 1
+  // loads tile t.  Per SIMD the matrix pipe always has one wave issuing MFMAs and the LDS / VMEM traffic of the partner runs under it.
+  //   load(s):     read the 18 fragments of tile s (stage s % 3); issue this wave's DMA pieces of B(s+2) (stage (s+2) % 3 = (s-1) % 3: both
+  //                groups are past their reads of tile s-1); drain LDS; wait until only the 7 youngest requests are in flight: A(s+2) -
+  //                requested two iterations ago - is in its registers and B(s+1) has landed.
+  //   compute(s):  the 60 MFMAs of tile s with the split of A(s+2) to bf16 hi / lo and its LDS stores (stage (s+2) % 3) interleaved into
+  //                their issue gaps (two VALU per MFMA fit under the 16 cycles the matrix pipe needs); then A(s+4) is requested into the
+  //                registers just emptied.
+  //   Tile s+2 is complete when both groups have run compute(s) (slots 2s+1 and 2s+2) and load(s+1) (B landed: slots 2s+2, 2s+3); its
+  //   first reader is group 0's load(s+2) in slot 2s+4.  Lead of the global requests: A two iterations, B one and a half.
+  //   MEASURED (round 3, same box, p = 0.25, us): lock-step loop 72.4-73.8 | ping-pong with split / stores / DMA in the LOAD phase 71.0-71.8
+  //   (any order of its pieces) | this form (split + stores interleaved into the MFMAs) 75.4 | ping-pong without any global traffic 53.6,
+  //   without MFMAs 57.1, without the epilogue 55.2 (the epilogue is 18 us: 51 MB of stores leave every CU at the same moment).
+  //   s_memtime stamps (PJ_PP_PROF): a load phase that also splits / stores / issues DMA takes ~1.8x the 60-MFMA phase (fragment reads ~480
+  //   cycles for 4 x 18 KB, split + 6 stores ~400, four DMA issues ~320, waits ~650) and sets the slot length; moved into the compute phase the
+  //   VALU chain of the split stalls the in-order MFMA issue instead.  The k-step moves 144 KB of fragment reads + 52 KB of operand writes
+  //   through the LDS against 2 x 1020 MFMA cycles: ~80 % LDS occupancy whatever the phase structure - the lever is fewer fragment bytes per
+  //   MFMA (larger wave tiles: 4 waves x 80 x 128 with 512 registers), not the phase order.  Kept out of the default build.
+  f32x4 x[NFR];
+#if defined(PJ_PP_NOREAD)
+  for (int q = 0; q < NFR; ++q) x[q] = f32x4{1.f, 2.f, 3.f, 4.f};
+#endif
+#ifdef PJ_PP_PROF
+  uint32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t pt = 0;
+#define PF_MARK(i) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); pf[i] += (uint32_t)(now_ - pt); pt = now_; }
+#define PF_START() { pt = __builtin_amdgcn_s_memtime(); }
+#else
+#define PF_MARK(i)
+#define PF_START()
+#endif
+  auto load_phase = [&](int s, ARegs& r_next) {               // r_next: the registers A(s+2) arrives in (stored by compute(s))
+    const unsigned so = (unsigned)((s % PNST) * PSTAGE);
+    PF_START();
+    MT_READ9(x, 5, 10, fa_lo + so, fb_hi + so);
+    MT_READ9(x, 0, 14, fa_hi + so, fb_lo + so);
+#ifndef PJ_PP_NODMA
+    issue_b(s + 2, s + 2 < nk);
+#endif
+    MT_WAIT9(0, x, 5, 10);
+    MT_WAIT9(0, x, 0, 14);
+    PF_MARK(0);
+#ifndef PJ_PP_NODMA
+    asm volatile("s_waitcnt vmcnt(7)" : "+v"(r_next.v0), "+v"(r_next.v1), "+v"(r_next.v2) : : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(r_next.v0), "+v"(r_next.v1), "+v"(r_next.v2) : : "memory");
+#endif
+    PF_MARK(2);
+  };
+  auto compute_phase = [&](int s, ARegs& r) {                 // r: A(s+2), arrived
+    PF_START();
+    __builtin_amdgcn_sched_barrier(0);
+    mt_term(x, 5, 10, acc);                                   // lo*hi
+    mt_term(x, 0, 14, acc);                                   // hi*lo
+    mt_term(x, 0, 10, acc);                                   // hi*hi
+#ifndef PJ_PP_NOSTORE
+    store_a(s + 2, r);            // (unconditional - one basic block with the MFMAs: past the last tile it writes clamped rows into a stage nobody reads)
+#ifndef PJ_PP_NOINTERLEAVE
+#pragma unroll
+    for (int q = 0; q < 30; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU
+      if (q % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // a DS write
+    }
+#endif
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    load_a_async(s + 4 < nk ? s + 4 : nk - 1, r);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my A(s+2) stores are in LDS before the slot's barrier
+    PF_MARK(4);
+  };
+  int pf_slot = 3;
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef PJ_PP_PROF
+    PF_MARK(pf_slot);
+    pf_slot = pf_slot == 3 ? 5 : 3;          // 3: barrier wait after a load phase, 5: after a compute phase (the loop alternates them)
+#endif
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my A(0) stores to LDS are done
+  slot_end();
+  // (one copy of the loop for both groups: group 1 runs it one slot later - it waits out slot 0, group 0 waits out the last slot)
+  const bool late = __builtin_amdgcn_readfirstlane(wm) != 0;
+  if (late) slot_end();
+  {
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < nk; t += 2) {
+      load_phase(t, rga);          slot_end();
+      compute_phase(t, rga);       slot_end();
+      load_phase(t + 1, rgb);      slot_end();
+      compute_phase(t + 1, rgb);   slot_end();
+    }
+    if (t < nk) {
+      load_phase(t, rga);          slot_end();
+      compute_phase(t, rga);       slot_end();
+    }
+  }
+  if (!late) slot_end();
+#else
   // Iteration t (3-stage ring, A and B both two tiles ahead):  [barrier: tile t complete in stage t%3]
   //   reads g1(t) = {A lo, B hi};  A(t+2) loads -> the free register set;  B(t+2) DMA -> stage (t+2)%3 (= (t-1)%3: every wave is
   //   past its reads);  20 MFMAs hi*lo of tile t-1 (operands still in registers: they cover the latency of g1);
@@ -241,6 +372,7 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
 #ifndef PJ_NOMMA
   mt_term(x, 0, 14, acc);                                     // hi*lo of the last tile
 #endif
+#endif
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(rga.v0), "+v"(rga.v1), "+v"(rga.v2), "+v"(rgb.v0), "+v"(rgb.v1), "+v"(rgb.v2) : : "memory");
 #ifdef PJ_NOEPI
   {
@@ -277,7 +409,10 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
     }
     if (hashed && tid < 80) rkeys[tid] = drop_row_key(dseed, (uint64_t)(m0 + half * 80 + tid));
     __syncthreads();
-#pragma unroll 1
+#ifndef PJ_EPI_UNROLL
+#define PJ_EPI_UNROLL 1
+#endif
+#pragma unroll PJ_EPI_UNROLL
     for (int r = r0; r < 80; r += 8) {
       const int64_t m = m0 + half * 80 + r;
       if (m >= g.N) break;
@@ -304,14 +439,31 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
           v[q] = y * ks[q];
           d[q] = (_Float16)(gq * ks[q]);
         }
+#if defined(PJ_EPI_NOSTORE)
+        if (d[0] == (_Float16)1234.5f) *reinterpret_cast<pj_h4*>(dact + m * g.E + n) = d;
+#elif defined(PJ_EPI_NT)
+        __builtin_nontemporal_store(d, reinterpret_cast<pj_h4*>(dact + m * g.E + n));
+#else
         *reinterpret_cast<pj_h4*>(dact + m * g.E + n) = d;
+#endif
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], g.act) * ks[q];
       }
+#if defined(PJ_EPI_NOSTORE)
+      if (v[0] == 1234.5f) *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
+#elif defined(PJ_EPI_NT)
+      __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(H.H + m * H.ldh + n));
+#else
       *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
+#endif
     }
   }
+#ifdef PJ_PP_PROF
+  __syncthreads();
+  if (m_tile == 1 && n_tile == 0 && lane == 0 && (wave == 0 || wave == 4))
+    for (int i = 0; i < 8; ++i) H.H[(m0 + wave) * H.ldh + i] = (float)pf[i];
+#endif
 }
 
 int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
