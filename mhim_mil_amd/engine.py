@@ -325,7 +325,7 @@ class FusedTrainer:
                 # student projects every row before it masks, mhim.py:335-336); the student's token rows are a gather, its projection
                 # gradient the matrix-core-image pair on (d tokens, d out / d pre in fp16)
                 heads = [ops.ProjHead(ops.pair_planes(t.feature[0].weight.data), t.feature[0].bias.data,
-                                      drop_p=t.dropout_p if t.training else 0.0, drop_seed=t._next_seed()),
+                                      drop_p=t.dropout_p if t.training else 0.0, drop_seed=t._next_seed(teacher=True)),
                          None]
                 seed_s = s._next_seed()
                 heads[1] = ops.ProjHead(ops.pair_planes(s.feature[0].weight.data), s.feature[0].bias.data, drop_p=s.dropout_p,
@@ -445,7 +445,7 @@ class FusedTrainer:
             heads = []
             if mhim:
                 p_t = t.dropout_p if t.training else 0.0            # the trainer keeps the teacher in train mode
-                heads.append(ops.ProjHead(prep_t["w1p"], t.feature[0].bias.data, drop_p=p_t, drop_seed=t._next_seed()))
+                heads.append(ops.ProjHead(prep_t["w1p"], t.feature[0].bias.data, drop_p=p_t, drop_seed=t._next_seed(teacher=True)))
             heads.append(ops.ProjHead(prep_s["w1p"], s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=s._next_seed(), out=Hbuf,
                                       want_dact=True))
             ops.bag_project(x, heads, act=act, drop_tick=self.tick)
@@ -490,7 +490,8 @@ class FusedTrainer:
             s.merge_enable = merge_on
         # (kept for inspection / parity tests: under graph replay these are the static buffers the replay rewrites)
         self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num, "rows": plan.rows,
-                     "score": score, "R": plan.R, "tokens": Hbuf[ps:] if mhim else None}
+                     "score": score, "R": plan.R, "tokens": Hbuf[ps:] if mhim else None,
+                     "H_student": Hbuf[:ps], "H_teacher": heads[0].out if mhim else None}
         return logits, losses
 
     # ------------------------------------------------------------------------------------------------- accumulation windows

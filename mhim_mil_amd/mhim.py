@@ -415,9 +415,14 @@ class MHIM(nn.Module):
         outputs are instance scores and gradients), so 'auto' and 'f16s' mean 'bf16x3' for these operators."""
         return "f32" if self.prec == "f32" else "bf16x3"
 
-    def _next_seed(self):
+    def _next_seed(self, teacher=False):
+        """Seed of the next counter-hash stream.  ``teacher``: the stream belongs to a teacher pass (forward_teacher / the trainer's teacher
+        head).  Teacher and student are built alike and call this in step, so without the role salt the trainer's teacher and student shared
+        ONE feature-dropout mask (found by the c2 parity test that reads the masks back); the reference draws them independently
+        (mhim.py:76 under base_engine.py:37-38)."""
         self._step += 1
-        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        salt = 0xA24BAED4963EE407 if teacher else 0
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03 + salt) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ student bag forward / backward
     def _bag_forward(self, x, plan: BagPlan, xp=None, prep=None):
@@ -748,7 +753,7 @@ class MHIM(nn.Module):
         x = self._check_x(x)
         p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
         if H is None:                                          # (H: the teacher's feature rows from the trainer's single-pass projection)
-            H = self._feature(x, None, p, self._next_seed(), drop_mask, xp=xp, w1p=w1p)
+            H = self._feature(x, None, p, self._next_seed(teacher=True), drop_mask, xp=xp, w1p=w1p)
         p0 = H.shape[0]
         T2 = None
         if self.merge_test:                                    # eval-mode merge over all rows (mhim.py:196-200)

@@ -625,8 +625,10 @@ def clip_grad_norm(grads, max_norm):
 
 
 def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shuffle=None,
-               aux_alpha=0.5, main_alpha=1.0, mm=0.9997, lr=2e-4, wd=1e-5, model="mhim", score_override=None, clip_grad=None):
-    """One CommonMIL.forward_func + BaseTrainer step (accumulation 1), dropout off.
+               aux_alpha=0.5, main_alpha=1.0, mm=0.9997, lr=2e-4, wd=1e-5, model="mhim", score_override=None, clip_grad=None,
+               drop_mask_t=None, drop_mask_s=None):
+    """One CommonMIL.forward_func + BaseTrainer step (accumulation 1).  Dropout (cfg.dropout > 0) takes injected keep-masks [N, E]
+    for the teacher's and the student's feature dropout (mhim.py:76; the trainer keeps the teacher in train mode, base_engine.py:37-38).
 
     stu/tea: dicts of fp32 tensors (reference key names).  opt_state: {name: (m, v)}.
     Returns (new_stu, new_tea, new_opt_state, info).
@@ -634,11 +636,11 @@ def train_step(x, label, stu, tea, opt_state, cfg: Cfg, step, perm=None, ids_shu
     stu_g = {k: v.clone().requires_grad_(k not in TRAINABLE_EXCLUDE) for k, v in stu.items()}
     if model == "mhim":
         with torch.no_grad():
-            t_feat, score = forward_teacher(x, tea, cfg)
+            t_feat, score = forward_teacher(x, tea, cfg, drop_mask_t)
         if score_override is not None:      # tests: select on the scores the device saw (its random subsets are read back as perm)
             score = score_override
         t_in = None if aux_alpha == 0.0 else t_feat                 # common_mil.py:24
-        logits, cls_loss, ps, keep, ex = forward_student(x, stu_g, cfg, score, t_in, perm, ids_shuffle)
+        logits, cls_loss, ps, keep, ex = forward_student(x, stu_g, cfg, score, t_in, perm, ids_shuffle, drop_mask=drop_mask_s)
     else:
         logits, cls_loss, ps, keep, ex = pure(x, stu_g, cfg), 0.0, x.shape[0], x.shape[0], {}
     if isinstance(logits, list):                                    # dsmil: common_mil.py:26-28 mixes the two logit vectors

@@ -293,3 +293,59 @@ def test_production_step_vs_oracle_c2():
     stu2, tea2, opt, info = O.train_step(bags[1], labels[1], stu1, tea1, opt, ocfg, 2, perm=perm, ids_shuffle=shuf,
                                          score_override=torch.from_numpy(score))
     check(1, info, stu2, tea2, tr.last["logits"], tr.last["losses"])
+
+
+def test_production_step_with_dropout_vs_oracle_c2():
+    """The timed configuration itself - dropout 0.25 on the teacher's AND the student's feature rows (the trainer keeps the teacher in
+    train mode, base_engine.py:37-38; mhim.py:76) - at c2 size: the keep-masks the projection kernel drew from its counter hash are read
+    back (a GELU output is exactly zero only where it was dropped) and handed to the oracle with the device's row sets and teacher scores:
+    logits 1e-4, every gradient 2e-3 of its scale, parameters after Adam + EMA.  (Merge's own 0.1 dropouts stay off here: its kernels'
+    masks are pinned by tests/test_ops_gpu.py.)"""
+    from mhim_mil_amd.engine import FusedTrainer
+    from mhim_mil_amd.mhim import MHIM
+    n, d = 10000, 1024
+    cfg = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True,
+               merge_k=5, merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.25)
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+
+    def mk(sd):
+        m = MHIM(input_dim=d, n_classes=2, baseline="attn", **cfg)
+        sd = dict(sd)
+        sd["merge.global_q"] = sd["merge.global_q_mm"]
+        m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+        m = m.to(DEV).train()
+        m.merge.dropout = 0.0
+        return m
+
+    s, t = mk(base), mk(tsd)
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    bag = torch.from_numpy(synth.bag(300, n, d))
+    logits, losses = tr.forward_backward(bag.to(DEV)[None], torch.tensor([1], device=DEV))
+    torch.cuda.synchronize()
+    keep_t, keep_s = (tr.last["H_teacher"] != 0).cpu(), (tr.last["H_student"] != 0).cpu()
+    for kp in (keep_t, keep_s):                                         # a 0.25 dropout, not a degenerate mask
+        assert abs(float(kp.float().mean()) - 0.75) < 2e-3
+    assert not torch.equal(keep_t, keep_s)
+    rows, score = tr.last["rows"].cpu().numpy(), tr.last["score"].cpu().numpy()
+    perm, shuf = _draws_from_device(score, rows, tr.last["R"], n, k, n_sel)
+    stu1, tea1, _, info = O.train_step(bag, 1, O.as_torch(base), O.as_torch(tsd), {}, O.Cfg(**cfg), 1, perm=perm, ids_shuffle=shuf,
+                                       score_override=torch.from_numpy(score), drop_mask_t=keep_t, drop_mask_s=keep_s)
+    np.testing.assert_allclose(score, O.forward_teacher(bag, O.as_torch(tsd), O.Cfg(**cfg), keep_t)[1].numpy().ravel(), atol=1e-4, rtol=2e-3)
+    np.testing.assert_allclose(logits.cpu().numpy().ravel(), info["logits"].numpy().ravel(), atol=1e-4, rtol=0)
+    assert abs(float(losses[0]) - info["loss"]) < 3e-4
+    gv = tr.flat.grad_views
+    for name, ref in info["grads"].items():
+        g, r = gv[name].cpu().numpy(), ref.numpy()
+        np.testing.assert_allclose(g, r.reshape(g.shape), atol=2e-3 * (np.abs(r).max() + 1e-30), rtol=2e-3, err_msg=name)
+    tr.update()
+    torch.cuda.synchronize()
+    sd, td = s.state_dict(), t.state_dict()
+    for name, ref in stu1.items():
+        if name == "merge.global_q":
+            continue
+        err = (sd[name].detach().cpu().double() - ref.double()).abs()
+        assert err.mean().item() <= 3e-6 and err.max().item() <= 4.1e-4, (name, err.mean().item(), err.max().item())
+        err = (td[name].detach().cpu().double() - tea1[name].double()).abs()
+        assert err.max().item() <= 2e-6, ("teacher", name, err.max().item())
