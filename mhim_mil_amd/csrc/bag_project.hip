@@ -23,6 +23,7 @@
 //   * epilogue through LDS in two 80-row halves (one compact loop: bias, GELU and its derivative from one erf, counter
 //     dropout with one hash per two elements, 512-byte row stores).  The student's d out / d pre goes out as fp16.
 //   * XCD-aware tile order: the four column tiles of one row tile run on the same XCD (X rows shared through its L2).
+#include <stdlib.h>
 #include "mma_tile.hpp"
 
 namespace mhimx {
@@ -466,6 +467,8 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
 #endif
 }
 
+int bag_project_ws(hipStream_t st, const mhimx_bag_project_args& g);       // bag_project_ws.hip
+
 int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
   MHIMX_CHECK_ARG(g.X && g.N >= 1 && g.D >= PBK && g.D % PBK == 0, "bag_project: X [N,D] with D a multiple of 32");
   MHIMX_CHECK_ARG(g.E >= PBN && g.E % PBN == 0, "bag_project: E must be a multiple of 256");
@@ -479,6 +482,10 @@ int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
     MHIMX_CHECK_ARG(H.drop_p >= 0.f && H.drop_p < 1.f, "bag_project: model %d: dropout probability outside [0,1)", h);
     MHIMX_CHECK_ARG(!H.drop_mask || (reinterpret_cast<uintptr_t>(H.drop_mask) & 3) == 0, "bag_project: model %d: unaligned mask", h);
   }
+  // the specialised-wave form (bag_project_ws.hip: 8 ping-pong consumer waves + 4 producer waves) is the default; MHIMX_PROJ_LOCKSTEP=1
+  // selects this file's uniform 8-wave kernel (same tiles, same arithmetic, same bits)
+  static const bool lockstep = getenv("MHIMX_PROJ_LOCKSTEP") != nullptr;
+  if (!lockstep) return bag_project_ws(st, g);
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE)));
   const int nN = (int)(g.n_heads * g.E / PBN), nM = (int)cdiv(g.N, PBM);
   dim3 grid((unsigned)(8 * nN * cdiv(nM, 8)));

@@ -1,0 +1,304 @@
+// bag_project_ws.hip — the bag projection of bag_project.hip (teacher + student, ONE pass over the raw fp32 bag, 3-term bf16) with
+// SPECIALISED waves and a ping-pong of the two consumer waves of every SIMD:
+//
+//   8 consumer waves (2 (M) x 4 (N) of 80 x 64 outputs, as in bag_project.hip) touch no global memory in the k loop: a k-step is a
+//     LOAD phase (the 18 fragment reads of the tile) and a COMPUTE phase (its 60 MFMAs, every operand in registers).  Waves w and w + 4
+//     share a SIMD and run half a k-step apart: while one issues MFMAs its partner reads its fragments, so the matrix pipe of every SIMD
+//     always has a wave feeding it and the LDS reads run under it;
+//   4 producer waves (one per SIMD) own the whole global -> LDS stream: the raw fp32 rows of X through registers (split to bf16 hi / lo on
+//     the way, the paired 128-byte row image), the paired weight planes by LDS-DMA.  Their waits on memory stall nobody's MFMA issue.
+//
+// Why (round 3 measurements on bag_project.hip): in its lock-step loop all eight waves read LDS, then all eight
+// issue MFMAs (MFMA-only loop 27 us, everything but the MFMAs 33 us, together 55 us); a ping-pong of UNspecialised waves hid the
+// fragment reads (no-global-traffic loop 35 us) but its load phase - reads + split + stores + four DMA issues (~60-100 cycles each) + the
+// wait on the landing data - was 1.8x the MFMA phase and set the pace (71 us, no gain).  The global stream alone needs ~26 us of the
+// launch (1.66 MB per CU at ~28 B/clk/CU): it has to run beside the MFMAs, not between them.
+//
+// Slots (a k-step s is two slots, a workgroup barrier after each; tile s lives in stage s % 3 of the 156 KB ring):
+//   slot 2s   : group 0 loads tile s    | group 1 computes tile s-1 | producers split + store A(s+1) (stage (s+1) % 3: tile s-2, long read),
+//                                                                     request A(s+3)
+//   slot 2s+1 : group 0 computes tile s | group 1 loads tile s      | producers issue the DMA of B(s+2) (stage (s+2) % 3 = (s-1) % 3: both
+//                                                                     groups are past tile s-1), then wait until A(s+2) is in registers and
+//                                                                     B(s+1) has landed
+//   Tile s+1 is complete at the end of slot 2s+1; its first reader is group 0 in slot 2s+2.  Requests run two k-steps ahead (A) / one and
+//   a half (B).
+#include "mma_tile.hpp"
+
+namespace mhimx {
+
+constexpr int WBM = 160, WBN = 256, WBK = 32;
+constexpr int W_CONS = 8, W_PROD = 4, WTHREADS = 64 * (W_CONS + W_PROD);                           // 768 threads: three waves per SIMD
+constexpr int WA_BYTES = WBM * 128, WB_BYTES = WBN * 128, WSTAGE = WA_BYTES + WB_BYTES, WNST = 3;     // 20 KiB + 32 KiB, x 3 = 156 KiB
+constexpr int WTP = WBN + 4;                                                                         // epilogue tile pitch (floats)
+
+typedef __bf16 pw_bf4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pw_h4 __attribute__((ext_vector_type(4)));
+
+MHIMX_DEV uint32_t pw_pair_hash(uint32_t row_key, uint32_t pair) { return mix32(row_key + pair * 0x85EBCA77u); }   // (bag_project.hip's stream)
+
+__global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_project_args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)((g.N + WBM - 1) / WBM);
+  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int m_tile = (sidx / nN) * 8 + xcd, n_tile = sidx % nN;             // the column tiles of one row tile share an XCD (X rows via its L2)
+  if (m_tile >= nM) return;
+  const int64_t m0 = (int64_t)m_tile * WBM;
+  const int tiles_per_head = (int)(g.E / WBN);
+  const int hd = n_tile / tiles_per_head;
+  const int64_t n0 = (int64_t)(n_tile % tiles_per_head) * WBN;
+  mhimx_proj_head H = g.head[0];
+  if (hd == 1) H = g.head[1];
+  const int nk = (int)(g.D / WBK);
+  const bool producer = wave >= W_CONS;
+  const int wm = (wave >> 2) & 1, wn = wave & 3;                            // consumer waves: M half (= ping-pong group), N quarter
+
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  f32x4 acc[NRA][NRB];
+#pragma unroll
+  for (int i = 0; i < NRA; ++i)
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (producer) {
+    // ================================================================= producers: 256 threads own the global -> LDS stream
+    // (a lean instruction stream matters: a producer wave shares its SIMD's issue with two consumer waves - the first version spent ~250
+    // instructions per k-step here, mostly 64-bit address arithmetic and unpacked conversions, and its slot outlasted the 60-MFMA phase)
+    const int pt = tid - 64 * W_CONS, pw = wave - W_CONS;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+    // A: 160 rows x 8 sixteen-byte units per k-step = 1280 units, five per thread: unit u = pt + 256 j -> row u >> 3, slot u & 7
+    unsigned aoff[5], a_hi[5], a_lo[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int u = pt + 256 * j, row = u >> 3, slot = u & 7;
+      int64_t m = m0 + row;
+      if (m >= g.N) m = g.N - 1;                                            // clamped rows feed accumulators that are never stored
+      aoff[j] = (unsigned)((m * g.ldx + slot * 4) * 4);
+      const int sw = mt_swz(row), kg2 = (slot >> 1) * 2;
+      a_hi[j] = lds0 + (unsigned)(row * 128 + ((kg2 ^ sw) << 4) + (slot & 1) * 8);
+      a_lo[j] = lds0 + (unsigned)(row * 128 + (((kg2 + 1) ^ sw) << 4) + (slot & 1) * 8);
+    }
+    // B: 32 DMA pieces of 1 KiB (8 rows x 128 B) per k-step, eight per producer wave: piece P = 8 pw + q covers rows 8 P .. 8 P + 7; the
+    // SOURCE slot is swizzled by the row (mt_swz depends on row & 15 = 8 (q & 1) + lane / 8).  One per-lane byte offset per piece against
+    // ONE uniform base that advances 128 B per k-step.
+    const int rl = lane >> 3, sl = lane & 7;
+    unsigned bvoff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      bvoff[q] = (unsigned)((((pw * 64 + q * 8 + rl) * g.D) + (sl ^ mt_swz(8 * (q & 1) + rl)) * 4) * 4);
+    const char* bcur = reinterpret_cast<const char*>(H.wp + n0 * g.D);     // + 128 B per k-step
+    const char* const bdummy = bcur;       // past the last tile the same COUNT of requests re-reads k-step 0 (uniform vmcnt; a stage nobody reads)
+    auto issue_b = [&](const char* bk, unsigned stage_off, int q0) {        // pieces q0 .. q0+3
+      const unsigned sb = lds0 + stage_off + WA_BYTES + pw * 8192;
+#pragma unroll
+      for (int q = q0; q < q0 + 4; ++q)
+        __builtin_amdgcn_global_load_lds((gptr_f)(bk + bvoff[q]), (lptr_f)(uintptr_t)(sb + q * 1024), 16, 0, 0);
+    };
+    struct ARegs { f32x4 v[5]; };
+    auto load_a3 = [&](const float* xk, ARegs& r) {                         // units 0..2
+      asm volatile("global_load_dwordx4 %0, %3, %6\n\tglobal_load_dwordx4 %1, %4, %6\n\tglobal_load_dwordx4 %2, %5, %6"
+                   : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]) : "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "s"(xk) : "memory");
+    };
+    auto load_a2 = [&](const float* xk, ARegs& r) {                         // units 3..4
+      asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4"
+                   : "=&v"(r.v[3]), "=&v"(r.v[4]) : "v"(aoff[3]), "v"(aoff[4]), "s"(xk) : "memory");
+    };
+    typedef float pw_f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pw_b2 __attribute__((ext_vector_type(2)));
+    typedef unsigned pw_u2 __attribute__((ext_vector_type(2)));
+    auto split_store = [&](const f32x4& v, unsigned hi_addr, unsigned lo_addr) {      // one v_cvt_pk_bf16_f32 per PAIR, one ds_write_b64 per plane
+      pw_u2 hi, lo;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float a = v[2 * p], b = v[2 * p + 1];
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f2{a, b}, pw_b2));
+        hi[p] = h;
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f2{a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u)}, pw_b2));
+      }
+      *reinterpret_cast<__attribute__((address_space(3))) pw_u2*>((uintptr_t)hi_addr) = hi;
+      *reinterpret_cast<__attribute__((address_space(3))) pw_u2*>((uintptr_t)lo_addr) = lo;
+    };
+#define PW_NAME5(r) "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4])
+    // prologue: B(0), B(1) requested, A(0) -> stage 0 (the compiler's wait in front of the conversion drains the DMA pieces too), A(1), A(2)
+    // requested into the two register sets; A(1) waited for
+    ARegs ra, rb;                                                           // ra: odd tiles, rb: even tiles
+    issue_b(bcur, 0, 0);
+    issue_b(bcur, 0, 4);
+    issue_b(bcur + (nk > 1 ? 128 : 0), WSTAGE, 0);
+    issue_b(bcur + (nk > 1 ? 128 : 0), WSTAGE, 4);
+    {
+      const char* xb = reinterpret_cast<const char*>(g.X);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) split_store(*reinterpret_cast<const f32x4*>(xb + aoff[j]), a_hi[j], a_lo[j]);
+    }
+    const float* xk = g.X;                                                  // k-step pointer of the NEXT A request
+    {
+      const float* x1 = g.X + (nk > 1 ? 1 : 0) * WBK;
+      const float* x2 = g.X + (nk > 2 ? 2 : nk - 1) * WBK;
+      load_a3(x1, ra); load_a2(x1, ra);
+      load_a3(x2, rb); load_a2(x2, rb);
+    }
+    asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");          // A(1) is here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // A(0) is in LDS
+    slot_end();                                                             // ---- tile 0 complete
+    // running state of k-step s: st1 = byte offset of stage (s+1) % 3 (A(s+1) is stored there), st2 = of stage (s+2) % 3 (B(s+2) lands there)
+    unsigned st1 = WSTAGE, st2 = 2 * WSTAGE;
+    bcur += 2 * 128;                                                        // -> B(s+2)
+    // Both slots of a k-step carry half of the work: units 0..2 / 3..4 of A(s+1) (split + stores) and of the A(s+3) request, pieces 0..3 /
+    // 4..7 of B(s+2).  After the odd slot: wait until only the 13 youngest requests are in flight (this k-step's A(s+3) [5] and B(s+2) [8]):
+    // A(s+2) - requested a k-step ago - is in its registers and B(s+1) has landed.
+    auto kstep = [&](int s, ARegs& r, ARegs& r_next) {                       // r: A(s+1), arrived; r_next: A(s+2), in flight
+      const bool st_ok = s + 1 < nk, b_ok = s + 2 < nk;
+      const float* xn = g.X + (int64_t)(s + 3 < nk ? s + 3 : nk - 1) * WBK;
+      const char* bk = b_ok ? bcur : bdummy;
+      // ---- slot 2s
+      if (st_ok) {
+        split_store(r.v[0], a_hi[0] + st1, a_lo[0] + st1);
+        split_store(r.v[1], a_hi[1] + st1, a_lo[1] + st1);
+        split_store(r.v[2], a_hi[2] + st1, a_lo[2] + st1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a3(xn, r);                                                       // (issued after the split read the registers)
+      issue_b(bk, st2, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot_end();
+      // ---- slot 2s+1
+      if (st_ok) {
+        split_store(r.v[3], a_hi[3] + st1, a_lo[3] + st1);
+        split_store(r.v[4], a_hi[4] + st1, a_lo[4] + st1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_a2(xn, r);
+      issue_b(bk, st2, 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(13)" : PW_NAME5(r_next) : : "memory");
+      slot_end();
+      st1 = st2;
+      st2 = st2 == 2 * WSTAGE ? 0u : st2 + WSTAGE;
+      bcur += 128;
+    };
+    int s = 0;
+#pragma unroll 1
+    for (; s + 1 < nk; s += 2) {
+      kstep(s, ra, rb);
+      kstep(s + 1, rb, ra);
+    }
+    if (s < nk) kstep(s, ra, rb);
+    slot_end();                                                             // slot 2 nk: group 1's last compute phase
+    asm volatile("s_waitcnt vmcnt(0)" : PW_NAME5(ra), PW_NAME5(rb) : : "memory");
+#undef PW_NAME5
+  } else {
+    // ================================================================= consumers: fragment reads and MFMAs only
+    const int r16 = lane & 15, kg = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+    const int ra_ = wm * 80 + r16, rb_ = wn * 64 + r16;
+    const unsigned fa_hi = lds0 + ra_ * 128 + (((2 * kg) ^ mt_swz(ra_)) << 4);
+    const unsigned fa_lo = lds0 + ra_ * 128 + (((2 * kg + 1) ^ mt_swz(ra_)) << 4);
+    const unsigned fb_hi = lds0 + WA_BYTES + rb_ * 128 + (((2 * kg) ^ mt_swz(rb_)) << 4);
+    const unsigned fb_lo = lds0 + WA_BYTES + rb_ * 128 + (((2 * kg + 1) ^ mt_swz(rb_)) << 4);
+    f32x4 x[NFR];
+    auto load_phase = [&](int s) {
+      const unsigned so = (unsigned)((s % WNST) * WSTAGE);
+      MT_READ9(x, 5, 10, fa_lo + so, fb_hi + so);
+      MT_READ9(x, 0, 14, fa_hi + so, fb_lo + so);
+      MT_WAIT9(0, x, 5, 10);
+      MT_WAIT9(0, x, 0, 14);
+    };
+    auto compute_phase = [&]() {
+#ifdef PW_NOMMA
+      return;
+#endif
+      mt_term(x, 5, 10, acc);                                               // lo*hi
+      mt_term(x, 0, 14, acc);                                               // hi*lo
+      mt_term(x, 0, 10, acc);                                               // hi*hi
+    };
+    slot_end();                                                             // ---- tile 0 complete (producers' prologue)
+    const bool late = wm != 0;                                              // group 1 runs the same loop one slot later
+    if (late) slot_end();
+#pragma unroll 1
+    for (int s = 0; s < nk; ++s) {
+      load_phase(s);       slot_end();
+      compute_phase();     slot_end();
+    }
+    if (!late) slot_end();
+  }
+
+  // ================================================================= epilogue: all twelve waves, two 80-row halves through LDS
+  float* tile = reinterpret_cast<float*>(smem);
+  uint32_t* rkeys = reinterpret_cast<uint32_t*>(smem + 80 * WTP * 4);
+  const int c4 = lane * 4, r0 = wave;                                       // this thread's 4 columns are fixed; rows wave, wave + 12, ..
+  const int64_t n = n0 + c4;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (H.bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(H.bias + n); bias[0] = b[0]; bias[1] = b[1]; bias[2] = b[2]; bias[3] = b[3]; }
+  const bool hashed = H.drop_p > 0.f && !H.drop_mask;
+  const uint64_t dseed = hashed ? eff_seed(H.drop_seed, g.drop_tick) : 0;
+  const uint32_t thr16 = (uint32_t)(H.drop_p * 65536.f + 0.5f);
+  const float inv_keep = H.drop_mask ? 1.f / (1.f - H.drop_p) : 65536.f / (float)(65536u - thr16);
+  _Float16* dact = reinterpret_cast<_Float16*>(H.dact);
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                                          // fragment reads / the previous half's tile reads are over
+    if (!producer && wm == half) {
+      const int cl = lane & 15, rq = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int j = 0; j < NRB; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tile[(i * 16 + rq * 4 + e) * WTP + wn * 64 + j * 16 + cl] = acc[i][j][e];
+    }
+    if (hashed && tid < 80) rkeys[tid] = drop_row_key(dseed, (uint64_t)(m0 + half * 80 + tid));
+    __syncthreads();
+#pragma unroll 1
+    for (int r = r0; r < 80; r += W_CONS + W_PROD) {
+      const int64_t m = m0 + half * 80 + r;
+      if (m >= g.N) break;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(tile + r * WTP + c4);
+      float v[4] = {a[0] + bias[0], a[1] + bias[1], a[2] + bias[2], a[3] + bias[3]};
+      float ks[4] = {1.f, 1.f, 1.f, 1.f};
+      if (H.drop_mask) {
+        const uchar4 mk = *reinterpret_cast<const uchar4*>(H.drop_mask + m * g.E + n);
+        ks[0] = mk.x ? inv_keep : 0.f; ks[1] = mk.y ? inv_keep : 0.f; ks[2] = mk.z ? inv_keep : 0.f; ks[3] = mk.w ? inv_keep : 0.f;
+      } else if (hashed) {
+        const uint32_t rk = rkeys[r];
+        const uint32_t h0 = pw_pair_hash(rk, (uint32_t)(n >> 1)), h1 = pw_pair_hash(rk, (uint32_t)(n >> 1) + 1u);
+        ks[0] = (h0 & 0xffffu) >= thr16 ? inv_keep : 0.f;
+        ks[1] = (h0 >> 16) >= thr16 ? inv_keep : 0.f;
+        ks[2] = (h1 & 0xffffu) >= thr16 ? inv_keep : 0.f;
+        ks[3] = (h1 >> 16) >= thr16 ? inv_keep : 0.f;
+      }
+      if (dact) {
+        pw_h4 d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float y, gq;
+          act_fwd_grad(v[q], g.act, y, gq);                   // d out / d pre for the backward (shares the erf)
+          v[q] = y * ks[q];
+          d[q] = (_Float16)(gq * ks[q]);
+        }
+        *reinterpret_cast<pw_h4*>(dact + m * g.E + n) = d;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], g.act) * ks[q];
+      }
+      *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+int bag_project_ws(hipStream_t st, const mhimx_bag_project_args& g) {
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
+  const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)cdiv(g.N, WBM);
+  dim3 grid((unsigned)(8 * nN * cdiv(nM, 8)));
+  hipLaunchKernelGGL(bag_project_ws_kernel, grid, dim3(WTHREADS), WNST * WSTAGE, st, g);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mhimx

@@ -43,7 +43,7 @@ def test_no_swizzled_packed_fp32_instruction(tmp_path):
     assert not bad, "op_sel-swizzled packed fp32 instructions (build the file without SLP, mhim_mil_amd/build.py):\n" + "\n".join(bad[:20])
 
 
-ASM_LOAD_SOURCES = ("bag_project.hip", "wgrad.hip", "scorer_fused.hip")      # the files with inline-asm vector loads
+ASM_LOAD_SOURCES = ("bag_project.hip", "bag_project_ws.hip", "wgrad.hip", "scorer_fused.hip")      # the files with inline-asm vector loads
 
 
 def test_asm_loads_keep_their_registers(tmp_path):
