@@ -521,6 +521,194 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Specialised waves AND a ping-pong of the consumers (the form of bag_project_ws.hip): 4 producer waves (one per SIMD: the X loads,
+// half-wave swap, bf16 split, LDS stores and the image DMA, half of a k-step's work in each of its two slots) and 8 consumer waves as
+// 2 x 4 of 64 x 64 outputs that only read fragments and issue MFMAs.  Consumers cw and cw + 4 share a SIMD and run half a k-step apart:
+// slot 2s: group 0 reads the 16 fragments of tile s | group 1 issues the 48 MFMAs of tile s-1;  slot 2s+1: the other way round - the
+// matrix pipe of every SIMD always has a wave feeding it and the fragment reads run under the partner's MFMAs (bag_wgrad_ws_kernel's four
+// consumers interleave their own reads with their own MFMAs: every fragment wait stalls that SIMD's matrix pipe).  A workgroup barrier
+// after each slot; 3-deep rings: in k-step s the producers store X(s+1) (stage of tile s-2), issue the DMA of image s+2 (stage of tile
+// s-1: both groups are past it) and request X(s+4); at its end they wait until X(s+2) is in registers and image s+1 has landed.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int PP_THREADS = 768;
+__global__ __launch_bounds__(PP_THREADS) void bag_wgrad_pp_kernel(WgradArgs g, int side_blocks, Merge2Side side) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < side_blocks) {
+    if (threadIdx.x < M2_THREADS) merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
+    return;
+  }
+  const unsigned bx = blockIdx.x - (unsigned)side_blocks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nJ = (int)(g.D / WBN), nIT = (int)(g.E / WBI), nT = nIT * nJ;
+  const int xcd = bx & 7, sidx = bx >> 3;
+  const int slab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
+  if (slab >= g.splits) return;
+  const int itile = tile / nJ;
+  const int64_t i0 = (int64_t)itile * WBI, n0 = (int64_t)(tile % nJ) * WBN;
+  const int ks0 = slab * g.kps;
+  const int nk = (ks0 + g.kps < g.ksteps ? ks0 + g.kps : g.ksteps) - ks0;
+  unsigned* rowtab = reinterpret_cast<unsigned*>(smem + SRING);
+  for (int q = tid; q < nk * WBK; q += PP_THREADS) {
+    int64_t l = (int64_t)ks0 * WBK + q;
+    if (l >= g.L) l = g.L - 1;
+    rowtab[q] = (unsigned)((g.rows ? g.rows[l] : l) * g.ldx * 4);
+  }
+  __syncthreads();
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+  auto slot_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (wave < 4) {
+    // =========================================================== producers: wave = row octet of the k-step
+    const int oct = wave, half = lane >> 5, c = lane & 31;
+    const unsigned colb0 = (unsigned)((n0 + 4 * c) * 4), colb1 = colb0 + 128 * 4;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct XSet { f32x4 v[8]; };                               // [column half][row of the lane's four]
+    auto row_offsets = [&](int t) {
+      return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(rowtab) + (oct * 8 + half * 4) * 4 + (t < nk ? t : nk - 1) * 128);
+    };
+    auto load_half = [&](const u32x4& ro, unsigned colb, f32x4* d) {          // four rows of one column half
+      asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\tglobal_load_dwordx4 %2, %6, %8\n\t"
+                   "global_load_dwordx4 %3, %7, %8"
+                   : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                   : "v"(ro[0] + colb), "v"(ro[1] + colb), "v"(ro[2] + colb), "v"(ro[3] + colb), "s"(g.X)
+                   : "memory");
+    };
+    const unsigned xs0 = (unsigned)(SNA * WA_BYTES + ((oct * 2) * 256 + (2 * half) * 64 + c) * 16);
+    auto store_half = [&](int t, int ch, const f32x4* d) {
+      char* sb = smem + (t % SNB) * WB_BYTES + xs0;
+      float a[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q][0] = d[q][0]; a[q][1] = d[q][1]; a[q][2] = d[q][2]; a[q][3] = d[q][3];
+        wg_swap(a[q][0], a[q][2]);
+        wg_swap(a[q][1], a[q][3]);
+      }
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        const float kv[8] = {a[0][sx], a[1][sx], a[2][sx], a[3][sx], a[0][sx + 2], a[1][sx + 2], a[2][sx + 2], a[3][sx + 2]};
+        f32x4 hi, lo;
+        wg_split8(kv, hi, lo);
+        *reinterpret_cast<f32x4*>(sb + ch * 512 + sx * 1024) = hi;
+        *reinterpret_cast<f32x4*>(sb + ch * 512 + sx * 1024 + 4096) = lo;
+      }
+    };
+    const char* abase = g.img + ((int64_t)ks0 * nIT + itile) * WA_BYTES + (wave * 64 + lane) * 16;
+    auto issue_a = [&](int t, bool live) {                     // 16 KiB by 256 threads: four 4 KiB pieces
+      char* sa = smem + (t % SNA) * WA_BYTES + wave * 1024;
+      const char* src = live ? abase + (int64_t)t * nIT * WA_BYTES : g.img;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_f)(live ? src + j * 4096 : src), (lptr_f)(sa + j * 4096), 16, 0, 0);
+    };
+#define PP_ALL(s) "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]), "+v"(s.v[6]), "+v"(s.v[7])
+    // prologue: images 0 and 1 requested, X(0) -> stage 0 (plain loads: the compiler's wait drains the DMA pieces too), X(1), X(2), X(3)
+    // requested into the three register sets, X(1) waited for
+    XSet sa_, sb_, sc_;
+    issue_a(0, true);
+    issue_a(1, nk > 1);
+    {
+      const char* xb = reinterpret_cast<const char*>(g.X);
+      const u32x4 ro = row_offsets(0);
+      XSet r0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        r0.v[q] = *reinterpret_cast<const f32x4*>(xb + ro[q] + colb0);
+        r0.v[4 + q] = *reinterpret_cast<const f32x4*>(xb + ro[q] + colb1);
+      }
+      store_half(0, 0, &r0.v[0]);
+      store_half(0, 1, &r0.v[4]);
+    }
+    { const u32x4 ro = row_offsets(1); load_half(ro, colb0, &sa_.v[0]); load_half(ro, colb1, &sa_.v[4]); }
+    { const u32x4 ro = row_offsets(2); load_half(ro, colb0, &sb_.v[0]); load_half(ro, colb1, &sb_.v[4]); }
+    { const u32x4 ro = row_offsets(3); load_half(ro, colb0, &sc_.v[0]); load_half(ro, colb1, &sc_.v[4]); }
+    asm volatile("s_waitcnt vmcnt(16)" : PP_ALL(sa_) : : "memory");          // X(1) is here (the images are older: landed)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    slot_end();                                               // ---- tile 0 complete
+    // k-step s: r = X(s+1) (arrived), r_next = X(s+2) (in flight, waited for at the end)
+    auto kstep = [&](int s, XSet& r, XSet& r_next) {
+      const bool st_ok = s + 1 < nk;
+      const u32x4 ro = row_offsets(s + 4);
+      // ---- slot 2s: the image DMA first (the end-of-k-step wait leaves everything younger than it in flight), column half 0
+#ifdef PPW_NOPROD
+      slot_end(); slot_end(); return;
+#endif
+      issue_a(s + 2, s + 2 < nk);
+      if (st_ok) store_half(s + 1, 0, &r.v[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_half(ro, colb0, &r.v[0]);                          // X(s+4), column half 0 (issued after the split read the registers)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot_end();
+      // ---- slot 2s+1: column half 1
+      if (st_ok) store_half(s + 1, 1, &r.v[4]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_half(ro, colb1, &r.v[4]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // in flight, oldest first: X(s+2) [8] | image s+1 [4], X(s+3) [8] | image s+2 [4], X(s+4) [8]: leave the 20 youngest
+      asm volatile("s_waitcnt vmcnt(20)" : PP_ALL(r_next) : : "memory");
+      slot_end();
+    };
+    // (the remainder k-steps sit INSIDE the rotation loop: separate tail copies are laid out where tools/asm_lint.py's linear scan cannot
+    // see the waits that precede them)
+#pragma unroll 1
+    for (int s = 0; s < nk; s += 3) {
+      kstep(s, sa_, sb_);
+      if (s + 1 < nk) kstep(s + 1, sb_, sc_);
+      if (s + 2 < nk) kstep(s + 2, sc_, sa_);
+    }
+    slot_end();                                               // slot 2 nk: group 1's last compute phase
+    asm volatile("s_waitcnt vmcnt(0)" : PP_ALL(sa_), PP_ALL(sb_), PP_ALL(sc_) : : "memory");
+#undef PP_ALL
+    return;
+  }
+
+  // =============================================================== consumers: 2 x 4 waves of 64 (E) x 64 (D)
+  const int cw = wave - 4, wm = cw >> 2, wn = cw & 3;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const unsigned fa_hi = lds0 + ((kg * 2) * 128 + 16 * wm + r16) * 16, fa_lo = fa_hi + 2048;
+  const unsigned fb_hi = lds0 + SNA * WA_BYTES + ((kg * 2) * 256 + 16 * wn + r16) * 16, fb_lo = fb_hi + 4096;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 x[WNF];
+  slot_end();                                                 // ---- tile 0 complete (producers' prologue)
+  const bool late = wm != 0;                                  // group 1 runs the same loop one slot later
+  if (late) slot_end();
+#pragma unroll 1
+  for (int s = 0; s < nk; ++s) {
+    const unsigned soa = (unsigned)((s % SNA) * WA_BYTES), sob = (unsigned)((s % SNB) * WB_BYTES);
+    WG_READ8(x, 4, 8, fa_lo + soa, fb_hi + sob);
+    WG_READ8(x, 0, 12, fa_hi + soa, fb_lo + sob);
+    WG_WAIT8(0, x, 4, 8);
+    WG_WAIT8(0, x, 0, 12);
+    slot_end();
+#ifndef PPW_NOMMA
+    wg_term(x, 4, 8, acc);                                    // lo*hi
+    wg_term(x, 0, 12, acc);                                   // hi*lo
+    wg_term(x, 0, 8, acc);                                    // hi*hi
+#endif
+    slot_end();
+  }
+  if (!late) slot_end();
+  // ---- epilogue: tile (ja, jb) of a lane is row 4 (16 wm + 4 (lane >> 4) + e) + ja, column 4 (16 wn + (lane & 15)) + jb: 16-byte stores
+  float* out = g.out + (int64_t)slab * g.E * g.D;
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i0 + 4 * (16 * wm + 4 * kg + e) + ja;
+      const int64_t n = n0 + 4 * (16 * wn + r16);
+      *reinterpret_cast<f32x4*>(out + i * g.D + n) = f32x4{acc[ja][0][e], acc[ja][1][e], acc[ja][2][e], acc[ja][3][e]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // dPRE -> matrix-core image + column-sum partials.  One workgroup per (32-row k-step, 256 columns); thread -> (4 columns, one row
 // octet): 8 x (16 B of dH + 8 B of dact16) in flight per thread, ~10 waves per CU.
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -675,8 +863,17 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   // (unused, clamped) last prefetch loads were still in flight, and their data landed on the row offsets of the next asm loads - only
   // when latency was stretched.  Fixed there, checked by tools/asm_lint.py (tests/test_isa_lint_cpu.py); 12 of 12 two-process runs
   // finish.  MHIMX_WGRAD_UNIFORM=1 selects the uniform kernel (experiments).
+  // Round 3: bag_wgrad_pp_kernel (specialised waves + ping-pong consumers, 768 threads: what took the projection from 73 to 63 us)
+  // measures the SAME as the specialised-wave kernel here (34.7 vs 34.5 us same-box; consumers alone 27.8, producers alone 27.8, both 37:
+  // ~13 us of the launch are the row table, the first tiles and the 33 MB of slab stores, outside the loop either form pipelines), so the
+  // round-2 kernel stays the default; MHIMX_WGRAD_PP=1 selects the ping-pong form, MHIMX_WGRAD_UNIFORM=1 the uniform one.
   static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;
-  if (ws_form) {
+  static const bool pp_form = ws_form && getenv("MHIMX_WGRAD_PP") != nullptr;
+  if (pp_form) {
+    const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
+    hipLaunchKernelGGL(bag_wgrad_pp_kernel, grid, dim3(PP_THREADS), smem2, (hipStream_t)stream, g, side_blocks, side);
+  } else if (ws_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
     hipLaunchKernelGGL(bag_wgrad_ws_kernel, grid, dim3(WTHREADS), smem2, (hipStream_t)stream, g, side_blocks, side);
