@@ -405,7 +405,10 @@ MHIMX_DEV uint32_t radix_select_regs(const uint32_t (&key)[KPT], const bool (&va
 
 // Thread t owns the CONTIGUOUS instances [t*KPT, (t+1)*KPT): every order-dependent step (ties lowest index first,
 // ascending compaction) then costs ONE block scan of per-thread counts instead of one per 1024-instance chunk.
-template <int KPT>
+// LEAN: the production call (mhimx_select_rows without a mask-id list: device-drawn subsets, no injected permutation, no earlier
+// mask, no top-k list) - the branches of every other form are compiled out.  The kernel runs ONCE per step on one workgroup: its
+// 4 151 instructions (~25 KB) are fetched cold by 16 waves; the lean instantiation has 3 452.
+template <int KPT, bool LEAN = false>
 __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     const float* __restrict__ score, int N, int k, int n_sel, int largest, const int64_t* __restrict__ perm,
     const int64_t* __restrict__ other, int64_t n_other, int64_t* __restrict__ mask_ids, int64_t* __restrict__ len_keep_dev,
@@ -475,9 +478,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   SEL_STAMP(2);
   // ---- 3. order the candidates: (value desc, index asc) == key desc
   // (the device-drawn random subset below depends on the candidate SET only: no ordering needed unless it is returned)
-  const bool dev_rand = use_rand && !perm && n_sel < k;
+  const bool dev_rand = LEAN || (use_rand && !perm && n_sel < k);
   const uint64_t* cand = sorted;
-  if (dev_rand && !topk_out) {
+  if (LEAN || (dev_rand && !topk_out)) {
     cand = keys;
   } else if (k <= 2048) {
     for (int j = tid; j < k; j += SEL_THREADS) {
@@ -501,12 +504,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
         __syncthreads();
       }
   }
-  if (topk_out)
+  if (!LEAN && topk_out)
     for (int j = tid; j < k; j += SEL_THREADS) topk_out[j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(sorted[j] & 0xFFFFFFFFull));
 
   SEL_STAMP(3);
   // ---- 4. flags (LDS bitmap)
-  const bool has_other = other != nullptr && n_other > 0;
+  const bool has_other = !LEAN && other != nullptr && n_other > 0;
   const int len_keep_simple = N - n_sel;
   if (dev_rand) {
     // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host
@@ -546,10 +549,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
       if (r < n_sel) {
         const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
         atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
-        if (!has_other && mask_ids) mask_ids[len_keep_simple + r] = (int64_t)idx;
+        if (!LEAN && !has_other && mask_ids) mask_ids[len_keep_simple + r] = (int64_t)idx;
       }
     }
-  } else {
+  } else if (!LEAN) {
     for (int j = tid; j < n_sel; j += SEL_THREADS) {
       const int64_t src = perm ? perm[j] : (int64_t)j;
       const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(sorted[src] & 0xFFFFFFFFull);
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   }
   uint32_t kept_total;
   uint32_t kpos = block_scan_excl(nkeep, wave_tot, &kept_total);
-  if (mask_ids) {
+  if (!LEAN && mask_ids) {
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
       if (kv[j]) mask_ids[kpos++] = i0 + j;
@@ -591,9 +594,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
         if (valid[j] && !kv[j]) mask_ids[mpos++] = i0 + j;
     }
   }
-  if (tid == 0 && len_keep_dev) *len_keep_dev = (int64_t)kept_total;
+  if (!LEAN && tid == 0 && len_keep_dev) *len_keep_dev = (int64_t)kept_total;
   SEL_STAMP(5);
-  if (!rows_out) return;
+  if (!LEAN && !rows_out) return;
 
   // ---- 6. Merge.masking (merge.py:158-176): a uniformly random R-subset of the kept rows is merged away.  Same device:
   // random 32-bit key per kept row, radix-select the R largest (ties by index), then ordered compactions ->
@@ -969,7 +972,21 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096))));
-    if (N <= 4096) MHIMX_SEL_SMALL(4);
+    const bool lean = g_use_rand && g_rows_out && !perm && !other && !mask_ids && !len_keep_dev && !topk_sorted && n_sel < k;
+    if (lean) {
+#define MHIMX_SEL_LEAN(KPT)                                                                                                    \
+      hipLaunchKernelGGL((select_small_kernel<KPT, true>), dim3(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
+                         (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,        \
+                         g_rand_seed, g_tick, g_merge_R, g_rows_out)
+      MHIMX_ONCE_PER_DEVICE(
+          MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+          MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
+          MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096))));
+      if (N <= 4096) MHIMX_SEL_LEAN(4);
+      else if (N <= 10240) MHIMX_SEL_LEAN(10);
+      else MHIMX_SEL_LEAN(16);
+#undef MHIMX_SEL_LEAN
+    } else if (N <= 4096) MHIMX_SEL_SMALL(4);
     else if (N <= 10240) MHIMX_SEL_SMALL(10);
     else MHIMX_SEL_SMALL(16);          // thread t owns instances [t*KPT, (t+1)*KPT)
 #undef MHIMX_SEL_SMALL

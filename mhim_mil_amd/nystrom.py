@@ -363,8 +363,9 @@ def _landmark_pinv_forward(lm, scale):
     return a2, z, z0, stats, chain
 
 
-def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm):
-    """Backward of _landmark_pinv_forward: dz (gradient of the pseudo-inverse) -> the S2 terms of dq~ / dk~, ADDED into dlm."""
+def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm, accumulate=True):
+    """Backward of _landmark_pinv_forward: dz (gradient of the pseudo-inverse) -> the S2 terms of dq~ / dk~, ADDED into dlm
+    (``accumulate=False``: written into it - a buffer of its own when the chain runs on a side stream)."""
     lib = L.lib()
     m, dev = LANDMARKS, lm.device
     ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
@@ -386,8 +387,58 @@ def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm):
     L.check(lib.mhimx_axpby(_st(), _ptr(dinit), _ptr(da2), da2.numel(), 1.0, 1.0), "axpby")
     L.check(lib.mhimx_softmax_rows_bwd(_st(), _ptr(a2), _ptr(da2), _ptr(da2), HEADS * m, m, float(scale)), "softmax_rows_bwd")
     ds2 = batched(da2)
-    _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=True)              # s2 = q~ k~^T: dq~ += ds2 k~
-    _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=True)              #               dk~ += ds2^T q~
+    _heads_mm("nn", ds2, kl, dql, HEADS, accumulate=accumulate)        # s2 = q~ k~^T: dq~ += ds2 k~
+    _heads_mm("tn", ds2, ql, dkl, HEADS, accumulate=accumulate)        #               dk~ += ds2^T q~
+
+
+# The pseudo-inverse chain (24 dependent launches of 128 workgroups forward, 24 pairs backward: ~8-13 us each, latency-bound) depends on
+# the landmark means alone; the streamed token passes beside it (a3 v forward; its backward) fill the chip with thousands of workgroups.
+# They are independent, so the chain runs on a SIDE stream (a second branch of the captured hipGraph) and joins where its result is
+# needed.  MEASURED (round 3, c3, same box, hipGraph replay): 11.07 ms with the fork against 10.88 ms on one stream - six fork / join pairs
+# per step cost more in cross-queue signalling (~60 us each on this ROCm build) than the overlapped launches save, so the fork is OPT-IN
+# (MHIMX_NYS_FORK=1); the accumulation window of the ABMIL trainer forks once per 8 bags and gains 1.7x from the same mechanism.
+_FORK = os.environ.get("MHIMX_NYS_FORK", "0") != "0"
+_SIDE = {}
+
+
+class _Side:
+    """with _Side(device) as f: ... work on the side stream ...;  f.join(tensors): the current stream waits for it (the tensors made on
+    the side stream are handed to the caching allocator as used by the current one)."""
+
+    def __init__(self, dev):
+        self.on = _FORK and dev.type == "cuda"
+        if self.on:
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            self.side = _SIDE.get(key)
+            if self.side is None:
+                self.side = _SIDE[key] = torch.cuda.Stream(dev)
+            self.cur = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.ctx.__exit__(*a)
+
+    def join(self, tensors=()):
+        if self.on:
+            self.cur.wait_stream(self.side)
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(self.cur)
+
+
+def _flat(x):
+    for t in x:
+        if isinstance(t, (list, tuple)):
+            yield from _flat(t)
+        else:
+            yield t
 
 
 def _core_forward(qkv, conv_w, l, scale):
@@ -399,8 +450,10 @@ def _core_forward(qkv, conv_w, l, scale):
     L.check(lib.mhimx_landmark_mean(_st(), _ptr(qkv), ld, T, l, 2 * INNER, _ptr(lm)), "landmark_mean")
     ql, kl = Op(lm, 0, DH, 2 * INNER, m, DH), Op(lm, INNER, DH, 2 * INNER, m, DH)
     no = ops.NysOperands(qkv, lm, scale)
-    a2, z, z0, stats, chain = _landmark_pinv_forward(lm, scale)
+    with _Side(dev) as fork:                                           # the landmark-only chain beside the token pass
+        a2, z, z0, stats, chain = _landmark_pinv_forward(lm, scale)
     a3v, lse3 = ops.nys_a3v_fwd(no)                                    # softmax_n(q~ k^T) v   nystrom:116,131,133
+    fork.join(_flat((a2, z, z0, stats, chain)))
     w2 = torch.empty((HEADS, m, DH), device=dev)
     _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
     out, lse1 = ops.nys_out_fwd(no, w2)                                # softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
@@ -431,11 +484,15 @@ def _core_backward(saved, dout):
     # w2 = z a3v
     dz = torch.empty_like(z)
     _heads_mm("nt", batched(dw2), batched(a3v), batched(dz), HEADS)    # dz = dw2 a3v^T
+    dlm2 = torch.empty_like(dlm)
+    with _Side(dev) as fork:                                           # the pseudo-inverse's backward beside the token-side backward
+        _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm2, accumulate=False)
     da3v = torch.empty_like(a3v)
     _heads_mm("tn", batched(z), batched(dw2), batched(da3v), HEADS)    # da3v = z^T dw2
     # a3v = a3 v: dk, dv +=, the S3 term of dq~
     ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, accumulate_dv=True)
-    _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm)
+    fork.join((dlm2,))
+    L.check(lib.mhimx_axpby(_st(), _ptr(dlm2), _ptr(dlm), dlm.numel(), 1.0, 1.0), "axpby")      # + the attn2 terms
     L.check(lib.mhimx_landmark_mean_bwd(_st(), _ptr(dlm), T, l, 2 * INNER, _ptr(dqkv), ld, 1), "landmark_mean_bwd")
     return dqkv, dwc.reshape(wshape)
 
