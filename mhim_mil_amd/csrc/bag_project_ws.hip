@@ -265,7 +265,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       if (H.drop_mask) {
         const uchar4 mk = *reinterpret_cast<const uchar4*>(H.drop_mask + m * g.E + n);
         ks[0] = mk.x ? inv_keep : 0.f; ks[1] = mk.y ? inv_keep : 0.f; ks[2] = mk.z ? inv_keep : 0.f; ks[3] = mk.w ? inv_keep : 0.f;
-      } else if (hashed) {
+      }
+#ifndef PW_EPI_NOHASH
+      else if (hashed) {
         const uint32_t rk = rkeys[r];
         const uint32_t h0 = pw_pair_hash(rk, (uint32_t)(n >> 1)), h1 = pw_pair_hash(rk, (uint32_t)(n >> 1) + 1u);
         ks[0] = (h0 & 0xffffu) >= thr16 ? inv_keep : 0.f;
@@ -273,6 +275,14 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
         ks[2] = (h1 & 0xffffu) >= thr16 ? inv_keep : 0.f;
         ks[3] = (h1 >> 16) >= thr16 ? inv_keep : 0.f;
       }
+#endif
+#ifdef PW_EPI_NOACT
+      if (dact) {
+        pw_h4 d;
+        for (int q = 0; q < 4; ++q) { d[q] = (_Float16)(v[q] * ks[q]); v[q] = v[q] * ks[q]; }
+        *reinterpret_cast<pw_h4*>(dact + m * g.E + n) = d;
+      } else
+#endif
       if (dact) {
         pw_h4 d;
 #pragma unroll
