@@ -117,6 +117,28 @@ int mhimx_bmm_affine(void* stream, int32_t mode, const mhimx_gemm_nt_args* args,
  * `7 I - xz` of nystrom_attention.py:23-25 in one launch */
 int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, int32_t batch, int64_t strideA, int64_t strideB,
                       int64_t strideC, float alpha, float ident, float* C2, float alpha2, float ident2);
+/* A CHAIN of dependent steps over batches of 8 contiguous [256, 256] matrices in ONE launch - the six iterations of the pseudo-inverse
+ * (nystrom_attention.py:21-25) are 24 products forward, 48 + 6 sums backward.  Operands are SPLIT IMAGES: per matrix, a bf16 hi plane
+ * then a bf16 lo plane, [256][256] each (hi = bf16(x), lo = bf16(x - hi); 128 KiB + 128 KiB = the bytes of the fp32 matrix, heads
+ * contiguous), of the matrix itself ("N") or of its transpose ("T").
+ *   kind 0:  P = A B  with A = an N image of A, B = a T image of B (3-term bf16, fp32 accumulate);
+ *            X1 = ident I + alpha P (+ D, an fp32 matrix, which may be C itself; it enters as the accumulator's start value D / alpha,
+ *            exact for |alpha| a power of two; not together with a second output);   X2 = ident2 I + alpha2 P;
+ *            any of: C = X1 (fp32), PN / PT = N / T image of X1, C2 = X2 (fp32), PN2 / PT2 = N / T image of X2.
+ *   kind 1:  no product: PN / PT = images of alpha * A (+ D), A and D fp32 matrices (how a chain takes its inputs in, or sums two).
+ *   kind -1: nothing (an idle slot of a two-group stage).
+ * The table is steps[stage * groups + group]: the steps of one stage are independent of each other and may read whatever earlier STAGES
+ * wrote.  128 x groups persistent workgroups of 1024 threads (groups = 1 or 2); the tiles of a head hand over through a per-head arrival
+ * counter (write-through stores, cache-bypassing loads: no grid barrier).  counters: 9 uint32, ZERO at launch; [0..7] are zero again
+ * when the launch ends; [8] != 0 afterwards means a workgroup gave up waiting (workgroups not co-resident: the launch needs
+ * 128 x groups free CUs) and the outputs are invalid.  stages * groups <= 42.  A step must not overwrite its own operands.
+ *   replaces: the same torch.matmul chain as mhimx_bmm_affine, 7.4 us per product (13.7 us per pair) as launches. */
+typedef struct {
+  const void* A; const void* B; float* C; float* C2; void* PN; void* PT; void* PN2; void* PT2; const float* D;
+  float alpha, ident, alpha2, ident2;
+  int32_t kind;
+} mhimx_bmm_step;
+int mhimx_bmm_chain(void* stream, const mhimx_bmm_step* steps, int32_t stages, int32_t groups, uint32_t* counters);
 /* two INDEPENDENT batches of 256 x 256 x 256 products in one launch (contiguous [batch, 256, 256] operands, stride = 65536): the
  * backward of a pseudo-inverse iteration is four such pairs (nystrom_attention.py:21-26 under autograd). */
 int mhimx_bmm_affine_pair(void* stream, int32_t mode0, const mhimx_gemm_nt_args* a0, float alpha0, float ident0, int32_t mode1,

@@ -140,6 +140,13 @@ class Nys(C.Structure):
                 ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
 
 
+class BmmStep(C.Structure):
+    """mhimx_bmm_step (include/mhimx.h)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p), ("PN", C.c_void_p), ("PT", C.c_void_p),
+                ("PN2", C.c_void_p), ("PT2", C.c_void_p), ("D", C.c_void_p), ("alpha", C.c_float), ("ident", C.c_float),
+                ("alpha2", C.c_float), ("ident2", C.c_float), ("kind", C.c_int32)]
+
+
 class OptimArgs(C.Structure):
     """mhimx_optim_args (include/mhimx.h)."""
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("teacher", C.c_void_p),
@@ -201,6 +208,7 @@ SYMBOLS = {
     "mhimx_colsum": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I64]),
     "mhimx_head_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _F, _F, _F, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mhimx_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _F, _F, _F, _F, _F, _F, _I32, _P, _P, _I64]),
+    "mhimx_bmm_chain": (C.c_int, [_P, C.POINTER(BmmStep), _I32, _I32, _P]),
     "mhimx_optim_step": (C.c_int, [_P, C.POINTER(OptimArgs)]),
     "mhimx_stream_copy": (C.c_int, [_P, _P, _P, _I64]),
     "mhimx_tick": (C.c_int, [_P, _P]),

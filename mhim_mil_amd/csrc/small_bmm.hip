@@ -203,6 +203,217 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0,
   else small_bmm_full_any(g1, mode1, (int)blockIdx.z - batch, sbf);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// A CHAIN of dependent batched 256 x 256 x 256 products in ONE launch (mhimx_bmm_chain): the Nystrom pseudo-inverse iteration is 24 such
+// products per layer pass, each reading the previous one's output (nystrom_attention.py:21-25).  As launches a product took 7.4 us, of
+// which (stamped, round 3): 1.0 us operand loads, 1.8 us LDS staging (transposing stores), 3.1 us the 16 dependent k-steps - and 2.5 us of
+// THOSE are the bf16 hi/lo splits, every operand element split again by each of the two waves that use it and again by every product
+// that reads the matrix.  Here
+//   * a matrix lives in memory as its SPLIT IMAGE - bf16 hi plane + bf16 lo plane, [256][256] each, in the orientation its reader wants
+//     ("N": rows k-contiguous as stored, the A operand; "T": the transpose, the B operand) - written once by the step that produces it
+//     (4096 splits per workgroup instead of 65536); fp32 copies are written only where something outside the chain reads them;
+//   * both operand panels ([64 rows][256 k] x 2 planes) go global -> LDS by DMA (no registers, no LDS stores), rows XOR-swizzled by the
+//     per-lane GLOBAL address (LDS stays lane-linear: chunk c of row r sits at chunk c ^ (r & 31)), so the fragment reads are b128 and
+//     conflict-free with an unpadded 512-byte pitch;
+//   * 16 waves: wave w owns the 32 x 32 block (w >> 1 & 1, w & 1) over the k quarter w >> 2 - 12 MFMAs, no VALU between - and the quarters
+//     meet through LDS in a fixed order;
+//   * 128 persistent workgroups (one 64 x 64 tile of one of the 8 heads each) walk the chain; only the 16 workgroups of a head depend on
+//     each other, so the hand-off is a per-head arrival counter, not a grid barrier:
+//       producer: everything leaves as 16-byte WRITE-THROUGH stores (sc0 sc1), s_waitcnt vmcnt(0), workgroup barrier, one relaxed
+//                 agent-scope atomic add;
+//       consumer: one lane polls the counter (relaxed agent-scope loads, s_sleep between), workgroup barrier, then DMA-loads its panels
+//                 with sc0 sc1 (they bypass this CU's L1 and this XCD's L2 and see what the producers wrote through) - the {sc0 sc1 stores
+//                 and loads on both sides} form of MI355X_MICROARCH.md: no L2 write-back, no L1 invalidate, placement-independent.
+// Workgroup b serves head b % 8.  The last arrival of a head's last step zeroes its counter: the counters are all-zero again when the
+// launch ends (hipGraph replays re-use them).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int CH_MAX = 42, CH_THREADS = 1024, CH_SPIN_MAX = 1 << 22;
+struct ChainStep {
+  const void* A; const void* B; float* C; float* C2; void* PN; void* PT; void* PN2; void* PT2; const float* D;
+  float alpha, ident, alpha2, ident2;
+  int kind;
+};
+struct Chain { ChainStep st[CH_MAX]; int n, groups; unsigned* ctr; };
+typedef unsigned sb_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) void* ch_gptr;
+typedef __attribute__((address_space(3))) void* ch_lptr;
+constexpr int CH_PLANE = SBF_KMAX * SBF_KMAX * 2;               // bytes of one bf16 plane of one head
+constexpr int CH_PANEL = SB_T * SBF_KMAX * 2;                   // bytes of one plane of one 64-row panel in LDS (32 KiB)
+
+__global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
+  extern __shared__ __attribute__((aligned(16))) char chs[];   // [A hi | A lo | B hi | B lo] panels; after the products: partials + tiles
+  float* P = reinterpret_cast<float*>(chs);                     // k-quarter partials [4][4 blocks][16][64 lanes]   (64 KiB)
+  float* T1 = reinterpret_cast<float*>(chs + 2 * CH_PANEL);     // output tiles [64][68] fp32
+  float* T2 = T1 + SB_T * 68;
+  float* TT = T2 + SB_T * 68;                                   // transposes of the first / second output
+  float* TT2 = TT + SB_T * 68;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = wave >> 2, wmn = wave & 3, wm = wmn >> 1, wn = wmn & 1;
+  const int head = (int)blockIdx.x & 7, tile = ((int)blockIdx.x >> 3) & 15, group = (int)blockIdx.x >> 7;
+  const int m0 = (tile >> 2) * SB_T, n0 = (tile & 3) * SB_T;
+  constexpr unsigned MAT_BYTES = SBF_KMAX * SBF_KMAX * 4;
+  constexpr int POL = 1 | 16;                                   // sc0 sc1
+  __shared__ int dead;
+  if (tid == 0) dead = 0;
+  const int64_t hoff = (int64_t)head * SBF_KMAX * SBF_KMAX;     // elements of an fp32 matrix; a split image has the same byte size
+  unsigned* ctr = c.ctr + head;
+#ifdef CH_PROF
+  unsigned long long tsv[12];
+#define CH_STAMP(i) do { if (s == CH_PROF) tsv[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CH_STAMP(i) do {} while (0)
+#endif
+  for (int s = 0; s < c.n; ++s) {
+    const ChainStep st = c.st[s * c.groups + group];
+    const unsigned per_stage = 16u * (unsigned)c.groups;
+    CH_STAMP(0);
+    if (s > 0) {                                                // every tile of this head's previous stage is written
+      if (tid == 0) {
+        const unsigned want = per_stage * (unsigned)s;
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < CH_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+        if (spins >= CH_SPIN_MAX) {                             // a workgroup of the head never arrived (not co-resident?): give up, loudly,
+          dead = 1;                                             // instead of hanging the GPU - counters[8] != 0 tells the host
+          __hip_atomic_store(c.ctr + 8, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __syncthreads();
+      if (dead) return;
+    }
+    CH_STAMP(1);
+    sb_f16 acc;
+    const int r = lane & 31, kh = lane >> 5;
+    if (st.kind < 0) {                                          // nothing to do for this group at this stage: only arrive
+    } else if (st.kind == 0) {
+      // 128 DMA instructions of 1 KiB (two 512-byte rows of one plane) per workgroup, 8 per wave
+      const char* ga = reinterpret_cast<const char*>(st.A) + hoff * 4 + (int64_t)m0 * 512;
+      const char* gb = reinterpret_cast<const char*>(st.B) + hoff * 4 + (int64_t)n0 * 512;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = wave * 8 + i, opnd = q >> 6, plane = (q >> 5) & 1, rp = q & 31;
+        const int row = 2 * rp + (lane >> 5), chunk = (lane & 31) ^ (row & 31);
+        const char* src = (opnd ? gb : ga) + plane * CH_PLANE + row * 512 + chunk * 16;
+        __builtin_amdgcn_global_load_lds((ch_gptr)src, (ch_lptr)(chs + (opnd * 2 + plane) * CH_PANEL + rp * 1024), 16, 0, POL);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      if (st.D && !kq) {                                        // the addend enters as the accumulator's start value, D / alpha (exact for the
+        const float ia = 1.f / st.alpha;                        // chain's alphas, +-1 and +-0.25): its loads fly with the DMA, no registers
+        __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(st.D + hoff), 0, MAT_BYTES, 0x00027000);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int ml = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh, nl = wn * 32 + r;
+          acc[e] = ia * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (unsigned)(((m0 + ml) * SBF_KMAX + n0 + nl) * 4), 0, POL));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my rows have landed in LDS
+      CH_STAMP(2);
+      __syncthreads();
+      CH_STAMP(3);
+      const int ra = wm * 32 + r, rb = wn * 32 + r;
+      const char* pa = chs + ra * 512;
+      const char* pb = chs + 2 * CH_PANEL + rb * 512;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = (kq * 4 + ks) * 2 + kh;
+        const int oa = ((chunk ^ (ra & 31)) * 16), ob = ((chunk ^ (rb & 31)) * 16);
+        const sb_b8 ah = *reinterpret_cast<const sb_b8*>(pa + oa), al = *reinterpret_cast<const sb_b8*>(pa + CH_PANEL + oa);
+        const sb_b8 bh = *reinterpret_cast<const sb_b8*>(pb + ob), bl = *reinterpret_cast<const sb_b8*>(pb + CH_PANEL + ob);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+      CH_STAMP(4);
+      __syncthreads();                                          // the panels are consumed: partials and tiles go through the same LDS
+      CH_STAMP(8);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) P[((kq * 4 + wmn) * 16 + e) * 64 + lane] = acc[e];
+      __syncthreads();
+      CH_STAMP(9);
+      {                                                         // every thread sums the four quarters of 4 elements (fixed order) -> tiles
+        const int bw = tid >> 8, eg = (tid >> 6) & 3;           // block, group of four accumulator rows
+        const float* pp = P + (bw * 16 + eg * 4) * 64 + lane;
+        float sum[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float q0 = pp[j * 64], q1 = pp[4096 + j * 64], q2 = pp[8192 + j * 64], q3 = pp[12288 + j * 64];
+          sum[j] = ((q0 + q1) + q2) + q3;
+        }
+        const int ml = (bw >> 1) * 32 + 8 * eg + 4 * kh, nl = (bw & 1) * 32 + r;
+        sb_f4 t, t2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool diag = (m0 + ml + j) == (n0 + nl);
+          const float v1 = st.alpha * sum[j] + (diag ? st.ident : 0.f);
+          const float v2 = st.alpha2 * sum[j] + (diag ? st.ident2 : 0.f);
+          T1[(ml + j) * 68 + nl] = v1;
+          T2[(ml + j) * 68 + nl] = v2;
+          t[j] = v1;
+          t2[j] = v2;
+        }
+        *reinterpret_cast<sb_f4*>(TT + nl * 68 + ml) = t;
+        *reinterpret_cast<sb_f4*>(TT2 + nl * 68 + ml) = t2;
+      }
+      CH_STAMP(10);
+    } else {                                                    // kind 1: split the fp32 matrix alpha * A (+ D) into its images, no product
+      const int row = tid >> 4, c4 = (tid & 15) * 4;
+      const unsigned off = (unsigned)(((m0 + row) * SBF_KMAX + n0 + c4) * 4);
+      __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const float*>(st.A) + hoff), 0, MAT_BYTES, 0x00027000);
+      sb_f4 v = st.alpha * __builtin_bit_cast(sb_f4, __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, POL));
+      if (st.D) {
+        __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(st.D + hoff), 0, MAT_BYTES, 0x00027000);
+        v += __builtin_bit_cast(sb_f4, __builtin_amdgcn_raw_buffer_load_b128(rD, off, 0, POL));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T1[row * 68 + c4 + q] = v[q];
+        TT[(c4 + q) * 68 + row] = v[q];
+      }
+    }
+    __syncthreads();
+    CH_STAMP(5);
+    {
+      const int row = tid >> 4, c4 = (tid & 15) * 4;
+      const unsigned off = (unsigned)(((m0 + row) * SBF_KMAX + n0 + c4) * 4);
+      if (st.C) {
+        __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(st.C + hoff), 0, MAT_BYTES, 0x00027000);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const sb_u4*>(T1 + row * 68 + c4), rC, off, 0, POL);
+      }
+      if (st.C2) {
+        __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(st.C2 + hoff), 0, MAT_BYTES, 0x00027000);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const sb_u4*>(T2 + row * 68 + c4), rC2, off, 0, POL);
+      }
+      // the split images: threads 0-511 the N image(s), 512-1023 the T image(s), 8 elements each
+      const int t = tid & 511, prow = t >> 3, c8 = (t & 7) * 8;
+      const bool second = tid >= 512;
+      const unsigned po = (unsigned)((((second ? n0 : m0) + prow) * SBF_KMAX + (second ? m0 : n0) + c8) * 2);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        void* img = o ? (second ? st.PT2 : st.PN2) : (second ? st.PT : st.PN);
+        if (img) {
+          const float* src = (o ? (second ? TT2 : T2) : (second ? TT : T1)) + prow * 68 + c8;
+          sb_b8 hi, lo;
+          sb_split(*reinterpret_cast<const sb_f4*>(src), *reinterpret_cast<const sb_f4*>(src + 4), hi, lo);
+          __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(img) + hoff * 4), 0, MAT_BYTES, 0x00027000);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sb_u4, hi), rP, po, 0, POL);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sb_u4, lo), rP, po + CH_PLANE, 0, POL);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my write-through stores have left (inline asm: the compiler must not drop it)
+    __syncthreads();                                            // ... and everybody's; the LDS tiles are free again
+    CH_STAMP(6);
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s == c.n - 1 && old == per_stage * (unsigned)c.n - 1u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    CH_STAMP(7);
+  }
+#ifdef CH_PROF
+  if (tid == 0 && blockIdx.x < 8) for (int i = 0; i < 12; ++i) reinterpret_cast<unsigned long long*>(c.ctr + 16)[blockIdx.x * 12 + i] = tsv[i];
+#endif
+}
+
 bool small_bmm_ok(int mode, const mhimx_gemm_nt_args& g, int batch, int64_t sA, int64_t sB, int64_t sC) {
   if (g.prec == MHIMX_PREC_F32 || g.rows || g.bias || g.M % SB_T || g.N % SB_T || g.K % SB_K) return false;
   if (g.M > 512 || g.N > 512 || g.K > 1024 || batch > 65535) return false;
@@ -285,4 +496,35 @@ extern "C" int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt
   MHIMX_CHECK_ARG(small_bmm_ok(mode, *a, batch, strideA, strideB, strideC),
                   "bmm_affine2: M, N multiples of 64 (<= 512), K = 256, 16-byte aligned operands, not the f32 mode");
   return small_bmm2((hipStream_t)stream, mode, *a, batch, strideA, strideB, strideC, alpha, ident, C2, alpha2, ident2);
+}
+
+extern "C" int mhimx_bmm_chain(void* stream, const mhimx_bmm_step* steps, int32_t stages, int32_t groups, uint32_t* counters) {
+  using namespace mhimx;
+  MHIMX_CHECK_ARG(steps && counters && stages >= 1 && (groups == 1 || groups == 2) && stages * groups <= CH_MAX,
+                  "bmm_chain: stages x groups (1 or 2) <= %d steps, 9 zeroed counters", CH_MAX);
+  Chain c;
+  c.n = stages;
+  c.groups = groups;
+  c.ctr = counters;
+  for (int i = 0; i < stages * groups; ++i) {
+    const mhimx_bmm_step& t = steps[i];
+    MHIMX_CHECK_ARG(t.kind >= -1 && t.kind <= 1, "bmm_chain: step %d: kind -1 (idle), 0 (product of two split images) or 1 (split an fp32 matrix)", i);
+    if (t.kind >= 0) {
+      const bool second = t.C2 || t.PN2 || t.PT2;
+      MHIMX_CHECK_ARG(t.A && (t.kind == 1 || t.B) && (t.C || t.PN || t.PT || second), "bmm_chain: step %d: missing operand / no output", i);
+      MHIMX_CHECK_ARG(t.kind == 0 || !(t.C || second), "bmm_chain: step %d: a split step (kind 1) has the outputs PN / PT only", i);
+      MHIMX_CHECK_ARG(!t.D || t.kind == 1 || (!t.C2 && !t.PN2 && !t.PT2 && t.alpha != 0.f), "bmm_chain: step %d: an addend goes with a single-output product, alpha != 0", i);
+      const void* all[9] = {t.A, t.B, t.C, t.C2, t.PN, t.PT, t.PN2, t.PT2, t.D};
+      for (const void* o : all) MHIMX_CHECK_ARG(aligned16(o), "bmm_chain: step %d: operands must be 16-byte aligned", i);
+      const void* outs[6] = {t.C, t.C2, t.PN, t.PT, t.PN2, t.PT2};
+      for (const void* o : outs)
+        MHIMX_CHECK_ARG(!o || (o != t.A && o != t.B && (o != t.D || o == t.C)), "bmm_chain: step %d: a step may not overwrite its own operands", i);
+    }
+    c.st[i] = ChainStep{t.A, t.B, t.C, t.C2, t.PN, t.PT, t.PN2, t.PT2, t.D, t.alpha, t.ident, t.alpha2, t.ident2, t.kind};
+  }
+  constexpr int SM = 2 * CH_PANEL + 4 * SB_T * 68 * 4;          // the partials over the A panels, four output tiles over (and past) the B panels
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bmm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM)));
+  hipLaunchKernelGGL(bmm_chain_kernel, dim3(128 * groups), dim3(CH_THREADS), SM, (hipStream_t)stream, c);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
 }

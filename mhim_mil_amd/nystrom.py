@@ -335,6 +335,41 @@ class MatmulAffine(torch.autograd.Function):
         return da, db, None, None
 
 
+_CHAIN = os.environ.get("MHIMX_PINV_CHAIN", "1") != "0"
+_CTRS = {}
+
+
+def _chain_counters(dev):
+    """The 8 per-head arrival counters of mhimx_bmm_chain, one set per (device, stream): zero between launches by the kernel's contract."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    c = _CTRS.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mhimx_bmm_chain: run one eager step on the capture stream first (its counters are allocated and zeroed there)")
+        c = _CTRS[key] = torch.zeros(256, dtype=torch.int32, device=dev)      # 8 counters (+ room for the CH_PROF stamps)
+    return c
+
+
+def _step(kind, A=None, B=None, C=None, C2=None, PN=None, PT=None, PN2=None, PT2=None, D=None, alpha=1.0, ident=0.0, alpha2=0.0, ident2=0.0):
+    """One mhimx_bmm_step (include/mhimx.h) from tensors."""
+    P = lambda t: _ptr(t) if t is not None else None
+    return L.BmmStep(P(A), P(B), P(C), P(C2), P(PN), P(PT), P(PN2), P(PT2), P(D), alpha, ident, alpha2, ident2, kind)
+
+
+_IDLE = lambda: L.BmmStep(None, None, None, None, None, None, None, None, None, 0.0, 0.0, 0.0, 0.0, -1)
+
+
+def _run_chain(steps, groups, dev):
+    """steps: stage-major list (groups entries per stage) -> one mhimx_bmm_chain launch."""
+    arr = (L.BmmStep * len(steps))(*steps)
+    L.check(L.lib().mhimx_bmm_chain(_st(), arr, len(steps) // groups, groups, _ptr(_chain_counters(dev))), "mhimx_bmm_chain")
+
+
+def chain_gave_up(dev):
+    """True if a chain launch on this device ever gave up waiting for a workgroup (counters[8], mhimx.h) - synchronises; for tests."""
+    return any(int(c[8].item()) != 0 for (d, _), c in _CTRS.items() if d == dev.index)
+
+
 def _landmark_pinv_forward(lm, scale):
     """The landmark-only part of the block: attn2 = softmax(scale q~ k~^T) and its iterative pseudo-inverse (nystrom_attention.py:12-27,
     :115,:130): z0 = a2^T / (max col sum * max row sum), six iterations, every intermediate kept for the backward.  Depends on the
@@ -351,6 +386,26 @@ def _landmark_pinv_forward(lm, scale):
     ws = torch.empty(2 * HEADS * m, device=dev)
     L.check(lib.mhimx_pinv_init(_st(), _ptr(a2), HEADS, m, _ptr(z), _ptr(stats), _ptr(ws)), "pinv_init")
     z0, chain = z, []
+    if _CHAIN and _PREC == "bf16x3":
+        # the 24 products as ONE persistent launch (mhimx_bmm_chain): matrices travel as split images (bf16 hi + lo planes, "N" as stored /
+        # "T" transposed - the bytes of the fp32 matrix), every product also leaves the images the BACKWARD chain multiplies by; only the
+        # result z exists in fp32
+        img = lambda: torch.empty_like(a2)
+        steps, a2N, a2T, zN, zT = [], img(), img(), img(), img()
+        steps.append(_step(1, A=a2, PN=a2N, PT=a2T))
+        steps.append(_step(1, A=z, PN=zN, PT=zT))
+        for it in range(PINV_ITERS):
+            azN, azT, t1N, t1T, t2N, t2T, t3N, t3T, znN, znT = (img() for _ in range(10))
+            last = it == PINV_ITERS - 1
+            zn = img() if last else None
+            steps.append(_step(0, A=a2N, B=zT, PN=azN, PT=azT, PN2=t1N, PT2=t1T, alpha=1.0, alpha2=-1.0, ident2=7.0))   # az = a2 z, t1 = 7 I - az
+            steps.append(_step(0, A=azN, B=t1T, PN=t2N, PT=t2T, alpha=-1.0, ident=15.0))                               # t2 = 15 I - az t1
+            steps.append(_step(0, A=azN, B=t2T, PN=t3N, PT=t3T, alpha=-1.0, ident=13.0))                               # t3 = 13 I - az t2
+            steps.append(_step(0, A=zN, B=t3T, C=zn, PN=None if last else znN, PT=None if last else znT, alpha=0.25))  # z' = 0.25 z t3
+            chain.append((zN, zT, azT, t1N, t2N, t3N, a2T))
+            z, zN, zT = zn, znN, znT
+        _run_chain(steps, 1, dev)
+        return a2, z, z0, stats, chain
     for _ in range(PINV_ITERS):
         az, t1 = torch.empty_like(a2), torch.empty_like(a2)                 # az = a2 z and t1 = 7 I - az from ONE launch
         g_ = L.GemmNT(A=_ptr(a2), lda=m, rows=None, B=_ptr(z), ldb=m, C=_ptr(az), ldc=m, M=m, N=m, K=m, accumulate=0, prec=L.PREC[_PREC])
@@ -373,6 +428,32 @@ def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm, accumulate
     # pseudo-inverse, backwards through the six iterations
     da2 = torch.empty_like(a2)
     first = True
+    if len(chain[0]) == 7:
+        # the images the forward chain left: the whole backward as TWO launches of mhimx_bmm_chain, two independent products per stage
+        # (256 workgroups).  Per iteration, with dz the gradient of z' = 0.25 zp t3 (reference order nystrom_attention.py:21-25, reversed):
+        #   1: dzp' = 0.25 dz t3^T          | dt3 = 0.25 zp^T dz
+        #   2: daz' = -dt3 t2^T             | dt2 = -az^T dt3
+        #   3: u    = daz' - dt2 t1^T       | w   = az^T dt2          (= -dt1: t1 = 7 I - az)
+        #   4: daz  = u + w  (images only)
+        #   5: da2 (+)= daz zp^T            | dzp = dzp' + a2^T daz   (the next iteration's dz)
+        img = lambda: torch.empty_like(a2)
+        dzN, dzT = img(), img()
+        steps = [_step(1, A=dz, PN=dzN, PT=dzT), _IDLE()]
+        for k, (zN, zT, azT, t1N, t2N, t3N, a2T) in enumerate(reversed(chain)):
+            dzp, dt3N, dt3T, dazp, dt2N, dt2T, w, dazN, dazT, ndzN, ndzT = (img() for _ in range(11))
+            last = k == PINV_ITERS - 1
+            steps += [_step(0, A=dzN, B=t3N, C=dzp, alpha=0.25), _step(0, A=zT, B=dzT, PN=dt3N, PT=dt3T, alpha=0.25),
+                      _step(0, A=dt3N, B=t2N, C=dazp, alpha=-1.0), _step(0, A=azT, B=dt3T, PN=dt2N, PT=dt2T, alpha=-1.0),
+                      _step(0, A=dt2N, B=t1N, C=dazp, D=dazp, alpha=-1.0), _step(0, A=azT, B=dt2T, C=w, alpha=1.0),
+                      _step(1, A=dazp, D=w, PN=dazN, PT=dazT), _IDLE(),
+                      _step(0, A=dazN, B=zN, C=da2, D=None if first else da2, alpha=1.0),
+                      _step(0, A=a2T, B=dazT, C=dzp if last else None, D=dzp, PN=None if last else ndzN, PT=None if last else ndzT, alpha=1.0)]
+            dz, dzN, dzT, first = dzp, ndzN, ndzT, False
+            if k == PINV_ITERS // 2 - 1:
+                _run_chain(steps, 2, dev)
+                steps = []
+        _run_chain(steps, 2, dev)
+        chain = ()
     for (zp, az, t1, t2, t3) in reversed(chain):                                  # four pairs of independent products per iteration
         dzp, dt3, daz, dt2, dt1 = (torch.empty_like(dz) for _ in range(5))
         _bmm_pair(("nt", dz, t3, dzp, 0.25, False), ("tn", zp, dz, dt3, 0.25, False))        # z' = 0.25 zp t3
