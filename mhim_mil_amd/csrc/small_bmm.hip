@@ -226,6 +226,12 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0,
 //                 and loads on both sides} form of MI355X_MICROARCH.md: no L2 write-back, no L1 invalidate, placement-independent.
 // Workgroup b serves head b % 8.  The last arrival of a head's last step zeroes its counter: the counters are all-zero again when the
 // launch ends (hipGraph replays re-use them).
+// MEASURED and not kept (round 3, same box, forward / forward + backward of one layer as hipGraph replays, 166 / 426 us here):
+//   * plain stores (acknowledged by the XCD's L2) instead of write-through ones when the head's workgroups verify at run time (HW_REG_XCC_ID
+//     table) that they share an XCD: 166 / 424 us, bit-identical over 300 repetitions under load - the store acknowledge is not the bound;
+//   * an arrival atomic without return value (no round trip for lane 0), s_sleep 0 / 4 in the poll: +-1 %.
+// One stage, stamped (shader clocks, forward): poll 900, panels by DMA 3700 (128 KiB per workgroup at the ~85 GB/s a block reads written-through
+// lines at), products 1900 (LDS-read bound: 256 KiB of fragments), quarters -> tiles 2300, stores + acknowledge 2400, arrival 1300.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int CH_MAX = 42, CH_THREADS = 1024, CH_SPIN_MAX = 1 << 22;
 struct ChainStep {

@@ -56,3 +56,23 @@ if os.environ.get("CH_PROF"):
     print("shader-clock cycles per phase of step CH_PROF, workgroups 0..7:")
     for i, n in enumerate(names): print(f"  {n:24s}", d[:, i].tolist())
     print("  total", (st[:, -1] - st[:, 0]).tolist())
+# stress: the hand-off with other work running beside it - every repetition must reproduce the first bit for bit
+if os.environ.get("CH_STRESS"):
+    ny._CHAIN = True
+    n_rep = int(os.environ["CH_STRESS"])
+    side = torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device=dev)
+    ref = None
+    bad = 0
+    for rep in range(n_rep):
+        if rep % 3 != 0:
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 4): big2 = big @ big if rep % 2 else big * 1.0001
+        sv = fb(); d = torch.empty_like(lm); bw(sv, d)
+        torch.cuda.synchronize()
+        cur = (sv[1].clone(), d.clone())
+        if ref is None: ref = cur
+        elif not (torch.equal(ref[0], cur[0]) and torch.equal(ref[1], cur[1])): bad += 1
+    print("stress:", n_rep, "repetitions,", bad, "differ from the first; counters", ny._CTRS[list(ny._CTRS)[0]][:9].tolist(), "gave up:", ny.chain_gave_up(dev))
+    import hashlib
+    print("digest", hashlib.sha1(ref[0].cpu().numpy().tobytes() + ref[1].cpu().numpy().tobytes()).hexdigest())
