@@ -307,6 +307,9 @@ int mhimx_layernorm_bwd_res(void* stream, const float* dy, const float* x, int64
                             const float* rstd, const float* resid, float* dx, float* d_w, float* d_b, int32_t accumulate, float* ws);
 /* out = x * keep/(1-p) with the counter-based mask of (seed + *tick, row, col): re-applies a forward dropout to a gradient */
 int mhimx_dropout_apply(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed, const uint64_t* tick);
+/* the same for the dropout stream of mhimx_bag_project's epilogue (one mix per PAIR of columns, 16-bit thresholds): the gradient of a
+ * projection that ran with drop_p > 0 and no stored mask.  E % 4 == 0, 0 < p < 1. */
+int mhimx_dropout_apply_proj(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed, const uint64_t* tick);
 /* y[r,:] = softmax(alpha * x[r,:]) over the last dim of x[R,L]; bwd: dx = alpha*y*(dy - sum(y*dy)).
  * replaces: `.softmax(dim=-1)` nystrom_attention.py:130 and its autograd. */
 int mhimx_softmax_rows(void* stream, const float* x, float* y, int64_t R, int64_t L, float alpha);

@@ -216,6 +216,7 @@ SYMBOLS = {
     "mhimx_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "mhimx_layernorm_bwd_res": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "mhimx_dropout_apply": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _U64, _P]),
+    "mhimx_dropout_apply_proj": (C.c_int, [_P, _P, _P, _I64, _I64, _F, _U64, _P]),
     "mhimx_softmax_rows": (C.c_int, [_P, _P, _P, _I64, _I64, _F]),
     "mhimx_softmax_rows_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F]),
     "mhimx_landmark_mean": (C.c_int, [_P, _P, _I64, _I64, _I64, _I64, _P]),

@@ -302,6 +302,29 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   }
 }
 
+// out = x * keep / (1 - p) with the PROJECTION kernels' dropout stream (one 32-bit mix per pair of columns, 16-bit thresholds: the
+// epilogue above): a backward re-applies the forward's mask to the incoming gradient, no mask is stored (mhimx_dropout_apply_proj).
+__global__ __launch_bounds__(256) void proj_dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t M, int E, float p,
+                                                                uint64_t seed0, const uint64_t* __restrict__ tick) {
+  const uint64_t seed = eff_seed(seed0, tick);
+  const uint32_t thr16 = (uint32_t)(p * 65536.f + 0.5f);
+  const float inv_keep = 65536.f / (float)(65536u - thr16);
+  const int e4 = E >> 2;
+  const int64_t n4 = M * e4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / e4;
+    const int n = (int)(i - m * e4) * 4;
+    const uint32_t rk = drop_row_key(seed, (uint64_t)m);
+    const uint32_t h0 = pw_pair_hash(rk, (uint32_t)(n >> 1)), h1 = pw_pair_hash(rk, (uint32_t)(n >> 1) + 1u);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + m * E + n);
+    v[0] = (h0 & 0xffffu) >= thr16 ? v[0] * inv_keep : 0.f;
+    v[1] = (h0 >> 16) >= thr16 ? v[1] * inv_keep : 0.f;
+    v[2] = (h1 & 0xffffu) >= thr16 ? v[2] * inv_keep : 0.f;
+    v[3] = (h1 >> 16) >= thr16 ? v[3] * inv_keep : 0.f;
+    *reinterpret_cast<f32x4*>(out + m * E + n) = v;
+  }
+}
+
 int bag_project_ws(hipStream_t st, const mhimx_bag_project_args& g) {
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
   const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)cdiv(g.N, WBM);
@@ -312,3 +335,14 @@ int bag_project_ws(hipStream_t st, const mhimx_bag_project_args& g) {
 }
 
 }  // namespace mhimx
+
+extern "C" int mhimx_dropout_apply_proj(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed, const uint64_t* tick) {
+  using namespace mhimx;
+  MHIMX_CHECK_ARG(x && out && M >= 0 && E > 0 && E % 4 == 0 && p > 0.f && p < 1.f && aligned16(x) && aligned16(out), "dropout_apply_proj: bad args");
+  if (M == 0) return 0;
+  const int64_t blocks = cdiv(M * (E / 4), 256);
+  hipLaunchKernelGGL(proj_dropout_apply_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, out, M, (int)E, p,
+                     seed, tick);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}

@@ -425,3 +425,43 @@ def test_gemm_batched_takes_the_small_kernel_and_agrees():
     ad, bd, wd = a.detach().double(), b.detach().double(), w.double()
     for got, ref in ((c.detach(), ad @ bd), (a.grad, wd @ bd.transpose(1, 2)), (b.grad, ad.transpose(1, 2) @ wd)):
         assert float((got.double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max())
+
+
+def test_fused_layer_output_dropout_on_projection_kernel():
+    """TransLayer (baseline.py:213-218) at n >= 2048: to_out runs on the projection kernel with ITS dropout stream (nystrom_attention.py:99-102:
+    nn.Dropout(0.1) after to_out); the backward re-applies exactly that mask (mhimx_dropout_apply_proj).  Reference: the same layer with the
+    dropout off, masked by what the forward kept - y = x + (y0 - x) * keep / (1 - p) - through autograd."""
+    from mhim_mil_amd import nystrom as ny
+    torch.manual_seed(3)
+    n, p = 3000, 0.1
+    layer = ny.TransLayer(512).to(DEV)
+    with torch.no_grad():
+        for q in layer.parameters():
+            q.normal_(0, 0.05)
+        layer.norm.weight.add_(1.0)
+    x = rnd(n, 512, seed=41, scale=0.5).requires_grad_()
+    ww = rnd(n, 512, seed=42)
+    tick = torch.tensor([5], dtype=torch.int64, device=DEV)
+    old = layer.attn.dropout
+    try:
+        layer.attn.dropout = p
+        y = layer(x, seed=1234, tick=tick, training=True)
+        y0 = layer(x, training=False)
+        lin, lin0 = (y - x).detach(), (y0 - x)
+        keep = (lin != 0).float()
+        assert abs(keep.mean().item() - (1 - p)) < 0.01
+        thr16 = round(p * 65536)                                     # the stream's 16-bit threshold: keep probability (65536 - thr16) / 65536
+        scale = 65536.0 / (65536 - thr16)
+        close(lin, lin0.detach() * keep * scale, 1e-4)
+        params = [x] + [q for q in layer.parameters()]
+        got = torch.autograd.grad((y * ww).sum(), params)
+        ref = torch.autograd.grad(((x + lin0 * keep * scale) * ww).sum(), params)
+        for gi, ri in zip(got, ref):
+            close(gi, ri, 2e-4)
+        # the same seed and tick draw the same mask again; another tick another one
+        y2 = layer(x, seed=1234, tick=tick, training=True)
+        assert torch.equal(y2, y)
+        y3 = layer(x, seed=1234, tick=tick + 1, training=True)
+        assert not torch.equal((y3 - x) != 0, lin != 0)
+    finally:
+        layer.attn.dropout = old
