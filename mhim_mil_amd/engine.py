@@ -324,15 +324,19 @@ class FusedTrainer:
                 # TransMIL / DSMIL: teacher AND student feature rows of all N bag rows in ONE pass over the raw bag (the reference's
                 # student projects every row before it masks, mhim.py:335-336); the student's token rows are a gather, its projection
                 # gradient the matrix-core-image pair on (d tokens, d out / d pre in fp16)
+                tok_t = None
+                if s.baseline == "selfattn":                 # the teacher's rows land under a free first row: [cls ; rows] without a copy
+                    tok_t = torch.empty((1 + x.shape[0], t.feature[0].weight.shape[0]), device=x.device)
                 heads = [ops.ProjHead(ops.pair_planes(t.feature[0].weight.data), t.feature[0].bias.data,
-                                      drop_p=t.dropout_p if t.training else 0.0, drop_seed=t._next_seed(teacher=True)),
+                                      drop_p=t.dropout_p if t.training else 0.0, drop_seed=t._next_seed(teacher=True),
+                                      out=None if tok_t is None else tok_t[1:]),
                          None]
                 seed_s = s._next_seed()
                 heads[1] = ops.ProjHead(ops.pair_planes(s.feature[0].weight.data), s.feature[0].bias.data, drop_p=s.dropout_p,
                                         drop_seed=seed_s, want_dact=True)
                 ops.bag_project(x, heads, act=mh.L.act_code(s.act, mh._FEATURE_ACTS), drop_tick=self.tick)
                 pre = (heads[1].out, heads[1].dact)
-                teacher_feat, score = t.forward_teacher(x, H=heads[0].out)
+                teacher_feat, score = t.forward_teacher(x, H=heads[0].out, tok_full=tok_t)
             else:
                 teacher_feat, score = t.forward_teacher(x, xp=xp, w1p=None if prep_t is None else prep_t["w1p"],
                                                         wa_frag=None if prep_t is None else prep_t.get("wa_frag"))

@@ -21,9 +21,11 @@ Nystrom) composes the encoder from kernel-backed auto
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import numpy as np
+
 import torch
 from torch import nn
 
@@ -148,6 +150,9 @@ class _HeadFn(torch.autograd.Function):
         return g_z.view_as(z), None, d_wp, d_bp, None
 
 
+_TOKENS_NODE = os.environ.get("MHIMX_TOKENS_NODE", "1") != "0"
+
+
 class _FeatureFn(torch.autograd.Function):
     """Token rows of the student: H = dropout(act(X[rows] W^T + b))  (mhim.py:68-76,337; masking.py:107 gathers the rows)."""
 
@@ -215,6 +220,52 @@ class _MergeFn(torch.autograd.Function):
         mw = model._merge_w(ctx.plan, need_t=True, q=ctx.q_old)
         mg = ops.merge_bwd(mw, ctx.X, dz.contiguous(), ctx.mws, grads={})
         return (None, None, mg["dX"], mg["d_ln_w"], mg["d_ln_b"], mg["d_wkv"], mg["d_wq"], mg["d_wo"], mg["d_bo"])
+
+
+class _StudentTokensFn(torch.autograd.Function):
+    """The TransMIL student's token matrix [cls ; kept tokens ; k merged tokens] (mhim.py:335-352, merge.py:131-144,190-194, baseline.py:
+    248-251) from the single-pass projection's rows (plan.pre) as ONE autograd node.  As the chain _FeatureFn -> slices -> _MergeFn -> cat ->
+    cat the forward copied the kept rows three times (gather, two concatenations) and the backward assembled d tokens from two zero-filled
+    slice gradients and an add (~0.25 ms per c3 step): here the gather writes the kept rows where the encoder reads them, the merged tokens
+    and the cls token are written beside them, and the backward hands the weight-gradient pair ONE compact [L, E] matrix (the kept rows'
+    gradient copied once, Merge's dX written into its tail)."""
+
+    @staticmethod
+    def forward(ctx, model, x, plan, cls, w, b, *mparams):
+        Hs, dact = plan.pre
+        Lk, R, E, N = plan.Lk, plan.R, Hs.shape[1], Hs.shape[0]
+        k = model.merge.k if R > 0 else 0
+        tok = torch.empty((1 + Lk + k, E), device=Hs.device)
+        ops.shard_gather(Hs, plan.rows[:Lk], 0, N, out=tok[1:1 + Lk])
+        jobs = [(ops.PREP_COPY, cls.reshape(1, E), tok[:1])]
+        ctx.merge = None
+        if R > 0:
+            X = ops.shard_gather(Hs, plan.rows[Lk:Lk + R], 0, N)
+            z_tok, q_new, mws = ops.merge_fwd(model._merge_w(plan), X, update_q=plan.training)
+            ctx.merge = (X, mws, model.merge.global_q_mm.data.clone())
+            if plan.training:
+                model.merge.global_q_mm.data.copy_(q_new.view_as(model.merge.global_q_mm))
+            jobs.append((ops.PREP_COPY, z_tok, tok[1 + Lk:]))
+        ops.prep_batch(jobs)
+        ctx.model, ctx.plan, ctx.x, ctx.dact, ctx.cls_shape = model, plan, x, dact, cls.shape
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        model, plan = ctx.model, ctx.plan
+        Lk, R = plan.Lk, plan.R
+        dtok = dtok.contiguous()
+        E = dtok.shape[1]
+        dH = torch.empty((Lk + R, E), device=dtok.device)
+        ops.stream_copy(dtok[1:1 + Lk], dH[:Lk])
+        mg = [None] * 6
+        if ctx.merge is not None:
+            X, mws, q_old = ctx.merge
+            mw = model._merge_w(plan, need_t=True, q=q_old)
+            g = ops.merge_bwd(mw, X, dtok[1 + Lk:], mws, grads={"dX": dH[Lk:]})
+            mg = [g["d_ln_w"], g["d_ln_b"], g["d_wkv"], g["d_wq"], g["d_wo"], g["d_bo"]]
+        dW, db = ops.bag_wgrad(dH, ctx.dact, ctx.x, plan.rows, plan.L, dh_compact=True)
+        return (None, None, None, dtok[:1].reshape(ctx.cls_shape), dW, db, *mg)
 
 
 class BagPlan:
@@ -749,7 +800,7 @@ class MHIM(nn.Module):
 
     # ------------------------------------------------------------------ reference entry points
     @torch.no_grad()
-    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None, wa_frag=None, H=None):
+    def forward_teacher(self, x, drop_mask=None, xp=None, w1p=None, wa_frag=None, H=None, tok_full=None):
         x = self._check_x(x)
         p = self.dropout_p if self.training else 0.0           # the trainer keeps the teacher in train mode
         if H is None:                                          # (H: the teacher's feature rows from the trainer's single-pass projection)
@@ -764,8 +815,12 @@ class MHIM(nn.Module):
             _, _, B, attn = self.online_encoder(tok, want_attn=True)
             return B.unsqueeze(0), attn[:p0].view(1, -1)
         if self.baseline == "selfattn":
-            tok = H if T2 is None else torch.cat([H, T2], 0)
-            z, attn, v = self._encode(tok, return_attn=True)
+            if tok_full is not None and T2 is None:            # H = tok_full[1:]: the projection wrote under a free first row - no concatenation
+                tok_full[:1].copy_(self.online_encoder.cls_token.data.view(1, -1))
+                z, attn, v = self._encode(tok_full, return_attn=True, has_cls=True)
+            else:
+                tok = H if T2 is None else torch.cat([H, T2], 0)
+                z, attn, v = self._encode(tok, return_attn=True)
             if self.attn2score:
                 score = self._trans_score(v[:p0], attn[0][:, :p0]).view(1, -1)
             else:
@@ -815,10 +870,11 @@ class MHIM(nn.Module):
         return logits, a
 
     # ------------------------------------------------------------------ TransMIL (selfattn) pieces
-    def _encode(self, tok, return_attn=False, no_norm=False):
-        """SAttention over the token rows [n, E]; train-mode to_out dropouts use the counter-based stream."""
+    def _encode(self, tok, return_attn=False, no_norm=False, has_cls=False):
+        """SAttention over the token rows [n, E] (has_cls: row 0 already holds the cls token); train-mode to_out dropouts use the
+        counter-based stream."""
         return self.online_encoder(tok, return_attn, no_norm, seeds=(self._next_seed(), self._next_seed()), tick=self._tick,
-                                   training=self.training)
+                                   training=self.training, has_cls=has_cls)
 
     def _trans_score(self, v, attn0):
         """get_pseudo_score_trans (scoring.py:9-34): v [n, (h d)] (a strided view into the packed qkv rows), attn0 [h, n]
@@ -843,6 +899,11 @@ class MHIM(nn.Module):
         return lb, li, B
 
     def _selfattn_student(self, x, plan):
+        if (getattr(plan, "pre", None) is not None and plan.rows is not None and _TOKENS_NODE and (plan.R == 0 or self.merge_enable)
+                and plan.L == plan.Lk + plan.R):
+            tok = _StudentTokensFn.apply(self, x, plan, self.online_encoder.cls_token, self.feature[0].weight, self.feature[0].bias,
+                                         *[self._param(n) for n in _MergeFn.NAMES])
+            return self._encode(tok, has_cls=True)
         H = _FeatureFn.apply(self, x, plan, self.feature[0].weight, self.feature[0].bias)
         if self.merge_enable and plan.R > 0:
             z_tok = _MergeFn.apply(self, plan, H[plan.Lk:], *[self._param(n) for n in _MergeFn.NAMES])

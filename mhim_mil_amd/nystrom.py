@@ -974,9 +974,10 @@ class SAttention(nn.Module):
         self.layer2 = TransLayer(mlp_dim)
         self.pos_embedding = _PPEG(mlp_dim)
 
-    def forward(self, h, return_attn=False, no_norm=False, seeds=(0, 0), tick=None, training=False):
-        """h [N, 512] tokens -> cls feature [512] (+ [attn_l1, attn_l2] each [8, N], v of layer 1 [N, (8 64)])."""
-        x = torch.cat([self.cls_token.view(1, -1), h], 0)
+    def forward(self, h, return_attn=False, no_norm=False, seeds=(0, 0), tick=None, training=False, has_cls=False):
+        """h [N, 512] tokens -> cls feature [512] (+ [attn_l1, attn_l2] each [8, N], v of layer 1 [N, (8 64)]).  has_cls: h is
+        [1 + N, 512] with the cls token already in row 0 (the caller assembled the matrix in place; its gradient reaches cls_token there)."""
+        x = h if has_cls else torch.cat([self.cls_token.view(1, -1), h], 0)
         attn = []
         if return_attn:
             x, a, v = self.layer1(x, True, no_norm, seeds[0], tick, training)

@@ -465,3 +465,31 @@ def test_fused_layer_output_dropout_on_projection_kernel():
         assert not torch.equal((y3 - x) != 0, lin != 0)
     finally:
         layer.attn.dropout = old
+
+
+def test_student_tokens_node_equals_the_chain_of_nodes():
+    """_StudentTokensFn ([cls ; kept ; merged] and its backward as one node) against the chain it replaces (_FeatureFn -> slices ->
+    _MergeFn -> two concatenations): same logits, same flat gradient, on the trainer's single-pass path."""
+    from mhim_mil_amd import mhim as MH
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d = 3000, 256
+    base = synth.mhim_state(23, input_dim=d, merge_k=5, baseline="selfattn")
+    x = torch.from_numpy(synth.bag(77, n, d)).to(DEV)
+    k, n_sel, _ = O.mask_count(n, V2["mask_ratio_h"], V2["mask_ratio_hr"])
+    perm, shuf = torch.from_numpy(synth.permutation(31, k)).to(DEV), torch.from_numpy(synth.permutation(41, n - n_sel)).to(DEV)
+    res = {}
+    old = MH._TOKENS_NODE
+    try:
+        for flag in (False, True):
+            MH._TOKENS_NODE = flag
+            s = build(base, input_dim=d, **V2).train()
+            t = build(synth.spread_teacher(base), input_dim=d, **V2).train()
+            tr = FusedTrainer(s, t, lr=2e-4, aux_alpha=0.5, mm=0.999)
+            assert tr.single_pass and s.single_projection_ok(x) and t.single_projection_ok(x)
+            logits, losses = tr.forward_backward(x, torch.tensor([1], device=DEV), perm=perm, ids_shuffle=shuf)
+            res[flag] = (logits.clone(), tr.flat.grad.clone(), s.merge.global_q_mm.data.clone())
+    finally:
+        MH._TOKENS_NODE = old
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
+    assert res[False][1].abs().max().item() > 0
+    close(res[True][1], res[False][1], 1e-6, "flat gradient")
