@@ -86,6 +86,8 @@ typedef struct {
   float* H; int64_t ldh;              /* output rows [N, ldh >= E]                                         */
   void* dact;                         /* optional fp16 [N,E]                                               */
   float drop_p; uint64_t drop_seed; const uint8_t* drop_mask;
+  const float* resid; int64_t ldr;    /* optional fp32 [N, ldr >= E], added AFTER activation and dropout: H = resid + dropout(act(..)) -  */
+                                      /* the residual connection around a TransLayer's to_out (baseline.py:215); not H itself; dact ignores it */
 } mhimx_proj_head;
 typedef struct {
   const float* X; int64_t ldx;        /* the bag [N, D] fp32                                               */

@@ -39,7 +39,7 @@ class GemmNT(C.Structure):
 
 class ProjHead(C.Structure):
     _fields_ = [("wp", c_f32p), ("bias", c_f32p), ("H", c_f32p), ("ldh", C.c_int64), ("dact", C.c_void_p),
-                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p), ("resid", c_f32p), ("ldr", C.c_int64)]
 
 
 class BagProject(C.Structure):

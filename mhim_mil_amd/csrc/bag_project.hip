@@ -451,6 +451,10 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], g.act) * ks[q];
       }
+      if (H.resid) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(H.resid + m * H.ldr + n);
+        v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+      }
 #if defined(PJ_EPI_NOSTORE)
       if (v[0] == 1234.5f) *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
 #elif defined(PJ_EPI_NT)
@@ -477,6 +481,7 @@ int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
   for (int h = 0; h < g.n_heads; ++h) {
     const mhimx_proj_head& H = g.head[h];
     MHIMX_CHECK_ARG(H.wp && H.H && aligned16(H.wp) && aligned16(H.H) && H.ldh % 4 == 0 && H.ldh >= g.E, "bag_project: model %d: null / unaligned weight image or output", h);
+    MHIMX_CHECK_ARG(!H.resid || (aligned16(H.resid) && H.ldr % 4 == 0 && H.ldr >= g.E && H.resid != H.H), "bag_project: model %d: unaligned residual rows / the output itself", h);
     MHIMX_CHECK_ARG(!H.bias || aligned16(H.bias), "bag_project: model %d: unaligned bias", h);
     MHIMX_CHECK_ARG(!H.dact || (reinterpret_cast<uintptr_t>(H.dact) & 7) == 0, "bag_project: model %d: unaligned dact", h);
     MHIMX_CHECK_ARG(H.drop_p >= 0.f && H.drop_p < 1.f, "bag_project: model %d: dropout probability outside [0,1)", h);

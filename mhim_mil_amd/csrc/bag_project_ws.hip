@@ -297,6 +297,10 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], g.act) * ks[q];
       }
+      if (H.resid) {
+        const f32x4 rr = *reinterpret_cast<const f32x4*>(H.resid + m * H.ldr + n);
+        v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+      }
       *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
     }
   }

@@ -645,11 +645,11 @@ class TransLayerFn(torch.autograd.Function):
         out, saved = _core_forward(qkv, conv_w, l, scale)
         proj = n >= 2048 and _PREC == "bf16x3" and _OUT_PROJ
         if proj:                              # to_out on the projection kernel too (bias + its own dropout stream in the epilogue; 154 -> ~85 us)
-            y = ops.bag_project(out[pad:], [ops.ProjHead(ops.pair_planes(w_out), b_out, drop_p=drop_p, drop_seed=seed)], act=0,
-                                drop_tick=tick if drop_p > 0 else None)[0].out
+            y = ops.bag_project(out[pad:], [ops.ProjHead(ops.pair_planes(w_out), b_out, drop_p=drop_p, drop_seed=seed, resid=x)], act=0,
+                                drop_tick=tick if drop_p > 0 else None)[0].out                           # y = x + dropout(to_out(.)): one launch
         else:
             y = ops.gemm_nt(out[pad:], w_out, bias=b_out, drop_p=drop_p, drop_seed=seed, drop_tick=tick, prec=_PREC)
-        L.check(lib.mhimx_axpby(_st(), _ptr(x), _ptr(y), y.numel(), 1.0, 1.0), "axpby")                 # y += x
+            L.check(lib.mhimx_axpby(_st(), _ptr(x), _ptr(y), y.numel(), 1.0, 1.0), "axpby")             # y += x
         ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, saved)
         ctx.cfg = (pad, drop_p, seed, tick, proj)
         if not need_attn:

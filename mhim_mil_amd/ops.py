@@ -74,9 +74,9 @@ def gemm_nt(a, b, out=None, rows=None, bias=None, act=0, pre=None, rowv=None, co
 class ProjHead:
     """One model of a bag projection (ops.bag_project): paired-plane weight image, bias, dropout stream, outputs."""
 
-    def __init__(self, wp, bias=None, drop_p=0.0, drop_seed=0, drop_mask=None, out=None, want_dact=False, dact=None):
+    def __init__(self, wp, bias=None, drop_p=0.0, drop_seed=0, drop_mask=None, out=None, want_dact=False, dact=None, resid=None):
         self.wp, self.bias, self.drop_p, self.drop_seed, self.drop_mask = wp, bias, float(drop_p), int(drop_seed), drop_mask
-        self.out, self.want_dact, self.dact = out, want_dact, dact
+        self.out, self.want_dact, self.dact, self.resid = out, want_dact, dact, resid
 
 
 def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
@@ -88,14 +88,15 @@ def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
     E = heads[0].wp.shape[0]
     a = L.BagProject(X=_p(x), ldx=x.stride(0), N=N, D=D, E=E, act=int(act), n_heads=len(heads), drop_tick=_p(drop_tick))
     for i, h in enumerate(heads):
-        _chk(h.wp, name="wp"); _chk(h.bias, name="bias"); _chk(h.drop_mask, torch.uint8, "drop_mask")
+        _chk(h.wp, name="wp"); _chk(h.bias, name="bias"); _chk(h.drop_mask, torch.uint8, "drop_mask"); _chk(h.resid, name="resid")
         if h.out is None:
             h.out = torch.empty((N + extra_rows, E), device=x.device)
         _chk(h.out, name="out")
         if h.want_dact and h.dact is None:
             h.dact = torch.empty((N, E), device=x.device, dtype=torch.float16)
         a.head[i] = L.ProjHead(wp=_p(h.wp), bias=_p(h.bias), H=_p(h.out), ldh=h.out.stride(0), dact=_p(h.dact),
-                               drop_p=h.drop_p, drop_seed=h.drop_seed & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(h.drop_mask))
+                               drop_p=h.drop_p, drop_seed=h.drop_seed & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(h.drop_mask),
+                               resid=_p(h.resid), ldr=h.resid.stride(0) if h.resid is not None else 0)
     evs = KERNEL_EVENT_HOOK("bag_project", N, E * len(heads), D) if KERNEL_EVENT_HOOK is not None else None
     if evs:
         evs[0].record()
