@@ -131,9 +131,12 @@ int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, i
  *   kind -1: nothing (an idle slot of a two-group stage).
  * The table is steps[stage * groups + group]: the steps of one stage are independent of each other and may read whatever earlier STAGES
  * wrote.  128 x groups persistent workgroups of 1024 threads (groups = 1 or 2); the tiles of a head hand over through a per-head arrival
- * counter (write-through stores, cache-bypassing loads: no grid barrier).  counters: 9 uint32, ZERO at launch; [0..7] are zero again
- * when the launch ends; [8] != 0 afterwards means a workgroup gave up waiting (workgroups not co-resident: the launch needs
- * 128 x groups free CUs) and the outputs are invalid.  stages * groups <= 42.  A step must not overwrite its own operands.
+ * counter (write-through stores, cache-bypassing loads: no grid barrier).  Tiles are drawn as TICKETS in stage order, so a launch
+ * completes whatever part of its grid is resident (other work on the GPU costs time, never the result).
+ * counters: 513 uint32, ZERO before the first launch (head h: arrivals at [64 h], tickets at [64 h + 32], leave count at [64 h + 48] -
+ * each head's hot words on 128-byte lines of their own); all zero again when a launch ends; [512] != 0 afterwards means a workgroup
+ * gave up waiting (a backstop: the ticket order excludes it) and the outputs are invalid.  stages * groups <= 42.  A step must not
+ * overwrite its own operands.
  *   replaces: the same torch.matmul chain as mhimx_bmm_affine, 7.4 us per product (13.7 us per pair) as launches. */
 typedef struct {
   const void* A; const void* B; float* C; float* C2; void* PN; void* PT; void* PN2; void* PT2; const float* D;

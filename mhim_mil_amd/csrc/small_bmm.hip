@@ -255,37 +255,54 @@ __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
   float* TT2 = TT + SB_T * 68;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = wave >> 2, wmn = wave & 3, wm = wmn >> 1, wn = wmn & 1;
-  const int head = (int)blockIdx.x & 7, tile = ((int)blockIdx.x >> 3) & 15, group = (int)blockIdx.x >> 7;
-  const int m0 = (tile >> 2) * SB_T, n0 = (tile & 3) * SB_T;
+  // Which tile a workgroup computes is NOT its block index: the workgroups of head b % 8 draw TICKETS (stage-major: ticket t = stage *
+  // per_stage + group * 16 + tile) from the head's ticket counter.  A ticket waits only for tickets below it, and every ticket below it
+  // is held by a workgroup that has started - so the chain completes with ANY number of resident workgroups (other kernels or processes
+  // holding CUs, a grid larger than the free CUs): co-residency buys speed, never correctness.  With all of them resident every workgroup
+  // draws one ticket per stage; the next ticket is drawn while the current one is computed (no exposed round trip).
+  const int head = (int)blockIdx.x & 7;
   constexpr unsigned MAT_BYTES = SBF_KMAX * SBF_KMAX * 4;
   constexpr int POL = 1 | 16;                                   // sc0 sc1
   __shared__ int dead;
-  if (tid == 0) dead = 0;
+  __shared__ unsigned next_ticket;
   const int64_t hoff = (int64_t)head * SBF_KMAX * SBF_KMAX;     // elements of an fp32 matrix; a split image has the same byte size
-  unsigned* ctr = c.ctr + head;
+  unsigned* ctr = c.ctr + head * 64;                            // arrivals of the head: a 128-byte line of its own (256 workgroups polling and
+  unsigned* tkt = ctr + 32;                                     // adding on ONE line serialised at its L2 bank: +4 us per stage); tickets: the next line
+  unsigned* lft = ctr + 48;
+  const unsigned per_stage = 16u * (unsigned)c.groups, total = per_stage * (unsigned)c.n;
+  if (tid == 0) {
+    dead = 0;
+    next_ticket = __hip_atomic_fetch_add(tkt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  unsigned ticket = __builtin_amdgcn_readfirstlane(next_ticket);        // wave-uniform BY CONSTRUCTION: say so (descriptors live in SGPRs)
 #ifdef CH_PROF
   unsigned long long tsv[12];
 #define CH_STAMP(i) do { if (s == CH_PROF) tsv[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define CH_STAMP(i) do {} while (0)
 #endif
-  for (int s = 0; s < c.n; ++s) {
+  while (ticket < total) {
+    const int s = (int)(ticket / per_stage), slot = (int)(ticket % per_stage);
+    const int group = slot >> 4, tile = slot & 15;
+    const int m0 = (tile >> 2) * SB_T, n0 = (tile & 3) * SB_T;
     const ChainStep st = c.st[s * c.groups + group];
-    const unsigned per_stage = 16u * (unsigned)c.groups;
     CH_STAMP(0);
-    if (s > 0) {                                                // every tile of this head's previous stage is written
-      if (tid == 0) {
+    unsigned nt = 0;
+    if (tid == 0) {
+      if (s > 0) {                                              // every tile of this head's previous stage is written
         const unsigned want = per_stage * (unsigned)s;
         int spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && ++spins < CH_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
-        if (spins >= CH_SPIN_MAX) {                             // a workgroup of the head never arrived (not co-resident?): give up, loudly,
-          dead = 1;                                             // instead of hanging the GPU - counters[8] != 0 tells the host
-          __hip_atomic_store(c.ctr + 8, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spins >= CH_SPIN_MAX) {                             // cannot happen by the ticket order; a backstop against a hung GPU all the same:
+          dead = 1;                                             // counters[512] != 0 tells the host, the outputs are invalid
+          __hip_atomic_store(c.ctr + 512, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      __syncthreads();
-      if (dead) return;
+      nt = __hip_atomic_fetch_add(tkt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next ticket: its round trip flies under this one's work
     }
+    __syncthreads();
+    if (dead) return;
     CH_STAMP(1);
     sb_f16 acc;
     const int r = lane & 31, kh = lane >> 5;
@@ -407,16 +424,25 @@ __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my write-through stores have left (inline asm: the compiler must not drop it)
+    if (tid == 0) next_ticket = nt;
     __syncthreads();                                            // ... and everybody's; the LDS tiles are free again
     CH_STAMP(6);
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (s == c.n - 1 && old == per_stage * (unsigned)c.n - 1u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CH_STAMP(7);
+    ticket = __builtin_amdgcn_readfirstlane(next_ticket);       // (written before this iteration's last barrier; rewritten after the next one's first)
+  }
+  // leaving: the head's LAST workgroup to leave puts its three counters back to zero for the next launch (nobody of this launch reads them
+  // after that: every other workgroup of the head has drawn its final, out-of-range ticket already)
+  if (tid == 0) {
+    const unsigned left = __hip_atomic_fetch_add(lft, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == per_stage - 1u) {
+      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tkt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(lft, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #ifdef CH_PROF
-  if (tid == 0 && blockIdx.x < 8) for (int i = 0; i < 12; ++i) reinterpret_cast<unsigned long long*>(c.ctr + 16)[blockIdx.x * 12 + i] = tsv[i];
+  if (tid == 0 && blockIdx.x < 8) for (int i = 0; i < 12; ++i) reinterpret_cast<unsigned long long*>(c.ctr + 576)[blockIdx.x * 12 + i] = tsv[i];
 #endif
 }
 
@@ -507,7 +533,7 @@ extern "C" int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt
 extern "C" int mhimx_bmm_chain(void* stream, const mhimx_bmm_step* steps, int32_t stages, int32_t groups, uint32_t* counters) {
   using namespace mhimx;
   MHIMX_CHECK_ARG(steps && counters && stages >= 1 && (groups == 1 || groups == 2) && stages * groups <= CH_MAX,
-                  "bmm_chain: stages x groups (1 or 2) <= %d steps, 9 zeroed counters", CH_MAX);
+                  "bmm_chain: stages x groups (1 or 2) <= %d steps, 513 zeroed counters", CH_MAX);
   Chain c;
   c.n = stages;
   c.groups = groups;

@@ -341,13 +341,13 @@ _CTRS = {}
 
 
 def _chain_counters(dev):
-    """The 8 per-head arrival counters of mhimx_bmm_chain, one set per (device, stream): zero between launches by the kernel's contract."""
+    """The counter block of mhimx_bmm_chain (include/mhimx.h), one per (device, stream): zero between launches by the kernel's contract."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     c = _CTRS.get(key)
     if c is None:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("mhimx_bmm_chain: run one eager step on the capture stream first (its counters are allocated and zeroed there)")
-        c = _CTRS[key] = torch.zeros(256, dtype=torch.int32, device=dev)      # 8 counters (+ room for the CH_PROF stamps)
+        c = _CTRS[key] = torch.zeros(1024, dtype=torch.int32, device=dev)     # the 513 words of mhimx_bmm_chain (+ room for the CH_PROF stamps)
     return c
 
 
@@ -367,8 +367,8 @@ def _run_chain(steps, groups, dev):
 
 
 def chain_gave_up(dev):
-    """True if a chain launch on this device ever gave up waiting for a workgroup (counters[8], mhimx.h) - synchronises; for tests."""
-    return any(int(c[8].item()) != 0 for (d, _), c in _CTRS.items() if d == dev.index)
+    """True if a chain launch on this device ever gave up waiting for a workgroup (counters[512], mhimx.h) - synchronises; for tests."""
+    return any(int(c[512].item()) != 0 for (d, _), c in _CTRS.items() if d == dev.index)
 
 
 def _landmark_pinv_forward(lm, scale):

@@ -17,7 +17,7 @@ for flag in (False, True):
     res[flag] = (z, dlm)
 print("z   max diff", (res[0][0] - res[1][0]).abs().max().item(), "scale", res[0][0].abs().max().item())
 print("dlm max diff", (res[0][1] - res[1][1]).abs().max().item(), "scale", res[0][1].abs().max().item())
-print("gave up:", ny.chain_gave_up(dev), " counters", ny._CTRS[list(ny._CTRS)[0]][:9].tolist())
+print("gave up:", ny.chain_gave_up(dev), " counters", ny._CTRS[list(ny._CTRS)[0]][:513].sum().item())
 
 
 def fb():
@@ -46,9 +46,11 @@ for flag in (False, True):
 if os.environ.get("CH_PROF"):
     import numpy as np
     ny._CHAIN = True
-    fb(); torch.cuda.synchronize()
+    sv = fb()
+    if os.environ.get("CH_PROF") == "bwd": bw(sv, torch.empty_like(lm))          # the stamps of the LAST launch (backward, second half) remain
+    torch.cuda.synchronize()
     c = ny._CTRS[list(ny._CTRS)[0]]
-    st = c[16:16 + 192].cpu().numpy().view(np.uint64).reshape(8, 12).astype(np.int64)
+    st = c[576:576 + 192].cpu().numpy().view(np.uint64).reshape(8, 12).astype(np.int64)
     order = [0, 1, 2, 3, 4, 8, 9, 10, 5, 6, 7]
     names = ["poll", "own DMA landed", "barrier (all DMA)", "mfma issue", "barrier (all mfma)", "partials + barrier", "reduce + tiles", "barrier", "stores + wait + barrier", "atomic"]
     st = st[:, order]
@@ -73,6 +75,6 @@ if os.environ.get("CH_STRESS"):
         cur = (sv[1].clone(), d.clone())
         if ref is None: ref = cur
         elif not (torch.equal(ref[0], cur[0]) and torch.equal(ref[1], cur[1])): bad += 1
-    print("stress:", n_rep, "repetitions,", bad, "differ from the first; counters", ny._CTRS[list(ny._CTRS)[0]][:9].tolist(), "gave up:", ny.chain_gave_up(dev))
+    print("stress:", n_rep, "repetitions,", bad, "differ from the first; counters", ny._CTRS[list(ny._CTRS)[0]][:513].sum().item(), "gave up:", ny.chain_gave_up(dev))
     import hashlib
     print("digest", hashlib.sha1(ref[0].cpu().numpy().tobytes() + ref[1].cpu().numpy().tobytes()).hexdigest())
