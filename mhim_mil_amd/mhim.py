@@ -885,8 +885,12 @@ class MHIM(nn.Module):
                                           ops._p(f)), "mhimx_scale_heads")
         to_out = self.online_encoder.layer1.attn.to_out[0]
         p = self.online_encoder.layer1.attn.dropout if self.training else 0.0
-        f = ops.gemm_nt(f, to_out.weight.data, bias=to_out.bias.data, drop_p=p, drop_seed=self._next_seed(), drop_tick=self._tick,
-                        prec="bf16x3")
+        if n >= 2048:                                           # on the projection kernel (its own dropout stream; nothing re-applies it)
+            f = ops.bag_project(f, [ops.ProjHead(ops.pair_planes(to_out.weight.data), to_out.bias.data, drop_p=p,
+                                                 drop_seed=self._next_seed())], act=0, drop_tick=self._tick if p > 0 else None)[0].out
+        else:
+            f = ops.gemm_nt(f, to_out.weight.data, bias=to_out.bias.data, drop_p=p, drop_seed=self._next_seed(), drop_tick=self._tick,
+                            prec="bf16x3")
         cam = ops.gemm_nt(f, self.predictor.weight.data, prec="bf16x3")
         return ops.pseudo_score(None, None, cam, self.predictor.bias.data)
 
