@@ -204,18 +204,17 @@ def finish_tail(grad, student, n_train, scale, chain=None):
 
 
 class _SplitStep:
-    """A captured data-parallel step: graph(forward + backward) -> eager all-reduce of the flat gradient -> graph(Adam + EMA)."""
+    """A captured data-parallel step: graph(forward + backward + tail fill) -> eager all-reduce of the flat buffer -> graph(tail
+    average + Adam + EMA)."""
 
     def __init__(self, trainer, g_fb, g_up):
         self.tr, self.g_fb, self.g_up = trainer, g_fb, g_up
 
     def replay(self):
         tr = self.tr
-        self.g_fb.replay()
-        if tr._chain is not None:
-            tr._chain.tokens = tr._chain_tokens                # (static buffer of the captured forward)
-        sync_flat_gradient(tr.flat.grad, tr.flat.student, tr.flat.n_train, tr.world, tr.pg, tr.comm, tr._chain)
-        self.g_up.replay()
+        self.g_fb.replay()                                     # ... + the buffer's tail filled
+        tr._all_reduce(tr.flat.grad)
+        self.g_up.replay()                                     # the tail averaged back + Adam + EMA
 
 
 class FusedTrainer:
@@ -701,6 +700,13 @@ class FusedTrainer:
             scale = sync_flat_gradient(fl.grad, fl.student, fl.n_train, self.world, self.pg, self.comm, self._chain)
         self._apply(scale)
 
+    def _all_reduce(self, buf):
+        """The ONE collective of an update: SUM over the ranks (RCCL through torch.distributed, or the C-ABI's own handle)."""
+        if self.comm is not None:
+            self.comm.allreduce(buf)
+        else:
+            torch.distributed.all_reduce(buf, group=self.pg)
+
     def _apply(self, scale):
         fl = self.flat
         fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
@@ -746,13 +752,21 @@ class FusedTrainer:
             # data parallel: the gradient all-reduce stays OUTSIDE the graphs (compute | RCCL all-reduce | optimiser): a
             # collective inside a captured graph depends on the RCCL build, and a rank that replays while another launches
             # eagerly would deadlock - two graph launches and one eager collective per step cost ~20 us of host time
+            # The tail traffic around the collective (the non-trainable parameters / this rank's weighted Merge tokens into the buffer's
+            # tail before the SUM, their average back into the student after it) is captured with the neighbouring graph: a replayed step
+            # is graph | one collective | graph, nothing else on the host.  capture_error_mode "thread_local": the process group's
+            # watchdog thread polls its events while we capture (a "global" capture would be invalidated by it).
+            fl = self.flat
             g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb, pool=self._graph_pool, stream=cs):
-                self.forward_backward(bag, label, **kw)
-            scale = sync_flat_gradient(self.flat.grad, self.flat.student, self.flat.n_train, self.world, self.pg, self.comm, self._chain)
-            with torch.cuda.graph(g_up, pool=self._graph_pool, stream=cs):
+            with torch.cuda.graph(g_fb, pool=self._graph_pool, stream=cs, capture_error_mode="thread_local"):
+                self.forward_backward(bag, label, **kw)        # (leaves the QueryChain's tokens: static buffer of this capture)
+                fill_tail(fl.grad, fl.student, fl.n_train, self._chain)
+            self._all_reduce(fl.grad)
+            scale = 1.0 / self.world
+            with torch.cuda.graph(g_up, pool=self._graph_pool, stream=cs, capture_error_mode="thread_local"):
+                finish_tail(fl.grad, fl.student, fl.n_train, scale, self._chain)
                 self._apply(scale)
-            self.flat.grad.zero_()                         # (the capture-time all-reduce summed stale values)
+            fl.grad.zero_()                                # (the capture-time all-reduce summed stale values)
             return _SplitStep(self, g_fb, g_up)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):
