@@ -65,11 +65,26 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   for (int i = 0; i < NRA; ++i)
 #pragma unroll
     for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef PW_PROF                                                  // cycles per phase, summed over the k loop (tools/exp_proj_prof.py)
+  const uint64_t pf_t0 = __builtin_readcyclecounter();
+  uint64_t pf_t1 = 0, pf_t2 = 0;
+  uint32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t pf_t = 0;
+#define PW_MARK(i) { const uint64_t now_ = __builtin_readcyclecounter(); pf[i] += (uint32_t)(now_ - pf_t); pf_t = now_; }
+#define PW_START() { pf_t = __builtin_readcyclecounter(); }
+#else
+#define PW_MARK(i)
+#define PW_START()
+#endif
 
   if (producer) {
     // ================================================================= producers: 256 threads own the global -> LDS stream
     // (a lean instruction stream matters: a producer wave shares its SIMD's issue with two consumer waves - the first version spent ~250
     // instructions per k-step here, mostly 64-bit address arithmetic and unpacked conversions, and its slot outlasted the 60-MFMA phase)
+#ifndef PW_PROD_PRIO
+#define PW_PROD_PRIO 1
+#endif
+    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
     const int pt = tid - 64 * W_CONS, pw = wave - W_CONS;
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
     // A: 160 rows x 8 sixteen-byte units per k-step = 1280 units, five per thread: unit u = pt + 256 j -> row u >> 3, slot u & 7
@@ -158,31 +173,43 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       const float* xn = g.X + (int64_t)(s + 3 < nk ? s + 3 : nk - 1) * WBK;
       const char* bk = b_ok ? bcur : bdummy;
       // ---- slot 2s
+      PW_START();
       if (st_ok) {
         split_store(r.v[0], a_hi[0] + st1, a_lo[0] + st1);
         split_store(r.v[1], a_hi[1] + st1, a_lo[1] + st1);
         split_store(r.v[2], a_hi[2] + st1, a_lo[2] + st1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      PW_MARK(0);
       load_a3(xn, r);                                                       // (issued after the split read the registers)
       issue_b(bk, st2, 0);
+      PW_MARK(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PW_MARK(2);
       slot_end();
+      PW_MARK(3);
       // ---- slot 2s+1
       if (st_ok) {
         split_store(r.v[3], a_hi[3] + st1, a_lo[3] + st1);
         split_store(r.v[4], a_hi[4] + st1, a_lo[4] + st1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      PW_MARK(4);
       load_a2(xn, r);
       issue_b(bk, st2, 4);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PW_MARK(5);
       asm volatile("s_waitcnt vmcnt(13)" : PW_NAME5(r_next) : : "memory");
+      PW_MARK(6);
       slot_end();
+      PW_MARK(7);
       st1 = st2;
       st2 = st2 == 2 * WSTAGE ? 0u : st2 + WSTAGE;
       bcur += 128;
     };
+#ifdef PW_PROF
+    pf_t1 = __builtin_readcyclecounter();
+#endif
     int s = 0;
 #pragma unroll 1
     for (; s + 1 < nk; s += 2) {
@@ -192,6 +219,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     if (s < nk) kstep(s, ra, rb);
     slot_end();                                                             // slot 2 nk: group 1's last compute phase
     asm volatile("s_waitcnt vmcnt(0)" : PW_NAME5(ra), PW_NAME5(rb) : : "memory");
+    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(0);                        // the epilogue shares its rows evenly among all twelve waves
 #undef PW_NAME5
   } else {
     // ================================================================= consumers: fragment reads and MFMAs only
@@ -219,16 +247,29 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       mt_term(x, 0, 10, acc);                                               // hi*hi
     };
     slot_end();                                                             // ---- tile 0 complete (producers' prologue)
+#ifdef PW_PROF
+    pf_t1 = __builtin_readcyclecounter();
+#endif
+#ifdef PW_G1_PRIO
+    if (wm != 0) __builtin_amdgcn_s_setprio(PW_G1_PRIO);
+#endif
     const bool late = wm != 0;                                              // group 1 runs the same loop one slot later
     if (late) slot_end();
 #pragma unroll 1
     for (int s = 0; s < nk; ++s) {
-      load_phase(s);       slot_end();
-      compute_phase();     slot_end();
+      PW_START();
+      load_phase(s);       PW_MARK(0);   slot_end();   PW_MARK(1);
+      compute_phase();     PW_MARK(2);   slot_end();   PW_MARK(3);
     }
     if (!late) slot_end();
+#ifdef PW_G1_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 
+#ifdef PW_PROF
+  pf_t2 = __builtin_readcyclecounter();
+#endif
   // ================================================================= epilogue: all twelve waves, two 80-row halves through LDS
   float* tile = reinterpret_cast<float*>(smem);
   uint32_t* rkeys = reinterpret_cast<uint32_t*>(smem + 80 * WTP * 4);
@@ -242,8 +283,16 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   const float inv_keep = H.drop_mask ? 1.f / (1.f - H.drop_p) : 65536.f / (float)(65536u - thr16);
   _Float16* dact = reinterpret_cast<_Float16*>(H.dact);
 #pragma unroll 1
+#ifdef PW_PROF
+  uint32_t pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  pf_t = __builtin_readcyclecounter();
+#define PE_MARK(i) { const uint64_t now_ = __builtin_readcyclecounter(); pe[i] += (uint32_t)(now_ - pf_t); pf_t = now_; }
+#else
+#define PE_MARK(i)
+#endif
   for (int half = 0; half < 2; ++half) {
     __syncthreads();                                          // fragment reads / the previous half's tile reads are over
+    PE_MARK(0);
     if (!producer && wm == half) {
       const int cl = lane & 15, rq = lane >> 4;
 #pragma unroll
@@ -254,7 +303,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
           for (int e = 0; e < 4; ++e) tile[(i * 16 + rq * 4 + e) * WTP + wn * 64 + j * 16 + cl] = acc[i][j][e];
     }
     if (hashed && tid < 80) rkeys[tid] = drop_row_key(dseed, (uint64_t)(m0 + half * 80 + tid));
+    PE_MARK(1);
     __syncthreads();
+    PE_MARK(2);
 #pragma unroll 1
     for (int r = r0; r < 80; r += W_CONS + W_PROD) {
       const int64_t m = m0 + half * 80 + r;
@@ -303,7 +354,21 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       }
       *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
     }
+    PE_MARK(3);
   }
+#ifdef PW_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t pf_t3a = __builtin_readcyclecounter();
+  __syncthreads();
+  if (blockIdx.x == 0 && lane == 0) {
+    const uint64_t pf_t3 = __builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) H.H[(m0 + wave) * H.ldh + i] = (float)(PW_PROF == 2 ? pe[i] : pf[i]);
+    H.H[(m0 + wave) * H.ldh + 8] = (float)(pf_t1 - pf_t0);      // entry -> main loop
+    H.H[(m0 + wave) * H.ldh + 9] = (float)(pf_t2 - pf_t1);      // main loop
+    H.H[(m0 + wave) * H.ldh + 10] = (float)(pf_t3 - pf_t2);     // epilogue
+    H.H[(m0 + wave) * H.ldh + 11] = (float)(pf_t3a - pf_t);     // the wave's last stores leave
+  }
+#endif
 }
 
 // out = x * keep / (1 - p) with the PROJECTION kernels' dropout stream (one 32-bit mix per pair of columns, 16-bit thresholds: the

@@ -351,6 +351,16 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
   __syncthreads();
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
 
+#if defined(WG_PROD_PRIO) || defined(WG_CONS_PRIO)
+#ifndef WG_PROD_PRIO
+#define WG_PROD_PRIO 0
+#endif
+#ifndef WG_CONS_PRIO
+#define WG_CONS_PRIO 0
+#endif
+  if (wave < 4) __builtin_amdgcn_s_setprio(WG_PROD_PRIO);
+  else __builtin_amdgcn_s_setprio(WG_CONS_PRIO);
+#endif
   if (wave < 4) {
     // =========================================================== producers: wave = row octet of the k-step
     const int oct = wave, half = lane >> 5, c = lane & 31;
