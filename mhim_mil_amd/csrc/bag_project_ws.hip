@@ -22,6 +22,19 @@
 //                                                                     B(s+1) has landed
 //   Tile s+1 is complete at the end of slot 2s+1; its first reader is group 0 in slot 2s+2.  Requests run two k-steps ahead (A) / one and
 //   a half (B).
+//
+// Stamped with -DPW_PROF (tools/exp_proj_prof.py; c2 shape, shader cycles of workgroup 0): entry -> loop 5.2 k, k loop 69.4 k (32 k-steps;
+// 2 x 60 MFMAs x 16 cycles = 61.4 k is the matrix pipe's own time), epilogue 27-29 k.  What the stamps changed:
+//   * the producer waves are the YOUNGEST of the workgroup and VALU issue is arbitrated by priority, then age: at priority 0 their split +
+//     store slots took 805 / 684 cycles of a ~1000-cycle slot and set the pace (78.7 k cycles for the loop); s_setprio 1 for the k loop
+//     (back to 0 for the epilogue, which shares rows evenly) brought the loop to 69.4 k: 65.5 -> 61.4 us per launch.  Priority 2 / 3, or
+//     priority 1 for the younger consumer group as well: no further gain.
+//   * the epilogue, MEASURED and not kept: transposed accumulators (MFMA operands exchanged: four consecutive output COLUMNS per lane) with
+//     bias / dropout / activation / 16-byte stores straight from the eight consumer waves' registers - no LDS staging, no barriers:
+//     epilogue 38.9 k cycles (eight waves instead of twelve carry the arithmetic; a store instruction touches 16 rows x 64 B instead of one
+//     1 KiB row), 65.6 vs 62.2 us; the same accumulators staged with 16-byte LDS stores (20 instead of 80 per lane): 64.2 vs 62.6 us.
+//     Without its arithmetic AND its global stores the launch is 5 us shorter: the epilogue is the drain of 51 MB into HBM by 252 workgroups
+//     that all reach it together, not instruction time.
 #include "mma_tile.hpp"
 
 namespace mhimx {

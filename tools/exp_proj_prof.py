@@ -19,8 +19,5 @@ cn = ["load phase (18 reads + wait)", "barrier", "compute phase (60 MFMA issue)"
 pn = ["slot A: split+store 3 units", "A loads + 4 DMA issue", "lgkm wait", "barrier", "slot B: split+store 2 units", "A loads + 4 DMA + lgkm", "vmcnt(13) wait", "barrier"]
 for w, names in ((0, cn), (4, cn), (8, pn)):
     v = hs[0].out[w, :20].cpu().tolist()
-    if os.environ.get("EPI"):
-        print(f"wave {w}: epilogue: " + ", ".join(f"{n} {c:.0f}" for n, c in zip(["wait at barrier", "stage acc -> LDS", "barrier", "rows: math + stores"], v[:4])) + f", stores drain {v[11]:.0f}")
-        continue
     print(f"wave {w}: entry->loop {v[8]:.0f}, main loop {v[9]:.0f}, epilogue {v[10]:.0f} cycles")
     print(f"wave {w}: " + "; ".join(f"{n}: {c / nk:.0f}" for n, c in zip(names, v)), " | per k-step:", round(sum(v[:len(names)]) / nk))
