@@ -377,6 +377,9 @@ def main():
         ok = 1
         try:
             graphs = [trainer.capture(bags[i], labels[i], warmup=1) for i in range(N_BAGS)]
+            for g_ in graphs:               # part of the capture: one replay per graph right after instantiation (the first launch of a
+                g_.replay()                 # hipGraphExec uploads it; with W < N_BAGS warm-up steps that would fall into the timed region)
+            torch.cuda.synchronize()
         except Exception as exc:            # noqa: BLE001 — any capture failure means "run eagerly"
             ok, graph_note = 0, f"{type(exc).__name__}: {str(exc)[:160]}"
             torch.cuda.synchronize()

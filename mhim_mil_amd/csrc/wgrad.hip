@@ -334,6 +334,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
   }
   const unsigned bx = blockIdx.x - (unsigned)side_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef WG_PROF                                                  // shader cycles: entry -> loop, loop, epilogue (tools/exp_wgrad.py WG_PROF=1)
+  const uint64_t wp_t0 = __builtin_readcyclecounter();
+#endif
   const int nJ = (int)(g.D / WBN), nIT = (int)(g.E / WBI), nT = nIT * nJ;
   const int xcd = bx & 7, sidx = bx >> 3;
   const int slab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
@@ -412,8 +415,8 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
     XSet s0, s1, s2;
     issue_a(0, true);
     issue_a(1, nk > 1);
-    {
-      const char* xb = reinterpret_cast<const char*>(g.X);
+    {                                                         // (requesting X(0), X(1), X(2) together shortens entry -> loop from 9.3 k to 7.7 k
+      const char* xb = reinterpret_cast<const char*>(g.X);    //  cycles - stamped, -DWG_PROF - and the launch not at all: 32.1 vs 32.0 us)
       for (int t = 0; t < 2 && t < nk; ++t) {
         const u32x4 ro = row_offsets(t);
         XSet r0;
@@ -440,6 +443,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // image tile t+2 landed, my X(t+2) stores are done
       __builtin_amdgcn_s_barrier();                           // #t+1
     };
+#ifdef WG_PROF
+    const uint64_t wp_t1 = __builtin_readcyclecounter();
+#endif
     int t = 0;
 #pragma unroll 1
     for (; t + 2 < nk; t += 3) {
@@ -455,6 +461,13 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
 #define WS_ALL(s) "+v"(s.v[0]), "+v"(s.v[1]), "+v"(s.v[2]), "+v"(s.v[3]), "+v"(s.v[4]), "+v"(s.v[5]), "+v"(s.v[6]), "+v"(s.v[7])
     asm volatile("s_waitcnt vmcnt(0)" : WS_ALL(s0), WS_ALL(s1), WS_ALL(s2) : : "memory");
 #undef WS_ALL
+#ifdef WG_PROF
+    if (bx == 0 && lane == 0) {
+      const uint64_t wp_t2 = __builtin_readcyclecounter();
+      float* pr = reinterpret_cast<float*>(const_cast<char*>(g.img) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;   // behind the image (the script allocates it)
+      pr[0] = (float)(wp_t1 - wp_t0); pr[1] = (float)(wp_t2 - wp_t1); pr[2] = 0.f; pr[3] = (float)nk;
+    }
+#endif
     return;
   }
 
@@ -474,6 +487,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
   //   u5 Ahi x P(Blo0)   [P <- Bhi0 of t+1]   u6 Ahi x Q(Blo1)   [Q <- Bhi1 of t+1, Ahi <- t+1]
   f32x4 alo[4], ahi[4], P[4], Q[4];
   __builtin_amdgcn_s_barrier();                               // #0
+#ifdef WG_PROF
+  const uint64_t wp_t1 = __builtin_readcyclecounter();
+#endif
   WS_READ4A(alo, fa_lo);
   WS_READ4B(P, fb_hi);
   WS_READ4B(Q, fb_hi + 256);
@@ -515,6 +531,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
     __builtin_amdgcn_s_barrier();                             // #t+1: tile t is retired, tile t+2 published
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef WG_PROF
+  const uint64_t wp_t2 = __builtin_readcyclecounter();
+#endif
   // epilogue: block (ja, jq = 4 cb + jb) of a lane is row 4 (16 wm + 4 kg + e) + ja, column 4 (16 (2 wn + cb) + r16) + jb
   float* out = g.out + (int64_t)slab * g.E * g.D;
 #pragma unroll
@@ -528,6 +547,14 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
         *reinterpret_cast<f32x4*>(out + i * g.D + n) =
             f32x4{acc[ja][4 * cb + 0][e], acc[ja][4 * cb + 1][e], acc[ja][4 * cb + 2][e], acc[ja][4 * cb + 3][e]};
       }
+#ifdef WG_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (bx == 0 && lane == 0) {
+    const uint64_t wp_t3 = __builtin_readcyclecounter();
+    float* pr = reinterpret_cast<float*>(const_cast<char*>(g.img) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;
+    pr[0] = (float)(wp_t1 - wp_t0); pr[1] = (float)(wp_t2 - wp_t1); pr[2] = (float)(wp_t3 - wp_t2); pr[3] = (float)nk;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ dact = torch.randn(N + 6, E, device="cuda").half()
 rows = torch.randperm(N, device="cuda")[:L_].sort().values
 ow, ob = torch.empty(E, D, device="cuda"), torch.empty(E, device="cuda")
 lib = L.lib()
-img = torch.empty(lib.mhimx_wgrad_image_bytes(L_, E) // 4, device="cuda")
+img = torch.zeros(lib.mhimx_wgrad_image_bytes(L_, E) // 4 + 1024, device="cuda")      # (+ room for the -DWG_PROF stamps behind the image)
 ws_b = torch.empty(2 * -(-L_ // 32) * E, device="cuda")
 ws = torch.empty(lib.mhimx_wgrad_ws_floats(L_, E, D), device="cuda")
 g = L.BagWgrad(img=img.data_ptr(), X=x.data_ptr(), ldx=D, n_bag_rows=N, rows=rows.data_ptr(), L=L_, E=E, D=D, C=ow.data_ptr(), ldc=D,
@@ -54,3 +54,9 @@ for name in which:
         fn()
     e1.record(); torch.cuda.synchronize()
     print("%-6s %.1f us per call (back-to-back launches)" % (name, e0.elapsed_time(e1) * 1e3 / 100))
+
+if os.environ.get("WG_PROF"):
+    wgrad(); torch.cuda.synchronize()
+    st = img[lib.mhimx_wgrad_image_bytes(L_, E) // 4:][:32].view(8, 4).cpu().tolist()
+    for w in (0, 4):
+        print("wave %d: entry -> loop %.0f, loop %.0f (%d k-steps), epilogue %.0f shader cycles" % (w, st[w][0], st[w][1], st[w][3], st[w][2]))
