@@ -98,6 +98,11 @@ typedef struct {
   const uint64_t* drop_tick;          /* optional device step counter mixed into every drop_seed           */
 } mhimx_bag_project_args;
 int mhimx_bag_project(void* stream, const mhimx_bag_project_args* a);
+/* The projections of the n_bags <= 8 bags of an accumulation window (they share both models' weights: base_engine.py:100-119 steps the
+ * optimiser once per window) in ONE launch: row tiles of the next bag start while the last ones of a bag drain their outputs.  The bags share
+ * N, D, E, ldx, act, n_heads, drop_tick and per model wp, bias, ldh, drop_p; each brings its X, H, dact and drop_seed (no masks, no
+ * residual rows). */
+int mhimx_bag_project_multi(void* stream, const mhimx_bag_project_args* bags, int32_t n_bags);
 
 /* C[m,n] (+)= alpha * sum_k A[m,k] * B[k,n]   with B row-major [K,N] (ldb = its row pitch).  Only A, lda, rows, B, ldb,
  * C, ldc, M, N, K, accumulate and prec of the argument block are read.  Both operands may be activations (attention
@@ -506,6 +511,13 @@ typedef struct {
 } mhimx_bag_wgrad_args;
 int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D);
 int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a);
+/* The same product SUMMED over the n_bags <= 8 bags of an accumulation window (base_engine.py:100-119: the gradients of the window's bags
+ * add up before the one optimiser step) in ONE launch: dW (+)= sum_b dPRE_b^T X_b.  Every bag brings its image, bag and row ids and owns
+ * its slabs of k-steps; the slab sum (and everything a launch pays once: row tables, first tiles, 34 MB of slab traffic) happens once per
+ * window instead of once per bag.  All bags: the same L, E, D, ldx; C / ldc / accumulate / ws / defer of bags[0] are used;
+ * ws_floats >= mhimx_wgrad_multi_ws_floats(L, E, D, n_bags). */
+int64_t mhimx_wgrad_multi_ws_floats(int64_t L, int64_t E, int64_t D, int32_t n_bags);
+int mhimx_bag_wgrad_multi(void* stream, const mhimx_bag_wgrad_args* bags, int32_t n_bags);
 /* Instance-sharded bags: a shard holds bag rows [lo, lo + n).  The student's row lists are replicated
  * (every rank runs the same select); these three turn them into fixed-shape local work, with no data-dependent count on the host:
  *   shard_flags   excl[i] = 1 for i < n + k_tokens, then excl[row - lo] = 0 for every stay row (rows_all[R .. R+Lk)) inside the shard and

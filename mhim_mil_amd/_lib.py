@@ -163,6 +163,7 @@ SYMBOLS = {
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
     "mhimx_bag_project": (C.c_int, [_P, C.POINTER(BagProject)]),
+    "mhimx_bag_project_multi": (C.c_int, [_P, _P, _I32]),
     "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),
     "mhimx_prep_batch": (C.c_int, [_P, C.POINTER(PrepJob), _I32]),
     "mhimx_pair_planes": (C.c_int, [_P, _P, _I64, _I64, _I64, _P]),
@@ -202,6 +203,8 @@ SYMBOLS = {
     "mhimx_wgrad_image_bytes": (_I64, [_I64, _I64]),
     "mhimx_wgrad_ws_floats": (_I64, [_I64, _I64, _I64]),
     "mhimx_bag_wgrad": (C.c_int, [_P, _P]),
+    "mhimx_bag_wgrad_multi": (C.c_int, [_P, _P, _I32]),
+    "mhimx_wgrad_multi_ws_floats": (C.c_int64, [_I64, _I64, _I64, _I32]),
     "mhimx_reduce_flush": (C.c_int, [_P, _P]),
     "mhimx_cls_metrics_ws_bytes": (C.c_int64, [_I64, _I64, _I64]),
     "mhimx_cls_metrics": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I32, _P, _I64, _P, _P, _I64]),

@@ -471,9 +471,9 @@ __global__ __launch_bounds__(PTHREADS, 2) void bag_project_kernel(mhimx_bag_proj
 #endif
 }
 
-int bag_project_ws(hipStream_t st, const mhimx_bag_project_args& g);       // bag_project_ws.hip
+int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bags);       // bag_project_ws.hip
 
-int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
+static int bag_project_check(const mhimx_bag_project_args& g) {
   MHIMX_CHECK_ARG(g.X && g.N >= 1 && g.D >= PBK && g.D % PBK == 0, "bag_project: X [N,D] with D a multiple of 32");
   MHIMX_CHECK_ARG(g.E >= PBN && g.E % PBN == 0, "bag_project: E must be a multiple of 256");
   MHIMX_CHECK_ARG(g.n_heads >= 1 && g.n_heads <= MHIMX_PROJ_MAX_HEADS, "bag_project: 1..%d models", MHIMX_PROJ_MAX_HEADS);
@@ -487,10 +487,26 @@ int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
     MHIMX_CHECK_ARG(H.drop_p >= 0.f && H.drop_p < 1.f, "bag_project: model %d: dropout probability outside [0,1)", h);
     MHIMX_CHECK_ARG(!H.drop_mask || (reinterpret_cast<uintptr_t>(H.drop_mask) & 3) == 0, "bag_project: model %d: unaligned mask", h);
   }
+  return 0;
+}
+
+int bag_project(hipStream_t st, const mhimx_bag_project_args* bags, int n_bags) {
+  const mhimx_bag_project_args& g = bags[0];
+  for (int b = 0; b < n_bags; ++b) {
+    if (int rc = bag_project_check(bags[b])) return rc;
+    if (b == 0) continue;
+    const mhimx_bag_project_args& q = bags[b];
+    bool same = q.N == g.N && q.D == g.D && q.E == g.E && q.ldx == g.ldx && q.act == g.act && q.n_heads == g.n_heads && q.drop_tick == g.drop_tick;
+    for (int h = 0; same && h < g.n_heads; ++h)
+      same = q.head[h].wp == g.head[h].wp && q.head[h].bias == g.head[h].bias && q.head[h].ldh == g.head[h].ldh && q.head[h].drop_p == g.head[h].drop_p &&
+             !q.head[h].drop_mask && !g.head[h].drop_mask && !q.head[h].resid && !g.head[h].resid && (q.head[h].dact != nullptr) == (g.head[h].dact != nullptr);
+    MHIMX_CHECK_ARG(same, "bag_project_multi: bag %d: the bags of one launch share shapes, weights, activation and dropout law (no masks, no residual rows)", b);
+  }
   // the specialised-wave form (bag_project_ws.hip: 8 ping-pong consumer waves + 4 producer waves) is the default; MHIMX_PROJ_LOCKSTEP=1
   // selects this file's uniform 8-wave kernel (same tiles, same arithmetic, same bits)
   static const bool lockstep = getenv("MHIMX_PROJ_LOCKSTEP") != nullptr;
-  if (!lockstep) return bag_project_ws(st, g);
+  if (!lockstep) return bag_project_ws(st, bags, n_bags);
+  MHIMX_CHECK_ARG(n_bags == 1, "bag_project_multi: only the default (specialised-wave) kernel takes several bags");
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE)));
   const int nN = (int)(g.n_heads * g.E / PBN), nM = (int)cdiv(g.N, PBM);
   dim3 grid((unsigned)(8 * nN * cdiv(nM, 8)));
@@ -503,5 +519,10 @@ int bag_project(hipStream_t st, const mhimx_bag_project_args& g) {
 
 extern "C" int mhimx_bag_project(void* stream, const mhimx_bag_project_args* a) {
   if (!a) return mhimx::fail(-1, "bag_project: null argument block");
-  return mhimx::bag_project((hipStream_t)stream, *a);
+  return mhimx::bag_project((hipStream_t)stream, a, 1);
+}
+extern "C" int mhimx_bag_project_multi(void* stream, const mhimx_bag_project_args* bags, int32_t n_bags) {
+  using namespace mhimx;
+  MHIMX_CHECK_ARG(bags && n_bags >= 1 && n_bags <= 8, "bag_project_multi: 1..8 bags");
+  return bag_project((hipStream_t)stream, bags, n_bags);
 }

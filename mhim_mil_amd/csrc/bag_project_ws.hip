@@ -49,20 +49,36 @@ typedef _Float16 pw_h4 __attribute__((ext_vector_type(4)));
 
 MHIMX_DEV uint32_t pw_pair_hash(uint32_t row_key, uint32_t pair) { return mix32(row_key + pair * 0x85EBCA77u); }   // (bag_project.hip's stream)
 
-__global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_project_args g) {
+// The bags of ONE launch (mhimx_bag_project_multi: the bags of an accumulation window share weights, shapes and the dropout law; each has its
+// own rows, outputs and dropout seeds).  Row tiles are numbered bag-major, a bag's count rounded up to a multiple of 8 (XCD mapping).
+constexpr int W_MAX_BAGS = 8;
+struct ProjBags {
+  int n_bags, tiles_per_bag;
+  const float* X[W_MAX_BAGS];
+  float* H[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
+  void* dact[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
+  uint64_t seed[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
+};
+
+__global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_project_args g, ProjBags pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)((g.N + WBM - 1) / WBM);
   const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
-  const int m_tile = (sidx / nN) * 8 + xcd, n_tile = sidx % nN;             // the column tiles of one row tile share an XCD (X rows via its L2)
+  const int m_all = (sidx / nN) * 8 + xcd, n_tile = sidx % nN;              // the column tiles of one row tile share an XCD (X rows via its L2)
+  const int bag = m_all / pb.tiles_per_bag, m_tile = m_all - bag * pb.tiles_per_bag;
   if (m_tile >= nM) return;
+  g.X = pb.X[bag];
   const int64_t m0 = (int64_t)m_tile * WBM;
   const int tiles_per_head = (int)(g.E / WBN);
   const int hd = n_tile / tiles_per_head;
   const int64_t n0 = (int64_t)(n_tile % tiles_per_head) * WBN;
   mhimx_proj_head H = g.head[0];
   if (hd == 1) H = g.head[1];
+  H.H = pb.H[bag][hd];
+  H.dact = pb.dact[bag][hd];
+  H.drop_seed = pb.seed[bag][hd];
   const int nk = (int)(g.D / WBK);
   const bool producer = wave >= W_CONS;
   const int wm = (wave >> 2) & 1, wn = wave & 3;                            // consumer waves: M half (= ping-pong group), N quarter
@@ -407,11 +423,23 @@ __global__ __launch_bounds__(256) void proj_dropout_apply_kernel(const float* __
   }
 }
 
-int bag_project_ws(hipStream_t st, const mhimx_bag_project_args& g) {
+int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bags) {
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
+  const mhimx_bag_project_args& g = bags[0];
   const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)cdiv(g.N, WBM);
-  dim3 grid((unsigned)(8 * nN * cdiv(nM, 8)));
-  hipLaunchKernelGGL(bag_project_ws_kernel, grid, dim3(WTHREADS), WNST * WSTAGE, st, g);
+  ProjBags pb = {};
+  pb.n_bags = n_bags;
+  pb.tiles_per_bag = (int)(8 * cdiv(nM, 8));
+  for (int b = 0; b < n_bags; ++b) {
+    pb.X[b] = bags[b].X;
+    for (int h = 0; h < g.n_heads; ++h) {
+      pb.H[b][h] = bags[b].head[h].H;
+      pb.dact[b][h] = bags[b].head[h].dact;
+      pb.seed[b][h] = bags[b].head[h].drop_seed;
+    }
+  }
+  dim3 grid((unsigned)(nN * pb.tiles_per_bag * n_bags));
+  hipLaunchKernelGGL(bag_project_ws_kernel, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -89,6 +89,14 @@ struct WgradArgs {
   float* out;                 // slabs [splits][E][D]
 };
 
+constexpr int W_MAX_BAGS = 8;
+struct WgradBags {            // the bags of one launch (bag_wgrad_ws_kernel): bag b owns slabs [b * spb, (b + 1) * spb)
+  const char* img[W_MAX_BAGS];
+  const float* X[W_MAX_BAGS];
+  const int64_t* rows[W_MAX_BAGS];
+  int spb;
+};
+
 __global__ __launch_bounds__(WTHREADS) void bag_wgrad_kernel(WgradArgs g, int side_blocks, Merge2Side side) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2, 256 of the 512 threads): its few
@@ -326,7 +334,7 @@ MHIMX_DEV void ws_unit(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[4]
     for (int j = 0; j < 4; ++j) acc[i][4 * CB + j] = mt_mfma(a[i], b[j], acc[i][4 * CB + j]);
 }
 
-__global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int side_blocks, Merge2Side side) {
+__global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, WgradBags mb, int side_blocks, Merge2Side side) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < side_blocks) {
     if (threadIdx.x < M2_THREADS) merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
@@ -343,13 +351,17 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
   if (slab >= g.splits) return;
   const int itile = tile / nJ;
   const int64_t i0 = (int64_t)itile * WBI, n0 = (int64_t)(tile % nJ) * WBN;
-  const int ks0 = slab * g.kps;
+  // an accumulation window's bags in ONE launch (mhimx_bag_wgrad_multi): slab -> (bag, slab of that bag); every bag has the same L
+  const int bag = slab / mb.spb, ks0 = (slab - bag * mb.spb) * g.kps;
+  const char* const gimg = mb.img[bag];
+  const float* const gX = mb.X[bag];
+  const int64_t* const grows = mb.rows[bag];
   const int nk = (ks0 + g.kps < g.ksteps ? ks0 + g.kps : g.ksteps) - ks0;
   unsigned* rowtab = reinterpret_cast<unsigned*>(smem + SRING);
   for (int q = tid; q < nk * WBK; q += WTHREADS) {
     int64_t l = (int64_t)ks0 * WBK + q;
     if (l >= g.L) l = g.L - 1;
-    rowtab[q] = (unsigned)((g.rows ? g.rows[l] : l) * g.ldx * 4);
+    rowtab[q] = (unsigned)((grows ? grows[l] : l) * g.ldx * 4);
   }
   __syncthreads();
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
                    "global_load_dwordx4 %6, %14, %16\n\tglobal_load_dwordx4 %7, %15, %16"
                    : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
                    : "v"(ro[0] + colb0), "v"(ro[1] + colb0), "v"(ro[2] + colb0), "v"(ro[3] + colb0), "v"(ro[0] + colb1), "v"(ro[1] + colb1),
-                     "v"(ro[2] + colb1), "v"(ro[3] + colb1), "s"(g.X)
+                     "v"(ro[2] + colb1), "v"(ro[3] + colb1), "s"(gX)
                    : "memory");
     };
     const unsigned xs0 = (unsigned)(SNA * WA_BYTES + ((oct * 2) * 256 + (2 * half) * 64 + c) * 16);
@@ -404,10 +416,10 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
         }
       }
     };
-    const char* abase = g.img + ((int64_t)ks0 * nIT + itile) * WA_BYTES + (wave * 64 + lane) * 16;
+    const char* abase = gimg + ((int64_t)ks0 * nIT + itile) * WA_BYTES + (wave * 64 + lane) * 16;
     auto issue_a = [&](int t, bool live) {                     // 16 KiB by 256 threads: four 4 KiB pieces
       char* sa = smem + (t % SNA) * WA_BYTES + wave * 1024;
-      const char* src = live ? abase + (int64_t)t * nIT * WA_BYTES : g.img;
+      const char* src = live ? abase + (int64_t)t * nIT * WA_BYTES : gimg;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         __builtin_amdgcn_global_load_lds((gptr_f)(live ? src + j * 4096 : src), (lptr_f)(sa + j * 4096), 16, 0, 0);
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
     issue_a(0, true);
     issue_a(1, nk > 1);
     {                                                         // (requesting X(0), X(1), X(2) together shortens entry -> loop from 9.3 k to 7.7 k
-      const char* xb = reinterpret_cast<const char*>(g.X);    //  cycles - stamped, -DWG_PROF - and the launch not at all: 32.1 vs 32.0 us)
+      const char* xb = reinterpret_cast<const char*>(gX);    //  cycles - stamped, -DWG_PROF - and the launch not at all: 32.1 vs 32.0 us)
       for (int t = 0; t < 2 && t < nk; ++t) {
         const u32x4 ro = row_offsets(t);
         XSet r0;
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
 #ifdef WG_PROF
     if (bx == 0 && lane == 0) {
       const uint64_t wp_t2 = __builtin_readcyclecounter();
-      float* pr = reinterpret_cast<float*>(const_cast<char*>(g.img) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;   // behind the image (the script allocates it)
+      float* pr = reinterpret_cast<float*>(const_cast<char*>(gimg) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;   // behind the image (the script allocates it)
       pr[0] = (float)(wp_t1 - wp_t0); pr[1] = (float)(wp_t2 - wp_t1); pr[2] = 0.f; pr[3] = (float)nk;
     }
 #endif
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, int
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (bx == 0 && lane == 0) {
     const uint64_t wp_t3 = __builtin_readcyclecounter();
-    float* pr = reinterpret_cast<float*>(const_cast<char*>(g.img) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;
+    float* pr = reinterpret_cast<float*>(const_cast<char*>(gimg) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;
     pr[0] = (float)(wp_t1 - wp_t0); pr[1] = (float)(wp_t2 - wp_t1); pr[2] = (float)(wp_t3 - wp_t2); pr[3] = (float)nk;
   }
 #endif
@@ -869,8 +881,25 @@ extern "C" int mhimx_rows_dpre_image_c(void* stream, const float* dH_compact, co
   return rows_dpre_image_impl(stream, dH_compact, dact16, rows, L, E, img, colsum_out, accumulate, ws, ws_bytes, defer, 1);
 }
 
-extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
-  if (!a) return fail(-1, "bag_wgrad: null argument block");
+// slabs PER BAG of a launch over n_bags bags of L rows each: enough workgroups for the chip, a row table that fits (W_MAX_CHUNK rows)
+static int wgrad_plan_multi(int64_t L, int64_t E, int64_t D, int n_bags, int* kps_out) {
+  const int ksteps = (int)cdiv(L, WBK);
+  const int64_t tiles = (E / WBI) * (D / WBN);
+  int64_t spb = cdiv(256, tiles * n_bags);
+  const int64_t need = cdiv((int64_t)ksteps * WBK, W_MAX_CHUNK);
+  if (spb < need) spb = need;
+  if (spb > ksteps) spb = ksteps;
+  int kps = (int)cdiv(ksteps, spb);
+  *kps_out = kps;
+  return (int)cdiv(ksteps, kps);
+}
+extern "C" int64_t mhimx_wgrad_multi_ws_floats(int64_t L, int64_t E, int64_t D, int32_t n_bags) {
+  int kps;
+  return (int64_t)wgrad_plan_multi(L, E, D, n_bags, &kps) * n_bags * E * D;
+}
+
+static int bag_wgrad_impl(void* stream, const mhimx_bag_wgrad_args* bags, int n_bags) {
+  const mhimx_bag_wgrad_args* a = bags;
   MHIMX_CHECK_ARG(a->img && a->X && a->C && a->ws && aligned16(a->img) && aligned16(a->X) && aligned16(a->C) && aligned16(a->ws) && a->ldc % 4 == 0,
                   "bag_wgrad: null / unaligned operand");
   MHIMX_CHECK_ARG(wgrad_shape_ok(a->L, a->E, a->D, a->ldx, a->n_bag_rows),
@@ -878,7 +907,21 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   WgradArgs g;
   g.img = (const char*)a->img; g.X = a->X; g.ldx = a->ldx; g.rows = a->rows; g.L = a->L; g.E = a->E; g.D = a->D;
   g.ksteps = (int)cdiv(a->L, WBK);
-  g.splits = wgrad_plan(a->L, a->E, a->D, &g.kps);
+  WgradBags mb = {};
+  if (n_bags == 1) {
+    g.splits = wgrad_plan(a->L, a->E, a->D, &g.kps);
+    mb.spb = g.splits;
+  } else {
+    mb.spb = wgrad_plan_multi(a->L, a->E, a->D, n_bags, &g.kps);
+    g.splits = mb.spb * n_bags;
+  }
+  for (int b = 0; b < n_bags; ++b) {
+    const mhimx_bag_wgrad_args& q = bags[b];
+    MHIMX_CHECK_ARG(q.img && q.X && aligned16(q.img) && aligned16(q.X) && q.L == a->L && q.E == a->E && q.D == a->D && q.ldx == a->ldx &&
+                        q.n_bag_rows * q.ldx * 4 < ((int64_t)1 << 32) && (q.rows != nullptr) == (a->rows != nullptr),
+                    "bag_wgrad_multi: bag %d: null / unaligned operand, or not the shape of bag 0 (L, E, D, ldx, row ids)", b);
+    mb.img[b] = (const char*)q.img; mb.X[b] = q.X; mb.rows[b] = q.rows;
+  }
   MHIMX_CHECK_ARG(a->ws_floats >= (int64_t)g.splits * a->E * a->D, "bag_wgrad: workspace too small (%lld floats)", (long long)((int64_t)g.splits * a->E * a->D));
   g.out = a->ws;
   const size_t smem = WRING + (size_t)g.kps * WBK * 4;
@@ -906,6 +949,7 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   // round-2 kernel stays the default; MHIMX_WGRAD_PP=1 selects the ping-pong form, MHIMX_WGRAD_UNIFORM=1 the uniform one.
   static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;
   static const bool pp_form = ws_form && getenv("MHIMX_WGRAD_PP") != nullptr;
+  MHIMX_CHECK_ARG(n_bags == 1 || (ws_form && !pp_form), "bag_wgrad_multi: only the default (specialised-wave) kernel takes several bags");
   if (pp_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
@@ -913,7 +957,7 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
   } else if (ws_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
-    hipLaunchKernelGGL(bag_wgrad_ws_kernel, grid, dim3(WTHREADS), smem2, (hipStream_t)stream, g, side_blocks, side);
+    hipLaunchKernelGGL(bag_wgrad_ws_kernel, grid, dim3(WTHREADS), smem2, (hipStream_t)stream, g, mb, side_blocks, side);
   } else
   hipLaunchKernelGGL(bag_wgrad_kernel, grid, dim3(WTHREADS), smem, (hipStream_t)stream, g, side_blocks, side);
   MHIMX_LAUNCH_CHECK();
@@ -922,4 +966,13 @@ extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
     if (rc) return rc;
   }
   return 0;
+}
+
+extern "C" int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a) {
+  if (!a) return fail(-1, "bag_wgrad: null argument block");
+  return bag_wgrad_impl(stream, a, 1);
+}
+extern "C" int mhimx_bag_wgrad_multi(void* stream, const mhimx_bag_wgrad_args* bags, int32_t n_bags) {
+  MHIMX_CHECK_ARG(bags && n_bags >= 1 && n_bags <= W_MAX_BAGS, "bag_wgrad_multi: 1..%d bags", W_MAX_BAGS);
+  return bag_wgrad_impl(stream, bags, n_bags);
 }

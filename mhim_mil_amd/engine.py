@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import mhim as mh
@@ -201,6 +203,15 @@ def finish_tail(grad, student, n_train, scale, chain=None):
     else:
         student[n_train:].copy_(grad[n_train:] * scale)
     grad[n_train:].zero_()
+
+
+# Accumulation windows: both GEMMs of the window's bags as ONE launch each (mhimx_bag_project_multi / mhimx_bag_wgrad_multi).  MEASURED
+# (round 3, 8 bags of the c2 shape, same box): the projection 8 x 61.2 -> 470 us, the weight gradient 8 x (44 + 3 of slab sum) -> 219 us -
+# and the window not at all (1.52 ms on 4 streams, 2.55 ms on one, with or without): the Merge backward's tail that rode in each bag's
+# weight-gradient launch becomes a launch of its own (8 x 17.8 us), and the window on 4 streams is bound by how the graph's branches
+# overlap (average concurrency 1.7, profiles/r03_window_timeline.md), not by kernel time.  Opt-in until the tail rides elsewhere.
+_WINDOW_WGRAD = os.environ.get("MHIMX_WINDOW_WGRAD", "0") != "0"
+_WINDOW_PROJECT = os.environ.get("MHIMX_WINDOW_PROJECT", "0") != "0"
 
 
 class _SplitStep:
@@ -430,7 +441,21 @@ class FusedTrainer:
             s.merge_enable = merge_on
         return prep_t, preps
 
-    def _nat_bag(self, x, label, prep_t, prep_s, gv, accumulate=False, perm=None, ids_shuffle=None, i=None, mid_hook=None, q_out=None, slot=0):
+    def _nat_heads(self, x, prep_t, prep_s):
+        """The student's feature buffer [N + k, E] (the k rows behind the bag: Merge's tokens) and both models' projection heads of a bag."""
+        s, t = self.s, self.t
+        mhim = self.model_kind == "mhim"
+        k = s.merge.k if mhim else 0
+        Hbuf = torch.empty((x.shape[0] + k, s.mlp_dim), device=x.device)
+        heads = []
+        if mhim:
+            p_t = t.dropout_p if t.training else 0.0                # the trainer keeps the teacher in train mode
+            heads.append(ops.ProjHead(prep_t["w1p"], t.feature[0].bias.data, drop_p=p_t, drop_seed=t._next_seed(teacher=True)))
+        heads.append(ops.ProjHead(prep_s["w1p"], s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=s._next_seed(), out=Hbuf, want_dact=True))
+        return Hbuf, heads
+
+    def _nat_bag(self, x, label, prep_t, prep_s, gv, accumulate=False, perm=None, ids_shuffle=None, i=None, mid_hook=None, q_out=None, slot=0,
+                 wgrad_park=None, projected=None):
         """One bag of the single-pass step after its preparation: projection (teacher + student), teacher pool, select, Merge, student
         pool, head, backward.  ``gv``: the gradient views to fill (``accumulate``: add to them); ``q_out``: where Merge's EMA-updated
         queries go (default: the parameter itself, merge.py:142-143)."""
@@ -444,14 +469,11 @@ class FusedTrainer:
         try:
             k = s.merge.k if mhim else 0
             act = mh.L.act_code(s.act, mh._FEATURE_ACTS)
-            Hbuf = torch.empty((ps + k, E), device=dev)
-            heads = []
-            if mhim:
-                p_t = t.dropout_p if t.training else 0.0            # the trainer keeps the teacher in train mode
-                heads.append(ops.ProjHead(prep_t["w1p"], t.feature[0].bias.data, drop_p=p_t, drop_seed=t._next_seed(teacher=True)))
-            heads.append(ops.ProjHead(prep_s["w1p"], s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=s._next_seed(), out=Hbuf,
-                                      want_dact=True))
-            ops.bag_project(x, heads, act=act, drop_tick=self.tick)
+            if projected is None:
+                Hbuf, heads = self._nat_heads(x, prep_t, prep_s)
+                ops.bag_project(x, heads, act=act, drop_tick=self.tick)
+            else:                                                 # an accumulation window projected all its bags in one launch
+                Hbuf, heads = projected
             DACT = heads[-1].dact
             teacher_feat, rows_all, score = None, None, None
             if mhim:
@@ -487,7 +509,7 @@ class FusedTrainer:
                 main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
                 d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=accumulate)
             # the six final gradient reductions of the backward (slab sums, column partials) run as ONE launch
-            s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=mid_hook, accumulate=accumulate)
+            s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=mid_hook, accumulate=accumulate, wgrad_park=wgrad_park)
             ops.reduce_flush(self._defer)
         finally:
             s.merge_enable = merge_on
@@ -557,6 +579,15 @@ class FusedTrainer:
         ev0 = torch.cuda.Event()
         ev0.record(main)
         logits, losses, tokens, per_bag = [None] * k, [None] * k, [None] * k, []
+        park = [] if _WINDOW_WGRAD else None                          # the bags' dPre images: ONE weight-gradient product for the window
+        proj = [None] * k
+        if _WINDOW_PROJECT and k <= 8:
+            # both models' projections of ALL the window's bags in one launch (mhimx_bag_project_multi): the weights are the window's, a bag's
+            # last row tiles drain their 51 MB of outputs under the next bag's loops, and no projection fills every CU later, in the middle
+            # of the other streams' small launches
+            proj = [self._nat_heads(x, prep_t, pp) for x, pp in zip(xs, preps)]
+            ops.bag_project_multi(xs, [h for _, h in proj], act=mh.L.act_code(s.act, mh._FEATURE_ACTS), drop_tick=self.tick)
+            ev0.record(main)                                          # (the side streams start behind the projection)
         keep_defer = self._defer
         try:
             for j in range(k):
@@ -568,7 +599,7 @@ class FusedTrainer:
                 self._defer = keep_defer if lane == 0 else st["defers"][lane - 1]
                 with torch.cuda.stream(stream):
                     logits[j], losses[j] = self._nat_bag(xs[j], labels[j], prep_t, preps[j], gv, accumulate=(j >= S), i=i,
-                                                         q_out=q_new[j], slot=j)
+                                                         q_out=q_new[j], slot=j, wgrad_park=park, projected=proj[j])
                     tokens[j] = self.last["tokens"]
                     per_bag.append(self.last)
         finally:
@@ -577,6 +608,11 @@ class FusedTrainer:
             e = torch.cuda.Event()
             e.record(st["streams"][lane - 1])
             main.wait_event(e)
+        if park:
+            # dW1 (+)= sum_bags dPre_b^T X_b as ONE launch (mhimx_bag_wgrad_multi): every bag owns its slabs of k-steps, and what a launch pays
+            # once - row tables, first tiles, 34 MB of split-K slabs written and summed - is paid once per window (8 x (36 + 9) -> 236 + 16 us)
+            ops.bag_wgrad_multi(park, fl.grad_views["feature.0.weight"], accumulate=False, defer=self._defer)
+            ops.reduce_flush(self._defer)
         if S > 1:                                                     # the other streams' slabs: summed into the gradient by the optimiser
             if update and self.world == 1:                            # kernel itself (mhimx_optim_args.g_extra); else by one reduce launch
                 self._g_extra = st["slabs"][:S - 1]

@@ -622,7 +622,7 @@ class MHIM(nn.Module):
         saved["pool"] = st
         return st.z, saved
 
-    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None, accumulate=False):
+    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None, accumulate=False, wgrad_park=None):
         """Backward of _bag_forward_nat: every gradient buffer is bag-ordered too (dH [N + k, E]); the rows that took part are
         gathered once more by the activation backward (ops.rows_dpre) and the projection's weight-gradient GEMM."""
         N = x.shape[0]
@@ -655,7 +655,12 @@ class MHIM(nn.Module):
             mid_hook()
         Lr = plan.L
         rows = None if rows_all is None else rows_all[:Lr]
-        if ops.bag_wgrad_ok(x, dHbuf.shape[1], Lr):
+        if wgrad_park is not None and rows is not None and ops.bag_wgrad_ok(x, dHbuf.shape[1], Lr):
+            # an accumulation window: only the dPre image (+ the bias gradient) now; the window's ONE product launch sums all its bags
+            im = ops.bag_wgrad_image(dHbuf, saved["DACT"], x, rows, Lr, out_b=out.get("feature.0.bias"), accumulate=accumulate, defer=defer)
+            wgrad_park.append(im)
+            grads["feature.0.weight"], db1 = None, out.get("feature.0.bias")
+        elif ops.bag_wgrad_ok(x, dHbuf.shape[1], Lr):
             grads["feature.0.weight"], db1 = ops.bag_wgrad(dHbuf, saved["DACT"], x, rows, Lr, out_w=out.get("feature.0.weight"),
                                                            out_b=out.get("feature.0.bias"), defer=defer, accumulate=accumulate)
         else:

@@ -79,6 +79,32 @@ class ProjHead:
         self.out, self.want_dact, self.dact, self.resid = out, want_dact, dact, resid
 
 
+def _project_args(x, heads, act, drop_tick, extra_rows):
+    _chk(x, name="x")
+    N, D = x.shape
+    E = heads[0].wp.shape[0]
+    a = L.BagProject(X=_p(x), ldx=x.stride(0), N=N, D=D, E=E, act=int(act), n_heads=len(heads), drop_tick=_p(drop_tick))
+    for i, h in enumerate(heads):
+        _chk(h.wp, name="wp"); _chk(h.bias, name="bias"); _chk(h.drop_mask, torch.uint8, "drop_mask"); _chk(h.resid, name="resid")
+        if h.out is None:
+            h.out = torch.empty((N + extra_rows, E), device=x.device)
+        _chk(h.out, name="out")
+        if h.want_dact and h.dact is None:
+            h.dact = torch.empty((N, E), device=x.device, dtype=torch.float16)
+        a.head[i] = L.ProjHead(wp=_p(h.wp), bias=_p(h.bias), H=_p(h.out), ldh=h.out.stride(0), dact=_p(h.dact),
+                               drop_p=h.drop_p, drop_seed=h.drop_seed & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(h.drop_mask),
+                               resid=_p(h.resid), ldr=h.resid.stride(0) if h.resid is not None else 0)
+    return a
+
+
+def bag_project_multi(xs, heads_per_bag, act=0, drop_tick=None, extra_rows=0):
+    """bag_project for the bags of an accumulation window in ONE launch (mhimx_bag_project_multi): xs[b] with heads_per_bag[b] (the same
+    models' ProjHeads: shared weight images / bias / drop_p, per-bag outputs and seeds)."""
+    arr = (L.BagProject * len(xs))(*[_project_args(x, hs, act, drop_tick, extra_rows) for x, hs in zip(xs, heads_per_bag)])
+    L.check(L.lib().mhimx_bag_project_multi(_stream(), arr, len(xs)), "mhimx_bag_project_multi")
+    return heads_per_bag
+
+
 def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
     """Every model's feature rows H_g = dropout_g(act(x W_g^T + b_g)) in ONE pass over the fp32 bag x [N,D] (mhimx_bag_project).
     heads: 1 or 2 ProjHead (teacher, student).  Fills head.out [N + extra_rows, E] fp32 (the extra rows are left for the caller:
@@ -506,6 +532,52 @@ def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=Fa
     if defer is not None:
         defer.keep.extend((ws_b, ws, img))
     return out_w, out_b
+
+
+class WgradImage:
+    """One bag's half of the projection's weight gradient, parked until the window's ONE product launch (bag_wgrad_multi): the dPre image
+    (mhimx_rows_dpre_image: already made, bias gradient included), the bag, its row ids."""
+
+    def __init__(self, img, x, rows, n_rows, E, keep):
+        self.img, self.x, self.rows, self.n_rows, self.E, self.keep = img, x, rows, int(n_rows), int(E), keep
+
+
+def bag_wgrad_image(dH, dact16, x, rows, n_rows, out_b=None, accumulate=False, defer=None):
+    """The first half of bag_wgrad alone: dPre = dH[rows] * dact16[rows] as the matrix-core image + the bias gradient out_b (+)= sum dPre.
+    Returns a WgradImage for bag_wgrad_multi."""
+    _chk(dH, name="dH"); _chk(dact16, torch.float16, "dact16"); _chk(rows, torch.int64, "rows")
+    E = dH.shape[1]
+    n_rows = int(n_rows)
+    dev = dH.device
+    lib = L.lib()
+    img = torch.empty(lib.mhimx_wgrad_image_bytes(n_rows, E) // 4, device=dev)
+    ws_b = torch.empty(-(-n_rows // 32) * E, device=dev)
+    if out_b is None:
+        out_b = torch.empty(E, device=dev)
+    L.check(lib.mhimx_rows_dpre_image(_stream(), _p(dH), _p(dact16), _p(rows), n_rows, E, _p(img), _p(out_b), int(bool(accumulate)), _p(ws_b),
+                                      ws_b.numel() * 4, _dp(defer)), "mhimx_rows_dpre_image")
+    if defer is not None:
+        defer.keep.append(ws_b)
+    return WgradImage(img, x, rows, n_rows, E, (ws_b, dH, dact16))
+
+
+def bag_wgrad_multi(images, out_w, accumulate=False, defer=None):
+    """out_w [E, D] (+)= sum over the window's bags of dPre_b^T x_b[rows_b]: ONE launch (mhimx_bag_wgrad_multi); images: WgradImage list."""
+    _chk(out_w, name="out_w")
+    a0 = images[0]
+    D = a0.x.shape[1]
+    lib = L.lib()
+    nb = len(images)
+    ws = torch.empty(lib.mhimx_wgrad_multi_ws_floats(a0.n_rows, a0.E, D, nb) if nb > 1 else lib.mhimx_wgrad_ws_floats(a0.n_rows, a0.E, D),
+                     device=out_w.device)
+    arr = (L.BagWgrad * nb)()
+    for b, im in enumerate(images):
+        arr[b] = L.BagWgrad(img=_p(im.img), X=_p(im.x), ldx=im.x.stride(0), n_bag_rows=im.x.shape[0], rows=_p(im.rows), L=im.n_rows, E=im.E, D=D,
+                            C=_p(out_w), ldc=out_w.stride(0), accumulate=int(bool(accumulate)), ws=_p(ws), ws_floats=ws.numel(), defer=_dp(defer))
+    L.check(lib.mhimx_bag_wgrad_multi(_stream(), arr, nb), "mhimx_bag_wgrad_multi")
+    if defer is not None:
+        defer.keep.extend([ws] + [im.img for im in images])
+    return out_w
 
 
 def shard_flags(rows_all, R, Lk, lo, n, k_tokens, tokens_live, out=None):

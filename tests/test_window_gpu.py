@@ -86,8 +86,19 @@ def _window_vs_oracle(tr, s, t, bags, labels, stu, tea, opt, ocfg, step, n, k, n
     return stu2, tea2, opt2, info
 
 
+@pytest.fixture(params=["per-bag GEMM launches", "one launch per GEMM"])
+def window_gemms(request):
+    """The window's projections / weight-gradient products per bag (default) or as ONE launch each (mhimx_bag_project_multi /
+    mhimx_bag_wgrad_multi; opt-in: MHIMX_WINDOW_PROJECT / MHIMX_WINDOW_WGRAD)."""
+    from mhim_mil_amd import engine as EN
+    old = EN._WINDOW_PROJECT, EN._WINDOW_WGRAD
+    EN._WINDOW_PROJECT = EN._WINDOW_WGRAD = request.param == "one launch per GEMM"
+    yield request.param
+    EN._WINDOW_PROJECT, EN._WINDOW_WGRAD = old
+
+
 @pytest.mark.parametrize("n_streams", [1, 3])
-def test_window_step_vs_oracle(n_streams):
+def test_window_step_vs_oracle(n_streams, window_gemms):
     from mhim_mil_amd.engine import FusedTrainer
     n, d, acc = 2100, 256, 4
     base = synth.mhim_state(7, input_dim=d, merge_k=5)
@@ -141,6 +152,38 @@ def test_window_streams_do_not_change_the_result():
     g0, g1 = res[0][2].numpy(), res[1][2].numpy()
     np.testing.assert_allclose(g0, g1, atol=2e-6 * np.abs(g0).max(), rtol=1e-4)
     assert torch.equal(res[0][3], res[1][3])
+
+
+def test_projection_and_weight_gradient_of_several_bags_in_one_launch():
+    """ops.bag_project_multi / ops.bag_wgrad_multi against per-bag ops.bag_project / ops.bag_wgrad with the same seeds: bit-identical
+    feature rows and d out / d pre (same tiles, same hash stream per bag), the summed weight gradient up to the slab-sum order."""
+    from mhim_mil_amd import ops
+    n, d, E, nb = 1300, 256, 512, 3
+    g = torch.Generator(device=DEV).manual_seed(11)
+    xs = [torch.randn(n, d, device=DEV, generator=g).abs_() for _ in range(nb)]
+    wt, ws_ = (torch.randn(E, d, device=DEV, generator=g) * 0.05 for _ in range(2))
+    bt, bs = (torch.randn(E, device=DEV, generator=g) * 0.1 for _ in range(2))
+    wtp, wsp = ops.pair_planes(wt), ops.pair_planes(ws_)
+    tick = torch.tensor([3], dtype=torch.int64, device=DEV)
+    mk = lambda b: [ops.ProjHead(wtp, bt, drop_p=0.25, drop_seed=100 + 2 * b), ops.ProjHead(wsp, bs, drop_p=0.25, drop_seed=101 + 2 * b, want_dact=True)]
+    one = [ops.bag_project(x, mk(b), act=2, drop_tick=tick) for b, x in enumerate(xs)]
+    many = ops.bag_project_multi(xs, [mk(b) for b in range(nb)], act=2, drop_tick=tick)
+    for a, m in zip(one, many):
+        assert torch.equal(a[0].out, m[0].out) and torch.equal(a[1].out, m[1].out) and torch.equal(a[1].dact, m[1].dact)
+    assert not torch.equal(many[0][1].out != 0, many[1][1].out != 0)          # every bag its own mask
+    rows = [torch.randperm(n, device=DEV, generator=g)[:1100].contiguous() for _ in range(nb)]
+    dHs = [torch.randn(n, E, device=DEV, generator=g) * 0.01 for _ in range(nb)]
+    w0, b0 = torch.empty(E, d, device=DEV), torch.empty(E, device=DEV)
+    for b in range(nb):
+        ops.bag_wgrad(dHs[b], many[b][1].dact, xs[b], rows[b], 1100, out_w=w0, out_b=b0, accumulate=b > 0)
+    w1, b1 = torch.empty(E, d, device=DEV), torch.empty(E, device=DEV)
+    ims = [ops.bag_wgrad_image(dHs[b], many[b][1].dact, xs[b], rows[b], 1100, out_b=b1, accumulate=b > 0) for b in range(nb)]
+    ops.bag_wgrad_multi(ims, w1)
+    torch.cuda.synchronize()
+    assert torch.equal(b0, b1)
+    ref = sum((dHs[b][rows[b]].double() * many[b][1].dact[rows[b]].double()).t() @ xs[b][rows[b]].double() for b in range(nb))
+    rel = lambda a: float((a.double() - ref).abs().max() / ref.abs().max())
+    assert rel(w0) < 2e-5 and rel(w1) < 2e-5
 
 
 def test_captured_window_replays_vs_oracle():
