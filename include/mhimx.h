@@ -429,6 +429,11 @@ int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int
 
 /* out[i] = a[b[i]]  (index composition: ids_keep[ids_shuffle]) */
 int mhimx_compose_ids(void* stream, const int64_t* a, const int64_t* b, int64_t* out, int64_t n);
+/* out[j] = pi(j) (src NULL) or src[pi(j)], pi = a keyed pseudo-random permutation of 0 .. n-1 (6-round Feistel network on 2^b >= n,
+ * cycle-walked; key = seed + *tick): the draws the reference takes from torch.randperm - the random subset of the top-k
+ * (masking.py:67) and Merge's random split of the kept rows (merge.py:165-170) - as one element-wise launch, reproducible from (seed, tick)
+ * alone (every rank of a sharded bag computes the same list).  Every element lands in a prefix of length m with probability m / n. */
+int mhimx_random_perm(void* stream, int64_t n, uint64_t seed, const uint64_t* tick, const int64_t* src, int64_t* out);
 
 /* ------------------------------------------------------------------------------------------
  * Merge / MCA                                                   

@@ -181,6 +181,7 @@ SYMBOLS = {
     "mhimx_select_rows": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _U64, _P, _I64, _P, _P, _P, _I64, _I32]),
     "mhimx_vote_scores": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64]),
     "mhimx_compose_ids": (C.c_int, [_P, _P, _P, _P, _I64]),
+    "mhimx_random_perm": (C.c_int, [_P, _I64, _U64, _P, _P, _P]),
     "mhimx_merge_ws_bytes": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "mhimx_merge_fwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I32, _P, _I64]),
     "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),

@@ -671,7 +671,7 @@ class MHIM(nn.Module):
         return grads
 
     # ------------------------------------------------------------------ masking (mhim.py:109-179)
-    def get_mask(self, ps, i, attn, mrh=None, perm=None, perms=None, generator=None):
+    def get_mask(self, ps, i, attn, mrh=None, perm=None, perms=None, generator=None, seed=None):
         """Device-side get_mask.  Returns (len_keep:int, mask_ids [1,ps] int64).  ``perm``/``perms`` inject the
         randperm draws of masking.py:67 (parity tests); otherwise they are drawn on the device."""
         if attn is None:
@@ -687,6 +687,7 @@ class MHIM(nn.Module):
         dev = attn.device
         perms = list(perms) if perms is not None else [None, None, perm]
         masked, n_masked, len_keep, mask_ids = None, 0, ps, None
+        n_draws = [0]
 
         def run(largest, ratio, rratio, pm):
             nonlocal masked, n_masked, len_keep, mask_ids
@@ -696,7 +697,11 @@ class MHIM(nn.Module):
             k = int(np.ceil(ps * eff))
             n_sel = int(np.ceil(k * rratio)) if rratio < 1.0 else k
             if rratio < 1.0 and pm is None:
-                pm = torch.randperm(k, device=dev, generator=generator)
+                if generator is not None:
+                    pm = torch.randperm(k, device=dev, generator=generator)
+                else:                         # masking.py:67's torch.randperm as ONE element-wise launch, reproducible from (seed, tick)
+                    n_draws[0] += 1
+                    pm = ops.random_perm(k, (self._next_seed() if seed is None else seed) + 0x51ED270B * n_draws[0], tick=self._tick, device=dev)
             elif pm is not None and not torch.is_tensor(pm):
                 pm = torch.as_tensor(np.asarray(pm), dtype=torch.int64, device=dev)
             sc, lg = score, largest
@@ -782,7 +787,9 @@ class MHIM(nn.Module):
                 rows = ops.select_rows(attn.reshape(-1).contiguous().float(), k, n_sel, R, self._next_seed() if seed is None else seed, tick=self._tick,
                                        merge_first=merge_first, out=None if rows_out is None else rows_out[:len_keep])
                 return rows, len_keep, Lk, R
-        len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm, generator=generator)
+        if generator is None and seed is None and (perm is None or ids_shuffle is None):
+            seed = self._next_seed()                           # one seed for this bag's device draws
+        len_keep, mask_ids = self.get_mask(ps, i, attn, mrh=mrh, perm=perm, generator=generator, seed=seed)
         if mask_ids is None:
             raise AssertionError("MHIM.forward needs a mask (mask_ratio_h > 0 or a v1 ratio), as the reference does "
                                  "(masking.py:104)")
@@ -791,11 +798,15 @@ class MHIM(nn.Module):
         if R == 0:
             raise L.MhimxError("merge_ratio leaves no rows to merge (int(L*merge_ratio) == L)")
         dev = mask_ids.device
-        if ids_shuffle is None:
-            ids_shuffle = torch.randperm(len_keep, device=dev, generator=generator)   # == argsort(rand(L)) in distribution
-        elif not torch.is_tensor(ids_shuffle):
-            ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=dev)
-        rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
+        if ids_shuffle is None and generator is None:
+            # merge.py:165-170's shuffle of the kept rows: rows = ids_keep[pi], pi a keyed pseudo-random permutation - one launch, no sort
+            rows = ops.random_perm(len_keep, seed ^ 0x3C6EF372FE94F82B, tick=self._tick, src=mask_ids.view(-1)[:len_keep].contiguous())
+        else:
+            if ids_shuffle is None:
+                ids_shuffle = torch.randperm(len_keep, device=dev, generator=generator)   # == argsort(rand(L)) in distribution
+            elif not torch.is_tensor(ids_shuffle):
+                ids_shuffle = torch.as_tensor(np.asarray(ids_shuffle), dtype=torch.int64, device=dev)
+            rows = ops.compose_ids(mask_ids.view(-1), ids_shuffle.contiguous())
         if merge_first:
             rows = torch.cat([rows[Lk:], rows[:Lk]])
         if rows_out is not None:

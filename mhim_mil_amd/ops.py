@@ -381,6 +381,17 @@ def vote_scores(attn, k, largest=True):
     return vote
 
 
+def random_perm(n, seed, tick=None, src=None, out=None, device=None):
+    """A keyed pseudo-random permutation of 0..n-1 (or src permuted by it) as ONE element-wise launch (mhimx_random_perm): what the
+    reference draws with torch.randperm."""
+    _chk(src, torch.int64, "src"); _chk(out, torch.int64, "out")
+    dev = device if device is not None else (src.device if src is not None else (out.device if out is not None else torch.device("cuda")))
+    if out is None:
+        out = torch.empty(int(n), dtype=torch.int64, device=dev)
+    L.check(L.lib().mhimx_random_perm(_stream(), int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(tick), _p(src), _p(out)), "mhimx_random_perm")
+    return out
+
+
 def compose_ids(a, b):
     _chk(a, torch.int64, "a"); _chk(b, torch.int64, "b")
     out = torch.empty_like(b)

@@ -224,14 +224,10 @@ class ShardedBagTrainer:
                     o += c
 
             # ---- select: replicated, identical on every rank -> [rows to merge (R) | rows that stay (Lk)]
-            # (draws: injected, or - up to 16 384 instances - made inside the select kernel from the model's seed counter and the device
-            # tick, the same on every rank; larger bags draw from the shared-seed generator)
-            injected = perm is not None and ids_shuffle is not None
-            # generator=None only when no host-side draw can happen: injected draws, or the in-kernel draw that MHIM.student_rows takes for
-            # the v2 recipe with N <= 16384 and k <= 4096 (seeded by shared_seed).  Everything else draws from the SHARED-seed generator:
-            # the process-default generator would give every rank its own "replicated" row list.
+            # (draws: injected, or made on the device from the SHARED seed and the device tick - inside the select kernel up to 16 384
+            # instances, as keyed permutations (mhimx_random_perm) beyond: every rank computes the same lists, no generator, no sort)
             rows, len_keep, Lk, R = s.student_rows(N, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, merge_first=True,
-                                                   generator=None if (injected or s.device_draw_ok(N, i)) else self.gen, seed=shared_seed)
+                                                   generator=None, seed=shared_seed)
             plan = BagPlan(rows=None, L=n, Lk=Lk, R=R, drop_seed=local_seed, mca_seed=shared_seed, training=True)
             excl = ops.shard_flags(rows, R, Lk, lo, n, k, cm.rank == 0)
 
@@ -371,8 +367,8 @@ class ShardedBagTrainer:
             del Ht, st_t
 
         # ---- select: replicated, identical on every rank (shared generator / injected draws)
-        rows, len_keep, Lk, R = s.student_rows(N, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle,
-                                               generator=None if (perm is not None and ids_shuffle is not None) else self.gen)
+        rows, len_keep, Lk, R = s.student_rows(N, i, score.view(1, -1), perm=perm, ids_shuffle=ids_shuffle, generator=None,
+                                               seed=shared_seed)
         rows_local, n_stay, merge_pos = partition_rows(rows, Lk, lo, n)
         n_loc = rows_local.numel()
         n_merge = n_loc - n_stay

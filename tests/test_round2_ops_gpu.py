@@ -135,3 +135,37 @@ def test_weight_gradient_pair_with_compact_dh_and_optional_dact(L_):
     xs = torch.randn(L_, 512, device=DEV, generator=g)
     dW3, b3 = ops.bag_wgrad(y, None, xs, None, L_)
     assert _rel(dW3, y.double().t() @ xs.double()) < 2e-5 and _rel(b3, y.double().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 6000, 197000])
+def test_random_perm_is_a_permutation_and_depends_on_the_key(n):
+    """mhimx_random_perm (what masking.py:67 and merge.py:165-170 draw with torch.randperm): a permutation of 0..n-1 for every key, another
+    one for another seed or tick, the same one for the same key; with a source list, the list permuted."""
+    tick = torch.tensor([4], dtype=torch.int64, device=DEV)
+    p0 = ops.random_perm(n, 123, tick=tick, device=DEV)
+    assert torch.equal(torch.sort(p0).values, torch.arange(n, device=DEV))
+    assert torch.equal(ops.random_perm(n, 123, tick=tick, device=DEV), p0)
+    if n > 7:
+        assert not torch.equal(ops.random_perm(n, 124, tick=tick, device=DEV), p0)
+        assert not torch.equal(ops.random_perm(n, 123, tick=tick + 1, device=DEV), p0)
+        assert not torch.equal(p0, torch.arange(n, device=DEV))
+    src = torch.arange(n, device=DEV) * 3 + 1
+    assert torch.equal(ops.random_perm(n, 123, tick=tick, src=src), src[p0])
+
+
+def test_random_perm_prefix_is_a_fair_subset():
+    """Every element lands in a prefix of length m with probability m / n (the subsets the path takes are prefixes): 4000 keys, n = 600,
+    m = 300 - the inclusion counts of all elements within 5 sigma of binomial, neighbours not travelling together."""
+    n, m, trials = 600, 300, 4000
+    counts = torch.zeros(n, device=DEV)
+    together = 0
+    for sd in range(trials):
+        p = ops.random_perm(n, 9000 + sd, device=DEV)[:m]
+        counts[p] += 1
+        inc = torch.zeros(n, dtype=torch.bool, device=DEV)
+        inc[p] = True
+        together += int((inc[:-1] & inc[1:]).sum())
+    sigma = math.sqrt(trials * 0.25)
+    assert float((counts - trials * m / n).abs().max()) < 5 * sigma
+    exp_pairs = trials * (n - 1) * (m / n) * ((m - 1) / (n - 1))                 # sampling without replacement
+    assert abs(together - exp_pairs) < 5 * math.sqrt(exp_pairs)
