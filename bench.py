@@ -397,19 +397,25 @@ def main():
         else:
             trainer.train_step(bags[i % N_BAGS], labels[i % N_BAGS])
 
-    dt = timed(a, world, dev, step)
-    if graphs is None:
-        ev[:] = ev[-a.steps:]                   # eager: keep the events of the timed steps only
     events_from = "the timed region"
+    ev_eager = None
     if graphs is not None and not a.no_kernel_events:
         # Host-side HIP event records cannot be placed between the nodes of a replayed hipGraph (ROCm rejects external
-        # event nodes), so the dominant kernel is bracketed in an eager pass of the SAME steps right after the timed
-        # region; profiles/ holds the rocprofv3 trace of the graph replays themselves for cross-checking.
+        # event nodes), so the dominant kernel is bracketed in an eager pass of the SAME steps right BEFORE the warm-up and the
+        # timed region (it used to run after them; before, its ~8 ms of launches also settle the clocks that a 5 + 20-step run
+        # would otherwise still be ramping through); profiles/ holds the rocprofv3 trace of the graph replays themselves.
         ev.clear()
         for i in range(min(a.steps, 20)):
             trainer.train_step(bags[i % N_BAGS], labels[i % N_BAGS])
         torch.cuda.synchronize()
-        events_from = f"an eager pass of {min(a.steps, 20)} steps right after the timed region (graph nodes cannot carry host events)"
+        ev_eager = list(ev)
+        events_from = f"an eager pass of {min(a.steps, 20)} steps right before the warm-up steps (graph nodes cannot carry host events)"
+        ops.KERNEL_EVENT_HOOK = None
+    dt = timed(a, world, dev, step)
+    if graphs is None:
+        ev[:] = ev[-a.steps:]                   # eager: keep the events of the timed steps only
+    elif ev_eager is not None:
+        ev[:] = ev_eager
     ops.KERNEL_EVENT_HOOK = None
 
     extras = {}
