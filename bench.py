@@ -355,14 +355,20 @@ def main():
 
     # per-kernel HIP events on the launch stream for the dominant kernel (the N x D -> E feature projection)
     ev = []
+    spin = [False]                             # (only in the dedicated eager pass: never under capture, never in a timed region)
+    hook = None
     if not a.no_kernel_events:
         def hook(tag, M, N, K):
             if tag == "bag_project" and M >= N_INST and K == D_IN:                # the teacher + student projection launch
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev.append((e0, e1))
+                # eager launches are host-bound (~20 us of Python per launch): with an idle stream the first event is processed long
+                # before the kernel's packet arrives and the interval contains that host gap (it read 69 us for a kernel the trace times
+                # at 60).  ~100 us of spin queued first keeps event, kernel, event back to back in the queue.
+                if spin[0]:
+                    torch.cuda._sleep(200000)
                 return e0, e1
             return None
-        ops.KERNEL_EVENT_HOOK = hook
 
     graphs, graph_note = None, None
     # N > 1 defaults to graph(fwd+bwd) | eager RCCL all-reduce | graph(Adam+EMA): no measurement on more than one GPU exists yet that
@@ -405,12 +411,16 @@ def main():
         # timed region (it used to run after them; before, its ~8 ms of launches also settle the clocks that a 5 + 20-step run
         # would otherwise still be ramping through); profiles/ holds the rocprofv3 trace of the graph replays themselves.
         ev.clear()
+        ops.KERNEL_EVENT_HOOK, spin[0] = hook, True
         for i in range(min(a.steps, 20)):
             trainer.train_step(bags[i % N_BAGS], labels[i % N_BAGS])
         torch.cuda.synchronize()
+        ops.KERNEL_EVENT_HOOK, spin[0] = None, False
         ev_eager = list(ev)
         events_from = f"an eager pass of {min(a.steps, 20)} steps right before the warm-up steps (graph nodes cannot carry host events)"
         ops.KERNEL_EVENT_HOOK = None
+    if graphs is None:
+        ops.KERNEL_EVENT_HOOK = hook            # eager steps: the events of the timed steps themselves
     dt = timed(a, world, dev, step)
     if graphs is None:
         ev[:] = ev[-a.steps:]                   # eager: keep the events of the timed steps only
