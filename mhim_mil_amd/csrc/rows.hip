@@ -1307,8 +1307,8 @@ __global__ __launch_bounds__(256) void random_perm_kernel(int64_t n, int bits, u
   }
 }
 extern "C" int mhimx_random_perm(void* stream, int64_t n, uint64_t seed, const uint64_t* tick, const int64_t* src, int64_t* out) {
-  MHIMX_CHECK_ARG(out && n >= 0 && n < ((int64_t)1 << 40) && out != src, "random_perm: n < 2^40, out != src");
   if (n == 0) return 0;
+  MHIMX_CHECK_ARG(out && n > 0 && n < ((int64_t)1 << 40) && out != src, "random_perm: 0 <= n < 2^40, out != src");
   int bits = 2;
   while (((int64_t)1 << bits) < n) bits += 2;
   hipLaunchKernelGGL(random_perm_kernel, dim3((unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0, (hipStream_t)stream, n, bits,

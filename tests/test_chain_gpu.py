@@ -150,3 +150,14 @@ def test_chains_competing_for_the_cus_complete_and_agree():
             assert int(c[:513].abs().sum()) == 0
     finally:
         NY._CHAIN = old
+
+
+def test_one_stage_chain_and_empty_permutation():
+    """Edge cases: a chain of ONE stage (nothing to wait for), and mhimx_random_perm of zero elements."""
+    from mhim_mil_amd import ops
+    a, = _mats(1, 5)
+    aN, aT = torch.empty_like(a), torch.empty_like(a)
+    NY._run_chain([NY._step(1, A=a, PN=aN, PT=aT, alpha=2.0)], 1, torch.device(DEV))
+    assert _rel(_image(aN), 2 * a) < 2e-5 and _rel(_image(aT), 2 * a.transpose(1, 2)) < 2e-5
+    assert int(NY._chain_counters(torch.device(DEV))[:513].abs().sum()) == 0
+    assert ops.random_perm(0, 1, device=torch.device(DEV)).numel() == 0

@@ -266,3 +266,29 @@ def test_clip_grad_and_lr_schedule_on_the_device():
                 o, nn_ = tr.flat.offsets[name], opt[name][0].numel()
                 tr.flat.m[o:o + nn_].copy_(opt[name][0].reshape(-1).to(DEV))
                 tr.flat.v[o:o + nn_].copy_(opt[name][1].reshape(-1).to(DEV))
+
+
+def test_several_bags_entries_reject_mixed_shapes_and_take_one_bag():
+    """mhimx_bag_wgrad_multi with ONE bag is mhimx_bag_wgrad; bags of different L (or E, D, ldx) are refused, so are more than 8 bags;
+    mhimx_bag_project_multi refuses bags that do not share the weight image."""
+    from mhim_mil_amd import ops, _lib as L
+    import ctypes as C
+    n, d, E = 700, 256, 512
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(n, d, device=DEV, generator=g).abs_()
+    dH = torch.randn(n, E, device=DEV, generator=g) * 0.01
+    dact = (torch.rand(n, E, device=DEV, generator=g) * 1.2).half()
+    rows = torch.randperm(n, device=DEV, generator=g)[:600].contiguous()
+    w0, _ = ops.bag_wgrad(dH, dact, x, rows, 600)
+    im = ops.bag_wgrad_image(dH, dact, x, rows, 600)
+    w1 = ops.bag_wgrad_multi([im], torch.empty(E, d, device=DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(w0, w1)
+    im2 = ops.bag_wgrad_image(dH, dact, x, rows[:500].contiguous(), 500)
+    with pytest.raises(L.MhimxError):
+        ops.bag_wgrad_multi([im, im2], torch.empty(E, d, device=DEV))
+    with pytest.raises(L.MhimxError):
+        ops.bag_wgrad_multi([im] * 9, torch.empty(E, d, device=DEV))
+    wa, wb = (ops.pair_planes(torch.randn(E, d, device=DEV, generator=g) * 0.05) for _ in range(2))
+    with pytest.raises(L.MhimxError):
+        ops.bag_project_multi([x, x], [[ops.ProjHead(wa)], [ops.ProjHead(wb)]], act=0)
