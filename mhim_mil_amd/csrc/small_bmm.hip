@@ -215,8 +215,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0,
 //   * both operand panels ([64 rows][256 k] x 2 planes) go global -> LDS by DMA (no registers, no LDS stores), rows XOR-swizzled by the
 //     per-lane GLOBAL address (LDS stays lane-linear: chunk c of row r sits at chunk c ^ (r & 31)), so the fragment reads are b128 and
 //     conflict-free with an unpadded 512-byte pitch;
-//   * 16 waves: wave w owns the 32 x 32 block (w >> 1 & 1, w & 1) over the k quarter w >> 2 - 12 MFMAs, no VALU between - and the quarters
-//     meet through LDS in a fixed order;
+//   * 16 waves: wave w owns the 16 x 16 block (w >> 2, w & 3) of the tile over the WHOLE k - 24 MFMAs (16x16x32), no VALU between, no
+//     partial sums (k quarters of 32 x 32 blocks meeting through LDS read half the fragments but paid 2 300 cycles for the meeting:
+//     168 -> 162 us per forward chain);
 //   * 128 persistent workgroups (one 64 x 64 tile of one of the 8 heads each) walk the chain; only the 16 workgroups of a head depend on
 //     each other, so the hand-off is a per-head arrival counter, not a grid barrier:
 //       producer: everything leaves as 16-byte WRITE-THROUGH stores (sc0 sc1), s_waitcnt vmcnt(0), workgroup barrier, one relaxed
@@ -230,8 +231,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0,
 //   * plain stores (acknowledged by the XCD's L2) instead of write-through ones when the head's workgroups verify at run time (HW_REG_XCC_ID
 //     table) that they share an XCD: 166 / 424 us, bit-identical over 300 repetitions under load - the store acknowledge is not the bound;
 //   * an arrival atomic without return value (no round trip for lane 0), s_sleep 0 / 4 in the poll: +-1 %.
-// One stage, stamped (shader clocks, forward): poll 900, panels by DMA 3700 (128 KiB per workgroup at the ~85 GB/s a block reads written-through
-// lines at), products 1900 (LDS-read bound: 256 KiB of fragments), quarters -> tiles 2300, stores + acknowledge 2400, arrival 1300.
+// One stage of the k-quarter form, stamped (shader clocks, forward): poll 900, panels by DMA 3700 (128 KiB per workgroup at the ~85 GB/s a
+// block reads written-through lines at), products 1900 (LDS-read bound: 256 KiB of fragments), quarters -> tiles 2300, stores + acknowledge
+// 2400, arrival 1300.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int CH_MAX = 42, CH_THREADS = 1024, CH_SPIN_MAX = 1 << 22;
 struct ChainStep {
@@ -247,14 +249,12 @@ constexpr int CH_PLANE = SBF_KMAX * SBF_KMAX * 2;               // bytes of one 
 constexpr int CH_PANEL = SB_T * SBF_KMAX * 2;                   // bytes of one plane of one 64-row panel in LDS (32 KiB)
 
 __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
-  extern __shared__ __attribute__((aligned(16))) char chs[];   // [A hi | A lo | B hi | B lo] panels; after the products: partials + tiles
-  float* P = reinterpret_cast<float*>(chs);                     // k-quarter partials [4][4 blocks][16][64 lanes]   (64 KiB)
+  extern __shared__ __attribute__((aligned(16))) char chs[];   // [A hi | A lo | B hi | B lo] panels; after the products: the output tiles
   float* T1 = reinterpret_cast<float*>(chs + 2 * CH_PANEL);     // output tiles [64][68] fp32
   float* T2 = T1 + SB_T * 68;
   float* TT = T2 + SB_T * 68;                                   // transposes of the first / second output
   float* TT2 = TT + SB_T * 68;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kq = wave >> 2, wmn = wave & 3, wm = wmn >> 1, wn = wmn & 1;
   // Which tile a workgroup computes is NOT its block index: the workgroups of head b % 8 draw TICKETS (stage-major: ticket t = stage *
   // per_stage + group * 16 + tile) from the head's ticket counter.  A ticket waits only for tickets below it, and every ticket below it
   // is held by a workgroup that has started - so the chain completes with ANY number of resident workgroups (other kernels or processes
@@ -304,8 +304,6 @@ __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
     __syncthreads();
     if (dead) return;
     CH_STAMP(1);
-    sb_f16 acc;
-    const int r = lane & 31, kh = lane >> 5;
     if (st.kind < 0) {                                          // nothing to do for this group at this stage: only arrive
     } else if (st.kind == 0) {
       // 128 DMA instructions of 1 KiB (two 512-byte rows of one plane) per workgroup, 8 per wave
@@ -318,57 +316,48 @@ __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
         const char* src = (opnd ? gb : ga) + plane * CH_PLANE + row * 512 + chunk * 16;
         __builtin_amdgcn_global_load_lds((ch_gptr)src, (ch_lptr)(chs + (opnd * 2 + plane) * CH_PANEL + rp * 1024), 16, 0, POL);
       }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      if (st.D && !kq) {                                        // the addend enters as the accumulator's start value, D / alpha (exact for the
-        const float ia = 1.f / st.alpha;                        // chain's alphas, +-1 and +-0.25): its loads fly with the DMA, no registers
+      // every wave one 16 x 16 block over the WHOLE k: no partial sums, no reduce (twice the fragment reads: 512 KiB per tile)
+      const int bm = wave >> 2, bn = wave & 3, c16 = lane & 15, q4 = lane >> 4;
+      sb_f4 a4 = sb_f4{0.f, 0.f, 0.f, 0.f};
+      if (st.D) {
+        const float ia = 1.f / st.alpha;
         __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(st.D + hoff), 0, MAT_BYTES, 0x00027000);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int ml = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh, nl = wn * 32 + r;
-          acc[e] = ia * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (unsigned)(((m0 + ml) * SBF_KMAX + n0 + nl) * 4), 0, POL));
-        }
+        for (int i = 0; i < 4; ++i)
+          a4[i] = ia * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                           rD, (unsigned)(((m0 + 16 * bm + 4 * q4 + i) * SBF_KMAX + n0 + 16 * bn + c16) * 4), 0, POL));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my rows have landed in LDS
       CH_STAMP(2);
       __syncthreads();
       CH_STAMP(3);
-      const int ra = wm * 32 + r, rb = wn * 32 + r;
-      const char* pa = chs + ra * 512;
-      const char* pb = chs + 2 * CH_PANEL + rb * 512;
+      {
+        const int ra = 16 * bm + c16, rb = 16 * bn + c16;
+        const char* pa = chs + ra * 512;
+        const char* pb = chs + 2 * CH_PANEL + rb * 512;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int chunk = (kq * 4 + ks) * 2 + kh;
-        const int oa = ((chunk ^ (ra & 31)) * 16), ob = ((chunk ^ (rb & 31)) * 16);
-        const sb_b8 ah = *reinterpret_cast<const sb_b8*>(pa + oa), al = *reinterpret_cast<const sb_b8*>(pa + CH_PANEL + oa);
-        const sb_b8 bh = *reinterpret_cast<const sb_b8*>(pb + ob), bl = *reinterpret_cast<const sb_b8*>(pb + CH_PANEL + ob);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks) {
+          const int chunk = 4 * ks + q4;
+          const int oa = ((chunk ^ (ra & 31)) * 16), ob = ((chunk ^ (rb & 31)) * 16);
+          const sb_b8 ah = *reinterpret_cast<const sb_b8*>(pa + oa), al = *reinterpret_cast<const sb_b8*>(pa + CH_PANEL + oa);
+          const sb_b8 bh = *reinterpret_cast<const sb_b8*>(pb + ob), bl = *reinterpret_cast<const sb_b8*>(pb + CH_PANEL + ob);
+          a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a4, 0, 0, 0);
+          a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a4, 0, 0, 0);
+          a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a4, 0, 0, 0);
+        }
       }
       CH_STAMP(4);
-      __syncthreads();                                          // the panels are consumed: partials and tiles go through the same LDS
+      __syncthreads();                                          // the panels are consumed: the tiles go through the same LDS
       CH_STAMP(8);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) P[((kq * 4 + wmn) * 16 + e) * 64 + lane] = acc[e];
-      __syncthreads();
       CH_STAMP(9);
-      {                                                         // every thread sums the four quarters of 4 elements (fixed order) -> tiles
-        const int bw = tid >> 8, eg = (tid >> 6) & 3;           // block, group of four accumulator rows
-        const float* pp = P + (bw * 16 + eg * 4) * 64 + lane;
-        float sum[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float q0 = pp[j * 64], q1 = pp[4096 + j * 64], q2 = pp[8192 + j * 64], q3 = pp[12288 + j * 64];
-          sum[j] = ((q0 + q1) + q2) + q3;
-        }
-        const int ml = (bw >> 1) * 32 + 8 * eg + 4 * kh, nl = (bw & 1) * 32 + r;
+      {
+        const int ml = 16 * bm + 4 * q4, nl = 16 * bn + c16;
         sb_f4 t, t2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool diag = (m0 + ml + j) == (n0 + nl);
-          const float v1 = st.alpha * sum[j] + (diag ? st.ident : 0.f);
-          const float v2 = st.alpha2 * sum[j] + (diag ? st.ident2 : 0.f);
+          const float v1 = st.alpha * a4[j] + (diag ? st.ident : 0.f);
+          const float v2 = st.alpha2 * a4[j] + (diag ? st.ident2 : 0.f);
           T1[(ml + j) * 68 + nl] = v1;
           T2[(ml + j) * 68 + nl] = v2;
           t[j] = v1;
