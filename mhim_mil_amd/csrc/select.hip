@@ -16,7 +16,7 @@
 
 namespace mhimx {
 
-#ifdef MHIMX_SEL_PROF
+#ifdef MHIMX_SEL_PROF                                           // phase stamps of select_small_kernel: tools/exp_select.py
 __device__ unsigned long long sel_prof[32];
 #define SEL_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) sel_prof[i] = wall_clock64(); } while (0)
 #else
@@ -904,7 +904,7 @@ static size_t select_smem(int P) { return (size_t)P * 8 + (SEL_WAVES * 256 + SEL
 
 using namespace mhimx;
 
-#ifdef MHIMX_SEL_PROF
+#ifdef MHIMX_SEL_PROF                                           // phase stamps of select_small_kernel: tools/exp_select.py
 extern "C" int mhimx_sel_prof_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mhimx::sel_prof), 32 * 8);
 }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0,
 //                 with sc0 sc1 (they bypass this CU's L1 and this XCD's L2 and see what the producers wrote through) - the {sc0 sc1 stores
 //                 and loads on both sides} form of MI355X_MICROARCH.md: no L2 write-back, no L1 invalidate, placement-independent.
 // Workgroup b serves head b % 8.  The last arrival of a head's last step zeroes its counter: the counters are all-zero again when the
-// launch ends (hipGraph replays re-use them).
+// launch ends (hipGraph replays re-use them).  tools/exp_chain.py: values, time, the phase stamps of one step (-DCH_PROF=<step>), a stress run.
 // MEASURED and not kept (round 3, same box, forward / forward + backward of one layer as hipGraph replays, 166 / 426 us here):
 //   * plain stores (acknowledged by the XCD's L2) instead of write-through ones when the head's workgroups verify at run time (HW_REG_XCC_ID
 //     table) that they share an XCD: 166 / 424 us, bit-identical over 300 repetitions under load - the store acknowledge is not the bound;

@@ -207,7 +207,7 @@ def finish_tail(grad, student, n_train, scale, chain=None):
 
 # Accumulation windows: both GEMMs of the window's bags as ONE launch each (mhimx_bag_project_multi / mhimx_bag_wgrad_multi).  MEASURED
 # (round 3, 8 bags of the c2 shape, same box): the projection 8 x 61.2 -> 470 us, the weight gradient 8 x (44 + 3 of slab sum) -> 219 us -
-# and the window not at all (1.52 ms on 4 streams, 2.55 ms on one, with or without): the Merge backward's tail that rode in each bag's
+# (tools/exp_wgrad_multi.py) and the window not at all (1.52 ms on 4 streams, 2.55 ms on one, with or without): the Merge backward's tail that rode in each bag's
 # weight-gradient launch becomes a launch of its own (8 x 17.8 us), and the window on 4 streams is bound by how the graph's branches
 # overlap (average concurrency 1.7, profiles/r03_window_timeline.md), not by kernel time.  Opt-in until the tail rides elsewhere.
 _WINDOW_WGRAD = os.environ.get("MHIMX_WINDOW_WGRAD", "0") != "0"
