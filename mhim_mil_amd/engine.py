@@ -210,6 +210,7 @@ def finish_tail(grad, student, n_train, scale, chain=None):
 # (tools/exp_wgrad_multi.py) and the window not at all (1.52 ms on 4 streams, 2.55 ms on one, with or without): the Merge backward's tail that rode in each bag's
 # weight-gradient launch becomes a launch of its own (8 x 17.8 us), and the window on 4 streams is bound by how the graph's branches
 # overlap (average concurrency 1.7, profiles/r03_window_timeline.md), not by kernel time.  Opt-in until the tail rides elsewhere.
+_FOREACH_GRADS = os.environ.get("MHIMX_FOREACH_GRADS", "1") != "0"   # autograd's per-parameter gradient adds as ONE multi-tensor launch
 _WINDOW_WGRAD = os.environ.get("MHIMX_WINDOW_WGRAD", "0") != "0"
 _WINDOW_PROJECT = os.environ.get("MHIMX_WINDOW_PROJECT", "0") != "0"
 
@@ -686,7 +687,7 @@ class FusedTrainer:
         Bt = teacher_feat[0].contiguous() if (teacher_feat is not None and self.aux_alpha != 0.) else None
         losses, g_lb, g_li, g_B = DS.dsmil_head(lb.detach(), li.detach(), label, B.detach().contiguous(), Bt, float(s.temp_t),
                                                 self.main_alpha, self.aux_alpha, 1.0 / self.accum)
-        torch.autograd.backward([lb, li, B], [g_lb, g_li, g_B])
+        self._backward_into_flat([lb, li, B], [g_lb, g_li, g_B])
         logits = 0.5 * (lb.detach() + li.detach())
         self._micro += 1
         self.last = {"logits": logits, "losses": losses, "patch_num": x.shape[0], "keep_num": keep_num}
@@ -710,10 +711,35 @@ class FusedTrainer:
             z.detach(), t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),
             main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
             d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=True)
-        z.backward(g_z)
+        self._backward_into_flat([z], [g_z])
         self._micro += 1
         self.last = {"logits": logits, "losses": losses, "patch_num": x.shape[0], "keep_num": keep_num}
         return logits, losses
+
+    def _backward_into_flat(self, outs, g_outs):
+        """torch.autograd.backward(outs, g_outs) with the parameter gradients landing in the flat buffer.  With .grad bound to the buffer's views autograd
+        ADDS every parameter's gradient in a launch of its own (~30 launches of ~5 us, most of them for a few hundred floats, strung
+        along the backward's chain); here .grad is empty during the backward - autograd just keeps the tensors our backward functions
+        return - and ONE multi-tensor add moves them all into the buffer (which is zero after every update)."""
+        if not _FOREACH_GRADS:
+            torch.autograd.backward(outs, g_outs)
+            return
+        fl = self.flat
+        pd = getattr(self, "_train_params", None)
+        if pd is None:
+            named = dict(self.s.named_parameters())
+            pd = self._train_params = [(named[n], fl.grad_views[n]) for n in fl.train_names]
+        for p, _ in pd:
+            p.grad = None
+        torch.autograd.backward(outs, g_outs)
+        views, grads = [], []
+        for p, v in pd:
+            if p.grad is not None:
+                views.append(v)
+                grads.append(p.grad.reshape(v.shape))
+            p.grad = v
+        if grads:
+            torch._foreach_add_(views, grads)
 
     def _mid_hook(self):
         """Data parallel, eager steps: everything but the projection's gradient (the head of the flat buffer) is final - start its
