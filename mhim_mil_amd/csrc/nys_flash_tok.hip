@@ -119,6 +119,24 @@ MHIMX_DEV void ny_chunk(const NyArgs& g, int ch, int& t_begin, int& t_end) {
   t_end = (int)(tiles * (ch + 1) / g.nch);
 }
 
+// ---- cross-wave sums of a [64 d][32 token] output: wave w's partial at part[w][token][NY_P68] (an accumulator's four values are
+// four consecutive d of one token: one 16-byte store; the reader takes 16 bytes per wave).  Conflict-free both ways: a store phase
+// is 8 lanes = 8 consecutive tokens (68 floats apart: 4 banks), a load phase 8 lanes = the 8 d-octets of one token.  The scalar
+// [w][d][36] form (64 + 64 four-byte LDS operations per thread and matrix, the reads four-way conflicted) was 18 % of these kernels.
+constexpr int NY_P68 = 68;
+constexpr int NY_PART_F = 4 * 32 * NY_P68;                    // floats of one matrix's partials
+MHIMX_DEV void ny_part_put(float* part, int w, int c, int kg, const f32x4 (&o)[4][2]) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) *reinterpret_cast<f32x4*>(part + (w * 32 + 16 * tb + c) * NY_P68 + 16 * db + 4 * kg) = o[db][tb];
+}
+MHIMX_DEV f32x4 ny_part_sum(const float* part, int tk, int d) {
+  const float* p = part + tk * NY_P68 + d;
+  return ((*reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + 32 * NY_P68)) + *reinterpret_cast<const f32x4*>(p + 64 * NY_P68)) +
+         *reinterpret_cast<const f32x4*>(p + 96 * NY_P68);
+}
+
 #define NYT_ZERO(a, n1, n2)                \
   _Pragma("unroll") for (int _i = 0; _i < n1; ++_i) _Pragma("unroll") for (int _j = 0; _j < n2; ++_j) a[_i][_j] = f32x4{0.f, 0.f, 0.f, 0.f}
 
@@ -126,7 +144,6 @@ MHIMX_DEV void ny_chunk(const NyArgs& g, int ch, int& t_begin, int& t_end) {
 // forward 2: out = softmax_m(q k~^T) w2.   token-column: S^T[lb][tb] = LM(k~) x RM(q); softmax over all 256 landmarks = over the
 // lane's rows, its k-octet lanes and the four waves (LDS); o^T[db][tb] = LT(w2) x P^T, summed over the waves through LDS.
 // ===========================================================================================================================
-constexpr int NY_P68 = 68, NY_P36 = 36;
 __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_kernel(NyArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   float* red = reinterpret_cast<float*>(sm + NY_IMG);          // [2][4][64]
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_kernel(NyArgs g) {
 __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_q_kernel(NyArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   float* red = reinterpret_cast<float*>(sm + 2 * NY_IMG);      // [4][32]
-  float* part = red + 128;                                     // [4][64 d][36]
+  float* part = red + 128;                                     // [4][32 tok][68]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
   const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
   int t_begin, t_end;
@@ -311,26 +328,13 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_q_kernel(NyArgs g) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) ny_mma_a<2>(kt.h[db][sx], kt.l[db][sx], ph, pl, o[db]);
       }
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) part[(w * 64 + 16 * db + 4 * kg + i) * NY_P36 + 16 * tb + c] = o[db][tb][i];
+      ny_part_put(part, w, c, kg, o);
       __syncthreads();
       {
         const int tk = tid >> 3, d0 = 8 * (tid & 7);
         float* op = g.out + (tok0 + tk) * g.ldo + h * NY_D + d0;
 #pragma unroll
-        for (int x4 = 0; x4 < 2; ++x4) {
-          f32x4 v;
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const int d = d0 + 4 * x4 + x;
-            v[x] = ((part[d * NY_P36 + tk] + part[(64 + d) * NY_P36 + tk]) + part[(128 + d) * NY_P36 + tk]) + part[(192 + d) * NY_P36 + tk];
-          }
-          *reinterpret_cast<f32x4*>(op + 4 * x4) = v;
-        }
+        for (int x4 = 0; x4 < 2; ++x4) *reinterpret_cast<f32x4*>(op + 4 * x4) = ny_part_sum(part, tk, d0 + 4 * x4);
       }
     }
   }
@@ -345,7 +349,7 @@ template <int MODE>
 __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_t_kernel(NyArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   float* lmst = reinterpret_cast<float*>(sm + 2 * NY_IMG);     // lse3[256] | delta3 or u [256]
-  float* part = lmst + 512;                                    // MODE 0: [2][4][64 d][36] ; MODE 1: red [4][64]
+  float* part = lmst + 512;                                    // MODE 0: [4][32 tok][68] ; MODE 1: red [4][64]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
   const int h = blockIdx.y, ch = blockIdx.x, lm0 = 64 * w;
   int t_begin, t_end;
@@ -398,8 +402,6 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_t_kernel(NyArgs g) {
     ny_lm_frags(g.da3v + (int64_t)h * NY_PART, NY_D, lm0, lane, af);
     ny_lt_frags(g.ql + h * NY_D, g.ldl, lm0, lane, qt);
     ny_lt_frags(g.da3v + (int64_t)h * NY_PART, NY_D, lm0, lane, at);
-    float* part_k = part;
-    float* part_v = part + 4 * 64 * NY_P36;
     f32x4 rk[4], rv[4];
     ny_load(kb, g.ld, (int64_t)t_begin * NY_TT, tid, rk);
     ny_load(vb, g.ld, (int64_t)t_begin * NY_TT, tid, rv);
@@ -443,71 +445,52 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_t_kernel(NyArgs g) {
               dp[lb][tb][i] = g.scale * p * (dp[lb][tb][i] - dl[i]);
             }
         }
+        f32x4 ov[4][2], ok[4][2];                               // [db][tb2]
+        NYT_ZERO(ov, 4, 2);
+        NYT_ZERO(ok, 4, 2);
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          f32x4 ph[2], pl[2];
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx][tb], s[2 * sx + 1][tb], ph[tb], pl[tb]);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) ny_mma_a<2>(at.h[db][sx], at.l[db][sx], ph, pl, ov[db]);
+        }
         __syncthreads();                                      // the previous half's partials have been read
-        {
-          f32x4 ov[4][2];                                     // [db][tb2]
-          NYT_ZERO(ov, 4, 2);
+        ny_part_put(part, w, c, kg, ov);
 #pragma unroll
-          for (int sx = 0; sx < 2; ++sx) {
-            f32x4 ph[2], pl[2];
+        for (int sx = 0; sx < 2; ++sx) {
+          f32x4 sh[2], sl[2];
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx][tb], s[2 * sx + 1][tb], ph[tb], pl[tb]);
+          for (int tb = 0; tb < 2; ++tb) ny_split44(dp[2 * sx][tb], dp[2 * sx + 1][tb], sh[tb], sl[tb]);
 #pragma unroll
-            for (int db = 0; db < 4; ++db) ny_mma_a<2>(at.h[db][sx], at.l[db][sx], ph, pl, ov[db]);
-          }
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) part_v[(w * 64 + 16 * db + 4 * kg + i) * NY_P36 + 16 * tb + c] = ov[db][tb][i];
+          for (int db = 0; db < 4; ++db) ny_mma_a<2>(qt.h[db][sx], qt.l[db][sx], sh, sl, ok[db]);
         }
-        {
-          f32x4 ok[4][2];
-          NYT_ZERO(ok, 4, 2);
-#pragma unroll
-          for (int sx = 0; sx < 2; ++sx) {
-            f32x4 sh[2], sl[2];
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) ny_split44(dp[2 * sx][tb], dp[2 * sx + 1][tb], sh[tb], sl[tb]);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) ny_mma_a<2>(qt.h[db][sx], qt.l[db][sx], sh, sl, ok[db]);
-          }
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) part_k[(w * 64 + 16 * db + 4 * kg + i) * NY_P36 + 16 * tb + c] = ok[db][tb][i];
-        }
+        const int tk = tid >> 3, d0 = 8 * (tid & 7);
+        const int64_t row = (int64_t)t * NY_TT + 32 * hf + tk;
+        float* okp = g.out + row * g.ldo + h * NY_D + d0;
+        float* ovp = g.out2 + row * g.ldo2 + h * NY_D + d0;
         __syncthreads();
-        {
-          const int tk = tid >> 3, d0 = 8 * (tid & 7);
-          const int64_t row = (int64_t)t * NY_TT + 32 * hf + tk;
-          float* okp = g.out + row * g.ldo + h * NY_D + d0;
-          float* ovp = g.out2 + row * g.ldo2 + h * NY_D + d0;
 #pragma unroll
-          for (int x4 = 0; x4 < 2; ++x4) {
-            f32x4 a, b;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const int d = d0 + 4 * x4 + x;
-              a[x] = ((part_k[d * NY_P36 + tk] + part_k[(64 + d) * NY_P36 + tk]) + part_k[(128 + d) * NY_P36 + tk]) + part_k[(192 + d) * NY_P36 + tk];
-              b[x] = ((part_v[d * NY_P36 + tk] + part_v[(64 + d) * NY_P36 + tk]) + part_v[(128 + d) * NY_P36 + tk]) + part_v[(192 + d) * NY_P36 + tk];
-            }
-            *reinterpret_cast<f32x4*>(okp + 4 * x4) = a;
-            if (g.accumulate) b += *reinterpret_cast<const f32x4*>(ovp + 4 * x4);
-            *reinterpret_cast<f32x4*>(ovp + 4 * x4) = b;
-          }
+        for (int x4 = 0; x4 < 2; ++x4) {
+          f32x4 b = ny_part_sum(part, tk, d0 + 4 * x4);
+          if (g.accumulate) b += *reinterpret_cast<const f32x4*>(ovp + 4 * x4);
+          *reinterpret_cast<f32x4*>(ovp + 4 * x4) = b;
         }
+        // dk through the SAME partials (its products were issued above, under the dv exchange)
+        __syncthreads();
+        ny_part_put(part, w, c, kg, ok);
+        __syncthreads();
+#pragma unroll
+        for (int x4 = 0; x4 < 2; ++x4) *reinterpret_cast<f32x4*>(okp + 4 * x4) = ny_part_sum(part, tk, d0 + 4 * x4);
       }
     }
   }
 }
 
 constexpr int NY_SM_OUT_FWD = NY_IMG + 512 * 4 + 4 * 64 * NY_P68 * 4;
-constexpr int NY_SM_BWD_Q = 2 * NY_IMG + 128 * 4 + 4 * 64 * NY_P36 * 4;
-constexpr int NY_SM_A3_T = 2 * NY_IMG + 512 * 4 + 2 * 4 * 64 * NY_P36 * 4;
+constexpr int NY_SM_BWD_Q = 2 * NY_IMG + 128 * 4 + NY_PART_F * 4;
+constexpr int NY_SM_A3_T = 2 * NY_IMG + 512 * 4 + NY_PART_F * 4;
 constexpr int NY_SM_CLS = 2 * NY_IMG + 512 * 4 + 256 * 4;
 
 }  // namespace nytok
@@ -519,15 +502,26 @@ int nytok_out_fwd(hipStream_t st, const NyArgs& g) {
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
-int nytok_out_bwd_q(hipStream_t st, const NyArgs& g) {
+// The two backward kernels write per-token outputs only (no per-chunk partials), so their chunking is free.  One workgroup per CU
+// (the landmark fragments fill 256 VGPRs + 155 / 205 AGPRs: one wave per SIMD): 64 chunks measured 9.48 vs 9.43 ms per c3 step.
+static NyArgs ny_tok_chunks(const NyArgs& g0) {
+  NyArgs g = g0;
+  static const int per = getenv("MHIMX_NYS_TOKCH") ? atoi(getenv("MHIMX_NYS_TOKCH")) : NY_MAXCH;
+  const int64_t tiles = g.T / NY_TT;
+  g.nch = (int)(tiles < per ? tiles : per);
+  return g;
+}
+int nytok_out_bwd_q(hipStream_t st, const NyArgs& g0) {
   using namespace nytok;
+  const NyArgs g = ny_tok_chunks(g0);
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_BWD_Q)));
   hipLaunchKernelGGL(ny_out_bwd_q_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_BWD_Q, st, g);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
-int nytok_a3v_bwd_t(hipStream_t st, const NyArgs& g, int mode) {
+int nytok_a3v_bwd_t(hipStream_t st, const NyArgs& g0, int mode) {
   using namespace nytok;
+  const NyArgs g = mode == 0 ? ny_tok_chunks(g0) : g0;
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_T));
                         MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_CLS)));
   if (mode == 0) hipLaunchKernelGGL(ny_a3v_bwd_t_kernel<0>, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_A3_T, st, g);
