@@ -488,6 +488,275 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_t_kernel(NyArgs g) {
   }
 }
 
+// ===========================================================================================================================
+// Token-owning form of the a3v token-side backward (dk, dv): NO barrier and no cross-wave sum in the loop.  The two landmark-side
+// matrices (q~ and da3v, [256, 64] of this head) sit in LDS ONCE, row-major, as bf16 hi / lo planes (128-byte rows, 16-byte chunk
+// index XOR (row & 7)): an LM fragment (landmark rows, 8 consecutive head dims per lane) is a 16-byte read of a row, an LT fragment
+// (head-dim rows, 8 landmarks per lane in accumulator-pair order) is TWO ds_read_b64_tr_b16 of the SAME planes - in a 16-lane group
+// lane 4 r + q supplies the address of (landmark r, dims 4 q .. 4 q + 3) and lane l receives dim l of landmarks 0..3 (probed:
+// tools/micro/tr_probe.hip).  Both reads are conflict-free under the XOR (b128: 16-lane groups {0-3,12-15,20-27}.. hit 16 different
+// 4-bank spans; tr: 32 lanes = 8 rows x 32 bytes, even rows banks 0-31, odd rows 32-63, chunk pair db ^ (r >> 1)).  Four fragment
+// images of the landmark-split form (256 KB) would not fit; the two planes pairs are 128 KB.
+// A wave owns 32 tokens and ALL 256 landmarks, streamed 32 at a time: S^T, dP^T [2 lb][2 tb] -> P, dS -> dv^T, dk^T [4 db][2 tb]
+// accumulate in registers.  k / v fragments come straight from global memory (8 consecutive head dims of the lane's token).
+// 281 -> 164 us at T = 50 176 (the out backward's twin below: 199 -> 103 us).  Measured and dropped: starting waves 4..7 (the second
+// wave of each SIMD) 8..48 x 64 cycles late so that the pair does not run its matrix and VALU phases in lockstep: +-1 %.
+// ===========================================================================================================================
+constexpr int NY8_THREADS = 512, NY8_NW = 8;
+constexpr int NY_PLANE = NY_M * 128;                           // one bf16 plane of a [256, 64] matrix
+constexpr int NY_SM_A3_T8 = 4 * NY_PLANE + 2 * NY_M * 4;
+typedef __bf16 ny_bf4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char* ny_lds;
+
+MHIMX_DEV void ny_plane_fill(char* hi, char* lo, const float* M, int64_t ldm, int tid) {
+#pragma unroll
+  for (int u = 0; u < NY_M * 8 / NY8_THREADS; ++u) {
+    const int unit = tid + NY8_THREADS * u, row = unit >> 3, oct = unit & 7;
+    const float* p = M + (int64_t)row * ldm + 8 * oct;
+    f32x4 h, l;
+    ny_split44(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), h, l);
+    const int off = row * 128 + ((oct ^ (row & 7)) << 4);
+    *reinterpret_cast<f32x4*>(hi + off) = h;
+    *reinterpret_cast<f32x4*>(lo + off) = l;
+  }
+}
+// LT fragment: landmarks 32 sx + {4 kg + i, 16 + 4 kg + i}, head dim 16 db + c; `a` = the lane's address for (sx 0, blk 0, this db)
+MHIMX_DEV f32x4 ny_plane_lt(ny_lds a, int sx) {
+  typedef __attribute__((address_space(3))) ny_bf4* P;
+  const ny_bf4 x = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((P)(a + sx * 4096));
+  const ny_bf4 y = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((P)(a + sx * 4096 + 2048));
+  bf8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = x[j]; r[4 + j] = y[j]; }
+  return __builtin_bit_cast(f32x4, r);
+}
+
+__global__ __launch_bounds__(NY8_THREADS) void ny_a3v_bwd_t8_kernel(NyArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* q_hi = sm;
+  char* q_lo = sm + NY_PLANE;
+  char* a_hi = sm + 2 * NY_PLANE;
+  char* a_lo = sm + 3 * NY_PLANE;
+  float* lmst = reinterpret_cast<float*>(sm + 4 * NY_PLANE);   // lse3[256] | delta3[256]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
+  const int h = blockIdx.y, ch = blockIdx.x;
+  int t_begin, t_end;
+  ny_chunk(g, ch, t_begin, t_end);
+  ny_plane_fill(q_hi, q_lo, g.ql + h * NY_D, g.ldl, tid);
+  ny_plane_fill(a_hi, a_lo, g.da3v + (int64_t)h * NY_PART, NY_D, tid);
+  if (tid < NY_M) {
+    lmst[tid] = g.lse3[h * NY_M + tid];
+    lmst[NY_M + tid] = g.delta3[h * NY_M + tid];
+  }
+  __syncthreads();
+  // per-lane offsets inside a plane
+  int lm_off[2];                                               // LM fragment (lb 0, ks)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) lm_off[ks] = c * 128 + (((4 * ks + kg) ^ (c & 7)) << 4);
+  int lt_off[4];                                               // LT fragment (sx 0, blk 0, db)
+  {
+    const int r = 4 * kg + (c >> 2), r7 = r & 7;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) lt_off[db] = r * 128 + (((2 * db + ((c & 3) >> 1)) ^ r7) << 4) + (c & 1) * 8;
+  }
+  const ny_lds lq_hi = (ny_lds)q_hi, lq_lo = (ny_lds)q_lo, la_hi = (ny_lds)a_hi, la_lo = (ny_lds)a_lo;
+  const float* kb = g.k + h * NY_D;
+  const float* vb = g.v + h * NY_D;
+  const int64_t grp_end = (int64_t)t_end * 2;
+  for (int64_t grp = (int64_t)t_begin * 2 + w; grp < grp_end; grp += NY8_NW) {
+    const int64_t tk0 = grp * 32;
+    f32x4 kh[2][2], kl[2][2], vh[2][2], vl[2][2];              // [ks][tb]
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int64_t o = (tk0 + 16 * tb + c) * g.ld + 32 * ks + 8 * kg;
+        ny_split44(*reinterpret_cast<const f32x4*>(kb + o), *reinterpret_cast<const f32x4*>(kb + o + 4), kh[ks][tb], kl[ks][tb]);
+        ny_split44(*reinterpret_cast<const f32x4*>(vb + o), *reinterpret_cast<const f32x4*>(vb + o + 4), vh[ks][tb], vl[ks][tb]);
+      }
+    f32x4 ov[4][2], ok[4][2];                                  // [db][tb]
+    NYT_ZERO(ov, 4, 2);
+    NYT_ZERO(ok, 4, 2);
+#pragma nounroll
+    for (int sx = 0; sx < 8; ++sx) {
+      f32x4 s[2][2], dp[2][2];                                 // [lb & 1][tb]
+      NYT_ZERO(s, 2, 2);
+      NYT_ZERO(dp, 2, 2);
+#pragma unroll
+      for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int o = (2 * sx + l2) * 2048 + lm_off[ks];
+          const f32x4 ah = *reinterpret_cast<const f32x4*>(q_hi + o), al = *reinterpret_cast<const f32x4*>(q_lo + o);
+          const f32x4 eh = *reinterpret_cast<const f32x4*>(a_hi + o), el = *reinterpret_cast<const f32x4*>(a_lo + o);
+          ny_mma_a<2>(ah, al, kh[ks], kl[ks], s[l2]);
+          ny_mma_a<2>(eh, el, vh[ks], vl[ks], dp[l2]);
+        }
+#pragma unroll
+      for (int l2 = 0; l2 < 2; ++l2) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lmst + 32 * sx + 16 * l2 + 4 * kg);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(lmst + NY_M + 32 * sx + 16 * l2 + 4 * kg);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pr = NY_EXP2(s[l2][tb][i] * g.sl2e - ls[i]);
+            s[l2][tb][i] = pr;
+            dp[l2][tb][i] = g.scale * pr * (dp[l2][tb][i] - dl[i]);
+          }
+      }
+      f32x4 ph[2], pl[2], sh[2], sl[2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        ny_split44(s[0][tb], s[1][tb], ph[tb], pl[tb]);
+        ny_split44(dp[0][tb], dp[1][tb], sh[tb], sl[tb]);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const f32x4 ath = ny_plane_lt(la_hi + lt_off[db], sx), atl = ny_plane_lt(la_lo + lt_off[db], sx);
+        const f32x4 qth = ny_plane_lt(lq_hi + lt_off[db], sx), qtl = ny_plane_lt(lq_lo + lt_off[db], sx);
+        ny_mma_a<2>(ath, atl, ph, pl, ov[db]);
+        ny_mma_a<2>(qth, qtl, sh, sl, ok[db]);
+      }
+    }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const int64_t row = tk0 + 16 * tb + c;
+      float* okp = g.out + row * g.ldo + h * NY_D + 4 * kg;
+      float* ovp = g.out2 + row * g.ldo2 + h * NY_D + 4 * kg;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        *reinterpret_cast<f32x4*>(okp + 16 * db) = ok[db][tb];
+        f32x4 b = ov[db][tb];
+        if (g.accumulate) b += *reinterpret_cast<const f32x4*>(ovp + 16 * db);
+        *reinterpret_cast<f32x4*>(ovp + 16 * db) = b;
+      }
+    }
+  }
+}
+
+// ===========================================================================================================================
+// Token-owning form of the out token-side backward (dq, delta): k~ (LM for S, LT for dq) and w2 (LM for dP) as row-major planes;
+// a wave owns 16 tokens and holds S^T and dP^T of ALL 256 landmarks ([16 lb] accumulators each), because delta = sum_m P dP of a
+// token must be complete before any dS: the softmax row is the lane's own accumulators + its three k-octet lanes, no cross-wave
+// step, no barrier.  q / dout fragments straight from global memory.
+// ===========================================================================================================================
+__global__ __launch_bounds__(NY8_THREADS) void ny_out_bwd_q8_kernel(NyArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* k_hi = sm;
+  char* k_lo = sm + NY_PLANE;
+  char* w_hi = sm + 2 * NY_PLANE;
+  char* w_lo = sm + 3 * NY_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
+  const int h = blockIdx.y, ch = blockIdx.x;
+  int t_begin, t_end;
+  ny_chunk(g, ch, t_begin, t_end);
+  ny_plane_fill(k_hi, k_lo, g.kl + h * NY_D, g.ldl, tid);
+  ny_plane_fill(w_hi, w_lo, g.w2 + (int64_t)h * NY_PART, NY_D, tid);
+  __syncthreads();
+  int lm_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) lm_off[ks] = c * 128 + (((4 * ks + kg) ^ (c & 7)) << 4);
+  int lt_off[4];
+  {
+    const int r = 4 * kg + (c >> 2), r7 = r & 7;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) lt_off[db] = r * 128 + (((2 * db + ((c & 3) >> 1)) ^ r7) << 4) + (c & 1) * 8;
+  }
+  const ny_lds lk_hi = (ny_lds)k_hi, lk_lo = (ny_lds)k_lo;
+  const float* qb = g.q + h * NY_D;
+  const float* gb = g.dout + h * NY_D;
+  const float* lse = g.lse1 + (int64_t)h * g.T;
+  const int64_t grp_end = (int64_t)t_end * 4;
+  for (int64_t grp = (int64_t)t_begin * 4 + w; grp < grp_end; grp += NY8_NW) {
+    const int64_t tok = grp * 16 + c;
+    f32x4 qh[2], ql[2], gh[2], gl[2];                          // [ks]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* pq = qb + tok * g.ld + 32 * ks + 8 * kg;
+      const float* pg = gb + tok * g.ldd + 32 * ks + 8 * kg;
+      ny_split44(*reinterpret_cast<const f32x4*>(pq), *reinterpret_cast<const f32x4*>(pq + 4), qh[ks], ql[ks]);
+      ny_split44(*reinterpret_cast<const f32x4*>(pg), *reinterpret_cast<const f32x4*>(pg + 4), gh[ks], gl[ks]);
+    }
+    const float ls = lse[tok];
+    f32x4 s[16], dp[16];                                       // [lb]
+#pragma unroll
+    for (int lb = 0; lb < 16; ++lb) { s[lb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[lb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // fragments of block lb + 1 are requested before the products of block lb (the scheduling barriers keep the 128 reads from
+    // being hoisted to the top)
+    f32x4 fa[8], fb[8];                                        // k~ (ks0 hi, lo, ks1 hi, lo), w2 (the same)
+    auto ld_lm = [&](int lb, f32x4 (&f)[8]) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int o = lb * 2048 + lm_off[ks];
+        f[2 * ks] = *reinterpret_cast<const f32x4*>(k_hi + o);
+        f[2 * ks + 1] = *reinterpret_cast<const f32x4*>(k_lo + o);
+        f[4 + 2 * ks] = *reinterpret_cast<const f32x4*>(w_hi + o);
+        f[5 + 2 * ks] = *reinterpret_cast<const f32x4*>(w_lo + o);
+      }
+    };
+    auto mm = [&](int lb, const f32x4 (&f)[8]) {                // term-major over the four (matrix, ks) products
+      s[lb] = mt_mfma(f[1], qh[0], s[lb]);
+      dp[lb] = mt_mfma(f[5], gh[0], dp[lb]);
+      s[lb] = mt_mfma(f[0], ql[0], s[lb]);
+      dp[lb] = mt_mfma(f[4], gl[0], dp[lb]);
+      s[lb] = mt_mfma(f[0], qh[0], s[lb]);
+      dp[lb] = mt_mfma(f[4], gh[0], dp[lb]);
+      s[lb] = mt_mfma(f[3], qh[1], s[lb]);
+      dp[lb] = mt_mfma(f[7], gh[1], dp[lb]);
+      s[lb] = mt_mfma(f[2], ql[1], s[lb]);
+      dp[lb] = mt_mfma(f[6], gl[1], dp[lb]);
+      s[lb] = mt_mfma(f[2], qh[1], s[lb]);
+      dp[lb] = mt_mfma(f[6], gh[1], dp[lb]);
+    };
+    ld_lm(0, fa);
+#pragma unroll
+    for (int lb = 0; lb < 16; lb += 2) {
+      ld_lm(lb + 1, fb);
+      mm(lb, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (lb + 2 < 16) ld_lm(lb + 2, fa);
+      mm(lb + 1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float dl = 0.f;
+#pragma unroll
+    for (int lb = 0; lb < 16; ++lb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pr = NY_EXP2(s[lb][i] * g.sl2e - ls);
+        s[lb][i] = pr;
+        dl += pr * dp[lb][i];
+      }
+    dl = ny_kgsum(dl);
+    if (kg == 0) g.delta[(int64_t)h * g.T + tok] = dl;
+    f32x4 o[4];                                                // [db]
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sx = 0; sx < 8; ++sx) {
+      f32x4 dh, dlo, th[4], tl[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) { th[db] = ny_plane_lt(lk_hi + lt_off[db], sx); tl[db] = ny_plane_lt(lk_lo + lt_off[db], sx); }
+#pragma unroll
+      for (int l2 = 0; l2 < 2; ++l2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[2 * sx + l2][i] = g.scale * s[2 * sx + l2][i] * (dp[2 * sx + l2][i] - dl);
+      ny_split44(s[2 * sx], s[2 * sx + 1], dh, dlo);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[db] = mt_mfma(tl[db], dh, o[db]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[db] = mt_mfma(th[db], dlo, o[db]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[db] = mt_mfma(th[db], dh, o[db]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* op = g.out + tok * g.ldo + h * NY_D + 4 * kg;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(op + 16 * db) = o[db];
+  }
+}
+
 constexpr int NY_SM_OUT_FWD = NY_IMG + 512 * 4 + 4 * 64 * NY_P68 * 4;
 constexpr int NY_SM_BWD_Q = 2 * NY_IMG + 128 * 4 + NY_PART_F * 4;
 constexpr int NY_SM_A3_T = 2 * NY_IMG + 512 * 4 + NY_PART_F * 4;
@@ -514,6 +783,13 @@ static NyArgs ny_tok_chunks(const NyArgs& g0) {
 int nytok_out_bwd_q(hipStream_t st, const NyArgs& g0) {
   using namespace nytok;
   const NyArgs g = ny_tok_chunks(g0);
+  static const bool v1 = getenv("MHIMX_NYS_BWD_Q_V1") != nullptr;       // (experiments: the landmark-split form with cross-wave sums)
+  if (!v1) {
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_bwd_q8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NY_PLANE)));
+    hipLaunchKernelGGL(ny_out_bwd_q8_kernel, dim3(g.nch, NY_H), dim3(NY8_THREADS), 4 * NY_PLANE, st, g);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_bwd_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_BWD_Q)));
   hipLaunchKernelGGL(ny_out_bwd_q_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_BWD_Q, st, g);
   MHIMX_LAUNCH_CHECK();
@@ -522,6 +798,13 @@ int nytok_out_bwd_q(hipStream_t st, const NyArgs& g0) {
 int nytok_a3v_bwd_t(hipStream_t st, const NyArgs& g0, int mode) {
   using namespace nytok;
   const NyArgs g = mode == 0 ? ny_tok_chunks(g0) : g0;
+  static const bool v1 = getenv("MHIMX_NYS_BWD_T_V1") != nullptr;       // (experiments: the landmark-split form with cross-wave sums)
+  if (mode == 0 && !v1) {
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_T8)));
+    hipLaunchKernelGGL(ny_a3v_bwd_t8_kernel, dim3(g.nch, NY_H), dim3(NY8_THREADS), NY_SM_A3_T8, st, g);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_T));
                         MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_CLS)));
   if (mode == 0) hipLaunchKernelGGL(ny_a3v_bwd_t_kernel<0>, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_A3_T, st, g);
