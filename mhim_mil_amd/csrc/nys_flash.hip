@@ -68,14 +68,19 @@ MHIMX_DEV void ny_split4(const f32x4& a, bf4& hi, bf4& lo) {
     lo[q] = (__bf16)(a[q] - (float)h);
   }
 }
-// RM image: fragment (tb, ks, hl) at ((tb*2 + ks)*2 + hl) KiB, lane (token & 15, dim octet & 3) x 16 B (a thread owns half a slot)
+// RM image: fragment (tb, ks, hl) at ((tb*2 + ks)*2 + hl) KiB, lane (token & 15, dim octet & 3) x 16 B (a thread owns half a slot).
+// The 16 lanes of a ds_write_b64 group hold ONE token and the 16 dim quads: their slots differ in (octet, ks) only, which are 256 B
+// and 2 KiB apart - two bank pairs for 16 lanes.  The token index is XORed with (octet + 4 ks), readers apply the same XOR (a
+// permutation inside aligned groups of 8 slots: the 16-lane groups of a ds_read_b128 still cover all 64 banks).  SQ_LDS_BANK_CONFLICT
+// was 56 % of the LDS-active cycles of the landmark-column kernels.
 MHIMX_DEV void ny_store_rm(char* img, int tid, const f32x4 (&r)[2]) {
   const int g = tid & 15, t = 2 * (tid >> 4);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     bf4 hi, lo;
     ny_split4(r[e], hi, lo);
-    char* p = img + ((((t + e) >> 4) * 2 + (g >> 3)) * 2) * 1024 + (((g >> 1) & 3) * 16 + ((t + e) & 15)) * 16 + (g & 1) * 8;
+    const int kgd = (g >> 1) & 3, ks = g >> 3;
+    char* p = img + ((((t + e) >> 4) * 2 + ks) * 2) * 1024 + (kgd * 16 + (((t + e) & 15) ^ (kgd + 4 * ks))) * 16 + (g & 1) * 8;
     *reinterpret_cast<bf4*>(p) = hi;
     *reinterpret_cast<bf4*>(p + 1024) = lo;
   }
@@ -85,7 +90,8 @@ MHIMX_DEV void ny_store_rm(char* img, int tid, const f32x4 (&r)[2]) {
 MHIMX_DEV void ny_store_tr(char* img, int tid, const f32x4 (&r)[2]) {
   const int g = tid & 15, t = 2 * (tid >> 4), u = t & 31;
   const int j = 4 * (u >> 4) + (u & 3), kgt = (u & 15) >> 2;
-  char* base = img + (((g >> 2) * 2 + (t >> 5)) * 2) * 1024 + (kgt * 16 + (g & 3) * 4) * 16 + j * 2;
+  const int db = g >> 2;                                       // slot index ^ db: the four d blocks are 4 KiB apart (same banks)
+  char* base = img + ((db * 2 + (t >> 5)) * 2) * 1024 + (kgt * 16 + (g & 3) * 4) * 16 + j * 2;
   bf4 ah, al, bh, bl;
   ny_split4(r[0], ah, al);
   ny_split4(r[1], bh, bl);
@@ -93,12 +99,15 @@ MHIMX_DEV void ny_store_tr(char* img, int tid, const f32x4 (&r)[2]) {
   for (int x = 0; x < 4; ++x) {
     bf2 h2, l2;
     h2[0] = ah[x]; h2[1] = bh[x]; l2[0] = al[x]; l2[1] = bl[x];
-    *reinterpret_cast<bf2*>(base + x * 16) = h2;
-    *reinterpret_cast<bf2*>(base + x * 16 + 1024) = l2;
+    *reinterpret_cast<bf2*>(base + (x ^ db) * 16) = h2;
+    *reinterpret_cast<bf2*>(base + (x ^ db) * 16 + 1024) = l2;
   }
 }
-MHIMX_DEV f32x4 ny_frag(const char* img, int blk, int step, int hl, int lane) {
-  return *reinterpret_cast<const f32x4*>(img + (((blk * 2 + step) * 2 + hl) * 64 + lane) * 16);
+MHIMX_DEV f32x4 ny_frag_rm(const char* img, int tb, int ks, int hl, int lane) {
+  return *reinterpret_cast<const f32x4*>(img + (((tb * 2 + ks) * 2 + hl) * 64 + (lane ^ ((lane >> 4) + 4 * ks))) * 16);
+}
+MHIMX_DEV f32x4 ny_frag_tr(const char* img, int db, int ts, int hl, int lane) {
+  return *reinterpret_cast<const f32x4*>(img + (((db * 2 + ts) * 2 + hl) * 64 + (lane ^ db)) * 16);
 }
 
 // ---- landmark-side fragments (global fp32 -> registers), M = [256, 64] of this head with row pitch ldm, the wave's landmarks at lm0
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
 #pragma unroll
       for (int lb = 0; lb < NY_LB; ++lb) { bh[lb] = qf.h[lb][ks]; bl[lb] = qf.l[lb][ks]; }
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) ny_mma_a<NY_LB>(ny_frag(sm, tb, ks, 0, lane), ny_frag(sm, tb, ks, 1, lane), bh, bl, s[tb]);
+      for (int tb = 0; tb < 4; ++tb) ny_mma_a<NY_LB>(ny_frag_rm(sm, tb, ks, 0, lane), ny_frag_rm(sm, tb, ks, 1, lane), bh, bl, s[tb]);
     }
 #pragma unroll
     for (int lb = 0; lb < NY_LB; ++lb) {
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
       for (int lb = 0; lb < NY_LB; ++lb) ny_split44(s[2 * ts][lb], s[2 * ts + 1][lb], ph[lb], pl[lb]);
 #pragma unroll
       for (int db = 0; db < 4; ++db)
-        ny_mma_a<NY_LB>(ny_frag(sm + NY_IMG, db, ts, 0, lane), ny_frag(sm + NY_IMG, db, ts, 1, lane), ph, pl, o[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm + NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + NY_IMG, db, ts, 1, lane), ph, pl, o[db]);
     }
   }
   float* pp = g.part + ((int64_t)h * g.nch + ch) * (NY_PART + 2 * NY_M);
@@ -308,8 +317,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
         for (int lb = 0; lb < NY_LB; ++lb) { bh[lb] = kf.h[lb][ks]; bl[lb] = kf.l[lb][ks]; eh[lb] = wf.h[lb][ks]; el[lb] = wf.l[lb][ks]; }
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-          ny_mma_a<NY_LB>(ny_frag(sm, 2 * ts + tb, ks, 0, lane), ny_frag(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
-          ny_mma_a<NY_LB>(ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
+          ny_mma_a<NY_LB>(ny_frag_rm(sm, 2 * ts + tb, ks, 0, lane), ny_frag_rm(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
+          ny_mma_a<NY_LB>(ny_frag_rm(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag_rm(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
         }
       }
 #pragma unroll
@@ -333,8 +342,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        ny_mma_a<NY_LB>(ny_frag(sm + 3 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 3 * NY_IMG, db, ts, 1, lane), ph, pl, dw2[db]);
-        ny_mma_a<NY_LB>(ny_frag(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dkl[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm + 3 * NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + 3 * NY_IMG, db, ts, 1, lane), ph, pl, dw2[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dkl[db]);
       }
     }
   }
@@ -418,8 +427,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
         for (int lb = 0; lb < NY_LB; ++lb) { bh[lb] = qf.h[lb][ks]; bl[lb] = qf.l[lb][ks]; eh[lb] = af.h[lb][ks]; el[lb] = af.l[lb][ks]; }
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-          ny_mma_a<NY_LB>(ny_frag(sm, 2 * ts + tb, ks, 0, lane), ny_frag(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
-          ny_mma_a<NY_LB>(ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
+          ny_mma_a<NY_LB>(ny_frag_rm(sm, 2 * ts + tb, ks, 0, lane), ny_frag_rm(sm, 2 * ts + tb, ks, 1, lane), bh, bl, s[tb]);
+          ny_mma_a<NY_LB>(ny_frag_rm(sm + NY_IMG, 2 * ts + tb, ks, 0, lane), ny_frag_rm(sm + NY_IMG, 2 * ts + tb, ks, 1, lane), eh, el, dp[tb]);
         }
       }
       f32x4 sh[NY_LB], sl[NY_LB];
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db)
-        ny_mma_a<NY_LB>(ny_frag(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dq[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dq[db]);
     }
   }
   float* p1 = g.part + ((int64_t)h * g.nch + ch) * NY_PART;
@@ -603,7 +612,9 @@ static int ny_base(const mhimx_nys* a, NyArgs& g, const char* who) {
   g.scale = a->scale;
   g.sl2e = a->scale * 1.4426950408889634f;
   const int64_t tiles = a->T / NY_TT;
-  g.nch = (int)(tiles < NY_MAXCH ? tiles : NY_MAXCH);
+  static const int lch = getenv("MHIMX_NYS_LMCH") ? atoi(getenv("MHIMX_NYS_LMCH")) : NY_MAXCH;   // (experiments; <= NY_MAXCH)
+  const int per = lch < 1 ? 1 : (lch > NY_MAXCH ? NY_MAXCH : lch);
+  g.nch = (int)(tiles < per ? tiles : per);
   return 0;
 }
 
@@ -635,6 +646,8 @@ extern "C" int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* 
   static const bool v1 = getenv("MHIMX_NYS_OUT_V1") != nullptr;         // (experiments: the landmark-split form with cross-wave sums)
   if (v1) return nytok_out_fwd((hipStream_t)stream, g);
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_fwd_tok8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_OUT8)));
+  const int64_t tiles = g.T / NY_TT;
+  g.nch = (int)(tiles < NY_TOKCH ? tiles : NY_TOKCH);                    // 128 KB of LDS: one workgroup per CU
   hipLaunchKernelGGL(ny_out_fwd_tok8_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_OUT8, (hipStream_t)stream, g);
   MHIMX_LAUNCH_CHECK();
   return 0;

@@ -43,31 +43,13 @@ MHIMX_DEV void ny_store_rm(char* img, int tid, const f32x4 (&r)[4]) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     ny_split44(r[2 * e], r[2 * e + 1], hi, lo);
-    char* p = img + ((((t + e) >> 4) * 2 + (g >> 2)) * 2) * 1024 + ((g & 3) * 16 + ((t + e) & 15)) * 16;
+    char* p = img + ((((t + e) >> 4) * 2 + (g >> 2)) * 2) * 1024 + ((g & 3) * 16 + (((t + e) & 15) ^ g)) * 16;   // ^ (octet + 4 ks): nys_flash.hip
     *reinterpret_cast<f32x4*>(p) = hi;
     *reinterpret_cast<f32x4*>(p + 1024) = lo;
   }
 }
-// TR image: fragment (db, ts, hl) at ((db*2 + ts)*2 + hl) KiB, lane (dim & 15, kg) x 16 B; token u of a 32-token step sits in
-// k-octet kg = (u & 15) >> 2 at slot j = 4 (u >> 4) + (u & 3) - the order of an accumulator pair
-MHIMX_DEV void ny_store_tr(char* img, int tid, const f32x4 (&r)[4]) {
-  const int g = tid & 7, t = 2 * (tid >> 3), u = t & 31;
-  const int j = 4 * (u >> 4) + (u & 3), kgt = (u & 15) >> 2;
-  char* base = img + (((g >> 1) * 2 + (t >> 5)) * 2) * 1024 + (kgt * 16 + (g & 1) * 8) * 16 + j * 2;
-#pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    const float a = r[x >> 2][x & 3], b = r[2 + (x >> 2)][x & 3];
-    const __bf16 ah = (__bf16)a, bh = (__bf16)b;
-    const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    bf2 h2, l2;
-    h2[0] = ah; h2[1] = bh; l2[0] = al; l2[1] = bl;
-    *reinterpret_cast<bf2*>(base + x * 16) = h2;
-    *reinterpret_cast<bf2*>(base + x * 16 + 1024) = l2;
-  }
-}
-MHIMX_DEV f32x4 ny_frag(const char* img, int blk, int step, int hl, int lane) {
-  return *reinterpret_cast<const f32x4*>(img + (((blk * 2 + step) * 2 + hl) * 64 + lane) * 16);
+MHIMX_DEV f32x4 ny_frag(const char* img, int blk, int step, int hl, int lane) {      // RM images only (the swizzle of ny_store_rm)
+  return *reinterpret_cast<const f32x4*>(img + (((blk * 2 + step) * 2 + hl) * 64 + (lane ^ ((lane >> 4) + 4 * step))) * 16);
 }
 
 // ---- landmark-side fragments (global fp32 -> registers), M = [256, 64] of this head with row pitch ldm, the wave's landmarks at lm0
@@ -497,9 +479,9 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_t_kernel(NyArgs g) {
 // tools/micro/tr_probe.hip).  Both reads are conflict-free under the XOR (b128: 16-lane groups {0-3,12-15,20-27}.. hit 16 different
 // 4-bank spans; tr: 32 lanes = 8 rows x 32 bytes, even rows banks 0-31, odd rows 32-63, chunk pair db ^ (r >> 1)).  Four fragment
 // images of the landmark-split form (256 KB) would not fit; the two planes pairs are 128 KB.
-// A wave owns 32 tokens and ALL 256 landmarks, streamed 32 at a time: S^T, dP^T [2 lb][2 tb] -> P, dS -> dv^T, dk^T [4 db][2 tb]
+// A wave owns 16 tokens and ALL 256 landmarks, streamed 32 at a time: S^T, dP^T [2 lb] -> P, dS -> dv^T, dk^T [4 db]
 // accumulate in registers.  k / v fragments come straight from global memory (8 consecutive head dims of the lane's token).
-// 281 -> 164 us at T = 50 176 (the out backward's twin below: 199 -> 103 us).  Measured and dropped: starting waves 4..7 (the second
+// 281 -> 156 us at T = 50 176 (the out backward's twin below: 199 -> 103 us).  Measured and dropped: starting waves 4..7 (the second
 // wave of each SIMD) 8..48 x 64 cycles late so that the pair does not run its matrix and VALU phases in lockstep: +-1 %.
 // ===========================================================================================================================
 constexpr int NY8_THREADS = 512, NY8_NW = 8;
@@ -550,87 +532,124 @@ __global__ __launch_bounds__(NY8_THREADS) void ny_a3v_bwd_t8_kernel(NyArgs g) {
   }
   __syncthreads();
   // per-lane offsets inside a plane
-  int lm_off[2];                                               // LM fragment (lb 0, ks)
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) lm_off[ks] = c * 128 + (((4 * ks + kg) ^ (c & 7)) << 4);
-  int lt_off[4];                                               // LT fragment (sx 0, blk 0, db)
-  {
-    const int r = 4 * kg + (c >> 2), r7 = r & 7;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) lt_off[db] = r * 128 + (((2 * db + ((c & 3) >> 1)) ^ r7) << 4) + (c & 1) * 8;
-  }
+  // (the XOR touches the chunk bits only: ks flips bit 6 of the offset, db bits 5-6 - one register each, an immediate per use)
+  const int lm_off0 = c * 128 + ((kg ^ (c & 7)) << 4);         // LM fragment (lb 0, ks 0); ks 1: ^ 64
+  const int lt_r = 4 * kg + (c >> 2);
+  const int lt_off0 = lt_r * 128 + ((((c & 3) >> 1) ^ (lt_r & 7)) << 4) + (c & 1) * 8;   // LT fragment (sx 0, blk 0, db 0); db: ^ (db << 5)
   const ny_lds lq_hi = (ny_lds)q_hi, lq_lo = (ny_lds)q_lo, la_hi = (ny_lds)a_hi, la_lo = (ny_lds)a_lo;
   const float* kb = g.k + h * NY_D;
   const float* vb = g.v + h * NY_D;
-  const int64_t grp_end = (int64_t)t_end * 2;
-  for (int64_t grp = (int64_t)t_begin * 2 + w; grp < grp_end; grp += NY8_NW) {
-    const int64_t tk0 = grp * 32;
-    f32x4 kh[2][2], kl[2][2], vh[2][2], vl[2][2];              // [ks][tb]
+  // 16 tokens per wave; the LDS reads of a phase are issued one phase ahead: the LT fragments of step sx before its S / dP products,
+  // the LM fragments of step sx + 1 before its exp / split work (step 8 = step 0 of the wave's next group: the landmark side does not
+  // depend on the tokens).  With the reads next to their use the waves sat in s_waitcnt for 47 % of their cycles (SQ_WAIT_ANY).
+  const int64_t grp_end = (int64_t)t_end * 4;
+  f32x4 lmf[16];                                               // [l2][ks][q~ hi, q~ lo, da hi, da lo]
+  auto ld_lm = [&](int sx) {
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int l2 = 0; l2 < 2; ++l2)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int64_t o = (tk0 + 16 * tb + c) * g.ld + 32 * ks + 8 * kg;
-        ny_split44(*reinterpret_cast<const f32x4*>(kb + o), *reinterpret_cast<const f32x4*>(kb + o + 4), kh[ks][tb], kl[ks][tb]);
-        ny_split44(*reinterpret_cast<const f32x4*>(vb + o), *reinterpret_cast<const f32x4*>(vb + o + 4), vh[ks][tb], vl[ks][tb]);
+        const int o = (2 * sx + l2) * 2048 + (lm_off0 ^ (ks << 6));
+        lmf[(l2 * 2 + ks) * 4 + 0] = *reinterpret_cast<const f32x4*>(q_hi + o);
+        lmf[(l2 * 2 + ks) * 4 + 1] = *reinterpret_cast<const f32x4*>(q_lo + o);
+        lmf[(l2 * 2 + ks) * 4 + 2] = *reinterpret_cast<const f32x4*>(a_hi + o);
+        lmf[(l2 * 2 + ks) * 4 + 3] = *reinterpret_cast<const f32x4*>(a_lo + o);
       }
-    f32x4 ov[4][2], ok[4][2];                                  // [db][tb]
-    NYT_ZERO(ov, 4, 2);
-    NYT_ZERO(ok, 4, 2);
+  };
+  ld_lm(0);
+  // kv: [k ks0 | k ks1 | v ks0 | v ks1] x (hi, lo), or the two raw 16-byte halves before the split.  (Requesting the next group's
+  // k / v into these registers as soon as the group's last S / dP products have issued measured SLOWER: 343 vs 336 us per entry.)
+  f32x4 kv[8];
+  auto ld_kv = [&](int64_t grp) {
+    const int64_t o = (grp * 16 + c) * g.ld + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kv[2 * ks] = *reinterpret_cast<const f32x4*>(kb + o + 32 * ks);
+      kv[2 * ks + 1] = *reinterpret_cast<const f32x4*>(kb + o + 32 * ks + 4);
+      kv[4 + 2 * ks] = *reinterpret_cast<const f32x4*>(vb + o + 32 * ks);
+      kv[5 + 2 * ks] = *reinterpret_cast<const f32x4*>(vb + o + 32 * ks + 4);
+    }
+  };
+  const int64_t grp0 = (int64_t)t_begin * 4 + w;
+  if (grp0 < grp_end) ld_kv(grp0);
+  for (int64_t grp = grp0; grp < grp_end; grp += NY8_NW) {
+    const int64_t tok = grp * 16 + c;
+    if (grp != grp0) ld_kv(grp);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      f32x4 hi, lo;
+      ny_split44(kv[2 * x], kv[2 * x + 1], hi, lo);
+      kv[2 * x] = hi;
+      kv[2 * x + 1] = lo;
+    }
+    f32x4 ov[4], ok[4];                                        // [db]
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { ov[db] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma nounroll
     for (int sx = 0; sx < 8; ++sx) {
-      f32x4 s[2][2], dp[2][2];                                 // [lb & 1][tb]
-      NYT_ZERO(s, 2, 2);
-      NYT_ZERO(dp, 2, 2);
+      f32x4 ath[4], atl[4], qth[4], qtl[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        ath[db] = ny_plane_lt(la_hi + (lt_off0 ^ (db << 5)), sx); atl[db] = ny_plane_lt(la_lo + (lt_off0 ^ (db << 5)), sx);
+        qth[db] = ny_plane_lt(lq_hi + (lt_off0 ^ (db << 5)), sx); qtl[db] = ny_plane_lt(lq_lo + (lt_off0 ^ (db << 5)), sx);
+      }
+      f32x4 ls[2], dl[2];                                      // (LDS reads return in order: these must not sit behind the LM prefetch)
+#pragma unroll
+      for (int l2 = 0; l2 < 2; ++l2) {
+        ls[l2] = *reinterpret_cast<const f32x4*>(lmst + 32 * sx + 16 * l2 + 4 * kg);
+        dl[l2] = *reinterpret_cast<const f32x4*>(lmst + NY_M + 32 * sx + 16 * l2 + 4 * kg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 s[2], dp[2];                                       // [lb & 1]
+#pragma unroll
+      for (int l2 = 0; l2 < 2; ++l2) { s[l2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[l2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {                         // term-major over the four (matrix, landmark block) accumulators
+#pragma unroll
+        for (int l2 = 0; l2 < 2; ++l2) {
+          s[l2] = mt_mfma(lmf[(l2 * 2 + ks) * 4 + 1], kv[2 * ks], s[l2]);
+          dp[l2] = mt_mfma(lmf[(l2 * 2 + ks) * 4 + 3], kv[4 + 2 * ks], dp[l2]);
+        }
+#pragma unroll
+        for (int l2 = 0; l2 < 2; ++l2) {
+          s[l2] = mt_mfma(lmf[(l2 * 2 + ks) * 4 + 0], kv[2 * ks + 1], s[l2]);
+          dp[l2] = mt_mfma(lmf[(l2 * 2 + ks) * 4 + 2], kv[5 + 2 * ks], dp[l2]);
+        }
+#pragma unroll
+        for (int l2 = 0; l2 < 2; ++l2) {
+          s[l2] = mt_mfma(lmf[(l2 * 2 + ks) * 4 + 0], kv[2 * ks], s[l2]);
+          dp[l2] = mt_mfma(lmf[(l2 * 2 + ks) * 4 + 2], kv[4 + 2 * ks], dp[l2]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ld_lm((sx + 1) & 7);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int l2 = 0; l2 < 2; ++l2)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int o = (2 * sx + l2) * 2048 + lm_off[ks];
-          const f32x4 ah = *reinterpret_cast<const f32x4*>(q_hi + o), al = *reinterpret_cast<const f32x4*>(q_lo + o);
-          const f32x4 eh = *reinterpret_cast<const f32x4*>(a_hi + o), el = *reinterpret_cast<const f32x4*>(a_lo + o);
-          ny_mma_a<2>(ah, al, kh[ks], kl[ks], s[l2]);
-          ny_mma_a<2>(eh, el, vh[ks], vl[ks], dp[l2]);
+        for (int i = 0; i < 4; ++i) {
+          const float pr = NY_EXP2(s[l2][i] * g.sl2e - ls[l2][i]);
+          s[l2][i] = pr;
+          dp[l2][i] = g.scale * pr * (dp[l2][i] - dl[l2][i]);
         }
+      f32x4 ph, pl, sh, sl;
+      ny_split44(s[0], s[1], ph, pl);
+      ny_split44(dp[0], dp[1], sh, sl);
 #pragma unroll
-      for (int l2 = 0; l2 < 2; ++l2) {
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(lmst + 32 * sx + 16 * l2 + 4 * kg);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(lmst + NY_M + 32 * sx + 16 * l2 + 4 * kg);
+      for (int db = 0; db < 4; ++db) { ov[db] = mt_mfma(atl[db], ph, ov[db]); ok[db] = mt_mfma(qtl[db], sh, ok[db]); }
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
+      for (int db = 0; db < 4; ++db) { ov[db] = mt_mfma(ath[db], pl, ov[db]); ok[db] = mt_mfma(qth[db], sl, ok[db]); }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float pr = NY_EXP2(s[l2][tb][i] * g.sl2e - ls[i]);
-            s[l2][tb][i] = pr;
-            dp[l2][tb][i] = g.scale * pr * (dp[l2][tb][i] - dl[i]);
-          }
-      }
-      f32x4 ph[2], pl[2], sh[2], sl[2];
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        ny_split44(s[0][tb], s[1][tb], ph[tb], pl[tb]);
-        ny_split44(dp[0][tb], dp[1][tb], sh[tb], sl[tb]);
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const f32x4 ath = ny_plane_lt(la_hi + lt_off[db], sx), atl = ny_plane_lt(la_lo + lt_off[db], sx);
-        const f32x4 qth = ny_plane_lt(lq_hi + lt_off[db], sx), qtl = ny_plane_lt(lq_lo + lt_off[db], sx);
-        ny_mma_a<2>(ath, atl, ph, pl, ov[db]);
-        ny_mma_a<2>(qth, qtl, sh, sl, ok[db]);
-      }
+      for (int db = 0; db < 4; ++db) { ov[db] = mt_mfma(ath[db], ph, ov[db]); ok[db] = mt_mfma(qth[db], sh, ok[db]); }
     }
+    float* okp = g.out + tok * g.ldo + h * NY_D + 4 * kg;
+    float* ovp = g.out2 + tok * g.ldo2 + h * NY_D + 4 * kg;
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-      const int64_t row = tk0 + 16 * tb + c;
-      float* okp = g.out + row * g.ldo + h * NY_D + 4 * kg;
-      float* ovp = g.out2 + row * g.ldo2 + h * NY_D + 4 * kg;
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        *reinterpret_cast<f32x4*>(okp + 16 * db) = ok[db][tb];
-        f32x4 b = ov[db][tb];
-        if (g.accumulate) b += *reinterpret_cast<const f32x4*>(ovp + 16 * db);
-        *reinterpret_cast<f32x4*>(ovp + 16 * db) = b;
-      }
+    for (int db = 0; db < 4; ++db) {
+      *reinterpret_cast<f32x4*>(okp + 16 * db) = ok[db];
+      f32x4 bv = ov[db];
+      if (g.accumulate) bv += *reinterpret_cast<const f32x4*>(ovp + 16 * db);
+      *reinterpret_cast<f32x4*>(ovp + 16 * db) = bv;
     }
   }
 }
@@ -775,7 +794,7 @@ int nytok_out_fwd(hipStream_t st, const NyArgs& g) {
 // (the landmark fragments fill 256 VGPRs + 155 / 205 AGPRs: one wave per SIMD): 64 chunks measured 9.48 vs 9.43 ms per c3 step.
 static NyArgs ny_tok_chunks(const NyArgs& g0) {
   NyArgs g = g0;
-  static const int per = getenv("MHIMX_NYS_TOKCH") ? atoi(getenv("MHIMX_NYS_TOKCH")) : NY_MAXCH;
+  static const int per = getenv("MHIMX_NYS_TOKCH") ? atoi(getenv("MHIMX_NYS_TOKCH")) : NY_TOKCH;
   const int64_t tiles = g.T / NY_TT;
   g.nch = (int)(tiles < per ? tiles : per);
   return g;
