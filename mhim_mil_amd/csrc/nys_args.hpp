@@ -7,7 +7,7 @@ namespace mhimx {
 
 #define NY_EXP2(x) __builtin_amdgcn_exp2f(x)
 
-constexpr int NY_H = 8, NY_D = 64, NY_M = 256, NY_TT = 64, NY_MAXCH = 64, NY_TOKCH = 32;     // chunks: workspace bound / token-owning kernels (one workgroup per CU)
+constexpr int NY_H = 8, NY_D = 64, NY_M = 256, NY_TT = 64, NY_MAXCH = 32, NY_TOKCH = 32;     // token chunks per head: landmark-column kernels (= workspace bound) / token-owning kernels
 constexpr int NY_IMG = 16384;                        // one fragment image of a 64 x 64 tile (hi + lo)
 constexpr int NY_PART = NY_M * NY_D;                 // floats of one [256, 64] partial
 

@@ -612,6 +612,8 @@ static int ny_base(const mhimx_nys* a, NyArgs& g, const char* who) {
   g.scale = a->scale;
   g.sl2e = a->scale * 1.4426950408889634f;
   const int64_t tiles = a->T / NY_TT;
+  // one workgroup per CU: 64 chunks (two per CU; the landmark-column kernels would fit) measured SLOWER - a3v forward + merge 146 vs
+  // 125 us, out backward 365 vs 341 us: twice the partials to write and merge, and these kernels are not latency-bound
   static const int lch = getenv("MHIMX_NYS_LMCH") ? atoi(getenv("MHIMX_NYS_LMCH")) : NY_MAXCH;   // (experiments; <= NY_MAXCH)
   const int per = lch < 1 ? 1 : (lch > NY_MAXCH ? NY_MAXCH : lch);
   g.nch = (int)(tiles < per ? tiles : per);
