@@ -247,24 +247,38 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
   }
 }
 
-// a3v[h][lm][d] = sum_ch o e^{(m_ch - M) scale} / L,  lse3[h][lm] = M sl2e + log2 L  (base-2 log-sum-exp of the scaled scores)
+// a3v[h][lm][d] = sum_ch o e^{(m_ch - M) scale} / L,  lse3[h][lm] = M sl2e + log2 L  (base-2 log-sum-exp of the scaled scores).
+// 64 outputs x 4 chunk quarters per workgroup: the maximum over ALL chunks first (LDS), then every quarter's weighted sums against
+// it, added in a fixed order.
 __global__ __launch_bounds__(256) void ny_a3v_merge_kernel(const float* part, int nch, float sl2e, float* a3v, float* lse3) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;            // (h, lm, d4)
+  __shared__ f32x4 sacc[3][64];
+  __shared__ float smax[4][64], sl[3][64];
+  const int q = threadIdx.x >> 6, t = threadIdx.x & 63, idx = blockIdx.x * 64 + t;            // (h, lm, d4)
   const int d4 = idx & 15, lm = (idx >> 4) & 255, h = idx >> 12;
   const float* pp = part + (int64_t)h * nch * (NY_PART + 2 * NY_M);
+  const int c0 = nch * q / 4, c1 = nch * (q + 1) / 4;
   float M = -__builtin_inff();
-  for (int ch = 0; ch < nch; ++ch) M = fmaxf(M, pp[(int64_t)ch * (NY_PART + 2 * NY_M) + NY_PART + lm]);
+  for (int ch = c0; ch < c1; ++ch) M = fmaxf(M, pp[(int64_t)ch * (NY_PART + 2 * NY_M) + NY_PART + lm]);
+  smax[q][t] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(smax[0][t], smax[1][t]), fmaxf(smax[2][t], smax[3][t]));
   float L = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int ch = 0; ch < nch; ++ch) {
+  for (int ch = c0; ch < c1; ++ch) {
     const float* pc = pp + (int64_t)ch * (NY_PART + 2 * NY_M);
     const float e = NY_EXP2((pc[NY_PART + lm] - M) * sl2e);
     L += pc[NY_PART + NY_M + lm] * e;
     acc += *reinterpret_cast<const f32x4*>(pc + lm * NY_D + 4 * d4) * e;
   }
-  const float inv = 1.f / L;
-  *reinterpret_cast<f32x4*>(a3v + ((int64_t)h * NY_M + lm) * NY_D + 4 * d4) = acc * inv;
-  if (d4 == 0) lse3[h * NY_M + lm] = M * sl2e + log2f(L);
+  if (q) { sacc[q - 1][t] = acc; sl[q - 1][t] = L; }
+  __syncthreads();
+  if (q == 0) {
+    acc = ((acc + sacc[0][t]) + sacc[1][t]) + sacc[2][t];
+    L = ((L + sl[0][t]) + sl[1][t]) + sl[2][t];
+    const float inv = 1.f / L;
+    *reinterpret_cast<f32x4*>(a3v + ((int64_t)h * NY_M + lm) * NY_D + 4 * d4) = acc * inv;
+    if (d4 == 0) lse3[h * NY_M + lm] = M * sl2e + log2f(L);
+  }
 }
 
 // ===========================================================================================================================
@@ -358,14 +372,28 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
     }
 }
 
-// out[h][lm][d] (row pitch ldo, head pitch hs) = sum_ch part[h][ch][lm][d]
-__global__ __launch_bounds__(256) void ny_reduce_kernel(const float* part, int nch, float* out, int64_t ldo, int64_t hs) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+// out[h][lm][d] (row pitch ldo, head pitch hs) = sum_ch part[h][ch][lm][d].  A workgroup = 64 outputs (16 bytes each) x 4 chunk
+// quarters, summed through LDS in a fixed order (128 workgroups of 32-deep serial sums were 11 us on half the CUs: latency-bound).
+// TWO reductions per launch (blockIdx.y; the second may be absent).
+struct NyReduce { const float* part; float* out; int64_t ldo, hs; };
+__global__ __launch_bounds__(256) void ny_reduce_kernel(NyReduce r0, NyReduce r1, int nch) {
+  __shared__ f32x4 sm[3][64];
+  const NyReduce r = blockIdx.y == 0 ? r0 : r1;
+  const int q = threadIdx.x >> 6, idx = blockIdx.x * 64 + (threadIdx.x & 63);
   const int d4 = idx & 15, lm = (idx >> 4) & 255, h = idx >> 12;
-  const float* pp = part + (int64_t)h * nch * NY_PART + lm * NY_D + 4 * d4;
+  const float* pp = r.part + (int64_t)h * nch * NY_PART + lm * NY_D + 4 * d4;
+  const int c0 = nch * q / 4, c1 = nch * (q + 1) / 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int ch = 0; ch < nch; ++ch) acc += *reinterpret_cast<const f32x4*>(pp + (int64_t)ch * NY_PART);
-  *reinterpret_cast<f32x4*>(out + (int64_t)h * hs + (int64_t)lm * ldo + 4 * d4) = acc;
+  for (int ch = c0; ch < c1; ++ch) acc += *reinterpret_cast<const f32x4*>(pp + (int64_t)ch * NY_PART);
+  if (q) sm[q - 1][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (q == 0) {
+    acc = ((acc + sm[0][threadIdx.x]) + sm[1][threadIdx.x]) + sm[2][threadIdx.x];
+    *reinterpret_cast<f32x4*>(r.out + (int64_t)h * r.hs + (int64_t)lm * r.ldo + 4 * d4) = acc;
+  }
+}
+static void ny_reduce(hipStream_t st, int nch, const NyReduce& a, const NyReduce* b = nullptr) {
+  hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 64, b ? 2 : 1), dim3(256), 0, st, a, b ? *b : a, nch);
 }
 
 // delta3[h][lm] = sum_d a3v da3v
@@ -635,7 +663,7 @@ extern "C" int mhimx_nys_a3v_fwd(void* stream, const mhimx_nys* a, float* a3v, f
   MHIMX_CHECK_ARG(a->k && a->v && a->ql && a3v && lse3 && aligned16(a->k) && aligned16(a->v) && aligned16(a->ql), "nys_a3v_fwd: null / unaligned operands");
   g.part = a->ws;
   hipLaunchKernelGGL(ny_a3v_fwd_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), 0, (hipStream_t)stream, g);
-  hipLaunchKernelGGL(ny_a3v_merge_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, (hipStream_t)stream, a->ws, g.nch, g.sl2e, a3v, lse3);
+  hipLaunchKernelGGL(ny_a3v_merge_kernel, dim3(NY_H * NY_M * 16 / 64), dim3(256), 0, (hipStream_t)stream, a->ws, g.nch, g.sl2e, a3v, lse3);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -668,8 +696,8 @@ extern "C" int mhimx_nys_out_bwd(void* stream, const mhimx_nys* a, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (int e = nytok_out_bwd_q(st, g)) return e;
   hipLaunchKernelGGL(ny_out_bwd_l_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_BWD_L, st, g);
-  hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, st, g.part, g.nch, dkl, lddl, (int64_t)NY_D);
-  hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, st, g.part2, g.nch, dw2, (int64_t)NY_D, (int64_t)NY_PART);
+  const NyReduce ra = {g.part, dkl, lddl, (int64_t)NY_D}, rb = {g.part2, dw2, (int64_t)NY_D, (int64_t)NY_PART};
+  ny_reduce(st, g.nch, ra, &rb);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -689,7 +717,7 @@ extern "C" int mhimx_nys_a3v_bwd(void* stream, const mhimx_nys* a, const float* 
   hipLaunchKernelGGL(ny_delta3_kernel, dim3(NY_H * NY_M / 256), dim3(256), 0, st, a3v, da3v, delta3);
   if (int e = nytok_a3v_bwd_t(st, g, 0)) return e;
   hipLaunchKernelGGL(ny_a3v_bwd_l_kernel, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_A3_L, st, g);
-  hipLaunchKernelGGL(ny_reduce_kernel, dim3(NY_H * NY_M * 16 / 256), dim3(256), 0, st, g.part, g.nch, dql, lddl, (int64_t)NY_D);
+  ny_reduce(st, g.nch, NyReduce{g.part, dql, lddl, (int64_t)NY_D});
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
