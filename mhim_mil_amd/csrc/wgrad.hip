@@ -832,6 +832,9 @@ using namespace mhimx;
 extern "C" int64_t mhimx_wgrad_image_bytes(int64_t L, int64_t E) { return cdiv(L, WBK) * WBK * E * 4; }
 
 // slabs the product will use for L rows, and the workspace (floats) they take
+// (Round 3: slab counts chosen to fill whole rounds of 256 workgroups - 24 tiles x 21 slabs of 66 k-steps instead of 24 x 15 of 96 for
+// the [1536 x 512] gradient of c3 - measured the SAME launch time, 264 vs 242 us on a slower box: with 12 row tiles re-reading X and 2
+// column tiles re-reading the image the launch moves ~1.6 GB through L2 and is bound there, not by how its workgroups fill the CUs.)
 static int wgrad_plan(int64_t L, int64_t E, int64_t D, int* kps_out) {
   const int ksteps = (int)cdiv(L, WBK);
   const int64_t tiles = (E / WBI) * (D / WBN);
