@@ -359,8 +359,9 @@ typedef struct mhimx_nys {
 int64_t mhimx_nys_ws_floats(int64_t T);
 /* a3v[8,256,64] = softmax_n(scale q~ k^T) v  (nystrom:116,131 + the attn3 @ v of :133), lse3[8,256] */
 int mhimx_nys_a3v_fwd(void* stream, const mhimx_nys* a, float* a3v, float* lse3);
-/* out[T, 64h..] (row pitch ldo) = softmax_m(scale q k~^T) w2, w2[8,256,64] = pinv(attn2) a3v  (nystrom:114,129,133); lse1[8,T] */
-int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* w2, float* out, int64_t ldo, float* lse1);
+/* out[T, 64h..] (row pitch ldo) = softmax_m(scale q k~^T) w2, w2[8,256,64] = pinv(attn2) a3v  (nystrom:114,129,133); lse1[8,T].
+ * accumulate != 0: out += (the residual convolution of v, nystrom:135-136, written there first: one pass over out less). */
+int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* w2, float* out, int64_t ldo, float* lse1, int32_t accumulate);
 /* its backward: dq (into [T, 64h..], pitch lddq), dkl (landmark layout, pitch lddl; the S1 term only), dw2[8,256,64];
  * delta1[8,T] is scratch (rowsum(P dP)). */
 int mhimx_nys_out_bwd(void* stream, const mhimx_nys* a, const float* w2, const float* dout, int64_t ldd, const float* lse1,

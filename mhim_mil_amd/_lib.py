@@ -239,7 +239,7 @@ SYMBOLS = {
     "mhimx_sincos_add": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),
     "mhimx_nys_ws_floats": (_I64, [_I64]),
     "mhimx_nys_a3v_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P]),
-    "mhimx_nys_out_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P]),
+    "mhimx_nys_out_fwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P, C.c_int32]),
     "mhimx_nys_out_bwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P]),
     "mhimx_nys_a3v_bwd": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _P, _P, _P, _I64, _I32, _P, _I64]),
     "mhimx_nys_cls_attn": (C.c_int, [_P, C.POINTER(Nys), _P, _P, _P]),

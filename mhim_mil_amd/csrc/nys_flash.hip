@@ -623,7 +623,12 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_tok8_kernel(NyArgs g) {
     for (int tb = 0; tb < 2; ++tb) {
       const int64_t row = tk0 + 16 * tb + c;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(g.out + row * g.ldo + h * NY_D + 16 * db + 4 * kg) = o[db][tb] * inv[tb];
+      for (int db = 0; db < 4; ++db) {
+        float* op = g.out + row * g.ldo + h * NY_D + 16 * db + 4 * kg;
+        f32x4 v = o[db][tb] * inv[tb];
+        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+        *reinterpret_cast<f32x4*>(op) = v;
+      }
       if (kg == 0 && g.lse1_o) g.lse1_o[(int64_t)h * g.T + row] = lse[tb];
     }
   }
@@ -670,11 +675,11 @@ extern "C" int mhimx_nys_a3v_fwd(void* stream, const mhimx_nys* a, float* a3v, f
   return 0;
 }
 
-extern "C" int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* w2, float* out, int64_t ldo, float* lse1) {
+extern "C" int mhimx_nys_out_fwd(void* stream, const mhimx_nys* a, const float* w2, float* out, int64_t ldo, float* lse1, int32_t accumulate) {
   NyArgs g;
   if (int e = ny_base(a, g, "nys_out_fwd")) return e;
   MHIMX_CHECK_ARG(a->q && a->kl && w2 && out && aligned16(a->q) && aligned16(a->kl) && aligned16(out) && ldo % 4 == 0, "nys_out_fwd: null / unaligned operands");
-  g.w2 = w2; g.out = out; g.ldo = ldo; g.lse1_o = lse1;
+  g.w2 = w2; g.out = out; g.ldo = ldo; g.lse1_o = lse1; g.accumulate = accumulate;
   static const bool v1 = getenv("MHIMX_NYS_OUT_V1") != nullptr;         // (experiments: the landmark-split form with cross-wave sums)
   if (v1) return nytok_out_fwd((hipStream_t)stream, g);
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_out_fwd_tok8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_OUT8)));

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_kernel(NyArgs g) {
           const int d = 16 * qd + 4 * x4 + x;
           v[x] = (((part[d * NY_P68 + tk] + part[(64 + d) * NY_P68 + tk]) + part[(128 + d) * NY_P68 + tk]) + part[(192 + d) * NY_P68 + tk]) * inv;
         }
+        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(op + 4 * x4);
         *reinterpret_cast<f32x4*>(op + 4 * x4) = v;
       }
       if (qd == 0 && g.lse1_o) {

@@ -538,10 +538,12 @@ def _core_forward(qkv, conv_w, l, scale):
     fork.join(_flat((a2, z, z0, stats, chain)))
     w2 = torch.empty((HEADS, m, DH), device=dev)
     _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
-    out, lse1 = ops.nys_out_fwd(no, w2)                                # softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
     wc = conv_w.reshape(HEADS, -1).contiguous()
-    L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 1, 0),
-            "resconv")                                                # out += res_conv(v)   nystrom:135-136
+    out = torch.empty((T, INNER), device=dev)
+    L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 0, 0),
+            "resconv")                                                # out = res_conv(v)   nystrom:135-136 (written FIRST: the
+    out, lse1 = ops.nys_out_fwd(no, w2, out, accumulate=True)          # attention adds to it in its epilogue - one pass over out less)
+    #                                                                   += softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
     return out, (qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, l, scale, conv_w.shape)
 
 

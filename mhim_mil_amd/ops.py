@@ -731,12 +731,14 @@ def nys_a3v_fwd(o: NysOperands):
     return a3v, lse3
 
 
-def nys_out_fwd(o: NysOperands, w2, out=None):
-    """out [T, 512] = softmax_m(scale q k~^T) w2 (heads side by side), lse1 [8, T]."""
+def nys_out_fwd(o: NysOperands, w2, out=None, accumulate=False):
+    """out [T, 512] (= or +=) softmax_m(scale q k~^T) w2 (heads side by side), lse1 [8, T]."""
     _chk(w2, name="w2")
+    if accumulate and out is None:
+        raise L.MhimxError("nys_out_fwd: accumulate needs the buffer to add to")
     out = torch.empty((o.T, 512), device=w2.device) if out is None else out
     lse1 = torch.empty((8, o.T), device=w2.device)
-    L.check(L.lib().mhimx_nys_out_fwd(_stream(), o.ref(), _p(w2), _p(out), out.stride(0), _p(lse1)), "mhimx_nys_out_fwd")
+    L.check(L.lib().mhimx_nys_out_fwd(_stream(), o.ref(), _p(w2), _p(out), out.stride(0), _p(lse1), int(bool(accumulate))), "mhimx_nys_out_fwd")
     return out, lse1
 
 

@@ -83,6 +83,19 @@ def test_out_forward_backward(T):
     assert _rel(dw2, w.grad) < 5e-5
 
 
+def test_out_forward_accumulates_into_a_given_buffer():
+    qkv, lm = _case(2112, seed=11)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    w2 = torch.randn(8, 256, 64, device="cuda", generator=g)
+    o = ops.NysOperands(qkv, lm, 0.125)
+    plain, l0 = ops.nys_out_fwd(o, w2)
+    base = torch.randn(2112, 512, device="cuda", generator=g)
+    acc, l1 = ops.nys_out_fwd(o, w2, base.clone(), accumulate=True)
+    assert torch.equal(acc, plain + base) and torch.equal(l0, l1)     # one fp32 add per element, after the same arithmetic
+    with pytest.raises(Exception):
+        ops.nys_out_fwd(o, w2, None, accumulate=True)
+
+
 def test_runs_are_bitwise_repeatable():
     qkv, lm = _case(2112, seed=5)
     o = ops.NysOperands(qkv, lm, 0.125)
