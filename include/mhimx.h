@@ -214,7 +214,9 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  *     mhimx_pool_grad.wa_t_frag takes (jobs of one launch run concurrently: one cannot read another's output),
  * 6 = the parameter-only part of a Merge forward (mhimx_merge_fwd with .prepared = 1 then skips it): `in` is the HOST address of the
  *     mhimx_merge block (read while enqueueing), out = the Merge workspace (device), R = rows to merge, C = workspace bytes.  Up to 8
- *     per launch when they share their parameters (the bags of an accumulation window: one workspace each). */
+ *     per launch when they share their parameters (the bags of an accumulation window: one workspace each),
+ * 7 = paired planes of the TRANSPOSE in^T [C,R] made straight from in[R,C] (R % 8 == 0): the weight image of a data-gradient product
+ *     dX = dY W on the projection kernel (the TransMIL layers' to_qkv / to_out, baseline.py:213-218). */
 #define MHIMX_PREP_MAX 24
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);

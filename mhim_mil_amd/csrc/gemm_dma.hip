@@ -525,7 +525,7 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
 
 // One launch for the parameter-only preparation of a train step (a block range per job).  kind 0: out[c,r] = in[r,c];
 // kind 1: paired planes of in[R,C]; kind 2: copy R*C floats; kind 3: *(uint64*)out += 1 (device step counters);
-// kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip); kind 5: the same image of in^T.
+// kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip); kind 5: the same image of in^T; kind 7: paired planes of in^T.
 // (kind 6, several per launch - the bags of an accumulation window share the parameters but each owns a Merge workspace whose head
 // holds the query-side images: job q's workspace starts m2_shift[q.R] floats behind the first one's; the layout is the same)
 constexpr int PREP_MERGE_MAX = 8;
@@ -603,6 +603,21 @@ __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
       o[0] = __builtin_bit_cast(f4, hi);
       o[1] = __builtin_bit_cast(f4, lo);
     }
+  } else if (jb.kind == 7) {
+    // paired planes of in^T [C, R]: item (g8, m) holds in[8 g8 + u][m], u < 8 (adjacent threads = adjacent columns m: coalesced reads)
+    const int64_t R8 = R / 8, n = R8 * C;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
+      const int64_t g8 = i / C, m = i % C;
+      const float* src = jb.in + 8 * g8 * C + m;
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = src[u * C];
+      b8 hi, lo;
+      Frag<MHIMX_PREC_BF16X3>::split(x, hi, lo);
+      f4* o = reinterpret_cast<f4*>(jb.out + (m * R8 + g8) * 8);
+      o[0] = __builtin_bit_cast(f4, hi);
+      o[1] = __builtin_bit_cast(f4, lo);
+    }
   } else if (jb.kind == 6) {
     Merge2Ws w = pj.m2.w;
     const int64_t sh = pj.m2_shift[jb.R];             // (only the fields the preparation writes are shifted)
@@ -618,7 +633,7 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
   for (int i = 0; i < n; ++i) {
     pj.j[i] = jobs[i];
     MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
-    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 6, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 7, "prep_batch: unknown job kind");
     if (jobs[i].kind == 6) {
       MHIMX_CHECK_ARG(n_merge < PREP_MERGE_MAX, "prep_batch: at most %d Merge preparation jobs per launch", PREP_MERGE_MAX);
       Merge2PrepArgs m2;
@@ -634,6 +649,7 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
                     "prep_batch: the transposed fragment image needs C % 32 == 0, R % 16 == 0 and a 16-byte aligned output");
     MHIMX_CHECK_ARG(jobs[i].kind != 4 || (jobs[i].R % 32 == 0 && jobs[i].C % 16 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: the fragment image needs R % 32 == 0, C % 16 == 0 and 16-byte aligned buffers");
+    MHIMX_CHECK_ARG(jobs[i].kind != 7 || (jobs[i].R % 8 == 0 && aligned16(jobs[i].out)), "prep_batch: pairing the transpose needs R % 8 == 0 and a 16-byte aligned output");
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
   }

@@ -210,6 +210,7 @@ def finish_tail(grad, student, n_train, scale, chain=None):
 # (tools/exp_wgrad_multi.py) and the window not at all (1.52 ms on 4 streams, 2.55 ms on one, with or without): the Merge backward's tail that rode in each bag's
 # weight-gradient launch becomes a launch of its own (8 x 17.8 us), and the window on 4 streams is bound by how the graph's branches
 # overlap (average concurrency 1.7, profiles/r03_window_timeline.md), not by kernel time.  Opt-in until the tail rides elsewhere.
+_STEP_IMAGES = os.environ.get("MHIMX_STEP_IMAGES", "1") != "0"       # TransMIL: the step's weight images in the preparation launch
 _FOREACH_GRADS = os.environ.get("MHIMX_FOREACH_GRADS", "1") != "0"   # autograd's per-parameter gradient adds as ONE multi-tensor launch
 _WINDOW_WGRAD = os.environ.get("MHIMX_WINDOW_WGRAD", "0") != "0"
 _WINDOW_PROJECT = os.environ.get("MHIMX_WINDOW_PROJECT", "0") != "0"
@@ -319,6 +320,23 @@ class FusedTrainer:
                 jobs += jt
             js, prep_s = s.prep_jobs(backward=True)
             jobs += js
+        if s.baseline == "selfattn" and _STEP_IMAGES and x.shape[0] >= 2048:
+            # TransMIL: the 12 weight images of the step (to_qkv / to_out of both layers: teacher and student as stored, the student's
+            # also transposed for the data gradients) in this launch instead of 13 pair + 4 transpose launches along the step
+            table = {}
+            for model, backward in ((t if self.model_kind == "mhim" else None, False), (s, True)):
+                if model is None:
+                    continue
+                for layer in (model.online_encoder.layer1, model.online_encoder.layer2):
+                    for w in (layer.attn.to_qkv.weight.data, layer.attn.to_out[0].weight.data):
+                        img = torch.empty_like(w)
+                        jobs.append((ops.PREP_PAIR, w, img))
+                        table[(w.data_ptr(), False)] = img
+                        if backward:
+                            img_t = torch.empty((w.shape[1], w.shape[0]), device=w.device)
+                            jobs.append((ops.PREP_PAIR_T, w, img_t))
+                            table[(w.data_ptr(), True)] = img_t
+            ops.step_images(table)
         # one bf16 hi/lo image of the bag for both projections: it depends on nothing either, so it rides in the same launch
         xp = None
         if s.baseline == "attn" and s._pairable(x):
@@ -751,6 +769,7 @@ class FusedTrainer:
     def update(self):
         """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
         fl = self.flat
+        ops.step_images(None)                              # the weights change below: this step's prepared images are stale
         if self._work_a is not None:                       # overlapped form: the rest of the buffer, then wait for both halves
             work_b = torch.distributed.all_reduce(fl.grad[:self._split], group=self.pg, async_op=True)
             self._work_a.wait()

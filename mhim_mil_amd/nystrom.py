@@ -681,7 +681,7 @@ class TransLayerFn(torch.autograd.Function):
         if pad:
             dout[:pad].zero_()
         if n >= 2048 and _PREC == "bf16x3":        # data gradients as products with the transposed weights on the projection kernel
-            ops.bag_project(g, [ops.ProjHead(ops.pair_planes(ops.transpose(w_out)), None, out=dout[pad:])], act=0)
+            ops.bag_project(g, [ops.ProjHead(ops.pair_planes_t(w_out), None, out=dout[pad:])], act=0)
         elif n >= 2048 and _PREC != "f32":
             ops.gemm_nt(g, ops.transpose(w_out), out=dout[pad:], prec=_PREC)
         else:
@@ -695,7 +695,7 @@ class TransLayerFn(torch.autograd.Function):
         dqkv, dwc = _core_backward(saved, dout)
         dxn = torch.empty_like(x)
         if n >= 2048 and _PREC == "bf16x3":
-            ops.bag_project(dqkv[pad:], [ops.ProjHead(ops.pair_planes(ops.transpose(w_qkv)), None, out=dxn)], act=0)
+            ops.bag_project(dqkv[pad:], [ops.ProjHead(ops.pair_planes_t(w_qkv), None, out=dxn)], act=0)
         elif n >= 2048 and _PREC != "f32":
             ops.gemm_nt(dqkv[pad:], ops.transpose(w_qkv), out=dxn, prec=_PREC)
         else:

@@ -132,7 +132,7 @@ def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
     return heads
 
 
-PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE = 0, 1, 2, 3, 4, 5, 6
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE, PREP_PAIR_T = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def prep_batch(jobs):
@@ -153,13 +153,38 @@ def prep_batch(jobs):
     L.check(L.lib().mhimx_prep_batch(_stream(), arr, len(jobs)), "mhimx_prep_batch")
 
 
+# Weight images of ONE train step made ahead by the trainer's preparation launch (FusedTrainer: prep_batch jobs PREP_PAIR /
+# PREP_PAIR_T), keyed by (storage address, transposed).  pair_planes / pair_planes_t hand them out instead of launching; the trainer
+# clears the table when the step's backward is done - the weights change then.
+_STEP_IMAGES = {}
+
+
+def step_images(table=None):
+    """Install (or, with None, drop) the table {(data_ptr, transposed): image} of this step's prepared weight images."""
+    _STEP_IMAGES.clear()
+    if table:
+        _STEP_IMAGES.update(table)
+
+
 def pair_planes(x):
     """x [M,K] fp32 -> its paired-plane image (same shape; 8 bf16 hi | 8 bf16 lo per 8 consecutive k) for gemm_nt(paired=True)."""
     _chk(x, name="x")
+    img = _STEP_IMAGES.get((x.data_ptr(), False))
+    if img is not None and img.shape == x.shape:
+        return img
     M, K = x.shape
     out = torch.empty_like(x)
     L.check(L.lib().mhimx_pair_planes(_stream(), _p(x), x.stride(0), M, K, _p(out)), "mhimx_pair_planes")
     return out
+
+
+def pair_planes_t(x):
+    """The paired-plane image of x^T ([K, M]) - the weight operand of dX = dY W on the projection kernel."""
+    _chk(x, name="x")
+    img = _STEP_IMAGES.get((x.data_ptr(), True))
+    if img is not None and img.shape == (x.shape[1], x.shape[0]):
+        return img
+    return pair_planes(transpose(x))
 
 
 class ReduceList:

@@ -493,3 +493,35 @@ def test_student_tokens_node_equals_the_chain_of_nodes():
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][2], res[False][2])
     assert res[False][1].abs().max().item() > 0
     close(res[True][1], res[False][1], 1e-6, "flat gradient")
+
+
+def test_prepared_step_images_are_the_launched_ones():
+    """prep_batch kind PREP_PAIR_T == pair_planes(transpose(w)) bit for bit, and a FusedTrainer step that takes its 12 weight images
+    from the preparation launch ends in the same parameters as one that launches each image where it is used."""
+    from mhim_mil_amd import engine as E, ops
+    from mhim_mil_amd.engine import FusedTrainer
+    g = torch.Generator(device=DEV).manual_seed(3)
+    w = torch.randn(1536, 512, device=DEV, generator=g)
+    img = torch.empty(512, 1536, device=DEV)
+    ops.prep_batch([(ops.PREP_PAIR_T, w, img)])
+    assert torch.equal(img.view(torch.int32), ops.pair_planes(ops.transpose(w)).view(torch.int32))
+    n, d = 4200, 64                                             # >= 2048 rows: the layers run on the projection kernel
+    base = synth.mhim_state(23, input_dim=d, merge_k=5, baseline="selfattn")
+    x = torch.from_numpy(synth.bag(77, n, d)).to(DEV)
+    lab = torch.tensor([1], device=DEV)
+    finals = []
+    for on in (True, False):
+        old = E._STEP_IMAGES
+        E._STEP_IMAGES = on
+        try:
+            s = build(base, input_dim=d, **V2).train()
+            t = build(synth.spread_teacher(base), input_dim=d, **V2).train()
+            tr = FusedTrainer(s, t, lr=2e-4, aux_alpha=0.5, mm=0.999)
+            for _ in range(2):
+                tr.train_step(x, lab)
+            assert not ops._STEP_IMAGES                           # dropped by update(): the weights moved
+            finals.append({k: v.detach().clone() for k, v in s.state_dict().items()})
+        finally:
+            E._STEP_IMAGES = old
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
