@@ -491,6 +491,7 @@ __global__ __launch_bounds__(AT) void ppeg_dw_kernel(const float* __restrict__ d
 // positions; the input window slides through registers so that every input value is loaded once per strip instead of
 // once per tap, all tap indices are compile-time constants and the lanes of a wave read consecutive channels (coalesced).
 // ------------------------------------------------------------------------------------------------
+// (Round 3: FOUR channels per thread - 16-byte loads and stores, 128 threads per 512-channel row - measured SLOWER: c3 9.00 vs 8.90 ms.)
 constexpr int RS = 16;                  // residual conv: outputs per thread along the token axis
 template <int KS>
 __global__ __launch_bounds__(AT) void resconv_strip_kernel(const float* __restrict__ v, int64_t ldv, const float* __restrict__ w, int dh,
