@@ -172,6 +172,31 @@ MHIMX_DEV uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// Keyed pseudo-random PERMUTATION of 0 .. n-1, one element at a time: a 6-round Feistel network on the smallest even-bit domain
+// 2^bits >= n (round function: one 32-bit mix of the half, the round and the key), cycle-walked into [0, n) (x = E(x) until x < n; fewer
+// than 4 steps on average).  perm_bits(n) gives `bits`.
+MHIMX_DEV uint64_t feistel_index(uint64_t j, uint64_t n, int bits, uint32_t k0, uint32_t k1) {
+  const int h = bits >> 1;
+  const uint32_t hm = (1u << h) - 1u;
+  uint64_t x = j;
+  do {
+    uint32_t l = (uint32_t)(x >> h) & hm, r = (uint32_t)x & hm;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      const uint32_t f = mix32(r * 0x9E3779B1u + (rd & 1 ? k1 : k0) + (uint32_t)rd * 0x7F4A7C15u) & hm;
+      const uint32_t nl = r;
+      r = l ^ f;
+      l = nl;
+    }
+    x = ((uint64_t)l << h) | r;
+  } while (x >= n);
+  return x;
+}
+MHIMX_DEV int perm_bits(uint64_t n) {
+  int bits = 2;
+  while (((uint64_t)1 << bits) < n) bits += 2;
+  return bits;
+}
 // two-level form: a per-(seed,row) key (two mixes, amortised over the columns a thread handles) and ONE mix per element
 MHIMX_DEV uint32_t drop_row_key(uint64_t seed, uint64_t row) {
   const uint32_t r = mix32((uint32_t)row * 0x9E3779B1u ^ (uint32_t)seed);

@@ -1288,21 +1288,8 @@ __global__ __launch_bounds__(256) void random_perm_kernel(int64_t n, int bits, u
                                                          const int64_t* __restrict__ src, int64_t* __restrict__ out) {
   const uint64_t seed = eff_seed(seed0, tick);
   const uint32_t k0 = mix32((uint32_t)seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu);
-  const int h = bits >> 1;
-  const uint32_t hm = (1u << h) - 1u;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
-    uint64_t x = (uint64_t)j;
-    do {
-      uint32_t l = (uint32_t)(x >> h) & hm, r = (uint32_t)x & hm;
-#pragma unroll
-      for (int rd = 0; rd < 6; ++rd) {
-        const uint32_t f = mix32(r * 0x9E3779B1u + (rd & 1 ? k1 : k0) + (uint32_t)rd * 0x7F4A7C15u) & hm;
-        const uint32_t nl = r;
-        r = l ^ f;
-        l = nl;
-      }
-      x = ((uint64_t)l << h) | r;
-    } while ((int64_t)x >= n);
+    const uint64_t x = feistel_index((uint64_t)j, (uint64_t)n, bits, k0, k1);
     out[j] = src ? src[x] : (int64_t)x;
   }
 }

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   uint32_t* misc = wave_tot + SEL_WAVES;                                // [8]
   uint32_t* bitmap = misc + 8;                                          // [512] = 16384 bits
   uint32_t* rank = bitmap + 512;                                        // [P]
-  uint16_t* stage = reinterpret_cast<uint16_t*>(smem_raw);              // [N] row list staging (aliases everything: last phase)
+  uint16_t* klist = reinterpret_cast<uint16_t*>(rank + P);              // [N] kept rows in ascending order (the Merge draw indexes it)
+  uint16_t* stage = reinterpret_cast<uint16_t*>(smem_raw);              // [N] row list staging (aliases keys / sorted / hist: last phase)
   const int tid = threadIdx.x;
   const bool lg = largest != 0;
   const int i0 = tid * KPT;
@@ -465,10 +466,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     ntake += t ? 1u : 0u;
   }
   {
-    const uint32_t inc = wave_scan_incl(ntake);
-    uint32_t base = 0;
-    if ((tid & 63) == 63 && inc) base = atomicAdd(&misc[2], inc);
-    uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - ntake;
+    // positions in THREAD order (one block scan): the device-drawn subset below picks candidates by their position in this list,
+    // so the list must not depend on which wave reserves its slots first
+    uint32_t tot;
+    uint32_t pos = block_scan_excl(ntake, wave_tot, &tot);
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
       if (take[j]) keys[pos++] = ((uint64_t)key[j] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(i0 + j));
@@ -512,45 +513,16 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   const bool has_other = !LEAN && other != nullptr && n_other > 0;
   const int len_keep_simple = N - n_sel;
   if (dev_rand) {
-    // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host
-    // permutation: every candidate gets a counter-based random key (a bijection of its index: no ties); the n_sel
-    // smallest keys win.  Rank counting over all 1024 threads: thread (j, seg) counts segment seg of the keys.
-    uint32_t* rk32 = reinterpret_cast<uint32_t*>((cand == keys) ? sorted : keys);   // [<= 2P] 32-bit random keys, 0xFFFFFFFF pad
-    const int kpad = (k + 3) & ~3;
-    for (int j = tid; j < kpad; j += SEL_THREADS) {
-      uint32_t r = 0xFFFFFFFFu;
-      if (j < k) {
-        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
-        r = mix32(mix32(idx ^ (uint32_t)rand_seed) + (uint32_t)(rand_seed >> 32));
-        rank[j] = 0;
-      }
-      rk32[j] = r;
-    }
-    __syncthreads();
-    int S = SEL_THREADS / k;
-    S = S < 1 ? 1 : (S > 8 ? 8 : S);
-    const int seg4 = (kpad / 4 + S - 1) / S;                 // uint4 groups per segment
-    for (int it = tid; it < k * S; it += SEL_THREADS) {
-      const int j = it % k, seg = it / k;
-      const uint32_t mine = rk32[j];
-      const int g1 = min(kpad / 4, (seg + 1) * seg4);
-      uint32_t r = 0;
-#pragma unroll 8
-      for (int g = seg * seg4; g < g1; ++g) {
-        const uint4 o = reinterpret_cast<const uint4*>(rk32)[g];
-        r += (o.x < mine ? 1u : 0u) + (o.y < mine ? 1u : 0u) + (o.z < mine ? 1u : 0u) + (o.w < mine ? 1u : 0u);
-      }
-      if (S > 1) atomicAdd(&rank[j], r);
-      else rank[j] = r;
-    }
-    __syncthreads();
-    for (int j = tid; j < k; j += SEL_THREADS) {
-      const int r = (int)rank[j];
-      if (r < n_sel) {
-        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
-        atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
-        if (!LEAN && !has_other && mask_ids) mask_ids[len_keep_simple + r] = (int64_t)idx;
-      }
+    // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host permutation and without
+    // ranking random keys (k^2 / 1024 compares per thread were 3 us of this kernel): candidate pi(i), i < n_sel, of a keyed
+    // pseudo-random permutation pi of the k list positions (common.hpp: feistel_index) - one short dependent chain per pick.
+    const uint32_t k0 = mix32((uint32_t)rand_seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(rand_seed >> 32) + 0x85EBCA6Bu);
+    const int bits = perm_bits((uint64_t)k);
+    for (int i = tid; i < n_sel; i += SEL_THREADS) {
+      const uint32_t j = (uint32_t)feistel_index((uint64_t)i, (uint64_t)k, bits, k0, k1);
+      const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
+      atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
+      if (!LEAN && !has_other && mask_ids) mask_ids[len_keep_simple + i] = (int64_t)idx;
     }
   } else if (!LEAN) {
     for (int j = tid; j < n_sel; j += SEL_THREADS) {
@@ -579,6 +551,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   }
   uint32_t kept_total;
   uint32_t kpos = block_scan_excl(nkeep, wave_tot, &kept_total);
+  const uint32_t kpos0 = kpos;
   if (!LEAN && mask_ids) {
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
@@ -598,26 +571,37 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   SEL_STAMP(5);
   if (!LEAN && !rows_out) return;
 
-  // ---- 6. Merge.masking (merge.py:158-176): a uniformly random R-subset of the kept rows is merged away.  Same device:
-  // random 32-bit key per kept row, radix-select the R largest (ties by index), then ordered compactions ->
-  // rows_out = [kept rows that stay (ascending) | rows to merge (ascending)].  The pool is order independent, so the
-  // reference's random ORDER of the kept rows is not reproduced (only fp summation order differs).
+  // ---- 6. Merge.masking (merge.py:158-176): a uniformly random R-subset of the kept rows is merged away.  Same device, the same
+  // draw as step 4: the kept rows go to an LDS list in ascending order, row klist[pi2(i)], i < R, of a second keyed permutation (of the
+  // Lrows list positions) is merged (flags in the bitmap, which step 5 has finished reading), then ordered compactions ->
+  // rows_out = [kept rows that stay (ascending) | rows to merge (ascending)].  (A random key per kept row + a radix select of the R
+  // largest was 4.1 us of this kernel.)  The pool is order independent, so the reference's random ORDER of the kept rows is not
+  // reproduced (only fp summation order differs).
   const int Lrows = (int)kept_total;
   const int Lk = Lrows - merge_R;
-  uint32_t rk[KPT];
-#pragma unroll
-  for (int j = 0; j < KPT; ++j)
-    rk[j] = mix32(mix32((uint32_t)(i0 + j) ^ (uint32_t)(rand_seed >> 17)) + (uint32_t)rand_seed * 0x9E3779B1u);
-  // the keys are a bijection of the row index (xor / odd multiplies / xor-shifts): no two rows tie
-  uint32_t T2 = 0, remaining2 = 0, neq2 = 0;
   const bool partial = merge_R > 0 && merge_R < Lrows;
-  if (partial) T2 = radix_select_regs<KPT, true>(rk, kv, (uint32_t)merge_R, hist, wave_tot, misc, &remaining2, &neq2);
+  if (partial) {
+    uint32_t kp = kpos0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (kv[j]) klist[kp++] = (uint16_t)(i0 + j);
+    for (int i = tid; i < 512; i += SEL_THREADS) bitmap[i] = 0;
+    __syncthreads();
+    const uint32_t q0 = mix32((uint32_t)(rand_seed >> 17) ^ 0x85EBCA6Bu), q1 = mix32((uint32_t)rand_seed * 0x9E3779B1u + 0xC2B2AE35u);
+    const int bits2 = perm_bits((uint64_t)Lrows);
+    for (int i = tid; i < merge_R; i += SEL_THREADS) {
+      const uint32_t row = klist[(uint32_t)feistel_index((uint64_t)i, (uint64_t)Lrows, bits2, q0, q1)];
+      atomicOr(&bitmap[row >> 5], 1u << (row & 31));
+    }
+    __syncthreads();
+  }
   SEL_STAMP(6);
   bool mrg[KPT];
   uint32_t nstay = 0, nmrg = 0;
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    const bool m = kv[j] && (merge_R >= Lrows || (partial && rk[j] >= T2));
+    const int i = i0 + j;
+    const bool m = kv[j] && (merge_R >= Lrows || (partial && ((bitmap[i >> 5] >> (i & 31)) & 1u)));
     mrg[j] = m;
     nmrg += m ? 1u : 0u;
     nstay += (kv[j] && !m) ? 1u : 0u;
@@ -887,9 +871,8 @@ __global__ __launch_bounds__(SEL_THREADS) void selm_compact_kernel(int64_t N, in
   }
 }
 
-static size_t select_small_smem(int P) {          // keys+sorted, hist, wave_tot, misc, bitmap, rank; >= the 32 KB row staging
-  const size_t a = (size_t)2 * P * 8 + (size_t)(SEL_COPIES * SEL_BINS + SEL_WAVES + 8 + 512 + P) * 4;
-  return a < 32768 ? 32768 : a;
+static size_t select_small_smem(int P) {          // keys+sorted, hist, wave_tot, misc, bitmap, rank, kept list (the 32 KB row staging aliases the head)
+  return (size_t)2 * P * 8 + (size_t)(SEL_COPIES * SEL_BINS + SEL_WAVES + 8 + 512 + P) * 4 + 16384 * 2;
 }
 
 static int next_pow2(int v) {
