@@ -192,6 +192,32 @@ MHIMX_DEV uint64_t feistel_index(uint64_t j, uint64_t n, int bits, uint32_t k0, 
   } while (x >= n);
   return x;
 }
+// The same for SMALL lists inside a kernel (n <= 2^16: the select's subset draws), tuned for a wave that waits for its slowest lane:
+// the domain is the smallest power of two >= n with ANY bit count (halves of floor / ceil(bits / 2) bits: round r XORs one half with a
+// function of the other, a bijection whatever the sizes) - fewer than 2 steps on average instead of up to 4, and the longest walk among
+// the lanes of a wave halves with it; 32-bit arithmetic, two multiplies per round, 4 rounds.
+MHIMX_DEV uint32_t feistel_small(uint32_t j, uint32_t n, int bits, uint32_t k0, uint32_t k1) {
+  const int rb = bits >> 1, lb = bits - rb;
+  const uint32_t rm = (1u << rb) - 1u, lm = (1u << lb) - 1u;
+  uint32_t x = j;
+  do {
+    uint32_t l = x >> rb, r = x & rm;
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      uint32_t f = ((rd & 1) ? l : r) * 0x9E3779B1u + ((rd & 1) ? k1 : k0) + (uint32_t)rd * 0x7F4A7C15u;
+      f ^= f >> 15; f *= 0x846ca68bU; f ^= f >> 13;
+      if (rd & 1) r ^= f & rm;
+      else l ^= f & lm;
+    }
+    x = (l << rb) | r;
+  } while (x >= n);
+  return x;
+}
+MHIMX_DEV int small_perm_bits(uint32_t n) {
+  int bits = 2;
+  while ((1u << bits) < n) ++bits;
+  return bits;
+}
 MHIMX_DEV int perm_bits(uint64_t n) {
   int bits = 2;
   while (((uint64_t)1 << bits) < n) bits += 2;

@@ -515,11 +515,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   if (dev_rand) {
     // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host permutation and without
     // ranking random keys (k^2 / 1024 compares per thread were 3 us of this kernel): candidate pi(i), i < n_sel, of a keyed
-    // pseudo-random permutation pi of the k list positions (common.hpp: feistel_index) - one short dependent chain per pick.
+    // pseudo-random permutation pi of the k list positions (common.hpp: feistel_small) - one short dependent chain per pick.
     const uint32_t k0 = mix32((uint32_t)rand_seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(rand_seed >> 32) + 0x85EBCA6Bu);
-    const int bits = perm_bits((uint64_t)k);
+    const int bits = small_perm_bits((uint32_t)k);
     for (int i = tid; i < n_sel; i += SEL_THREADS) {
-      const uint32_t j = (uint32_t)feistel_index((uint64_t)i, (uint64_t)k, bits, k0, k1);
+      const uint32_t j = feistel_small((uint32_t)i, (uint32_t)k, bits, k0, k1);
       const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(cand[j] & 0xFFFFFFFFull);
       atomicOr(&bitmap[idx >> 5], 1u << (idx & 31));
       if (!LEAN && !has_other && mask_ids) mask_ids[len_keep_simple + i] = (int64_t)idx;
@@ -588,9 +588,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     for (int i = tid; i < 512; i += SEL_THREADS) bitmap[i] = 0;
     __syncthreads();
     const uint32_t q0 = mix32((uint32_t)(rand_seed >> 17) ^ 0x85EBCA6Bu), q1 = mix32((uint32_t)rand_seed * 0x9E3779B1u + 0xC2B2AE35u);
-    const int bits2 = perm_bits((uint64_t)Lrows);
+    const int bits2 = small_perm_bits((uint32_t)Lrows);
     for (int i = tid; i < merge_R; i += SEL_THREADS) {
-      const uint32_t row = klist[(uint32_t)feistel_index((uint64_t)i, (uint64_t)Lrows, bits2, q0, q1)];
+      const uint32_t row = klist[feistel_small((uint32_t)i, (uint32_t)Lrows, bits2, q0, q1)];
       atomicOr(&bitmap[row >> 5], 1u << (row & 31));
     }
     __syncthreads();
