@@ -70,46 +70,43 @@ MHIMX_DEV void ny_split4(const f32x4& a, bf4& hi, bf4& lo) {
     lo[q] = (__bf16)(a[q] - (float)h);
   }
 }
-// RM image: fragment (tb, ks, hl) at ((tb*2 + ks)*2 + hl) KiB, lane (token & 15, dim octet & 3) x 16 B (a thread owns half a slot).
-// The 16 lanes of a ds_write_b64 group hold ONE token and the 16 dim quads: their slots differ in (octet, ks) only, which are 256 B
-// and 2 KiB apart - two bank pairs for 16 lanes.  The token index is XORed with (octet + 4 ks), readers apply the same XOR (a
-// permutation inside aligned groups of 8 slots: the 16-lane groups of a ds_read_b128 still cover all 64 banks).  SQ_LDS_BANK_CONFLICT
-// was 56 % of the LDS-active cycles of the landmark-column kernels.
-MHIMX_DEV void ny_store_rm(char* img, int tid, const f32x4 (&r)[2]) {
+// Token tile [64 tokens, 64 dims] in LDS: ONE row-major pair of bf16 planes per matrix (hi at +0, lo at +8 KiB; 128-byte rows, the
+// 16-byte chunk index XORed with row & 7) serves BOTH fragment forms - "RM" (index = token, k = 8 consecutive dims: a 16-byte read of
+// the token's row) and "TR" (index = dim, k = 8 tokens in accumulator-pair order: two ds_read_b64_tr_b16, see nys_flash_tok.hip for
+// the lane mapping of that instruction).  The first form kept two ready-made fragment images per matrix (RM and TR): the tile was
+// split twice and the TR image written with eight 4-byte stores per thread (56 % of the LDS-active cycles were bank conflicts before
+// a slot swizzle, profiles/r03_pmc_lds_c3.md); here a thread writes its 4 dims of a token as ONE 8-byte store per plane (the 16 lanes of
+// a store group = one token's row: conflict-free), and all three reads are conflict-free under the XOR.
+typedef __attribute__((address_space(3))) char* ny_lds;
+typedef __bf16 ny_bf4 __attribute__((ext_vector_type(4)));
+MHIMX_DEV void ny_store_pl(char* pl, int tid, const f32x4 (&r)[2]) {
   const int g = tid & 15, t = 2 * (tid >> 4);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     bf4 hi, lo;
     ny_split4(r[e], hi, lo);
-    const int kgd = (g >> 1) & 3, ks = g >> 3;
-    char* p = img + ((((t + e) >> 4) * 2 + ks) * 2) * 1024 + (kgd * 16 + (((t + e) & 15) ^ (kgd + 4 * ks))) * 16 + (g & 1) * 8;
+    const int row = t + e;
+    char* p = pl + row * 128 + (((g >> 1) ^ (row & 7)) << 4) + (g & 1) * 8;
     *reinterpret_cast<bf4*>(p) = hi;
-    *reinterpret_cast<bf4*>(p + 1024) = lo;
+    *reinterpret_cast<bf4*>(p + 8192) = lo;
   }
 }
-// TR image: fragment (db, ts, hl) at ((db*2 + ts)*2 + hl) KiB, lane (dim & 15, kg) x 16 B; token u of a 32-token step sits in
-// k-octet kg = (u & 15) >> 2 at slot j = 4 (u >> 4) + (u & 3) - the order of an accumulator pair
-MHIMX_DEV void ny_store_tr(char* img, int tid, const f32x4 (&r)[2]) {
-  const int g = tid & 15, t = 2 * (tid >> 4), u = t & 31;
-  const int j = 4 * (u >> 4) + (u & 3), kgt = (u & 15) >> 2;
-  const int db = g >> 2;                                       // slot index ^ db: the four d blocks are 4 KiB apart (same banks)
-  char* base = img + ((db * 2 + (t >> 5)) * 2) * 1024 + (kgt * 16 + (g & 3) * 4) * 16 + j * 2;
-  bf4 ah, al, bh, bl;
-  ny_split4(r[0], ah, al);
-  ny_split4(r[1], bh, bl);
+MHIMX_DEV f32x4 ny_frag_rm(const char* pl, int tb, int ks, int hl, int lane) {
+  const int c = lane & 15, kg = lane >> 4;
+  return *reinterpret_cast<const f32x4*>(pl + hl * 8192 + (16 * tb + c) * 128 + (((4 * ks + kg) ^ (c & 7)) << 4));
+}
+// TR fragment (db, ts): lane (dim c, kg) holds tokens 32 ts + {4 kg + i, 16 + 4 kg + i} of dim 16 db + c
+MHIMX_DEV f32x4 ny_frag_tr(const char* pl, int db, int ts, int hl, int lane) {
+  typedef __attribute__((address_space(3))) ny_bf4* P;
+  const int c = lane & 15, kg = lane >> 4;
+  const int r = 4 * kg + (c >> 2);
+  const ny_lds a = (ny_lds)pl + hl * 8192 + (32 * ts + r) * 128 + (((2 * db + ((c & 3) >> 1)) ^ (r & 7)) << 4) + (c & 1) * 8;
+  const ny_bf4 x = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((P)a);
+  const ny_bf4 y = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((P)(a + 2048));
+  bf8 o;
 #pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    bf2 h2, l2;
-    h2[0] = ah[x]; h2[1] = bh[x]; l2[0] = al[x]; l2[1] = bl[x];
-    *reinterpret_cast<bf2*>(base + (x ^ db) * 16) = h2;
-    *reinterpret_cast<bf2*>(base + (x ^ db) * 16 + 1024) = l2;
-  }
-}
-MHIMX_DEV f32x4 ny_frag_rm(const char* img, int tb, int ks, int hl, int lane) {
-  return *reinterpret_cast<const f32x4*>(img + (((tb * 2 + ks) * 2 + hl) * 64 + (lane ^ ((lane >> 4) + 4 * ks))) * 16);
-}
-MHIMX_DEV f32x4 ny_frag_tr(const char* img, int db, int ts, int hl, int lane) {
-  return *reinterpret_cast<const f32x4*>(img + (((db * 2 + ts) * 2 + hl) * 64 + (lane ^ db)) * 16);
+  for (int j = 0; j < 4; ++j) { o[j] = x[j]; o[4 + j] = y[j]; }
+  return __builtin_bit_cast(f32x4, o);
 }
 
 // ---- landmark-side fragments (global fp32 -> registers), M = [256, 64] of this head with row pitch ldm, the wave's landmarks at lm0
@@ -183,8 +180,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_fwd_kernel(NyArgs g) {
   ny_load(vb, g.ld, (int64_t)t_begin * NY_TT, tid, rv);
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
-    ny_store_rm(sm, tid, rk);
-    ny_store_tr(sm + NY_IMG, tid, rv);
+    ny_store_pl(sm, tid, rk);
+    ny_store_pl(sm + NY_IMG, tid, rv);
     __syncthreads();
     if (t + 1 < t_end) {
       ny_load(kb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rk);
@@ -289,7 +286,7 @@ __global__ __launch_bounds__(256) void ny_a3v_merge_kernel(const float* part, in
 // ===========================================================================================================================
 __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  float* rowst = reinterpret_cast<float*>(sm + 4 * NY_IMG);    // lse1[64] | delta[64]
+  float* rowst = reinterpret_cast<float*>(sm + 2 * NY_IMG);    // lse1[64] | delta[64]
   NY_IDS;
   NyLM kf, wf;
   ny_lm_frags(g.kl + h * NY_D, g.ldl, lm0, lane, kf);
@@ -310,10 +307,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
   load_st(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
-    ny_store_rm(sm, tid, rq);
-    ny_store_rm(sm + NY_IMG, tid, rg);
-    ny_store_tr(sm + 2 * NY_IMG, tid, rq);
-    ny_store_tr(sm + 3 * NY_IMG, tid, rg);
+    ny_store_pl(sm, tid, rq);
+    ny_store_pl(sm + NY_IMG, tid, rg);
     if (tid < 128) rowst[tid] = rst;
     __syncthreads();
     if (t + 1 < t_end) {
@@ -358,8 +353,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_bwd_l_kernel(NyArgs g) {
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        ny_mma_a<NY_LB>(ny_frag_tr(sm + 3 * NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + 3 * NY_IMG, db, ts, 1, lane), ph, pl, dw2[db]);
-        ny_mma_a<NY_LB>(ny_frag_tr(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dkl[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm + NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + NY_IMG, db, ts, 1, lane), ph, pl, dw2[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm, db, ts, 0, lane), ny_frag_tr(sm, db, ts, 1, lane), sh, sl, dkl[db]);
       }
     }
   }
@@ -437,9 +432,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
   ny_load(vb, g.ld, (int64_t)t_begin * NY_TT, tid, rv);
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
-    ny_store_rm(sm, tid, rk);
-    ny_store_rm(sm + NY_IMG, tid, rv);
-    ny_store_tr(sm + 2 * NY_IMG, tid, rk);
+    ny_store_pl(sm, tid, rk);
+    ny_store_pl(sm + NY_IMG, tid, rv);
     __syncthreads();
     if (t + 1 < t_end) {
       ny_load(kb, g.ld, (int64_t)(t + 1) * NY_TT, tid, rk);
@@ -473,7 +467,7 @@ __global__ __launch_bounds__(NY_THREADS) void ny_a3v_bwd_l_kernel(NyArgs g) {
       }
 #pragma unroll
       for (int db = 0; db < 4; ++db)
-        ny_mma_a<NY_LB>(ny_frag_tr(sm + 2 * NY_IMG, db, ts, 0, lane), ny_frag_tr(sm + 2 * NY_IMG, db, ts, 1, lane), sh, sl, dq[db]);
+        ny_mma_a<NY_LB>(ny_frag_tr(sm, db, ts, 0, lane), ny_frag_tr(sm, db, ts, 1, lane), sh, sl, dq[db]);
     }
   }
   float* p1 = g.part + ((int64_t)h * g.nch + ch) * NY_PART;
@@ -635,8 +629,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_tok8_kernel(NyArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int NY_SM_BWD_L = 4 * NY_IMG + 128 * 4;
-constexpr int NY_SM_A3_L = 3 * NY_IMG;
+constexpr int NY_SM_BWD_L = 2 * NY_IMG + 128 * 4;
+constexpr int NY_SM_A3_L = 2 * NY_IMG;
 
 static int ny_base(const mhimx_nys* a, NyArgs& g, const char* who) {
   MHIMX_CHECK_ARG(a && a->T >= NY_TT && a->T % NY_TT == 0, "%s: T must be a positive multiple of 64", who);
