@@ -777,6 +777,76 @@ __global__ __launch_bounds__(NY8_THREADS) void ny_out_bwd_q8_kernel(NyArgs g) {
   }
 }
 
+// ===========================================================================================================================
+// The cls row r[token] = sum_lm u[lm] softmax_n(q~ k^T)[lm, token] (nystrom:143-150) in the token-owning form: q~ as row-major planes,
+// a wave owns 16 tokens and all 256 landmarks (S^T[16 lb] in registers), no barrier in the loop.
+// ===========================================================================================================================
+__global__ __launch_bounds__(NY8_THREADS) void ny_cls_row8_kernel(NyArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char* q_hi = sm;
+  char* q_lo = sm + NY_PLANE;
+  float* lmst = reinterpret_cast<float*>(sm + 2 * NY_PLANE);   // lse3[256] | u[256]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, kg = lane >> 4;
+  const int h = blockIdx.y, ch = blockIdx.x;
+  int t_begin, t_end;
+  ny_chunk(g, ch, t_begin, t_end);
+  ny_plane_fill(q_hi, q_lo, g.ql + h * NY_D, g.ldl, tid);
+  if (tid < NY_M) {
+    lmst[tid] = g.lse3[h * NY_M + tid];
+    lmst[NY_M + tid] = g.u[h * NY_M + tid];
+  }
+  __syncthreads();
+  int lm_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) lm_off[ks] = c * 128 + (((4 * ks + kg) ^ (c & 7)) << 4);
+  const float* kb = g.k + h * NY_D;
+  const int64_t grp_end = (int64_t)t_end * 4;
+  for (int64_t grp = (int64_t)t_begin * 4 + w; grp < grp_end; grp += NY8_NW) {
+    const int64_t tok = grp * 16 + c;
+    f32x4 kh[2], kl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* pk = kb + tok * g.ld + 32 * ks + 8 * kg;
+      ny_split44(*reinterpret_cast<const f32x4*>(pk), *reinterpret_cast<const f32x4*>(pk + 4), kh[ks], kl[ks]);
+    }
+    float r = 0.f;
+    f32x4 fa[4], fb[4];                                        // (ks0 hi, lo, ks1 hi, lo) of one landmark block
+    auto ld_lm = [&](int lb, f32x4 (&f)[4]) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int o = lb * 2048 + lm_off[ks];
+        f[2 * ks] = *reinterpret_cast<const f32x4*>(q_hi + o);
+        f[2 * ks + 1] = *reinterpret_cast<const f32x4*>(q_lo + o);
+      }
+    };
+    auto blk = [&](int lb, const f32x4 (&f)[4]) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      s = mt_mfma(f[1], kh[0], s);
+      s = mt_mfma(f[0], kl[0], s);
+      s = mt_mfma(f[0], kh[0], s);
+      s = mt_mfma(f[3], kh[1], s);
+      s = mt_mfma(f[2], kl[1], s);
+      s = mt_mfma(f[2], kh[1], s);
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(lmst + 16 * lb + 4 * kg);
+      const f32x4 uu = *reinterpret_cast<const f32x4*>(lmst + NY_M + 16 * lb + 4 * kg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r += uu[i] * NY_EXP2(s[i] * g.sl2e - ls[i]);
+    };
+    ld_lm(0, fa);
+#pragma unroll
+    for (int lb = 0; lb < 16; lb += 2) {
+      ld_lm(lb + 1, fb);
+      blk(lb, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (lb + 2 < 16) ld_lm(lb + 2, fa);
+      blk(lb + 1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    r = ny_kgsum(r);
+    if (kg == 0) g.out[(int64_t)h * g.T + tok] = r;
+  }
+}
+
 constexpr int NY_SM_OUT_FWD = NY_IMG + 512 * 4 + 4 * 64 * NY_P68 * 4;
 constexpr int NY_SM_BWD_Q = 2 * NY_IMG + 128 * 4 + NY_PART_F * 4;
 constexpr int NY_SM_A3_T = 2 * NY_IMG + 512 * 4 + NY_PART_F * 4;
@@ -827,6 +897,17 @@ int nytok_a3v_bwd_t(hipStream_t st, const NyArgs& g0, int mode) {
   }
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_A3_T));
                         MHIMX_HIP(hipFuncSetAttribute((const void*)ny_a3v_bwd_t_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NY_SM_CLS)));
+  if (mode == 1 && !v1) {
+    constexpr int sm_cls = 2 * NY_PLANE + 2 * NY_M * 4;
+    NyArgs gc = g0;                                            // 66 KB of LDS, 84 VGPRs: two workgroups per CU
+    static const int cls_ch = getenv("MHIMX_NYS_CLSCH") ? atoi(getenv("MHIMX_NYS_CLSCH")) : 64;
+    const int64_t tiles = gc.T / NY_TT;
+    gc.nch = (int)(tiles < cls_ch ? tiles : cls_ch);
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)ny_cls_row8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sm_cls)));
+    hipLaunchKernelGGL(ny_cls_row8_kernel, dim3(gc.nch, NY_H), dim3(NY8_THREADS), sm_cls, st, gc);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   if (mode == 0) hipLaunchKernelGGL(ny_a3v_bwd_t_kernel<0>, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_A3_T, st, g);
   else hipLaunchKernelGGL(ny_a3v_bwd_t_kernel<1>, dim3(g.nch, NY_H), dim3(NY_THREADS), NY_SM_CLS, st, g);
   MHIMX_LAUNCH_CHECK();
