@@ -480,6 +480,7 @@ def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm, accumulate
 # per step cost more in cross-queue signalling (~60 us each on this ROCm build) than the overlapped launches save, so the fork is OPT-IN
 # (MHIMX_NYS_FORK=1); the accumulation window of the ABMIL trainer forks once per 8 bags and gains 1.7x from the same mechanism.
 _FORK = os.environ.get("MHIMX_NYS_FORK", "0") != "0"
+_CONV_FIRST = os.environ.get("MHIMX_NYS_CONV_FIRST", "1") != "0"
 _SIDE = {}
 
 
@@ -539,11 +540,15 @@ def _core_forward(qkv, conv_w, l, scale):
     w2 = torch.empty((HEADS, m, DH), device=dev)
     _heads_mm("nn", batched(z), batched(a3v), batched(w2), HEADS)     # pinv (a3 v)
     wc = conv_w.reshape(HEADS, -1).contiguous()
-    out = torch.empty((T, INNER), device=dev)
-    L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 0, 0),
-            "resconv")                                                # out = res_conv(v)   nystrom:135-136 (written FIRST: the
-    out, lse1 = ops.nys_out_fwd(no, w2, out, accumulate=True)          # attention adds to it in its epilogue - one pass over out less)
-    #                                                                   += softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
+    if _CONV_FIRST:
+        out = torch.empty((T, INNER), device=dev)
+        L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 0, 0),
+                "resconv")                                            # out = res_conv(v)   nystrom:135-136 (written FIRST: the
+        out, lse1 = ops.nys_out_fwd(no, w2, out, accumulate=True)      # attention adds to it in its epilogue - one pass over out less)
+    else:
+        out, lse1 = ops.nys_out_fwd(no, w2)                            # softmax_m(q k~^T) (pinv a3 v) -> [T, (h d)]
+        L.check(lib.mhimx_resconv(_st(), _ptr(qkv, 2 * INNER), ld, _ptr(wc), wc.shape[1], DH, T, INNER, _ptr(out), INNER, 1, 0),
+                "resconv")                                            # out += res_conv(v)   nystrom:135-136
     return out, (qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, l, scale, conv_w.shape)
 
 
