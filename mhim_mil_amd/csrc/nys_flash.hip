@@ -595,7 +595,8 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_tok8_kernel(NyArgs g) {
         f[2 * db + 1] = *reinterpret_cast<const f32x4*>(sm + 65536 + ((db * 8 + sx) * 2 + 1) * 1024 + lane * 16);
       }
     };
-    f32x4 wa[8], wb[8];
+    f32x4 wa[8], wb[8], old[4][2];
+    NY_ZERO(old, 4, 2);
     ld_w(0, wa);
 #pragma unroll
     for (int sx = 0; sx < 8; sx += 2) {
@@ -607,6 +608,13 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_tok8_kernel(NyArgs g) {
       for (int db = 0; db < 4; ++db) ny_mma_a<2>(wa[2 * db], wa[2 * db + 1], ph, pl, o[db]);
       __builtin_amdgcn_sched_barrier(0);
       if (sx + 2 < 8) ld_w(sx + 2, wa);
+      if (sx == 4 && g.accumulate) {                            // out += : what the buffer holds, requested under the last PV steps (half the
+#pragma unroll                                                  // score registers are free by now); a read at the store was +10 us per launch
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int db = 0; db < 4; ++db)
+            old[db][tb] = *reinterpret_cast<const f32x4*>(g.out + (tk0 + 16 * tb + c) * g.ldo + h * NY_D + 16 * db + 4 * kg);
+      }
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) ny_split44(s[2 * sx + 2][tb], s[2 * sx + 3][tb], ph[tb], pl[tb]);
 #pragma unroll
@@ -619,8 +627,13 @@ __global__ __launch_bounds__(NY_THREADS) void ny_out_fwd_tok8_kernel(NyArgs g) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         float* op = g.out + row * g.ldo + h * NY_D + 16 * db + 4 * kg;
-        f32x4 v = o[db][tb] * inv[tb];
-        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+        f32x4 v;                                               // (rounded product, then the add: out += is bit for bit plain + old)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float pr = o[db][tb][i] * inv[tb];
+          asm volatile("" : "+v"(pr));                         // (no fused multiply-add across the two roundings)
+          v[i] = pr + old[db][tb][i];
+        }
         *reinterpret_cast<f32x4*>(op) = v;
       }
       if (kg == 0 && g.lse1_o) g.lse1_o[(int64_t)h * g.T + row] = lse[tb];

@@ -35,6 +35,7 @@ def timed(name, fn):
 
 timed("a3v_fwd", lambda: ops.nys_a3v_fwd(no))
 timed("out_fwd", lambda: ops.nys_out_fwd(no, w2, out))
+timed("out_fwd+=", lambda: ops.nys_out_fwd(no, w2, out, accumulate=True))
 timed("out_bwd", lambda: ops.nys_out_bwd(no, w2, dout, lse1, dqkv, dlm))
 timed("a3v_bwd", lambda: ops.nys_a3v_bwd(no, a3v, da3v, lse3, dqkv, dlm, True))
 print("checks", float(dqkv.abs().sum()), float(dlm.abs().sum()))
