@@ -21,7 +21,7 @@ int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_p
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
-constexpr int TN_SLABS = 64;           // split-reduction slabs for d_wa = du^T T (fills the chip: 4 tiles x 64 = 256 workgroups)
+constexpr int TN_SLABS = 128;          // split-reduction slabs for d_wa = du^T T (4 tiles x 128 = 512 workgroups: two per CU once the row table is <= 12 KiB)
 
 MHIMX_DEV float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -974,8 +974,11 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     // split the long reduction (the library raises the slab count until the launch fills the chip, up to the workspace)
     int splits = gr->splits > 1 ? gr->splits : 1;
     if (splits > TN_SLABS) splits = TN_SLABS;
+    if (Ms[seg] < 65536 && splits > 64) splits = 64;
     if (Ms[seg] < 2048) splits = 1;
-    t.splits = splits; t.ws = w.tn_ws; t.ws_floats = (int64_t)TN_SLABS * A * E;
+    // (the library raises the slab count up to the workspace it is shown: 128 slabs pay at c5 - 200 000 rows, the row table of a slab
+    // shrinks to 12 KiB and two workgroups share a CU, 3.96 -> 3.92 ms per step - and cost 2 us at c2, so short bags are shown 64)
+    t.splits = splits; t.ws = w.tn_ws; t.ws_floats = (int64_t)(Ms[seg] >= 65536 ? TN_SLABS : 64) * A * E;
     t.defer = (io->M2 == 0 && !gated) ? gr->defer : nullptr;        // one GEMM per workspace: its slabs may wait for the flush
     static_assert(sizeof(mhimx_gemm_tn_args) <= sizeof(((mhimx_parked_gemm*)nullptr)->blob), "mhimx_parked_gemm.blob too small");
     if (t.defer && fused && !t.defer->parked.pending) {
