@@ -523,6 +523,54 @@ __global__ __launch_bounds__(AT) void resconv_strip_kernel(const float* __restri
       *p = accumulate ? *p + acc[j] : acc[j];
     }
 }
+// The same stencil with the input window staged ONCE in LDS: a workgroup = 128 output tokens x 64 channels, the 160 input rows (16 of
+// halo on each side) arrive by 16-byte loads (a row's 256 bytes from 16 lanes) and every thread slides its 16-output strips over the
+// LDS copy (64 lanes = 64 consecutive channels of a row: conflict-free).  The register-sliding form above reads every input row three
+// times through L2 (48 rows per 16 outputs).
+constexpr int RT_ROWS = 128, RT_CH = 64;
+template <int KS>
+__global__ __launch_bounds__(256) void resconv_tile_kernel(const float* __restrict__ v, int64_t ldv, const float* __restrict__ w, int dh,
+                                                           int64_t T, int C, float* __restrict__ out, int64_t ldo, int accumulate,
+                                                           int flip) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int P = KS / 2, IN = RT_ROWS + 2 * P;
+  __shared__ __attribute__((aligned(16))) float tile[IN * RT_CH];
+  const int tid = threadIdx.x, c0 = blockIdx.y * RT_CH;
+  const int64_t t0 = (int64_t)blockIdx.x * RT_ROWS;
+  for (int idx = tid; idx < IN * (RT_CH / 4); idx += 256) {
+    const int row = idx / (RT_CH / 4), c4 = idx % (RT_CH / 4);
+    const int64_t tt = t0 - P + row;
+    f4 x = {0.f, 0.f, 0.f, 0.f};
+    if (tt >= 0 && tt < T) x = *reinterpret_cast<const f4*>(v + tt * ldv + c0 + 4 * c4);
+    *reinterpret_cast<f4*>(tile + row * RT_CH + 4 * c4) = x;
+  }
+  const int c = tid & 63, rg = tid >> 6;
+  const float* wh = w + ((c0 + c) / dh) * KS;
+  float wr[KS];
+#pragma unroll
+  for (int tau = 0; tau < KS; ++tau) wr[tau] = flip ? wh[KS - 1 - tau] : wh[tau];
+  __syncthreads();
+#pragma unroll 1
+  for (int strip = 0; strip < 2; ++strip) {
+    const int r0 = 32 * rg + 16 * strip;                       // first output row of the strip (tile-relative); its window starts at r0
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16 + KS - 1; ++r) {
+      const float x = tile[(r0 + r) * RT_CH + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (r - j >= 0 && r - j < KS) acc[j] = fmaf(wr[r - j], x, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (t0 + r0 + j < T) {
+        float* p = out + (t0 + r0 + j) * ldo + c0 + c;
+        *p = accumulate ? *p + acc[j] : acc[j];
+      }
+  }
+}
 // dw partials: block (x = token chunk, y = 256-channel group = 4 heads of 64); part[x][h*KS + tau]
 template <int KS>
 __global__ __launch_bounds__(AT) void resconv_dw_strip_kernel(const float* __restrict__ dout, int64_t ldo, const float* __restrict__ v,
@@ -853,6 +901,13 @@ extern "C" int mhimx_pinv_init_bwd(void* stream, const float* dz, const float* z
 extern "C" int mhimx_resconv(void* stream, const float* v, int64_t ldv, const float* w, int64_t KS, int64_t dh, int64_t T, int64_t C,
                              float* out, int64_t ldo, int32_t accumulate, int32_t flip) {
   MHIMX_CHECK_ARG(v && w && out && KS % 2 == 1 && C % dh == 0, "resconv: bad args");
+  static const bool strips = getenv("MHIMX_RESCONV_STRIPS") != nullptr;  // (experiments: the register-sliding strips)
+  if (KS == 33 && !strips && C % RT_CH == 0 && ldv % 4 == 0 && ((uintptr_t)v & 15) == 0) {
+    hipLaunchKernelGGL(resconv_tile_kernel<33>, dim3((unsigned)cdiv(T, RT_ROWS), (unsigned)(C / RT_CH)), dim3(256), 0, (hipStream_t)stream, v, ldv,
+                       w, (int)dh, T, (int)C, out, ldo, accumulate, flip);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
   if (KS == 33) {        // the reference's residual_conv_kernel (nystrom_attention.py:43): register-sliding strips
     hipLaunchKernelGGL(resconv_strip_kernel<33>, dim3((unsigned)cdiv(T, RS), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, v, ldv,
                        w, (int)dh, T, (int)C, out, ldo, accumulate, flip);
