@@ -609,6 +609,9 @@ constexpr int PS = 8;                   // PPEG: outputs per thread along a grid
 // A thread owns one channel of a PS x PSY patch of grid cells: every input row it loads (PS + 6 values) feeds up to PSY output rows,
 // (PSY + 6)(PS + 6) loads for PS PSY outputs = 4.4 per output instead of 12.25 with one-row strips - the stencil is bound by L2 -> L1
 // traffic of the re-read neighbour rows (1.2 GB per launch at N = 50 000, C = 512 with one-row strips).
+// (Round 3: the same patches fed from an LDS copy of a 22 x 22 x 32-channel window - 1.9 loads per output through L2 - measured SLOWER,
+// c3 8.73 vs 8.65 ms: 61 KB of LDS leave 8 waves per CU to hide 140 dependent LDS reads per thread; the 33-tap token-axis convolution
+// above, with 3 reads per output, does gain from its LDS window.)
 constexpr int PSY = 4;
 template <int FLIP>
 __global__ __launch_bounds__(AT) void ppeg_strip_kernel(const float* __restrict__ in, int64_t N, int C, int H, int64_t wrapN,
