@@ -12,6 +12,8 @@ c_f32p = C.c_void_p
 c_i64p = C.c_void_p
 c_u8p = C.c_void_p
 
+ABI_VERSION = 400          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
+
 ACT = {None: 0, "none": 0, "identity": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"f32": 0, "f16s": 1, "bf16x3": 2}
 
@@ -274,6 +276,9 @@ def lib():
         fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if L.mhimx_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} is ABI version {L.mhimx_version()}, this binding expects {ABI_VERSION}: a stale build "
+                           f"(rebuild with `python -m mhim_mil_amd.build --force`)")
     _lib = L
     return L
 

@@ -480,9 +480,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   // ---- 3. order the candidates: (value desc, index asc) == key desc
   // (the device-drawn random subset below depends on the candidate SET only: no ordering needed unless it is returned)
   const bool dev_rand = LEAN || (use_rand && !perm && n_sel < k);
-  const uint64_t* cand = sorted;
+  // The device-drawn subset ALWAYS picks by position in `keys` - the candidates in ascending row index (thread order) - whether or not the
+  // value-ordered list is wanted as well: the same (seed, tick) masks the same rows with and without topk_out / LEAN.
+  const uint64_t* cand = keys;
   if (LEAN || (dev_rand && !topk_out)) {
-    cand = keys;
+    // (no value-ordered list needed)
   } else if (k <= 2048) {
     for (int j = tid; j < k; j += SEL_THREADS) {
       const uint64_t mine = keys[j];

@@ -228,6 +228,7 @@ class _SplitStep:
         self.g_fb.replay()                                     # ... + the buffer's tail filled
         tr._all_reduce(tr.flat.grad)
         self.g_up.replay()                                     # the tail averaged back + Adam + EMA
+        ops.step_images(None)                                  # (nothing on the host installed any; a replay must not leave any either)
 
 
 class FusedTrainer:
@@ -254,7 +255,11 @@ class FusedTrainer:
         self.model_kind = model
         # data parallel, one bag per rank per update, single-pass ABMIL step: the queries' EMA is chained over the ranks (QueryChain)
         self._chain, self._chain_tokens, self._q_scratch = None, None, None
-        if self.world > 1 and self.accum == 1 and model == "mhim" and student.merge_enable and "merge.global_q_mm" in self.flat.offsets:
+        # Participation is a property of the MODEL (ABMIL baseline with Merge), never of a bag: every path an ABMIL step can take - the
+        # single-pass step, the generic step of a small / odd-shaped bag, a bag with no rows to merge - leaves this rank's tokens for the
+        # chain (forward_backward raises if one did not), so that no two ranks finish an update with different formulas
+        if (self.world > 1 and self.accum == 1 and model == "mhim" and student.merge_enable and student.baseline == "attn"
+                and "merge.global_q_mm" in self.flat.offsets):
             rank = torch.distributed.get_rank(process_group)
             self._chain = QueryChain(self.flat.offsets["merge.global_q_mm"], student.merge.global_q_mm.numel(), float(student.merge.g_q_mm),
                                      self.world, rank)
@@ -374,6 +379,10 @@ class FusedTrainer:
             plan = BagPlan(rows=rows, L=len_keep, Lk=Lk, R=R, drop_seed=s._next_seed() if seed_s is None else seed_s,
                            mca_seed=s._next_seed(), training=True, merge_first=mf)
             plan.pre = pre
+            if self._chain is not None:                     # data parallel: the queries stay q0 until the update (QueryChain)
+                if self._q_scratch is None:
+                    self._q_scratch = torch.empty((s.merge.k, s.mlp_dim), device=x.device)
+                plan.q_out = self._q_scratch
             keep_num = Lk + s.merge.k
         else:
             teacher_feat = None
@@ -389,6 +398,11 @@ class FusedTrainer:
             s.merge_enable = False
         try:
             z, saved = s._bag_forward(x, plan, xp=xp, prep=prep_s)
+            if self._chain is not None and self.model_kind == "mhim":
+                # this rank's term of the chain: the tokens its Merge produced; a bag with no rows to merge leaves the queries alone in the
+                # reference (its EMA step is skipped) - handing the chain the current queries does the same up to second order in 1 - mm
+                tok = saved.get("z_tok")
+                self._chain.tokens = self._chain_tokens = tok if tok is not None else s.merge.global_q_mm.data.view(s.merge.k, -1).clone()
             t_in = teacher_feat.view(-1) if (teacher_feat is not None and self.aux_alpha != 0.) else None
             logits, losses, g_z, _, _ = ops.head_fwd_bwd(
                 z, t_in, s.predictor.weight.data, s.predictor.bias.data, label, temp_t=float(s.temp_t),
@@ -550,6 +564,8 @@ class FusedTrainer:
                     and s.v2_counts(x.shape[0], i) is not None and s.device_draw_ok(x.shape[0], i)
                     and ops.bag_wgrad_ok(x, s.mlp_dim, s.v2_counts(x.shape[0], i)[2])):
                 return False
+        if (_WINDOW_WGRAD or _WINDOW_PROJECT) and len({tuple((b[0] if b.dim() == 3 else b).shape) for b in bags}) > 1:
+            return False                                   # the opt-in multi-bag launches size their workspace from bag 0
         return True
 
     def _window_state(self, n_streams, dev):
@@ -769,7 +785,9 @@ class FusedTrainer:
     def update(self):
         """All-reduce (data parallel) + fused Adam + EMA teacher.  Call once per ``accumulation_steps`` bags."""
         fl = self.flat
-        ops.step_images(None)                              # the weights change below: this step's prepared images are stale
+        if self._chain is not None and self._chain.tokens is None:
+            raise mh.L.MhimxError("data-parallel update: this rank's step left no Merge tokens for the query chain (QueryChain) - the ranks "
+                                  "would finish the update with different formulas for merge.global_q_mm")
         if self._work_a is not None:                       # overlapped form: the rest of the buffer, then wait for both halves
             work_b = torch.distributed.all_reduce(fl.grad[:self._split], group=self.pg, async_op=True)
             self._work_a.wait()
@@ -790,6 +808,10 @@ class FusedTrainer:
 
     def _apply(self, scale):
         fl = self.flat
+        # the weights change below: this step's prepared weight images (ops.step_images, keyed by storage address) are stale from here
+        # on, whoever runs the update - update(), or the captured data-parallel step (graph | all-reduce | graph), which never passes
+        # through update() (an eval forward between replays picked up images of the pre-update weights)
+        ops.step_images(None)
         fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
         ops.optim_step(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                        fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
@@ -842,6 +864,7 @@ class FusedTrainer:
             with torch.cuda.graph(g_fb, pool=self._graph_pool, stream=cs, capture_error_mode="thread_local"):
                 self.forward_backward(bag, label, **kw)        # (leaves the QueryChain's tokens: static buffer of this capture)
                 fill_tail(fl.grad, fl.student, fl.n_train, self._chain)
+            ops.step_images(None)                              # (graph-static images of the capture-time weights: never hand them out)
             self._all_reduce(fl.grad)
             scale = 1.0 / self.world
             with torch.cuda.graph(g_up, pool=self._graph_pool, stream=cs, capture_error_mode="thread_local"):

@@ -505,7 +505,9 @@ class MHIM(nn.Module):
                 q_old = self.merge.global_q_mm.data.clone()
             # in-forward EMA of the global queries (merge.py:142-143), written in place: the pre-update values the
             # backward needs were snapshotted above
-            q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
+            q_param = getattr(plan, "q_out", None)                          # (a data-parallel step sends the EMA result to scratch)
+            if q_param is None:
+                q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
             Hm = H[:plan.R] if plan.merge_first else H[plan.Lk:]
             z_tok, _, mws = ops.merge_fwd(mw, Hm, z_out=Hbuf[Lrows:], update_q=plan.training,
                                           q_out=q_param if plan.training else None)

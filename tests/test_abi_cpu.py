@@ -21,7 +21,9 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libmhimx.so lacks {n}"
         assert n in L.SYMBOLS, f"ctypes binding lacks {n}"
     assert set(L.SYMBOLS) == set(names)
-    assert lib.mhimx_version() == 100
+    assert lib.mhimx_version() == L.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "mhimx.h")).read()
+    assert int(re.search(r"#define MHIMX_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -44,3 +46,13 @@ def test_comm_handle_argument_errors():
     assert lib.mhimx_comm_init(C.byref(h), C.create_string_buffer(128), 3, 2) < 0
     assert lib.mhimx_comm_allreduce(None, None, None, 4, 0) < 0
     assert lib.mhimx_comm_unique_id(None) < 0
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    from mhim_mil_amd import _lib as L
+    assert L.lib().mhimx_version() == L.ABI_VERSION
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
+    import pytest
+    with pytest.raises(RuntimeError, match="ABI version"):
+        L.lib()
