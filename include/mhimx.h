@@ -517,6 +517,11 @@ typedef struct {
   float* C; int64_t ldc; int32_t accumulate;
   float* ws; int64_t ws_floats;
   mhimx_reduce_list* defer;                              /* optional: queue the slab sum                                */
+  int32_t ride_tail;                                     /* with defer: every reduction ALREADY queued on the list (their inputs are final
+                                                            before this launch starts) and the last stage of a parked Merge-backward tail run
+                                                            as trailing workgroups of this launch - in the CUs its last round of tiles leaves
+                                                            idle - instead of in mhimx_reduce_flush; the list then holds this launch's own
+                                                            slab sum only (which mhimx_optim_step can fold into the update: `fold`)   */
 } mhimx_bag_wgrad_args;
 int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D);
 int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a);
@@ -597,7 +602,8 @@ int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, float* v, f
  *             streams of an accumulation window (--accumulation_steps, base_engine.py:29,100-102) accumulate into their own slabs;
  *  clip_norm  > 0: torch.nn.utils.clip_grad_norm_(parameters, clip_norm) on the scaled, summed gradient, i.e. --clip_grad
  *             (base_engine.py:115-119, timm dispatch_clip_grad mode 'norm'): g *= min(1, clip_norm / (||g||_2 + 1e-6)); one extra
- *             launch (per-block sums of squares into ws, >= 1024 floats), the final sum in every block of the update in a fixed order. */
+ *             launch (per-block sums of squares into ws, >= 1024 floats), the final sum in every block of the update in a fixed order;
+ *  fold       see the field. */
 typedef struct {
   float* p; float* g; float* m; float* v; float* teacher;
   int64_t n_train, n_all;
@@ -609,6 +615,11 @@ typedef struct {
   const float* g_extra; int64_t n_extra; int64_t extra_pitch;
   float clip_norm;
   float* ws; int64_t ws_floats;
+  mhimx_reduce_list* fold;      /* optional: a step's deferred reductions.  Split-K slab sums on it (kind 1, <= 4 of them, <= 64 slabs each) whose
+                                   contiguous, 16-byte aligned output lies inside g[0, n_train) are taken off the list and summed by the update
+                                   kernel itself while it reads the gradient - same order, same bits, no separate pass over the slabs;
+                                   whatever else the list holds is flushed first (mhimx_reduce_flush).  Not with clip_norm (the norm needs the
+                                   final gradient): the whole list is flushed then. */
 } mhimx_optim_args;
 int mhimx_optim_step(void* stream, const mhimx_optim_args* a);
 

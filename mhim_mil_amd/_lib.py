@@ -52,7 +52,7 @@ class BagProject(C.Structure):
 class BagWgrad(C.Structure):
     _fields_ = [("img", C.c_void_p), ("X", c_f32p), ("ldx", C.c_int64), ("n_bag_rows", C.c_int64), ("rows", C.c_void_p),
                 ("L", C.c_int64), ("E", C.c_int64), ("D", C.c_int64), ("C", c_f32p), ("ldc", C.c_int64), ("accumulate", C.c_int32),
-                ("ws", c_f32p), ("ws_floats", C.c_int64), ("defer", C.c_void_p)]
+                ("ws", c_f32p), ("ws_floats", C.c_int64), ("defer", C.c_void_p), ("ride_tail", C.c_int32)]
 
 
 class PrepJob(C.Structure):
@@ -157,7 +157,7 @@ class OptimArgs(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float),
                 ("ema_mm", C.c_float), ("mm_table", C.c_void_p), ("mm_len", C.c_int64), ("zero_grad", C.c_int32),
                 ("g_extra", C.c_void_p), ("n_extra", C.c_int64), ("extra_pitch", C.c_int64), ("clip_norm", C.c_float),
-                ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
+                ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("fold", C.c_void_p)]
 
 
 SYMBOLS = {

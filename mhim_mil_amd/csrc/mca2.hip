@@ -271,6 +271,11 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_o_kernel(const float* __res
   m2_head_dots<16>(wkv + (int64_t)(M2_I + h * 64 + qd * 16) * M2_E, ys, k, oh, 16, w.O + h * 64 + qd * 16);       // the V half of to_kv
 }
 
+// (Round 4, measured and NOT kept: 3a + 3b + mca_out as ONE launch - 8 head workgroups of 1024 threads: partial merge -> O_h -> the head's
+// share of to_out as a [k, 512] partial, a ticket, the last head sums the 8 partials, applies bias / dropout / the EMA.  27 us in its first
+// form (ten dependent memory round trips), 33 us with every load of a phase in flight (128 VGPRs, 12 spilled) against 4.7 + 7.8 + 9.2 us
+// for the three launches: each of these kernels is a chain of 3-6 dependent round trips of ~1.5 us, a launch boundary costs ~3 us, and
+// eight workgroups cannot hide what 160 + 32 + 128 do.  The step kept the three launches.)
 // ----------------------------------------------------------------------------------------------------------------------
 // 4. backward, parameters x dz: dz0 = dz keep/(1-p), d_bo, dO = dz0 Wo, dY[(h,i),:] = sum_d dO[i,h,d] Wv[h*64+d,:] (as the two
 //    fragment images), delta partials dY.Y.   grid = 8 heads x 8 column blocks of 64.
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
   const int64_t row0 = (int64_t)t * M2_ROWS;
   M2Frags fr;
   m2_fetch_frags(w.dyf, fr);
+  if (t == 0 && tid == 0) *w.gate = 0u;               // (the tail's stage-2 arrivals are counted from here: bag_wgrad_ws_kernel)
   if (tid < M2_JK) {
     const int j = tid;
     float mx = 0.f, il = 0.f, de = 0.f;

@@ -15,6 +15,7 @@ typedef float m2_f4 __attribute__((ext_vector_type(4)));
 struct Merge2Ws {
   float *gq, *gmean, *grstd, *Q, *aq, *aqf, *gtf_aq, *mean, *rstd, *S, *pm, *pl, *psd, *ypart, *stats, *Y, *O;
   float *dO, *dyf, *gtf_dy, *dpart, *upart, *lnpart, *dQ;
+  unsigned* gate;            // arrivals of the backward tail's stage 2 (zeroed by the rows backward): stage 3 may share its launch
   int T;
 };
 
@@ -46,6 +47,7 @@ inline int64_t merge2_ws_layout(Arena& ar, int64_t R, int64_t k, Merge2Ws* out) 
   w.upart = ar.take<float>(T * M2_JP * M2_E);
   w.lnpart = ar.take<float>(T * 2 * M2_E);
   w.dQ = ar.take<float>(k * M2_I);
+  w.gate = reinterpret_cast<unsigned*>(ar.take<float>(64));
   if (out) *out = w;
   return ar.off;
 }

@@ -153,7 +153,11 @@ MHIMX_DEV void merge2_grads1_body(int block, float* lds, const Merge2Side& a) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) { u0[i] = us[i * M2_E + tid]; u1[i] = us[i * M2_E + tid + 256]; }
   __syncthreads();
-  if (tid < 16 * 6 && (tid / 16) < k) w.dQ[(tid / 16) * M2_I + h * 64 + qr * 16 + (tid & 15)] = scale * dqh[tid];
+  // (dQ is what stage 3 reads from this stage.  When both share a launch (bag_wgrad_ws_kernel's trailing workgroups) their workgroups sit on
+  // different XCDs: agent-scope relaxed atomics = write-through stores / cache-bypassing loads of just these 10 KB, instead of an L2
+  // write-back and invalidation per workgroup - the invalidations took the weight-gradient tiles' operands out of the L2s: +6 us)
+  if (tid < 16 * 6 && (tid / 16) < k)
+    __hip_atomic_store(w.dQ + (tid / 16) * M2_I + h * 64 + qr * 16 + (tid & 15), scale * dqh[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll 4
   for (int dl = 0; dl < 16; ++dl) {
     const m2_f4 c0 = *reinterpret_cast<const m2_f4*>(qd + dl * 12), c1 = *reinterpret_cast<const m2_f4*>(qd + dl * 12 + 4),
@@ -196,7 +200,7 @@ MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
     }
     for (int idx = tid; idx < 32 * 8; idx += M2_THREADS) {
       const int r = idx >> 3, i = idx & 7;
-      part[idx] = i < k ? w.dQ[i * M2_I + c0 + r] : 0.f;
+      part[idx] = i < k ? __hip_atomic_load(w.dQ + i * M2_I + c0 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     }
     __syncthreads();
 #pragma unroll 4
@@ -218,7 +222,7 @@ MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
   float wv[32];
 #pragma unroll
   for (int q = 0; q < 32; ++q) wv[q] = wq[(int64_t)(cq + 16 * q) * M2_E + e];
-  for (int idx = tid; idx < 6 * M2_I; idx += M2_THREADS) dqs[idx] = idx < k * M2_I ? w.dQ[idx] : 0.f;
+  for (int idx = tid; idx < 6 * M2_I; idx += M2_THREADS) dqs[idx] = idx < k * M2_I ? __hip_atomic_load(w.dQ + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 32; ++q)

@@ -6,6 +6,8 @@
 
 namespace mhimx {
 
+int reduce_flush(hipStream_t st, mhimx_reduce_list* list);      // rows.hip
+
 constexpr int HEAD_THREADS = 256;
 
 MHIMX_DEV float blk_sum(float v, float* red) {
@@ -156,8 +158,28 @@ __global__ __launch_bounds__(HEAD_THREADS) void dsmil_head_kernel(const float* _
 }
 
 // optional parts of an optimiser step (mhimx_optim_step): learning-rate table, gradient slabs to add, global-norm clipping
+// (fold: split-K slab sums the update kernel performs itself - gradient elements [off, off + n) = sum_z parts[z * n + i])
+constexpr int FOLD_MAX = 4;
+struct FoldJobs { const float* parts[FOLD_MAX]; int64_t off[FOLD_MAX], n[FOLD_MAX]; int G[FOLD_MAX], accumulate[FOLD_MAX]; int count; };
 struct OptimExtra { const float* lr_table; int64_t lr_len; const float* g_extra; int64_t n_extra, extra_pitch; float clip_norm;
-                    const float* sq_parts; int n_parts; };
+                    const float* sq_parts; int n_parts; FoldJobs fold; };
+
+// the slab sum of reduce_jobs.hpp (kind 1) for four neighbouring elements: four running sums, eight slabs in flight, then four, then one -
+// the same additions in the same order, so a folded gradient has the bits of a reduced one
+MHIMX_DEV float4 fold_sum4(const float* __restrict__ parts, int64_t n, int64_t idx, int G) {
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  auto ld = [&](int z) { return *reinterpret_cast<const float4*>(parts + (int64_t)z * n + idx); };
+  auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  int z = 0;
+  for (; z + 8 <= G; z += 8) {
+    const float4 p0 = ld(z), p1 = ld(z + 1), p2 = ld(z + 2), p3 = ld(z + 3), p4 = ld(z + 4), p5 = ld(z + 5), p6 = ld(z + 6), p7 = ld(z + 7);
+    add(s0, p0); add(s1, p1); add(s2, p2); add(s3, p3);
+    add(s0, p4); add(s1, p5); add(s2, p6); add(s3, p7);
+  }
+  for (; z + 4 <= G; z += 4) { add(s0, ld(z)); add(s1, ld(z + 1)); add(s2, ld(z + 2)); add(s3, ld(z + 3)); }
+  for (; z < G; ++z) add(s0, ld(z));
+  return make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+}
 
 // per-block partial sums of squares of the (scaled, slab-summed) gradient: the first stage of clip_grad_norm_ (base_engine.py:115-119)
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float gscale, OptimExtra ex, float* __restrict__ parts) {
@@ -245,6 +267,12 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
       float4 w = reinterpret_cast<float4*>(p)[q];
       if (i0 < n_train) {
         float4 gi = reinterpret_cast<float4*>(g)[q], mi = reinterpret_cast<float4*>(m)[q], vi = reinterpret_cast<float4*>(v)[q];
+        for (int f = 0; f < ex.fold.count; ++f)           // a folded split-K slab sum: this gradient element is summed here, not by a reduction pass
+          if (i0 >= ex.fold.off[f] && i0 < ex.fold.off[f] + ex.fold.n[f]) {
+            const float4 sv = fold_sum4(ex.fold.parts[f], ex.fold.n[f], i0 - ex.fold.off[f], ex.fold.G[f]);
+            if (ex.fold.accumulate[f]) { gi.x += sv.x; gi.y += sv.y; gi.z += sv.z; gi.w += sv.w; }
+            else gi = sv;
+          }
         for (int64_t z = 0; z < ex.n_extra; ++z) {       // gradient slabs of the other streams of an accumulation window (fixed order)
           const float4 e = *reinterpret_cast<const float4*>(ex.g_extra + z * ex.extra_pitch + i0);
           gi.x += e.x; gi.y += e.y; gi.z += e.z; gi.w += e.w;
@@ -320,7 +348,31 @@ extern "C" int mhimx_optim_step(void* stream, const mhimx_optim_args* a) {
   MHIMX_CHECK_ARG(!(a->clip_norm > 0.f) || (a->ws && a->ws_floats >= 1024), "optim_step: clipping needs a workspace of 1024 floats");
   int64_t step = a->step < 1 ? 1 : a->step;
   if (a->n_all == 0) return 0;
-  OptimExtra ex{a->lr_table, a->lr_len, a->g_extra, a->n_extra, a->extra_pitch, a->clip_norm > 0.f ? a->clip_norm : 0.f, a->ws, 0};
+  OptimExtra ex{a->lr_table, a->lr_len, a->g_extra, a->n_extra, a->extra_pitch, a->clip_norm > 0.f ? a->clip_norm : 0.f, a->ws, 0, {}};
+  if (a->fold) {
+    mhimx_reduce_list* l = a->fold;
+    MHIMX_CHECK_ARG(l->n >= 0 && l->n <= MHIMX_REDUCE_MAX, "optim_step: bad reduction list");
+    // the vector path of the update kernel is the one that folds: every buffer 16-byte aligned
+    const bool vec_ok = aligned16(a->p) && aligned16(a->g) && aligned16(a->m) && aligned16(a->v) && (!a->teacher || aligned16(a->teacher));
+    if (!(a->clip_norm > 0.f) && vec_ok) {
+      int kept = 0;
+      for (int i = 0; i < l->n; ++i) {
+        const mhimx_reduce_job& j = l->j[i];
+        const int64_t n = j.K1 * j.K2, off = j.out - a->g;
+        const bool take = j.kind == 1 && ex.fold.count < FOLD_MAX && j.G >= 1 && j.G <= 64 && j.ldo == j.K2 && n > 0 && n % 4 == 0 && aligned16(j.parts) &&
+                          j.out >= a->g && off % 4 == 0 && off + n <= a->n_train / 4 * 4;
+        if (take) {
+          const int f = ex.fold.count++;
+          ex.fold.parts[f] = j.parts; ex.fold.off[f] = off; ex.fold.n[f] = n; ex.fold.G[f] = (int)j.G; ex.fold.accumulate[f] = j.accumulate;
+        } else {
+          l->j[kept++] = j;
+        }
+      }
+      l->n = kept;
+    }
+    if (l->n > 0 || l->side.pending || l->parked.pending)
+      if (int r = reduce_flush((hipStream_t)stream, l)) return r;
+  }
   if (ex.clip_norm > 0.f && a->n_train > 0) {
     const int64_t nb = cdiv(a->n_train, 1024) < 1024 ? cdiv(a->n_train, 1024) : 1024;
     ex.n_parts = (int)nb;

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "mca2_side.hpp"
+#include "reduce_jobs.hpp"
 
 namespace mhimx {
 
@@ -298,7 +299,7 @@ int reduce_parts_now(hipStream_t st, const float* part, int64_t G, int64_t W, in
 
 // every queued final reduction of a step in one launch (mhimx_reduce_flush): job jb owns blocks [first[jb], first[jb+1]).
 // Same arithmetic as reduce_parts_kernel (kind 0) and reduce_slabs_kernel (kind 1): queued or not, the bits are the same.
-struct ReduceJobs { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int first[MHIMX_REDUCE_MAX + 1]; int n; int side_blocks; Merge2Side side; };
+struct ReduceJobs { ReduceTable t; int side_blocks; Merge2Side side; };
 __global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj) {
   // the last stage of a parked Merge-backward tail rides along (256 of the 1024 threads).  Its workgroups come FIRST: they are a ~9 us
   // latency chain, and behind 600 reduction workgroups (two resident per CU) they started a round late (reduce 11 us alone, 16 with them last)
@@ -308,54 +309,7 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj)
     return;
   }
   __shared__ float red[32][33];
-  const int bx = (int)blockIdx.x - rj.side_blocks;
-  int jb = 0;
-  while (jb + 1 < rj.n && bx >= rj.first[jb + 1]) ++jb;
-  const mhimx_reduce_job J = rj.j[jb];
-  const int blk = bx - rj.first[jb], nblk = rj.first[jb + 1] - rj.first[jb];
-  if (J.kind == 0) {
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    for (int64_t j0 = (int64_t)blk * 32; j0 < J.W; j0 += (int64_t)nblk * 32) {
-      const int64_t j = j0 + c;
-      float acc = 0.f;
-      if (j < J.W) {
-#pragma unroll 8
-        for (int64_t b = rg; b < J.G; b += 32) acc += J.parts[b * J.ld + j];
-      }
-      red[rg][c] = acc;
-      __syncthreads();
-      if (rg == 0 && j < J.W) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) v += red[q][c];
-        J.out[j] = J.accumulate ? J.out[j] + v : v;
-      }
-      __syncthreads();
-    }
-  } else {
-    const int64_t n = J.K1 * J.K2;
-    for (int64_t idx = (int64_t)blk * RP_THREADS + threadIdx.x; idx < n; idx += (int64_t)nblk * RP_THREADS) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int64_t z = 0;
-      for (; z + 8 <= J.G; z += 8) {                   // (eight slabs in flight; the same sums in the same order as four at a time)
-        const float p0 = J.parts[(z + 0) * n + idx], p1 = J.parts[(z + 1) * n + idx], p2 = J.parts[(z + 2) * n + idx],
-                    p3 = J.parts[(z + 3) * n + idx], p4 = J.parts[(z + 4) * n + idx], p5 = J.parts[(z + 5) * n + idx],
-                    p6 = J.parts[(z + 6) * n + idx], p7 = J.parts[(z + 7) * n + idx];
-        s0 += p0; s1 += p1; s2 += p2; s3 += p3;
-        s0 += p4; s1 += p5; s2 += p6; s3 += p7;
-      }
-      for (; z + 4 <= J.G; z += 4) {
-        s0 += J.parts[(z + 0) * n + idx];
-        s1 += J.parts[(z + 1) * n + idx];
-        s2 += J.parts[(z + 2) * n + idx];
-        s3 += J.parts[(z + 3) * n + idx];
-      }
-      for (; z < J.G; ++z) s0 += J.parts[z * n + idx];
-      const float v = (s0 + s1) + (s2 + s3);
-      float* p = J.out + (idx / J.K2) * J.ldo + (idx % J.K2);
-      *p = J.accumulate ? *p + v : v;
-    }
-  }
+  reduce_jobs_block<RP_THREADS>(rj.t, (int)blockIdx.x - rj.side_blocks, red);      // (reduce_jobs.hpp)
 }
 
 // two independent partial sets in one launch (blockIdx.y selects): LayerNorm's d_w and d_b
@@ -1101,24 +1055,17 @@ int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   if (int r = merge2_side_finish(st, &list->side, list->n == 0 ? 3 : 2)) return r;
   if (list->n == 0) return 0;
   ReduceJobs rj;
-  rj.n = list->n;
   rj.side_blocks = 0;
   if (list->side.pending == 3) {
     memcpy(&rj.side, list->side.blob, sizeof(rj.side));
     rj.side_blocks = merge2_side_blocks(3, rj.side);
     list->side.pending = 0;
   }
-  int first = 0;
   for (int i = 0; i < list->n; ++i) {
     const mhimx_reduce_job& j = list->j[i];
     MHIMX_CHECK_ARG(j.parts && j.out && j.G > 0 && (j.kind == 0 ? j.W > 0 : (j.kind == 1 && j.K1 > 0 && j.K2 > 0)), "reduce_flush: bad job %d", i);
-    rj.j[i] = j;
-    rj.first[i] = first;
-    int64_t nb = j.kind == 0 ? cdiv(j.W, 32) : cdiv(j.K1 * j.K2, RP_THREADS);
-    if (nb > 512) nb = 512;
-    first += (int)nb;
   }
-  rj.first[list->n] = first;
+  const int first = reduce_table_fill(rj.t, list->j, list->n, RP_THREADS);
   list->n = 0;
   hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(first + rj.side_blocks)), dim3(RP_THREADS), 0, st, rj);
   MHIMX_LAUNCH_CHECK();
@@ -1290,7 +1237,7 @@ extern "C" int mhimx_layernorm_bwd_res(void* stream, const float* dy, const floa
 __global__ __launch_bounds__(256) void random_perm_kernel(int64_t n, int bits, uint64_t seed0, const uint64_t* __restrict__ tick,
                                                          const int64_t* __restrict__ src, int64_t* __restrict__ out) {
   const uint64_t seed = eff_seed(seed0, tick);
-  const uint32_t k0 = mix32((uint32_t)seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu);
+  const uint32_t k0 = mix32((uint32_t)seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu + k0 * 0x632BE5ABu);   // (both keys: the whole seed)
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
     const uint64_t x = feistel_index((uint64_t)j, (uint64_t)n, bits, k0, k1);
     out[j] = src ? src[x] : (int64_t)x;

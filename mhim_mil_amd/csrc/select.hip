@@ -518,7 +518,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     // masking.py:66-71 keeps a uniformly random n_sel-subset of the k candidates.  Drawn here without a host permutation and without
     // ranking random keys (k^2 / 1024 compares per thread were 3 us of this kernel): candidate pi(i), i < n_sel, of a keyed
     // pseudo-random permutation pi of the k list positions (common.hpp: feistel_small) - one short dependent chain per pick.
-    const uint32_t k0 = mix32((uint32_t)rand_seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(rand_seed >> 32) + 0x85EBCA6Bu);
+    // (both round keys depend on the WHOLE seed: with k1 a function of the high word alone, seeds that differ in the low word only - small
+    // integers - shared it, and the 4-round network on a 6-bit domain masked one of 56 candidates 6.5 sigma off its share over 2000 seeds;
+    // tools/feistel_sim.py, tests/test_round4_gpu.py::test_select_rows_draws_are_fair_on_small_lists)
+    const uint32_t k0 = mix32((uint32_t)rand_seed ^ 0x9E3779B9u), k1 = mix32((uint32_t)(rand_seed >> 32) + 0x85EBCA6Bu + k0 * 0x632BE5ABu);
     const int bits = small_perm_bits((uint32_t)k);
     for (int i = tid; i < n_sel; i += SEL_THREADS) {
       const uint32_t j = feistel_small((uint32_t)i, (uint32_t)k, bits, k0, k1);
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
       if (kv[j]) klist[kp++] = (uint16_t)(i0 + j);
     for (int i = tid; i < 512; i += SEL_THREADS) bitmap[i] = 0;
     __syncthreads();
-    const uint32_t q0 = mix32((uint32_t)(rand_seed >> 17) ^ 0x85EBCA6Bu), q1 = mix32((uint32_t)rand_seed * 0x9E3779B1u + 0xC2B2AE35u);
+    const uint32_t q1 = mix32((uint32_t)rand_seed * 0x9E3779B1u + 0xC2B2AE35u), q0 = mix32(((uint32_t)(rand_seed >> 17) ^ 0x85EBCA6Bu) + q1 * 0x632BE5ABu);
     const int bits2 = small_perm_bits((uint32_t)Lrows);
     for (int i = tid; i < merge_R; i += SEL_THREADS) {
       const uint32_t row = klist[feistel_small((uint32_t)i, (uint32_t)Lrows, bits2, q0, q1)];

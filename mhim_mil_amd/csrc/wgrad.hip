@@ -28,6 +28,7 @@
 
 #include "mma_tile.hpp"
 #include "mca2_side.hpp"
+#include "reduce_jobs.hpp"
 
 namespace mhimx {
 
@@ -88,6 +89,14 @@ struct WgradArgs {
   int ksteps, kps, splits;    // k-steps in all, per slab, slabs
   float* out;                 // slabs [splits][E][D]
 };
+
+// Trailing workgroups of a launch (mhimx_bag_wgrad_args.ride_tail): blocks [first, first + n_reduce) run the step's deferred reductions that
+// were already queued (reduce_jobs.hpp), the stage3 blocks in front of them the last stage of the Merge backward's tail - behind a gate: the stage-2
+// blocks at the FRONT of the same grid count their arrivals in side.w.gate (relaxed agent-scope atomics; the one matrix that crosses, dQ,
+// travels as write-through stores and cache-bypassing loads) and a stage-3 block starts when all of them have arrived.  Blocks are dispatched in order, so the stage-2 blocks are resident or done long before a trailing block
+// starts: the wait cannot deadlock, and with a grid of more than one round of tiles it is over before it begins.
+struct WgradTail { int first, n_reduce, stage3, gate_want; ReduceTable t; };      // blocks: [first, first + stage3) stage 3, then n_reduce reductions
+constexpr unsigned WG_GATE_SPINS = 1u << 20;
 
 constexpr int W_MAX_BAGS = 8;
 struct WgradBags {            // the bags of one launch (bag_wgrad_ws_kernel): bag b owns slabs [b * spb, (b + 1) * spb)
@@ -334,10 +343,32 @@ MHIMX_DEV void ws_unit(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[4]
     for (int j = 0; j < 4; ++j) acc[i][4 * CB + j] = mt_mfma(a[i], b[j], acc[i][4 * CB + j]);
 }
 
-__global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, WgradBags mb, int side_blocks, Merge2Side side) {
+__global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, WgradBags mb, int side_blocks, Merge2Side side, WgradTail tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < side_blocks) {
-    if (threadIdx.x < M2_THREADS) merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
+    if (threadIdx.x < M2_THREADS) {
+      merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
+      if (tail.stage3) {                         // (the waves above M2_THREADS have left: the barrier counts the four that remain)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores of dQ are acknowledged ...
+        __syncthreads();                         // ... before the barrier that precedes the arrival
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(side.w.gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  if (tail.first && (int)blockIdx.x >= tail.first) {
+    const int tb = (int)blockIdx.x - tail.first;
+    if (tb >= tail.stage3) {
+      reduce_jobs_block<WTHREADS>(tail.t, tb - tail.stage3, reinterpret_cast<float(*)[33]>(smem));
+    } else if (threadIdx.x < M2_THREADS) {       // (the tail's stage-3 workgroups come first: the longest chain of the trailing blocks)
+      if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(side.w.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tail.gate_want && ++spins < WG_GATE_SPINS)
+          __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();                           // (what stage 3 reads of stage 2 - dQ - it reads past the caches: mca2_side.hpp)
+      merge2_side_stage(3, tb, reinterpret_cast<float*>(smem), side);
+    }
     return;
   }
   const unsigned bx = blockIdx.x - (unsigned)side_blocks;
@@ -940,6 +971,25 @@ static int bag_wgrad_impl(void* stream, const mhimx_bag_wgrad_args* bags, int n_
   }
   const int64_t tiles = (a->E / WBI) * (a->D / WBN);
   dim3 grid((unsigned)(8 * tiles * cdiv(g.splits, 8) + side_blocks));
+  static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;
+  static const bool pp_form = ws_form && getenv("MHIMX_WGRAD_PP") != nullptr;
+  WgradTail tail = {};
+  if (a->ride_tail && defer && ws_form && !pp_form && n_bags == 1 && (defer->n > 0 || defer->side.pending == 3)) {
+    // the reductions queued so far and (behind the stage-2 gate) the tail's last stage: trailing workgroups of this launch
+    for (int i = 0; i < defer->n; ++i) {
+      const mhimx_reduce_job& j = defer->j[i];
+      MHIMX_CHECK_ARG(j.parts && j.out && j.G > 0 && (j.kind == 0 ? j.W > 0 : (j.kind == 1 && j.K1 > 0 && j.K2 > 0)), "bag_wgrad: bad queued reduction %d", i);
+    }
+    tail.first = (int)grid.x;
+    tail.n_reduce = reduce_table_fill(tail.t, defer->j, defer->n, WTHREADS);
+    defer->n = 0;
+    if (defer->side.pending == 3 && side_blocks > 0) {          // (its stage 2 rides at the front of THIS grid: the gate counts those blocks)
+      tail.stage3 = merge2_side_blocks(3, side);
+      tail.gate_want = side_blocks;
+      defer->side.pending = 0;
+    }
+    grid.x += (unsigned)(tail.n_reduce + tail.stage3);
+  }
   // The specialised-wave form (bag_wgrad_ws_kernel, ~5 % faster) is the default again.  It was opt-in for a while: with two processes
   // time-slicing one GPU it ended in a GPU memory access fault on the long TransMIL-shaped launches (tools/two_proc_c3.sh: 3 of 6 runs
   // died).  Cause: its last asm wait named 6 of the 24 prefetch registers, so the compiler handed the other 18 out again while the
@@ -950,8 +1000,6 @@ static int bag_wgrad_impl(void* stream, const mhimx_bag_wgrad_args* bags, int n_
   // measures the SAME as the specialised-wave kernel here (34.7 vs 34.5 us same-box; consumers alone 27.8, producers alone 27.8, both 37:
   // ~13 us of the launch are the row table, the first tiles and the 33 MB of slab stores, outside the loop either form pipelines), so the
   // round-2 kernel stays the default; MHIMX_WGRAD_PP=1 selects the ping-pong form, MHIMX_WGRAD_UNIFORM=1 the uniform one.
-  static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;
-  static const bool pp_form = ws_form && getenv("MHIMX_WGRAD_PP") != nullptr;
   MHIMX_CHECK_ARG(n_bags == 1 || (ws_form && !pp_form), "bag_wgrad_multi: only the default (specialised-wave) kernel takes several bags");
   if (pp_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
@@ -960,7 +1008,7 @@ static int bag_wgrad_impl(void* stream, const mhimx_bag_wgrad_args* bags, int n_
   } else if (ws_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
-    hipLaunchKernelGGL(bag_wgrad_ws_kernel, grid, dim3(WTHREADS), smem2, (hipStream_t)stream, g, mb, side_blocks, side);
+    hipLaunchKernelGGL(bag_wgrad_ws_kernel, grid, dim3(WTHREADS), smem2, (hipStream_t)stream, g, mb, side_blocks, side, tail);
   } else
   hipLaunchKernelGGL(bag_wgrad_kernel, grid, dim3(WTHREADS), smem, (hipStream_t)stream, g, side_blocks, side);
   MHIMX_LAUNCH_CHECK();

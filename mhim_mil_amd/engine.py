@@ -293,6 +293,8 @@ class FusedTrainer:
         self.lr_table = None if lr_sche is None else torch.as_tensor(lr_sche, dtype=torch.float32).to(dev).contiguous()
         self._clip_ws = torch.empty(1024, device=dev) if self.clip_grad else None
         self._g_extra = None
+        self._fold_now, self._fold_list = False, None      # (train_step: the backward's last reductions inside the update kernel)
+        self.fold_reductions = os.environ.get("MHIMX_FOLD_REDUCTIONS", "1") != "0"
         self._graph_pool = None
         self._cap_stream = None
         self._side = None
@@ -542,8 +544,16 @@ class FusedTrainer:
                 main_alpha=self.main_alpha, aux_alpha=self.aux_alpha, inv_accum=1.0 / self.accum,
                 d_wp=gv["predictor.weight"], d_bp=gv["predictor.bias"], accumulate=accumulate)
             # the six final gradient reductions of the backward (slab sums, column partials) run as ONE launch
-            s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=mid_hook, accumulate=accumulate, wgrad_park=wgrad_park)
-            ops.reduce_flush(self._defer)
+            # train_step (one bag per update, one process, no clipping): nothing reads the gradient between this backward and the update,
+            # so no reduction launch stands between them - the reductions that are final before the weight-gradient product starts ride in
+            # its launch (ride_tail), and the product's own split-K slab sum is folded into the update kernel (_apply: fold)
+            fold = self._fold_now and not accumulate and wgrad_park is None and mid_hook is None
+            s._bag_backward_nat(x, plan, saved, g_z, gv, defer=self._defer, mid_hook=mid_hook, accumulate=accumulate, wgrad_park=wgrad_park,
+                                ride_tail=fold)
+            if fold:
+                self._fold_list = self._defer
+            else:
+                ops.reduce_flush(self._defer)
         finally:
             s.merge_enable = merge_on
         # (kept for inspection / parity tests: under graph replay these are the static buffers the replay rewrites)
@@ -816,8 +826,9 @@ class FusedTrainer:
         ops.optim_step(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
                        fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
                        grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step, mm_table=self.mm_table,
-                       lr_table=self.lr_table, g_extra=self._g_extra, clip_norm=self.clip_grad, ws=self._clip_ws)
+                       lr_table=self.lr_table, g_extra=self._g_extra, clip_norm=self.clip_grad, ws=self._clip_ws, fold=self._fold_list)
         self._g_extra = None
+        self._fold_list = None
         self._micro = 0
 
     def capture(self, bag, label, warmup=2, **kw):
@@ -878,7 +889,12 @@ class FusedTrainer:
         return g
 
     def train_step(self, bag, label, **kw):
-        out = self.forward_backward(bag, label, **kw)
+        # (a step that is followed by its update right here may leave its last reductions to the update kernel: _nat_bag)
+        self._fold_now = self.fold_reductions and self.accum == 1 and self.world == 1 and not self.clip_grad
+        try:
+            out = self.forward_backward(bag, label, **kw)
+        finally:
+            self._fold_now = False
         if self._micro >= self.accum:
             self.update()
         return out

@@ -624,7 +624,8 @@ class MHIM(nn.Module):
         saved["pool"] = st
         return st.z, saved
 
-    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None, accumulate=False, wgrad_park=None):
+    def _bag_backward_nat(self, x, plan: BagPlan, saved, g_z, out, defer=None, mid_hook=None, accumulate=False, wgrad_park=None,
+                          ride_tail=False):
         """Backward of _bag_forward_nat: every gradient buffer is bag-ordered too (dH [N + k, E]); the rows that took part are
         gathered once more by the activation backward (ops.rows_dpre) and the projection's weight-gradient GEMM."""
         N = x.shape[0]
@@ -664,7 +665,8 @@ class MHIM(nn.Module):
             grads["feature.0.weight"], db1 = None, out.get("feature.0.bias")
         elif ops.bag_wgrad_ok(x, dHbuf.shape[1], Lr):
             grads["feature.0.weight"], db1 = ops.bag_wgrad(dHbuf, saved["DACT"], x, rows, Lr, out_w=out.get("feature.0.weight"),
-                                                           out_b=out.get("feature.0.bias"), defer=defer, accumulate=accumulate)
+                                                           out_b=out.get("feature.0.bias"), defer=defer, accumulate=accumulate,
+                                                           ride_tail=ride_tail)
         else:
             dpre, db1 = ops.rows_dpre(dHbuf, saved["DACT"], rows, Lr, colsum_out=out.get("feature.0.bias"), defer=defer, accumulate=accumulate)
             grads["feature.0.weight"] = ops.gemm_tn(dpre, x, out=out.get("feature.0.weight"), rows=rows, splits=8 if Lr >= 2048 else 1,

@@ -537,12 +537,14 @@ def bag_wgrad_ok(x, E, n_rows):
 
 
 def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=False, defer=None, rows_dh="same", want_bias=True,
-              dh_compact=False):
+              dh_compact=False, ride_tail=False):
     """The projection's weight and bias gradient from the bag-ordered buffers:
     dPre[p] = dH[rows[p]] * dact16[rows[p]],  out_b (+)= sum_p dPre[p],  out_w [E,D] (+)= dPre^T x[rows]   (p < n_rows)
     — mhimx_rows_dpre_image (dPre as a bf16 hi/lo matrix-core image) + mhimx_bag_wgrad.
     dact16 None: dPre = dH (any Linear's weight gradient dy^T x); rows_dh: the row list of dH when it differs from x's (None: dH is
-    compact); want_bias False: no column sums; dh_compact: dH is compact while dact16 is gathered by rows (mhimx_rows_dpre_image_c)."""
+    compact); want_bias False: no column sums; dh_compact: dH is compact while dact16 is gathered by rows (mhimx_rows_dpre_image_c).
+    ride_tail (with defer): the reductions already queued on the list and the last stage of a parked Merge tail run as trailing workgroups
+    of the product launch (mhimx_bag_wgrad_args.ride_tail) - the list then holds the product's own slab sum only."""
     _chk(dH, name="dH"); _chk(dact16, torch.float16, "dact16"); _chk(rows, torch.int64, "rows")
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise L.MhimxError("x: expected a GPU fp32 matrix with contiguous rows")
@@ -563,7 +565,8 @@ def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=Fa
                                       int(bool(accumulate)), _p(ws_b), ws_b.numel() * 4 if want_bias else 0, _dp(defer)), "mhimx_rows_dpre_image")
     ws = torch.empty(lib.mhimx_wgrad_ws_floats(n_rows, E, D), device=dev)
     g = L.BagWgrad(img=_p(img), X=_p(x), ldx=x.stride(0), n_bag_rows=x.shape[0], rows=_p(rows), L=n_rows, E=E, D=D, C=_p(out_w),
-                   ldc=out_w.stride(0), accumulate=int(bool(accumulate)), ws=_p(ws), ws_floats=ws.numel(), defer=_dp(defer))
+                   ldc=out_w.stride(0), accumulate=int(bool(accumulate)), ws=_p(ws), ws_floats=ws.numel(), defer=_dp(defer),
+                   ride_tail=int(bool(ride_tail and defer is not None)))
     L.check(lib.mhimx_bag_wgrad(_stream(), C.byref(g)), "mhimx_bag_wgrad")
     if defer is not None:
         defer.keep.extend((ws_b, ws, img))
@@ -679,9 +682,10 @@ def adam_ema(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999
 
 
 def optim_step(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5, grad_scale=1.0,
-               ema_mm=0.9997, zero_grad=True, step_dev=None, mm_table=None, lr_table=None, g_extra=None, clip_norm=None, ws=None):
+               ema_mm=0.9997, zero_grad=True, step_dev=None, mm_table=None, lr_table=None, g_extra=None, clip_norm=None, ws=None, fold=None):
     """mhimx_optim_step: fused Adam + EMA with the optional device-side pieces - ``lr_table`` (per-update schedule), ``g_extra``
-    ([S, pitch] gradient slabs added to g first), ``clip_norm`` (clip_grad_norm_; ``ws``: >= 1024 floats)."""
+    ([S, pitch] gradient slabs added to g first), ``clip_norm`` (clip_grad_norm_; ``ws``: >= 1024 floats), ``fold`` (a ReduceList: its
+    split-K slab sums into g are performed by the update kernel itself, the rest is flushed first)."""
     _chk(g_extra, name="g_extra"); _chk(lr_table, name="lr_table"); _chk(mm_table, name="mm_table")
     if clip_norm and ws is None:
         ws = torch.empty(1024, device=p.device)
@@ -691,8 +695,10 @@ def optim_step(p, g, m, v, teacher, n_train, step, lr=2e-4, beta1=0.9, beta2=0.9
                     ema_mm=float(ema_mm), mm_table=_p(mm_table), mm_len=0 if mm_table is None else mm_table.numel(),
                     zero_grad=int(bool(zero_grad)), g_extra=_p(g_extra), n_extra=0 if g_extra is None else g_extra.shape[0],
                     extra_pitch=0 if g_extra is None else g_extra.stride(0), clip_norm=float(clip_norm or 0.0), ws=_p(ws),
-                    ws_floats=0 if ws is None else ws.numel())
+                    ws_floats=0 if ws is None else ws.numel(), fold=_dp(fold))
     L.check(L.lib().mhimx_optim_step(_stream(), C.byref(a)), "mhimx_optim_step")
+    if fold is not None:
+        fold.keep.clear()                      # (the slabs were read by the launch just enqueued; stream order protects them)
     return ws
 
 
