@@ -271,6 +271,12 @@ typedef struct {
                                          (its score is written as -inf: softmax weight 0, zero gradient in the backward).  Lets a shard of an
                                          instance-sharded bag run the pool over ALL its rows with fixed launch shapes (no data-dependent
                                          counts, no host sync).  One-pass scorer shapes only. */
+  const mhimx_prep_job* ride_jobs;    /* optional: n_ride_jobs parameter-only preparation jobs (mhimx_prep_batch's) that run as extra workgroups of the
+                                         one-pass scorer launch of this forward - in the workgroup slots it leaves free - instead of in a launch
+                                         of their own in front of the step: whatever the teacher's forward does not read itself (the student's
+                                         images, the backward's transposes, the Merge preparation's chain).  Their outputs are complete when
+                                         this call's launches are.  Other scorer shapes: a launch of their own inside this call. */
+  int32_t n_ride_jobs;
 } mhimx_pool_io;
 int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
 int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io);

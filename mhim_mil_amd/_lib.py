@@ -103,7 +103,7 @@ class PoolIO(C.Structure):
                 ("s", c_f32p), ("stats", c_f32p), ("z", c_f32p), ("u_pre", c_f32p),
                 ("wp", c_f32p), ("C", C.c_int64), ("cproj", c_f32p),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p), ("rows1", c_i64p),
-                ("excl", C.c_void_p)]
+                ("excl", C.c_void_p), ("ride_jobs", C.c_void_p), ("n_ride_jobs", C.c_int32)]
 
 
 class PoolGrad(C.Structure):

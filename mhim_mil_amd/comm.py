@@ -23,7 +23,8 @@ def unique_id() -> bytes:
 class NativeComm:
     """One RCCL communicator behind the C boundary.  ``init`` is collective: every rank calls it with the same id."""
 
-    def __init__(self, rank: int, world: int, id_bytes: bytes | None = None, group=None):
+    def __init__(self, rank: int, world: int, id_bytes: bytes | None = None, group=None, mode: int = 0):
+        self.mode = int(mode)            # default form of allreduce(): 0 = ncclAllReduce, 1 = reduce-scatter + all-gather (mesh)
         if id_bytes is None:
             if world == 1:
                 id_bytes = unique_id()
@@ -39,12 +40,12 @@ class NativeComm:
         L.check(L.lib().mhimx_comm_init(C.byref(h), C.create_string_buffer(id_bytes, 128), rank, world), "mhimx_comm_init")
         self._h = h
 
-    def allreduce(self, t: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    def allreduce(self, t: torch.Tensor, mode: int | None = None) -> torch.Tensor:
         """In-place fp32 SUM over the ranks on torch's current stream (enqueue only).  mode 1: reduce-scatter + all-gather."""
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise L.MhimxError("NativeComm.allreduce: a contiguous fp32 GPU tensor")
         L.check(L.lib().mhimx_comm_allreduce(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(t.data_ptr()),
-                                             t.numel(), int(mode)), "mhimx_comm_allreduce")
+                                             t.numel(), self.mode if mode is None else int(mode)), "mhimx_comm_allreduce")
         return t
 
     def close(self):

@@ -15,6 +15,7 @@
 
 #include "common.hpp"
 #include "mca2_side.hpp"
+#include "prep_jobs.hpp"
 
 namespace mhimx {
 
@@ -528,106 +529,15 @@ int pair_planes(hipStream_t st, const float* x, int64_t ldx, int64_t M, int64_t 
 // kind 4: MFMA B-fragment image of in[R,C] (scorer_fused.hip); kind 5: the same image of in^T; kind 7: paired planes of in^T.
 // (kind 6, several per launch - the bags of an accumulation window share the parameters but each owns a Merge workspace whose head
 // holds the query-side images: job q's workspace starts m2_shift[q.R] floats behind the first one's; the layout is the same)
-constexpr int PREP_MERGE_MAX = 8;
-struct PrepJobs { mhimx_prep_job j[MHIMX_PREP_MAX]; int first[MHIMX_PREP_MAX + 1]; int n; Merge2PrepArgs m2; int64_t m2_shift[PREP_MERGE_MAX]; };
-int merge2_prep_args(const mhimx_merge* m, int64_t R, void* ws, int64_t ws_bytes, Merge2PrepArgs* out);      // mca2.hip
 __global__ __launch_bounds__(256) void prep_batch_kernel(PrepJobs pj) {
-  // 1-D grid: job q owns blocks [first[q], first[q+1]) - sized per job (the bag's paired-plane image wants thousands of
-  // workgroups, a weight transpose a few dozen; a rectangular grid would launch tens of thousands of empty blocks)
-  int q = 0;
-  while (q + 1 < pj.n && (int)blockIdx.x >= pj.first[q + 1]) ++q;
-  const mhimx_prep_job jb = pj.j[q];
-  const int bid = (int)blockIdx.x - pj.first[q], nblk = pj.first[q + 1] - pj.first[q];
-  const int64_t R = jb.R, C = jb.C;
-  if (jb.kind == 0) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                   // 32 x 8
-    const int64_t tiles_c = (C + 31) / 32, ntiles = ((R + 31) / 32) * tiles_c;
-    for (int64_t t = bid; t < ntiles; t += nblk) {
-      const int64_t r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
-      for (int i = ty; i < 32; i += 8) {
-        const int64_t r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? jb.in[r * C + c] : 0.f;
-      }
-      __syncthreads();
-      for (int i = ty; i < 32; i += 8) {
-        const int64_t c = c0 + i, r = r0 + tx;
-        if (r < R && c < C) jb.out[c * R + r] = tile[tx][i];
-      }
-      __syncthreads();
-    }
-  } else if (jb.kind == 1) {
-    const int64_t K8 = C / 8, n = R * K8;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
-      const f4 a = *reinterpret_cast<const f4*>(jb.in + i * 8);
-      const f4 b = *reinterpret_cast<const f4*>(jb.in + i * 8 + 4);
-      b8 hi, lo;
-      Frag<MHIMX_PREC_BF16X3>::split2(a, b, hi, lo);
-      f4* o = reinterpret_cast<f4*>(jb.out + i * 8);
-      o[0] = __builtin_bit_cast(f4, hi);
-      o[1] = __builtin_bit_cast(f4, lo);
-    }
-  } else if (jb.kind == 2) {
-    const int64_t n = R * C;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) jb.out[i] = jb.in[i];
-  } else if (jb.kind == 3) {
-    if (bid == 0 && threadIdx.x == 0) *reinterpret_cast<uint64_t*>(jb.out) += 1;
-  } else if (jb.kind == 4) {
-    // B-operand fragment image for v_mfma_f32_32x32x16_bf16: item (nt, ks, lane) holds the 8 hi | 8 lo bf16 of
-    // in[32 nt + (lane & 31)][16 ks + 8 (lane >> 5) .. + 8]: a wave's fragment load is 2 KB contiguous
-    const int64_t KS = C / 16, n = R * C / 8;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
-      const int64_t lane = i & 63, ks = (i >> 6) % KS, nt = (i >> 6) / KS;
-      const float* src = jb.in + (32 * nt + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5);
-      const f4 a = *reinterpret_cast<const f4*>(src);
-      const f4 b = *reinterpret_cast<const f4*>(src + 4);
-      b8 hi, lo;
-      Frag<MHIMX_PREC_BF16X3>::split2(a, b, hi, lo);
-      f4* o = reinterpret_cast<f4*>(jb.out + i * 8);
-      o[0] = __builtin_bit_cast(f4, hi);
-      o[1] = __builtin_bit_cast(f4, lo);
-    }
-  } else if (jb.kind == 5) {
-    // the kind-4 image of in^T ([C, R]) made straight from in[R,C]: item (nt, ks, lane) holds in[16 ks + 8 (lane >> 5) + u][32 nt + (lane & 31)],
-    // u < 8 (a job of the same launch cannot read the transpose another job is still writing)
-    const int64_t KS = R / 16, n = R * C / 8;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
-      const int64_t lane = i & 63, ks = (i >> 6) % KS, nt = (i >> 6) / KS;
-      const float* src = jb.in + (16 * ks + 8 * (lane >> 5)) * C + 32 * nt + (lane & 31);
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = src[u * C];
-      b8 hi, lo;
-      Frag<MHIMX_PREC_BF16X3>::split(x, hi, lo);
-      f4* o = reinterpret_cast<f4*>(jb.out + i * 8);
-      o[0] = __builtin_bit_cast(f4, hi);
-      o[1] = __builtin_bit_cast(f4, lo);
-    }
-  } else if (jb.kind == 7) {
-    // paired planes of in^T [C, R]: item (g8, m) holds in[8 g8 + u][m], u < 8 (adjacent threads = adjacent columns m: coalesced reads)
-    const int64_t R8 = R / 8, n = R8 * C;
-    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
-      const int64_t g8 = i / C, m = i % C;
-      const float* src = jb.in + 8 * g8 * C + m;
-      float x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = src[u * C];
-      b8 hi, lo;
-      Frag<MHIMX_PREC_BF16X3>::split(x, hi, lo);
-      f4* o = reinterpret_cast<f4*>(jb.out + (m * R8 + g8) * 8);
-      o[0] = __builtin_bit_cast(f4, hi);
-      o[1] = __builtin_bit_cast(f4, lo);
-    }
-  } else if (jb.kind == 6) {
-    Merge2Ws w = pj.m2.w;
-    const int64_t sh = pj.m2_shift[jb.R];             // (only the fields the preparation writes are shifted)
-    w.gq += sh; w.gmean += sh; w.grstd += sh; w.Q += sh; w.aq += sh; w.aqf += sh; w.gtf_aq += sh;
-    merge2_prep_body(bid, pj.m2.q_param, pj.m2.ln_w, pj.m2.ln_b, pj.m2.wq, pj.m2.wkv, pj.m2.k, pj.m2.scale, w);
-  }
+  __shared__ __attribute__((aligned(16))) float lds[PREP_LDS_FLOATS];
+  prep_job_block(pj, (int)blockIdx.x, lds);                    // (prep_jobs.hpp)
 }
-int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
+int merge2_prep_args(const mhimx_merge* m, int64_t R, void* ws, int64_t ws_bytes, Merge2PrepArgs* out);      // mca2.hip
+// the job table of a launch (validated, block ranges assigned); returns the number of 256-thread blocks, < 0 on error
+int prep_jobs_fill(const mhimx_prep_job* jobs, int n, PrepJobs* out) {
   MHIMX_CHECK_ARG(jobs && n >= 1 && n <= MHIMX_PREP_MAX, "prep_batch: 1..%d jobs", MHIMX_PREP_MAX);
-  PrepJobs pj;
+  PrepJobs& pj = *out;
   pj.n = n;
   int n_merge = 0;
   for (int i = 0; i < n; ++i) {
@@ -664,7 +574,13 @@ int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
     first += (int)want;
   }
   pj.first[n] = first;
-  hipLaunchKernelGGL(prep_batch_kernel, dim3((unsigned)first), dim3(256), 0, st, pj);
+  return first;
+}
+int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n) {
+  PrepJobs pj;
+  const int blocks = prep_jobs_fill(jobs, n, &pj);
+  if (blocks < 0) return blocks;
+  hipLaunchKernelGGL(prep_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pj);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

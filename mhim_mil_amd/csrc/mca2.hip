@@ -42,7 +42,8 @@ bool merge2_ok(const mhimx_merge* m, int64_t R) {
 // 1. parameters (mca2_prep.hpp): standalone launch; a trainer runs the same body as a job of its preparation launch instead
 // ----------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(Merge2PrepArgs a) {
-  merge2_prep_body((int)blockIdx.x, a.q_param, a.ln_w, a.ln_b, a.wq, a.wkv, a.k, a.scale, a.w);
+  __shared__ __attribute__((aligned(16))) float lds[6 * M2_E + 6 * 64];
+  merge2_prep_body((int)blockIdx.x, lds, a.q_param, a.ln_w, a.ln_b, a.wq, a.wkv, a.k, a.scale, a.w);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------

@@ -148,10 +148,11 @@ MHIMX_DEV void m2_zero_tail(float* v, int k) {
 // ----------------------------------------------------------------------------------------------------------------------
 // (a device function: it is the body of merge2_prep_kernel (mca2.hip) and of job kind 6 of the step's ONE preparation launch
 // (prep_batch_kernel, gemm_dma.hip), where it runs beside the other parameter-only jobs instead of on the student's chain)
-MHIMX_DEV void merge2_prep_body(int block, const float* __restrict__ q_param, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+// lds: 6 * 512 + 6 * 64 floats, 16-byte aligned (the caller's: a rider must not add static LDS to its host kernel)
+MHIMX_DEV void merge2_prep_body(int block, float* lds, const float* __restrict__ q_param, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                 const float* __restrict__ wq, const float* __restrict__ wkv, int k, float scale, const Merge2Ws& w) {
-  __shared__ __attribute__((aligned(16))) float gqs[6 * M2_E];
-  __shared__ float qh[6 * 64];
+  float* gqs = lds;                 // [6][512]
+  float* qh = gqs + 6 * M2_E;       // [6][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = block >> 3, eb = block & 7;
   const int J = M2_H * k;

@@ -15,7 +15,8 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, const float* wa, const float* wp, int64_t C);
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl);
+                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl, const mhimx_prep_job* ride_jobs, int n_ride_jobs);
+int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);      // gemm_dma.hip
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
                      float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows);
@@ -792,6 +793,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   const int64_t Ms[2] = {io->M1, io->M2};
   int64_t off = 0;
   int G = 0;
+  bool rode = false;                            // (io->ride_jobs go with the first one-pass scorer launch; no such launch: a launch of their own)
   for (int seg = 0; seg < 2; ++seg) {
     if (Ms[seg] == 0) continue;
     if (scorer_fused_ok(E, A, gated, sc->prec, Ts[seg], sc->wa, io->cproj ? io->wp : nullptr, io->C)) {
@@ -799,8 +801,9 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       const int g1 = scorer_fused_fwd(st, Ts[seg], Ms[seg], sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, io->cproj ? io->wp : nullptr,
                                       (int)io->C, u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
                                       w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART, seg == 0 ? io->rows1 : nullptr,
-                                      seg == 0 ? io->excl : nullptr);
+                                      seg == 0 ? io->excl : nullptr, rode ? nullptr : io->ride_jobs, rode ? 0 : io->n_ride_jobs);
       if (g1 < 0) return g1;
+      rode = true;
       G += g1;
       off += Ms[seg];
       continue;
@@ -837,6 +840,8 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     G += grid;
     off += Ms[seg];
   }
+  if (!rode && io->ride_jobs && io->n_ride_jobs > 0)
+    if (int r = prep_batch(st, io->ride_jobs, io->n_ride_jobs)) return r;
   MHIMX_CHECK_ARG(!io->pscore || io->cproj, "pool_fwd: pscore needs cproj (and wp)");
   static_assert(2 * MAX_PART <= FIN_THREADS, "pool_finalize_kernel reads one partial per thread");
   // the pseudo score of the instances (if asked for) on blocks of its own, beside the E/64 blocks that merge the pooled row

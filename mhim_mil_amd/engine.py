@@ -123,8 +123,8 @@ class FlatState:
             off += (sizes[n] + 3) // 4 * 4                  # keep every tensor 16-byte aligned
             if n == self.train_names[-1]:
                 self.n_train = off
-        self.n_all = off
-        self.student = self._adopt(student, dev)
+        self.n_all = (off + 63) // 64 * 64         # (a multiple of every world size up to 64: the mesh form of the gradient exchange -
+        self.student = self._adopt(student, dev)   #  reduce-scatter + all-gather on count / world slices - takes the whole buffer)
         self.teacher = self._adopt(teacher, dev) if teacher is not None else None
         self.grad = torch.zeros(self.n_all, device=dev)
         self.m = torch.zeros(self.n_train, device=dev)
@@ -295,6 +295,7 @@ class FusedTrainer:
         self._g_extra = None
         self._fold_now, self._fold_list = False, None      # (train_step: the backward's last reductions inside the update kernel)
         self.fold_reductions = os.environ.get("MHIMX_FOLD_REDUCTIONS", "1") != "0"
+        self.ride_prep = os.environ.get("MHIMX_RIDE_PREP", "1") != "0"   # the student-side preparation jobs in the teacher's scorer launch
         self._graph_pool = None
         self._cap_stream = None
         self._side = None
@@ -431,7 +432,9 @@ class FusedTrainer:
         (the reference's student projects all N rows before it masks, mhim.py:335-336); the rows stay in bag order and the scorer,
         Merge, their backwards and the projection's weight-gradient GEMM gather the rows that take part by index."""
         first = self._micro == 0
-        prep_t, preps = self._nat_prep([x], i, with_opt_tick=first)
+        res = self._nat_prep([x], i, with_opt_tick=first, split=self.ride_prep)
+        prep_t, preps = res[0], res[1]
+        preps[0]["_ride_jobs"] = res[2] if len(res) > 2 else None
         hook = self._mid_hook if (first and self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1
                                   and not self._capturing and self._split > 0) else None
         out = self._nat_bag(x, label, prep_t, preps[0], self.flat.grad_views, accumulate=not first, perm=perm, ids_shuffle=ids_shuffle,
@@ -439,10 +442,14 @@ class FusedTrainer:
         self._micro += 1
         return out
 
-    def _nat_prep(self, xs, i, with_opt_tick=True):
+    def _nat_prep(self, xs, i, with_opt_tick=True, split=False):
         """The parameter-only preparation for the bags ``xs`` that share the current weights (one bag, or an accumulation window) as ONE
         launch: device counters, paired-plane / fragment / transposed weight images of both models, and - per bag, because it lives at the
-        head of that bag's Merge workspace - the query side of the projection-free Merge.  Returns (teacher prep, [student prep per bag])."""
+        head of that bag's Merge workspace - the query side of the projection-free Merge.  Returns (teacher prep, [student prep per bag]).
+        ``split`` (one bag, MHIM): only what the projection and the teacher's scorer read - the counters, both projection weight images,
+        the teacher's scorer image - is launched here; everything else (the student's scorer images, the backward's transposes, the query
+        snapshot, the Merge preparation's chain: ~2/3 of the launch's time) is returned as a third value and rides in the teacher's scorer
+        launch (ops.abmil_pool_fwd(ride_jobs=)), off the head of the step's chain."""
         s, t = self.s, self.t
         mhim = self.model_kind == "mhim"
         dev = xs[0].device
@@ -471,10 +478,16 @@ class FusedTrainer:
                     pb["_merge_prep_w"] = mw_prep                          # (keeps the weight struct alive until the launch is enqueued)
                     js.append((ops.PREP_MERGE, mw_prep, (pb["merge_ws"], R)))
                 preps.append(pb)
+            late = []
+            if split and mhim and len(xs) == 1:
+                w1_ptr = s.feature[0].weight.data_ptr()
+                early = [j for j in js if j[0] == ops.PREP_PAIR and j[1].data_ptr() == w1_ptr]
+                late = [j for j in js if not any(j is e for e in early)]
+                js = early
             ops.prep_batch(jobs + js)
         finally:
             s.merge_enable = merge_on
-        return prep_t, preps
+        return (prep_t, preps, late) if split else (prep_t, preps)
 
     def _nat_heads(self, x, prep_t, prep_s):
         """The student's feature buffer [N + k, E] (the k rows behind the bag: Merge's tokens) and both models' projection heads of a bag."""
@@ -514,7 +527,7 @@ class FusedTrainer:
             if mhim:
                 wp = t.predictor.weight.data if t.attn2score else None
                 st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp,
-                                          bp=t.predictor.bias.data if t.attn2score else None)
+                                          bp=t.predictor.bias.data if t.attn2score else None, ride_jobs=prep_s.get("_ride_jobs"))
                 score = st_t.pscore if t.attn2score else ops.softmax_from_stats(st_t.s, st_t.stats)
                 teacher_feat = st_t.z
                 _, _, len_keep, Lk, R = s.v2_counts(ps, i)

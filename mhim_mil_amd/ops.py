@@ -135,10 +135,8 @@ def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
 PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE, PREP_PAIR_T = 0, 1, 2, 3, 4, 5, 6, 7
 
 
-def prep_batch(jobs):
-    """jobs: list of (kind, in_tensor | None, out_tensor) -> ONE launch.  kind: PREP_TRANSPOSE (out = in^T), PREP_PAIR
-    (paired bf16 planes), PREP_COPY, PREP_TICK (out: int64/uint64 [1] counter += 1), PREP_FRAG (matrix-core fragment image
-    of a [32a, 16b] weight, see mhimx.h)."""
+def _prep_array(jobs):
+    """The C job array of a (kind, in_tensor | None, out_tensor) list (mhimx_prep_job)."""
     arr = (L.PrepJob * len(jobs))()
     for i, (kind, src, dst) in enumerate(jobs):
         if kind == PREP_TICK:
@@ -150,6 +148,14 @@ def prep_batch(jobs):
             _chk(src, name="prep in"); _chk(dst, name="prep out")
             R, Cc = (src.shape[0], src.numel() // src.shape[0]) if src.dim() >= 2 else (1, src.numel())
             arr[i] = L.PrepJob(kind, _p(src), _p(dst), R, Cc)
+    return arr
+
+
+def prep_batch(jobs):
+    """jobs: list of (kind, in_tensor | None, out_tensor) -> ONE launch.  kind: PREP_TRANSPOSE (out = in^T), PREP_PAIR
+    (paired bf16 planes), PREP_COPY, PREP_TICK (out: int64/uint64 [1] counter += 1), PREP_FRAG (matrix-core fragment image
+    of a [32a, 16b] weight, see mhimx.h)."""
+    arr = _prep_array(jobs)
     L.check(L.lib().mhimx_prep_batch(_stream(), arr, len(jobs)), "mhimx_prep_batch")
 
 
@@ -288,6 +294,7 @@ class PoolState:
         self.bp = bp
         self.pscore = torch.empty(M1, device=dev) if (wp is not None and bp is not None) else None
         self.ws = None
+        self.ride = None                     # (C job array, count): preparation jobs riding in the forward's scorer launch
 
     def io(self, sc: ScorerW):
         M = self.M1 + self.M2
@@ -297,18 +304,23 @@ class PoolState:
         return L.PoolIO(T1=_p(self.T1), M1=self.M1, T2=_p(self.T2), M2=self.M2, s=_p(self.s), stats=_p(self.stats),
                         z=_p(self.z), u_pre=None, wp=_p(self.wp), C=0 if self.cproj is None else self.cproj.shape[1],
                         cproj=_p(self.cproj), ws=_p(self.ws), ws_bytes=self.ws.numel(), bp=_p(self.bp), pscore=_p(self.pscore),
-                        rows1=_p(self.rows1), excl=_p(self.excl))
+                        rows1=_p(self.rows1), excl=_p(self.excl),
+                        ride_jobs=None if self.ride is None else C.cast(self.ride[0], C.c_void_p), n_ride_jobs=0 if self.ride is None else self.ride[1])
 
 
-def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=None):
+def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=None, ride_jobs=None):
     """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj; with ``bp`` also ``pscore`` [M1], the
     pseudo score of the T1 instances, written by the pool's finalize launch).  ``rows1`` (int64): the tokens are T1[rows1].
-    ``excl`` (uint8, by source row): rows that do not take part (score -inf; see mhimx_pool_io.excl)."""
+    ``excl`` (uint8, by source row): rows that do not take part (score -inf; see mhimx_pool_io.excl).  ``ride_jobs``: prep_batch
+    jobs that run as extra workgroups of this forward's scorer launch (mhimx_pool_io.ride_jobs)."""
     _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp"); _chk(bp, name="bp"); _chk(rows1, torch.int64, "rows1")
     _chk(excl, torch.uint8, "excl")
     st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp, rows1=rows1, excl=excl)
+    if ride_jobs:
+        st.ride = (_prep_array(ride_jobs), len(ride_jobs))
     io = st.io(sc)
     L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd")
+    st.ride = None                           # (the jobs ran with the forward; the backward's io carries none)
     return st
 
 
