@@ -26,8 +26,9 @@ from .mhim import MHIM, BagPlan
 class CommonMIL:
     """Hook object of the reference trainer (engines/common_mil.py)."""
 
-    def __init__(self, args=None) -> None:
+    def __init__(self, args=None, fused=None) -> None:
         self.training = True
+        self.fused = fused                 # optional optim.FusedAdamEMA: forward_func may run the native forward + backward (its docstring)
 
     def init_func_train(self, args, **kwargs):
         self.training = True
@@ -47,6 +48,19 @@ class CommonMIL:
     def forward_func(self, args, model, model_ema, bag, label, criterion, batch_size, i, epoch, n_iter, pos, **kwargs):
         """-> (logits, label, aux_loss, patch_num, keep_num, pad_ratio, kn_std)   (common_mil.py:14-48)"""
         dsmil = getattr(args, "baseline", "attn") == "dsmil"
+        fz = self.fused
+        if (fz is not None and model is fz.model and model_ema is fz.model_ema and model.training and not dsmil
+                and args.model == fz.trainer.model_kind and type(criterion) is torch.nn.CrossEntropyLoss and criterion.weight is None
+                and criterion.label_smoothing == 0.0 and criterion.reduction == "mean" and batch_size == 1):
+            # the loop's loss is main_alpha * CE + aux_alpha * aux (/ accumulation_steps), base_engine.py:99-102: the native step computes
+            # exactly that and its gradient (no autograd graph); the loop gets LEAVES - its criterion / backward touch no parameter
+            tr = fz.trainer
+            tr.main_alpha, tr.aux_alpha = float(getattr(args, "main_alpha", 1.0)), float(args.aux_alpha)
+            extra = {k: kwargs[k] for k in ("perm", "ids_shuffle") if k in kwargs}
+            logits, losses = tr.forward_backward(bag, label.view(-1)[:1], i=n_iter, **extra)
+            lg = logits.detach().view(batch_size, -1).requires_grad_(True)
+            aux = losses[2].detach().clone().requires_grad_(True)
+            return lg, label, aux, tr.last["patch_num"], tr.last["keep_num"], 0., 0.
         if args.model == "mhim":
             teacher_feat, score = (None, None)
             if model_ema is not None:

@@ -318,6 +318,14 @@ class MHIM(nn.Module):
                                    # FusedTrainer so that a captured hipGraph draws fresh masks on each replay
 
     # ------------------------------------------------------------------ weights in kernel layout
+    def parameters(self, recurse: bool = True):
+        """nn.Module.parameters - except for a teacher whose EMA a fused optimiser owns (optim.FusedAdamEMA sets ``_ema_owned``): the
+        reference trainer's per-parameter EMA loop (base_engine.py:166-167, ``zip(model.parameters(), model_ema.parameters())``) then finds
+        nothing left to update.  named_parameters / state_dict / load_state_dict are untouched."""
+        if getattr(self, "_ema_owned", False):
+            return iter(())
+        return super().parameters(recurse)
+
     @property
     def _bag_param_names(self):
         names = ["feature.0.weight", "feature.0.bias"]

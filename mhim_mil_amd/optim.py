@@ -1,0 +1,80 @@
+"""A fused optimiser for the REFERENCE trainer's own loop (engines/base_engine.py:76-167 unchanged).
+
+The two-line swap of INTEGRATION.md section 2 keeps the reference's host loop: ``loss.backward()``, ``optimizer.step()``,
+``optimizer.zero_grad()`` and the per-parameter EMA of the teacher (base_engine.py:155-167) - with ``torch.optim.Adam`` and the
+Python EMA loop that is ~60 launches per update around ~20 kernels of model.  ``FusedAdamEMA`` is a ``torch.optim.Optimizer`` that
+does all of it in ONE launch (``mhimx_optim_step``: Adam with the L2 term in the gradient - train_utils.py:58-65 - and the EMA of
+every parameter, ``merge.global_q_mm`` included) over flat buffers:
+
+    optimizer = FusedAdamEMA(model, model_ema, lr=args.lr, weight_decay=args.weight_decay, mm=args.mm,
+                             mm_sche=model_others['mm_sche'], main_alpha=args.main_alpha, aux_alpha=args.aux_alpha,
+                             accumulation_steps=args.accumulation_steps)      # instead of train_utils.py:58-65's torch.optim.Adam
+    engine = CommonMIL(args, fused=optimizer)                                  # optional: the native forward + backward as well
+
+* every parameter of both models becomes a view into one flat fp32 buffer per model (state_dict / load_state_dict keep working),
+  every ``.grad`` a view of one flat gradient buffer: autograd accumulates straight into what the update kernel reads;
+* ``step()`` is one launch; it also zeroes the gradient, so ``zero_grad()`` has nothing left to do (``.grad`` stays bound);
+* the teacher's EMA happens inside ``step()``.  The loop's own EMA (``for param_q, param_k in zip(model.parameters(),
+  model_ema.parameters())``, base_engine.py:166-167) must then find nothing to update: the adopted teacher's ``parameters()`` yields
+  nothing (``MHIM.parameters`` honours ``_ema_owned``; ``named_parameters`` / ``state_dict`` / ``load_state_dict`` are untouched).
+  The momentum of update t is ``mm_sche[t - 1]`` when a schedule is given (modules/__init__.py:177-181; the loop indexes it by
+  ``epoch * len(loader) + batch_idx``, which is the same count when accumulation_steps == 1), else ``mm``;
+* learning-rate schedulers work as with any optimiser: they write ``param_groups[0]['lr']``, ``step()`` reads it;
+* ``--clip_grad`` (dispatch_clip_grad on the parameters' ``.grad``: views of the flat buffer) works unchanged; the GradScaler path
+  (``--amp``) is not supported - the path computes in fp32-class arithmetic;
+* ``CommonMIL(args, fused=optimizer)``: ``forward_func`` then runs the NATIVE teacher forward + select + student forward + head + backward
+  (FusedTrainer.forward_backward: hand-derived backward, one projection launch for both models, no autograd graph) and hands the loop
+  leaf tensors - the loop's ``criterion`` / ``loss.backward()`` run on two leaves and touch no parameter.  Taken only when the loop's
+  loss IS ``main_alpha * CrossEntropyLoss(logits, label) + aux_alpha * aux_loss`` (base_engine.py:99-102: a plain
+  ``nn.CrossEntropyLoss``); anything else falls back to the autograd path, which lands in the same flat gradient.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .engine import FusedTrainer
+
+
+class FusedAdamEMA(torch.optim.Optimizer):
+    def __init__(self, model, model_ema=None, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, mm=0.9997, mm_sche=None,
+                 main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, model_kind=None):
+        if not any(p.is_cuda for p in model.parameters()):
+            raise ValueError("FusedAdamEMA: move the model to the GPU first (the flat buffers live where the parameters are)")
+        kind = model_kind or ("mhim" if model_ema is not None else "mhim_pure")
+        self.trainer = FusedTrainer(model, model_ema, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, mm=mm, main_alpha=main_alpha,
+                                    aux_alpha=aux_alpha, accumulation_steps=accumulation_steps, model=kind, mm_sche=mm_sche)
+        self.flat = self.trainer.flat
+        named = dict(model.named_parameters())
+        params = [named[n] for n in self.flat.train_names]
+        for n in self.flat.train_names:
+            named[n].grad = self.flat.grad_views[n]            # autograd accumulates into the flat buffer
+        self.trainer._grads_bound = True
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model, self.model_ema = model, model_ema
+        self._views = [(named[n], self.flat.grad_views[n]) for n in self.flat.train_names]
+        if model_ema is not None:
+            model_ema._ema_owned = True                          # base_engine.py:166-167 finds no parameter left to update
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None if closure is None else closure()
+        for p, v in self._views:                                # (a loop that set .grad to None or swapped it: fold it back)
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.add_(p.grad.reshape(v.shape))
+                p.grad = v
+        g = self.param_groups[0]
+        tr = self.trainer
+        tr.lr, tr.betas, tr.eps, tr.wd = float(g["lr"]), tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if tr._micro == 0:                                      # the gradient came through autograd: the native forward (which advances the
+            ops.tick(tr.opt_step)                               # device-resident Adam step counter in its preparation launch) did not run
+        tr.update()                                             # ONE launch: Adam + EMA, the gradient zeroed (+ the data-parallel sum when ranks > 1)
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Nothing to launch: ``step()`` zeroed the flat gradient.  Between updates of an accumulation window the gradient must
+        survive, and the reference only calls this after an update (base_engine.py:151)."""
+        if self.flat.step == 0:
+            self.flat.grad.zero_()

@@ -376,6 +376,34 @@ class TransMIL(_AttnMILBase):
         return [logits, attn, v] if return_act else [logits, attn]
 
 
+def build_teacher(model, others=None, teacher_init=None, no_tea_init=False, tea_type="ema", mm_sche=None):
+    """The MHIM teacher seam of the reference factory (modules/__init__.py:176-214): ``model_tea = deepcopy(model)`` (a device-resident
+    model copies on the device), the optional ``--teacher_init`` checkpoint loaded with ``strict=False`` after the ``module.`` prefix of a
+    DistributedDataParallel checkpoint is added / stripped to match (an ``mhim_pure`` checkpoint has no ``merge.*`` keys: they keep the
+    student's values), ``tea_type == 'same'`` -> the student itself, ``merge_test = False``.  Fills ``others['model_ema']`` and
+    ``others['mm_sche']`` as the factory does and returns the teacher."""
+    import copy
+    others = {} if others is None else others
+    others["mm_sche"] = mm_sche
+    tea = copy.deepcopy(model)
+    if teacher_init is not None and not no_tea_init and tea_type != "same":
+        pre = torch.load(teacher_init, weights_only=True) if isinstance(teacher_init, (str, bytes)) or hasattr(teacher_init, "read") else teacher_init
+        if "model" in pre:
+            pre = pre["model"]
+        model_has = any(k.startswith("module.") for k in tea.state_dict())
+        pre_has = any(k.startswith("module.") for k in pre)
+        if model_has and not pre_has:
+            pre = {"module." + k: v for k, v in pre.items()}
+        elif pre_has and not model_has:
+            pre = {k.replace("module.", ""): v for k, v in pre.items()}
+        others["teacher_init_info"] = tea.load_state_dict(pre, strict=False)
+    if tea_type == "same":
+        tea = model
+    tea.merge_test = False
+    others["model_ema"] = tea
+    return tea
+
+
 def build_model(model_name, **params):
     """The kernel-sharing branches of modules/__init__.py:71-116; ``params`` are the constructor arguments the reference's
     factory assembles (``genera_model_params`` / the MHIM ``model_params``)."""

@@ -135,3 +135,115 @@ def test_select_rows_draws_are_fair_on_small_lists(n, ratio_h, ratio_hr):
     q = R / L_
     g = cnt_merge[never] / T
     assert np.abs(g - q).max() < 4.5 * np.sqrt(q * (1 - q) / T) + 1e-9, (g.min(), g.max(), q)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the reference trainer's loop with the fused optimiser, and the factory's teacher seam
+# ------------------------------------------------------------------------------------------------------------------------------
+def _ref_loop_steps(model, ema, optimizer, own_ema, mm, steps, fused=None):
+    """The body of base_engine.py:76-167 for args.model == 'mhim' (forward_func, criterion, backward, optimizer.step, zero_grad, the
+    per-parameter EMA loop) on injected draws."""
+    import types
+    from mhim_mil_amd.engine import CommonMIL
+    args = types.SimpleNamespace(model="mhim", baseline="attn", aux_alpha=0.5, main_alpha=1.0)
+    eng = CommonMIL(args, fused=fused)
+    crit = torch.nn.CrossEntropyLoss()
+    out = []
+    for step in range(steps):
+        x = torch.from_numpy(synth.bag(3300 + step, N, D)).to(DEV)[None]
+        label = torch.tensor([step % 2], device=DEV)
+        k, n_sel, _ = O.mask_count(N, V2["mask_ratio_h"], V2["mask_ratio_hr"])
+        perm = torch.from_numpy(synth.permutation(250 + step, k)).to(DEV)
+        shuf = torch.from_numpy(synth.permutation(270 + step, N - n_sel)).to(DEV)
+        logits, lab, aux, pn, kn, _, _ = eng.forward_func(args, model, ema, x, label, crit, 1, step, 0, step, None, perm=perm, ids_shuffle=shuf)
+        loss = args.main_alpha * crit(logits.view(1, -1), lab) + args.aux_alpha * aux
+        loss.backward()
+        optimizer.step()
+        eng.after_backward_func(args, model=model, others=None, num_updates=step)
+        optimizer.zero_grad()
+        n_updated = 0
+        for pq, pk in zip(model.parameters(), ema.parameters()):                # base_engine.py:166-167
+            pk.data.mul_(mm).add_(pq.data, alpha=1. - mm)
+            n_updated += 1
+        assert (n_updated == 0) == (not own_ema)
+        out.append(float(loss))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_fused_adam_ema_under_the_reference_loop_equals_torch_adam_plus_ema_loop():
+    from mhim_mil_amd.optim import FusedAdamEMA
+    mm = 0.99
+    s1, t1 = _models()
+    for p in t1.parameters():
+        p.requires_grad_(False)
+    opt1 = torch.optim.Adam([p for p in s1.parameters() if p.requires_grad], lr=2e-4, weight_decay=1e-5)
+    l1 = _ref_loop_steps(s1, t1, opt1, True, mm, 3)
+    s2, t2 = _models()
+    opt2 = FusedAdamEMA(s2, t2, lr=2e-4, weight_decay=1e-5, mm=mm)
+    assert list(t2.parameters()) == [] and len(list(t2.named_parameters())) == len(list(s2.named_parameters()))
+    l2 = _ref_loop_steps(s2, t2, opt2, False, mm, 3)
+    np.testing.assert_allclose(l1, l2, rtol=0, atol=2e-5)
+    for (n, a), (_, b) in zip(s1.state_dict().items(), s2.state_dict().items()):
+        if "global_q" in n:
+            continue                                                            # (Merge's in-forward EMA of the queries: both loops do it)
+        err = (a.double() - b.double()).abs()
+        assert err.mean().item() <= 2e-6 and err.max().item() <= 3 * 4.1e-4, (n, err.mean().item(), err.max().item())
+    for (n, a), (_, b) in zip(t1.state_dict().items(), t2.state_dict().items()):
+        err = (a.double() - b.double()).abs().max().item()
+        assert err <= 3e-5, ("teacher", n, err)
+    # the flat gradient is zero after an update, .grad still bound to it
+    assert float(opt2.flat.grad.abs().max()) == 0.0
+    assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in opt2._views)
+    # CommonMIL(args, fused=optimizer): forward_func runs the native forward + backward, the loop's criterion / backward see two leaves
+    s3, t3 = _models()
+    opt3 = FusedAdamEMA(s3, t3, lr=2e-4, weight_decay=1e-5, mm=mm)
+    calls = []
+    orig = opt3.trainer.forward_backward
+    opt3.trainer.forward_backward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    l3 = _ref_loop_steps(s3, t3, opt3, False, mm, 3, fused=opt3)
+    assert len(calls) == 3
+    np.testing.assert_allclose(l1, l3, rtol=0, atol=2e-5)
+    for (n, a), (_, b) in zip(s1.state_dict().items(), s3.state_dict().items()):
+        if "global_q" in n:
+            continue
+        err = (a.double() - b.double()).abs()
+        assert err.mean().item() <= 2e-6 and err.max().item() <= 3 * 4.1e-4, ("native", n, err.mean().item(), err.max().item())
+    for (n, a), (_, b) in zip(t1.state_dict().items(), t3.state_dict().items()):
+        assert (a.double() - b.double()).abs().max().item() <= 3e-5, ("native teacher", n)
+
+
+def test_factory_teacher_seam_on_the_device():
+    """modules/__init__.py:176-214 on device-resident models: deepcopy of a student whose parameters are views of a trainer's flat buffer,
+    --teacher_init of an mhim_pure checkpoint saved from DistributedDataParallel (module. keys, no merge.*) with strict=False,
+    merge_test False, others['model_ema'] / ['mm_sche']; the pair then trains under FusedTrainer."""
+    from mhim_mil_amd.engine import FusedTrainer
+    from mhim_mil_amd.standalone import build_teacher
+    s, t0 = _models()
+    tr0 = FusedTrainer(s, t0, aux_alpha=0.5, mm=0.999)                           # (s's parameters are views of tr0's flat buffer now)
+    x = torch.from_numpy(synth.bag(77, N, D)).to(DEV)
+    tr0.train_step(x, torch.tensor([1], device=DEV))
+    others = {}
+    pure = {("module." + k): (v.detach().clone() + 0.25) for k, v in s.state_dict().items() if not k.startswith("merge.")}
+    tea = build_teacher(s, others, teacher_init={"model": pure}, mm_sche=None)
+    assert others["model_ema"] is tea and others["mm_sche"] is None and tea.merge_test is False and tea is not s
+    info = others["teacher_init_info"]
+    assert sorted(info.missing_keys) == sorted(k for k in s.state_dict() if k.startswith("merge.")) and not info.unexpected_keys
+    for k, v in s.state_dict().items():
+        tv = tea.state_dict()[k]
+        assert tv.is_cuda and tv.data_ptr() != v.data_ptr()
+        want = v if k.startswith("merge.") else v + 0.25
+        assert torch.equal(tv, want), k
+    before = {k: v.clone() for k, v in tea.state_dict().items()}
+    s.feature[0].weight.data.add_(1.0)                                          # the copy does not alias the student's flat buffer
+    assert torch.equal(tea.state_dict()["feature.0.weight"], before["feature.0.weight"])
+    s.feature[0].weight.data.sub_(1.0)
+    same = build_teacher(s, {}, tea_type="same")
+    assert same is s and s.merge_test is False
+    tr = FusedTrainer(s, tea, aux_alpha=0.5, mm=0.999)
+    logits, losses = tr.train_step(x, torch.tensor([0], device=DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(losses).all()
+    # the teacher moved by the EMA of the update: (1 - mm) of the distance to the student
+    d = (tea.state_dict()["feature.0.bias"] - before["feature.0.bias"]).abs().max().item()
+    assert 0 < d < 1e-3

@@ -67,7 +67,25 @@ def timed(fn, name):
 
 
 timed(ref_step, f"drop-in classes under the reference loop ({BASE})")
+
+# ---- the same loop with the fused optimiser (optim.FusedAdamEMA: Adam + every parameter's EMA in ONE launch; the loop's own EMA finds
+# no teacher parameter left to update)
+from mhim_mil_amd.optim import FusedAdamEMA
+model, ema = mk(), mk()
+opt = FusedAdamEMA(model, ema, lr=2e-4, weight_decay=1e-5, mm=mm)
+timed(ref_step, f"the same loop with optim.FusedAdamEMA ({BASE})")
+model, ema = mk(), mk()
+opt = FusedAdamEMA(model, ema, lr=2e-4, weight_decay=1e-5, mm=mm)
+engine = CommonMIL(args, fused=opt)                       # forward_func runs the native forward + backward; the loop is unchanged
+timed(ref_step, f"... + CommonMIL(args, fused=optimizer) ({BASE})")
 tr = FusedTrainer(mk(), mk(), aux_alpha=0.5)
 timed(lambda i: tr.train_step(bags[i % 4][0], label), "FusedTrainer.train_step, eager")
+if os.environ.get("PROFILE_EAGER") == "1":
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for i in range(20):
+        tr.train_step(bags[i % 4][0], label)
+    torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 graphs = [tr.capture(bags[i][0], label, warmup=2) for i in range(4)]
 timed(lambda i: graphs[i % 4].replay(), "FusedTrainer, hipGraph replay")
