@@ -466,6 +466,14 @@ typedef struct {
                                          dX[x_rows[n]] (backward): merge.py:158-176 masking without a row copy         */
   int32_t prepared;                   /* 1: the parameter-only part (LN(q), Q, the score vectors) is already in the workspace, written by a
                                          kind-6 job of mhimx_prep_batch on the same stream, for the same weights, R and workspace */
+  int64_t own_lo, own_n;              /* an instance-sharded bag (one bag's rows split over the GPUs, BASELINE c5): x_rows holds BAG row ids, this
+                                         shard owns [own_lo, own_lo + own_n) and its X / dX hold only those rows (row id - own_lo).  Rows of the
+                                         list that are another shard's take no part here.  Forward: mhimx_merge_fwd_part on every shard, an
+                                         all-gather of the blocks, mhimx_merge_fwd_finish on every shard.  Backward: mhimx_merge_bwd - dX for the
+                                         own rows, parameter gradients as PARTIAL sums over the shards (the caller's gradient all-reduce adds
+                                         them).  own_n == 0: one process holds every row.  Projection-free form only (E = 512, 8 x 64, k <= 6). */
+  float rep;                          /* with own_n > 0: weight of the gradient terms every shard computes identically (d_bo, d_wo, the V half of
+                                         d_wkv) - 1 on one shard, 0 on the others, so that the sum over the shards counts them once */
 } mhimx_merge;
 int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
 /* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */
@@ -477,6 +485,17 @@ typedef struct {
   mhimx_reduce_list* defer;           /* optional: queue the d_ln_w / d_ln_b / d_wkv final reductions            */
 } mhimx_merge_grad;
 /* dz[k,E] -> dX[R,E] (overwritten) and parameter gradients. */
+/* The forward of an instance-sharded bag (mhimx_merge.own_n > 0), in two halves around ONE all-gather of mhimx_merge_part_floats() floats
+ * per shard (99 KB; the replicated form all-reduced the [R, 512] block of rows to merge: 39.7 MB at c5):
+ *   fwd_part    the rows pass over this shard's rows and the merge of its tile partials, left raw: part = {max[48] | sum[48] | dropped
+ *               sum[48] | pooled rows [48][512]} per score slot (head, query);
+ *   fwd_finish  parts [W][mhimx_merge_part_floats()] of all shards (the same on every shard, shard order = merge order: bit-identical
+ *               replicas) -> pooled rows Y + softmax statistics in this shard's workspace, tokens z, the queries' EMA.
+ * R, ws: the same on both calls and on mhimx_merge_bwd. */
+int64_t mhimx_merge_part_floats(void);
+int mhimx_merge_fwd_part(void* stream, const mhimx_merge* m, const float* X, int64_t R, float* part, void* ws, int64_t ws_bytes);
+int mhimx_merge_fwd_finish(void* stream, const mhimx_merge* m, const float* parts, int32_t W, int64_t R, float* z, float* q_new,
+                           int32_t update_q, void* ws, int64_t ws_bytes);
 int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX,
                     const mhimx_merge_grad* g, void* ws, int64_t ws_bytes);
 

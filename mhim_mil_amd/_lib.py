@@ -119,7 +119,8 @@ class Merge(C.Structure):
                 ("wkv", c_f32p), ("wq", c_f32p), ("wo", c_f32p), ("bo", c_f32p),
                 ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
                 ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p),
-                ("wkv_frag", c_f32p), ("x_rows", c_i64p), ("prepared", C.c_int32)]
+                ("wkv_frag", c_f32p), ("x_rows", c_i64p), ("prepared", C.c_int32), ("own_lo", C.c_int64), ("own_n", C.c_int64),
+                ("rep", C.c_float)]
 
 
 class MergeGrad(C.Structure):
@@ -186,6 +187,9 @@ SYMBOLS = {
     "mhimx_random_perm": (C.c_int, [_P, _I64, _U64, _P, _P, _P]),
     "mhimx_merge_ws_bytes": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "mhimx_merge_fwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I32, _P, _I64]),
+    "mhimx_merge_part_floats": (_I64, []),
+    "mhimx_merge_fwd_part": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I64]),
+    "mhimx_merge_fwd_finish": (C.c_int, [_P, C.POINTER(Merge), _P, _I32, _I64, _P, _P, _I32, _P, _I64]),
     "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
     "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_softmax_cols": (C.c_int, [_P, _P, _P, _I64, _I64, _F]),

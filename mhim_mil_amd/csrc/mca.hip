@@ -26,6 +26,10 @@ int colsum(hipStream_t st, const float* X, int64_t M, int64_t E, float* out, int
 bool merge2_ok(const mhimx_merge* m, int64_t R);
 int64_t merge2_ws_bytes(int64_t R, int64_t k);
 int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new, int update_q, void* ws, int64_t ws_bytes);
+int merge2_fwd_part(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* part, void* ws, int64_t ws_bytes);
+int merge2_fwd_finish(hipStream_t st, const mhimx_merge* m, const float* parts, int W, int64_t R, float* z, float* q_new, int update_q, void* ws,
+                      int64_t ws_bytes);
+int64_t merge2_part_floats();
 int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* gr, void* ws,
                int64_t ws_bytes);
 
@@ -518,6 +522,7 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   if (int r = check_merge(m)) return r;
   MHIMX_CHECK_ARG(X && z && R > 0, "merge_fwd: null args");
   if (merge2_ok(m, R)) return merge2_fwd(st, m, X, R, z, q_new, update_q, ws, ws_bytes);
+  MHIMX_CHECK_ARG(m->own_n == 0, "merge_fwd: a shard of an instance-sharded bag needs the projection-free form (E = 512, 8 x 64, k <= 6)");
   const int64_t E = m->E, k = m->k, H = m->heads, I = H * m->dim_head;
   Arena ar(ws, ws_bytes);
   MergeWs w;
@@ -579,6 +584,7 @@ int merge_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, c
   MHIMX_CHECK_ARG(X && dz && dX && gr && R > 0, "merge_bwd: null args");
   MHIMX_CHECK_ARG(gr->d_ln_w && gr->d_ln_b && gr->d_wkv && gr->d_wq && gr->d_wo && gr->d_bo, "merge_bwd: null grads");
   if (merge2_ok(m, R)) return merge2_bwd(st, m, X, R, dz, dX, gr, ws, ws_bytes);
+  MHIMX_CHECK_ARG(m->own_n == 0, "merge_bwd: a shard of an instance-sharded bag needs the projection-free form (E = 512, 8 x 64, k <= 6)");
   MHIMX_CHECK_ARG(m->wkv_t && m->wq_t && m->wo_t, "merge_bwd: transposed weights missing");
   const int64_t E = m->E, k = m->k, H = m->heads, I = H * m->dim_head;
   Arena ar(ws, ws_bytes);
@@ -660,6 +666,18 @@ extern "C" int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t
 extern "C" int mhimx_merge_fwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new,
                                int32_t update_q, void* ws, int64_t ws_bytes) {
   return merge_fwd((hipStream_t)stream, m, X, R, z, q_new, update_q, ws, ws_bytes);
+}
+extern "C" int64_t mhimx_merge_part_floats(void) { return merge2_part_floats(); }
+extern "C" int mhimx_merge_fwd_part(void* stream, const mhimx_merge* m, const float* X, int64_t R, float* part, void* ws, int64_t ws_bytes) {
+  if (int r = check_merge(m)) return r;
+  MHIMX_CHECK_ARG(X && R > 0 && ws && merge2_ok(m, R), "merge_fwd_part: needs the projection-free form (E = 512, 8 x 64, k <= 6, R <= 32768, not exact f32)");
+  return merge2_fwd_part((hipStream_t)stream, m, X, R, part, ws, ws_bytes);
+}
+extern "C" int mhimx_merge_fwd_finish(void* stream, const mhimx_merge* m, const float* parts, int32_t W, int64_t R, float* z, float* q_new,
+                                      int32_t update_q, void* ws, int64_t ws_bytes) {
+  if (int r = check_merge(m)) return r;
+  MHIMX_CHECK_ARG(R > 0 && ws && merge2_ok(m, R), "merge_fwd_finish: needs the projection-free form");
+  return merge2_fwd_finish((hipStream_t)stream, m, parts, W, R, z, q_new, update_q, ws, ws_bytes);
 }
 extern "C" int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX,
                                const mhimx_merge_grad* g, void* ws, int64_t ws_bytes) {

@@ -27,6 +27,7 @@
 
 namespace mhimx {
 
+int64_t merge2_part_floats() { return M2_PART_FLOATS; }
 int64_t merge2_ws_bytes(int64_t R, int64_t k) {
   Arena ar(nullptr, 0);
   return merge2_ws_layout(ar, R, k, nullptr);
@@ -51,17 +52,47 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(Merge2PrepArgs 
 // ----------------------------------------------------------------------------------------------------------------------
 // rows of the tile -> xhat = (x - mean) rstd in LDS [32][516]; HAVE_STATS: mean / rstd are read instead of computed.
 // Also stages the LayerNorm weight and bias in LDS (lnw[512], lnb[512]).
+// ok[32] (LDS): 1.f for the rows of the tile that take part - inside the list AND, for an instance-sharded bag (Merge2Ws.own_*), owned by
+// this shard; the others are loaded as zeros (their source is clamped to a valid row).  Returns nothing; a tile without any such row is
+// detected by the caller (m2_tile_dead) before this is called.
+MHIMX_DEV bool m2_row_ok(const int64_t* __restrict__ xrows, int64_t R, int64_t n, const Merge2Ws& w, int64_t& src_row) {
+  if (n >= R) { src_row = 0; return false; }
+  const int64_t id = xrows ? xrows[n] : n;
+  if (w.own_n > 0) {
+    const bool own = id >= w.own_lo && id < w.own_lo + w.own_n;
+    src_row = own ? id - w.own_lo : 0;
+    return own;
+  }
+  src_row = id;
+  return true;
+}
+// sharded bags only: true when no row of the tile is this shard's (every thread gets the same answer; flags: 4 ints of LDS)
+MHIMX_DEV bool m2_tile_dead(const int64_t* __restrict__ xrows, int64_t R, int64_t row0, const Merge2Ws& w, int* flags) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t dummy;
+  const bool mine = lane < 8 && m2_row_ok(xrows, R, row0 + wave + 4 * lane, w, dummy);
+  const bool any = __builtin_amdgcn_ballot_w64(mine) != 0;
+  if (lane == 0) flags[wave] = any ? 1 : 0;
+  __syncthreads();
+  const bool dead = (flags[0] | flags[1] | flags[2] | flags[3]) == 0;
+  __syncthreads();
+  return dead;
+}
 template <bool HAVE_STATS>
 MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R, int64_t row0, float* xh, float* mean,
-                            float* rstd, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* lnw, float* lnb, float* rs_tile) {
+                            float* rstd, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* lnw, float* lnb, float* rs_tile,
+                            const Merge2Ws& w, float* ok) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   m2_f4 a[8], b[8];
   float mu8[8], rs8[8];
+  bool okq[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {                               // all 16 row loads of this wave in flight
     const int64_t n = row0 + wave + 4 * q;
     const int64_t nc = n < R ? n : R - 1;
-    const float* src = X + (xrows ? xrows[nc] : nc) * M2_E;
+    int64_t srow;
+    okq[q] = m2_row_ok(xrows, R, n, w, srow);
+    const float* src = X + srow * M2_E;
     a[q] = *reinterpret_cast<const m2_f4*>(src + 4 * lane);
     b[q] = *reinterpret_cast<const m2_f4*>(src + 256 + 4 * lane);
     if (HAVE_STATS) { mu8[q] = mean[nc]; rs8[q] = rstd[nc]; }
@@ -79,10 +110,11 @@ MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restri
       if (lane == 0) rs_tile[rr] = rs;
     } else {
       m2_ln_stats(a[q], b[q], mu, rs);
-      if (lane == 0 && n < R) { mean[n] = mu; rstd[n] = rs; }
+      if (lane == 0 && okq[q]) { mean[n] = mu; rstd[n] = rs; }
     }
+    if (lane == 0) ok[rr] = okq[q] ? 1.f : 0.f;
     m2_f4 ya = (a[q] - mu) * rs, yb = (b[q] - mu) * rs;
-    if (n >= R) { ya = m2_f4{0.f, 0.f, 0.f, 0.f}; yb = ya; }
+    if (!okq[q]) { ya = m2_f4{0.f, 0.f, 0.f, 0.f}; yb = ya; }
     *reinterpret_cast<m2_f4*>(xh + rr * M2_XLD + 4 * lane) = ya;
     *reinterpret_cast<m2_f4*>(xh + rr * M2_XLD + 256 + 4 * lane) = yb;
   }
@@ -173,7 +205,7 @@ MHIMX_DEV bool m2_keep(uint64_t seed, int j, int64_t r, float p) { return drop_k
 // ----------------------------------------------------------------------------------------------------------------------
 // 2. rows forward: LayerNorm, scores against the J slots, per-tile softmax partials, pooled rows.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t M2_FWD_SMEM = (size_t)(M2_ROWS * M2_XLD + 4 * M2_ROWS * M2_JP + M2_JP * M2_PLD + 2 * M2_E) * sizeof(float);
+constexpr size_t M2_FWD_SMEM = (size_t)(M2_ROWS * M2_XLD + 4 * M2_ROWS * M2_JP + M2_JP * M2_PLD + 2 * M2_E + M2_ROWS + 4) * sizeof(float);
 
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
@@ -184,12 +216,19 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
   float* pdT = red + 4 * M2_ROWS * M2_JP;            // [48][36]
   float* lnw = pdT + M2_JP * M2_PLD;                 // [512]
   float* lnb = lnw + M2_E;                           // [512]
+  float* ok = lnb + M2_E;                            // [32] 1 = the row takes part
+  int* flags = reinterpret_cast<int*>(ok + M2_ROWS); // [4]
   const int tid = threadIdx.x;
   const int t = blockIdx.x;
   const int64_t row0 = (int64_t)t * M2_ROWS;
+  if (w.own_n > 0 && m2_tile_dead(xrows, R, row0, w, flags)) {
+    // an instance-sharded bag: no row of this tile is this shard's - an empty partial (weight 0 in every merge; its pooled rows are never read)
+    if (tid < M2_JP) { w.pm[t * M2_JP + tid] = -INFINITY; w.pl[t * M2_JP + tid] = 0.f; w.psd[t * M2_JP + tid] = 0.f; }
+    return;
+  }
   M2Frags fr;
   m2_fetch_frags(w.aqf, fr);
-  m2_load_rows<false>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr);
+  m2_load_rows<false>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr, w, ok);
   __syncthreads();
   m2_rows_times_slots(xh, lnw, lnb, fr, red);
   __syncthreads();
@@ -203,14 +242,15 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
   // per-slot softmax partials of the tile: 4 threads per slot (8 rows each), combined through LDS
   float* sc = red + M2_ROWS * M2_JP;                 // [3][4][48] scratch (the partial-product slabs 1..3 are free)
   const int j = tid % M2_JP, rq = tid / M2_JP;        // rq < 4 for the first 192 threads
-  const int nv = (int)((R - row0) < M2_ROWS ? (R - row0) : M2_ROWS);
   float sreg[8], m = -INFINITY;
+  bool rv[8];
   if (rq < 4) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = rq * 8 + q;
       sreg[q] = red[r * M2_JP + j];
-      if (j < J && r < nv) m = fmaxf(m, sreg[q]);
+      rv[q] = ok[r] != 0.f;
+      if (j < J && rv[q]) m = fmaxf(m, sreg[q]);
     }
     sc[rq * M2_JP + j] = m;
   }
@@ -224,7 +264,7 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
     for (int q = 0; q < 8; ++q) {
       const int r = rq * 8 + q;
       float p = 0.f, pd = 0.f;
-      if (j < J && r < nv) {
+      if (j < J && rv[q]) {
         p = __expf(sreg[q] - m);
         pd = (drop_p > 0.f && !m2_keep(seed, j, row0 + r, drop_p)) ? 0.f : p * ks;
       }
@@ -250,11 +290,12 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
 //     SOFTMAX: wgt_t = e^{pm_t - M} / L (online softmax merge, fixed order), out = y ln_w + (sum_t psd_t wgt_t) ln_b, stats = (M, L);
 //     else wgt_t = 1 and out = u ln_w.
 // ----------------------------------------------------------------------------------------------------------------------
-template <bool SOFTMAX>
-__global__ __launch_bounds__(M2_THREADS) void merge2_partials_kernel(const float* __restrict__ part, const float* __restrict__ ln_w,
-                                                                    const float* __restrict__ ln_b, float* __restrict__ out, Merge2Ws w) {
+template <int MODE>
+__global__ __launch_bounds__(M2_THREADS) void merge2_partials_kernel(M2Parts in, int live_only, const float* __restrict__ ln_w,
+                                                                    const float* __restrict__ ln_b, float* __restrict__ out,
+                                                                    float* __restrict__ stats, float* __restrict__ raw_stats) {
   __shared__ float lds[M2_PARTIALS_LDS];
-  merge2_partials_body<SOFTMAX>((int)blockIdx.x, lds, part, ln_w, ln_b, out, w);
+  merge2_partials_body<MODE>((int)blockIdx.x, lds, in, live_only != 0, ln_w, ln_b, out, stats, raw_stats);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -284,16 +325,16 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_o_kernel(const float* __res
 __global__ __launch_bounds__(M2_THREADS) void merge2_bwd_pre_kernel(const float* __restrict__ dz, const float* __restrict__ wo_t,
                                                                    const float* __restrict__ wkv, int k, float drop_p, uint64_t seed0,
                                                                    const uint64_t* __restrict__ tick, float* __restrict__ d_bo, int accumulate,
-                                                                   Merge2Ws w) {
+                                                                   Merge2Ws w, float rep) {
   __shared__ __attribute__((aligned(16))) float lds[M2_BWD_PRE_LDS];
-  merge2_bwd_pre_body((int)blockIdx.x, lds, dz, wo_t, wkv, k, drop_p, seed0, tick, d_bo, accumulate, w);      // (mca2_side.hpp)
+  merge2_bwd_pre_body((int)blockIdx.x, lds, dz, wo_t, wkv, k, drop_p, seed0, tick, d_bo, accumulate, w, rep);      // (mca2_side.hpp)
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // 5. rows backward: dPd = xn dY^T, softmax backward, dxn = ds aq + Pd dY, LayerNorm backward (dX scattered to the rows' places,
 //    per-tile d_ln_w / d_ln_b partials), pooled U partials.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t M2_BWD_SMEM = (size_t)(2 * M2_ROWS * M2_XLD + M2_ROWS * M2_CLD + M2_JP * M2_PLD + 2 * M2_E + 3 * M2_JK + M2_ROWS) * sizeof(float);
+constexpr size_t M2_BWD_SMEM = (size_t)(2 * M2_ROWS * M2_XLD + M2_ROWS * M2_CLD + M2_JP * M2_PLD + 2 * M2_E + 3 * M2_JK + 2 * M2_ROWS + 4) * sizeof(float);
 static_assert(M2_ROWS * M2_CLD >= 8 * M2_E, "the LayerNorm partials reuse the coefficient tile");
 
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
@@ -309,14 +350,19 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
   float* lnb = lnw + M2_E;                            // [512]
   float* sst = lnb + M2_E;                            // [64][3]: softmax max, 1 / sum, delta of every slot
   float* rst = sst + 3 * M2_JK;                       // [32] rstd of the tile's rows
+  float* ok = rst + M2_ROWS;                          // [32] 1 = the row takes part
+  int* flags = reinterpret_cast<int*>(ok + M2_ROWS);  // [4]
   float* lnred = cf;                                  // [4][2][512]: the coefficient tile is in registers by then
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
   const int t = blockIdx.x;
   const int64_t row0 = (int64_t)t * M2_ROWS;
+  if (t == 0 && tid == 0) *w.gate = 0u;               // (the tail's stage-2 arrivals are counted from here: bag_wgrad_ws_kernel)
+  // an instance-sharded bag: a tile without a row of this shard leaves no gradient and no partial (the merges of the pooled / LayerNorm
+  // partials skip the tiles whose forward partial is empty: w.pl == 0)
+  if (w.own_n > 0 && m2_tile_dead(xrows, R, row0, w, flags)) return;
   M2Frags fr;
   m2_fetch_frags(w.dyf, fr);
-  if (t == 0 && tid == 0) *w.gate = 0u;               // (the tail's stage-2 arrivals are counted from here: bag_wgrad_ws_kernel)
   if (tid < M2_JK) {
     const int j = tid;
     float mx = 0.f, il = 0.f, de = 0.f;
@@ -335,7 +381,7 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
     const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
     sv[q] = (j < J && row0 + r < R) ? w.S[(row0 + r) * M2_JP + j] : 0.f;
   }
-  m2_load_rows<true>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, rst);
+  m2_load_rows<true>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, rst, w, ok);
   __syncthreads();
   m2_rows_times_slots(xh, lnw, lnb, fr, dxs);
   __syncthreads();
@@ -347,7 +393,7 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
     for (int q = 0; q < M2_ROWS * M2_JK / M2_THREADS; ++q) {
       const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
       float ds = 0.f, pd = 0.f;
-      if (j < J && row0 + r < R) {
+      if (j < J && ok[r] != 0.f) {
         const int qq = r * M2_JP + j;
         const float dpd = (dxs[qq] + dxs[M2_ROWS * M2_JP + qq]) + (dxs[2 * M2_ROWS * M2_JP + qq] + dxs[3 * M2_ROWS * M2_JP + qq]);
         const float p = __expf(sv[q] - sst[3 * j]) * sst[3 * j + 1];
@@ -409,8 +455,8 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
     int64_t dst_row[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int64_t n = row0 + wave + 4 * q;
-      dst_row[q] = n < R ? (xrows ? xrows[n] : n) : -1;
+      int64_t srow;
+      dst_row[q] = m2_row_ok(xrows, R, row0 + wave + 4 * q, w, srow) ? srow : -1;      // (a shard's dX holds its own rows: id - own_lo)
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -469,8 +515,8 @@ int mca_out(hipStream_t st, const float* O, const float* wo, const float* bo, in
 int reduce_parts2(hipStream_t st, const float* part0, const float* part1, int G, int W, int ld, float* out0, float* out1, int accumulate);   // rows.hip
 
 int merge2_side_launch(hipStream_t st, int stage, const Merge2Side& sd) {
-  if (stage == 1) hipLaunchKernelGGL(merge2_partials_kernel<false>, dim3((unsigned)(sd.J * 4)), dim3(M2_THREADS), 0, st, sd.w.upart, sd.ln_w, sd.ln_b,
-                                     const_cast<float*>(sd.U), sd.w);
+  if (stage == 1) hipLaunchKernelGGL(merge2_partials_kernel<0>, dim3((unsigned)(sd.J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(sd.w, sd.w.upart),
+                                     sd.w.own_n > 0 ? 1 : 0, sd.ln_w, sd.ln_b, const_cast<float*>(sd.U), (float*)nullptr, (float*)nullptr);
   else if (stage == 2) hipLaunchKernelGGL(merge2_grads1_kernel, dim3(M2_GRADS1_BLOCKS), dim3(M2_THREADS), 0, st, sd);
   else hipLaunchKernelGGL(merge2_grads2_kernel, dim3(M2_GRADS2_BLOCKS), dim3(M2_THREADS), 0, st, sd);
   MHIMX_LAUNCH_CHECK();
@@ -487,12 +533,16 @@ int merge2_side_finish(hipStream_t st, mhimx_side_work* side, int upto_stage) {
   return 0;
 }
 
-int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new, int update_q, void* ws, int64_t ws_bytes) {
+// the forward up to the row tiles' partials: parameters (unless prepared), rows pass.  An instance-sharded bag (m->own_n > 0): only the rows
+// this shard owns take part.
+static int merge2_fwd_rows(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, void* ws, int64_t ws_bytes, Merge2Ws* wout) {
   Arena ar(ws, ws_bytes);
   Merge2Ws w;
   merge2_ws_layout(ar, R, m->k, &w);
   MHIMX_CHECK_ARG(ar.ok(), "merge_fwd: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ar.off);
-  MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd: update_q needs q_new");
+  MHIMX_CHECK_ARG(m->own_n >= 0 && (m->own_n == 0 || m->x_rows), "merge_fwd: a shard's row range needs the bag-level row list (x_rows)");
+  w.own_lo = m->own_n > 0 ? m->own_lo : 0;
+  w.own_n = m->own_n;
   const int k = (int)m->k, J = M2_H * k;
   const float scale = 1.0f / sqrtf((float)M2_DH);
   if (!m->prepared) {
@@ -503,12 +553,59 @@ int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   hipLaunchKernelGGL(merge2_rows_fwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_FWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
                      m->drop_seed, m->drop_tick, w);
   MHIMX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(merge2_partials_kernel<true>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, w.ypart, m->ln_w, m->ln_b, w.Y, w);
-  MHIMX_LAUNCH_CHECK();
+  *wout = w;
+  return 0;
+}
+// from the merged pooled rows Y (and the softmax statistics) to the tokens: O = Wv Y, to_out, dropout, the queries' EMA
+static int merge2_fwd_tail(hipStream_t st, const mhimx_merge* m, float* z, float* q_new, int update_q, const Merge2Ws& w) {
+  const int k = (int)m->k;
   hipLaunchKernelGGL(merge2_o_kernel, dim3(M2_H * 4), dim3(M2_THREADS), 0, st, m->wkv, k, w);
   MHIMX_LAUNCH_CHECK();
   return mca_out(st, w.O, m->wo, m->bo, k, M2_E, M2_I, m->drop_p, m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, z, m->q_param,
                  update_q ? q_new : (float*)nullptr, m->mm);
+}
+
+int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* z, float* q_new, int update_q, void* ws, int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd: update_q needs q_new");
+  MHIMX_CHECK_ARG(m->own_n == 0, "merge_fwd: a shard of an instance-sharded bag runs mhimx_merge_fwd_part + mhimx_merge_fwd_finish");
+  Merge2Ws w;
+  if (int r = merge2_fwd_rows(st, m, X, R, ws, ws_bytes, &w)) return r;
+  const int J = M2_H * (int)m->k;
+  hipLaunchKernelGGL(merge2_partials_kernel<1>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(w, w.ypart), 0, m->ln_w, m->ln_b, w.Y,
+                     w.stats, (float*)nullptr);
+  MHIMX_LAUNCH_CHECK();
+  return merge2_fwd_tail(st, m, z, q_new, update_q, w);
+}
+
+// One shard's half of the forward of an instance-sharded bag (sharded.py, BASELINE c5): the rows pass over the rows this shard owns and the
+// merge of ITS tile partials, left raw: part [M2_PART_FLOATS] = {max[48] | sum[48] | dropped sum[48] | sum_t e^{pm_t - max} ypart_t [48][512]}.
+// The shards all-gather their blocks (99 KB each instead of an all-reduce of the [R, 512] rows) and every shard finishes alike.
+int merge2_fwd_part(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, float* part, void* ws, int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(part && aligned16(part), "merge_fwd_part: null / unaligned output block");
+  Merge2Ws w;
+  if (int r = merge2_fwd_rows(st, m, X, R, ws, ws_bytes, &w)) return r;
+  const int J = M2_H * (int)m->k;
+  // (slots >= J keep whatever the block held: nobody reads them)
+  hipLaunchKernelGGL(merge2_partials_kernel<2>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(w, w.ypart), 0, m->ln_w, m->ln_b,
+                     part + 3 * M2_JP, (float*)nullptr, part);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+// ... and the other half, the same on every shard: the W blocks merged in shard order (a second level of the same online-softmax merge:
+// fixed order, bit-identical replicas) -> Y and the statistics in THIS shard's workspace (its backward reads them), then the tokens.
+int merge2_fwd_finish(hipStream_t st, const mhimx_merge* m, const float* parts, int W, int64_t R, float* z, float* q_new, int update_q, void* ws,
+                      int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(parts && W >= 1 && W <= 256 && z, "merge_fwd_finish: 1..256 shard blocks");
+  MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd_finish: update_q needs q_new");
+  Arena ar(ws, ws_bytes);
+  Merge2Ws w;
+  merge2_ws_layout(ar, R, m->k, &w);
+  MHIMX_CHECK_ARG(ar.ok(), "merge_fwd_finish: workspace too small");
+  const int J = M2_H * (int)m->k;
+  hipLaunchKernelGGL(merge2_partials_kernel<1>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_shards(parts, W), 0, m->ln_w, m->ln_b, w.Y,
+                     w.stats, (float*)nullptr);
+  MHIMX_LAUNCH_CHECK();
+  return merge2_fwd_tail(st, m, z, q_new, update_q, w);
 }
 
 int gemm_tn_rider(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge2Side* rider, int stage);      // gemm.hip
@@ -519,6 +616,9 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   Merge2Ws w;
   merge2_ws_layout(ar, R, m->k, &w);
   MHIMX_CHECK_ARG(ar.ok(), "merge_bwd: workspace too small");
+  MHIMX_CHECK_ARG(m->own_n >= 0 && (m->own_n == 0 || m->x_rows), "merge_bwd: a shard's row range needs the bag-level row list (x_rows)");
+  w.own_lo = m->own_n > 0 ? m->own_lo : 0;           // (an instance-sharded bag: this shard's rows only; dX holds them at row id - own_lo)
+  w.own_n = m->own_n;
   MHIMX_CHECK_ARG(m->wo_t && aligned16(m->wo_t), "merge_bwd: transposed to_out weight missing");
   const int k = (int)m->k, J = M2_H * k;
   const float scale = 1.0f / sqrtf((float)M2_DH);
@@ -528,6 +628,7 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   sd.w = w; sd.dz = dz; sd.U = w.aq; sd.ln_w = m->ln_w; sd.ln_b = m->ln_b; sd.wkv = m->wkv; sd.wq = m->wq; sd.q_param = m->q_param; sd.wo_t = m->wo_t;
   sd.d_wkv = gr->d_wkv; sd.d_wo = gr->d_wo; sd.d_wq = gr->d_wq; sd.d_ln_w = gr->d_ln_w; sd.d_ln_b = gr->d_ln_b; sd.d_bo = gr->d_bo; sd.tick = m->drop_tick;
   sd.oseed = oseed; sd.scale = scale; sd.drop_p = m->drop_p; sd.k = k; sd.accumulate = acc; sd.J = J;
+  sd.rep = m->own_n > 0 ? m->rep : 1.f;
   bool pre_done = false;
   if (gr->defer && gr->defer->parked.pending) {
     // the pool backward's scorer-weight-gradient GEMM waits in the list: launch it now, with this backward's parameter-only first stage
@@ -540,7 +641,7 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
     pre_done = rc == 1;
   }
   if (!pre_done) {
-    hipLaunchKernelGGL(merge2_bwd_pre_kernel, dim3(M2_BWD_PRE_BLOCKS), dim3(M2_THREADS), 0, st, dz, m->wo_t, m->wkv, k, m->drop_p, oseed, m->drop_tick, gr->d_bo, acc, w);
+    hipLaunchKernelGGL(merge2_bwd_pre_kernel, dim3(M2_BWD_PRE_BLOCKS), dim3(M2_THREADS), 0, st, dz, m->wo_t, m->wkv, k, m->drop_p, oseed, m->drop_tick, gr->d_bo, acc, w, sd.rep);
     MHIMX_LAUNCH_CHECK();
   }
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M2_BWD_SMEM)));

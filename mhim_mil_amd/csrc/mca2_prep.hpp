@@ -16,6 +16,10 @@ struct Merge2Ws {
   float *gq, *gmean, *grstd, *Q, *aq, *aqf, *gtf_aq, *mean, *rstd, *S, *pm, *pl, *psd, *ypart, *stats, *Y, *O;
   float *dO, *dyf, *gtf_dy, *dpart, *upart, *lnpart, *dQ;
   unsigned* gate;            // arrivals of the backward tail's stage 2 (zeroed by the rows backward): stage 3 may share its launch
+  // An instance-sharded bag (sharded.py, BASELINE c5): the row list x_rows holds BAG row ids, this shard owns [own_lo, own_lo + own_n) and
+  // its X / dX hold only those rows (row id - own_lo).  Rows of the list outside the range take no part here (score -inf, zero gradient):
+  // they are another shard's.  own_n == 0: every row is this process's (one GPU).
+  int64_t own_lo, own_n;
   int T;
 };
 
@@ -48,6 +52,7 @@ inline int64_t merge2_ws_layout(Arena& ar, int64_t R, int64_t k, Merge2Ws* out) 
   w.lnpart = ar.take<float>(T * 2 * M2_E);
   w.dQ = ar.take<float>(k * M2_I);
   w.gate = reinterpret_cast<unsigned*>(ar.take<float>(64));
+  w.own_lo = 0; w.own_n = 0;
   if (out) *out = w;
   return ar.off;
 }

@@ -16,33 +16,50 @@ struct Merge2Side {
   uint64_t oseed;
   float scale, drop_p;
   int k, accumulate, J;
+  float rep;       // weight of the terms every shard of an instance-sharded bag computes identically (d_bo, d_wo, the V half of d_wkv): 1 on one
+                   // shard, 0 on the others, so that the SUM over the shards counts them once; 1 for one process
 };
 static_assert(sizeof(Merge2Side) <= MHIMX_SIDE_BYTES, "Merge2Side must fit the opaque side-work block of mhimx_reduce_list");
 
 constexpr int M2_PARTIALS_LDS = 256 + 8 + 128;
-template <bool SOFTMAX>
-MHIMX_DEV void merge2_partials_body(int block, float* lds, const float* __restrict__ part, const float* __restrict__ ln_w,
-                                    const float* __restrict__ ln_b, float* __restrict__ out, const Merge2Ws& w) {
+// Where the partials of a merge live.  Tiles of ONE process: the workspace arrays (stats pitch 48, pooled rows [T][48][512]).  The shards
+// of an instance-sharded bag: the all-gathered per-shard blocks [W][M2_PART_FLOATS] = {max[48] | sum[48] | dropped sum[48] | rows[48][512]}.
+constexpr int M2_PART_FLOATS = 3 * M2_JP + M2_JP * M2_E;
+struct M2Parts { const float *pm, *pl, *psd, *y; int T; int64_t ld_s, ld_y; };
+inline __host__ __device__ M2Parts m2_parts_tiles(const Merge2Ws& w, const float* y) { return M2Parts{w.pm, w.pl, w.psd, y, w.T, M2_JP, (int64_t)M2_JP * M2_E}; }
+inline __host__ __device__ M2Parts m2_parts_shards(const float* parts, int W) {
+  return M2Parts{parts, parts + M2_JP, parts + 2 * M2_JP, parts + 3 * M2_JP, W, M2_PART_FLOATS, M2_PART_FLOATS};
+}
+// MODE 0: out[j] = (sum_t y_t[j]) ln_w            (the backward's pooled U; LIVE: only the tiles whose forward partial is not empty count -
+//                                                   an instance-sharded bag leaves the others unwritten)
+// MODE 1: the online-softmax merge, out = y ln_w + (sum_t psd_t wgt_t) ln_b with wgt_t = e^{pm_t - M} / L, stats = (M, L)
+// MODE 2: the same merge left RAW for a second level: raw[j] = sum_t y_t[j] e^{pm_t - M} and (M, L, SD) - one shard's block of the exchange
+template <int MODE>
+MHIMX_DEV void merge2_partials_body(int block, float* lds, const M2Parts& in, bool live_only, const float* __restrict__ ln_w,
+                                    const float* __restrict__ ln_b, float* __restrict__ out, float* __restrict__ stats /* MODE 1: [48][2] */,
+                                    float* __restrict__ raw_stats /* MODE 2: {M[48] | L[48] | SD[48]} */) {
+  constexpr bool SOFTMAX = MODE != 0;
   float* wt = lds;              // [256]: the weights of one chunk of 256 row tiles
   float* red = wt + 256;        // [8]
   float* half1 = red + 8;       // [128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = block >> 2, e = (block & 3) * 128 + (tid & 127), half = tid >> 7;
-  const int T = w.T;
+  const int T = in.T;
   float sdl = 0.f, M = 0.f, Lsum = 1.f;
   if (SOFTMAX) {
     // statistics over ALL T tiles (T <= 256: one element per thread, as before; more tiles: a strided loop - R up to 32 768 rows)
     float pm = -INFINITY;
-    for (int tt = tid; tt < T; tt += M2_THREADS) pm = fmaxf(pm, w.pm[tt * M2_JP + j]);
+    for (int tt = tid; tt < T; tt += M2_THREADS) pm = fmaxf(pm, in.pm[tt * in.ld_s + j]);
     float m = wave_max(pm);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float pls = 0.f, pss = 0.f;
     for (int tt = tid; tt < T; tt += M2_THREADS) {
-      const float wgt = __expf(w.pm[tt * M2_JP + j] - M);
-      pls += w.pl[tt * M2_JP + j] * wgt;
-      pss += w.psd[tt * M2_JP + j] * wgt;
+      const float pmt = in.pm[tt * in.ld_s + j];
+      const float wgt = pmt == -INFINITY ? 0.f : __expf(pmt - M);         // (an empty partial: weight 0, also when every partial is empty)
+      pls += in.pl[tt * in.ld_s + j] * wgt;
+      pss += in.psd[tt * in.ld_s + j] * wgt;
     }
     const float l = wave_sum(pls), sd = wave_sum(pss);
     if (lane == 0) { red[4 + wave] = l; half1[wave] = sd; }
@@ -51,15 +68,25 @@ MHIMX_DEV void merge2_partials_body(int block, float* lds, const float* __restri
     const float SD = (half1[0] + half1[1]) + (half1[2] + half1[3]);
     Lsum = L;
     sdl = SD / L;
-    if ((block & 3) == 0 && tid == 0) { w.stats[2 * j] = M; w.stats[2 * j + 1] = L; }
+    if (MODE == 1 && (block & 3) == 0 && tid == 0) { stats[2 * j] = M; stats[2 * j + 1] = L; }
+    if (MODE == 2 && (block & 3) == 0 && tid == 0) { raw_stats[j] = M; raw_stats[M2_JP + j] = L; raw_stats[2 * M2_JP + j] = SD; }
   }
   float acc = 0.f;
-  const float* pj = part + (int64_t)j * M2_E + e;
+  const float* pj = in.y + (int64_t)j * M2_E + e;
 #pragma unroll 1
   for (int c0 = 0; c0 < T; c0 += 256) {                     // chunks of 256 tiles: their weights in LDS
     __syncthreads();                                        // (the statistics scratch / the previous chunk's weights have been read)
     const int tt = c0 + tid;
-    wt[tid] = tt < T ? (SOFTMAX ? __expf(w.pm[tt * M2_JP + j] - M) / Lsum : 1.f) : 0.f;
+    float wv = 0.f;
+    if (tt < T) {
+      if (SOFTMAX) {
+        const float pmt = in.pm[tt * in.ld_s + j];
+        wv = pmt == -INFINITY ? 0.f : (MODE == 1 ? __expf(pmt - M) / Lsum : __expf(pmt - M));
+      } else {
+        wv = (!live_only || in.pl[tt * in.ld_s] != 0.f) ? 1.f : 0.f;
+      }
+    }
+    wt[tid] = wv;
     __syncthreads();
     const int Tc = T - c0 < 256 ? T - c0 : 256;
 #pragma unroll 1
@@ -68,7 +95,7 @@ MHIMX_DEV void merge2_partials_body(int block, float* lds, const float* __restri
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int t = t0 + half * 16 + q;
-        v[q] = t < Tc ? pj[(int64_t)(c0 + t) * M2_JP * M2_E] : 0.f;
+        v[q] = (t < Tc && wt[t & 255] != 0.f) ? pj[(int64_t)(c0 + t) * in.ld_y] : 0.f;      // (a tile of weight 0 is never read: it may be unwritten)
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc += v[q] * wt[(t0 + half * 16 + q) & 255];
@@ -79,7 +106,7 @@ MHIMX_DEV void merge2_partials_body(int block, float* lds, const float* __restri
   __syncthreads();
   if (half == 0) {
     acc += half1[tid];
-    out[j * M2_E + e] = SOFTMAX ? acc * ln_w[e] + sdl * ln_b[e] : acc * ln_w[e];
+    out[j * M2_E + e] = MODE == 1 ? acc * ln_w[e] + sdl * ln_b[e] : (MODE == 2 ? acc : acc * ln_w[e]);
   }
 }
 
@@ -129,8 +156,8 @@ MHIMX_DEV void merge2_grads1_body(int block, float* lds, const Merge2Side& a) {
       const float s0 = z0[0] * o0[0] + z0[1] * o0[1] + z0[2] * o0[2] + z0[3] * o0[3] + z1[0] * o0[4] + z1[1] * o0[5];
       const float s1 = z0[0] * o1[0] + z0[1] * o1[1] + z0[2] * o1[2] + z0[3] * o1[3] + z1[0] * o1[4] + z1[1] * o1[5];
       float* o = d_wo + (int64_t)(e0 + r) * M2_I + tid;
-      o[0] = accumulate ? o[0] + s0 : s0;
-      o[256] = accumulate ? o[256] + s1 : s1;
+      o[0] = accumulate ? o[0] + a.rep * s0 : a.rep * s0;
+      o[256] = accumulate ? o[256] + a.rep * s1 : a.rep * s1;
     }
     return;
   }
@@ -172,8 +199,8 @@ MHIMX_DEV void merge2_grads1_body(int block, float* lds, const Merge2Side& a) {
     float* ov = d_wkv + (int64_t)(M2_I + h * 64 + qr * 16 + dl) * M2_E + tid;
     ok[0] = accumulate ? ok[0] + sk0 : sk0;
     ok[256] = accumulate ? ok[256] + sk1 : sk1;
-    ov[0] = accumulate ? ov[0] + sv0 : sv0;
-    ov[256] = accumulate ? ov[256] + sv1 : sv1;
+    ov[0] = accumulate ? ov[0] + a.rep * sv0 : a.rep * sv0;          // (dO (x) Y: the same on every shard of a sharded bag - Merge2Side.rep)
+    ov[256] = accumulate ? ov[256] + a.rep * sv1 : a.rep * sv1;
   }
 }
 
@@ -247,7 +274,8 @@ MHIMX_DEV void merge2_grads2_body(int block, float* lds, const Merge2Side& a) {
       float pw[16], pb[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const bool ok = t0 + q < w.T;
+        // (an instance-sharded bag: the tiles without a row of this shard wrote no partial - their forward partial is empty)
+        const bool ok = t0 + q < w.T && (w.own_n == 0 || w.pl[(int64_t)(t0 + q) * M2_JP] != 0.f);
         pw[q] = ok ? lp[(int64_t)(t0 + q) * 2 * M2_E] : 0.f;
         pb[q] = ok ? lp[(int64_t)(t0 + q) * 2 * M2_E + M2_E] : 0.f;
       }
@@ -269,7 +297,7 @@ constexpr int M2_SIDE_LDS = M2_GRADS1_LDS;                   // floats: the larg
 constexpr int M2_BWD_PRE_BLOCKS = 64, M2_BWD_PRE_LDS = 6 * M2_E + 6 * 64;
 MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restrict__ dz, const float* __restrict__ wo_t,
                                    const float* __restrict__ wkv, int k, float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick,
-                                   float* __restrict__ d_bo, int accumulate, const Merge2Ws& w) {
+                                   float* __restrict__ d_bo, int accumulate, const Merge2Ws& w, float rep = 1.f) {
   float* dzs = lds;                 // [6][512]
   float* doh = dzs + 6 * M2_E;      // [6][64]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -294,7 +322,7 @@ MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restric
   if (h == 0 && tid < 64) {
     float s = 0.f;
     for (int i = 0; i < k; ++i) s += dzs[i * M2_E + e];
-    d_bo[e] = accumulate ? d_bo[e] + s : s;
+    d_bo[e] = accumulate ? d_bo[e] + rep * s : rep * s;
   }
   m2_head_dots<64>(wo_t + (int64_t)h * 64 * M2_E, dzs, k, doh, 64, eb == 0 ? w.dO + h * 64 : nullptr);
   __syncthreads();
@@ -312,8 +340,8 @@ MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restric
 }
 
 MHIMX_DEV void merge2_side_stage(int stage, int b, float* lds, const Merge2Side& a) {
-  if (stage == 0) merge2_bwd_pre_body(b, lds, a.dz, a.wo_t, a.wkv, a.k, a.drop_p, a.oseed, a.tick, a.d_bo, a.accumulate, a.w);
-  else if (stage == 1) merge2_partials_body<false>(b, lds, a.w.upart, a.ln_w, a.ln_b, const_cast<float*>(a.U), a.w);
+  if (stage == 0) merge2_bwd_pre_body(b, lds, a.dz, a.wo_t, a.wkv, a.k, a.drop_p, a.oseed, a.tick, a.d_bo, a.accumulate, a.w, a.rep);
+  else if (stage == 1) merge2_partials_body<0>(b, lds, m2_parts_tiles(a.w, a.w.upart), a.w.own_n > 0, a.ln_w, a.ln_b, const_cast<float*>(a.U), nullptr, nullptr);
   else if (stage == 2) merge2_grads1_body(b, lds, a);
   else merge2_grads2_body(b, lds, a);
 }

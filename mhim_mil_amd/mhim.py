@@ -409,7 +409,7 @@ class MHIM(nn.Module):
             ops.prep_batch(jobs)
         return prep
 
-    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None, x_rows=None, prepared=False):
+    def _merge_w(self, plan: Optional[BagPlan], need_t=False, q=None, tr=None, wkv_frag=None, x_rows=None, prepared=False, own=None, rep=1.0):
         m = self.merge
         if need_t and tr is None:
             tr = (ops.transpose(m.attn.to_kv.weight.data), ops.transpose(m.attn.to_q.weight.data),
@@ -419,7 +419,7 @@ class MHIM(nn.Module):
         return ops.MergeW(q, m.norm.weight.data, m.norm.bias.data, m.attn.to_kv.weight.data,
                           m.attn.to_q.weight.data, m.attn.to_out[0].weight.data, m.attn.to_out[0].bias.data, m.g_q_mm,
                           drop_p=drop, drop_seed=plan.mca_seed if plan is not None else 0, prec=self._op_prec, transposes=tr,
-                          drop_tick=self._tick, wkv_frag=wkv_frag, x_rows=x_rows, prepared=prepared)
+                          drop_tick=self._tick, wkv_frag=wkv_frag, x_rows=x_rows, prepared=prepared, own=own, rep=rep)
 
     # ------------------------------------------------------------------ kernels: feature rows
     def _check_x(self, x):

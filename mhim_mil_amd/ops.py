@@ -439,7 +439,9 @@ def compose_ids(a, b):
 # ------------------------------------------------------------------------------------------------ merge
 class MergeW:
     def __init__(self, q_param, ln_w, ln_b, wkv, wq, wo, bo, mm, heads=8, dim_head=64, drop_p=0.0, drop_seed=0,
-                 prec="bf16x3", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None, prepared=False):
+                 prec="bf16x3", transposes=None, drop_tick=None, wkv_frag=None, x_rows=None, prepared=False, own=None, rep=1.0):
+        """own = (lo, n): a shard of an instance-sharded bag - x_rows holds bag row ids, X / dX only the rows [lo, lo + n) (mhimx_merge.own_*);
+        rep: weight of the gradient terms every shard computes alike (1 on one shard, 0 on the others)."""
         self.t = [q_param, ln_w, ln_b, wkv, wq, wo, bo, wkv_frag]
         _chk(x_rows, torch.int64, "x_rows")
         self.x_rows = x_rows
@@ -452,7 +454,9 @@ class MergeW:
                          ln_b=_p(ln_b), wkv=_p(wkv), wq=_p(wq), wo=_p(wo), bo=_p(bo), wkv_t=_p(self.tr[0]),
                          wq_t=_p(self.tr[1]), wo_t=_p(self.tr[2]), mm=float(mm), drop_p=float(drop_p),
                          drop_seed=int(drop_seed) & 0xFFFFFFFFFFFFFFFF, prec=prec_code(prec), drop_tick=_p(drop_tick),
-                         wkv_frag=_p(wkv_frag), x_rows=_p(x_rows), prepared=int(bool(prepared)))
+                         wkv_frag=_p(wkv_frag), x_rows=_p(x_rows), prepared=int(bool(prepared)),
+                         own_lo=0 if own is None else int(own[0]), own_n=0 if own is None else int(own[1]), rep=float(rep))
+        self.own = own
 
     def ws_for(self, R, device):
         n = L.lib().mhimx_merge_ws_bytes(R, self.E, self.k, self.heads, self.dim_head)
@@ -471,6 +475,29 @@ def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
     L.check(L.lib().mhimx_merge_fwd(_stream(), C.byref(mw.c), _p(X), R, _p(z), _p(q_new), int(bool(update_q)), _p(ws),
                                     ws.numel()), "mhimx_merge_fwd")
     return z, q_new, ws
+
+
+def merge_fwd_part(mw: MergeW, X, ws=None, part=None):
+    """One shard's half of the forward of an instance-sharded bag (mhimx_merge_fwd_part): -> (part [mhimx_merge_part_floats()], ws)."""
+    _chk(X, name="X")
+    R = mw.x_rows.shape[0]
+    dev = X.device
+    part = part if part is not None else torch.empty(L.lib().mhimx_merge_part_floats(), device=dev)
+    ws = ws if ws is not None else mw.ws_for(R, dev)
+    L.check(L.lib().mhimx_merge_fwd_part(_stream(), C.byref(mw.c), _p(X), R, _p(part), _p(ws), ws.numel()), "mhimx_merge_fwd_part")
+    return part, ws
+
+
+def merge_fwd_finish(mw: MergeW, parts, ws, z_out=None, update_q=True, q_out=None):
+    """The other half (mhimx_merge_fwd_finish): parts [W, part floats] of all shards -> (tokens z, updated queries)."""
+    _chk(parts, name="parts")
+    R = mw.x_rows.shape[0]
+    dev = parts.device
+    z = z_out if z_out is not None else torch.empty((mw.k, mw.E), device=dev)
+    q_new = (q_out if q_out is not None else torch.empty((mw.k, mw.E), device=dev)) if update_q else None
+    L.check(L.lib().mhimx_merge_fwd_finish(_stream(), C.byref(mw.c), _p(parts), parts.shape[0], R, _p(z), _p(q_new), int(bool(update_q)),
+                                           _p(ws), ws.numel()), "mhimx_merge_fwd_finish")
+    return z, q_new
 
 
 def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False, defer=None):

@@ -7,13 +7,16 @@ MHIM(ABMIL) train step needs exactly these exchanges (RCCL on GPUs; every one is
             all-gather of the per-instance scores                                         (N floats in total)
   select    none — every rank runs the same top-k / random subsample on the full score vector with a shared-seed
             generator, so the index sets are identical on all ranks and identical to the single-GPU result
-  student   all-reduce of the [R, E] block of rows-to-merge (each row is non-zero on exactly one rank => exact)
+  student   all-gather of Merge's per-slot partials (max, sum, dropped sum, pooled row: 48 x 515 floats = 99 KB per rank; every rank
+            runs Merge's rows pass over ITS rows of the merge list only - round 4; rounds 1-3 all-reduced the [R, E] block of rows to
+            merge, 39.7 MB at c5, and ran Merge over all R rows on every rank)
             all-gather of the pool partial                                                (E+2 floats per rank)
   backward  all-reduce (= broadcast from rank 0) of d(merged tokens) [k, E]
             all-reduce(SUM) of the flat gradient buffer (replicated terms are kept on rank 0 only)
 
-The Merge cross-attention (R = 10 % of the kept rows), the head and the optimiser run replicated: they are O(R*E) / O(E)
-and keeping them replicated keeps ``merge.global_q_mm`` and the Adam state bit-identical on every rank with no extra traffic.
+Merge's query side (O(k E^2)), the head and the optimiser run replicated on identical inputs: ``merge.global_q_mm`` and the Adam state
+stay bit-identical on every rank with no extra traffic.  Merge's parameter gradients are partial sums over the ranks (the terms every rank
+computes alike are weighted 1 on rank 0 and 0 elsewhere) and ride in the flat-gradient all-reduce.
 
 Everything numeric is a kernel of libmhimx.so; torch.distributed only moves buffers.  With a ``gloo`` group (the CPU-side
 test harness on a 1-GPU box) buffers are staged through host memory; with ``nccl`` (= RCCL) they stay in HBM.
@@ -118,6 +121,7 @@ class ShardedBagTrainer:
         self.opt_step = torch.zeros(1, dtype=torch.int64, device=dev)
         self.tick = torch.zeros(1, dtype=torch.int64, device=dev)           # device step counter mixed into the fixed-shape step's dropout seeds
         self.step_count = 0
+        self.shard_merge = True                      # Merge's rows sharded like the pool (world > 1; False: the replicated round-1..3 form)
         self.last = {}
 
     def _seeds(self):
@@ -231,11 +235,24 @@ class ShardedBagTrainer:
             plan = BagPlan(rows=None, L=n, Lk=Lk, R=R, drop_seed=local_seed, mca_seed=shared_seed, training=True)
             excl = ops.shard_flags(rows, R, Lk, lo, n, k, cm.rank == 0)
 
-            # ---- Merge on the replicated [R, E] block (each row comes from exactly one rank)
-            Hm = ops.shard_gather(Hbuf, rows[:R], lo, n)
-            if cm.world > 1:
-                yield lambda: cm.all_reduce_sum(Hm)
-            z_tok, q_new, mws = ops.merge_fwd(s._merge_w(plan, wkv_frag=prep_s.get("wkv_frag")), Hm, z_out=Hbuf[n:], update_q=True)
+            # ---- Merge.  Sharded like the pool (round 4): every rank runs the rows pass over ITS rows of the merge list only (the list holds
+            # bag row ids; Hbuf the shard's rows), merges its tile partials and the ranks all-gather ONE 99 KB block each - per score slot
+            # (max, sum, dropped sum, pooled row) - which every rank merges in rank order (mhimx_merge_fwd_part / _finish).  The replicated
+            # form all-reduced the [R, E] block of rows to merge (39.7 MB at c5) and ran Merge over all R rows on every rank.
+            shard_merge = (self.shard_merge and cm.world > 1 and s._op_prec != "f32" and E == 512 and s.merge.k * 8 <= 48 and R <= 32768)
+            Hm = None
+            if shard_merge:
+                own, rep = (lo, n), (1.0 if cm.rank == 0 else 0.0)
+                mw = s._merge_w(plan, x_rows=rows[:R], own=own, rep=rep)
+                mpart, mws = ops.merge_fwd_part(mw, Hbuf)
+                mparts = torch.empty((cm.world, mpart.numel()), device=dev)
+                yield lambda: cm.all_gather_into(mparts, mpart)
+                z_tok, q_new = ops.merge_fwd_finish(mw, mparts, mws, z_out=Hbuf[n:], update_q=True)
+            else:                                                  # replicated: the [R, E] block (each row comes from exactly one rank)
+                Hm = ops.shard_gather(Hbuf, rows[:R], lo, n)
+                if cm.world > 1:
+                    yield lambda: cm.all_reduce_sum(Hm)
+                z_tok, q_new, mws = ops.merge_fwd(s._merge_w(plan, wkv_frag=prep_s.get("wkv_frag")), Hm, z_out=Hbuf[n:], update_q=True)
             q_old = prep_s["q_old"]
             s.merge.global_q_mm.data.copy_(q_new.view_as(s.merge.global_q_mm))
 
@@ -267,8 +284,16 @@ class ShardedBagTrainer:
                 yield lambda: cm.all_reduce_sum(dT2)               # = broadcast from rank 0
             mgr = {"d_ln_w": gv["merge.norm.weight"], "d_ln_b": gv["merge.norm.bias"], "d_wkv": gv["merge.attn.to_kv.weight"],
                    "d_wq": gv["merge.attn.to_q.weight"], "d_wo": gv["merge.attn.to_out.0.weight"], "d_bo": gv["merge.attn.to_out.0.bias"]}
-            mg = ops.merge_bwd(s._merge_w(plan, need_t=True, q=q_old, tr=prep_s.get("merge_t")), Hm, dT2, mws, grads=mgr, defer=defer)
-            ops.shard_scatter(mg["dX"], rows[:R], lo, n, dHbuf)    # (those rows were excluded from the pool: their slots hold zeros)
+            if shard_merge:
+                # dX for the own rows lands in dHbuf directly (those rows were excluded from the pool: their slots hold zeros); the
+                # parameter gradients are this rank's PARTIAL sums - the flat-gradient all-reduce below adds them (terms every rank
+                # computes alike are weighted by rep: counted once)
+                mgr["dX"] = dHbuf
+                ops.merge_bwd(s._merge_w(plan, need_t=True, q=q_old, tr=prep_s.get("merge_t"), x_rows=rows[:R], own=own, rep=rep), Hbuf, dT2, mws,
+                              grads=mgr, defer=defer)
+            else:
+                mg = ops.merge_bwd(s._merge_w(plan, need_t=True, q=q_old, tr=prep_s.get("merge_t")), Hm, dT2, mws, grads=mgr, defer=defer)
+                ops.shard_scatter(mg["dX"], rows[:R], lo, n, dHbuf)    # (those rows were excluded from the pool: their slots hold zeros)
             if ops.bag_wgrad_ok(x, E, n):
                 ops.bag_wgrad(dHbuf, DACT, x, None, n, out_w=gv["feature.0.weight"], out_b=gv["feature.0.bias"], defer=defer)
             else:
@@ -278,7 +303,7 @@ class ShardedBagTrainer:
             if cm.world > 1:
                 if cm.rank != 0:                                   # replicated terms: counted once in the SUM
                     for name in fl.train_names:
-                        if name.startswith("predictor.") or name.startswith("merge."):
+                        if name.startswith("predictor.") or (name.startswith("merge.") and not shard_merge):
                             gv[name].zero_()
                 yield lambda: cm.all_reduce_sum(fl.grad[:fl.n_train])
 
