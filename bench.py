@@ -356,10 +356,13 @@ def pick_collective(a, trainer, graphs, bags, labels, world, dev):
     if graphs is not None:
         forms["graph | torch.distributed all_reduce (RCCL picks ring / tree) | graph"] = (None, lambda i: graphs[i % N_BAGS].replay())
         native, err = None, None
-        try:
-            native = CM.NativeComm(int(os.environ.get("RANK", "0")), world, mode=1)
-        except Exception as e:  # noqa: BLE001
-            err = f"{type(e).__name__}: {str(e)[:120]}"
+        if os.environ.get("MHIMX_BENCH_SELFTEST") == "1":
+            err = "skipped: the self-test's ranks share one device (RCCL refuses two ranks on a device)"
+        else:
+            try:
+                native = CM.NativeComm(int(os.environ.get("RANK", "0")), world, mode=1)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {str(e)[:120]}"
         if agree(native is not None):
             forms["graph | mhimx_comm_allreduce mode 1 (reduce-scatter + all-gather over the xGMI mesh) | graph"] = (native, lambda i: graphs[i % N_BAGS].replay())
         else:

@@ -247,3 +247,73 @@ def test_factory_teacher_seam_on_the_device():
     # the teacher moved by the EMA of the update: (1 - mm) of the distance to the student
     d = (tea.state_dict()["feature.0.bias"] - before["feature.0.bias"]).abs().max().item()
     assert 0 < d < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Merge over the shards of an instance-sharded bag (mhimx_merge_fwd_part / _finish, mhimx_merge_bwd with own rows): W shards run one after
+# another in ONE process against the fp64 oracle of the whole row block
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,W,order", [(970, 2, "ascending"), (1000, 4, "shuffled"), (19400, 8, "ascending"), (45, 3, "shuffled")])
+def test_merge_sharded_rows_equal_the_whole_block(R, W, order):
+    from mhim_mil_amd import ops
+    from tests.test_ops_gpu import rnd
+    E, k = 512, 5
+    Nbag = 4 * R + 7 * W                                           # the bag: the merge list picks R of its rows
+    sd = synth.mhim_state(7, input_dim=64, merge_k=k)
+    p = {kk: torch.from_numpy(v).double() for kk, v in sd.items() if kk.startswith("merge.")}
+    p["merge.norm.weight"] = p["merge.norm.weight"] + rnd(161, (E,), std=0.1).double()
+    p["merge.norm.bias"] = rnd(162, (E,), std=0.1).double()
+    p["merge.attn.to_out.0.bias"] = rnd(163, (E,), std=0.1).double()
+    for kk in p:
+        p[kk].requires_grad_(kk != "merge.global_q_mm")
+    Hbag = (rnd(164, (Nbag, E)).abs() * 0.7)
+    ids = np.sort(synth.permutation(165, Nbag)[:R]) if order == "ascending" else synth.permutation(165, Nbag)[:R]
+    ids = np.ascontiguousarray(ids).astype(np.int64)
+    X = Hbag[torch.from_numpy(ids)].double().requires_grad_(True)
+    z, q_ref = O.merge_tokens(X, p, 0.9999, True)
+    dz = rnd(166, (k, E), std=0.1)
+    (z * dz.double()).sum().backward()
+    f32 = lambda t: t.detach().float().contiguous().to(DEV)
+    tr = (ops.transpose(f32(p["merge.attn.to_kv.weight"])), ops.transpose(f32(p["merge.attn.to_q.weight"])),
+          ops.transpose(f32(p["merge.attn.to_out.0.weight"])))
+    rows = torch.from_numpy(ids).to(DEV)
+    bounds = [Nbag * r // W for r in range(W + 1)]                  # contiguous shards of the bag's rows (ragged)
+    mws, parts, wss, Hloc = [], [], [], []
+    for r in range(W):
+        lo, n = bounds[r], bounds[r + 1] - bounds[r]
+        mw = ops.MergeW(f32(p["merge.global_q_mm"]).reshape(k, E), f32(p["merge.norm.weight"]), f32(p["merge.norm.bias"]),
+                        f32(p["merge.attn.to_kv.weight"]), f32(p["merge.attn.to_q.weight"]), f32(p["merge.attn.to_out.0.weight"]),
+                        f32(p["merge.attn.to_out.0.bias"]), 0.9999, transposes=tr, x_rows=rows, own=(lo, n), rep=1.0 if r == 0 else 0.0)
+        h = Hbag[lo:lo + n].to(DEV).contiguous()
+        part, ws = ops.merge_fwd_part(mw, h)
+        mws.append(mw); parts.append(part); wss.append(ws); Hloc.append(h)
+    allparts = torch.stack(parts).contiguous()
+    zs = [ops.merge_fwd_finish(mws[r], allparts, wss[r]) for r in range(W)]
+    for zr, qr in zs:                                              # every shard finishes alike, bit for bit
+        assert torch.equal(zr, zs[0][0]) and torch.equal(qr, zs[0][1])
+    np.testing.assert_allclose(zs[0][0].cpu().numpy(), z.detach().float().numpy(), atol=2e-5, rtol=4e-5)
+    np.testing.assert_allclose(zs[0][1].cpu().numpy(), q_ref.detach().float().numpy(), atol=1e-7, rtol=1e-6)
+    names = {"d_ln_w": "merge.norm.weight", "d_ln_b": "merge.norm.bias", "d_wkv": "merge.attn.to_kv.weight", "d_wq": "merge.attn.to_q.weight",
+             "d_wo": "merge.attn.to_out.0.weight", "d_bo": "merge.attn.to_out.0.bias"}
+    total = {kk: 0 for kk in names}
+    dX = torch.zeros((R, E))
+    for r in range(W):
+        lo, n = bounds[r], bounds[r + 1] - bounds[r]
+        dH = torch.full((n, E), float("nan"), device=DEV)           # only this shard's merge rows may be written
+        g = ops.merge_bwd(mws[r], Hloc[r], dz.to(DEV), wss[r], grads={"dX": dH})
+        torch.cuda.synchronize()
+        own = (ids >= lo) & (ids < lo + n)
+        written = ~torch.isnan(dH[:, 0]).cpu().numpy()
+        assert set(np.nonzero(written)[0].tolist()) == set((ids[own] - lo).tolist())
+        dX[torch.from_numpy(np.nonzero(own)[0])] = dH[torch.from_numpy(ids[own] - lo).to(DEV)].cpu()
+        for kk in names:
+            total[kk] = total[kk] + g[kk].double().cpu()
+
+    def close(name, got, ref):
+        ref = ref.float().numpy()
+        np.testing.assert_allclose(np.asarray(got, dtype=np.float32).reshape(ref.shape), ref, atol=2e-4 * (np.abs(ref).max() + 1e-30), rtol=1.2e-3,
+                                   err_msg=name)
+
+    close("dX", dX.numpy(), X.grad)
+    for kk, nm in names.items():
+        close(kk, total[kk].numpy(), p[nm].grad)

@@ -100,12 +100,15 @@ def test_world1_equals_fused_trainer():
             assert err.mean().item() <= 2e-6 and err.max().item() <= 4.1e-4, (k, err.mean().item(), err.max().item())
 
 
-def _worker(rank, port, out):
+def _worker(rank, port, out, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=2)
     from mhim_mil_amd.sharded import ShardedBagTrainer
     s, t = _models()
     tr = ShardedBagTrainer(s, t, counts=COUNTS, aux_alpha=0.5, mm=0.999)
@@ -411,12 +414,15 @@ def _dp_draws(step, rank):
             torch.from_numpy(synth.permutation(70 + 2 * step + rank, N - n_sel)).to(DEV))
 
 
-def _dp_diff_worker(rank, port, out, mode):
+def _dp_diff_worker(rank, port, out, mode, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)      # (nccl = RCCL: one device per rank; gloo: both ranks share the box's one GPU)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=2)
     from mhim_mil_amd.engine import FusedTrainer, _SplitStep
     s, t = _models()
     tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
