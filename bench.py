@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -50,6 +51,9 @@ def parse():
                     help="N > 1: eager steps whose all-reduce overlaps the backward instead of graph(fwd+bwd) | all-reduce | graph(Adam+EMA)")
     ap.add_argument("--no-extras", action="store_true", help="c2, one GPU: skip the accumulate8 / hbm_copy / other_workloads legs")
     ap.add_argument("--window-streams", type=int, default=4, help="HIP streams of the accumulate-8 window")
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="c2, one GPU: consecutive complete train steps (one bag, one update each) captured per hipGraph (FusedTrainer.capture_steps); "
+                         "0 = the largest divisor of gcd(steps, warmup) that is <= 8, 1 = one graph per bag")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil"],
                     help="c2 (default, BASELINE.json's metric): MHIM(ABMIL) N=10k D=1024, one bag per GPU per step; "
                          "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs; "
@@ -445,6 +449,13 @@ def main():
             return None
 
     graphs, graph_note = None, None
+    # steps per captured graph (one GPU): every chunk is `chunk` complete steps; warm-up and timed region are whole numbers of chunks
+    chunk = 1
+    if world == 1 and not a.no_graph:
+        g0 = math.gcd(a.steps, a.warmup) if a.warmup > 0 else a.steps
+        chunk = a.steps_per_graph if a.steps_per_graph > 0 else max(d for d in range(1, 9) if g0 % d == 0)
+        if a.steps % chunk or a.warmup % chunk:
+            chunk = 1
     # N > 1 defaults to graph(fwd+bwd) | eager RCCL all-reduce | graph(Adam+EMA): no measurement on more than one GPU exists yet that
     # shows the eager form (all-reduce of every gradient but the projection's started in the middle of the backward,
     # FusedTrainer._mid_hook: hides up to ~80 us of collective, pays ~3 % of eager launches at N = 1) winning; --dp-eager selects it.
@@ -456,7 +467,15 @@ def main():
         # eager launches together — the decision is all-reduced so that no rank replays while another launches eagerly.
         ok = 1
         try:
-            graphs = [trainer.capture(bags[i], labels[i], warmup=1) for i in range(N_BAGS)]
+            if world == 1 and chunk > 1:
+                # one graph per CHUNK of consecutive steps (each a complete step on its own bag, with its own update): the rotation over the
+                # resident bags continues from chunk to chunk, N_BAGS / gcd(chunk, N_BAGS) distinct graphs
+                n_graphs = N_BAGS // math.gcd(chunk, N_BAGS)
+                graphs = [trainer.capture_steps([bags[(q * chunk + j) % N_BAGS] for j in range(chunk)],
+                                                [labels[(q * chunk + j) % N_BAGS] for j in range(chunk)], warmup=1 if q == 0 else 0)
+                          for q in range(n_graphs)]
+            else:
+                graphs = [trainer.capture(bags[i], labels[i], warmup=1) for i in range(N_BAGS)]
             for g_ in graphs:               # part of the capture: one replay per graph right after instantiation (the first launch of a
                 g_.replay()                 # hipGraphExec uploads it; with W < N_BAGS warm-up steps that would fall into the timed region)
             torch.cuda.synchronize()
@@ -473,7 +492,11 @@ def main():
 
     def step(i):
         if graphs is not None:
-            graphs[i % N_BAGS].replay()
+            if chunk > 1:
+                if i % chunk == 0:                          # (one replay = `chunk` steps: the calls in between are already done)
+                    graphs[(i // chunk) % len(graphs)].replay()
+            else:
+                graphs[i % N_BAGS].replay()
         else:
             trainer.train_step(bags[i % N_BAGS], labels[i % N_BAGS])
 
@@ -527,7 +550,8 @@ def main():
                        **({"collective": collective, "collective_candidates_ms_per_step": collective_ms} if collective else {}),
                        "launch": (("eager" if world == 1 else "eager, gradient all-reduce in two pieces, the first overlapped with the dW1 GEMM of the backward")
                                   + (f" (graph capture failed: {graph_note})" if graph_note else "")) if graphs is None
-                                 else ("hipGraph replay, one graph per resident bag" if world == 1 else
+                                 else ((f"hipGraph replay, {chunk} consecutive complete steps (one bag + one update each) per graph" if chunk > 1 else
+                                        "hipGraph replay, one graph per resident bag") if world == 1 else
                                        "hipGraph replay per resident bag: graph(fwd+bwd) | eager RCCL all-reduce | graph(Adam+EMA)")},
             "whole_step_hbm_roofline": {"algorithmic_bytes_per_instance": ALGO_BYTES_PER_INST_STEP,
                                         "achieved_GBps": value / world * ALGO_BYTES_PER_INST_STEP / 1e9,
