@@ -403,24 +403,22 @@ extern "C" int mhimx_adam_ema(void* stream, float* p, const float* g, float* m, 
   return mhimx_optim_step(stream, &a);
 }
 
-// float4 grid-stride copy: the on-box HBM stream rate bench.py prints beside the 8 TB/s nominal peak
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
-  // four 16-byte loads in flight per lane (1 KiB per wave-instruction, 4 KiB per wave), then the four stores
+// float4 stream copy: the on-box HBM stream rate bench.py prints beside the 8 TB/s nominal peak.  One 16-byte element
+// per thread, non-temporal load and store, as many 256-thread workgroups as elements / 256 (tools/micro/copy_bw.hip, round 4: 6.7-6.8 TB/s
+// for 1 GiB -> 1 GiB at 131 072+ workgroups against 5.0-5.6 TB/s for the round-3 form - four loads in flight per lane, 65 536 workgroups,
+// plain accesses - and 5.1 TB/s for hipMemcpyAsync; the guide quotes 6.29)
+typedef float sc_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(const sc_f4* __restrict__ src, sc_f4* __restrict__ dst, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n4; i += stride) dst[i] = src[i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 extern "C" int mhimx_stream_copy(void* stream, const float* src, float* dst, int64_t n_floats) {
   MHIMX_CHECK_ARG(src && dst && n_floats >= 0 && n_floats % 4 == 0 && aligned16(src) && aligned16(dst), "stream_copy: 16-byte aligned buffers, n % 4 == 0");
   if (n_floats == 0) return 0;
   const int64_t n4 = n_floats / 4;
-  const int64_t blocks = cdiv(n4, 1024) < 65536 ? cdiv(n4, 1024) : 65536;        // (tools/micro/copy_bw.hip: many short workgroups stream fastest)
-  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src),
-                     reinterpret_cast<float4*>(dst), n4);
+  const int64_t blocks = cdiv(n4, 256) < (1 << 20) ? cdiv(n4, 256) : (1 << 20);
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const sc_f4*>(src),
+                     reinterpret_cast<sc_f4*>(dst), n4);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -317,3 +317,31 @@ def test_merge_sharded_rows_equal_the_whole_block(R, W, order):
     close("dX", dX.numpy(), X.grad)
     for kk, nm in names.items():
         close(kk, total[kk].numpy(), p[nm].grad)
+
+
+def test_capture_steps_replays_the_same_steps_as_train_step():
+    """FusedTrainer.capture_steps: ONE hipGraph of consecutive complete steps == the same steps called one by one (injected draws, no
+    dropout: the steps do not depend on the seed counters the capture advanced)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    k, n_sel, _ = O.mask_count(N, V2["mask_ratio_h"], V2["mask_ratio_hr"])
+    perm = torch.from_numpy(synth.permutation(350, k)).to(DEV)
+    shuf = torch.from_numpy(synth.permutation(370, N - n_sel)).to(DEV)
+    bags = [torch.from_numpy(synth.bag(4100 + j, N, D)).to(DEV) for j in range(3)]
+    labels = [torch.tensor([j % 2], device=DEV) for j in range(3)]
+    sa, ta = _models()
+    tra = FusedTrainer(sa, ta, aux_alpha=0.5, mm=0.999)
+    for b, l in zip(bags, labels):
+        tra.train_step(b, l, perm=perm, ids_shuffle=shuf)
+    sb, tb = _models()
+    trb = FusedTrainer(sb, tb, aux_alpha=0.5, mm=0.999)
+    snap = [trb.flat.student.clone(), trb.flat.teacher.clone(), trb.flat.m.clone(), trb.flat.v.clone(), trb.opt_step.clone(), trb.tick.clone()]
+    g = trb.capture_steps(bags, labels, warmup=1, perm=perm, ids_shuffle=shuf)
+    trb.flat.student.copy_(snap[0]); trb.flat.teacher.copy_(snap[1]); trb.flat.m.copy_(snap[2]); trb.flat.v.copy_(snap[3])
+    trb.opt_step.copy_(snap[4]); trb.tick.copy_(snap[5]); trb.flat.step = 0
+    trb.flat.grad.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for (n, a), (_, b) in zip(sa.state_dict().items(), sb.state_dict().items()):
+        assert torch.equal(a, b), n
+    for (n, a), (_, b) in zip(ta.state_dict().items(), tb.state_dict().items()):
+        assert torch.equal(a, b), ("teacher", n)

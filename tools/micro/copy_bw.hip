@@ -39,6 +39,9 @@ int main() {
            2.0 * n * 4 / run<8, false>(s, d, n4, blocks) / 1e6, 2.0 * n * 4 / run<4, true>(s, d, n4, blocks) / 1e6,
            2.0 * n * 4 / run<8, true>(s, d, n4, blocks) / 1e6);
   }
+  for (int blocks : {16384, 32768, 65536, 131072, 262144})
+    printf("blocks %6d: U1nt %.0f  U2nt %.0f  U2 %.0f GB/s\n", blocks, 2.0 * n * 4 / run<1, true>(s, d, n4, blocks) / 1e6,
+           2.0 * n * 4 / run<2, true>(s, d, n4, blocks) / 1e6, 2.0 * n * 4 / run<2, false>(s, d, n4, blocks) / 1e6);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   hipEventRecord(a); hipMemcpyAsync(d, s, n * 4, hipMemcpyDeviceToDevice, 0); hipEventRecord(b); hipEventSynchronize(b);
   hipEventRecord(a); hipMemcpyAsync(d, s, n * 4, hipMemcpyDeviceToDevice, 0); hipEventRecord(b); hipEventSynchronize(b);
