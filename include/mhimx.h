@@ -90,6 +90,30 @@ typedef struct {
   const float* resid; int64_t ldr;    /* optional fp32 [N, ldr >= E], added AFTER activation and dropout: H = resid + dropout(act(..)) -  */
                                       /* the residual connection around a TransLayer's to_out (baseline.py:215); not H itself; dact ignores it */
 } mhimx_proj_head;
+/* The teacher's scorer INSIDE the projection (round 4; modules/mhim.py:193-205 forward_teacher: feature -> DAttention -> pseudo score):
+ * with this block model 0's feature rows never reach HBM.  A workgroup of model 0 holds 160 rows x 256 of the 512 feature columns after the
+ * k loop; in its epilogue it applies bias / activation / dropout in registers, multiplies its half rows with the matching half of
+ * [Wa ; Wp] on the matrix cores (3-term bf16), swaps the [160, 144] partial products with the workgroup that owns the other 256 columns
+ * (same XCD, neighbouring block index: a pair gate in `gate`), and both finish alike: s = wc . act(u), the class projections, and the
+ * log-sum-exp pool partial (max, sum, sum_r e^{s_r - max} h_r over its own 256 columns).  mhimx_pool_finalize merges the G partials.
+ * head[0].H may then be NULL (non-NULL: the rows are written as well - tests).  E = 512, scorer width 128, no scorer bias, C <= 16. */
+typedef struct {
+  const float* wa16;                  /* prep kind-8 image of [Wa (128 rows) ; Wp (C rows)] stacked: 9 blocks of 16 rows, K = E         */
+  const float* wc;                    /* [128] second scorer layer                                                                    */
+  int32_t act;                        /* scorer activation (MHIMX_ACT_*)                                                              */
+  int32_t C;                          /* classes whose projections h . Wp_c are wanted (0: none)                                      */
+  float* s;                           /* [N] scorer outputs                                                                           */
+  float* cproj;                       /* [N, C]                                                                                       */
+  float* pm; float* pl; float* pz;    /* pool partials of the G = mhimx_proj_score_parts(N) row tiles: [G], [G], [G, E]               */
+  float* xch;                         /* exchange scratch, mhimx_proj_score_xch_floats(N) floats                                      */
+  uint32_t* gate;                     /* [G] pair counters: zero ONCE (they only count up, two per launch)                             */
+} mhimx_proj_score;
+/* merges G pool partials (pm, pl, pz [G, E]) into stats = {max, sum}, z [E] and - with pscore - the pseudo score of the M1 instances
+ * (mhimx_pseudo_score's arithmetic): the last launch of mhimx_abmil_pool_fwd, for partials the caller holds (mhimx_proj_score's) */
+int mhimx_pool_finalize(void* stream, const float* pm, const float* pl, const float* pz, int64_t G, int64_t E, float* stats, float* z,
+                        const float* s, const float* cproj, const float* bp, int64_t C, int64_t M1, float* pscore);
+int64_t mhimx_proj_score_parts(int64_t N);
+int64_t mhimx_proj_score_xch_floats(int64_t N);
 typedef struct {
   const float* X; int64_t ldx;        /* the bag [N, D] fp32                                               */
   int64_t N, D, E;
@@ -97,6 +121,7 @@ typedef struct {
   int32_t n_heads;
   mhimx_proj_head head[MHIMX_PROJ_MAX_HEADS];
   const uint64_t* drop_tick;          /* optional device step counter mixed into every drop_seed           */
+  const mhimx_proj_score* score0;     /* optional: model 0's scorer + pool partials in the epilogue (above) */
 } mhimx_bag_project_args;
 int mhimx_bag_project(void* stream, const mhimx_bag_project_args* a);
 /* The projections of the n_bags <= 8 bags of an accumulation window (they share both models' weights: base_engine.py:100-119 steps the
@@ -217,7 +242,10 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  *     mhimx_merge block (read while enqueueing), out = the Merge workspace (device), R = rows to merge, C = workspace bytes.  Up to 8
  *     per launch when they share their parameters (the bags of an accumulation window: one workspace each),
  * 7 = paired planes of the TRANSPOSE in^T [C,R] made straight from in[R,C] (R % 8 == 0): the weight image of a data-gradient product
- *     dX = dY W on the projection kernel (the TransMIL layers' to_qkv / to_out, baseline.py:213-218). */
+ *     dX = dY W on the projection kernel (the TransMIL layers' to_qkv / to_out, baseline.py:213-218),
+ * 8 = the fragment image of in[R,C] for 16-row blocks and 32-deep steps (rows padded to a multiple of 16 with zeros, C % 32 == 0; out:
+ *     ceil(R / 16) * 16 * C floats): item (nb, ks, lane) = 8 hi | 8 lo bf16 of in[16 nb + lane % 16][32 ks + 8 (lane / 16) ..] - what
+ *     mhimx_proj_score.wa16 takes. */
 #define MHIMX_PREP_MAX 24
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);

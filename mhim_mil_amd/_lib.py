@@ -44,9 +44,15 @@ class ProjHead(C.Structure):
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_mask", c_u8p), ("resid", c_f32p), ("ldr", C.c_int64)]
 
 
+class ProjScore(C.Structure):
+    """mhimx_proj_score (include/mhimx.h)."""
+    _fields_ = [("wa16", c_f32p), ("wc", c_f32p), ("act", C.c_int32), ("C", C.c_int32), ("s", c_f32p), ("cproj", c_f32p),
+                ("pm", c_f32p), ("pl", c_f32p), ("pz", c_f32p), ("xch", c_f32p), ("gate", C.c_void_p)]
+
+
 class BagProject(C.Structure):
     _fields_ = [("X", c_f32p), ("ldx", C.c_int64), ("N", C.c_int64), ("D", C.c_int64), ("E", C.c_int64),
-                ("act", C.c_int32), ("n_heads", C.c_int32), ("head", ProjHead * 2), ("drop_tick", C.c_void_p)]
+                ("act", C.c_int32), ("n_heads", C.c_int32), ("head", ProjHead * 2), ("drop_tick", C.c_void_p), ("score0", C.c_void_p)]
 
 
 class BagWgrad(C.Structure):
@@ -165,6 +171,9 @@ SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
     "mhimx_gemm_nt": (C.c_int, [_P, C.POINTER(GemmNT)]),
+    "mhimx_pool_finalize": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mhimx_proj_score_parts": (_I64, [_I64]),
+    "mhimx_proj_score_xch_floats": (_I64, [_I64]),
     "mhimx_bag_project": (C.c_int, [_P, C.POINTER(BagProject)]),
     "mhimx_bag_project_multi": (C.c_int, [_P, _P, _I32]),
     "mhimx_gemm_nn": (C.c_int, [_P, C.POINTER(GemmNT), _F, _I32, _P]),

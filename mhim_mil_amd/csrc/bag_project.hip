@@ -480,7 +480,9 @@ static int bag_project_check(const mhimx_bag_project_args& g) {
   MHIMX_CHECK_ARG(g.ldx % 4 == 0 && g.ldx >= g.D && aligned16(g.X), "bag_project: X rows must be 16-byte aligned");
   for (int h = 0; h < g.n_heads; ++h) {
     const mhimx_proj_head& H = g.head[h];
-    MHIMX_CHECK_ARG(H.wp && H.H && aligned16(H.wp) && aligned16(H.H) && H.ldh % 4 == 0 && H.ldh >= g.E, "bag_project: model %d: null / unaligned weight image or output", h);
+    const bool scored = h == 0 && g.score0 != nullptr;          // (the scored model 0 may leave its feature rows unwritten)
+    MHIMX_CHECK_ARG(H.wp && (H.H || scored) && aligned16(H.wp) && aligned16(H.H) && (!H.H || (H.ldh % 4 == 0 && H.ldh >= g.E)),
+                    "bag_project: model %d: null / unaligned weight image or output", h);
     MHIMX_CHECK_ARG(!H.resid || (aligned16(H.resid) && H.ldr % 4 == 0 && H.ldr >= g.E && H.resid != H.H), "bag_project: model %d: unaligned residual rows / the output itself", h);
     MHIMX_CHECK_ARG(!H.bias || aligned16(H.bias), "bag_project: model %d: unaligned bias", h);
     MHIMX_CHECK_ARG(!H.dact || (reinterpret_cast<uintptr_t>(H.dact) & 7) == 0, "bag_project: model %d: unaligned dact", h);
@@ -505,7 +507,7 @@ int bag_project(hipStream_t st, const mhimx_bag_project_args* bags, int n_bags) 
   // the specialised-wave form (bag_project_ws.hip: 8 ping-pong consumer waves + 4 producer waves) is the default; MHIMX_PROJ_LOCKSTEP=1
   // selects this file's uniform 8-wave kernel (same tiles, same arithmetic, same bits)
   static const bool lockstep = getenv("MHIMX_PROJ_LOCKSTEP") != nullptr;
-  if (!lockstep) return bag_project_ws(st, bags, n_bags);
+  if (!lockstep || g.score0) return bag_project_ws(st, bags, n_bags);
   MHIMX_CHECK_ARG(n_bags == 1, "bag_project_multi: only the default (specialised-wave) kernel takes several bags");
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE)));
   const int nN = (int)(g.n_heads * g.E / PBN), nM = (int)cdiv(g.N, PBM);

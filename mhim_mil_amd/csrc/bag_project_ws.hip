@@ -60,7 +60,211 @@ struct ProjBags {
   uint64_t seed[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
 };
 
-__global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_project_args g, ProjBags pb) {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The teacher's scorer in the epilogue (mhimx_proj_score, round 4).  Called by all twelve waves of a MODEL-0 workgroup after the k loop
+// with the 160 x 256 pre-activations in the consumers' accumulators (wave (wm, wn): rows 80 wm .., columns 64 wn ..).
+//   per 80-row half:  h = dropout(act(acc + bias)) in the owners' registers (it stays there: the pool needs it again), its bf16 hi / lo
+//                     image to LDS [8 k-steps][80 rows][128 B] (the k loop's A-tile layout), then u_part [80, 144] = h [Wa ; Wp]_half^T
+//                     on the matrix cores - wave w owns the 16-column block w of the 9 (wave 8, a producer, the class projections) -
+//                     written through to the exchange scratch;
+//   pair gate:        one arrival per workgroup, wait for the partner (block index +- 8: the same XCD, dispatched next to this one);
+//   both alike:       u = u_part(columns 0..255) + u_part(columns 256..511) in that order, s = wc . act(u), class projections, the tile's
+//                     max / sum, and sum_r e^{s_r - max} h_r over the OWN 256 columns from the registers.
+// Nothing of the [N, 512] feature rows is written (unless H.H is given).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct ProjScore { const float *wa16, *wc; int act, C; float *s, *cproj, *pm, *pl, *pz, *xch; uint32_t* gate; };
+constexpr int PS_UCOLS = 144;                       // 128 scorer columns + 16 (class projections, padded)
+constexpr unsigned PS_GATE_SPINS = 1u << 22;
+
+MHIMX_DEV float ps_row16_sum(float v) {              // sum over the 16 lanes of a DPP row, in every lane of the row
+  v += dpp_mov<0xB1, 0xf>(0.f, v);
+  v += dpp_mov<0x4E, 0xf>(0.f, v);
+  v += dpp_mov<0x141, 0xf>(0.f, v);
+  v += dpp_mov<0x140, 0xf>(0.f, v);
+  return v;
+}
+
+template <bool WRITE_H>
+MHIMX_DEV void pw_scored_epilogue(const mhimx_bag_project_args& g, const mhimx_proj_head& H, const ProjScore& sc, f32x4 (&acc)[NRA][NRB],
+                                  char* smem, int m_tile, int64_t m0, int64_t n0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < W_CONS;
+  const int wm = (wave >> 2) & 1, wn = wave & 3;
+  const int cl = lane & 15, rq = lane >> 4;
+  const int colhalf = (int)(n0 / WBN);
+  const int E = (int)g.E;
+  char* img = smem;                                                      // [8][80][128 B] = 80 KiB
+  uint32_t* rkeys = reinterpret_cast<uint32_t*>(smem + 81920);           // [160]
+  float* sred = reinterpret_cast<float*>(smem + 81920 + 1024);           // [8][160]
+  float* srow = sred + 8 * 160;                                          // [160]
+  float* prow = srow + 160;                                              // [160]
+  float* zred = prow + 160;                                              // [2][256]
+  float* red = zred + 512;                                               // [16]
+  const bool hashed = H.drop_p > 0.f;                                    // (no injected masks here: the host refuses them)
+  const uint64_t dseed = hashed ? eff_seed(H.drop_seed, g.drop_tick) : 0;
+  const uint32_t thr16 = (uint32_t)(H.drop_p * 65536.f + 0.5f);
+  const float inv_keep = 65536.f / (float)(65536u - thr16);
+  __syncthreads();                                                       // the k loop's fragment reads are over
+  if (hashed && tid < 160) rkeys[tid] = drop_row_key(dseed, (uint64_t)(m0 + tid));
+  const int64_t xbase = ((int64_t)m_tile * 2) * 160 * PS_UCOLS;          // this row tile's two blocks of the exchange scratch
+  float* xmine = sc.xch + xbase + (int64_t)colhalf * 160 * PS_UCOLS;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();                                                     // row keys visible / the previous half's image reads are over
+    if (consumer && wm == half) {
+      // (row-major over (i, e), the four column blocks inside: one row key and one swizzle per row, and a scheduling fence per row - left
+      // to itself the compiler interleaves all 80 elements' activations and spills 300 registers beside the 80 accumulators)
+      float bias4[NRB];
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) bias4[j] = H.bias ? H.bias[n0 + wn * 64 + j * 16 + cl] : 0.f;
+      const int kin0 = cl, g80 = cl >> 3, idx = cl & 7;                  // column block j: k-step wn * 2 + (j >> 1), slot group (j & 1) * 2 + g80
+#pragma unroll
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int rl = i * 16 + rq * 4 + e;                            // row inside the half
+          const int64_t m = m0 + half * 80 + rl;
+          const int sw = mt_swz(rq * 4 + e);                             // (mt_swz depends on row & 15 only)
+          const uint32_t rk = hashed ? rkeys[half * 80 + rl] : 0u;
+          char* rowp = img + rl * 128 + idx * 2;
+#pragma unroll
+          for (int j = 0; j < NRB; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 16 + cl;
+            float v = act_fwd(acc[i][j][e] + bias4[j], g.act);
+            float ks = 1.f;
+            if (hashed) {
+              const uint32_t hsh = pw_pair_hash(rk, (uint32_t)(n >> 1));
+              ks = ((n & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= thr16 ? inv_keep : 0.f;
+            }
+            v *= ks;
+            acc[i][j][e] = v;
+            if constexpr (WRITE_H)                                       // (tests only - its own instantiation: the 64-bit addresses cost ~60
+              if (m < g.N) H.H[m * H.ldh + n] = v;                       //  registers beside the 80 accumulators; production passes no buffer)
+            const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+            const int g8 = (j & 1) * 2 + g80;
+            char* base = rowp + (wn * 2 + (j >> 1)) * 10240;
+            *reinterpret_cast<__bf16*>(base + (((2 * g8) ^ sw) << 4)) = hi;
+            *reinterpret_cast<__bf16*>(base + (((2 * g8 + 1) ^ sw) << 4)) = lo;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          (void)kin0;
+        }
+    }
+    __syncthreads();
+    if (wave < 8 || (wave == 8 && sc.C > 0)) {
+      const int ab = wave;
+      f32x4 u[NRA];
+#pragma unroll
+      for (int i = 0; i < NRA; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* bimg = sc.wa16 + ((int64_t)(ab * (E / 32) + (int)(n0 >> 5)) * 64 + lane) * 8;      // + 512 floats per k-step
+      const int r16 = lane & 15, kg = lane >> 4, sw = mt_swz(r16);
+      const char* fa_hi = img + r16 * 128 + (((2 * kg) ^ sw) << 4);
+      const char* fa_lo = img + r16 * 128 + (((2 * kg + 1) ^ sw) << 4);
+      f32x4 bh = *reinterpret_cast<const f32x4*>(bimg), bl = *reinterpret_cast<const f32x4*>(bimg + 4);
+#pragma unroll 1
+      for (int kk = 0; kk < 8; ++kk) {
+        const int kn = kk + 1 < 8 ? kk + 1 : kk;
+        const f32x4 nbh = *reinterpret_cast<const f32x4*>(bimg + kn * 512), nbl = *reinterpret_cast<const f32x4*>(bimg + kn * 512 + 4);
+#pragma unroll
+        for (int i = 0; i < NRA; ++i) {
+          const f32x4 ah = *reinterpret_cast<const f32x4*>(fa_hi + kk * 10240 + i * 2048);
+          const f32x4 al = *reinterpret_cast<const f32x4*>(fa_lo + kk * 10240 + i * 2048);
+          u[i] = mt_mfma(al, bh, u[i]);
+          u[i] = mt_mfma(ah, bl, u[i]);
+          u[i] = mt_mfma(ah, bh, u[i]);
+        }
+        bh = nbh;
+        bl = nbl;
+      }
+#pragma unroll
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __hip_atomic_store(xmine + (int64_t)(half * 80 + i * 16 + rq * 4 + e) * PS_UCOLS + ab * 16 + cl, u[i][e], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- pair gate (counters only count up: an even value = nobody of the current launch has arrived)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(sc.gate + m_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (old | 1u) + 1u;
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(sc.gate + m_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && ++spins < PS_GATE_SPINS)
+      __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  // ---- scores: wave w sums its 16 scorer columns of every row; the class projections are columns 128.. of wave 8
+  const float* x0 = sc.xch + xbase;
+  const float* x1 = x0 + 160 * PS_UCOLS;
+  if (wave < 8) {
+    const float wca = sc.wc[wave * 16 + cl];
+#pragma unroll 2
+    for (int i2 = 0; i2 < 10; ++i2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = i2 * 16 + rq * 4 + e;
+        const int64_t o = (int64_t)row * PS_UCOLS + wave * 16 + cl;
+        const float uu = __hip_atomic_load(x0 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                         __hip_atomic_load(x1 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float t = ps_row16_sum(wca * act_fwd(uu, sc.act));
+        if (cl == 0) sred[wave * 160 + row] = t;
+      }
+  } else if (wave == 8 && sc.C > 0 && colhalf == 0) {
+    for (int i2 = 0; i2 < 10; ++i2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = i2 * 16 + rq * 4 + e;
+        const int64_t m = m0 + row;
+        const int64_t o = (int64_t)row * PS_UCOLS + 128 + cl;
+        if (cl < sc.C && m < g.N)
+          sc.cproj[m * sc.C + cl] = __hip_atomic_load(x0 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                                    __hip_atomic_load(x1 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+  __syncthreads();
+  if (tid < 160) {
+    float sv = ((sred[tid] + sred[160 + tid]) + (sred[320 + tid] + sred[480 + tid])) + ((sred[640 + tid] + sred[800 + tid]) + (sred[960 + tid] + sred[1120 + tid]));
+    const int64_t m = m0 + tid;
+    if (m >= g.N) sv = -INFINITY;
+    else if (colhalf == 0) sc.s[m] = sv;
+    srow[tid] = sv;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float a = srow[lane], b = srow[lane + 64], c = lane < 32 ? srow[lane + 128] : -INFINITY;
+    const float mt = wave_max(fmaxf(fmaxf(a, b), c));
+    if (lane == 0) red[0] = mt;
+  }
+  __syncthreads();
+  const float mt = red[0];
+  if (tid < 160) prow[tid] = srow[tid] == -INFINITY ? 0.f : __expf(srow[tid] - mt);
+  __syncthreads();
+  if (wave == 0) {
+    const float l = wave_sum((prow[lane] + prow[lane + 64]) + (lane < 32 ? prow[lane + 128] : 0.f));
+    if (lane == 0 && colhalf == 0) { sc.pm[m_tile] = mt; sc.pl[m_tile] = l; }
+  }
+  if (consumer) {
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      float zc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zc += prow[wm * 80 + i * 16 + rq * 4 + e] * acc[i][j][e];
+      zc += __shfl_xor(zc, 16);
+      zc += __shfl_xor(zc, 32);
+      if (rq == 0) zred[wm * 256 + wn * 64 + j * 16 + cl] = zc;
+    }
+  }
+  __syncthreads();
+  if (tid < 256) sc.pz[(int64_t)m_tile * E + n0 + tid] = zred[tid] + zred[256 + tid];
+}
+
+template <int SCORED>           // 0: feature rows only; 1: model 0 scored in the epilogue, its rows not written; 2: scored AND written (tests)
+__global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_project_args g, ProjBags pb, ProjScore sc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,6 +503,12 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #ifdef PW_PROF
   pf_t2 = __builtin_readcyclecounter();
 #endif
+  if constexpr (SCORED) {
+    if (hd == 0) {                                            // model 0: scorer + pool partials instead of the feature rows
+      pw_scored_epilogue<SCORED == 2>(g, H, sc, acc, smem, m_tile, m0, n0);
+      return;
+    }
+  }
   // ================================================================= epilogue: all twelve waves, two 80-row halves through LDS
   float* tile = reinterpret_cast<float*>(smem);
   uint32_t* rkeys = reinterpret_cast<uint32_t*>(smem + 80 * WTP * 4);
@@ -437,8 +647,19 @@ __global__ __launch_bounds__(256) void proj_dropout_apply_kernel(const float* __
 }
 
 int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bags) {
-  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE));
+                        MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE));
+                        MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
   const mhimx_bag_project_args& g = bags[0];
+  ProjScore sc = {};
+  if (g.score0) {
+    const mhimx_proj_score& q = *g.score0;
+    MHIMX_CHECK_ARG(n_bags == 1 && g.E == 512 && q.wa16 && q.wc && q.s && q.pm && q.pl && q.pz && q.xch && q.gate && q.C >= 0 && q.C <= 16 &&
+                        (q.C == 0 || q.cproj) && aligned16(q.wa16) && !g.head[0].resid && !g.head[0].dact && !g.head[0].drop_mask,
+                    "bag_project: the scored model 0 needs E = 512, one bag, every output of mhimx_proj_score, no residual rows / dact / injected mask");
+    static_assert(81920 + 1024 + (8 * 160 + 160 + 160 + 512 + 16) * 4 <= WNST * WSTAGE, "the scored epilogue's LDS fits the ring");
+    sc = ProjScore{q.wa16, q.wc, q.act, q.C, q.s, q.cproj, q.pm, q.pl, q.pz, q.xch, q.gate};
+  }
   const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)cdiv(g.N, WBM);
   ProjBags pb = {};
   pb.n_bags = n_bags;
@@ -452,12 +673,17 @@ int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bag
     }
   }
   dim3 grid((unsigned)(nN * pb.tiles_per_bag * n_bags));
-  hipLaunchKernelGGL(bag_project_ws_kernel, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb);
+  if (g.score0 && g.head[0].H) hipLaunchKernelGGL(bag_project_ws_kernel<2>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
+  else if (g.score0) hipLaunchKernelGGL(bag_project_ws_kernel<1>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
+  else hipLaunchKernelGGL(bag_project_ws_kernel<0>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace mhimx
+
+extern "C" int64_t mhimx_proj_score_parts(int64_t N) { return (N + mhimx::WBM - 1) / mhimx::WBM; }
+extern "C" int64_t mhimx_proj_score_xch_floats(int64_t N) { return mhimx_proj_score_parts(N) * 2 * 160 * mhimx::PS_UCOLS; }
 
 extern "C" int mhimx_dropout_apply_proj(void* stream, const float* x, float* out, int64_t M, int64_t E, float p, uint64_t seed, const uint64_t* tick) {
   using namespace mhimx;

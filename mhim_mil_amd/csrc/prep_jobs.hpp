@@ -117,6 +117,26 @@ MHIMX_DEV void prep_job_block(const PrepJobs& pj, int block, float* lds) {
       o[0] = __builtin_bit_cast(pj_f4, hi);
       o[1] = __builtin_bit_cast(pj_f4, lo);
     }
+  } else if (jb.kind == 8) {
+    // B-operand fragment image for v_mfma_f32_16x16x32_bf16 of in[R, C] with the rows padded to a multiple of 16 (zeros): item (nb, ks, lane)
+    // holds the 8 hi | 8 lo bf16 of in[16 nb + (lane & 15)][32 ks + 8 (lane >> 4) .. + 8] - a wave's fragment load is 2 KB contiguous
+    // (what mhimx_proj_score.wa16 takes: the teacher's scorer inside the projection's epilogue, bag_project_ws.hip)
+    const int64_t KS = C / 32, NB = (R + 15) / 16, n = NB * KS * 64;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
+      const int64_t lane = i & 63, ks = (i >> 6) % KS, nb = (i >> 6) / KS;
+      const int64_t row = 16 * nb + (lane & 15);
+      pj_f4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+      if (row < R) {
+        const float* src = jb.in + row * C + 32 * ks + 8 * (lane >> 4);
+        a = *reinterpret_cast<const pj_f4*>(src);
+        b = *reinterpret_cast<const pj_f4*>(src + 4);
+      }
+      pj_b8 hi, lo;
+      pj_split2(a, b, hi, lo);
+      pj_f4* o = reinterpret_cast<pj_f4*>(jb.out + i * 8);
+      o[0] = __builtin_bit_cast(pj_f4, hi);
+      o[1] = __builtin_bit_cast(pj_f4, lo);
+    }
   } else if (jb.kind == 6) {
     Merge2Ws w = pj.m2.w;
     const int64_t sh = pj.m2_shift[jb.R];             // (only the fields the preparation writes are shifted)

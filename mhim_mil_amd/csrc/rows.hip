@@ -1211,6 +1211,18 @@ extern "C" int mhimx_mul_colsum(void* stream, float* dH, const float* dact, int6
   }
   return 0;
 }
+// the pool's finalize launch on caller-held partials (the scored projection's: mhimx_proj_score) - the same kernel mhimx_abmil_pool_fwd ends with
+extern "C" int mhimx_pool_finalize(void* stream, const float* pm, const float* pl, const float* pz, int64_t G, int64_t E, float* stats, float* z,
+                                   const float* s, const float* cproj, const float* bp, int64_t C, int64_t M1, float* pscore) {
+  MHIMX_CHECK_ARG(pm && pl && pz && stats && z && G >= 1 && G <= 2 * MAX_PART && E >= 1, "pool_finalize: 1..%d partials", 2 * MAX_PART);
+  MHIMX_CHECK_ARG(!pscore || (s && cproj && C >= 1 && M1 >= 1), "pool_finalize: the pseudo score needs s, cproj and the instance count");
+  const int64_t ps_blocks = pscore ? (cdiv(M1, FIN_THREADS) < 64 ? cdiv(M1, FIN_THREADS) : 64) : 0;
+  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)(cdiv(E, 64) + ps_blocks)), dim3(FIN_THREADS), 0, (hipStream_t)stream, pm, pl, pz, (int)G, (int)E,
+                     stats, z, s, cproj, bp, (int)C, M1, pscore);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list) { return reduce_flush((hipStream_t)stream, list); }
 extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate, void* ws,
                             int64_t ws_bytes) {

@@ -79,6 +79,41 @@ class ProjHead:
         self.out, self.want_dact, self.dact, self.resid = out, want_dact, dact, resid
 
 
+class ProjScoreBuf:
+    """The teacher's scorer inside the projection (mhimx_proj_score): the [Wa ; Wp] image, the second scorer layer, and the buffers the
+    launch fills - s [N], cproj [N, C], the G pool partials - plus the pair-exchange scratch and its counters (allocated once per N: the
+    counters are zeroed once and only count up).  ``finalize`` merges the partials (mhimx_pool_finalize)."""
+
+    _scratch = {}
+
+    def __init__(self, N, wa16, wc, act, C_classes, device):
+        lib = L.lib()
+        self.N, self.C_classes, self.act = int(N), int(C_classes), int(act)
+        self.wa16, self.wc = wa16, wc
+        G = self.G = lib.mhimx_proj_score_parts(self.N)
+        key = (self.N, str(device))
+        sc = ProjScoreBuf._scratch.get(key)
+        if sc is None:
+            sc = ProjScoreBuf._scratch[key] = (torch.empty(lib.mhimx_proj_score_xch_floats(self.N), device=device),
+                                               torch.zeros(G, dtype=torch.int32, device=device))
+        self.xch, self.gate = sc
+        E = 512
+        self.s = torch.empty(self.N, device=device)
+        self.cproj = torch.empty((self.N, max(self.C_classes, 1)), device=device) if self.C_classes else None
+        self.pm, self.pl, self.pz = torch.empty(G, device=device), torch.empty(G, device=device), torch.empty((G, E), device=device)
+        self.stats, self.z, self.pscore = torch.empty(2, device=device), torch.empty(E, device=device), None
+        self.c = L.ProjScore(wa16=_p(wa16), wc=_p(wc), act=self.act, C=self.C_classes, s=_p(self.s), cproj=_p(self.cproj), pm=_p(self.pm),
+                             pl=_p(self.pl), pz=_p(self.pz), xch=_p(self.xch), gate=_p(self.gate))
+
+    def finalize(self, bp=None):
+        """-> self (stats, z and, with the predictor bias ``bp``, pscore [N] filled)."""
+        if bp is not None:
+            self.pscore = torch.empty(self.N, device=self.s.device)
+        L.check(L.lib().mhimx_pool_finalize(_stream(), _p(self.pm), _p(self.pl), _p(self.pz), self.G, 512, _p(self.stats), _p(self.z), _p(self.s),
+                                            _p(self.cproj), _p(bp), self.C_classes, self.N, _p(self.pscore)), "mhimx_pool_finalize")
+        return self
+
+
 def _project_args(x, heads, act, drop_tick, extra_rows):
     _chk(x, name="x")
     N, D = x.shape
@@ -105,22 +140,25 @@ def bag_project_multi(xs, heads_per_bag, act=0, drop_tick=None, extra_rows=0):
     return heads_per_bag
 
 
-def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
+def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0, score0=None, keep_rows0=False):
     """Every model's feature rows H_g = dropout_g(act(x W_g^T + b_g)) in ONE pass over the fp32 bag x [N,D] (mhimx_bag_project).
     heads: 1 or 2 ProjHead (teacher, student).  Fills head.out [N + extra_rows, E] fp32 (the extra rows are left for the caller:
-    merged tokens) and, with want_dact, head.dact [N, E] fp16 (d out / d pre).  Returns the heads."""
+    merged tokens) and, with want_dact, head.dact [N, E] fp16 (d out / d pre).  Returns the heads.
+    ``score0`` (ProjScoreBuf): model 0's scorer and pool partials are computed in the launch's epilogue and its feature rows are NOT
+    written (heads[0].out stays None) unless ``keep_rows0`` (tests)."""
     _chk(x, name="x")
     N, D = x.shape
     E = heads[0].wp.shape[0]
-    a = L.BagProject(X=_p(x), ldx=x.stride(0), N=N, D=D, E=E, act=int(act), n_heads=len(heads), drop_tick=_p(drop_tick))
+    a = L.BagProject(X=_p(x), ldx=x.stride(0), N=N, D=D, E=E, act=int(act), n_heads=len(heads), drop_tick=_p(drop_tick),
+                     score0=None if score0 is None else C.cast(C.pointer(score0.c), C.c_void_p))
     for i, h in enumerate(heads):
         _chk(h.wp, name="wp"); _chk(h.bias, name="bias"); _chk(h.drop_mask, torch.uint8, "drop_mask"); _chk(h.resid, name="resid")
-        if h.out is None:
+        if h.out is None and not (i == 0 and score0 is not None and not keep_rows0):
             h.out = torch.empty((N + extra_rows, E), device=x.device)
         _chk(h.out, name="out")
         if h.want_dact and h.dact is None:
             h.dact = torch.empty((N, E), device=x.device, dtype=torch.float16)
-        a.head[i] = L.ProjHead(wp=_p(h.wp), bias=_p(h.bias), H=_p(h.out), ldh=h.out.stride(0), dact=_p(h.dact),
+        a.head[i] = L.ProjHead(wp=_p(h.wp), bias=_p(h.bias), H=_p(h.out), ldh=E if h.out is None else h.out.stride(0), dact=_p(h.dact),
                                drop_p=h.drop_p, drop_seed=h.drop_seed & 0xFFFFFFFFFFFFFFFF, drop_mask=_p(h.drop_mask),
                                resid=_p(h.resid), ldr=h.resid.stride(0) if h.resid is not None else 0)
     evs = KERNEL_EVENT_HOOK("bag_project", N, E * len(heads), D) if KERNEL_EVENT_HOOK is not None else None
@@ -132,7 +170,7 @@ def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0):
     return heads
 
 
-PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE, PREP_PAIR_T = 0, 1, 2, 3, 4, 5, 6, 7
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE, PREP_PAIR_T, PREP_FRAG16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def _prep_array(jobs):

@@ -345,3 +345,70 @@ def test_capture_steps_replays_the_same_steps_as_train_step():
         assert torch.equal(a, b), n
     for (n, a), (_, b) in zip(ta.state_dict().items(), tb.state_dict().items()):
         assert torch.equal(a, b), ("teacher", n)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the teacher's scorer inside the projection's epilogue (mhimx_proj_score) == projection + one-pass scorer + finalize
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,p,two_heads", [(10000, 0.0, True), (1000, 0.25, True), (330, 0.25, False), (160, 0.0, False)])
+def test_scored_projection_equals_projection_plus_scorer(n, p, two_heads):
+    from mhim_mil_amd import ops
+    from mhim_mil_amd import _lib as L
+    from tests.test_ops_gpu import rnd
+    d, E, A, Cc = 1024, 512, 128, 2
+    x = torch.from_numpy(synth.bag(5100, n, d)).to(DEV)
+    w1 = (rnd(201, (E, d), std=0.03)).to(DEV); b1 = rnd(202, (E,), std=0.1).to(DEV)
+    w1s = (rnd(203, (E, d), std=0.03)).to(DEV); b1s = rnd(204, (E,), std=0.1).to(DEV)
+    wa = rnd(205, (A, E), std=0.05).to(DEV); wc = (rnd(206, (1, A), std=0.3) * 5).to(DEV)
+    wp = rnd(207, (Cc, E), std=0.05).to(DEV); bp = rnd(208, (Cc,), std=0.1).to(DEV)
+    act = L.ACT["gelu"]
+    sact = L.ACT["relu"]
+    tick = torch.zeros(1, dtype=torch.int64, device=DEV)
+
+    def heads():
+        hs = [ops.ProjHead(ops.pair_planes(w1), b1, drop_p=p, drop_seed=777)]
+        if two_heads:
+            hs.append(ops.ProjHead(ops.pair_planes(w1s), b1s, drop_p=p, drop_seed=778, want_dact=True))
+        return hs
+    # A: rows to HBM, then the one-pass scorer + finalize
+    ha = heads()
+    ops.bag_project(x, ha, act=act, drop_tick=tick)
+    frag = torch.empty_like(wa)
+    ops.prep_batch([(ops.PREP_FRAG, wa, frag)])
+    sc = ops.ScorerW(wa, wc, sact, wa_frag=frag)
+    st = ops.abmil_pool_fwd(sc, ha[0].out, None, wp=wp, bp=bp)
+    # B: scored in the epilogue
+    img = torch.empty(144 * E, device=DEV)
+    ops.prep_batch([(ops.PREP_FRAG16, wa, img), (ops.PREP_FRAG16, wp, img[128 * E:])])
+    for keep in (True, False):
+        buf = ops.ProjScoreBuf(n, img, wc.view(-1).contiguous(), sact, Cc, x.device)
+        hb = heads()
+        ops.bag_project(x, hb, act=act, drop_tick=tick, score0=buf, keep_rows0=keep)
+        buf.finalize(bp)
+        torch.cuda.synchronize()
+        if keep:
+            assert torch.equal(hb[0].out, ha[0].out)                      # the same rows, bit for bit (same activation, same dropout stream)
+        else:
+            assert hb[0].out is None
+        if two_heads:
+            assert torch.equal(hb[1].out, ha[1].out) and torch.equal(hb[1].dact, ha[1].dact)
+        sa, sb = st.s.double().cpu(), buf.s.double().cpu()
+        scale = sa.abs().max().item()
+        assert (sa - sb).abs().max().item() <= 3e-5 * scale, ((sa - sb).abs().max().item(), scale)
+        ca, cb = st.cproj.double().cpu(), buf.cproj.double().cpu()
+        assert (ca - cb).abs().max().item() <= 3e-5 * ca.abs().max().item()
+        za, zb = st.z.double().cpu(), buf.z.double().cpu()
+        assert (za - zb).abs().max().item() <= 2e-4 * za.abs().max().item(), (za - zb).abs().max().item()
+        # the statistics against fp64 of the device's own scores
+        mref = sb.max().item()
+        lref = torch.exp(sb - mref).sum().item()
+        assert abs(buf.stats[0].item() - mref) <= 1e-6 * max(1.0, abs(mref)) and abs(buf.stats[1].item() - lref) <= 2e-5 * lref
+        pa, pb = st.pscore.double().cpu(), buf.pscore.double().cpu()
+        assert (pa - pb).abs().max().item() <= 2e-5
+    # replaying the launch: the pair counters only count up
+    for _ in range(3):
+        buf2 = ops.ProjScoreBuf(n, img, wc.view(-1).contiguous(), sact, Cc, x.device)
+        ops.bag_project(x, heads(), act=act, drop_tick=tick, score0=buf2)
+        buf2.finalize(bp)
+    torch.cuda.synchronize()
+    assert torch.equal(buf2.s, buf.s) and torch.equal(buf2.z, buf.z) and torch.equal(buf2.pscore, buf.pscore)
