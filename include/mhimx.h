@@ -245,7 +245,11 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  *     dX = dY W on the projection kernel (the TransMIL layers' to_qkv / to_out, baseline.py:213-218),
  * 8 = the fragment image of in[R,C] for 16-row blocks and 32-deep steps (rows padded to a multiple of 16 with zeros, C % 32 == 0; out:
  *     ceil(R / 16) * 16 * C floats): item (nb, ks, lane) = 8 hi | 8 lo bf16 of in[16 nb + lane % 16][32 ks + 8 (lane / 16) ..] - what
- *     mhimx_proj_score.wa16 takes. */
+ *     mhimx_proj_score.wa16 takes,
+ * 9 = the bag in[R,C] (contiguous rows, C % 256 == 0) as the D-side operand image of the weight-gradient product (mhimx_bag_wgrad_args.ximg;
+ *     out: ceil(R / 32) * 32 * C floats): per 32-row k-step ks and 256-column block cb one 32 KiB tile (ks * C / 256 + cb) laid out
+ *     [row octet 4][hi | lo][column slot 256][8 bf16], column c of the block in slot (c % 4) * 64 + c / 4; rows past R are zero.  Not a
+ *     parameter-only job (it reads the bag) but one that depends on nothing else: it rides in a forward launch that leaves the chip idle. */
 #define MHIMX_PREP_MAX 24
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
@@ -557,6 +561,10 @@ int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, con
  * rows that were gathered out of a bag-ordered projection (the TransMIL / DSMIL students: masking.py:107 after mhim.py:335-336) */
 int mhimx_rows_dpre_image_c(void* stream, const float* dH_compact, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
                             float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
+/* the same in BAG order: row n of the image is dH[n] * dact16[n] if keep[n] (uint8 [N]; NULL: every row), a zero row otherwise - the
+ * E-side operand of mhimx_bag_wgrad with .ximg (the k dimension runs over the bag's rows as they lie in memory: no gather) */
+int mhimx_rows_dpre_image_k(void* stream, const float* dH, const void* dact16, const uint8_t* keep, int64_t N, int64_t E, void* img,
+                            float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer /* optional */);
 /* The projection's weight gradient (modules/mhim.py:69-76 backward; the last GEMM of the step):
  *     C[E,D] (+)= dPre[L,E]^T . X[rows ? rows[p] : p][D],   p < L
  * dPre as the image above, X the raw fp32 bag (split to bf16 hi/lo on its way into LDS, transposed with v_permlane32_swap); 3-term bf16
@@ -575,6 +583,11 @@ typedef struct {
                                                             as trailing workgroups of this launch - in the CUs its last round of tiles leaves
                                                             idle - instead of in mhimx_reduce_flush; the list then holds this launch's own
                                                             slab sum only (which mhimx_optim_step can fold into the update: `fold`)   */
+  const void* ximg;                                      /* optional: the bag as the product's D-side operand image (mhimx_prep_batch kind 9 of
+                                                            X[n_bag_rows, D], contiguous rows).  Then img is the dPRE image in BAG order
+                                                            (mhimx_rows_dpre_image_k: rows that did not take part are zero rows), rows = NULL,
+                                                            L = n_bag_rows, and both operands reach LDS by linear DMA: no register path, no
+                                                            split in the loop (the four E-side tiles of a k-step no longer split X four times) */
 } mhimx_bag_wgrad_args;
 int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D);
 int mhimx_bag_wgrad(void* stream, const mhimx_bag_wgrad_args* a);

@@ -58,7 +58,7 @@ class BagProject(C.Structure):
 class BagWgrad(C.Structure):
     _fields_ = [("img", C.c_void_p), ("X", c_f32p), ("ldx", C.c_int64), ("n_bag_rows", C.c_int64), ("rows", C.c_void_p),
                 ("L", C.c_int64), ("E", C.c_int64), ("D", C.c_int64), ("C", c_f32p), ("ldc", C.c_int64), ("accumulate", C.c_int32),
-                ("ws", c_f32p), ("ws_floats", C.c_int64), ("defer", C.c_void_p), ("ride_tail", C.c_int32)]
+                ("ws", c_f32p), ("ws_floats", C.c_int64), ("defer", C.c_void_p), ("ride_tail", C.c_int32), ("ximg", C.c_void_p)]
 
 
 class PrepJob(C.Structure):
@@ -216,6 +216,7 @@ SYMBOLS = {
     "mhimx_shard_scatter": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _P]),
     "mhimx_rows_dpre_image": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_rows_dpre_image_c": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
+    "mhimx_rows_dpre_image_k": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_wgrad_image_bytes": (_I64, [_I64, _I64]),
     "mhimx_wgrad_ws_floats": (_I64, [_I64, _I64, _I64]),
     "mhimx_bag_wgrad": (C.c_int, [_P, _P]),

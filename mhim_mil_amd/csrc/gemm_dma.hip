@@ -543,7 +543,7 @@ int prep_jobs_fill(const mhimx_prep_job* jobs, int n, PrepJobs* out) {
   for (int i = 0; i < n; ++i) {
     pj.j[i] = jobs[i];
     MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
-    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 8, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 9, "prep_batch: unknown job kind");
     if (jobs[i].kind == 6) {
       MHIMX_CHECK_ARG(n_merge < PREP_MERGE_MAX, "prep_batch: at most %d Merge preparation jobs per launch", PREP_MERGE_MAX);
       Merge2PrepArgs m2;
@@ -561,6 +561,8 @@ int prep_jobs_fill(const mhimx_prep_job* jobs, int n, PrepJobs* out) {
                     "prep_batch: the fragment image needs R % 32 == 0, C % 16 == 0 and 16-byte aligned buffers");
     MHIMX_CHECK_ARG(jobs[i].kind != 8 || (jobs[i].C % 32 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: the 16-row fragment image needs C % 32 == 0 and 16-byte aligned buffers");
+    MHIMX_CHECK_ARG(jobs[i].kind != 9 || (jobs[i].C % 256 == 0 && jobs[i].R >= 1 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
+                    "prep_batch: the bag image needs C % 256 == 0 and 16-byte aligned buffers");
     MHIMX_CHECK_ARG(jobs[i].kind != 7 || (jobs[i].R % 8 == 0 && aligned16(jobs[i].out)), "prep_batch: pairing the transpose needs R % 8 == 0 and a 16-byte aligned output");
     MHIMX_CHECK_ARG(jobs[i].kind != 1 || (jobs[i].C % 8 == 0 && aligned16(jobs[i].in) && aligned16(jobs[i].out)),
                     "prep_batch: pairing needs C % 8 == 0 and 16-byte aligned buffers");
@@ -571,6 +573,7 @@ int prep_jobs_fill(const mhimx_prep_job* jobs, int n, PrepJobs* out) {
                           (jobs[i].kind == 8 ? cdiv(jobs[i].R, 16) * 16 * jobs[i].C / 8 : jobs[i].R * jobs[i].C / 8));
     int64_t want = jobs[i].kind == 0 ? items : cdiv(items, 256);
     if (jobs[i].kind == 6) want = 64;                  // 8 heads x 8 column blocks
+    if (jobs[i].kind == 9) want = cdiv(jobs[i].R, 32) * (jobs[i].C / 256);   // one 32 KiB tile per workgroup
     if (want < 1) want = 1;
     if (want > 4096) want = 4096;                      // every job loop is grid-stride
     pj.first[i] = first;

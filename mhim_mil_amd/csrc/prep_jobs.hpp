@@ -137,6 +137,28 @@ MHIMX_DEV void prep_job_block(const PrepJobs& pj, int block, float* lds) {
       o[0] = __builtin_bit_cast(pj_f4, hi);
       o[1] = __builtin_bit_cast(pj_f4, lo);
     }
+  } else if (jb.kind == 9) {
+    // the bag as the weight-gradient product's D-side operand image (wgrad.hip, bag_wgrad_dma_kernel): tile (ks, cb) = rows 32 ks .. + 32,
+    // columns 256 cb .. + 256; thread -> (row octet, column quad q): 8 rows x 16 B in flight, then the 8 k-consecutive values of each of
+    // its four columns as 16 B of bf16 hi and 16 B of lo - a wave's stores are 1 KiB contiguous (column 4 q + j lives in slot 64 j + q)
+    const int64_t nJ = C / 256, ntiles = ((R + 31) / 32) * nJ;
+    const int koct = threadIdx.x >> 6, q = threadIdx.x & 63;
+    for (int64_t t = bid; t < ntiles; t += nblk) {
+      const int64_t ks = t / nJ, cb = t % nJ, r0 = ks * 32 + koct * 8;
+      const float* src = jb.in + r0 * C + cb * 256 + 4 * q;
+      pj_f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = r0 + u < R ? *reinterpret_cast<const pj_f4*>(src + u * C) : pj_f4{0.f, 0.f, 0.f, 0.f};
+      char* tile = reinterpret_cast<char*>(jb.out) + t * 32768 + ((koct * 2) * 256 + q) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x[8] = {v[0][j], v[1][j], v[2][j], v[3][j], v[4][j], v[5][j], v[6][j], v[7][j]};
+        pj_b8 hi, lo;
+        pj_split(x, hi, lo);
+        *reinterpret_cast<pj_f4*>(tile + j * 1024) = __builtin_bit_cast(pj_f4, hi);
+        *reinterpret_cast<pj_f4*>(tile + j * 1024 + 4096) = __builtin_bit_cast(pj_f4, lo);
+      }
+    }
   } else if (jb.kind == 6) {
     Merge2Ws w = pj.m2.w;
     const int64_t sh = pj.m2_shift[jb.R];             // (only the fields the preparation writes are shifted)

@@ -98,6 +98,37 @@ struct WgradArgs {
 struct WgradTail { int first, n_reduce, stage3, gate_want; ReduceTable t; };      // blocks: [first, first + stage3) stage 3, then n_reduce reductions
 constexpr unsigned WG_GATE_SPINS = 1u << 20;
 
+// the rider workgroups of a weight-gradient launch (see WgradTail): true if this block was one
+MHIMX_DEV bool wg_rider_block(char* smem, int side_blocks, const Merge2Side& side, const WgradTail& tail) {
+  if ((int)blockIdx.x < side_blocks) {
+    if (threadIdx.x < M2_THREADS) {
+      merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
+      if (tail.stage3) {                         // (the waves above M2_THREADS have left: the barrier counts the four that remain)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores of dQ are acknowledged ...
+        __syncthreads();                         // ... before the barrier that precedes the arrival
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(side.w.gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return true;
+  }
+  if (tail.first && (int)blockIdx.x >= tail.first) {
+    const int tb = (int)blockIdx.x - tail.first;
+    if (tb >= tail.stage3) {
+      reduce_jobs_block<WTHREADS>(tail.t, tb - tail.stage3, reinterpret_cast<float(*)[33]>(smem));
+    } else if (threadIdx.x < M2_THREADS) {       // (the tail's stage-3 workgroups come first: the longest chain of the trailing blocks)
+      if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(side.w.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tail.gate_want && ++spins < WG_GATE_SPINS)
+          __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();                           // (what stage 3 reads of stage 2 - dQ - it reads past the caches: mca2_side.hpp)
+      merge2_side_stage(3, tb, reinterpret_cast<float*>(smem), side);
+    }
+    return true;
+  }
+  return false;
+}
+
 constexpr int W_MAX_BAGS = 8;
 struct WgradBags {            // the bags of one launch (bag_wgrad_ws_kernel): bag b owns slabs [b * spb, (b + 1) * spb)
   const char* img[W_MAX_BAGS];
@@ -345,32 +376,7 @@ MHIMX_DEV void ws_unit(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[4]
 
 __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, WgradBags mb, int side_blocks, Merge2Side side, WgradTail tail) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x < side_blocks) {
-    if (threadIdx.x < M2_THREADS) {
-      merge2_side_stage(2, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
-      if (tail.stage3) {                         // (the waves above M2_THREADS have left: the barrier counts the four that remain)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores of dQ are acknowledged ...
-        __syncthreads();                         // ... before the barrier that precedes the arrival
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(side.w.gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    return;
-  }
-  if (tail.first && (int)blockIdx.x >= tail.first) {
-    const int tb = (int)blockIdx.x - tail.first;
-    if (tb >= tail.stage3) {
-      reduce_jobs_block<WTHREADS>(tail.t, tb - tail.stage3, reinterpret_cast<float(*)[33]>(smem));
-    } else if (threadIdx.x < M2_THREADS) {       // (the tail's stage-3 workgroups come first: the longest chain of the trailing blocks)
-      if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(side.w.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tail.gate_want && ++spins < WG_GATE_SPINS)
-          __builtin_amdgcn_s_sleep(4);
-      }
-      __syncthreads();                           // (what stage 3 reads of stage 2 - dQ - it reads past the caches: mca2_side.hpp)
-      merge2_side_stage(3, tb, reinterpret_cast<float*>(smem), side);
-    }
-    return;
-  }
+  if (wg_rider_block(smem, side_blocks, side, tail)) return;
   const unsigned bx = blockIdx.x - (unsigned)side_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef WG_PROF                                                  // shader cycles: entry -> loop, loop, epilogue (tools/exp_wgrad.py WG_PROF=1)
@@ -789,12 +795,118 @@ __global__ __launch_bounds__(PP_THREADS) void bag_wgrad_pp_kernel(WgradArgs g, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// BOTH operands as images (round 4).  The kernels above read X raw and split it on its way into LDS: four E-side tiles do that work for
+// every X element, and it is half of the loop (stamped: the consumers alone and the producers alone take the same time).  Here the bag
+// has been laid down ONCE as the D-side operand image (prep job kind 9: per 32-row k-step and 256-column block one 32 KiB tile, byte for
+// byte the LDS stage of the kernels above), by workgroups that ride in a launch of the forward that leaves the chip idle, and dPRE^T's
+// image is in BAG order (rows that did not take part: zeros) - so a k-step is 48 KiB of linear LDS-DMA, nothing goes through registers,
+// every wave only reads fragments and multiplies.  8 waves as 2 x 4 of 64 x 64 (bag_wgrad_kernel's consumer schedule: the hi*lo term of
+// tile t-1 under the first fragment reads of tile t), 3 stages of [A 16 KiB | B 32 KiB]: tile t+2 is requested when tile t-1 retires.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int DNS = 3, DSTAGE = WA_BYTES + WB_BYTES, DRING = DNS * DSTAGE;                        // 144 KiB
+
+__global__ __launch_bounds__(WTHREADS) void bag_wgrad_dma_kernel(WgradArgs g, const char* ximg, int side_blocks, Merge2Side side, WgradTail tail) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (wg_rider_block(smem, side_blocks, side, tail)) return;
+  const unsigned bx = blockIdx.x - (unsigned)side_blocks;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nJ = (int)(g.D / WBN), nIT = (int)(g.E / WBI), nT = nIT * nJ;
+  const int xcd = bx & 7, sidx = bx >> 3;
+  const int slab = (sidx / nT) * 8 + xcd, tile = sidx % nT;
+  if (slab >= g.splits) return;
+  const int itile = tile / nJ, jtile = tile % nJ;
+  const int64_t i0 = (int64_t)itile * WBI, n0 = (int64_t)jtile * WBN;
+  const int ks0 = slab * g.kps;
+  const int nk = (ks0 + g.kps < g.ksteps ? ks0 + g.kps : g.ksteps) - ks0;
+
+  // a k-step: 16 KiB of dPRE^T + 32 KiB of X, 6 x 16 B per thread.  `live` false: the pieces come from ONE address and land in a stage nobody
+  // reads any more, so that every iteration has the same VMEM count and the vmcnt waits need no branch.
+  const char* abase = g.img + ((int64_t)ks0 * nIT + itile) * WA_BYTES + tid * 16;
+  const char* bbase = ximg + ((int64_t)ks0 * nJ + jtile) * WB_BYTES + tid * 16;
+  auto issue = [&](int t, bool live) {
+    char* sa = smem + (t % DNS) * DSTAGE + wave * 1024;
+    const char* a = live ? abase + (int64_t)t * nIT * WA_BYTES : g.img;
+    const char* b = live ? bbase + (int64_t)t * nJ * WB_BYTES : g.img;
+    __builtin_amdgcn_global_load_lds((gptr_f)a, (lptr_f)sa, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_f)(live ? a + 8192 : a), (lptr_f)(sa + 8192), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds((gptr_f)(live ? b + j * 8192 : b), (lptr_f)(sa + WA_BYTES + j * 8192), 16, 0, 0);
+  };
+  issue(0, true);
+  issue(1, nk > 1);
+
+  const int r16 = lane & 15, kg = lane >> 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+  const unsigned fa_hi = lds0 + ((kg * 2) * 128 + 16 * wm + r16) * 16, fa_lo = fa_hi + 2048;
+  const unsigned fb_hi = lds0 + WA_BYTES + ((kg * 2) * 256 + 16 * wn + r16) * 16, fb_lo = fb_hi + 4096;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 x[WNF];
+#if defined(WGD_NOREAD) || defined(WGD_HALFREAD)
+  for (int q = 0; q < WNF; ++q) x[q] = f32x4{1.f, 2.f, 3.f, 4.f};
+#endif
+#pragma unroll 1
+  for (int t = 0; t < nk; ++t) {
+#ifndef WGD_NODMA
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // my pieces of tile t have landed (tile t+1's six may be in flight)
+#endif
+    __builtin_amdgcn_s_barrier();                              // ... and everybody's; every wave is past its reads of tile t-1
+    const unsigned so = (unsigned)((t % DNS) * DSTAGE);
+#ifndef WGD_NODMA
+    issue(t + 2, t + 2 < nk);                                  // -> the stage of tile t-1
+#endif
+#ifndef WGD_NOREAD
+    WG_READ8(x, 4, 8, fa_lo + so, fb_hi + so);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WGD_NOMMA
+    if (t > 0) wg_term(x, 0, 12, acc);                         // hi*lo of tile t-1 (operands still in registers)
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WGD_NOREAD
+    WG_WAIT8(0, x, 4, 8);
+#ifndef WGD_HALFREAD
+    WG_READ8(x, 0, 12, fa_hi + so, fb_lo + so);
+#endif
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WGD_NOMMA
+    wg_term(x, 4, 8, acc);                                     // lo*hi
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WGD_NOREAD
+    WG_WAIT8(0, x, 0, 12);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WGD_NOMMA
+    wg_term(x, 0, 8, acc);                                     // hi*hi
+#endif
+  }
+  wg_term(x, 0, 12, acc);                                      // hi*lo of the last tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the last dummy pieces: nothing may land after the workgroup's LDS is handed on)
+  float* out = g.out + (int64_t)slab * g.E * g.D;
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i0 + 4 * (16 * wm + 4 * kg + e) + ja;
+      const int64_t n = n0 + 4 * (16 * wn + r16);
+      *reinterpret_cast<f32x4*>(out + i * g.D + n) = f32x4{acc[ja][0][e], acc[ja][1][e], acc[ja][2][e], acc[ja][3][e]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // dPRE -> matrix-core image + column-sum partials.  One workgroup per (32-row k-step, 256 columns); thread -> (4 columns, one row
 // octet): 8 x (16 B of dH + 8 B of dact16) in flight per thread, ~10 waves per CU.
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __restrict__ dH, const _Float16* __restrict__ dact,
                                                              const int64_t* __restrict__ rows, int64_t L, int E, char* __restrict__ img,
-                                                             float* __restrict__ part, int side_blocks, Merge2Side side, int dh_compact) {
+                                                             float* __restrict__ part, int side_blocks, Merge2Side side, int dh_compact,
+                                                             const uint8_t* __restrict__ keep) {
   __shared__ __attribute__((aligned(16))) float lds[M2_PARTIALS_LDS > 3 * 256 * 4 ? M2_PARTIALS_LDS : 3 * 256 * 4];
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 1), its workgroups first
     merge2_side_stage(1, (int)blockIdx.x, lds, side);
@@ -815,6 +927,7 @@ __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __res
     for (int q = 0; q < 8; ++q) {
       const int64_t l = (int64_t)ks * WBK + koct * 8 + q;
       r[q] = l < L ? (rows ? rows[l] : l) : -1;
+      if (keep && l < L && !keep[l]) r[q] = -1;                 // bag order: a row that did not take part is a zero row of the image
     }
     f32x4 gv[8];
     h4v dv[8];
@@ -883,7 +996,8 @@ extern "C" int64_t mhimx_wgrad_ws_floats(int64_t L, int64_t E, int64_t D) {
 }
 
 static int rows_dpre_image_impl(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
-                                float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer, int dh_compact) {
+                                float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer, int dh_compact,
+                                const uint8_t* keep = nullptr) {
   MHIMX_CHECK_ARG(dH && img && L >= 1 && E >= WBI && E % WBI == 0 && aligned16(dH) && aligned16(img) &&
                       (reinterpret_cast<uintptr_t>(dact16) & 7) == 0,
                   "rows_dpre_image: E must be a multiple of 128, buffers aligned");
@@ -897,7 +1011,7 @@ static int rows_dpre_image_impl(void* stream, const float* dH, const void* dact1
     defer->side.pending = 2;
   }
   hipLaunchKernelGGL(rows_dpre_image_kernel, dim3((unsigned)(ksteps * ncb + side_blocks)), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16,
-                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side, dh_compact);
+                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side, dh_compact, keep);
   MHIMX_LAUNCH_CHECK();
   if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
     const int rc = reduce_parts_now((hipStream_t)stream, (const float*)ws, nblk, E, E, colsum_out, accumulate);
@@ -909,6 +1023,10 @@ static int rows_dpre_image_impl(void* stream, const float* dH, const void* dact1
 extern "C" int mhimx_rows_dpre_image(void* stream, const float* dH, const void* dact16, const int64_t* rows, int64_t L, int64_t E, void* img,
                                      float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
   return rows_dpre_image_impl(stream, dH, dact16, rows, L, E, img, colsum_out, accumulate, ws, ws_bytes, defer, 0);
+}
+extern "C" int mhimx_rows_dpre_image_k(void* stream, const float* dH, const void* dact16, const uint8_t* keep, int64_t N, int64_t E, void* img,
+                                       float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
+  return rows_dpre_image_impl(stream, dH, dact16, nullptr, N, E, img, colsum_out, accumulate, ws, ws_bytes, defer, 0, keep);
 }
 extern "C" int mhimx_rows_dpre_image_c(void* stream, const float* dH_compact, const void* dact16, const int64_t* rows, int64_t L, int64_t E,
                                        void* img, float* colsum_out, int32_t accumulate, void* ws, int64_t ws_bytes, mhimx_reduce_list* defer) {
@@ -974,7 +1092,9 @@ static int bag_wgrad_impl(void* stream, const mhimx_bag_wgrad_args* bags, int n_
   static const bool ws_form = getenv("MHIMX_WGRAD_UNIFORM") == nullptr;
   static const bool pp_form = ws_form && getenv("MHIMX_WGRAD_PP") != nullptr;
   WgradTail tail = {};
-  if (a->ride_tail && defer && ws_form && !pp_form && n_bags == 1 && (defer->n > 0 || defer->side.pending == 3)) {
+  MHIMX_CHECK_ARG(!a->ximg || (n_bags == 1 && !a->rows && aligned16(a->ximg) && a->L == a->n_bag_rows),
+                  "bag_wgrad: the bag image (ximg) goes with a bag-ordered dPRE image: one bag, no row list, L = n_bag_rows");
+  if (a->ride_tail && defer && ((ws_form && !pp_form) || a->ximg) && n_bags == 1 && (defer->n > 0 || defer->side.pending == 3)) {
     // the reductions queued so far and (behind the stage-2 gate) the tail's last stage: trailing workgroups of this launch
     for (int i = 0; i < defer->n; ++i) {
       const mhimx_reduce_job& j = defer->j[i];
@@ -1001,7 +1121,10 @@ static int bag_wgrad_impl(void* stream, const mhimx_bag_wgrad_args* bags, int n_
   // ~13 us of the launch are the row table, the first tiles and the 33 MB of slab stores, outside the loop either form pipelines), so the
   // round-2 kernel stays the default; MHIMX_WGRAD_PP=1 selects the ping-pong form, MHIMX_WGRAD_UNIFORM=1 the uniform one.
   MHIMX_CHECK_ARG(n_bags == 1 || (ws_form && !pp_form), "bag_wgrad_multi: only the default (specialised-wave) kernel takes several bags");
-  if (pp_form) {
+  if (a->ximg) {                                               // both operands as images: nothing but linear DMA and fragments in the loop
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DRING)));
+    hipLaunchKernelGGL(bag_wgrad_dma_kernel, grid, dim3(WTHREADS), DRING, (hipStream_t)stream, g, (const char*)a->ximg, side_blocks, side, tail);
+  } else if (pp_form) {
     const size_t smem2 = SRING + (size_t)g.kps * WBK * 4;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_wgrad_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SRING + W_MAX_CHUNK * 4)));
     hipLaunchKernelGGL(bag_wgrad_pp_kernel, grid, dim3(PP_THREADS), smem2, (hipStream_t)stream, g, side_blocks, side);

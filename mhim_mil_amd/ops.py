@@ -170,7 +170,7 @@ def bag_project(x, heads, act=0, drop_tick=None, extra_rows=0, score0=None, keep
     return heads
 
 
-PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE, PREP_PAIR_T, PREP_FRAG16 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+PREP_TRANSPOSE, PREP_PAIR, PREP_COPY, PREP_TICK, PREP_FRAG, PREP_FRAG_T, PREP_MERGE, PREP_PAIR_T, PREP_FRAG16, PREP_XIMG = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def _prep_array(jobs):
@@ -613,8 +613,18 @@ def bag_wgrad_ok(x, E, n_rows):
             and x.shape[0] * x.stride(0) * 4 < (1 << 32))
 
 
+def bag_ximage_floats(x):
+    """Floats of the bag's weight-gradient operand image (prep job PREP_XIMG of x [N, D])."""
+    return -(-x.shape[0] // 32) * 32 * x.shape[1]
+
+
+def bag_wgrad_ximg_ok(x, E):
+    """Shapes the all-image weight-gradient product takes (bag_wgrad(ximg=)): contiguous rows, D % 256 == 0, E % 128 == 0."""
+    return x.dim() == 2 and x.is_contiguous() and x.shape[1] % 256 == 0 and E % 128 == 0
+
+
 def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=False, defer=None, rows_dh="same", want_bias=True,
-              dh_compact=False, ride_tail=False):
+              dh_compact=False, ride_tail=False, ximg=None, keep=None):
     """The projection's weight and bias gradient from the bag-ordered buffers:
     dPre[p] = dH[rows[p]] * dact16[rows[p]],  out_b (+)= sum_p dPre[p],  out_w [E,D] (+)= dPre^T x[rows]   (p < n_rows)
     — mhimx_rows_dpre_image (dPre as a bf16 hi/lo matrix-core image) + mhimx_bag_wgrad.
@@ -625,6 +635,30 @@ def bag_wgrad(dH, dact16, x, rows, n_rows, out_w=None, out_b=None, accumulate=Fa
     _chk(dH, name="dH"); _chk(dact16, torch.float16, "dact16"); _chk(rows, torch.int64, "rows")
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise L.MhimxError("x: expected a GPU fp32 matrix with contiguous rows")
+    if ximg is not None:
+        # both operands as images (mhimx_bag_wgrad_args.ximg): the k dimension runs over the bag's rows in memory order, `keep` (uint8 [N])
+        # says which of them took part (rows / n_rows are not used)
+        _chk(ximg, name="ximg"); _chk(keep, torch.uint8, "keep")
+        N, E, D = x.shape[0], dH.shape[1], x.shape[1]
+        if not bag_wgrad_ximg_ok(x, E) or ximg.numel() < bag_ximage_floats(x) or (keep is not None and keep.numel() < N):
+            raise L.MhimxError("bag_wgrad(ximg=): contiguous bag, D % 256 == 0, E % 128 == 0, image / keep flags of the bag's size")
+        dev, lib = dH.device, L.lib()
+        if out_w is None:
+            out_w = torch.empty((E, D), device=dev)
+        if out_b is None and want_bias:
+            out_b = torch.empty(E, device=dev)
+        img = torch.empty(lib.mhimx_wgrad_image_bytes(N, E) // 4, device=dev)
+        ws_b = torch.empty(-(-N // 32) * E, device=dev) if want_bias else None
+        L.check(lib.mhimx_rows_dpre_image_k(_stream(), _p(dH), _p(dact16), _p(keep), N, E, _p(img), _p(out_b) if want_bias else None,
+                                            int(bool(accumulate)), _p(ws_b), ws_b.numel() * 4 if want_bias else 0, _dp(defer)), "mhimx_rows_dpre_image_k")
+        ws = torch.empty(lib.mhimx_wgrad_ws_floats(N, E, D), device=dev)
+        g = L.BagWgrad(img=_p(img), X=_p(x), ldx=x.stride(0), n_bag_rows=N, rows=None, L=N, E=E, D=D, C=_p(out_w), ldc=out_w.stride(0),
+                       accumulate=int(bool(accumulate)), ws=_p(ws), ws_floats=ws.numel(), defer=_dp(defer),
+                       ride_tail=int(bool(ride_tail and defer is not None)), ximg=_p(ximg))
+        L.check(lib.mhimx_bag_wgrad(_stream(), C.byref(g)), "mhimx_bag_wgrad")
+        if defer is not None:
+            defer.keep.extend((ws_b, ws, img))
+        return out_w, out_b
     rows_h = rows if isinstance(rows_dh, str) else rows_dh
     _chk(rows_h, torch.int64, "rows_dh")
     E, D = dH.shape[1], x.shape[1]

@@ -56,3 +56,9 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
     import pytest
     with pytest.raises(RuntimeError, match="ABI version"):
         L.lib()
+
+
+def test_graft_entry_build_passes():
+    """The driver's build check: compiles (or finds) the library, loads it, checks the ABI version and imports the package."""
+    import __graft_entry__ as g
+    g.build()

@@ -42,9 +42,33 @@ def old():
     ops.gemm_tn(dpre, x, out=ow, rows=rows, splits=8, prec="bf16x3", M=L_)
 
 
-which = sys.argv[1:] or ["image", "wgrad", "old", "image", "wgrad"]
+keep = torch.zeros(N, dtype=torch.uint8, device="cuda"); keep[rows] = 1
+ximg = torch.empty(ops.bag_ximage_floats(x), device="cuda")
+img2 = torch.zeros(lib.mhimx_wgrad_image_bytes(N, E) // 4, device="cuda")
+ws2 = torch.empty(lib.mhimx_wgrad_ws_floats(N, E, D), device="cuda")
+g2 = L.BagWgrad(img=img2.data_ptr(), X=x.data_ptr(), ldx=D, n_bag_rows=N, rows=None, L=N, E=E, D=D, C=ow.data_ptr(), ldc=D,
+                accumulate=0, ws=ws2.data_ptr(), ws_floats=ws2.numel(), defer=None, ximg=ximg.data_ptr())
+
+
+def ximage():
+    ops.prep_batch([(ops.PREP_XIMG, x, ximg)])
+
+
+def image_k():
+    lst.c.n = 0
+    L.check(lib.mhimx_rows_dpre_image_k(None, dH.data_ptr(), dact.data_ptr(), keep.data_ptr(), N, E, img2.data_ptr(), ob.data_ptr(), 0,
+                                        ws_b.data_ptr(), ws_b.numel() * 4, lst.ptr()), "image_k")
+
+
+def wgrad_dma():
+    lst.c.n = 0
+    g2.defer = lst.ptr()
+    L.check(lib.mhimx_bag_wgrad(None, C.byref(g2)), "wgrad_dma")
+
+
+which = sys.argv[1:] or ["image", "wgrad", "ximage", "image_k", "wgrad_dma", "image", "wgrad", "wgrad_dma"]
 for name in which:
-    fn = {"image": image, "wgrad": wgrad, "old": old}[name]
+    fn = {"image": image, "wgrad": wgrad, "old": old, "ximage": ximage, "image_k": image_k, "wgrad_dma": wgrad_dma}[name]
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
