@@ -50,10 +50,12 @@ def _halo_rows(comm, block):
 
 
 class ShardedTransLayerFn(torch.autograd.Function):
-    """y_r = x_r + to_out(Nystrom(to_qkv(LayerNorm(x))))_r for this rank's token block (no dropout: eval-mode attention)."""
+    """y_r = x_r + dropout(to_out(Nystrom(to_qkv(LayerNorm(x)))))_r for this rank's token block.  drop_p / seed: to_out's dropout
+    (nystrom_attention.py:60-63) from the counter stream keyed by (seed, LOCAL element index) - give every rank its own seed.  need_attn:
+    also returns the cls token's attention row over THIS block's tokens [8, Tr] (nystrom:143-150) and the block's v rows [Tr, 512]."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, conv_w, scale, comm, pad=0):
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, conv_w, scale, comm, pad=0, drop_p=0.0, seed=0, need_attn=False):
         lib = L.lib()
         x = x.contiguous()
         Tr, E = x.shape
@@ -90,25 +92,46 @@ class ShardedTransLayerFn(torch.autograd.Function):
         L.check(lib.mhimx_resconv(NY._st(), NY._ptr(v_ext), INNER, NY._ptr(wc), KS, DH, Tr + 2 * HALO, INNER, NY._ptr(conv), INNER, 0, 0), "resconv")
         mid = conv[HALO:HALO + Tr]
         L.check(lib.mhimx_axpby(NY._st(), NY._ptr(mid), NY._ptr(out), out.numel(), 1.0, 1.0), "axpby")      # out += res_conv(v) (nystrom:135-136)
-        y = ops.gemm_nt(out, w_out, bias=b_out, prec=NY._PREC)
+        y = ops.gemm_nt(out, w_out, bias=b_out, drop_p=float(drop_p), drop_seed=int(seed), prec=NY._PREC)
         L.check(lib.mhimx_axpby(NY._st(), NY._ptr(x), NY._ptr(y), y.numel(), 1.0, 1.0), "axpby")            # y += x
         ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, v_ext)
-        ctx.cfg = (l, gl, scale, comm, conv_w.shape, npad)
-        return y
+        ctx.cfg = (l, gl, scale, comm, conv_w.shape, npad, float(drop_p), int(seed))
+        if not need_attn:
+            return y
+        # the cls token's attention row (nystrom:143-150) = (attn1[cls] pinv) attn3: the owner of the cls row forms u = softmax(q_cls k~^T) z
+        # [8, 256], everybody gets it (a sum against zeros), and attn3's columns of the local tokens need the global lse3 only
+        g0 = comm.rank * Tr
+        u = torch.zeros((HEADS, M), device=dev)
+        if g0 <= pad < g0 + Tr:
+            a1c = torch.empty((HEADS, 1, M), device=dev)
+            NY._heads_mm("nt", NY.Op(qkv, (pad - g0) * ld, DH, ld, 1, DH), NY.Op(lm, INNER, DH, 2 * INNER, M, DH), NY.batched(a1c), HEADS)
+            L.check(lib.mhimx_softmax_rows(NY._st(), NY._ptr(a1c), NY._ptr(a1c), HEADS, M, float(scale)), "softmax_rows")
+            u3 = torch.empty((HEADS, 1, M), device=dev)
+            NY._heads_mm("nn", NY.batched(a1c), NY.batched(z), NY.batched(u3), HEADS)
+            u.copy_(u3.view(HEADS, M))
+        comm.all_reduce_sum(u)
+        attn = ops.nys_cls_attn(ops.NysOperands(qkv, lm, scale), lse3, u.contiguous())  # [8, Tr] (a workspace of its own: the backward keeps no.ws)
+        v = qkv[:, 2 * INNER:]
+        ctx.mark_non_differentiable(attn, v)
+        return y, attn, v
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         lib = L.lib()
         x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, v_ext = ctx.saved
         ctx.saved = None
-        l, gl, scale, comm, wshape, npad = ctx.cfg
+        l, gl, scale, comm, wshape, npad, drop_p, seed = ctx.cfg
         dy = dy.contiguous()
         Tr, E = x.shape
         dev, ld = x.device, qkv.shape[1]
+        g = dy
+        if drop_p > 0:                          # the forward's mask again (the stream of the kernel that drew it)
+            g = torch.empty_like(dy)
+            L.check(lib.mhimx_dropout_apply(NY._st(), NY._ptr(dy), NY._ptr(g), Tr, E, drop_p, seed & 0xFFFFFFFFFFFFFFFF, None), "dropout_apply")
         dout = torch.empty((Tr, INNER), device=dev)
-        NY._gemm("nn", dy, 0, E, w_out, 0, INNER, dout, 0, INNER, Tr, INNER, E)
-        dw_out = ops.gemm_tn(dy, out, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
-        db_out = ops.colsum(dy)
+        NY._gemm("nn", g, 0, E, w_out, 0, INNER, dout, 0, INNER, Tr, INNER, E)
+        dw_out = ops.gemm_tn(g, out, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
+        db_out = ops.colsum(g)
         dqkv = torch.empty_like(qkv)
         # residual convolution: dv = flip-conv(dout) with dout's halo rows; its weight gradient from the local outputs against v with halos
         g_ext = _halo_rows(comm, dout)
@@ -144,16 +167,16 @@ class ShardedTransLayerFn(torch.autograd.Function):
         wsl = torch.empty(2 * 512 * E, device=dev)
         L.check(lib.mhimx_layernorm_bwd_res(NY._st(), NY._ptr(dxn), NY._ptr(x), Tr, E, NY._ptr(ln_w), NY._ptr(mean), NY._ptr(rstd), NY._ptr(dy),
                                             NY._ptr(dx), NY._ptr(dlw), NY._ptr(dlb), 0, NY._ptr(wsl)), "layernorm_bwd_res")
-        return dx, dlw, dlb, dw_qkv, dw_out, db_out, dwc.reshape(wshape), None, None, None
+        return dx, dlw, dlb, dw_qkv, dw_out, db_out, dwc.reshape(wshape), None, None, None, None, None, None
 
 
-def sharded_trans_layer(layer: "NY.TransLayer", x_local, comm=None, pad=0):
+def sharded_trans_layer(layer: "NY.TransLayer", x_local, comm=None, pad=0, drop_p=0.0, seed=0, need_attn=False):
     """``layer`` (nystrom.TransLayer: the reference's parameter names) applied to this rank's token block of a sharded sequence whose
     first ``pad`` rows (global indices) are the front zero padding of nystrom_attention.py:70-73."""
     comm = comm if comm is not None else _Comm()
     a = layer.attn
     return ShardedTransLayerFn.apply(x_local, layer.norm.weight, layer.norm.bias, a.to_qkv.weight, a.to_out[0].weight, a.to_out[0].bias,
-                                     a.res_conv.weight, a.scale, comm, pad)
+                                     a.res_conv.weight, a.scale, comm, pad, drop_p, seed, need_attn)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -193,7 +216,7 @@ class _OwnerRow(torch.autograd.Function):
         return dx, None, None
 
 
-def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None):
+def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None, return_attn=False, seeds=(0, 0), training=False):
     """mhim_modules/baseline.SAttention (cls token, TransLayer, PPEG, TransLayer, LayerNorm of the cls row: baseline.py:222-288) on a
     sequence sharded over the ranks.  h_local: this rank's block of the PADDED token sequence [zeros(pad) | cls slot | n - 1 token rows]
     (T = pad + n, T % 256 == 0; the cls slot's content is ignored).  Returns the cls feature [512] on every rank.
@@ -206,14 +229,26 @@ def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None):
     if g0 <= pad < g0 + Tr:                                                  # the cls token's row lives here (baseline.py:253-255)
         i = pad - g0
         x = torch.cat([h_local[:i], enc.cls_token.view(1, -1), h_local[i + 1:]], 0)
-    x = sharded_trans_layer(enc.layer1, x, comm, pad)
+    p1 = enc.layer1.attn.dropout if training else 0.0
+    p2 = enc.layer2.attn.dropout if training else 0.0
+    attn, v = [], None
+    if return_attn:
+        x, a, v = sharded_trans_layer(enc.layer1, x, comm, pad, p1, seeds[0], True)
+        attn.append(a)
+    else:
+        x = sharded_trans_layer(enc.layer1, x, comm, pad, p1, seeds[0])
     full = _GatherRows.apply(x, comm)                                        # baseline.py:265-266: cat([cls, ppeg(tokens)])
     full = enc.pos_embedding(full, skip=pad + 1)                             # rows [0, pad] pass through; the stencil sees the n - 1 tokens
     x = full[g0:g0 + Tr]
-    x = sharded_trans_layer(enc.layer2, x, comm, pad)
+    if return_attn:
+        x, a, _ = sharded_trans_layer(enc.layer2, x, comm, pad, p2, seeds[1], True)
+        attn.append(a)
+    else:
+        x = sharded_trans_layer(enc.layer2, x, comm, pad, p2, seeds[1])
     row = _OwnerRow.apply(x, pad, comm)
     # only the cls row is used (baseline.py:276-278).  The final LayerNorm runs replicated: its parameter gradient is counted ONCE, on the
     # rank that owns the cls row (the others see constants), so that the flat-gradient SUM over the ranks is the gradient
     own = g0 <= pad < g0 + Tr
     w, b = (enc.norm.weight, enc.norm.bias) if own else (enc.norm.weight.detach(), enc.norm.bias.detach())
-    return NY.LayerNorm.apply(row, w, b)[0]
+    z = NY.LayerNorm.apply(row, w, b)[0]
+    return (z, attn, v) if return_attn else z                      # attn: per layer [8, Tr] over THIS block's rows (global row pad + 1 + j = token j)

@@ -97,13 +97,13 @@ def partition_rows(rows, Lk, lo, n):
 
 
 class ShardedBagTrainer:
-    """Train step of MHIM(ABMIL) on ONE bag whose rows are split across the ranks of ``group``."""
+    """Train step of MHIM(ABMIL) - or MHIM(TransMIL): sharded_transmil.py - on ONE bag whose rows are split across the ranks of ``group``."""
 
     def __init__(self, student: MHIM, teacher: MHIM, counts=None, group=None, seed=0, lr=2e-4, weight_decay=1e-5,
                  betas=(0.9, 0.999), eps=1e-8, mm=0.9997, main_alpha=1.0, aux_alpha=0.5):
-        if student.baseline != "attn":
-            raise NotImplementedError("instance sharding is built for the ABMIL encoder; Nystrom bags are replicas only "
-                                      "(SURVEY.md §8(e))")
+        if student.baseline not in ("attn", "selfattn") or teacher.baseline != student.baseline:
+            raise NotImplementedError("instance sharding is built for the ABMIL and the TransMIL (Nystrom) encoders, teacher and student alike "
+                                      "(SURVEY.md §8(e)); DSMIL bags are replicas only")
         self.s, self.t = student, teacher
         # this trainer's kernels take their dropout stream position from the by-value seeds alone: a device tick left behind by
         # a FusedTrainer that held these models earlier would enter the forward's seed but not the backward's
@@ -154,6 +154,9 @@ class ShardedBagTrainer:
 
     def train_step(self, x_local, label, perm=None, ids_shuffle=None, i=None):
         """x_local [n_r, D]: this rank's rows (rank order = row order of the bag).  Returns (logits [C], losses [3])."""
+        if self.s.baseline == "selfattn":              # TransMIL: re-balancing exchange + sequence-parallel encoder (sharded_transmil.py)
+            from .sharded_transmil import transmil_step
+            return transmil_step(self, x_local, label, perm, ids_shuffle, i)
         if self.fixed_shape_ok(x_local) and self.s.v2_counts(self._bag_rows(x_local), i) is not None:
             return self._step_fixed(x_local, label, perm, ids_shuffle, i)
         return self._step_generic(x_local, label, perm, ids_shuffle, i)

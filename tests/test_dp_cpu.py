@@ -223,3 +223,50 @@ def test_cosine_scheduler_matches_reference_fixture():
     for i, (base, final, ep, nit, warm, start) in enumerate(meta["cases"]):
         got = cosine_scheduler(base, final, epochs=ep, niter_per_ep=nit, warmup_epochs=warm, start_warmup_value=start)
         np.testing.assert_allclose(got, a[f"c{i}"], rtol=0, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------- sharded TransMIL: the re-balancing exchange
+def _exchange_case():
+    """A bag of 1000 rows over two shards [0, 600) | [600, 1000); 300 kept rows in shuffled token order; 5 tail tokens."""
+    ids = torch.from_numpy(synth.permutation(3, 1000)[:300].astype(np.int64))
+    rows = torch.from_numpy(synth.normal(5, (1000, 8), std=1.0).astype(np.float32))       # "feature rows" of the whole bag
+    tail = torch.from_numpy(synth.normal(6, (5, 8), std=1.0).astype(np.float32))
+    g = torch.from_numpy(synth.normal(7, (512, 8), std=1.0).astype(np.float32))           # d block of the whole sequence (T = 512)
+    return ids, rows, tail, g, [0, 600, 1000]
+
+
+def _exchange_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from mhim_mil_amd.sharded import _Comm
+    from mhim_mil_amd.sharded_transmil import ExchangePlan, _AssembleTokens, seq_layout
+    ids, rows, tail, g, bounds = _exchange_case()
+    pad, T, Tr = seq_layout(300 + 5, WORLD)
+    plan = ExchangePlan(ids, bounds, pad, Tr, _Comm())
+    mine = rows[ids[plan.local]].clone().requires_grad_()            # my kept rows in ascending token order
+    tl = tail.clone().requires_grad_()
+    blk = _AssembleTokens.apply(mine, tl, plan, pad + 1 + 300)
+    blk.backward(g[rank * Tr:(rank + 1) * Tr])
+    torch.save({"blk": blk.detach(), "drows": mine.grad, "dtail": tl.grad, "local": plan.local, "pad": pad, "T": T}, os.path.join(out, f"x{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_transmil_token_exchange_two_ranks(tmp_path):
+    """sharded_transmil._AssembleTokens over gloo: the ranks' blocks are the sequence [zeros(pad) | cls slot | kept rows in token order |
+    tail]; the backward returns each row's gradient to its owner and the tail's gradient (summed over its owners) to everybody."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"x{r}.pt")) for r in range(WORLD)]
+    ids, rows, tail, g, bounds = _exchange_case()
+    pad, T = res[0]["pad"], res[0]["T"]
+    seq = torch.cat([r["blk"] for r in res])
+    assert seq.shape[0] == T == 512 and pad == 512 - 306
+    assert float(seq[:pad + 1].abs().max()) == 0.0
+    assert torch.equal(seq[pad + 1:pad + 301], rows[ids]) and torch.equal(seq[pad + 301:], tail)
+    for r in range(WORLD):
+        loc = res[r]["local"]
+        assert bool(((ids[loc] >= bounds[r]) & (ids[loc] < bounds[r + 1])).all())
+        assert torch.equal(res[r]["drows"], g[pad + 1 + loc])
+        assert torch.equal(res[r]["dtail"], g[pad + 301:])
+    assert sum(r["local"].numel() for r in res) == 300

@@ -31,6 +31,17 @@ def B_():
     buf.finalize(bp)
 def P_():
     ops.bag_project(x, hA, act=act, drop_tick=tick)
+xs = [torch.from_numpy(synth.bag(5200 + j, n, d)).to(DEV) for j in range(8)]
+cnt = [0]
+def PC_():                                   # a different (cold) bag per launch
+    cnt[0] += 1
+    ops.bag_project(xs[cnt[0] % 8], hA, act=act, drop_tick=tick)
+scrub = torch.empty(96 << 20, device=DEV)    # 384 MB
+def PS_():                                   # the same bag, 384 MB of other traffic in between
+    scrub.add_(1.0)
+    ops.bag_project(x, hA, act=act, drop_tick=tick)
+def S_():
+    scrub.add_(1.0)
 def time(fn, name):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -51,5 +62,8 @@ def time(fn, name):
     print(f"{name}: {best:.1f} us")
 for _ in range(2):
     time(P_, "projection only (2 heads)")
+    time(PC_, "projection, rotating bags")
+    time(S_, "scrub only")
+    time(PS_, "scrub + projection")
     time(A_, "projection + one-pass scorer")
     time(B_, "scored projection + finalize")
