@@ -433,6 +433,20 @@ int mhimx_ppeg_fwd(void* stream, const float* x, int64_t N, int64_t C, const flo
 int64_t mhimx_ppeg_bwd_ws_floats(int64_t N, int64_t C);
 int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int64_t N, int64_t C, const float* wc, float* dx, float* dwc, float* dbc,
                    float* ws, int64_t grid);
+/* PPEG on a band of the token grid (the sequence-parallel encoder: every rank holds its own tokens' grid rows + three halo rows either
+ * side, emb_position.py:92-120).  side = mhimx_ppeg_side(N, &wrapN): the grid is side x side, cells [N, wrapN) repeat the first tokens
+ * (emb_position.py:100-103), cells past wrapN are zero.  The buffers hold the CELLS [cell0, cell0 + ncell) (cell0 % side == 0), wrap cells
+ * filled by the caller's exchange:
+ *   band_fwd   y[cell - out0] for cell in [out0, out1)  from xb                       (out1 <= N)
+ *   band_bwd   dx[cell - out0] for cell in [out0, out1) from dyb (dy of the band's cells; zero for cells >= N) - out1 may reach wrapN: the
+ *              wrap cells' gradient belongs to the first tokens (the caller sends it there); dwc [C,49] / dbc [C] = this band's partial sums
+ *              over its first n_dw produced cells (the ones that are outputs of the forward).  ws: mhimx_ppeg_band_bwd_ws_floats(out1 - out0, C). */
+typedef struct { int64_t H, cell0, ncell, out0, out1; } mhimx_ppeg_band;
+int64_t mhimx_ppeg_side(int64_t N, int64_t* wrapN);
+int mhimx_ppeg_band_fwd(void* stream, const float* xb, const mhimx_ppeg_band* band, int64_t C, const float* wc, const float* bc, float* y);
+int64_t mhimx_ppeg_band_bwd_ws_floats(int64_t n_out, int64_t C);
+int mhimx_ppeg_band_bwd(void* stream, const float* dyb, const float* xb, const mhimx_ppeg_band* band, int64_t n_dw, int64_t C, const float* wc,
+                        float* dx, float* dwc, float* dbc, float* ws);
 /* out[t,c] = v[t,c] * a[c/dh, t]   (scoring.py:25: per-head value x attention, heads interleaved as (h d)) */
 int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, const float* a, int64_t lda, int64_t dh, int64_t T, int64_t C, float* out);
 

@@ -61,6 +61,10 @@ class BagWgrad(C.Structure):
                 ("ws", c_f32p), ("ws_floats", C.c_int64), ("defer", C.c_void_p), ("ride_tail", C.c_int32), ("ximg", C.c_void_p)]
 
 
+class PpegBand(C.Structure):
+    _fields_ = [("H", C.c_int64), ("cell0", C.c_int64), ("ncell", C.c_int64), ("out0", C.c_int64), ("out1", C.c_int64)]
+
+
 class PrepJob(C.Structure):
     _fields_ = [("kind", C.c_int32), ("inp", C.c_void_p), ("out", C.c_void_p), ("R", C.c_int64), ("C", C.c_int64)]
 
@@ -266,6 +270,10 @@ SYMBOLS = {
     "mhimx_ppeg_fwd": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _I64]),
     "mhimx_ppeg_bwd_ws_floats": (_I64, [_I64, _I64]),
     "mhimx_ppeg_bwd": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I64]),
+    "mhimx_ppeg_side": (_I64, [_I64, _P]),
+    "mhimx_ppeg_band_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
+    "mhimx_ppeg_band_bwd_ws_floats": (_I64, [_I64, _I64]),
+    "mhimx_ppeg_band_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "mhimx_scale_heads": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
 }
 

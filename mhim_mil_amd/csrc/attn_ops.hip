@@ -1043,6 +1043,171 @@ extern "C" int mhimx_ppeg_bwd(void* stream, const float* dy, const float* x, int
   if (int r = transpose(st, dwc_t, dwc, 49, C)) return r;
   return attn_reduce(st, part_b, nblk, C, dbc);
 }
+// ------------------------------------------------------------------------------------------------
+// PPEG on a BAND of the token grid (sequence-parallel encoder, nystrom_sharded.py): a rank holds the grid cells [cell0, cell0 + ncell)
+// (whole grid rows: its own tokens' rows and three halo rows either side; the cells that wrap - the first side^2 - N tokens appended again,
+// emb_position.py:100-103 - filled in by the exchange, cells past them zero) and produces the cells [out0, out1).  The patch schedule of
+// ppeg_strip_kernel / ppeg_dw_strip_kernel with explicit buffers: the band IS the padded grid, no index wraps.
+// FLIP = 0: y[cell - out0] = bc + sum_tap wc[tap] xb[cell + tap];  FLIP = 1: dx[cell - out0] = sum_tap wc[flipped tap] dyb[cell + tap]
+// ------------------------------------------------------------------------------------------------
+struct PpegBand { int H; int row0, nrows; int64_t cell0, ncell, out0, out1; };
+template <int FLIP>
+__global__ __launch_bounds__(AT) void ppeg_band_strip_kernel(const float* __restrict__ in, PpegBand b, int C, const float* __restrict__ wc,
+                                                             const float* __restrict__ bc, float* __restrict__ out, int nsx, int prow0) {
+  const int c = blockIdx.y * AT + threadIdx.x;
+  if (c >= C) return;
+  const int H = b.H;
+  const int gy0 = prow0 + (blockIdx.x / nsx) * PSY, gx0 = (blockIdx.x % nsx) * PS;       // (global grid coordinates)
+  float w[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) w[i] = wc[c * 49 + i];
+  float acc[PSY][PS];
+  const float b0 = FLIP ? 0.f : bc[c];
+#pragma unroll
+  for (int jy = 0; jy < PSY; ++jy)
+#pragma unroll
+    for (int j = 0; j < PS; ++j) acc[jy][j] = b0;
+#pragma unroll
+  for (int r = 0; r < PSY + 6; ++r) {
+    const int yy = gy0 - 3 + r;
+    if (yy < 0 || yy >= H) continue;
+    float xin[PS + 6];
+#pragma unroll
+    for (int i = 0; i < PS + 6; ++i) {
+      const int xx = gx0 - 3 + i;
+      float val = 0.f;
+      if (xx >= 0 && xx < H) {
+        const int64_t cell = (int64_t)yy * H + xx - b.cell0;
+        if (cell >= 0 && cell < b.ncell) val = in[cell * C + c];
+      }
+      xin[i] = val;
+    }
+#pragma unroll
+    for (int jy = 0; jy < PSY; ++jy) {
+      const int dy = r - 3 - jy;
+      if (dy < -3 || dy > 3) continue;
+#pragma unroll
+      for (int j = 0; j < PS; ++j)
+#pragma unroll
+        for (int dx = -3; dx <= 3; ++dx) {
+          const int tap = FLIP ? (3 - dy) * 7 + (3 - dx) : (dy + 3) * 7 + (dx + 3);
+          acc[jy][j] = fmaf(w[tap], xin[j + dx + 3], acc[jy][j]);
+        }
+    }
+  }
+#pragma unroll
+  for (int jy = 0; jy < PSY; ++jy)
+#pragma unroll
+    for (int j = 0; j < PS; ++j) {
+      const int64_t cell = (int64_t)(gy0 + jy) * H + gx0 + j;
+      if (gy0 + jy < H && gx0 + j < H && cell >= b.out0 && cell < b.out1) out[(cell - b.out0) * C + c] = acc[jy][j];
+    }
+}
+// dwc / dbc partials over the produced cells [out0, out1): g = dyb at the cell, inputs from the band
+__global__ __launch_bounds__(AT) void ppeg_band_dw_kernel(const float* __restrict__ dyb, const float* __restrict__ xb, PpegBand b, int C, int nsx,
+                                                          int prow0, int npatch, int spb, float* __restrict__ part, float* __restrict__ part_b) {
+  const int c = blockIdx.y * AT + threadIdx.x;
+  if (c >= C) return;
+  const int H = b.H;
+  float acc[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) acc[i] = 0.f;
+  float ab = 0.f;
+  for (int s = blockIdx.x * spb; s < (int)(blockIdx.x + 1) * spb && s < npatch; ++s) {
+    const int gy0 = prow0 + (s / nsx) * PSY, gx0 = (s % nsx) * PS;
+    float g[PSY][PS];
+#pragma unroll
+    for (int jy = 0; jy < PSY; ++jy)
+#pragma unroll
+      for (int j = 0; j < PS; ++j) {
+        const int64_t cell = (int64_t)(gy0 + jy) * H + gx0 + j;
+        g[jy][j] = (gy0 + jy < H && gx0 + j < H && cell >= b.out0 && cell < b.out1) ? dyb[(cell - b.cell0) * C + c] : 0.f;
+        ab += g[jy][j];
+      }
+#pragma unroll
+    for (int r = 0; r < PSY + 6; ++r) {
+      const int yy = gy0 - 3 + r;
+      if (yy < 0 || yy >= H) continue;
+      float xin[PS + 6];
+#pragma unroll
+      for (int i = 0; i < PS + 6; ++i) {
+        const int xx = gx0 - 3 + i;
+        float val = 0.f;
+        if (xx >= 0 && xx < H) {
+          const int64_t cell = (int64_t)yy * H + xx - b.cell0;
+          if (cell >= 0 && cell < b.ncell) val = xb[cell * C + c];
+        }
+        xin[i] = val;
+      }
+#pragma unroll
+      for (int jy = 0; jy < PSY; ++jy) {
+        const int ddy = r - 3 - jy;
+        if (ddy < -3 || ddy > 3) continue;
+#pragma unroll
+        for (int j = 0; j < PS; ++j)
+#pragma unroll
+          for (int dx = -3; dx <= 3; ++dx) acc[(ddy + 3) * 7 + dx + 3] = fmaf(g[jy][j], xin[j + dx + 3], acc[(ddy + 3) * 7 + dx + 3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 49; ++i) part[((int64_t)blockIdx.x * 49 + i) * C + c] = acc[i];
+  part_b[(int64_t)blockIdx.x * C + c] = ab;
+}
+
+extern "C" int64_t mhimx_ppeg_side(int64_t N, int64_t* wrapN) {
+  int H; int64_t w;
+  ppeg_geom(N, 0, &H, &w);
+  if (wrapN) *wrapN = w;
+  return H;
+}
+static int ppeg_band_check(const mhimx_ppeg_band* b, PpegBand* o) {
+  MHIMX_CHECK_ARG(b && b->H >= 7 && b->H <= 32768 && b->cell0 >= 0 && b->cell0 % b->H == 0 && b->ncell > 0 && b->out0 >= b->cell0 &&
+                      b->out1 > b->out0 && b->out1 <= b->cell0 + b->ncell && b->out1 <= b->H * b->H,
+                  "ppeg_band: the band holds whole grid rows from cell0 and contains the cells it produces (side >= 7)");
+  o->H = (int)b->H; o->cell0 = b->cell0; o->ncell = b->ncell; o->out0 = b->out0; o->out1 = b->out1;
+  o->row0 = (int)(b->out0 / b->H);                                  // patch rows start at the first produced cell's row
+  o->nrows = (int)((b->out1 - 1) / b->H) - o->row0 + 1;
+  return 0;
+}
+extern "C" int mhimx_ppeg_band_fwd(void* stream, const float* xb, const mhimx_ppeg_band* band, int64_t C, const float* wc, const float* bc, float* y) {
+  MHIMX_CHECK_ARG(xb && wc && bc && y, "ppeg_band_fwd: null args");
+  PpegBand b;
+  if (int r = ppeg_band_check(band, &b)) return r;
+  const int nsx = (int)cdiv(b.H, PS);
+  hipLaunchKernelGGL(ppeg_band_strip_kernel<0>, dim3((unsigned)(nsx * cdiv(b.nrows, PSY)), (unsigned)cdiv(C, AT)), dim3(AT), 0, (hipStream_t)stream, xb, b,
+                     (int)C, wc, bc, y, nsx, b.row0);
+  MHIMX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int64_t mhimx_ppeg_band_bwd_ws_floats(int64_t n_out, int64_t C) { return cdiv(n_out, 64) * C * 50 + 49 * C; }
+extern "C" int mhimx_ppeg_band_bwd(void* stream, const float* dyb, const float* xb, const mhimx_ppeg_band* band, int64_t n_dw, int64_t C, const float* wc,
+                                   float* dx, float* dwc, float* dbc, float* ws) {
+  MHIMX_CHECK_ARG(dyb && xb && wc && dx && dwc && dbc && ws, "ppeg_band_bwd: null args");
+  PpegBand b;
+  if (int r = ppeg_band_check(band, &b)) return r;
+  MHIMX_CHECK_ARG(n_dw >= 1 && b.out0 + n_dw <= b.out1, "ppeg_band_bwd: the weight gradient runs over the first n_dw produced cells");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsx = (int)cdiv(b.H, PS);
+  hipLaunchKernelGGL(ppeg_band_strip_kernel<1>, dim3((unsigned)(nsx * cdiv(b.nrows, PSY)), (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dyb, b, (int)C, wc,
+                     (const float*)nullptr, dx, nsx, b.row0);
+  MHIMX_LAUNCH_CHECK();
+  PpegBand bw = b;                                                  // weight gradient: over the cells that ARE outputs of the forward
+  bw.out1 = b.out0 + n_dw;
+  bw.nrows = (int)((bw.out1 - 1) / b.H) - bw.row0 + 1;
+  const int nblk = (int)cdiv(b.out1 - b.out0, 64);
+  float* part = ws;
+  float* part_b = ws + (int64_t)nblk * C * 49;
+  float* dwc_t = part_b + (int64_t)nblk * C;
+  const int npatch = (int)cdiv(bw.nrows, PSY) * nsx;
+  const int spb = (int)cdiv(npatch, nblk);
+  hipLaunchKernelGGL(ppeg_band_dw_kernel, dim3((unsigned)nblk, (unsigned)cdiv(C, AT)), dim3(AT), 0, st, dyb, xb, bw, (int)C, nsx, bw.row0, npatch, spb,
+                     part, part_b);
+  MHIMX_LAUNCH_CHECK();
+  if (int r = attn_reduce(st, part, nblk, C * 49, dwc_t)) return r;
+  if (int r = transpose(st, dwc_t, dwc, 49, C)) return r;
+  return attn_reduce(st, part_b, nblk, C, dbc);
+}
 extern "C" int mhimx_scale_heads(void* stream, const float* v, int64_t ldv, const float* a, int64_t lda, int64_t dh, int64_t T, int64_t C,
                                  float* out) {
   MHIMX_CHECK_ARG(v && a && out && C % dh == 0, "scale_heads: bad args");

@@ -16,14 +16,16 @@ every rank owns 256/W WHOLE landmark groups - the caller re-balances ragged shar
             conv backward                16 halo rows of dout; the conv weight gradient is a local partial sum
 Parameter gradients leave as LOCAL partial sums (the data-parallel flat-gradient all-reduce adds them up, as for instance-sharded ABMIL).
 
-``sharded_sattention`` is the encoder level (cls token, front padding, the two layers, the PPEG between them - replicated on an
-all-gathered copy in this first cut, LayerNorm of the cls row).  Still open for a sharded MHIM(TransMIL) STEP: ragged shards of a masked
-bag (a validity bound in the kernels or a re-balancing all-to-all from the instance shards), the PPEG's 2-d halo instead of the replica.  All exchanges go through ``sharded._Comm`` (RCCL; gloo with host
-staging in the one-GPU tests).
+``sharded_sattention`` is the encoder level (cls token, front padding, the two layers, LayerNorm of the cls row) and the PPEG between the
+layers on a band of its token grid per rank (``ShardedPPEGFn``: the rank's own grid rows, three halo rows either side and the cells that
+wrap, fetched by ONE all-to-all; rounds 3: an all-gathered replica of the sequence).  The sharded MHIM(TransMIL) train STEP on top of it -
+the re-balancing all-to-all from the instance shards into these token blocks, the teacher's cls attention and pseudo score, the trainer
+wiring - is sharded_transmil.py.  All exchanges go through ``sharded._Comm`` (RCCL; gloo with host staging in the one-GPU tests).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -33,6 +35,7 @@ from . import ops
 from .sharded import _Comm
 
 HEADS, DH, INNER, M, KS, HALO = NY.HEADS, NY.DH, NY.INNER, NY.LANDMARKS, NY.CONV_K, NY.CONV_K // 2
+_PPEG_HALO = os.environ.get("MHIMX_PPEG_REPLICA", "0") != "1"          # (1: the round-3 form, the PPEG on an all-gathered replica)
 
 
 def _halo_rows(comm, block):
@@ -216,6 +219,146 @@ class _OwnerRow(torch.autograd.Function):
         return dx, None, None
 
 
+# ---------------------------------------------------------------------------------------------------- PPEG with halos
+_PPEG_PLANS = {}
+
+
+class _BandPlan:
+    """The band of the PPEG's token grid one rank works on, and the exchange that fills it - from the layout alone (pad, tokens, ranks).
+    The sequence is [zeros(pad) | cls | n_tok tokens] in blocks of Tr rows; token j is grid cell j of a side x side grid whose cells
+    [n_tok, wrapN) repeat the first tokens (emb_position.py:100-103).  Rank q owns the cells of its tokens [t0, t1) (the owner of the last
+    token also answers for the wrap cells' gradient) and needs the grid rows of those cells plus three either side."""
+
+    def __init__(self, pad, n_tok, Tr, comm, dev):
+        import numpy as np
+        W, me = comm.world, comm.rank
+        wrap = C.c_int64(0)
+        H = int(L.lib().mhimx_ppeg_side(n_tok, C.byref(wrap)))
+        wrapN, skip = int(wrap.value), pad + 1
+        self.H, self.wrapN, self.n_tok, self.skip, self.Tr = H, wrapN, n_tok, skip, Tr
+        rng = [(min(max(q * Tr - skip, 0), n_tok), min(max((q + 1) * Tr - skip, 0), n_tok)) for q in range(W)]
+        last = max(q for q in range(W) if rng[q][1] > rng[q][0])
+
+        def band(q):
+            t0, t1 = rng[q]
+            if t1 <= t0:
+                return None
+            t1e = wrapN if q == last else t1
+            rA, rB = max(0, t0 // H - 3), min(H, (t1e - 1) // H + 4)
+            return t0, t1, t1e, rA * H, (rB - rA) * H
+
+        need = []
+        for q in range(W):
+            bq = band(q)
+            if bq is None:
+                need.append(np.zeros(0, dtype=np.int64))
+                continue
+            cells = bq[3] + np.arange(bq[4], dtype=np.int64)
+            need.append(np.where(cells < n_tok, skip + cells, np.where(cells < wrapN, skip + cells - n_tok, -1)))
+        self.band = band(me)
+        send_idx, self.send_counts = [], []
+        for q in range(W):
+            nl = need[q]
+            own = (nl >= 0) & (nl // Tr == me)
+            send_idx.append(nl[own] - me * Tr)
+            self.send_counts.append(int(own.sum()))
+        self.send_idx = torch.as_tensor(np.concatenate(send_idx), dtype=torch.int64).to(dev)
+        mine = need[me]
+        owner = np.where(mine >= 0, mine // Tr, W)
+        order = np.argsort(owner, kind="stable")
+        order = order[owner[order] < W]
+        self.place = torch.as_tensor(order, dtype=torch.int64).to(dev)
+        self.recv_counts = [int((owner == q).sum()) for q in range(W)]
+        self.last = last
+        self.comm = comm
+
+    def fetch(self, block):
+        """This rank's band [ncell, C] of cells from the ranks' sequence blocks (zero where the grid has no token)."""
+        got = self.comm.all_to_all_rows(block.index_select(0, self.send_idx), self.send_counts, self.recv_counts)
+        out = torch.zeros((self.band[4] if self.band is not None else 0, block.shape[1]), device=block.device)
+        if got.shape[0]:
+            out.index_copy_(0, self.place, got)
+        return out
+
+
+def _band_plan(pad, n_tok, Tr, comm, dev):
+    key = (pad, n_tok, Tr, comm.world, comm.rank, str(dev))
+    pl = _PPEG_PLANS.get(key)
+    if pl is None:
+        if len(_PPEG_PLANS) > 64:
+            _PPEG_PLANS.clear()
+        pl = _PPEG_PLANS[key] = _BandPlan(pad, n_tok, Tr, comm, dev)
+    return pl
+
+
+class ShardedPPEGFn(torch.autograd.Function):
+    """baseline.py:265-266 `cat([cls, ppeg(tokens)])` on a sequence sharded in blocks: the 7 x 7 stencil (emb_position.py:92-120) of this
+    rank's tokens from a band of the grid - its own grid rows, three halo rows either side and the wrap cells, fetched with ONE all-to-all
+    (forward: token rows; backward: their gradients) instead of an all-gathered replica of the sequence.  The gradient of the wrap cells
+    (computed where the grid ends) returns to the first tokens through one small all-reduce ((side^2 - n_tok) x C floats).  The rows of the
+    block that are not tokens (front padding, the cls row) pass through.  Parameter gradients: local partial sums."""
+
+    @staticmethod
+    def forward(ctx, x, w7, w5, w3, b7, b5, b3, comm, pad, n):
+        lib = L.lib()
+        x = x.contiguous()
+        Tr, Cc = x.shape
+        pl = _band_plan(int(pad), int(n) - 1, Tr, comm, x.device)
+        wc, bc = torch.empty((Cc, 49), device=x.device), torch.empty(Cc, device=x.device)
+        L.check(lib.mhimx_ppeg_combine(NY._st(), NY._ptr(w7.contiguous()), NY._ptr(w5.contiguous()), NY._ptr(w3.contiguous()), NY._ptr(b7),
+                                       NY._ptr(b5), NY._ptr(b3), Cc, NY._ptr(wc), NY._ptr(bc)), "ppeg_combine")
+        xb = pl.fetch(x)
+        y = x.clone()                                                                    # (pass-through rows; the token rows are overwritten)
+        if pl.band is not None:
+            t0, t1, t1e, cell0, ncell = pl.band
+            bd = L.PpegBand(H=pl.H, cell0=cell0, ncell=ncell, out0=t0, out1=t1)
+            r0 = pl.skip + t0 - comm.rank * Tr                                           # block row of token t0
+            L.check(lib.mhimx_ppeg_band_fwd(NY._st(), NY._ptr(xb), C.byref(bd), Cc, NY._ptr(wc), NY._ptr(bc), NY._ptr(y, r0 * Cc)), "ppeg_band_fwd")
+        ctx.saved = (xb, wc)
+        ctx.cfg = (pl, comm, Tr, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        xb, wc = ctx.saved
+        ctx.saved = None
+        pl, comm, Tr, Cc = ctx.cfg
+        dy = dy.contiguous()
+        dev = dy.device
+        dyb = pl.fetch(dy)
+        dx = dy.clone()                                                                  # pass-through rows
+        add = pl.wrapN - pl.n_tok
+        dxw = torch.zeros((add, Cc), device=dev) if add else None
+        dwc, dbc = torch.zeros((Cc, 49), device=dev), torch.zeros(Cc, device=dev)
+        if pl.band is not None:
+            t0, t1, t1e, cell0, ncell = pl.band
+            if pl.n_tok - cell0 < ncell:
+                dyb[max(pl.n_tok - cell0, 0):].zero_()                                   # the fetch filled the wrap cells with dy of the first tokens: not outputs
+            bd = L.PpegBand(H=pl.H, cell0=cell0, ncell=ncell, out0=t0, out1=t1e)
+            dxo = torch.empty((t1e - t0, Cc), device=dev)
+            ws = torch.empty(lib.mhimx_ppeg_band_bwd_ws_floats(t1e - t0, Cc), device=dev)
+            L.check(lib.mhimx_ppeg_band_bwd(NY._st(), NY._ptr(dyb), NY._ptr(xb), C.byref(bd), t1 - t0, Cc, NY._ptr(wc), NY._ptr(dxo), NY._ptr(dwc),
+                                            NY._ptr(dbc), NY._ptr(ws)), "ppeg_band_bwd")
+            r0 = pl.skip + t0 - comm.rank * Tr
+            dx[r0:r0 + (t1 - t0)].copy_(dxo[:t1 - t0])
+            if t1e > t1 and add:
+                dxw.copy_(dxo[t1 - t0:])
+        if add:
+            comm.all_reduce_sum(dxw)                                                     # (one contributor: the rank where the grid ends)
+            if pl.band is not None and pl.band[0] < add:                                # my tokens among the first `add`
+                t0, t1 = pl.band[0], min(pl.band[1], add)
+                r0 = pl.skip + t0 - comm.rank * Tr
+                seg = dx[r0:r0 + (t1 - t0)]
+                L.check(lib.mhimx_axpby(NY._st(), NY._ptr(dxw, t0 * Cc), NY._ptr(seg), seg.numel(), 1.0, 1.0), "axpby")
+        g = dwc.view(Cc, 1, 7, 7)
+        return (dx, g.contiguous(), g[:, :, 1:6, 1:6].contiguous(), g[:, :, 2:5, 2:5].contiguous(), dbc, dbc.clone(), dbc.clone(), None, None, None)
+
+
+def sharded_ppeg(pe: "NY._PPEG", x_local, comm, pad, n):
+    return ShardedPPEGFn.apply(x_local, pe.proj.weight, pe.proj1.weight, pe.proj2.weight, pe.proj.bias, pe.proj1.bias, pe.proj2.bias, comm, pad, n)
+
+
 def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None, return_attn=False, seeds=(0, 0), training=False):
     """mhim_modules/baseline.SAttention (cls token, TransLayer, PPEG, TransLayer, LayerNorm of the cls row: baseline.py:222-288) on a
     sequence sharded over the ranks.  h_local: this rank's block of the PADDED token sequence [zeros(pad) | cls slot | n - 1 token rows]
@@ -237,9 +380,12 @@ def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None, return_
         attn.append(a)
     else:
         x = sharded_trans_layer(enc.layer1, x, comm, pad, p1, seeds[0])
-    full = _GatherRows.apply(x, comm)                                        # baseline.py:265-266: cat([cls, ppeg(tokens)])
-    full = enc.pos_embedding(full, skip=pad + 1)                             # rows [0, pad] pass through; the stencil sees the n - 1 tokens
-    x = full[g0:g0 + Tr]
+    if n - 1 >= 49 and _PPEG_HALO:                                           # baseline.py:265-266: cat([cls, ppeg(tokens)])
+        x = sharded_ppeg(enc.pos_embedding, x, comm, pad, n)                 # its own grid rows + halos: one all-to-all (ShardedPPEGFn)
+    else:                                                                    # (grids below 7 x 7: the zero-padded rule, on a replica)
+        full = _GatherRows.apply(x, comm)
+        full = enc.pos_embedding(full, skip=pad + 1)                         # rows [0, pad] pass through; the stencil sees the n - 1 tokens
+        x = full[g0:g0 + Tr]
     if return_attn:
         x, a, _ = sharded_trans_layer(enc.layer2, x, comm, pad, p2, seeds[1], True)
         attn.append(a)

@@ -75,6 +75,16 @@ class _Comm:
             dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
         return out
 
+    def all_to_all_rows(self, send, send_counts, recv_counts):
+        """send [sum(send_counts), C], grouped by destination rank -> [sum(recv_counts), C], grouped by source rank."""
+        if self.world == 1:
+            return send
+        src = send.cpu() if self.stage else send.contiguous()
+        out = torch.empty((int(sum(recv_counts)), send.shape[1]), dtype=send.dtype, device=src.device)
+        dist.all_to_all_single(out, src, output_split_sizes=[int(c) for c in recv_counts], input_split_sizes=[int(c) for c in send_counts],
+                               group=self.group)
+        return out.to(send.device)
+
     def all_gather_rows(self, t, counts):
         """Concatenate per-rank vectors of (known) different lengths."""
         if self.world == 1:

@@ -16,14 +16,14 @@ re-balancing exchange:
   backward  the exchanges in reverse (all-to-all of d tokens; d merged tokens summed over the owners; the merge rows' gradient is read
             off the replicated dX); parameter gradients are local partial sums (replicated terms counted on rank 0 only) and ride in ONE
             all-reduce of the flat gradient; Adam + EMA replicated.
-The PPEG between the layers runs on an all-gathered copy of the sequence (nystrom_sharded.sharded_sattention).  Dropout streams are
+The PPEG between the layers works on a band of its token grid per rank - own grid rows, three halo rows either side, the wrap cells: one
+all-to-all each way (nystrom_sharded.ShardedPPEGFn).  Dropout streams are
 keyed by rank-local element indices with rank-salted seeds: valid, independent masks, not the single-process ones (the equality tests run
 with dropout 0).  One host read-back per exchange plan (the W x W row counts).
 """
 from __future__ import annotations
 
 import torch
-import torch.distributed as dist
 
 from . import _lib as L
 from . import nystrom as NY
@@ -33,14 +33,7 @@ from .nystrom_sharded import sharded_sattention
 
 
 def _all_to_all_rows(comm, send, send_counts, recv_counts):
-    """send [sum(send_counts), C], grouped by destination rank -> [sum(recv_counts), C], grouped by source rank."""
-    if comm.world == 1:
-        return send
-    src = send.cpu() if comm.stage else send.contiguous()
-    out = torch.empty((int(sum(recv_counts)), send.shape[1]), dtype=send.dtype, device=src.device)
-    dist.all_to_all_single(out, src, output_split_sizes=[int(c) for c in recv_counts], input_split_sizes=[int(c) for c in send_counts],
-                           group=comm.group)
-    return out.to(send.device)
+    return comm.all_to_all_rows(send, send_counts, recv_counts)
 
 
 class ExchangePlan:

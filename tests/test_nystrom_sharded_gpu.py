@@ -83,7 +83,8 @@ def test_shard_alignment_is_checked():
 N_TOK = 1850                                               # + cls = 1851 tokens -> 197 front pad rows -> T = 2048
 
 
-def _encoder_and_tokens():
+def _encoder_and_tokens(n_tok=None):
+    n_tok = N_TOK if n_tok is None else n_tok
     from mhim_mil_amd import nystrom as NY
     torch.manual_seed(21)
     enc = NY.SAttention(E)
@@ -92,21 +93,22 @@ def _encoder_and_tokens():
         enc.norm.weight.add_(0.1 * torch.randn(E))
         enc.norm.bias.add_(0.1 * torch.randn(E))
     g = torch.Generator().manual_seed(22)
-    h = torch.randn(N_TOK, E, generator=g) * 0.7
+    h = torch.randn(n_tok, E, generator=g) * 0.7
     dz = torch.randn(E, generator=g)
     return enc, h, dz
 
 
-def _enc_worker(rank, world, port, out):
+def _enc_worker(rank, world, port, out, n_tok=None):
+    n_tok = N_TOK if n_tok is None else n_tok
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mhim_mil_amd.nystrom_sharded import sharded_sattention
-    enc, h, dz = _encoder_and_tokens()
+    enc, h, dz = _encoder_and_tokens(n_tok)
     enc = enc.to(DEV).eval()
-    n = N_TOK + 1
+    n = n_tok + 1
     pad = (256 - n % 256) % 256
     seq = torch.cat([torch.zeros(pad + 1, E), h])          # [zeros(pad) | cls slot | tokens]
     Tr = seq.shape[0] // world
@@ -118,21 +120,24 @@ def _enc_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_encoder_equals_the_single_rank_encoder(tmp_path, world):
-    enc, h, dz = _encoder_and_tokens()
+# (1850 tokens: a 44 x 44 grid with 86 wrap cells, every rank holds tokens; 300 tokens over 4 ranks: T = 512, the first rank is all front
+#  padding, the second holds the cls row and 44 tokens - the PPEG's band exchange with ranks that own nothing; 3000: several grid rows
+#  per halo, blocks that do not start on a grid row)
+@pytest.mark.parametrize("world,n_tok", [(2, N_TOK), (4, N_TOK), (4, 300), (2, 3000)])
+def test_sharded_encoder_equals_the_single_rank_encoder(tmp_path, world, n_tok):
+    enc, h, dz = _encoder_and_tokens(n_tok)
     enc = enc.to(DEV).eval()
     hd = h.to(DEV).requires_grad_()
     z_ref = enc(hd)
     z_ref.backward(dz.to(DEV))
     g_ref = {k: p.grad.detach().cpu() for k, p in enc.named_parameters()}
     port = 35100 + (os.getpid() % 1500) + world
-    mp.spawn(_enc_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_enc_worker, args=(world, port, str(tmp_path), n_tok), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"e{r}.pt")) for r in range(world)]
     rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
     for r in res:                                           # the cls feature is replicated
         assert rel(r["z"], z_ref.detach().cpu()) < 5e-5
-    pad = (256 - (N_TOK + 1) % 256) % 256
+    pad = (256 - (n_tok + 1) % 256) % 256
     dh = torch.cat([r["dh"] for r in res])[pad + 1:]        # the token rows of the padded sequence
     assert rel(dh, hd.grad.cpu()) < 5e-4
     for k, ref in g_ref.items():
