@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point or a struct changes shape; the ctypes binding (mhim_mil_amd/_lib.py ABI_VERSION) refuses any other value */
-#define MHIMX_VERSION 400
+#define MHIMX_VERSION 401
 
 /* activations (feature act: mhim.py:71-74 relu|gelu|none; scorer act: baseline.py:17-22 gelu|relu|tanh|none) */
 enum { MHIMX_ACT_NONE = 0, MHIMX_ACT_RELU = 1, MHIMX_ACT_GELU = 2, MHIMX_ACT_TANH = 3 };

@@ -12,7 +12,7 @@ c_f32p = C.c_void_p
 c_i64p = C.c_void_p
 c_u8p = C.c_void_p
 
-ABI_VERSION = 400          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
+ABI_VERSION = 401          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
 
 ACT = {None: 0, "none": 0, "identity": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"f32": 0, "f16s": 1, "bf16x3": 2}
