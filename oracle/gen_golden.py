@@ -193,6 +193,23 @@ def g5_select(ns):
                                       msa_fusion="vote")
     _save("g5_select_vote_n600", dict(n=n, heads=h, mask_ratio_h=0.05, mask_ratio_hr=0.5, sseed=88, k=k),
           attn=a, perm=perm, len_keep=len_keep, kept=ids[0, :len_keep].numpy(), masked=ids[0, len_keep:].numpy())
+    # 3-D 'mean' fusion (masking.py:44-48: per-head top-(k // h), their sorted union) with a random half of the union masked
+    n, h = 600, 8
+    a = ((np.stack([synth.permutation(120 + i, n) for i in range(h)]) + 0.25 * synth.uniform(89, (h, n))) / n).astype(np.float32)
+    kk = int(np.ceil(n * min(0.2 / 0.5, 1.0)) // h)
+    union = np.unique(np.concatenate([np.argsort(-a[i], kind="stable")[:kk] for i in range(h)]))
+    torch.manual_seed(6)
+    perm = torch.randperm(len(union)).numpy()
+    torch.manual_seed(6)
+    len_keep, ids = ns.select_mask_fn(n, torch.from_numpy(a)[None], True, 0.2, len_keep_other=n, random_ratio=0.5, msa_fusion="mean")
+    _save("g5_select_mean_n600", dict(n=n, heads=h, mask_ratio_h=0.2, mask_ratio_hr=0.5, sseed=89, kk=kk, union=int(len(union))),
+          attn=a, perm=perm, len_keep=len_keep, kept=ids[0, :len_keep].numpy(), masked=ids[0, len_keep:].numpy())
+    # select_inv (masking.py:82-84): the SELECTED rows come first and len_keep counts them
+    n = 512
+    s = ((synth.permutation(131, n) + 0.25 * synth.uniform(131, (n,))) / n).astype(np.float32)
+    len_keep, ids = ns.select_mask_fn(n, torch.from_numpy(s)[None], True, 0.1, select_inv=True)
+    _save("g5_select_inv_n512", dict(n=n, mask_ratio_h=0.1, sseed=131), score=s, len_keep=len_keep,
+          first=ids[0, :len_keep].numpy(), rest=ids[0, len_keep:].numpy())
     # v1 combined masks through MHIM.get_mask: random .5 + low .2 + high .01/.5
     n = 1500
     s = synth.uniform(99, (n,)).astype(np.float32)

@@ -154,6 +154,23 @@ def test_g5_select_low():
     assert np.array_equal(ids[:len_keep], a["kept"]) and np.array_equal(ids[len_keep:], a["masked"])
 
 
+def test_g5_select_mean():
+    """msa_fusion='mean' (masking.py:44-48): per-head top-(k // h), their sorted union, a random half of it masked."""
+    meta, a = G.load("g5_select_mean_n600")
+    len_keep, ids, _ = O.select_mask(meta["n"], a["attn"], True, meta["mask_ratio_h"], random_ratio=meta["mask_ratio_hr"], perm=a["perm"],
+                                     msa_fusion="mean")
+    assert len_keep == int(a["len_keep"]) and len(a["perm"]) == meta["union"]
+    assert np.array_equal(ids[:len_keep], a["kept"]) and np.array_equal(ids[len_keep:], a["masked"])
+
+
+def test_g5_select_inv():
+    """select_inv (masking.py:82-84): the selected rows first, len_keep = their number."""
+    meta, a = G.load("g5_select_inv_n512")
+    len_keep, ids, _ = O.select_mask(meta["n"], a["score"], True, meta["mask_ratio_h"], select_inv=True)
+    assert len_keep == int(a["len_keep"])
+    assert np.array_equal(ids[:len_keep], a["first"]) and np.array_equal(ids[len_keep:], a["rest"])
+
+
 def test_g5_select_vote():
     meta, a = G.load("g5_select_vote_n600")
     len_keep, ids, _ = O.select_mask(meta["n"], a["attn"], True, meta["mask_ratio_h"],
