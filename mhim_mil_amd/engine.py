@@ -26,9 +26,58 @@ from .mhim import MHIM, BagPlan
 class CommonMIL:
     """Hook object of the reference trainer (engines/common_mil.py)."""
 
-    def __init__(self, args=None, fused=None) -> None:
+    def __init__(self, args=None, fused=None, graph_cache=0) -> None:
         self.training = True
         self.fused = fused                 # optional optim.FusedAdamEMA: forward_func may run the native forward + backward (its docstring)
+        # graph_cache = K > 0 (with fused=): the native forward + backward of the K most recent bag SHAPES as captured hipGraphs - the second
+        # bag of a shape is captured (into buffers of its own: the bag is copied in, one launch), every later one replays; other shapes
+        # run eagerly as before.  One process, accumulation_steps == 1, no HAM-ratio schedule (its launch shapes change per iteration).
+        self.graph_cache = int(graph_cache)
+        self._graphs, self._seen = {}, {}
+
+    def _native_step(self, tr, bag, label, n_iter, extra):
+        """The native forward + backward of one bag: a replay of the shape's captured graph when there is one (graph_cache), else eager."""
+        x = bag[0] if bag.dim() == 3 else bag
+        ok = (self.graph_cache > 0 and not extra and tr.accum == 1 and tr.world == 1 and tr.s.mrh_sche is None and x.is_cuda
+              and not tr._capturing)
+        if not ok:
+            logits, losses = tr.forward_backward(bag, label, i=n_iter, **extra)
+            return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
+        key = (tuple(x.shape), x.dtype, x.device.index)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._seen[key] = self._seen.get(key, 0) + 1
+            if self._seen[key] < 2:                            # first bag of the shape: eager (it also is the kernels' warm-up)
+                logits, losses = tr.forward_backward(bag, label, i=n_iter)
+                return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
+            if len(self._graphs) >= self.graph_cache:          # the oldest shape makes room
+                self._graphs.pop(next(iter(self._graphs)))
+            xs, ls = torch.empty_like(x), torch.empty_like(label)
+            if tr._cap_stream is None:
+                tr._cap_stream = torch.cuda.Stream()
+            if tr._graph_pool is None:
+                tr._graph_pool = torch.cuda.graph_pool_handle()
+            cs = tr._cap_stream
+            cs.wait_stream(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            micro = tr._micro
+            tr._capturing = True
+            try:
+                with torch.cuda.graph(g, pool=tr._graph_pool, stream=cs):      # (recorded, not run: the replay below is this bag's step)
+                    logits, losses = tr.forward_backward(xs, ls, i=n_iter)
+            finally:
+                tr._capturing = False
+            ops.step_images(None)
+            tr._micro = micro
+            ent = self._graphs[key] = (g, xs, ls, logits, losses, tr.last["patch_num"], tr.last["keep_num"], dict(tr.last))
+        g, xs, ls, logits, losses, pn, kn, last = ent
+        xs.copy_(x)
+        ls.copy_(label)
+        g.replay()
+        tr._micro += 1
+        tr.last = last
+        return logits, losses, pn, kn
 
     def init_func_train(self, args, **kwargs):
         self.training = True
@@ -57,10 +106,10 @@ class CommonMIL:
             tr = fz.trainer
             tr.main_alpha, tr.aux_alpha = float(getattr(args, "main_alpha", 1.0)), float(args.aux_alpha)
             extra = {k: kwargs[k] for k in ("perm", "ids_shuffle") if k in kwargs}
-            logits, losses = tr.forward_backward(bag, label.view(-1)[:1], i=n_iter, **extra)
-            lg = logits.detach().view(batch_size, -1).requires_grad_(True)
+            logits, losses, patch_num, keep_num = self._native_step(tr, bag, label.view(-1)[:1], n_iter, extra)
+            lg = logits.detach().view(batch_size, -1).clone().requires_grad_(True)     # (clone: a replay rewrites the graph's buffers)
             aux = losses[2].detach().clone().requires_grad_(True)
-            return lg, label, aux, tr.last["patch_num"], tr.last["keep_num"], 0., 0.
+            return lg, label, aux, patch_num, keep_num, 0., 0.
         if args.model == "mhim":
             teacher_feat, score = (None, None)
             if model_ema is not None:

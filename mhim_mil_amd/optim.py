@@ -27,6 +27,8 @@ every parameter, ``merge.global_q_mm`` included) over flat buffers:
   leaf tensors - the loop's ``criterion`` / ``loss.backward()`` run on two leaves and touch no parameter.  Taken only when the loop's
   loss IS ``main_alpha * CrossEntropyLoss(logits, label) + aux_alpha * aux_loss`` (base_engine.py:99-102: a plain
   ``nn.CrossEntropyLoss``); anything else falls back to the autograd path, which lands in the same flat gradient.
+  ``CommonMIL(args, fused=optimizer, graph_cache=K)`` replays that native step as a captured hipGraph for the K most recent bag shapes
+  (c2, same box: 1.75 ms for the plain swap -> 1.29 fused optimiser -> 0.69 native step eager -> 0.37 replayed).
 """
 from __future__ import annotations
 

@@ -78,6 +78,10 @@ model, ema = mk(), mk()
 opt = FusedAdamEMA(model, ema, lr=2e-4, weight_decay=1e-5, mm=mm)
 engine = CommonMIL(args, fused=opt)                       # forward_func runs the native forward + backward; the loop is unchanged
 timed(ref_step, f"... + CommonMIL(args, fused=optimizer) ({BASE})")
+model, ema = mk(), mk()
+opt = FusedAdamEMA(model, ema, lr=2e-4, weight_decay=1e-5, mm=mm)
+engine = CommonMIL(args, fused=opt, graph_cache=4)        # ... and replays a captured graph for a bag shape it has seen twice
+timed(ref_step, f"... + graph_cache=4 ({BASE})")
 tr = FusedTrainer(mk(), mk(), aux_alpha=0.5)
 timed(lambda i: tr.train_step(bags[i % 4][0], label), "FusedTrainer.train_step, eager")
 if os.environ.get("PROFILE_EAGER") == "1":
