@@ -291,11 +291,50 @@ def accumulate8(a, dev, bags, labels):
                          "chained over the window's tokens (every bag attends with the window's first queries: second order in 1 - merge_mm)"}
 
 
+def reference_loop(a, dev, bags, labels):
+    """The reference trainer's OWN loop body (engines/base_engine.py:76-167: forward_func, criterion, loss.backward(), optimizer.step(),
+    zero_grad, the per-parameter EMA loop) on the drop-in classes with optim.FusedAdamEMA and CommonMIL(fused=, graph_cache=): what a user
+    gets from the two-line swap of INTEGRATION.md section 2, beside the native FusedTrainer step the headline times."""
+    import types
+    from mhim_mil_amd.engine import CommonMIL
+    from mhim_mil_amd.optim import FusedAdamEMA
+    steps, warm, mm = 48, 8, 0.9997
+    model, ema, _ = make_models(dev, a.prec)
+    args = types.SimpleNamespace(model="mhim", baseline="attn", aux_alpha=0.5, main_alpha=1.0)
+    opt = FusedAdamEMA(model, ema, lr=2e-4, weight_decay=1e-5, mm=mm)
+    engine = CommonMIL(args, fused=opt, graph_cache=0 if a.no_graph else 2)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def step(i):
+        bag, label = bags[i % len(bags)][None], labels[i % len(bags)]
+        logits, lab, aux, _, _, _, _ = engine.forward_func(args, model, ema, bag, label, crit, 1, i, 0, i, None)
+        loss = args.main_alpha * crit(logits.view(1, -1), lab) + args.aux_alpha * aux
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        for pq, pk in zip(model.parameters(), ema.parameters()):            # base_engine.py:166-167 (an adopted teacher yields nothing)
+            pk.data.mul_(mm).add_(pq.data, alpha=1. - mm)
+
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": N_INST / dt, "unit": "patch-instances/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warm,
+            "loop": "engines/base_engine.py:76-167 restated verbatim (forward_func, nn.CrossEntropyLoss, loss.backward(), optimizer.step(), "
+                    "zero_grad(), per-parameter EMA loop) with optim.FusedAdamEMA + CommonMIL(args, fused=optimizer, graph_cache=2)",
+            "launch": "eager native step" if a.no_graph else "the native forward + backward replayed as a hipGraph per bag shape; bag copied into the graph's buffer"}
+
+
 def run_extras(a, dev, bags, labels):
     """The legs the default one-GPU run adds to the headline line; each catches its own failure so the headline always prints."""
     import copy
     out = {}
-    for name, fn in (("hbm_copy", lambda: hbm_copy_rate(dev)), ("accumulate8", lambda: accumulate8(a, dev, bags, labels))):
+    for name, fn in (("hbm_copy", lambda: hbm_copy_rate(dev)), ("accumulate8", lambda: accumulate8(a, dev, bags, labels)),
+                     ("reference_loop", lambda: reference_loop(a, dev, bags, labels))):
         try:
             out[name] = fn()
         except Exception as e:  # noqa: BLE001
