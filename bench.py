@@ -324,7 +324,7 @@ def reference_loop(a, dev, bags, labels):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"value": N_INST / dt, "unit": "patch-instances/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warm,
-            "loop": "engines/base_engine.py:76-167 restated verbatim (forward_func, nn.CrossEntropyLoss, loss.backward(), optimizer.step(), "
+            "loop": "the call sequence of engines/base_engine.py:76-167 (forward_func, nn.CrossEntropyLoss, loss.backward(), optimizer.step(), "
                     "zero_grad(), per-parameter EMA loop) with optim.FusedAdamEMA + CommonMIL(args, fused=optimizer, graph_cache=2)",
             "launch": "eager native step" if a.no_graph else "the native forward + backward replayed as a hipGraph per bag shape; bag copied into the graph's buffer"}
 
