@@ -31,15 +31,16 @@ class CommonMIL:
         self.fused = fused                 # optional optim.FusedAdamEMA: forward_func may run the native forward + backward (its docstring)
         # graph_cache = K > 0 (with fused=): the native forward + backward of the K most recent bag SHAPES as captured hipGraphs - the second
         # bag of a shape is captured (into buffers of its own: the bag is copied in, one launch), every later one replays; other shapes
-        # run eagerly as before.  One process, accumulation_steps == 1, no HAM-ratio schedule (its launch shapes change per iteration).
+        # run eagerly as before.  MHIM(ABMIL), one process, accumulation_steps == 1, no HAM-ratio schedule (its launch shapes change per iteration).
         self.graph_cache = int(graph_cache)
         self._graphs, self._seen = {}, {}
 
     def _native_step(self, tr, bag, label, n_iter, extra):
         """The native forward + backward of one bag: a replay of the shape's captured graph when there is one (graph_cache), else eager."""
         x = bag[0] if bag.dim() == 3 else bag
+        # (ABMIL only: the TransMIL / DSMIL students run autograd nodes, whose streams a capture without a warm-up on its own stream cannot take)
         ok = (self.graph_cache > 0 and not extra and tr.accum == 1 and tr.world == 1 and tr.s.mrh_sche is None and x.is_cuda
-              and not tr._capturing)
+              and not tr._capturing and tr.s.baseline == "attn")
         if not ok:
             logits, losses = tr.forward_backward(bag, label, i=n_iter, **extra)
             return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
