@@ -74,7 +74,12 @@ class ShardedTransLayerFn(torch.autograd.Function):
                 "layernorm_fwd")
         if npad:
             xn[:npad].zero_()                        # nystrom_attention.py:70-73 pads AFTER the LayerNorm: pad tokens are zero rows of q, k, v
-        qkv = ops.gemm_nt(xn, w_qkv, prec=NY._PREC)                                     # [Tr, 1536]
+        big = Tr >= 2048 and NY._PREC == "bf16x3"                                       # (the projection / weight-gradient kernels, as TransLayerFn)
+        if big:
+            qkv = torch.empty((Tr, 3 * INNER), device=dev)
+            ops.bag_project(xn, [ops.ProjHead(ops.pair_planes(w_qkv), None, out=qkv)], act=0)
+        else:
+            qkv = ops.gemm_nt(xn, w_qkv, prec=NY._PREC)                                 # [Tr, 1536]
         ld = qkv.shape[1]
         lm_loc = torch.empty((gl, 2 * INNER), device=dev)
         L.check(lib.mhimx_landmark_mean(NY._st(), NY._ptr(qkv), ld, Tr, l, 2 * INNER, NY._ptr(lm_loc)), "landmark_mean")
@@ -95,10 +100,13 @@ class ShardedTransLayerFn(torch.autograd.Function):
         L.check(lib.mhimx_resconv(NY._st(), NY._ptr(v_ext), INNER, NY._ptr(wc), KS, DH, Tr + 2 * HALO, INNER, NY._ptr(conv), INNER, 0, 0), "resconv")
         mid = conv[HALO:HALO + Tr]
         L.check(lib.mhimx_axpby(NY._st(), NY._ptr(mid), NY._ptr(out), out.numel(), 1.0, 1.0), "axpby")      # out += res_conv(v) (nystrom:135-136)
-        y = ops.gemm_nt(out, w_out, bias=b_out, drop_p=float(drop_p), drop_seed=int(seed), prec=NY._PREC)
-        L.check(lib.mhimx_axpby(NY._st(), NY._ptr(x), NY._ptr(y), y.numel(), 1.0, 1.0), "axpby")            # y += x
+        if big:                                                                         # y = x + dropout(to_out(.)): one launch
+            y = ops.bag_project(out, [ops.ProjHead(ops.pair_planes(w_out), b_out, drop_p=float(drop_p), drop_seed=int(seed), resid=x)], act=0)[0].out
+        else:
+            y = ops.gemm_nt(out, w_out, bias=b_out, drop_p=float(drop_p), drop_seed=int(seed), prec=NY._PREC)
+            L.check(lib.mhimx_axpby(NY._st(), NY._ptr(x), NY._ptr(y), y.numel(), 1.0, 1.0), "axpby")        # y += x
         ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, v_ext)
-        ctx.cfg = (l, gl, scale, comm, conv_w.shape, npad, float(drop_p), int(seed))
+        ctx.cfg = (l, gl, scale, comm, conv_w.shape, npad, float(drop_p), int(seed), big)
         if not need_attn:
             return y
         # the cls token's attention row (nystrom:143-150) = (attn1[cls] pinv) attn3: the owner of the cls row forms u = softmax(q_cls k~^T) z
@@ -123,18 +131,26 @@ class ShardedTransLayerFn(torch.autograd.Function):
         lib = L.lib()
         x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, v_ext = ctx.saved
         ctx.saved = None
-        l, gl, scale, comm, wshape, npad, drop_p, seed = ctx.cfg
+        l, gl, scale, comm, wshape, npad, drop_p, seed, big = ctx.cfg
         dy = dy.contiguous()
         Tr, E = x.shape
         dev, ld = x.device, qkv.shape[1]
         g = dy
         if drop_p > 0:                          # the forward's mask again (the stream of the kernel that drew it)
             g = torch.empty_like(dy)
-            L.check(lib.mhimx_dropout_apply(NY._st(), NY._ptr(dy), NY._ptr(g), Tr, E, drop_p, seed & 0xFFFFFFFFFFFFFFFF, None), "dropout_apply")
+            fn = lib.mhimx_dropout_apply_proj if big else lib.mhimx_dropout_apply
+            L.check(fn(NY._st(), NY._ptr(dy), NY._ptr(g), Tr, E, drop_p, seed & 0xFFFFFFFFFFFFFFFF, None), "dropout_apply")
         dout = torch.empty((Tr, INNER), device=dev)
-        NY._gemm("nn", g, 0, E, w_out, 0, INNER, dout, 0, INNER, Tr, INNER, E)
-        dw_out = ops.gemm_tn(g, out, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
-        db_out = ops.colsum(g)
+        wg = big and ops.bag_wgrad_ok(x, INNER, Tr)
+        if big:
+            ops.bag_project(g, [ops.ProjHead(ops.pair_planes_t(w_out), None, out=dout)], act=0)
+        else:
+            NY._gemm("nn", g, 0, E, w_out, 0, INNER, dout, 0, INNER, Tr, INNER, E)
+        if wg:
+            dw_out, db_out = ops.bag_wgrad(g, None, out, None, Tr)
+        else:
+            dw_out = ops.gemm_tn(g, out, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
+            db_out = ops.colsum(g)
         dqkv = torch.empty_like(qkv)
         # residual convolution: dv = flip-conv(dout) with dout's halo rows; its weight gradient from the local outputs against v with halos
         g_ext = _halo_rows(comm, dout)
@@ -162,10 +178,16 @@ class ShardedTransLayerFn(torch.autograd.Function):
         own = dlm[comm.rank * gl:(comm.rank + 1) * gl].contiguous()
         L.check(lib.mhimx_landmark_mean_bwd(NY._st(), NY._ptr(own), Tr, l, 2 * INNER, NY._ptr(dqkv), ld, 1), "landmark_mean_bwd")
         dxn = torch.empty_like(x)
-        NY._gemm("nn", dqkv, 0, ld, w_qkv, 0, E, dxn, 0, E, Tr, E, ld)
+        if big:
+            ops.bag_project(dqkv, [ops.ProjHead(ops.pair_planes_t(w_qkv), None, out=dxn)], act=0)
+        else:
+            NY._gemm("nn", dqkv, 0, ld, w_qkv, 0, E, dxn, 0, E, Tr, E, ld)
         if npad:
             dxn[:npad].zero_()                       # the pad rows of xn are constants
-        dw_qkv = ops.gemm_tn(dqkv, xn, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
+        if wg:
+            dw_qkv, _ = ops.bag_wgrad(dqkv, None, xn, None, Tr, want_bias=False)
+        else:
+            dw_qkv = ops.gemm_tn(dqkv, xn, splits=8 if Tr >= 4096 else 1, prec=NY._PREC)
         dx, dlw, dlb = torch.empty_like(x), torch.empty_like(ln_w), torch.empty_like(ln_w)
         wsl = torch.empty(2 * 512 * E, device=dev)
         L.check(lib.mhimx_layernorm_bwd_res(NY._st(), NY._ptr(dxn), NY._ptr(x), Tr, E, NY._ptr(ln_w), NY._ptr(mean), NY._ptr(rstd), NY._ptr(dy),

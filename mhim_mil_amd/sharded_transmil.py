@@ -28,7 +28,7 @@ import torch
 from . import _lib as L
 from . import nystrom as NY
 from . import ops
-from .mhim import BagPlan, _FeatureFn, _MergeFn
+from .mhim import BagPlan, _FeatureFn, _MergeFn, _FEATURE_ACTS
 from .nystrom_sharded import sharded_sattention
 
 
@@ -143,9 +143,20 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
     mix = lambda a: (local_seed + a * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
     # ---- teacher: feature rows -> token blocks -> sequence-parallel encoder with the cls attention -> per-token score -> all-gather
+    pre = None
     with torch.no_grad():
         p = t.dropout_p if t.training else 0.0
-        Ht = t._feature(x, None, p, mix(1))
+        if s.single_projection_ok(x) and t.single_projection_ok(x) and s.act == t.act:
+            # teacher AND student feature rows of all local bag rows in ONE pass over the raw rows (as FusedTrainer: the reference's student
+            # projects every row before it masks, mhim.py:335-336); the student's token rows are then a gather, its projection gradient the
+            # matrix-core-image pair on (d tokens, d out / d pre in fp16)
+            heads = [ops.ProjHead(ops.pair_planes(t.feature[0].weight.data), t.feature[0].bias.data, drop_p=p, drop_seed=mix(1)),
+                     ops.ProjHead(ops.pair_planes(s.feature[0].weight.data), s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=mix(4),
+                                  want_dact=True)]
+            ops.bag_project(x, heads, act=L.act_code(s.act, _FEATURE_ACTS))
+            Ht, pre = heads[0].out, (heads[1].out, heads[1].dact)
+        else:
+            Ht = t._feature(x, None, p, mix(1))
         pad_t, T_t, Tr_t = seq_layout(N, W)
         plan_t = ExchangePlan(torch.arange(N, device=dev), bounds, pad_t, Tr_t, cm)
         blk = _AssembleTokens.apply(Ht, None, plan_t, 0)
@@ -177,6 +188,7 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
     pd = dict(s.named_parameters())
     par = lambda name: pd[name] if first else pd[name].detach()                          # replicated terms: counted once in the SUM
     plan_f = BagPlan(rows=rows_local, L=n_loc, Lk=n_stay, R=n_loc - n_stay, drop_seed=mix(4), mca_seed=shared_seed, training=True)
+    plan_f.pre = pre
     H = _FeatureFn.apply(s, x, plan_f, s.feature[0].weight, s.feature[0].bias)           # [n_loc, E]: stay rows first, then rows to merge
     Hm = _GatherMergeRows.apply(H[n_stay:], merge_pos, R, cm)
     plan_m = BagPlan(rows=None, L=R, Lk=0, R=R, drop_seed=0, mca_seed=shared_seed, training=True)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 V2 = dict(act="gelu", da_act="relu", mask_ratio_h=0.03, mask_ratio_hr=0.5, attn2score=True, merge_enable=True,
           merge_k=5, merge_mm=0.9999, merge_ratio=0.9, temp_t=0.1, dropout=0.0)
-N, D = 1900, 64
+N, D = 1900, 256                       # (D % 256 == 0: the single-pass projection + matrix-core-image weight gradient take these shapes)
 COUNTS = {1: [1900], 2: [1000, 900], 4: [500, 450, 550, 400]}
 
 
