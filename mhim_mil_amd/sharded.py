@@ -155,6 +155,8 @@ class ShardedBagTrainer:
         """The sync-free step needs the one-pass scorer (its ``excl`` flags) and the single-pass projection; train_step also asks for
         the v2 recipe (HAM mask only): a v1 ratio makes the number of masked rows data dependent (one host read-back in get_mask)."""
         s = self.s
+        if s.baseline != "attn":
+            return False
         att = s.online_encoder.attention
         return (not s.online_encoder.gated and s.prec != "f32" and s.mlp_dim == 512 and att.attention[0].weight.shape[0] == 128
                 and x.shape[1] % 32 == 0 and s._feature_prec(1 << 20) == "bf16x3" and s.merge_enable)
@@ -334,6 +336,8 @@ class ShardedBagTrainer:
         """Capture the fixed-shape step as hipGraph segments with the exchanges between them (graph | collective | graph ...: a
         collective inside a captured graph depends on the RCCL build, and ranks must not mix replayed and eager collectives).  Returns
         a callable; every call replays one step on the SAME (x_local, label) buffers (copy the next shard into them)."""
+        if self.s.baseline != "attn":
+            raise L.MhimxError("capture(): the sharded TransMIL step (sharded_transmil.py) plans its exchanges on the host every step: run it eagerly")
         if not (self.fixed_shape_ok(x_local) and self.s.v2_counts(self._bag_rows(x_local), i) is not None):
             raise L.MhimxError("capture(): this model takes the generic sharded step (one host read-back per step): run it eagerly")
         if self.s.mrh_sche is not None:
