@@ -88,3 +88,40 @@ def test_mask_fn_gathers_the_kept_rows():
     ids = _t(synth.permutation(5, 700).astype(np.int64))[None]
     out = mask_fn(x, ids, 333)
     assert out.shape == (1, 333, 96) and torch.equal(out[0], x[0][ids[0, :333]])
+
+
+# ---------------------------------------------------------------------------------------------------- scoring.py's free functions
+def test_get_pseudo_score_matches_the_oracle():
+    from mhim_mil_amd.scoring import get_pseudo_score
+    n, E, Cc = 1500, 512, 2
+    h = torch.from_numpy(synth.normal(61, (n, E), std=1.0).astype(np.float32)).abs()
+    s = torch.from_numpy(synth.normal(62, (n,), std=2.0).astype(np.float32))
+    attn = torch.softmax(s, 0)
+    clf = torch.nn.Linear(E, Cc)
+    with torch.no_grad():
+        clf.weight.copy_(torch.from_numpy(synth.normal(63, (Cc, E), std=0.5).astype(np.float32)))
+        clf.bias.copy_(torch.tensor([0.3, -0.2]))
+    ref = O.pseudo_score(h.double(), attn.double(), clf.weight.detach().double(), clf.bias.detach().double())
+    got = get_pseudo_score(clf.to(DEV), h.to(DEV)[None], attn.to(DEV)[None])
+    assert got.shape == (1, n)
+    assert float((got[0].cpu().double() - ref).abs().max()) <= 2e-5
+
+
+def test_get_pseudo_score_trans_matches_the_oracle():
+    from mhim_mil_amd.scoring import get_pseudo_score_trans
+    n, hh, d, E, Cc = 900, 8, 64, 512, 2
+    v = torch.from_numpy(synth.normal(71, (hh, n, d), std=1.0).astype(np.float32))
+    attn = torch.softmax(torch.from_numpy(synth.normal(72, (hh, n), std=2.0).astype(np.float32)), 1)
+    to_out = torch.nn.Sequential(torch.nn.Linear(hh * d, E), torch.nn.Dropout(0.1)).eval()
+    clf = torch.nn.Linear(E, Cc)
+    with torch.no_grad():
+        to_out[0].weight.copy_(torch.from_numpy(synth.normal(73, (E, hh * d), std=0.05).astype(np.float32)))
+        to_out[0].bias.copy_(torch.from_numpy(synth.normal(74, (E,), std=0.1).astype(np.float32)))
+        clf.weight.copy_(torch.from_numpy(synth.normal(75, (Cc, E), std=0.5).astype(np.float32)))
+        clf.bias.copy_(torch.tensor([0.1, 0.4]))
+    params = {"p.to_out.0.weight": to_out[0].weight.detach().double(), "p.to_out.0.bias": to_out[0].bias.detach().double(),
+              "predictor.weight": clf.weight.detach().double(), "predictor.bias": clf.bias.detach().double()}
+    ref = O.pseudo_score_trans(v.double(), attn.double(), params, to_out_prefix="p.")
+    got = get_pseudo_score_trans(clf.to(DEV), v.to(DEV)[None], attn.to(DEV)[None], to_out.to(DEV))
+    assert got.shape == (1, n)
+    assert float((got[0].cpu().double() - ref).abs().max()) <= 5e-5
