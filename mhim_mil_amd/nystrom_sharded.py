@@ -330,12 +330,16 @@ class ShardedPPEGFn(torch.autograd.Function):
         L.check(lib.mhimx_ppeg_combine(NY._st(), NY._ptr(w7.contiguous()), NY._ptr(w5.contiguous()), NY._ptr(w3.contiguous()), NY._ptr(b7),
                                        NY._ptr(b5), NY._ptr(b3), Cc, NY._ptr(wc), NY._ptr(bc)), "ppeg_combine")
         xb = pl.fetch(x)
-        y = x.clone()                                                                    # (pass-through rows; the token rows are overwritten)
         if pl.band is not None:
             t0, t1, t1e, cell0, ncell = pl.band
             bd = L.PpegBand(H=pl.H, cell0=cell0, ncell=ncell, out0=t0, out1=t1)
             r0 = pl.skip + t0 - comm.rank * Tr                                           # block row of token t0
+            y = torch.empty_like(x)
+            y[:r0].copy_(x[:r0])                                                         # the rows that are not tokens pass through
+            y[r0 + (t1 - t0):].copy_(x[r0 + (t1 - t0):])
             L.check(lib.mhimx_ppeg_band_fwd(NY._st(), NY._ptr(xb), C.byref(bd), Cc, NY._ptr(wc), NY._ptr(bc), NY._ptr(y, r0 * Cc)), "ppeg_band_fwd")
+        else:
+            y = x.clone()
         ctx.saved = (xb, wc)
         ctx.cfg = (pl, comm, Tr, Cc)
         return y
@@ -349,7 +353,13 @@ class ShardedPPEGFn(torch.autograd.Function):
         dy = dy.contiguous()
         dev = dy.device
         dyb = pl.fetch(dy)
-        dx = dy.clone()                                                                  # pass-through rows
+        if pl.band is not None:                                                          # pass-through rows (the token rows are written below)
+            r0_, nt_ = pl.skip + pl.band[0] - comm.rank * Tr, pl.band[1] - pl.band[0]
+            dx = torch.empty_like(dy)
+            dx[:r0_].copy_(dy[:r0_])
+            dx[r0_ + nt_:].copy_(dy[r0_ + nt_:])
+        else:
+            dx = dy.clone()
         add = pl.wrapN - pl.n_tok
         dxw = torch.zeros((add, Cc), device=dev) if add else None
         dwc, dbc = torch.zeros((Cc, 49), device=dev), torch.zeros(Cc, device=dev)

@@ -58,6 +58,25 @@ class ExchangePlan:
         self.Tr, self.comm = Tr, comm
 
 
+class IdentityPlan:
+    """ExchangePlan for tokens in BAG order (the teacher: token j = bag row j): everything follows from the shard bounds on the host - no
+    device work, no read-back - and what a rank receives is ONE contiguous run of its block (sources ascending = positions ascending)."""
+
+    def __init__(self, N, bounds, pad, Tr, comm):
+        W, r = comm.world, comm.rank
+
+        def overlap(q, d):                                   # rows of shard q whose sequence position falls into block d
+            lo, hi = max(pad + 1 + bounds[q], d * Tr), min(pad + 1 + bounds[q + 1], (d + 1) * Tr)
+            return max(hi - lo, 0)
+
+        self.send_counts = [overlap(r, d) for d in range(W)]
+        self.recv_counts = [overlap(q, r) for q in range(W)]
+        a = max(pad + 1, r * Tr)
+        self.run = (a - r * Tr, a - r * Tr + sum(self.recv_counts))      # block rows [start, end) the received rows fill, in order
+        self.place = None
+        self.Tr, self.comm = Tr, comm
+
+
 class _AssembleTokens(torch.autograd.Function):
     """This rank's block [Tr, E] of the token sequence: its share of the exchanged rows (``rows_local``: my rows in ascending token order)
     and - ``tail`` [k, E], replicated, sequence rows tail_pos .. tail_pos + k - 1 - the tail rows the block owns.  Everything else is zero
@@ -68,9 +87,16 @@ class _AssembleTokens(torch.autograd.Function):
         comm, Tr = plan.comm, plan.Tr
         E = rows_local.shape[1]
         got = _all_to_all_rows(comm, rows_local.contiguous(), plan.send_counts, plan.recv_counts)
-        block = torch.zeros((Tr, E), device=rows_local.device)
-        if got.shape[0]:
-            block.index_copy_(0, plan.place, got)
+        if plan.place is None:                               # bag order: one contiguous run
+            a, b = plan.run
+            block = torch.empty((Tr, E), device=rows_local.device)
+            block[:a].zero_()
+            block[b:].zero_()
+            block[a:b].copy_(got)
+        else:
+            block = torch.zeros((Tr, E), device=rows_local.device)
+            if got.shape[0]:
+                block.index_copy_(0, plan.place, got)
         own = None
         if tail is not None:
             k = tail.shape[0]
@@ -87,7 +113,10 @@ class _AssembleTokens(torch.autograd.Function):
     def backward(ctx, dblock):
         plan, comm = ctx.plan, ctx.plan.comm
         dblock = dblock.contiguous()
-        dgot = dblock.index_select(0, plan.place) if plan.place.numel() else dblock[:0]
+        if plan.place is None:
+            dgot = dblock[plan.run[0]:plan.run[1]]
+        else:
+            dgot = dblock.index_select(0, plan.place) if plan.place.numel() else dblock[:0]
         drows = _all_to_all_rows(comm, dgot, plan.recv_counts, plan.send_counts)
         dtail = None
         if ctx.tail_shape is not None:
@@ -158,7 +187,7 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
         else:
             Ht = t._feature(x, None, p, mix(1))
         pad_t, T_t, Tr_t = seq_layout(N, W)
-        plan_t = ExchangePlan(torch.arange(N, device=dev), bounds, pad_t, Tr_t, cm)
+        plan_t = IdentityPlan(N, bounds, pad_t, Tr_t, cm)
         blk = _AssembleTokens.apply(Ht, None, plan_t, 0)
         del Ht
         t_feat, attn, v = sharded_sattention(t.online_encoder, blk, pad_t, 1 + N, cm, return_attn=True, seeds=(mix(2), mix(3)),
