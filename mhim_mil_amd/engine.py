@@ -33,7 +33,7 @@ class CommonMIL:
         # bag of a shape is captured (into buffers of its own: the bag is copied in, one launch), every later one replays; other shapes
         # run eagerly as before.  MHIM(ABMIL), one process, accumulation_steps == 1, no HAM-ratio schedule (its launch shapes change per iteration).
         self.graph_cache = int(graph_cache)
-        self._graphs, self._seen = {}, {}
+        self._graphs, self._seen, self._arena = {}, {}, None
 
     def _native_step(self, tr, bag, label, n_iter, extra):
         """The native forward + backward of one bag: a replay of the shape's captured graph when there is one (graph_cache), else eager."""
@@ -53,7 +53,12 @@ class CommonMIL:
                 return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
             if len(self._graphs) >= self.graph_cache:          # the oldest shape makes room
                 self._graphs.pop(next(iter(self._graphs)))
-            xs, ls = torch.empty_like(x), torch.empty_like(label)
+            # the graphs never run concurrently: they share ONE bag buffer (the largest bag seen so far; a bigger bag gets a new one and the
+            # older graphs keep theirs) - a cache of thousands of shapes (every bag of a dataset from its second epoch on) costs host memory only
+            need = x.numel()
+            if self._arena is None or self._arena.numel() < need or self._arena.dtype != x.dtype or self._arena.device != x.device:
+                self._arena = torch.empty(need, dtype=x.dtype, device=x.device)
+            xs, ls = self._arena[:need].view(x.shape), torch.empty_like(label)
             if tr._cap_stream is None:
                 tr._cap_stream = torch.cuda.Stream()
             if tr._graph_pool is None:

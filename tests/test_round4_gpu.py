@@ -452,6 +452,7 @@ def test_common_mil_graph_cache_replays_the_native_step():
 
     a, sa, ta, eng = run(2)
     assert len(eng._graphs) == 1 and eng._seen[next(iter(eng._graphs))] == 2
+    assert eng._arena is not None and eng._arena.numel() == N * D                 # (the graphs' shared bag buffer: the largest bag captured)
     b, sb, tb, _ = run(0)
     for (la, pa, ka), (lb_, pb, kb) in zip(a, b):
         assert pa == pb and ka == kb
@@ -459,3 +460,34 @@ def test_common_mil_graph_cache_replays_the_native_step():
             assert la == lb_, (la, lb_)
     # the other-shaped bag ran eagerly in both runs but with different host seeds (run b's counters were rewound): compare the bags up to it
     assert [x[0] for x in a[:3]] == [x[0] for x in b[:3]]
+
+
+def test_common_mil_graph_cache_many_shapes_share_one_bag_buffer():
+    """A dataset of bags of different sizes under graph_cache: every shape is captured at its second visit (one shared bag buffer: the graphs
+    never run concurrently), replayed from the third on; the oldest shape leaves when the cache is full."""
+    import types
+    from mhim_mil_amd.engine import CommonMIL
+    from mhim_mil_amd.optim import FusedAdamEMA
+    args = types.SimpleNamespace(model="mhim", baseline="attn", aux_alpha=0.5, main_alpha=1.0)
+    crit = torch.nn.CrossEntropyLoss()
+    s, t = _models()
+    opt = FusedAdamEMA(s, t, lr=2e-4, weight_decay=1e-5, mm=0.999)
+    eng = CommonMIL(args, fused=opt, graph_cache=2)
+    sizes = [N, N - 160, N - 320]
+    bags = [torch.from_numpy(synth.bag(4300 + i, n, D)).to(DEV)[None] for i, n in enumerate(sizes)]
+    w0 = s.feature[0].weight.detach().clone()
+    losses = []
+    for epoch in range(3):
+        for x in bags:
+            label = torch.tensor([epoch % 2], device=DEV)
+            logits, lb, aux, pn, kn, _, _ = eng.forward_func(args, s, t, x, label, crit, 1, epoch, 0, epoch, None)
+            assert pn == x.shape[1]
+            loss = args.main_alpha * crit(logits.view(1, -1), lb) + args.aux_alpha * aux
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and len(eng._graphs) == 2                       # three shapes, room for two
+    assert eng._arena.numel() == N * D and all(e[1].data_ptr() == eng._arena.data_ptr() for e in eng._graphs.values())
+    assert float((s.feature[0].weight.detach() - w0).abs().max()) > 0
