@@ -33,57 +33,15 @@ class CommonMIL:
         # bag of a shape is captured (into buffers of its own: the bag is copied in, one launch), every later one replays; other shapes
         # run eagerly as before.  MHIM(ABMIL), one process, accumulation_steps == 1, no HAM-ratio schedule (its launch shapes change per iteration).
         self.graph_cache = int(graph_cache)
-        self._graphs, self._seen, self._arena = {}, {}, None
 
     def _native_step(self, tr, bag, label, n_iter, extra):
         """The native forward + backward of one bag: a replay of the shape's captured graph when there is one (graph_cache), else eager."""
-        x = bag[0] if bag.dim() == 3 else bag
-        # (ABMIL only: the TransMIL / DSMIL students run autograd nodes, whose streams a capture without a warm-up on its own stream cannot take)
-        ok = (self.graph_cache > 0 and not extra and tr.accum == 1 and tr.world == 1 and tr.s.mrh_sche is None and x.is_cuda
-              and not tr._capturing and tr.s.baseline == "attn")
-        if not ok:
-            logits, losses = tr.forward_backward(bag, label, i=n_iter, **extra)
-            return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
-        key = (tuple(x.shape), x.dtype, x.device.index)
-        ent = self._graphs.get(key)
-        if ent is None:
-            self._seen[key] = self._seen.get(key, 0) + 1
-            if self._seen[key] < 2:                            # first bag of the shape: eager (it also is the kernels' warm-up)
-                logits, losses = tr.forward_backward(bag, label, i=n_iter)
-                return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
-            if len(self._graphs) >= self.graph_cache:          # the oldest shape makes room
-                self._graphs.pop(next(iter(self._graphs)))
-            # the graphs never run concurrently: they share ONE bag buffer (the largest bag seen so far; a bigger bag gets a new one and the
-            # older graphs keep theirs) - a cache of thousands of shapes (every bag of a dataset from its second epoch on) costs host memory only
-            need = x.numel()
-            if self._arena is None or self._arena.numel() < need or self._arena.dtype != x.dtype or self._arena.device != x.device:
-                self._arena = torch.empty(need, dtype=x.dtype, device=x.device)
-            xs, ls = self._arena[:need].view(x.shape), torch.empty_like(label)
-            if tr._cap_stream is None:
-                tr._cap_stream = torch.cuda.Stream()
-            if tr._graph_pool is None:
-                tr._graph_pool = torch.cuda.graph_pool_handle()
-            cs = tr._cap_stream
-            cs.wait_stream(torch.cuda.current_stream())
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            micro = tr._micro
-            tr._capturing = True
-            try:
-                with torch.cuda.graph(g, pool=tr._graph_pool, stream=cs):      # (recorded, not run: the replay below is this bag's step)
-                    logits, losses = tr.forward_backward(xs, ls, i=n_iter)
-            finally:
-                tr._capturing = False
-            ops.step_images(None)
-            tr._micro = micro
-            ent = self._graphs[key] = (g, xs, ls, logits, losses, tr.last["patch_num"], tr.last["keep_num"], dict(tr.last))
-        g, xs, ls, logits, losses, pn, kn, last = ent
-        xs.copy_(x)
-        ls.copy_(label)
-        g.replay()
-        tr._micro += 1
-        tr.last = last
-        return logits, losses, pn, kn
+        if self.graph_cache > 0 and not extra:
+            out = tr.shape_cached("forward_backward", bag, label, i=n_iter, cache=self.graph_cache)
+            if out is not None:
+                return out
+        logits, losses = tr.forward_backward(bag, label, i=n_iter, **extra)
+        return logits, losses, tr.last["patch_num"], tr.last["keep_num"]
 
     def init_func_train(self, args, **kwargs):
         self.training = True
@@ -999,6 +957,67 @@ class FusedTrainer:
             return g
         finally:
             self._capturing = False
+
+    def shape_cached(self, what, bag, label, i=None, cache=64):
+        """``what`` = 'forward_backward' or 'train_step' on ``bag`` through a cache of captured hipGraphs keyed by the bag's SHAPE: the first
+        bag of a shape runs eagerly (it is the kernels' warm-up), the second is captured - into buffers of the graph's own: the bag is copied
+        into ONE buffer all the graphs share (they never run concurrently; so do they their memory pool), one launch - and replayed, every later
+        one replays.  A dataset of bags of many sizes replays from its second epoch on.  The draw / dropout streams advance through the device
+        step counter: replays draw fresh masks.  MHIM(ABMIL) (the TransMIL / DSMIL students run autograd nodes whose streams a capture without
+        a warm-up of its own cannot take), one process, accumulation_steps == 1, no HAM-ratio schedule.  Returns (logits, losses, patch_num,
+        keep_num) - the graph's static output buffers: read them before the next call - or None when the step cannot be cached (run it
+        eagerly)."""
+        x = bag[0] if bag.dim() == 3 else bag
+        if not (self.accum == 1 and self.world == 1 and self.s.mrh_sche is None and x.is_cuda and not self._capturing
+                and self.s.baseline == "attn" and self._micro == 0):
+            return None
+        st = getattr(self, "_shape_graphs", None)
+        if st is None:
+            st = self._shape_graphs = {"graphs": {}, "seen": {}, "arena": None}
+        key = (what, tuple(x.shape), x.dtype, x.device.index)
+        ent = st["graphs"].get(key)
+        fn = self.train_step if what == "train_step" else self.forward_backward
+        if ent is None:
+            st["seen"][key] = st["seen"].get(key, 0) + 1
+            if st["seen"][key] < 2:
+                logits, losses = fn(bag, label, i=i)
+                return logits, losses, self.last["patch_num"], self.last["keep_num"]
+            while len(st["graphs"]) >= max(1, int(cache)):        # the oldest shape makes room
+                st["graphs"].pop(next(iter(st["graphs"])))
+            need = x.numel()
+            ar = st["arena"]
+            if ar is None or ar.numel() < need or ar.dtype != x.dtype or ar.device != x.device:
+                ar = st["arena"] = torch.empty(need, dtype=x.dtype, device=x.device)
+            xs, ls = ar[:need].view(x.shape), torch.empty_like(label)
+            if self._cap_stream is None:
+                self._cap_stream = torch.cuda.Stream()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            cs = self._cap_stream
+            cs.wait_stream(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            micro, host_step = self._micro, self.flat.step
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):      # (recorded, not run: the replay below is this bag's step)
+                    logits, losses = fn(xs, ls, i=i)
+            finally:
+                self._capturing = False
+            ops.step_images(None)
+            self._micro, self.flat.step = micro, host_step
+            ent = st["graphs"][key] = (g, xs, ls, logits, losses, self.last["patch_num"], self.last["keep_num"], dict(self.last))
+        g, xs, ls, logits, losses, pn, kn, last = ent
+        xs.copy_(x)
+        ls.copy_(label)
+        g.replay()
+        if what == "train_step":
+            self.flat.step += 1                                # (the host's count of updates: the device counter advanced in the graph)
+            ops.step_images(None)
+        else:
+            self._micro += 1
+        self.last = last
+        return logits, losses, pn, kn
 
     def train_step(self, bag, label, **kw):
         # (a step that is followed by its update right here may leave its last reductions to the update kernel: _nat_bag)

@@ -451,8 +451,9 @@ def test_common_mil_graph_cache_replays_the_native_step():
         return out, {k: v.detach().clone() for k, v in s.state_dict().items()}, {k: v.detach().clone() for k, v in t.state_dict().items()}, eng
 
     a, sa, ta, eng = run(2)
-    assert len(eng._graphs) == 1 and eng._seen[next(iter(eng._graphs))] == 2
-    assert eng._arena is not None and eng._arena.numel() == N * D                 # (the graphs' shared bag buffer: the largest bag captured)
+    sg = eng.fused.trainer._shape_graphs
+    assert len(sg["graphs"]) == 1 and sg["seen"][next(iter(sg["graphs"]))] == 2
+    assert sg["arena"] is not None and sg["arena"].numel() == N * D               # (the graphs' shared bag buffer: the largest bag captured)
     b, sb, tb, _ = run(0)
     for (la, pa, ka), (lb_, pb, kb) in zip(a, b):
         assert pa == pb and ka == kb
@@ -488,6 +489,40 @@ def test_common_mil_graph_cache_many_shapes_share_one_bag_buffer():
             opt.zero_grad()
             losses.append(float(loss.detach()))
     torch.cuda.synchronize()
-    assert all(np.isfinite(losses)) and len(eng._graphs) == 2                       # three shapes, room for two
-    assert eng._arena.numel() == N * D and all(e[1].data_ptr() == eng._arena.data_ptr() for e in eng._graphs.values())
+    sg = opt.trainer._shape_graphs
+    assert all(np.isfinite(losses)) and len(sg["graphs"]) == 2                    # three shapes, room for two
+    assert sg["arena"].numel() == N * D and all(e[1].data_ptr() == sg["arena"].data_ptr() for e in sg["graphs"].values())
     assert float((s.feature[0].weight.detach() - w0).abs().max()) > 0
+
+
+def test_trainer_shape_cached_train_step_equals_eager_steps_with_the_capture_seeds():
+    """FusedTrainer.shape_cached('train_step'): complete steps (update and folded reductions included) replayed per bag shape."""
+    from mhim_mil_amd.engine import FusedTrainer
+    bags = [torch.from_numpy(synth.bag(4400 + i, N, D)).to(DEV) for i in range(5)]
+
+    def run(cached):
+        torch.manual_seed(13)
+        s, t = _models()
+        tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
+        out, frozen = [], None
+        for step, x in enumerate(bags):
+            label = torch.tensor([step % 2], device=DEV)
+            if cached:
+                lg, ls, pn, kn = tr.shape_cached("train_step", x, label, cache=4)
+            else:
+                if step == 1:
+                    frozen = (s._step, t._step)
+                if step >= 1:
+                    s._step, t._step = frozen
+                lg, ls = tr.train_step(x, label)
+            out.append((lg.cpu().clone(), ls.cpu().clone()))
+        torch.cuda.synchronize()
+        return out, {k: v.detach().cpu().clone() for k, v in s.state_dict().items()}, tr
+
+    a, sa, tra = run(True)
+    b, sb, trb = run(False)
+    assert tra.flat.step == trb.flat.step == len(bags)
+    for (la, sa_), (lb, sb_) in zip(a, b):
+        assert torch.equal(la, lb) and torch.equal(sa_, sb_)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
