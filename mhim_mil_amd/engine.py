@@ -459,13 +459,14 @@ class FusedTrainer:
         (the reference's student projects all N rows before it masks, mhim.py:335-336); the rows stay in bag order and the scorer,
         Merge, their backwards and the projection's weight-gradient GEMM gather the rows that take part by index."""
         first = self._micro == 0
-        res = self._nat_prep([x], i, with_opt_tick=first, split=self.ride_prep)
-        prep_t, preps = res[0], res[1]
-        preps[0]["_ride_jobs"] = res[2] if len(res) > 2 else None
-        hook = self._mid_hook if (first and self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1
-                                  and not self._capturing and self._split > 0) else None
-        out = self._nat_bag(x, label, prep_t, preps[0], self.flat.grad_views, accumulate=not first, perm=perm, ids_shuffle=ids_shuffle,
-                            i=i, mid_hook=hook)
+        with ops.pinned_stream():                              # (one bag, one stream: the launches' stream is looked up once)
+            res = self._nat_prep([x], i, with_opt_tick=first, split=self.ride_prep)
+            prep_t, preps = res[0], res[1]
+            preps[0]["_ride_jobs"] = res[2] if len(res) > 2 else None
+            hook = self._mid_hook if (first and self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1
+                                      and not self._capturing and self._split > 0) else None
+            out = self._nat_bag(x, label, prep_t, preps[0], self.flat.grad_views, accumulate=not first, perm=perm, ids_shuffle=ids_shuffle,
+                                i=i, mid_hook=hook)
         self._micro += 1
         return out
 

@@ -19,8 +19,28 @@ from . import _lib as L
 KERNEL_EVENT_HOOK = None
 
 
+_STREAM_PIN = None
+
+
 def _stream():
+    if _STREAM_PIN is not None:
+        return _STREAM_PIN
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class pinned_stream:
+    """``with ops.pinned_stream():`` - every launch inside goes to the stream that is current at entry, looked up ONCE (a step's ~20 launches
+    each asked torch for it: ~4 us of host time apiece, and the eager step is host-bound).  Only around code that does not switch streams."""
+
+    def __enter__(self):
+        global _STREAM_PIN
+        self._old = _STREAM_PIN
+        _STREAM_PIN = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return self
+
+    def __exit__(self, *a):
+        global _STREAM_PIN
+        _STREAM_PIN = self._old
 
 
 def _p(t: Optional[torch.Tensor]):
