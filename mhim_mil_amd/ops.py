@@ -48,7 +48,7 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _chk(t, dtype=torch.float32, name="tensor"):
-    if t is None:
+    if t is None or _STREAM_PIN is not None:         # (inside a trainer's pinned step every tensor is the trainer's own: the bag was checked at entry)
         return
     if not t.is_cuda:
         raise L.MhimxError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
