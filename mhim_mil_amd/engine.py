@@ -31,7 +31,7 @@ class CommonMIL:
         self.fused = fused                 # optional optim.FusedAdamEMA: forward_func may run the native forward + backward (its docstring)
         # graph_cache = K > 0 (with fused=): the native forward + backward of the K most recent bag SHAPES as captured hipGraphs - the second
         # bag of a shape is captured (into buffers of its own: the bag is copied in, one launch), every later one replays; other shapes
-        # run eagerly as before.  MHIM(ABMIL), one process, accumulation_steps == 1, no HAM-ratio schedule (its launch shapes change per iteration).
+        # run eagerly as before.  MHIM(ABMIL), one process, accumulation_steps == 1 (FusedTrainer.shape_cached).
         self.graph_cache = int(graph_cache)
 
     def _native_step(self, tr, bag, label, n_iter, extra):
@@ -965,17 +965,20 @@ class FusedTrainer:
         into ONE buffer all the graphs share (they never run concurrently; so do they their memory pool), one launch - and replayed, every later
         one replays.  A dataset of bags of many sizes replays from its second epoch on.  The draw / dropout streams advance through the device
         step counter: replays draw fresh masks.  MHIM(ABMIL) (the TransMIL / DSMIL students run autograd nodes whose streams a capture without
-        a warm-up of its own cannot take), one process, accumulation_steps == 1, no HAM-ratio schedule.  Returns (logits, losses, patch_num,
+        a warm-up of its own cannot take), one process, accumulation_steps == 1 (a HAM-ratio schedule's row counts are part of the key).  Returns (logits, losses, patch_num,
         keep_num) - the graph's static output buffers: read them before the next call - or None when the step cannot be cached (run it
         eagerly)."""
         x = bag[0] if bag.dim() == 3 else bag
-        if not (self.accum == 1 and self.world == 1 and self.s.mrh_sche is None and x.is_cuda and not self._capturing
-                and self.s.baseline == "attn" and self._micro == 0):
+        if not (self.accum == 1 and self.world == 1 and x.is_cuda and not self._capturing and self.s.baseline == "attn" and self._micro == 0):
+            return None
+        # (a HAM-ratio schedule, --mrh_sche, changes the row counts - the launch shapes - every few hundred iterations: they are part of the key)
+        counts = self.s.v2_counts(x.shape[0], i) if (self.model_kind == "mhim" and self.s.mrh_sche is not None) else None
+        if self.model_kind == "mhim" and self.s.mrh_sche is not None and counts is None:
             return None
         st = getattr(self, "_shape_graphs", None)
         if st is None:
             st = self._shape_graphs = {"graphs": {}, "seen": {}, "arena": None}
-        key = (what, tuple(x.shape), x.dtype, x.device.index)
+        key = (what, tuple(x.shape), x.dtype, x.device.index, counts)
         ent = st["graphs"].get(key)
         fn = self.train_step if what == "train_step" else self.forward_backward
         if ent is None:

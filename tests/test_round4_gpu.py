@@ -526,3 +526,23 @@ def test_trainer_shape_cached_train_step_equals_eager_steps_with_the_capture_see
         assert torch.equal(la, lb) and torch.equal(sa_, sb_)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_shape_cached_follows_a_ham_ratio_schedule():
+    """--mrh_sche: the row counts change when the scheduled ratio crosses a rounding boundary; they are part of the cache key, so every
+    plateau of the schedule gets its own graph and the masked / kept counts follow the schedule."""
+    from mhim_mil_amd.engine import FusedTrainer
+    s, t = _models()
+    s.mrh_sche = [0.03, 0.03, 0.03, 0.02, 0.02, 0.02, 0.0295]
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.999)
+    keeps = []
+    for step in range(len(s.mrh_sche)):
+        x = torch.from_numpy(synth.bag(4500 + step, N, D)).to(DEV)
+        out = tr.shape_cached("train_step", x, torch.tensor([step % 2], device=DEV), i=step, cache=4)
+        assert out is not None and bool(torch.isfinite(out[1]).all())
+        keeps.append(out[3])
+        assert out[3] == s.v2_counts(N, step)[3] + s.merge.k
+    torch.cuda.synchronize()
+    assert keeps[0] == keeps[2] and keeps[3] == keeps[5] and keeps[0] != keeps[3]
+    assert len(tr._shape_graphs["graphs"]) == 2                     # one per plateau seen twice (the last ratio was seen once: eager)
+    assert tr.flat.step == len(s.mrh_sche)
