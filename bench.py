@@ -76,6 +76,19 @@ def make_models(dev, prec):
     return mk(base), mk(base), base           # teacher = deepcopy(student) at init (modules/__init__.py:176-214)
 
 
+def cpu_model():
+    """The host CPU's model string ("print CPU model and core count")."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(steps, base):
     """The oracle (a port of the reference's math; the reference itself cannot travel) on the host cores."""
     import numpy as np
@@ -111,7 +124,7 @@ def cpu_baseline(steps, base):
         if time.perf_counter() - t0 > 15.0:
             break
     dt = time.perf_counter() - t0
-    return {"value": N_INST * done / dt, "unit": "patch-instances/s", "cores": cores, "kind": "port",
+    return {"value": N_INST * done / dt, "unit": "patch-instances/s", "cores": cores, "cpu_model": cpu_model(), "host_threads": ncpu, "kind": "port",
             "sample": f"{done} oracle train steps (torch CPU fp32, {cores} threads = best of an 8/16/32/64 sweep on a "
                       f"{ncpu}-thread host, dropout 0.25 drawn by torch) on one N={N_INST} D={D_IN} bag, {dt:.1f} s"}
 
@@ -128,11 +141,19 @@ def cpu_baseline_other(workload, base, n, d, bl):
     perm, shuf = synth.permutation(1, k), synth.permutation(2, n - n_sel)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    opt = {}
     t0 = time.perf_counter()
-    O.train_step(x, 1, stu, tea, {}, cfg, 1, perm=perm, ids_shuffle=shuf)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "patch-instances/s", "cores": cores, "kind": "port",
-            "sample": f"1 oracle train step (torch CPU fp32, {cores} threads, dropout 0.25 drawn by torch, no warm-up) on one N={n} D={d} bag, {dt:.1f} s"}
+    stu, tea, opt, _ = O.train_step(x, 1, stu, tea, opt, cfg, 1, perm=perm, ids_shuffle=shuf)     # warm-up (untimed)
+    warm = time.perf_counter() - t0
+    # a bounded sample: three timed steps unless one step already takes more than ~8 s (then as many as fit ~20 s, at least one)
+    n_timed = 3 if warm < 8.0 else max(1, int(20.0 // warm))
+    t0 = time.perf_counter()
+    for q in range(n_timed):
+        stu, tea, opt, _ = O.train_step(x, q % 2, stu, tea, opt, cfg, q + 2, perm=perm, ids_shuffle=shuf)
+    dt = (time.perf_counter() - t0) / n_timed
+    return {"value": n / dt, "unit": "patch-instances/s", "cores": cores, "cpu_model": cpu_model(), "host_threads": os.cpu_count() or 1, "kind": "port",
+            "sample": f"{n_timed} oracle train steps after one warm-up step (torch CPU fp32, {cores} threads, dropout 0.25 drawn by torch) on one "
+                      f"N={n} D={d} bag, {dt:.1f} s per step"}
 
 
 def timed(a, world, dev, step):

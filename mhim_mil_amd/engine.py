@@ -152,7 +152,9 @@ class FlatState:
                 self.n_train = off
         self.n_all = (off + 63) // 64 * 64         # (a multiple of every world size up to 64: the mesh form of the gradient exchange -
         self.student = self._adopt(student, dev)   #  reduce-scatter + all-gather on count / world slices - takes the whole buffer)
-        self.teacher = self._adopt(teacher, dev) if teacher is not None else None
+        # --tea_type same (modules/__init__.py:211-212: the teacher IS the student; base_engine.py:157-158: no EMA): one buffer, adopted once
+        self.same_teacher = teacher is not None and teacher is student
+        self.teacher = self.student if self.same_teacher else (self._adopt(teacher, dev) if teacher is not None else None)
         self.grad = torch.zeros(self.n_all, device=dev)
         self.m = torch.zeros(self.n_train, device=dev)
         self.v = torch.zeros(self.n_train, device=dev)
@@ -342,8 +344,7 @@ class FusedTrainer:
         # (kept on the launch stream: a parallel branch in the captured hipGraph costs ~60 us of cross-queue signalling on
         # ROCm 7.2 — measured, profiles/ r01 notes — against ~40 us of kernels it would hide)
         # together with the two device counters (dropout stream position, Adam step) it is ONE launch
-        if self.single_pass and s.baseline == "attn" and s.bag_ordered_ok(x) and (self.model_kind != "mhim" or (
-                t is not None and t.bag_ordered_ok(x) and not t.merge_test and s.merge_enable and s.v2_counts(x.shape[0], i) is not None)):
+        if self._nat_ok(x, i):
             return self._forward_backward_nat(x, label, perm, ids_shuffle, i)
         prep_s = prep_t = None
         jobs = [(ops.PREP_TICK, None, self.tick)]
@@ -454,11 +455,21 @@ class FusedTrainer:
         self.last = {"logits": logits, "losses": losses, "patch_num": ps, "keep_num": keep_num}
         return logits, losses
 
+    def _nat_ok(self, x, i=None):
+        """True when the bag takes the single-pass ABMIL step (_forward_backward_nat): no host read-back anywhere, fixed launch shapes."""
+        s, t = self.s, self.t
+        return bool(self.single_pass and s.baseline == "attn" and s.bag_ordered_ok(x) and (self.model_kind != "mhim" or (
+            t is not None and t.bag_ordered_ok(x) and not t.merge_test and s.merge_enable and s.v2_counts(x.shape[0], i) is not None)))
+
     def _forward_backward_nat(self, x, label, perm, ids_shuffle, i):
         """The single-pass ABMIL step: ONE projection launch computes the teacher's and the student's feature rows from the raw bag
         (the reference's student projects all N rows before it masks, mhim.py:335-336); the rows stay in bag order and the scorer,
         Merge, their backwards and the projection's weight-gradient GEMM gather the rows that take part by index."""
         first = self._micro == 0
+        # caller-supplied tensors are validated HERE: inside the pinned step the wrappers skip their argument checks (ops._chk)
+        for tns, nm in ((label, "label"), (perm, "perm"), (ids_shuffle, "ids_shuffle")):
+            if torch.is_tensor(tns) and not (tns.is_cuda and tns.dtype == torch.int64 and tns.is_contiguous() and tns.device == x.device):
+                raise mh.L.MhimxError(f"{nm}: expected a contiguous int64 tensor on the bag's device ({x.device}), got {tns.dtype} on {tns.device}")
         with ops.pinned_stream():                              # (one bag, one stream: the launches' stream is looked up once)
             res = self._nat_prep([x], i, with_opt_tick=first, split=self.ride_prep)
             prep_t, preps = res[0], res[1]
@@ -864,7 +875,7 @@ class FusedTrainer:
         # through update() (an eval forward between replays picked up images of the pre-update weights)
         ops.step_images(None)
         fl.step += 1                                   # (the device-side counter was advanced by the step's prep launch)
-        ops.optim_step(fl.student, fl.grad, fl.m, fl.v, fl.teacher if self.model_kind == "mhim" else None, fl.n_train,
+        ops.optim_step(fl.student, fl.grad, fl.m, fl.v, fl.teacher if (self.model_kind == "mhim" and not fl.same_teacher) else None, fl.n_train,
                        fl.step, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
                        grad_scale=scale, ema_mm=self.mm, zero_grad=True, step_dev=self.opt_step, mm_table=self.mm_table,
                        lr_table=self.lr_table, g_extra=self._g_extra, clip_norm=self.clip_grad, ws=self._clip_ws, fold=self._fold_list)
@@ -964,21 +975,27 @@ class FusedTrainer:
         bag of a shape runs eagerly (it is the kernels' warm-up), the second is captured - into buffers of the graph's own: the bag is copied
         into ONE buffer all the graphs share (they never run concurrently; so do they their memory pool), one launch - and replayed, every later
         one replays.  A dataset of bags of many sizes replays from its second epoch on.  The draw / dropout streams advance through the device
-        step counter: replays draw fresh masks.  MHIM(ABMIL) (the TransMIL / DSMIL students run autograd nodes whose streams a capture without
-        a warm-up of its own cannot take), one process, accumulation_steps == 1 (a HAM-ratio schedule's row counts are part of the key).  Returns (logits, losses, patch_num,
-        keep_num) - the graph's static output buffers: read them before the next call - or None when the step cannot be cached (run it
-        eagerly)."""
+        step counter: replays draw fresh masks.  Only the single-pass ABMIL step is cached (``_nat_ok``: no host read-back, fixed launch
+        shapes - a v1 mask ratio or a shape the one-pass kernels do not take runs eagerly), one process, accumulation_steps == 1.  The key
+        holds everything a capture bakes in on the host: shape, the HAM-ratio schedule's row counts, the models' train / eval state, the
+        Merge switch, the loss weights and - for 'train_step' - the optimiser's scalars.  ``cache``: the K most recently USED shapes stay.
+        Returns (logits, losses, patch_num, keep_num) - the graph's static output buffers: read them before the next call - or None when
+        the step cannot be cached (run it eagerly)."""
         x = bag[0] if bag.dim() == 3 else bag
-        if not (self.accum == 1 and self.world == 1 and x.is_cuda and not self._capturing and self.s.baseline == "attn" and self._micro == 0):
+        s, t = self.s, self.t
+        if not (self.accum == 1 and self.world == 1 and x.is_cuda and x.dim() == 2 and not self._capturing and self._micro == 0
+                and self._nat_ok(x, i)):
             return None
         # (a HAM-ratio schedule, --mrh_sche, changes the row counts - the launch shapes - every few hundred iterations: they are part of the key)
-        counts = self.s.v2_counts(x.shape[0], i) if (self.model_kind == "mhim" and self.s.mrh_sche is not None) else None
-        if self.model_kind == "mhim" and self.s.mrh_sche is not None and counts is None:
-            return None
+        counts = s.v2_counts(x.shape[0], i) if self.model_kind == "mhim" else None
         st = getattr(self, "_shape_graphs", None)
         if st is None:
-            st = self._shape_graphs = {"graphs": {}, "seen": {}, "arena": None}
-        key = (what, tuple(x.shape), x.dtype, x.device.index, counts)
+            st = self._shape_graphs = {"graphs": {}, "seen": {}, "arena": None, "bad": set()}
+        key = (what, tuple(x.shape), x.dtype, x.device.index, counts, s.training, None if t is None else t.training, s.merge_enable,
+               float(self.main_alpha), float(self.aux_alpha), tuple(label.shape),
+               (float(self.lr), tuple(self.betas), float(self.eps), float(self.wd), float(self.mm)) if what == "train_step" else None)
+        if key in st["bad"]:
+            return None
         ent = st["graphs"].get(key)
         fn = self.train_step if what == "train_step" else self.forward_backward
         if ent is None:
@@ -986,7 +1003,7 @@ class FusedTrainer:
             if st["seen"][key] < 2:
                 logits, losses = fn(bag, label, i=i)
                 return logits, losses, self.last["patch_num"], self.last["keep_num"]
-            while len(st["graphs"]) >= max(1, int(cache)):        # the oldest shape makes room
+            while len(st["graphs"]) >= max(1, int(cache)):        # the least recently used shape makes room
                 st["graphs"].pop(next(iter(st["graphs"])))
             need = x.numel()
             ar = st["arena"]
@@ -1006,11 +1023,22 @@ class FusedTrainer:
             try:
                 with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):      # (recorded, not run: the replay below is this bag's step)
                     logits, losses = fn(xs, ls, i=i)
+            except Exception:
+                # a step that turned out not to be capturable (a host read-back somewhere): this shape runs eagerly from now on
+                st["bad"].add(key)
+                self._micro, self.flat.step = micro, host_step
+                self._fold_list = None
+                self._defer = ops.ReduceList()
+                ops.step_images(None)
+                torch.cuda.synchronize()
+                return None
             finally:
                 self._capturing = False
             ops.step_images(None)
             self._micro, self.flat.step = micro, host_step
             ent = st["graphs"][key] = (g, xs, ls, logits, losses, self.last["patch_num"], self.last["keep_num"], dict(self.last))
+        else:
+            st["graphs"][key] = st["graphs"].pop(key)             # most recently used: to the end of the (insertion-ordered) dict
         g, xs, ls, logits, losses, pn, kn, last = ent
         xs.copy_(x)
         ls.copy_(label)

@@ -326,6 +326,17 @@ class MHIM(nn.Module):
             return iter(())
         return super().parameters(recurse)
 
+    def __deepcopy__(self, memo):
+        """A copy (a best-teacher snapshot, a re-built teacher) is an ordinary module: the ``_ema_owned`` mark belongs to the instance a
+        fused optimiser adopted, not to its copies (they would look parameterless to requires_grad_ / zero_grad / a second optimiser)."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, val in self.__dict__.items():
+            if key != "_ema_owned":
+                new.__dict__[key] = copy.deepcopy(val, memo)
+        return new
+
     @property
     def _bag_param_names(self):
         names = ["feature.0.weight", "feature.0.bias"]

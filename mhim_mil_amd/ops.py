@@ -19,28 +19,39 @@ from . import _lib as L
 KERNEL_EVENT_HOOK = None
 
 
-_STREAM_PIN = None
+import threading
+
+_PIN = threading.local()        # .stream (c_void_p) / .device (index): the pinned launch stream of THIS thread's trainer step
+
+
+def _pinned():
+    st = getattr(_PIN, "stream", None)
+    if st is not None and getattr(_PIN, "device", -1) == torch.cuda.current_device():
+        return st
+    return None
 
 
 def _stream():
-    if _STREAM_PIN is not None:
-        return _STREAM_PIN
+    st = _pinned()
+    if st is not None:
+        return st
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class pinned_stream:
     """``with ops.pinned_stream():`` - every launch inside goes to the stream that is current at entry, looked up ONCE (a step's ~20 launches
-    each asked torch for it: ~4 us of host time apiece, and the eager step is host-bound).  Only around code that does not switch streams."""
+    each asked torch for it: ~4 us of host time apiece, and the eager step is host-bound).  Only around code that does not switch streams.
+    The pin belongs to the calling THREAD and to the device that is current at entry: another thread, or a trainer on another device, never
+    sees it (and launches on its own current stream)."""
 
     def __enter__(self):
-        global _STREAM_PIN
-        self._old = _STREAM_PIN
-        _STREAM_PIN = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._old = (getattr(_PIN, "stream", None), getattr(_PIN, "device", -1))
+        _PIN.device = torch.cuda.current_device()
+        _PIN.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         return self
 
     def __exit__(self, *a):
-        global _STREAM_PIN
-        _STREAM_PIN = self._old
+        _PIN.stream, _PIN.device = self._old
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -48,7 +59,8 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _chk(t, dtype=torch.float32, name="tensor"):
-    if t is None or _STREAM_PIN is not None:         # (inside a trainer's pinned step every tensor is the trainer's own: the bag was checked at entry)
+    if t is None or _pinned() is not None:           # (inside a trainer's pinned step every tensor is the trainer's own: the bag, the label and
+                                                      #  injected draws were checked at entry, FusedTrainer._forward_backward_nat)
         return
     if not t.is_cuda:
         raise L.MhimxError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")

@@ -44,6 +44,12 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if not any(p.is_cuda for p in model.parameters()):
             raise ValueError("FusedAdamEMA: move the model to the GPU first (the flat buffers live where the parameters are)")
         kind = model_kind or ("mhim" if model_ema is not None else "mhim_pure")
+        # the loop indexes the momentum schedule by BAG (mm_sche[epoch * len(loader) + batch_idx], base_engine.py:161-162) and reads it at the
+        # bag that triggers the update; the update kernel indexes its table by UPDATE: with accumulation the table is the schedule at every
+        # accumulation_steps-th bag (identical when no batch is skipped)
+        acc = max(1, int(accumulation_steps))
+        if mm_sche is not None and acc > 1:
+            mm_sche = list(mm_sche)[acc - 1::acc]
         self.trainer = FusedTrainer(model, model_ema, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, mm=mm, main_alpha=main_alpha,
                                     aux_alpha=aux_alpha, accumulation_steps=accumulation_steps, model=kind, mm_sche=mm_sche)
         self.flat = self.trainer.flat
@@ -55,8 +61,21 @@ class FusedAdamEMA(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.model, self.model_ema = model, model_ema
         self._views = [(named[n], self.flat.grad_views[n]) for n in self.flat.train_names]
-        if model_ema is not None:
+        # --tea_type same (modules/__init__.py:211-212): model_ema IS model - the reference runs no EMA then (base_engine.py:157-158) and the
+        # student must keep its parameters() (the optimiser's, clip_grad's): nothing is adopted twice, nothing is hidden
+        if model_ema is not None and model_ema is not model:
             model_ema._ema_owned = True                          # base_engine.py:166-167 finds no parameter left to update
+
+    def close(self):
+        """Give the teacher its ``parameters()`` back (the fused EMA ends here): call when the optimiser is dropped."""
+        if self.model_ema is not None and getattr(self.model_ema, "_ema_owned", False):
+            self.model_ema._ema_owned = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     @torch.no_grad()
     def step(self, closure=None):

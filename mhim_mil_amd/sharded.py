@@ -323,7 +323,7 @@ class ShardedBagTrainer:
                 yield lambda: cm.all_reduce_sum(fl.grad[:fl.n_train])
 
             self.step_count += 1
-            ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher, fl.n_train, self.step_count, lr=self.lr, beta1=self.betas[0],
+            ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, None if fl.same_teacher else fl.teacher, fl.n_train, self.step_count, lr=self.lr, beta1=self.betas[0],
                          beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, grad_scale=1.0, ema_mm=self.mm, zero_grad=True,
                          step_dev=self.opt_step)
         finally:
@@ -475,7 +475,7 @@ class ShardedBagTrainer:
         # ---- optimiser + EMA teacher (replicated, identical inputs on every rank)
         self.step_count += 1
         ops.tick(self.opt_step)
-        ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher, fl.n_train, self.step_count, lr=self.lr, beta1=self.betas[0],
+        ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, None if fl.same_teacher else fl.teacher, fl.n_train, self.step_count, lr=self.lr, beta1=self.betas[0],
                      beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, grad_scale=1.0, ema_mm=self.mm, zero_grad=True,
                      step_dev=self.opt_step)
         self.last = {"logits": logits, "losses": losses, "patch_num": N, "keep_num": Lk + s.merge.k, "rows": rows,

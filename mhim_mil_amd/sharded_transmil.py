@@ -205,8 +205,15 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
     from .sharded import partition_rows
     rows_local, n_stay, merge_pos = partition_rows(rows, Lk, lo, n)
     n_loc = rows_local.numel()
-    if n_loc == 0:
-        raise L.MhimxError("a shard without kept rows is not supported (bag too small for this many ranks)")
+    # a shard without kept rows is not supported - and EVERY rank must say so: the row list and the bounds are replicated, so every rank
+    # counts every shard's kept rows alike and all of them raise together (a rank-local raise left the others hanging in the next collective)
+    if W > 1:
+        owner_all = torch.bucketize(rows[:len_keep], torch.as_tensor(bounds[1:-1], dtype=torch.int64, device=rows.device), right=True)
+        per_shard = torch.bincount(owner_all, minlength=W).tolist()
+    else:
+        per_shard = [n_loc]
+    if min(per_shard) == 0:
+        raise L.MhimxError(f"a shard without kept rows is not supported (bag too small for this many ranks): kept rows per shard {per_shard}")
     k = s.merge.k
     pad_s, T_s, Tr_s = seq_layout(Lk + k, W)
     plan_x = ExchangePlan(rows[:Lk], bounds, pad_s, Tr_s, cm)
@@ -249,7 +256,7 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
     cm.all_reduce_sum(fl.grad[:fl.n_train])
     tr.step_count += 1
     ops.tick(tr.opt_step)
-    ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, fl.teacher, fl.n_train, tr.step_count, lr=tr.lr, beta1=tr.betas[0], beta2=tr.betas[1],
+    ops.adam_ema(fl.student, fl.grad, fl.m, fl.v, None if fl.same_teacher else fl.teacher, fl.n_train, tr.step_count, lr=tr.lr, beta1=tr.betas[0], beta2=tr.betas[1],
                  eps=tr.eps, weight_decay=tr.wd, grad_scale=1.0, ema_mm=tr.mm, zero_grad=True, step_dev=tr.opt_step)
     tr.last = {"logits": logits, "losses": losses, "patch_num": N, "keep_num": Lk + k, "rows": rows, "len_keep": len_keep,
                "score": score, "teacher_feat": t_feat}
