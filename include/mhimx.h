@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point or a struct changes shape; the ctypes binding (mhim_mil_amd/_lib.py ABI_VERSION) refuses any other value */
-#define MHIMX_VERSION 401
+#define MHIMX_VERSION 500
 
 /* activations (feature act: mhim.py:71-74 relu|gelu|none; scorer act: baseline.py:17-22 gelu|relu|tanh|none) */
 enum { MHIMX_ACT_NONE = 0, MHIMX_ACT_RELU = 1, MHIMX_ACT_GELU = 2, MHIMX_ACT_TANH = 3 };
@@ -198,14 +198,17 @@ typedef struct {
  * launches of the same backward that take the list give its stages a ride as extra workgroups: stage 1 in mhimx_rows_dpre, stage 2 in the
  * projection's weight-gradient mhimx_gemm_tn, stage 3 in mhimx_reduce_flush; mhimx_reduce_flush first launches whatever got no ride.
  * pending: 0 = nothing parked, else the next stage to run. */
-#define MHIMX_SIDE_BYTES 384
+#define MHIMX_SIDE_BYTES 512
 typedef struct { int32_t pending; int32_t reserved; unsigned char blob[MHIMX_SIDE_BYTES]; } mhimx_side_work;
 /* A parked GEMM: with a list, mhimx_abmil_pool_bwd does not launch its scorer-weight gradient GEMM (d_wa = du^T T, ~12 us, needed by the
  * optimiser only) but parks its arguments here; the Merge backward that follows (mhimx_merge_bwd with the same list) launches it with
  * its own first, parameter-only stage riding along as extra workgroups - one launch instead of two on the serial chain; without a Merge
  * backward mhimx_reduce_flush launches it.  blob = a mhimx_gemm_tn_args. */
 typedef struct { int32_t pending; int32_t reserved; unsigned char blob[128]; } mhimx_parked_gemm;
-typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; mhimx_side_work side; mhimx_parked_gemm parked; } mhimx_reduce_list;
+/* pre (round 5): the FIRST stage of a Merge backward (parameters x dz, where dz = the merged tokens' gradient rows that the pool backward
+ * produces) parked by mhimx_merge_bwd_park BEFORE mhimx_abmil_pool_bwd: the pool backward's one-pass rows launch gives it a ride behind a
+ * gate on the row tile(s) that hold dz, and mhimx_merge_bwd then finds it done (pending: 0 nothing, 1 parked, 2 it rode). */
+typedef struct { mhimx_reduce_job j[MHIMX_REDUCE_MAX]; int32_t n; mhimx_side_work side; mhimx_parked_gemm parked; mhimx_side_work pre; } mhimx_reduce_list;
 int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list);      /* no-op when list->n == 0; list->n = 0 on return */
 
 /* C[i,j] = sum_m A[m,i] * B[rows?rows[m]:m, j]   (weight gradients dW = dY^T X), reduction split over
@@ -544,6 +547,11 @@ int mhimx_merge_fwd_finish(void* stream, const mhimx_merge* m, const float* part
                            int32_t update_q, void* ws, int64_t ws_bytes);
 int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX,
                     const mhimx_merge_grad* g, void* ws, int64_t ws_bytes);
+/* The same arguments BEFORE the pool backward that produces dz (= a row block of its dT1 buffer, e.g. the k token rows behind a bag's
+ * feature gradients): parks the backward's first stage on g->defer (mhimx_reduce_list.pre) so that it rides in the pool backward's rows
+ * launch; a no-op (returns 0, nothing parked) without a list or for shapes that take the general Merge path.  Enqueues nothing itself. */
+int mhimx_merge_bwd_park(const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* g, void* ws,
+                         int64_t ws_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * Feature projection backward pieces                            

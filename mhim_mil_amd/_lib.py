@@ -12,7 +12,7 @@ c_f32p = C.c_void_p
 c_i64p = C.c_void_p
 c_u8p = C.c_void_p
 
-ABI_VERSION = 401          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
+ABI_VERSION = 500          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
 
 ACT = {None: 0, "none": 0, "identity": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"f32": 0, "f16s": 1, "bf16x3": 2}
@@ -77,7 +77,7 @@ class ReduceJob(C.Structure):
 REDUCE_MAX = 16
 
 
-SIDE_BYTES = 384
+SIDE_BYTES = 512
 
 
 class SideWork(C.Structure):
@@ -89,7 +89,7 @@ class ParkedGemm(C.Structure):
 
 
 class ReduceListC(C.Structure):
-    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32), ("side", SideWork), ("parked", ParkedGemm)]
+    _fields_ = [("j", ReduceJob * REDUCE_MAX), ("n", C.c_int32), ("side", SideWork), ("parked", ParkedGemm), ("pre", SideWork)]
 
 
 class GemmTN(C.Structure):
@@ -204,6 +204,7 @@ SYMBOLS = {
     "mhimx_merge_fwd_part": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, _I64]),
     "mhimx_merge_fwd_finish": (C.c_int, [_P, C.POINTER(Merge), _P, _I32, _I64, _P, _P, _I32, _P, _I64]),
     "mhimx_merge_bwd": (C.c_int, [_P, C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
+    "mhimx_merge_bwd_park": (C.c_int, [C.POINTER(Merge), _P, _I64, _P, _P, C.POINTER(MergeGrad), _P, _I64]),
     "mhimx_act_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I32, _F, _U64, _P, _P, _P, _I32, _P, _I64, _P]),
     "mhimx_softmax_cols": (C.c_int, [_P, _P, _P, _I64, _I64, _F]),
     "mhimx_softmax_cols_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _F]),

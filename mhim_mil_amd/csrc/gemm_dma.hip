@@ -14,7 +14,7 @@
 #include <string.h>
 
 #include "common.hpp"
-#include "mca2_side.hpp"
+#include "mca2_rows.hpp"
 #include "prep_jobs.hpp"
 
 namespace mhimx {
@@ -390,13 +390,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
 // =================================================================================================
 // TN
 // =================================================================================================
-template <int PREC>
+// ROWS: the riders are the row tiles of a Merge backward's rows pass (stage 4, mca2_rows.hpp; 161 KB of LDS: one workgroup per CU, the
+// caller sizes the product so that tiles + riders fit the chip at once) - an instantiation of its own, so that the plain product keeps its
+// register count and occupancy.
+template <int PREC, bool ROWS = false>
 __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, int side_stage, Merge2Side side) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2): its few short workgroups are
-    merge2_side_stage(side_stage, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);      // dispatched first and free their slots early
+    if constexpr (ROWS) {                        // dispatched first and free their slots early
+      if ((int)blockIdx.x < side.w.T)
+        merge2_rows_bwd_body((int)blockIdx.x, reinterpret_cast<float*>(smem), side.X, side.xrows, side.R, side.ln_w, side.ln_b, side.J, side.drop_p,
+                             side.seed0, side.tick, side.dX, side.w);
+    } else {
+      merge2_side_stage(side_stage, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
+    }
     return;
   }
   const unsigned bx = blockIdx.x - (unsigned)side_blocks;      // (side_blocks % 8 == 0: the XCD of a tile does not move)
@@ -659,14 +668,37 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
     ++splits;
     if ((int64_t)splits * g.K1 * g.K2 > ws_floats_avail) return -2;      // caller falls back to the register-staged kernel
   }
+  // stage 4: the Merge backward's rows pass rides (one 161 KB-LDS workgroup per CU, as every tile of this launch then is): the product
+  // takes the CUs the row tiles leave free, all of it in ONE round - 4 output tiles x 56 slabs = 224 tiles beside 31 row tiles at c2
+  // (the product runs as fast on 32 slabs as on 64: it is latency, not slab traffic)
+  const bool rows_ride = rider && rider_stage == 4 && DTHREADS == M2_THREADS;
+  int rows_blocks = 0;
+  if (rows_ride) {
+    rows_blocks = (int)align_up(rider->w.T, 8);
+    const int64_t room = 256 - rows_blocks;
+    int cap = (int)(room / tiles) / 8 * 8;
+    if (cap < 8 || rows_blocks > 128) rows_blocks = 0;            // no room for the product beside the rows: they do not ride
+    else if (splits > cap) splits = cap;
+  }
   g.splits = splits;
   const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);
-  const size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;
+  size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8)));
   Merge2Side side = {};
   int side_blocks = 0, side_stage = 2;
   if (rode) *rode = false;
-  if (rider && DTHREADS == M2_THREADS && smem >= M2_SIDE_LDS * sizeof(float) && merge2_side_blocks(rider_stage, *rider) % 8 == 0) {
+  if (rows_ride && rows_blocks > 0 && cdiv(g.M, splits) <= MAX_TN_CHUNK) {
+    constexpr size_t ROWS_SMEM = M2_BWD_SMEM > TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8 ? M2_BWD_SMEM : TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8;
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROWS_SMEM)));
+    if (smem < M2_BWD_SMEM) smem = M2_BWD_SMEM;
+    side = *rider;
+    if (rode) *rode = true;
+    dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + rows_blocks));
+    hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, true>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side);
+    MHIMX_LAUNCH_CHECK();
+    return splits;
+  }
+  if (rider && rider_stage != 4 && DTHREADS == M2_THREADS && smem >= M2_SIDE_LDS * sizeof(float) && merge2_side_blocks(rider_stage, *rider) % 8 == 0) {
     side = *rider;
     side_stage = rider_stage;
     side_blocks = merge2_side_blocks(rider_stage, side);

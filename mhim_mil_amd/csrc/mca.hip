@@ -30,6 +30,7 @@ int merge2_fwd_part(hipStream_t st, const mhimx_merge* m, const float* X, int64_
 int merge2_fwd_finish(hipStream_t st, const mhimx_merge* m, const float* parts, int W, int64_t R, float* z, float* q_new, int update_q, void* ws,
                       int64_t ws_bytes);
 int64_t merge2_part_floats();
+int merge2_bwd_park(const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* gr, void* ws, int64_t ws_bytes);
 int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* gr, void* ws,
                int64_t ws_bytes);
 
@@ -431,6 +432,13 @@ __global__ __launch_bounds__(256) void mca_out_kernel(const float* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;
   if (n >= E) return;
+  // Everything the epilogue reads is REQUESTED here, ahead of the dot products: the step counter behind the dropout seed, the bias and the
+  // k old query values were three dependent cache misses behind the reduction (~1.5 us each on a cold launch of 128 workgroups).
+  const uint64_t seed = p > 0.f ? eff_seed(seed0, tick) : 0;
+  const float bias = bo[n];
+  float qv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) qv[i] = (q_new && i < k) ? q[(int64_t)i * E + n] : 0.f;
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -445,15 +453,17 @@ __global__ __launch_bounds__(256) void mca_out_kernel(const float* __restrict__ 
       }
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = wave_sum(acc[i]);
+  for (int i = 0; i < 16; ++i)
+    if (i < k) acc[i] = wave_sum(acc[i]);                    // (k is uniform: no reduction for the unused accumulators)
   if (lane != 0) return;
-  const uint64_t seed = eff_seed(seed0, tick);
   const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  for (int i = 0; i < k; ++i) {
-    float v = acc[i] + bo[n];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i >= k) break;
+    float v = acc[i] + bias;
     if (p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)n, p) ? v * ks : 0.f;
     z[(int64_t)i * E + n] = v;
-    if (q_new) q_new[(int64_t)i * E + n] = q[(int64_t)i * E + n] * mm + v * (1.f - mm);
+    if (q_new) q_new[(int64_t)i * E + n] = qv[i] * mm + v * (1.f - mm);
   }
 }
 
@@ -678,6 +688,13 @@ extern "C" int mhimx_merge_fwd_finish(void* stream, const mhimx_merge* m, const 
   if (int r = check_merge(m)) return r;
   MHIMX_CHECK_ARG(R > 0 && ws && merge2_ok(m, R), "merge_fwd_finish: needs the projection-free form");
   return merge2_fwd_finish((hipStream_t)stream, m, parts, W, R, z, q_new, update_q, ws, ws_bytes);
+}
+extern "C" int mhimx_merge_bwd_park(const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX, const mhimx_merge_grad* g, void* ws,
+                                    int64_t ws_bytes) {
+  if (check_merge(m)) return 0;
+  if (!(X && dz && dX && g && R > 0 && g->d_ln_w && g->d_ln_b && g->d_wkv && g->d_wq && g->d_wo && g->d_bo && m->wo_t)) return 0;
+  if (!merge2_ok(m, R) || m->own_n != 0) return 0;        // (the general path / a shard of a sharded bag: the stage runs where it always did)
+  return merge2_bwd_park(m, X, R, dz, dX, g, ws, ws_bytes);
 }
 extern "C" int mhimx_merge_bwd(void* stream, const mhimx_merge* m, const float* X, int64_t R, const float* dz, float* dX,
                                const mhimx_merge_grad* g, void* ws, int64_t ws_bytes) {

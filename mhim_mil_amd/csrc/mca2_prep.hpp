@@ -107,18 +107,26 @@ MHIMX_DEV void m2_ln_stats(const m2_f4& a, const m2_f4& b, float& mu, float& rs)
 // zero), on the matrix cores (3-term bf16): [6 -> 16 x 512] . [512 x 16 rows per wave] = 16 MFMA steps per wave and NO cross-lane
 // reductions (the wave-per-row form spent most of its time in 96 DPP reductions per wave).  Every load of the wave's 16 rows is in flight
 // before the first MFMA.  gout (optional): the same values to global [i][512].
+// the weight rows of m2_head_dots as a register block: requested by m2_head_rows_load (as early as the caller can - ahead of the barrier
+// that publishes `vec`), consumed by m2_head_dots_use
+struct M2HeadRows { m2_f4 b0[16], b1[16]; };
 template <int NR>
-MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, int k, float* out, int out_ld, float* gout) {
+MHIMX_DEV void m2_head_rows_load(const float* __restrict__ rows, M2HeadRows& r) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (NR == 16 && wave != 0) return;
   const int n = lane & 15, kg = lane >> 4, wrow0 = NR == 16 ? 0 : wave * 16;
   const float* rp = rows + (int64_t)(wrow0 + n) * M2_E + kg * 8;
-  m2_f4 b0[16], b1[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    b0[ks] = *reinterpret_cast<const m2_f4*>(rp + ks * 32);
-    b1[ks] = *reinterpret_cast<const m2_f4*>(rp + ks * 32 + 4);
+    r.b0[ks] = *reinterpret_cast<const m2_f4*>(rp + ks * 32);
+    r.b1[ks] = *reinterpret_cast<const m2_f4*>(rp + ks * 32 + 4);
   }
+}
+template <int NR>
+MHIMX_DEV void m2_head_dots_use(const M2HeadRows& r, const float* vec, int k, float* out, int out_ld, float* gout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (NR == 16 && wave != 0) return;
+  const int n = lane & 15, kg = lane >> 4, wrow0 = NR == 16 ? 0 : wave * 16;
   const bool am = n < 6;                                     // A row m = lane & 15: vector m (zero beyond the 6th)
   const float* ap = vec + (am ? n : 0) * M2_E + kg * 8;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -127,7 +135,7 @@ MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, in
     m2_f4 a0 = *reinterpret_cast<const m2_f4*>(ap + ks * 32), a1 = *reinterpret_cast<const m2_f4*>(ap + ks * 32 + 4);
     if (!am) { a0 = m2_f4{0.f, 0.f, 0.f, 0.f}; a1 = a0; }
     const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    const float bv[8] = {b0[ks][0], b0[ks][1], b0[ks][2], b0[ks][3], b1[ks][0], b1[ks][1], b1[ks][2], b1[ks][3]};
+    const float bv[8] = {r.b0[ks][0], r.b0[ks][1], r.b0[ks][2], r.b0[ks][3], r.b1[ks][0], r.b1[ks][1], r.b1[ks][2], r.b1[ks][3]};
     bf8 ah, al, bh, bl;
     m2_split8(av, ah, al);
     m2_split8(bv, bh, bl);
@@ -137,10 +145,16 @@ MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, in
   for (int i = 0; i < 4; ++i) {
     const int m = 4 * kg + i;                                // C: row m = vector, column n = weight row
     if (m < k) {
-      out[m * out_ld + wrow0 + n] = acc[i];
+      if (out) out[m * out_ld + wrow0 + n] = acc[i];
       if (gout) gout[m * M2_I + wrow0 + n] = acc[i];
     }
   }
+}
+template <int NR>
+MHIMX_DEV void m2_head_dots(const float* __restrict__ rows, const float* vec, int k, float* out, int out_ld, float* gout) {
+  M2HeadRows r;
+  m2_head_rows_load<NR>(rows, r);
+  m2_head_dots_use<NR>(r, vec, k, out, out_ld, gout);
 }
 // zero the rows k..5 of a [6][512] LDS block (so that loops over the queries can be a compile-time 6)
 MHIMX_DEV void m2_zero_tail(float* v, int k) {

@@ -16,6 +16,8 @@ struct Merge2Side {
   uint64_t oseed;
   float scale, drop_p;
   int k, accumulate, J;
+  // the rows backward as a stage of its own (stage 4: it rides in the scorer-weight-gradient product's launch, mca2_rows.hpp): its operands
+  const float* X; const int64_t* xrows; int64_t R; float* dX; uint64_t seed0;
   float rep;       // weight of the terms every shard of an instance-sharded bag computes identically (d_bo, d_wo, the V half of d_wkv): 1 on one
                    // shard, 0 on the others, so that the SUM over the shards counts them once; 1 for one process
 };
@@ -295,9 +297,14 @@ constexpr int M2_SIDE_LDS = M2_GRADS1_LDS;                   // floats: the larg
 // Stage 0 (the first stage of the backward, parameters x dz): dz0 = dz keep/(1-p), d_bo, dO = dz0 Wo, dY[(h,i),:] = sum_d dO[i,h,d] Wv[h*64+d,:]
 // (as the two fragment images), delta partials dY.Y.   64 blocks = 8 heads x 8 column blocks of 64.  lds: 6 * 512 + 6 * 64 floats.
 constexpr int M2_BWD_PRE_BLOCKS = 64, M2_BWD_PRE_LDS = 6 * M2_E + 6 * 64;
+// gate (optional): the stage rides in the launch that PRODUCES dz (scorer_fused_bwd_kernel): it requests everything that does not depend on
+// dz, then waits until `gate_target` workgroups have announced their rows of dz (write-through stores + one relaxed agent-scope add each)
+// and reads dz past the caches.  A bounded spin: the riders are the launch's LAST workgroups, so the producers are resident or done.
+constexpr unsigned M2_GATE_SPINS = 1u << 22;
 MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restrict__ dz, const float* __restrict__ wo_t,
                                    const float* __restrict__ wkv, int k, float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick,
-                                   float* __restrict__ d_bo, int accumulate, const Merge2Ws& w, float rep = 1.f) {
+                                   float* __restrict__ d_bo, int accumulate, const Merge2Ws& w, float rep = 1.f, const unsigned* gate = nullptr,
+                                   unsigned gate_target = 0) {
   float* dzs = lds;                 // [6][512]
   float* doh = dzs + 6 * M2_E;      // [6][64]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -309,11 +316,21 @@ MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restric
   for (int d = 0; d < 64; ++d) wv[d] = wkv[(int64_t)(M2_I + h * 64 + d) * M2_E + e];
   float yv[2] = {0.f, 0.f};
   for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) yv[q] = w.Y[(h * k + i) * M2_E + e];
+  M2HeadRows wr;                                              // ... and so are the head's 64 rows of Wo^T
+  m2_head_rows_load<64>(wo_t + (int64_t)h * 64 * M2_E, wr);
   const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
   const float ks = 1.f / (1.f - drop_p);
+  const float dbo_old = (h == 0 && tid < 64 && accumulate) ? d_bo[e] : 0.f;
+  if (gate) {
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target && ++spins < M2_GATE_SPINS) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+  }
   for (int idx = tid; idx < k * M2_E; idx += M2_THREADS) {
     const int i = idx >> 9, ee = idx & 511;
-    float v = dz[idx];
+    float v = gate ? __hip_atomic_load(dz + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dz[idx];
     if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)ee, drop_p) ? v * ks : 0.f;
     dzs[idx] = v;
   }
@@ -322,9 +339,9 @@ MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restric
   if (h == 0 && tid < 64) {
     float s = 0.f;
     for (int i = 0; i < k; ++i) s += dzs[i * M2_E + e];
-    d_bo[e] = accumulate ? d_bo[e] + rep * s : rep * s;
+    d_bo[e] = accumulate ? dbo_old + rep * s : rep * s;
   }
-  m2_head_dots<64>(wo_t + (int64_t)h * 64 * M2_E, dzs, k, doh, 64, eb == 0 ? w.dO + h * 64 : nullptr);
+  m2_head_dots_use<64>(wr, dzs, k, doh, 64, eb == 0 ? w.dO + h * 64 : nullptr);
   __syncthreads();
   for (int i = tid >> 6, q = 0; i < k; i += 4, ++q) {
     float acc = 0.f;

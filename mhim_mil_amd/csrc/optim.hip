@@ -1,6 +1,7 @@
 // optim.hip — the bag-level tail of a train step: predictor + losses (+ their gradients) in one launch,
 // and the fused Adam + EMA-teacher update over flat parameter buffers.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -98,6 +99,154 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_kernel(const float* __restr
       }
   }
   if (d_bp && tid < C) d_bp[tid] = accumulate ? d_bp[tid] + gl[tid] : gl[tid];
+}
+
+// The same head for the production shapes (E <= 4 x 256, C <= 4) as a SHORT dependency chain: the kernel runs on one workgroup in the middle
+// of the step's serial chain, and the generic form above is three dependent memory round trips (z / wp, then label / bp, then t) and
+// 2 + C + 3 block reductions of two barriers each.  Here every input is requested at entry (registers), and the block reductions are
+// batched: {C logit sums, max z, max t} -> {sum e^z, sum e^t} -> {soft-target CE}: three barrier pairs.  Same sums in the same order
+// (wave_sum, then the four wave values left to right): the bits of head_kernel.
+template <int Q>
+__global__ __launch_bounds__(HEAD_THREADS) void head_fast_kernel(const float* __restrict__ z, const float* __restrict__ t,
+                                                                 const float* __restrict__ wp, const float* __restrict__ bp,
+                                                                 const int64_t* __restrict__ label, int E, int C, float temp_t,
+                                                                 float main_alpha, float aux_alpha, float inv_accum,
+                                                                 float* __restrict__ logits, float* __restrict__ losses,
+                                                                 float* __restrict__ g_z, float* __restrict__ d_wp,
+                                                                 float* __restrict__ d_bp, int accumulate,
+                                                                 const float* __restrict__ g_logits_in,
+                                                                 const float* __restrict__ g_cl_in) {
+  __shared__ float red[8][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool aux = (t != nullptr);
+  // ---- every load of the kernel, in flight together
+  float zv[Q], tv[Q], wv[4][Q], dw_old[4][Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = tid + q * HEAD_THREADS;
+    const bool in = e < E;
+    zv[q] = in ? z[e] : 0.f;
+    tv[q] = (in && aux) ? t[e] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      wv[c][q] = (in && c < C) ? wp[c * E + e] : 0.f;
+      dw_old[c][q] = (in && c < C && d_wp && accumulate) ? d_wp[c * E + e] : 0.f;
+    }
+  }
+  const int y = label ? (int)label[0] : 0;
+  float bpv[4], glin[4], dbp_old[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bpv[c] = (bp && c < C) ? bp[c] : 0.f;
+    glin[c] = (!label && g_logits_in && c < C) ? g_logits_in[c] : 0.f;
+    dbp_old[c] = (d_bp && accumulate && c < C) ? d_bp[c] : 0.f;
+  }
+  if (g_cl_in) aux_alpha = g_cl_in[0];
+  // ---- reduction 1: the C logit sums, max z, max t / temp_t
+  float p[4] = {0.f, 0.f, 0.f, 0.f}, a = -INFINITY, b = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const bool in = tid + q * HEAD_THREADS < E;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] += wv[c][q] * zv[q];
+    if (in) { a = fmaxf(a, zv[q]); b = fmaxf(b, tv[q] / temp_t); }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) p[c] = wave_sum(p[c]);
+  a = wave_max(a);
+  b = wave_max(b);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[c][wave] = p[c];
+    red[4][wave] = a;
+    red[5][wave] = b;
+  }
+  __syncthreads();
+  float lg[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) lg[c] = (red[c][0] + red[c][1] + red[c][2] + red[c][3]) + bpv[c];
+  const float zmx = aux ? fmaxf(fmaxf(red[4][0], red[4][1]), fmaxf(red[4][2], red[4][3])) : 0.f;
+  const float tmx = aux ? fmaxf(fmaxf(red[5][0], red[5][1]), fmaxf(red[5][2], red[5][3])) : 0.f;
+  // cross entropy on the logits (every thread: C <= 4 values)
+  float ce = 0.f, gl[4] = {0.f, 0.f, 0.f, 0.f};
+  if (label) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < C) mx = fmaxf(mx, lg[c]);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < C) den += expf(lg[c] - mx);
+    float ly = lg[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) if (c == y) ly = lg[c];
+    ce = -(ly - mx - logf(den));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < C) gl[c] = main_alpha * inv_accum * (expf(lg[c] - mx) / den - (c == y ? 1.f : 0.f));
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gl[c] = glin[c];
+  }
+  // ---- reduction 2: the two softmax denominators
+  float cl = 0.f, zden = 1.f, tden = 1.f;
+  float ez[Q], et[Q];
+  if (aux) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const bool in = tid + q * HEAD_THREADS < E;
+      ez[q] = in ? expf(zv[q] - zmx) : 0.f;
+      et[q] = in ? expf(tv[q] / temp_t - tmx) : 0.f;
+      sa += ez[q];
+      sb += et[q];
+    }
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    if (lane == 0) { red[6][wave] = sa; red[7][wave] = sb; }
+    __syncthreads();
+    zden = red[6][0] + red[6][1] + red[6][2] + red[6][3];
+    tden = red[7][0] + red[7][1] + red[7][2] + red[7][3];
+    // ---- reduction 3: cl = -sum softmax(t / temp_t) log_softmax(z)
+    const float lz = logf(zden);
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      if (tid + q * HEAD_THREADS < E) acc += (et[q] / tden) * (zv[q] - zmx - lz);
+    acc = wave_sum(acc);
+    if (lane == 0) red[0][wave] = acc;                          // (red[0]'s logit sums were read by everybody before the barrier above)
+    __syncthreads();
+    cl = -(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+  }
+  if (tid == 0) {
+    for (int c = 0; c < C; ++c) logits[c] = lg[c];
+    losses[0] = main_alpha * ce + aux_alpha * cl;
+    losses[1] = ce;
+    losses[2] = cl;
+  }
+  // ---- gradients
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int e = tid + q * HEAD_THREADS;
+    if (e >= E) continue;
+    float g = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (c < C) g += wv[c][q] * gl[c];
+    if (aux) g += aux_alpha * inv_accum * (ez[q] / zden - et[q] / tden);
+    g_z[e] = g;
+    if (d_wp) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) {
+          const float v = gl[c] * zv[q];
+          d_wp[c * E + e] = accumulate ? dw_old[c][q] + v : v;
+        }
+    }
+  }
+  if (d_bp && tid < C) {
+    float gv = gl[0], ov = dbp_old[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) if (c == tid) { gv = gl[c]; ov = dbp_old[c]; }
+    d_bp[tid] = accumulate ? ov + gv : gv;
+  }
 }
 
 // DSMIL head (common_mil.py:26-28, mhim.py:355-364, losses.py:26-45): logits = 0.5 (bag + max-instance), CE on them, and the
@@ -320,6 +469,14 @@ extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, 
                                   float* d_bp, int32_t accumulate, const float* g_logits_in, const float* g_cl_in) {
   MHIMX_CHECK_ARG(z && wp && logits && losses && g_z, "head: null args");
   MHIMX_CHECK_ARG(C > 0 && C <= 16 && E > 0, "head: bad dims");
+  static const bool slow_head = getenv("MHIMX_HEAD_GENERIC") != nullptr;
+  if (!slow_head && C <= 4 && E <= 2 * HEAD_THREADS)
+    hipLaunchKernelGGL(head_fast_kernel<2>, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
+                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
+  else if (!slow_head && C <= 4 && E <= 4 * HEAD_THREADS)
+    hipLaunchKernelGGL(head_fast_kernel<4>, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
+                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
+  else
   hipLaunchKernelGGL(head_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
                      temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
   MHIMX_LAUNCH_CHECK();

@@ -19,7 +19,7 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);      // gemm_dma.hip
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
-                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows);
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows, const void* pre_side, int64_t gate_row0);
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
@@ -877,9 +877,23 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   MHIMX_CHECK_ARG(!io->rows1 || (fused && io->M2 == 0), "pool_bwd: gathered tokens (rows1) need the one-pass backward and a single segment");
   for (int seg = 0; seg < 2 && fused; ++seg) {
     if (Ms[seg] == 0) continue;
+    // a Merge backward's first stage parked on the list (mhimx_merge_bwd_park) rides in this launch when its dz is a block of whole rows of
+    // THIS launch's gradient buffer (the k token rows behind a bag's feature gradients)
+    const void* pre_side = nullptr;
+    int64_t gate_row0 = -1;
+    if (seg == 0 && io->M2 == 0 && gr->defer && gr->defer->pre.pending == 1) {
+      Merge2Side psd;
+      memcpy(&psd, gr->defer->pre.blob, sizeof(psd));
+      const int64_t d = psd.dz - dTs[0];
+      if (psd.dz >= dTs[0] && d % E == 0) {
+        pre_side = gr->defer->pre.blob;
+        gate_row0 = d / E;
+        gr->defer->pre.pending = 2;
+      }
+    }
     const int g1 = scorer_fused_bwd(st, Ts[seg], Ms[seg], u_pre + off * ldu, io->s + off, io->stats, gr->g_z, io->z, sc->wc, sc->act,
                                     gr->wa_t, gr->wa_t_frag, w.du + off * ldu, dTs[seg], w.dwc_part + (int64_t)G * A, w.dbc_part + G,
-                                    MAX_PART, seg == 0 ? io->rows1 : nullptr);
+                                    MAX_PART, seg == 0 ? io->rows1 : nullptr, pre_side, gate_row0);
     if (g1 < 0) return g1;
     G += g1;
     off += Ms[seg];

@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include "common.hpp"
+#include "mca2_side.hpp"
 #include "prep_jobs.hpp"
 
 namespace mhimx {
@@ -309,8 +310,18 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     const float* __restrict__ stats, const float* __restrict__ g_z, const float* __restrict__ z, const float* __restrict__ wc, int act,
     const float* __restrict__ wat, const float* __restrict__ wat_frag, float* __restrict__ du, float* __restrict__ dT,
     float* __restrict__ dwc_part, float* __restrict__ dbc_part, int tiles,
-    const int64_t* __restrict__ rows /* optional: token n is T[rows[n]] and its gradient goes to dT[rows[n]] */) {
+    const int64_t* __restrict__ rows /* optional: token n is T[rows[n]] and its gradient goes to dT[rows[n]] */,
+    int n_main /* workgroups of the backward itself; the blocks behind them: a Merge backward's first stage, riding */, Merge2Side pre,
+    int64_t gate_row0 /* >= 0: the rows gate_row0 .. of dT are that stage's dz - stored write-through and announced on pre.w.gate[1] */) {
   extern __shared__ __attribute__((aligned(16))) float sb_sm[];
+  if ((int)blockIdx.x >= n_main) {
+    // (the LAST blocks of the grid: every producer of dz is resident or done when one of these starts; they request their weights, then
+    // wait for pre.k announced rows)
+    merge2_bwd_pre_body((int)blockIdx.x - n_main, sb_sm, pre.dz, pre.wo_t, pre.wkv, pre.k, pre.drop_p, pre.oseed, pre.tick, pre.d_bo, pre.accumulate,
+                        pre.w, pre.rep, pre.w.gate + 1, (unsigned)pre.k);
+    return;
+  }
+  const bool gated = gate_row0 >= 0;
   float* Ds = sb_sm;                           // [32][132] du tile (A operand)
   float* gzs = Ds + SF_ROWS * SB_LD;           // [512]
   float* an_s = gzs + SF_E;                    // [32] attn
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
   const float wca = wc[a_col];
   float dwc_run = 0.f, dbc_run = 0.f;
 
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < tiles; tile += n_main) {
     const int64_t row0 = (int64_t)tile * SF_ROWS;
     if (rows) {
       if (tid < SF_ROWS) { const int64_t n = row0 + tid; ridx[tid] = rows[n < M ? n : M - 1]; }
@@ -463,10 +474,24 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
       for (int i = 0; i < 16; ++i) {
         const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
         const int64_t n = row0 + row;
-        if (n < M) dT[(rows ? ridx[row] : n) * SF_E + e] = acc[nt][i] + an_s[row] * ge;
+        if (n < M) {
+          const int64_t dr = rows ? ridx[row] : n;
+          const float v = acc[nt][i] + an_s[row] * ge;
+          // (a row of the riding stage's dz: past the caches - its readers sit on other XCDs of this same launch)
+          if (gated && dr >= gate_row0) __hip_atomic_store(dT + dr * SF_E + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else dT[dr * SF_E + e] = v;
+        }
       }
     }
+    if (gated) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores are acknowledged before the barrier
     __syncthreads();                           // Ds / an_s / gs_s are rewritten by the next tile
+    if (gated && wave == 0) {
+      // the tile's rows of dz, counted once per row: their number is added to the gate (the riders wait for pre.k rows in all)
+      const int64_t n = row0 + lane;
+      const bool mine = lane < SF_ROWS && n < M && (rows ? ridx[lane < SF_ROWS ? lane : 0] : n) >= gate_row0;
+      const unsigned cnt = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));
+      if (lane == 0 && cnt) __hip_atomic_fetch_add(pre.w.gate + 1, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   dwc_s[half * SF_A + a_col] = dwc_run;
   __syncthreads();
@@ -511,12 +536,22 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
 // returns the number of d_wc / d_bc partial rows written (<= max_parts), < 0 on error
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
-                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows) {
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows, const void* pre_side, int64_t gate_row0) {
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM)));
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
-  hipLaunchKernelGGL(scorer_fused_bwd_kernel, dim3(grid), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
-                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows);
+  static_assert(SB_SMEM >= M2_BWD_PRE_LDS * sizeof(float), "the riding Merge stage's LDS is the backward's");
+  static_assert(SF_THREADS == M2_THREADS, "the riding Merge stage is written for 256 threads");
+  Merge2Side pre = {};
+  int ride = 0;
+  if (pre_side) {
+    pre = *reinterpret_cast<const Merge2Side*>(pre_side);
+    ride = M2_BWD_PRE_BLOCKS;
+  } else {
+    gate_row0 = -1;
+  }
+  hipLaunchKernelGGL(scorer_fused_bwd_kernel, dim3(grid + ride), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
+                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows, grid, pre, gate_row0);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

@@ -657,8 +657,7 @@ class MHIM(nn.Module):
         for key, nm in (("d_wa", "0.weight"), ("d_wc", "2.weight")):
             if pre + nm in out:
                 pool_g[key] = out[pre + nm]
-        g = ops.abmil_pool_bwd(sc, st, g_z, prep["wa_t"], grads=pool_g, defer=defer, wa_t_frag=prep.get("wa_t_frag"), accumulate=accumulate)
-        grads[pre + "0.weight"], grads[pre + "2.weight"] = g["d_wa"], g["d_wc"]
+        mw = mgr = None
         if rows_all is not None:
             mw = self._merge_w(plan, need_t=True, q=saved["q_old"], tr=prep.get("merge_t"), x_rows=rows_all[:plan.R])
             mgr = {"dX": dHbuf}
@@ -667,6 +666,13 @@ class MHIM(nn.Module):
                             ("d_bo", "merge.attn.to_out.0.bias")):
                 if nm in out:
                     mgr[key] = out[nm]
+            if len(mgr) == 7:
+                # the Merge backward's first stage (parameters x d tokens) rides in the pool backward's rows launch, behind a gate on the
+                # tile that writes the tokens' gradient rows dHbuf[N:] (ops.merge_bwd_park)
+                ops.merge_bwd_park(mw, Hbuf, dHbuf[N:], saved["mws"], mgr, accumulate=accumulate, defer=defer)
+        g = ops.abmil_pool_bwd(sc, st, g_z, prep["wa_t"], grads=pool_g, defer=defer, wa_t_frag=prep.get("wa_t_frag"), accumulate=accumulate)
+        grads[pre + "0.weight"], grads[pre + "2.weight"] = g["d_wa"], g["d_wc"]
+        if rows_all is not None:
             mg = ops.merge_bwd(mw, Hbuf, dHbuf[N:], saved["mws"], grads=mgr, defer=defer, accumulate=accumulate)
             grads["merge.norm.weight"], grads["merge.norm.bias"] = mg["d_ln_w"], mg["d_ln_b"]
             grads["merge.attn.to_kv.weight"], grads["merge.attn.to_q.weight"] = mg["d_wkv"], mg["d_wq"]

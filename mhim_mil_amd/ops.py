@@ -273,6 +273,7 @@ class ReduceList:
         self.c.n = 0
         self.c.side.pending = 0
         self.c.parked.pending = 0
+        self.c.pre.pending = 0
         self.keep = []
 
     def ptr(self):
@@ -568,6 +569,18 @@ def merge_fwd_finish(mw: MergeW, parts, ws, z_out=None, update_q=True, q_out=Non
     L.check(L.lib().mhimx_merge_fwd_finish(_stream(), C.byref(mw.c), _p(parts), parts.shape[0], R, _p(z), _p(q_new), int(bool(update_q)),
                                            _p(ws), ws.numel()), "mhimx_merge_fwd_finish")
     return z, q_new
+
+
+def merge_bwd_park(mw: MergeW, X, dz, ws, grads, accumulate=False, defer=None):
+    """BEFORE the pool backward that produces ``dz``: park the Merge backward's first stage on the step's list so that it rides in the pool
+    backward's rows launch (mhimx_merge_bwd_park; a no-op for shapes / callers it does not apply to).  Same ``mw`` / ``grads`` / ``ws`` as the
+    merge_bwd call that follows."""
+    if defer is None or mw.x_rows is None:
+        return
+    R = mw.x_rows.shape[0]
+    g = L.MergeGrad(d_ln_w=_p(grads["d_ln_w"]), d_ln_b=_p(grads["d_ln_b"]), d_wkv=_p(grads["d_wkv"]), d_wq=_p(grads["d_wq"]),
+                    d_wo=_p(grads["d_wo"]), d_bo=_p(grads["d_bo"]), accumulate=int(bool(accumulate)), splits=8, defer=_dp(defer))
+    L.check(L.lib().mhimx_merge_bwd_park(C.byref(mw.c), _p(X), R, _p(dz), _p(grads["dX"]), C.byref(g), _p(ws), ws.numel()), "mhimx_merge_bwd_park")
 
 
 def merge_bwd(mw: MergeW, X, dz, ws, splits=8, grads=None, accumulate=False, defer=None):
