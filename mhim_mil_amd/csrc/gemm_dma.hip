@@ -393,15 +393,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
 // ROWS: the riders are the row tiles of a Merge backward's rows pass (stage 4, mca2_rows.hpp; 161 KB of LDS: one workgroup per CU, the
 // caller sizes the product so that tiles + riders fit the chip at once) - an instantiation of its own, so that the plain product keeps its
 // register count and occupancy.
-template <int PREC, bool ROWS = false>
+template <int PREC, int ROWS = 0>
 __global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, int side_stage, Merge2Side side) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2): its few short workgroups are
-    if constexpr (ROWS) {                        // dispatched first and free their slots early
+    if constexpr (ROWS != 0) {                   // dispatched first and free their slots early
       if ((int)blockIdx.x < side.w.T)
-        merge2_rows_bwd_body((int)blockIdx.x, reinterpret_cast<float*>(smem), side.X, side.xrows, side.R, side.ln_w, side.ln_b, side.J, side.drop_p,
+        merge2_rows_bwd_body<ROWS>((int)blockIdx.x, reinterpret_cast<float*>(smem), side.X, side.xrows, side.R, side.ln_w, side.ln_b, side.J, side.drop_p,
                              side.seed0, side.tick, side.dX, side.w);
     } else {
       merge2_side_stage(side_stage, (int)blockIdx.x, reinterpret_cast<float*>(smem), side);
@@ -688,13 +688,19 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   int side_blocks = 0, side_stage = 2;
   if (rode) *rode = false;
   if (rows_ride && rows_blocks > 0 && cdiv(g.M, splits) <= MAX_TN_CHUNK) {
-    constexpr size_t ROWS_SMEM = M2_BWD_SMEM > TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8 ? M2_BWD_SMEM : TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8;
-    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROWS_SMEM)));
-    if (smem < M2_BWD_SMEM) smem = M2_BWD_SMEM;
+    constexpr size_t GEMM_MAX = TN_STAGES * STAGE_BYTES + (MAX_TN_CHUNK + DBK) * 8;
+    constexpr size_t ROWS_SMEM = M2_BWD_SMEM > GEMM_MAX ? M2_BWD_SMEM : GEMM_MAX;
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROWS_SMEM));
+                          MHIMX_HIP(hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROWS_SMEM)));
+    const size_t rows_smem = m2_bwd_smem(rider->w.rt);
+    if (smem < rows_smem) smem = rows_smem;
     side = *rider;
     if (rode) *rode = true;
     dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + rows_blocks));
-    hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, true>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side);
+    if (side.w.rt == 16)
+      hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 16>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side);
+    else
+      hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 32>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side);
     MHIMX_LAUNCH_CHECK();
     return splits;
   }

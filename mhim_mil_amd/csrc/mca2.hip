@@ -50,50 +50,52 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(Merge2PrepArgs 
 // ----------------------------------------------------------------------------------------------------------------------
 // 2. rows forward: LayerNorm, scores against the J slots, per-tile softmax partials, pooled rows.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t M2_FWD_SMEM = (size_t)(M2_ROWS * M2_XLD + 4 * M2_ROWS * M2_JP + M2_JP * M2_PLD + 2 * M2_E + M2_ROWS + 4) * sizeof(float);
+constexpr size_t m2_fwd_smem(int rt) { return (size_t)(rt * M2_XLD + 4 * rt * M2_JP + M2_JP * (rt + 4) + 2 * M2_E + rt + 4) * sizeof(float); }
 
+template <int RT>
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
                                                                     float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick, Merge2Ws w) {
   extern __shared__ __attribute__((aligned(16))) float m2sm[];
-  float* xh = m2sm;                                  // [32][516]
-  float* red = xh + M2_ROWS * M2_XLD;                // [4][32][48]
-  float* pdT = red + 4 * M2_ROWS * M2_JP;            // [48][36]
-  float* lnw = pdT + M2_JP * M2_PLD;                 // [512]
+  constexpr int PLD = RT + 4, RQ = RT / 4;            // RQ: rows per thread of the four that share a slot
+  float* xh = m2sm;                                  // [RT][516]
+  float* red = xh + RT * M2_XLD;                     // [4][RT][48]
+  float* pdT = red + 4 * RT * M2_JP;                 // [48][RT + 4]
+  float* lnw = pdT + M2_JP * PLD;                    // [512]
   float* lnb = lnw + M2_E;                           // [512]
-  float* ok = lnb + M2_E;                            // [32] 1 = the row takes part
-  int* flags = reinterpret_cast<int*>(ok + M2_ROWS); // [4]
+  float* ok = lnb + M2_E;                            // [RT] 1 = the row takes part
+  int* flags = reinterpret_cast<int*>(ok + RT);      // [4]
   const int tid = threadIdx.x;
   const int t = blockIdx.x;
-  const int64_t row0 = (int64_t)t * M2_ROWS;
+  const int64_t row0 = (int64_t)t * RT;
   if (t == 0 && tid == 0) w.gate[1] = 0u;           // (the backward's first stage may ride behind this gate: scorer_fused_bwd_kernel)
-  if (w.own_n > 0 && m2_tile_dead(xrows, R, row0, w, flags)) {
+  if (w.own_n > 0 && m2_tile_dead<RT>(xrows, R, row0, w, flags)) {
     // an instance-sharded bag: no row of this tile is this shard's - an empty partial (weight 0 in every merge; its pooled rows are never read)
     if (tid < M2_JP) { w.pm[t * M2_JP + tid] = -INFINITY; w.pl[t * M2_JP + tid] = 0.f; w.psd[t * M2_JP + tid] = 0.f; }
     return;
   }
   M2Frags fr;
   m2_fetch_frags(w.aqf, fr);
-  m2_load_rows<false>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr, w, ok);
+  m2_load_rows<false, RT>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr, w, ok);
   __syncthreads();
-  m2_rows_times_slots(xh, lnw, lnb, fr, red);
+  m2_rows_times_slots<RT>(xh, lnw, lnb, fr, red);
   __syncthreads();
-  for (int idx = tid; idx < M2_ROWS * M2_JP; idx += M2_THREADS) {
-    const float s = (red[idx] + red[M2_ROWS * M2_JP + idx]) + (red[2 * M2_ROWS * M2_JP + idx] + red[3 * M2_ROWS * M2_JP + idx]);
+  for (int idx = tid; idx < RT * M2_JP; idx += M2_THREADS) {
+    const float s = (red[idx] + red[RT * M2_JP + idx]) + (red[2 * RT * M2_JP + idx] + red[3 * RT * M2_JP + idx]);
     red[idx] = s;
     const int r = idx / M2_JP;
     if (row0 + r < R) w.S[(row0 + r) * M2_JP + (idx - r * M2_JP)] = s;
   }
   __syncthreads();
-  // per-slot softmax partials of the tile: 4 threads per slot (8 rows each), combined through LDS
-  float* sc = red + M2_ROWS * M2_JP;                 // [3][4][48] scratch (the partial-product slabs 1..3 are free)
+  // per-slot softmax partials of the tile: 4 threads per slot (RT / 4 rows each), combined through LDS
+  float* sc = red + RT * M2_JP;                      // [3][4][48] scratch (the partial-product slabs 1..3 are free)
   const int j = tid % M2_JP, rq = tid / M2_JP;        // rq < 4 for the first 192 threads
-  float sreg[8], m = -INFINITY;
-  bool rv[8];
+  float sreg[RQ], m = -INFINITY;
+  bool rv[RQ];
   if (rq < 4) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = rq * 8 + q;
+    for (int q = 0; q < RQ; ++q) {
+      const int r = rq * RQ + q;
       sreg[q] = red[r * M2_JP + j];
       rv[q] = ok[r] != 0.f;
       if (j < J && rv[q]) m = fmaxf(m, sreg[q]);
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
     const float ks = 1.f / (1.f - drop_p);
     float l = 0.f, sd = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = rq * 8 + q;
+    for (int q = 0; q < RQ; ++q) {
+      const int r = rq * RQ + q;
       float p = 0.f, pd = 0.f;
       if (j < J && rv[q]) {
         p = __expf(sreg[q] - m);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
       }
       l += p;
       sd += pd;
-      pdT[j * M2_PLD + r] = pd;
+      pdT[j * PLD + r] = pd;
     }
     sc[(4 + rq) * M2_JP + j] = l;
     sc[(8 + rq) * M2_JP + j] = sd;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
     w.pl[t * M2_JP + tid] = (sc[4 * M2_JP + tid] + sc[5 * M2_JP + tid]) + (sc[6 * M2_JP + tid] + sc[7 * M2_JP + tid]);
     w.psd[t * M2_JP + tid] = (sc[8 * M2_JP + tid] + sc[9 * M2_JP + tid]) + (sc[10 * M2_JP + tid] + sc[11 * M2_JP + tid]);
   }
-  m2_pool_rows(pdT, xh, w.ypart + (int64_t)t * M2_JP * M2_E);
+  m2_pool_rows<RT>(pdT, xh, w.ypart + (int64_t)t * M2_JP * M2_E);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -181,12 +183,13 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_bwd_pre_kernel(const float*
 // ----------------------------------------------------------------------------------------------------------------------
 // 5. rows backward (body: mca2_rows.hpp).   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
+template <int RT>
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
                                                                     float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick,
                                                                     float* __restrict__ dX, Merge2Ws w) {
   extern __shared__ __attribute__((aligned(16))) float m2sm[];
-  merge2_rows_bwd_body((int)blockIdx.x, m2sm, X, xrows, R, ln_w, ln_b, J, drop_p, seed0, tick, dX, w);
+  merge2_rows_bwd_body<RT>((int)blockIdx.x, m2sm, X, xrows, R, ln_w, ln_b, J, drop_p, seed0, tick, dX, w);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -249,9 +252,14 @@ static int merge2_fwd_rows(hipStream_t st, const mhimx_merge* m, const float* X,
     hipLaunchKernelGGL(merge2_prep_kernel, dim3(64), dim3(M2_THREADS), 0, st, Merge2PrepArgs{m->q_param, m->ln_w, m->ln_b, m->wq, m->wkv, k, scale, w});
     MHIMX_LAUNCH_CHECK();
   }
-  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M2_FWD_SMEM)));
-  hipLaunchKernelGGL(merge2_rows_fwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_FWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
-                     m->drop_seed, m->drop_tick, w);
+  MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_fwd_smem(32)));
+                        MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_fwd_smem(16))));
+  if (w.rt == 16)
+    hipLaunchKernelGGL(merge2_rows_fwd_kernel<16>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_fwd_smem(16), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                       m->drop_seed, m->drop_tick, w);
+  else
+    hipLaunchKernelGGL(merge2_rows_fwd_kernel<32>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_fwd_smem(32), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                       m->drop_seed, m->drop_tick, w);
   MHIMX_LAUNCH_CHECK();
   *wout = w;
   return 0;
@@ -387,9 +395,14 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
     MHIMX_LAUNCH_CHECK();
   }
   if (!rows_done) {
-    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M2_BWD_SMEM)));
-    hipLaunchKernelGGL(merge2_rows_bwd_kernel, dim3((unsigned)w.T), dim3(M2_THREADS), M2_BWD_SMEM, st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
-                       m->drop_seed, m->drop_tick, dX, w);
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_bwd_smem(32)));
+                          MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_bwd_smem(16))));
+    if (w.rt == 16)
+      hipLaunchKernelGGL(merge2_rows_bwd_kernel<16>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_bwd_smem(16), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                         m->drop_seed, m->drop_tick, dX, w);
+    else
+      hipLaunchKernelGGL(merge2_rows_bwd_kernel<32>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_bwd_smem(32), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                         m->drop_seed, m->drop_tick, dX, w);
     MHIMX_LAUNCH_CHECK();
   }
   // the parameter-gradient tail: U [J, E] takes the place of the fp32 copy of aq (not needed any more)

@@ -1,6 +1,8 @@
 // mca2_prep.hpp — the pieces of the projection-free Merge (mca2.hip) that the step's preparation launch (gemm_dma.hip) shares: workspace
 // layout, fragment-image stores, and the parameter-only kernel body (gq = LN(q), Q, aq and its images).
 #pragma once
+#include <stdlib.h>
+
 #include "mma_tile.hpp"
 
 namespace mhimx {
@@ -20,12 +22,23 @@ struct Merge2Ws {
   // its X / dX hold only those rows (row id - own_lo).  Rows of the list outside the range take no part here (score -inf, zero gradient):
   // they are another shard's.  own_n == 0: every row is this process's (one GPU).
   int64_t own_lo, own_n;
-  int T;
+  int T;                     // row tiles
+  int rt;                    // rows per tile: 16 (R <= 4096: twice the workgroups on a pass that is a latency chain per tile) or 32
 };
+
+// rows per tile of a Merge over R rows.  The row passes are per-tile latency chains on ceil(R / rt) CUs; half-size tiles halve the row loads,
+// LayerNorm reductions and matrix-core steps of every wave and double the CUs at work (c2: 970 rows, 31 -> 61 workgroups).  Long row
+// lists keep 32 rows (the per-tile pooled partials are [48, 512] floats each: twice the tiles = twice that traffic).
+inline int m2_tile_rows(int64_t R) {
+  static const int forced = getenv("MHIMX_MERGE_TILE") ? atoi(getenv("MHIMX_MERGE_TILE")) : 0;
+  if (forced == 16 || forced == 32) return forced;
+  return R <= 4096 ? 16 : 32;
+}
 
 inline int64_t merge2_ws_layout(Arena& ar, int64_t R, int64_t k, Merge2Ws* out) {
   Merge2Ws w;
-  const int64_t T = cdiv(R, M2_ROWS);
+  w.rt = m2_tile_rows(R);
+  const int64_t T = cdiv(R, w.rt);
   w.T = (int)T;
   w.gq = ar.take<float>(k * M2_E);
   w.gmean = ar.take<float>(k);

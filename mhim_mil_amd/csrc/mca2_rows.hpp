@@ -27,10 +27,11 @@ MHIMX_DEV bool m2_row_ok(const int64_t* __restrict__ xrows, int64_t R, int64_t n
   return true;
 }
 // sharded bags only: true when no row of the tile is this shard's (every thread gets the same answer; flags: 4 ints of LDS)
+template <int RT>
 MHIMX_DEV bool m2_tile_dead(const int64_t* __restrict__ xrows, int64_t R, int64_t row0, const Merge2Ws& w, int* flags) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t dummy;
-  const bool mine = lane < 8 && m2_row_ok(xrows, R, row0 + wave + 4 * lane, w, dummy);
+  const bool mine = lane < RT / 4 && m2_row_ok(xrows, R, row0 + wave + 4 * lane, w, dummy);
   const bool any = __builtin_amdgcn_ballot_w64(mine) != 0;
   if (lane == 0) flags[wave] = any ? 1 : 0;
   __syncthreads();
@@ -38,16 +39,18 @@ MHIMX_DEV bool m2_tile_dead(const int64_t* __restrict__ xrows, int64_t R, int64_
   __syncthreads();
   return dead;
 }
-template <bool HAVE_STATS>
+// RT = rows of a tile (16 or 32: M2_ROWS is the larger; the LDS pitches are the same, the row counts are RT)
+template <bool HAVE_STATS, int RT>
 MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R, int64_t row0, float* xh, float* mean,
                             float* rstd, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* lnw, float* lnb, float* rs_tile,
                             const Merge2Ws& w, float* ok) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  m2_f4 a[8], b[8];
-  float mu8[8], rs8[8];
-  bool okq[8];
+  constexpr int QN = RT / 4;                                  // rows per wave
+  m2_f4 a[QN], b[QN];
+  float mu8[QN], rs8[QN];
+  bool okq[QN];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {                               // all 16 row loads of this wave in flight
+  for (int q = 0; q < QN; ++q) {                              // all the row loads of this wave in flight
     const int64_t n = row0 + wave + 4 * q;
     const int64_t nc = n < R ? n : R - 1;
     int64_t srow;
@@ -60,7 +63,7 @@ MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restri
   if (tid < 128) *reinterpret_cast<m2_f4*>(lnw + 4 * tid) = *reinterpret_cast<const m2_f4*>(ln_w + 4 * tid);
   else *reinterpret_cast<m2_f4*>(lnb + 4 * (tid - 128)) = *reinterpret_cast<const m2_f4*>(ln_b + 4 * (tid - 128));
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < QN; ++q) {
     const int rr = wave + 4 * q;
     const int64_t n = row0 + rr;
     float mu, rs;
@@ -95,12 +98,14 @@ MHIMX_DEV void m2_fetch_frags(const float* __restrict__ img, M2Frags& f) {
 }
 
 // red[wave][32][48] = (xhat w + b)[32 x 512] . img^T over this wave's quarter of the 512-deep reduction (3-term bf16)
+template <int RT>
 MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* lnw, const float* lnb, const M2Frags& f, float* red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
-  f32x4 acc[2][3];
+  constexpr int RB = RT / 16;
+  f32x4 acc[RB][3];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -108,9 +113,9 @@ MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* lnw, const floa
     const int e0 = (4 * wave + q) * 32 + kg * 8;
     const m2_f4 w0 = *reinterpret_cast<const m2_f4*>(lnw + e0), w1 = *reinterpret_cast<const m2_f4*>(lnw + e0 + 4);
     const m2_f4 b0 = *reinterpret_cast<const m2_f4*>(lnb + e0), b1 = *reinterpret_cast<const m2_f4*>(lnb + e0 + 4);
-    bf8 ah[2], al[2];
+    bf8 ah[RB], al[RB];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < RB; ++rb) {
       const float* p = xh + (rb * 16 + r16) * M2_XLD + e0;
       const m2_f4 x0 = *reinterpret_cast<const m2_f4*>(p) * w0 + b0, x1 = *reinterpret_cast<const m2_f4*>(p + 4) * w1 + b1;
       const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
@@ -120,12 +125,12 @@ MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* lnw, const floa
     for (int nb = 0; nb < 3; ++nb) {
       const bf8 bh = __builtin_bit_cast(bf8, f.h[nb][q]), bl = __builtin_bit_cast(bf8, f.l[nb][q]);
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) acc[rb][nb] = m2_mfma3(ah[rb], al[rb], bh, bl, acc[rb][nb]);
+      for (int rb = 0; rb < RB; ++rb) acc[rb][nb] = m2_mfma3(ah[rb], al[rb], bh, bl, acc[rb][nb]);
     }
   }
-  float* out = red + wave * (M2_ROWS * M2_JP);
+  float* out = red + wave * (RT * M2_JP);
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
@@ -133,14 +138,19 @@ MHIMX_DEV void m2_rows_times_slots(const float* xh, const float* lnw, const floa
 }
 
 // part[slot][:] = sum_r coefT[slot][r] xhat[r][:]   ([48 x 32] . [32 x 512], 3-term bf16): one 32-deep MFMA step per 16 x 16 block
-MHIMX_DEV void m2_pool_rows(const float* coefT /* LDS [48][36] */, const float* xh, float* __restrict__ part /* global [48][512] */) {
+// (RT = 16: the upper half of the 32-deep step is zero - rows 16..31 do not exist)
+template <int RT>
+MHIMX_DEV void m2_pool_rows(const float* coefT /* LDS [48][RT + 4] */, const float* xh, float* __restrict__ part /* global [48][512] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
+  constexpr int PLD = RT + 4;
+  const bool kin = kg * 8 < RT;
   bf8 ah[3], al[3];
 #pragma unroll
   for (int jb = 0; jb < 3; ++jb) {
-    const float* p = coefT + (jb * 16 + r16) * M2_PLD + kg * 8;
-    const m2_f4 c0 = *reinterpret_cast<const m2_f4*>(p), c1 = *reinterpret_cast<const m2_f4*>(p + 4);
+    const float* p = coefT + (jb * 16 + r16) * PLD + (kin ? kg * 8 : 0);
+    m2_f4 c0 = *reinterpret_cast<const m2_f4*>(p), c1 = *reinterpret_cast<const m2_f4*>(p + 4);
+    if (!kin) { c0 = m2_f4{0.f, 0.f, 0.f, 0.f}; c1 = c0; }
     const float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
     m2_split8(v, ah[jb], al[jb]);
   }
@@ -148,7 +158,7 @@ MHIMX_DEV void m2_pool_rows(const float* coefT /* LDS [48][36] */, const float* 
   for (int eb = 8 * wave; eb < 8 * wave + 8; ++eb) {
     float v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = xh[(kg * 8 + q) * M2_XLD + eb * 16 + r16];
+    for (int q = 0; q < 8; ++q) v[q] = kin ? xh[(kg * 8 + q) * M2_XLD + eb * 16 + r16] : 0.f;
     bf8 bh, bl;
     m2_split8(v, bh, bl);
 #pragma unroll
@@ -160,38 +170,42 @@ MHIMX_DEV void m2_pool_rows(const float* coefT /* LDS [48][36] */, const float* 
   }
 }
 
+// rows per tile of a Merge over R rows (mca2_prep.hpp: merge2_ws_layout lays the partial buffers out for the same choice)
 MHIMX_DEV bool m2_keep(uint64_t seed, int j, int64_t r, float p) { return drop_keep(seed, (uint64_t)j, (uint32_t)r, p); }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // 5. rows backward: dPd = xn dY^T, softmax backward, dxn = ds aq + Pd dY, LayerNorm backward (dX scattered to the rows' places,
 //    per-tile d_ln_w / d_ln_b partials), pooled U partials.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t M2_BWD_SMEM = (size_t)(2 * M2_ROWS * M2_XLD + M2_ROWS * M2_CLD + M2_JP * M2_PLD + 2 * M2_E + 3 * M2_JK + 2 * M2_ROWS + 4) * sizeof(float);
-static_assert(M2_ROWS * M2_CLD >= 8 * M2_E, "the LayerNorm partials reuse the coefficient tile");
+constexpr size_t m2_bwd_smem(int rt) { return (size_t)(2 * rt * M2_XLD + rt * M2_CLD + M2_JP * (rt + 4) + 2 * M2_E + 3 * M2_JK + 2 * rt + 4) * sizeof(float); }
+constexpr size_t M2_BWD_SMEM = m2_bwd_smem(M2_ROWS);
+static_assert(16 * M2_XLD >= 8 * M2_E, "the LayerNorm partials reuse the gradient tile");
 
 // (a device function: the body of merge2_rows_bwd_kernel (mca2.hip) and of the rows pass that rides in the scorer-weight-gradient product's
 // launch, gemm_dma.hip: gemm_tn_dma_kernel<.., true>)   t: the row tile; m2sm: M2_BWD_SMEM bytes of LDS, 16-byte aligned
+template <int RT>
 MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J, float drop_p, uint64_t seed0,
                                     const uint64_t* __restrict__ tick, float* __restrict__ dX, const Merge2Ws& w) {
-  float* xh = m2sm;                                   // [32][516]
-  float* dxs = xh + M2_ROWS * M2_XLD;                 // [32][516]; first the [4][32][48] reduction buffer of dPd
-  float* cf = dxs + M2_ROWS * M2_XLD;                 // [32][132]: ds (slots 0..63) | Pd (64..127)
-  float* dsT = cf + M2_ROWS * M2_CLD;                 // [48][36]
-  float* lnw = dsT + M2_JP * M2_PLD;                  // [512]
+  constexpr int PLD = RT + 4, RB = RT / 16, QN = RT / 4;
+  float* xh = m2sm;                                   // [RT][516]
+  float* dxs = xh + RT * M2_XLD;                      // [RT][516]; first the [4][RT][48] reduction buffer of dPd
+  float* cf = dxs + RT * M2_XLD;                      // [RT][132]: ds (slots 0..63) | Pd (64..127)
+  float* dsT = cf + RT * M2_CLD;                      // [48][RT + 4]
+  float* lnw = dsT + M2_JP * PLD;                     // [512]
   float* lnb = lnw + M2_E;                            // [512]
   float* sst = lnb + M2_E;                            // [64][3]: softmax max, 1 / sum, delta of every slot
-  float* rst = sst + 3 * M2_JK;                       // [32] rstd of the tile's rows
-  float* ok = rst + M2_ROWS;                          // [32] 1 = the row takes part
-  int* flags = reinterpret_cast<int*>(ok + M2_ROWS);  // [4]
-  float* lnred = cf;                                  // [4][2][512]: the coefficient tile is in registers by then
+  float* rst = sst + 3 * M2_JK;                       // [RT] rstd of the tile's rows
+  float* ok = rst + RT;                               // [RT] 1 = the row takes part
+  int* flags = reinterpret_cast<int*>(ok + RT);       // [4]
+  float* lnred = dxs;                                 // [4][2][512]: the gradient tile has gone out to dX by then
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
-  const int64_t row0 = (int64_t)t * M2_ROWS;
+  const int64_t row0 = (int64_t)t * RT;
   if (t == 0 && tid == 0) *w.gate = 0u;               // (the tail's stage-2 arrivals are counted from here: bag_wgrad_ws_kernel)
   // an instance-sharded bag: a tile without a row of this shard leaves no gradient and no partial (the merges of the pooled / LayerNorm
   // partials skip the tiles whose forward partial is empty: w.pl == 0)
-  if (w.own_n > 0 && m2_tile_dead(xrows, R, row0, w, flags)) return;
+  if (w.own_n > 0 && m2_tile_dead<RT>(xrows, R, row0, w, flags)) return;
   M2Frags fr;
   m2_fetch_frags(w.dyf, fr);
   if (tid < M2_JK) {
@@ -206,27 +220,27 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
     sst[3 * j] = mx; sst[3 * j + 1] = il; sst[3 * j + 2] = de;
   }
   // the scores of the tile's (row, slot) pairs this thread will turn into probabilities: in flight under the row loads
-  float sv[M2_ROWS * M2_JK / M2_THREADS];
+  float sv[RT * M2_JK / M2_THREADS];
 #pragma unroll
-  for (int q = 0; q < M2_ROWS * M2_JK / M2_THREADS; ++q) {
+  for (int q = 0; q < RT * M2_JK / M2_THREADS; ++q) {
     const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
     sv[q] = (j < J && row0 + r < R) ? w.S[(row0 + r) * M2_JP + j] : 0.f;
   }
-  m2_load_rows<true>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, rst, w, ok);
+  m2_load_rows<true, RT>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, rst, w, ok);
   __syncthreads();
-  m2_rows_times_slots(xh, lnw, lnb, fr, dxs);
+  m2_rows_times_slots<RT>(xh, lnw, lnb, fr, dxs);
   __syncthreads();
   // ---- softmax backward per (row, slot)
   {
     const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
     const float ks = 1.f / (1.f - drop_p);
 #pragma unroll
-    for (int q = 0; q < M2_ROWS * M2_JK / M2_THREADS; ++q) {
+    for (int q = 0; q < RT * M2_JK / M2_THREADS; ++q) {
       const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
       float ds = 0.f, pd = 0.f;
       if (j < J && ok[r] != 0.f) {
         const int qq = r * M2_JP + j;
-        const float dpd = (dxs[qq] + dxs[M2_ROWS * M2_JP + qq]) + (dxs[2 * M2_ROWS * M2_JP + qq] + dxs[3 * M2_ROWS * M2_JP + qq]);
+        const float dpd = (dxs[qq] + dxs[RT * M2_JP + qq]) + (dxs[2 * RT * M2_JP + qq] + dxs[3 * RT * M2_JP + qq]);
         const float p = __expf(sv[q] - sst[3 * j]) * sst[3 * j + 1];
         const float kf = (drop_p > 0.f && !m2_keep(seed, j, row0 + r, drop_p)) ? 0.f : ks;
         pd = p * kf;
@@ -234,16 +248,16 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
       }
       cf[r * M2_CLD + j] = ds;
       cf[r * M2_CLD + M2_JK + j] = pd;
-      if (j < M2_JP) dsT[j * M2_PLD + r] = ds;
+      if (j < M2_JP) dsT[j * PLD + r] = ds;
     }
   }
   __syncthreads();
   // ---- dxn[32 x 512] = cf[32 x 128] . [aq ; dY]  (K = 128 = 4 steps of 32; B from the transposed fragment images, 4 column blocks
   //      = 32 fragment loads in flight at a time)
   {
-    bf8 ah[2][4], al[2][4];
+    bf8 ah[RB][4], al[RB][4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const float* p = cf + (rb * 16 + r16) * M2_CLD + ks * 32 + kg * 8;
@@ -265,14 +279,16 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
         }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb)
+          for (int rb = 0; rb < RB; ++rb)
             acc[rb] = m2_mfma3(ah[rb][ks], al[rb][ks], __builtin_bit_cast(bf8, bh[q][ks]), __builtin_bit_cast(bf8, bl[q][ks]), acc[rb]);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
           for (int i = 0; i < 4; ++i) dxs[(rb * 16 + 4 * kg + i) * M2_XLD + (eb0 + q) * 16 + r16] = acc[rb][i];
       }
@@ -283,14 +299,14 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
   {
     const m2_f4 wa = *reinterpret_cast<const m2_f4*>(lnw + 4 * lane), wb = *reinterpret_cast<const m2_f4*>(lnw + 256 + 4 * lane);
     m2_f4 dwa = m2_f4{0.f, 0.f, 0.f, 0.f}, dwb = dwa, dba = dwa, dbb = dwa;
-    int64_t dst_row[8];
+    int64_t dst_row[QN];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < QN; ++q) {
       int64_t srow;
       dst_row[q] = m2_row_ok(xrows, R, row0 + wave + 4 * q, w, srow) ? srow : -1;      // (a shard's dX holds its own rows: id - own_lo)
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < QN; ++q) {
       const int rr = wave + 4 * q;
       if (dst_row[q] < 0) continue;
       const m2_f4 ga = *reinterpret_cast<const m2_f4*>(dxs + rr * M2_XLD + 4 * lane), gb = *reinterpret_cast<const m2_f4*>(dxs + rr * M2_XLD + 256 + 4 * lane);
@@ -307,7 +323,7 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
       *reinterpret_cast<m2_f4*>(dst + 4 * lane) = (ha - s1 - xa * s2) * rs;
       *reinterpret_cast<m2_f4*>(dst + 256 + 4 * lane) = (hb - s1 - xb * s2) * rs;
     }
-    __syncthreads();                                  // (lnred aliases cf; nobody reads cf any more, but keep the waves together)
+    __syncthreads();                                  // (lnred aliases dxs: every wave has read its rows of the gradient tile)
     *reinterpret_cast<m2_f4*>(lnred + (wave * 2) * M2_E + 4 * lane) = dwa;
     *reinterpret_cast<m2_f4*>(lnred + (wave * 2) * M2_E + 256 + 4 * lane) = dwb;
     *reinterpret_cast<m2_f4*>(lnred + (wave * 2 + 1) * M2_E + 4 * lane) = dba;
@@ -317,7 +333,7 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
   for (int idx = tid; idx < 2 * M2_E; idx += M2_THREADS)
     w.lnpart[(int64_t)t * 2 * M2_E + idx] = (lnred[idx] + lnred[2 * M2_E + idx]) + (lnred[4 * M2_E + idx] + lnred[6 * M2_E + idx]);
   // ---- pooled U partial (of xhat; the LayerNorm weight is applied when the partials are merged)
-  m2_pool_rows(dsT, xh, w.upart + (int64_t)t * M2_JP * M2_E);
+  m2_pool_rows<RT>(dsT, xh, w.upart + (int64_t)t * M2_JP * M2_E);
 }
 
 
