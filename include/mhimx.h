@@ -252,7 +252,10 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  * 9 = the bag in[R,C] (contiguous rows, C % 256 == 0) as the D-side operand image of the weight-gradient product (mhimx_bag_wgrad_args.ximg;
  *     out: ceil(R / 32) * 32 * C floats): per 32-row k-step ks and 256-column block cb one 32 KiB tile (ks * C / 256 + cb) laid out
  *     [row octet 4][hi | lo][column slot 256][8 bf16], column c of the block in slot (c % 4) * 64 + c / 4; rows past R are zero.  Not a
- *     parameter-only job (it reads the bag) but one that depends on nothing else: it rides in a forward launch that leaves the chip idle. */
+ *     parameter-only job (it reads the bag) but one that depends on nothing else: it rides in a forward launch that leaves the chip idle.
+ * 10 = ((int64_t*)out)[i] = R + i for i < C (in unused): the constant tail of a step's row list - the ids N .. N + k - 1 of the k merged-token
+ *     rows behind a bag's N feature rows (mhimx_step_run writes it with the step's first launch).
+ */
 #define MHIMX_PREP_MAX 24
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
@@ -710,6 +713,75 @@ typedef struct {
                                    final gradient): the whole list is flushed then. */
 } mhimx_optim_args;
 int mhimx_optim_step(void* stream, const mhimx_optim_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * The whole MHIM(ABMIL) train step of one bag behind ONE call        (round 5)
+ * replaces: engines/common_mil.py:14-48 (forward_func: model_ema.forward_teacher -> model(bag, score, teacher_feat)) together with
+ *           engines/base_engine.py:76-167 (criterion, loss.backward(), optimizer.step(), the per-parameter EMA) for one bag, i.e.
+ *           modules/mhim.py:181-227 (forward_teacher) -> :109-179 (get_mask) -> :318-378 (forward) -> their autograd -> Adam + EMA.
+ * One call enqueues the step's ~17 launches (the entry points above, in the order mhim_mil_amd/engine.py issues them: same kernels, same
+ * arguments, same bits) on `stream`: no allocation, no host sync, nothing read back - the host cost of a step is the launches themselves
+ * (tens of microseconds) instead of ~1700 interpreter calls, and any language binds the step with one function.  Capturable into a hipGraph.
+ *   teacher and student projection in one pass over the bag -> teacher scorer + pool (+ pseudo score) -> device-drawn HAM mask and Merge
+ *   split (mhimx_select_rows) -> Merge -> student scorer + pool -> head (CE + distillation) -> backward -> [fused Adam + EMA teacher].
+ * Shapes: the single-pass ABMIL step's (E = 512, A = 128, plain scorer, C <= 4, 8 x 64 Merge heads with 8 k <= 48, D % 256 == 0,
+ * 64 <= N <= 16384, k_top <= 4096); anything else returns < 0 and the caller composes the step from the building blocks.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {                                  /* one model's parameters: device pointers (views of a flat parameter buffer)          */
+  const float* w1; const float* b1;               /* feature.0.weight [E,D], feature.0.bias [E]                                          */
+  const float* wa; const float* wc;               /* online_encoder.attention.attention.0.weight [A,E], attention.2.weight [A]           */
+  const float* wp; const float* bp;               /* predictor.weight [C,E], predictor.bias [C]                                          */
+  float* q;                                       /* merge.global_q_mm [k,E]: the student's is EMA-updated by its own forward (merge.py:142-143) */
+  const float* ln_w; const float* ln_b;           /* merge.norm                                                                          */
+  const float* wkv; const float* wq; const float* wo; const float* bo;   /* merge.attn.to_kv [2I,E], to_q [I,E], to_out.0 [E,I], bias [E] */
+} mhimx_step_params;
+typedef struct {                                  /* where the gradients go (views of the flat gradient buffer), overwritten               */
+  float* w1; float* b1; float* wa; float* wc; float* wp; float* bp; float* ln_w; float* ln_b; float* wkv; float* wq; float* wo; float* bo;
+} mhimx_step_grads;
+typedef struct {
+  int64_t D, E, A, C, k;                          /* input_dim, mlp_dim, scorer width, classes, merge_k                                  */
+  int32_t act, da_act;                            /* MHIMX_ACT_* of the feature / the scorer                                             */
+  int32_t attn2score;                             /* the teacher's instance score: 1 = pseudo score (scoring.py:37-58), 0 = attention    */
+  float drop_p_teacher, drop_p_student;           /* feature dropout (mhim.py:76); the teacher's is 0 unless it runs in train mode        */
+  float merge_drop_p, merge_mm;                   /* MCA dropout (merge.py:33,40), EMA momentum of the global queries                    */
+  float temp_t, main_alpha, aux_alpha;
+  mhimx_step_params student, teacher;             /* (teacher: the merge.* fields are not read)                                          */
+  mhimx_step_grads grad;
+  float* p; float* g; float* m; float* v; float* p_teacher;    /* the flat buffers of mhimx_optim_step (p_teacher NULL: no EMA)           */
+  int64_t n_train, n_all;
+  float lr, beta1, beta2, eps, weight_decay, ema_mm;
+  const float* mm_table; int64_t mm_len; const float* lr_table; int64_t lr_len;
+  uint64_t* tick; uint64_t* opt_step;             /* device counters: dropout / draw stream position, Adam step (advanced by the step)   */
+} mhimx_step_cfg;
+/* row counts of one step (masking.py:30-35,61 and merge.py:163 in float64, as the reference computes them):
+ * k_top = ceil(N r), r = mask_ratio_h / mask_ratio_hr (r > 1: r = 1, hr = mask_ratio_h); n_sel = ceil(k_top hr) if hr < 1 else k_top;
+ * len_keep = N - n_sel; Lk = int(len_keep merge_ratio); R = len_keep - Lk.   returns < 0 when the recipe leaves nothing to mask or merge */
+typedef struct { int64_t k_top, n_sel, len_keep, Lk, R; } mhimx_step_counts;
+int mhimx_step_counts_of(int64_t N, double mask_ratio_h, double mask_ratio_hr, double merge_ratio, mhimx_step_counts* out);
+/* seeds of the step's four counter-hash streams (mixed with *tick on the device) */
+typedef struct { uint64_t drop_teacher, drop_student, select, mca; } mhimx_step_seeds;
+/* byte offsets, inside the workspace, of what a caller may want to look at after a step (valid until the next step on that workspace) */
+typedef struct {
+  int64_t total;                                  /* bytes mhimx_step_run needs for this (N, counts)                                      */
+  int64_t logits, losses;                         /* float [C], float [3] = {main ce + aux cl, ce, cl}                                    */
+  int64_t score;                                  /* float [N]: the teacher's instance score                                             */
+  int64_t rows_all;                               /* int64 [len_keep + k] = [rows to merge (R) | rows that stay (Lk) | N .. N+k-1]        */
+  int64_t H_teacher, H_student;                   /* float [N,E], float [N+k,E] (rows N..: the merged tokens)                             */
+  int64_t dact;                                   /* fp16 [N,E]: d out / d pre of the student's projection                                */
+  int64_t z_teacher, z_student, g_z;              /* float [E] each                                                                       */
+  int64_t dH;                                     /* float [N+k,E]: gradient of the student's feature rows                                */
+} mhimx_step_layout;
+int mhimx_step_layout_of(const mhimx_step_cfg* cfg, int64_t N, const mhimx_step_counts* cnt, mhimx_step_layout* out);
+/* one bag.  update = 1: the fused Adam + EMA follows (the backward's last reductions ride / fold as in the trainer's own step);
+ * update = 0: forward + backward only, the complete gradient in cfg->grad.  host_step: the Adam step after this update when
+ * cfg->opt_step is NULL.  X [N, ldx] fp32 device, label_dev int64 [1] device. */
+int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const float* X, int64_t ldx, int64_t N, const int64_t* label_dev,
+                   const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws, int64_t ws_bytes, int32_t update);
+/* n_bags consecutive complete steps (one update each), bag after bag, on one workspace of max_b layout.total bytes (SURVEY.md 7 H4
+ * "run_steps"): a resident dataset's epoch as one call per chunk of bags. */
+int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, const int64_t* ldx, const int64_t* N,
+                        const int64_t* const* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step0,
+                        void* ws, int64_t ws_bytes);
 
 /* dst = src (float4 grid-stride stream copy): the on-box HBM copy rate bench.py reports beside the nominal 8 TB/s */
 int mhimx_stream_copy(void* stream, const float* src, float* dst, int64_t n_floats);

@@ -171,6 +171,43 @@ class OptimArgs(C.Structure):
                 ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("fold", C.c_void_p)]
 
 
+class StepParams(C.Structure):
+    """mhimx_step_params (include/mhimx.h): one model's parameters as device pointers."""
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "wa", "wc", "wp", "bp", "q", "ln_w", "ln_b", "wkv", "wq", "wo", "bo")]
+
+
+class StepGrads(C.Structure):
+    """mhimx_step_grads."""
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "wa", "wc", "wp", "bp", "ln_w", "ln_b", "wkv", "wq", "wo", "bo")]
+
+
+class StepCfg(C.Structure):
+    """mhimx_step_cfg."""
+    _fields_ = [("D", C.c_int64), ("E", C.c_int64), ("A", C.c_int64), ("C", C.c_int64), ("k", C.c_int64),
+                ("act", C.c_int32), ("da_act", C.c_int32), ("attn2score", C.c_int32),
+                ("drop_p_teacher", C.c_float), ("drop_p_student", C.c_float), ("merge_drop_p", C.c_float), ("merge_mm", C.c_float),
+                ("temp_t", C.c_float), ("main_alpha", C.c_float), ("aux_alpha", C.c_float),
+                ("student", StepParams), ("teacher", StepParams), ("grad", StepGrads),
+                ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("p_teacher", C.c_void_p),
+                ("n_train", C.c_int64), ("n_all", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("ema_mm", C.c_float),
+                ("mm_table", C.c_void_p), ("mm_len", C.c_int64), ("lr_table", C.c_void_p), ("lr_len", C.c_int64),
+                ("tick", C.c_void_p), ("opt_step", C.c_void_p)]
+
+
+class StepCounts(C.Structure):
+    _fields_ = [("k_top", C.c_int64), ("n_sel", C.c_int64), ("len_keep", C.c_int64), ("Lk", C.c_int64), ("R", C.c_int64)]
+
+
+class StepSeeds(C.Structure):
+    _fields_ = [("drop_teacher", C.c_uint64), ("drop_student", C.c_uint64), ("select", C.c_uint64), ("mca", C.c_uint64)]
+
+
+class StepLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("total", "logits", "losses", "score", "rows_all", "H_teacher", "H_student", "dact", "z_teacher",
+                                        "z_student", "g_z", "dH")]
+
+
 SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
@@ -276,6 +313,10 @@ SYMBOLS = {
     "mhimx_ppeg_band_bwd_ws_floats": (_I64, [_I64, _I64]),
     "mhimx_ppeg_band_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "mhimx_scale_heads": (C.c_int, [_P, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
+    "mhimx_step_counts_of": (C.c_int, [_I64, C.c_double, C.c_double, C.c_double, C.POINTER(StepCounts)]),
+    "mhimx_step_layout_of": (C.c_int, [C.POINTER(StepCfg), _I64, C.POINTER(StepCounts), C.POINTER(StepLayout)]),
+    "mhimx_step_run": (C.c_int, [_P, C.POINTER(StepCfg), _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),
+    "mhimx_step_run_many": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _P, _P, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64]),
 }
 
 _lib = None

@@ -551,8 +551,8 @@ int prep_jobs_fill(const mhimx_prep_job* jobs, int n, PrepJobs* out) {
   int n_merge = 0;
   for (int i = 0; i < n; ++i) {
     pj.j[i] = jobs[i];
-    MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].in), "prep_batch: null pointer in job %d", i);
-    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 9, "prep_batch: unknown job kind");
+    MHIMX_CHECK_ARG(jobs[i].out && (jobs[i].kind == 3 || jobs[i].kind == 10 || jobs[i].in), "prep_batch: null pointer in job %d", i);
+    MHIMX_CHECK_ARG(jobs[i].kind >= 0 && jobs[i].kind <= 10, "prep_batch: unknown job kind");
     if (jobs[i].kind == 6) {
       MHIMX_CHECK_ARG(n_merge < PREP_MERGE_MAX, "prep_batch: at most %d Merge preparation jobs per launch", PREP_MERGE_MAX);
       Merge2PrepArgs m2;
@@ -578,7 +578,7 @@ int prep_jobs_fill(const mhimx_prep_job* jobs, int n, PrepJobs* out) {
   }
   int first = 0;
   for (int i = 0; i < n; ++i) {
-    const int64_t items = jobs[i].kind == 3 ? 1 : (jobs[i].kind == 0 ? cdiv(jobs[i].R, 32) * cdiv(jobs[i].C, 32) :
+    const int64_t items = (jobs[i].kind == 3 || jobs[i].kind == 10) ? 1 : (jobs[i].kind == 0 ? cdiv(jobs[i].R, 32) * cdiv(jobs[i].C, 32) :
                           (jobs[i].kind == 8 ? cdiv(jobs[i].R, 16) * 16 * jobs[i].C / 8 : jobs[i].R * jobs[i].C / 8));
     int64_t want = jobs[i].kind == 0 ? items : cdiv(items, 256);
     if (jobs[i].kind == 6) want = 64;                  // 8 heads x 8 column blocks

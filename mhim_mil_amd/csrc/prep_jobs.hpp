@@ -159,6 +159,10 @@ MHIMX_DEV void prep_job_block(const PrepJobs& pj, int block, float* lds) {
         *reinterpret_cast<pj_f4*>(tile + j * 1024 + 4096) = __builtin_bit_cast(pj_f4, lo);
       }
     }
+  } else if (jb.kind == 10) {
+    // ((int64_t*)out)[i] = R + i, i < C: the constant tail of a step's row list (the k merged-token rows behind a bag's N feature rows)
+    int64_t* o = reinterpret_cast<int64_t*>(jb.out);
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < C; i += (int64_t)nblk * 256) o[i] = R + i;
   } else if (jb.kind == 6) {
     Merge2Ws w = pj.m2.w;
     const int64_t sh = pj.m2_shift[jb.R];             // (only the fields the preparation writes are shifted)

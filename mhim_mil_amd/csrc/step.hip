@@ -1,0 +1,292 @@
+// step.hip — mhimx_step_run: the whole MHIM(ABMIL) train step of one bag behind ONE C call (include/mhimx.h).
+//
+// replaces: engines/common_mil.py:14-48 + engines/base_engine.py:76-167 for one bag - and, on this side of the boundary, the Python
+// orchestration of mhim_mil_amd/engine.py (FusedTrainer._nat_prep / _nat_bag / _apply): the SAME entry points in the SAME order with the SAME
+// arguments, so a step through this executor has the bits of a step through the Python path given the same seeds.  Host code only: every
+// launch goes through the library's own extern "C" entry points.  No allocation, no synchronisation: the caller owns the workspace.
+//
+//   launch  1  mhimx_prep_batch         counters, both projection weight images, the teacher's scorer image (+ the row list's constant tail)
+//           2  mhimx_bag_project        teacher + student feature rows in ONE pass over the raw bag
+//         3,4  mhimx_abmil_pool_fwd     teacher scorer + pool partials (the student-side preparation jobs ride here) | finalize + pseudo score
+//           5  mhimx_select_rows        HAM mask + Merge split, both random subsets drawn on the device
+//        6..9  mhimx_merge_fwd          rows pass | partial merge | O | to_out + EMA of the global queries
+//       10,11  mhimx_abmil_pool_fwd     student scorer over [stay | tokens] | finalize
+//          12  mhimx_head_fwd_bwd       predictor, CE, distillation, their gradients
+//          13  mhimx_abmil_pool_bwd     one-pass rows backward (the Merge backward's first stage rides behind its gate)
+//          14  mhimx_merge_bwd          rows backward + the parked scorer-weight-gradient product in one launch
+//       15,16  rows_dpre_image | bag_wgrad   the projection's gradient pair (the Merge tail and the last reductions ride)
+//          17  mhimx_optim_step         Adam + EMA teacher (folds the split-K slab sum)
+#include <math.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace mhimx {
+
+namespace {
+
+struct Carve {
+  char* base;
+  int64_t off = 0;
+  explicit Carve(void* p) : base(static_cast<char*>(p)) {}
+  int64_t take_off(int64_t bytes) {
+    const int64_t o = off;
+    off = (off + bytes + 255) / 256 * 256;
+    return o;
+  }
+  template <typename T> T* at(int64_t o) const { return base ? reinterpret_cast<T*>(base + o) : nullptr; }
+};
+
+// every buffer of a step as a byte offset into the workspace
+struct StepBufs {
+  int64_t w1p_t, wa_frag_t, w1p_s, wa_frag_s, wa_t, wa_t_frag, wo_t, q_old, merge_ws, merge_ws_bytes;
+  int64_t H_t, Hbuf, dact;
+  int64_t s_t, stats_t, z_t, cproj_t, pscore, attn, pool_ws_t, pool_ws_t_bytes;
+  int64_t rows_all, sel_ws, sel_ws_bytes;
+  int64_t s_s, stats_s, z_s, pool_ws_s, pool_ws_s_bytes;
+  int64_t logits, losses, g_z;
+  int64_t dH, img, ws_b, ws_b_bytes, wg_ws, wg_ws_floats;
+  int64_t total;
+};
+
+int check_cfg(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n) {
+  MHIMX_CHECK_ARG(c && n, "step: null configuration / counts");
+  MHIMX_CHECK_ARG(c->E == 512 && c->A == 128 && c->C >= 1 && c->C <= 4 && c->k >= 1 && 8 * c->k <= 48 && c->D > 0 && c->D % 256 == 0,
+                  "step: shapes outside the single-pass ABMIL step (E = 512, A = 128, C <= 4, 8 k <= 48, D %% 256 == 0)");
+  MHIMX_CHECK_ARG(N >= 64 && N <= 16384 && n->k_top >= 1 && n->k_top <= 4096 && n->n_sel >= 1 && n->n_sel <= n->k_top && n->len_keep == N - n->n_sel &&
+                      n->Lk >= 1 && n->R >= 1 && n->R <= 32768 && n->Lk + n->R == n->len_keep,
+                  "step: row counts outside the device-drawn select (64 <= N <= 16384, k_top <= 4096, rows to merge and rows that stay >= 1)");
+  const mhimx_step_params &s = c->student, &t = c->teacher;
+  MHIMX_CHECK_ARG(s.w1 && s.b1 && s.wa && s.wc && s.wp && s.bp && s.q && s.ln_w && s.ln_b && s.wkv && s.wq && s.wo && s.bo, "step: null student parameter");
+  MHIMX_CHECK_ARG(t.w1 && t.b1 && t.wa && t.wc && (!c->attn2score || (t.wp && t.bp)), "step: null teacher parameter");
+  const mhimx_step_grads& g = c->grad;
+  MHIMX_CHECK_ARG(g.w1 && g.b1 && g.wa && g.wc && g.wp && g.bp && g.ln_w && g.ln_b && g.wkv && g.wq && g.wo && g.bo, "step: null gradient view");
+  MHIMX_CHECK_ARG(c->tick, "step: the device dropout / draw counter (tick) is required");
+  return 0;
+}
+
+void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, StepBufs* b) {
+  const int64_t D = c->D, E = c->E, A = c->A, C = c->C, k = c->k, I = 512;
+  Carve cv(nullptr);
+  const int64_t F = sizeof(float);
+  b->w1p_t = cv.take_off(E * D * F);
+  b->wa_frag_t = cv.take_off(A * E * F);
+  b->w1p_s = cv.take_off(E * D * F);
+  b->wa_frag_s = cv.take_off(A * E * F);
+  b->wa_t = cv.take_off(E * A * F);
+  b->wa_t_frag = cv.take_off(E * A * F);
+  b->wo_t = cv.take_off(I * E * F);
+  b->q_old = cv.take_off(k * E * F);
+  b->merge_ws_bytes = mhimx_merge_ws_bytes(n->R, E, k, 8, 64);
+  b->merge_ws = cv.take_off(b->merge_ws_bytes);
+  b->H_t = cv.take_off(N * E * F);
+  b->Hbuf = cv.take_off((N + k) * E * F);
+  b->dact = cv.take_off(N * E * 2);
+  b->s_t = cv.take_off(N * F);
+  b->stats_t = cv.take_off(2 * F);
+  b->z_t = cv.take_off(E * F);
+  b->cproj_t = cv.take_off(N * C * F);
+  b->pscore = cv.take_off(N * F);
+  b->attn = cv.take_off(N * F);
+  b->pool_ws_t_bytes = mhimx_abmil_pool_ws_bytes(N, E, A, 0);
+  b->pool_ws_t = cv.take_off(b->pool_ws_t_bytes);
+  b->rows_all = cv.take_off((n->len_keep + k) * 8);
+  b->sel_ws_bytes = mhimx_select_ws_bytes(N);
+  b->sel_ws = cv.take_off(b->sel_ws_bytes);
+  const int64_t M = n->Lk + k;
+  b->s_s = cv.take_off(M * F);
+  b->stats_s = cv.take_off(2 * F);
+  b->z_s = cv.take_off(E * F);
+  b->pool_ws_s_bytes = mhimx_abmil_pool_ws_bytes(M, E, A, 0);
+  b->pool_ws_s = cv.take_off(b->pool_ws_s_bytes);
+  b->logits = cv.take_off(16 * F);
+  b->losses = cv.take_off(4 * F);
+  b->g_z = cv.take_off(E * F);
+  b->dH = cv.take_off((N + k) * E * F);
+  b->img = cv.take_off(mhimx_wgrad_image_bytes(n->len_keep, E));
+  b->ws_b_bytes = (n->len_keep + 31) / 32 * E * F;
+  b->ws_b = cv.take_off(b->ws_b_bytes);
+  b->wg_ws_floats = mhimx_wgrad_ws_floats(n->len_keep, E, D);
+  b->wg_ws = cv.take_off(b->wg_ws_floats * F);
+  b->total = cv.off;
+}
+
+}  // namespace
+
+}  // namespace mhimx
+
+using namespace mhimx;
+
+extern "C" int mhimx_step_counts_of(int64_t N, double mask_ratio_h, double mask_ratio_hr, double merge_ratio, mhimx_step_counts* out) {
+  MHIMX_CHECK_ARG(out && N >= 1 && mask_ratio_h > 0.0 && mask_ratio_hr > 0.0 && merge_ratio > 0.0, "step_counts: bad arguments");
+  // masking.py:30-35: mask_ratio = mask_ratio / random_ratio; if mask_ratio > 1: random_ratio, mask_ratio = mask_ratio_h, 1  (float64, as numpy)
+  double eff = mask_ratio_h / mask_ratio_hr, rr = mask_ratio_hr;
+  if (eff > 1.0) { rr = mask_ratio_h; eff = 1.0; }
+  const int64_t k = (int64_t)ceil((double)N * eff);
+  const int64_t n_sel = rr < 1.0 ? (int64_t)ceil((double)k * rr) : k;
+  const int64_t len_keep = N - n_sel;
+  const int64_t Lk = (int64_t)((double)len_keep * merge_ratio);            // merge.py:163 int(L * merge_ratio)
+  *out = mhimx_step_counts{k, n_sel, len_keep, Lk, len_keep - Lk};
+  MHIMX_CHECK_ARG(k >= 1 && n_sel >= 1 && len_keep >= 1 && Lk >= 1 && len_keep - Lk >= 1, "step_counts: the recipe leaves nothing to mask, keep or merge");
+  return 0;
+}
+
+extern "C" int mhimx_step_layout_of(const mhimx_step_cfg* cfg, int64_t N, const mhimx_step_counts* cnt, mhimx_step_layout* out) {
+  MHIMX_CHECK_ARG(out, "step_layout: null output");
+  if (int r = check_cfg(cfg, N, cnt)) return r;
+  StepBufs b;
+  layout(cfg, N, cnt, &b);
+  *out = mhimx_step_layout{b.total, b.logits, b.losses, cfg->attn2score ? b.pscore : b.attn, b.rows_all, b.H_t, b.Hbuf, b.dact, b.z_t, b.z_s, b.g_z, b.dH};
+  return 0;
+}
+
+extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const float* X, int64_t ldx, int64_t N, const int64_t* label_dev,
+                              const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws, int64_t ws_bytes, int32_t update) {
+  if (int r = check_cfg(cfg, N, cnt)) return r;
+  MHIMX_CHECK_ARG(X && label_dev && seeds && ws && ldx >= cfg->D && ldx % 4 == 0 && N * ldx * 4 < ((int64_t)1 << 32) && aligned16(X),
+                  "step: null bag / label / seeds / workspace, or a row pitch the weight-gradient product does not take");
+  MHIMX_CHECK_ARG(!update || (cfg->p && cfg->g && cfg->m && cfg->v && cfg->n_train > 0 && cfg->n_all >= cfg->n_train), "step: update needs the flat optimiser buffers");
+  StepBufs b;
+  layout(cfg, N, cnt, &b);
+  MHIMX_CHECK_ARG(ws_bytes >= b.total && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "step: workspace too small (%lld < %lld) or not 256-byte aligned",
+                  (long long)ws_bytes, (long long)b.total);
+  const mhimx_step_cfg& c = *cfg;
+  const mhimx_step_params &S = c.student, &T = c.teacher;
+  const int64_t D = c.D, E = c.E, A = c.A, C = c.C, k = c.k, I = 512;
+  const int64_t R = cnt->R, Lk = cnt->Lk, len_keep = cnt->len_keep;
+  Carve cv(ws);
+  float* w1p_t = cv.at<float>(b.w1p_t);
+  float* wa_frag_t = cv.at<float>(b.wa_frag_t);
+  float* w1p_s = cv.at<float>(b.w1p_s);
+  float* wa_frag_s = cv.at<float>(b.wa_frag_s);
+  float* wa_t = cv.at<float>(b.wa_t);
+  float* wa_t_frag = cv.at<float>(b.wa_t_frag);
+  float* wo_t = cv.at<float>(b.wo_t);
+  float* q_old = cv.at<float>(b.q_old);
+  void* merge_ws = cv.at<char>(b.merge_ws);
+  float* H_t = cv.at<float>(b.H_t);
+  float* Hbuf = cv.at<float>(b.Hbuf);
+  void* dact = cv.at<char>(b.dact);
+  int64_t* rows_all = cv.at<int64_t>(b.rows_all);
+  float* dH = cv.at<float>(b.dH);
+  const uint64_t* tick = c.tick;
+
+  // ---- 1. the step's first launch: counters, both projection weight images, the teacher's scorer image, the row list's constant tail.
+  //         Everything else the step prepares (late[]) rides in the teacher's scorer launch, off the head of the chain.
+  mhimx_merge mw_prep = {};            // the parameter-only part of the student's Merge (read while enqueueing: prep job kind 6)
+  mw_prep.E = E; mw_prep.k = k; mw_prep.heads = 8; mw_prep.dim_head = 64;
+  mw_prep.q_param = S.q; mw_prep.ln_w = S.ln_w; mw_prep.ln_b = S.ln_b; mw_prep.wkv = S.wkv; mw_prep.wq = S.wq; mw_prep.wo = S.wo; mw_prep.bo = S.bo;
+  mw_prep.mm = c.merge_mm; mw_prep.prec = MHIMX_PREC_BF16X3; mw_prep.drop_tick = tick; mw_prep.rep = 1.f;
+  {
+    mhimx_prep_job early[8];
+    int n = 0;
+    early[n++] = mhimx_prep_job{3, nullptr, reinterpret_cast<float*>(c.tick), 1, 1};
+    if (c.opt_step) early[n++] = mhimx_prep_job{3, nullptr, reinterpret_cast<float*>(c.opt_step), 1, 1};
+    early[n++] = mhimx_prep_job{1, T.w1, w1p_t, E, D};
+    early[n++] = mhimx_prep_job{4, T.wa, wa_frag_t, A, E};
+    early[n++] = mhimx_prep_job{1, S.w1, w1p_s, E, D};
+    early[n++] = mhimx_prep_job{10, nullptr, reinterpret_cast<float*>(rows_all + len_keep), N, k};
+    if (int r = mhimx_prep_batch(stream, early, n)) return r;
+  }
+  mhimx_prep_job late[6];
+  late[0] = mhimx_prep_job{4, S.wa, wa_frag_s, A, E};
+  late[1] = mhimx_prep_job{0, S.wa, wa_t, A, E};
+  late[2] = mhimx_prep_job{5, S.wa, wa_t_frag, A, E};
+  late[3] = mhimx_prep_job{0, S.wo, wo_t, E, I};
+  late[4] = mhimx_prep_job{2, S.q, q_old, 1, k * E};
+  late[5] = mhimx_prep_job{6, reinterpret_cast<const float*>(&mw_prep), static_cast<float*>(merge_ws), R, b.merge_ws_bytes};
+
+  // ---- 2. both models' feature rows in one pass over the raw bag (mhim.py:186 and :335-336)
+  {
+    mhimx_bag_project_args a = {};
+    a.X = X; a.ldx = ldx; a.N = N; a.D = D; a.E = E; a.act = c.act; a.n_heads = 2; a.drop_tick = tick;
+    a.head[0].wp = w1p_t; a.head[0].bias = T.b1; a.head[0].H = H_t; a.head[0].ldh = E; a.head[0].drop_p = c.drop_p_teacher; a.head[0].drop_seed = seeds->drop_teacher;
+    a.head[1].wp = w1p_s; a.head[1].bias = S.b1; a.head[1].H = Hbuf; a.head[1].ldh = E; a.head[1].dact = dact; a.head[1].drop_p = c.drop_p_student;
+    a.head[1].drop_seed = seeds->drop_student;
+    if (int r = mhimx_bag_project(stream, &a)) return r;
+  }
+
+  // ---- 3, 4. the teacher: scorer + softmax pool (+ class projections and the pseudo score, scoring.py:37-58)
+  mhimx_scorer sc_t = {};
+  sc_t.E = E; sc_t.A = A; sc_t.act = c.da_act; sc_t.prec = MHIMX_PREC_BF16X3; sc_t.wa = T.wa; sc_t.wc = T.wc; sc_t.wa_frag = wa_frag_t;
+  const float* score = nullptr;
+  {
+    mhimx_pool_io io = {};
+    io.T1 = H_t; io.M1 = N; io.s = cv.at<float>(b.s_t); io.stats = cv.at<float>(b.stats_t); io.z = cv.at<float>(b.z_t);
+    io.ws = cv.at<char>(b.pool_ws_t); io.ws_bytes = b.pool_ws_t_bytes;
+    if (c.attn2score) { io.wp = T.wp; io.C = C; io.cproj = cv.at<float>(b.cproj_t); io.bp = T.bp; io.pscore = cv.at<float>(b.pscore); }
+    io.ride_jobs = late; io.n_ride_jobs = 6;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_t, &io)) return r;
+    if (c.attn2score) score = io.pscore;
+    else {
+      if (int r = mhimx_softmax_from_stats(stream, io.s, io.stats, cv.at<float>(b.attn), N)) return r;
+      score = cv.at<float>(b.attn);
+    }
+  }
+  const float* z_t = cv.at<float>(b.z_t);
+
+  // ---- 5. HAM mask + Merge split: rows_all = [rows to merge (R) | rows that stay (Lk) | N .. N + k - 1]
+  if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds->select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+    return r;
+
+  // ---- 6..9. Merge (merge.py:127-203): the k tokens land behind the bag's rows, the queries' EMA in place
+  mhimx_merge mw = mw_prep;
+  mw.drop_p = c.merge_drop_p; mw.drop_seed = seeds->mca; mw.x_rows = rows_all; mw.prepared = 1;
+  if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+
+  // ---- 10, 11. the student: scorer + pool over [rows that stay | tokens]
+  mhimx_scorer sc_s = sc_t;
+  sc_s.wa = S.wa; sc_s.wc = S.wc; sc_s.wa_frag = wa_frag_s;
+  mhimx_pool_io io_s = {};
+  io_s.T1 = Hbuf; io_s.M1 = Lk + k; io_s.s = cv.at<float>(b.s_s); io_s.stats = cv.at<float>(b.stats_s); io_s.z = cv.at<float>(b.z_s);
+  io_s.ws = cv.at<char>(b.pool_ws_s); io_s.ws_bytes = b.pool_ws_s_bytes; io_s.rows1 = rows_all + R;
+  if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+
+  // ---- 12. head: predictor, CE, distillation against the teacher's bag feature, and their gradients
+  float* g_z = cv.at<float>(b.g_z);
+  if (int r = mhimx_head_fwd_bwd(stream, io_s.z, c.aux_alpha != 0.f ? z_t : nullptr, S.wp, S.bp, label_dev, E, C, c.temp_t, c.main_alpha, c.aux_alpha, 1.f,
+                                 cv.at<float>(b.logits), cv.at<float>(b.losses), g_z, c.grad.wp, c.grad.bp, 0, nullptr, nullptr))
+    return r;
+
+  // ---- 13..16. backward
+  mhimx_reduce_list lst;
+  memset(&lst, 0, sizeof(lst));
+  mhimx_merge mwb = mw;
+  mwb.q_param = q_old; mwb.wo_t = wo_t; mwb.prepared = 0;
+  mhimx_merge_grad mg = {};
+  mg.d_ln_w = c.grad.ln_w; mg.d_ln_b = c.grad.ln_b; mg.d_wkv = c.grad.wkv; mg.d_wq = c.grad.wq; mg.d_wo = c.grad.wo; mg.d_bo = c.grad.bo;
+  mg.accumulate = 0; mg.splits = 8; mg.defer = &lst;
+  if (int r = mhimx_merge_bwd_park(&mwb, Hbuf, R, dH + N * E, dH, &mg, merge_ws, b.merge_ws_bytes)) return r;
+  {
+    mhimx_scorer sc_b = sc_s;
+    sc_b.wa_frag = nullptr;
+    mhimx_pool_grad pg = {};
+    pg.g_z = g_z; pg.dT1 = dH; pg.d_wa = c.grad.wa; pg.d_wc = c.grad.wc; pg.wa_t = wa_t; pg.accumulate = 0; pg.splits = 8; pg.defer = &lst; pg.wa_t_frag = wa_t_frag;
+    if (int r = mhimx_abmil_pool_bwd(stream, &sc_b, &io_s, &pg)) return r;
+  }
+  if (int r = mhimx_merge_bwd(stream, &mwb, Hbuf, R, dH + N * E, dH, &mg, merge_ws, b.merge_ws_bytes)) return r;
+  if (int r = mhimx_rows_dpre_image(stream, dH, dact, rows_all, len_keep, E, cv.at<char>(b.img), c.grad.b1, 0, cv.at<char>(b.ws_b), b.ws_b_bytes, &lst)) return r;
+  {
+    mhimx_bag_wgrad_args g = {};
+    g.img = cv.at<char>(b.img); g.X = X; g.ldx = ldx; g.n_bag_rows = N; g.rows = rows_all; g.L = len_keep; g.E = E; g.D = D; g.C = c.grad.w1; g.ldc = D;
+    g.accumulate = 0; g.ws = cv.at<float>(b.wg_ws); g.ws_floats = b.wg_ws_floats; g.defer = &lst; g.ride_tail = update ? 1 : 0;
+    if (int r = mhimx_bag_wgrad(stream, &g)) return r;
+  }
+  if (!update) return mhimx_reduce_flush(stream, &lst);
+
+  // ---- 17. Adam + EMA teacher; the weight gradient's split-K slab sum is folded into the update
+  mhimx_optim_args o = {};
+  o.p = c.p; o.g = c.g; o.m = c.m; o.v = c.v; o.teacher = c.p_teacher; o.n_train = c.n_train; o.n_all = c.n_all; o.step = host_step; o.step_dev = c.opt_step;
+  o.lr = c.lr; o.lr_table = c.lr_table; o.lr_len = c.lr_len; o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.weight_decay = c.weight_decay;
+  o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = &lst;
+  return mhimx_optim_step(stream, &o);
+}
+
+extern "C" int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, const int64_t* ldx, const int64_t* N,
+                                   const int64_t* const* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step0,
+                                   void* ws, int64_t ws_bytes) {
+  MHIMX_CHECK_ARG(n_bags >= 1 && X && ldx && N && labels_dev && cnt && seeds, "step_run_many: null arguments");
+  for (int32_t i = 0; i < n_bags; ++i)
+    if (int r = mhimx_step_run(stream, cfg, X[i], ldx[i], N[i], labels_dev[i], cnt + i, seeds + i, host_step0 + i, ws, ws_bytes, 1)) return r;
+  return 0;
+}

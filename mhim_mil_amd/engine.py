@@ -328,6 +328,11 @@ class FusedTrainer:
         self._graph_pool = None
         self._cap_stream = None
         self._side = None
+        # the whole step as ONE C call (mhimx_step_run, csrc/step.hip): the same launches as _forward_backward_nat + _apply, enqueued by the
+        # library itself - a bag costs one ctypes call instead of ~1700 interpreter calls (the eager step was host-bound).  MHIMX_STEP_EXEC=0:
+        # the Python orchestration (kept: it is the executor's specification and takes every case the executor refuses)
+        self.use_executor = os.environ.get("MHIMX_STEP_EXEC", "1") != "0"
+        self._exec = None
         self.single_pass = True            # ABMIL: one projection launch for teacher + student, bag-ordered buffers (when shapes allow)
         self.window_streams = 4            # accumulation windows (window_step): HIP streams the window's bags are issued on
         self._rows_cache = {}
@@ -345,6 +350,8 @@ class FusedTrainer:
         # ROCm 7.2 — measured, profiles/ r01 notes — against ~40 us of kernels it would hide)
         # together with the two device counters (dropout stream position, Adam step) it is ONE launch
         if self._nat_ok(x, i):
+            if self._exec_ok(x, i, perm, ids_shuffle):
+                return self._exec_step(x, label, i)
             return self._forward_backward_nat(x, label, perm, ids_shuffle, i)
         prep_s = prep_t = None
         jobs = [(ops.PREP_TICK, None, self.tick)]
@@ -460,6 +467,147 @@ class FusedTrainer:
         s, t = self.s, self.t
         return bool(self.single_pass and s.baseline == "attn" and s.bag_ordered_ok(x) and (self.model_kind != "mhim" or (
             t is not None and t.bag_ordered_ok(x) and not t.merge_test and s.merge_enable and s.v2_counts(x.shape[0], i) is not None)))
+
+    # ------------------------------------------------------------------------------------------------- the step behind the C-ABI
+    def _exec_ok(self, x, i=None, perm=None, ids_shuffle=None):
+        """True when mhimx_step_run takes this bag's step: the single-pass ABMIL step with device-drawn subsets, one process, one bag per
+        update, no injected draws (csrc/step.hip: check_cfg)."""
+        s, t = self.s, self.t
+        if not (self.use_executor and self.model_kind == "mhim" and self.accum == 1 and self.world == 1 and self._chain is None and perm is None
+                and ids_shuffle is None and self.ride_prep and s.training and s.n_classes <= 4 and s._op_prec != "f32"
+                and s.merge.k * 8 <= 48 and x.shape[1] % 256 == 0 and x.stride(0) % 4 == 0 and x.shape[0] * x.stride(0) * 4 < (1 << 32)):
+            return False
+        if not s.device_draw_ok(x.shape[0], i):
+            return False
+        c = s.v2_counts(x.shape[0], i)
+        return c is not None and c[3] >= 1 and 1 <= c[4] <= 32768
+
+    def _exec_cfg(self):
+        """The mhimx_step_cfg of this trainer: parameter / gradient pointers into the flat buffers (stable for the trainer's lifetime), the
+        model's hyper-parameters; the optimiser's scalars are refreshed on every call."""
+        s, t, fl = self.s, self.t, self.flat
+        L = mh.L
+        ex = self._exec
+        key = (s.feature[0].weight.data_ptr(), t.feature[0].weight.data_ptr(), fl.grad.data_ptr())
+        if ex is None or ex["key"] != key:
+            P = lambda tns: tns.data_ptr()
+            def params(m, with_merge):
+                att = m.online_encoder.attention
+                pr = L.StepParams(w1=P(m.feature[0].weight), b1=P(m.feature[0].bias), wa=P(att.attention[0].weight), wc=P(att.attention[2].weight),
+                                  wp=P(m.predictor.weight), bp=P(m.predictor.bias))
+                if with_merge:
+                    mg = m.merge
+                    pr.q, pr.ln_w, pr.ln_b = P(mg.global_q_mm), P(mg.norm.weight), P(mg.norm.bias)
+                    pr.wkv, pr.wq, pr.wo, pr.bo = P(mg.attn.to_kv.weight), P(mg.attn.to_q.weight), P(mg.attn.to_out[0].weight), P(mg.attn.to_out[0].bias)
+                return pr
+            gv = fl.grad_views
+            pre = "online_encoder.attention.attention."
+            grads = L.StepGrads(w1=P(gv["feature.0.weight"]), b1=P(gv["feature.0.bias"]), wa=P(gv[pre + "0.weight"]), wc=P(gv[pre + "2.weight"]),
+                                wp=P(gv["predictor.weight"]), bp=P(gv["predictor.bias"]), ln_w=P(gv["merge.norm.weight"]), ln_b=P(gv["merge.norm.bias"]),
+                                wkv=P(gv["merge.attn.to_kv.weight"]), wq=P(gv["merge.attn.to_q.weight"]), wo=P(gv["merge.attn.to_out.0.weight"]),
+                                bo=P(gv["merge.attn.to_out.0.bias"]))
+            cfg = L.StepCfg(D=s.input_dim, E=s.mlp_dim, A=s.online_encoder.attention.attention[0].weight.shape[0], C=s.n_classes, k=s.merge.k,
+                            act=L.act_code(s.act, mh._FEATURE_ACTS), da_act=L.act_code(s.da_act, mh._SCORER_ACTS),
+                            student=params(s, True), teacher=params(t, False), grad=grads,
+                            p=P(fl.student), g=P(fl.grad), m=P(fl.m), v=P(fl.v), n_train=fl.n_train, n_all=fl.n_all,
+                            tick=P(self.tick), opt_step=P(self.opt_step))
+            ex = self._exec = {"key": key, "cfg": cfg, "layouts": {}, "ws": None}
+        cfg = ex["cfg"]
+        cfg.attn2score = int(bool(t.attn2score))
+        cfg.drop_p_teacher = float(t.dropout_p if t.training else 0.0)
+        cfg.drop_p_student = float(s.dropout_p)
+        cfg.merge_drop_p, cfg.merge_mm = float(s.merge.dropout), float(s.merge.g_q_mm)
+        cfg.temp_t, cfg.main_alpha, cfg.aux_alpha = float(s.temp_t), float(self.main_alpha), float(self.aux_alpha)
+        cfg.p_teacher = None if fl.same_teacher else fl.teacher.data_ptr()
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay, cfg.ema_mm = self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.mm
+        cfg.mm_table, cfg.mm_len = (None, 0) if self.mm_table is None else (self.mm_table.data_ptr(), self.mm_table.numel())
+        cfg.lr_table, cfg.lr_len = (None, 0) if self.lr_table is None else (self.lr_table.data_ptr(), self.lr_table.numel())
+        return ex
+
+    def _exec_plan(self, ex, N, i):
+        """(counts, layout) of a bag of N rows at iteration i - cached: they follow from N and the HAM ratio alone."""
+        import ctypes as C
+        L = mh.L
+        k, n_sel, len_keep, Lk, R = self.s.v2_counts(N, i)
+        key = (N, k, n_sel, Lk)
+        ent = ex["layouts"].get(key)
+        if ent is None:
+            cnt = L.StepCounts(k_top=k, n_sel=n_sel, len_keep=len_keep, Lk=Lk, R=R)
+            lay = L.StepLayout()
+            L.check(L.lib().mhimx_step_layout_of(C.byref(ex["cfg"]), N, C.byref(cnt), C.byref(lay)), "mhimx_step_layout_of")
+            ent = ex["layouts"][key] = (cnt, lay)
+        return ent
+
+    def _exec_step(self, x, label, i):
+        """forward_backward (+ the update, inside train_step) of one bag as ONE call of mhimx_step_run."""
+        import ctypes as C
+        L = mh.L
+        s, t, fl = self.s, self.t, self.flat
+        if not (torch.is_tensor(label) and label.is_cuda and label.dtype == torch.int64 and label.is_contiguous() and label.device == x.device):
+            raise L.MhimxError(f"label: expected a contiguous int64 tensor on the bag's device ({x.device})")
+        ex = self._exec_cfg()
+        N = x.shape[0]
+        cnt, lay = self._exec_plan(ex, N, i)
+        # a captured step owns its workspace (the graph's memory pool); eager steps share one that only grows
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(lay.total, dtype=torch.uint8, device=x.device)
+        else:
+            ws = ex["ws"]
+            if ws is None or ws.numel() < lay.total or ws.device != x.device:
+                ws = ex["ws"] = torch.empty(int(lay.total * 1.25), dtype=torch.uint8, device=x.device)
+        seeds = L.StepSeeds(drop_teacher=t._next_seed(teacher=True), drop_student=s._next_seed(), select=s._next_seed(), mca=s._next_seed())
+        update = bool(self._fold_now)
+        if update:
+            fl.step += 1
+        L.check(L.lib().mhimx_step_run(ops._stream(), C.byref(ex["cfg"]), x.data_ptr(), x.stride(0), N, label.data_ptr(), C.byref(cnt), C.byref(seeds),
+                                       fl.step, ws.data_ptr(), ws.numel(), int(update)), "mhimx_step_run")
+        km, E = s.merge.k, s.mlp_dim
+
+        def view(off, n, dtype=torch.float32):
+            return ws[off:off + n * dtype.itemsize].view(dtype)
+
+        Hs = view(lay.H_student, (N + km) * E).view(N + km, E)
+        logits, losses = view(lay.logits, s.n_classes), view(lay.losses, 3)
+        rows_all = view(lay.rows_all, cnt.len_keep + km, torch.int64)
+        self.last = {"logits": logits, "losses": losses, "patch_num": N, "keep_num": cnt.Lk + km, "rows": rows_all[:cnt.len_keep],
+                     "score": view(lay.score, N), "R": cnt.R, "tokens": Hs[N:], "H_student": Hs[:N],
+                     "H_teacher": view(lay.H_teacher, N * E).view(N, E), "ws": ws}
+        if update:
+            ops.step_images(None)
+            self._micro = 0
+        else:
+            self._micro += 1
+        return logits, losses
+
+    def run_steps(self, bags, labels, i=None):
+        """len(bags) consecutive complete train steps (one update each) as ONE call of mhimx_step_run_many (SURVEY 7 H4 "run_steps"): the
+        bags of a resident dataset, bag after bag, on one workspace.  Returns the last bag's (logits, losses)."""
+        import ctypes as C
+        L = mh.L
+        xs = [self.s._check_x(b) for b in bags]
+        assert self._micro == 0 and all(self._exec_ok(x, i) and self._nat_ok(x, i) for x in xs), "run_steps: bags the step executor takes, a fresh update"
+        ex = self._exec_cfg()
+        plans = [self._exec_plan(ex, x.shape[0], i) for x in xs]
+        total = max(p[1].total for p in plans)
+        ws = ex["ws"]
+        if ws is None or ws.numel() < total:
+            ws = ex["ws"] = torch.empty(int(total * 1.25), dtype=torch.uint8, device=xs[0].device)
+        n = len(xs)
+        Xp = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        ld = (C.c_int64 * n)(*[x.stride(0) for x in xs])
+        Ns = (C.c_int64 * n)(*[x.shape[0] for x in xs])
+        lab = (C.c_void_p * n)(*[l.data_ptr() for l in labels])
+        cnts = (L.StepCounts * n)(*[p[0] for p in plans])
+        seeds = (L.StepSeeds * n)()
+        for j in range(n):
+            seeds[j] = L.StepSeeds(drop_teacher=self.t._next_seed(teacher=True), drop_student=self.s._next_seed(), select=self.s._next_seed(),
+                                   mca=self.s._next_seed())
+        L.check(L.lib().mhimx_step_run_many(ops._stream(), C.byref(ex["cfg"]), n, Xp, ld, Ns, lab, cnts, seeds, self.flat.step + 1, ws.data_ptr(),
+                                            ws.numel()), "mhimx_step_run_many")
+        self.flat.step += n
+        ops.step_images(None)
+        lay = plans[-1][1]
+        return ws[lay.logits:lay.logits + 4 * self.s.n_classes].view(torch.float32), ws[lay.losses:lay.losses + 12].view(torch.float32)
 
     def _forward_backward_nat(self, x, label, perm, ids_shuffle, i):
         """The single-pass ABMIL step: ONE projection launch computes the teacher's and the student's feature rows from the raw bag

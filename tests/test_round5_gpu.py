@@ -93,3 +93,97 @@ def test_pinned_step_rejects_a_cpu_label():
         tr.train_step(x, torch.tensor([1]))
     with pytest.raises(L.MhimxError):
         tr.train_step(x, torch.tensor([1], device="cuda", dtype=torch.int32))
+
+
+# ------------------------------------------------------------------------------------------------- the step behind the C-ABI (mhimx_step_run)
+def _pair_of_trainers(D=512, dropout=0.25, **kw):
+    from mhim_mil_amd.engine import FusedTrainer
+    out = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        s, t = _models(D=D, dropout=dropout, seed=11)
+        out.append(FusedTrainer(s, t, lr=1e-3, mm=0.999, aux_alpha=0.5, **kw))
+    return out
+
+
+def _state(tr):
+    fl = tr.flat
+    return [fl.student.clone(), fl.teacher.clone(), fl.m.clone(), fl.v.clone(), tr.opt_step.clone(), tr.tick.clone()]
+
+
+def test_step_executor_equals_the_python_step_bit_for_bit():
+    """mhimx_step_run issues the launches of FusedTrainer._forward_backward_nat + _apply itself: the same kernels, arguments and seeds, so
+    parameters, optimiser state, logits, row sets and teacher scores agree BIT FOR BIT with the Python orchestration - over bags whose size
+    changes every step (nothing is captured), dropout on."""
+    tr_c, tr_p = _pair_of_trainers()
+    tr_p.use_executor = False
+    g = torch.Generator(device="cuda").manual_seed(9)
+    sizes = [2048, 1777, 3001, 1024, 2500]
+    for step, n in enumerate(sizes):
+        x = torch.randn(n, 512, device="cuda", generator=g).abs_()
+        lab = torch.tensor([step % 2], device="cuda")
+        lc, sc = tr_c.train_step(x, lab)
+        lp, sp = tr_p.train_step(x, lab)
+        assert tr_c._exec is not None and tr_c.last.get("ws") is not None, "the executor did not run"
+        assert torch.equal(lc, lp) and torch.equal(sc, sp), (step, lc, lp)
+        assert torch.equal(tr_c.last["rows"], tr_p.last["rows"]) and torch.equal(tr_c.last["score"], tr_p.last["score"])
+        assert torch.equal(tr_c.last["tokens"], tr_p.last["tokens"])
+        for a, b in zip(_state(tr_c), _state(tr_p)):
+            assert torch.equal(a, b), step
+    assert tr_c.flat.step == tr_p.flat.step == len(sizes)
+
+
+def test_step_executor_forward_backward_only_and_clip():
+    """update = 0 (forward_backward: the complete gradient, no optimiser) and the --clip_grad path (the update stays outside the call)."""
+    from mhim_mil_amd.engine import FusedTrainer
+    tr_c, tr_p = _pair_of_trainers(clip_grad=0.5)
+    tr_p.use_executor = False
+    x = torch.rand(1500, 512, device="cuda")
+    lab = torch.tensor([1], device="cuda")
+    for tr in (tr_c, tr_p):
+        tr.forward_backward(x, lab)
+    assert torch.equal(tr_c.flat.grad, tr_p.flat.grad) and tr_c.flat.grad.abs().max() > 0
+    for tr in (tr_c, tr_p):
+        tr.update()
+        tr.train_step(x, lab)
+    for a, b in zip(_state(tr_c), _state(tr_p)):
+        assert torch.equal(a, b)
+
+
+def test_run_steps_equals_train_steps():
+    """mhimx_step_run_many: a chunk of bags as ONE C call == train_step bag after bag."""
+    tr_m, tr_1 = _pair_of_trainers()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    bags = [torch.randn(n, 512, device="cuda", generator=g).abs_() for n in (1200, 1536, 999, 2048)]
+    labels = [torch.tensor([j % 2], device="cuda") for j in range(len(bags))]
+    lm, _ = tr_m.run_steps(bags, labels)
+    for b, l in zip(bags, labels):
+        l1, _ = tr_1.train_step(b, l)
+    assert torch.equal(lm, l1)
+    for a, b in zip(_state(tr_m), _state(tr_1)):
+        assert torch.equal(a, b)
+
+
+def test_step_executor_under_capture_and_shape_cache():
+    """The executor is enqueue-only: a captured step (shape_cached: eager, captured on the second visit, replayed afterwards) through it
+    equals the same sequence through the Python orchestration bit for bit (both captures freeze the same host-side seeds)."""
+    tr_c, tr_p = _pair_of_trainers()
+    tr_p.use_executor = False
+    x = torch.rand(1800, 512, device="cuda")
+    lab = torch.tensor([0], device="cuda")
+    for _ in range(4):
+        for tr in (tr_c, tr_p):
+            assert tr.shape_cached("train_step", x, lab) is not None
+    torch.cuda.synchronize()
+    for a, b in zip(_state(tr_c), _state(tr_p)):
+        assert torch.equal(a, b)
+
+
+def test_step_counts_match_the_reference_formulas():
+    import ctypes as C
+    from mhim_mil_amd import _lib as L
+    s, _ = _models(D=256)
+    for n in (64, 257, 1000, 9999, 10000, 16384):
+        c = L.StepCounts()
+        L.check(L.lib().mhimx_step_counts_of(n, s.mask_ratio_h, s.mask_ratio_hr, s.merge.merge_ratio, C.byref(c)))
+        assert (c.k_top, c.n_sel, c.len_keep, c.Lk, c.R) == s.v2_counts(n), n
