@@ -473,6 +473,8 @@ class FusedTrainer:
         """True when mhimx_step_run takes this bag's step: the single-pass ABMIL step with device-drawn subsets, one process, one bag per
         update, no injected draws (csrc/step.hip: check_cfg)."""
         s, t = self.s, self.t
+        if ops.KERNEL_EVENT_HOOK is not None:          # (a caller brackets single launches with events: only the Python orchestration can)
+            return False
         if not (self.use_executor and self.model_kind == "mhim" and self.accum == 1 and self.world == 1 and self._chain is None and perm is None
                 and ids_shuffle is None and self.ride_prep and s.training and s.n_classes <= 4 and s._op_prec != "f32"
                 and s.merge.k * 8 <= 48 and x.shape[1] % 256 == 0 and x.stride(0) % 4 == 0 and x.shape[0] * x.stride(0) * 4 < (1 << 32)):
