@@ -315,9 +315,26 @@ typedef struct {
                                          images, the backward's transposes, the Merge preparation's chain).  Their outputs are complete when
                                          this call's launches are.  Other scorer shapes: a launch of their own inside this call. */
   int32_t n_ride_jobs;
+  /* (round 5) The forward in two calls around the launches that PRODUCE the last `tail_tokens` tokens of segment 1 - the student's pool over
+   * [rows that stay | merged tokens] (mhim.py:351-366) where the tokens come out of Merge, which itself only needs the rows to merge:
+   *   phase 1  the one-pass scorer launch over the first M1 - tail_tokens tokens (their partials stay in ws); with ride_merge, the row tiles of
+   *            that Merge forward run as the launch's FIRST workgroups (ride_X / ride_R / ride_ws: mhimx_merge_fwd's X, R, ws) - the scorer's
+   *            tiles and the Merge rows pass are independent, and the latter heads the longer chain;
+   *   (caller)  mhimx_merge_fwd with .rows_done = 1: partial merge, O, to_out -> the tokens;
+   *   phase 2  the finalize launch, which first scores the tail tokens itself (u_pre, s written like the scorer's) and merges them with the
+   *            partials: stats, z.
+   * phase 0 (default): the whole forward in one call, as always.  One-pass scorer shapes, M2 == 0, no pscore / cproj, tail_tokens <= 6. */
+  int32_t phase; int32_t tail_tokens;
+  const void* ride_merge;             /* const mhimx_merge* (prepared = 1, projection-free form, R <= 4096) or NULL */
+  const float* ride_X; int64_t ride_R; void* ride_ws; int64_t ride_ws_bytes;
+  int32_t rode_merge;                 /* OUT (phase 1): 1 if the Merge rows pass rode (then call mhimx_merge_fwd with rows_done = 1), else 0 */
+  const float* tail_wa_t;             /* phase 2, optional: transpose of sc->wa [E, A] (prep kind 0; what the backward takes as wa_t): the tail
+                                         tokens' scorer product then reads the weight coalesced, without cross-lane reductions */
+  int64_t tail_row0;                  /* phase 2: >= 0: the tail tokens are the rows tail_row0 .. tail_row0 + tail_tokens - 1 of T1 (what rows1's
+                                         last entries hold - the caller's word, saves the finalize launch a dependent load); < 0: read rows1 */
 } mhimx_pool_io;
 int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
-int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io);
+int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, mhimx_pool_io* io);      /* (io->rode_merge is written in phase 1) */
 
 /* Backward of the pool given g_z[E] (= dLoss/dz).  Produces dT1,dT2 (overwritten), and the scorer
  * weight gradients (overwritten unless accumulate).  wa_t = transpose(wa) [E,A] (and wb_t). */
@@ -526,6 +543,8 @@ typedef struct {
                                          them).  own_n == 0: one process holds every row.  Projection-free form only (E = 512, 8 x 64, k <= 6). */
   float rep;                          /* with own_n > 0: weight of the gradient terms every shard computes identically (d_bo, d_wo, the V half of
                                          d_wkv) - 1 on one shard, 0 on the others, so that the sum over the shards counts them once */
+  int32_t rows_done;                  /* 1: the rows pass of this forward already ran as riding workgroups of the caller's previous launch on this
+                                         workspace (mhimx_pool_io.ride_merge): mhimx_merge_fwd starts at the merge of the tile partials */
 } mhimx_merge;
 int64_t mhimx_merge_ws_bytes(int64_t R, int64_t E, int64_t k, int64_t heads, int64_t dim_head);
 /* X[R,E] rows to merge -> z[k,E]; q_new[k,E] = mm*q + (1-mm)*z if update_q; ws keeps what backward needs. */

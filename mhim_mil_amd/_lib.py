@@ -113,7 +113,9 @@ class PoolIO(C.Structure):
                 ("s", c_f32p), ("stats", c_f32p), ("z", c_f32p), ("u_pre", c_f32p),
                 ("wp", c_f32p), ("C", C.c_int64), ("cproj", c_f32p),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p), ("rows1", c_i64p),
-                ("excl", C.c_void_p), ("ride_jobs", C.c_void_p), ("n_ride_jobs", C.c_int32)]
+                ("excl", C.c_void_p), ("ride_jobs", C.c_void_p), ("n_ride_jobs", C.c_int32),
+                ("phase", C.c_int32), ("tail_tokens", C.c_int32), ("ride_merge", C.c_void_p), ("ride_X", c_f32p), ("ride_R", C.c_int64),
+                ("ride_ws", C.c_void_p), ("ride_ws_bytes", C.c_int64), ("rode_merge", C.c_int32), ("tail_wa_t", c_f32p), ("tail_row0", C.c_int64)]
 
 
 class PoolGrad(C.Structure):
@@ -130,7 +132,7 @@ class Merge(C.Structure):
                 ("wkv_t", c_f32p), ("wq_t", c_f32p), ("wo_t", c_f32p),
                 ("mm", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("prec", C.c_int32), ("drop_tick", C.c_void_p),
                 ("wkv_frag", c_f32p), ("x_rows", c_i64p), ("prepared", C.c_int32), ("own_lo", C.c_int64), ("own_n", C.c_int64),
-                ("rep", C.c_float)]
+                ("rep", C.c_float), ("rows_done", C.c_int32)]
 
 
 class MergeGrad(C.Structure):

@@ -50,86 +50,12 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(Merge2PrepArgs 
 // ----------------------------------------------------------------------------------------------------------------------
 // 2. rows forward: LayerNorm, scores against the J slots, per-tile softmax partials, pooled rows.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t m2_fwd_smem(int rt) { return (size_t)(rt * M2_XLD + 4 * rt * M2_JP + M2_JP * (rt + 4) + 2 * M2_E + rt + 4) * sizeof(float); }
-
 template <int RT>
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
                                                                     float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick, Merge2Ws w) {
   extern __shared__ __attribute__((aligned(16))) float m2sm[];
-  constexpr int PLD = RT + 4, RQ = RT / 4;            // RQ: rows per thread of the four that share a slot
-  float* xh = m2sm;                                  // [RT][516]
-  float* red = xh + RT * M2_XLD;                     // [4][RT][48]
-  float* pdT = red + 4 * RT * M2_JP;                 // [48][RT + 4]
-  float* lnw = pdT + M2_JP * PLD;                    // [512]
-  float* lnb = lnw + M2_E;                           // [512]
-  float* ok = lnb + M2_E;                            // [RT] 1 = the row takes part
-  int* flags = reinterpret_cast<int*>(ok + RT);      // [4]
-  const int tid = threadIdx.x;
-  const int t = blockIdx.x;
-  const int64_t row0 = (int64_t)t * RT;
-  if (t == 0 && tid == 0) w.gate[1] = 0u;           // (the backward's first stage may ride behind this gate: scorer_fused_bwd_kernel)
-  if (w.own_n > 0 && m2_tile_dead<RT>(xrows, R, row0, w, flags)) {
-    // an instance-sharded bag: no row of this tile is this shard's - an empty partial (weight 0 in every merge; its pooled rows are never read)
-    if (tid < M2_JP) { w.pm[t * M2_JP + tid] = -INFINITY; w.pl[t * M2_JP + tid] = 0.f; w.psd[t * M2_JP + tid] = 0.f; }
-    return;
-  }
-  M2Frags fr;
-  m2_fetch_frags(w.aqf, fr);
-  m2_load_rows<false, RT>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr, w, ok);
-  __syncthreads();
-  m2_rows_times_slots<RT>(xh, lnw, lnb, fr, red);
-  __syncthreads();
-  for (int idx = tid; idx < RT * M2_JP; idx += M2_THREADS) {
-    const float s = (red[idx] + red[RT * M2_JP + idx]) + (red[2 * RT * M2_JP + idx] + red[3 * RT * M2_JP + idx]);
-    red[idx] = s;
-    const int r = idx / M2_JP;
-    if (row0 + r < R) w.S[(row0 + r) * M2_JP + (idx - r * M2_JP)] = s;
-  }
-  __syncthreads();
-  // per-slot softmax partials of the tile: 4 threads per slot (RT / 4 rows each), combined through LDS
-  float* sc = red + RT * M2_JP;                      // [3][4][48] scratch (the partial-product slabs 1..3 are free)
-  const int j = tid % M2_JP, rq = tid / M2_JP;        // rq < 4 for the first 192 threads
-  float sreg[RQ], m = -INFINITY;
-  bool rv[RQ];
-  if (rq < 4) {
-#pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int r = rq * RQ + q;
-      sreg[q] = red[r * M2_JP + j];
-      rv[q] = ok[r] != 0.f;
-      if (j < J && rv[q]) m = fmaxf(m, sreg[q]);
-    }
-    sc[rq * M2_JP + j] = m;
-  }
-  __syncthreads();
-  if (rq < 4) {
-    m = fmaxf(fmaxf(sc[j], sc[M2_JP + j]), fmaxf(sc[2 * M2_JP + j], sc[3 * M2_JP + j]));
-    const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
-    const float ks = 1.f / (1.f - drop_p);
-    float l = 0.f, sd = 0.f;
-#pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int r = rq * RQ + q;
-      float p = 0.f, pd = 0.f;
-      if (j < J && rv[q]) {
-        p = __expf(sreg[q] - m);
-        pd = (drop_p > 0.f && !m2_keep(seed, j, row0 + r, drop_p)) ? 0.f : p * ks;
-      }
-      l += p;
-      sd += pd;
-      pdT[j * PLD + r] = pd;
-    }
-    sc[(4 + rq) * M2_JP + j] = l;
-    sc[(8 + rq) * M2_JP + j] = sd;
-  }
-  __syncthreads();
-  if (tid < M2_JP) {
-    w.pm[t * M2_JP + tid] = fmaxf(fmaxf(sc[tid], sc[M2_JP + tid]), fmaxf(sc[2 * M2_JP + tid], sc[3 * M2_JP + tid]));
-    w.pl[t * M2_JP + tid] = (sc[4 * M2_JP + tid] + sc[5 * M2_JP + tid]) + (sc[6 * M2_JP + tid] + sc[7 * M2_JP + tid]);
-    w.psd[t * M2_JP + tid] = (sc[8 * M2_JP + tid] + sc[9 * M2_JP + tid]) + (sc[10 * M2_JP + tid] + sc[11 * M2_JP + tid]);
-  }
-  m2_pool_rows<RT>(pdT, xh, w.ypart + (int64_t)t * M2_JP * M2_E);
+  merge2_rows_fwd_body<RT>((int)blockIdx.x, m2sm, X, xrows, R, ln_w, ln_b, J, drop_p, seed0, tick, w);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -238,6 +164,22 @@ int merge2_side_finish(hipStream_t st, mhimx_side_work* side, int upto_stage) {
 
 // the forward up to the row tiles' partials: parameters (unless prepared), rows pass.  An instance-sharded bag (m->own_n > 0): only the rows
 // this shard owns take part.
+// The rows pass as a rider of another launch (round 5: the student's one-pass scorer launch, scorer_fused.hip - the row tiles of the Merge and
+// the scorer's tiles over the rows that stay are independent until the tokens exist): the kernel arguments of the pass for this Merge and
+// workspace.  Returns 0 and fills *out when the pass can ride (projection-free form, prepared parameters, one process, 16-row tiles: 53 KB of
+// LDS under the scorer's 75 KB), 1 when it cannot (the caller runs mhimx_merge_fwd as always), < 0 on error.
+int merge2_fwd_rows_args(const mhimx_merge* m, const float* X, int64_t R, void* ws, int64_t ws_bytes, M2RowsFwd* out) {
+  if (!m || !X || !merge2_ok(m, R) || !m->prepared || m->own_n != 0) return 1;
+  Arena ar(ws, ws_bytes);
+  Merge2Ws w;
+  merge2_ws_layout(ar, R, m->k, &w);
+  MHIMX_CHECK_ARG(ar.ok(), "merge rows rider: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)ar.off);
+  if (w.rt != 16) return 1;
+  w.own_lo = 0; w.own_n = 0;
+  *out = M2RowsFwd{X, m->x_rows, R, m->ln_w, m->ln_b, M2_H * (int)m->k, m->drop_p, m->drop_seed, m->drop_tick, w};
+  return 0;
+}
+
 static int merge2_fwd_rows(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, void* ws, int64_t ws_bytes, Merge2Ws* wout) {
   Arena ar(ws, ws_bytes);
   Merge2Ws w;
@@ -248,6 +190,10 @@ static int merge2_fwd_rows(hipStream_t st, const mhimx_merge* m, const float* X,
   w.own_n = m->own_n;
   const int k = (int)m->k, J = M2_H * k;
   const float scale = 1.0f / sqrtf((float)M2_DH);
+  if (m->rows_done) {                  // (the rows pass rode in the caller's previous launch: merge2_fwd_rows_args)
+    *wout = w;
+    return 0;
+  }
   if (!m->prepared) {
     hipLaunchKernelGGL(merge2_prep_kernel, dim3(64), dim3(M2_THREADS), 0, st, Merge2PrepArgs{m->q_param, m->ln_w, m->ln_b, m->wq, m->wkv, k, scale, w});
     MHIMX_LAUNCH_CHECK();

@@ -174,6 +174,93 @@ MHIMX_DEV void m2_pool_rows(const float* coefT /* LDS [48][RT + 4] */, const flo
 MHIMX_DEV bool m2_keep(uint64_t seed, int j, int64_t r, float p) { return drop_keep(seed, (uint64_t)j, (uint32_t)r, p); }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// 2. rows forward: LayerNorm, scores against the J slots, per-tile softmax partials, pooled rows.   grid = ceil(R / RT)
+// ----------------------------------------------------------------------------------------------------------------------
+struct M2RowsFwd { const float* X; const int64_t* xrows; int64_t R; const float *ln_w, *ln_b; int J; float drop_p; uint64_t seed0; const uint64_t* tick; Merge2Ws w; };
+constexpr size_t m2_fwd_smem(int rt) { return (size_t)(rt * M2_XLD + 4 * rt * M2_JP + M2_JP * (rt + 4) + 2 * M2_E + rt + 4) * sizeof(float); }
+
+// (a device function: the body of merge2_rows_fwd_kernel (mca2.hip) and of the row tiles that ride at the front of the student's one-pass
+// scorer launch, scorer_fused.hip)   t: the row tile; m2sm: m2_fwd_smem(RT) bytes of LDS, 16-byte aligned
+template <int RT>
+MHIMX_DEV void merge2_rows_fwd_body(const int t, float* m2sm, const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
+                                    const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J, float drop_p, uint64_t seed0,
+                                    const uint64_t* __restrict__ tick, const Merge2Ws& w) {
+  constexpr int PLD = RT + 4, RQ = RT / 4;            // RQ: rows per thread of the four that share a slot
+  float* xh = m2sm;                                  // [RT][516]
+  float* red = xh + RT * M2_XLD;                     // [4][RT][48]
+  float* pdT = red + 4 * RT * M2_JP;                 // [48][RT + 4]
+  float* lnw = pdT + M2_JP * PLD;                    // [512]
+  float* lnb = lnw + M2_E;                           // [512]
+  float* ok = lnb + M2_E;                            // [RT] 1 = the row takes part
+  int* flags = reinterpret_cast<int*>(ok + RT);      // [4]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)t * RT;
+  if (t == 0 && tid == 0) w.gate[1] = 0u;           // (the backward's first stage may ride behind this gate: scorer_fused_bwd_kernel)
+  if (w.own_n > 0 && m2_tile_dead<RT>(xrows, R, row0, w, flags)) {
+    // an instance-sharded bag: no row of this tile is this shard's - an empty partial (weight 0 in every merge; its pooled rows are never read)
+    if (tid < M2_JP) { w.pm[t * M2_JP + tid] = -INFINITY; w.pl[t * M2_JP + tid] = 0.f; w.psd[t * M2_JP + tid] = 0.f; }
+    return;
+  }
+  M2Frags fr;
+  m2_fetch_frags(w.aqf, fr);
+  m2_load_rows<false, RT>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, nullptr, w, ok);
+  __syncthreads();
+  m2_rows_times_slots<RT>(xh, lnw, lnb, fr, red);
+  __syncthreads();
+  for (int idx = tid; idx < RT * M2_JP; idx += M2_THREADS) {
+    const float s = (red[idx] + red[RT * M2_JP + idx]) + (red[2 * RT * M2_JP + idx] + red[3 * RT * M2_JP + idx]);
+    red[idx] = s;
+    const int r = idx / M2_JP;
+    if (row0 + r < R) w.S[(row0 + r) * M2_JP + (idx - r * M2_JP)] = s;
+  }
+  __syncthreads();
+  // per-slot softmax partials of the tile: 4 threads per slot (RT / 4 rows each), combined through LDS
+  float* sc = red + RT * M2_JP;                      // [3][4][48] scratch (the partial-product slabs 1..3 are free)
+  const int j = tid % M2_JP, rq = tid / M2_JP;        // rq < 4 for the first 192 threads
+  float sreg[RQ], m = -INFINITY;
+  bool rv[RQ];
+  if (rq < 4) {
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int r = rq * RQ + q;
+      sreg[q] = red[r * M2_JP + j];
+      rv[q] = ok[r] != 0.f;
+      if (j < J && rv[q]) m = fmaxf(m, sreg[q]);
+    }
+    sc[rq * M2_JP + j] = m;
+  }
+  __syncthreads();
+  if (rq < 4) {
+    m = fmaxf(fmaxf(sc[j], sc[M2_JP + j]), fmaxf(sc[2 * M2_JP + j], sc[3 * M2_JP + j]));
+    const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
+    const float ks = 1.f / (1.f - drop_p);
+    float l = 0.f, sd = 0.f;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int r = rq * RQ + q;
+      float p = 0.f, pd = 0.f;
+      if (j < J && rv[q]) {
+        p = __expf(sreg[q] - m);
+        pd = (drop_p > 0.f && !m2_keep(seed, j, row0 + r, drop_p)) ? 0.f : p * ks;
+      }
+      l += p;
+      sd += pd;
+      pdT[j * PLD + r] = pd;
+    }
+    sc[(4 + rq) * M2_JP + j] = l;
+    sc[(8 + rq) * M2_JP + j] = sd;
+  }
+  __syncthreads();
+  if (tid < M2_JP) {
+    w.pm[t * M2_JP + tid] = fmaxf(fmaxf(sc[tid], sc[M2_JP + tid]), fmaxf(sc[2 * M2_JP + tid], sc[3 * M2_JP + tid]));
+    w.pl[t * M2_JP + tid] = (sc[4 * M2_JP + tid] + sc[5 * M2_JP + tid]) + (sc[6 * M2_JP + tid] + sc[7 * M2_JP + tid]);
+    w.psd[t * M2_JP + tid] = (sc[8 * M2_JP + tid] + sc[9 * M2_JP + tid]) + (sc[10 * M2_JP + tid] + sc[11 * M2_JP + tid]);
+  }
+  m2_pool_rows<RT>(pdT, xh, w.ypart + (int64_t)t * M2_JP * M2_E);
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------------
 // 5. rows backward: dPd = xn dY^T, softmax backward, dxn = ds aq + Pd dY, LayerNorm backward (dX scattered to the rows' places,
 //    per-tile d_ln_w / d_ln_b partials), pooled U partials.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------

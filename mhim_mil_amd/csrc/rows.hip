@@ -5,7 +5,7 @@
 #include <math.h>
 #include <string.h>
 
-#include "mca2_side.hpp"
+#include "mca2_rows.hpp"
 #include "reduce_jobs.hpp"
 
 namespace mhimx {
@@ -15,7 +15,9 @@ int gemm_tn(hipStream_t st, const mhimx_gemm_tn_args& g);
 bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, const float* wa, const float* wp, int64_t C);
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl, const mhimx_prep_job* ride_jobs, int n_ride_jobs);
+                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl, const mhimx_prep_job* ride_jobs, int n_ride_jobs,
+                     const void* merge_rows);
+int merge2_fwd_rows_args(const mhimx_merge* m, const float* X, int64_t R, void* ws, int64_t ws_bytes, M2RowsFwd* out);      // mca2.hip
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);      // gemm_dma.hip
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
@@ -186,6 +188,158 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
     z[e] = a / L;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = mx; stats[1] = L; }
+}
+
+// The finalize of a forward whose last K tokens were NOT scored by the scorer launch (mhimx_pool_io.phase 2: the student's merged tokens,
+// produced by launches issued after it): every block first scores the K <= 6 tokens itself - u = Wa t (+ ba), s = wc . act(u) (+ bc), the
+// scorer's arithmetic in fp32 FMAs, 0.33 MFLOP - and merges them with the G partials as K more one-row partials (fixed order).  Block 0 also
+// writes the tokens' u_pre and s where the scorer would have (the backward reads them there).   grid = E / 64, 1024 threads.
+constexpr int FIN_MAXTOK = 6;
+__global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                         const float* __restrict__ pz, int G, int E, float* __restrict__ stats,
+                                                                         float* __restrict__ z, const float* __restrict__ T,
+                                                                         const int64_t* __restrict__ rows_tail, int64_t row0, int K,
+                                                                         const float* __restrict__ wa, const float* __restrict__ wa_t,
+                                                                         const float* __restrict__ ba, const float* __restrict__ wc,
+                                                                         const float* __restrict__ bc, int A, int act,
+                                                                         float* __restrict__ u_pre_tail, float* __restrict__ s_tail) {
+  __shared__ float red[16];
+  __shared__ float wgt[2 * MAX_PART];
+  __shared__ float acc16[16][64];
+  __shared__ __attribute__((aligned(16))) float tks[FIN_MAXTOK][512];
+  __shared__ float up[8][FIN_MAXTOK][128];                    // the 8 e-chunks' partial products
+  __shared__ float us[FIN_MAXTOK][128];
+  __shared__ float stok[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the partial statistics and this wave's first 8 pooled rows: requested now, in flight under the token scoring
+  const float pm1 = tid < G ? pm[tid] : -INFINITY, pl1 = tid < G ? pl[tid] : 0.f;
+  const int e = blockIdx.x * 64 + lane;
+  float pzv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int b = wave + 16 * q;
+    pzv[q] = (e < E && b < G) ? pz[(int64_t)b * E + e] : 0.f;
+  }
+  // ---- token rows -> LDS (rows K.. zero)
+  for (int idx = tid; idx < FIN_MAXTOK * (E / 4); idx += FIN_THREADS) {
+    const int i = idx / (E / 4), c4 = idx - i * (E / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < K) {
+      const int64_t r = rows_tail ? rows_tail[i] : row0 + i;
+      v = reinterpret_cast<const float4*>(T + r * E)[c4];
+    }
+    reinterpret_cast<float4*>(&tks[i][0])[c4] = v;
+  }
+  if (wa_t && A == 128 && E == 512) {
+    // thread = (scorer column a, chunk of 64 feature dims): the transposed weight is read coalesced (128 threads x 4 B per dim), 16 loads in
+    // flight, the tokens broadcast from LDS; no cross-lane reduction - the 8 chunk partials meet in LDS
+    const int a = tid & 127, ch = tid >> 7;
+    const float* wp = wa_t + (int64_t)(ch * 64) * A + a;
+    float acc[FIN_MAXTOK];
+#pragma unroll
+    for (int i = 0; i < FIN_MAXTOK; ++i) acc[i] = 0.f;
+    float wv[64];                                             // ALL of this thread's weights in flight at once: one memory round trip
+#pragma unroll
+    for (int u = 0; u < 64; ++u) wv[u] = wp[(int64_t)u * A];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (a fence for the scheduler: the 64 loads are issued above it, as one batch)
+    __syncthreads();                                          // the token rows are in LDS
+#pragma unroll
+    for (int u4 = 0; u4 < 64; u4 += 4) {
+#pragma unroll
+      for (int i = 0; i < FIN_MAXTOK; ++i) {
+        const float4 tv = *reinterpret_cast<const float4*>(&tks[i][ch * 64 + u4]);      // (broadcast read: every lane the same address)
+        acc[i] += tv.x * wv[u4] + tv.y * wv[u4 + 1] + tv.z * wv[u4 + 2] + tv.w * wv[u4 + 3];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FIN_MAXTOK; ++i) up[ch][i][a] = acc[i];
+    __syncthreads();
+    if (tid < K * 128) {
+      const int i = tid >> 7, aa = tid & 127;
+      float v = ((up[0][i][aa] + up[1][i][aa]) + (up[2][i][aa] + up[3][i][aa])) + ((up[4][i][aa] + up[5][i][aa]) + (up[6][i][aa] + up[7][i][aa]));
+      us[i][aa] = v + (ba ? ba[aa] : 0.f);
+    }
+  } else {
+    // (no transposed weight at hand: wave = 8 scorer rows, lanes along the feature dims, a wave reduction per product)
+    float4 w0[8], w1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int a = wave * 8 + q;
+      const float* wr = wa + (int64_t)(a < A ? a : 0) * E + lane * 8;
+      w0[q] = *reinterpret_cast<const float4*>(wr);
+      w1[q] = *reinterpret_cast<const float4*>(wr + 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int a = wave * 8 + q;
+      for (int i = 0; i < K; ++i) {
+        const float4 t0 = *reinterpret_cast<const float4*>(&tks[i][lane * 8]), t1 = *reinterpret_cast<const float4*>(&tks[i][lane * 8 + 4]);
+        float d = t0.x * w0[q].x + t0.y * w0[q].y + t0.z * w0[q].z + t0.w * w0[q].w + t1.x * w1[q].x + t1.y * w1[q].y + t1.z * w1[q].z + t1.w * w1[q].w;
+        d = wave_sum(d);
+        if (lane == 0 && a < A) us[i][a] = d + (ba ? ba[a] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int idx = tid; idx < K * A; idx += FIN_THREADS) u_pre_tail[idx] = us[idx / A][idx % A];
+  if (wave < K) {                                             // wave i: s_i = wc . act(u_i) + bc   (A = 128: two per lane)
+    float v = 0.f;
+    for (int a = lane; a < A; a += 64) v += wc[a] * act_fwd(us[wave][a], act);
+    v = wave_sum(v) + (bc ? bc[0] : 0.f);
+    if (lane == 0) {
+      stok[wave] = v;
+      if (blockIdx.x == 0) s_tail[wave] = v;
+    }
+  }
+  // ---- statistics over the G partials and the K tokens
+  float m = wave_max(pm1);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  float mx = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  for (int i = 0; i < K; ++i) mx = fmaxf(mx, stok[i]);
+  __syncthreads();
+  float lp = 0.f;
+  if (tid < G) {
+    const float w = (pm1 == -INFINITY) ? 0.f : __expf(pm1 - mx);
+    wgt[tid] = w;
+    lp = pl1 * w;
+  }
+  lp = wave_sum(lp);
+  if (lane == 0) red[wave] = lp;
+  __syncthreads();
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) L += red[w];
+  float wt[FIN_MAXTOK];
+#pragma unroll
+  for (int i = 0; i < FIN_MAXTOK; ++i) {
+    wt[i] = i < K ? __expf(stok[i] - mx) : 0.f;
+    L += wt[i];
+  }
+  float acc = 0.f;
+  if (e < E) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (wave + 16 * q < G) acc += pzv[q] * wgt[wave + 16 * q];
+#pragma unroll 8
+    for (int b = wave + 128; b < G; b += 16) acc += pz[(int64_t)b * E + e] * wgt[b];
+  }
+  acc16[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && e < E) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a += acc16[w][lane];
+#pragma unroll
+    for (int i = 0; i < FIN_MAXTOK; ++i)
+      if (i < K) a += wt[i] * tks[i][e];
+    z[e] = a / L;
+  }
+  if (blockIdx.x == 0 && tid == 0) { stats[0] = mx; stats[1] = L; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,7 +925,7 @@ static int check_scorer(const mhimx_scorer* sc) {
   return 0;
 }
 
-int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* io) {
+int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, mhimx_pool_io* io) {
   if (int r = check_scorer(sc)) return r;
   MHIMX_CHECK_ARG(io && io->T1 && io->M1 > 0 && io->s && io->stats && io->z, "pool_fwd: null io");
   MHIMX_CHECK_ARG(io->M2 == 0 || io->T2, "pool_fwd: M2>0 needs T2");
@@ -788,6 +942,35 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   MHIMX_CHECK_ARG(ar.ok(), "pool_fwd: workspace too small (%lld < %lld)", (long long)io->ws_bytes, (long long)ar.off);
   float* u_pre = io->u_pre ? io->u_pre : w.u_pre;
   const int64_t ldu = A * (1 + gated);
+  if (io->phase != 0) {
+    // the forward in two calls around the launches that produce the last tail_tokens tokens (include/mhimx.h)
+    const int64_t K = io->tail_tokens, Ms1 = io->M1 - K;
+    MHIMX_CHECK_ARG((io->phase == 1 || io->phase == 2) && K >= 1 && K <= FIN_MAXTOK && Ms1 >= 1 && io->M2 == 0 && !io->cproj && !io->pscore && !io->excl &&
+                        E == 512 && A == 128 && scorer_fused_ok(E, A, gated, sc->prec, io->T1, sc->wa, nullptr, 0),
+                    "pool_fwd: the two-call forward takes the one-pass scorer shapes, one segment, 1..%d tail tokens, no class projections", FIN_MAXTOK);
+    const int tiles = (int)cdiv(Ms1, 32);
+    const int G1 = tiles < MAX_PART ? tiles : MAX_PART;
+    if (io->phase == 1) {
+      M2RowsFwd mfbuf;
+      const void* mf = nullptr;
+      io->rode_merge = 0;
+      static const bool ride_ok = getenv("MHIMX_MERGE_FWD_RIDE") == nullptr || atoi(getenv("MHIMX_MERGE_FWD_RIDE")) != 0;
+      if (io->ride_merge && ride_ok) {
+        const int rc = merge2_fwd_rows_args(reinterpret_cast<const mhimx_merge*>(io->ride_merge), io->ride_X, io->ride_R, io->ride_ws, io->ride_ws_bytes,
+                                            &mfbuf);
+        if (rc < 0) return rc;
+        if (rc == 0) { mf = &mfbuf; io->rode_merge = 1; }
+      }
+      const int g1 = scorer_fused_fwd(st, io->T1, Ms1, sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, nullptr, 0, u_pre, io->s, nullptr, w.pm, w.pl,
+                                      w.pz, MAX_PART, io->rows1, nullptr, io->ride_jobs, io->n_ride_jobs, mf);
+      return g1 < 0 ? g1 : 0;
+    }
+    hipLaunchKernelGGL(pool_finalize_tok_kernel, dim3((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G1, (int)E, io->stats, io->z, io->T1,
+                       (io->rows1 && io->tail_row0 < 0) ? io->rows1 + Ms1 : nullptr, io->rows1 ? io->tail_row0 : Ms1, (int)K, sc->wa, io->tail_wa_t, sc->ba, sc->wc,
+                       sc->bc, (int)A, sc->act, u_pre + Ms1 * ldu, io->s + Ms1);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
 
   const float* Ts[2] = {io->T1, io->T2};
   const int64_t Ms[2] = {io->M1, io->M2};
@@ -801,7 +984,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
       const int g1 = scorer_fused_fwd(st, Ts[seg], Ms[seg], sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, io->cproj ? io->wp : nullptr,
                                       (int)io->C, u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
                                       w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART, seg == 0 ? io->rows1 : nullptr,
-                                      seg == 0 ? io->excl : nullptr, rode ? nullptr : io->ride_jobs, rode ? 0 : io->n_ride_jobs);
+                                      seg == 0 ? io->excl : nullptr, rode ? nullptr : io->ride_jobs, rode ? 0 : io->n_ride_jobs, nullptr);
       if (g1 < 0) return g1;
       rode = true;
       G += g1;
@@ -1116,7 +1299,7 @@ extern "C" int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, in
   Arena ar(nullptr, 0);
   return pool_ws_layout(ar, M, E, A, gated ? 1 : 0, nullptr);
 }
-extern "C" int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io) {
+extern "C" int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, mhimx_pool_io* io) {
   return abmil_pool_fwd((hipStream_t)stream, sc, io);
 }
 extern "C" int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* g) {

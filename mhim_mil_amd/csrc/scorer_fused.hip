@@ -14,7 +14,7 @@
 #include <math.h>
 
 #include "common.hpp"
-#include "mca2_side.hpp"
+#include "mca2_rows.hpp"
 #include "prep_jobs.hpp"
 
 namespace mhimx {
@@ -62,12 +62,21 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     float* __restrict__ s_out, float* __restrict__ cproj, float* __restrict__ pm, float* __restrict__ pl, float* __restrict__ pz,
     int tiles, const int64_t* __restrict__ rows /* optional gather: token n is T[rows[n]] */,
     const uint8_t* __restrict__ excl /* optional, by source row: the row does not take part (score -inf) */,
-    int n_main /* workgroups of the scorer itself; the blocks behind them are riders */, PrepJobs rider) {
+    int n_main /* workgroups of the scorer itself; the blocks behind them are riders */, PrepJobs rider,
+    int n_front /* round 5: the FIRST n_front blocks are the row tiles of a Merge forward (mca2_rows.hpp) - the student's scorer over the rows
+                   that stay and the Merge over the rows to merge are independent until the tokens exist, and the Merge heads the longer chain */,
+    M2RowsFwd mf) {
   extern __shared__ __attribute__((aligned(16))) float sf_sm[];
-  if ((int)blockIdx.x >= n_main) {
+  if ((int)blockIdx.x < n_front) {
+    if ((int)blockIdx.x < mf.w.T)
+      merge2_rows_fwd_body<16>((int)blockIdx.x, sf_sm, mf.X, mf.xrows, mf.R, mf.ln_w, mf.ln_b, mf.J, mf.drop_p, mf.seed0, mf.tick, mf.w);
+    return;
+  }
+  const int bid = (int)blockIdx.x - n_front;
+  if (bid >= n_main) {
     // parameter-only preparation jobs of the step riding in this launch's free workgroup slots (prep_jobs.hpp; the table is a by-value
     // kernel argument: only these blocks read it)
-    prep_job_block(rider, (int)blockIdx.x - n_main, sf_sm);
+    prep_job_block(rider, bid - n_main, sf_sm);
     return;
   }
   float* Hs = sf_sm;                          // [32][516]
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     for (int i = tid; i < C * SF_E / 4; i += SF_THREADS) reinterpret_cast<sf_f4*>(wps)[i] = reinterpret_cast<const sf_f4*>(wp)[i];
 
   float m_run = -INFINITY, l_run = 0.f, z0 = 0.f, z1 = 0.f;
-  for (int tile = blockIdx.x; tile < tiles; tile += n_main) {
+  for (int tile = bid; tile < tiles; tile += n_main) {
     const int64_t row0 = (int64_t)tile * SF_ROWS;
     SF_STAMP(0);
     sf_f32x16 acc, acc2, acc3;                  // one accumulator per bf16x3 term: an MFMA into the accumulator of the previous one waits out its latency
@@ -289,9 +298,9 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     __syncthreads();                           // the next tile overwrites Hs / srow
     SF_STAMP(5);
   }
-  if (tid == 0) { pm[blockIdx.x] = m_run; pl[blockIdx.x] = l_run; }
-  pz[(int64_t)blockIdx.x * SF_E + tid] = z0;
-  pz[(int64_t)blockIdx.x * SF_E + tid + SF_THREADS] = z1;
+  if (tid == 0) { pm[bid] = m_run; pl[bid] = l_run; }
+  pz[(int64_t)bid * SF_E + tid] = z0;
+  pz[(int64_t)bid * SF_E + tid + SF_THREADS] = z1;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -510,25 +519,33 @@ bool scorer_fused_ok(int64_t E, int64_t A, int gated, int prec, const float* T, 
 // one launch per token segment; returns the number of partials written to pm/pl/pz (<= max_parts), < 0 on error
 int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa, const float* wa_frag, const float* ba, int act, const float* wc,
                      const float* bc, const float* wp, int C, float* u_pre, float* s_out, float* cproj, float* pm, float* pl,
-                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl, const mhimx_prep_job* ride_jobs, int n_ride_jobs) {
+                     float* pz, int max_parts, const int64_t* rows, const uint8_t* excl, const mhimx_prep_job* ride_jobs, int n_ride_jobs,
+                     const void* merge_rows /* optional M2RowsFwd: its row tiles ride at the front of the launch */) {
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SF_SMEM)));
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   static_assert(SF_SMEM >= PREP_LDS_FLOATS * sizeof(float), "the riders' LDS is the scorer's");
-  static_assert(SF_THREADS == 256, "the preparation jobs are written for 256 threads");
+  static_assert(SF_SMEM >= m2_fwd_smem(16), "the Merge row tiles' LDS is the scorer's");
+  static_assert(SF_THREADS == 256 && SF_THREADS == M2_THREADS, "the preparation jobs and the Merge row tiles are written for 256 threads");
   PrepJobs rider = {};
   int ride_blocks = 0;
   if (ride_jobs && n_ride_jobs > 0) {
     ride_blocks = prep_jobs_fill(ride_jobs, n_ride_jobs, &rider);
     if (ride_blocks < 0) return ride_blocks;
   }
+  M2RowsFwd mf = {};
+  int n_front = 0;
+  if (merge_rows) {
+    mf = *reinterpret_cast<const M2RowsFwd*>(merge_rows);
+    n_front = mf.w.T;
+  }
   if (wa_frag)
-    hipLaunchKernelGGL(scorer_fused_kernel<true>, dim3(grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
-                       cproj, pm, pl, pz, tiles, rows, excl, grid, rider);
+    hipLaunchKernelGGL(scorer_fused_kernel<true>, dim3(n_front + grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre,
+                       s_out, cproj, pm, pl, pz, tiles, rows, excl, grid, rider, n_front, mf);
   else
-    hipLaunchKernelGGL(scorer_fused_kernel<false>, dim3(grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre, s_out,
-                       cproj, pm, pl, pz, tiles, rows, excl, grid, rider);
+    hipLaunchKernelGGL(scorer_fused_kernel<false>, dim3(n_front + grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre,
+                       s_out, cproj, pm, pl, pz, tiles, rows, excl, grid, rider, n_front, mf);
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

@@ -17,6 +17,7 @@
 //       15,16  rows_dpre_image | bag_wgrad   the projection's gradient pair (the Merge tail and the last reductions ride)
 //          17  mhimx_optim_step         Adam + EMA teacher (folds the split-K slab sum)
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -232,15 +233,30 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
   // ---- 6..9. Merge (merge.py:127-203): the k tokens land behind the bag's rows, the queries' EMA in place
   mhimx_merge mw = mw_prep;
   mw.drop_p = c.merge_drop_p; mw.drop_seed = seeds->mca; mw.x_rows = rows_all; mw.prepared = 1;
-  if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
-
-  // ---- 10, 11. the student: scorer + pool over [rows that stay | tokens]
+  // ---- 6..11. the student's forward.  Its scorer over the rows that stay and Merge's rows pass are independent: ONE launch runs both (the Merge
+  //      row tiles ride at its front), the Merge tail then makes the tokens, and the pool's finalize launch scores those k rows itself
+  //      (mhimx_pool_io.phase; MHIMX_SPLIT_POOL=0: Merge, then the scorer over [stay | tokens], as rounds 2-4 had it)
   mhimx_scorer sc_s = sc_t;
   sc_s.wa = S.wa; sc_s.wc = S.wc; sc_s.wa_frag = wa_frag_s;
   mhimx_pool_io io_s = {};
   io_s.T1 = Hbuf; io_s.M1 = Lk + k; io_s.s = cv.at<float>(b.s_s); io_s.stats = cv.at<float>(b.stats_s); io_s.z = cv.at<float>(b.z_s);
   io_s.ws = cv.at<char>(b.pool_ws_s); io_s.ws_bytes = b.pool_ws_s_bytes; io_s.rows1 = rows_all + R;
-  if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+  static const bool split_pool = getenv("MHIMX_SPLIT_POOL") == nullptr || atoi(getenv("MHIMX_SPLIT_POOL")) != 0;
+  io_s.tail_row0 = -1;
+  if (split_pool && k <= 6) {
+    io_s.phase = 1; io_s.tail_tokens = (int32_t)k;
+    io_s.ride_merge = &mw; io_s.ride_X = Hbuf; io_s.ride_R = R; io_s.ride_ws = merge_ws; io_s.ride_ws_bytes = b.merge_ws_bytes;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+    mw.rows_done = io_s.rode_merge;
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+    mw.rows_done = 0;
+    io_s.phase = 2; io_s.tail_wa_t = wa_t; io_s.tail_row0 = N;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+    io_s.phase = 0; io_s.ride_merge = nullptr;
+  } else {
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+  }
 
   // ---- 12. head: predictor, CE, distillation against the teacher's bag feature, and their gradients
   float* g_z = cv.at<float>(b.g_z);

@@ -36,6 +36,7 @@ from . import ops
 
 _FEATURE_ACTS = ("relu", "gelu")
 _SCORER_ACTS = ("relu", "gelu", "tanh")
+_SPLIT_POOL = os.environ.get("MHIMX_SPLIT_POOL", "1") != "0"      # the student's pool forward in two calls around the Merge tail (ops.abmil_pool_fwd_split)
 
 
 # ----------------------------------------------------------------------------------------------- holders
@@ -634,9 +635,19 @@ class MHIM(nn.Module):
             q_param = getattr(plan, "q_out", None)                          # (a window step sends the per-bag EMA result elsewhere)
             if q_param is None:
                 q_param = self.merge.global_q_mm.data.view(self.merge.k, -1)
-            _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None,
-                                      ws=prep.get("merge_ws"))
-            st = ops.abmil_pool_fwd(sc, Hbuf, None, rows1=rows_all[plan.R:])
+            k = self.merge.k
+            if _SPLIT_POOL and "merge_ws" in prep and k <= 6 and rows_all.numel() - plan.R > k:
+                # (round 5) the student's scorer over the rows that stay does not need the tokens, and Merge's rows pass does not need the
+                # scorer: ONE launch runs both (the Merge row tiles at its front); then the Merge tail makes the tokens, and the pool's
+                # finalize launch scores those k rows itself (mhimx_pool_io.phase) - the scorer launch is off the serial chain
+                st, rode = ops.abmil_pool_fwd_split(sc, Hbuf, rows_all[plan.R:], k, ride_merge=(mw, Hbuf, prep["merge_ws"]))
+                _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None,
+                                          ws=prep["merge_ws"], rows_done=rode)
+                ops.abmil_pool_fwd_finish(sc, st, wa_t=prep.get("wa_t"), tail_row0=N)
+            else:
+                _, _, mws = ops.merge_fwd(mw, Hbuf, z_out=Hbuf[N:], update_q=plan.training, q_out=q_param if plan.training else None,
+                                          ws=prep.get("merge_ws"))
+                st = ops.abmil_pool_fwd(sc, Hbuf, None, rows1=rows_all[plan.R:])
             saved.update(mws=mws, q_old=prep.get("q_old"))
         else:
             st = ops.abmil_pool_fwd(sc, Hbuf[:N], None)

@@ -379,6 +379,34 @@ class PoolState:
                         ride_jobs=None if self.ride is None else C.cast(self.ride[0], C.c_void_p), n_ride_jobs=0 if self.ride is None else self.ride[1])
 
 
+def abmil_pool_fwd_split(sc: ScorerW, T1, rows1, tail_tokens, ride_merge=None):
+    """The pool forward in two calls around the launches that produce the last ``tail_tokens`` tokens of the list (mhimx_pool_io.phase):
+    this is phase 1 - the one-pass scorer launch over the first len(rows1) - tail_tokens tokens, with, for ``ride_merge`` = (MergeW, X, ws),
+    the row tiles of that Merge forward riding at its front.  Returns (PoolState, rode): when ``rode``, call merge_fwd(rows_done=True);
+    then abmil_pool_fwd_finish(sc, state)."""
+    _chk(T1, name="T1"); _chk(rows1, torch.int64, "rows1")
+    st = PoolState(T1, None, 0, None, rows1=rows1)
+    st.tail_tokens = int(tail_tokens)
+    io = st.io(sc)
+    io.phase, io.tail_tokens = 1, st.tail_tokens
+    if ride_merge is not None:
+        mw, X, ws = ride_merge
+        io.ride_merge, io.ride_X = C.cast(C.pointer(mw.c), C.c_void_p), _p(X)
+        io.ride_R, io.ride_ws, io.ride_ws_bytes = mw.x_rows.shape[0], _p(ws), ws.numel()
+    L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd (phase 1)")
+    return st, bool(io.rode_merge)
+
+
+def abmil_pool_fwd_finish(sc: ScorerW, st: PoolState, wa_t=None, tail_row0=-1):
+    """Phase 2 of abmil_pool_fwd_split: the finalize launch scores the tail tokens and merges them with the partials -> st.stats, st.z.
+    ``wa_t``: the transposed scorer weight [E, A] if at hand; ``tail_row0`` >= 0: the tail tokens are the rows tail_row0.. of T1."""
+    io = st.io(sc)
+    io.phase, io.tail_tokens = 2, st.tail_tokens
+    io.tail_wa_t, io.tail_row0 = _p(wa_t), int(tail_row0)
+    L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd (phase 2)")
+    return st
+
+
 def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=None, ride_jobs=None):
     """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj; with ``bp`` also ``pscore`` [M1], the
     pseudo score of the T1 instances, written by the pool's finalize launch).  ``rows1`` (int64): the tokens are T1[rows1].
@@ -534,7 +562,7 @@ class MergeW:
         return torch.empty(n, device=device, dtype=torch.uint8)
 
 
-def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
+def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None, rows_done=False):
     """q_out: where the EMA-updated queries go (may be the query parameter itself: the update is element-wise and the
     forward has consumed LayerNorm(q) by then)."""
     _chk(X, name="X")
@@ -543,8 +571,10 @@ def merge_fwd(mw: MergeW, X, z_out=None, update_q=True, ws=None, q_out=None):
     z = z_out if z_out is not None else torch.empty((mw.k, mw.E), device=dev)
     q_new = (q_out if q_out is not None else torch.empty((mw.k, mw.E), device=dev)) if update_q else None
     ws = ws if ws is not None else mw.ws_for(R, dev)
+    mw.c.rows_done = int(bool(rows_done))            # (the rows pass rode in the caller's previous launch: abmil_pool_fwd_split)
     L.check(L.lib().mhimx_merge_fwd(_stream(), C.byref(mw.c), _p(X), R, _p(z), _p(q_new), int(bool(update_q)), _p(ws),
                                     ws.numel()), "mhimx_merge_fwd")
+    mw.c.rows_done = 0
     return z, q_new, ws
 
 
