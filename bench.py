@@ -248,6 +248,15 @@ def other_workload(a, world, rank, dev, embedded=False):
             extra["roofline"] = {"kernel": "whole step (projection + weight-gradient GEMMs 63 %, scorer passes, select, Merge)", "bound": "hbm",
                                  "achieved": hb["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb["frac_of_8TBps"], "traffic": None,
                                  "algorithmic_bytes_per_instance": algo}
+        # step-level HBM-side bytes from the committed rocprofv3 --pmc passes of this same command, eager (tools/pmc_step.py: FETCH_SIZE x2 +
+        # WRITE_SIZE summed over every launch of one step; counters cannot be read from inside the process being timed)
+        for pmc_name in (f"r05_pmc_traffic_{a.workload}.json",):
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc) and "roofline" in extra:
+                pj = json.load(open(pmc))
+                extra["roofline"]["traffic"] = pj["step_traffic_bytes"]
+                extra["roofline"]["traffic_unit"] = "bytes per step (all launches)"
+                extra["roofline"]["traffic_source"] = f"profiles/{pmc_name}: read {pj['step_read_bytes'] / 1e6:.0f} MB + write {pj['step_write_bytes'] / 1e6:.0f} MB per step"
         if world == 1 and a.cpu_steps > 0:
             extra["cpu_baseline"] = cpu_baseline_other(a.workload, base, n_total, d, bl)
         return {
@@ -607,6 +616,8 @@ def main():
                                    + (" + RCCL all-reduce of the 6.6 MB flat gradient" if world > 1 else "") + ")",
                        "bags_per_step": world, "rotating_bags_per_gpu": N_BAGS, "matrix_core_form": student._feature_prec(N_INST),
                        "dropout": CFG["dropout"], "parallelism": f"dp{world}",
+                       "step_issued_by": ("mhimx_step_run (csrc/step.hip: the step's launches enqueued by ONE C call; captured into the graphs)"
+                                          if trainer._exec is not None else "the Python orchestration of engine.py (one ctypes call per launch)"),
                        **({"collective": collective, "collective_candidates_ms_per_step": collective_ms} if collective else {}),
                        "launch": (("eager" if world == 1 else "eager, gradient all-reduce in two pieces, the first overlapped with the dW1 GEMM of the backward")
                                   + (f" (graph capture failed: {graph_note})" if graph_note else "")) if graphs is None
@@ -631,7 +642,7 @@ def main():
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc.sh + tools/pmc_project.py; counters cannot be read from inside the process being timed)
             traffic, tsrc = None, None
-            for pmc_name in ("r04_pmc_bag_project.json", "r03_pmc_bag_project.json", "r02_pmc_bag_project.json"):
+            for pmc_name in ("r05_pmc_bag_project.json", "r04_pmc_bag_project.json", "r03_pmc_bag_project.json", "r02_pmc_bag_project.json"):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
                 if os.path.exists(pmc):
                     pj = json.load(open(pmc))
@@ -639,6 +650,13 @@ def main():
                                                           f"KiB, separate --pmc passes; read {pj['fetch_bytes'] / 1e6:.1f} MB + write "
                                                           f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
                     break
+            step_traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r05_pmc_traffic_c2.json")
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                step_traffic = {"bytes_per_step": pj["step_traffic_bytes"], "read": pj["step_read_bytes"], "write": pj["step_write_bytes"],
+                                "over_algorithmic": pj["traffic_over_algorithmic"],
+                                "source": "profiles/r05_pmc_traffic_c2.md: FETCH_SIZE x2 + WRITE_SIZE over every launch of one step (two --pmc passes)"}
             # SURVEY 8(d) / BASELINE.md section 4: the HBM fraction on the ALGORITHMIC bytes is the headline figure of the dominant kernel - this
             # launch stands for two of the step's three passes over X (4096 B per instance each); the matrix-core figures sit beside it.
             # attainable: every product runs as 3 bf16 terms (section 3 of DESIGN.md: two terms miss the 1e-4 logit bound under peaked
@@ -657,7 +675,7 @@ def main():
                                                       "step_mfma_floor_ms": 3 * 39.3e9 / 2500e12 * 1e3,
                                                       "why": "3 bf16 MFMA terms per product (fp32-class instance scores feed a top-k; 2 terms miss the 1e-4 logit bound under peaked attention: profiles/r03_two_term.md): the dense-peak time of the issued flop is the floor"},
                                "flops_note": "issued = bf16 MFMA flop actually issued: 3 terms (hi*hi + hi*lo + lo*hi) x 2 N D 1024; useful = fp32-equivalent = a third",
-                               "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "avg_kernel_ms": avg,
+                               "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": tsrc, "step_traffic": step_traffic, "avg_kernel_ms": avg,
                                "launches_timed": len(ms), "hip_events_over": events_from,
                                "hbm": {"basis": "bytes the launch must move: X read once + both weight images + H_teacher, H_student (fp32) and d out/d pre (fp16) written",
                                        "bytes_per_launch": read_once + written, "achieved_GBps": (read_once + written) / (avg * 1e-3) / 1e9,

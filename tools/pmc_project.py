@@ -1,5 +1,5 @@
 """Post-process the two rocprofv3 --pmc passes of tools/pmc.sh (FETCH_SIZE, WRITE_SIZE) over `bench.py --no-graph`:
-per-launch HBM-side traffic of the dominant kernel (bag_project_kernel: the teacher's AND the student's feature projection in
+per-launch HBM-side traffic of the dominant kernel (bag_project_ws_kernel<0>: the teacher's AND the student's feature projection in
 one pass over the raw fp32 bag), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts
 128-B read requests as 64 B: x2; WRITE_SIZE calibrated here against the exactly known output size).  Writes <out>.md and .json.
 
@@ -31,7 +31,7 @@ def main():
     fetch, write = 2 * avg(f, 1) * kib, avg(w, 1) * kib                 # gfx950 correction: x2 on reads
     algo_read = N * D * 4 + 2 * E * D * 4                               # X once + the two weight matrices once
     algo_write = 2 * N * E * 4 + N * E * 2                              # H_teacher, H_student fp32 + d out/d pre of the student in fp16
-    res = {"kernel": "bag_project_kernel (teacher + student feature projection of one bag, M=10000 N=2x512 K=1024, raw fp32 X)",
+    res = {"kernel": "bag_project_ws_kernel<0> (teacher + student feature projection of one bag, M=10000 N=2x512 K=1024, raw fp32 X)",
            "launches": len(f), "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write,
            "fetch_size_raw_KiB": avg(f, 1), "write_size_raw_KiB": avg(w, 1),
            "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": algo_write,
@@ -46,7 +46,7 @@ def main():
         fo.write("# rocprofv3 --pmc: HBM-side traffic of the single-pass feature projection (bench.py c2, eager launches)\n\n")
         fo.write("Two separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each with `--kernel-trace` only) of\n"
                  "`python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-graph --no-kernel-events`; per-dispatch sums over all\n"
-                 "counter instances, averaged over the launches of `bag_project_kernel` (one per step).\n\n")
+                 "counter instances, averaged over the launches of `bag_project_ws_kernel<0>` (one per step).\n\n")
         fo.write("| launch | FETCH_SIZE raw KiB | fetch bytes (x2) | WRITE_SIZE raw KiB | write bytes | algorithmic read | algorithmic write |\n")
         fo.write("|---|---:|---:|---:|---:|---:|---:|\n")
         fo.write(f"| X[10000,1024] -> H_teacher, H_student, dact16 | {avg(f, 1):.1f} | {fetch / 1e6:.2f} MB | {avg(w, 1):.1f} | {write / 1e6:.2f} MB | "
