@@ -1133,8 +1133,14 @@ class FusedTrainer:
         the step cannot be cached (run it eagerly)."""
         x = bag[0] if bag.dim() == 3 else bag
         s, t = self.s, self.t
-        if not (self.accum == 1 and self.world == 1 and x.is_cuda and x.dim() == 2 and not self._capturing and self._micro == 0
-                and self._nat_ok(x, i)):
+        if not (self.accum == 1 and self.world == 1 and x.is_cuda and x.dim() == 2 and not self._capturing and self._micro == 0):
+            return None
+        nat = self._nat_ok(x, i)
+        # (round 5) the TransMIL / DSMIL students: their step runs autograd over kernel-backed nodes whose gradient-accumulation nodes belong to
+        # the stream they were first run on, so EVERY step of such a shape runs on the trainer's capture stream - eager on the first two
+        # visits (the second is the capture's warm-up), captured on the third.  v2 recipe only (a v1 ratio reads a count back).
+        auto = (not nat) and s.baseline in ("selfattn", "dsmil") and (self.model_kind != "mhim" or s.v2_counts(x.shape[0], i) is not None)
+        if not (nat or auto):
             return None
         # (a HAM-ratio schedule, --mrh_sche, changes the row counts - the launch shapes - every few hundred iterations: they are part of the key)
         counts = s.v2_counts(x.shape[0], i) if self.model_kind == "mhim" else None
@@ -1148,10 +1154,19 @@ class FusedTrainer:
             return None
         ent = st["graphs"].get(key)
         fn = self.train_step if what == "train_step" else self.forward_backward
+        if auto and self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
         if ent is None:
             st["seen"][key] = st["seen"].get(key, 0) + 1
-            if st["seen"][key] < 2:
-                logits, losses = fn(bag, label, i=i)
+            if st["seen"][key] < (3 if auto else 2):
+                if auto:
+                    cur = torch.cuda.current_stream()
+                    self._cap_stream.wait_stream(cur)
+                    with torch.cuda.stream(self._cap_stream):
+                        logits, losses = fn(bag, label, i=i)
+                    cur.wait_stream(self._cap_stream)
+                else:
+                    logits, losses = fn(bag, label, i=i)
                 return logits, losses, self.last["patch_num"], self.last["keep_num"]
             while len(st["graphs"]) >= max(1, int(cache)):        # the least recently used shape makes room
                 st["graphs"].pop(next(iter(st["graphs"])))
