@@ -155,9 +155,9 @@ int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, i
  * then a bf16 lo plane, [256][256] each (hi = bf16(x), lo = bf16(x - hi); 128 KiB + 128 KiB = the bytes of the fp32 matrix, heads
  * contiguous), of the matrix itself ("N") or of its transpose ("T").
  *   kind 0:  P = A B  with A = an N image of A, B = a T image of B (3-term bf16, fp32 accumulate);
- *            X1 = ident I + alpha P (+ D, an fp32 matrix, which may be C itself; it enters as the accumulator's start value D / alpha,
- *            exact for |alpha| a power of two; not together with a second output);   X2 = ident2 I + alpha2 P;
- *            any of: C = X1 (fp32), PN / PT = N / T image of X1, C2 = X2 (fp32), PN2 / PT2 = N / T image of X2.
+ *            X1 = ident I + alpha P (+ dscale D + d2scale D2: fp32 matrices - D may be C itself; they enter as the accumulator's start value
+ *            (dscale D + d2scale D2) / alpha, exact for |alpha| a power of two; a scale of 0 means 1; not together with a second output);
+ *            X2 = ident2 I + alpha2 P;   any of: C = X1 (fp32), PN / PT = N / T image of X1, PN2 / PT2 = N / T image of X2.
  *   kind 1:  no product: PN / PT = images of alpha * A (+ D), A and D fp32 matrices (how a chain takes its inputs in, or sums two).
  *   kind -1: nothing (an idle slot of a two-group stage).
  * The table is steps[stage * groups + group]: the steps of one stage are independent of each other and may read whatever earlier STAGES
@@ -166,12 +166,17 @@ int mhimx_bmm_affine2(void* stream, int32_t mode, const mhimx_gemm_nt_args* a, i
  * completes whatever part of its grid is resident (other work on the GPU costs time, never the result).
  * counters: 513 uint32, ZERO before the first launch (head h: arrivals at [64 h], tickets at [64 h + 32], leave count at [64 h + 48] -
  * each head's hot words on 128-byte lines of their own); all zero again when a launch ends; [512] != 0 afterwards means a workgroup
- * gave up waiting (a backstop: the ticket order excludes it) and the outputs are invalid.  stages * groups <= 42.  A step must not
+ * gave up waiting (a backstop: the ticket order excludes it) and the outputs are invalid.  stages * groups <= 38.  A step must not
  * overwrite its own operands.
+ * Round 5: the scaled addends dscale D + d2scale D2 let the pseudo-inverse iteration z' = 1/4 z (13 I - M (15 I - M (7 I - M))), M = a2 z
+ * (nystrom_attention.py:21-25), also run in its EXPANDED form - three dependent levels instead of Horner's four: M = a2 z;  P = z M  ||
+ * N' = -15 I + 7 M - M M;  z' = 1/4 P N' + 13/4 z (the backward: four two-product stages per iteration instead of five).  The host side
+ * (nystrom.py) keeps Horner's four levels as the default and the expanded form behind MHIMX_PINV_LEVELS=3: measured equal
+ * (profiles/r05_pinv_levels.md).
  *   replaces: the same torch.matmul chain as mhimx_bmm_affine, 7.4 us per product (13.7 us per pair) as launches. */
 typedef struct {
-  const void* A; const void* B; float* C; float* C2; void* PN; void* PT; void* PN2; void* PT2; const float* D;
-  float alpha, ident, alpha2, ident2;
+  const void* A; const void* B; float* C; void* PN; void* PT; void* PN2; void* PT2; const float* D; const float* D2;
+  float alpha, ident, alpha2, ident2, dscale, d2scale;
   int32_t kind;
 } mhimx_bmm_step;
 int mhimx_bmm_chain(void* stream, const mhimx_bmm_step* steps, int32_t stages, int32_t groups, uint32_t* counters);

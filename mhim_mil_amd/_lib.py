@@ -157,9 +157,9 @@ class Nys(C.Structure):
 
 class BmmStep(C.Structure):
     """mhimx_bmm_step (include/mhimx.h)."""
-    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p), ("PN", C.c_void_p), ("PT", C.c_void_p),
-                ("PN2", C.c_void_p), ("PT2", C.c_void_p), ("D", C.c_void_p), ("alpha", C.c_float), ("ident", C.c_float),
-                ("alpha2", C.c_float), ("ident2", C.c_float), ("kind", C.c_int32)]
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("PN", C.c_void_p), ("PT", C.c_void_p),
+                ("PN2", C.c_void_p), ("PT2", C.c_void_p), ("D", C.c_void_p), ("D2", C.c_void_p), ("alpha", C.c_float), ("ident", C.c_float),
+                ("alpha2", C.c_float), ("ident2", C.c_float), ("dscale", C.c_float), ("d2scale", C.c_float), ("kind", C.c_int32)]
 
 
 class OptimArgs(C.Structure):

@@ -235,12 +235,13 @@ __global__ __launch_bounds__(SB_THREADS) void small_bmm_pair_kernel(SmallBmm g0,
 // block reads written-through lines at), products 1900 (LDS-read bound: 256 KiB of fragments), quarters -> tiles 2300, stores + acknowledge
 // 2400, arrival 1300.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int CH_MAX = 42, CH_THREADS = 1024, CH_SPIN_MAX = 1 << 22;
-struct ChainStep {
-  const void* A; const void* B; float* C; float* C2; void* PN; void* PT; void* PN2; void* PT2; const float* D;
-  float alpha, ident, alpha2, ident2;
+constexpr int CH_MAX = 38, CH_THREADS = 1024, CH_SPIN_MAX = 1 << 22;
+struct ChainStep {             // (104 bytes: 38 of them + the header must fit the 4 KiB of kernel arguments)
+  const void* A; const void* B; float* C; void* PN; void* PT; void* PN2; void* PT2; const float* D; const float* D2;
+  float alpha, ident, alpha2, ident2, dscale, d2scale;
   int kind;
 };
+static_assert(sizeof(ChainStep) * CH_MAX + 32 <= 4096, "the chain table is a by-value kernel argument");
 struct Chain { ChainStep st[CH_MAX]; int n, groups; unsigned* ctr; };
 typedef unsigned sb_u4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) void* ch_gptr;
@@ -319,13 +320,21 @@ __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
       // every wave one 16 x 16 block over the WHOLE k: no partial sums, no reduce (twice the fragment reads: 512 KiB per tile)
       const int bm = wave >> 2, bn = wave & 3, c16 = lane & 15, q4 = lane >> 4;
       sb_f4 a4 = sb_f4{0.f, 0.f, 0.f, 0.f};
-      if (st.D) {
-        const float ia = 1.f / st.alpha;
+      if (st.D) {                                               // the accumulator starts at (dscale D + d2scale D2) / alpha
+        const float ia = st.dscale / st.alpha;
         __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(st.D + hoff), 0, MAT_BYTES, 0x00027000);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           a4[i] = ia * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                            rD, (unsigned)(((m0 + 16 * bm + 4 * q4 + i) * SBF_KMAX + n0 + 16 * bn + c16) * 4), 0, POL));
+        if (st.D2) {
+          const float ib = st.d2scale / st.alpha;
+          __amdgpu_buffer_rsrc_t rD2 = __builtin_amdgcn_make_buffer_rsrc((void*)(st.D2 + hoff), 0, MAT_BYTES, 0x00027000);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            a4[i] += ib * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                              rD2, (unsigned)(((m0 + 16 * bm + 4 * q4 + i) * SBF_KMAX + n0 + 16 * bn + c16) * 4), 0, POL));
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // my rows have landed in LDS
       CH_STAMP(2);
@@ -390,10 +399,6 @@ __global__ __launch_bounds__(CH_THREADS) void bmm_chain_kernel(Chain c) {
       if (st.C) {
         __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(st.C + hoff), 0, MAT_BYTES, 0x00027000);
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const sb_u4*>(T1 + row * 68 + c4), rC, off, 0, POL);
-      }
-      if (st.C2) {
-        __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)(st.C2 + hoff), 0, MAT_BYTES, 0x00027000);
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const sb_u4*>(T2 + row * 68 + c4), rC2, off, 0, POL);
       }
       // the split images: threads 0-511 the N image(s), 512-1023 the T image(s), 8 elements each
       const int t = tid & 511, prow = t >> 3, c8 = (t & 7) * 8;
@@ -531,17 +536,19 @@ extern "C" int mhimx_bmm_chain(void* stream, const mhimx_bmm_step* steps, int32_
     const mhimx_bmm_step& t = steps[i];
     MHIMX_CHECK_ARG(t.kind >= -1 && t.kind <= 1, "bmm_chain: step %d: kind -1 (idle), 0 (product of two split images) or 1 (split an fp32 matrix)", i);
     if (t.kind >= 0) {
-      const bool second = t.C2 || t.PN2 || t.PT2;
+      const bool second = t.PN2 || t.PT2;
       MHIMX_CHECK_ARG(t.A && (t.kind == 1 || t.B) && (t.C || t.PN || t.PT || second), "bmm_chain: step %d: missing operand / no output", i);
       MHIMX_CHECK_ARG(t.kind == 0 || !(t.C || second), "bmm_chain: step %d: a split step (kind 1) has the outputs PN / PT only", i);
-      MHIMX_CHECK_ARG(!t.D || t.kind == 1 || (!t.C2 && !t.PN2 && !t.PT2 && t.alpha != 0.f), "bmm_chain: step %d: an addend goes with a single-output product, alpha != 0", i);
-      const void* all[9] = {t.A, t.B, t.C, t.C2, t.PN, t.PT, t.PN2, t.PT2, t.D};
+      MHIMX_CHECK_ARG(!t.D || t.kind == 1 || (!second && t.alpha != 0.f), "bmm_chain: step %d: an addend goes with a single-output product, alpha != 0", i);
+      MHIMX_CHECK_ARG(!t.D2 || (t.D && t.kind == 0), "bmm_chain: step %d: a second addend goes with a first one, on a product", i);
+      const void* all[9] = {t.A, t.B, t.C, t.PN, t.PT, t.PN2, t.PT2, t.D, t.D2};
       for (const void* o : all) MHIMX_CHECK_ARG(aligned16(o), "bmm_chain: step %d: operands must be 16-byte aligned", i);
-      const void* outs[6] = {t.C, t.C2, t.PN, t.PT, t.PN2, t.PT2};
+      const void* outs[5] = {t.C, t.PN, t.PT, t.PN2, t.PT2};
       for (const void* o : outs)
-        MHIMX_CHECK_ARG(!o || (o != t.A && o != t.B && (o != t.D || o == t.C)), "bmm_chain: step %d: a step may not overwrite its own operands", i);
+        MHIMX_CHECK_ARG(!o || (o != t.A && o != t.B && o != t.D2 && (o != t.D || o == t.C)), "bmm_chain: step %d: a step may not overwrite its own operands", i);
     }
-    c.st[i] = ChainStep{t.A, t.B, t.C, t.C2, t.PN, t.PT, t.PN2, t.PT2, t.D, t.alpha, t.ident, t.alpha2, t.ident2, t.kind};
+    c.st[i] = ChainStep{t.A, t.B, t.C, t.PN, t.PT, t.PN2, t.PT2, t.D, t.D2, t.alpha, t.ident, t.alpha2, t.ident2, t.dscale != 0.f ? t.dscale : 1.f,
+                        t.d2scale != 0.f ? t.d2scale : 1.f, t.kind};
   }
   constexpr int SM = 2 * CH_PANEL + 4 * SB_T * 68 * 4;          // the partials over the A panels, four output tiles over (and past) the B panels
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bmm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM)));

@@ -336,6 +336,11 @@ class MatmulAffine(torch.autograd.Function):
 
 
 _CHAIN = os.environ.get("MHIMX_PINV_CHAIN", "1") != "0"
+# MHIMX_PINV_LEVELS=3: the pseudo-inverse iteration in its expanded, three-level form (round 5, VERDICT r4 item 2a: 19 grid-wide stages of two
+# products instead of 26 of one, the backward 4 stages per iteration instead of 5).  Built, parity-tested (tests/test_chain_gpu.py, the g7 / c3
+# checks pass with it) and MEASURED EQUAL: the chain launches of a c3 step total 27.66 ms over 29 steps either way (profiles/r05_pinv_levels.md)
+# - a stage's cost follows its outputs and hand-over (two products and five images per stage cost 7-8 us, one product 5 us), not its count.
+_PINV3 = os.environ.get("MHIMX_PINV_LEVELS", "4") == "3"
 _OUT_PROJ = os.environ.get("MHIMX_NYS_OUT_PROJ", "1") != "0"
 _CTRS = {}
 
@@ -351,13 +356,14 @@ def _chain_counters(dev):
     return c
 
 
-def _step(kind, A=None, B=None, C=None, C2=None, PN=None, PT=None, PN2=None, PT2=None, D=None, alpha=1.0, ident=0.0, alpha2=0.0, ident2=0.0):
+def _step(kind, A=None, B=None, C=None, PN=None, PT=None, PN2=None, PT2=None, D=None, D2=None, alpha=1.0, ident=0.0, alpha2=0.0, ident2=0.0,
+          dscale=1.0, d2scale=1.0):
     """One mhimx_bmm_step (include/mhimx.h) from tensors."""
     P = lambda t: _ptr(t) if t is not None else None
-    return L.BmmStep(P(A), P(B), P(C), P(C2), P(PN), P(PT), P(PN2), P(PT2), P(D), alpha, ident, alpha2, ident2, kind)
+    return L.BmmStep(P(A), P(B), P(C), P(PN), P(PT), P(PN2), P(PT2), P(D), P(D2), alpha, ident, alpha2, ident2, dscale, d2scale, kind)
 
 
-_IDLE = lambda: L.BmmStep(None, None, None, None, None, None, None, None, None, 0.0, 0.0, 0.0, 0.0, -1)
+_IDLE = lambda: L.BmmStep(None, None, None, None, None, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1)
 
 
 def _run_chain(steps, groups, dev):
@@ -391,22 +397,43 @@ def _landmark_pinv_forward(lm, scale):
         # the 24 products as ONE persistent launch (mhimx_bmm_chain): matrices travel as split images (bf16 hi + lo planes, "N" as stored /
         # "T" transposed - the bytes of the fp32 matrix), every product also leaves the images the BACKWARD chain multiplies by; only the
         # result z exists in fp32
+        if not _PINV3:
+            img = lambda: torch.empty_like(a2)
+            steps, a2N, a2T, zN, zT = [], img(), img(), img(), img()
+            steps.append(_step(1, A=a2, PN=a2N, PT=a2T))
+            steps.append(_step(1, A=z, PN=zN, PT=zT))
+            for it in range(PINV_ITERS):
+                azN, azT, t1N, t1T, t2N, t2T, t3N, t3T, znN, znT = (img() for _ in range(10))
+                last = it == PINV_ITERS - 1
+                zn = img() if last else None
+                steps.append(_step(0, A=a2N, B=zT, PN=azN, PT=azT, PN2=t1N, PT2=t1T, alpha=1.0, alpha2=-1.0, ident2=7.0))   # az = a2 z, t1 = 7 I - az
+                steps.append(_step(0, A=azN, B=t1T, PN=t2N, PT=t2T, alpha=-1.0, ident=15.0))                               # t2 = 15 I - az t1
+                steps.append(_step(0, A=azN, B=t2T, PN=t3N, PT=t3T, alpha=-1.0, ident=13.0))                               # t3 = 13 I - az t2
+                steps.append(_step(0, A=zN, B=t3T, C=zn, PN=None if last else znN, PT=None if last else znT, alpha=0.25))  # z' = 0.25 z t3
+                chain.append((zN, zT, azT, t1N, t2N, t3N, a2T))
+                z, zN, zT = zn, znN, znT
+            _run_chain(steps, 1, dev)
+            return a2, z, z0, stats, chain
+        # (round 5) the iteration z' = 1/4 z (13 I - M (15 I - M (7 I - M))), M = a2 z, in its EXPANDED form: three dependent levels instead of
+        # Horner's four -   M = a2 z;   P = z M  ||  N' = -15 I + 7 M - M M;   z' = 1/4 P N' + 13/4 z   - 18 grid-wide stages instead of 24
+        # (a stage is ~4-5 us of hand-over around ~0.8 us of product).  Same polynomial; the rounding differs (3.25 z - 2.25 z at
+        # convergence instead of z (13 - 9) / 4), inside the g7 / c3 tolerances.
         img = lambda: torch.empty_like(a2)
         steps, a2N, a2T, zN, zT = [], img(), img(), img(), img()
-        steps.append(_step(1, A=a2, PN=a2N, PT=a2T))
-        steps.append(_step(1, A=z, PN=zN, PT=zT))
+        steps += [_step(1, A=a2, PN=a2N, PT=a2T), _step(1, A=z, PN=zN, PT=zT)]
+        zf = z                                                          # the fp32 iterate (the addend of the last level)
         for it in range(PINV_ITERS):
-            azN, azT, t1N, t1T, t2N, t2T, t3N, t3T, znN, znT = (img() for _ in range(10))
+            M, MN, MT, PNi, PTi, NpN, NpT, zn = (img() for _ in range(8))
             last = it == PINV_ITERS - 1
-            zn = img() if last else None
-            steps.append(_step(0, A=a2N, B=zT, PN=azN, PT=azT, PN2=t1N, PT2=t1T, alpha=1.0, alpha2=-1.0, ident2=7.0))   # az = a2 z, t1 = 7 I - az
-            steps.append(_step(0, A=azN, B=t1T, PN=t2N, PT=t2T, alpha=-1.0, ident=15.0))                               # t2 = 15 I - az t1
-            steps.append(_step(0, A=azN, B=t2T, PN=t3N, PT=t3T, alpha=-1.0, ident=13.0))                               # t3 = 13 I - az t2
-            steps.append(_step(0, A=zN, B=t3T, C=zn, PN=None if last else znN, PT=None if last else znT, alpha=0.25))  # z' = 0.25 z t3
-            chain.append((zN, zT, azT, t1N, t2N, t3N, a2T))
-            z, zN, zT = zn, znN, znT
-        _run_chain(steps, 1, dev)
-        return a2, z, z0, stats, chain
+            znN, znT = (None, None) if last else (img(), img())
+            steps += [_step(0, A=a2N, B=zT, C=M, PN=MN, PT=MT), _IDLE(),                                          # M = a2 z
+                      _step(0, A=zN, B=MT, PN=PNi, PT=PTi),                                                       # P = z M
+                      _step(0, A=MN, B=MT, PN=NpN, PT=NpT, alpha=-1.0, ident=-15.0, D=M, dscale=7.0),             # N' = -15 I + 7 M - M M
+                      _step(0, A=PNi, B=NpT, C=zn, PN=znN, PT=znT, alpha=0.25, D=zf, dscale=3.25), _IDLE()]        # z' = 1/4 P N' + 13/4 z
+            chain.append((zN, zT, MN, MT, PNi, PTi, NpN, a2T))
+            zf, zN, zT = zn, znN, znT
+        _run_chain(steps, 2, dev)
+        return a2, zf, z0, stats, chain
     for _ in range(PINV_ITERS):
         az, t1 = torch.empty_like(a2), torch.empty_like(a2)                 # az = a2 z and t1 = 7 I - az from ONE launch
         g_ = L.GemmNT(A=_ptr(a2), lda=m, rows=None, B=_ptr(z), ldb=m, C=_ptr(az), ldc=m, M=m, N=m, K=m, accumulate=0, prec=L.PREC[_PREC])
@@ -454,6 +481,33 @@ def _landmark_pinv_backward(lm, scale, a2, z0, stats, chain, dz, dlm, accumulate
                 _run_chain(steps, 2, dev)
                 steps = []
         _run_chain(steps, 2, dev)
+        chain = ()
+    elif len(chain[0]) == 8:
+        # the images the forward chain left: the whole backward as TWO launches of mhimx_bmm_chain, two independent products per stage
+        # (256 workgroups), FOUR stages per iteration.  With G the gradient of z' = 1/4 P N' + 13/4 z, P = z M, N' = -15 I + 7 M - M M, M = a2 z:
+        #   1: dP  = 1/4 G N'^T                      | dN' = 1/4 P^T G
+        #   2: U   = 7 dN' - dN' M^T                 | V   = -M^T dN'
+        #   3: dM  = z^T dP + U + V  (images)        | dz' = dP M^T + 13/4 G
+        #   4: da2 (+)= dM z^T                       | dz  = a2^T dM + dz'      (the next iteration's G)
+        # (an X^T operand is the other image of X: N image of X^T = T image of X)
+        img = lambda: torch.empty_like(a2)
+        G, GN, GT = dz, img(), img()
+        steps = [_step(1, A=G, PN=GN, PT=GT), _IDLE()]
+        for k, (zN, zT, MN, MT, PNi, PTi, NpN, a2T) in enumerate(reversed(chain)):
+            dPN, dPT, dNp, dNpN, dNpT, U, V, dMN, dMT, dzp = (img() for _ in range(10))
+            last = k == PINV_ITERS - 1
+            nGN, nGT = (None, None) if last else (img(), img())
+            steps += [_step(0, A=GN, B=NpN, PN=dPN, PT=dPT, alpha=0.25), _step(0, A=PTi, B=GT, C=dNp, PN=dNpN, PT=dNpT, alpha=0.25),
+                      _step(0, A=dNpN, B=MN, C=U, alpha=-1.0, D=dNp, dscale=7.0), _step(0, A=MT, B=dNpT, C=V, alpha=-1.0),
+                      _step(0, A=zT, B=dPT, PN=dMN, PT=dMT, alpha=1.0, D=U, D2=V), _step(0, A=dPN, B=MN, C=dzp, alpha=1.0, D=G, dscale=3.25),
+                      _step(0, A=dMN, B=zN, C=da2, D=None if first else da2, alpha=1.0),
+                      _step(0, A=a2T, B=dMT, C=dzp, D=dzp, PN=nGN, PT=nGT, alpha=1.0)]
+            G, GN, GT, first = dzp, nGN, nGT, False
+            if k == PINV_ITERS // 2 - 1:
+                _run_chain(steps, 2, dev)
+                steps = []
+        _run_chain(steps, 2, dev)
+        dz = G
         chain = ()
     for (zp, az, t1, t2, t3) in reversed(chain):                                  # four pairs of independent products per iteration
         dzp, dt3, daz, dt2, dt1 = (torch.empty_like(dz) for _ in range(5))

@@ -30,9 +30,9 @@ def _mats(n, seed):
 def test_split_images_and_products_match_torch():
     """kind 1 (images of alpha A + D), kind 0 with both outputs, all four images, identity terms."""
     a, b, d = _mats(3, 0)
-    aN, bT, sN, sT, c1, c2, pN, pT, pN2, pT2 = (torch.empty_like(a) for _ in range(10))
+    aN, bT, sN, sT, c1, pN, pT, pN2, pT2 = (torch.empty_like(a) for _ in range(9))
     steps = [NY._step(1, A=a, PN=aN), NY._step(1, A=b, PT=bT), NY._step(1, A=a, D=d, PN=sN, PT=sT, alpha=0.5),
-             NY._step(0, A=aN, B=bT, C=c1, C2=c2, PN=pN, PT=pT, PN2=pN2, PT2=pT2, alpha=-1.0, ident=15.0, alpha2=0.25, ident2=7.0)]
+             NY._step(0, A=aN, B=bT, C=c1, PN=pN, PT=pT, PN2=pN2, PT2=pT2, alpha=-1.0, ident=15.0, alpha2=0.25, ident2=7.0)]
     NY._run_chain(steps, 1, torch.device(DEV))
     eye = torch.eye(256, device=DEV, dtype=torch.float64)
     assert _rel(_image(aN), a) < 2e-5 and _rel(_image(bT), b.transpose(1, 2)) < 2e-5                       # hi + lo = 16 mantissa bits
@@ -40,7 +40,7 @@ def test_split_images_and_products_match_torch():
     assert _rel(_image(sN), s) < 2e-5 and _rel(_image(sT), s.transpose(1, 2)) < 2e-5
     ref = a.double() @ b.double()
     x1, x2 = 15 * eye - ref, 7 * eye + 0.25 * ref
-    assert _rel(c1, x1) < 2e-5 and _rel(c2, x2) < 2e-5
+    assert _rel(c1, x1) < 2e-5
     assert _rel(_image(pN), x1) < 3e-5 and _rel(_image(pT), x1.transpose(1, 2)) < 3e-5
     assert _rel(_image(pN2), x2) < 3e-5 and _rel(_image(pT2), x2.transpose(1, 2)) < 3e-5
     assert not NY.chain_gave_up(torch.device(DEV))
@@ -68,9 +68,11 @@ def test_two_groups_addend_and_idle_slots():
     assert not NY.chain_gave_up(torch.device(DEV))
 
 
-def test_pinv_chain_equals_launch_path_and_is_reproducible():
+@pytest.mark.parametrize("levels3", [False, True])
+def test_pinv_chain_equals_launch_path_and_is_reproducible(levels3):
     """The forward (one launch) and backward (two launches) of the pseudo-inverse against the launch-per-product path (the same 3-term
-    products, another summation order: fp32 rounding, amplified by the iteration), and bit-reproducible under other load."""
+    products, another summation order: fp32 rounding, amplified by the iteration), and bit-reproducible under other load.  levels3: the
+    expanded three-level form of the iteration (MHIMX_PINV_LEVELS=3; round 5) - the same polynomial, the same bounds."""
     dev = torch.device(DEV)
     g = torch.Generator(device=DEV).manual_seed(2)
     lm = torch.randn(256, 2 * 512, device=DEV, generator=g) * 0.5
@@ -82,11 +84,11 @@ def test_pinv_chain_equals_launch_path_and_is_reproducible():
         NY._landmark_pinv_backward(lm, 0.125, a2, z0, stats, chain, dz.clone(), dlm, accumulate=False)
         return z, dlm
 
-    old = NY._CHAIN
+    old, old3 = NY._CHAIN, NY._PINV3
     try:
         NY._CHAIN = False
         z0_, d0 = run()
-        NY._CHAIN = True
+        NY._CHAIN, NY._PINV3 = True, levels3
         z1, d1 = run()
         assert _rel(z1, z0_) < 1e-4 and _rel(d1, d0) < 1e-4
         side, big = torch.cuda.Stream(), torch.randn(4096, 4096, device=DEV)
@@ -99,7 +101,21 @@ def test_pinv_chain_equals_launch_path_and_is_reproducible():
         torch.cuda.synchronize()
         assert not NY.chain_gave_up(dev)
     finally:
-        NY._CHAIN = old
+        NY._CHAIN, NY._PINV3 = old, old3
+
+
+def test_scaled_addends_of_a_product():
+    """Round 5: X = ident I + alpha A B + dscale D + d2scale D2 (the expanded pseudo-inverse polynomial's levels and its backward)."""
+    a, b, d, e = _mats(4, 7)
+    aN, bT, x, y, yN = (torch.empty_like(a) for _ in range(5))
+    steps = [NY._step(1, A=a, PN=aN), NY._step(1, A=b, PT=bT),
+             NY._step(0, A=aN, B=bT, C=x, alpha=-1.0, ident=-15.0, D=d, dscale=7.0), NY._step(0, A=aN, B=bT, C=y, PN=yN, alpha=0.25, D=d, D2=e, dscale=3.25)]
+    NY._run_chain(steps, 2, torch.device(DEV))
+    A, B, D, E = (t.double() for t in (a, b, d, e))
+    eye = torch.eye(256, device=DEV, dtype=torch.float64)
+    assert _rel(x, -15 * eye - A @ B + 7 * D) < 2e-5
+    assert _rel(y, 0.25 * A @ B + 3.25 * D + E) < 2e-5 and _rel(_image(yN), 0.25 * A @ B + 3.25 * D + E) < 3e-5
+    assert not NY.chain_gave_up(torch.device(DEV))
 
 
 def test_chain_rejects_bad_tables():
@@ -109,8 +125,8 @@ def test_chain_rejects_bad_tables():
     one = (L.BmmStep * 1)(NY._step(0, A=a, B=a, C=a))                                 # overwrites its own operand
     assert lib.mhimx_bmm_chain(NY._st(), one, 1, 1, NY._ptr(ctr)) != 0
     many = (L.BmmStep * 64)(*[NY._step(1, A=a, PN=torch.empty_like(a)) for _ in range(64)])
-    assert lib.mhimx_bmm_chain(NY._st(), many, 64, 1, NY._ptr(ctr)) != 0              # more than 42 steps
-    two = (L.BmmStep * 1)(NY._step(0, A=a, B=a, C=torch.empty_like(a), C2=torch.empty_like(a), D=a))
+    assert lib.mhimx_bmm_chain(NY._st(), many, 64, 1, NY._ptr(ctr)) != 0              # more than 38 steps
+    two = (L.BmmStep * 1)(NY._step(0, A=a, B=a, C=torch.empty_like(a), PN2=torch.empty_like(a), D=a))
     assert lib.mhimx_bmm_chain(NY._st(), two, 1, 1, NY._ptr(ctr)) != 0                # an addend with two outputs
     assert lib.mhimx_bmm_chain(NY._st(), one, 1, 3, NY._ptr(ctr)) != 0                # groups
 

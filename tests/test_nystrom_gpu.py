@@ -448,7 +448,14 @@ def test_fused_layer_output_dropout_on_projection_kernel():
         y = layer(x, seed=1234, tick=tick, training=True)
         y0 = layer(x, training=False)
         lin, lin0 = (y - x).detach(), (y0 - x)
-        keep = (lin != 0).float()
+        # the mask the forward drew = the projection kernels' dropout stream at (seed, tick), read back through mhimx_dropout_apply_proj;
+        # (lin != 0 recovers it too, except where the branch's value is below half an ulp of x and y == x exactly: one element in 1.5 M
+        # with the round-5 pseudo-inverse's rounding - which is how this was found)
+        ones, kept = torch.ones_like(ww), torch.empty_like(ww)
+        from mhim_mil_amd import _lib as L
+        L.check(L.lib().mhimx_dropout_apply_proj(ny._st(), ny._ptr(ones), ny._ptr(kept), n, 512, float(p), 1234, ny._ptr(tick)), "dropout_apply_proj")
+        keep = (kept != 0).float()
+        assert ((lin != 0).float() - keep).abs().sum().item() <= 3 and not ((lin != 0) & (keep == 0)).any()
         assert abs(keep.mean().item() - (1 - p)) < 0.01
         thr16 = round(p * 65536)                                     # the stream's 16-bit threshold: keep probability (65536 - thr16) / 65536
         scale = 65536.0 / (65536 - thr16)
