@@ -521,7 +521,6 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   const uint32_t thr16 = (uint32_t)(H.drop_p * 65536.f + 0.5f);
   const float inv_keep = H.drop_mask ? 1.f / (1.f - H.drop_p) : 65536.f / (float)(65536u - thr16);
   _Float16* dact = reinterpret_cast<_Float16*>(H.dact);
-#pragma unroll 1
 #ifdef PW_PROF
   uint32_t pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   pf_t = __builtin_readcyclecounter();
@@ -529,6 +528,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #else
 #define PE_MARK(i)
 #endif
+#pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     // residual rows (the TransLayer's y = x + ...): a wave's seven rows of the half are read one after another - with the read next to
     // its add every row waited a memory latency (the resid launches of c3 ran ~160 us against ~81 us for the same product without).
@@ -612,7 +612,10 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint64_t pf_t3a = __builtin_readcyclecounter();
   __syncthreads();
-  if (blockIdx.x == 0 && lane == 0) {
+#ifndef PW_PROF_BLOCK
+#define PW_PROF_BLOCK 0
+#endif
+  if (blockIdx.x == PW_PROF_BLOCK && lane == 0) {
     const uint64_t pf_t3 = __builtin_readcyclecounter();
     for (int i = 0; i < 8; ++i) H.H[(m0 + wave) * H.ldh + i] = (float)(PW_PROF == 2 ? pe[i] : pf[i]);
     H.H[(m0 + wave) * H.ldh + 8] = (float)(pf_t1 - pf_t0);      // entry -> main loop
