@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=0,
                     help="c2, one GPU: consecutive complete train steps (one bag, one update each) captured per hipGraph (FusedTrainer.capture_steps); "
                          "0 = the largest divisor of gcd(steps, warmup) that is <= 8, 1 = one graph per bag")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c2-dsmil", "c3-sharded"],
                     help="c2 (default, BASELINE.json's metric): MHIM(ABMIL) N=10k D=1024, one bag per GPU per step; "
                          "c3: MHIM(TransMIL) N=50k D=1024 (replicas); c5: ONE bag N=200k D=1536 instance-sharded over the GPUs; "
                          "c2-dsmil: MHIM(DSMIL) N=10k D=1024 (scope row N1)")
@@ -185,8 +185,8 @@ def other_workload(a, world, rank, dev, embedded=False):
     from mhim_mil_amd import synth
     from mhim_mil_amd.mhim import MHIM
     c3 = a.workload in ("c3", "c2-dsmil")                 # replicas driven by FusedTrainer's autograd path
-    bl = {"c3": "selfattn", "c5": "attn", "c2-dsmil": "dsmil"}[a.workload]
-    n_total, d = {"c3": (50000, 1024), "c5": (200000, 1536), "c2-dsmil": (N_INST, D_IN)}[a.workload]
+    bl = {"c3": "selfattn", "c5": "attn", "c2-dsmil": "dsmil", "c3-sharded": "selfattn"}[a.workload]
+    n_total, d = {"c3": (50000, 1024), "c5": (200000, 1536), "c2-dsmil": (N_INST, D_IN), "c3-sharded": (50000, 1024)}[a.workload]
     base = synth.mhim_state(7, input_dim=d, merge_k=5, baseline=bl)
 
     def mk():
@@ -217,7 +217,9 @@ def other_workload(a, world, rank, dev, embedded=False):
         bags = [torch.randn(n, d, device=dev, generator=g).abs_() for _ in range(2)]
         step = lambda i: tr.train_step(bags[i % 2], lab)
         c5_launch = "eager"
-        if not a.no_graph:
+        if bl == "selfattn":
+            c5_launch = "eager (the sequence-parallel TransMIL step plans its exchanges on the host every step: sharded_transmil.py)"
+        elif not a.no_graph:
             # graph | exchange | graph ...: one set of segments per resident shard buffer
             try:
                 replays = [tr.capture(b, lab, warmup=2) for b in bags]
@@ -226,7 +228,8 @@ def other_workload(a, world, rank, dev, embedded=False):
             except Exception as e:  # noqa: BLE001 - reported in the JSON line
                 c5_launch = f"eager (segment capture failed: {type(e).__name__}: {str(e)[:160]})"
         per_step, scaling, par = n_total, "strong", f"instance-sharded over {world} GPU(s), {n} rows each"
-        name = f"c5: MHIM(ABMIL) train step on ONE bag N={n_total} D={d} sharded by rows"
+        name = (f"c5: MHIM(ABMIL) train step on ONE bag N={n_total} D={d} sharded by rows" if bl == "attn" else
+                f"c3-sharded: MHIM(TransMIL/Nystrom) train step on ONE bag N={n_total} D={d} sharded by rows, sequence-parallel encoder")
     dt = timed(a, world, dev, step)
     if rank == 0:
         algo = 3 * d * 4 + 4 * (1 + 2) + 8                   # three passes over X + score / ids, per instance per step
@@ -235,8 +238,8 @@ def other_workload(a, world, rank, dev, embedded=False):
                                              "frac_of_8TBps": per_step * a.steps / dt / world * algo / 1e9 / HBM_PEAK_GBS,
                                              "note": "step-level figure (no single dominant kernel; the attention matrices are streamed, "
                                                      "never materialised): the TransMIL step is matrix-core work, see `roofline`"
-                                             if a.workload == "c3" else "step-level figure"}}
-        if a.workload == "c3":
+                                             if bl == "selfattn" else "step-level figure"}}
+        if bl == "selfattn":
             # ~38 MFLOP per instance per train step (fp32-equivalent: every product runs as 3 bf16 MFMA terms)
             tf = per_step * a.steps / dt / world * 38e6 / 1e12
             extra["roofline"] = {"kernel": "whole step (flat profile: GEMMs 32 %, streamed Nystrom kernels 21 %, pseudo-inverse 13 %)",
@@ -452,6 +455,31 @@ def pick_collective(a, trainer, graphs, bags, labels, world, dev):
             results[name] = ms
         else:
             results[name] = ms if not ok else "failed on another rank"
+    # the bare exchange of every form: the flat gradient buffer all-reduced alone, bus bandwidth = 2 (W - 1) / W x bytes / time (the figure
+    # rccl-tests prints: what a link carries) - printed beside the step times so that a slow step can be told from a slow wire
+    buf = trainer.flat.grad[:trainer.flat.n_train]
+    nbytes = buf.numel() * 4
+    bus = {}
+
+    def wire(name, fn):
+        try:
+            keep = buf.clone()
+            ms = timed_ms(lambda i: fn(), n=10, warm=3)
+            buf.copy_(keep)
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            ms, ok = f"{type(e).__name__}: {str(e)[:120]}", False
+        if agree(ok):
+            bus[name] = {"bytes": nbytes, "ms": ms, "bus_GBps": 2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
+        else:
+            bus[name] = ms if not ok else "failed on another rank"
+
+    wire("torch.distributed all_reduce", lambda: torch.distributed.all_reduce(buf))
+    for name, (cm, _) in forms.items():
+        if cm is not None and cm != "eager":
+            wire("mhimx_comm_allreduce mode 0 (ncclAllReduce)", lambda cm=cm: cm.allreduce(buf, mode=0))
+            wire("mhimx_comm_allreduce mode 1 (reduce-scatter + all-gather)", lambda cm=cm: cm.allreduce(buf, mode=1))
+    results["flat_gradient_all_reduce_alone"] = bus
     best = min((n for n in forms if isinstance(results.get(n), float)), key=lambda n: results[n])
     cm, step = forms[best]
     trainer.comm = cm if (cm is not None and cm != "eager") else None

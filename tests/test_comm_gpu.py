@@ -128,3 +128,30 @@ def test_bench_self_launches_and_picks_a_collective(tmp_path):
     cands = d["config"]["collective_candidates_ms_per_step"]
     assert d["config"]["collective"] in cands and isinstance(cands[d["config"]["collective"]], float)
     assert any("eager" in k for k in cands) and any("torch.distributed all_reduce" in k for k in cands)
+    wire = cands["flat_gradient_all_reduce_alone"]["torch.distributed all_reduce"]                  # the bare exchange beside the step times
+    assert wire["bytes"] > 6e6 and wire["ms"] > 0 and wire["bus_GBps"] > 0
+
+
+@pytest.mark.parametrize("workload", ["c5", "c3-sharded"])
+def test_bench_sharded_workloads_self_launch(tmp_path, workload):
+    """`python bench.py --workload c5 --gpus 2` (one bag sharded by rows, the exchanges between hipGraph segments) and the
+    sequence-parallel MHIM(TransMIL) step (`--workload c3-sharded`) through the SAME argument plumbing the driver's multi-GPU run uses -
+    self-launch under torch.distributed.run, barriers, max-over-ranks timing, rank 0's ONE JSON line.  MHIMX_BENCH_SELFTEST=1: both ranks on
+    this box's one GPU over gloo - the code path, not the numbers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MHIMX_BENCH_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--cpu-steps", "0"], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-400:], r.stderr[-1200:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "2 GPU(s)" in d["config"]["parallelism"] and workload in d["config"]["workload"]
+    if workload == "c5":
+        assert d["config"]["launch"].startswith("hipGraph segments"), d["config"]["launch"]
