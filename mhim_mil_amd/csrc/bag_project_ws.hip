@@ -42,6 +42,7 @@ namespace mhimx {
 constexpr int WBM = 160, WBN = 256, WBK = 32;
 constexpr int W_CONS = 8, W_PROD = 4, WTHREADS = 64 * (W_CONS + W_PROD);                           // 768 threads: three waves per SIMD
 constexpr int WA_BYTES = WBM * 128, WB_BYTES = WBN * 128, WSTAGE = WA_BYTES + WB_BYTES, WNST = 3;     // 20 KiB + 32 KiB, x 3 = 156 KiB
+constexpr int W_CUS = 256;                                                                          // MI355X: one persistent workgroup per CU
 constexpr int WTP = WBN + 4;                                                                         // epilogue tile pitch (floats)
 
 typedef __bf16 pw_bf4 __attribute__((ext_vector_type(4)));
@@ -269,23 +270,41 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nN = (int)(g.n_heads * g.E / WBN), nM = (int)((g.N + WBM - 1) / WBM);
-  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
-  const int m_all = (sidx / nN) * 8 + xcd, n_tile = sidx % nN;              // the column tiles of one row tile share an XCD (X rows via its L2)
-  const int bag = m_all / pb.tiles_per_bag, m_tile = m_all - bag * pb.tiles_per_bag;
-  if (m_tile >= nM) return;
-  g.X = pb.X[bag];
-  const int64_t m0 = (int64_t)m_tile * WBM;
   const int tiles_per_head = (int)(g.E / WBN);
-  const int hd = n_tile / tiles_per_head;
-  const int64_t n0 = (int64_t)(n_tile % tiles_per_head) * WBN;
-  mhimx_proj_head H = g.head[0];
-  if (hd == 1) H = g.head[1];
-  H.H = pb.H[bag][hd];
-  H.dact = pb.dact[bag][hd];
-  H.drop_seed = pb.seed[bag][hd];
   const int nk = (int)(g.D / WBK);
   const bool producer = wave >= W_CONS;
   const int wm = (wave >> 2) & 1, wn = wave & 3;                            // consumer waves: M half (= ping-pong group), N quarter
+  // PERSISTENT workgroups (round 5): virtual block v = blockIdx.x + j gridDim.x (the grid is a multiple of 8, so a workgroup keeps its
+  // XCD); the column tiles of one row tile share an XCD (X rows via its L2) as before.  A launch's workgroups all take the same time, so
+  // its cohorts run in lock-step and a new tile's first cold loads ran into the store burst of every other CU's epilogue
+  // (profiles/r05_store_path.md: 8.7-10.3 k cycles entry -> loop in the third cohort against 4.8 k in the first): now the producers request
+  // the NEXT tile's first stages right after the barrier that ends the k loop - B(0) by DMA into ring stage 2, which the epilogue's staging
+  // tile (the low 83.5 KB) leaves alone; A(0), A(1), A(2) into their idle registers - and the k loop of the next tile starts one barrier
+  // after the last row of this one.  Tile s of EVERY k loop lives in ring stage (s + 2) % 3 for that.
+  const int total = nN * pb.tiles_per_bag * pb.n_bags;
+  const int G = (int)gridDim.x;
+  auto decode = [&](int v, int& bag, int& m_tile, int& n_tile) {
+    const int xcd = v & 7, sidx = v >> 3;
+    const int m_all = (sidx / nN) * 8 + xcd;
+    n_tile = sidx % nN;
+    bag = m_all / pb.tiles_per_bag;
+    m_tile = m_all - bag * pb.tiles_per_bag;
+  };
+  auto next_tile = [&](int v) {                                             // the next virtual block of this workgroup that holds rows
+    for (v += G; v < total; v += G) {
+      int b_, m_, n_;
+      decode(v, b_, m_, n_);
+      if (m_ < nM) return v;
+    }
+    return total;
+  };
+  int vb = (int)blockIdx.x;
+  {
+    int b_, m_, n_;
+    decode(vb, b_, m_, n_);
+    if (m_ >= nM) vb = next_tile(vb);
+  }
+  if (vb >= total) return;
 
   auto slot_end = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -293,16 +312,17 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  f32x4 acc[NRA][NRB];
-#pragma unroll
-  for (int i = 0; i < NRA; ++i)
-#pragma unroll
-    for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef PW_PROF                                                  // cycles per phase, summed over the k loop (tools/exp_proj_prof.py)
-  const uint64_t pf_t0 = __builtin_readcyclecounter();
-  uint64_t pf_t1 = 0, pf_t2 = 0;
+#ifndef PW_PROF_BLOCK
+#define PW_PROF_BLOCK 0
+#endif
+#ifndef PW_PROF_TILE
+#define PW_PROF_TILE 0
+#endif
+  uint64_t pf_t0 = 0, pf_t1 = 0, pf_t2 = 0;
   uint32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t pf_t = 0;
+  int pf_iter = 0;
 #define PW_MARK(i) { const uint64_t now_ = __builtin_readcyclecounter(); pf[i] += (uint32_t)(now_ - pf_t); pf_t = now_; }
 #define PW_START() { pf_t = __builtin_readcyclecounter(); }
 #else
@@ -310,209 +330,135 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #define PW_START()
 #endif
 
-  if (producer) {
-    // ================================================================= producers: 256 threads own the global -> LDS stream
-    // (a lean instruction stream matters: a producer wave shares its SIMD's issue with two consumer waves - the first version spent ~250
-    // instructions per k-step here, mostly 64-bit address arithmetic and unpacked conversions, and its slot outlasted the 60-MFMA phase)
+  // ---------------------------------------------------------------- producers' state (256 threads own the global -> LDS stream)
+  // (a lean instruction stream matters: a producer wave shares its SIMD's issue with two consumer waves - the first version spent ~250
+  // instructions per k-step here, mostly 64-bit address arithmetic and unpacked conversions, and its slot outlasted the 60-MFMA phase)
 #ifndef PW_PROD_PRIO
 #define PW_PROD_PRIO 1
 #endif
-    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
-    const int pt = tid - 64 * W_CONS, pw = wave - W_CONS;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
-    // A: 160 rows x 8 sixteen-byte units per k-step = 1280 units, five per thread: unit u = pt + 256 j -> row u >> 3, slot u & 7
-    unsigned aoff[5], a_hi[5], a_lo[5];
+  const int pt = tid - 64 * W_CONS, pw = wave - W_CONS;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
+  // A: 160 rows x 8 sixteen-byte units per k-step = 1280 units, five per thread: unit u = pt + 256 j -> row u >> 3, slot u & 7
+  unsigned aoff[5], a_hi[5], a_lo[5];
+  // B: 32 DMA pieces of 1 KiB (8 rows x 128 B) per k-step, eight per producer wave: piece P = 8 pw + q covers rows 8 P .. 8 P + 7; the
+  // SOURCE slot is swizzled by the row (mt_swz depends on row & 15 = 8 (q & 1) + lane / 8).  One per-lane byte offset per piece against
+  // ONE uniform base that advances 128 B per k-step.
+  unsigned bvoff[8];
+  const float* px = nullptr;                                                // the tile's bag
+  const char* bbase = nullptr;                                              // the tile's weight rows, k-step 0
+  struct ARegs { f32x4 v[5]; };
+  if (producer) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int u = pt + 256 * j, row = u >> 3, slot = u & 7;
+      const int sw = mt_swz(row), kg2 = (slot >> 1) * 2;
+      a_hi[j] = lds0 + (unsigned)(row * 128 + ((kg2 ^ sw) << 4) + (slot & 1) * 8);
+      a_lo[j] = lds0 + (unsigned)(row * 128 + (((kg2 + 1) ^ sw) << 4) + (slot & 1) * 8);
+    }
+    const int rl = lane >> 3, sl = lane & 7;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      bvoff[q] = (unsigned)((((pw * 64 + q * 8 + rl) * g.D) + (sl ^ mt_swz(8 * (q & 1) + rl)) * 4) * 4);
+  }
+  auto p_setup = [&](int v) {                                               // the tile's row offsets and weight rows
+    int bag, m_tile, n_tile;
+    decode(v, bag, m_tile, n_tile);
+    px = pb.X[bag];
+    const int64_t m0 = (int64_t)m_tile * WBM;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int u = pt + 256 * j, row = u >> 3, slot = u & 7;
       int64_t m = m0 + row;
       if (m >= g.N) m = g.N - 1;                                            // clamped rows feed accumulators that are never stored
       aoff[j] = (unsigned)((m * g.ldx + slot * 4) * 4);
-      const int sw = mt_swz(row), kg2 = (slot >> 1) * 2;
-      a_hi[j] = lds0 + (unsigned)(row * 128 + ((kg2 ^ sw) << 4) + (slot & 1) * 8);
-      a_lo[j] = lds0 + (unsigned)(row * 128 + (((kg2 + 1) ^ sw) << 4) + (slot & 1) * 8);
     }
-    // B: 32 DMA pieces of 1 KiB (8 rows x 128 B) per k-step, eight per producer wave: piece P = 8 pw + q covers rows 8 P .. 8 P + 7; the
-    // SOURCE slot is swizzled by the row (mt_swz depends on row & 15 = 8 (q & 1) + lane / 8).  One per-lane byte offset per piece against
-    // ONE uniform base that advances 128 B per k-step.
-    const int rl = lane >> 3, sl = lane & 7;
-    unsigned bvoff[8];
+    const float* wp = (n_tile / tiles_per_head == 1) ? g.head[1].wp : g.head[0].wp;
+    bbase = reinterpret_cast<const char*>(wp + (int64_t)(n_tile % tiles_per_head) * WBN * g.D);     // + 128 B per k-step
+  };
+  auto issue_b = [&](const char* bk, unsigned stage_off, int q0) {          // pieces q0 .. q0+3
+    const unsigned sb = lds0 + stage_off + WA_BYTES + pw * 8192;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-      bvoff[q] = (unsigned)((((pw * 64 + q * 8 + rl) * g.D) + (sl ^ mt_swz(8 * (q & 1) + rl)) * 4) * 4);
-    const char* bcur = reinterpret_cast<const char*>(H.wp + n0 * g.D);     // + 128 B per k-step
-    const char* const bdummy = bcur;       // past the last tile the same COUNT of requests re-reads k-step 0 (uniform vmcnt; a stage nobody reads)
-    auto issue_b = [&](const char* bk, unsigned stage_off, int q0) {        // pieces q0 .. q0+3
-      const unsigned sb = lds0 + stage_off + WA_BYTES + pw * 8192;
+    for (int q = q0; q < q0 + 4; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_f)(bk + bvoff[q]), (lptr_f)(uintptr_t)(sb + q * 1024), 16, 0, 0);
+  };
+  auto uni = [](const float* p) {                                           // (a loop-carried pointer: the compiler cannot see that it is uniform)
+    const uint64_t u = (uint64_t)(uintptr_t)p;
+    return reinterpret_cast<const float*>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u)));
+  };
+  auto load_a3 = [&](const float* xk, ARegs& r) {                           // units 0..2
+    asm volatile("global_load_dwordx4 %0, %3, %6\n\tglobal_load_dwordx4 %1, %4, %6\n\tglobal_load_dwordx4 %2, %5, %6"
+                 : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]) : "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "s"(xk) : "memory");
+  };
+  auto load_a2 = [&](const float* xk, ARegs& r) {                           // units 3..4
+    asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4"
+                 : "=&v"(r.v[3]), "=&v"(r.v[4]) : "v"(aoff[3]), "v"(aoff[4]), "s"(xk) : "memory");
+  };
+  typedef float pw_f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 pw_b2 __attribute__((ext_vector_type(2)));
+  typedef unsigned pw_u2 __attribute__((ext_vector_type(2)));
+  auto split_store = [&](const f32x4& v, unsigned hi_addr, unsigned lo_addr) {        // one v_cvt_pk_bf16_f32 per PAIR, one ds_write_b64 per plane
+    pw_u2 hi, lo;
 #pragma unroll
-      for (int q = q0; q < q0 + 4; ++q)
-        __builtin_amdgcn_global_load_lds((gptr_f)(bk + bvoff[q]), (lptr_f)(uintptr_t)(sb + q * 1024), 16, 0, 0);
-    };
-    struct ARegs { f32x4 v[5]; };
-    auto load_a3 = [&](const float* xk, ARegs& r) {                         // units 0..2
-      asm volatile("global_load_dwordx4 %0, %3, %6\n\tglobal_load_dwordx4 %1, %4, %6\n\tglobal_load_dwordx4 %2, %5, %6"
-                   : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]) : "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "s"(xk) : "memory");
-    };
-    auto load_a2 = [&](const float* xk, ARegs& r) {                         // units 3..4
-      asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4"
-                   : "=&v"(r.v[3]), "=&v"(r.v[4]) : "v"(aoff[3]), "v"(aoff[4]), "s"(xk) : "memory");
-    };
-    typedef float pw_f2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 pw_b2 __attribute__((ext_vector_type(2)));
-    typedef unsigned pw_u2 __attribute__((ext_vector_type(2)));
-    auto split_store = [&](const f32x4& v, unsigned hi_addr, unsigned lo_addr) {      // one v_cvt_pk_bf16_f32 per PAIR, one ds_write_b64 per plane
-      pw_u2 hi, lo;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const float a = v[2 * p], b = v[2 * p + 1];
-        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f2{a, b}, pw_b2));
-        hi[p] = h;
-        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f2{a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u)}, pw_b2));
-      }
-      *reinterpret_cast<__attribute__((address_space(3))) pw_u2*>((uintptr_t)hi_addr) = hi;
-      *reinterpret_cast<__attribute__((address_space(3))) pw_u2*>((uintptr_t)lo_addr) = lo;
-    };
+    for (int p = 0; p < 2; ++p) {
+      const float a = v[2 * p], b = v[2 * p + 1];
+      const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f2{a, b}, pw_b2));
+      hi[p] = h;
+      lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f2{a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u)}, pw_b2));
+    }
+    *reinterpret_cast<__attribute__((address_space(3))) pw_u2*>((uintptr_t)hi_addr) = hi;
+    *reinterpret_cast<__attribute__((address_space(3))) pw_u2*>((uintptr_t)lo_addr) = lo;
+  };
 #define PW_NAME5(r) "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4])
-    // prologue: B(0), B(1) requested, A(0) -> stage 0 (the compiler's wait in front of the conversion drains the DMA pieces too), A(1), A(2)
-    // requested into the two register sets; A(1) waited for
-    ARegs ra, rb;                                                           // ra: odd tiles, rb: even tiles
-    issue_b(bcur, 0, 0);
-    issue_b(bcur, 0, 4);
-    issue_b(bcur + (nk > 1 ? 128 : 0), WSTAGE, 0);
-    issue_b(bcur + (nk > 1 ? 128 : 0), WSTAGE, 4);
-    {
-      const char* xb = reinterpret_cast<const char*>(g.X);
+  // the NEXT tile's first stages, requested from inside this tile's epilogue - by LDS-DMA only, into the 72 KB the staging rows leave free: the
+  // producers' registers must not hold requests in flight across compiler-scheduled code (a first version kept A(0..2) in registers: the
+  // compiler moved them between physical registers around the loops BEFORE the wait, and spilled one).  B(0) -> its place in ring stage 2;
+  // the raw fp32 rows of A(0) -> the A region of stage 2 ([row][128 B]: unit u of the producers' mapping is bytes 16 u .. 16 u + 15, so a wave's
+  // DMA instruction j covers its 8 rows 8 pw + 32 j ..), converted IN PLACE at the top of the next tile (the 8 units of a row belong to 8
+  // consecutive lanes of one wave: all of them have read before any writes); the raw rows of A(1) -> the gap between the staging rows and
+  // stage 2, read into `ra` there.
+  constexpr unsigned RAW1_OFF = 82 * 1024;                                  // staging rows + row keys end at 83 520
+  static_assert(80 * WTP * 4 + 320 <= RAW1_OFF && RAW1_OFF + WA_BYTES <= 2 * WSTAGE, "raw A(1) sits between the staging rows and ring stage 2");
+  auto prefetch = [&]() {
+    issue_b(bbase, 2 * WSTAGE, 0);
+    issue_b(bbase, 2 * WSTAGE, 4);
+    const char* xb0 = reinterpret_cast<const char*>(px);
+    const char* xb1 = xb0 + (nk > 1 ? 128 : 0);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) split_store(*reinterpret_cast<const f32x4*>(xb + aoff[j]), a_hi[j], a_lo[j]);
+    for (int j = 0; j < 5; ++j) {
+      const unsigned dst = lds0 + (unsigned)((pw * 8 + 32 * j) * 128);
+      __builtin_amdgcn_global_load_lds((gptr_f)(xb0 + aoff[j]), (lptr_f)(uintptr_t)(dst + 2 * WSTAGE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_f)(xb1 + aoff[j]), (lptr_f)(uintptr_t)(dst + RAW1_OFF), 16, 0, 0);
     }
-    const float* xk = g.X;                                                  // k-step pointer of the NEXT A request
-    {
-      const float* x1 = g.X + (nk > 1 ? 1 : 0) * WBK;
-      const float* x2 = g.X + (nk > 2 ? 2 : nk - 1) * WBK;
-      load_a3(x1, ra); load_a2(x1, ra);
-      load_a3(x2, rb); load_a2(x2, rb);
-    }
-    asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");          // A(1) is here
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // A(0) is in LDS
-    slot_end();                                                             // ---- tile 0 complete
-    // running state of k-step s: st1 = byte offset of stage (s+1) % 3 (A(s+1) is stored there), st2 = of stage (s+2) % 3 (B(s+2) lands there)
-    unsigned st1 = WSTAGE, st2 = 2 * WSTAGE;
-    bcur += 2 * 128;                                                        // -> B(s+2)
-    // Both slots of a k-step carry half of the work: units 0..2 / 3..4 of A(s+1) (split + stores) and of the A(s+3) request, pieces 0..3 /
-    // 4..7 of B(s+2).  After the odd slot: wait until only the 13 youngest requests are in flight (this k-step's A(s+3) [5] and B(s+2) [8]):
-    // A(s+2) - requested a k-step ago - is in its registers and B(s+1) has landed.
-    auto kstep = [&](int s, ARegs& r, ARegs& r_next) {                       // r: A(s+1), arrived; r_next: A(s+2), in flight
-      const bool st_ok = s + 1 < nk, b_ok = s + 2 < nk;
-      const float* xn = g.X + (int64_t)(s + 3 < nk ? s + 3 : nk - 1) * WBK;
-      const char* bk = b_ok ? bcur : bdummy;
-      // ---- slot 2s
-      PW_START();
-      if (st_ok) {
-        split_store(r.v[0], a_hi[0] + st1, a_lo[0] + st1);
-        split_store(r.v[1], a_hi[1] + st1, a_lo[1] + st1);
-        split_store(r.v[2], a_hi[2] + st1, a_lo[2] + st1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      PW_MARK(0);
-      load_a3(xn, r);                                                       // (issued after the split read the registers)
-      issue_b(bk, st2, 0);
-      PW_MARK(1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PW_MARK(2);
-      slot_end();
-      PW_MARK(3);
-      // ---- slot 2s+1
-      if (st_ok) {
-        split_store(r.v[3], a_hi[3] + st1, a_lo[3] + st1);
-        split_store(r.v[4], a_hi[4] + st1, a_lo[4] + st1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      PW_MARK(4);
-      load_a2(xn, r);
-      issue_b(bk, st2, 4);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PW_MARK(5);
-      asm volatile("s_waitcnt vmcnt(13)" : PW_NAME5(r_next) : : "memory");
-      PW_MARK(6);
-      slot_end();
-      PW_MARK(7);
-      st1 = st2;
-      st2 = st2 == 2 * WSTAGE ? 0u : st2 + WSTAGE;
-      bcur += 128;
-    };
-#ifdef PW_PROF
-    pf_t1 = __builtin_readcyclecounter();
-#endif
-    int s = 0;
-#pragma unroll 1
-    for (; s + 1 < nk; s += 2) {
-      kstep(s, ra, rb);
-      kstep(s + 1, rb, ra);
-    }
-    if (s < nk) kstep(s, ra, rb);
-    slot_end();                                                             // slot 2 nk: group 1's last compute phase
-    asm volatile("s_waitcnt vmcnt(0)" : PW_NAME5(ra), PW_NAME5(rb) : : "memory");
-    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(0);                        // the epilogue shares its rows evenly among all twelve waves
-#undef PW_NAME5
-  } else {
-    // ================================================================= consumers: fragment reads and MFMAs only
-    const int r16 = lane & 15, kg = lane >> 4;
-    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_f)smem;
-    const int ra_ = wm * 80 + r16, rb_ = wn * 64 + r16;
-    const unsigned fa_hi = lds0 + ra_ * 128 + (((2 * kg) ^ mt_swz(ra_)) << 4);
-    const unsigned fa_lo = lds0 + ra_ * 128 + (((2 * kg + 1) ^ mt_swz(ra_)) << 4);
-    const unsigned fb_hi = lds0 + WA_BYTES + rb_ * 128 + (((2 * kg) ^ mt_swz(rb_)) << 4);
-    const unsigned fb_lo = lds0 + WA_BYTES + rb_ * 128 + (((2 * kg + 1) ^ mt_swz(rb_)) << 4);
-    f32x4 x[NFR];
-    auto load_phase = [&](int s) {
-      const unsigned so = (unsigned)((s % WNST) * WSTAGE);
-      MT_READ9(x, 5, 10, fa_lo + so, fb_hi + so);
-      MT_READ9(x, 0, 14, fa_hi + so, fb_lo + so);
-      MT_WAIT9(0, x, 5, 10);
-      MT_WAIT9(0, x, 0, 14);
-    };
-    auto compute_phase = [&]() {
-#ifdef PW_NOMMA
-      return;
-#endif
-      mt_term(x, 5, 10, acc);                                               // lo*hi
-      mt_term(x, 0, 14, acc);                                               // hi*lo
-      mt_term(x, 0, 10, acc);                                               // hi*hi
-    };
-    slot_end();                                                             // ---- tile 0 complete (producers' prologue)
-#ifdef PW_PROF
-    pf_t1 = __builtin_readcyclecounter();
-#endif
-#ifdef PW_G1_PRIO
-    if (wm != 0) __builtin_amdgcn_s_setprio(PW_G1_PRIO);
-#endif
-    const bool late = wm != 0;                                              // group 1 runs the same loop one slot later
-    if (late) slot_end();
-#pragma unroll 1
-    for (int s = 0; s < nk; ++s) {
-      PW_START();
-      load_phase(s);       PW_MARK(0);   slot_end();   PW_MARK(1);
-      compute_phase();     PW_MARK(2);   slot_end();   PW_MARK(3);
-    }
-    if (!late) slot_end();
-#ifdef PW_G1_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-  }
-
-#ifdef PW_PROF
-  pf_t2 = __builtin_readcyclecounter();
-#endif
-  if constexpr (SCORED) {
-    if (hd == 0) {                                            // model 0: scorer + pool partials instead of the feature rows
-      pw_scored_epilogue<SCORED == 2>(g, H, sc, acc, smem, m_tile, m0, n0);
-      return;
-    }
-  }
+  };
+  struct TileCtx { int m_tile, hd, vb_next; int64_t m0, n0; mhimx_proj_head H; };
+  auto tile_ctx = [&](int v) {
+    int bag, m_tile, n_tile;
+    decode(v, bag, m_tile, n_tile);
+    TileCtx t;
+    t.m_tile = m_tile;
+    t.vb_next = next_tile(v);
+    t.m0 = (int64_t)m_tile * WBM;
+    t.hd = n_tile / tiles_per_head;
+    t.n0 = (int64_t)(n_tile % tiles_per_head) * WBN;
+    t.H = g.head[0];
+    if (t.hd == 1) t.H = g.head[1];
+    t.H.H = pb.H[bag][t.hd];
+    t.H.dact = pb.dact[bag][t.hd];
+    t.H.drop_seed = pb.seed[bag][t.hd];
+    return t;
+  };
   // ================================================================= epilogue: all twelve waves, two 80-row halves through LDS
+  // (a lambda instantiated once per ROLE: the tile loops below are separate per role, so that the producers' loop-carried registers - row
+  // offsets, the three A register sets - and the consumers' accumulators are never live together: in one loop they spilled 576 bytes)
+  auto epilogue = [&](auto is_prod, f32x4 (&acc)[NRA][NRB], const TileCtx& t) {
+  constexpr bool producer = decltype(is_prod)::value;
+  const int64_t m0 = t.m0, n0 = t.n0;
+  const mhimx_proj_head& H = t.H;
+  const int vb_next = t.vb_next;
   float* tile = reinterpret_cast<float*>(smem);
   uint32_t* rkeys = reinterpret_cast<uint32_t*>(smem + 80 * WTP * 4);
-  const int c4 = lane * 4, r0 = wave;                                       // this thread's 4 columns are fixed; rows wave, wave + 12, ..
+  const int c4 = lane * 4, r0w = wave;                                      // this thread's 4 columns are fixed; rows wave, wave + 12, ..
   const int64_t n = n0 + c4;
   float bias[4] = {0.f, 0.f, 0.f, 0.f};
   if (H.bias) { const f32x4 b = *reinterpret_cast<const f32x4*>(H.bias + n); bias[0] = b[0]; bias[1] = b[1]; bias[2] = b[2]; bias[3] = b[3]; }
@@ -540,10 +486,15 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       if (r < 80 && m < g.N) v = *reinterpret_cast<const f32x4*>(H.resid + m * H.ldr + n);
       return v;
     };
-    if (H.resid) { rq0 = ld_res(r0); rq1 = ld_res(r0 + (W_CONS + W_PROD)); rq2 = ld_res(r0 + 2 * (W_CONS + W_PROD)); }
+    if (H.resid) { rq0 = ld_res(r0w); rq1 = ld_res(r0w + (W_CONS + W_PROD)); rq2 = ld_res(r0w + 2 * (W_CONS + W_PROD)); }
     __syncthreads();                                          // fragment reads / the previous half's tile reads are over
+    if constexpr (producer)
+      if (half == 0 && vb_next < total) {                     // every stage is free now: the next tile's first requests leave before the rows
+        p_setup(vb_next);
+        prefetch();
+      }
     PE_MARK(0);
-    if (!producer && wm == half) {
+    if constexpr (!producer) if (wm == half) {
       const int cl = lane & 15, rq = lane >> 4;
 #pragma unroll
       for (int i = 0; i < NRA; ++i)
@@ -557,7 +508,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     __syncthreads();
     PE_MARK(2);
 #pragma unroll 1
-    for (int r = r0; r < 80; r += W_CONS + W_PROD) {
+    for (int r = r0w; r < 80; r += W_CONS + W_PROD) {
       const int64_t m = m0 + half * 80 + r;
       if (m >= g.N) break;
       const f32x4 a = *reinterpret_cast<const f32x4*>(tile + r * WTP + c4);
@@ -609,21 +560,225 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     PE_MARK(3);
   }
 #ifdef PW_PROF
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint64_t pf_t3a = __builtin_readcyclecounter();
-  __syncthreads();
-#ifndef PW_PROF_BLOCK
-#define PW_PROF_BLOCK 0
-#endif
-  if (blockIdx.x == PW_PROF_BLOCK && lane == 0) {
-    const uint64_t pf_t3 = __builtin_readcyclecounter();
-    for (int i = 0; i < 8; ++i) H.H[(m0 + wave) * H.ldh + i] = (float)(PW_PROF == 2 ? pe[i] : pf[i]);
-    H.H[(m0 + wave) * H.ldh + 8] = (float)(pf_t1 - pf_t0);      // entry -> main loop
-    H.H[(m0 + wave) * H.ldh + 9] = (float)(pf_t2 - pf_t1);      // main loop
-    H.H[(m0 + wave) * H.ldh + 10] = (float)(pf_t3 - pf_t2);     // epilogue
-    H.H[(m0 + wave) * H.ldh + 11] = (float)(pf_t3a - pf_t);     // the wave's last stores leave
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint64_t pf_t3a = __builtin_readcyclecounter();
+    __syncthreads();
+    if (blockIdx.x == PW_PROF_BLOCK && pf_iter == PW_PROF_TILE && lane == 0) {
+      const uint64_t pf_t3 = __builtin_readcyclecounter();
+      for (int i = 0; i < 8; ++i) H.H[(m0 + wave) * H.ldh + i] = (float)(PW_PROF == 2 ? pe[i] : pf[i]);
+      H.H[(m0 + wave) * H.ldh + 8] = (float)(pf_t1 - pf_t0);      // tile top -> main loop
+      H.H[(m0 + wave) * H.ldh + 9] = (float)(pf_t2 - pf_t1);      // main loop
+      H.H[(m0 + wave) * H.ldh + 10] = (float)(pf_t3 - pf_t2);     // epilogue
+      H.H[(m0 + wave) * H.ldh + 11] = (float)(pf_t3a - pf_t);     // the wave's last stores leave
+      H.H[(m0 + wave) * H.ldh + 12] = (float)m0;
+    }
+    ++pf_iter;
   }
 #endif
+  };
+
+  if (producer) {
+    p_setup(vb);
+    bool first = true;
+#pragma unroll 1
+    for (;;) {
+    const TileCtx t = tile_ctx(vb);
+#ifdef PW_PROF
+    pf_t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) pf[i] = 0;
+#endif
+    // ================================================================= producers
+    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
+    ARegs ra, rb;                                                           // ra: odd tiles, rb: even tiles
+    const float* const pxu = uni(px);
+    const float* const x2 = pxu + (nk > 2 ? 2 : nk - 1) * WBK;
+    if (first) {
+      // the launch's first tile: B(0), B(1) requested, A(0) -> stage 2 (the compiler's wait in front of the conversion drains the DMA pieces
+      // too), A(1), A(2) requested into the two register sets; A(1) waited for
+      issue_b(bbase, 2 * WSTAGE, 0);
+      issue_b(bbase, 2 * WSTAGE, 4);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 4);
+      {
+        const char* xb = reinterpret_cast<const char*>(px);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) split_store(*reinterpret_cast<const f32x4*>(xb + aoff[j]), a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
+      }
+      const float* x1 = pxu + (nk > 1 ? 1 : 0) * WBK;
+      load_a3(x1, ra); load_a2(x1, ra);
+      load_a3(x2, rb); load_a2(x2, rb);
+      asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");        // A(1) is here
+    } else {
+      // a later tile: B(0) and the raw rows of A(0), A(1) landed during the previous epilogue (its closing wait and barrier).  A(1) -> ra,
+      // A(0) converted in place, A(2) requested, B(1) -> stage 0 (which held the staging rows until that barrier)
+      ARegs r0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        r0.v[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + 2 * WSTAGE + (unsigned)(pt + 256 * j) * 16));
+        ra.v[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + RAW1_OFF + (unsigned)(pt + 256 * j) * 16));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : PW_NAME5(r0), PW_NAME5(ra) : : "memory");
+      load_a3(x2, rb); load_a2(x2, rb);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) split_store(r0.v[j], a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // A(0) is in LDS
+    slot_end();                                                             // ---- tile 0 complete
+    // running state of k-step s: st1 = byte offset of the stage of tile s+1 (A(s+1) is stored there), st2 = of tile s+2 (B(s+2) lands there)
+    unsigned st1 = 0, st2 = WSTAGE;
+    const char* bcur = bbase + 2 * 128;                                     // -> B(s+2)
+    const char* const bdummy = bbase;      // past the last tile the same COUNT of requests re-reads k-step 0 (uniform vmcnt; a stage nobody reads)
+    // Both slots of a k-step carry half of the work: units 0..2 / 3..4 of A(s+1) (split + stores) and of the A(s+3) request, pieces 0..3 /
+    // 4..7 of B(s+2).  After the odd slot: wait until only the 13 youngest requests are in flight (this k-step's A(s+3) [5] and B(s+2) [8]):
+    // A(s+2) - requested a k-step ago - is in its registers and B(s+1) has landed.
+    auto kstep = [&](int s, ARegs& r, ARegs& r_next) {                       // r: A(s+1), arrived; r_next: A(s+2), in flight
+      const bool st_ok = s + 1 < nk, b_ok = s + 2 < nk;
+      const float* xn = pxu + (int64_t)(s + 3 < nk ? s + 3 : nk - 1) * WBK;
+      const char* bk = b_ok ? bcur : bdummy;
+      // ---- slot 2s
+      PW_START();
+      if (st_ok) {
+        split_store(r.v[0], a_hi[0] + st1, a_lo[0] + st1);
+        split_store(r.v[1], a_hi[1] + st1, a_lo[1] + st1);
+        split_store(r.v[2], a_hi[2] + st1, a_lo[2] + st1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      PW_MARK(0);
+      load_a3(xn, r);                                                       // (issued after the split read the registers)
+      issue_b(bk, st2, 0);
+      PW_MARK(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PW_MARK(2);
+      slot_end();
+      PW_MARK(3);
+      // ---- slot 2s+1
+      if (st_ok) {
+        split_store(r.v[3], a_hi[3] + st1, a_lo[3] + st1);
+        split_store(r.v[4], a_hi[4] + st1, a_lo[4] + st1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      PW_MARK(4);
+      load_a2(xn, r);
+      issue_b(bk, st2, 4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PW_MARK(5);
+      asm volatile("s_waitcnt vmcnt(13)" : PW_NAME5(r_next) : : "memory");
+      PW_MARK(6);
+      slot_end();
+      PW_MARK(7);
+      st1 = st2;
+      st2 = st2 == 2 * WSTAGE ? 0u : st2 + WSTAGE;
+      bcur += 128;
+    };
+#ifdef PW_PROF
+    pf_t1 = __builtin_readcyclecounter();
+#endif
+    int s = 0;
+#pragma unroll 1
+    for (; s + 1 < nk; s += 2) {
+      kstep(s, ra, rb);
+      kstep(s + 1, rb, ra);
+    }
+    if (s < nk) kstep(s, ra, rb);
+    slot_end();                                                             // slot 2 nk: group 1's last compute phase
+    asm volatile("s_waitcnt vmcnt(0)" : PW_NAME5(ra), PW_NAME5(rb) : : "memory");
+    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(0);                        // the epilogue shares its rows evenly among all twelve waves
+#ifdef PW_PROF
+    pf_t2 = __builtin_readcyclecounter();
+#endif
+    f32x4 acc0[NRA][NRB];                                                   // (the producers hold no outputs; the scored epilogue reads zeros)
+    if constexpr (SCORED) {
+#pragma unroll
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t.hd == 0) {                                      // model 0: scorer + pool partials instead of the feature rows
+        pw_scored_epilogue<SCORED == 2>(g, t.H, sc, acc0, smem, t.m_tile, t.m0, t.n0);   // (scored launches are not persistent: one tile per workgroup)
+        return;
+      }
+    }
+    epilogue(std::true_type{}, acc0, t);
+    if (t.vb_next >= total) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next tile's first stages have landed (and this tile's stores are out)
+    __syncthreads();                                          // the staging rows are read: B(1) of the next tile may land in stage 0
+    vb = t.vb_next;
+    first = false;
+    }
+  } else {
+#pragma unroll 1
+    for (;;) {
+    const TileCtx t = tile_ctx(vb);
+    f32x4 acc[NRA][NRB];
+#pragma unroll
+    for (int i = 0; i < NRA; ++i)
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef PW_PROF
+    pf_t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) pf[i] = 0;
+#endif
+    // ================================================================= consumers: fragment reads and MFMAs only
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ra_ = wm * 80 + r16, rb_ = wn * 64 + r16;
+    const unsigned fa_hi = lds0 + ra_ * 128 + (((2 * kg) ^ mt_swz(ra_)) << 4);
+    const unsigned fa_lo = lds0 + ra_ * 128 + (((2 * kg + 1) ^ mt_swz(ra_)) << 4);
+    const unsigned fb_hi = lds0 + WA_BYTES + rb_ * 128 + (((2 * kg) ^ mt_swz(rb_)) << 4);
+    const unsigned fb_lo = lds0 + WA_BYTES + rb_ * 128 + (((2 * kg + 1) ^ mt_swz(rb_)) << 4);
+    f32x4 x[NFR];
+    auto load_phase = [&](unsigned so) {
+      MT_READ9(x, 5, 10, fa_lo + so, fb_hi + so);
+      MT_READ9(x, 0, 14, fa_hi + so, fb_lo + so);
+      MT_WAIT9(0, x, 5, 10);
+      MT_WAIT9(0, x, 0, 14);
+    };
+    auto compute_phase = [&]() {
+#ifdef PW_NOMMA
+      return;
+#endif
+      mt_term(x, 5, 10, acc);                                               // lo*hi
+      mt_term(x, 0, 14, acc);                                               // hi*lo
+      mt_term(x, 0, 10, acc);                                               // hi*hi
+    };
+    slot_end();                                                             // ---- tile 0 complete (producers' prologue)
+#ifdef PW_PROF
+    pf_t1 = __builtin_readcyclecounter();
+#endif
+#ifdef PW_G1_PRIO
+    if (wm != 0) __builtin_amdgcn_s_setprio(PW_G1_PRIO);
+#endif
+    const bool late = wm != 0;                                              // group 1 runs the same loop one slot later
+    if (late) slot_end();
+    unsigned so = 2 * WSTAGE;                                               // tile s lives in ring stage (s + 2) % 3
+#pragma unroll 1
+    for (int s = 0; s < nk; ++s) {
+      PW_START();
+      load_phase(so);      PW_MARK(0);   slot_end();   PW_MARK(1);
+      compute_phase();     PW_MARK(2);   slot_end();   PW_MARK(3);
+      so = so == 2 * WSTAGE ? 0u : so + WSTAGE;
+    }
+    if (!late) slot_end();
+#ifdef PW_G1_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef PW_PROF
+    pf_t2 = __builtin_readcyclecounter();
+#endif
+    if constexpr (SCORED) {
+      if (t.hd == 0) {
+        pw_scored_epilogue<SCORED == 2>(g, t.H, sc, acc, smem, t.m_tile, t.m0, t.n0);
+        return;
+      }
+    }
+    epilogue(std::false_type{}, acc, t);
+    if (t.vb_next >= total) break;
+    __syncthreads();
+    vb = t.vb_next;
+    }
+  }
+#undef PW_NAME5
 }
 
 // out = x * keep / (1 - p) with the PROJECTION kernels' dropout stream (one 32-bit mix per pair of columns, 16-bit thresholds: the
@@ -675,7 +830,12 @@ int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bag
       pb.seed[b][h] = bags[b].head[h].drop_seed;
     }
   }
-  dim3 grid((unsigned)(nN * pb.tiles_per_bag * n_bags));
+  // persistent workgroups (one per CU; the grid stays a multiple of 8: XCD mapping) unless the launch is scored (its epilogue pairs workgroups
+  // through a gate: every tile needs its partner resident) or MHIMX_PROJ_PERSIST=0 asks for one workgroup per tile
+  static const bool persist = [] { const char* e = getenv("MHIMX_PROJ_PERSIST"); return !(e && e[0] == '0'); }();
+  unsigned nblocks = (unsigned)(nN * pb.tiles_per_bag * n_bags);
+  if (persist && !g.score0 && nblocks > W_CUS) nblocks = W_CUS;
+  dim3 grid(nblocks);
   if (g.score0 && g.head[0].H) hipLaunchKernelGGL(bag_project_ws_kernel<2>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
   else if (g.score0) hipLaunchKernelGGL(bag_project_ws_kernel<1>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
   else hipLaunchKernelGGL(bag_project_ws_kernel<0>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
