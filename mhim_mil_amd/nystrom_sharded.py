@@ -38,18 +38,59 @@ HEADS, DH, INNER, M, KS, HALO = NY.HEADS, NY.DH, NY.INNER, NY.LANDMARKS, NY.CONV
 _PPEG_HALO = os.environ.get("MHIMX_PPEG_REPLICA", "0") != "1"          # (1: the round-3 form, the PPEG on an all-gathered replica)
 
 
-def _halo_rows(comm, block):
-    """block [Tr, C] (local rows, contiguous) -> [HALO + Tr + HALO, C]: the neighbours' boundary rows around it (zeros at the sequence ends)."""
-    Tr, Cc = block.shape
+def _edge_halos(comm, block, ld=None):
+    """The neighbours' boundary rows of a row-sharded [Tr, C] block (``block`` may be a strided view: ``ld`` floats between rows):
+    (prev [HALO, C] = the last rows of rank - 1, next [HALO, C] = the first rows of rank + 1), None at the sequence ends.  World 1: no traffic."""
+    if comm.world == 1:
+        return None, None
+    Tr = block.shape[0]
     edges = torch.stack([block[:HALO], block[Tr - HALO:]]).contiguous()              # [2, 16, C]: my first / last rows
     allg = comm.all_gather(edges)                                                      # [W, 2, 16, C]
-    ext = torch.zeros((Tr + 2 * HALO, Cc), device=block.device)
-    ext[HALO:HALO + Tr].copy_(block)
-    if comm.rank > 0:
-        ext[:HALO].copy_(allg[comm.rank - 1, 1])
-    if comm.rank < comm.world - 1:
-        ext[HALO + Tr:].copy_(allg[comm.rank + 1, 0])
-    return ext
+    prev = allg[comm.rank - 1, 1].contiguous() if comm.rank > 0 else None
+    nxt = allg[comm.rank + 1, 0].contiguous() if comm.rank < comm.world - 1 else None
+    return prev, nxt
+
+
+def _resconv_sharded(x, wc, out, accumulate, flip, prev, nxt):
+    """out (+)= res_conv(x) for this rank's rows of a row-sharded sequence (x, out: [Tr, 512], row-strided views welcome; mhimx_resconv pads
+    with zeros outside its rows): ONE launch on the block where it lies - no halo-extended copy of the block (round 4 built a [Tr + 32, C]
+    copy per call, ~75 us at c3 size) - plus, where a neighbour exists, what ITS 16 boundary rows add to my first / last 16 outputs: the same
+    stencil on a 48-row buffer [halo | zeros] (or [zeros | halo]) whose middle 16 outputs are exactly those terms."""
+    lib = L.lib()
+    Tr = x.shape[0]
+    assert x.stride(1) == 1 and out.stride(1) == 1
+    L.check(lib.mhimx_resconv(NY._st(), NY._ptr(x), x.stride(0), NY._ptr(wc), KS, DH, Tr, INNER, NY._ptr(out), out.stride(0), int(accumulate),
+                              int(flip)), "resconv")
+    for halo, first in ((prev, True), (nxt, False)):
+        if halo is None:
+            continue
+        small = torch.zeros((3 * HALO, INNER), device=halo.device)
+        (small[:HALO] if first else small[2 * HALO:]).copy_(halo)
+        part = torch.empty((3 * HALO, INNER), device=halo.device)
+        L.check(lib.mhimx_resconv(NY._st(), NY._ptr(small), INNER, NY._ptr(wc), KS, DH, 3 * HALO, INNER, NY._ptr(part), INNER, 0, int(flip)), "resconv")
+        (out[:HALO] if first else out[Tr - HALO:]).add_(part[HALO:2 * HALO])          # the outputs at the 16 rows next to the halo
+
+
+def _resconv_dw_sharded(dout, v, prev_v, next_v):
+    """d(conv weight) [8, 33] of this rank's OUTPUT rows (a local partial sum): the block's own (dout, v) pairs in one launch on the rows where
+    they lie, plus the pairs of my first / last 16 outputs with the neighbour's halo rows of v (48-row buffers, as _resconv_sharded)."""
+    lib = L.lib()
+    dev, Tr = dout.device, dout.shape[0]
+    dwc = torch.empty((HEADS, KS), device=dev)
+    ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(Tr, INNER, DH, KS), device=dev)
+    L.check(lib.mhimx_resconv_dw(NY._st(), NY._ptr(dout), dout.stride(0), NY._ptr(v), v.stride(0), KS, DH, Tr, INNER, NY._ptr(dwc), NY._ptr(ws)),
+            "resconv_dw")
+    for halo, first in ((prev_v, True), (next_v, False)):
+        if halo is None:
+            continue
+        vs, gs = torch.zeros((3 * HALO, INNER), device=dev), torch.zeros((3 * HALO, INNER), device=dev)
+        (vs[:HALO] if first else vs[2 * HALO:]).copy_(halo)
+        gs[HALO:2 * HALO].copy_(dout[:HALO] if first else dout[Tr - HALO:])
+        part = torch.empty((HEADS, KS), device=dev)
+        ws2 = torch.empty(lib.mhimx_resconv_dw_ws_floats(3 * HALO, INNER, DH, KS), device=dev)
+        L.check(lib.mhimx_resconv_dw(NY._st(), NY._ptr(gs), INNER, NY._ptr(vs), INNER, KS, DH, 3 * HALO, INNER, NY._ptr(part), NY._ptr(ws2)), "resconv_dw")
+        dwc += part
+    return dwc
 
 
 class ShardedTransLayerFn(torch.autograd.Function):
@@ -95,17 +136,14 @@ class ShardedTransLayerFn(torch.autograd.Function):
         NY._heads_mm("nn", NY.batched(z), NY.batched(a3v), NY.batched(w2), HEADS)
         out, lse1 = ops.nys_out_fwd(no, w2)
         wc = conv_w.reshape(HEADS, -1).contiguous()
-        v_ext = _halo_rows(comm, qkv[:, 2 * INNER:].contiguous())
-        conv = torch.empty((Tr + 2 * HALO, INNER), device=dev)
-        L.check(lib.mhimx_resconv(NY._st(), NY._ptr(v_ext), INNER, NY._ptr(wc), KS, DH, Tr + 2 * HALO, INNER, NY._ptr(conv), INNER, 0, 0), "resconv")
-        mid = conv[HALO:HALO + Tr]
-        L.check(lib.mhimx_axpby(NY._st(), NY._ptr(mid), NY._ptr(out), out.numel(), 1.0, 1.0), "axpby")      # out += res_conv(v) (nystrom:135-136)
+        v_prev, v_next = _edge_halos(comm, qkv[:, 2 * INNER:])                         # the neighbours' 16 boundary rows of v (kept for d conv weight)
+        _resconv_sharded(qkv[:, 2 * INNER:], wc, out, 1, 0, v_prev, v_next)              # out += res_conv(v) (nystrom:135-136)
         if big:                                                                         # y = x + dropout(to_out(.)): one launch
             y = ops.bag_project(out, [ops.ProjHead(ops.pair_planes(w_out), b_out, drop_p=float(drop_p), drop_seed=int(seed), resid=x)], act=0)[0].out
         else:
             y = ops.gemm_nt(out, w_out, bias=b_out, drop_p=float(drop_p), drop_seed=int(seed), prec=NY._PREC)
             L.check(lib.mhimx_axpby(NY._st(), NY._ptr(x), NY._ptr(y), y.numel(), 1.0, 1.0), "axpby")        # y += x
-        ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, v_ext)
+        ctx.saved = (x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, no.ws, v_prev, v_next)
         ctx.cfg = (l, gl, scale, comm, conv_w.shape, npad, float(drop_p), int(seed), big)
         if not need_attn:
             return y
@@ -129,7 +167,7 @@ class ShardedTransLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_):
         lib = L.lib()
-        x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, v_ext = ctx.saved
+        x, xn, mean, rstd, ln_w, w_qkv, w_out, out, qkv, lm, a2, z, z0, stats, chain, a3v, w2, wc, lse1, lse3, nws, v_prev, v_next = ctx.saved
         ctx.saved = None
         l, gl, scale, comm, wshape, npad, drop_p, seed, big = ctx.cfg
         dy = dy.contiguous()
@@ -153,16 +191,9 @@ class ShardedTransLayerFn(torch.autograd.Function):
             db_out = ops.colsum(g)
         dqkv = torch.empty_like(qkv)
         # residual convolution: dv = flip-conv(dout) with dout's halo rows; its weight gradient from the local outputs against v with halos
-        g_ext = _halo_rows(comm, dout)
-        dvx = torch.empty((Tr + 2 * HALO, INNER), device=dev)
-        L.check(lib.mhimx_resconv(NY._st(), NY._ptr(g_ext), INNER, NY._ptr(wc), KS, DH, Tr + 2 * HALO, INNER, NY._ptr(dvx), INNER, 0, 1), "resconv")
-        dqkv[:, 2 * INNER:].copy_(dvx[HALO:HALO + Tr])
-        g_own = torch.zeros_like(g_ext)
-        g_own[HALO:HALO + Tr].copy_(dout)                                                # (the halo rows belong to the neighbours' sums)
-        dwc = torch.empty_like(wc)
-        ws = torch.empty(lib.mhimx_resconv_dw_ws_floats(Tr + 2 * HALO, INNER, DH, KS), device=dev)
-        L.check(lib.mhimx_resconv_dw(NY._st(), NY._ptr(g_own), INNER, NY._ptr(v_ext), INNER, KS, DH, Tr + 2 * HALO, INNER, NY._ptr(dwc), NY._ptr(ws)),
-                "resconv_dw")
+        g_prev, g_next = _edge_halos(comm, dout)
+        _resconv_sharded(dout, wc, dqkv[:, 2 * INNER:], 0, 1, g_prev, g_next)            # dv, written where it lies in dqkv
+        dwc = _resconv_dw_sharded(dout, qkv[:, 2 * INNER:], v_prev, v_next)              # (my outputs against v with the neighbours' halo rows)
         # out = attn1 w2 : dq local, the token-side term of dk~ and dw2 are partial sums over this shard
         no = ops.NysOperands(qkv, lm, scale, ws=nws)
         dlm = torch.empty_like(lm)
@@ -218,6 +249,24 @@ class _GatherRows(torch.autograd.Function):
         comm, Tr = ctx.comm, ctx.Tr
         dfull = comm.all_reduce_sum(dfull.contiguous().clone())
         return dfull[comm.rank * Tr:(comm.rank + 1) * Tr].contiguous(), None
+
+
+class _PutRow(torch.autograd.Function):
+    """x[i] = row, IN PLACE (x: this rank's freshly assembled token block, whose slot i is the cls token's - baseline.py:253-255; round 4
+    rebuilt the block with torch.cat: one more pass over 100 MB).  Backward: d row = dy[i]; the slot's own gradient is zero."""
+
+    @staticmethod
+    def forward(ctx, x, row, i):
+        ctx.mark_dirty(x)
+        x[i].copy_(row.reshape(-1))
+        ctx.i, ctx.rshape = i, row.shape
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        drow = dy[ctx.i].clone().reshape(ctx.rshape)
+        dy[ctx.i].zero_()                                   # (dy is the layer's fresh dx: nobody else reads it)
+        return dy, drow, None
 
 
 class _OwnerRow(torch.autograd.Function):
@@ -278,28 +327,61 @@ class _BandPlan:
             cells = bq[3] + np.arange(bq[4], dtype=np.int64)
             need.append(np.where(cells < n_tok, skip + cells, np.where(cells < wrapN, skip + cells - n_tok, -1)))
         self.band = band(me)
+        mine = need[me]
+        owner = np.where(mine >= 0, mine // Tr, W)
+
+        def runs(pos, src):                                   # maximal runs where band position and source row advance together
+            if pos.size == 0:
+                return []
+            cut = np.flatnonzero((np.diff(pos) != 1) | (np.diff(src) != 1)) + 1
+            st = np.concatenate([[0], cut])
+            en = np.concatenate([cut, [pos.size]])
+            return [(int(pos[a]), int(src[a]), int(b - a)) for a, b in zip(st, en)]
+
+        # the cells this rank holds ITSELF (all of them at world 1; its own tokens and most of the halo otherwise) are block rows in the same
+        # order: slice copies instead of a gather into a send buffer and a scatter out of the receive buffer (round 4: 53 + 60 us per fetch at
+        # c3 size); cells without a token: zeroed as runs instead of a zero fill of the whole band
+        selfp = np.flatnonzero(owner == me)
+        self.self_runs = runs(selfp, mine[selfp] - me * Tr)
+        nonep = np.flatnonzero(owner == W)
+        self.zero_runs = [(a, n_) for a, _, n_ in runs(nonep, nonep)]
+        if len(self.self_runs) > 16 or len(self.zero_runs) > 16:                       # (a layout that fragments: the general path for everything)
+            self.self_runs, self.zero_runs = None, None
+        by_runs = self.self_runs is not None
         send_idx, self.send_counts = [], []
         for q in range(W):
             nl = need[q]
             own = (nl >= 0) & (nl // Tr == me)
+            if by_runs and q == me:
+                own = np.zeros_like(own)
             send_idx.append(nl[own] - me * Tr)
             self.send_counts.append(int(own.sum()))
         self.send_idx = torch.as_tensor(np.concatenate(send_idx), dtype=torch.int64).to(dev)
-        mine = need[me]
-        owner = np.where(mine >= 0, mine // Tr, W)
         order = np.argsort(owner, kind="stable")
-        order = order[owner[order] < W]
+        order = order[(owner[order] < W) & ((owner[order] != me) | (not by_runs))]
         self.place = torch.as_tensor(order, dtype=torch.int64).to(dev)
-        self.recv_counts = [int((owner == q).sum()) for q in range(W)]
+        self.recv_counts = [int((owner == q).sum()) if not (by_runs and q == me) else 0 for q in range(W)]
         self.last = last
         self.comm = comm
 
     def fetch(self, block):
         """This rank's band [ncell, C] of cells from the ranks' sequence blocks (zero where the grid has no token)."""
-        got = self.comm.all_to_all_rows(block.index_select(0, self.send_idx), self.send_counts, self.recv_counts)
-        out = torch.zeros((self.band[4] if self.band is not None else 0, block.shape[1]), device=block.device)
-        if got.shape[0]:
-            out.index_copy_(0, self.place, got)
+        ncell = self.band[4] if self.band is not None else 0
+        if self.self_runs is None:
+            got = self.comm.all_to_all_rows(block.index_select(0, self.send_idx), self.send_counts, self.recv_counts)
+            out = torch.zeros((ncell, block.shape[1]), device=block.device)
+            if got.shape[0]:
+                out.index_copy_(0, self.place, got)
+            return out
+        out = torch.empty((ncell, block.shape[1]), device=block.device)
+        for a, n_ in self.zero_runs:
+            out[a:a + n_].zero_()
+        for a, src, n_ in self.self_runs:
+            out[a:a + n_].copy_(block[src:src + n_])
+        if self.comm.world > 1:                                                        # (every rank calls it: the counts may be zero here only)
+            got = self.comm.all_to_all_rows(block.index_select(0, self.send_idx), self.send_counts, self.recv_counts)
+            if got.shape[0]:
+                out.index_copy_(0, self.place, got)
         return out
 
 
@@ -403,7 +485,10 @@ def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None, return_
     x = h_local
     if g0 <= pad < g0 + Tr:                                                  # the cls token's row lives here (baseline.py:253-255)
         i = pad - g0
-        x = torch.cat([h_local[:i], enc.cls_token.view(1, -1), h_local[i + 1:]], 0)
+        if (h_local.requires_grad and h_local.is_leaf) or not h_local.is_contiguous():
+            x = torch.cat([h_local[:i], enc.cls_token.view(1, -1), h_local[i + 1:]], 0)
+        else:
+            x = _PutRow.apply(h_local, enc.cls_token, i)
     p1 = enc.layer1.attn.dropout if training else 0.0
     p2 = enc.layer2.attn.dropout if training else 0.0
     attn, v = [], None

@@ -44,6 +44,12 @@ class ExchangePlan:
 
     def __init__(self, ids, bounds, pad, Tr, comm):
         W, r, dev = comm.world, comm.rank, ids.device
+        self.Tr, self.comm, self.run = Tr, comm, None
+        if W == 1:                                          # everything stays: token j -> block row pad + 1 + j, no device work, no read-back
+            n = ids.numel()
+            self.send_counts, self.recv_counts = [n], [n]
+            self.run, self.place, self.local = (pad + 1, pad + 1 + n), None, None
+            return
         b = torch.as_tensor(bounds[1:-1], dtype=torch.int64, device=dev)
         owner = torch.bucketize(ids, b, right=True)                      # shard of the row behind every token
         pos = pad + 1 + torch.arange(ids.numel(), device=dev)
@@ -55,7 +61,6 @@ class ExchangePlan:
         order = torch.sort(owner[mine], stable=True).indices             # ... grouped by source rank
         self.place = (pos[mine][order] - r * Tr).contiguous()
         self.local = torch.nonzero(owner == r).view(-1)                  # my rows' token indices, ascending (= the send order)
-        self.Tr, self.comm = Tr, comm
 
 
 class IdentityPlan:
@@ -86,8 +91,19 @@ class _AssembleTokens(torch.autograd.Function):
     def forward(ctx, rows_local, tail, plan: ExchangePlan, tail_pos):
         comm, Tr = plan.comm, plan.Tr
         E = rows_local.shape[1]
-        got = _all_to_all_rows(comm, rows_local.contiguous(), plan.send_counts, plan.recv_counts)
-        if plan.place is None:                               # bag order: one contiguous run
+        inplace = getattr(plan, "block", None)                # (world 1: the producer wrote its rows into the block already)
+        if inplace is not None:
+            a, b = plan.run
+            assert rows_local.data_ptr() == inplace[a:b].data_ptr() and rows_local.shape[0] == b - a
+            block = inplace
+            block[:a].zero_()
+            block[b:].zero_()
+            got = None
+        else:
+            got = _all_to_all_rows(comm, rows_local.contiguous(), plan.send_counts, plan.recv_counts)
+        if got is None:
+            pass
+        elif plan.place is None:                             # bag order (or world 1): one contiguous run
             a, b = plan.run
             block = torch.empty((Tr, E), device=rows_local.device)
             block[:a].zero_()
@@ -182,12 +198,19 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
             heads = [ops.ProjHead(ops.pair_planes(t.feature[0].weight.data), t.feature[0].bias.data, drop_p=p, drop_seed=mix(1)),
                      ops.ProjHead(ops.pair_planes(s.feature[0].weight.data), s.feature[0].bias.data, drop_p=s.dropout_p, drop_seed=mix(4),
                                   want_dact=True)]
+            pad_t, T_t, Tr_t = seq_layout(N, W)
+            tblock = None
+            if W == 1:                                      # the teacher's feature rows land in its token block (no copy into it)
+                tblock = torch.empty((Tr_t, E), device=dev)
+                heads[0].out = tblock[pad_t + 1:pad_t + 1 + N]
             ops.bag_project(x, heads, act=L.act_code(s.act, _FEATURE_ACTS))
             Ht, pre = heads[0].out, (heads[1].out, heads[1].dact)
         else:
+            tblock = None
             Ht = t._feature(x, None, p, mix(1))
         pad_t, T_t, Tr_t = seq_layout(N, W)
         plan_t = IdentityPlan(N, bounds, pad_t, Tr_t, cm)
+        plan_t.block = tblock
         blk = _AssembleTokens.apply(Ht, None, plan_t, 0)
         del Ht
         t_feat, attn, v = sharded_sattention(t.online_encoder, blk, pad_t, 1 + N, cm, return_attn=True, seeds=(mix(2), mix(3)),
@@ -203,7 +226,10 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
     # ---- select: replicated
     rows, len_keep, Lk, R = s.student_rows(N, i, score, perm=perm, ids_shuffle=ids_shuffle, generator=None, seed=shared_seed)
     from .sharded import partition_rows
-    rows_local, n_stay, merge_pos = partition_rows(rows, Lk, lo, n)
+    if W == 1:                                                                           # (no host sync: every row is local)
+        rows_local, n_stay, merge_pos = rows, Lk, torch.arange(rows.numel() - Lk, device=dev)
+    else:
+        rows_local, n_stay, merge_pos = partition_rows(rows, Lk, lo, n)
     n_loc = rows_local.numel()
     # a shard without kept rows is not supported - and EVERY rank must say so: the row list and the bounds are replicated, so every rank
     # counts every shard's kept rows alike and all of them raise together (a rank-local raise left the others hanging in the next collective)
@@ -217,7 +243,7 @@ def transmil_step(tr, x_local, label, perm=None, ids_shuffle=None, i=None):
     k = s.merge.k
     pad_s, T_s, Tr_s = seq_layout(Lk + k, W)
     plan_x = ExchangePlan(rows[:Lk], bounds, pad_s, Tr_s, cm)
-    assert plan_x.local.numel() == n_stay
+    assert plan_x.local is None or plan_x.local.numel() == n_stay
 
     # ---- student forward (autograd over kernel-backed nodes; parameter .grad = views of the flat gradient buffer)
     first = cm.rank == 0

@@ -214,3 +214,37 @@ def test_shape_cached_captures_the_transmil_and_dsmil_students(baseline):
     for a, b in zip(snaps[:-1], snaps[1:]):
         assert not torch.equal(a, b) and torch.isfinite(b).all()
     assert int(tr.opt_step.item()) == 6 and tr.flat.step == 6
+
+
+def test_persistent_projection_equals_one_workgroup_per_tile():
+    """Round 5: launches of more than 256 tiles run PERSISTENT workgroups that request the next tile's first stages from inside the epilogue
+    (csrc/bag_project_ws.hip).  (a) one bag of 24 000 rows (150 row tiles x 4 column tiles = 600 tiles, residual rows, bias, two heads)
+    against the same rows projected in chunks of <= 252 tiles - one tile per workgroup there: bit-identical (a tile's arithmetic does not
+    depend on who runs it); (b) three bags of 10 000 rows in ONE launch (768 virtual tiles, dropout, d out / d pre) against per-bag launches
+    of 252 tiles: bit-identical masks and rows."""
+    from mhim_mil_amd import ops
+    DEV = "cuda"
+    g = torch.Generator(device=DEV).manual_seed(5)
+    n, d, E = 24000, 512, 512
+    x = torch.randn(n, d, device=DEV, generator=g)
+    wa, wb = (torch.randn(E, d, device=DEV, generator=g) * 0.05 for _ in range(2))
+    ba, bb = (torch.randn(E, device=DEV, generator=g) * 0.1 for _ in range(2))
+    wap, wbp = ops.pair_planes(wa), ops.pair_planes(wb)
+    res = torch.randn(n, E, device=DEV, generator=g)
+    full = ops.bag_project(x, [ops.ProjHead(wap, ba, resid=res), ops.ProjHead(wbp, bb)], act=0)
+    chunk = 4800                                               # 30 row tiles x 4 = 120 tiles per launch
+    for lo in range(0, n, chunk):
+        part = ops.bag_project(x[lo:lo + chunk], [ops.ProjHead(wap, ba, resid=res[lo:lo + chunk]), ops.ProjHead(wbp, bb)], act=0)
+        assert torch.equal(part[0].out, full[0].out[lo:lo + chunk]) and torch.equal(part[1].out, full[1].out[lo:lo + chunk]), lo
+    ref = x.double() @ wa.double().t() + ba.double() + res.double()
+    assert float((full[0].out.double() - ref).abs().max() / ref.abs().max()) < 1e-5           # (three-term bf16 products, K = 512)
+    nb, nr, dd = 3, 10000, 256
+    xs = [torch.randn(nr, dd, device=DEV, generator=g).abs_() for _ in range(nb)]
+    wt, ws_ = (torch.randn(E, dd, device=DEV, generator=g) * 0.05 for _ in range(2))
+    wtp, wsp = ops.pair_planes(wt), ops.pair_planes(ws_)
+    tick = torch.tensor([9], dtype=torch.int64, device=DEV)
+    mk = lambda b: [ops.ProjHead(wtp, ba, drop_p=0.25, drop_seed=50 + 2 * b), ops.ProjHead(wsp, bb, drop_p=0.25, drop_seed=51 + 2 * b, want_dact=True)]
+    one = [ops.bag_project(xb, mk(b), act=1, drop_tick=tick) for b, xb in enumerate(xs)]
+    many = ops.bag_project_multi(xs, [mk(b) for b in range(nb)], act=1, drop_tick=tick)
+    for a, m in zip(one, many):
+        assert torch.equal(a[0].out, m[0].out) and torch.equal(a[1].out, m[1].out) and torch.equal(a[1].dact, m[1].dact)

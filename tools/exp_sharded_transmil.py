@@ -39,7 +39,10 @@ def timed(fn, name, steps=6):
     print(f"{name:60s} {dt * 1e3:8.3f} ms/step", flush=True)
 
 
-tr = FusedTrainer(mk(), mk(), aux_alpha=0.5)
-timed(lambda i: tr.train_step(bags[i % 2], label), "FusedTrainer.train_step (TransMIL), eager")
+if not os.environ.get("SHARDED_ONLY"):
+    tr = FusedTrainer(mk(), mk(), aux_alpha=0.5)
+    timed(lambda i: tr.train_step(bags[i % 2], label), "FusedTrainer.train_step (TransMIL), eager")
+    g = [tr.capture(b, label, warmup=2) for b in bags]
+    timed(lambda i: g[i % 2].replay(), "FusedTrainer (TransMIL), hipGraph replay")
 st = ShardedBagTrainer(mk(), mk(), aux_alpha=0.5)
 timed(lambda i: st.train_step(bags[i % 2], label), "ShardedBagTrainer.train_step (TransMIL), world 1, eager")
