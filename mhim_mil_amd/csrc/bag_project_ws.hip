@@ -579,52 +579,11 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   };
 
   if (producer) {
-    p_setup(vb);
-    bool first = true;
-#pragma unroll 1
-    for (;;) {
-    const TileCtx t = tile_ctx(vb);
-#ifdef PW_PROF
-    pf_t0 = __builtin_readcyclecounter();
-    for (int i = 0; i < 8; ++i) pf[i] = 0;
-#endif
     // ================================================================= producers
-    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
+    // (the launch's first tile is peeled off the loop: its prologue requests everything itself, a later tile's finds its first stages in LDS -
+    // as two branches of one loop body the listing was no straight line any more and tools/asm_lint.py could not follow the registers in flight)
     ARegs ra, rb;                                                           // ra: odd tiles, rb: even tiles
-    const float* const pxu = uni(px);
-    const float* const x2 = pxu + (nk > 2 ? 2 : nk - 1) * WBK;
-    if (first) {
-      // the launch's first tile: B(0), B(1) requested, A(0) -> stage 2 (the compiler's wait in front of the conversion drains the DMA pieces
-      // too), A(1), A(2) requested into the two register sets; A(1) waited for
-      issue_b(bbase, 2 * WSTAGE, 0);
-      issue_b(bbase, 2 * WSTAGE, 4);
-      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
-      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 4);
-      {
-        const char* xb = reinterpret_cast<const char*>(px);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) split_store(*reinterpret_cast<const f32x4*>(xb + aoff[j]), a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
-      }
-      const float* x1 = pxu + (nk > 1 ? 1 : 0) * WBK;
-      load_a3(x1, ra); load_a2(x1, ra);
-      load_a3(x2, rb); load_a2(x2, rb);
-      asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");        // A(1) is here
-    } else {
-      // a later tile: B(0) and the raw rows of A(0), A(1) landed during the previous epilogue (its closing wait and barrier).  A(1) -> ra,
-      // A(0) converted in place, A(2) requested, B(1) -> stage 0 (which held the staging rows until that barrier)
-      ARegs r0;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        r0.v[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + 2 * WSTAGE + (unsigned)(pt + 256 * j) * 16));
-        ra.v[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + RAW1_OFF + (unsigned)(pt + 256 * j) * 16));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" : PW_NAME5(r0), PW_NAME5(ra) : : "memory");
-      load_a3(x2, rb); load_a2(x2, rb);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) split_store(r0.v[j], a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
-      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
-      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 4);
-    }
+    auto tile_body = [&](const TileCtx& t, const float* pxu) -> bool {      // the k loop and the epilogue; true: another tile follows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // A(0) is in LDS
     slot_end();                                                             // ---- tile 0 complete
     // running state of k-step s: st1 = byte offset of the stage of tile s+1 (A(s+1) is stored there), st2 = of tile s+2 (B(s+2) lands there)
@@ -697,15 +656,67 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
         for (int j = 0; j < NRB; ++j) acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (t.hd == 0) {                                      // model 0: scorer + pool partials instead of the feature rows
         pw_scored_epilogue<SCORED == 2>(g, t.H, sc, acc0, smem, t.m_tile, t.m0, t.n0);   // (scored launches are not persistent: one tile per workgroup)
-        return;
+        return false;
       }
     }
     epilogue(std::true_type{}, acc0, t);
-    if (t.vb_next >= total) break;
+    if (t.vb_next >= total) return false;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next tile's first stages have landed (and this tile's stores are out)
     __syncthreads();                                          // the staging rows are read: B(1) of the next tile may land in stage 0
-    vb = t.vb_next;
-    first = false;
+    return true;
+    };
+    p_setup(vb);
+    TileCtx t = tile_ctx(vb);
+#ifdef PW_PROF
+    pf_t0 = __builtin_readcyclecounter();
+#endif
+    if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
+    const float* pxu = uni(px);
+    {
+      // the launch's first tile: B(0), B(1) requested, A(0) -> stage 2 (the compiler's wait in front of the conversion drains the DMA pieces
+      // too), A(1), A(2) requested into the two register sets; A(1) waited for
+      issue_b(bbase, 2 * WSTAGE, 0);
+      issue_b(bbase, 2 * WSTAGE, 4);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 4);
+      {
+        const char* xb = reinterpret_cast<const char*>(px);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) split_store(*reinterpret_cast<const f32x4*>(xb + aoff[j]), a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
+      }
+      const float* x1 = pxu + (nk > 1 ? 1 : 0) * WBK;
+      const float* x2 = pxu + (nk > 2 ? 2 : nk - 1) * WBK;
+      load_a3(x1, ra); load_a2(x1, ra);
+      load_a3(x2, rb); load_a2(x2, rb);
+      asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");        // A(1) is here
+    }
+    bool more = tile_body(t, pxu);
+#pragma unroll 1
+    while (more) {
+      vb = t.vb_next;
+      t = tile_ctx(vb);
+#ifdef PW_PROF
+      pf_t0 = __builtin_readcyclecounter();
+      for (int i = 0; i < 8; ++i) pf[i] = 0;
+#endif
+      if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
+      pxu = uni(px);
+      // a later tile: B(0) and the raw rows of A(0), A(1) landed during the previous epilogue (its closing wait and barrier).  A(1) -> ra,
+      // A(0) converted in place, A(2) requested, B(1) -> stage 0 (which held the staging rows until that barrier)
+      ARegs r0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        r0.v[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + 2 * WSTAGE + (unsigned)(pt + 256 * j) * 16));
+        ra.v[j] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(lds0 + RAW1_OFF + (unsigned)(pt + 256 * j) * 16));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : PW_NAME5(r0), PW_NAME5(ra) : : "memory");
+      const float* x2 = pxu + (nk > 2 ? 2 : nk - 1) * WBK;
+      load_a3(x2, rb); load_a2(x2, rb);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) split_store(r0.v[j], a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
+      issue_b(bbase + (nk > 1 ? 128 : 0), 0, 4);
+      more = tile_body(t, pxu);
     }
   } else {
 #pragma unroll 1

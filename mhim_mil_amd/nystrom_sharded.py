@@ -128,10 +128,13 @@ class ShardedTransLayerFn(torch.autograd.Function):
         a2, z, z0, stats, chain = NY._landmark_pinv_forward(lm, scale)                  # replicated
         no = ops.NysOperands(qkv, lm, scale)
         a3v_r, lse_r = ops.nys_a3v_fwd(no)
-        A, Ls = comm.all_gather(a3v_r), comm.all_gather(lse_r)                          # [W,8,256,64], [W,8,256]
-        mx = Ls.max(0).values
-        lse3 = (mx + torch.log2(torch.exp2(Ls - mx).sum(0))).contiguous()               # fixed rank order: every rank gets the same bits
-        a3v = (torch.exp2(Ls - lse3).unsqueeze(-1) * A).sum(0).contiguous()
+        if W == 1:                                                                      # (the merge below with one term: the same bits)
+            a3v, lse3 = a3v_r, lse_r
+        else:
+            A, Ls = comm.all_gather(a3v_r), comm.all_gather(lse_r)                      # [W,8,256,64], [W,8,256]
+            mx = Ls.max(0).values
+            lse3 = (mx + torch.log2(torch.exp2(Ls - mx).sum(0))).contiguous()           # fixed rank order: every rank gets the same bits
+            a3v = (torch.exp2(Ls - lse3).unsqueeze(-1) * A).sum(0).contiguous()
         w2 = torch.empty((HEADS, M, DH), device=dev)
         NY._heads_mm("nn", NY.batched(z), NY.batched(a3v), NY.batched(w2), HEADS)
         out, lse1 = ops.nys_out_fwd(no, w2)

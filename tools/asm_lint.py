@@ -4,7 +4,8 @@ Vector loads return in order, so `s_waitcnt vmcnt(N)` leaves the N youngest vect
 this invariant for its own loads; for loads issued by inline asm it cannot (it believes an asm's outputs are ready when the statement
 ends): if such a register is not named by the asm wait that covers it, the compiler may copy it early or hand it out again while the load
 has not landed.  That is how bag_wgrad_ws_kernel faulted when a second process stretched the latency.  The scan is
-linear per kernel (branches are not followed): it is exact for the straight-line pipelines it is meant for.
+linear per kernel (branches are not followed; the queue is dropped after an unconditional branch): it is exact for the straight-line
+pipelines it is meant for.
 
 Only loads inside `;;#ASMSTART` / `;;#ASMEND` blocks are tracked by default (hipcc -S output: the compiler's own loads obey the rule by
 construction, and branches make a linear scan of them noisy); --all tracks every vector load (also works on llvm-objdump -d output).
@@ -47,9 +48,9 @@ def lint(path, track_all=False):
             continue
         op = body.split()[0]
         rest = body[len(op):]
-        if op == 's_endpgm':
-            q = []
-            continue
+        if op in ('s_endpgm', 's_branch'):                  # nothing falls through an unconditional branch: what follows in the listing is
+            q = []                                          # reached from elsewhere (an if / else pair: the persistent projection's two
+            continue                                        # prologues end in different queue states) - tracking restarts there
         if op.startswith('s_waitcnt'):
             m = re.search(r'vmcnt\((\d+)\)', body)
             if m:
