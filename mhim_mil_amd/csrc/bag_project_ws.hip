@@ -55,6 +55,7 @@ MHIMX_DEV uint32_t pw_pair_hash(uint32_t row_key, uint32_t pair) { return mix32(
 constexpr int W_MAX_BAGS = 8;
 struct ProjBags {
   int n_bags, tiles_per_bag;
+  int stagger;                      // shader cycles the workgroups with the SHORTER tile list wait before their first tile (0: none)
   const float* X[W_MAX_BAGS];
   float* H[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
   void* dact[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
@@ -305,6 +306,25 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     if (m_ >= nM) vb = next_tile(vb);
   }
   if (vb >= total) return;
+  // The workgroups of a launch all take the same time per tile, so their epilogues - each a burst at the chip's store ceiling - stay in
+  // lock-step through every cohort (profiles/r05_store_path.md).  When the tiles do not divide evenly, the workgroups with one tile fewer
+  // have a tile's time to spare: they start half a tile late, and the launch's stores leave as two smaller bursts in antiphase - for free.
+  // Measured same-box: c3 (7-8 cohorts per product) 8.34 -> 8.22-8.26 ms for offsets of 20-45 k cycles; c5 (one product of 19.5 cohorts)
+  // 3.85 -> 3.88-4.00 ms: over many cohorts the workgroups drift apart by themselves and the offset only costs - so up to 10 cohorts.
+  if (pb.stagger > 0 && total > 2 * G && total <= 10 * G) {
+    int mine = 0, longest = 0;
+    for (int v = vb; v < total; v = next_tile(v)) ++mine;
+    {
+      int v0 = 0, b_, m_, n_;
+      decode(v0, b_, m_, n_);
+      if (m_ >= nM) v0 = next_tile(v0);
+      for (; v0 < total; v0 = next_tile(v0)) ++longest;                      // (workgroup 0 holds a longest list)
+    }
+    if (mine < longest) {
+      const uint64_t t0 = __builtin_readcyclecounter();
+      while ((int64_t)(__builtin_readcyclecounter() - t0) < (int64_t)pb.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+  }
 
   auto slot_end = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -451,8 +471,14 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
   // ================================================================= epilogue: all twelve waves, two 80-row halves through LDS
   // (a lambda instantiated once per ROLE: the tile loops below are separate per role, so that the producers' loop-carried registers - row
   // offsets, the three A register sets - and the consumers' accumulators are never live together: in one loop they spilled 576 bytes)
+  const int lane_ = lane, tid_ = tid;
   auto epilogue = [&](auto is_prod, f32x4 (&acc)[NRA][NRB], const TileCtx& t) {
   constexpr bool producer = decltype(is_prod)::value;
+  // (laundered lane / thread ids: everything the epilogue derives from them - column offsets, 64-bit row addresses, bias - is the same for
+  // every tile, so the compiler hoisted it out of the tile loop, kept it live across the k loop beside 152 accumulator and fragment
+  // registers and spilled it around the loop: 60 bytes of scratch per lane, +7 MB of traffic each way per c2 launch under the counters)
+  int lane = lane_, tid = tid_;
+  asm volatile("" : "+v"(lane), "+v"(tid));
   const int64_t m0 = t.m0, n0 = t.n0;
   const mhimx_proj_head& H = t.H;
   const int vb_next = t.vb_next;
@@ -691,6 +717,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");        // A(1) is here
     }
     bool more = tile_body(t, pxu);
+    if constexpr (SCORED) more = false;                       // (scored launches: one tile per workgroup, the loop is not instantiated)
 #pragma unroll 1
     while (more) {
       vb = t.vb_next;
@@ -784,6 +811,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       }
     }
     epilogue(std::false_type{}, acc, t);
+    if constexpr (SCORED) break;
     if (t.vb_next >= total) break;
     __syncthreads();
     vb = t.vb_next;
@@ -833,6 +861,12 @@ int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bag
   ProjBags pb = {};
   pb.n_bags = n_bags;
   pb.tiles_per_bag = (int)(8 * cdiv(nM, 8));
+  {
+    // half of a steady-state tile's life in shader cycles: k-step ~2.5 k, prologue + epilogue ~22 k (profiles/r05_store_path.md);
+    // MHIMX_PROJ_STAGGER=0 switches the offset off, another value replaces the estimate
+    static const int stagger_env = [] { const char* e = getenv("MHIMX_PROJ_STAGGER"); return e ? atoi(e) : -1; }();
+    pb.stagger = stagger_env >= 0 ? stagger_env : (int)((g.D / WBK) * 1250 + 11000);
+  }
   for (int b = 0; b < n_bags; ++b) {
     pb.X[b] = bags[b].X;
     for (int h = 0; h < g.n_heads; ++h) {
