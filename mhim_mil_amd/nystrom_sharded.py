@@ -36,6 +36,7 @@ from .sharded import _Comm
 
 HEADS, DH, INNER, M, KS, HALO = NY.HEADS, NY.DH, NY.INNER, NY.LANDMARKS, NY.CONV_K, NY.CONV_K // 2
 _PPEG_HALO = os.environ.get("MHIMX_PPEG_REPLICA", "0") != "1"          # (1: the round-3 form, the PPEG on an all-gathered replica)
+_PPEG_BAND_W1 = os.environ.get("MHIMX_PPEG_BAND_W1", "0") == "1"        # (1: the band kernels at world 1 too - tests of the band path on one rank)
 
 
 def _edge_halos(comm, block, ld=None):
@@ -500,7 +501,9 @@ def sharded_sattention(enc: "NY.SAttention", h_local, pad, n, comm=None, return_
         attn.append(a)
     else:
         x = sharded_trans_layer(enc.layer1, x, comm, pad, p1, seeds[0])
-    if n - 1 >= 49 and _PPEG_HALO:                                           # baseline.py:265-266: cat([cls, ppeg(tokens)])
+    if comm.world == 1 and not _PPEG_BAND_W1:                                # one rank: the band is the whole grid - the replica path's PPEG
+        x = enc.pos_embedding(x, skip=pad + 1)                               # on the block itself (rows [0, pad] pass through), no band copy
+    elif n - 1 >= 49 and _PPEG_HALO:                                         # baseline.py:265-266: cat([cls, ppeg(tokens)])
         x = sharded_ppeg(enc.pos_embedding, x, comm, pad, n)                 # its own grid rows + halos: one all-to-all (ShardedPPEGFn)
     else:                                                                    # (grids below 7 x 7: the zero-padded rule, on a replica)
         full = _GatherRows.apply(x, comm)
