@@ -265,8 +265,15 @@ MHIMX_DEV void pw_scored_epilogue(const mhimx_bag_project_args& g, const mhimx_p
   if (tid < 256) sc.pz[(int64_t)m_tile * E + n0 + tid] = zred[tid] + zred[256 + tid];
 }
 
-template <int SCORED>           // 0: feature rows only; 1: model 0 scored in the epilogue, its rows not written; 2: scored AND written (tests)
+// MODE 0: feature rows only; 1: model 0 scored in the epilogue, its rows not written; 2: scored AND written (tests); 3: PLAIN products (no
+// activation / dropout / residual rows / d out-d pre on any head: to_qkv, the backward's dX products) - the consumer waves store their
+// accumulators straight from registers (64-byte segments: 68-71 B/ns for one CU against 139 for 16-byte stores, both far above a CU's share
+// of the chip's 5.4-7.3 TB/s, tools/micro/store_rate.hip) while the producers are already on the next tile's prologue: no staging rows, no
+// epilogue barriers, every tile takes the direct prologue.
+template <int MODE>
 __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_project_args g, ProjBags pb, ProjScore sc) {
+  constexpr bool PLAIN = MODE == 3;
+  constexpr int SCORED = PLAIN ? 0 : MODE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -670,6 +677,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     if (s < nk) kstep(s, ra, rb);
     slot_end();                                                             // slot 2 nk: group 1's last compute phase
     asm volatile("s_waitcnt vmcnt(0)" : PW_NAME5(ra), PW_NAME5(rb) : : "memory");
+    if constexpr (PLAIN) return t.vb_next < total;                          // (the consumers store their registers themselves)
     if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(0);                        // the epilogue shares its rows evenly among all twelve waves
 #ifdef PW_PROF
     pf_t2 = __builtin_readcyclecounter();
@@ -698,9 +706,9 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #endif
     if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
     const float* pxu = uni(px);
-    {
-      // the launch's first tile: B(0), B(1) requested, A(0) -> stage 2 (the compiler's wait in front of the conversion drains the DMA pieces
-      // too), A(1), A(2) requested into the two register sets; A(1) waited for
+    auto prologue_direct = [&](const float* pxu_) {
+      // B(0), B(1) requested, A(0) -> stage 2 (the compiler's wait in front of the conversion drains the DMA pieces too), A(1), A(2)
+      // requested into the two register sets; A(1) waited for.  (The launch's first tile; every tile of a PLAIN launch.)
       issue_b(bbase, 2 * WSTAGE, 0);
       issue_b(bbase, 2 * WSTAGE, 4);
       issue_b(bbase + (nk > 1 ? 128 : 0), 0, 0);
@@ -710,12 +718,13 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #pragma unroll
         for (int j = 0; j < 5; ++j) split_store(*reinterpret_cast<const f32x4*>(xb + aoff[j]), a_hi[j] + 2 * WSTAGE, a_lo[j] + 2 * WSTAGE);
       }
-      const float* x1 = pxu + (nk > 1 ? 1 : 0) * WBK;
-      const float* x2 = pxu + (nk > 2 ? 2 : nk - 1) * WBK;
+      const float* x1 = pxu_ + (nk > 1 ? 1 : 0) * WBK;
+      const float* x2 = pxu_ + (nk > 2 ? 2 : nk - 1) * WBK;
       load_a3(x1, ra); load_a2(x1, ra);
       load_a3(x2, rb); load_a2(x2, rb);
       asm volatile("s_waitcnt vmcnt(5)" : PW_NAME5(ra) : : "memory");        // A(1) is here
-    }
+    };
+    prologue_direct(pxu);
     bool more = tile_body(t, pxu);
     if constexpr (SCORED) more = false;                       // (scored launches: one tile per workgroup, the loop is not instantiated)
 #pragma unroll 1
@@ -727,6 +736,13 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       for (int i = 0; i < 8; ++i) pf[i] = 0;
 #endif
       if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
+      if constexpr (PLAIN) {                                  // nothing was requested ahead: the consumers' stores cover this prologue
+        p_setup(vb);
+        pxu = uni(px);
+        prologue_direct(pxu);
+        more = tile_body(t, pxu);
+        continue;
+      }
       pxu = uni(px);
       // a later tile: B(0) and the raw rows of A(0), A(1) landed during the previous epilogue (its closing wait and barrier).  A(1) -> ra,
       // A(0) converted in place, A(2) requested, B(1) -> stage 0 (which held the staging rows until that barrier)
@@ -810,6 +826,30 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
         return;
       }
     }
+    if constexpr (PLAIN) {
+      // registers -> global: lane (cl, rq) holds rows rq * 4 + e of the 16-row blocks i and column cl of the 16-column blocks j; one store
+      // instruction = 4 rows x 64 B.  No barrier: the producers' next prologue is running, the ring is theirs.
+      const int cl = lane & 15, rq = lane >> 4;
+      const int64_t ncol = t.n0 + wn * 64 + cl;
+      float bias4[NRB];
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) bias4[j] = t.H.bias ? t.H.bias[ncol + j * 16] : 0.f;
+      float* orow = t.H.H + (t.m0 + wm * 80 + rq * 4) * t.H.ldh + ncol;
+      const int64_t mrow = t.m0 + wm * 80 + rq * 4;
+#pragma unroll
+      for (int i = 0; i < NRA; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (mrow + i * 16 + e < g.N) {
+            float* o = orow + (int64_t)(i * 16 + e) * t.H.ldh;
+#pragma unroll
+            for (int j = 0; j < NRB; ++j) o[j * 16] = acc[i][j][e] + bias4[j];
+          }
+        }
+      if (t.vb_next >= total) break;
+      vb = t.vb_next;
+      continue;
+    }
     epilogue(std::false_type{}, acc, t);
     if constexpr (SCORED) break;
     if (t.vb_next >= total) break;
@@ -846,7 +886,8 @@ __global__ __launch_bounds__(256) void proj_dropout_apply_kernel(const float* __
 int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bags) {
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE));
                         MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE));
-                        MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
+                        MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE));
+                        MHIMX_HIP(hipFuncSetAttribute((const void*)bag_project_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WNST * WSTAGE)));
   const mhimx_bag_project_args& g = bags[0];
   ProjScore sc = {};
   if (g.score0) {
@@ -881,7 +922,15 @@ int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bag
   unsigned nblocks = (unsigned)(nN * pb.tiles_per_bag * n_bags);
   if (persist && !g.score0 && nblocks > W_CUS) nblocks = W_CUS;
   dim3 grid(nblocks);
-  if (g.score0 && g.head[0].H) hipLaunchKernelGGL(bag_project_ws_kernel<2>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
+  bool plain = !g.score0 && g.act == MHIMX_ACT_NONE;
+  for (int b = 0; b < n_bags && plain; ++b)
+    for (int h = 0; h < g.n_heads; ++h) {
+      const mhimx_proj_head& q = bags[b].head[h];
+      if (q.drop_p > 0.f || q.drop_mask || q.resid || q.dact) plain = false;
+    }
+  static const bool plain_ok = [] { const char* e = getenv("MHIMX_PROJ_PLAIN"); return !(e && e[0] == '0'); }();
+  if (plain && plain_ok) hipLaunchKernelGGL(bag_project_ws_kernel<3>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
+  else if (g.score0 && g.head[0].H) hipLaunchKernelGGL(bag_project_ws_kernel<2>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
   else if (g.score0) hipLaunchKernelGGL(bag_project_ws_kernel<1>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
   else hipLaunchKernelGGL(bag_project_ws_kernel<0>, grid, dim3(WTHREADS), WNST * WSTAGE, st, g, pb, sc);
   MHIMX_LAUNCH_CHECK();

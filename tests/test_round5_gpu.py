@@ -236,6 +236,16 @@ def test_persistent_projection_equals_one_workgroup_per_tile():
     for lo in range(0, n, chunk):
         part = ops.bag_project(x[lo:lo + chunk], [ops.ProjHead(wap, ba, resid=res[lo:lo + chunk]), ops.ProjHead(wbp, bb)], act=0)
         assert torch.equal(part[0].out, full[0].out[lo:lo + chunk]) and torch.equal(part[1].out, full[1].out[lo:lo + chunk]), lo
+    # PLAIN launches (no activation / dropout / residual rows / d out-d pre): the consumer waves store their accumulators from registers, every
+    # tile takes the direct prologue - against the staged epilogue of the same products (the residual head above minus its residual rows)
+    plain = ops.bag_project(x[:n - 37], [ops.ProjHead(wap, ba), ops.ProjHead(wbp, None)], act=0)      # (a ragged last tile: 23 963 rows)
+    assert torch.equal(plain[0].out, full[0].out[:n - 37] - res[:n - 37]) or \
+        float((plain[0].out - (full[0].out[:n - 37] - res[:n - 37])).abs().max()) < 2e-6        # (x + r - r: one rounding of the residual add)
+    refb = x[:n - 37].double() @ wb.double().t()
+    assert float((plain[1].out.double() - refb).abs().max() / refb.abs().max()) < 1e-5
+    assert torch.equal(plain[1].out + bb, full[1].out[:n - 37]) or float((plain[1].out + bb - full[1].out[:n - 37]).abs().max()) < 1e-6
+    small = ops.bag_project(x[:1000], [ops.ProjHead(wap, ba)], act=0)                                   # one tile per workgroup, ragged
+    assert torch.equal(small[0].out, plain[0].out[:1000])
     ref = x.double() @ wa.double().t() + ba.double() + res.double()
     assert float((full[0].out.double() - ref).abs().max() / ref.abs().max()) < 1e-5           # (three-term bf16 products, K = 512)
     nb, nr, dd = 3, 10000, 256

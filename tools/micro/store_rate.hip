@@ -20,7 +20,16 @@ __global__ __launch_bounds__(768) void store_kernel(float* out, int rows, int pi
       if (MODE == 0) *reinterpret_cast<f4*>(p) = v;
       else if (MODE == 1) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
       else if (MODE == 2) { float* q = base + (size_t)r * pitch_f + lane * 2; *reinterpret_cast<f2*>(q) = f2{v[0], v[1]}; *reinterpret_cast<f2*>(q + 128) = f2{v[2], v[3]}; }
-      else { float* q = base + (size_t)r * pitch_f + lane; q[0] = v[0]; q[64] = v[1]; q[128] = v[2]; q[192] = v[3]; }
+      else if (MODE == 3) { float* q = base + (size_t)r * pitch_f + lane; q[0] = v[0]; q[64] = v[1]; q[128] = v[2]; q[192] = v[3]; }
+      else {
+        // the MFMA accumulator layout stored straight from registers: one instruction = 4 rows x 16 consecutive floats (64 B segments); 16
+        // instructions cover a wave's 4 rows x 256 columns (here: rows 4 r .. 4 r + 3 of the workgroup's tile, r = the wave's row group)
+        if (4 * r + 3 < rows) {
+          float* q = base + (size_t)(4 * r + (lane >> 4)) * pitch_f + (lane & 15);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) q[16 * j] = v[j & 3];
+        }
+      }
       v[0] += 1.f;
     }
   }
@@ -46,12 +55,13 @@ int main() {
   float* out;
   const int pitch_f = 512;                                        // 2 KiB row pitch (E = 512 fp32), a workgroup writes the left KiB of its rows
   hipMalloc(&out, (size_t)256 * 4096 * pitch_f * 4 + 4096);
-  for (int blocks : {256, 32, 1})
-    for (int waves : {12, 8, 4, 1}) {
+  for (int blocks : {256, 1})
+    for (int waves : {12, 8}) {
       run<0>("dwordx4", out, blocks, 160, pitch_f, waves, 64);
       run<1>("dwordx4 nontemporal", out, blocks, 160, pitch_f, waves, 64);
       run<2>("dwordx2 x 2", out, blocks, 160, pitch_f, waves, 64);
       run<3>("dword x 4", out, blocks, 160, pitch_f, waves, 64);
+      run<4>("dword, 4 rows x 64 B per instr", out, blocks, 160, pitch_f, waves, 64);
     }
   // a longer stream (rows per workgroup x4: no re-writing of the same lines)
   run<0>("dwordx4, 2560 rows once", out, 256, 2560, pitch_f, 12, 1);
