@@ -56,6 +56,7 @@ constexpr int W_MAX_BAGS = 8;
 struct ProjBags {
   int n_bags, tiles_per_bag;
   int stagger;                      // shader cycles the workgroups with the SHORTER tile list wait before their first tile (0: none)
+  int stagger_spread;               // 1: each of them waits its own fraction of 2 x stagger (a whole tile's time) instead
   const float* X[W_MAX_BAGS];
   float* H[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
   void* dact[W_MAX_BAGS][MHIMX_PROJ_MAX_HEADS];
@@ -328,8 +329,10 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       for (; v0 < total; v0 = next_tile(v0)) ++longest;                      // (workgroup 0 holds a longest list)
     }
     if (mine < longest) {
+      // spread over the whole spare tile time (a 97-stride permutation of the block index: neighbours - one XCD's CUs - far apart)
+      const int64_t wait = pb.stagger_spread ? ((int64_t)pb.stagger * 2 * (int)((blockIdx.x * 97u) & 255u)) >> 8 : (int64_t)pb.stagger;
       const uint64_t t0 = __builtin_readcyclecounter();
-      while ((int64_t)(__builtin_readcyclecounter() - t0) < (int64_t)pb.stagger) __builtin_amdgcn_s_sleep(16);
+      while ((int64_t)(__builtin_readcyclecounter() - t0) < wait) __builtin_amdgcn_s_sleep(16);
     }
   }
 
@@ -907,6 +910,8 @@ int bag_project_ws(hipStream_t st, const mhimx_bag_project_args* bags, int n_bag
     // MHIMX_PROJ_STAGGER=0 switches the offset off, another value replaces the estimate
     static const int stagger_env = [] { const char* e = getenv("MHIMX_PROJ_STAGGER"); return e ? atoi(e) : -1; }();
     pb.stagger = stagger_env >= 0 ? stagger_env : (int)((g.D / WBK) * 1250 + 11000);
+    static const int spread_env = [] { const char* e = getenv("MHIMX_PROJ_SPREAD"); return e ? atoi(e) : 1; }();
+    pb.stagger_spread = spread_env;         // (c3 same-box: 8.523 -> 8.479 ms against the one half-tile offset, which itself measured 0 to -1 %)
   }
   for (int b = 0; b < n_bags; ++b) {
     pb.X[b] = bags[b].X;
