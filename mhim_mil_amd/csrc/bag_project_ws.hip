@@ -14,7 +14,9 @@
 // wait on the landing data - was 1.8x the MFMA phase and set the pace (71 us, no gain).  The global stream alone needs ~26 us of the
 // launch (1.66 MB per CU at ~28 B/clk/CU): it has to run beside the MFMAs, not between them.
 //
-// Slots (a k-step s is two slots, a workgroup barrier after each; tile s lives in stage s % 3 of the 156 KB ring):
+// Slots (a k-step s is two slots, a workgroup barrier after each; k-step s's tile lives in stage (s + 2) % 3 of the 156 KB ring - the
+// offset of 2 since round 5: the epilogue's staging rows take the low 83.5 KB, and the NEXT output tile's first stages are requested into
+// stage 2 while they are read; the stage indices below are relative to that offset):
 //   slot 2s   : group 0 loads tile s    | group 1 computes tile s-1 | producers split + store A(s+1) (stage (s+1) % 3: tile s-2, long read),
 //                                                                     request A(s+3)
 //   slot 2s+1 : group 0 computes tile s | group 1 loads tile s      | producers issue the DMA of B(s+2) (stage (s+2) % 3 = (s-1) % 3: both
@@ -35,6 +37,12 @@
 //     1 KiB row), 65.6 vs 62.2 us; the same accumulators staged with 16-byte LDS stores (20 instead of 80 per lane): 64.2 vs 62.6 us.
 //     Without its arithmetic AND its global stores the launch is 5 us shorter: the epilogue is the drain of 51 MB into HBM by 252 workgroups
 //     that all reach it together, not instruction time.
+//
+// Round 5 (profiles/r05_store_path.md; the comments at the sites): PERSISTENT workgroups for launches of more than 256 output tiles, the next
+// tile's first stages requested by LDS-DMA from inside the epilogue (first tile peeled: a straight-line listing for tools/asm_lint.py);
+// the workgroups with the shorter tile list start late, each by its own fraction of the spare tile time (no lock-step store bursts);
+// MODE 3 = PLAIN products (no activation / dropout / residual / d out-d pre): accumulators stored from the consumers' registers while the
+// producers run the next tile's direct prologue.
 #include "mma_tile.hpp"
 
 namespace mhimx {
