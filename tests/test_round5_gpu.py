@@ -248,6 +248,14 @@ def test_persistent_projection_equals_one_workgroup_per_tile():
     assert torch.equal(small[0].out, plain[0].out[:1000])
     ref = x.double() @ wa.double().t() + ba.double() + res.double()
     assert float((full[0].out.double() - ref).abs().max() / ref.abs().max()) < 1e-5           # (three-term bf16 products, K = 512)
+    for dk in (32, 64):                                        # one and two k-steps per tile: the prologues' clamped requests (persistent, plain and staged)
+        xs_, wk = x[:, :dk].contiguous(), wa[:, :dk].contiguous()
+        wkp = ops.pair_planes(wk)
+        refk = xs_.double() @ wk.double().t()
+        pk = ops.bag_project(xs_, [ops.ProjHead(wkp, None)], act=0)[0].out
+        sk = ops.bag_project(xs_, [ops.ProjHead(wkp, None, resid=res)], act=0)[0].out
+        assert float((pk.double() - refk).abs().max() / refk.abs().max()) < 1e-5, dk
+        assert float((sk.double() - refk - res.double()).abs().max() / refk.abs().max()) < 1e-5, dk
     nb, nr, dd = 3, 10000, 256
     xs = [torch.randn(nr, dd, device=DEV, generator=g).abs_() for _ in range(nb)]
     wt, ws_ = (torch.randn(E, dd, device=DEV, generator=g) * 0.05 for _ in range(2))
