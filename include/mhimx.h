@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point or a struct changes shape; the ctypes binding (mhim_mil_amd/_lib.py ABI_VERSION) refuses any other value */
-#define MHIMX_VERSION 500
+#define MHIMX_VERSION 600
 
 /* activations (feature act: mhim.py:71-74 relu|gelu|none; scorer act: baseline.py:17-22 gelu|relu|tanh|none) */
 enum { MHIMX_ACT_NONE = 0, MHIMX_ACT_RELU = 1, MHIMX_ACT_GELU = 2, MHIMX_ACT_TANH = 3 };
@@ -209,7 +209,9 @@ typedef struct { int32_t pending; int32_t reserved; unsigned char blob[MHIMX_SID
  * optimiser only) but parks its arguments here; the Merge backward that follows (mhimx_merge_bwd with the same list) launches it with
  * its own first, parameter-only stage riding along as extra workgroups - one launch instead of two on the serial chain; without a Merge
  * backward mhimx_reduce_flush launches it.  blob = a mhimx_gemm_tn_args. */
-typedef struct { int32_t pending; int32_t reserved; unsigned char blob[128]; } mhimx_parked_gemm;
+typedef struct { int32_t pending; int32_t reserved /* > 0: size the product as if reserved - 1 Merge row tiles shared its launch (the
+                                                        chain form's slab count - mhimx_step_run's DAG form keeps the chain's bits) */;
+                 unsigned char blob[128]; } mhimx_parked_gemm;
 /* pre (round 5): the FIRST stage of a Merge backward (parameters x dz, where dz = the merged tokens' gradient rows that the pool backward
  * produces) parked by mhimx_merge_bwd_park BEFORE mhimx_abmil_pool_bwd: the pool backward's one-pass rows launch gives it a ride behind a
  * gate on the row tile(s) that hold dz, and mhimx_merge_bwd then finds it done (pending: 0 nothing, 1 parked, 2 it rode). */
@@ -776,6 +778,13 @@ typedef struct {
   float lr, beta1, beta2, eps, weight_decay, ema_mm;
   const float* mm_table; int64_t mm_len; const float* lr_table; int64_t lr_len;
   uint64_t* tick; uint64_t* opt_step;             /* device counters: dropout / draw stream position, Adam step (advanced by the step)   */
+  void* side_stream;                              /* optional second hipStream_t (round 6): the step is enqueued as a DAG instead of a chain - the
+                                                     launches that share no data run as two branches that fork from and join `stream` through
+                                                     events (capturable: a hipGraph of the step then has parallel branches):
+                                                       forward   student scorer over the rows that stay  ||  Merge (rows pass, partial merge, O, to_out);
+                                                       backward  scorer-weight-gradient product, Merge parameter-gradient tail, queued reductions
+                                                                 ||  Merge rows backward -> dPRE image -> projection weight gradient.
+                                                     Same kernels on the same data: the results have the bits of the chain.  NULL: one stream, the chain. */
 } mhimx_step_cfg;
 /* row counts of one step (masking.py:30-35,61 and merge.py:163 in float64, as the reference computes them):
  * k_top = ceil(N r), r = mask_ratio_h / mask_ratio_hr (r > 1: r = 1, hr = mask_ratio_h); n_sel = ceil(k_top hr) if hr < 1 else k_top;

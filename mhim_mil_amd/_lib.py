@@ -12,7 +12,7 @@ c_f32p = C.c_void_p
 c_i64p = C.c_void_p
 c_u8p = C.c_void_p
 
-ABI_VERSION = 500          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
+ABI_VERSION = 600          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
 
 ACT = {None: 0, "none": 0, "identity": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"f32": 0, "f16s": 1, "bf16x3": 2}
@@ -194,7 +194,7 @@ class StepCfg(C.Structure):
                 ("n_train", C.c_int64), ("n_all", C.c_int64),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("ema_mm", C.c_float),
                 ("mm_table", C.c_void_p), ("mm_len", C.c_int64), ("lr_table", C.c_void_p), ("lr_len", C.c_int64),
-                ("tick", C.c_void_p), ("opt_step", C.c_void_p)]
+                ("tick", C.c_void_p), ("opt_step", C.c_void_p), ("side_stream", C.c_void_p)]
 
 
 class StepCounts(C.Structure):

@@ -358,6 +358,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #define PW_PROF_TILE 0
 #endif
   uint64_t pf_t0 = 0, pf_t1 = 0, pf_t2 = 0;
+  uint64_t pf_rt0 = 0;                                            // the 100 MHz constant clock at the same instants (round 6: the shader clock a launch holds)
   uint32_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t pf_t = 0;
   int pf_iter = 0;
@@ -616,6 +617,8 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       H.H[(m0 + wave) * H.ldh + 10] = (float)(pf_t3 - pf_t2);     // epilogue
       H.H[(m0 + wave) * H.ldh + 11] = (float)(pf_t3a - pf_t);     // the wave's last stores leave
       H.H[(m0 + wave) * H.ldh + 12] = (float)m0;
+      H.H[(m0 + wave) * H.ldh + 13] = (float)(wall_clock64() - pf_rt0);   // tile top -> here, in 10 ns ticks
+      H.H[(m0 + wave) * H.ldh + 14] = (float)(pf_t3 - pf_t0);             // the same span in shader cycles
     }
     ++pf_iter;
   }
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
     p_setup(vb);
     TileCtx t = tile_ctx(vb);
 #ifdef PW_PROF
-    pf_t0 = __builtin_readcyclecounter();
+    pf_t0 = __builtin_readcyclecounter(); pf_rt0 = wall_clock64();
 #endif
     if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
     const float* pxu = uni(px);
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       vb = t.vb_next;
       t = tile_ctx(vb);
 #ifdef PW_PROF
-      pf_t0 = __builtin_readcyclecounter();
+      pf_t0 = __builtin_readcyclecounter(); pf_rt0 = wall_clock64();
       for (int i = 0; i < 8; ++i) pf[i] = 0;
 #endif
       if (PW_PROD_PRIO) __builtin_amdgcn_s_setprio(PW_PROD_PRIO);
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
 #pragma unroll
       for (int j = 0; j < NRB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef PW_PROF
-    pf_t0 = __builtin_readcyclecounter();
+    pf_t0 = __builtin_readcyclecounter(); pf_rt0 = wall_clock64();
     for (int i = 0; i < 8; ++i) pf[i] = 0;
 #endif
     // ================================================================= consumers: fragment reads and MFMAs only

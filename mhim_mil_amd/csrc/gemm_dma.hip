@@ -671,7 +671,10 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   // stage 4: the Merge backward's rows pass rides (one 161 KB-LDS workgroup per CU, as every tile of this launch then is): the product
   // takes the CUs the row tiles leave free, all of it in ONE round - 4 output tiles x 56 slabs = 224 tiles beside 31 row tiles at c2
   // (the product runs as fast on 32 slabs as on 64: it is latency, not slab traffic)
-  const bool rows_ride = rider && rider_stage == 4 && DTHREADS == M2_THREADS;
+  // rider_stage 5 (round 6, the step as a DAG): nothing rides - the rows pass is a launch of its own on another branch - but the product is
+  // SIZED as if rider->w.T row tiles rode (the same slab count = the same summation order = the bits of the chain form)
+  const bool size_only = rider && rider_stage == 5;
+  const bool rows_ride = rider && (rider_stage == 4 || size_only) && DTHREADS == M2_THREADS;
   int rows_blocks = 0;
   if (rows_ride) {
     rows_blocks = (int)align_up(rider->w.T, 8);
@@ -680,6 +683,7 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
     if (cap < 8 || rows_blocks > 128) rows_blocks = 0;            // no room for the product beside the rows: they do not ride
     else if (splits > cap) splits = cap;
   }
+  if (size_only) { rows_blocks = 0; rider = nullptr; }
   g.splits = splits;
   const int64_t mchunk = align_up(cdiv(g.M, splits), DBK);
   size_t smem = TN_STAGES * STAGE_BYTES + (size_t)mchunk * 8;

@@ -28,6 +28,7 @@
 namespace mhimx {
 
 int64_t merge2_part_floats() { return M2_PART_FLOATS; }
+int64_t merge2_rows_tiles(int64_t R) { return cdiv(R, m2_tile_rows(R)); }
 int64_t merge2_ws_bytes(int64_t R, int64_t k) {
   Arena ar(nullptr, 0);
   return merge2_ws_layout(ar, R, k, nullptr);

@@ -1244,6 +1244,7 @@ int reduce_parts2(hipStream_t st, const float* part0, const float* part1, int G,
 }
 
 int merge2_side_finish(hipStream_t st, mhimx_side_work* side, int upto_stage);      // mca2.hip
+int gemm_tn_rider(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge2Side* rider, int stage);      // gemm.hip
 
 int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   MHIMX_CHECK_ARG(list && list->n >= 0 && list->n <= MHIMX_REDUCE_MAX, "reduce_flush: bad list");
@@ -1251,7 +1252,13 @@ int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
     mhimx_gemm_tn_args pg;
     memcpy(&pg, list->parked.blob, sizeof(pg));
     list->parked.pending = 0;
-    if (int r = gemm_tn(st, pg)) return r;                      // (queues its slab sum on this same list)
+    if (list->parked.reserved > 0) {                            // (round 6, the step as a DAG: sized as beside `reserved - 1` Merge row tiles)
+      Merge2Side sz = {};
+      sz.w.T = list->parked.reserved - 1;
+      list->parked.reserved = 0;
+      const int rc = gemm_tn_rider(st, pg, &sz, 5);
+      if (rc < 0) return rc;
+    } else if (int r = gemm_tn(st, pg)) return r;               // (queues its slab sum on this same list)
   }
   // a parked Merge-backward tail: the stages that found no ride run now, in order; the last one may ride in the reduction launch
   if (int r = merge2_side_finish(st, &list->side, list->n == 0 ? 3 : 2)) return r;

@@ -16,6 +16,21 @@
 //          14  mhimx_merge_bwd          rows backward + the parked scorer-weight-gradient product in one launch
 //       15,16  rows_dpre_image | bag_wgrad   the projection's gradient pair (the Merge tail and the last reductions ride)
 //          17  mhimx_optim_step         Adam + EMA teacher (folds the split-K slab sum)
+//
+// Round 6 - the step as a DAG (mhimx_step_cfg.side_stream).  The chain above serialises launches that share no data;
+// with a second stream the executor forks and joins through events (capturable: the trainer's hipGraph of the step gets parallel branches):
+//   forward   after the select:   side: student scorer over the rows that stay   ||  main: Merge rows pass -> partial merge -> O -> to_out
+//             join -> the finalize that scores the tokens -> head
+//   backward  after the pool backward's rows launch:
+//             side: the scorer-weight-gradient product (d_wa) + the reductions queued so far -> [wait: Merge rows backward] -> the Merge
+//                   parameter-gradient tail (three stages) + its reductions
+//             main: Merge rows backward -> dPRE image -> projection weight gradient (no riders: they are on the side branch)
+//             join -> Adam + EMA
+// The same entry points with the same arguments on the same buffers - only WHICH launch a rider sits in changes, and riders compute the
+// same sums in the same order wherever they run: a DAG step has the bits of a chain step (tests/test_round6_gpu.py).
+// MEASURED (profiles/r06_dag.md): on this runtime every fork or join between two queues of a hipGraph costs 5-13 us of idle chip - more than
+// the 3-15 us of launches a branch takes off the chain: c2 0.300 -> 0.317 (forward fork alone) / 0.333 (backward alone) / 0.341 ms (both).
+// The trainer therefore passes no side stream unless MHIMX_STEP_DAG=1; the form stays as the measured answer to "run the step as a DAG".
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,7 +39,33 @@
 
 namespace mhimx {
 
+int64_t merge2_rows_tiles(int64_t R);            // mca2.hip: row tiles of a Merge over R rows
+
 namespace {
+
+// fork / join events of the DAG form: six per device, created on first use (a trainer's first step is eager: not under capture)
+struct DagEvents {
+  hipEvent_t e[64][6];
+  bool have[64] = {};
+  int get(hipEvent_t** out) {
+    int dev = 0;
+    MHIMX_HIP(hipGetDevice(&dev));
+    MHIMX_CHECK_ARG(dev >= 0 && dev < 64, "step: device index %d", dev);
+    if (!have[dev]) {
+      for (int i = 0; i < 6; ++i) MHIMX_HIP(hipEventCreateWithFlags(&e[dev][i], hipEventDisableTiming));
+      have[dev] = true;
+    }
+    *out = e[dev];
+    return 0;
+  }
+};
+DagEvents g_dag_events;
+// `to` continues after everything enqueued on `from` so far
+int dag_edge(hipEvent_t ev, hipStream_t from, hipStream_t to) {
+  MHIMX_HIP(hipEventRecord(ev, from));
+  MHIMX_HIP(hipStreamWaitEvent(to, ev, 0));
+  return 0;
+}
 
 struct Carve {
   char* base;
@@ -171,6 +212,15 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
   int64_t* rows_all = cv.at<int64_t>(b.rows_all);
   float* dH = cv.at<float>(b.dH);
   const uint64_t* tick = c.tick;
+  // the DAG form (header comment): a second stream and its fork / join events.  MHIMX_STEP_DAG=0: the chain, whatever the caller passes
+  static const bool dag_on = getenv("MHIMX_STEP_DAG") == nullptr || atoi(getenv("MHIMX_STEP_DAG")) != 0;      // (the caller decides: side_stream)
+  static const bool dag_fwd = getenv("MHIMX_STEP_DAG_FWD") == nullptr || atoi(getenv("MHIMX_STEP_DAG_FWD")) != 0;
+  static const bool dag_bwd = getenv("MHIMX_STEP_DAG_BWD") == nullptr || atoi(getenv("MHIMX_STEP_DAG_BWD")) != 0;
+  const hipStream_t main_st = (hipStream_t)stream, side_st = (hipStream_t)c.side_stream;
+  const bool dag = dag_on && c.side_stream != nullptr && c.side_stream != stream;
+  hipEvent_t* ev = nullptr;
+  if (dag)
+    if (int r = g_dag_events.get(&ev)) return r;
 
   // ---- 1. the step's first launch: counters, both projection weight images, the teacher's scorer image, the row list's constant tail.
   //         Everything else the step prepares (late[]) rides in the teacher's scorer launch, off the head of the chain.
@@ -243,7 +293,17 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
   io_s.ws = cv.at<char>(b.pool_ws_s); io_s.ws_bytes = b.pool_ws_s_bytes; io_s.rows1 = rows_all + R;
   static const bool split_pool = getenv("MHIMX_SPLIT_POOL") == nullptr || atoi(getenv("MHIMX_SPLIT_POOL")) != 0;
   io_s.tail_row0 = -1;
-  if (split_pool && k <= 6) {
+  if (dag && dag_fwd && split_pool && k <= 6) {
+    // two branches: the scorer over the rows that stay (side) || Merge's whole chain (main); they meet at the finalize that scores the tokens
+    if (int r = dag_edge(ev[0], main_st, side_st)) return r;
+    io_s.phase = 1; io_s.tail_tokens = (int32_t)k;
+    if (int r = mhimx_abmil_pool_fwd(side_st, &sc_s, &io_s)) return r;
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+    if (int r = dag_edge(ev[1], side_st, main_st)) return r;
+    io_s.phase = 2; io_s.tail_wa_t = wa_t; io_s.tail_row0 = N;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+    io_s.phase = 0;
+  } else if (split_pool && k <= 6) {
     io_s.phase = 1; io_s.tail_tokens = (int32_t)k;
     io_s.ride_merge = &mw; io_s.ride_X = Hbuf; io_s.ride_R = R; io_s.ride_ws = merge_ws; io_s.ride_ws_bytes = b.merge_ws_bytes;
     if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
@@ -280,21 +340,42 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     pg.g_z = g_z; pg.dT1 = dH; pg.d_wa = c.grad.wa; pg.d_wc = c.grad.wc; pg.wa_t = wa_t; pg.accumulate = 0; pg.splits = 8; pg.defer = &lst; pg.wa_t_frag = wa_t_frag;
     if (int r = mhimx_abmil_pool_bwd(stream, &sc_b, &io_s, &pg)) return r;
   }
+  mhimx_reduce_list lst_main;                    // (DAG form: what the main branch queues - the bias partials, the weight gradient's slab sum)
+  memset(&lst_main, 0, sizeof(lst_main));
+  const bool dagb = dag && dag_bwd;
+  mhimx_reduce_list* lm = dagb ? &lst_main : &lst;
+  if (dagb) {
+    // side branch, first half: the parked scorer-weight-gradient product (its inputs are the pool backward's) and the reductions queued so far
+    if (int r = dag_edge(ev[2], main_st, side_st)) return r;
+    // (the chain runs the product beside the Merge rows backward's tiles and sizes it for the CUs they leave - when the first stage rode:
+    // the same slab count here keeps the chain's summation order)
+    static const bool fuse_rows = getenv("MHIMX_MERGE_BWD_FUSE") == nullptr || atoi(getenv("MHIMX_MERGE_BWD_FUSE")) != 0;
+    if (lst.parked.pending && lst.pre.pending == 2 && fuse_rows) lst.parked.reserved = (int32_t)merge2_rows_tiles(R) + 1;
+    if (int r = mhimx_reduce_flush(side_st, &lst)) return r;
+  }
+  // main: the Merge rows backward (DAG form: a launch of its own - the product it used to share a launch with is on the side branch)
   if (int r = mhimx_merge_bwd(stream, &mwb, Hbuf, R, dH + N * E, dH, &mg, merge_ws, b.merge_ws_bytes)) return r;
-  if (int r = mhimx_rows_dpre_image(stream, dH, dact, rows_all, len_keep, E, cv.at<char>(b.img), c.grad.b1, 0, cv.at<char>(b.ws_b), b.ws_b_bytes, &lst)) return r;
+  if (dagb) {
+    // side branch, second half: the Merge parameter-gradient tail reads what the rows backward wrote (the pooled-row partials U)
+    if (int r = dag_edge(ev[3], main_st, side_st)) return r;
+    if (int r = mhimx_reduce_flush(side_st, &lst)) return r;      // (the tail's stages as launches, the last one inside the reduction launch)
+  }
+  if (int r = mhimx_rows_dpre_image(stream, dH, dact, rows_all, len_keep, E, cv.at<char>(b.img), c.grad.b1, 0, cv.at<char>(b.ws_b), b.ws_b_bytes, lm)) return r;
   {
     mhimx_bag_wgrad_args g = {};
     g.img = cv.at<char>(b.img); g.X = X; g.ldx = ldx; g.n_bag_rows = N; g.rows = rows_all; g.L = len_keep; g.E = E; g.D = D; g.C = c.grad.w1; g.ldc = D;
-    g.accumulate = 0; g.ws = cv.at<float>(b.wg_ws); g.ws_floats = b.wg_ws_floats; g.defer = &lst; g.ride_tail = update ? 1 : 0;
+    g.accumulate = 0; g.ws = cv.at<float>(b.wg_ws); g.ws_floats = b.wg_ws_floats; g.defer = lm; g.ride_tail = update ? 1 : 0;
     if (int r = mhimx_bag_wgrad(stream, &g)) return r;
   }
-  if (!update) return mhimx_reduce_flush(stream, &lst);
+  if (dagb)
+    if (int r = dag_edge(ev[4], side_st, main_st)) return r;
+  if (!update) return mhimx_reduce_flush(stream, lm);
 
   // ---- 17. Adam + EMA teacher; the weight gradient's split-K slab sum is folded into the update
   mhimx_optim_args o = {};
   o.p = c.p; o.g = c.g; o.m = c.m; o.v = c.v; o.teacher = c.p_teacher; o.n_train = c.n_train; o.n_all = c.n_all; o.step = host_step; o.step_dev = c.opt_step;
   o.lr = c.lr; o.lr_table = c.lr_table; o.lr_len = c.lr_len; o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.weight_decay = c.weight_decay;
-  o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = &lst;
+  o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = lm;
   return mhimx_optim_step(stream, &o);
 }
 

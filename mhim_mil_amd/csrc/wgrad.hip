@@ -381,6 +381,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, Wgr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef WG_PROF                                                  // shader cycles: entry -> loop, loop, epilogue (tools/exp_wgrad.py WG_PROF=1)
   const uint64_t wp_t0 = __builtin_readcyclecounter();
+  const uint64_t wp_rt0 = wall_clock64();                        // (round 6: the 100 MHz clock beside it -> the shader clock the launch holds)
 #endif
   const int nJ = (int)(g.D / WBN), nIT = (int)(g.E / WBI), nT = nIT * nJ;
   const int xcd = bx & 7, sidx = bx >> 3;
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, Wgr
     const uint64_t wp_t3 = __builtin_readcyclecounter();
     float* pr = reinterpret_cast<float*>(const_cast<char*>(gimg) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;
     pr[0] = (float)(wp_t1 - wp_t0); pr[1] = (float)(wp_t2 - wp_t1); pr[2] = (float)(wp_t3 - wp_t2); pr[3] = (float)nk;
+    if (wave == 0) { pr[32] = (float)(wall_clock64() - wp_rt0); pr[33] = (float)(wp_t3 - wp_t0); }     // 10 ns ticks | shader cycles, entry -> end
   }
 #endif
 }

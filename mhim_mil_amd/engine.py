@@ -327,12 +327,15 @@ class FusedTrainer:
         self.ride_prep = os.environ.get("MHIMX_RIDE_PREP", "1") != "0"   # the student-side preparation jobs in the teacher's scorer launch
         self._graph_pool = None
         self._cap_stream = None
-        self._side = None
+        self._side = None                  # the step executor's second stream (mhimx_step_cfg.side_stream: the step as a DAG), made on first use
+        # (off by default: measured slower - every fork / join between two queues of a hipGraph costs 5-13 us, profiles/r06_dag.md)
+        self.step_dag = os.environ.get("MHIMX_STEP_DAG", "0") != "0"
         # the whole step as ONE C call (mhimx_step_run, csrc/step.hip): the same launches as _forward_backward_nat + _apply, enqueued by the
         # library itself - a bag costs one ctypes call instead of ~1700 interpreter calls (the eager step was host-bound).  MHIMX_STEP_EXEC=0:
         # the Python orchestration (kept: it is the executor's specification and takes every case the executor refuses)
         self.use_executor = os.environ.get("MHIMX_STEP_EXEC", "1") != "0"
         self._exec = None
+        self.exec_max_rows = 16384         # csrc/step.hip:check_cfg (the one-workgroup select)
         self.single_pass = True            # ABMIL: one projection launch for teacher + student, bag-ordered buffers (when shapes allow)
         self.window_streams = 4            # accumulation windows (window_step): HIP streams the window's bags are issued on
         self._rows_cache = {}
@@ -479,10 +482,17 @@ class FusedTrainer:
                 and ids_shuffle is None and self.ride_prep and s.training and s.n_classes <= 4 and s._op_prec != "f32"
                 and s.merge.k * 8 <= 48 and x.shape[1] % 256 == 0 and x.stride(0) % 4 == 0 and x.shape[0] * x.stride(0) * 4 < (1 << 32)):
             return False
+        # (csrc/step.hip:check_cfg and mhimx_step_run's own argument checks, mirrored: a bag they would refuse takes the Python path instead
+        # of raising - ADVICE r5)
+        mg = s.merge
+        att = s.online_encoder.attention.attention
+        if not (s.mlp_dim == 512 and att[0].weight.shape[0] == 128 and x.data_ptr() % 16 == 0 and x.stride(0) >= x.shape[1] and x.stride(1) == 1
+                and mg.attn.to_q.weight.shape[0] == 512 and mg.attn.to_kv.weight.shape[0] == 1024 and 64 <= x.shape[0] <= self.exec_max_rows):
+            return False
         if not s.device_draw_ok(x.shape[0], i):
             return False
         c = s.v2_counts(x.shape[0], i)
-        return c is not None and c[3] >= 1 and 1 <= c[4] <= 32768
+        return c is not None and 1 <= c[0] <= 4096 and c[3] >= 1 and 1 <= c[4] <= 32768
 
     def _exec_cfg(self):
         """The mhimx_step_cfg of this trainer: parameter / gradient pointers into the flat buffers (stable for the trainer's lifetime), the
@@ -515,6 +525,12 @@ class FusedTrainer:
                             tick=P(self.tick), opt_step=P(self.opt_step))
             ex = self._exec = {"key": key, "cfg": cfg, "layouts": {}, "ws": None}
         cfg = ex["cfg"]
+        if self.step_dag:
+            if self._side is None or self._side.device != fl.student.device:
+                self._side = torch.cuda.Stream(device=fl.student.device)
+            cfg.side_stream = self._side.cuda_stream
+        else:
+            cfg.side_stream = None
         cfg.attn2score = int(bool(t.attn2score))
         cfg.drop_p_teacher = float(t.dropout_p if t.training else 0.0)
         cfg.drop_p_student = float(s.dropout_p)
@@ -559,10 +575,10 @@ class FusedTrainer:
                 ws = ex["ws"] = torch.empty(int(lay.total * 1.25), dtype=torch.uint8, device=x.device)
         seeds = L.StepSeeds(drop_teacher=t._next_seed(teacher=True), drop_student=s._next_seed(), select=s._next_seed(), mca=s._next_seed())
         update = bool(self._fold_now)
-        if update:
-            fl.step += 1
         L.check(L.lib().mhimx_step_run(ops._stream(), C.byref(ex["cfg"]), x.data_ptr(), x.stride(0), N, label.data_ptr(), C.byref(cnt), C.byref(seeds),
-                                       fl.step, ws.data_ptr(), ws.numel(), int(update)), "mhimx_step_run")
+                                       fl.step + int(update), ws.data_ptr(), ws.numel(), int(update)), "mhimx_step_run")
+        if update:                                      # (only a step that was enqueued counts: a refused call leaves host and device counters equal)
+            fl.step += 1
         km, E = s.merge.k, s.mlp_dim
 
         def view(off, n, dtype=torch.float32):
@@ -583,18 +599,35 @@ class FusedTrainer:
 
     def run_steps(self, bags, labels, i=None):
         """len(bags) consecutive complete train steps (one update each) as ONE call of mhimx_step_run_many (SURVEY 7 H4 "run_steps"): the
-        bags of a resident dataset, bag after bag, on one workspace.  Returns the last bag's (logits, losses)."""
+        bags of a resident dataset, bag after bag, on one workspace.  ``i``: the iteration of the FIRST bag (bag j runs at i + j, as the
+        reference's loop counts them - base_engine.py:78) or a sequence with one entry per bag.  Returns the last bag's (logits, losses).
+        What the executor's in-launch update does not do - gradient clipping (base_engine.py:115-119), unfolded reductions, accumulation -
+        goes bag by bag through train_step, which does."""
         import ctypes as C
         L = mh.L
+        n = len(bags)
+        if n == 0 or len(labels) != n:
+            raise L.MhimxError(f"run_steps: {n} bags, {len(labels)} labels")
+        its = list(i) if isinstance(i, (list, tuple)) else [None if i is None else i + j for j in range(n)]
+        if len(its) != n:
+            raise L.MhimxError(f"run_steps: {len(its)} iteration indices for {n} bags")
         xs = [self.s._check_x(b) for b in bags]
-        assert self._micro == 0 and all(self._exec_ok(x, i) and self._nat_ok(x, i) for x in xs), "run_steps: bags the step executor takes, a fresh update"
+        if self._micro != 0:
+            raise L.MhimxError("run_steps: called inside an accumulation window (a fresh update is required)")
+        if self.clip_grad or not self.fold_reductions or self.accum != 1 or not all(self._exec_ok(x, it) and self._nat_ok(x, it) for x, it in zip(xs, its)):
+            out = None
+            for b, l, it in zip(bags, labels, its):
+                out = self.train_step(b, l, i=it)
+            return out
+        for x, l in zip(xs, labels):
+            if not (torch.is_tensor(l) and l.is_cuda and l.dtype == torch.int64 and l.is_contiguous() and l.device == x.device and l.numel() >= 1):
+                raise L.MhimxError(f"run_steps: every label must be a contiguous int64 tensor on its bag's device ({x.device})")
         ex = self._exec_cfg()
-        plans = [self._exec_plan(ex, x.shape[0], i) for x in xs]
+        plans = [self._exec_plan(ex, x.shape[0], it) for x, it in zip(xs, its)]
         total = max(p[1].total for p in plans)
         ws = ex["ws"]
-        if ws is None or ws.numel() < total:
+        if ws is None or ws.numel() < total or ws.device != xs[0].device:
             ws = ex["ws"] = torch.empty(int(total * 1.25), dtype=torch.uint8, device=xs[0].device)
-        n = len(xs)
         Xp = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
         ld = (C.c_int64 * n)(*[x.stride(0) for x in xs])
         Ns = (C.c_int64 * n)(*[x.shape[0] for x in xs])
@@ -1148,11 +1181,30 @@ class FusedTrainer:
         if st is None:
             st = self._shape_graphs = {"graphs": {}, "seen": {}, "arena": None, "bad": set()}
         key = (what, tuple(x.shape), x.dtype, x.device.index, counts, s.training, None if t is None else t.training, s.merge_enable,
-               float(self.main_alpha), float(self.aux_alpha), tuple(label.shape),
-               (float(self.lr), tuple(self.betas), float(self.eps), float(self.wd), float(self.mm)) if what == "train_step" else None)
+               float(self.main_alpha), float(self.aux_alpha), tuple(label.shape))
+        # the optimiser's by-value scalars are baked into a captured update; scalars that come from a DEVICE table (lr_table / mm_table,
+        # indexed by the device step counter) are not.  They are kept beside the graph, not in its key (with a host-side
+        # scheduler every step had a new key, nothing was ever replayed and the visit counts grew without bound): a shape whose scalars
+        # changed is captured again, and one whose scalars keep changing runs eagerly.
+        scal = None
+        if what == "train_step":
+            scal = (None if self.lr_table is not None else float(self.lr), tuple(self.betas), float(self.eps), float(self.wd),
+                    None if self.mm_table is not None else float(self.mm))
         if key in st["bad"]:
             return None
         ent = st["graphs"].get(key)
+        if ent is not None and ent[8] != scal:
+            st["graphs"].pop(key)
+            ent = None
+            n_re = st.setdefault("rescaled", {})
+            n_re[key] = n_re.get(key, 0) + 1
+            if n_re[key] > 2:
+                st["bad"].add(key)
+                st["seen"].pop(key, None)
+                return None
+            st["seen"][key] = 2                                  # (the shape is warm: capture on this visit)
+        if len(st["seen"]) > 4096:                               # (visit counts of shapes that never came back)
+            st["seen"] = {k_: v_ for k_, v_ in st["seen"].items() if k_ in st["graphs"]}
         fn = self.train_step if what == "train_step" else self.forward_backward
         if auto and self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream()
@@ -1188,9 +1240,19 @@ class FusedTrainer:
             try:
                 with torch.cuda.graph(g, pool=self._graph_pool, stream=cs):      # (recorded, not run: the replay below is this bag's step)
                     logits, losses = fn(xs, ls, i=i)
-            except Exception:
-                # a step that turned out not to be capturable (a host read-back somewhere): this shape runs eagerly from now on
+            except Exception as exc:
+                # a step that turned out not to be capturable (a host read-back somewhere): this shape runs eagerly from now on.  Argument
+                # errors of the library (a label on the wrong device, a refused shape) are the caller's bug, not a capture problem: they
+                # propagate; the first capture failure of every other kind is kept for inspection
+                if isinstance(exc, mh.L.MhimxError):
+                    self._capturing = False
+                    self._micro, self.flat.step = micro, host_step
+                    self._fold_list = None
+                    self._defer = ops.ReduceList()
+                    ops.step_images(None)
+                    raise
                 st["bad"].add(key)
+                st.setdefault("errors", []).append(repr(exc))
                 self._micro, self.flat.step = micro, host_step
                 self._fold_list = None
                 self._defer = ops.ReduceList()
@@ -1201,10 +1263,10 @@ class FusedTrainer:
                 self._capturing = False
             ops.step_images(None)
             self._micro, self.flat.step = micro, host_step
-            ent = st["graphs"][key] = (g, xs, ls, logits, losses, self.last["patch_num"], self.last["keep_num"], dict(self.last))
+            ent = st["graphs"][key] = (g, xs, ls, logits, losses, self.last["patch_num"], self.last["keep_num"], dict(self.last), scal)
         else:
             st["graphs"][key] = st["graphs"].pop(key)             # most recently used: to the end of the (insertion-ordered) dict
-        g, xs, ls, logits, losses, pn, kn, last = ent
+        g, xs, ls, logits, losses, pn, kn, last, _ = ent
         xs.copy_(x)
         ls.copy_(label)
         g.replay()

@@ -38,18 +38,33 @@ from . import ops
 from .engine import FusedTrainer
 
 
+def schedule_at_updates(sche, accumulation_steps=1, len_loader=None):
+    """A per-BAG schedule (base_engine.py:161-162) at the bags that trigger an update (base_engine.py:47-49) - the per-UPDATE table the
+    optimiser kernel indexes with its device step counter."""
+    acc = max(1, int(accumulation_steps))
+    if sche is None or (acc == 1 and not len_loader):
+        return sche
+    sche = list(sche)
+    if not len_loader:
+        return sche[acc - 1::acc]
+    n_l = int(len_loader)
+    idx = [e * n_l + b for e in range(-(-len(sche) // n_l)) for b in range(n_l) if (b + 1) % acc == 0 or b == n_l - 1]
+    return [sche[j] for j in idx if j < len(sche)]
+
+
 class FusedAdamEMA(torch.optim.Optimizer):
     def __init__(self, model, model_ema=None, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, mm=0.9997, mm_sche=None,
-                 main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, model_kind=None):
+                 main_alpha=1.0, aux_alpha=0.5, accumulation_steps=1, model_kind=None, len_loader=None):
         if not any(p.is_cuda for p in model.parameters()):
             raise ValueError("FusedAdamEMA: move the model to the GPU first (the flat buffers live where the parameters are)")
         kind = model_kind or ("mhim" if model_ema is not None else "mhim_pure")
         # the loop indexes the momentum schedule by BAG (mm_sche[epoch * len(loader) + batch_idx], base_engine.py:161-162) and reads it at the
-        # bag that triggers the update; the update kernel indexes its table by UPDATE: with accumulation the table is the schedule at every
-        # accumulation_steps-th bag (identical when no batch is skipped)
-        acc = max(1, int(accumulation_steps))
-        if mm_sche is not None and acc > 1:
-            mm_sche = list(mm_sche)[acc - 1::acc]
+        # bag that triggers the update; the update kernel indexes its table by UPDATE.  The bags that trigger one (base_engine.py:47-49:
+        # ``need_update = last_batch or (batch_idx + 1) % accumulation_steps == 0``, the count restarting every epoch) are every
+        # accumulation_steps-th bag of an epoch AND its last one: with ``len_loader`` given the table holds the schedule at exactly those
+        # bags - ceil(len / acc) per epoch (ADVICE r5: the plain [acc - 1::acc] slice ran ahead of the reference whenever len % acc != 0,
+        # and the update kernel then clamped to mm ~ 1 early).  Without ``len_loader`` the slice stays (exact when acc divides len).
+        mm_sche = schedule_at_updates(mm_sche, accumulation_steps, len_loader)
         self.trainer = FusedTrainer(model, model_ema, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, mm=mm, main_alpha=main_alpha,
                                     aux_alpha=aux_alpha, accumulation_steps=accumulation_steps, model=kind, mm_sche=mm_sche)
         self.flat = self.trainer.flat

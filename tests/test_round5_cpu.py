@@ -44,3 +44,17 @@ def test_pinned_stream_is_thread_local():
     th.join()
     assert seen["stream"] is None
     ops._PIN.stream, ops._PIN.device = None, -1
+
+
+def test_schedule_at_updates_follows_the_loop_update_rule():
+    """base_engine.py:47-49: an update after every accumulation_steps-th bag of an epoch AND after its last bag; the momentum schedule is
+    read at epoch * len(loader) + batch_idx of that bag (base_engine.py:161-162).  ADVICE r5: the [acc - 1::acc] slice drifts when
+    len(loader) % acc != 0."""
+    from mhim_mil_amd.optim import schedule_at_updates
+    sche = list(range(30))                           # 3 epochs of 10 bags, value == global bag index
+    assert schedule_at_updates(sche, 1, None) is sche
+    assert schedule_at_updates(sche, 5, None) == sche[4::5]
+    assert schedule_at_updates(sche, 5, 10) == sche[4::5]                    # acc divides len: the two agree
+    got = schedule_at_updates(sche, 4, 10)                                   # updates at bags 3, 7, 9 of every epoch
+    assert got == [3, 7, 9, 13, 17, 19, 23, 27, 29]
+    assert schedule_at_updates(sche, 1, 10) == sche

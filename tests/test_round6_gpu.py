@@ -1,0 +1,115 @@
+"""Round-6 GPU tests: the step as a DAG (mhimx_step_cfg.side_stream), ADVICE r5 fixes on the executor path."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(mask_ratio_h=0.03, mask_ratio_hr=0.5, merge_enable=True, merge_k=5, merge_mm=0.9999, merge_ratio=0.9, act="gelu", da_act="relu",
+           attn2score=True, temp_t=0.1)
+
+
+def _models(D=256, dropout=0.0, seed=3):
+    from mhim_mil_amd.mhim import MHIM
+    torch.manual_seed(seed)
+    s = MHIM(input_dim=D, n_classes=2, baseline="attn", dropout=dropout, **CFG).cuda().train()
+    t = copy.deepcopy(s)
+    t.merge_test = False
+    return s, t.train()
+
+
+def _pair_of_trainers(D=512, dropout=0.25, **kw):
+    from mhim_mil_amd.engine import FusedTrainer
+    out = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        s, t = _models(D=D, dropout=dropout, seed=11)
+        out.append(FusedTrainer(s, t, lr=1e-3, mm=0.999, aux_alpha=0.5, **kw))
+    return out
+
+
+def _state(tr):
+    fl = tr.flat
+    return [fl.student.clone(), fl.teacher.clone(), fl.m.clone(), fl.v.clone(), tr.opt_step.clone(), tr.tick.clone()]
+
+
+def test_dag_step_equals_the_chain_bit_for_bit():
+    """mhimx_step_cfg.side_stream: the executor forks the launches that share no data onto a second stream and joins them through events.
+    Same kernels, arguments and seeds (the scorer-weight-gradient product keeps the slab count it has beside the Merge row tiles): the
+    DAG step has the bits of the one-stream chain - over bags whose size changes every step, dropout on, nothing captured."""
+    tr_d, tr_c = _pair_of_trainers()
+    tr_d.step_dag, tr_c.step_dag = True, False
+    g = torch.Generator(device="cuda").manual_seed(9)
+    sizes = [2048, 1777, 3001, 1024, 2500, 10000]
+    for step, n in enumerate(sizes):
+        x = torch.randn(n, 512, device="cuda", generator=g).abs_()
+        lab = torch.tensor([step % 2], device="cuda")
+        ld, sd = tr_d.train_step(x, lab)
+        lc, sc = tr_c.train_step(x, lab)
+        assert tr_d._exec is not None and tr_d._exec["cfg"].side_stream and not tr_c._exec["cfg"].side_stream
+        assert torch.equal(ld, lc) and torch.equal(sd, sc), (step, ld, lc)
+        assert torch.equal(tr_d.last["rows"], tr_c.last["rows"]) and torch.equal(tr_d.last["tokens"], tr_c.last["tokens"])
+        for a, b in zip(_state(tr_d), _state(tr_c)):
+            assert torch.equal(a, b), step
+    assert tr_d.flat.step == tr_c.flat.step == len(sizes)
+
+
+def test_dag_step_forward_backward_only():
+    """update = 0 through the DAG form: the complete gradient (both branches joined, every queued reduction flushed) equals the chain's."""
+    tr_d, tr_c = _pair_of_trainers(clip_grad=0.5)
+    tr_d.step_dag, tr_c.step_dag = True, False
+    x = torch.rand(1500, 512, device="cuda")
+    lab = torch.tensor([1], device="cuda")
+    for tr in (tr_d, tr_c):
+        tr.forward_backward(x, lab)
+    assert torch.equal(tr_d.flat.grad, tr_c.flat.grad) and tr_d.flat.grad.abs().max() > 0
+    for tr in (tr_d, tr_c):
+        tr.update()
+        tr.train_step(x, lab)
+    for a, b in zip(_state(tr_d), _state(tr_c)):
+        assert torch.equal(a, b)
+
+
+def test_dag_step_captured_graph_has_branches_and_replays_equal():
+    """A hipGraph of the DAG step (shape_cached: eager, captured on the second visit, replayed afterwards) equals the same sequence through
+    the chain bit for bit: the fork / join events become graph dependencies, both branches end inside the capture."""
+    tr_d, tr_c = _pair_of_trainers()
+    tr_d.step_dag, tr_c.step_dag = True, False
+    x = torch.rand(1800, 512, device="cuda")
+    lab = torch.tensor([0], device="cuda")
+    for it in range(5):
+        od = tr_d.shape_cached("train_step", x, lab)
+        oc = tr_c.shape_cached("train_step", x, lab)
+        assert od is not None and oc is not None
+        torch.cuda.synchronize()
+        assert torch.equal(od[0], oc[0]) and torch.equal(od[1], oc[1]), it
+    assert len(tr_d._shape_graphs["graphs"]) == 1 and not tr_d._shape_graphs["bad"], tr_d._shape_graphs.get("errors")
+    for a, b in zip(_state(tr_d), _state(tr_c)):
+        assert torch.equal(a, b)
+
+
+def test_run_steps_takes_the_per_bag_path_when_the_executor_cannot_clip():
+    """run_steps with --clip_grad (base_engine.py:115-119) used to run the executor's unclipped update.  It now goes bag by bag
+    through train_step (which clips): identical to calling train_step in a loop; labels are validated; a per-bag iteration index is taken."""
+    from mhim_mil_amd import _lib as L
+    tr_m, tr_1 = _pair_of_trainers(clip_grad=0.05)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    bags = [torch.randn(n, 512, device="cuda", generator=g).abs_() for n in (1200, 1536, 999)]
+    labels = [torch.tensor([j % 2], device="cuda") for j in range(len(bags))]
+    lm, _ = tr_m.run_steps(bags, labels, i=0)
+    for j, (b, l) in enumerate(zip(bags, labels)):
+        l1, _ = tr_1.train_step(b, l, i=j)
+    assert torch.equal(lm, l1)
+    for a, b in zip(_state(tr_m), _state(tr_1)):
+        assert torch.equal(a, b)
+    # and the clip did something: an unclipped trainer ends elsewhere
+    tr_u, _ = _pair_of_trainers()
+    for b, l in zip(bags, labels):
+        tr_u.train_step(b, l)
+    assert not torch.equal(tr_u.flat.student, tr_m.flat.student)
+    tr_e, _ = _pair_of_trainers()
+    with pytest.raises(L.MhimxError):
+        tr_e.run_steps(bags, [torch.tensor([1])] * 3)                  # CPU labels
+    with pytest.raises(L.MhimxError):
+        tr_e.run_steps(bags, labels[:2])

@@ -81,6 +81,9 @@ for name in which:
 
 if os.environ.get("WG_PROF"):
     wgrad(); torch.cuda.synchronize()
-    st = img[lib.mhimx_wgrad_image_bytes(L_, E) // 4:][:32].view(8, 4).cpu().tolist()
+    tail_ = img[lib.mhimx_wgrad_image_bytes(L_, E) // 4:][:64].cpu()
+    st = tail_[:32].view(8, 4).tolist()
+    if float(tail_[32]) > 0:
+        print("workgroup 0: %.0f shader cycles in %.2f us (100 MHz clock) -> %.3f GHz" % (float(tail_[33]), float(tail_[32]) / 100, float(tail_[33]) / float(tail_[32]) / 10))
     for w in (0, 4):
         print("wave %d: entry -> loop %.0f, loop %.0f (%d k-steps), epilogue %.0f shader cycles" % (w, st[w][0], st[w][1], st[w][3], st[w][2]))
