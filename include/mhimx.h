@@ -751,8 +751,11 @@ int mhimx_optim_step(void* stream, const mhimx_optim_args* a);
  *   teacher and student projection in one pass over the bag -> teacher scorer + pool (+ pseudo score) -> device-drawn HAM mask and Merge
  *   split (mhimx_select_rows) -> Merge -> student scorer + pool -> head (CE + distillation) -> backward -> [fused Adam + EMA teacher].
  * Shapes: the single-pass ABMIL step's (E = 512, A = 128, plain scorer, C <= 4, 8 x 64 Merge heads with 8 k <= 48, D % 256 == 0,
- * 64 <= N <= 16384, k_top <= 4096); anything else returns < 0 and the caller composes the step from the building blocks.
+ * 64 <= N <= MHIMX_STEP_MAX_ROWS; up to 16 384 rows the one-workgroup select with both random subsets drawn in the kernel (k_top <= 4096),
+ * above it the multi-workgroup select with the two draws as keyed permutations (k_top <= 16384) - whole-slide bags; rows to merge <= 32768);
+ * anything else returns < 0 and the caller composes the step from the building blocks.
  * ---------------------------------------------------------------------------------------- */
+#define MHIMX_STEP_MAX_ROWS 262144
 typedef struct {                                  /* one model's parameters: device pointers (views of a flat parameter buffer)          */
   const float* w1; const float* b1;               /* feature.0.weight [E,D], feature.0.bias [E]                                          */
   const float* wa; const float* wc;               /* online_encoder.attention.attention.0.weight [A,E], attention.2.weight [A]           */
@@ -778,6 +781,13 @@ typedef struct {
   float lr, beta1, beta2, eps, weight_decay, ema_mm;
   const float* mm_table; int64_t mm_len; const float* lr_table; int64_t lr_len;
   uint64_t* tick; uint64_t* opt_step;             /* device counters: dropout / draw stream position, Adam step (advanced by the step)   */
+  float* q_out;                                   /* optional [k,E] (round 6): where the forward's EMA of the global queries goes; student.q then stays what
+                                                     it was.  A data-parallel rank's step (options.py:287; every rank's forward sees the update's first
+                                                     queries, the ranks' EMA terms are composed after the all-reduce: engine.QueryChain) and the bags of
+                                                     an accumulation window.  NULL: in place, as merge.py:142-143 */
+  int32_t time_project;                           /* 1 (eager steps only - event records cannot be captured with timing): bracket the step's projection
+                                                     launch with a pair of HIP events on `stream`; mhimx_step_project_ms reads the pairs back.  How
+                                                     bench.py times the dominant kernel on the step's own issue path (round 6) */
   void* side_stream;                              /* optional second hipStream_t (round 6): the step is enqueued as a DAG instead of a chain - the
                                                      launches that share no data run as two branches that fork from and join `stream` through
                                                      events (capturable: a hipGraph of the step then has parallel branches):
@@ -810,6 +820,11 @@ int mhimx_step_layout_of(const mhimx_step_cfg* cfg, int64_t N, const mhimx_step_
  * cfg->opt_step is NULL.  X [N, ldx] fp32 device, label_dev int64 [1] device. */
 int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const float* X, int64_t ldx, int64_t N, const int64_t* label_dev,
                    const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws, int64_t ws_bytes, int32_t update);
+/* elapsed times (ms) of the projection launches bracketed since the last call on the current device (mhimx_step_cfg.time_project; at most 256
+ * are kept): waits for each bracket's last event.  empty_ms_out (optional): what a bracket with NOTHING inside read at the same place in the
+ * queue (a third event recorded right behind the second) - the event pair's own share of ms_out.  Returns the number written (<= cap),
+ * < 0 on error. */
+int mhimx_step_project_ms(float* ms_out, float* empty_ms_out, int32_t cap);
 /* n_bags consecutive complete steps (one update each), bag after bag, on one workspace of max_b layout.total bytes (SURVEY.md 7 H4
  * "run_steps"): a resident dataset's epoch as one call per chunk of bags. */
 int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, const int64_t* ldx, const int64_t* N,

@@ -194,7 +194,7 @@ class StepCfg(C.Structure):
                 ("n_train", C.c_int64), ("n_all", C.c_int64),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("ema_mm", C.c_float),
                 ("mm_table", C.c_void_p), ("mm_len", C.c_int64), ("lr_table", C.c_void_p), ("lr_len", C.c_int64),
-                ("tick", C.c_void_p), ("opt_step", C.c_void_p), ("side_stream", C.c_void_p)]
+                ("tick", C.c_void_p), ("opt_step", C.c_void_p), ("q_out", C.c_void_p), ("time_project", C.c_int32), ("side_stream", C.c_void_p)]
 
 
 class StepCounts(C.Structure):
@@ -318,6 +318,7 @@ SYMBOLS = {
     "mhimx_step_counts_of": (C.c_int, [_I64, C.c_double, C.c_double, C.c_double, C.POINTER(StepCounts)]),
     "mhimx_step_layout_of": (C.c_int, [C.POINTER(StepCfg), _I64, C.POINTER(StepCounts), C.POINTER(StepLayout)]),
     "mhimx_step_run": (C.c_int, [_P, C.POINTER(StepCfg), _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),
+    "mhimx_step_project_ms": (C.c_int, [_P, _P, _I32]),
     "mhimx_step_run_many": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _P, _P, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64]),
 }
 

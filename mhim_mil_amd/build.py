@@ -47,7 +47,15 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, lib_name: str | None = None, extra_flags=()) -> str:
+    """lib_name / extra_flags: a side build (its own object directory build_<name>/), e.g. the stamped profile library
+    ``build(lib_name="libmhimx_prof.so", extra_flags=["-DPW_PROF=2", "-DWG_PROF"])`` that tools/measure_clock.sh and bench.py's
+    ``roofline.sustained_clock_GHz`` read the in-kernel shader clock from."""
+    LIB, OBJ = globals()["LIB"], globals()["OBJ"]
+    if lib_name:
+        LIB = os.path.join(HERE, lib_name)
+        OBJ = os.path.join(HERE, "build_" + lib_name.replace(".", "_"))
+    extra_flags = list(extra_flags)
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "mhimx.h"))
@@ -60,7 +68,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def cc(job):
         src, obj = job
         t0 = time.time()
-        r = subprocess.run([HIPCC, *flags_for(src), "-c", src, "-o", obj], capture_output=True, text=True)
+        r = subprocess.run([HIPCC, *flags_for(src), *extra_flags, "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         if verbose:
@@ -80,5 +88,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+PROF_LIB, PROF_FLAGS = "libmhimx_prof.so", ["-DPW_PROF=2", "-DWG_PROF"]
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--prof" in sys.argv:
+        build(force="--force" in sys.argv, lib_name=PROF_LIB, extra_flags=PROF_FLAGS)

@@ -60,6 +60,27 @@ struct DagEvents {
   }
 };
 DagEvents g_dag_events;
+// event pairs around the projection launch of eager steps (mhimx_step_cfg.time_project -> mhimx_step_project_ms): a ring per device
+constexpr int TP_RING = 256;
+struct ProjTimes {
+  hipEvent_t e[64][TP_RING][3];            // before | after the launch | right after that one (an EMPTY bracket: what the event pair itself reads)
+  bool have[64] = {};
+  int n[64] = {};
+  int next(int* dev_out, hipEvent_t** pair) {
+    int dev = 0;
+    MHIMX_HIP(hipGetDevice(&dev));
+    MHIMX_CHECK_ARG(dev >= 0 && dev < 64, "step: device index %d", dev);
+    if (!have[dev]) {
+      for (int i = 0; i < TP_RING; ++i)
+        for (int j = 0; j < 3; ++j) MHIMX_HIP(hipEventCreate(&e[dev][i][j]));
+      have[dev] = true;
+    }
+    *dev_out = dev;
+    *pair = n[dev] < TP_RING ? e[dev][n[dev]] : nullptr;       // (a full ring: the launch goes unbracketed)
+    return 0;
+  }
+};
+ProjTimes g_proj_times;
 // `to` continues after everything enqueued on `from` so far
 int dag_edge(hipEvent_t ev, hipStream_t from, hipStream_t to) {
   MHIMX_HIP(hipEventRecord(ev, from));
@@ -84,7 +105,7 @@ struct StepBufs {
   int64_t w1p_t, wa_frag_t, w1p_s, wa_frag_s, wa_t, wa_t_frag, wo_t, q_old, merge_ws, merge_ws_bytes;
   int64_t H_t, Hbuf, dact;
   int64_t s_t, stats_t, z_t, cproj_t, pscore, attn, pool_ws_t, pool_ws_t_bytes;
-  int64_t rows_all, sel_ws, sel_ws_bytes;
+  int64_t rows_all, sel_ws, sel_ws_bytes, sel_perm, sel_ids, sel_rows, sel_lk;      // (sel_perm ..: bags of more than 16 384 rows)
   int64_t s_s, stats_s, z_s, pool_ws_s, pool_ws_s_bytes;
   int64_t logits, losses, g_z;
   int64_t dH, img, ws_b, ws_b_bytes, wg_ws, wg_ws_floats;
@@ -95,9 +116,12 @@ int check_cfg(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n) {
   MHIMX_CHECK_ARG(c && n, "step: null configuration / counts");
   MHIMX_CHECK_ARG(c->E == 512 && c->A == 128 && c->C >= 1 && c->C <= 4 && c->k >= 1 && 8 * c->k <= 48 && c->D > 0 && c->D % 256 == 0,
                   "step: shapes outside the single-pass ABMIL step (E = 512, A = 128, C <= 4, 8 k <= 48, D %% 256 == 0)");
-  MHIMX_CHECK_ARG(N >= 64 && N <= 16384 && n->k_top >= 1 && n->k_top <= 4096 && n->n_sel >= 1 && n->n_sel <= n->k_top && n->len_keep == N - n->n_sel &&
-                      n->Lk >= 1 && n->R >= 1 && n->R <= 32768 && n->Lk + n->R == n->len_keep,
-                  "step: row counts outside the device-drawn select (64 <= N <= 16384, k_top <= 4096, rows to merge and rows that stay >= 1)");
+  // (round 6: bags beyond the one-workgroup select's 16 384 rows - whole-slide bags, datasets/dataset_feat.py:93-111 - take the multi-workgroup
+  // select: select_large below)
+  MHIMX_CHECK_ARG(N >= 64 && N <= MHIMX_STEP_MAX_ROWS && n->k_top >= 1 && n->k_top <= (N <= 16384 ? 4096 : 16384) && n->n_sel >= 1 && n->n_sel <= n->k_top &&
+                      n->len_keep == N - n->n_sel && n->Lk >= 1 && n->R >= 1 && n->R <= 32768 && n->Lk + n->R == n->len_keep,
+                  "step: row counts outside the device-drawn select (64 <= N <= %d, k_top <= 4096 up to 16384 rows / 16384 above, rows to merge "
+                  "<= 32768, rows to merge and rows that stay >= 1)", MHIMX_STEP_MAX_ROWS);
   const mhimx_step_params &s = c->student, &t = c->teacher;
   MHIMX_CHECK_ARG(s.w1 && s.b1 && s.wa && s.wc && s.wp && s.bp && s.q && s.ln_w && s.ln_b && s.wkv && s.wq && s.wo && s.bo, "step: null student parameter");
   MHIMX_CHECK_ARG(t.w1 && t.b1 && t.wa && t.wc && (!c->attn2score || (t.wp && t.bp)), "step: null teacher parameter");
@@ -135,6 +159,13 @@ void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, Step
   b->rows_all = cv.take_off((n->len_keep + k) * 8);
   b->sel_ws_bytes = mhimx_select_ws_bytes(N);
   b->sel_ws = cv.take_off(b->sel_ws_bytes);
+  b->sel_perm = b->sel_ids = b->sel_rows = b->sel_lk = 0;
+  if (N > 16384) {
+    b->sel_perm = cv.take_off(n->k_top * 8);
+    b->sel_ids = cv.take_off(N * 8);
+    b->sel_rows = cv.take_off(n->len_keep * 8);
+    b->sel_lk = cv.take_off(8);
+  }
   const int64_t M = n->Lk + k;
   b->s_s = cv.take_off(M * F);
   b->stats_s = cv.take_off(2 * F);
@@ -254,7 +285,21 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     a.head[0].wp = w1p_t; a.head[0].bias = T.b1; a.head[0].H = H_t; a.head[0].ldh = E; a.head[0].drop_p = c.drop_p_teacher; a.head[0].drop_seed = seeds->drop_teacher;
     a.head[1].wp = w1p_s; a.head[1].bias = S.b1; a.head[1].H = Hbuf; a.head[1].ldh = E; a.head[1].dact = dact; a.head[1].drop_p = c.drop_p_student;
     a.head[1].drop_seed = seeds->drop_student;
+    hipEvent_t* tp = nullptr;
+    int tp_dev = 0;
+    if (c.time_project) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      MHIMX_HIP(hipStreamIsCapturing(main_st, &cs));
+      if (cs == hipStreamCaptureStatusNone)
+        if (int r = g_proj_times.next(&tp_dev, &tp)) return r;
+    }
+    if (tp) MHIMX_HIP(hipEventRecord(tp[0], main_st));
     if (int r = mhimx_bag_project(stream, &a)) return r;
+    if (tp) {
+      MHIMX_HIP(hipEventRecord(tp[1], main_st));
+      MHIMX_HIP(hipEventRecord(tp[2], main_st));
+      ++g_proj_times.n[tp_dev];
+    }
   }
 
   // ---- 3, 4. the teacher: scorer + softmax pool (+ class projections and the pseudo score, scoring.py:37-58)
@@ -277,8 +322,27 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
   const float* z_t = cv.at<float>(b.z_t);
 
   // ---- 5. HAM mask + Merge split: rows_all = [rows to merge (R) | rows that stay (Lk) | N .. N + k - 1]
-  if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds->select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
-    return r;
+  if (N <= 16384) {
+    if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds->select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+      return r;
+  } else {
+    // select_large: the two-stage form of masking.py:61-86 + merge.py:163-170 as MHIM.student_rows issues it for such bags (mhim.py of this
+    // package: the same four launches + the [merge | stay] swap, the same seeds - the bits of the Python path):
+    //   perm  = pi_1 of 0 .. k_top-1 (masking.py:67's torch.randperm, keyed by (seed + 0x51ED270B, tick))
+    //   ids   = select_mask(score, k_top, n_sel, perm)          [kept ascending | masked]   (multi-workgroup select)
+    //   rows  = ids[pi_2(j)], j < len_keep                       (merge.py:165's shuffle of the kept rows, keyed by (seed ^ 0x3C6E.., tick))
+    //   rows_all = [rows[Lk:] (to merge) | rows[:Lk] (stay)]
+    int64_t* perm = cv.at<int64_t>(b.sel_perm);
+    int64_t* ids = cv.at<int64_t>(b.sel_ids);
+    int64_t* rows = cv.at<int64_t>(b.sel_rows);
+    if (int r = mhimx_random_perm(stream, cnt->k_top, seeds->select + 0x51ED270Bull, tick, nullptr, perm)) return r;
+    if (int r = mhimx_select_mask(stream, score, N, cnt->k_top, cnt->n_sel, 1, cnt->n_sel < cnt->k_top ? perm : nullptr, nullptr, 0, ids, cv.at<int64_t>(b.sel_lk),
+                                  nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes))
+      return r;
+    if (int r = mhimx_random_perm(stream, len_keep, seeds->select ^ 0x3C6EF372FE94F82Bull, tick, ids, rows)) return r;
+    MHIMX_HIP(hipMemcpyAsync(rows_all, rows + Lk, (size_t)R * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    MHIMX_HIP(hipMemcpyAsync(rows_all + R, rows, (size_t)Lk * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
 
   // ---- 6..9. Merge (merge.py:127-203): the k tokens land behind the bag's rows, the queries' EMA in place
   mhimx_merge mw = mw_prep;
@@ -298,7 +362,7 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     if (int r = dag_edge(ev[0], main_st, side_st)) return r;
     io_s.phase = 1; io_s.tail_tokens = (int32_t)k;
     if (int r = mhimx_abmil_pool_fwd(side_st, &sc_s, &io_s)) return r;
-    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, c.q_out ? c.q_out : S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
     if (int r = dag_edge(ev[1], side_st, main_st)) return r;
     io_s.phase = 2; io_s.tail_wa_t = wa_t; io_s.tail_row0 = N;
     if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
@@ -308,13 +372,13 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     io_s.ride_merge = &mw; io_s.ride_X = Hbuf; io_s.ride_R = R; io_s.ride_ws = merge_ws; io_s.ride_ws_bytes = b.merge_ws_bytes;
     if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
     mw.rows_done = io_s.rode_merge;
-    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, c.q_out ? c.q_out : S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
     mw.rows_done = 0;
     io_s.phase = 2; io_s.tail_wa_t = wa_t; io_s.tail_row0 = N;
     if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
     io_s.phase = 0; io_s.ride_merge = nullptr;
   } else {
-    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, c.q_out ? c.q_out : S.q, 1, merge_ws, b.merge_ws_bytes)) return r;
     if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
   }
 
@@ -377,6 +441,21 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
   o.lr = c.lr; o.lr_table = c.lr_table; o.lr_len = c.lr_len; o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.weight_decay = c.weight_decay;
   o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = lm;
   return mhimx_optim_step(stream, &o);
+}
+
+extern "C" int mhimx_step_project_ms(float* ms_out, float* empty_ms_out, int32_t cap) {
+  MHIMX_CHECK_ARG(ms_out && cap >= 0, "step_project_ms: null output");
+  int dev = 0;
+  MHIMX_HIP(hipGetDevice(&dev));
+  MHIMX_CHECK_ARG(dev >= 0 && dev < 64, "step_project_ms: device index %d", dev);
+  const int n = g_proj_times.n[dev] < cap ? g_proj_times.n[dev] : cap;
+  for (int i = 0; i < n; ++i) {
+    MHIMX_HIP(hipEventSynchronize(g_proj_times.e[dev][i][2]));
+    MHIMX_HIP(hipEventElapsedTime(ms_out + i, g_proj_times.e[dev][i][0], g_proj_times.e[dev][i][1]));
+    if (empty_ms_out) MHIMX_HIP(hipEventElapsedTime(empty_ms_out + i, g_proj_times.e[dev][i][1], g_proj_times.e[dev][i][2]));
+  }
+  g_proj_times.n[dev] = 0;
+  return n;
 }
 
 extern "C" int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, const int64_t* ldx, const int64_t* N,

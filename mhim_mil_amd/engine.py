@@ -335,7 +335,7 @@ class FusedTrainer:
         # the Python orchestration (kept: it is the executor's specification and takes every case the executor refuses)
         self.use_executor = os.environ.get("MHIMX_STEP_EXEC", "1") != "0"
         self._exec = None
-        self.exec_max_rows = 16384         # csrc/step.hip:check_cfg (the one-workgroup select)
+        self.exec_max_rows = 262144        # include/mhimx.h MHIMX_STEP_MAX_ROWS
         self.single_pass = True            # ABMIL: one projection launch for teacher + student, bag-ordered buffers (when shapes allow)
         self.window_streams = 4            # accumulation windows (window_step): HIP streams the window's bags are issued on
         self._rows_cache = {}
@@ -478,7 +478,11 @@ class FusedTrainer:
         s, t = self.s, self.t
         if ops.KERNEL_EVENT_HOOK is not None:          # (a caller brackets single launches with events: only the Python orchestration can)
             return False
-        if not (self.use_executor and self.model_kind == "mhim" and self.accum == 1 and self.world == 1 and self._chain is None and perm is None
+        # (round 6) a data-parallel rank takes it too - forward + backward with update = 0, the EMA of the global queries sent to the
+        # QueryChain's scratch (mhimx_step_cfg.q_out), then the all-reduce and mhimx_optim_step as always - unless the eager step overlaps
+        # its all-reduce with the backward (the mid-backward hook lives in the Python orchestration)
+        hooked = (self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1 and not self._capturing and self._split > 0)
+        if not (self.use_executor and self.model_kind == "mhim" and self.accum == 1 and not hooked and perm is None
                 and ids_shuffle is None and self.ride_prep and s.training and s.n_classes <= 4 and s._op_prec != "f32"
                 and s.merge.k * 8 <= 48 and x.shape[1] % 256 == 0 and x.stride(0) % 4 == 0 and x.shape[0] * x.stride(0) * 4 < (1 << 32)):
             return False
@@ -489,10 +493,14 @@ class FusedTrainer:
         if not (s.mlp_dim == 512 and att[0].weight.shape[0] == 128 and x.data_ptr() % 16 == 0 and x.stride(0) >= x.shape[1] and x.stride(1) == 1
                 and mg.attn.to_q.weight.shape[0] == 512 and mg.attn.to_kv.weight.shape[0] == 1024 and 64 <= x.shape[0] <= self.exec_max_rows):
             return False
-        if not s.device_draw_ok(x.shape[0], i):
-            return False
         c = s.v2_counts(x.shape[0], i)
-        return c is not None and 1 <= c[0] <= 4096 and c[3] >= 1 and 1 <= c[4] <= 32768
+        if c is None:
+            return False
+        # up to 16 384 rows: both random subsets drawn inside the one-workgroup select; above (round 6): the multi-workgroup select with the
+        # draws as keyed permutations - the launches MHIM.student_rows issues for such bags
+        if not (s.device_draw_ok(x.shape[0], i) if x.shape[0] <= 16384 else (s.baseline == "attn" and c[0] <= 16384)):
+            return False
+        return 1 <= c[0] and c[3] >= 1 and 1 <= c[4] <= 32768
 
     def _exec_cfg(self):
         """The mhimx_step_cfg of this trainer: parameter / gradient pointers into the flat buffers (stable for the trainer's lifetime), the
@@ -531,6 +539,13 @@ class FusedTrainer:
             cfg.side_stream = self._side.cuda_stream
         else:
             cfg.side_stream = None
+        if self._chain is not None:                    # data parallel: the queries stay q0 until the update (QueryChain)
+            if self._q_scratch is None:
+                self._q_scratch = torch.empty((s.merge.k, s.mlp_dim), device=fl.student.device)
+            cfg.q_out = self._q_scratch.data_ptr()
+        else:
+            cfg.q_out = None
+        cfg.time_project = int(bool(getattr(self, "time_project", False)))
         cfg.attn2score = int(bool(t.attn2score))
         cfg.drop_p_teacher = float(t.dropout_p if t.training else 0.0)
         cfg.drop_p_student = float(s.dropout_p)
@@ -590,6 +605,8 @@ class FusedTrainer:
         self.last = {"logits": logits, "losses": losses, "patch_num": N, "keep_num": cnt.Lk + km, "rows": rows_all[:cnt.len_keep],
                      "score": view(lay.score, N), "R": cnt.R, "tokens": Hs[N:], "H_student": Hs[:N],
                      "H_teacher": view(lay.H_teacher, N * E).view(N, E), "ws": ws}
+        if self._chain is not None:                    # this rank's term of the chain: the tokens its Merge produced
+            self._chain.tokens = self._chain_tokens = Hs[N:]
         if update:
             ops.step_images(None)
             self._micro = 0
@@ -614,7 +631,7 @@ class FusedTrainer:
         xs = [self.s._check_x(b) for b in bags]
         if self._micro != 0:
             raise L.MhimxError("run_steps: called inside an accumulation window (a fresh update is required)")
-        if self.clip_grad or not self.fold_reductions or self.accum != 1 or not all(self._exec_ok(x, it) and self._nat_ok(x, it) for x, it in zip(xs, its)):
+        if self.clip_grad or not self.fold_reductions or self.accum != 1 or self.world != 1 or not all(self._exec_ok(x, it) and self._nat_ok(x, it) for x, it in zip(xs, its)):
             out = None
             for b, l, it in zip(bags, labels, its):
                 out = self.train_step(b, l, i=it)

@@ -113,3 +113,76 @@ def test_run_steps_takes_the_per_bag_path_when_the_executor_cannot_clip():
         tr_e.run_steps(bags, [torch.tensor([1])] * 3)                  # CPU labels
     with pytest.raises(L.MhimxError):
         tr_e.run_steps(bags, labels[:2])
+
+
+@pytest.mark.parametrize("n", [16385, 20000, 40000])
+def test_step_executor_takes_whole_slide_bags(n):
+    """VERDICT r5 missing 1: bags of more than 16 384 rows (datasets/dataset_feat.py:93-111 yields whatever the slide has) ran the Python
+    orchestration.  mhimx_step_run now issues the multi-workgroup select and the two keyed permutations MHIM.student_rows issues for such
+    bags - same launches, same seeds: logits, row lists, parameters and optimiser state agree bit for bit with the Python path."""
+    tr_c, tr_p = _pair_of_trainers()
+    tr_p.use_executor = False
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for step in range(2):
+        x = torch.randn(n, 512, device="cuda", generator=g).abs_()
+        lab = torch.tensor([step % 2], device="cuda")
+        assert tr_c._exec_ok(x)
+        lc, sc = tr_c.train_step(x, lab)
+        lp, sp = tr_p.train_step(x, lab)
+        assert tr_c.last.get("ws") is not None, "the executor did not run"
+        assert torch.equal(lc, lp) and torch.equal(sc, sp), (step, lc, lp)
+        assert torch.equal(tr_c.last["rows"], tr_p.last["rows"]) and torch.equal(tr_c.last["score"], tr_p.last["score"])
+        rows = tr_c.last["rows"]
+        assert rows.unique().numel() == rows.numel() and int(rows.max()) < n            # a set of distinct bag rows
+        for a, b in zip(_state(tr_c), _state(tr_p)):
+            assert torch.equal(a, b), step
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# a data-parallel rank's step through the executor (VERDICT r5 item 6): forward + backward with update = 0 and the global queries' EMA
+# sent to the QueryChain's scratch (mhimx_step_cfg.q_out), then the all-reduce and the update as always
+# ------------------------------------------------------------------------------------------------------------------------------
+def _dp_exec_worker(rank, port, out, use_exec):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)                                   # (both ranks share the box's one GPU; gloo stages through the host)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from mhim_mil_amd.engine import FusedTrainer
+    torch.manual_seed(11)
+    s, t = _models(D=512, dropout=0.25, seed=11)
+    tr = FusedTrainer(s, t, lr=1e-3, mm=0.999, aux_alpha=0.5)
+    assert tr._chain is not None and tr.world == 2
+    tr.overlap_comm = False                                    # (the mid-backward all-reduce hook lives in the Python orchestration)
+    tr.use_executor = bool(use_exec)
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    logits = []
+    for step, n in enumerate((2048, 1500 + 300 * rank, 17000)):
+        x = torch.randn(n, 512, device="cuda", generator=g).abs_()
+        lab = torch.tensor([(step + rank) % 2], device="cuda")
+        lg, _ = tr.train_step(x, lab)
+        assert (tr.last.get("ws") is not None) == bool(use_exec), "wrong step path"
+        logits.append(lg.cpu().clone())
+    torch.cuda.synchronize()
+    torch.save({"logits": logits, "state": [v.cpu() for v in _state(tr)]}, os.path.join(out, f"dpx{int(use_exec)}{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_rank_step_through_the_executor(tmp_path):
+    import os
+    import torch.multiprocessing as mp
+    res = {}
+    for use_exec in (1, 0):
+        port = 42300 + (os.getpid() % 500) + 7 * use_exec
+        mp.spawn(_dp_exec_worker, args=(port, str(tmp_path), use_exec), nprocs=2, join=True)
+        res[use_exec] = [torch.load(os.path.join(tmp_path, f"dpx{use_exec}{r}.pt")) for r in range(2)]
+    for use_exec in (1, 0):                                    # replicas stay bit-identical (parameters, optimiser state, counters)
+        for a, b in zip(res[use_exec][0]["state"], res[use_exec][1]["state"]):
+            assert torch.equal(a, b)
+    for r in range(2):                                         # and the executor's ranks have the bits of the Python orchestration's
+        for a, b in zip(res[1][r]["logits"], res[0][r]["logits"]):
+            assert torch.equal(a, b)
+        for a, b in zip(res[1][r]["state"], res[0][r]["state"]):
+            assert torch.equal(a, b)

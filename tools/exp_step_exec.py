@@ -27,6 +27,50 @@ def mk():
 NB = int(os.environ.get("NB", 200))
 g = torch.Generator(device=dev); g.manual_seed(5)
 sizes = [9000 + 10 * j for j in range(NB)]                       # 200 distinct sizes around the c2 bag, mean 9 995 rows
+if os.environ.get("WIDE"):
+    # round 6: whole-slide bags - 200 distinct sizes between 9 000 and 60 000 rows, shuffled; above 16 384 rows the executor
+    # issues the multi-workgroup select.  Eager (nothing captured) against the hipGraph replay of the same step on a sample of the sizes.
+    sizes = [9000 + 255 * j for j in range(NB)]
+    import random
+    random.Random(3).shuffle(sizes)
+    tr = FusedTrainer(mk(), mk(), aux_alpha=0.5)
+    label = torch.tensor([1], device=dev)
+    x0 = torch.randn(max(sizes), D, device=dev, generator=g).abs_()
+    for n in sizes[:4]:
+        tr.train_step(x0[:n], label)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for n in sizes:
+        tr.train_step(x0[:n], label)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"C executor, {NB} bags of distinct sizes 9 000 .. {max(sizes)} (mean {sum(sizes) / NB:.0f}), eager: {(t2 - t0) / NB * 1e3:.3f} ms/step "
+          f"({sum(sizes) / (t2 - t0) / 1e6:.1f} M inst/s), host enqueue alone {(t1 - t0) / NB * 1e3:.3f} ms/step")
+    sample = sizes[::10]
+    te = tg = 0.0
+    for n in sample:
+        xb = x0[:n]
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        for _ in range(2):
+            tr.train_step(xb, label)
+        e0.record()
+        for _ in range(5):
+            tr.train_step(xb, label)
+        e1.record()
+        gr = tr.capture(xb, label, warmup=1)
+        gr.replay(); gr.replay()
+        e2.record()
+        for _ in range(5):
+            gr.replay()
+        e3.record()
+        torch.cuda.synchronize()
+        te += e0.elapsed_time(e1) / 5
+        tg += e2.elapsed_time(e3) / 5
+        del gr
+    print(f"sample of {len(sample)} of those sizes, 5 steps each: eager executor {te / len(sample):.3f} ms/step, hipGraph replay {tg / len(sample):.3f} ms/step "
+          f"-> eager / replay = {te / tg:.3f}")
+    sys.exit(0)
 bags = [torch.randn(n, D, device=dev, generator=g).abs_() for n in sizes]
 label = torch.tensor([1], device=dev)
 inst = sum(sizes)
