@@ -88,7 +88,7 @@ def build(force: bool = False, verbose: bool = True, lib_name: str | None = None
     return LIB
 
 
-PROF_LIB, PROF_FLAGS = "libmhimx_prof.so", ["-DPW_PROF=2", "-DWG_PROF"]
+PROF_LIB, PROF_FLAGS = "libmhimx_prof.so", ["-DPW_PROF=2", "-DWG_PROF", "-DMHIMX_FT_PROF"]
 
 
 if __name__ == "__main__":

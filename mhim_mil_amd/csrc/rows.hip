@@ -195,6 +195,12 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
 // scorer's arithmetic in fp32 FMAs, 0.33 MFLOP - and merges them with the G partials as K more one-row partials (fixed order).  Block 0 also
 // writes the tokens' u_pre and s where the scorer would have (the backward reads them there).   grid = E / 64, 1024 threads.
 constexpr int FIN_MAXTOK = 6;
+#ifdef MHIMX_FT_PROF                                            // phase stamps of pool_finalize_tok_kernel (block 0): tools/exp_fintok.py
+__device__ unsigned long long ft_prof[16];
+#define FT_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) ft_prof[i] = wall_clock64(); } while (0)
+#else
+#define FT_STAMP(i)
+#endif
 __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                                          const float* __restrict__ pz, int G, int E, float* __restrict__ stats,
                                                                          float* __restrict__ z, const float* __restrict__ T,
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
   __shared__ float us[FIN_MAXTOK][128];
   __shared__ float stok[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FT_STAMP(0);
   // the partial statistics and this wave's first 8 pooled rows: requested now, in flight under the token scoring
   const float pm1 = tid < G ? pm[tid] : -INFINITY, pl1 = tid < G ? pl[tid] : 0.f;
   const int e = blockIdx.x * 64 + lane;
@@ -230,6 +237,12 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
     }
     reinterpret_cast<float4*>(&tks[i][0])[c4] = v;
   }
+  // Round 6, stamped (tools/exp_fintok.py, block 0 inside a c2 step, us): weights + token rows landed 4.0 | products + chunk sums 3.3 | token
+  // scores 1.0 | statistics 1.2 | pooled rows + z 1.9 = 11.4 of the launch's ~12.  Measured and not kept: the token product on the matrix cores
+  // (the one-pass scorer's 3-term bf16 form; wave = 16 scorer columns x half of K, 16 float4 of weights per lane): loads 4.0 -> 8.2 us (a
+  // lane's 32-byte pieces of 16 different weight rows against 128 coalesced lanes of the transposed weight), products 3.3 -> 5.0 us (the bf16
+  // splits); the second batch of pooled rows requested ahead of the scores: the last phase 2.1 -> 1.7 us, the phase that issues them 1.0 ->
+  // 1.6 us - nothing at step level (0.3047-0.3056 ms either way).
   if (wa_t && A == 128 && E == 512) {
     // thread = (scorer column a, chunk of 64 feature dims): the transposed weight is read coalesced (128 threads x 4 B per dim), 16 loads in
     // flight, the tokens broadcast from LDS; no cross-lane reduction - the 8 chunk partials meet in LDS
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
     for (int u = 0; u < 64; ++u) wv[u] = wp[(int64_t)u * A];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (a fence for the scheduler: the 64 loads are issued above it, as one batch)
     __syncthreads();                                          // the token rows are in LDS
+    FT_STAMP(1);
 #pragma unroll
     for (int u4 = 0; u4 < 64; u4 += 4) {
 #pragma unroll
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
     }
   }
   __syncthreads();
+  FT_STAMP(2);
   if (blockIdx.x == 0)
     for (int idx = tid; idx < K * A; idx += FIN_THREADS) u_pre_tail[idx] = us[idx / A][idx % A];
   if (wave < K) {                                             // wave i: s_i = wc . act(u_i) + bc   (A = 128: two per lane)
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
     }
   }
   // ---- statistics over the G partials and the K tokens
+  FT_STAMP(3);
   float m = wave_max(pm1);
   if (lane == 0) red[wave] = m;
   __syncthreads();
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
     wt[i] = i < K ? __expf(stok[i] - mx) : 0.f;
     L += wt[i];
   }
+  FT_STAMP(4);
   float acc = 0.f;
   if (e < E) {
 #pragma unroll
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
     z[e] = a / L;
   }
   if (blockIdx.x == 0 && tid == 0) { stats[0] = mx; stats[1] = L; }
+  FT_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1427,6 +1445,9 @@ extern "C" int mhimx_pool_finalize(void* stream, const float* pm, const float* p
   return 0;
 }
 
+#ifdef MHIMX_FT_PROF
+extern "C" int mhimx_ft_prof_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mhimx::ft_prof), 16 * 8); }
+#endif
 extern "C" int mhimx_reduce_flush(void* stream, mhimx_reduce_list* list) { return reduce_flush((hipStream_t)stream, list); }
 extern "C" int mhimx_colsum(void* stream, const float* X, int64_t M, int64_t E, float* out, int32_t accumulate, void* ws,
                             int64_t ws_bytes) {

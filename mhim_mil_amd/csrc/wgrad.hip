@@ -603,7 +603,7 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, Wgr
     const uint64_t wp_t3 = __builtin_readcyclecounter();
     float* pr = reinterpret_cast<float*>(const_cast<char*>(gimg) + (int64_t)g.ksteps * nIT * WA_BYTES) + wave * 4;
     pr[0] = (float)(wp_t1 - wp_t0); pr[1] = (float)(wp_t2 - wp_t1); pr[2] = (float)(wp_t3 - wp_t2); pr[3] = (float)nk;
-    if (wave == 0) { pr[32] = (float)(wall_clock64() - wp_rt0); pr[33] = (float)(wp_t3 - wp_t0); }     // 10 ns ticks | shader cycles, entry -> end
+    if (wave == 4) { pr[32 - 16] = (float)(wall_clock64() - wp_rt0); pr[33 - 16] = (float)(wp_t3 - wp_t0); }   // (wave 4 = the first consumer wave: pr = base + 16) 10 ns ticks | shader cycles, entry -> end
   }
 #endif
 }

@@ -11,7 +11,7 @@ echo "== projection, c5 shape (N=200000, D=1536), 20 launches"
 MHIMX_LIB_NAME=libmhimx_prof.so REPS=20 N=200000 D=1536 python tools/exp_proj_prof.py 2>&1 | grep "GHz\|wave 0: entry"
 echo "== weight gradient, c2 shape (100 launches back to back, then the stamped one)"
 MHIMX_LIB_NAME=libmhimx_prof.so WG_PROF=1 python tools/exp_wgrad.py 2>&1 | grep "GHz\|wave\|wgrad"
-echo "== rocm-smi during bench.py c2 (400 steps x 3 regions)"
+echo "== rocm-smi during bench.py c2 (4000 steps; the tool polls slower than the clock moves: kept only to show that it cannot answer the question)"
 ( for i in $(seq 1 40); do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Socket Power\|mclk" | tr '\n' ' '; echo; sleep 0.25; done ) > gpurun_out/r06_smi.txt &
 SMI=$!
 python bench.py --no-extras --cpu-steps 0 --steps 4000 --warmup 40 2>/dev/null | cut -c1-200
