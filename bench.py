@@ -742,7 +742,7 @@ def main():
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
             # (tools/pmc.sh + tools/pmc_project.py; counters cannot be read from inside the process being timed)
             traffic, tsrc = None, None
-            for pmc_name in ("r05_pmc_bag_project.json", "r04_pmc_bag_project.json", "r03_pmc_bag_project.json", "r02_pmc_bag_project.json"):
+            for pmc_name in ("r06_pmc_bag_project.json", "r05_pmc_bag_project.json", "r04_pmc_bag_project.json", "r03_pmc_bag_project.json", "r02_pmc_bag_project.json"):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
                 if os.path.exists(pmc):
                     pj = json.load(open(pmc))
@@ -751,12 +751,12 @@ def main():
                                                           f"{pj['write_bytes'] / 1e6:.1f} MB per launch")
                     break
             step_traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r05_pmc_traffic_c2.json")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", nm) for nm in ("r06_pmc_traffic_c2.json", "r05_pmc_traffic_c2.json")) if os.path.exists(q)), "")
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 step_traffic = {"bytes_per_step": pj["step_traffic_bytes"], "read": pj["step_read_bytes"], "write": pj["step_write_bytes"],
                                 "over_algorithmic": pj["traffic_over_algorithmic"],
-                                "source": "profiles/r05_pmc_traffic_c2.md: FETCH_SIZE x2 + WRITE_SIZE over every launch of one step (two --pmc passes)"}
+                                "source": f"profiles/{os.path.basename(pmc)[:-5]}.md: FETCH_SIZE x2 + WRITE_SIZE over every launch of one step (two --pmc passes)"}
             # SURVEY 8(d) / BASELINE.md section 4: the HBM fraction on the ALGORITHMIC bytes is the headline figure of the dominant kernel - this
             # launch stands for two of the step's three passes over X (4096 B per instance each); the matrix-core figures sit beside it.
             # attainable: every product runs as 3 bf16 terms (section 3 of DESIGN.md: two terms miss the 1e-4 logit bound under peaked

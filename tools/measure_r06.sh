@@ -26,8 +26,8 @@ if has c2; then
   rm -f gpurun_out/prof_r06/r06_results.db
 fi
 if has pmc; then
-  tools/pmc.sh fetch FETCH_SIZE $ROOT/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-graph --no-kernel-events --no-extras > $O/pmc_fetch.md 2>&1
-  tools/pmc.sh write WRITE_SIZE $ROOT/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-graph --no-kernel-events --no-extras > $O/pmc_write.md 2>&1
+  tools/pmc.sh fetch FETCH_SIZE $ROOT/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-graph --no-kernel-events --no-extras --no-repeats > $O/pmc_fetch.md 2>&1
+  tools/pmc.sh write WRITE_SIZE $ROOT/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-graph --no-kernel-events --no-extras --no-repeats > $O/pmc_write.md 2>&1
   python tools/pmc_project.py gpurun_out/pmc_fetch/fetch_results.db gpurun_out/pmc_write/write_results.db $O/pmc_bag_project > /dev/null 2>&1
   python tools/pmc_step.py gpurun_out/pmc_fetch/fetch_results.db gpurun_out/pmc_write/write_results.db 25 123080000 $O/pmc_traffic_c2 "bench.py c2 (N=10 000, D=1024), eager, 25 steps" > /dev/null 2>&1
   rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
