@@ -321,16 +321,23 @@ MHIMX_DEV void merge2_bwd_pre_body(int block, float* lds, const float* __restric
   const uint64_t seed = drop_p > 0.f ? eff_seed(seed0, tick) : 0;
   const float ks = 1.f / (1.f - drop_p);
   const float dbo_old = (h == 0 && tid < 64 && accumulate) ? d_bo[e] : 0.f;
+  bool gave_up = false;
   if (gate) {
     if (tid == 0) {
       unsigned spins = 0;
       while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_target && ++spins < M2_GATE_SPINS) __builtin_amdgcn_s_sleep(1);
+      doh[0] = spins >= M2_GATE_SPINS ? 1.f : 0.f;            // (doh is written for real only after the loop below)
     }
+    __syncthreads();
+    // the backstop expired (it cannot in a launch whose producers are dispatched first; a preempted or CU-masked queue could): the gradients
+    // of this Merge are POISONED with NaN instead of being computed from stale rows of dz - a loud failure, not a silent one
+    gave_up = doh[0] != 0.f;
     __syncthreads();
   }
   for (int idx = tid; idx < k * M2_E; idx += M2_THREADS) {
     const int i = idx >> 9, ee = idx & 511;
     float v = gate ? __hip_atomic_load(dz + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dz[idx];
+    if (gave_up) v = __builtin_nanf("");
     if (drop_p > 0.f) v = drop_keep(seed, (uint64_t)i, (uint32_t)ee, drop_p) ? v * ks : 0.f;
     dzs[idx] = v;
   }
