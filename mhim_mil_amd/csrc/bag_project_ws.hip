@@ -577,7 +577,11 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
       if (dact) {
         pw_h4 d;
         for (int q = 0; q < 4; ++q) { d[q] = (_Float16)(v[q] * ks[q]); v[q] = v[q] * ks[q]; }
+#ifdef MHIMX_PROJ_WT2
+        st_b8_wt(dact + m * g.E + n, __builtin_bit_cast(f32x2_wt, d));
+#else
         *reinterpret_cast<pw_h4*>(dact + m * g.E + n) = d;
+#endif
       } else
 #endif
       if (dact) {
@@ -589,7 +593,11 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
           v[q] = y * ks[q];
           d[q] = (_Float16)(gq * ks[q]);
         }
+#ifdef MHIMX_PROJ_WT2
+        st_b8_wt(dact + m * g.E + n, __builtin_bit_cast(f32x2_wt, d));
+#else
         *reinterpret_cast<pw_h4*>(dact + m * g.E + n) = d;
+#endif
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = act_fwd(v[q], g.act) * ks[q];
@@ -600,7 +608,11 @@ __global__ __launch_bounds__(WTHREADS) void bag_project_ws_kernel(mhimx_bag_proj
         rq2 = ld_res(r + 3 * (W_CONS + W_PROD));
         v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
       }
+#if defined(MHIMX_PROJ_WT) || defined(MHIMX_PROJ_WT2)
+      st_f4_wt(H.H + m * H.ldh + n, f32x4{v[0], v[1], v[2], v[3]});
+#else
       *reinterpret_cast<f32x4*>(H.H + m * H.ldh + n) = f32x4{v[0], v[1], v[2], v[3]};
+#endif
     }
     PE_MARK(3);
   }

@@ -10,6 +10,18 @@
 namespace mhimx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// a 16-byte store that goes THROUGH the XCD's L2 to memory as it is issued (sc1: the line is not kept dirty in L2) - for outputs the next
+// LAUNCH reads: a kernel ends with a write-back of every dirty L2 line (MI355X_MICROARCH.md "boundary", "publish-large").
+// MEASURED, round 6 (side builds -DMHIMX_PROJ_WT2 / -DMHIMX_IMG_WT / -DMHIMX_SLAB_WT: the projection's feature rows + d out / d pre, the dPRE
+// image, the weight gradient's split-K slabs; parity tests green): the producers get shorter (projection 65.0 -> 63.1 us, image 13.7 -> 12.2,
+// weight gradient 46.2 -> 45.5) and their consumers longer by the same (teacher scorer 21.1 -> 23.4, Adam 18.1 -> 19.2): one step on the
+// timeline 308.7 -> 309.5 us under the profiler, 0.3084-0.3117 -> 0.3051-0.3054 ms in `tools/ab.sh` (inside the box's run-to-run spread).
+// The write-back a launch boundary pays is not saved, it moves.  Not enabled.
+// (the s_nop: a VMEM store of more than 8 bytes must not be followed at once by a VALU write of its data registers - the compiler's hazard
+// recogniser does not look into asm, and without the wait states the next store's address arithmetic overwrote the data: NaN images)
+__device__ __forceinline__ void st_f4_wt(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory"); }
+typedef float f32x2_wt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_b8_wt(void* p, const f32x2_wt& v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory"); }
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const void* gptr_f;
 typedef __attribute__((address_space(3))) void* lptr_f;

@@ -594,8 +594,12 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_ws_kernel(WgradArgs g, Wgr
       for (int e = 0; e < 4; ++e) {
         const int64_t i = i0 + 4 * (16 * wm + 4 * kg + e) + ja;
         const int64_t n = n0 + 4 * (16 * (2 * wn + cb) + r16);
+#ifdef MHIMX_SLAB_WT
+        st_f4_wt(out + i * g.D + n, f32x4{acc[ja][4 * cb + 0][e], acc[ja][4 * cb + 1][e], acc[ja][4 * cb + 2][e], acc[ja][4 * cb + 3][e]});
+#else
         *reinterpret_cast<f32x4*>(out + i * g.D + n) =
             f32x4{acc[ja][4 * cb + 0][e], acc[ja][4 * cb + 1][e], acc[ja][4 * cb + 2][e], acc[ja][4 * cb + 3][e]};
+#endif
       }
 #ifdef WG_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -951,8 +955,13 @@ __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __res
       const float kv[8] = {gv[0][j], gv[1][j], gv[2][j], gv[3][j], gv[4][j], gv[5][j], gv[6][j], gv[7][j]};
       f32x4 hi, lo;
       wg_split8(kv, hi, lo);
+#ifdef MHIMX_IMG_WT
+      st_f4_wt(reinterpret_cast<float*>(tile + j * 512), hi);
+      st_f4_wt(reinterpret_cast<float*>(tile + j * 512 + 2048), lo);
+#else
       *reinterpret_cast<f32x4*>(tile + j * 512) = hi;
       *reinterpret_cast<f32x4*>(tile + j * 512 + 2048) = lo;
+#endif
     }
   }
   if (part) {                                                   // the four octets' column sums -> one partial row per k-step
