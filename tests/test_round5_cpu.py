@@ -58,3 +58,31 @@ def test_schedule_at_updates_follows_the_loop_update_rule():
     got = schedule_at_updates(sche, 4, 10)                                   # updates at bags 3, 7, 9 of every epoch
     assert got == [3, 7, 9, 13, 17, 19, 23, 27, 29]
     assert schedule_at_updates(sche, 1, 10) == sche
+
+
+def test_step_layout_takes_whole_slide_bags_and_refuses_beyond_the_limit():
+    """mhimx_step_layout_of is host code: the executor's shape checks (csrc/step.hip:check_cfg) without a GPU.  Round 6: bags up to
+    MHIMX_STEP_MAX_ROWS = 262 144 rows (the multi-workgroup select above 16 384), k_top <= 16 384, rows to merge <= 32 768."""
+    import ctypes as C
+    from mhim_mil_amd import _lib as L
+    lib = L.lib()
+    one = C.c_void_p(256)                                  # any non-null "device pointer": nothing is dereferenced on the host
+    par = L.StepParams(**{f: 256 for f, _ in L.StepParams._fields_})
+    grd = L.StepGrads(**{f: 256 for f, _ in L.StepGrads._fields_})
+    cfg = L.StepCfg(D=1024, E=512, A=128, C=2, k=5, act=2, da_act=1, attn2score=1, student=par, teacher=par, grad=grd, tick=256)
+    totals = []
+    for n in (64, 10000, 16384, 16385, 60000, 262144):
+        cnt, lay = L.StepCounts(), L.StepLayout()
+        assert lib.mhimx_step_counts_of(n, 0.03, 0.5, 0.9, C.byref(cnt)) == 0
+        assert lib.mhimx_step_layout_of(C.byref(cfg), n, C.byref(cnt), C.byref(lay)) == 0, (n, lib.mhimx_last_error())
+        assert lay.total > 0 and lay.rows_all > 0 and lay.logits > 0
+        totals.append(lay.total)
+    assert totals == sorted(totals)
+    cnt, lay = L.StepCounts(), L.StepLayout()
+    assert lib.mhimx_step_counts_of(262145, 0.03, 0.5, 0.9, C.byref(cnt)) == 0
+    assert lib.mhimx_step_layout_of(C.byref(cfg), 262145, C.byref(cnt), C.byref(lay)) < 0
+    assert b"262144" in lib.mhimx_last_error()
+    # a recipe that leaves more than 32 768 rows to merge (merge_ratio 0.5 on 200 000 rows) is refused as well
+    assert lib.mhimx_step_counts_of(200000, 0.03, 0.5, 0.5, C.byref(cnt)) == 0 and cnt.R > 32768
+    assert lib.mhimx_step_layout_of(C.byref(cfg), 200000, C.byref(cnt), C.byref(lay)) < 0
+    _ = one

@@ -115,16 +115,16 @@ def test_run_steps_takes_the_per_bag_path_when_the_executor_cannot_clip():
         tr_e.run_steps(bags, labels[:2])
 
 
-@pytest.mark.parametrize("n", [16385, 20000, 40000])
-def test_step_executor_takes_whole_slide_bags(n):
+@pytest.mark.parametrize("n,D", [(16385, 512), (20000, 512), (40000, 512), (120000, 256)])
+def test_step_executor_takes_whole_slide_bags(n, D):
     """VERDICT r5 missing 1: bags of more than 16 384 rows (datasets/dataset_feat.py:93-111 yields whatever the slide has) ran the Python
     orchestration.  mhimx_step_run now issues the multi-workgroup select and the two keyed permutations MHIM.student_rows issues for such
     bags - same launches, same seeds: logits, row lists, parameters and optimiser state agree bit for bit with the Python path."""
-    tr_c, tr_p = _pair_of_trainers()
+    tr_c, tr_p = _pair_of_trainers(D=D)
     tr_p.use_executor = False
     g = torch.Generator(device="cuda").manual_seed(n)
     for step in range(2):
-        x = torch.randn(n, 512, device="cuda", generator=g).abs_()
+        x = torch.randn(n, D, device="cuda", generator=g).abs_()
         lab = torch.tensor([step % 2], device="cuda")
         assert tr_c._exec_ok(x)
         lc, sc = tr_c.train_step(x, lab)
