@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* bumped whenever an entry point or a struct changes shape; the ctypes binding (mhim_mil_amd/_lib.py ABI_VERSION) refuses any other value */
-#define MHIMX_VERSION 600
+#define MHIMX_VERSION 610
 
 /* activations (feature act: mhim.py:71-74 relu|gelu|none; scorer act: baseline.py:17-22 gelu|relu|tanh|none) */
 enum { MHIMX_ACT_NONE = 0, MHIMX_ACT_RELU = 1, MHIMX_ACT_GELU = 2, MHIMX_ACT_TANH = 3 };
@@ -263,7 +263,7 @@ int mhimx_pair_planes(void* stream, const float* x, int64_t ldx, int64_t M, int6
  * 10 = ((int64_t*)out)[i] = R + i for i < C (in unused): the constant tail of a step's row list - the ids N .. N + k - 1 of the k merged-token
  *     rows behind a bag's N feature rows (mhimx_step_run writes it with the step's first launch).
  */
-#define MHIMX_PREP_MAX 24
+#define MHIMX_PREP_MAX 32
 typedef struct { int32_t kind; const float* in; float* out; int64_t R, C; } mhimx_prep_job;
 int mhimx_prep_batch(void* stream, const mhimx_prep_job* jobs, int32_t n);
 
@@ -756,6 +756,7 @@ int mhimx_optim_step(void* stream, const mhimx_optim_args* a);
  * anything else returns < 0 and the caller composes the step from the building blocks.
  * ---------------------------------------------------------------------------------------- */
 #define MHIMX_STEP_MAX_ROWS 262144
+#define MHIMX_WINDOW_MAX 8                        /* bags of one mhimx_window_run */
 typedef struct {                                  /* one model's parameters: device pointers (views of a flat parameter buffer)          */
   const float* w1; const float* b1;               /* feature.0.weight [E,D], feature.0.bias [E]                                          */
   const float* wa; const float* wc;               /* online_encoder.attention.attention.0.weight [A,E], attention.2.weight [A]           */
@@ -830,6 +831,24 @@ int mhimx_step_project_ms(float* ms_out, float* empty_ms_out, int32_t cap);
 int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, const int64_t* ldx, const int64_t* N,
                         const int64_t* const* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step0,
                         void* ws, int64_t ws_bytes);
+
+/* An accumulation window (--accumulation_steps n, base_engine.py:29,47-49,100-119: n bags share the weights, their gradients add up, ONE
+ * optimiser step) with every launch over ALL its bags (round 6): one preparation, both projections of the n bags in one launch, the step's
+ * middle (teacher scorer, select, Merge, student scorer, head, backward to the dPRE image) issued once with one grid plane per bag, ONE
+ * weight-gradient launch over the n images, the EMA chain of the global queries, Adam + EMA: ~22 launches instead of n x 16.
+ * The bags have ONE shape: X[b] [N, ldx] fp32 device (b < n_bags, 2 <= n_bags <= MHIMX_WINDOW_MAX), N <= 16384, merge_k <= 6; labels_dev
+ * int64 [n_bags] CONTIGUOUS on the device; seeds [n_bags]; cfg as for mhimx_step_run with every cfg->grad view inside cfg->g[0, n_train)
+ * (q_out, side_stream, time_project unused: NULL / 0).  Every bag's loss is scaled by 1 / n_bags.  Per bag the arithmetic is
+ * mhimx_step_run(update = 0)'s with that bag's seeds and the window's FIRST global queries (the queries' EMA is chained over the n token sets
+ * afterwards: q <- mm^n q + (1 - mm) sum_b mm^(n-1-b) z_b - second order in 1 - merge_mm against the bag-after-bag order).
+ * update = 1: Adam + EMA on the summed gradient; update = 0: the summed gradient is left in cfg->g.
+ * Workspace: mhimx_window_layout_of(...).total bytes, 256-byte aligned; bag b's copy of a per-bag buffer lies at layout.bag.<field> +
+ * b * bag_stride (logits, losses, score, rows_all, ...); bag b's gradient slab (everything but feature.0.weight) at grad_slab + b * bag_stride. */
+typedef struct { int64_t total, bag0, bag_stride, grad_slab; mhimx_step_layout bag; } mhimx_window_layout;
+int mhimx_window_layout_of(const mhimx_step_cfg* cfg, int32_t n_bags, int64_t N, const mhimx_step_counts* cnt, mhimx_window_layout* out);
+int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, int64_t ldx, int64_t N,
+                     const int64_t* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws,
+                     int64_t ws_bytes, int32_t update);
 
 /* dst = src (float4 grid-stride stream copy): the on-box HBM copy rate bench.py reports beside the nominal 8 TB/s */
 int mhimx_stream_copy(void* stream, const float* src, float* dst, int64_t n_floats);

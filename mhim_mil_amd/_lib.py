@@ -12,7 +12,7 @@ c_f32p = C.c_void_p
 c_i64p = C.c_void_p
 c_u8p = C.c_void_p
 
-ABI_VERSION = 600          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
+ABI_VERSION = 610          # == MHIMX_VERSION of the include/mhimx.h this binding was written against
 
 ACT = {None: 0, "none": 0, "identity": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"f32": 0, "f16s": 1, "bf16x3": 2}
@@ -210,6 +210,13 @@ class StepLayout(C.Structure):
                                         "z_student", "g_z", "dH")]
 
 
+class WindowLayout(C.Structure):
+    """mhimx_window_layout: bag b's copy of a per-bag buffer lies at bag.<field> + b * bag_stride."""
+    _fields_ = [("total", C.c_int64), ("bag0", C.c_int64), ("bag_stride", C.c_int64), ("grad_slab", C.c_int64), ("bag", StepLayout)]
+
+
+WINDOW_MAX = 8               # MHIMX_WINDOW_MAX
+
 SYMBOLS = {
     "mhimx_last_error": (C.c_char_p, []),
     "mhimx_version": (C.c_int, []),
@@ -319,6 +326,8 @@ SYMBOLS = {
     "mhimx_step_layout_of": (C.c_int, [C.POINTER(StepCfg), _I64, C.POINTER(StepCounts), C.POINTER(StepLayout)]),
     "mhimx_step_run": (C.c_int, [_P, C.POINTER(StepCfg), _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),
     "mhimx_step_project_ms": (C.c_int, [_P, _P, _I32]),
+    "mhimx_window_layout_of": (C.c_int, [C.POINTER(StepCfg), _I32, _I64, C.POINTER(StepCounts), C.POINTER(WindowLayout)]),
+    "mhimx_window_run": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),
     "mhimx_step_run_many": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _P, _P, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64]),
 }
 

@@ -100,8 +100,42 @@ struct Arena {
   bool ok() const { return off <= cap && (base != nullptr || off == 0); }
 };
 
+// ---------------------------------------------------------------- bag batching (round 6: mhimx_window_run, step.hip)
+// The launches between the projection and the weight gradient of an accumulation window are issued ONCE for all its bags: gridDim.z = bags,
+// blockIdx.z = the bag a workgroup works for.  The bags have the same shape and each owns a copy of the step's workspace at a fixed stride,
+// so the host enqueues the window's middle exactly as it enqueues one bag's - with bag 0's pointers - and every kernel on that path starts
+// by moving the pointers it was given to its own bag's copy: a pointer inside one of (up to three) address ranges moves by bag * stride of
+// that range (the per-bag workspace; the labels, 8 bytes apart); any other pointer (parameters, prepared weight images, the dropout tick)
+// is shared by the bags and stays.  Seeds: a bag's counter-hash streams differ from bag 0's by a per-bag additive constant (every seed the
+// host derives is seed + constant).  A plain launch has n = 0 and gridDim.z = 1: blockIdx.z = 0 moves nothing.
+constexpr int BAG_BATCH_MAX = MHIMX_WINDOW_MAX;
+struct BagBatch {
+  int32_t n, pad;
+  uint64_t lo[3], span[3];
+  int64_t stride[3];
+  uint64_t dsel[BAG_BATCH_MAX], dmca[BAG_BATCH_MAX];       // seed of bag b = seed of bag 0 + d*[b] (the select's / Merge's streams)
+};
+// host: the batch the calling thread is enqueueing (none: n = 0), set by the window executor around the window's middle
+const BagBatch& cur_batch();
+void set_batch(const BagBatch* b);
+inline dim3 bgrid(unsigned x, unsigned y = 1) { return dim3(x, y, cur_batch().n > 0 ? (unsigned)cur_batch().n : 1u); }
+
 // ---------------------------------------------------------------- device helpers
 #define MHIMX_DEV __device__ __forceinline__
+
+template <typename T>
+MHIMX_DEV T* bag_ptr(T* p, const BagBatch& bb) {
+  const unsigned bag = blockIdx.z;
+  if (bag == 0) return p;
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    if (a - bb.lo[r] < bb.span[r]) return reinterpret_cast<T*>(a + (uint64_t)bag * (uint64_t)bb.stride[r]);
+  return p;
+}
+#define MHIMX_BAG(p) p = ::mhimx::bag_ptr(p, bb)
+MHIMX_DEV uint64_t bag_sel_seed(uint64_t s, const BagBatch& bb) { return blockIdx.z ? s + bb.dsel[blockIdx.z] : s; }
+MHIMX_DEV uint64_t bag_mca_seed(uint64_t s, const BagBatch& bb) { return blockIdx.z ? s + bb.dmca[blockIdx.z] : s; }
 
 // erf to fp32 rounding level (|error| <= 1.5e-7, Abramowitz & Stegun 7.1.26) in ~14 VALU operations instead of the ~40 of
 // the library erff: the GELU epilogues are VALU-bound tails of their kernels.

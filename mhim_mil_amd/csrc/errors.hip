@@ -16,6 +16,14 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 const std::string& last_error() { return g_err; }
+
+// the bag batch the calling thread is enqueueing (common.hpp: BagBatch)
+static thread_local BagBatch g_batch = {};
+const BagBatch& cur_batch() { return g_batch; }
+void set_batch(const BagBatch* b) {
+  if (b) g_batch = *b;
+  else g_batch = BagBatch{};
+}
 }  // namespace mhimx
 
 extern "C" const char* mhimx_last_error(void) { return mhimx::last_error().c_str(); }

@@ -501,6 +501,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ ws, float* __restr
 int reduce_slabs_now(hipStream_t st, const float* ws, float* C, int64_t K1, int64_t K2, int64_t ldc, int splits, int accumulate, int batch,
                      int64_t sC) {
   const int64_t n = K1 * K2;
+  MHIMX_CHECK_ARG(cur_batch().n == 0, "reduce: a bag-batched launch queues its slab sums (mhimx_reduce_list full?)");
   if (batch == 1 && reduce_slabs_as_parts(splits, K1, K2, ldc)) return reduce_parts_now(st, ws, splits, n, n, C, accumulate);
   const int blocks = (int)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048);
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks, batch), dim3(256), 0, st, ws, C, K1, K2, ldc, splits, accumulate, sC);
@@ -535,6 +536,7 @@ static int gemm_tn_impl(hipStream_t st, const mhimx_gemm_tn_args& g, const Merge
   MHIMX_CHECK_ARG(g.M >= 0 && g.K1 > 0 && g.K2 > 0, "gemm_tn: bad dims");
   MHIMX_CHECK_ARG(g.A && g.B && g.C, "gemm_tn: null operand");
   MHIMX_CHECK_ARG(g.splits <= 1 || g.ws, "gemm_tn: splits>1 needs ws");
+  MHIMX_CHECK_ARG(cur_batch().n == 0 || (g.M > SKINNY_M && tn_dma_ok(g) && g.defer), "gemm_tn: a bag-batched launch takes the LDS-DMA product with its slab sum queued");
   if (g.M <= SKINNY_M) {
     hipLaunchKernelGGL(skinny_tn_kernel, dim3((unsigned)cdiv(g.K2, 256), (unsigned)g.K1), dim3(256), 0, st, g);
     MHIMX_LAUNCH_CHECK();

@@ -394,10 +394,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_dma_kernel(mhimx_gemm_nt_args
 // caller sizes the product so that tiles + riders fit the chip at once) - an instantiation of its own, so that the plain product keeps its
 // register count and occupancy.
 template <int PREC, int ROWS = 0>
-__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, int side_stage, Merge2Side side) {
+__global__ __launch_bounds__(DTHREADS) void gemm_tn_dma_kernel(mhimx_gemm_tn_args g, int64_t mchunk, int side_blocks, int side_stage, Merge2Side side,
+                                                               BagBatch bb) {
   using FR = Frag<PREC>;
   using V8 = typename FR::V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.z) {
+    g.A = bag_ptr(g.A, bb); g.B = bag_ptr(g.B, bb); g.C = bag_ptr(g.C, bb); g.ws = bag_ptr(g.ws, bb); g.rows = bag_ptr(g.rows, bb);
+    if (side_blocks > 0) bag_move(side, bb);
+  }
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 2): its few short workgroups are
     if constexpr (ROWS != 0) {                   // dispatched first and free their slots early
       if ((int)blockIdx.x < side.w.T)
@@ -678,7 +683,11 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   int rows_blocks = 0;
   if (rows_ride) {
     rows_blocks = (int)align_up(rider->w.T, 8);
-    const int64_t room = 256 - rows_blocks;
+    // (a bag-batched launch - common.hpp: every bag of the window brings its own product and row tiles - sizes each bag's product for its share
+    // of two rounds of the chip, at least 8 slabs)
+    const int nbags = cur_batch().n > 0 ? cur_batch().n : 1;
+    int64_t room = (nbags > 1 ? 512 / nbags : 256) - rows_blocks;
+    if (nbags > 1 && room < 8 * tiles) room = 8 * tiles;
     int cap = (int)(room / tiles) / 8 * 8;
     if (cap < 8 || rows_blocks > 128) rows_blocks = 0;            // no room for the product beside the rows: they do not ride
     else if (splits > cap) splits = cap;
@@ -700,11 +709,11 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
     if (smem < rows_smem) smem = rows_smem;
     side = *rider;
     if (rode) *rode = true;
-    dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + rows_blocks));
+    dim3 grid = bgrid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + rows_blocks));
     if (side.w.rt == 16)
-      hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 16>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side);
+      hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 16>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side, cur_batch());
     else
-      hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 32>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side);
+      hipLaunchKernelGGL((gemm_tn_dma_kernel<MHIMX_PREC_BF16X3, 32>), grid, dim3(DTHREADS), smem, st, g, mchunk, rows_blocks, 4, side, cur_batch());
     MHIMX_LAUNCH_CHECK();
     return splits;
   }
@@ -719,8 +728,8 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
     if (side_blocks % 8 == 0) g.defer->side.pending = 3;
     else side_blocks = 0;
   }
-  dim3 grid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + side_blocks));
-  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk, side_blocks, side_stage, side);
+  dim3 grid = bgrid((unsigned)(8 * (g.K2 / DBN) * (g.K1 / DBM) * cdiv(splits, 8) + side_blocks));
+  hipLaunchKernelGGL(gemm_tn_dma_kernel<MHIMX_PREC_BF16X3>, grid, dim3(DTHREADS), smem, st, g, mchunk, side_blocks, side_stage, side, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return splits;
 }

@@ -428,7 +428,11 @@ __global__ void mca_dz0_kernel(const float* __restrict__ dz, float* __restrict__
 // (merge.py:127-129,142-143).  One wave per output column; q_new may alias q.
 __global__ __launch_bounds__(256) void mca_out_kernel(const float* __restrict__ O, const float* __restrict__ wo, const float* __restrict__ bo,
                                                      int k, int E, int I, float p, uint64_t seed0, const uint64_t* __restrict__ tick,
-                                                     float* __restrict__ z, const float* q, float* q_new, float mm) {
+                                                     float* __restrict__ z, const float* q, float* q_new, float mm, BagBatch bb) {
+  if (blockIdx.z) {
+    MHIMX_BAG(O); MHIMX_BAG(z); MHIMX_BAG(q); MHIMX_BAG(q_new);
+    seed0 = bag_mca_seed(seed0, bb);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;
   if (n >= E) return;
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256) void mca_out_kernel(const float* __restrict__ 
 
 int mca_out(hipStream_t st, const float* O, const float* wo, const float* bo, int k, int E, int I, float p, uint64_t seed0, const uint64_t* tick,
             float* z, const float* q, float* q_new, float mm) {
-  hipLaunchKernelGGL(mca_out_kernel, dim3((unsigned)cdiv(E, 4)), dim3(256), 0, st, O, wo, bo, k, E, I, p, seed0, tick, z, q, q_new, mm);
+  hipLaunchKernelGGL(mca_out_kernel, bgrid((unsigned)cdiv(E, 4)), dim3(256), 0, st, O, wo, bo, k, E, I, p, seed0, tick, z, q, q_new, mm, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -583,7 +587,7 @@ int merge_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, f
   MHIMX_CHECK_ARG(!update_q || q_new, "merge_fwd: update_q needs q_new");
   MHIMX_CHECK_ARG(I % 4 == 0, "merge_fwd: inner width must be a multiple of 4");
   hipLaunchKernelGGL(mca_out_kernel, dim3((unsigned)cdiv(E, 4)), dim3(256), 0, st, w.O, m->wo, m->bo, (int)k, (int)E, (int)I, m->drop_p,
-                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, z, m->q_param, update_q ? q_new : (float*)nullptr, m->mm);
+                     m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, z, m->q_param, update_q ? q_new : (float*)nullptr, m->mm, BagBatch{});
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

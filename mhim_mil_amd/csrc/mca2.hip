@@ -54,8 +54,13 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_prep_kernel(Merge2PrepArgs 
 template <int RT>
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
-                                                                    float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick, Merge2Ws w) {
+                                                                    float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick, Merge2Ws w, BagBatch bb) {
   extern __shared__ __attribute__((aligned(16))) float m2sm[];
+  if (blockIdx.z) {
+    MHIMX_BAG(X); MHIMX_BAG(xrows);
+    seed0 = bag_mca_seed(seed0, bb);
+    bag_move(w, bb);
+  }
   merge2_rows_fwd_body<RT>((int)blockIdx.x, m2sm, X, xrows, R, ln_w, ln_b, J, drop_p, seed0, tick, w);
 }
 
@@ -68,16 +73,21 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_fwd_kernel(const float
 template <int MODE>
 __global__ __launch_bounds__(M2_THREADS) void merge2_partials_kernel(M2Parts in, int live_only, const float* __restrict__ ln_w,
                                                                     const float* __restrict__ ln_b, float* __restrict__ out,
-                                                                    float* __restrict__ stats, float* __restrict__ raw_stats) {
+                                                                    float* __restrict__ stats, float* __restrict__ raw_stats, BagBatch bb) {
   __shared__ float lds[M2_PARTIALS_LDS];
+  if (blockIdx.z) {
+    in.pm = bag_ptr(in.pm, bb); in.pl = bag_ptr(in.pl, bb); in.psd = bag_ptr(in.psd, bb); in.y = bag_ptr(in.y, bb);
+    MHIMX_BAG(out); MHIMX_BAG(stats); MHIMX_BAG(raw_stats);
+  }
   merge2_partials_body<MODE>((int)blockIdx.x, lds, in, live_only != 0, ln_w, ln_b, out, stats, raw_stats);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // 3b. O[i, h*64+d] = Wv[h*64+d, :] . Y[(h,i), :].   grid = 8 heads x 4 quarters of the head's 64 columns
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_o_kernel(const float* __restrict__ wkv, int k, Merge2Ws w) {
+__global__ __launch_bounds__(M2_THREADS) void merge2_o_kernel(const float* __restrict__ wkv, int k, Merge2Ws w, BagBatch bb) {
   __shared__ __attribute__((aligned(16))) float ys[6 * M2_E];
+  bag_move(w, bb);
   const int tid = threadIdx.x;
   const int h = blockIdx.x >> 2, qd = blockIdx.x & 3;
   // (the weight rows are requested BEFORE the pooled rows go through LDS: one memory round trip on the chain instead of two)
@@ -102,8 +112,13 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_o_kernel(const float* __res
 __global__ __launch_bounds__(M2_THREADS) void merge2_bwd_pre_kernel(const float* __restrict__ dz, const float* __restrict__ wo_t,
                                                                    const float* __restrict__ wkv, int k, float drop_p, uint64_t seed0,
                                                                    const uint64_t* __restrict__ tick, float* __restrict__ d_bo, int accumulate,
-                                                                   Merge2Ws w, float rep) {
+                                                                   Merge2Ws w, float rep, BagBatch bb) {
   __shared__ __attribute__((aligned(16))) float lds[M2_BWD_PRE_LDS];
+  if (blockIdx.z) {
+    MHIMX_BAG(dz); MHIMX_BAG(wo_t); MHIMX_BAG(d_bo);
+    seed0 = bag_mca_seed(seed0, bb);
+    bag_move(w, bb);
+  }
   merge2_bwd_pre_body((int)blockIdx.x, lds, dz, wo_t, wkv, k, drop_p, seed0, tick, d_bo, accumulate, w, rep);      // (mca2_side.hpp)
 }
 
@@ -114,8 +129,13 @@ template <int RT>
 __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float* __restrict__ X, const int64_t* __restrict__ xrows, int64_t R,
                                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b, int J,
                                                                     float drop_p, uint64_t seed0, const uint64_t* __restrict__ tick,
-                                                                    float* __restrict__ dX, Merge2Ws w) {
+                                                                    float* __restrict__ dX, Merge2Ws w, BagBatch bb) {
   extern __shared__ __attribute__((aligned(16))) float m2sm[];
+  if (blockIdx.z) {
+    MHIMX_BAG(X); MHIMX_BAG(xrows); MHIMX_BAG(dX);
+    seed0 = bag_mca_seed(seed0, bb);
+    bag_move(w, bb);
+  }
   merge2_rows_bwd_body<RT>((int)blockIdx.x, m2sm, X, xrows, R, ln_w, ln_b, J, drop_p, seed0, tick, dX, w);
 }
 
@@ -123,8 +143,9 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_rows_bwd_kernel(const float
 // 6. rank-k gradients, first launch (U merged by merge2_partials_kernel<false> before).   blocks 0..31: (head, quarter): dQ = scale Wk U and
 //    16 + 16 rows of d_wkv (K part: scale Q (x) U, V part: dO (x) Y);   blocks 32..47: 32 rows of d_wo = dz0^T O.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(Merge2Side a) {
+__global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(Merge2Side a, BagBatch bb) {
   __shared__ __attribute__((aligned(16))) float lds[M2_GRADS1_LDS];
+  bag_move(a, bb);
   merge2_grads1_body((int)blockIdx.x, lds, a);
 }
 
@@ -132,8 +153,9 @@ __global__ __launch_bounds__(M2_THREADS) void merge2_grads1_kernel(Merge2Side a)
 // 7. rank-k gradients, second launch (needs all of dQ).   blocks 0..15: 32 rows of d_wq = dQ^T gq;   blocks 16..23: 64 columns of
 //    dgq = dQ Wq and their LayerNorm-parameter gradients (the queries themselves are not trained) -> partial row T of lnpart.
 // ----------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(M2_THREADS) void merge2_grads2_kernel(Merge2Side a) {
+__global__ __launch_bounds__(M2_THREADS) void merge2_grads2_kernel(Merge2Side a, BagBatch bb) {
   __shared__ __attribute__((aligned(16))) float lds[M2_GRADS2_LDS];
+  bag_move(a, bb);
   merge2_grads2_body((int)blockIdx.x, lds, a);
 }
 
@@ -145,10 +167,10 @@ int mca_out(hipStream_t st, const float* O, const float* wo, const float* bo, in
 int reduce_parts2(hipStream_t st, const float* part0, const float* part1, int G, int W, int ld, float* out0, float* out1, int accumulate);   // rows.hip
 
 int merge2_side_launch(hipStream_t st, int stage, const Merge2Side& sd) {
-  if (stage == 1) hipLaunchKernelGGL(merge2_partials_kernel<0>, dim3((unsigned)(sd.J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(sd.w, sd.w.upart),
-                                     sd.w.own_n > 0 ? 1 : 0, sd.ln_w, sd.ln_b, const_cast<float*>(sd.U), (float*)nullptr, (float*)nullptr);
-  else if (stage == 2) hipLaunchKernelGGL(merge2_grads1_kernel, dim3(M2_GRADS1_BLOCKS), dim3(M2_THREADS), 0, st, sd);
-  else hipLaunchKernelGGL(merge2_grads2_kernel, dim3(M2_GRADS2_BLOCKS), dim3(M2_THREADS), 0, st, sd);
+  if (stage == 1) hipLaunchKernelGGL(merge2_partials_kernel<0>, bgrid((unsigned)(sd.J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(sd.w, sd.w.upart),
+                                     sd.w.own_n > 0 ? 1 : 0, sd.ln_w, sd.ln_b, const_cast<float*>(sd.U), (float*)nullptr, (float*)nullptr, cur_batch());
+  else if (stage == 2) hipLaunchKernelGGL(merge2_grads1_kernel, bgrid(M2_GRADS1_BLOCKS), dim3(M2_THREADS), 0, st, sd, cur_batch());
+  else hipLaunchKernelGGL(merge2_grads2_kernel, bgrid(M2_GRADS2_BLOCKS), dim3(M2_THREADS), 0, st, sd, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -202,11 +224,11 @@ static int merge2_fwd_rows(hipStream_t st, const mhimx_merge* m, const float* X,
   MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_fwd_smem(32)));
                         MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_fwd_smem(16))));
   if (w.rt == 16)
-    hipLaunchKernelGGL(merge2_rows_fwd_kernel<16>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_fwd_smem(16), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
-                       m->drop_seed, m->drop_tick, w);
+    hipLaunchKernelGGL(merge2_rows_fwd_kernel<16>, bgrid((unsigned)w.T), dim3(M2_THREADS), m2_fwd_smem(16), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                       m->drop_seed, m->drop_tick, w, cur_batch());
   else
-    hipLaunchKernelGGL(merge2_rows_fwd_kernel<32>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_fwd_smem(32), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
-                       m->drop_seed, m->drop_tick, w);
+    hipLaunchKernelGGL(merge2_rows_fwd_kernel<32>, bgrid((unsigned)w.T), dim3(M2_THREADS), m2_fwd_smem(32), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                       m->drop_seed, m->drop_tick, w, cur_batch());
   MHIMX_LAUNCH_CHECK();
   *wout = w;
   return 0;
@@ -214,7 +236,7 @@ static int merge2_fwd_rows(hipStream_t st, const mhimx_merge* m, const float* X,
 // from the merged pooled rows Y (and the softmax statistics) to the tokens: O = Wv Y, to_out, dropout, the queries' EMA
 static int merge2_fwd_tail(hipStream_t st, const mhimx_merge* m, float* z, float* q_new, int update_q, const Merge2Ws& w) {
   const int k = (int)m->k;
-  hipLaunchKernelGGL(merge2_o_kernel, dim3(M2_H * 4), dim3(M2_THREADS), 0, st, m->wkv, k, w);
+  hipLaunchKernelGGL(merge2_o_kernel, bgrid(M2_H * 4), dim3(M2_THREADS), 0, st, m->wkv, k, w, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return mca_out(st, w.O, m->wo, m->bo, k, M2_E, M2_I, m->drop_p, m->drop_seed + 0x9E3779B97F4A7C15ull, m->drop_tick, z, m->q_param,
                  update_q ? q_new : (float*)nullptr, m->mm);
@@ -226,8 +248,8 @@ int merge2_fwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
   Merge2Ws w;
   if (int r = merge2_fwd_rows(st, m, X, R, ws, ws_bytes, &w)) return r;
   const int J = M2_H * (int)m->k;
-  hipLaunchKernelGGL(merge2_partials_kernel<1>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(w, w.ypart), 0, m->ln_w, m->ln_b, w.Y,
-                     w.stats, (float*)nullptr);
+  hipLaunchKernelGGL(merge2_partials_kernel<1>, bgrid((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(w, w.ypart), 0, m->ln_w, m->ln_b, w.Y,
+                     w.stats, (float*)nullptr, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return merge2_fwd_tail(st, m, z, q_new, update_q, w);
 }
@@ -242,7 +264,7 @@ int merge2_fwd_part(hipStream_t st, const mhimx_merge* m, const float* X, int64_
   const int J = M2_H * (int)m->k;
   // (slots >= J keep whatever the block held: nobody reads them)
   hipLaunchKernelGGL(merge2_partials_kernel<2>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_tiles(w, w.ypart), 0, m->ln_w, m->ln_b,
-                     part + 3 * M2_JP, (float*)nullptr, part);
+                     part + 3 * M2_JP, (float*)nullptr, part, BagBatch{});
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -258,7 +280,7 @@ int merge2_fwd_finish(hipStream_t st, const mhimx_merge* m, const float* parts, 
   MHIMX_CHECK_ARG(ar.ok(), "merge_fwd_finish: workspace too small");
   const int J = M2_H * (int)m->k;
   hipLaunchKernelGGL(merge2_partials_kernel<1>, dim3((unsigned)(J * 4)), dim3(M2_THREADS), 0, st, m2_parts_shards(parts, W), 0, m->ln_w, m->ln_b, w.Y,
-                     w.stats, (float*)nullptr);
+                     w.stats, (float*)nullptr, BagBatch{});
   MHIMX_LAUNCH_CHECK();
   return merge2_fwd_tail(st, m, z, q_new, update_q, w);
 }
@@ -338,18 +360,18 @@ int merge2_bwd(hipStream_t st, const mhimx_merge* m, const float* X, int64_t R, 
     }
   }
   if (!pre_done) {
-    hipLaunchKernelGGL(merge2_bwd_pre_kernel, dim3(M2_BWD_PRE_BLOCKS), dim3(M2_THREADS), 0, st, dz, m->wo_t, m->wkv, k, m->drop_p, oseed, m->drop_tick, gr->d_bo, acc, w, sd.rep);
+    hipLaunchKernelGGL(merge2_bwd_pre_kernel, bgrid(M2_BWD_PRE_BLOCKS), dim3(M2_THREADS), 0, st, dz, m->wo_t, m->wkv, k, m->drop_p, oseed, m->drop_tick, gr->d_bo, acc, w, sd.rep, cur_batch());
     MHIMX_LAUNCH_CHECK();
   }
   if (!rows_done) {
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_bwd_smem(32)));
                           MHIMX_HIP(hipFuncSetAttribute((const void*)merge2_rows_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m2_bwd_smem(16))));
     if (w.rt == 16)
-      hipLaunchKernelGGL(merge2_rows_bwd_kernel<16>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_bwd_smem(16), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
-                         m->drop_seed, m->drop_tick, dX, w);
+      hipLaunchKernelGGL(merge2_rows_bwd_kernel<16>, bgrid((unsigned)w.T), dim3(M2_THREADS), m2_bwd_smem(16), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                         m->drop_seed, m->drop_tick, dX, w, cur_batch());
     else
-      hipLaunchKernelGGL(merge2_rows_bwd_kernel<32>, dim3((unsigned)w.T), dim3(M2_THREADS), m2_bwd_smem(32), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
-                         m->drop_seed, m->drop_tick, dX, w);
+      hipLaunchKernelGGL(merge2_rows_bwd_kernel<32>, bgrid((unsigned)w.T), dim3(M2_THREADS), m2_bwd_smem(32), st, X, m->x_rows, R, m->ln_w, m->ln_b, J, m->drop_p,
+                         m->drop_seed, m->drop_tick, dX, w, cur_batch());
     MHIMX_LAUNCH_CHECK();
   }
   // the parameter-gradient tail: U [J, E] takes the place of the fp32 copy of aq (not needed any more)

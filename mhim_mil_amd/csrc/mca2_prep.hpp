@@ -26,6 +26,16 @@ struct Merge2Ws {
   int rt;                    // rows per tile: 16 (R <= 4096: twice the workgroups on a pass that is a latency chain per tile) or 32
 };
 
+// a workgroup of a bag-batched launch (common.hpp: BagBatch) moves the workspace pointers to its own bag's copy
+MHIMX_DEV void bag_move(Merge2Ws& w, const BagBatch& bb) {
+  if (blockIdx.z == 0) return;
+#define M2_MV(f) w.f = bag_ptr(w.f, bb)
+  M2_MV(gq); M2_MV(gmean); M2_MV(grstd); M2_MV(Q); M2_MV(aq); M2_MV(aqf); M2_MV(gtf_aq); M2_MV(mean); M2_MV(rstd); M2_MV(S); M2_MV(pm); M2_MV(pl);
+  M2_MV(psd); M2_MV(ypart); M2_MV(stats); M2_MV(Y); M2_MV(O); M2_MV(dO); M2_MV(dyf); M2_MV(gtf_dy); M2_MV(dpart); M2_MV(upart); M2_MV(lnpart);
+  M2_MV(dQ); M2_MV(gate);
+#undef M2_MV
+}
+
 // rows per tile of a Merge over R rows.  The row passes are per-tile latency chains on ceil(R / rt) CUs; half-size tiles halve the row loads,
 // LayerNorm reductions and matrix-core steps of every wave and double the CUs at work (c2: 970 rows, 31 -> 61 workgroups).  Long row
 // lists keep 32 rows (the per-tile pooled partials are [48, 512] floats each: twice the tiles = twice that traffic).

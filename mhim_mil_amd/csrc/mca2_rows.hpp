@@ -177,6 +177,13 @@ MHIMX_DEV bool m2_keep(uint64_t seed, int j, int64_t r, float p) { return drop_k
 // 2. rows forward: LayerNorm, scores against the J slots, per-tile softmax partials, pooled rows.   grid = ceil(R / RT)
 // ----------------------------------------------------------------------------------------------------------------------
 struct M2RowsFwd { const float* X; const int64_t* xrows; int64_t R; const float *ln_w, *ln_b; int J; float drop_p; uint64_t seed0; const uint64_t* tick; Merge2Ws w; };
+MHIMX_DEV void bag_move(M2RowsFwd& a, const BagBatch& bb) {
+  if (blockIdx.z == 0) return;
+  bag_move(a.w, bb);
+  a.X = bag_ptr(a.X, bb);
+  a.xrows = bag_ptr(a.xrows, bb);
+  a.seed0 = bag_mca_seed(a.seed0, bb);
+}
 constexpr size_t m2_fwd_smem(int rt) { return (size_t)(rt * M2_XLD + 4 * rt * M2_JP + M2_JP * (rt + 4) + 2 * M2_E + rt + 4) * sizeof(float); }
 
 // (a device function: the body of merge2_rows_fwd_kernel (mca2.hip) and of the row tiles that ride at the front of the student's one-pass

@@ -22,6 +22,17 @@ struct Merge2Side {
                    // shard, 0 on the others, so that the SUM over the shards counts them once; 1 for one process
 };
 static_assert(sizeof(Merge2Side) <= MHIMX_SIDE_BYTES, "Merge2Side must fit the opaque side-work block of mhimx_reduce_list");
+// a workgroup of a bag-batched launch: its own bag's workspace, dz / dX / gradient slab and Merge seeds (parameters are shared: they stay)
+MHIMX_DEV void bag_move(Merge2Side& a, const BagBatch& bb) {
+  if (blockIdx.z == 0) return;
+  bag_move(a.w, bb);
+#define M2_MV(f) a.f = bag_ptr(a.f, bb)
+  M2_MV(dz); M2_MV(U); M2_MV(q_param); M2_MV(wo_t); M2_MV(d_wkv); M2_MV(d_wo); M2_MV(d_wq); M2_MV(d_ln_w); M2_MV(d_ln_b); M2_MV(d_bo); M2_MV(X); M2_MV(xrows);
+  M2_MV(dX);
+#undef M2_MV
+  a.oseed = bag_mca_seed(a.oseed, bb);
+  a.seed0 = bag_mca_seed(a.seed0, bb);
+}
 
 constexpr int M2_PARTIALS_LDS = 256 + 8 + 128;
 // Where the partials of a merge live.  Tiles of ONE process: the workspace arrays (stats pitch 48, pooled rows [T][48][512]).  The shards

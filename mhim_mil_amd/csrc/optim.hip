@@ -115,8 +115,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fast_kernel(const float* __
                                                                  float* __restrict__ g_z, float* __restrict__ d_wp,
                                                                  float* __restrict__ d_bp, int accumulate,
                                                                  const float* __restrict__ g_logits_in,
-                                                                 const float* __restrict__ g_cl_in) {
+                                                                 const float* __restrict__ g_cl_in, BagBatch bb) {
   __shared__ float red[8][4];
+  if (blockIdx.z) {      // (common.hpp: one workgroup per bag of an accumulation window; the label list is one of the moving ranges)
+    MHIMX_BAG(z); MHIMX_BAG(t); MHIMX_BAG(label); MHIMX_BAG(logits); MHIMX_BAG(losses); MHIMX_BAG(g_z); MHIMX_BAG(d_wp); MHIMX_BAG(d_bp);
+    MHIMX_BAG(g_logits_in); MHIMX_BAG(g_cl_in);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool aux = (t != nullptr);
   // ---- every load of the kernel, in flight together
@@ -471,11 +475,13 @@ extern "C" int mhimx_head_fwd_bwd(void* stream, const float* z, const float* t, 
   MHIMX_CHECK_ARG(C > 0 && C <= 16 && E > 0, "head: bad dims");
   static const bool slow_head = getenv("MHIMX_HEAD_GENERIC") != nullptr;
   if (!slow_head && C <= 4 && E <= 2 * HEAD_THREADS)
-    hipLaunchKernelGGL(head_fast_kernel<2>, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
-                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
+    hipLaunchKernelGGL(head_fast_kernel<2>, bgrid(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
+                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in, cur_batch());
   else if (!slow_head && C <= 4 && E <= 4 * HEAD_THREADS)
-    hipLaunchKernelGGL(head_fast_kernel<4>, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
-                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);
+    hipLaunchKernelGGL(head_fast_kernel<4>, bgrid(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
+                     temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in, cur_batch());
+  else if (cur_batch().n > 0)
+    return fail(-1, "head: a bag-batched launch takes the short-chain head (C <= 4, E <= 1024)");
   else
   hipLaunchKernelGGL(head_kernel, dim3(1), dim3(HEAD_THREADS), 0, (hipStream_t)stream, z, t, wp, bp, label_dev, (int)E, (int)C,
                      temp_t, main_alpha, aux_alpha, inv_accum, logits, losses, g_z, d_wp, d_bp, accumulate, g_logits_in, g_cl_in);

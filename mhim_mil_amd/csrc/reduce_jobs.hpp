@@ -29,13 +29,20 @@ inline int reduce_table_fill(ReduceTable& t, const mhimx_reduce_job* jobs, int n
 
 // block bx (of t.first[t.n]) of the table; red: [32][33] floats of LDS.  THREADS = 32 columns x THREADS / 32 row groups; a kind-0 sum always
 // goes through 32 row-group partials (a thread of a smaller block owns several), so its bits do not depend on the block size.
-template <int THREADS>
-MHIMX_DEV void reduce_jobs_block(const ReduceTable& t, int bx, float (*red)[33]) {
+template <int THREADS, bool BATCHED = false>
+MHIMX_DEV void reduce_jobs_block(const ReduceTable& t, int bx, float (*red)[33], const BagBatch& bb /* BATCHED: a bag-batched launch, common.hpp */) {
   static_assert(THREADS % 32 == 0 && THREADS <= 1024 && 32 % (THREADS / 32) == 0, "32 columns x a divisor of 32 row groups");
   constexpr int NRG = THREADS / 32;
   int jb = 0;
   while (jb + 1 < t.n && bx >= t.first[jb + 1]) ++jb;
   const mhimx_reduce_job J = t.j[jb];
+  // (a bag-batched launch: this bag's partials and outputs.  Local copies of the two pointers - writing into a copy of the table entry
+  // sent the whole by-value table through scratch memory: 520 us for a 15 us launch)
+  const float* __restrict__ parts = J.parts;
+  float* __restrict__ outp = J.out;
+  if constexpr (BATCHED) {
+    if (blockIdx.z) { parts = bag_ptr(parts, bb); outp = bag_ptr(outp, bb); }
+  }
   const int blk = bx - t.first[jb], nblk = t.first[jb + 1] - t.first[jb];
   if (J.kind == 0) {
     const int c = threadIdx.x & 31, rg0 = threadIdx.x >> 5;
@@ -46,7 +53,7 @@ MHIMX_DEV void reduce_jobs_block(const ReduceTable& t, int bx, float (*red)[33])
         float acc = 0.f;
         if (j < J.W) {
 #pragma unroll 8
-          for (int64_t b = rg; b < J.G; b += 32) acc += J.parts[b * J.ld + j];
+          for (int64_t b = rg; b < J.G; b += 32) acc += parts[b * J.ld + j];
         }
         red[rg][c] = acc;
       }
@@ -55,7 +62,7 @@ MHIMX_DEV void reduce_jobs_block(const ReduceTable& t, int bx, float (*red)[33])
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < 32; ++q) v += red[q][c];
-        J.out[j] = J.accumulate ? J.out[j] + v : v;
+        outp[j] = J.accumulate ? outp[j] + v : v;
       }
       __syncthreads();
     }
@@ -65,24 +72,29 @@ MHIMX_DEV void reduce_jobs_block(const ReduceTable& t, int bx, float (*red)[33])
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int64_t z = 0;
       for (; z + 8 <= J.G; z += 8) {                   // (eight slabs in flight; the same sums in the same order as four at a time)
-        const float p0 = J.parts[(z + 0) * n + idx], p1 = J.parts[(z + 1) * n + idx], p2 = J.parts[(z + 2) * n + idx],
-                    p3 = J.parts[(z + 3) * n + idx], p4 = J.parts[(z + 4) * n + idx], p5 = J.parts[(z + 5) * n + idx],
-                    p6 = J.parts[(z + 6) * n + idx], p7 = J.parts[(z + 7) * n + idx];
+        const float p0 = parts[(z + 0) * n + idx], p1 = parts[(z + 1) * n + idx], p2 = parts[(z + 2) * n + idx],
+                    p3 = parts[(z + 3) * n + idx], p4 = parts[(z + 4) * n + idx], p5 = parts[(z + 5) * n + idx],
+                    p6 = parts[(z + 6) * n + idx], p7 = parts[(z + 7) * n + idx];
         s0 += p0; s1 += p1; s2 += p2; s3 += p3;
         s0 += p4; s1 += p5; s2 += p6; s3 += p7;
       }
       for (; z + 4 <= J.G; z += 4) {
-        s0 += J.parts[(z + 0) * n + idx];
-        s1 += J.parts[(z + 1) * n + idx];
-        s2 += J.parts[(z + 2) * n + idx];
-        s3 += J.parts[(z + 3) * n + idx];
+        s0 += parts[(z + 0) * n + idx];
+        s1 += parts[(z + 1) * n + idx];
+        s2 += parts[(z + 2) * n + idx];
+        s3 += parts[(z + 3) * n + idx];
       }
-      for (; z < J.G; ++z) s0 += J.parts[z * n + idx];
+      for (; z < J.G; ++z) s0 += parts[z * n + idx];
       const float v = (s0 + s1) + (s2 + s3);
-      float* p = J.out + (idx / J.K2) * J.ldo + (idx % J.K2);
+      float* p = outp + (idx / J.K2) * J.ldo + (idx % J.K2);
       *p = J.accumulate ? *p + v : v;
     }
   }
+}
+
+template <int THREADS>
+MHIMX_DEV void reduce_jobs_block(const ReduceTable& t, int bx, float (*red)[33]) {
+  reduce_jobs_block<THREADS, false>(t, bx, red, BagBatch{});
 }
 
 }  // namespace mhimx

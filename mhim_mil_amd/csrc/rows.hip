@@ -132,10 +132,13 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_kernel(const float*
                                                                      float* __restrict__ stats, float* __restrict__ z,
                                                                      const float* __restrict__ s, const float* __restrict__ cproj,
                                                                      const float* __restrict__ bp, int C, int64_t M1,
-                                                                     float* __restrict__ pscore) {
+                                                                     float* __restrict__ pscore, BagBatch bb) {
   __shared__ float red[16];
   __shared__ float wgt[2 * MAX_PART];
   __shared__ float acc16[16][64];
+  if (blockIdx.z) {
+    MHIMX_BAG(pm); MHIMX_BAG(pl); MHIMX_BAG(pz); MHIMX_BAG(stats); MHIMX_BAG(z); MHIMX_BAG(s); MHIMX_BAG(cproj); MHIMX_BAG(pscore);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (G <= 2 MAX_PART = FIN_THREADS: one partial per thread, its max and its sum requested together)
   const int b1 = threadIdx.x;
@@ -208,7 +211,11 @@ __global__ __launch_bounds__(FIN_THREADS) void pool_finalize_tok_kernel(const fl
                                                                          const float* __restrict__ wa, const float* __restrict__ wa_t,
                                                                          const float* __restrict__ ba, const float* __restrict__ wc,
                                                                          const float* __restrict__ bc, int A, int act,
-                                                                         float* __restrict__ u_pre_tail, float* __restrict__ s_tail) {
+                                                                         float* __restrict__ u_pre_tail, float* __restrict__ s_tail, BagBatch bb) {
+  if (blockIdx.z) {
+    MHIMX_BAG(pm); MHIMX_BAG(pl); MHIMX_BAG(pz); MHIMX_BAG(stats); MHIMX_BAG(z); MHIMX_BAG(T); MHIMX_BAG(rows_tail); MHIMX_BAG(wa_t); MHIMX_BAG(u_pre_tail);
+    MHIMX_BAG(s_tail);
+  }
   __shared__ float red[16];
   __shared__ float wgt[2 * MAX_PART];
   __shared__ float acc16[16][64];
@@ -465,6 +472,7 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts_kernel(const float* _
 }
 
 int reduce_parts_now(hipStream_t st, const float* part, int64_t G, int64_t W, int64_t ld, float* out, int accumulate) {
+  MHIMX_CHECK_ARG(cur_batch().n == 0, "reduce: a bag-batched launch queues its reductions (mhimx_reduce_list full?)");
   hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(W, 32)), dim3(RP_THREADS), 0, st, part, (int)G, (int)W, (int)ld, out, accumulate);
   MHIMX_LAUNCH_CHECK();
   return 0;
@@ -473,16 +481,18 @@ int reduce_parts_now(hipStream_t st, const float* part, int64_t G, int64_t W, in
 // every queued final reduction of a step in one launch (mhimx_reduce_flush): job jb owns blocks [first[jb], first[jb+1]).
 // Same arithmetic as reduce_parts_kernel (kind 0) and reduce_slabs_kernel (kind 1): queued or not, the bits are the same.
 struct ReduceJobs { ReduceTable t; int side_blocks; Merge2Side side; };
-__global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj) {
+__global__ __launch_bounds__(RP_THREADS) void reduce_batch_kernel(ReduceJobs rj, BagBatch bb) {
   // the last stage of a parked Merge-backward tail rides along (256 of the 1024 threads).  Its workgroups come FIRST: they are a ~9 us
   // latency chain, and behind 600 reduction workgroups (two resident per CU) they started a round late (reduce 11 us alone, 16 with them last)
   if ((int)blockIdx.x < rj.side_blocks) {
     __shared__ __attribute__((aligned(16))) float side_lds[M2_GRADS2_LDS];
-    if (threadIdx.x < M2_THREADS) merge2_side_stage(3, (int)blockIdx.x, side_lds, rj.side);
+    Merge2Side side = rj.side;             // (a copy of the stage's block alone: moving pointers inside rj sends the whole table through scratch)
+    bag_move(side, bb);
+    if (threadIdx.x < M2_THREADS) merge2_side_stage(3, (int)blockIdx.x, side_lds, side);
     return;
   }
   __shared__ float red[32][33];
-  reduce_jobs_block<RP_THREADS>(rj.t, (int)blockIdx.x - rj.side_blocks, red);      // (reduce_jobs.hpp)
+  reduce_jobs_block<RP_THREADS, true>(rj.t, (int)blockIdx.x - rj.side_blocks, red, bb);      // (reduce_jobs.hpp)
 }
 
 // two independent partial sets in one launch (blockIdx.y selects): LayerNorm's d_w and d_b
@@ -513,7 +523,8 @@ __global__ __launch_bounds__(RP_THREADS) void reduce_parts2_kernel(const float* 
 }
 
 __global__ void softmax_from_stats_kernel(const float* __restrict__ s, const float* __restrict__ stats,
-                                          float* __restrict__ attn, int64_t M) {
+                                          float* __restrict__ attn, int64_t M, BagBatch bb) {
+  if (blockIdx.z) { MHIMX_BAG(s); MHIMX_BAG(stats); MHIMX_BAG(attn); }
   const float mx = stats[0], invL = 1.f / stats[1];
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < M; n += (int64_t)gridDim.x * blockDim.x)
     attn[n] = __expf(s[n] - mx) * invL;
@@ -983,9 +994,9 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, mhimx_pool_io* io) {
                                       w.pz, MAX_PART, io->rows1, nullptr, io->ride_jobs, io->n_ride_jobs, mf);
       return g1 < 0 ? g1 : 0;
     }
-    hipLaunchKernelGGL(pool_finalize_tok_kernel, dim3((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G1, (int)E, io->stats, io->z, io->T1,
+    hipLaunchKernelGGL(pool_finalize_tok_kernel, bgrid((unsigned)cdiv(E, 64)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G1, (int)E, io->stats, io->z, io->T1,
                        (io->rows1 && io->tail_row0 < 0) ? io->rows1 + Ms1 : nullptr, io->rows1 ? io->tail_row0 : Ms1, (int)K, sc->wa, io->tail_wa_t, sc->ba, sc->wc,
-                       sc->bc, (int)A, sc->act, u_pre + Ms1 * ldu, io->s + Ms1);
+                       sc->bc, (int)A, sc->act, u_pre + Ms1 * ldu, io->s + Ms1, cur_batch());
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
@@ -1009,6 +1020,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, mhimx_pool_io* io) {
       off += Ms[seg];
       continue;
     }
+    MHIMX_CHECK_ARG(cur_batch().n == 0, "pool_fwd: a bag-batched launch needs the one-pass scorer");
     mhimx_gemm_nt_args g = {};
     g.A = Ts[seg]; g.lda = E; g.B = sc->wa; g.ldb = E; g.C = u_pre + off * ldu; g.ldc = ldu;
     g.M = Ms[seg]; g.N = A; g.K = E; g.bias = sc->ba;
@@ -1047,8 +1059,8 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, mhimx_pool_io* io) {
   static_assert(2 * MAX_PART <= FIN_THREADS, "pool_finalize_kernel reads one partial per thread");
   // the pseudo score of the instances (if asked for) on blocks of its own, beside the E/64 blocks that merge the pooled row
   const int64_t ps_blocks = io->pscore ? (cdiv(io->M1, FIN_THREADS) < 64 ? cdiv(io->M1, FIN_THREADS) : 64) : 0;
-  hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)(cdiv(E, 64) + ps_blocks)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats,
-                     io->z, io->s, io->cproj, io->bp, (int)io->C, io->M1, io->pscore);
+  hipLaunchKernelGGL(pool_finalize_kernel, bgrid((unsigned)(cdiv(E, 64) + ps_blocks)), dim3(FIN_THREADS), 0, st, w.pm, w.pl, w.pz, G, (int)E, io->stats,
+                     io->z, io->s, io->cproj, io->bp, (int)io->C, io->M1, io->pscore, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -1076,6 +1088,8 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   const bool fused = scorer_fused_ok(E, A, gated, sc->prec, io->T1, gr->wa_t, nullptr, 0) && aligned16(gr->dT1) &&
                      (io->M2 == 0 || (aligned16(io->T2) && aligned16(gr->dT2))) && aligned16(u_pre) && aligned16(w.du);
   MHIMX_CHECK_ARG(!io->rows1 || (fused && io->M2 == 0), "pool_bwd: gathered tokens (rows1) need the one-pass backward and a single segment");
+  MHIMX_CHECK_ARG(cur_batch().n == 0 || (fused && io->M2 == 0 && !gated && gr->defer && !gr->d_bc && !gr->d_ba && !gr->d_bb),
+                  "pool_bwd: a bag-batched launch needs the one-pass backward with its reductions queued");
   for (int seg = 0; seg < 2 && fused; ++seg) {
     if (Ms[seg] == 0) continue;
     // a Merge backward's first stage parked on the list (mhimx_merge_bwd_park) rides in this launch when its dz is a block of whole rows of
@@ -1294,7 +1308,7 @@ int reduce_flush(hipStream_t st, mhimx_reduce_list* list) {
   }
   const int first = reduce_table_fill(rj.t, list->j, list->n, RP_THREADS);
   list->n = 0;
-  hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(first + rj.side_blocks)), dim3(RP_THREADS), 0, st, rj);
+  hipLaunchKernelGGL(reduce_batch_kernel, bgrid((unsigned)(first + rj.side_blocks)), dim3(RP_THREADS), 0, st, rj, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -1332,8 +1346,8 @@ extern "C" int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const 
 }
 extern "C" int mhimx_softmax_from_stats(void* stream, const float* s, const float* stats, float* attn, int64_t M) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(softmax_from_stats_kernel, dim3((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0,
-                     (hipStream_t)stream, s, stats, attn, M);
+  hipLaunchKernelGGL(softmax_from_stats_kernel, bgrid((unsigned)(cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024)), dim3(256), 0,
+                     (hipStream_t)stream, s, stats, attn, M, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return 0;
 }
@@ -1440,7 +1454,7 @@ extern "C" int mhimx_pool_finalize(void* stream, const float* pm, const float* p
   MHIMX_CHECK_ARG(!pscore || (s && cproj && C >= 1 && M1 >= 1), "pool_finalize: the pseudo score needs s, cproj and the instance count");
   const int64_t ps_blocks = pscore ? (cdiv(M1, FIN_THREADS) < 64 ? cdiv(M1, FIN_THREADS) : 64) : 0;
   hipLaunchKernelGGL(pool_finalize_kernel, dim3((unsigned)(cdiv(E, 64) + ps_blocks)), dim3(FIN_THREADS), 0, (hipStream_t)stream, pm, pl, pz, (int)G, (int)E,
-                     stats, z, s, cproj, bp, (int)C, M1, pscore);
+                     stats, z, s, cproj, bp, (int)C, M1, pscore, BagBatch{});
   MHIMX_LAUNCH_CHECK();
   return 0;
 }

@@ -65,8 +65,13 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
     int n_main /* workgroups of the scorer itself; the blocks behind them are riders */, PrepJobs rider,
     int n_front /* round 5: the FIRST n_front blocks are the row tiles of a Merge forward (mca2_rows.hpp) - the student's scorer over the rows
                    that stay and the Merge over the rows to merge are independent until the tokens exist, and the Merge heads the longer chain */,
-    M2RowsFwd mf) {
+    M2RowsFwd mf, BagBatch bb /* common.hpp: blockIdx.z = the bag of an accumulation window this workgroup works for */) {
   extern __shared__ __attribute__((aligned(16))) float sf_sm[];
+  if (blockIdx.z) {
+    MHIMX_BAG(T); MHIMX_BAG(u_pre); MHIMX_BAG(s_out); MHIMX_BAG(cproj); MHIMX_BAG(pm); MHIMX_BAG(pl); MHIMX_BAG(pz); MHIMX_BAG(rows); MHIMX_BAG(excl);
+    MHIMX_BAG(wa_frag);
+    bag_move(mf, bb);
+  }
   if ((int)blockIdx.x < n_front) {
     if ((int)blockIdx.x < mf.w.T)
       merge2_rows_fwd_body<16>((int)blockIdx.x, sf_sm, mf.X, mf.xrows, mf.R, mf.ln_w, mf.ln_b, mf.J, mf.drop_p, mf.seed0, mf.tick, mf.w);
@@ -321,8 +326,14 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     float* __restrict__ dwc_part, float* __restrict__ dbc_part, int tiles,
     const int64_t* __restrict__ rows /* optional: token n is T[rows[n]] and its gradient goes to dT[rows[n]] */,
     int n_main /* workgroups of the backward itself; the blocks behind them: a Merge backward's first stage, riding */, Merge2Side pre,
-    int64_t gate_row0 /* >= 0: the rows gate_row0 .. of dT are that stage's dz - stored write-through and announced on pre.w.gate[1] */) {
+    int64_t gate_row0 /* >= 0: the rows gate_row0 .. of dT are that stage's dz - stored write-through and announced on pre.w.gate[1] */,
+    BagBatch bb) {
   extern __shared__ __attribute__((aligned(16))) float sb_sm[];
+  if (blockIdx.z) {
+    MHIMX_BAG(T); MHIMX_BAG(u_pre); MHIMX_BAG(s_in); MHIMX_BAG(stats); MHIMX_BAG(g_z); MHIMX_BAG(z); MHIMX_BAG(du); MHIMX_BAG(dT); MHIMX_BAG(dwc_part);
+    MHIMX_BAG(dbc_part); MHIMX_BAG(rows); MHIMX_BAG(wat); MHIMX_BAG(wat_frag);
+    bag_move(pre, bb);
+  }
   if ((int)blockIdx.x >= n_main) {
     // (the LAST blocks of the grid: every producer of dz is resident or done when one of these starts; they request their weights, then
     // wait for pre.k announced rows)
@@ -530,6 +541,7 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
   static_assert(SF_THREADS == 256 && SF_THREADS == M2_THREADS, "the preparation jobs and the Merge row tiles are written for 256 threads");
   PrepJobs rider = {};
   int ride_blocks = 0;
+  MHIMX_CHECK_ARG(!(ride_jobs && n_ride_jobs > 0 && cur_batch().n > 0), "scorer: preparation jobs do not ride in a bag-batched launch");
   if (ride_jobs && n_ride_jobs > 0) {
     ride_blocks = prep_jobs_fill(ride_jobs, n_ride_jobs, &rider);
     if (ride_blocks < 0) return ride_blocks;
@@ -541,11 +553,11 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
     n_front = mf.w.T;
   }
   if (wa_frag)
-    hipLaunchKernelGGL(scorer_fused_kernel<true>, dim3(n_front + grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre,
-                       s_out, cproj, pm, pl, pz, tiles, rows, excl, grid, rider, n_front, mf);
+    hipLaunchKernelGGL(scorer_fused_kernel<true>, bgrid(n_front + grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre,
+                       s_out, cproj, pm, pl, pz, tiles, rows, excl, grid, rider, n_front, mf, cur_batch());
   else
-    hipLaunchKernelGGL(scorer_fused_kernel<false>, dim3(n_front + grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre,
-                       s_out, cproj, pm, pl, pz, tiles, rows, excl, grid, rider, n_front, mf);
+    hipLaunchKernelGGL(scorer_fused_kernel<false>, bgrid(n_front + grid + ride_blocks), dim3(SF_THREADS), SF_SMEM, st, T, M, wa, wa_frag, ba, act, wc, bc, wp, C, u_pre,
+                       s_out, cproj, pm, pl, pz, tiles, rows, excl, grid, rider, n_front, mf, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return grid;
 }
@@ -567,8 +579,8 @@ int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_p
   } else {
     gate_row0 = -1;
   }
-  hipLaunchKernelGGL(scorer_fused_bwd_kernel, dim3(grid + ride), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
-                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows, grid, pre, gate_row0);
+  hipLaunchKernelGGL(scorer_fused_bwd_kernel, bgrid(grid + ride), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
+                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows, grid, pre, gate_row0, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

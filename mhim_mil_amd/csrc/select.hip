@@ -413,8 +413,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     const float* __restrict__ score, int N, int k, int n_sel, int largest, const int64_t* __restrict__ perm,
     const int64_t* __restrict__ other, int64_t n_other, int64_t* __restrict__ mask_ids, int64_t* __restrict__ len_keep_dev,
     int64_t* __restrict__ topk_out, int P, int use_rand, uint64_t rand_seed0, const uint64_t* __restrict__ tick, int merge_R,
-    int64_t* __restrict__ rows_out) {
+    int64_t* __restrict__ rows_out, BagBatch bb /* common.hpp: one workgroup per bag of an accumulation window */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.z) {
+    MHIMX_BAG(score); MHIMX_BAG(perm); MHIMX_BAG(other); MHIMX_BAG(mask_ids); MHIMX_BAG(len_keep_dev); MHIMX_BAG(topk_out); MHIMX_BAG(rows_out);
+    rand_seed0 = bag_sel_seed(rand_seed0, bb);
+  }
   const uint64_t rand_seed = eff_seed(rand_seed0, tick);
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);               // [P] gathered, [P] sorted / random keys
   uint64_t* sorted = keys + P;
@@ -953,9 +957,9 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
   if (N <= 16384 && P <= 4096) {                       // registers + LDS fast path
     const size_t sm = select_small_smem(P);
 #define MHIMX_SEL_SMALL(KPT)                                                                                                   \
-    hipLaunchKernelGGL(select_small_kernel<KPT>, dim3(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
+    hipLaunchKernelGGL(select_small_kernel<KPT>, bgrid(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
                        (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,          \
-                       g_rand_seed, g_tick, g_merge_R, g_rows_out)
+                       g_rand_seed, g_tick, g_merge_R, g_rows_out, cur_batch())
     MHIMX_ONCE_PER_DEVICE(
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
@@ -963,9 +967,9 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
     const bool lean = g_use_rand && g_rows_out && !perm && !other && !mask_ids && !len_keep_dev && !topk_sorted && n_sel < k;
     if (lean) {
 #define MHIMX_SEL_LEAN(KPT)                                                                                                    \
-      hipLaunchKernelGGL((select_small_kernel<KPT, true>), dim3(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
+      hipLaunchKernelGGL((select_small_kernel<KPT, true>), bgrid(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
                          (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,        \
-                         g_rand_seed, g_tick, g_merge_R, g_rows_out)
+                         g_rand_seed, g_tick, g_merge_R, g_rows_out, cur_batch())
       MHIMX_ONCE_PER_DEVICE(
           MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
           MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
@@ -981,6 +985,7 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
+  MHIMX_CHECK_ARG(cur_batch().n == 0, "select: a bag-batched launch takes the one-workgroup select (N <= 16384, k <= 4096)");
   const size_t smem = select_smem(P);
     MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))); MHIMX_HIP(hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_smem(16384))));
   MHIMX_CHECK_ARG(!g_use_rand && !g_rows_out, "select: the random-subset forms need N <= 16384 and k <= 4096");

@@ -109,6 +109,8 @@ struct StepBufs {
   int64_t s_s, stats_s, z_s, pool_ws_s, pool_ws_s_bytes;
   int64_t logits, losses, g_z;
   int64_t dH, img, ws_b, ws_b_bytes, wg_ws, wg_ws_floats;
+  int64_t q_scr, gslab;              // (a window's bag: where its forward's query EMA goes, its gradient slab)
+  int64_t bag0, bag_stride;          // the per-bag part of the workspace: bag b's copy of everything from merge_ws on starts bag0 + b * bag_stride
   int64_t total;
 };
 
@@ -131,7 +133,10 @@ int check_cfg(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n) {
   return 0;
 }
 
-void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, StepBufs* b) {
+// n_bags > 1: the workspace of an accumulation window (mhimx_window_run) - the parameter images once, ONE weight-gradient workspace for the
+// window's multi-bag product, then n_bags copies of the per-bag part (the same offsets as a single step's, plus the bag's query scratch and
+// gradient slab) at a fixed stride
+void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, StepBufs* b, int n_bags = 1) {
   const int64_t D = c->D, E = c->E, A = c->A, C = c->C, k = c->k, I = 512;
   Carve cv(nullptr);
   const int64_t F = sizeof(float);
@@ -143,6 +148,11 @@ void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, Step
   b->wa_t_frag = cv.take_off(E * A * F);
   b->wo_t = cv.take_off(I * E * F);
   b->q_old = cv.take_off(k * E * F);
+  if (n_bags > 1) {
+    b->wg_ws_floats = mhimx_wgrad_multi_ws_floats(n->len_keep, E, D, n_bags);
+    b->wg_ws = cv.take_off(b->wg_ws_floats * F);
+  }
+  b->bag0 = cv.off;
   b->merge_ws_bytes = mhimx_merge_ws_bytes(n->R, E, k, 8, 64);
   b->merge_ws = cv.take_off(b->merge_ws_bytes);
   b->H_t = cv.take_off(N * E * F);
@@ -179,9 +189,16 @@ void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, Step
   b->img = cv.take_off(mhimx_wgrad_image_bytes(n->len_keep, E));
   b->ws_b_bytes = (n->len_keep + 31) / 32 * E * F;
   b->ws_b = cv.take_off(b->ws_b_bytes);
-  b->wg_ws_floats = mhimx_wgrad_ws_floats(n->len_keep, E, D);
-  b->wg_ws = cv.take_off(b->wg_ws_floats * F);
-  b->total = cv.off;
+  b->q_scr = b->gslab = 0;
+  if (n_bags > 1) {
+    b->q_scr = cv.take_off(k * E * F);
+    b->gslab = cv.take_off(c->n_all * F);
+  } else {
+    b->wg_ws_floats = mhimx_wgrad_ws_floats(n->len_keep, E, D);
+    b->wg_ws = cv.take_off(b->wg_ws_floats * F);
+  }
+  b->bag_stride = cv.off - b->bag0;
+  b->total = b->bag0 + (int64_t)n_bags * b->bag_stride;
 }
 
 }  // namespace
@@ -440,6 +457,270 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
   o.p = c.p; o.g = c.g; o.m = c.m; o.v = c.v; o.teacher = c.p_teacher; o.n_train = c.n_train; o.n_all = c.n_all; o.step = host_step; o.step_dev = c.opt_step;
   o.lr = c.lr; o.lr_table = c.lr_table; o.lr_len = c.lr_len; o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.weight_decay = c.weight_decay;
   o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = lm;
+  return mhimx_optim_step(stream, &o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 6 - an accumulation window with every launch over ALL its bags (base_engine.py:29,47-49,100-119).
+//   prep (once)  ->  both projections of the n bags in ONE launch  ->  the step's middle (teacher scorer ... dPRE image: launches 3-15 of
+//   the list at the top of this file) issued ONCE with gridDim.z = n (common.hpp: BagBatch - every kernel moves the pointers it was given to
+//   its own bag's copy of the workspace)  ->  ONE weight-gradient launch over the n images  ->  the queries' EMA chain  ->  Adam + EMA.
+// ~22 launches per window instead of ~127: the latency-bound links of the chain (select, Merge tail, finalizes, head: one to a few dozen
+// workgroups each) run for 8 bags in the time of one, which HIP streams / graph branches never delivered (at most two queues make progress
+// at a time on this runtime: profiles/r06_window_batched.md).  Same kernels, same arithmetic per bag as mhimx_step_run(update = 0) with
+// that bag's seeds; the forward has its bits, the gradient differs only where a split-K slab count follows the launch's size.
+// ------------------------------------------------------------------------------------------------------------------------------------
+namespace mhimx {
+namespace {
+
+// q <- wq q + sum_b w[b] z_b   (the window's EMA chain of the global queries on the tokens its forwards produced: merge.py:142-143 applied bag
+// after bag, q <- mm q + (1 - mm) z_b, with every z_b computed from the window's first queries - engine.py window_step's contract)
+struct QChainW { float wq; float w[MHIMX_WINDOW_MAX]; };
+__global__ __launch_bounds__(256) void window_q_chain_kernel(float* __restrict__ q, const float* __restrict__ z0, int64_t z_stride, int n_bags, int64_t n,
+                                                             QChainW cw) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < n_bags; ++b) acc += z0[b * z_stride + i] * cw.w[b];
+    q[i] = q[i] * cw.wq + acc;
+  }
+}
+// g += sum_b slab_b   (update = 0: the window's complete gradient in the flat buffer)
+__global__ __launch_bounds__(256) void window_sum_slabs_kernel(float* __restrict__ g, const float* __restrict__ slab0, int64_t pitch, int n_bags, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = g[i];
+    for (int b = 0; b < n_bags; ++b) acc += slab0[b * pitch + i];
+    g[i] = acc;
+  }
+}
+
+int check_window(const mhimx_step_cfg* c, int32_t n_bags, int64_t N, const mhimx_step_counts* n) {
+  if (int r = check_cfg(c, N, n)) return r;
+  MHIMX_CHECK_ARG(n_bags >= 2 && n_bags <= MHIMX_WINDOW_MAX, "window: 2..%d bags", MHIMX_WINDOW_MAX);
+  MHIMX_CHECK_ARG(N <= 16384 && c->k <= 6, "window: bags of up to 16384 rows (the one-workgroup select), merge_k <= 6");
+  MHIMX_CHECK_ARG(c->g && c->n_train > 0 && c->n_all >= c->n_train && c->n_all % 4 == 0, "window: the flat gradient buffer (n_all %% 4 == 0) is required");
+  MHIMX_CHECK_ARG(!c->q_out && !c->side_stream, "window: q_out / side_stream are single-step options");
+  const mhimx_step_grads& g = c->grad;
+  const float* gp[12] = {g.w1, g.b1, g.wa, g.wc, g.wp, g.bp, g.ln_w, g.ln_b, g.wkv, g.wq, g.wo, g.bo};
+  for (int i = 0; i < 12; ++i)
+    MHIMX_CHECK_ARG(gp[i] >= c->g && gp[i] < c->g + c->n_train, "window: every gradient view lies inside the flat gradient buffer g[0, n_train)");
+  return 0;
+}
+
+}  // namespace
+}  // namespace mhimx
+
+extern "C" int mhimx_window_layout_of(const mhimx_step_cfg* cfg, int32_t n_bags, int64_t N, const mhimx_step_counts* cnt, mhimx_window_layout* out) {
+  MHIMX_CHECK_ARG(out, "window_layout: null output");
+  if (int r = check_window(cfg, n_bags, N, cnt)) return r;
+  StepBufs b;
+  layout(cfg, N, cnt, &b, n_bags);
+  out->total = b.total; out->bag0 = b.bag0; out->bag_stride = b.bag_stride; out->grad_slab = b.gslab;
+  out->bag = mhimx_step_layout{b.total, b.logits, b.losses, cfg->attn2score ? b.pscore : b.attn, b.rows_all, b.H_t, b.Hbuf, b.dact, b.z_t, b.z_s, b.g_z, b.dH};
+  return 0;
+}
+
+extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, int64_t ldx, int64_t N,
+                                const int64_t* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws,
+                                int64_t ws_bytes, int32_t update) {
+  if (int r = check_window(cfg, n_bags, N, cnt)) return r;
+  MHIMX_CHECK_ARG(X && labels_dev && seeds && ws && ldx >= cfg->D && ldx % 4 == 0 && N * ldx * 4 < ((int64_t)1 << 32),
+                  "window: null bags / labels / seeds / workspace, or a row pitch the weight-gradient product does not take");
+  for (int32_t i = 0; i < n_bags; ++i) MHIMX_CHECK_ARG(X[i] && aligned16(X[i]), "window: bag %d null or not 16-byte aligned", i);
+  MHIMX_CHECK_ARG(!update || (cfg->p && cfg->m && cfg->v), "window: update needs the flat optimiser buffers");
+  StepBufs b;
+  layout(cfg, N, cnt, &b, n_bags);
+  MHIMX_CHECK_ARG(ws_bytes >= b.total && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "window: workspace too small (%lld < %lld) or not 256-byte aligned",
+                  (long long)ws_bytes, (long long)b.total);
+  const mhimx_step_cfg& c = *cfg;
+  const mhimx_step_params &S = c.student, &T = c.teacher;
+  const int64_t D = c.D, E = c.E, A = c.A, C = c.C, k = c.k, I = 512;
+  const int64_t R = cnt->R, Lk = cnt->Lk, len_keep = cnt->len_keep;
+  const hipStream_t st = (hipStream_t)stream;
+  Carve cv(ws);
+  const int64_t BS = b.bag_stride;                                     // bytes from a bag's copy of a buffer to the next bag's
+  auto bag = [&](int64_t off, int i) { return cv.at<char>(off) + (int64_t)i * BS; };
+  float* w1p_t = cv.at<float>(b.w1p_t);
+  float* wa_frag_t = cv.at<float>(b.wa_frag_t);
+  float* w1p_s = cv.at<float>(b.w1p_s);
+  float* wa_frag_s = cv.at<float>(b.wa_frag_s);
+  float* wa_t = cv.at<float>(b.wa_t);
+  float* wa_t_frag = cv.at<float>(b.wa_t_frag);
+  float* wo_t = cv.at<float>(b.wo_t);
+  float* q_old = cv.at<float>(b.q_old);
+  // bag 0's copies: what the middle is enqueued with
+  void* merge_ws = cv.at<char>(b.merge_ws);
+  float* H_t = cv.at<float>(b.H_t);
+  float* Hbuf = cv.at<float>(b.Hbuf);
+  int64_t* rows_all = cv.at<int64_t>(b.rows_all);
+  float* dH = cv.at<float>(b.dH);
+  float* slab0 = cv.at<float>(b.gslab);
+  const uint64_t* tick = c.tick;
+  auto gs = [&](float* view) { return slab0 + (view - c.g); };          // a gradient view's place in bag 0's slab
+
+  // the flat gradient takes the weight gradient of the projection (written by the window's ONE product) and nothing else: the bags' slabs are
+  // added by the update kernel (g_extra) / by window_sum_slabs_kernel
+  MHIMX_HIP(hipMemsetAsync(c.g, 0, (size_t)c.n_train * sizeof(float), st));
+
+  // ---- 1. preparation, once for the window (nothing rides: the middle's launches are bag-batched)
+  mhimx_merge mw_prep = {};
+  mw_prep.E = E; mw_prep.k = k; mw_prep.heads = 8; mw_prep.dim_head = 64;
+  mw_prep.q_param = S.q; mw_prep.ln_w = S.ln_w; mw_prep.ln_b = S.ln_b; mw_prep.wkv = S.wkv; mw_prep.wq = S.wq; mw_prep.wo = S.wo; mw_prep.bo = S.bo;
+  mw_prep.mm = c.merge_mm; mw_prep.prec = MHIMX_PREC_BF16X3; mw_prep.drop_tick = tick; mw_prep.rep = 1.f;
+  {
+    mhimx_prep_job jobs[MHIMX_PREP_MAX];
+    int n = 0;
+    jobs[n++] = mhimx_prep_job{3, nullptr, reinterpret_cast<float*>(c.tick), 1, 1};
+    if (c.opt_step) jobs[n++] = mhimx_prep_job{3, nullptr, reinterpret_cast<float*>(c.opt_step), 1, 1};
+    jobs[n++] = mhimx_prep_job{1, T.w1, w1p_t, E, D};
+    jobs[n++] = mhimx_prep_job{4, T.wa, wa_frag_t, A, E};
+    jobs[n++] = mhimx_prep_job{1, S.w1, w1p_s, E, D};
+    jobs[n++] = mhimx_prep_job{4, S.wa, wa_frag_s, A, E};
+    jobs[n++] = mhimx_prep_job{0, S.wa, wa_t, A, E};
+    jobs[n++] = mhimx_prep_job{5, S.wa, wa_t_frag, A, E};
+    jobs[n++] = mhimx_prep_job{0, S.wo, wo_t, E, I};
+    jobs[n++] = mhimx_prep_job{2, S.q, q_old, 1, k * E};
+    for (int i = 0; i < n_bags; ++i) {
+      jobs[n++] = mhimx_prep_job{10, nullptr, reinterpret_cast<float*>(reinterpret_cast<int64_t*>(bag(b.rows_all, i)) + len_keep), N, k};
+      jobs[n++] = mhimx_prep_job{6, reinterpret_cast<const float*>(&mw_prep), reinterpret_cast<float*>(bag(b.merge_ws, i)), R, b.merge_ws_bytes};
+    }
+    static_assert(10 + 2 * MHIMX_WINDOW_MAX <= MHIMX_PREP_MAX, "the window's preparation is one launch");
+    if (int r = mhimx_prep_batch(stream, jobs, n)) return r;
+  }
+
+  // ---- 2. both models' feature rows of every bag: ONE launch (mhim.py:186 and :335-336)
+  {
+    mhimx_bag_project_args pa[MHIMX_WINDOW_MAX];
+    for (int i = 0; i < n_bags; ++i) {
+      mhimx_bag_project_args a = {};
+      a.X = X[i]; a.ldx = ldx; a.N = N; a.D = D; a.E = E; a.act = c.act; a.n_heads = 2; a.drop_tick = tick;
+      a.head[0].wp = w1p_t; a.head[0].bias = T.b1; a.head[0].H = reinterpret_cast<float*>(bag(b.H_t, i)); a.head[0].ldh = E; a.head[0].drop_p = c.drop_p_teacher;
+      a.head[0].drop_seed = seeds[i].drop_teacher;
+      a.head[1].wp = w1p_s; a.head[1].bias = S.b1; a.head[1].H = reinterpret_cast<float*>(bag(b.Hbuf, i)); a.head[1].ldh = E; a.head[1].dact = bag(b.dact, i);
+      a.head[1].drop_p = c.drop_p_student; a.head[1].drop_seed = seeds[i].drop_student;
+      pa[i] = a;
+    }
+    if (int r = mhimx_bag_project_multi(stream, pa, n_bags)) return r;
+  }
+
+  // ---- 3..15. the middle, enqueued once with bag 0's pointers, gridDim.z = n_bags
+  BagBatch bb = {};
+  bb.n = n_bags;
+  bb.lo[0] = reinterpret_cast<uint64_t>(cv.at<char>(b.bag0)); bb.span[0] = (uint64_t)BS; bb.stride[0] = BS;
+  bb.lo[1] = reinterpret_cast<uint64_t>(labels_dev); bb.span[1] = 8; bb.stride[1] = 8;
+  for (int i = 0; i < n_bags; ++i) {
+    bb.dsel[i] = seeds[i].select - seeds[0].select;
+    bb.dmca[i] = seeds[i].mca - seeds[0].mca;
+  }
+  struct BatchScope {                                                 // (every return path leaves the thread without a batch)
+    explicit BatchScope(const BagBatch* p) { set_batch(p); }
+    ~BatchScope() { set_batch(nullptr); }
+  };
+  {
+    BatchScope scope(&bb);
+    // teacher: scorer + softmax pool (+ class projections and the pseudo score, scoring.py:37-58)
+    mhimx_scorer sc_t = {};
+    sc_t.E = E; sc_t.A = A; sc_t.act = c.da_act; sc_t.prec = MHIMX_PREC_BF16X3; sc_t.wa = T.wa; sc_t.wc = T.wc; sc_t.wa_frag = wa_frag_t;
+    const float* score = nullptr;
+    {
+      mhimx_pool_io io = {};
+      io.T1 = H_t; io.M1 = N; io.s = cv.at<float>(b.s_t); io.stats = cv.at<float>(b.stats_t); io.z = cv.at<float>(b.z_t);
+      io.ws = cv.at<char>(b.pool_ws_t); io.ws_bytes = b.pool_ws_t_bytes;
+      if (c.attn2score) { io.wp = T.wp; io.C = C; io.cproj = cv.at<float>(b.cproj_t); io.bp = T.bp; io.pscore = cv.at<float>(b.pscore); }
+      if (int r = mhimx_abmil_pool_fwd(stream, &sc_t, &io)) return r;
+      if (c.attn2score) score = io.pscore;
+      else {
+        if (int r = mhimx_softmax_from_stats(stream, io.s, io.stats, cv.at<float>(b.attn), N)) return r;
+        score = cv.at<float>(b.attn);
+      }
+    }
+    const float* z_t = cv.at<float>(b.z_t);
+    // HAM mask + Merge split
+    if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds[0].select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+      return r;
+    // the student's forward: scorer over the rows that stay (Merge's row tiles ride at its front), Merge tail, the finalize that scores the tokens
+    mhimx_merge mw = mw_prep;
+    mw.drop_p = c.merge_drop_p; mw.drop_seed = seeds[0].mca; mw.x_rows = rows_all; mw.prepared = 1;
+    mhimx_scorer sc_s = sc_t;
+    sc_s.wa = S.wa; sc_s.wc = S.wc; sc_s.wa_frag = wa_frag_s;
+    mhimx_pool_io io_s = {};
+    io_s.T1 = Hbuf; io_s.M1 = Lk + k; io_s.s = cv.at<float>(b.s_s); io_s.stats = cv.at<float>(b.stats_s); io_s.z = cv.at<float>(b.z_s);
+    io_s.ws = cv.at<char>(b.pool_ws_s); io_s.ws_bytes = b.pool_ws_s_bytes; io_s.rows1 = rows_all + R;
+    io_s.tail_row0 = -1;
+    io_s.phase = 1; io_s.tail_tokens = (int32_t)k;
+    io_s.ride_merge = &mw; io_s.ride_X = Hbuf; io_s.ride_R = R; io_s.ride_ws = merge_ws; io_s.ride_ws_bytes = b.merge_ws_bytes;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+    mw.rows_done = io_s.rode_merge;
+    if (int r = mhimx_merge_fwd(stream, &mw, Hbuf, R, Hbuf + N * E, cv.at<float>(b.q_scr), 1, merge_ws, b.merge_ws_bytes)) return r;
+    mw.rows_done = 0;
+    io_s.phase = 2; io_s.tail_wa_t = wa_t; io_s.tail_row0 = N;
+    if (int r = mhimx_abmil_pool_fwd(stream, &sc_s, &io_s)) return r;
+    io_s.phase = 0; io_s.ride_merge = nullptr;
+
+    // head: every bag's loss / n_bags (base_engine.py:102)
+    float* g_z = cv.at<float>(b.g_z);
+    if (int r = mhimx_head_fwd_bwd(stream, io_s.z, c.aux_alpha != 0.f ? z_t : nullptr, S.wp, S.bp, labels_dev, E, C, c.temp_t, c.main_alpha, c.aux_alpha,
+                                   1.f / (float)n_bags, cv.at<float>(b.logits), cv.at<float>(b.losses), g_z, gs(c.grad.wp), gs(c.grad.bp), 0, nullptr, nullptr))
+      return r;
+
+    // backward up to the dPRE image; every parameter gradient but the projection weight's lands in the bag's slab
+    mhimx_reduce_list lst;
+    memset(&lst, 0, sizeof(lst));
+    mhimx_merge mwb = mw;
+    mwb.q_param = q_old; mwb.wo_t = wo_t; mwb.prepared = 0;
+    mhimx_merge_grad mg = {};
+    mg.d_ln_w = gs(c.grad.ln_w); mg.d_ln_b = gs(c.grad.ln_b); mg.d_wkv = gs(c.grad.wkv); mg.d_wq = gs(c.grad.wq); mg.d_wo = gs(c.grad.wo); mg.d_bo = gs(c.grad.bo);
+    mg.accumulate = 0; mg.splits = 8; mg.defer = &lst;
+    if (int r = mhimx_merge_bwd_park(&mwb, Hbuf, R, dH + N * E, dH, &mg, merge_ws, b.merge_ws_bytes)) return r;
+    {
+      mhimx_scorer sc_b = sc_s;
+      sc_b.wa_frag = nullptr;
+      mhimx_pool_grad pg = {};
+      pg.g_z = g_z; pg.dT1 = dH; pg.d_wa = gs(c.grad.wa); pg.d_wc = gs(c.grad.wc); pg.wa_t = wa_t; pg.accumulate = 0; pg.splits = 8; pg.defer = &lst;
+      pg.wa_t_frag = wa_t_frag;
+      if (int r = mhimx_abmil_pool_bwd(stream, &sc_b, &io_s, &pg)) return r;
+    }
+    if (int r = mhimx_merge_bwd(stream, &mwb, Hbuf, R, dH + N * E, dH, &mg, merge_ws, b.merge_ws_bytes)) return r;
+    if (int r = mhimx_rows_dpre_image(stream, dH, cv.at<char>(b.dact), rows_all, len_keep, E, cv.at<char>(b.img), gs(c.grad.b1), 0, cv.at<char>(b.ws_b), b.ws_b_bytes,
+                                      &lst))
+      return r;
+    if (int r = mhimx_reduce_flush(stream, &lst)) return r;          // (the Merge tail's remaining stages + every queued reduction, bag-batched)
+  }
+
+  // ---- 16. dW1 = sum_bags dPRE_b^T X_b: ONE launch, straight into the flat gradient
+  mhimx_reduce_list lst_w;
+  memset(&lst_w, 0, sizeof(lst_w));
+  {
+    mhimx_bag_wgrad_args ga[MHIMX_WINDOW_MAX];
+    for (int i = 0; i < n_bags; ++i) {
+      mhimx_bag_wgrad_args g = {};
+      g.img = bag(b.img, i); g.X = X[i]; g.ldx = ldx; g.n_bag_rows = N; g.rows = reinterpret_cast<const int64_t*>(bag(b.rows_all, i)); g.L = len_keep; g.E = E; g.D = D;
+      g.C = c.grad.w1; g.ldc = D; g.accumulate = 0; g.ws = cv.at<float>(b.wg_ws); g.ws_floats = b.wg_ws_floats; g.defer = &lst_w;
+      ga[i] = g;
+    }
+    if (int r = mhimx_bag_wgrad_multi(stream, ga, n_bags)) return r;
+  }
+  // ---- the queries' EMA chain over the window's tokens: q <- mm^n q + (1 - mm) sum_b mm^(n-1-b) z_b
+  {
+    QChainW cw;
+    const double mm = (double)c.merge_mm;
+    cw.wq = (float)pow(mm, (double)n_bags);
+    for (int i = 0; i < MHIMX_WINDOW_MAX; ++i) cw.w[i] = i < n_bags ? (float)((1.0 - mm) * pow(mm, (double)(n_bags - 1 - i))) : 0.f;
+    hipLaunchKernelGGL(window_q_chain_kernel, dim3((unsigned)cdiv(k * E, 256)), dim3(256), 0, st, S.q, Hbuf + N * E, BS / 4, (int)n_bags, k * E, cw);
+    MHIMX_LAUNCH_CHECK();
+  }
+  if (!update) {
+    if (int r = mhimx_reduce_flush(stream, &lst_w)) return r;
+    hipLaunchKernelGGL(window_sum_slabs_kernel, dim3((unsigned)(cdiv(c.n_train, 256) < 2048 ? cdiv(c.n_train, 256) : 2048)), dim3(256), 0, st, c.g, slab0, BS / 4,
+                       (int)n_bags, c.n_train);
+    MHIMX_LAUNCH_CHECK();
+    return 0;
+  }
+  // ---- 17. Adam + EMA teacher on g + the bags' slabs; the weight gradient's split-K slab sum is folded into the update
+  mhimx_optim_args o = {};
+  o.p = c.p; o.g = c.g; o.m = c.m; o.v = c.v; o.teacher = c.p_teacher; o.n_train = c.n_train; o.n_all = c.n_all; o.step = host_step; o.step_dev = c.opt_step;
+  o.lr = c.lr; o.lr_table = c.lr_table; o.lr_len = c.lr_len; o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.weight_decay = c.weight_decay;
+  o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = &lst_w;
+  o.g_extra = slab0; o.n_extra = n_bags; o.extra_pitch = BS / 4;
   return mhimx_optim_step(stream, &o);
 }
 

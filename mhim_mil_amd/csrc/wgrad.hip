@@ -912,8 +912,12 @@ __global__ __launch_bounds__(WTHREADS) void bag_wgrad_dma_kernel(WgradArgs g, co
 __global__ __launch_bounds__(256) void rows_dpre_image_kernel(const float* __restrict__ dH, const _Float16* __restrict__ dact,
                                                              const int64_t* __restrict__ rows, int64_t L, int E, char* __restrict__ img,
                                                              float* __restrict__ part, int side_blocks, Merge2Side side, int dh_compact,
-                                                             const uint8_t* __restrict__ keep) {
+                                                             const uint8_t* __restrict__ keep, BagBatch bb) {
   __shared__ __attribute__((aligned(16))) float lds[M2_PARTIALS_LDS > 3 * 256 * 4 ? M2_PARTIALS_LDS : 3 * 256 * 4];
+  if (blockIdx.z) {      // (common.hpp: a bag of an accumulation window)
+    MHIMX_BAG(dH); MHIMX_BAG(dact); MHIMX_BAG(rows); MHIMX_BAG(img); MHIMX_BAG(part); MHIMX_BAG(keep);
+    if (side_blocks > 0) bag_move(side, bb);
+  }
   if ((int)blockIdx.x < side_blocks) {          // a parked Merge-backward tail rides along (stage 1), its workgroups first
     merge2_side_stage(1, (int)blockIdx.x, lds, side);
     return;
@@ -1021,8 +1025,9 @@ static int rows_dpre_image_impl(void* stream, const float* dH, const void* dact1
     side_blocks = merge2_side_blocks(1, side);
     defer->side.pending = 2;
   }
-  hipLaunchKernelGGL(rows_dpre_image_kernel, dim3((unsigned)(ksteps * ncb + side_blocks)), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16,
-                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side, dh_compact, keep);
+  MHIMX_CHECK_ARG(cur_batch().n == 0 || !colsum_out || defer, "rows_dpre_image: a bag-batched launch queues its column sums");
+  hipLaunchKernelGGL(rows_dpre_image_kernel, bgrid((unsigned)(ksteps * ncb + side_blocks)), dim3(256), 0, (hipStream_t)stream, dH, (const _Float16*)dact16,
+                     rows, L, (int)E, (char*)img, colsum_out ? (float*)ws : nullptr, side_blocks, side, dh_compact, keep, cur_batch());
   MHIMX_LAUNCH_CHECK();
   if (colsum_out && !defer_push(defer, reduce_job_parts((const float*)ws, nblk, E, E, colsum_out, accumulate))) {
     const int rc = reduce_parts_now((hipStream_t)stream, (const float*)ws, nblk, E, E, colsum_out, accumulate);

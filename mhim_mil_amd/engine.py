@@ -241,6 +241,7 @@ def finish_tail(grad, student, n_train, scale, chain=None):
 # overlap (average concurrency 1.7, profiles/r03_window_timeline.md), not by kernel time.  Opt-in until the tail rides elsewhere.
 _STEP_IMAGES = os.environ.get("MHIMX_STEP_IMAGES", "1") != "0"       # TransMIL: the step's weight images in the preparation launch
 _FOREACH_GRADS = os.environ.get("MHIMX_FOREACH_GRADS", "1") != "0"   # autograd's per-parameter gradient adds as ONE multi-tensor launch
+_WINDOW_BATCHED = os.environ.get("MHIMX_WINDOW_BATCHED", "1") != "0"      # (round 6) mhimx_window_run for windows of same-shaped bags
 _WINDOW_WGRAD = os.environ.get("MHIMX_WINDOW_WGRAD", "0") != "0"
 _WINDOW_PROJECT = os.environ.get("MHIMX_WINDOW_PROJECT", "0") != "0"
 
@@ -338,6 +339,9 @@ class FusedTrainer:
         self.exec_max_rows = 262144        # include/mhimx.h MHIMX_STEP_MAX_ROWS
         self.single_pass = True            # ABMIL: one projection launch for teacher + student, bag-ordered buffers (when shapes allow)
         self.window_streams = 4            # accumulation windows (window_step): HIP streams the window's bags are issued on
+        # (round 6) a window of same-shaped bags as ONE C call with every launch over all its bags (mhimx_window_run, csrc/step.hip);
+        # MHIMX_WINDOW_BATCHED=0: the bags on HIP streams, as rounds 3-5 had it
+        self.window_batched = _WINDOW_BATCHED
         self._rows_cache = {}
 
     def _dist(self):
@@ -472,9 +476,9 @@ class FusedTrainer:
             t is not None and t.bag_ordered_ok(x) and not t.merge_test and s.merge_enable and s.v2_counts(x.shape[0], i) is not None)))
 
     # ------------------------------------------------------------------------------------------------- the step behind the C-ABI
-    def _exec_ok(self, x, i=None, perm=None, ids_shuffle=None):
+    def _exec_ok(self, x, i=None, perm=None, ids_shuffle=None, window=False):
         """True when mhimx_step_run takes this bag's step: the single-pass ABMIL step with device-drawn subsets, one process, one bag per
-        update, no injected draws (csrc/step.hip: check_cfg)."""
+        update, no injected draws (csrc/step.hip: check_cfg).  ``window``: as a bag of mhimx_window_run (several bags per update)."""
         s, t = self.s, self.t
         if ops.KERNEL_EVENT_HOOK is not None:          # (a caller brackets single launches with events: only the Python orchestration can)
             return False
@@ -482,7 +486,7 @@ class FusedTrainer:
         # QueryChain's scratch (mhimx_step_cfg.q_out), then the all-reduce and mhimx_optim_step as always - unless the eager step overlaps
         # its all-reduce with the backward (the mid-backward hook lives in the Python orchestration)
         hooked = (self.overlap_comm and self.comm is None and self.world > 1 and self.accum == 1 and not self._capturing and self._split > 0)
-        if not (self.use_executor and self.model_kind == "mhim" and self.accum == 1 and not hooked and perm is None
+        if not (self.use_executor and self.model_kind == "mhim" and (self.accum == 1 or window) and not hooked and perm is None
                 and ids_shuffle is None and self.ride_prep and s.training and s.n_classes <= 4 and s._op_prec != "f32"
                 and s.merge.k * 8 <= 48 and x.shape[1] % 256 == 0 and x.stride(0) % 4 == 0 and x.shape[0] * x.stride(0) * 4 < (1 << 32)):
             return False
@@ -556,6 +560,88 @@ class FusedTrainer:
         cfg.mm_table, cfg.mm_len = (None, 0) if self.mm_table is None else (self.mm_table.data_ptr(), self.mm_table.numel())
         cfg.lr_table, cfg.lr_len = (None, 0) if self.lr_table is None else (self.lr_table.data_ptr(), self.lr_table.numel())
         return ex
+
+    def _exec_window_ok(self, xs, labels, i=None):
+        """True when mhimx_window_run takes this window: 2..8 bags of ONE shape that each pass _exec_ok, up to 16 384 rows (the one-workgroup
+        select), merge_k <= 6, one process, no mid-run ratio schedule (csrc/step.hip: check_window)."""
+        from . import _lib as LB
+        n = len(xs)
+        if not (self.window_batched and 2 <= n <= LB.WINDOW_MAX and self.world == 1 and self._chain is None and not self.step_dag
+                and self.flat.n_all % 4 == 0 and self.s.merge.k <= 6 and self.s.mrh_sche is None):
+            return False
+        x0 = xs[0]
+        if not (x0.dim() == 2 and x0.shape[0] <= 16384 and all(x.shape == x0.shape and x.stride() == x0.stride() and x.device == x0.device for x in xs)):
+            return False
+        if not all(torch.is_tensor(l) and l.is_cuda and l.dtype == torch.int64 and l.numel() == 1 and l.device == x0.device for l in labels):
+            return False
+        return all(self._exec_ok(x, i, window=True) for x in xs)
+
+    def _exec_window(self, xs, labels, i, update):
+        """One accumulation window as ONE call of mhimx_window_run: every launch between the projections and the weight gradient covers all
+        the bags (include/mhimx.h).  Returns ([logits per bag], [losses per bag]); self.last["bags"] holds each bag's views."""
+        import ctypes as C
+        L = mh.L
+        s, t, fl = self.s, self.t, self.flat
+        n = len(xs)
+        ex = self._exec_cfg()
+        N = xs[0].shape[0]
+        k, n_sel, len_keep, Lk, R = s.v2_counts(N, i)
+        key = ("window", n, N, k, n_sel, Lk)
+        ent = ex["layouts"].get(key)
+        if ent is None:
+            cnt = L.StepCounts(k_top=k, n_sel=n_sel, len_keep=len_keep, Lk=Lk, R=R)
+            lay = L.WindowLayout()
+            L.check(L.lib().mhimx_window_layout_of(C.byref(ex["cfg"]), n, N, C.byref(cnt), C.byref(lay)), "mhimx_window_layout_of")
+            ent = ex["layouts"][key] = (cnt, lay)
+        cnt, lay = ent
+        dev = xs[0].device
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(lay.total, dtype=torch.uint8, device=dev)
+        else:
+            ws = ex.get("ws_win")
+            if ws is None or ws.numel() < lay.total or ws.device != dev:
+                ws = ex["ws_win"] = torch.empty(lay.total, dtype=torch.uint8, device=dev)
+        # the labels as one int64 [n] list (the head's grid plane b reads entry b)
+        if all(labels[j].data_ptr() == labels[0].data_ptr() + 8 * j for j in range(n)):
+            lab = labels[0]
+        else:
+            lab = torch.cat([l.reshape(1) for l in labels])
+        # (the order the stream form with MHIMX_WINDOW_PROJECT=1 draws them in: every bag's dropout streams at the projection, then bag
+        # after bag the select's and Merge's - the two forms of a window make the same draws)
+        seeds = (L.StepSeeds * n)()
+        for j in range(n):
+            seeds[j].drop_teacher, seeds[j].drop_student = t._next_seed(teacher=True), s._next_seed()
+        for j in range(n):
+            seeds[j].select, seeds[j].mca = s._next_seed(), s._next_seed()
+        Xp = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        inside = bool(update and not self.clip_grad)              # (clipping needs the norm of the final gradient: the update stays outside)
+        L.check(L.lib().mhimx_window_run(ops._stream(), C.byref(ex["cfg"]), n, Xp, xs[0].stride(0), N, lab.data_ptr(), C.byref(cnt), seeds,
+                                         fl.step + int(inside), ws.data_ptr(), ws.numel(), int(inside)), "mhimx_window_run")
+        km, E = s.merge.k, s.mlp_dim
+        bg = lay.bag
+
+        def view(off, j, cnt_, dtype=torch.float32):
+            o = off + j * lay.bag_stride
+            return ws[o:o + cnt_ * dtype.itemsize].view(dtype)
+
+        per, logits, losses = [], [], []
+        for j in range(n):
+            Hs = view(bg.H_student, j, (N + km) * E).view(N + km, E)
+            lg, ls = view(bg.logits, j, s.n_classes), view(bg.losses, j, 3)
+            rows_all = view(bg.rows_all, j, cnt.len_keep + km, torch.int64)
+            per.append({"logits": lg, "losses": ls, "patch_num": N, "keep_num": cnt.Lk + km, "rows": rows_all[:cnt.len_keep],
+                        "score": view(bg.score, j, N), "R": cnt.R, "tokens": Hs[N:], "H_student": Hs[:N],
+                        "H_teacher": view(bg.H_teacher, j, N * E).view(N, E)})
+            logits.append(lg); losses.append(ls)
+        self.last = dict(per[-1], logits=logits, losses=losses, bags=per, ws=ws, labels=lab)
+        self._micro = n
+        if inside:
+            fl.step += 1
+            ops.step_images(None)
+            self._micro = 0
+        elif update:
+            self.update()
+        return logits, losses
 
     def _exec_plan(self, ex, N, i):
         """(counts, layout) of a bag of N rows at iteration i - cached: they follow from N and the HAM ratio alone."""
@@ -865,6 +951,8 @@ class FusedTrainer:
                     for j, (b, l) in enumerate(zip(bags, labels))]
             return [o[0] for o in outs], [o[1] for o in outs]
         assert self._micro == 0, "window_step starts a fresh accumulation window"
+        if self._exec_window_ok(xs, labels, i):
+            return self._exec_window(xs, labels, i, update)
         S = max(1, min(int(n_streams or self.window_streams), k))
         dev = xs[0].device
         s, fl = self.s, self.flat

@@ -86,15 +86,17 @@ def _window_vs_oracle(tr, s, t, bags, labels, stu, tea, opt, ocfg, step, n, k, n
     return stu2, tea2, opt2, info
 
 
-@pytest.fixture(params=["per-bag GEMM launches", "one launch per GEMM"])
+@pytest.fixture(params=["per-bag GEMM launches", "one launch per GEMM", "every launch over all bags"])
 def window_gemms(request):
-    """The window's projections / weight-gradient products per bag (default) or as ONE launch each (mhimx_bag_project_multi /
-    mhimx_bag_wgrad_multi; opt-in: MHIMX_WINDOW_PROJECT / MHIMX_WINDOW_WGRAD)."""
+    """The window's bags on HIP streams with the projections / weight-gradient products per bag or as ONE launch each
+    (mhimx_bag_project_multi / mhimx_bag_wgrad_multi; opt-in: MHIMX_WINDOW_PROJECT / MHIMX_WINDOW_WGRAD) - or (round 6, the default for
+    same-shaped bags) the whole window as ONE call of mhimx_window_run: every launch covers all the bags."""
     from mhim_mil_amd import engine as EN
-    old = EN._WINDOW_PROJECT, EN._WINDOW_WGRAD
+    old = EN._WINDOW_PROJECT, EN._WINDOW_WGRAD, EN._WINDOW_BATCHED
     EN._WINDOW_PROJECT = EN._WINDOW_WGRAD = request.param == "one launch per GEMM"
+    EN._WINDOW_BATCHED = request.param == "every launch over all bags"
     yield request.param
-    EN._WINDOW_PROJECT, EN._WINDOW_WGRAD = old
+    EN._WINDOW_PROJECT, EN._WINDOW_WGRAD, EN._WINDOW_BATCHED = old
 
 
 @pytest.mark.parametrize("n_streams", [1, 3])
@@ -152,6 +154,56 @@ def test_window_streams_do_not_change_the_result():
     g0, g1 = res[0][2].numpy(), res[1][2].numpy()
     np.testing.assert_allclose(g0, g1, atol=2e-6 * np.abs(g0).max(), rtol=1e-4)
     assert torch.equal(res[0][3], res[1][3])
+
+
+def test_batched_window_equals_the_stream_window():
+    """mhimx_window_run (every launch over all the bags, round 6) against the same window on HIP streams with per-bag launches of the same
+    kernels: the two forms draw the same seeds, so per-bag scores, row lists and logits are bit-identical; the accumulated gradient and the
+    updated parameters agree up to the slab counts that follow a launch's size; dropout 0.25, 8 bags, then a second window."""
+    from mhim_mil_amd import engine as EN
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d, acc = 1500, 256, 8
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    cfg = dict(V2, dropout=0.25)
+    xs = [torch.from_numpy(synth.bag(900 + j, n, d)).to(DEV)[None] for j in range(acc)]
+    ls = [torch.tensor([j % 2], device=DEV) for j in range(acc)]
+    old = EN._WINDOW_PROJECT, EN._WINDOW_BATCHED
+    res = []
+    try:
+        for batched in (False, True):
+            EN._WINDOW_PROJECT, EN._WINDOW_BATCHED = True, batched
+            torch.manual_seed(5)
+            s, t = _mk(base, d, **cfg), _mk(synth.spread_teacher(base), d, **cfg)
+            tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997, accumulation_steps=acc)
+            assert tr._exec_window_ok([x[0] for x in xs], ls) == batched
+            out = []
+            for w in range(2):
+                logits, losses = tr.window_step(xs, ls, n_streams=2, update=False)
+                torch.cuda.synchronize()
+                per = tr.last["bags"]
+                out.append((torch.stack([l.reshape(-1) for l in logits]).cpu().clone(), torch.stack([l.reshape(-1)[:3] for l in losses]).cpu().clone(),
+                            [b["rows"].cpu().clone() for b in per], [b["score"].cpu().clone() for b in per], [b["tokens"].cpu().clone() for b in per],
+                            tr.flat.grad.cpu().clone(), s.merge.global_q_mm.detach().cpu().clone()))
+                tr.update()
+                torch.cuda.synchronize()
+                out.append(tr.flat.student.cpu().clone())
+            res.append(out)
+    finally:
+        EN._WINDOW_PROJECT, EN._WINDOW_BATCHED = old
+    a, b = res
+    for w in (0, 2):
+        if w == 0:                                                         # (the second window starts from parameters that differ in the last bits)
+            assert torch.equal(a[w][0], b[w][0]) and torch.equal(a[w][1], b[w][1])
+            assert all(torch.equal(x, y) for x, y in zip(a[w][2], b[w][2]))
+            assert all(torch.equal(x, y) for x, y in zip(a[w][3], b[w][3]))
+            assert all(torch.equal(x, y) for x, y in zip(a[w][4], b[w][4]))
+        else:
+            np.testing.assert_allclose(a[w][0].numpy(), b[w][0].numpy(), atol=2e-5, rtol=0)
+        g0, g1 = a[w][5].numpy(), b[w][5].numpy()
+        np.testing.assert_allclose(g0, g1, atol=3e-6 * np.abs(g0).max(), rtol=1e-4)
+        np.testing.assert_allclose(a[w][6].numpy(), b[w][6].numpy(), atol=1e-6, rtol=0)
+        p0, p1 = a[w + 1].numpy(), b[w + 1].numpy()
+        assert np.abs(p0 - p1).mean() < 2e-6, np.abs(p0 - p1).mean()
 
 
 def test_projection_and_weight_gradient_of_several_bags_in_one_launch():
