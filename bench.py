@@ -314,7 +314,9 @@ def hbm_copy_rate(dev):
 
 def accumulate8(a, dev, bags, labels):
     """--accumulation_steps 8 (base_engine.py:29,100-119; SURVEY 8(d) c4: 'also report accumulate-8'): one optimiser update per 8 bags,
-    the window captured as ONE hipGraph (FusedTrainer.capture_window: one preparation, the 8 bags on HIP streams, one Adam + EMA)."""
+    the window captured as ONE hipGraph (FusedTrainer.capture_window).  Round 6: the window is ONE call of mhimx_window_run - every
+    launch between the projections and the weight gradient covers all 8 bags (gridDim.z = bag), ~20 launches per window;
+    MHIMX_WINDOW_BATCHED=0: the bags on HIP streams (~127 launches), as rounds 3-5 had it."""
     from mhim_mil_amd.engine import FusedTrainer
     K, reps, warm = 8, 12, 3
     student, teacher, _ = make_models(dev, a.prec)
@@ -329,7 +331,9 @@ def accumulate8(a, dev, bags, labels):
     else:
         wins = [tr.capture_window(b, l, warmup=1, n_streams=a.window_streams) for b, l in sets]
         run = [w.replay for w in wins]
-        launch = "ONE hipGraph per window, the HIP streams as its branches"
+        batched = tr._exec_window_ok([b[0] if b.dim() == 3 else b for b in sets[0][0]], sets[0][1])
+        launch = ("ONE hipGraph per window: mhimx_window_run, every launch over all 8 bags (one projection launch, the step's middle with one grid plane "
+                  "per bag, one weight-gradient launch, one Adam + EMA)" if batched else "ONE hipGraph per window, the HIP streams as its branches")
     for i in range(warm):
         run[i % 2]()
     torch.cuda.synchronize()

@@ -737,6 +737,9 @@ typedef struct {
                                    kernel itself while it reads the gradient - same order, same bits, no separate pass over the slabs;
                                    whatever else the list holds is flushed first (mhimx_reduce_flush).  Not with clip_norm (the norm needs the
                                    final gradient): the whole list is flushed then. */
+  int64_t extra_lo;             /* (round 6) the slabs of g_extra cover the gradient elements [extra_lo, n_train) only (a multiple of 4; 0: all)  */
+  int32_t extra_only;           /* 1: from extra_lo on the gradient is the slabs' sum ALONE - g is neither read nor expected to hold anything
+                                   there (mhimx_window_run: g carries feature.0.weight's gradient, the bags' slabs everything else)            */
 } mhimx_optim_args;
 int mhimx_optim_step(void* stream, const mhimx_optim_args* a);
 
@@ -836,9 +839,10 @@ int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags,
  * optimiser step) with every launch over ALL its bags (round 6): one preparation, both projections of the n bags in one launch, the step's
  * middle (teacher scorer, select, Merge, student scorer, head, backward to the dPRE image) issued once with one grid plane per bag, ONE
  * weight-gradient launch over the n images, the EMA chain of the global queries, Adam + EMA: ~22 launches instead of n x 16.
- * The bags have ONE shape: X[b] [N, ldx] fp32 device (b < n_bags, 2 <= n_bags <= MHIMX_WINDOW_MAX), N <= 16384, merge_k <= 6; labels_dev
- * int64 [n_bags] CONTIGUOUS on the device; seeds [n_bags]; cfg as for mhimx_step_run with every cfg->grad view inside cfg->g[0, n_train)
- * (q_out, side_stream, time_project unused: NULL / 0).  Every bag's loss is scaled by 1 / n_bags.  Per bag the arithmetic is
+ * The bags have ONE shape: X[b] [N, ldx] fp32 device (b < n_bags, 2 <= n_bags <= MHIMX_WINDOW_MAX), N <= 16384, merge_k <= 6; labels_dev[b]
+ * int64 [1] on the device; seeds [n_bags]; cfg as for mhimx_step_run with every cfg->grad view inside cfg->g[0, n_train) and
+ * feature.0.weight's FIRST (cfg->grad.w1 == cfg->g: the flat buffer then holds that gradient and nothing else until the update adds the
+ * bags' slabs; q_out, side_stream, time_project unused: NULL / 0).  Every bag's loss is scaled by 1 / n_bags.  Per bag the arithmetic is
  * mhimx_step_run(update = 0)'s with that bag's seeds and the window's FIRST global queries (the queries' EMA is chained over the n token sets
  * afterwards: q <- mm^n q + (1 - mm) sum_b mm^(n-1-b) z_b - second order in 1 - merge_mm against the bag-after-bag order).
  * update = 1: Adam + EMA on the summed gradient; update = 0: the summed gradient is left in cfg->g.
@@ -847,7 +851,7 @@ int mhimx_step_run_many(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags,
 typedef struct { int64_t total, bag0, bag_stride, grad_slab; mhimx_step_layout bag; } mhimx_window_layout;
 int mhimx_window_layout_of(const mhimx_step_cfg* cfg, int32_t n_bags, int64_t N, const mhimx_step_counts* cnt, mhimx_window_layout* out);
 int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, int64_t ldx, int64_t N,
-                     const int64_t* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws,
+                     const int64_t* const* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws,
                      int64_t ws_bytes, int32_t update);
 
 /* dst = src (float4 grid-stride stream copy): the on-box HBM copy rate bench.py reports beside the nominal 8 TB/s */

@@ -170,7 +170,7 @@ class OptimArgs(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("grad_scale", C.c_float),
                 ("ema_mm", C.c_float), ("mm_table", C.c_void_p), ("mm_len", C.c_int64), ("zero_grad", C.c_int32),
                 ("g_extra", C.c_void_p), ("n_extra", C.c_int64), ("extra_pitch", C.c_int64), ("clip_norm", C.c_float),
-                ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("fold", C.c_void_p)]
+                ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("fold", C.c_void_p), ("extra_lo", C.c_int64), ("extra_only", C.c_int32)]
 
 
 class StepParams(C.Structure):
@@ -327,7 +327,7 @@ SYMBOLS = {
     "mhimx_step_run": (C.c_int, [_P, C.POINTER(StepCfg), _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),
     "mhimx_step_project_ms": (C.c_int, [_P, _P, _I32]),
     "mhimx_window_layout_of": (C.c_int, [C.POINTER(StepCfg), _I32, _I64, C.POINTER(StepCounts), C.POINTER(WindowLayout)]),
-    "mhimx_window_run": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),
+    "mhimx_window_run": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _I64, _I64, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64, _I32]),   # (labels: void*[n])
     "mhimx_step_run_many": (C.c_int, [_P, C.POINTER(StepCfg), _I32, _P, _P, _P, _P, C.POINTER(StepCounts), C.POINTER(StepSeeds), _I64, _P, _I64]),
 }
 

@@ -105,8 +105,8 @@ struct Arena {
 // blockIdx.z = the bag a workgroup works for.  The bags have the same shape and each owns a copy of the step's workspace at a fixed stride,
 // so the host enqueues the window's middle exactly as it enqueues one bag's - with bag 0's pointers - and every kernel on that path starts
 // by moving the pointers it was given to its own bag's copy: a pointer inside one of (up to three) address ranges moves by bag * stride of
-// that range (the per-bag workspace; the labels, 8 bytes apart); any other pointer (parameters, prepared weight images, the dropout tick)
-// is shared by the bags and stays.  Seeds: a bag's counter-hash streams differ from bag 0's by a per-bag additive constant (every seed the
+// that range (the per-bag workspace), a pointer equal to the table key (bag 0's label) is replaced by the bag's table entry; any other
+// pointer (parameters, prepared weight images, the dropout tick) is shared by the bags and stays.  Seeds: a bag's counter-hash streams differ from bag 0's by a per-bag additive constant (every seed the
 // host derives is seed + constant).  A plain launch has n = 0 and gridDim.z = 1: blockIdx.z = 0 moves nothing.
 constexpr int BAG_BATCH_MAX = MHIMX_WINDOW_MAX;
 struct BagBatch {
@@ -114,6 +114,7 @@ struct BagBatch {
   uint64_t lo[3], span[3];
   int64_t stride[3];
   uint64_t dsel[BAG_BATCH_MAX], dmca[BAG_BATCH_MAX];       // seed of bag b = seed of bag 0 + d*[b] (the select's / Merge's streams)
+  uint64_t tab_key, tab[BAG_BATCH_MAX];                    // a pointer EQUAL to tab_key (bag 0's label) stands for tab[b] in bag b's plane
 };
 // host: the batch the calling thread is enqueueing (none: n = 0), set by the window executor around the window's middle
 const BagBatch& cur_batch();
@@ -131,6 +132,7 @@ MHIMX_DEV T* bag_ptr(T* p, const BagBatch& bb) {
 #pragma unroll
   for (int r = 0; r < 3; ++r)
     if (a - bb.lo[r] < bb.span[r]) return reinterpret_cast<T*>(a + (uint64_t)bag * (uint64_t)bb.stride[r]);
+  if (a == bb.tab_key) return reinterpret_cast<T*>(bb.tab[bag]);
   return p;
 }
 #define MHIMX_BAG(p) p = ::mhimx::bag_ptr(p, bb)

@@ -13,6 +13,7 @@
 // 16-byte aligned rows.
 #include <string.h>
 
+#include <stdlib.h>
 #include "common.hpp"
 #include "mca2_rows.hpp"
 #include "prep_jobs.hpp"
@@ -667,6 +668,13 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
   int64_t want = cdiv(512, tiles);
   if (want > cdiv(g.M, 4 * DBK)) want = cdiv(g.M, 4 * DBK);
   if (want < 1) want = 1;
+  // (a bag-batched launch, common.hpp: the bags' products TOGETHER fill the chip - one round of 256 workgroups, at least 8 slabs per bag;
+  // 8 bags at the single-bag slab count were 2048 workgroups in 8 rounds, 88 us, and 56 slabs per bag for the reduction to sum)
+  if (cur_batch().n > 1) {
+    int64_t share = 256 / (tiles * cur_batch().n) / 8 * 8;
+    if (share < 8) share = 8;
+    if (want > share) want = share;
+  }
   if (g.ws && want > splits) splits = (int)want;
   while (splits > 1 && (int64_t)splits * g.K1 * g.K2 > ws_floats_avail) --splits;
   while (cdiv(g.M, splits) > MAX_TN_CHUNK) {
@@ -689,7 +697,10 @@ int gemm_tn_dma(hipStream_t st, const mhimx_gemm_tn_args& g0, int64_t ws_floats_
     int64_t room = (nbags > 1 ? 512 / nbags : 256) - rows_blocks;
     if (nbags > 1 && room < 8 * tiles) room = 8 * tiles;
     int cap = (int)(room / tiles) / 8 * 8;
-    if (cap < 8 || rows_blocks > 128) rows_blocks = 0;            // no room for the product beside the rows: they do not ride
+    // (MEASURED, 8 bags: with the rows riding every workgroup of the launch takes the rows pass's LDS - one per CU, 768 workgroups, three rounds,
+    // 131 us; apart, the product keeps its own slab count and the rows pass is a launch of two rounds.  MHIMX_WINDOW_ROWS_RIDE=1: together)
+    static const bool batched_ride = getenv("MHIMX_WINDOW_ROWS_RIDE") != nullptr && atoi(getenv("MHIMX_WINDOW_ROWS_RIDE")) != 0;
+    if (cap < 8 || rows_blocks > 128 || (nbags > 1 && !batched_ride)) rows_blocks = 0;      // no room for the product beside the rows: they do not ride
     else if (splits > cap) splits = cap;
   }
   if (size_only) { rows_blocks = 0; rider = nullptr; }

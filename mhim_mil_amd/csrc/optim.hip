@@ -315,7 +315,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void dsmil_head_kernel(const float* _
 constexpr int FOLD_MAX = 4;
 struct FoldJobs { const float* parts[FOLD_MAX]; int64_t off[FOLD_MAX], n[FOLD_MAX]; int G[FOLD_MAX], accumulate[FOLD_MAX]; int count; };
 struct OptimExtra { const float* lr_table; int64_t lr_len; const float* g_extra; int64_t n_extra, extra_pitch; float clip_norm;
-                    const float* sq_parts; int n_parts; FoldJobs fold; };
+                    const float* sq_parts; int n_parts; FoldJobs fold; int64_t extra_lo; int extra_only; };
 
 // the slab sum of reduce_jobs.hpp (kind 1) for four neighbouring elements: four running sums, eight slabs in flight, then four, then one -
 // the same additions in the same order, so a folded gradient has the bits of a reduced one
@@ -339,8 +339,10 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict
   __shared__ float red[256];
   float a = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float v = g[i];
-    for (int64_t z = 0; z < ex.n_extra; ++z) v += ex.g_extra[z * ex.extra_pitch + i];
+    const bool slabs = i >= ex.extra_lo;
+    float v = (slabs && ex.extra_only) ? 0.f : g[i];
+    if (slabs)
+      for (int64_t z = 0; z < ex.n_extra; ++z) v += ex.g_extra[z * ex.extra_pitch + i];
     v *= gscale;
     a += v * v;
   }
@@ -419,14 +421,16 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
     if (vec_ok && q < n4 && (i0 + 4 <= n_train || i0 >= n_train)) {
       float4 w = reinterpret_cast<float4*>(p)[q];
       if (i0 < n_train) {
-        float4 gi = reinterpret_cast<float4*>(g)[q], mi = reinterpret_cast<float4*>(m)[q], vi = reinterpret_cast<float4*>(v)[q];
+        const bool slabs = i0 >= ex.extra_lo;                 // (extra_lo % 4 == 0: the four elements are on one side)
+        float4 gi = (slabs && ex.extra_only) ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(g)[q];
+        float4 mi = reinterpret_cast<float4*>(m)[q], vi = reinterpret_cast<float4*>(v)[q];
         for (int f = 0; f < ex.fold.count; ++f)           // a folded split-K slab sum: this gradient element is summed here, not by a reduction pass
           if (i0 >= ex.fold.off[f] && i0 < ex.fold.off[f] + ex.fold.n[f]) {
             const float4 sv = fold_sum4(ex.fold.parts[f], ex.fold.n[f], i0 - ex.fold.off[f], ex.fold.G[f]);
             if (ex.fold.accumulate[f]) { gi.x += sv.x; gi.y += sv.y; gi.z += sv.z; gi.w += sv.w; }
             else gi = sv;
           }
-        for (int64_t z = 0; z < ex.n_extra; ++z) {       // gradient slabs of the other streams of an accumulation window (fixed order)
+        for (int64_t z = 0; slabs && z < ex.n_extra; ++z) {       // gradient slabs of an accumulation window's other streams / bags (fixed order)
           const float4 e = *reinterpret_cast<const float4*>(ex.g_extra + z * ex.extra_pitch + i0);
           gi.x += e.x; gi.y += e.y; gi.z += e.z; gi.w += e.w;
         }
@@ -450,8 +454,9 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(
     for (int64_t i = i0; i < i0 + 4 && i < n_all; ++i) {
       float w = p[i];
       if (i < n_train) {
-        float gi = g[i], mi = m[i], vi = v[i];
-        for (int64_t z = 0; z < ex.n_extra; ++z) gi += ex.g_extra[z * ex.extra_pitch + i];
+        const bool slabs = i >= ex.extra_lo;
+        float gi = (slabs && ex.extra_only) ? 0.f : g[i], mi = m[i], vi = v[i];
+        for (int64_t z = 0; slabs && z < ex.n_extra; ++z) gi += ex.g_extra[z * ex.extra_pitch + i];
         adam_one(w, gi, mi, vi, lr_over_bc1, bc2s, beta1, beta2, eps, wd, gscale);
         m[i] = mi;
         v[i] = vi;
@@ -509,9 +514,11 @@ extern "C" int mhimx_optim_step(void* stream, const mhimx_optim_args* a) {
   MHIMX_CHECK_ARG(a->n_extra >= 0 && (a->n_extra == 0 || (a->g_extra && a->extra_pitch >= a->n_train && a->extra_pitch % 4 == 0 && aligned16(a->g_extra))),
                   "optim_step: gradient slabs need a 16-byte aligned base and a pitch >= n_train that is a multiple of 4");
   MHIMX_CHECK_ARG(!(a->clip_norm > 0.f) || (a->ws && a->ws_floats >= 1024), "optim_step: clipping needs a workspace of 1024 floats");
+  MHIMX_CHECK_ARG(a->extra_lo >= 0 && a->extra_lo % 4 == 0 && (a->n_extra > 0 || (a->extra_lo == 0 && !a->extra_only)),
+                  "optim_step: extra_lo (a multiple of 4) / extra_only describe the gradient slabs of g_extra");
   int64_t step = a->step < 1 ? 1 : a->step;
   if (a->n_all == 0) return 0;
-  OptimExtra ex{a->lr_table, a->lr_len, a->g_extra, a->n_extra, a->extra_pitch, a->clip_norm > 0.f ? a->clip_norm : 0.f, a->ws, 0, {}};
+  OptimExtra ex{a->lr_table, a->lr_len, a->g_extra, a->n_extra, a->extra_pitch, a->clip_norm > 0.f ? a->clip_norm : 0.f, a->ws, 0, {}, a->extra_lo, a->extra_only};
   if (a->fold) {
     mhimx_reduce_list* l = a->fold;
     MHIMX_CHECK_ARG(l->n >= 0 && l->n <= MHIMX_REDUCE_MAX, "optim_step: bad reduction list");

@@ -484,10 +484,10 @@ __global__ __launch_bounds__(256) void window_q_chain_kernel(float* __restrict__
     q[i] = q[i] * cw.wq + acc;
   }
 }
-// g += sum_b slab_b   (update = 0: the window's complete gradient in the flat buffer)
+// g = sum_b slab_b   (update = 0: the window's complete gradient in the flat buffer; bag order, as the update kernel adds them)
 __global__ __launch_bounds__(256) void window_sum_slabs_kernel(float* __restrict__ g, const float* __restrict__ slab0, int64_t pitch, int n_bags, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float acc = g[i];
+    float acc = 0.f;
     for (int b = 0; b < n_bags; ++b) acc += slab0[b * pitch + i];
     g[i] = acc;
   }
@@ -503,6 +503,8 @@ int check_window(const mhimx_step_cfg* c, int32_t n_bags, int64_t N, const mhimx
   const float* gp[12] = {g.w1, g.b1, g.wa, g.wc, g.wp, g.bp, g.ln_w, g.ln_b, g.wkv, g.wq, g.wo, g.bo};
   for (int i = 0; i < 12; ++i)
     MHIMX_CHECK_ARG(gp[i] >= c->g && gp[i] < c->g + c->n_train, "window: every gradient view lies inside the flat gradient buffer g[0, n_train)");
+  MHIMX_CHECK_ARG(g.w1 == c->g && (c->E * c->D) % 4 == 0, "window: feature.0.weight's gradient is the FIRST block of the flat gradient buffer");
+  for (int i = 1; i < 12; ++i) MHIMX_CHECK_ARG(gp[i] >= c->g + c->E * c->D, "window: gradient views overlap feature.0.weight's");
   return 0;
 }
 
@@ -520,12 +522,12 @@ extern "C" int mhimx_window_layout_of(const mhimx_step_cfg* cfg, int32_t n_bags,
 }
 
 extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t n_bags, const float* const* X, int64_t ldx, int64_t N,
-                                const int64_t* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws,
+                                const int64_t* const* labels_dev, const mhimx_step_counts* cnt, const mhimx_step_seeds* seeds, int64_t host_step, void* ws,
                                 int64_t ws_bytes, int32_t update) {
   if (int r = check_window(cfg, n_bags, N, cnt)) return r;
   MHIMX_CHECK_ARG(X && labels_dev && seeds && ws && ldx >= cfg->D && ldx % 4 == 0 && N * ldx * 4 < ((int64_t)1 << 32),
                   "window: null bags / labels / seeds / workspace, or a row pitch the weight-gradient product does not take");
-  for (int32_t i = 0; i < n_bags; ++i) MHIMX_CHECK_ARG(X[i] && aligned16(X[i]), "window: bag %d null or not 16-byte aligned", i);
+  for (int32_t i = 0; i < n_bags; ++i) MHIMX_CHECK_ARG(X[i] && aligned16(X[i]) && labels_dev[i], "window: bag %d / its label null or not 16-byte aligned", i);
   MHIMX_CHECK_ARG(!update || (cfg->p && cfg->m && cfg->v), "window: update needs the flat optimiser buffers");
   StepBufs b;
   layout(cfg, N, cnt, &b, n_bags);
@@ -557,9 +559,10 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
   const uint64_t* tick = c.tick;
   auto gs = [&](float* view) { return slab0 + (view - c.g); };          // a gradient view's place in bag 0's slab
 
-  // the flat gradient takes the weight gradient of the projection (written by the window's ONE product) and nothing else: the bags' slabs are
-  // added by the update kernel (g_extra) / by window_sum_slabs_kernel
-  MHIMX_HIP(hipMemsetAsync(c.g, 0, (size_t)c.n_train * sizeof(float), st));
+  // the flat gradient takes the weight gradient of the projection (the window's ONE product writes it: elements [0, E D)) and nothing else;
+  // from E D on the gradient is the sum of the bags' slabs - taken by the update kernel itself (g_extra, extra_lo, extra_only) or written
+  // into the flat buffer by window_sum_slabs_kernel (update = 0)
+  const int64_t g_lo = E * D;
 
   // ---- 1. preparation, once for the window (nothing rides: the middle's launches are bag-batched)
   mhimx_merge mw_prep = {};
@@ -606,10 +609,11 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
   BagBatch bb = {};
   bb.n = n_bags;
   bb.lo[0] = reinterpret_cast<uint64_t>(cv.at<char>(b.bag0)); bb.span[0] = (uint64_t)BS; bb.stride[0] = BS;
-  bb.lo[1] = reinterpret_cast<uint64_t>(labels_dev); bb.span[1] = 8; bb.stride[1] = 8;
+  bb.tab_key = reinterpret_cast<uint64_t>(labels_dev[0]);
   for (int i = 0; i < n_bags; ++i) {
     bb.dsel[i] = seeds[i].select - seeds[0].select;
     bb.dmca[i] = seeds[i].mca - seeds[0].mca;
+    bb.tab[i] = reinterpret_cast<uint64_t>(labels_dev[i]);
   }
   struct BatchScope {                                                 // (every return path leaves the thread without a batch)
     explicit BatchScope(const BagBatch* p) { set_batch(p); }
@@ -658,7 +662,7 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
 
     // head: every bag's loss / n_bags (base_engine.py:102)
     float* g_z = cv.at<float>(b.g_z);
-    if (int r = mhimx_head_fwd_bwd(stream, io_s.z, c.aux_alpha != 0.f ? z_t : nullptr, S.wp, S.bp, labels_dev, E, C, c.temp_t, c.main_alpha, c.aux_alpha,
+    if (int r = mhimx_head_fwd_bwd(stream, io_s.z, c.aux_alpha != 0.f ? z_t : nullptr, S.wp, S.bp, labels_dev[0], E, C, c.temp_t, c.main_alpha, c.aux_alpha,
                                    1.f / (float)n_bags, cv.at<float>(b.logits), cv.at<float>(b.losses), g_z, gs(c.grad.wp), gs(c.grad.bp), 0, nullptr, nullptr))
       return r;
 
@@ -710,8 +714,8 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
   }
   if (!update) {
     if (int r = mhimx_reduce_flush(stream, &lst_w)) return r;
-    hipLaunchKernelGGL(window_sum_slabs_kernel, dim3((unsigned)(cdiv(c.n_train, 256) < 2048 ? cdiv(c.n_train, 256) : 2048)), dim3(256), 0, st, c.g, slab0, BS / 4,
-                       (int)n_bags, c.n_train);
+    hipLaunchKernelGGL(window_sum_slabs_kernel, dim3((unsigned)(cdiv(c.n_train - g_lo, 256) < 2048 ? cdiv(c.n_train - g_lo, 256) : 2048)), dim3(256), 0, st,
+                       c.g + g_lo, slab0 + g_lo, BS / 4, (int)n_bags, c.n_train - g_lo);
     MHIMX_LAUNCH_CHECK();
     return 0;
   }
@@ -720,7 +724,7 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
   o.p = c.p; o.g = c.g; o.m = c.m; o.v = c.v; o.teacher = c.p_teacher; o.n_train = c.n_train; o.n_all = c.n_all; o.step = host_step; o.step_dev = c.opt_step;
   o.lr = c.lr; o.lr_table = c.lr_table; o.lr_len = c.lr_len; o.beta1 = c.beta1; o.beta2 = c.beta2; o.eps = c.eps; o.weight_decay = c.weight_decay;
   o.grad_scale = 1.f; o.ema_mm = c.ema_mm; o.mm_table = c.mm_table; o.mm_len = c.mm_len; o.zero_grad = 1; o.fold = &lst_w;
-  o.g_extra = slab0; o.n_extra = n_bags; o.extra_pitch = BS / 4;
+  o.g_extra = slab0; o.n_extra = n_bags; o.extra_pitch = BS / 4; o.extra_lo = g_lo; o.extra_only = 1;
   return mhimx_optim_step(stream, &o);
 }
 

@@ -567,7 +567,7 @@ class FusedTrainer:
         from . import _lib as LB
         n = len(xs)
         if not (self.window_batched and 2 <= n <= LB.WINDOW_MAX and self.world == 1 and self._chain is None and not self.step_dag
-                and self.flat.n_all % 4 == 0 and self.s.merge.k <= 6 and self.s.mrh_sche is None):
+                and self.flat.n_all % 4 == 0 and self.s.merge.k <= 6 and self.s.mrh_sche is None and self.flat.names[0] == "feature.0.weight"):
             return False
         x0 = xs[0]
         if not (x0.dim() == 2 and x0.shape[0] <= 16384 and all(x.shape == x0.shape and x.stride() == x0.stride() and x.device == x0.device for x in xs)):
@@ -601,11 +601,6 @@ class FusedTrainer:
             ws = ex.get("ws_win")
             if ws is None or ws.numel() < lay.total or ws.device != dev:
                 ws = ex["ws_win"] = torch.empty(lay.total, dtype=torch.uint8, device=dev)
-        # the labels as one int64 [n] list (the head's grid plane b reads entry b)
-        if all(labels[j].data_ptr() == labels[0].data_ptr() + 8 * j for j in range(n)):
-            lab = labels[0]
-        else:
-            lab = torch.cat([l.reshape(1) for l in labels])
         # (the order the stream form with MHIMX_WINDOW_PROJECT=1 draws them in: every bag's dropout streams at the projection, then bag
         # after bag the select's and Merge's - the two forms of a window make the same draws)
         seeds = (L.StepSeeds * n)()
@@ -614,8 +609,9 @@ class FusedTrainer:
         for j in range(n):
             seeds[j].select, seeds[j].mca = s._next_seed(), s._next_seed()
         Xp = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        Lp = (C.c_void_p * n)(*[l.data_ptr() for l in labels])
         inside = bool(update and not self.clip_grad)              # (clipping needs the norm of the final gradient: the update stays outside)
-        L.check(L.lib().mhimx_window_run(ops._stream(), C.byref(ex["cfg"]), n, Xp, xs[0].stride(0), N, lab.data_ptr(), C.byref(cnt), seeds,
+        L.check(L.lib().mhimx_window_run(ops._stream(), C.byref(ex["cfg"]), n, Xp, xs[0].stride(0), N, Lp, C.byref(cnt), seeds,
                                          fl.step + int(inside), ws.data_ptr(), ws.numel(), int(inside)), "mhimx_window_run")
         km, E = s.merge.k, s.mlp_dim
         bg = lay.bag
@@ -633,7 +629,7 @@ class FusedTrainer:
                         "score": view(bg.score, j, N), "R": cnt.R, "tokens": Hs[N:], "H_student": Hs[:N],
                         "H_teacher": view(bg.H_teacher, j, N * E).view(N, E)})
             logits.append(lg); losses.append(ls)
-        self.last = dict(per[-1], logits=logits, losses=losses, bags=per, ws=ws, labels=lab)
+        self.last = dict(per[-1], logits=logits, losses=losses, bags=per, ws=ws)
         self._micro = n
         if inside:
             fl.step += 1
