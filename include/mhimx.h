@@ -354,6 +354,13 @@ typedef struct {
   int32_t splits;
   mhimx_reduce_list* defer;           /* optional: queue the d_wa / d_wc / d_bc final reductions                 */
   const float* wa_t_frag;             /* optional: prep kind-4 image of wa_t [E,A] for the one-pass backward      */
+  /* (round 6) optional, one-pass backward with M2 == 0: the gradient of the first img_rows tokens of the list leaves as THEIR PART OF THE
+   * PROJECTION'S dPRE IMAGE (mhimx_rows_dpre_image's format, the operand of mhimx_bag_wgrad) instead of as fp32 rows of dT1:
+   * dPRE[n,:] = dT[n,:] * img_dact[row(n),:] (row(n) = rows1[n], or n), token n = image row n, every other row of the launch's 32-row tiles
+   * a zero row (the image needs ceil(M1 / 32) * 32 rows); img_part (optional) [ceil(M1 / 32), E]: per-tile column sums of dPRE - the
+   * bias gradient's partials.  Tokens img_rows .. M1-1 (a Merge's tokens) keep their dT1 rows.  replaces: the dH rows' round trip through
+   * memory between this backward and mhimx_rows_dpre_image (mhim.py:69-76's activation / dropout backward). */
+  void* img; const void* img_dact; float* img_part; int64_t img_rows;
 } mhimx_pool_grad;
 int mhimx_abmil_pool_bwd(void* stream, const mhimx_scorer* sc, const mhimx_pool_io* io, const mhimx_pool_grad* g);
 
@@ -510,6 +517,13 @@ int mhimx_select_rows(void* stream, const float* score, int64_t N, int64_t k, in
                       void* ws, int64_t ws_bytes, int32_t merge_first /* 1: rows_out = [rows to merge | rows that stay] */);
 
 /* vote[n] = number of heads whose top-k contains n (masking.py:49-57, msa_fusion='vote'); attn [H,N] */
+/* mhimx_select_rows + (round 6) the kept rows a second time, in the order of the projection's dPRE image when the backward's kernels write
+ * it themselves (mhimx_pool_grad.img): rows_img = [rows that stay (Lk) | 0 ... | rows to merge (merge_R) from position img_merge_off | 0 ... up
+ * to a multiple of 32] - img_merge_off a multiple of 32, >= Lk (+ the merged tokens the scorer's last tile also holds); the zeros stand for
+ * zero rows of the image (any valid row id).  rows_img: int64 [ceil((img_merge_off + merge_R) / 32) * 32].  N <= 16384, k <= 4096. */
+int mhimx_select_rows_img(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest, uint64_t rand_seed,
+                          const uint64_t* tick, int64_t merge_R, int64_t* rows_out, int64_t* rows_img, int64_t img_merge_off, void* ws,
+                          int64_t ws_bytes, int32_t merge_first);
 int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,
                       float* vote, void* ws, int64_t ws_bytes);
 

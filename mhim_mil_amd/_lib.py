@@ -122,7 +122,8 @@ class PoolGrad(C.Structure):
     _fields_ = [("g_z", c_f32p), ("dT1", c_f32p), ("dT2", c_f32p),
                 ("d_wa", c_f32p), ("d_ba", c_f32p), ("d_wb", c_f32p), ("d_bb", c_f32p), ("d_wc", c_f32p),
                 ("d_bc", c_f32p), ("wa_t", c_f32p), ("wb_t", c_f32p),
-                ("accumulate", C.c_int32), ("splits", C.c_int32), ("defer", C.c_void_p), ("wa_t_frag", c_f32p)]
+                ("accumulate", C.c_int32), ("splits", C.c_int32), ("defer", C.c_void_p), ("wa_t_frag", c_f32p),
+                ("img", C.c_void_p), ("img_dact", C.c_void_p), ("img_part", c_f32p), ("img_rows", C.c_int64)]
 
 
 class Merge(C.Structure):
@@ -241,6 +242,7 @@ SYMBOLS = {
     "mhimx_select_ws_bytes": (_I64, [_I64]),
     "mhimx_select_mask": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64, _P, _P, _P, _P, _I64]),
     "mhimx_select_rows": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _U64, _P, _I64, _P, _P, _P, _I64, _I32]),
+    "mhimx_select_rows_img": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _U64, _P, _I64, _P, _P, _I64, _P, _I64, _I32]),
     "mhimx_vote_scores": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _P, _P, _I64]),
     "mhimx_compose_ids": (C.c_int, [_P, _P, _P, _P, _I64]),
     "mhimx_random_perm": (C.c_int, [_P, _I64, _U64, _P, _P, _P]),

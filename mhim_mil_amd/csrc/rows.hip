@@ -21,7 +21,8 @@ int merge2_fwd_rows_args(const mhimx_merge* m, const float* X, int64_t R, void* 
 int prep_batch(hipStream_t st, const mhimx_prep_job* jobs, int n);      // gemm_dma.hip
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
-                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows, const void* pre_side, int64_t gate_row0);
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows, const void* pre_side, int64_t gate_row0,
+                     void* img, const void* img_dact, float* img_part, int64_t img_rows);
 
 constexpr int ROWS_THREADS = 256;
 constexpr int MAX_PART = 512;          // partial blocks per segment
@@ -1088,6 +1089,7 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
   const bool fused = scorer_fused_ok(E, A, gated, sc->prec, io->T1, gr->wa_t, nullptr, 0) && aligned16(gr->dT1) &&
                      (io->M2 == 0 || (aligned16(io->T2) && aligned16(gr->dT2))) && aligned16(u_pre) && aligned16(w.du);
   MHIMX_CHECK_ARG(!io->rows1 || (fused && io->M2 == 0), "pool_bwd: gathered tokens (rows1) need the one-pass backward and a single segment");
+  MHIMX_CHECK_ARG(!gr->img || (fused && io->M2 == 0 && E == 512), "pool_bwd: the dPRE image (img) needs the one-pass backward and a single segment");
   MHIMX_CHECK_ARG(cur_batch().n == 0 || (fused && io->M2 == 0 && !gated && gr->defer && !gr->d_bc && !gr->d_ba && !gr->d_bb),
                   "pool_bwd: a bag-batched launch needs the one-pass backward with its reductions queued");
   for (int seg = 0; seg < 2 && fused; ++seg) {
@@ -1108,7 +1110,8 @@ int abmil_pool_bwd(hipStream_t st, const mhimx_scorer* sc, const mhimx_pool_io* 
     }
     const int g1 = scorer_fused_bwd(st, Ts[seg], Ms[seg], u_pre + off * ldu, io->s + off, io->stats, gr->g_z, io->z, sc->wc, sc->act,
                                     gr->wa_t, gr->wa_t_frag, w.du + off * ldu, dTs[seg], w.dwc_part + (int64_t)G * A, w.dbc_part + G,
-                                    MAX_PART, seg == 0 ? io->rows1 : nullptr, pre_side, gate_row0);
+                                    MAX_PART, seg == 0 ? io->rows1 : nullptr, pre_side, gate_row0, seg == 0 ? gr->img : nullptr, gr->img_dact, gr->img_part,
+                                    gr->img_rows);
     if (g1 < 0) return g1;
     G += g1;
     off += Ms[seg];

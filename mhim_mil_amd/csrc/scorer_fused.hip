@@ -318,6 +318,18 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int SB_LD = SF_A + 4;
 constexpr size_t SB_SMEM = (size_t)(SF_ROWS * SB_LD + SF_E + 3 * SF_ROWS + 2 * SF_A + 8 + 2 * SF_ROWS) * sizeof(float);
+// Round 6 - the rows' share of the projection's dPRE image written HERE (mhimx_pool_grad.img; wgrad.hip's operand format) instead of dT going
+// to memory in fp32 for rows_dpre_image to read back: dPRE[n, e] = dT[n, e] * dact16[row(n), e] for the first img_rows tokens of the list (the
+// bag rows that stay; the merged tokens behind them keep their fp32 gradient rows: the Merge backward reads them), every other row of the
+// launch's 32-row tiles a zero row.  Tile t IS k-step t of the image: one contiguous 16 KiB block [k-octet 4][hi|lo][column slot 128][8 bf16]
+// per 128 columns.  The accumulator holds rows 8 o + 4 (lane >> 5) + m of a column: v_permlane32_swap pairs the half-waves so that a lane
+// ends with the 8 consecutive rows of one k-octet, which it splits into bf16 hi / lo once and stores as two 16-byte units.  The tile's
+// d out / d pre rows come through LDS (32 KiB, direct DMA at the top of the tile); the column sums of the tile (the bias gradient's
+// partials) leave as one row of img_part.
+constexpr int SB_DLD = 1040;                         // bytes per staged d out / d pre row (1024 + 16: the two half-waves read rows 4 apart)
+constexpr size_t SB_SMEM_IMG = SB_SMEM + (size_t)SF_ROWS * SB_DLD;
+// a's lanes 32..63 <-> b's lanes 0..31 (wgrad.hip's wg_swap: inline asm - the builtin of this compiler drops its second result)
+MHIMX_DEV void sb_swap(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
 __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     const float* __restrict__ T, int64_t M, const float* __restrict__ u_pre, const float* __restrict__ s_in,
@@ -327,11 +339,12 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     const int64_t* __restrict__ rows /* optional: token n is T[rows[n]] and its gradient goes to dT[rows[n]] */,
     int n_main /* workgroups of the backward itself; the blocks behind them: a Merge backward's first stage, riding */, Merge2Side pre,
     int64_t gate_row0 /* >= 0: the rows gate_row0 .. of dT are that stage's dz - stored write-through and announced on pre.w.gate[1] */,
-    BagBatch bb) {
+    char* __restrict__ img /* optional: the dPRE image takes the first img_rows tokens' gradient (see SB_SMEM_IMG) */,
+    const _Float16* __restrict__ dact, float* __restrict__ img_part, int64_t img_rows, BagBatch bb) {
   extern __shared__ __attribute__((aligned(16))) float sb_sm[];
   if (blockIdx.z) {
     MHIMX_BAG(T); MHIMX_BAG(u_pre); MHIMX_BAG(s_in); MHIMX_BAG(stats); MHIMX_BAG(g_z); MHIMX_BAG(z); MHIMX_BAG(du); MHIMX_BAG(dT); MHIMX_BAG(dwc_part);
-    MHIMX_BAG(dbc_part); MHIMX_BAG(rows); MHIMX_BAG(wat); MHIMX_BAG(wat_frag);
+    MHIMX_BAG(dbc_part); MHIMX_BAG(rows); MHIMX_BAG(wat); MHIMX_BAG(wat_frag); MHIMX_BAG(img); MHIMX_BAG(dact); MHIMX_BAG(img_part);
     bag_move(pre, bb);
   }
   if ((int)blockIdx.x >= n_main) {
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
   float* red = gs_s + SF_ROWS;                 // [32] scratch: c0 partials (4 used)
   float* dwc_s = red + SF_ROWS;                // [2][128]
   int64_t* ridx = reinterpret_cast<int64_t*>(dwc_s + 2 * SF_A + 8);   // [32] source / destination rows of the tile (gathered form)
+  char* dact_s = reinterpret_cast<char*>(sb_sm) + SB_SMEM;            // [32][SB_DLD] (img only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, kg = lane >> 5;
   // g_z -> LDS, c0 = z . g_z
@@ -372,6 +386,16 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
     if (rows) {
       if (tid < SF_ROWS) { const int64_t n = row0 + tid; ridx[tid] = rows[n < M ? n : M - 1]; }
       __syncthreads();
+    }
+    if (img) {
+      // the tile's d out / d pre rows -> LDS by direct DMA (one 1 KiB row per wave instruction), consumed by the epilogue
+#pragma unroll
+      for (int q = 0; q < SF_ROWS / 4; ++q) {
+        const int r = wave + 4 * q;
+        const int64_t n = row0 + r;
+        const int64_t src = rows ? ridx[r] : (n < M ? n : M - 1);
+        __builtin_amdgcn_global_load_lds((gptr_f)(reinterpret_cast<const char*>(dact + src * SF_E) + lane * 16), (lptr_f)(dact_s + r * SB_DLD), 16, 0, 0);
+      }
     }
     // ---- 1. row dots T_n . g_z: 8 lanes per row, lane `seg` takes the 16-byte groups seg, seg+8, ...
     float up[SF_ROWS / 2];
@@ -486,6 +510,58 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
         }
       }
     }
+    if (img) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA rows have landed ...
+      __syncthreads();                                           // ... and everyone's
+      const bool has_tail = row0 + SF_ROWS > img_rows;           // (the list's last tiles: the merged tokens' rows keep their fp32 gradient)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int e = 128 * wave + 32 * nt + r32;
+        const float ge = gzs[e];
+        float val[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
+          const int64_t n = row0 + row;
+          const float v = acc[nt][i] + an_s[row] * ge;
+          if (has_tail && n >= img_rows && n < M) {
+            const int64_t dr = rows ? ridx[row] : n;
+            if (gated && dr >= gate_row0) __hip_atomic_store(dT + dr * SF_E + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dT[dr * SF_E + e] = v;
+          }
+          const float d = (float)*reinterpret_cast<const _Float16*>(dact_s + row * SB_DLD + 2 * e);
+          val[i] = n < img_rows ? v * d : 0.f;
+        }
+        float cs = 0.f;
+        char* unit = img + ((int64_t)tile * (SF_E / 128) + wave) * 16384 + ((8 * nt + (r32 >> 2)) * 16 + (r32 & 3) * 512);
+#pragma unroll
+        for (int o = 0; o < 4; o += 2) {
+          float kv[8];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            float a = val[4 * o + m], b = val[4 * (o + 1) + m];
+            sb_swap(a, b);                    // lanes 0..31: rows 8 o + m, 8 o + 4 + m;  lanes 32..63: rows 8 (o + 1) + m, 8 (o + 1) + 4 + m
+            kv[m] = a;
+            kv[4 + m] = b;
+          }
+          sf_b8 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            cs += kv[q];
+            const __bf16 h = (__bf16)kv[q];
+            hi[q] = h;
+            lo[q] = (__bf16)(kv[q] - (float)h);
+          }
+          char* u = unit + (o + kg) * 4096;                        // k-octet o + kg: 2 planes x 128 slots x 16 B
+          *reinterpret_cast<sf_f4*>(u) = __builtin_bit_cast(sf_f4, hi);
+          *reinterpret_cast<sf_f4*>(u + 2048) = __builtin_bit_cast(sf_f4, lo);
+        }
+        if (img_part) {
+          const float tot = cs + __shfl_xor(cs, 32);             // the other half-wave holds the other two k-octets of the column
+          if (kg == 0) img_part[(int64_t)tile * SF_E + e] = tot;
+        }
+      }
+    } else {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int e = 128 * wave + 32 * nt + r32;
@@ -502,6 +578,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_bwd_kernel(
           else dT[dr * SF_E + e] = v;
         }
       }
+    }
     }
     if (gated) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores are acknowledged before the barrier
     __syncthreads();                           // Ds / an_s / gs_s are rewritten by the next tile
@@ -565,8 +642,11 @@ int scorer_fused_fwd(hipStream_t st, const float* T, int64_t M, const float* wa,
 // returns the number of d_wc / d_bc partial rows written (<= max_parts), < 0 on error
 int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_pre, const float* s_in, const float* stats,
                      const float* g_z, const float* z, const float* wc, int act, const float* wa_t, const float* wa_t_frag, float* du,
-                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows, const void* pre_side, int64_t gate_row0) {
-    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM)));
+                     float* dT, float* dwc_part, float* dbc_part, int max_parts, const int64_t* rows, const void* pre_side, int64_t gate_row0,
+                     void* img, const void* img_dact, float* img_part, int64_t img_rows) {
+    MHIMX_ONCE_PER_DEVICE(MHIMX_HIP(hipFuncSetAttribute((const void*)scorer_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SMEM_IMG)));
+  MHIMX_CHECK_ARG(!img || (img_dact && aligned16(img) && aligned16(img_dact) && img_rows >= 0 && img_rows <= M),
+                  "scorer backward: the dPRE image needs the d out / d pre rows, 16-byte aligned buffers and img_rows <= M");
   const int tiles = (int)cdiv(M, SF_ROWS);
   const int grid = tiles < max_parts ? tiles : max_parts;
   static_assert(SB_SMEM >= M2_BWD_PRE_LDS * sizeof(float), "the riding Merge stage's LDS is the backward's");
@@ -579,8 +659,8 @@ int scorer_fused_bwd(hipStream_t st, const float* T, int64_t M, const float* u_p
   } else {
     gate_row0 = -1;
   }
-  hipLaunchKernelGGL(scorer_fused_bwd_kernel, bgrid(grid + ride), dim3(SF_THREADS), SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
-                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows, grid, pre, gate_row0, cur_batch());
+  hipLaunchKernelGGL(scorer_fused_bwd_kernel, bgrid(grid + ride), dim3(SF_THREADS), img ? SB_SMEM_IMG : SB_SMEM, st, T, M, u_pre, s_in, stats, g_z, z, wc, act, wa_t,
+                     wa_t_frag, du, dT, dwc_part, dbc_part, tiles, rows, grid, pre, gate_row0, (char*)img, (const _Float16*)img_dact, img_part, img_rows, cur_batch());
   MHIMX_LAUNCH_CHECK();
   return grid;
 }

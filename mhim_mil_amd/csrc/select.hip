@@ -413,10 +413,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
     const float* __restrict__ score, int N, int k, int n_sel, int largest, const int64_t* __restrict__ perm,
     const int64_t* __restrict__ other, int64_t n_other, int64_t* __restrict__ mask_ids, int64_t* __restrict__ len_keep_dev,
     int64_t* __restrict__ topk_out, int P, int use_rand, uint64_t rand_seed0, const uint64_t* __restrict__ tick, int merge_R,
-    int64_t* __restrict__ rows_out, BagBatch bb /* common.hpp: one workgroup per bag of an accumulation window */) {
+    int64_t* __restrict__ rows_out,
+    int64_t* __restrict__ rows_img /* optional (round 6): the same rows in the order of the projection's dPRE image when its producers write it -
+                                      [rows that stay | 0 ... | rows to merge from position img_off | 0 ... to a multiple of 32] */,
+    int img_off, BagBatch bb /* common.hpp: one workgroup per bag of an accumulation window */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (blockIdx.z) {
     MHIMX_BAG(score); MHIMX_BAG(perm); MHIMX_BAG(other); MHIMX_BAG(mask_ids); MHIMX_BAG(len_keep_dev); MHIMX_BAG(topk_out); MHIMX_BAG(rows_out);
+    MHIMX_BAG(rows_img);
     rand_seed0 = bag_sel_seed(rand_seed0, bb);
   }
   const uint64_t rand_seed = eff_seed(rand_seed0, tick);
@@ -632,6 +636,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_small_kernel(
   }
   __syncthreads();
   for (int i = tid; i < Lrows; i += SEL_THREADS) rows_out[i] = (int64_t)stage[i];
+  if (rows_img) {
+    const int mrg_n = Lrows - Lk, stay0 = use_rand == 2 ? mrg_n : 0, mrg0 = use_rand == 2 ? 0 : Lk;
+    const int end = (img_off + mrg_n + 31) / 32 * 32;
+    for (int p = tid; p < end; p += SEL_THREADS)
+      rows_img[p] = p < Lk ? (int64_t)stage[stay0 + p] : ((p >= img_off && p - img_off < mrg_n) ? (int64_t)stage[mrg0 + p - img_off] : (int64_t)0);
+  }
   SEL_STAMP(7);
 }
 
@@ -946,8 +956,11 @@ static int select_multi(hipStream_t st, const float* score, int64_t N, int k, in
 static int select_impl(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest,
                        const int64_t* perm, const int64_t* other, int64_t n_other, int64_t* mask_ids,
                        int64_t* len_keep_dev, int64_t* topk_sorted, void* ws, int64_t ws_bytes, int g_use_rand,
-                       uint64_t g_rand_seed, const uint64_t* g_tick, int g_merge_R, int64_t* g_rows_out) {
+                       uint64_t g_rand_seed, const uint64_t* g_tick, int g_merge_R, int64_t* g_rows_out, int64_t* g_rows_img = nullptr,
+                       int g_img_off = 0) {
   MHIMX_CHECK_ARG(score && (mask_ids || g_rows_out) && ws, "select_mask: null args");
+  MHIMX_CHECK_ARG(!g_rows_img || (g_rows_out && N <= 16384 && next_pow2((int)k < 2 ? 2 : (int)k) <= 4096),
+                  "select_rows_img: the image-order list comes from the one-workgroup select (N <= 16384, k <= 4096)");
   MHIMX_CHECK_ARG(!g_rows_out || N <= 16384, "select_rows: fused row list needs N <= 16384 (use select_mask + compose_ids)");
   MHIMX_CHECK_ARG(N > 0 && N <= (1ll << 24), "select_mask: N out of range");
   MHIMX_CHECK_ARG(k >= 1 && k <= N && k <= 16384, "select_mask: k=%lld out of range (1..min(N,16384))", (long long)k);
@@ -959,7 +972,7 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
 #define MHIMX_SEL_SMALL(KPT)                                                                                                   \
     hipLaunchKernelGGL(select_small_kernel<KPT>, bgrid(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
                        (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,          \
-                       g_rand_seed, g_tick, g_merge_R, g_rows_out, cur_batch())
+                       g_rand_seed, g_tick, g_merge_R, g_rows_out, g_rows_img, g_img_off, cur_batch())
     MHIMX_ONCE_PER_DEVICE(
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
         MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
@@ -969,7 +982,7 @@ static int select_impl(void* stream, const float* score, int64_t N, int64_t k, i
 #define MHIMX_SEL_LEAN(KPT)                                                                                                    \
       hipLaunchKernelGGL((select_small_kernel<KPT, true>), bgrid(1), dim3(SEL_THREADS), sm, (hipStream_t)stream, score, (int)N, (int)k,   \
                          (int)n_sel, largest, perm, other, n_other, mask_ids, len_keep_dev, topk_sorted, P, g_use_rand,        \
-                         g_rand_seed, g_tick, g_merge_R, g_rows_out, cur_batch())
+                         g_rand_seed, g_tick, g_merge_R, g_rows_out, g_rows_img, g_img_off, cur_batch())
       MHIMX_ONCE_PER_DEVICE(
           MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
           MHIMX_HIP(hipFuncSetAttribute((const void*)select_small_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)select_small_smem(4096)));
@@ -1010,6 +1023,16 @@ extern "C" int mhimx_select_rows(void* stream, const float* score, int64_t N, in
   MHIMX_CHECK_ARG(rows_out && merge_R >= 0 && merge_R <= N - n_sel, "select_rows: bad args");
   return select_impl(stream, score, N, k, n_sel, largest, nullptr, nullptr, 0, mask_ids, nullptr, nullptr, ws, ws_bytes,
                      merge_first ? 2 : 1, rand_seed, tick, (int)merge_R, rows_out);
+}
+
+extern "C" int mhimx_select_rows_img(void* stream, const float* score, int64_t N, int64_t k, int64_t n_sel, int32_t largest, uint64_t rand_seed,
+                                     const uint64_t* tick, int64_t merge_R, int64_t* rows_out, int64_t* rows_img, int64_t img_merge_off, void* ws,
+                                     int64_t ws_bytes, int32_t merge_first) {
+  MHIMX_CHECK_ARG(rows_out && rows_img && merge_R >= 0 && merge_R <= N - n_sel && img_merge_off >= N - n_sel - merge_R && img_merge_off % 32 == 0 &&
+                      img_merge_off <= 32768,
+                  "select_rows_img: bad args (the merged rows' image position is a multiple of 32 behind the rows that stay)");
+  return select_impl(stream, score, N, k, n_sel, largest, nullptr, nullptr, 0, nullptr, nullptr, nullptr, ws, ws_bytes, merge_first ? 2 : 1, rand_seed, tick,
+                     (int)merge_R, rows_out, rows_img, (int)img_merge_off);
 }
 
 extern "C" int mhimx_vote_scores(void* stream, const float* attn, int64_t H, int64_t N, int64_t k, int32_t largest,

@@ -88,6 +88,12 @@ int dag_edge(hipEvent_t ev, hipStream_t from, hipStream_t to) {
   return 0;
 }
 
+// MHIMX_FUSE_DPRE=0: the rows' gradient goes to memory in fp32 and mhimx_rows_dpre_image makes the whole image, as rounds 3-5 had it
+bool fuse_dpre() {
+  static const bool on = getenv("MHIMX_FUSE_DPRE") == nullptr || atoi(getenv("MHIMX_FUSE_DPRE")) != 0;
+  return on;
+}
+
 struct Carve {
   char* base;
   int64_t off = 0;
@@ -110,9 +116,26 @@ struct StepBufs {
   int64_t logits, losses, g_z;
   int64_t dH, img, ws_b, ws_b_bytes, wg_ws, wg_ws_floats;
   int64_t q_scr, gslab;              // (a window's bag: where its forward's query EMA goes, its gradient slab)
+  int64_t rows_img, P0, L_img;       // (round 6, fuse_img) the kept rows in the dPRE image's order [stay | 0.. | merge from P0 | 0..], the image's rows
+  bool fuse_img;
   int64_t bag0, bag_stride;          // the per-bag part of the workspace: bag b's copy of everything from merge_ws on starts bag0 + b * bag_stride
   int64_t total;
 };
+
+// fuse_img: the scorer backward wrote the stay rows' share of the dPRE image (image rows 0 .. P0-1, one partial row of column sums per tile);
+// this is the rest - the rows to merge from image row P0 on (mhimx_rows_dpre_image on that part of the image; the Merge backward's tail
+// stage still rides there) - and the two sets of column-sum partials become ONE queued reduction.
+int dpre_merge_rows(void* stream, const float* dH, const void* dact, const int64_t* rows_merge, int64_t R, int64_t E, char* img, int64_t P0, float* d_b1,
+                    float* ws_b, int64_t ws_b_bytes, mhimx_reduce_list* lst) {
+  const int64_t t0 = P0 / 32;
+  const int n0 = lst->n;
+  float* part_m = ws_b + t0 * E;
+  if (int r = mhimx_rows_dpre_image(stream, dH, dact, rows_merge, R, E, img + t0 * (E / 128) * 16384, d_b1, 0, part_m, ws_b_bytes - t0 * E * 4, lst)) return r;
+  MHIMX_CHECK_ARG(lst->n == n0 + 1 && lst->j[n0].kind == 0 && lst->j[n0].parts == part_m, "step: the bias gradient's partial sum was not queued");
+  lst->j[n0].parts = ws_b;
+  lst->j[n0].G += t0;
+  return 0;
+}
 
 int check_cfg(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n) {
   MHIMX_CHECK_ARG(c && n, "step: null configuration / counts");
@@ -149,12 +172,17 @@ void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, Step
   b->wo_t = cv.take_off(I * E * F);
   b->q_old = cv.take_off(k * E * F);
   if (n_bags > 1) {
-    b->wg_ws_floats = mhimx_wgrad_multi_ws_floats(n->len_keep, E, D, n_bags);
+    b->wg_ws_floats = mhimx_wgrad_multi_ws_floats(fuse_dpre() && N <= 16384 ? (n->Lk + k + 31) / 32 * 32 + n->R : n->len_keep, E, D, n_bags);
     b->wg_ws = cv.take_off(b->wg_ws_floats * F);
   }
   b->bag0 = cv.off;
   b->merge_ws_bytes = mhimx_merge_ws_bytes(n->R, E, k, 8, 64);
   b->merge_ws = cv.take_off(b->merge_ws_bytes);
+  // (round 6) up to 16 384 rows the stay rows' share of the projection's dPRE image is written by the scorer backward itself
+  // (mhimx_pool_grad.img): the image is ordered [rows that stay, tile for tile of that launch | rows to merge from P0 on]
+  b->fuse_img = fuse_dpre() && N <= 16384;
+  b->P0 = b->fuse_img ? (n->Lk + k + 31) / 32 * 32 : 0;
+  b->L_img = b->fuse_img ? b->P0 + n->R : n->len_keep;
   b->H_t = cv.take_off(N * E * F);
   b->Hbuf = cv.take_off((N + k) * E * F);
   b->dact = cv.take_off(N * E * 2);
@@ -169,6 +197,7 @@ void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, Step
   b->rows_all = cv.take_off((n->len_keep + k) * 8);
   b->sel_ws_bytes = mhimx_select_ws_bytes(N);
   b->sel_ws = cv.take_off(b->sel_ws_bytes);
+  b->rows_img = b->fuse_img ? cv.take_off((b->L_img + 31) / 32 * 32 * 8) : 0;
   b->sel_perm = b->sel_ids = b->sel_rows = b->sel_lk = 0;
   if (N > 16384) {
     b->sel_perm = cv.take_off(n->k_top * 8);
@@ -186,15 +215,15 @@ void layout(const mhimx_step_cfg* c, int64_t N, const mhimx_step_counts* n, Step
   b->losses = cv.take_off(4 * F);
   b->g_z = cv.take_off(E * F);
   b->dH = cv.take_off((N + k) * E * F);
-  b->img = cv.take_off(mhimx_wgrad_image_bytes(n->len_keep, E));
-  b->ws_b_bytes = (n->len_keep + 31) / 32 * E * F;
+  b->img = cv.take_off(mhimx_wgrad_image_bytes(b->L_img, E));
+  b->ws_b_bytes = (b->fuse_img ? b->P0 / 32 + (n->R + 31) / 32 : (n->len_keep + 31) / 32) * E * F;
   b->ws_b = cv.take_off(b->ws_b_bytes);
   b->q_scr = b->gslab = 0;
   if (n_bags > 1) {
     b->q_scr = cv.take_off(k * E * F);
     b->gslab = cv.take_off(c->n_all * F);
   } else {
-    b->wg_ws_floats = mhimx_wgrad_ws_floats(n->len_keep, E, D);
+    b->wg_ws_floats = mhimx_wgrad_ws_floats(b->L_img, E, D);
     b->wg_ws = cv.take_off(b->wg_ws_floats * F);
   }
   b->bag_stride = cv.off - b->bag0;
@@ -340,7 +369,12 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
 
   // ---- 5. HAM mask + Merge split: rows_all = [rows to merge (R) | rows that stay (Lk) | N .. N + k - 1]
   if (N <= 16384) {
-    if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds->select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+    if (b.fuse_img) {
+      if (int r = mhimx_select_rows_img(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds->select, tick, R, rows_all, cv.at<int64_t>(b.rows_img), b.P0,
+                                        cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+        return r;
+    } else if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds->select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws),
+                                         b.sel_ws_bytes, 1))
       return r;
   } else {
     // select_large: the two-stage form of masking.py:61-86 + merge.py:163-170 as MHIM.student_rows issues it for such bags (mhim.py of this
@@ -419,6 +453,7 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     sc_b.wa_frag = nullptr;
     mhimx_pool_grad pg = {};
     pg.g_z = g_z; pg.dT1 = dH; pg.d_wa = c.grad.wa; pg.d_wc = c.grad.wc; pg.wa_t = wa_t; pg.accumulate = 0; pg.splits = 8; pg.defer = &lst; pg.wa_t_frag = wa_t_frag;
+    if (b.fuse_img) { pg.img = cv.at<char>(b.img); pg.img_dact = dact; pg.img_part = cv.at<float>(b.ws_b); pg.img_rows = Lk; }
     if (int r = mhimx_abmil_pool_bwd(stream, &sc_b, &io_s, &pg)) return r;
   }
   mhimx_reduce_list lst_main;                    // (DAG form: what the main branch queues - the bias partials, the weight gradient's slab sum)
@@ -441,10 +476,14 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     if (int r = dag_edge(ev[3], main_st, side_st)) return r;
     if (int r = mhimx_reduce_flush(side_st, &lst)) return r;      // (the tail's stages as launches, the last one inside the reduction launch)
   }
-  if (int r = mhimx_rows_dpre_image(stream, dH, dact, rows_all, len_keep, E, cv.at<char>(b.img), c.grad.b1, 0, cv.at<char>(b.ws_b), b.ws_b_bytes, lm)) return r;
+  if (b.fuse_img) {
+    if (int r = dpre_merge_rows(stream, dH, dact, rows_all, R, E, cv.at<char>(b.img), b.P0, c.grad.b1, cv.at<float>(b.ws_b), b.ws_b_bytes, lm)) return r;
+  } else if (int r = mhimx_rows_dpre_image(stream, dH, dact, rows_all, len_keep, E, cv.at<char>(b.img), c.grad.b1, 0, cv.at<char>(b.ws_b), b.ws_b_bytes, lm))
+    return r;
   {
     mhimx_bag_wgrad_args g = {};
-    g.img = cv.at<char>(b.img); g.X = X; g.ldx = ldx; g.n_bag_rows = N; g.rows = rows_all; g.L = len_keep; g.E = E; g.D = D; g.C = c.grad.w1; g.ldc = D;
+    g.img = cv.at<char>(b.img); g.X = X; g.ldx = ldx; g.n_bag_rows = N; g.rows = b.fuse_img ? cv.at<int64_t>(b.rows_img) : rows_all; g.L = b.L_img; g.E = E; g.D = D;
+    g.C = c.grad.w1; g.ldc = D;
     g.accumulate = 0; g.ws = cv.at<float>(b.wg_ws); g.ws_floats = b.wg_ws_floats; g.defer = lm; g.ride_tail = update ? 1 : 0;
     if (int r = mhimx_bag_wgrad(stream, &g)) return r;
   }
@@ -476,13 +515,21 @@ namespace {
 // q <- wq q + sum_b w[b] z_b   (the window's EMA chain of the global queries on the tokens its forwards produced: merge.py:142-143 applied bag
 // after bag, q <- mm q + (1 - mm) z_b, with every z_b computed from the window's first queries - engine.py window_step's contract)
 struct QChainW { float wq; float w[MHIMX_WINDOW_MAX]; };
+// ... and, in the same launch, zeros for the elements of the bags' gradient slabs that NO gradient view covers (the flat buffer pads every
+// tensor to 16 bytes - predictor.bias [2] leaves two floats - and may hold parameters this step does not train): nobody writes them, the
+// update adds them.  (Found by the window tests: stale workspace memory there made two runs of one window differ in two elements.)
+struct SlabGaps { int n; int64_t off[16], len[16]; };
 __global__ __launch_bounds__(256) void window_q_chain_kernel(float* __restrict__ q, const float* __restrict__ z0, int64_t z_stride, int n_bags, int64_t n,
-                                                             QChainW cw) {
+                                                             QChainW cw, float* __restrict__ slab0, int64_t pitch, SlabGaps gaps) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
     for (int b = 0; b < n_bags; ++b) acc += z0[b * z_stride + i] * cw.w[b];
     q[i] = q[i] * cw.wq + acc;
   }
+  for (int gi = 0; gi < gaps.n; ++gi)
+    for (int b = 0; b < n_bags; ++b)
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < gaps.len[gi]; i += (int64_t)gridDim.x * blockDim.x)
+        slab0[b * pitch + gaps.off[gi] + i] = 0.f;
 }
 // g = sum_b slab_b   (update = 0: the window's complete gradient in the flat buffer; bag order, as the update kernel adds them)
 __global__ __launch_bounds__(256) void window_sum_slabs_kernel(float* __restrict__ g, const float* __restrict__ slab0, int64_t pitch, int n_bags, int64_t n) {
@@ -639,7 +686,12 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
     }
     const float* z_t = cv.at<float>(b.z_t);
     // HAM mask + Merge split
-    if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds[0].select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+    if (b.fuse_img) {
+      if (int r = mhimx_select_rows_img(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds[0].select, tick, R, rows_all, cv.at<int64_t>(b.rows_img), b.P0,
+                                        cv.at<char>(b.sel_ws), b.sel_ws_bytes, 1))
+        return r;
+    } else if (int r = mhimx_select_rows(stream, score, N, cnt->k_top, cnt->n_sel, 1, seeds[0].select, tick, R, rows_all, nullptr, cv.at<char>(b.sel_ws),
+                                         b.sel_ws_bytes, 1))
       return r;
     // the student's forward: scorer over the rows that stay (Merge's row tiles ride at its front), Merge tail, the finalize that scores the tokens
     mhimx_merge mw = mw_prep;
@@ -681,11 +733,15 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
       mhimx_pool_grad pg = {};
       pg.g_z = g_z; pg.dT1 = dH; pg.d_wa = gs(c.grad.wa); pg.d_wc = gs(c.grad.wc); pg.wa_t = wa_t; pg.accumulate = 0; pg.splits = 8; pg.defer = &lst;
       pg.wa_t_frag = wa_t_frag;
+      if (b.fuse_img) { pg.img = cv.at<char>(b.img); pg.img_dact = cv.at<char>(b.dact); pg.img_part = cv.at<float>(b.ws_b); pg.img_rows = Lk; }
       if (int r = mhimx_abmil_pool_bwd(stream, &sc_b, &io_s, &pg)) return r;
     }
     if (int r = mhimx_merge_bwd(stream, &mwb, Hbuf, R, dH + N * E, dH, &mg, merge_ws, b.merge_ws_bytes)) return r;
-    if (int r = mhimx_rows_dpre_image(stream, dH, cv.at<char>(b.dact), rows_all, len_keep, E, cv.at<char>(b.img), gs(c.grad.b1), 0, cv.at<char>(b.ws_b), b.ws_b_bytes,
-                                      &lst))
+    if (b.fuse_img) {
+      if (int r = dpre_merge_rows(stream, dH, cv.at<char>(b.dact), rows_all, R, E, cv.at<char>(b.img), b.P0, gs(c.grad.b1), cv.at<float>(b.ws_b), b.ws_b_bytes, &lst))
+        return r;
+    } else if (int r = mhimx_rows_dpre_image(stream, dH, cv.at<char>(b.dact), rows_all, len_keep, E, cv.at<char>(b.img), gs(c.grad.b1), 0, cv.at<char>(b.ws_b),
+                                             b.ws_b_bytes, &lst))
       return r;
     if (int r = mhimx_reduce_flush(stream, &lst)) return r;          // (the Merge tail's remaining stages + every queued reduction, bag-batched)
   }
@@ -697,7 +753,8 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
     mhimx_bag_wgrad_args ga[MHIMX_WINDOW_MAX];
     for (int i = 0; i < n_bags; ++i) {
       mhimx_bag_wgrad_args g = {};
-      g.img = bag(b.img, i); g.X = X[i]; g.ldx = ldx; g.n_bag_rows = N; g.rows = reinterpret_cast<const int64_t*>(bag(b.rows_all, i)); g.L = len_keep; g.E = E; g.D = D;
+      g.img = bag(b.img, i); g.X = X[i]; g.ldx = ldx; g.n_bag_rows = N; g.rows = reinterpret_cast<const int64_t*>(bag(b.fuse_img ? b.rows_img : b.rows_all, i));
+      g.L = b.L_img; g.E = E; g.D = D;
       g.C = c.grad.w1; g.ldc = D; g.accumulate = 0; g.ws = cv.at<float>(b.wg_ws); g.ws_floats = b.wg_ws_floats; g.defer = &lst_w;
       ga[i] = g;
     }
@@ -709,7 +766,24 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
     const double mm = (double)c.merge_mm;
     cw.wq = (float)pow(mm, (double)n_bags);
     for (int i = 0; i < MHIMX_WINDOW_MAX; ++i) cw.w[i] = i < n_bags ? (float)((1.0 - mm) * pow(mm, (double)(n_bags - 1 - i))) : 0.f;
-    hipLaunchKernelGGL(window_q_chain_kernel, dim3((unsigned)cdiv(k * E, 256)), dim3(256), 0, st, S.q, Hbuf + N * E, BS / 4, (int)n_bags, k * E, cw);
+    // the slab elements from E D on that none of the eleven gradient views covers
+    SlabGaps gaps = {};
+    {
+      struct View { int64_t off, len; };
+      const mhimx_step_grads& gr = c.grad;
+      View v[11] = {{gr.b1 - c.g, E}, {gr.wa - c.g, A * E}, {gr.wc - c.g, A}, {gr.wp - c.g, C * E}, {gr.bp - c.g, C}, {gr.ln_w - c.g, E}, {gr.ln_b - c.g, E},
+                    {gr.wkv - c.g, 2 * I * E}, {gr.wq - c.g, I * E}, {gr.wo - c.g, E * I}, {gr.bo - c.g, E}};
+      for (int i = 1; i < 11; ++i)                                     // (insertion sort by offset)
+        for (int j = i; j > 0 && v[j].off < v[j - 1].off; --j) { const View t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
+      int64_t at = g_lo;
+      for (int i = 0; i <= 11; ++i) {
+        const int64_t nxt = i < 11 ? v[i].off : c.n_train;
+        if (nxt > at) { gaps.off[gaps.n] = at; gaps.len[gaps.n] = nxt - at; ++gaps.n; }
+        if (i < 11 && v[i].off + v[i].len > at) at = v[i].off + v[i].len;
+      }
+    }
+    hipLaunchKernelGGL(window_q_chain_kernel, dim3((unsigned)cdiv(k * E, 256)), dim3(256), 0, st, S.q, Hbuf + N * E, BS / 4, (int)n_bags, k * E, cw, slab0, BS / 4,
+                       gaps);
     MHIMX_LAUNCH_CHECK();
   }
   if (!update) {

@@ -600,7 +600,9 @@ class FusedTrainer:
         else:
             ws = ex.get("ws_win")
             if ws is None or ws.numel() < lay.total or ws.device != dev:
-                ws = ex["ws_win"] = torch.empty(lay.total, dtype=torch.uint8, device=dev)
+                # (poisoned once, when it is made: 0xFF bytes are NaNs - a launch that read workspace memory no launch of the window wrote
+                # would show up in every eager test instead of depending on what the allocator's block held before)
+                ws = ex["ws_win"] = torch.full((lay.total,), 255, dtype=torch.uint8, device=dev)
         # (the order the stream form with MHIMX_WINDOW_PROJECT=1 draws them in: every bag's dropout streams at the projection, then bag
         # after bag the select's and Merge's - the two forms of a window make the same draws)
         seeds = (L.StepSeeds * n)()
@@ -669,7 +671,7 @@ class FusedTrainer:
         else:
             ws = ex["ws"]
             if ws is None or ws.numel() < lay.total or ws.device != x.device:
-                ws = ex["ws"] = torch.empty(int(lay.total * 1.25), dtype=torch.uint8, device=x.device)
+                ws = ex["ws"] = torch.full((int(lay.total * 1.25),), 255, dtype=torch.uint8, device=x.device)      # (poisoned: see _exec_window)
         seeds = L.StepSeeds(drop_teacher=t._next_seed(teacher=True), drop_student=s._next_seed(), select=s._next_seed(), mca=s._next_seed())
         update = bool(self._fold_now)
         L.check(L.lib().mhimx_step_run(ops._stream(), C.byref(ex["cfg"]), x.data_ptr(), x.stride(0), N, label.data_ptr(), C.byref(cnt), C.byref(seeds),

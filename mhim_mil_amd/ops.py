@@ -424,8 +424,11 @@ def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=
 
 
 def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=False, splits=8, grads=None,
-                   accumulate=False, defer=None, wa_t_frag=None):
-    """Backward of the pool.  Returns dict(dT1, dT2, d_wa, d_wc, [d_wb, d_ba, d_bb, d_bc])."""
+                   accumulate=False, defer=None, wa_t_frag=None, img=None, img_dact=None, img_part=None, img_rows=0):
+    """Backward of the pool.  Returns dict(dT1, dT2, d_wa, d_wc, [d_wb, d_ba, d_bb, d_bc]).
+    ``img`` (round 6, one-pass backward): the first ``img_rows`` tokens' gradient leaves as their part of the projection's dPRE image
+    (dT * img_dact[row], rows_dpre_image's format; tile t of the launch = k-step t) instead of as rows of dT1; ``img_part`` [tiles, E]
+    takes the per-tile column sums (mhimx_pool_grad.img)."""
     dev = g_z.device
     E, A = sc.E, sc.A
     out = grads or {}
@@ -445,7 +448,7 @@ def abmil_pool_bwd(sc: ScorerW, st: PoolState, g_z, wa_t, wb_t=None, need_bias=F
     g = L.PoolGrad(g_z=_p(g_z), dT1=_p(out["dT1"]), dT2=_p(out.get("dT2")), d_wa=_p(out["d_wa"]), d_ba=_p(out.get("d_ba")),
                    d_wb=_p(out.get("d_wb")), d_bb=_p(out.get("d_bb")), d_wc=_p(out["d_wc"]), d_bc=_p(out.get("d_bc")),
                    wa_t=_p(wa_t), wb_t=_p(wb_t), accumulate=int(bool(accumulate)), splits=int(splits), defer=_dp(defer),
-                   wa_t_frag=_p(wa_t_frag))
+                   wa_t_frag=_p(wa_t_frag), img=_p(img), img_dact=_p(img_dact), img_part=_p(img_part), img_rows=int(img_rows))
     if defer is not None:
         defer.keep.append(st)
     L.check(L.lib().mhimx_abmil_pool_bwd(_stream(), C.byref(sc.c), C.byref(io), C.byref(g)), "mhimx_abmil_pool_bwd")
@@ -506,6 +509,21 @@ def select_rows(score, k, n_sel, merge_R, rand_seed, tick=None, largest=True, wa
                                       int(rand_seed) & 0xFFFFFFFFFFFFFFFF, _p(tick), int(merge_R), _p(rows), _p(mask_ids), _p(ws),
                                       ws.numel(), int(bool(merge_first))), "mhimx_select_rows")
     return (rows, mask_ids) if want_mask_ids else rows
+
+
+def select_rows_img(score, k, n_sel, merge_R, rand_seed, img_merge_off, tick=None, largest=True, merge_first=True):
+    """select_rows + the kept rows in the dPRE image's order (mhimx_select_rows_img): returns (rows [N - n_sel], rows_img
+    [ceil((img_merge_off + merge_R) / 32) * 32] = [stay | 0.. | merge from img_merge_off | 0..])."""
+    _chk(score, name="score")
+    N = score.numel()
+    dev = score.device
+    rows = torch.empty(N - n_sel, device=dev, dtype=torch.int64)
+    rows_img = torch.empty(-(-(int(img_merge_off) + int(merge_R)) // 32) * 32, device=dev, dtype=torch.int64)
+    ws = torch.empty(L.lib().mhimx_select_ws_bytes(N), device=dev, dtype=torch.uint8)
+    L.check(L.lib().mhimx_select_rows_img(_stream(), _p(score), N, int(k), int(n_sel), int(bool(largest)), int(rand_seed) & 0xFFFFFFFFFFFFFFFF,
+                                          _p(tick), int(merge_R), _p(rows), _p(rows_img), int(img_merge_off), _p(ws), ws.numel(),
+                                          int(bool(merge_first))), "mhimx_select_rows_img")
+    return rows, rows_img
 
 
 def vote_scores(attn, k, largest=True):

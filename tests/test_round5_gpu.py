@@ -111,10 +111,28 @@ def _state(tr):
     return [fl.student.clone(), fl.teacher.clone(), fl.m.clone(), fl.v.clone(), tr.opt_step.clone(), tr.tick.clone()]
 
 
+def _same_state(tr_c, tr_p, steps, lr=1e-3):
+    """Round 6: up to 16 384 rows the executor's scorer backward writes the stay rows' share of the dPRE image itself (mhimx_pool_grad.img) and
+    the image is ordered [stay | merge]: the projection's weight / bias gradient is the same sum in another order, so the two paths' parameters
+    agree to rounding - which Adam turns into up to ~2 lr on an element whose gradient is at rounding level - and no longer bit for bit
+    (MHIMX_FUSE_DPRE=0 in the environment: the old route, bit-identical again).  Counters stay exact."""
+    import os
+    sc, sp = _state(tr_c), _state(tr_p)
+    assert torch.equal(sc[4], sp[4]) and torch.equal(sc[5], sp[5])
+    if os.environ.get("MHIMX_FUSE_DPRE", "1") == "0":
+        for a, b in zip(sc[:4], sp[:4]):
+            assert torch.equal(a, b)
+        return
+    for name, a, b in zip(("student", "teacher", "m", "v"), sc[:4], sp[:4]):
+        d = (a - b).abs()
+        assert float(d.mean()) <= 4e-6 * steps and float(d.max()) <= 2.2 * lr * steps, (name, float(d.mean()), float(d.max()))
+
+
 def test_step_executor_equals_the_python_step_bit_for_bit():
     """mhimx_step_run issues the launches of FusedTrainer._forward_backward_nat + _apply itself: the same kernels, arguments and seeds, so
-    parameters, optimiser state, logits, row sets and teacher scores agree BIT FOR BIT with the Python orchestration - over bags whose size
-    changes every step (nothing is captured), dropout on."""
+    logits, row sets, teacher scores and merged tokens of the first step agree BIT FOR BIT with the Python orchestration, parameters and
+    optimiser state to rounding (_same_state: the dPRE image's row order) - over bags whose size changes every step (nothing is captured),
+    dropout on."""
     tr_c, tr_p = _pair_of_trainers()
     tr_p.use_executor = False
     g = torch.Generator(device="cuda").manual_seed(9)
@@ -125,11 +143,13 @@ def test_step_executor_equals_the_python_step_bit_for_bit():
         lc, sc = tr_c.train_step(x, lab)
         lp, sp = tr_p.train_step(x, lab)
         assert tr_c._exec is not None and tr_c.last.get("ws") is not None, "the executor did not run"
-        assert torch.equal(lc, lp) and torch.equal(sc, sp), (step, lc, lp)
-        assert torch.equal(tr_c.last["rows"], tr_p.last["rows"]) and torch.equal(tr_c.last["score"], tr_p.last["score"])
-        assert torch.equal(tr_c.last["tokens"], tr_p.last["tokens"])
-        for a, b in zip(_state(tr_c), _state(tr_p)):
-            assert torch.equal(a, b), step
+        if step == 0:
+            assert torch.equal(lc, lp) and torch.equal(sc, sp), (step, lc, lp)
+            assert torch.equal(tr_c.last["rows"], tr_p.last["rows"]) and torch.equal(tr_c.last["score"], tr_p.last["score"])
+            assert torch.equal(tr_c.last["tokens"], tr_p.last["tokens"])
+        else:
+            assert torch.allclose(lc, lp, atol=2e-4) and torch.allclose(sc, sp, atol=2e-4), (step, lc, lp)
+        _same_state(tr_c, tr_p, step + 1)
     assert tr_c.flat.step == tr_p.flat.step == len(sizes)
 
 
@@ -142,12 +162,14 @@ def test_step_executor_forward_backward_only_and_clip():
     lab = torch.tensor([1], device="cuda")
     for tr in (tr_c, tr_p):
         tr.forward_backward(x, lab)
-    assert torch.equal(tr_c.flat.grad, tr_p.flat.grad) and tr_c.flat.grad.abs().max() > 0
+    gc, gp = tr_c.flat.grad, tr_p.flat.grad
+    assert gc.abs().max() > 0 and float((gc - gp).abs().max()) <= 2e-6 * float(gp.abs().max())
+    n_w1 = tr_c.s.feature[0].weight.numel() + tr_c.s.feature[0].bias.numel()
+    assert torch.equal(gc[n_w1:], gp[n_w1:])                   # (everything but the projection's gradient pair: the same launches, the same bits)
     for tr in (tr_c, tr_p):
         tr.update()
         tr.train_step(x, lab)
-    for a, b in zip(_state(tr_c), _state(tr_p)):
-        assert torch.equal(a, b)
+    _same_state(tr_c, tr_p, 2)
 
 
 def test_run_steps_equals_train_steps():
@@ -175,8 +197,7 @@ def test_step_executor_under_capture_and_shape_cache():
         for tr in (tr_c, tr_p):
             assert tr.shape_cached("train_step", x, lab) is not None
     torch.cuda.synchronize()
-    for a, b in zip(_state(tr_c), _state(tr_p)):
-        assert torch.equal(a, b)
+    _same_state(tr_c, tr_p, 4)
 
 
 def test_step_counts_match_the_reference_formulas():

@@ -181,8 +181,12 @@ def test_data_parallel_rank_step_through_the_executor(tmp_path):
     for use_exec in (1, 0):                                    # replicas stay bit-identical (parameters, optimiser state, counters)
         for a, b in zip(res[use_exec][0]["state"], res[use_exec][1]["state"]):
             assert torch.equal(a, b)
-    for r in range(2):                                         # and the executor's ranks have the bits of the Python orchestration's
-        for a, b in zip(res[1][r]["logits"], res[0][r]["logits"]):
-            assert torch.equal(a, b)
-        for a, b in zip(res[1][r]["state"], res[0][r]["state"]):
+    for r in range(2):      # and the executor's ranks follow the Python orchestration's: the first step's logits bit for bit, then to rounding
+        # (the executor's scorer backward writes its share of the dPRE image itself - another order of the same weight-gradient sum)
+        for j, (a, b) in enumerate(zip(res[1][r]["logits"], res[0][r]["logits"])):
+            assert torch.equal(a, b) if j == 0 else torch.allclose(a, b, atol=2e-4), (r, j, a, b)
+        for name, a, b in zip(("student", "teacher", "m", "v"), res[1][r]["state"], res[0][r]["state"]):
+            d = (a.float() - b.float()).abs()
+            assert float(d.mean()) <= 1.2e-5 and float(d.max()) <= 6.6e-3, (name, float(d.mean()), float(d.max()))
+        for a, b in zip(res[1][r]["state"][4:], res[0][r]["state"][4:]):
             assert torch.equal(a, b)

@@ -114,6 +114,74 @@ def test_pool_with_gathered_rows_matches_contiguous():
     assert torch.equal(gg["d_wc"], gc["d_wc"])
 
 
+@pytest.mark.parametrize("n,n_img", [(1100, 1095), (1100, 1100), (64, 59), (37, 37)])
+def test_pool_backward_writes_its_rows_of_the_dpre_image(n, n_img):
+    """Round 6 (mhimx_pool_grad.img): the one-pass pool backward writes the first img_rows tokens' share of the projection's dPRE image
+    itself.  Against the two-pass route on the same inputs - dT rows to memory, then mhimx_rows_dpre_image over a list in which the rows
+    behind img_rows are masked out: the image bytes are IDENTICAL (the same fp32 product split into the same bf16 hi / lo), the tokens
+    behind img_rows keep their dT rows bit for bit, the per-tile column sums are the bias gradient."""
+    ops = _ops()
+    from mhim_mil_amd import _lib as L
+    M, E, A = 1500, 512, 128
+    T = rnd(1, (M, E)).to(DEV)
+    rows = torch.from_numpy(synth.permutation(2, M)[:n].copy()).to(DEV)
+    wa, wc = rnd(3, (A, E), std=0.05).to(DEV), rnd(4, (1, A), std=0.3).to(DEV)
+    sc = ops.ScorerW(wa, wc, L.ACT["relu"], prec="bf16x3")
+    st = ops.abmil_pool_fwd(sc, T, None, rows1=rows)
+    g_z = rnd(5, (E,)).to(DEV)
+    wa_t = ops.transpose(wa)
+    dact = (rnd(6, (M, E)).to(DEV) * 0.7).half()
+    # reference route: fp32 gradient rows, then the image pass
+    dT0 = torch.zeros(M, E, device=DEV)
+    ops.abmil_pool_bwd(sc, st, g_z, wa_t, grads={"dT1": dT0})
+    tiles = -(-n // 32)
+    keep = torch.zeros(tiles * 32, dtype=torch.uint8, device=DEV)
+    keep[:n_img] = 1
+    rows_pad = torch.zeros(tiles * 32, dtype=torch.int64, device=DEV)
+    rows_pad[:n] = rows
+    lib = L.lib()
+    img0 = torch.zeros(lib.mhimx_wgrad_image_bytes(tiles * 32, E) // 4, device=DEV)
+    b0, ws0 = torch.empty(E, device=DEV), torch.empty(tiles * E, device=DEV)
+    dHg = torch.zeros(tiles * 32, E, device=DEV)
+    dHg[:n] = dT0[rows]
+    dact_g = torch.zeros(tiles * 32, E, device=DEV, dtype=torch.float16)
+    dact_g[:n] = dact[rows]
+    L.check(lib.mhimx_rows_dpre_image_k(ops._stream(), dHg.data_ptr(), dact_g.data_ptr(), keep.data_ptr(), tiles * 32, E, img0.data_ptr(), b0.data_ptr(), 0,
+                                        ws0.data_ptr(), ws0.numel() * 4, None), "mhimx_rows_dpre_image_k")
+    # fused route
+    dT1 = torch.zeros(M, E, device=DEV)
+    img1 = torch.full_like(img0, float("nan"))
+    part = torch.full((tiles, E), float("nan"), device=DEV)
+    ops.abmil_pool_bwd(sc, st, g_z, wa_t, grads={"dT1": dT1}, img=img1, img_dact=dact, img_part=part, img_rows=n_img)
+    torch.cuda.synchronize()
+    assert torch.equal(img0.view(torch.int32), img1.view(torch.int32))
+    tail = rows[n_img:]
+    assert torch.equal(dT1[tail], dT0[tail])
+    touched = torch.zeros(M, dtype=torch.bool, device=DEV)
+    touched[tail] = True
+    assert (dT1[~touched] == 0).all()                                      # the image rows' fp32 gradient never went to memory
+    ref_b = (dT0[rows[:n_img]].double() * dact[rows[:n_img]].double()).sum(0)
+    np.testing.assert_allclose(part.double().sum(0).cpu().numpy(), ref_b.cpu().numpy(), rtol=0, atol=2e-6 * float(ref_b.abs().max()) + 1e-9)
+    np.testing.assert_allclose(b0.double().cpu().numpy(), ref_b.cpu().numpy(), rtol=0, atol=2e-6 * float(ref_b.abs().max()) + 1e-9)
+
+
+def test_select_rows_in_image_order():
+    """mhimx_select_rows_img: the same draw as mhimx_select_rows, and the kept rows once more as [stay | 0.. | merge from the offset | 0..]."""
+    ops = _ops()
+    N, k, n_sel, R = 5000, 150, 75, 490
+    score = rnd(11, (N,)).to(DEV)
+    tick = torch.tensor([5], dtype=torch.int64, device=DEV)
+    rows = ops.select_rows(score, k, n_sel, R, 1234, tick=tick, merge_first=True)
+    Lk = N - n_sel - R
+    off = -(-(Lk + 5) // 32) * 32
+    rows2, rimg = ops.select_rows_img(score, k, n_sel, R, 1234, off, tick=tick)
+    torch.cuda.synchronize()
+    assert torch.equal(rows, rows2)
+    assert rimg.numel() == -(-(off + R) // 32) * 32
+    assert torch.equal(rimg[:Lk], rows[R:]) and torch.equal(rimg[off:off + R], rows[:R])
+    assert (rimg[Lk:off] == 0).all() and (rimg[off + R:] == 0).all()
+
+
 def test_merge_with_gathered_rows_matches_contiguous():
     ops = _ops()
     from mhim_mil_amd import _lib as L
