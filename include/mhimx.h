@@ -339,6 +339,8 @@ typedef struct {
                                          tokens' scorer product then reads the weight coalesced, without cross-lane reductions */
   int64_t tail_row0;                  /* phase 2: >= 0: the tail tokens are the rows tail_row0 .. tail_row0 + tail_tokens - 1 of T1 (what rows1's
                                          last entries hold - the caller's word, saves the finalize launch a dependent load); < 0: read rows1 */
+  int32_t no_backward;                /* (round 6) 1: no backward follows (a teacher's forward): the one-pass scorer does not store the
+                                         pre-activations u_pre [M, A] - 5 MB per 10 000 rows nobody reads */
 } mhimx_pool_io;
 int64_t mhimx_abmil_pool_ws_bytes(int64_t M, int64_t E, int64_t A, int32_t gated);
 int mhimx_abmil_pool_fwd(void* stream, const mhimx_scorer* sc, mhimx_pool_io* io);      /* (io->rode_merge is written in phase 1) */

@@ -115,7 +115,8 @@ class PoolIO(C.Structure):
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("bp", c_f32p), ("pscore", c_f32p), ("rows1", c_i64p),
                 ("excl", C.c_void_p), ("ride_jobs", C.c_void_p), ("n_ride_jobs", C.c_int32),
                 ("phase", C.c_int32), ("tail_tokens", C.c_int32), ("ride_merge", C.c_void_p), ("ride_X", c_f32p), ("ride_R", C.c_int64),
-                ("ride_ws", C.c_void_p), ("ride_ws_bytes", C.c_int64), ("rode_merge", C.c_int32), ("tail_wa_t", c_f32p), ("tail_row0", C.c_int64)]
+                ("ride_ws", C.c_void_p), ("ride_ws_bytes", C.c_int64), ("rode_merge", C.c_int32), ("tail_wa_t", c_f32p), ("tail_row0", C.c_int64),
+                ("no_backward", C.c_int32)]
 
 
 class PoolGrad(C.Structure):

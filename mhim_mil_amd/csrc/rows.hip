@@ -1012,7 +1012,7 @@ int abmil_pool_fwd(hipStream_t st, const mhimx_scorer* sc, mhimx_pool_io* io) {
     if (scorer_fused_ok(E, A, gated, sc->prec, Ts[seg], sc->wa, io->cproj ? io->wp : nullptr, io->C)) {
       // one pass over the rows: GEMM + scores + class projections + pool partials (scorer_fused.hip)
       const int g1 = scorer_fused_fwd(st, Ts[seg], Ms[seg], sc->wa, sc->wa_frag, sc->ba, sc->act, sc->wc, sc->bc, io->cproj ? io->wp : nullptr,
-                                      (int)io->C, u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
+                                      (int)io->C, io->no_backward ? nullptr : u_pre + off * ldu, io->s + off, io->cproj ? io->cproj + off * io->C : nullptr,
                                       w.pm + G, w.pl + G, w.pz + (int64_t)G * E, MAX_PART, seg == 0 ? io->rows1 : nullptr,
                                       seg == 0 ? io->excl : nullptr, rode ? nullptr : io->ride_jobs, rode ? 0 : io->n_ride_jobs, nullptr);
       if (g1 < 0) return g1;

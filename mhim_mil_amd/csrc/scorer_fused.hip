@@ -238,7 +238,7 @@ __global__ __launch_bounds__(SF_THREADS, 2) void scorer_fused_kernel(
       const int row = 8 * (i >> 2) + 4 * kg + (i & 3);
       const int64_t n = row0 + row;
       const float u = acc[i] + bn;
-      if (n < M) u_pre[n * SF_A + n_col] = u;
+      if (n < M && u_pre) u_pre[n * SF_A + n_col] = u;
       const float v = sf_sum32(wn * act_fwd(u, act));
       if (r32 == 31) sred[wave * SF_ROWS + row] = v;
     }

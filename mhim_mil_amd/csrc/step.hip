@@ -357,6 +357,7 @@ extern "C" int mhimx_step_run(void* stream, const mhimx_step_cfg* cfg, const flo
     io.T1 = H_t; io.M1 = N; io.s = cv.at<float>(b.s_t); io.stats = cv.at<float>(b.stats_t); io.z = cv.at<float>(b.z_t);
     io.ws = cv.at<char>(b.pool_ws_t); io.ws_bytes = b.pool_ws_t_bytes;
     if (c.attn2score) { io.wp = T.wp; io.C = C; io.cproj = cv.at<float>(b.cproj_t); io.bp = T.bp; io.pscore = cv.at<float>(b.pscore); }
+    io.no_backward = 1;
     io.ride_jobs = late; io.n_ride_jobs = 6;
     if (int r = mhimx_abmil_pool_fwd(stream, &sc_t, &io)) return r;
     if (c.attn2score) score = io.pscore;
@@ -677,6 +678,7 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
       io.T1 = H_t; io.M1 = N; io.s = cv.at<float>(b.s_t); io.stats = cv.at<float>(b.stats_t); io.z = cv.at<float>(b.z_t);
       io.ws = cv.at<char>(b.pool_ws_t); io.ws_bytes = b.pool_ws_t_bytes;
       if (c.attn2score) { io.wp = T.wp; io.C = C; io.cproj = cv.at<float>(b.cproj_t); io.bp = T.bp; io.pscore = cv.at<float>(b.pscore); }
+    io.no_backward = 1;
       if (int r = mhimx_abmil_pool_fwd(stream, &sc_t, &io)) return r;
       if (c.attn2score) score = io.pscore;
       else {
