@@ -60,8 +60,10 @@ MHIMX_DEV void m2_load_rows(const float* __restrict__ X, const int64_t* __restri
     b[q] = *reinterpret_cast<const m2_f4*>(src + 256 + 4 * lane);
     if (HAVE_STATS) { mu8[q] = mean[nc]; rs8[q] = rstd[nc]; }
   }
-  if (tid < 128) *reinterpret_cast<m2_f4*>(lnw + 4 * tid) = *reinterpret_cast<const m2_f4*>(ln_w + 4 * tid);
-  else *reinterpret_cast<m2_f4*>(lnb + 4 * (tid - 128)) = *reinterpret_cast<const m2_f4*>(ln_b + 4 * (tid - 128));
+  if (lnw) {                                                  // (the backward reads the 4 KB of LayerNorm parameters where they lie: no LDS copy)
+    if (tid < 128) *reinterpret_cast<m2_f4*>(lnw + 4 * tid) = *reinterpret_cast<const m2_f4*>(ln_w + 4 * tid);
+    else *reinterpret_cast<m2_f4*>(lnb + 4 * (tid - 128)) = *reinterpret_cast<const m2_f4*>(ln_b + 4 * (tid - 128));
+  }
 #pragma unroll
   for (int q = 0; q < QN; ++q) {
     const int rr = wave + 4 * q;
@@ -271,7 +273,9 @@ MHIMX_DEV void merge2_rows_fwd_body(const int t, float* m2sm, const float* __res
 // 5. rows backward: dPd = xn dY^T, softmax backward, dxn = ds aq + Pd dY, LayerNorm backward (dX scattered to the rows' places,
 //    per-tile d_ln_w / d_ln_b partials), pooled U partials.   grid = ceil(R / 32)
 // ----------------------------------------------------------------------------------------------------------------------
-constexpr size_t m2_bwd_smem(int rt) { return (size_t)(2 * rt * M2_XLD + rt * M2_CLD + M2_JP * (rt + 4) + 2 * M2_E + 3 * M2_JK + 2 * rt + 4) * sizeof(float); }
+// (round 6: no LDS copy of the LayerNorm weight / bias - 4 KB that put a 16-row tile's 83.3 KB above half a CU's LDS: two tiles per CU now)
+constexpr size_t m2_bwd_smem(int rt) { return (size_t)(2 * rt * M2_XLD + rt * M2_CLD + M2_JP * (rt + 4) + 3 * M2_JK + 2 * rt + 4) * sizeof(float); }
+static_assert(2 * m2_bwd_smem(16) <= 160 * 1024, "two 16-row tiles of the Merge rows backward share a CU");
 constexpr size_t M2_BWD_SMEM = m2_bwd_smem(M2_ROWS);
 static_assert(16 * M2_XLD >= 8 * M2_E, "the LayerNorm partials reuse the gradient tile");
 
@@ -286,9 +290,9 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
   float* dxs = xh + RT * M2_XLD;                      // [RT][516]; first the [4][RT][48] reduction buffer of dPd
   float* cf = dxs + RT * M2_XLD;                      // [RT][132]: ds (slots 0..63) | Pd (64..127)
   float* dsT = cf + RT * M2_CLD;                      // [48][RT + 4]
-  float* lnw = dsT + M2_JP * PLD;                     // [512]
-  float* lnb = lnw + M2_E;                            // [512]
-  float* sst = lnb + M2_E;                            // [64][3]: softmax max, 1 / sum, delta of every slot
+  const float* lnw = ln_w;                            // (read where they lie: global memory, 2 KB each, cache resident)
+  const float* lnb = ln_b;
+  float* sst = dsT + M2_JP * PLD;                     // [64][3]: softmax max, 1 / sum, delta of every slot
   float* rst = sst + 3 * M2_JK;                       // [RT] rstd of the tile's rows
   float* ok = rst + RT;                               // [RT] 1 = the row takes part
   int* flags = reinterpret_cast<int*>(ok + RT);       // [4]
@@ -320,7 +324,7 @@ MHIMX_DEV void merge2_rows_bwd_body(const int t, float* m2sm, const float* __res
     const int idx = tid + q * M2_THREADS, r = idx >> 6, j = idx & 63;
     sv[q] = (j < J && row0 + r < R) ? w.S[(row0 + r) * M2_JP + j] : 0.f;
   }
-  m2_load_rows<true, RT>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, lnw, lnb, rst, w, ok);
+  m2_load_rows<true, RT>(X, xrows, R, row0, xh, w.mean, w.rstd, ln_w, ln_b, nullptr, nullptr, rst, w, ok);
   __syncthreads();
   m2_rows_times_slots<RT>(xh, lnw, lnb, fr, dxs);
   __syncthreads();
