@@ -131,6 +131,34 @@ def test_window_step_vs_oracle(n_streams, window_gemms):
         t.load_state_dict({**tea, "merge.global_q": tea["merge.global_q_mm"]})
 
 
+def test_batched_window_at_baseline_size_vs_oracle():
+    """BASELINE c2's shape under --accumulation_steps 8: eight bags of N = 10 000, D = 1024 through mhimx_window_run (captured, then replayed
+    from the restored state) against the oracle's window step on the draws the device made: per-bag logits 1e-4, the parameters after the
+    update, the chained global queries."""
+    from mhim_mil_amd.engine import FusedTrainer
+    n, d, acc = 10000, 1024, 8
+    base = synth.mhim_state(7, input_dim=d, merge_k=5)
+    tsd = synth.spread_teacher(base)
+    s, t = _mk(base, d, **V2), _mk(tsd, d, **V2)
+    tr = FusedTrainer(s, t, aux_alpha=0.5, mm=0.9997, accumulation_steps=acc)
+    bags = [torch.from_numpy(synth.bag(1300 + j, n, d)) for j in range(acc)]
+    labels = [j % 2 for j in range(acc)]
+    xs = [b.to(DEV)[None] for b in bags]
+    ls = [torch.tensor([l], device=DEV) for l in labels]
+    assert tr._exec_window_ok([x[0] for x in xs], ls), "the window did not take the batched form"
+    snap = [tr.flat.student.clone(), tr.flat.teacher.clone(), tr.flat.m.clone(), tr.flat.v.clone(), tr.opt_step.clone(), tr.tick.clone(), tr.flat.step]
+    g = tr.capture_window(xs, ls, warmup=1)
+    tr.flat.student.copy_(snap[0]); tr.flat.teacher.copy_(snap[1]); tr.flat.m.copy_(snap[2]); tr.flat.v.copy_(snap[3])
+    tr.opt_step.copy_(snap[4]); tr.tick.copy_(snap[5]); tr.flat.step = snap[6]
+    tr.flat.grad.zero_()
+    ocfg = O.Cfg(**V2)
+    k, n_sel, _ = O.mask_count(n, 0.03, 0.5)
+    stu, tea, opt, _ = _window_vs_oracle(tr, s, t, bags, labels, O.as_torch(base), O.as_torch(tsd), {}, ocfg, 1, n, k, n_sel, g.replay)
+    _check_params(s, stu, 3e-6, 4.1e-4, "student after the replayed window")
+    _check_params(t, tea, 1e-6, 2e-6, "teacher after the replayed window")
+    np.testing.assert_allclose(s.merge.global_q_mm.detach().cpu().numpy(), stu["merge.global_q_mm"].numpy(), atol=2e-6, rtol=0)
+
+
 def test_window_streams_do_not_change_the_result():
     """The same window on 1 stream and on 4: identical draws (the seeds do not depend on the stream), bit-identical per-bag logits, the
     accumulated gradient equal up to the order of the slab sum."""
