@@ -850,7 +850,7 @@ class FusedTrainer:
             if mhim:
                 wp = t.predictor.weight.data if t.attn2score else None
                 st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp,
-                                          bp=t.predictor.bias.data if t.attn2score else None, ride_jobs=prep_s.get("_ride_jobs"))
+                                          bp=t.predictor.bias.data if t.attn2score else None, ride_jobs=prep_s.get("_ride_jobs"), no_backward=True)
                 score = st_t.pscore if t.attn2score else ops.softmax_from_stats(st_t.s, st_t.stats)
                 teacher_feat = st_t.z
                 _, _, len_keep, Lk, R = s.v2_counts(ps, i)

@@ -407,17 +407,19 @@ def abmil_pool_fwd_finish(sc: ScorerW, st: PoolState, wa_t=None, tail_row0=-1):
     return st
 
 
-def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=None, ride_jobs=None):
+def abmil_pool_fwd(sc: ScorerW, T1, T2=None, wp=None, bp=None, rows1=None, excl=None, ride_jobs=None, no_backward=False):
     """Scorer + softmax pool over tokens [T1; T2] -> PoolState (s, stats, z, cproj; with ``bp`` also ``pscore`` [M1], the
     pseudo score of the T1 instances, written by the pool's finalize launch).  ``rows1`` (int64): the tokens are T1[rows1].
     ``excl`` (uint8, by source row): rows that do not take part (score -inf; see mhimx_pool_io.excl).  ``ride_jobs``: prep_batch
-    jobs that run as extra workgroups of this forward's scorer launch (mhimx_pool_io.ride_jobs)."""
+    jobs that run as extra workgroups of this forward's scorer launch (mhimx_pool_io.ride_jobs).  ``no_backward``: a teacher's forward -
+    the one-pass scorer does not store its pre-activations (mhimx_pool_io.no_backward); abmil_pool_bwd must not follow."""
     _chk(T1, name="T1"); _chk(T2, name="T2"); _chk(wp, name="wp"); _chk(bp, name="bp"); _chk(rows1, torch.int64, "rows1")
     _chk(excl, torch.uint8, "excl")
     st = PoolState(T1, T2, 0 if wp is None else wp.shape[0], wp, bp=bp, rows1=rows1, excl=excl)
     if ride_jobs:
         st.ride = (_prep_array(ride_jobs), len(ride_jobs))
     io = st.io(sc)
+    io.no_backward = int(bool(no_backward))
     L.check(L.lib().mhimx_abmil_pool_fwd(_stream(), C.byref(sc.c), C.byref(io)), "mhimx_abmil_pool_fwd")
     st.ride = None                           # (the jobs ran with the forward; the backward's io carries none)
     return st

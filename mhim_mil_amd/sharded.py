@@ -217,7 +217,7 @@ class ShardedBagTrainer:
 
             # ---- teacher: partial pool -> the bag's (stats, z); scores need the bag's denominators
             wp = t.predictor.weight.data if t.attn2score else None
-            st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp)
+            st_t = ops.abmil_pool_fwd(t._scorer(prep_t.get("wa_frag")), heads[0].out, None, wp=wp, no_backward=True)
             part = torch.empty(E + 2, device=dev)
             parts = torch.empty((cm.world, E + 2), device=dev)
             part[:2].copy_(st_t.stats)
@@ -399,7 +399,7 @@ class ShardedBagTrainer:
             p = t.dropout_p if t.training else 0.0
             Ht = t._feature(x, None, p, local_seed ^ 0x5bd1e995)
             wp = t.predictor.weight.data if t.attn2score else None
-            st_t = ops.abmil_pool_fwd(t._scorer(), Ht, None, wp=wp)
+            st_t = ops.abmil_pool_fwd(t._scorer(), Ht, None, wp=wp, no_backward=True)
             gstats, t_feat = self._pool_merge(st_t, E, dev)
             if t.attn2score:
                 sc_loc = ops.pseudo_score(st_t.s, gstats, st_t.cproj, t.predictor.bias.data)
