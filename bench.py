@@ -319,12 +319,27 @@ def accumulate8(a, dev, bags, labels):
     MHIMX_WINDOW_BATCHED=0: the bags on HIP streams (~127 launches), as rounds 3-5 had it."""
     from mhim_mil_amd.engine import FusedTrainer
     K, reps, warm = 8, 12, 3
-    student, teacher, _ = make_models(dev, a.prec)
-    tr = FusedTrainer(student, teacher, aux_alpha=0.5, mm=0.9997, accumulation_steps=K)
     g = torch.Generator(device=dev)
     g.manual_seed(777)
     more = [torch.randn(N_INST, D_IN, device=dev, generator=g).abs_() for _ in range(K)]     # second window: 16 distinct bags = 655 MB
     sets = [(bags[:K], labels[:K]), (more, labels[:K])]
+    res = _accumulate8_form(a, dev, sets, K, reps, warm, batched=None)
+    was_batched = res.pop("_batched", False)
+    if not a.no_graph and was_batched:
+        # the same two windows in the stream form of rounds 3-5, on this box, right behind the batched form: the A/B in the line itself
+        st = _accumulate8_form(a, dev, sets, K, reps, warm, batched=False)
+        st.pop("_batched", None)
+        res["stream_form_same_box"] = {k: st[k] for k in ("ms_per_bag", "ms_per_window", "launch")}
+    return res
+
+
+def _accumulate8_form(a, dev, sets, K, reps, warm, batched):
+    from mhim_mil_amd.engine import FusedTrainer
+    student, teacher, _ = make_models(dev, a.prec)
+    tr = FusedTrainer(student, teacher, aux_alpha=0.5, mm=0.9997, accumulation_steps=K)
+    if batched is not None:
+        tr.window_batched = bool(batched)
+    batched = False
     if a.no_graph:
         run = [lambda b=b, l=l: tr.window_step(b, l, n_streams=a.window_streams) for b, l in sets]
         launch = "eager"
@@ -342,7 +357,7 @@ def accumulate8(a, dev, bags, labels):
         run[i % 2]()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return {"value": N_INST * K / dt, "unit": "patch-instances/s", "ms_per_bag": 1e3 * dt / K, "ms_per_window": 1e3 * dt, "bags_per_update": K,
+    return {"_batched": batched, "value": N_INST * K / dt, "unit": "patch-instances/s", "ms_per_bag": 1e3 * dt / K, "ms_per_window": 1e3 * dt, "bags_per_update": K,
             "windows_timed": reps, "warmup_windows": warm, "streams": a.window_streams, "launch": launch,
             "whole_step_hbm_roofline_frac_of_8TBps": N_INST * K / dt * ALGO_BYTES_PER_INST_STEP / 1e9 / HBM_PEAK_GBS,
             "semantics": "reference --accumulation_steps 8: loss/8 per bag, gradients summed, one Adam + EMA per window; Merge's query EMA "
