@@ -135,7 +135,10 @@ def test_batched_window_at_baseline_size_vs_oracle():
     """BASELINE c2's shape under --accumulation_steps 8: eight bags of N = 10 000, D = 1024 through mhimx_window_run (captured, then replayed
     from the restored state) against the oracle's window step on the draws the device made: per-bag logits 1e-4, the parameters after the
     update, the chained global queries."""
+    from mhim_mil_amd import engine as EN
     from mhim_mil_amd.engine import FusedTrainer
+    if not EN._WINDOW_BATCHED:
+        pytest.skip("MHIMX_WINDOW_BATCHED=0: the stream form is selected")
     n, d, acc = 10000, 1024, 8
     base = synth.mhim_state(7, input_dim=d, merge_k=5)
     tsd = synth.spread_teacher(base)
