@@ -641,6 +641,10 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
   // ---- 2. both models' feature rows of every bag: ONE launch (mhim.py:186 and :335-336)
   {
     mhimx_bag_project_args pa[MHIMX_WINDOW_MAX];
+    // the launch projects the bags LAST to FIRST: the middle's planes are dispatched bag 0 first, and its first readers then find the rows
+    // written most recently (the window's 400 MB of feature rows do not fit the 256 MB Infinity Cache).  Same bits; 0.5 % of a window,
+    // same box, twice (MHIMX_WINDOW_PROJ_REV=0: first to last)
+    static const bool proj_rev = getenv("MHIMX_WINDOW_PROJ_REV") == nullptr || atoi(getenv("MHIMX_WINDOW_PROJ_REV")) != 0;
     for (int i = 0; i < n_bags; ++i) {
       mhimx_bag_project_args a = {};
       a.X = X[i]; a.ldx = ldx; a.N = N; a.D = D; a.E = E; a.act = c.act; a.n_heads = 2; a.drop_tick = tick;
@@ -648,7 +652,7 @@ extern "C" int mhimx_window_run(void* stream, const mhimx_step_cfg* cfg, int32_t
       a.head[0].drop_seed = seeds[i].drop_teacher;
       a.head[1].wp = w1p_s; a.head[1].bias = S.b1; a.head[1].H = reinterpret_cast<float*>(bag(b.Hbuf, i)); a.head[1].ldh = E; a.head[1].dact = bag(b.dact, i);
       a.head[1].drop_p = c.drop_p_student; a.head[1].drop_seed = seeds[i].drop_student;
-      pa[i] = a;
+      pa[proj_rev ? n_bags - 1 - i : i] = a;
     }
     if (int r = mhimx_bag_project_multi(stream, pa, n_bags)) return r;
   }
